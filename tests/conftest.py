@@ -1,0 +1,39 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+GOLDEN = os.path.join(REPO, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    out = {}
+    for k in z.files:
+        v = z[k]
+        if v.dtype == np.float32 or v.dtype == np.int64 or v.dtype == np.uint8:
+            out[k] = torch.from_numpy(v) if v.ndim > 0 else v.item()
+        elif v.ndim == 0:
+            out[k] = v.item()
+        else:
+            out[k] = torch.from_numpy(v)
+    return out
+
+
+@pytest.fixture
+def golden():
+    return load_golden
+
+
+def has_gpu():
+    return torch.cuda.is_available()
