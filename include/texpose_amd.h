@@ -1,0 +1,187 @@
+/*
+ * texpose_amd.h -- C ABI of the MI355X (gfx950) ray-marching library.
+ *
+ * Drop-in boundary: the reference has no FFI; its boundary is the Python
+ * class protocol  Graph.render / NeRF.composite / RaySampler.get_rays ...  selected by module
+ * name (reference train.py:18-19, model/base.py:42-44).  texpose_amd/ mirrors that protocol in
+ * Python and reaches the GPU only through the entry points below (ctypes, see
+ * texpose_amd/_lib.py and INTEGRATION.md).  Every pointer is a DEVICE pointer unless noted,
+ * every tensor is dense row-major fp32, indices are int64, `stream` is a hipStream_t.
+ * Launchers only enqueue work on `stream`: no allocation, no synchronisation, graph-capturable.
+ *
+ * Return value: 0 on success, a hipError_t (>0) when the launch failed, <0 for invalid
+ * arguments.  tp_last_error() returns a static, thread-local description.
+ *
+ * "ref:" comments cite the reference file:line each entry point replaces.
+ */
+#ifndef TEXPOSE_AMD_H
+#define TEXPOSE_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* tp_stream_t; /* hipStream_t */
+
+#define TP_ABI_VERSION 1
+
+int tp_abi_version(void);
+const char* tp_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * K1  fused ray generation + depth bounds + stratified samples
+ * ref: tools/ray_sampler.py:24-69 (train rays/bounds), camera.py:292-314 +
+ *      model/nerf_adapt_st_gan.py:573-579,702-710 (eval rays + row gather),
+ *      camera.py:415-433 / compute_box.py:69-87,270-272 + data/lm.py:349-350 (AABB bounds),
+ *      model/nerf_adapt_st_gan.py:683-700 (sample_depth).
+ * ------------------------------------------------------------------------------------------ */
+enum tp_pixel_mode {
+  TP_PIX_COORDS = 0, /* train: coords [B,R,2] in [-1,1] (x,y); u,v = bilinear index-grid lookup */
+  TP_PIX_INDEX = 1   /* eval : ray_idx [B,R] int64 row-major pixel index; u,v = col+.5,row+.5 */
+};
+enum tp_bounds_mode {
+  TP_BOUNDS_MAP = 0,  /* z_near/z_far [B,H*W] maps: bilinear (coords) or gathered (index) */
+  TP_BOUNDS_AABB = 1, /* in-kernel slab test against aabb_min/aabb_max, misses -> bg range */
+  TP_BOUNDS_NONE = 2  /* rays only: near/far/depth outputs untouched */
+};
+enum tp_jitter_mode {
+  TP_JITTER_MID = 0,    /* sample_stratified=false: 0.5 */
+  TP_JITTER_GIVEN = 1,  /* rand [B,R,N] supplied by the caller (parity runs) */
+  TP_JITTER_PHILOX = 2  /* in-kernel Philox4x32-10 keyed by (seed, offset) */
+};
+
+typedef struct tp_raygen_args {
+  const float* intr;      /* [B,3,3] */
+  const float* pose;      /* [B,3,4] object->camera [R|t] */
+  const float* coords;    /* [B,R,2] (TP_PIX_COORDS) or NULL */
+  const int64_t* ray_idx; /* [B,R]   (TP_PIX_INDEX)  or NULL */
+  const float* z_near;    /* [B,H*W] (TP_BOUNDS_MAP) or NULL */
+  const float* z_far;     /* [B,H*W] */
+  const float* rand;      /* [B,R,N] (TP_JITTER_GIVEN) or NULL */
+  float aabb_min[3];      /* TP_BOUNDS_AABB (host values) */
+  float aabb_max[3];
+  float bg_near, bg_far;  /* TP_BOUNDS_AABB fallback range */
+  uint64_t seed, offset;  /* TP_JITTER_PHILOX */
+  int B, R, H, W, N;      /* N = samples per ray (0: no depth output) */
+  int pixel_mode, bounds_mode, jitter_mode;
+  float* center;          /* [B,R,3] out */
+  float* ray;             /* [B,R,3] out (camera-z component == 1) */
+  float* near;            /* [B,R] out, may be NULL */
+  float* far;             /* [B,R] out, may be NULL */
+  float* depth;           /* [B,R,N] out, may be NULL */
+} tp_raygen_args;
+
+int tp_raygen(const tp_raygen_args* args /* host struct */, tp_stream_t stream);
+
+/* Standalone slab test (camera.py:415-433): o,d [n,3] -> t_near,t_far [n], valid [n] (uint8). */
+int tp_aabb(const float* aabb_min3 /*host*/, const float* aabb_max3 /*host*/, const float* o, const float* d,
+            int64_t n, float* t_near, float* t_far, uint8_t* valid, tp_stream_t stream);
+
+/* Standalone Graph.sample_depth (model/nerf_adapt_st_gan.py:683-700): near,far [n] -> depth [n,N]. */
+int tp_sample_depth(const float* near, const float* far, const float* rand /*[n,N] or NULL*/, int jitter_mode,
+                    uint64_t seed, uint64_t offset, int64_t n, int N, float* depth, tp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K2/K3  positional encoding + static/transient/light MLP
+ * ref: layers/nerf_static_transient_light.py:76-145 (forward), :147-166 (forward_samples),
+ *      :217-234 (positional_encoding), camera.py:317-322 (points from depth).
+ * Architecture is the reference default (options/nerf_lm_adapt_gan.yaml:9-17,37-40): width 256,
+ * 8 trunk layers with skip at 4, L_3D=10, L_view=4, 16 transient + 48 light latents.
+ * ------------------------------------------------------------------------------------------ */
+
+/* Pointers to the reference state-dict tensors, device memory, W [out,in]. */
+typedef struct tp_mlp_weights {
+  const float* feat_w[8];  const float* feat_b[8];   /* mlp_feat.{0..7}   */
+  const float* rgb_w[4];   const float* rgb_b[4];    /* mlp_rgb.{0..3}    */
+  const float* trans_w[4]; const float* trans_b[4];  /* mlp_trans.{0..3}  */
+} tp_mlp_weights;
+
+/* Size in bytes of the packed (MFMA-fragment-ordered, streaming-ordered) weight image. */
+size_t tp_mlp_packed_bytes(void);
+/* Which parts to (re)pack: the trunk is frozen, the heads change every optimiser step. */
+enum { TP_PACK_TRUNK = 1, TP_PACK_HEADS = 2, TP_PACK_ALL = 3 };
+int tp_mlp_pack(const tp_mlp_weights* w /*host struct of device ptrs*/, int parts, void* packed, tp_stream_t stream);
+/* Same image built on the host from HOST weight pointers (no GPU needed; used by the CPU tests). */
+int tp_mlp_pack_host(const tp_mlp_weights* w_host, float* packed_host);
+
+/* Bytes of scratch the forward needs for a given launch (per-workgroup spill of the trunk feature). */
+size_t tp_mlp_workspace_bytes(int64_t n_samples);
+/* Bytes of the optional activation record kept for the backward pass (7 x 256 floats / sample,
+ * rounded up to whole 128-sample tiles). */
+size_t tp_mlp_saved_bytes(int64_t n_samples);
+
+typedef struct tp_mlp_fwd_args {
+  const void* packed;      /* tp_mlp_pack output */
+  /* input form A (forward_samples): center,ray [B,R,3], depth [B,R,N] */
+  const float* center; const float* ray; const float* depth;
+  /* input form B (NeRF.forward): points, ray_unit [B,R,N,3]; used when center == NULL */
+  const float* points; const float* ray_unit;
+  const float* lat_trans;  /* [B,16] */
+  const float* lat_light;  /* [B,48] */
+  int B, R, N;
+  float* rgb;              /* [B,R,N,3,2] out (last dim: static, transient) */
+  float* density;          /* [B,R,N,2]   out */
+  float* uncert;           /* [B,R,N,1]   out */
+  float* saved;            /* optional activations for tp_mlp_bwd (tp_mlp_saved_bytes) or NULL */
+  void* workspace;         /* tp_mlp_workspace_bytes */
+} tp_mlp_fwd_args;
+
+int tp_mlp_fwd(const tp_mlp_fwd_args* args, tp_stream_t stream);
+
+/* Standalone positional encoding (layers/...light.py:217-234): x [n,C] -> [n, 2*C*L]. */
+int tp_posenc(const float* x, int64_t n, int C, int L, float* out, tp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K4  per-ray alpha composite
+ * ref: layers/nerf_static_transient_light.py:168-212
+ * ------------------------------------------------------------------------------------------ */
+typedef struct tp_composite_args {
+  const float* ray;      /* [n,3]     */
+  const float* rgb;      /* [n,N,3,2] */
+  const float* density;  /* [n,N,2]   */
+  const float* depth;    /* [n,N]     */
+  const float* uncert;   /* [n,N]     */
+  int64_t n; int N; float min_uncert;
+  float* out_ray;        /* [n,14]: rgb3 rgb_static3 rgb_transient3 depth opacity opacity_static opacity_transient uncert */
+  float* alpha_static;   /* [n,N] or NULL */
+  float* alpha_transient;/* [n,N] or NULL */
+  float* prob;           /* [n,N] or NULL */
+} tp_composite_args;
+int tp_composite_fwd(const tp_composite_args* args, tp_stream_t stream);
+
+typedef struct tp_composite_bwd_args {
+  tp_composite_args fwd;        /* same inputs as the forward (outputs ignored) */
+  const float* g_out_ray;       /* [n,14] cotangent of out_ray */
+  const float* g_alpha_static;  /* [n,N] or NULL */
+  const float* g_alpha_transient;
+  const float* g_prob;
+  float* g_rgb;                 /* [n,N,3,2] out */
+  float* g_density;             /* [n,N,2]   out */
+  float* g_uncert;              /* [n,N]     out */
+} tp_composite_bwd_args;
+int tp_composite_bwd(const tp_composite_bwd_args* args, tp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K5  patch gather for the photometric / PatchGAN inputs
+ * ref: model/nerf_adapt_st_gan.py:444-461,516-545,726-745 (8 grid_sample calls per step)
+ * ------------------------------------------------------------------------------------------ */
+typedef struct tp_patch_gather_args {
+  const float* coords;     /* [B,P,2] (x,y) in [-1,1], P = p*p */
+  const float* image;      /* [B,3,H,W] */
+  const float* image_syn;  /* [B,3,H,W] */
+  const float* nocs;       /* [B,3,H,W] */
+  const float* normal;     /* [B,3,H,W] */
+  const float* obj_mask;   /* [B,H,W]   (binarised > 0 in-kernel) */
+  const float* mask_syn;   /* [B,H,W]   */
+  int B, P, H, W;
+  float* out;              /* [B,14,P]: image3 image_syn3 nocs3*mask_syn normal3*mask_syn mask mask_syn */
+} tp_patch_gather_args;
+int tp_patch_gather(const tp_patch_gather_args* args, tp_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TEXPOSE_AMD_H */

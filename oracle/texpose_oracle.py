@@ -272,13 +272,16 @@ def philox4x32(counter: np.ndarray, key: Tuple[int, int]) -> np.ndarray:
 
 
 def philox_uniform(n_elems: int, seed: int, offset: int = 0) -> np.ndarray:
-    """Uniform [0,1) float32 stream used by tp_raygen_*: element e uses word
-    (e & 3) of philox(counter=(e>>2, offset, 0, 0), key=(seed_lo, seed_hi)),
-    mapped as (w >> 8) * 2^-24."""
+    """Uniform [0,1) float32 stream used by tp_raygen / tp_sample_depth: element e uses
+    word (e & 3) of philox(counter=(lo32(e>>2), lo32(offset), hi32(e>>2), hi32(offset)),
+    key=(seed_lo, seed_hi)), mapped as (w >> 8) * 2^-24."""
     e = np.arange(n_elems, dtype=np.uint64)
     ctr = np.zeros((n_elems, 4), dtype=np.uint32)
-    ctr[:, 0] = (e >> np.uint64(2)).astype(np.uint32)
+    cnt = e >> np.uint64(2)
+    ctr[:, 0] = (cnt & np.uint64(0xFFFFFFFF)).astype(np.uint32)
     ctr[:, 1] = np.uint32(offset & 0xFFFFFFFF)
+    ctr[:, 2] = (cnt >> np.uint64(32)).astype(np.uint32)
+    ctr[:, 3] = np.uint32((offset >> 32) & 0xFFFFFFFF)
     out = philox4x32(ctr, (seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF))
     w = out[np.arange(n_elems), (e & np.uint64(3)).astype(np.int64)]
     return ((w >> np.uint32(8)).astype(np.float32) * np.float32(2.0 ** -24)).astype(np.float32)

@@ -1,0 +1,115 @@
+"""ctypes binding of libtexpose_amd.so (the C ABI declared in include/texpose_amd.h).
+
+There is deliberately NO fallback: if the HIP library is missing or a launch fails, the
+product path raises.  (The CPU oracle under oracle/ is test infrastructure only.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtexpose_amd.so")
+
+ABI_VERSION = 1
+
+# Every symbol include/texpose_amd.h declares (checked by tests/test_capi_cpu.py).
+SYMBOLS = (
+    "tp_abi_version", "tp_last_error",
+    "tp_raygen", "tp_aabb", "tp_sample_depth",
+    "tp_mlp_packed_bytes", "tp_mlp_pack", "tp_mlp_pack_host", "tp_mlp_workspace_bytes", "tp_mlp_fwd", "tp_posenc",
+    "tp_mlp_saved_bytes",
+    "tp_composite_fwd", "tp_composite_bwd",
+    "tp_patch_gather",
+)
+
+vp = C.c_void_p
+
+
+class RaygenArgs(C.Structure):
+    _fields_ = [("intr", vp), ("pose", vp), ("coords", vp), ("ray_idx", vp), ("z_near", vp),
+                ("z_far", vp), ("rand", vp), ("aabb_min", C.c_float * 3), ("aabb_max", C.c_float * 3),
+                ("bg_near", C.c_float), ("bg_far", C.c_float), ("seed", C.c_uint64), ("offset", C.c_uint64),
+                ("B", C.c_int), ("R", C.c_int), ("H", C.c_int), ("W", C.c_int), ("N", C.c_int),
+                ("pixel_mode", C.c_int), ("bounds_mode", C.c_int), ("jitter_mode", C.c_int),
+                ("center", vp), ("ray", vp), ("near", vp), ("far", vp), ("depth", vp)]
+
+
+class MlpWeights(C.Structure):
+    _fields_ = [("feat_w", vp * 8), ("feat_b", vp * 8), ("rgb_w", vp * 4), ("rgb_b", vp * 4),
+                ("trans_w", vp * 4), ("trans_b", vp * 4)]
+
+
+class MlpFwdArgs(C.Structure):
+    _fields_ = [("packed", vp), ("center", vp), ("ray", vp), ("depth", vp), ("points", vp),
+                ("ray_unit", vp), ("lat_trans", vp), ("lat_light", vp),
+                ("B", C.c_int), ("R", C.c_int), ("N", C.c_int),
+                ("rgb", vp), ("density", vp), ("uncert", vp), ("saved", vp), ("workspace", vp)]
+
+
+class CompositeArgs(C.Structure):
+    _fields_ = [("ray", vp), ("rgb", vp), ("density", vp), ("depth", vp), ("uncert", vp),
+                ("n", C.c_int64), ("N", C.c_int), ("min_uncert", C.c_float),
+                ("out_ray", vp), ("alpha_static", vp), ("alpha_transient", vp), ("prob", vp)]
+
+
+class CompositeBwdArgs(C.Structure):
+    _fields_ = [("fwd", CompositeArgs), ("g_out_ray", vp), ("g_alpha_static", vp),
+                ("g_alpha_transient", vp), ("g_prob", vp), ("g_rgb", vp), ("g_density", vp),
+                ("g_uncert", vp)]
+
+
+class PatchGatherArgs(C.Structure):
+    _fields_ = [("coords", vp), ("image", vp), ("image_syn", vp), ("nocs", vp), ("normal", vp),
+                ("obj_mask", vp), ("mask_syn", vp), ("B", C.c_int), ("P", C.c_int), ("H", C.c_int),
+                ("W", C.c_int), ("out", vp)]
+
+
+class TexposeLibraryError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load the HIP library (after torch, so that both share one libamdhip64 runtime)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    import torch  # noqa: F401  (loads torch's bundled libamdhip64.so.7 first; same SONAME => one runtime)
+    if not os.path.exists(LIB_PATH):
+        raise TexposeLibraryError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  texpose_amd has no CPU or eager fallback.")
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    lib.tp_abi_version.restype = C.c_int
+    lib.tp_last_error.restype = C.c_char_p
+    if lib.tp_abi_version() != ABI_VERSION:
+        raise TexposeLibraryError(f"ABI mismatch: library {lib.tp_abi_version()} != binding {ABI_VERSION}")
+
+    def sig(name, argtypes, restype=C.c_int):
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = restype
+
+    sig("tp_raygen", [C.POINTER(RaygenArgs), vp])
+    sig("tp_aabb", [C.POINTER(C.c_float), C.POINTER(C.c_float), vp, vp, C.c_int64, vp, vp, vp, vp])
+    sig("tp_sample_depth", [vp, vp, vp, C.c_int, C.c_uint64, C.c_uint64, C.c_int64, C.c_int, vp, vp])
+    sig("tp_composite_fwd", [C.POINTER(CompositeArgs), vp])
+    sig("tp_composite_bwd", [C.POINTER(CompositeBwdArgs), vp])
+    sig("tp_mlp_packed_bytes", [], C.c_size_t)
+    sig("tp_mlp_workspace_bytes", [C.c_int64], C.c_size_t)
+    sig("tp_mlp_saved_bytes", [C.c_int64], C.c_size_t)
+    sig("tp_mlp_pack", [C.POINTER(MlpWeights), C.c_int, vp, vp])
+    sig("tp_mlp_pack_host", [C.POINTER(MlpWeights), vp])
+    sig("tp_mlp_fwd", [C.POINTER(MlpFwdArgs), vp])
+    sig("tp_posenc", [vp, C.c_int64, C.c_int, C.c_int, vp, vp])
+    sig("tp_patch_gather", [C.POINTER(PatchGatherArgs), vp])
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise TexposeLibraryError(f"{what} failed (rc={rc}): {load().tp_last_error().decode()}")

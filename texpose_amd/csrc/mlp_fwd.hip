@@ -1,0 +1,397 @@
+// K2: fused positional encoding + static / transient / light MLP forward for gfx950 (CDNA4).
+//
+// Replaces NeRF.forward / forward_samples (reference layers/nerf_static_transient_light.py:76-166,
+// camera.py:317-322): 16 Linear layers + concats + activations whose [S,256..334] intermediates
+// the reference streams through memory.  Here a sample never leaves the register file between
+// its 3 input coordinates and its 9 outputs.
+//
+// Design (MI355X-first, not a translation):
+//  * exact-fp32 matrix cores: v_mfma_f32_32x32x2_f32 (bit-identical to an fmaf chain), needed for
+//    the 1e-4 parity bar through 12 chained layers; roofline = 157 TFLOP/s.
+//  * SAMPLES sit on the MFMA column/lane axis, FEATURES on the accumulator-register axis:
+//    out[f][s] = sum_k W[f][k] h[k][s].  The weights are the A operand, and a layer's 8x(32x32)
+//    accumulator tiles ARE the next layer's B operands (k-step (ts,r) contracts the two features
+//    held by register r of tile ts in the two lane halves) -- no LDS round trip, no shuffles.
+//  * one wave owns 32 samples x 256 features = 128 accumulator VGPRs + 128 for the previous
+//    layer; 4 waves (one per SIMD, ~340 of the 512 unified VGPR/AGPRs) = 128 samples / workgroup.
+//  * weights are pre-packed in exactly the order the kernel consumes them (mlp_layout.h) and are
+//    streamed L2 -> LDS in 32 KiB chunks with global_load_lds_dwordx4 (LDS-DMA), double buffered:
+//    the DMA for chunk c+1 is issued before the 128 MFMAs (8192 cycles) of chunk c, and one
+//    __syncthreads (which drains vmcnt) per chunk hands the buffer over.  A fragments are read
+//    with ds_read_b128 (4 fragments per read, conflict-free: lane-linear).
+//  * 3.7 MB of packed weights stay L2 / Infinity-Cache resident; HBM sees 12..32 B in and 36 B
+//    out per sample against 1.82 MFLOP of work.
+//  * persistent workgroups (grid <= CUs) walk sample tiles; the trunk feature needed by both
+//    heads is parked in a per-workgroup scratch slab (each lane re-reads only what it wrote).
+#include "tp_common.h"
+#include "mlp_layout.h"
+
+namespace {
+using namespace tp_layout;
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int kThreads = 256;
+constexpr int kTileSamples = 128;
+constexpr int kBiasPad = (kBiasFloats + 63) / 64 * 64;
+constexpr int kEncFloats = 32 * kThreads;                     // per-lane [x, PE(x)] B operands
+constexpr int kExFloats = 40 * kThreads;                      // per-lane head extras (latents, view encoding)
+// 2 x 32 KiB weight buffers + biases + the per-lane "extra input" B operands = 150 KiB of the 160 KiB LDS
+constexpr int kLdsFloats = 2 * kChunkFloats + kBiasPad + kEncFloats + kExFloats;
+constexpr int kSavedSlots = 7;                                // feat, T0,T1,T2, R0,R1,R2 activations
+
+#define AS1(p) ((const __attribute__((address_space(1))) void*)(p))
+#define AS3(p) ((__attribute__((address_space(3))) void*)(p))
+
+__device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+struct Pipe {
+  const float* stream;  // packed chunks (global)
+  float* lds;           // two chunk buffers
+  int chunk;            // chunk resident in buffer `buf`
+  int buf;
+  int wave, lane;
+};
+
+__device__ __forceinline__ void dma_chunk(const Pipe& p, int chunk, int buf) {
+  const float* src = p.stream + (size_t)chunk * kChunkFloats + p.wave * 2048 + p.lane * 4;
+  float* dst = p.lds + buf * kChunkFloats + p.wave * 2048;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) __builtin_amdgcn_global_load_lds(AS1(src + k * 256), AS3(dst + k * 256), 16, 0, 0);
+}
+
+// prefetch the next chunk of the stream (wrapping to the next tile's first chunk)
+__device__ __forceinline__ void chunk_begin(Pipe& p) {
+  int nxt = p.chunk + 1;
+  if (nxt == kNumChunks) nxt = 0;
+  dma_chunk(p, nxt, p.buf ^ 1);
+}
+// all waves are done with the current buffer and the prefetch has landed (syncthreads drains vmcnt)
+__device__ __forceinline__ void chunk_end(Pipe& p) {
+  __syncthreads();
+  p.chunk = (p.chunk + 1 == kNumChunks) ? 0 : p.chunk + 1;
+  p.buf ^= 1;
+}
+__device__ __forceinline__ const float* chunk_ptr(const Pipe& p) { return p.lds + p.buf * kChunkFloats + p.lane * 4; }
+
+// KS k-steps of an 8-tile (256-output) layer; B operand of k-step s is b(s).
+// The A fragments (and an LDS-resident B operand) of k-step s+1 are fetched before the 8 MFMAs of
+// k-step s; sched_group_barrier pins that order (hipcc otherwise sinks each ds_read to just before
+// its first use and stalls one wave per SIMD on lgkmcnt(0) every 4 MFMAs).
+template <int KS, int NDS, class BFn>
+__device__ __forceinline__ void mma_wide(f32x16 (&acc)[8], const float* l, BFn b) {
+  f32x4 a0 = *reinterpret_cast<const f32x4*>(l);
+  f32x4 a1 = *reinterpret_cast<const f32x4*>(l + 256);
+  float bv = b(0);
+  __builtin_amdgcn_sched_group_barrier(0x100, NDS, 0);
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    f32x4 n0 = a0, n1 = a1;
+    float nb = bv;
+    if (s + 1 < KS) {
+      n0 = *reinterpret_cast<const f32x4*>(l + (s * 2 + 2) * 256);
+      n1 = *reinterpret_cast<const f32x4*>(l + (s * 2 + 3) * 256);
+      nb = b(s + 1);
+    }
+    acc[0] = mfma(a0.x, bv, acc[0]);
+    acc[1] = mfma(a0.y, bv, acc[1]);
+    acc[2] = mfma(a0.z, bv, acc[2]);
+    acc[3] = mfma(a0.w, bv, acc[3]);
+    acc[4] = mfma(a1.x, bv, acc[4]);
+    acc[5] = mfma(a1.y, bv, acc[5]);
+    acc[6] = mfma(a1.z, bv, acc[6]);
+    acc[7] = mfma(a1.w, bv, acc[7]);
+    if (s + 1 < KS) __builtin_amdgcn_sched_group_barrier(0x100, NDS, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+    a0 = n0; a1 = n1; bv = nb;
+  }
+}
+
+// one generic 256->256 part: 8 chunks, chunk ts contracts the 32 features of tile ts of `h`
+__device__ __forceinline__ void part_gen(Pipe& p, f32x16 (&acc)[8], const f32x16 (&h)[8]) {
+#pragma unroll
+  for (int ts = 0; ts < 8; ++ts) {
+    chunk_begin(p);
+    const f32x16 hv = h[ts];
+    mma_wide<16, 2>(acc, chunk_ptr(p), [&](int s) { return hv[s]; });
+    chunk_end(p);
+  }
+}
+
+// 1..5-row head: one chunk, 128 k-steps over all of `h`, single accumulator tile
+__device__ __forceinline__ f32x16 part_head(Pipe& p, const f32x16 (&h)[8]) {
+  f32x16 acc = {0};
+  chunk_begin(p);
+  const float* l = chunk_ptr(p);
+  f32x4 a = *reinterpret_cast<const f32x4*>(l);
+  __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#pragma unroll
+  for (int s4 = 0; s4 < 32; ++s4) {
+    f32x4 n = a;
+    if (s4 + 1 < 32) n = *reinterpret_cast<const f32x4*>(l + (s4 + 1) * 256);
+    const f32x16 hv = h[s4 >> 2];
+    acc = mfma(a.x, hv[(s4 & 3) * 4 + 0], acc);
+    acc = mfma(a.y, hv[(s4 & 3) * 4 + 1], acc);
+    acc = mfma(a.z, hv[(s4 & 3) * 4 + 2], acc);
+    acc = mfma(a.w, hv[(s4 & 3) * 4 + 3], acc);
+    if (s4 + 1 < 32) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+    a = n;
+  }
+  chunk_end(p);
+  return acc;
+}
+
+__device__ __forceinline__ float softplus(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
+__device__ __forceinline__ float sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+struct Params {
+  const float* packed;
+  const float* center; const float* ray; const float* depth;
+  const float* points; const float* ray_unit;
+  const float* lat_trans; const float* lat_light;
+  int B, R, N;
+  int64_t n_samples, n_tiles;
+  float* rgb; float* density; float* uncert; float* saved; float* workspace;
+};
+
+__global__ __launch_bounds__(kThreads, 1) void mlp_fwd_kernel(Params P) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 31, hh = lane >> 5;
+  float* bias_lds = lds + 2 * kChunkFloats;
+  // Inputs that do not come from a previous layer are staged per lane in LDS ([k-step][thread]):
+  // each lane reads back only what it wrote, so no barrier is involved, and the trigonometry runs
+  // as a rolled loop instead of 42 inlined sinf/cosf expansions holding registers.
+  float* enc_lds = bias_lds + kBiasPad + tid;
+  float* ex_lds = bias_lds + kBiasPad + kEncFloats + tid;
+
+  Pipe p;
+  p.stream = P.packed; p.lds = lds; p.chunk = 0; p.buf = 0; p.wave = wave; p.lane = lane;
+  // biases -> LDS once per workgroup; first weight chunk -> buffer 0
+  for (int i = tid; i < kBiasFloats; i += kThreads) bias_lds[i] = P.packed[(size_t)kNumChunks * kChunkFloats + i];
+  dma_chunk(p, 0, 0);
+  __syncthreads();
+
+  float* ws = P.workspace + (size_t)blockIdx.x * (kTileSamples * 256);
+
+  for (int64_t tile = blockIdx.x; tile < P.n_tiles; tile += gridDim.x) {
+    // ------------------------------------------------------------------ per-sample inputs
+    const int64_t s_raw = tile * kTileSamples + wave * 32 + j;
+    const bool live = s_raw < P.n_samples;
+    const int64_t s = live ? s_raw : P.n_samples - 1;
+    const int64_t q = s / P.N;              // ray
+    const int b = (int)(q / P.R);           // image
+    float x[3], vu[3];
+    if (P.center != nullptr) {
+      const float z = P.depth[s];
+      float nrm = 0.f;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float d = P.ray[3 * q + c];
+        x[c] = tp::add_rn(P.center[3 * q + c], tp::mul_rn(d, z));   // camera.py:321
+        nrm = tp::add_rn(nrm, tp::mul_rn(d, d));
+        vu[c] = d;
+      }
+      const float den = fmaxf(sqrtf(nrm), 1e-12f);                   // F.normalize (layers/...light.py:156)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) vu[c] = tp::div_rn(vu[c], den);
+    } else {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { x[c] = P.points[3 * s + c]; vu[c] = P.ray_unit[3 * s + c]; }
+    }
+    // positional encoding of x: this lane half evaluates sin (h=0) or cos (h=1) of x_c * 2^l * pi
+#pragma nounroll
+    for (int r = 0; r < 30; ++r) {
+      const int c = r / 10;
+      const float xc = c == 0 ? x[0] : (c == 1 ? x[1] : x[2]);
+      const float arg = tp::mul_rn(xc, ldexpf(3.14159274101257324f, r - c * 10));
+      enc_lds[r * kThreads] = hh ? cosf(arg) : sinf(arg);
+    }
+    enc_lds[30 * kThreads] = hh ? x[1] : x[0];
+    enc_lds[31 * kThreads] = hh ? 0.0f : x[2];
+
+    f32x16 h[8], acc[8];
+    float sig_s = 0.f, sig_t = 0.f, unc = 0.f, rgb_t[3] = {0.f, 0.f, 0.f}, rgb_s[3] = {0.f, 0.f, 0.f};
+
+#pragma nounroll
+    for (int li = 0; li < kNumWide; ++li) {
+      if (li == L7) {   // static density = softplus(row 0 of mlp_feat.7) (layers/...light.py:94-98)
+        const f32x16 a = part_head(p, h);
+        sig_s = softplus(a[0] + bias_lds[kHeadBiasOff + 0]);
+      }
+      if (li == R0) {   // bring the trunk feature back for the rgb head
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(ws + ((t * 4 + g) * kThreads + tid) * 4);
+            h[t][g * 4 + 0] = v.x; h[t][g * 4 + 1] = v.y; h[t][g * 4 + 2] = v.z; h[t][g * 4 + 3] = v.w;
+          }
+      }
+#pragma unroll
+      for (int t = 0; t < 8; ++t) acc[t] = f32x16{0};
+
+      if (li != L0) part_gen(p, acc, h);
+
+      if (li == L0 || li == L4) {          // [x, PE(x)] columns (layers/...light.py:81-82,90-91)
+#pragma unroll
+        for (int qd = 0; qd < 2; ++qd) {
+          chunk_begin(p);
+          mma_wide<16, 3>(acc, chunk_ptr(p), [&](int s_) { return enc_lds[(qd * 16 + s_) * kThreads]; });
+          chunk_end(p);
+        }
+      } else if (li == T0) {               // transient latent (layers/...light.py:126-128)
+#pragma unroll
+        for (int r = 0; r < 8; ++r) ex_lds[r * kThreads] = P.lat_trans[b * 16 + r + 8 * hh];
+        chunk_begin(p);
+        mma_wide<8, 3>(acc, chunk_ptr(p), [&](int s_) { return ex_lds[s_ * kThreads]; });
+        chunk_end(p);
+      } else if (li == R0) {               // [ray_unit, PE(ray_unit), x, light] (layers/...light.py:104-117)
+#pragma nounroll
+        for (int r = 0; r < 12; ++r) {
+          const int c = r >> 2;
+          const float vc = c == 0 ? vu[0] : (c == 1 ? vu[1] : vu[2]);
+          const float arg = tp::mul_rn(vc, ldexpf(3.14159274101257324f, r & 3));
+          ex_lds[r * kThreads] = hh ? cosf(arg) : sinf(arg);
+        }
+        ex_lds[12 * kThreads] = hh ? vu[1] : vu[0];
+        ex_lds[13 * kThreads] = hh ? x[0] : vu[2];
+        ex_lds[14 * kThreads] = hh ? x[2] : x[1];
+#pragma unroll
+        for (int r = 15; r < 39; ++r) ex_lds[r * kThreads] = P.lat_light[b * 48 + (r - 15) + 24 * hh];
+        ex_lds[39 * kThreads] = 0.0f;
+#pragma unroll
+        for (int qd = 0; qd < 3; ++qd) {
+          chunk_begin(p);
+          if (qd < 2) mma_wide<16, 3>(acc, chunk_ptr(p), [&](int s_) { return ex_lds[(qd * 16 + s_) * kThreads]; });
+          else mma_wide<8, 3>(acc, chunk_ptr(p), [&](int s_) { return ex_lds[(32 + s_) * kThreads]; });
+          chunk_end(p);
+        }
+      }
+
+      // bias + ReLU; the result is the next layer's B operand
+      const float* bl = bias_lds + (li * 2 + hh) * 128;
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 bv = *reinterpret_cast<const f32x4*>(bl + t * 16 + g * 4);
+          h[t][g * 4 + 0] = fmaxf(acc[t][g * 4 + 0] + bv.x, 0.0f);
+          h[t][g * 4 + 1] = fmaxf(acc[t][g * 4 + 1] + bv.y, 0.0f);
+          h[t][g * 4 + 2] = fmaxf(acc[t][g * 4 + 2] + bv.z, 0.0f);
+          h[t][g * 4 + 3] = fmaxf(acc[t][g * 4 + 3] + bv.w, 0.0f);
+        }
+
+      if (P.saved != nullptr && li >= L7 && live) {
+        // activations for the backward: [32-sample group][slot][feature][sample]
+        float* sv = P.saved + (((tile * 4 + wave) * kSavedSlots + (li - L7)) * 256) * 32 + j;
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sv[feat_of(t, r, hh) * 32] = h[t][r];
+      }
+      if (li == L7) {   // park the trunk feature for the second head
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            f32x4 v = {h[t][g * 4 + 0], h[t][g * 4 + 1], h[t][g * 4 + 2], h[t][g * 4 + 3]};
+            *reinterpret_cast<f32x4*>(ws + ((t * 4 + g) * kThreads + tid) * 4) = v;
+          }
+      }
+      if (li == T2) {   // transient head: rgb_t (sigmoid), sigma_t, uncert (softplus) (layers/...light.py:135-137)
+        const f32x16 a = part_head(p, h);
+        const float* hb = bias_lds + kHeadBiasOff + 1;
+        rgb_t[0] = sigmoid(a[0] + hb[0]); rgb_t[1] = sigmoid(a[1] + hb[1]); rgb_t[2] = sigmoid(a[2] + hb[2]);
+        sig_t = softplus(a[3] + hb[3]);
+        unc = softplus(a[0] + hb[4]);       // row 4 lives in register 0 of the upper lane half
+      }
+      if (li == R2) {   // static rgb (layers/...light.py:122)
+        const f32x16 a = part_head(p, h);
+        const float* hb = bias_lds + kHeadBiasOff + 6;
+        rgb_s[0] = sigmoid(a[0] + hb[0]); rgb_s[1] = sigmoid(a[1] + hb[1]); rgb_s[2] = sigmoid(a[2] + hb[2]);
+      }
+    }
+
+    // ------------------------------------------------------------------ outputs (36 B / sample)
+    if (live) {
+      if (hh == 0) {
+        float2* o = reinterpret_cast<float2*>(P.rgb + s * 6);
+        o[0] = make_float2(rgb_s[0], rgb_t[0]);
+        o[1] = make_float2(rgb_s[1], rgb_t[1]);
+        o[2] = make_float2(rgb_s[2], rgb_t[2]);
+        *reinterpret_cast<float2*>(P.density + s * 2) = make_float2(sig_s, sig_t);
+      } else {
+        P.uncert[s] = unc;
+      }
+    }
+  }
+}
+
+// standalone positional encoding (API parity with NeRF.positional_encoding)
+__global__ void posenc_kernel(const float* __restrict__ x, int64_t n, int C, int L, float* __restrict__ out) {
+  const int64_t total = n * C * 2 * L;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int l = (int)(e % L), sc = (int)((e / L) % 2), c = (int)((e / (2 * L)) % C);
+    const int64_t i = e / (2 * L * C);
+    const float arg = tp::mul_rn(x[i * C + c], ldexpf(3.14159274101257324f, l));
+    out[e] = sc ? cosf(arg) : sinf(arg);
+  }
+}
+
+int persistent_grid(int64_t n_tiles) {
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  return (int)(n_tiles < cus ? n_tiles : cus);
+}
+
+}  // namespace
+
+extern "C" size_t tp_mlp_workspace_bytes(int64_t n_samples) {
+  const int64_t tiles = (n_samples + kTileSamples - 1) / kTileSamples;
+  const int64_t wgs = tiles < 1024 ? tiles : 1024;   // upper bound on the persistent grid
+  return (size_t)(wgs > 0 ? wgs : 1) * kTileSamples * 256 * sizeof(float);
+}
+
+extern "C" size_t tp_mlp_saved_bytes(int64_t n_samples) {
+  const int64_t groups = ((n_samples + kTileSamples - 1) / kTileSamples) * 4;
+  return (size_t)groups * kSavedSlots * 256 * 32 * sizeof(float);
+}
+
+extern "C" int tp_mlp_fwd(const tp_mlp_fwd_args* a, tp_stream_t stream) {
+  TP_REQUIRE(a && a->packed && a->lat_trans && a->lat_light && a->rgb && a->density && a->uncert && a->workspace,
+             "null pointer");
+  TP_REQUIRE(a->B > 0 && a->R > 0 && a->N > 0, "bad sizes");
+  TP_REQUIRE((a->center && a->ray && a->depth) || (a->points && a->ray_unit), "need (center,ray,depth) or (points,ray_unit)");
+  Params P;
+  P.packed = (const float*)a->packed;
+  P.center = a->center; P.ray = a->ray; P.depth = a->depth; P.points = a->points; P.ray_unit = a->ray_unit;
+  P.lat_trans = a->lat_trans; P.lat_light = a->lat_light;
+  P.B = a->B; P.R = a->R; P.N = a->N;
+  P.n_samples = (int64_t)a->B * a->R * a->N;
+  P.n_tiles = (P.n_samples + kTileSamples - 1) / kTileSamples;
+  P.rgb = a->rgb; P.density = a->density; P.uncert = a->uncert; P.saved = a->saved; P.workspace = (float*)a->workspace;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)mlp_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       kLdsFloats * (int)sizeof(float));
+    if (e != hipSuccess) { tp::set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+    attr_set = true;
+  }
+  const int grid = persistent_grid(P.n_tiles);
+  hipLaunchKernelGGL(mlp_fwd_kernel, dim3(grid), dim3(kThreads), kLdsFloats * sizeof(float), (hipStream_t)stream, P);
+  return tp::check_launch("tp_mlp_fwd");
+}
+
+extern "C" int tp_posenc(const float* x, int64_t n, int C, int L, float* out, tp_stream_t stream) {
+  TP_REQUIRE(x && out && C > 0 && L > 0 && n >= 0, "bad arguments");
+  if (n == 0) return 0;
+  int64_t blocks = (n * C * 2 * L + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(posenc_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, n, C, L, out);
+  return tp::check_launch("tp_posenc");
+}

@@ -1,0 +1,122 @@
+// Packed weight-stream layout shared by the pack kernel, the fused MLP forward and its tests.
+//
+// The fused MLP (mlp_fwd.hip) keeps activations in registers with SAMPLES on the MFMA column
+// (lane) axis and FEATURES on the accumulator-register axis, so the weight matrix is always the
+// A operand of v_mfma_f32_32x32x2_f32 and one layer's output registers are directly the next
+// layer's B operand.  Consequences for the layout:
+//
+//  * accumulator tile t (32 features), register r (0..15), lane half h (lane>>5) holds feature
+//        feat_of(t, r, h) = 32 t + (r & 3) + 8 (r >> 2) + 4 h            (MFMA C/D map)
+//    so k-step (ts, r) of the NEXT layer contracts features feat_of(ts, r, 0|1), and the A
+//    fragment for output tile t must hold  W[32 t + (lane & 31)][feat_of(ts, r, lane >> 5)].
+//  * the whole network is consumed as a linear stream of 32 KiB chunks in execution order, each
+//    chunk = 16 k-steps x 8 output tiles x 64 lanes (wide layers) or 128 k-steps x 1 tile
+//    (3/5/1-row heads); inside a chunk four fragments are interleaved per lane so that one
+//    ds_read_b128 feeds four MFMAs:   float index = ((kstep*2 + t/4)*64 + lane)*4 + t%4
+//    (heads: ((kstep/4)*64 + lane)*4 + kstep%4).
+//  * per-sample inputs that are not produced by a previous layer (positional encodings, raw
+//    coordinates, latents) live in "extra" k-steps whose (k-step, half) -> input-column maps are
+//    enc_col / x40_col / x8_col below.
+//
+// Reference: layers/nerf_static_transient_light.py:16-61 (layer shapes), :76-145 (concat orders).
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__) || defined(__CUDACC__)
+#define TP_HD __host__ __device__ __forceinline__
+#else
+#define TP_HD inline
+#endif
+
+namespace tp_layout {
+
+constexpr int kChunkFloats = 8192;           // 32 KiB
+constexpr int kNumChunks = 115;
+constexpr int kNumWide = 14;                 // wide (256-out) layers: L0..L7, T0..T2, R0..R2
+constexpr int kBiasFloats = kNumWide * 256 + 16;
+constexpr int64_t kPackedFloats = (int64_t)kNumChunks * kChunkFloats + kBiasFloats;
+constexpr int kFirstHeadChunk = 61;          // chunks >= this belong to the trainable heads (T*, R*)
+constexpr int kFirstHeadWide = 8;            // wide-layer index of T0
+
+// wide-layer indices
+enum { L0 = 0, L1, L2, L3, L4, L5, L6, L7, T0, T1, T2, R0, R1, R2 };
+// weight-matrix ids
+enum { W_FEAT0 = 0, W_RGB0 = 8, W_TRANS0 = 12 };
+
+enum ChunkKind { CK_GEN = 0, CK_ENC = 1, CK_X8 = 2, CK_X40 = 3, CK_HEAD = 4 };
+
+struct ChunkDesc {
+  int kind;     // ChunkKind
+  int mat;      // weight matrix id (W_FEAT0 + i, W_RGB0 + i, W_TRANS0 + i)
+  int sub;      // GEN: ts (0..7); ENC/X40: 16-k-step block index; HEAD: number of valid rows
+  int row_off;  // first output row (1 for L7: row 0 is the density head)
+  int col_off;  // first input column of this part
+  int in_dim;   // row length of the weight matrix
+};
+
+TP_HD int feat_of(int t, int r, int h) { return 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// positional-encoded 3D point, 32 k-steps: input vector = [x(3), PE(x) (c*20 + s*10 + l)], 63 wide
+TP_HD int enc_col(int r, int h) {
+  if (r < 30) return 3 + (r / 10) * 20 + h * 10 + (r % 10);
+  if (r == 30) return h;            // x[0], x[1]
+  return h == 0 ? 2 : -1;           // x[2], pad
+}
+// rgb-head extras, 40 k-steps: [ray_unit(3), PE(ray_unit) (c*8+s*4+l) (24), x(3), light(48)], 78 wide
+TP_HD int x40_col(int r, int h) {
+  if (r < 12) return 3 + (r / 4) * 8 + h * 4 + (r % 4);
+  if (r == 12) return h;                    // ray_unit[0], ray_unit[1]
+  if (r == 13) return h == 0 ? 2 : 27;      // ray_unit[2], x[0]
+  if (r == 14) return 28 + h;               // x[1], x[2]
+  if (r < 39) return 30 + (r - 15) + 24 * h;  // light[a], light[24+a]
+  return -1;
+}
+// transient-head extras, 8 k-steps: trans latent (16)
+TP_HD int x8_col(int r, int h) { return r < 8 ? r + 8 * h : -1; }
+
+TP_HD ChunkDesc chunk_desc(int c) {
+  // schedule (must match mlp_fwd.hip): see the table in DESIGN.md
+  if (c < 2) return {CK_ENC, W_FEAT0 + 0, c, 0, 0, 63};
+  if (c < 26) { int l = 1 + (c - 2) / 8; return {CK_GEN, W_FEAT0 + l, (c - 2) % 8, 0, 0, 256}; }
+  if (c < 34) return {CK_GEN, W_FEAT0 + 4, c - 26, 0, 0, 319};
+  if (c < 36) return {CK_ENC, W_FEAT0 + 4, c - 34, 0, 256, 319};
+  if (c < 52) { int l = 5 + (c - 36) / 8; return {CK_GEN, W_FEAT0 + l, (c - 36) % 8, 0, 0, 256}; }
+  if (c == 52) return {CK_HEAD, W_FEAT0 + 7, 1, 0, 0, 256};
+  if (c < 61) return {CK_GEN, W_FEAT0 + 7, c - 53, 1, 0, 256};
+  if (c < 69) return {CK_GEN, W_TRANS0 + 0, c - 61, 0, 0, 272};
+  if (c == 69) return {CK_X8, W_TRANS0 + 0, 0, 0, 256, 272};
+  if (c < 86) { int l = 1 + (c - 70) / 8; return {CK_GEN, W_TRANS0 + l, (c - 70) % 8, 0, 0, 256}; }
+  if (c == 86) return {CK_HEAD, W_TRANS0 + 3, 5, 0, 0, 256};
+  if (c < 95) return {CK_GEN, W_RGB0 + 0, c - 87, 0, 0, 334};
+  if (c < 98) return {CK_X40, W_RGB0 + 0, c - 95, 0, 256, 334};
+  if (c < 114) { int l = 1 + (c - 98) / 8; return {CK_GEN, W_RGB0 + l, (c - 98) % 8, 0, 0, 256}; }
+  return {CK_HEAD, W_RGB0 + 3, 3, 0, 0, 256};
+}
+
+// Source element of packed float `idx` (0..8191) of chunk c: returns (row, col) of the weight matrix
+// chunk_desc(c).mat, or row = -1 for a zero pad.
+TP_HD void chunk_src(const ChunkDesc& d, int idx, int& row, int& col) {
+  const int sub = idx & 3, lane = (idx >> 2) & 63, i = lane & 31, h = lane >> 5;
+  row = -1; col = 0;
+  if (d.kind == CK_HEAD) {
+    const int s = (idx >> 8) * 4 + sub;            // k-step 0..127
+    if (i < d.sub) { row = i; col = feat_of(s >> 4, s & 15, h); }
+    return;
+  }
+  const int g = (idx >> 8) & 1, rr = idx >> 9;     // tile group, k-step within the chunk
+  const int t = g * 4 + sub;
+  int k;
+  if (d.kind == CK_GEN) k = feat_of(d.sub, rr, h);
+  else if (d.kind == CK_ENC) k = enc_col(d.sub * 16 + rr, h);
+  else if (d.kind == CK_X8) k = x8_col(rr, h);
+  else k = x40_col(d.sub * 16 + rr, h);
+  if (k < 0) return;
+  row = d.row_off + 32 * t + i;
+  col = d.col_off + k;
+}
+
+// bias block: [wide layer][h][t][r] then 16 head scalars: b7[0], T3 bias[0..4], R3 bias[0..2]
+TP_HD int bias_index(int wide, int h, int t, int r) { return ((wide * 2 + h) * 8 + t) * 16 + r; }
+constexpr int kHeadBiasOff = kNumWide * 256;
+
+}  // namespace tp_layout

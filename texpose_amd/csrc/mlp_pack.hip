@@ -1,0 +1,103 @@
+// Packs the reference state-dict weights (W [out,in]) into the MFMA-fragment-ordered,
+// execution-ordered stream consumed by mlp_fwd.hip (layout: mlp_layout.h).  One thread per packed
+// float; the trunk part is packed once (frozen, reference layers/...light.py:34,236-239), the
+// heads are re-packed after every optimiser step (442k floats).
+#include "tp_common.h"
+#include "mlp_layout.h"
+
+namespace {
+using namespace tp_layout;
+
+struct W {
+  const float* w[16];
+  const float* b[16];
+};
+
+__global__ void pack_kernel(W w, int chunk0, int chunk1, float* __restrict__ out) {
+  const int64_t n = (int64_t)(chunk1 - chunk0) * kChunkFloats;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+    const int c = chunk0 + (int)(e / kChunkFloats), idx = (int)(e % kChunkFloats);
+    const ChunkDesc d = chunk_desc(c);
+    int row, col;
+    chunk_src(d, idx, row, col);
+    out[(int64_t)c * kChunkFloats + idx] = row < 0 ? 0.0f : w.w[d.mat][(int64_t)row * d.in_dim + col];
+  }
+}
+
+__global__ void pack_bias_kernel(W w, int wide0, int wide1, float* __restrict__ out) {
+  float* bias = out + (int64_t)kNumChunks * kChunkFloats;
+  const int n = (wide1 - wide0) * 256;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < n) {
+    const int wide = wide0 + e / 256, rem = e % 256, h = rem / 128, t = (rem / 16) % 8, r = rem % 16;
+    const int mat = wide <= L7 ? W_FEAT0 + wide : (wide <= T2 ? W_TRANS0 + (wide - T0) : W_RGB0 + (wide - R0));
+    const int off = wide == L7 ? 1 : 0;
+    bias[bias_index(wide, h, t, r)] = w.b[mat][off + feat_of(t, r, h)];
+  }
+  if (e < 16) {
+    float v = 0.0f;
+    if (e == 0) { if (wide0 <= L7) v = w.b[W_FEAT0 + 7][0]; else return; }
+    else if (e < 6) { if (wide1 > T0) v = w.b[W_TRANS0 + 3][e - 1]; else return; }
+    else if (e < 9) { if (wide1 > T0) v = w.b[W_RGB0 + 3][e - 6]; else return; }
+    bias[kHeadBiasOff + e] = v;
+  }
+}
+}  // namespace
+
+// Host-side packer (same layout functions, no GPU involved): used by the CPU tests to check the
+// stream layout against the oracle, and as the reference for the device packer.
+extern "C" int tp_mlp_pack_host(const tp_mlp_weights* p, float* out) {
+  TP_REQUIRE(p && out, "null pointer");
+  const float* w[16]; const float* b[16];
+  for (int i = 0; i < 8; ++i) { w[W_FEAT0 + i] = p->feat_w[i]; b[W_FEAT0 + i] = p->feat_b[i]; }
+  for (int i = 0; i < 4; ++i) {
+    w[W_RGB0 + i] = p->rgb_w[i]; b[W_RGB0 + i] = p->rgb_b[i];
+    w[W_TRANS0 + i] = p->trans_w[i]; b[W_TRANS0 + i] = p->trans_b[i];
+  }
+  for (int i = 0; i < 16; ++i) TP_REQUIRE(w[i] && b[i], "null weight pointer");
+  for (int c = 0; c < kNumChunks; ++c) {
+    const ChunkDesc d = chunk_desc(c);
+    for (int idx = 0; idx < kChunkFloats; ++idx) {
+      int row, col;
+      chunk_src(d, idx, row, col);
+      out[(int64_t)c * kChunkFloats + idx] = row < 0 ? 0.0f : w[d.mat][(int64_t)row * d.in_dim + col];
+    }
+  }
+  float* bias = out + (int64_t)kNumChunks * kChunkFloats;
+  for (int wide = 0; wide < kNumWide; ++wide) {
+    const int mat = wide <= L7 ? W_FEAT0 + wide : (wide <= T2 ? W_TRANS0 + (wide - T0) : W_RGB0 + (wide - R0));
+    const int off = wide == L7 ? 1 : 0;
+    for (int h = 0; h < 2; ++h)
+      for (int t = 0; t < 8; ++t)
+        for (int r = 0; r < 16; ++r) bias[bias_index(wide, h, t, r)] = b[mat][off + feat_of(t, r, h)];
+  }
+  for (int e = 0; e < 16; ++e) bias[kHeadBiasOff + e] = 0.0f;
+  bias[kHeadBiasOff + 0] = b[W_FEAT0 + 7][0];
+  for (int e = 0; e < 5; ++e) bias[kHeadBiasOff + 1 + e] = b[W_TRANS0 + 3][e];
+  for (int e = 0; e < 3; ++e) bias[kHeadBiasOff + 6 + e] = b[W_RGB0 + 3][e];
+  return 0;
+}
+
+extern "C" size_t tp_mlp_packed_bytes(void) { return (size_t)tp_layout::kPackedFloats * sizeof(float); }
+
+extern "C" int tp_mlp_pack(const tp_mlp_weights* p, int parts, void* packed, tp_stream_t stream) {
+  TP_REQUIRE(p && packed, "null pointer");
+  TP_REQUIRE((parts & ~TP_PACK_ALL) == 0 && parts != 0, "bad parts mask");
+  W w;
+  for (int i = 0; i < 8; ++i) { w.w[W_FEAT0 + i] = p->feat_w[i]; w.b[W_FEAT0 + i] = p->feat_b[i]; }
+  for (int i = 0; i < 4; ++i) {
+    w.w[W_RGB0 + i] = p->rgb_w[i]; w.b[W_RGB0 + i] = p->rgb_b[i];
+    w.w[W_TRANS0 + i] = p->trans_w[i]; w.b[W_TRANS0 + i] = p->trans_b[i];
+  }
+  const bool trunk = parts & TP_PACK_TRUNK, heads = parts & TP_PACK_HEADS;
+  for (int i = 0; i < 16; ++i) {
+    const bool is_trunk = i < 8;
+    if ((is_trunk && trunk) || (!is_trunk && heads)) TP_REQUIRE(w.w[i] && w.b[i], "null weight pointer");
+  }
+  const int c0 = trunk ? 0 : kFirstHeadChunk, c1 = heads ? kNumChunks : kFirstHeadChunk;
+  const int w0 = trunk ? 0 : kFirstHeadWide, w1 = heads ? kNumWide : kFirstHeadWide;
+  hipLaunchKernelGGL(pack_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, w, c0, c1, (float*)packed);
+  hipLaunchKernelGGL(pack_bias_kernel, dim3(((w1 - w0) * 256 + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, w0,
+                     w1, (float*)packed);
+  return tp::check_launch("tp_mlp_pack");
+}

@@ -1,0 +1,71 @@
+// K5: patch gather for the photometric / perceptual / PatchGAN inputs (gfx950).
+//
+// Replaces the 8 F.grid_sample calls the reference issues per training step, twice (nerf step and
+// discriminator step): model/nerf_adapt_st_gan.py:444-461 (sample_geometry), :726-745
+// (compute_loss).  image / image_syn / nocs / normal are bilinear with align_corners=True;
+// obj_mask / mask_syn are binarised (>0) and sampled 'nearest' with the default
+// align_corners=False (the two conventions disagree by up to half a
+// pixel and x=+1 rounds out of range).  One thread per patch pixel gathers all 14 channels, so
+// the coordinate algebra is done once instead of 8 times; output is channel-major [B,14,P].
+// HBM-bound gather: <= 14 ch x 4 taps x 4 B read + 56 B written per patch pixel.
+#include "tp_common.h"
+
+namespace {
+
+__global__ void patch_gather_kernel(tp_patch_gather_args a) {
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)a.B * a.P;
+  if (q >= total) return;
+  const int b = (int)(q / a.P), p = (int)(q - (int64_t)b * a.P);
+  const int H = a.H, W = a.W;
+  const int64_t HW = (int64_t)H * W;
+  const float x = a.coords[2 * q], y = a.coords[2 * q + 1];
+  // bilinear, align_corners=True
+  const float ix = tp::mul_rn(tp::add_rn(x, 1.0f), (float)(W - 1) * 0.5f);
+  const float iy = tp::mul_rn(tp::add_rn(y, 1.0f), (float)(H - 1) * 0.5f);
+  const float fx = floorf(ix), fy = floorf(iy);
+  const float w = tp::sub_rn(ix, fx), e = tp::sub_rn(1.0f, w), n = tp::sub_rn(iy, fy), s = tp::sub_rn(1.0f, n);
+  const float nw = tp::mul_rn(e, s), ne = tp::mul_rn(w, s), sw = tp::mul_rn(e, n), se = tp::mul_rn(w, n);
+  const int x0 = (int)fminf(fmaxf(fx, -2.0f), (float)W + 1.0f), y0 = (int)fminf(fmaxf(fy, -2.0f), (float)H + 1.0f);
+  const bool xin0 = x0 >= 0 && x0 <= W - 1, xin1 = x0 + 1 >= 0 && x0 + 1 <= W - 1;
+  const bool yin0 = y0 >= 0 && y0 <= H - 1, yin1 = y0 + 1 >= 0 && y0 + 1 <= H - 1;
+  const bool ok00 = xin0 && yin0, ok10 = xin1 && yin0, ok01 = xin0 && yin1, ok11 = xin1 && yin1;
+  const int64_t o00 = (int64_t)y0 * W + x0;
+  // nearest, align_corners=False, round half to even
+  const float jx = rintf(tp::sub_rn(tp::mul_rn(tp::add_rn(x, 1.0f), (float)W * 0.5f), 0.5f));
+  const float jy = rintf(tp::sub_rn(tp::mul_rn(tp::add_rn(y, 1.0f), (float)H * 0.5f), 0.5f));
+  const bool nok = jx >= 0.0f && jx <= (float)(W - 1) && jy >= 0.0f && jy <= (float)(H - 1);
+  const int64_t on = nok ? (int64_t)jy * W + (int64_t)jx : 0;
+  const float m = nok ? (a.obj_mask[b * HW + on] > 0.0f ? 1.0f : 0.0f) : 0.0f;
+  const float ms = nok ? (a.mask_syn[b * HW + on] > 0.0f ? 1.0f : 0.0f) : 0.0f;
+
+  float* out = a.out + (int64_t)b * 14 * a.P + p;
+  const float* srcs[4] = {a.image, a.image_syn, a.nocs, a.normal};
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float* pl = srcs[t] + ((int64_t)b * 3 + c) * HW;
+      float r = tp::mul_rn(ok00 ? pl[o00] : 0.0f, nw);
+      r = tp::fma_rn(ok10 ? pl[o00 + 1] : 0.0f, ne, r);
+      r = tp::fma_rn(ok01 ? pl[o00 + W] : 0.0f, sw, r);
+      r = tp::fma_rn(ok11 ? pl[o00 + W + 1] : 0.0f, se, r);
+      if (t >= 2) r = tp::mul_rn(r, ms);  // nocs_sample / normal_sample = gathered * mask_syn (:459-460)
+      out[(int64_t)(t * 3 + c) * a.P] = r;
+    }
+  }
+  out[(int64_t)12 * a.P] = m;
+  out[(int64_t)13 * a.P] = ms;
+}
+
+}  // namespace
+
+extern "C" int tp_patch_gather(const tp_patch_gather_args* a, tp_stream_t stream) {
+  TP_REQUIRE(a && a->coords && a->image && a->image_syn && a->nocs && a->normal && a->obj_mask && a->mask_syn &&
+                 a->out, "null pointer");
+  TP_REQUIRE(a->B > 0 && a->P > 0 && a->H > 0 && a->W > 0, "bad sizes");
+  const int64_t total = (int64_t)a->B * a->P;
+  hipLaunchKernelGGL(patch_gather_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     *a);
+  return tp::check_launch("tp_patch_gather");
+}

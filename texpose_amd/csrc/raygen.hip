@@ -1,0 +1,333 @@
+// K1: fused ray generation + per-ray depth bounds + stratified depth samples (gfx950).
+//
+// Replaces (reference file:line):
+//   tools/ray_sampler.py:40-69    train rays from continuous patch coordinates
+//   tools/ray_sampler.py:24-37    bilinear lookup of the z_near / z_far maps
+//   camera.py:292-314 + model/nerf_adapt_st_gan.py:573-579,702-710   eval rays: the reference
+//       materialises all H*W rays for every 2048-ray chunk and gathers; here only the requested
+//       pixels are generated, straight from ray_idx
+//   camera.py:415-433, compute_box.py:69-87,270-272, data/lm.py:349-350   AABB slab bounds
+//   model/nerf_adapt_st_gan.py:683-700   stratified sample_depth
+//
+// HBM-bound streaming kernel: algorithmic traffic is 8 B/ray read (+84 B per image of camera
+// constants, served from L2) and 24 + 4N B/ray written.  One 256-thread workgroup owns 256
+// consecutive rays: phase 1 is one thread per ray (camera algebra, bounds), phase 2 has the whole
+// workgroup write the 256*N depth samples of the tile as contiguous 16-byte stores, with the
+// per-ray (near, far-near) pair staged in LDS.
+#include "tp_common.h"
+
+namespace {
+
+constexpr int kTile = 256;
+
+struct Cam {
+  float kinv[9];
+  float rt[9];    // R^T
+  float tinv[3];  // -R^T t
+};
+
+__device__ __forceinline__ void load_cam(const float* __restrict__ intr, const float* __restrict__ pose, int b, Cam& c) {
+  const float* K = intr + 9 * b;
+  const float a = K[0], bb = K[1], cc = K[2], d = K[3], e = K[4], f = K[5], g = K[6], h = K[7], i = K[8];
+  const float A = e * i - f * h, Bc = -(d * i - f * g), C = d * h - e * g;
+  const float det = a * A + bb * Bc + cc * C;
+  const float r = 1.0f / det;
+  c.kinv[0] = A * r;  c.kinv[1] = -(bb * i - cc * h) * r;  c.kinv[2] = (bb * f - cc * e) * r;
+  c.kinv[3] = Bc * r; c.kinv[4] = (a * i - cc * g) * r;    c.kinv[5] = -(a * f - cc * d) * r;
+  c.kinv[6] = C * r;  c.kinv[7] = -(a * h - bb * g) * r;   c.kinv[8] = (a * e - bb * d) * r;
+  const float* P = pose + 12 * b;
+#pragma unroll
+  for (int r_ = 0; r_ < 3; ++r_)
+#pragma unroll
+    for (int c_ = 0; c_ < 3; ++c_) c.rt[r_ * 3 + c_] = P[c_ * 4 + r_];
+  const float t0 = P[3], t1 = P[7], t2 = P[11];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    float acc = tp::mul_rn(-c.rt[j * 3 + 0], t0);
+    acc = tp::fma_rn(-c.rt[j * 3 + 1], t1, acc);
+    acc = tp::fma_rn(-c.rt[j * 3 + 2], t2, acc);
+    c.tinv[j] = acc;
+  }
+}
+
+// grid_sample(bilinear, align_corners=True, zeros) of one channel, accumulated the way torch's
+// CPU kernel does (one multiply, three fused multiply-adds in nw,ne,sw,se order).
+struct Bilin {
+  int x0, y0;
+  float nw, ne, sw, se;
+  bool ok00, ok10, ok01, ok11;
+};
+
+__device__ __forceinline__ Bilin bilin_setup(float x, float y, int H, int W) {
+  Bilin b;
+  const float ix = tp::mul_rn(tp::add_rn(x, 1.0f), (float)(W - 1) * 0.5f);
+  const float iy = tp::mul_rn(tp::add_rn(y, 1.0f), (float)(H - 1) * 0.5f);
+  const float fx = floorf(ix), fy = floorf(iy);
+  const float w = tp::sub_rn(ix, fx), e = tp::sub_rn(1.0f, w);
+  const float n = tp::sub_rn(iy, fy), s = tp::sub_rn(1.0f, n);
+  b.nw = tp::mul_rn(e, s); b.ne = tp::mul_rn(w, s); b.sw = tp::mul_rn(e, n); b.se = tp::mul_rn(w, n);
+  // clamp before the int conversion so that wild coordinates cannot overflow
+  const float cx = fminf(fmaxf(fx, -2.0f), (float)W + 1.0f), cy = fminf(fmaxf(fy, -2.0f), (float)H + 1.0f);
+  b.x0 = (int)cx; b.y0 = (int)cy;
+  const bool xin0 = b.x0 >= 0 && b.x0 <= W - 1, xin1 = b.x0 + 1 >= 0 && b.x0 + 1 <= W - 1;
+  const bool yin0 = b.y0 >= 0 && b.y0 <= H - 1, yin1 = b.y0 + 1 >= 0 && b.y0 + 1 <= H - 1;
+  b.ok00 = xin0 && yin0; b.ok10 = xin1 && yin0; b.ok01 = xin0 && yin1; b.ok11 = xin1 && yin1;
+  return b;
+}
+
+__device__ __forceinline__ float bilin_apply(const Bilin& b, float v00, float v10, float v01, float v11) {
+  float r = tp::mul_rn(b.ok00 ? v00 : 0.0f, b.nw);
+  r = tp::fma_rn(b.ok10 ? v10 : 0.0f, b.ne, r);
+  r = tp::fma_rn(b.ok01 ? v01 : 0.0f, b.sw, r);
+  r = tp::fma_rn(b.ok11 ? v11 : 0.0f, b.se, r);
+  return r;
+}
+
+__device__ __forceinline__ float bilin_map(const Bilin& b, const float* __restrict__ m, int W) {
+  const float v00 = b.ok00 ? m[b.y0 * W + b.x0] : 0.0f;
+  const float v10 = b.ok10 ? m[b.y0 * W + b.x0 + 1] : 0.0f;
+  const float v01 = b.ok01 ? m[(b.y0 + 1) * W + b.x0] : 0.0f;
+  const float v11 = b.ok11 ? m[(b.y0 + 1) * W + b.x0 + 1] : 0.0f;
+  return bilin_apply(b, v00, v10, v01, v11);
+}
+
+// Philox4x32-10 (Salmon et al., SC'11); stream layout documented in oracle.philox_uniform.
+__device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+    c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
+    k.x += 0x9E3779B9u; k.y += 0xBB67AE85u;
+  }
+  return c;
+}
+__device__ __forceinline__ float u01(uint32_t w) { return (float)(w >> 8) * 5.9604644775390625e-08f; }
+
+__device__ __forceinline__ float strat(float r, int i, float fN, float span, float near) {
+  // ((rand + i) / N) * (far - near) + near, each op rounded as in the reference expression
+  return tp::add_rn(tp::mul_rn(tp::div_rn(tp::add_rn(r, (float)i), fN), span), near);
+}
+
+struct Args {
+  const float* intr; const float* pose; const float* coords; const int64_t* ray_idx;
+  const float* z_near; const float* z_far; const float* rnd;
+  float amin[3], amax[3], bg_near, bg_far;
+  uint64_t seed, offset;
+  int B, R, H, W, N, pixel_mode, bounds_mode, jitter_mode;
+  float* center; float* ray; float* near; float* far; float* depth;
+};
+
+__device__ __forceinline__ void slab(const float* amin, const float* amax, const float* o, const float* d,
+                                     float& tn, float& tf, bool& valid) {
+  tn = -INFINITY; tf = INFINITY;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float inv = tp::div_rn(1.0f, d[a]);
+    const float ta = tp::mul_rn(tp::sub_rn(amin[a], o[a]), inv);
+    const float tb = tp::mul_rn(tp::sub_rn(amax[a], o[a]), inv);
+    // torch.minimum/maximum propagate NaN (0*inf when the origin sits on a slab plane of a parallel ray)
+    const float lo = (ta != ta || tb != tb) ? NAN : fminf(ta, tb);
+    const float hi = (ta != ta || tb != tb) ? NAN : fmaxf(ta, tb);
+    tn = (tn != tn || lo != lo) ? NAN : fmaxf(tn, lo);
+    tf = (tf != tf || hi != hi) ? NAN : fminf(tf, hi);
+  }
+  valid = (tf > 0.0f) && (tf > tn);
+}
+
+__global__ __launch_bounds__(kTile) void raygen_kernel(Args a) {
+  __shared__ float s_near[kTile];
+  __shared__ float s_span[kTile];
+  const int64_t total = (int64_t)a.B * a.R;
+  const int64_t tile0 = (int64_t)blockIdx.x * kTile;
+  const int64_t q = tile0 + threadIdx.x;
+  float near = 0.0f, far = 0.0f;
+  if (q < total) {
+    const int b = (int)(q / a.R);
+    Cam cam;
+    load_cam(a.intr, a.pose, b, cam);
+    float u, v;
+    Bilin bl;
+    int64_t pix = 0;
+    if (a.pixel_mode == TP_PIX_COORDS) {
+      const float x = a.coords[2 * q], y = a.coords[2 * q + 1];
+      bl = bilin_setup(x, y, a.H, a.W);
+      u = bilin_apply(bl, (float)bl.x0, (float)(bl.x0 + 1), (float)bl.x0, (float)(bl.x0 + 1));
+      v = bilin_apply(bl, (float)bl.y0, (float)bl.y0, (float)(bl.y0 + 1), (float)(bl.y0 + 1));
+    } else {
+      pix = a.ray_idx[q];
+      const int row = (int)(pix / a.W), col = (int)(pix - (int64_t)row * a.W);
+      u = (float)col + 0.5f;
+      v = (float)row + 0.5f;
+    }
+    // g = K^-1 [u,v,1];  world = R^T g + tinv;  ray = world - tinv  (camera.py:266-277,308-314)
+    float g[3], o[3], d[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      float acc = tp::mul_rn(u, cam.kinv[j * 3 + 0]);
+      acc = tp::fma_rn(v, cam.kinv[j * 3 + 1], acc);
+      g[j] = tp::add_rn(acc, cam.kinv[j * 3 + 2]);
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      float acc = tp::mul_rn(g[0], cam.rt[j * 3 + 0]);
+      acc = tp::fma_rn(g[1], cam.rt[j * 3 + 1], acc);
+      acc = tp::fma_rn(g[2], cam.rt[j * 3 + 2], acc);
+      const float world = tp::add_rn(acc, cam.tinv[j]);
+      o[j] = cam.tinv[j];
+      d[j] = tp::sub_rn(world, cam.tinv[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      a.center[3 * q + j] = o[j];
+      a.ray[3 * q + j] = d[j];
+    }
+    if (a.bounds_mode == TP_BOUNDS_MAP) {
+      const float* zn = a.z_near + (int64_t)b * a.H * a.W;
+      const float* zf = a.z_far + (int64_t)b * a.H * a.W;
+      if (a.pixel_mode == TP_PIX_COORDS) {
+        near = bilin_map(bl, zn, a.W);
+        far = bilin_map(bl, zf, a.W);
+      } else {
+        near = zn[pix];
+        far = zf[pix];
+      }
+    } else if (a.bounds_mode == TP_BOUNDS_AABB) {
+      float tn, tf; bool ok;
+      slab(a.amin, a.amax, o, d, tn, tf, ok);
+      tn = ok ? tn : 0.0f;
+      tf = ok ? tf : 0.0f;
+      near = tn > 0.0f ? tn : a.bg_near;
+      far = tf > 0.0f ? tf : a.bg_far;
+    }
+    if (a.bounds_mode != TP_BOUNDS_NONE) {
+      if (a.near) a.near[q] = near;
+      if (a.far) a.far[q] = far;
+    }
+  }
+  if (a.depth == nullptr || a.N <= 0 || a.bounds_mode == TP_BOUNDS_NONE) return;
+  s_near[threadIdx.x] = near;
+  s_span[threadIdx.x] = tp::sub_rn(far, near);
+  __syncthreads();
+  const int64_t rays_here = (total - tile0) < kTile ? (total - tile0) : kTile;
+  const int64_t n_el = rays_here * a.N;
+  const int64_t e0 = tile0 * a.N;  // first global element of this tile
+  const float fN = (float)a.N;
+  const uint2 key = make_uint2((uint32_t)a.seed, (uint32_t)(a.seed >> 32));
+  if ((a.N & 3) == 0) {
+    for (int64_t e = (int64_t)threadIdx.x * 4; e < n_el; e += kTile * 4) {
+      const int r = (int)(e / a.N), i = (int)(e - (int64_t)r * a.N);
+      float4 rr = make_float4(0.5f, 0.5f, 0.5f, 0.5f);
+      if (a.jitter_mode == TP_JITTER_GIVEN) {
+        rr = *reinterpret_cast<const float4*>(a.rnd + e0 + e);
+      } else if (a.jitter_mode == TP_JITTER_PHILOX) {
+        const uint64_t cnt = (uint64_t)(e0 + e) >> 2;
+        const uint4 w = philox4x32_10(make_uint4((uint32_t)cnt, (uint32_t)a.offset, (uint32_t)(cnt >> 32),
+                                                 (uint32_t)(a.offset >> 32)), key);
+        rr = make_float4(u01(w.x), u01(w.y), u01(w.z), u01(w.w));
+      }
+      const float nr = s_near[r], sp = s_span[r];
+      float4 z;
+      z.x = strat(rr.x, i + 0, fN, sp, nr);
+      z.y = strat(rr.y, i + 1, fN, sp, nr);
+      z.z = strat(rr.z, i + 2, fN, sp, nr);
+      z.w = strat(rr.w, i + 3, fN, sp, nr);
+      *reinterpret_cast<float4*>(a.depth + e0 + e) = z;
+    }
+  } else {
+    for (int64_t e = threadIdx.x; e < n_el; e += kTile) {
+      const int r = (int)(e / a.N), i = (int)(e - (int64_t)r * a.N);
+      float rr = 0.5f;
+      if (a.jitter_mode == TP_JITTER_GIVEN) {
+        rr = a.rnd[e0 + e];
+      } else if (a.jitter_mode == TP_JITTER_PHILOX) {
+        const uint64_t ge = (uint64_t)(e0 + e), cnt = ge >> 2;
+        const uint4 w = philox4x32_10(make_uint4((uint32_t)cnt, (uint32_t)a.offset, (uint32_t)(cnt >> 32),
+                                                 (uint32_t)(a.offset >> 32)), key);
+        const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
+        rr = u01(ws[ge & 3]);
+      }
+      a.depth[e0 + e] = strat(rr, i, fN, s_span[r], s_near[r]);
+    }
+  }
+}
+
+__global__ void aabb_kernel(float3 lo, float3 hi, const float* __restrict__ o, const float* __restrict__ d, int64_t n,
+                            float* __restrict__ t_near, float* __restrict__ t_far, uint8_t* __restrict__ valid) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float amin[3] = {lo.x, lo.y, lo.z}, amax[3] = {hi.x, hi.y, hi.z};
+  const float oo[3] = {o[3 * i], o[3 * i + 1], o[3 * i + 2]}, dd[3] = {d[3 * i], d[3 * i + 1], d[3 * i + 2]};
+  float tn, tf; bool ok;
+  slab(amin, amax, oo, dd, tn, tf, ok);
+  t_near[i] = tn; t_far[i] = tf; valid[i] = ok ? 1 : 0;
+}
+
+__global__ void sample_depth_kernel(const float* __restrict__ near, const float* __restrict__ far,
+                                    const float* __restrict__ rnd, int jitter, uint64_t seed, uint64_t offset,
+                                    int64_t n, int N, float* __restrict__ depth) {
+  const int64_t total = n * N;
+  const uint2 key = make_uint2((uint32_t)seed, (uint32_t)(seed >> 32));
+  const float fN = (float)N;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = e / N;
+    const int i = (int)(e - r * N);
+    float rr = 0.5f;
+    if (jitter == TP_JITTER_GIVEN) rr = rnd[e];
+    else if (jitter == TP_JITTER_PHILOX) {
+      const uint64_t cnt = (uint64_t)e >> 2;
+      const uint4 w = philox4x32_10(make_uint4((uint32_t)cnt, (uint32_t)offset, (uint32_t)(cnt >> 32),
+                                               (uint32_t)(offset >> 32)), key);
+      const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
+      rr = u01(ws[e & 3]);
+    }
+    const float nr = near[r];
+    depth[e] = strat(rr, i, fN, tp::sub_rn(far[r], nr), nr);
+  }
+}
+
+}  // namespace
+
+extern "C" int tp_raygen(const tp_raygen_args* p, tp_stream_t stream) {
+  TP_REQUIRE(p != nullptr, "null args");
+  TP_REQUIRE(p->B > 0 && p->R > 0 && p->H > 0 && p->W > 0, "bad sizes");
+  TP_REQUIRE(p->intr && p->pose && p->center && p->ray, "null camera / output pointer");
+  TP_REQUIRE(p->pixel_mode == TP_PIX_COORDS ? p->coords != nullptr : p->ray_idx != nullptr, "missing pixel source");
+  TP_REQUIRE(p->bounds_mode != TP_BOUNDS_MAP || (p->z_near && p->z_far), "missing z_near/z_far maps");
+  TP_REQUIRE(p->jitter_mode != TP_JITTER_GIVEN || p->depth == nullptr || p->rand != nullptr, "missing rand tensor");
+  Args a;
+  a.intr = p->intr; a.pose = p->pose; a.coords = p->coords; a.ray_idx = p->ray_idx;
+  a.z_near = p->z_near; a.z_far = p->z_far; a.rnd = p->rand;
+  for (int i = 0; i < 3; ++i) { a.amin[i] = p->aabb_min[i]; a.amax[i] = p->aabb_max[i]; }
+  a.bg_near = p->bg_near; a.bg_far = p->bg_far; a.seed = p->seed; a.offset = p->offset;
+  a.B = p->B; a.R = p->R; a.H = p->H; a.W = p->W; a.N = p->N;
+  a.pixel_mode = p->pixel_mode; a.bounds_mode = p->bounds_mode; a.jitter_mode = p->jitter_mode;
+  a.center = p->center; a.ray = p->ray; a.near = p->near; a.far = p->far; a.depth = p->depth;
+  const int64_t total = (int64_t)p->B * p->R;
+  const int64_t blocks = (total + kTile - 1) / kTile;
+  TP_REQUIRE(blocks < (1ll << 31), "too many rays for one launch");
+  hipLaunchKernelGGL(raygen_kernel, dim3((unsigned)blocks), dim3(kTile), 0, (hipStream_t)stream, a);
+  return tp::check_launch("tp_raygen");
+}
+
+extern "C" int tp_aabb(const float* lo, const float* hi, const float* o, const float* d, int64_t n, float* t_near,
+                       float* t_far, uint8_t* valid, tp_stream_t stream) {
+  TP_REQUIRE(lo && hi && o && d && t_near && t_far && valid, "null pointer");
+  if (n == 0) return 0;
+  const int64_t blocks = (n + 255) / 256;
+  hipLaunchKernelGGL(aabb_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                     make_float3(lo[0], lo[1], lo[2]), make_float3(hi[0], hi[1], hi[2]), o, d, n, t_near, t_far, valid);
+  return tp::check_launch("tp_aabb");
+}
+
+extern "C" int tp_sample_depth(const float* near, const float* far, const float* rnd, int jitter, uint64_t seed,
+                               uint64_t offset, int64_t n, int N, float* depth, tp_stream_t stream) {
+  TP_REQUIRE(near && far && depth && N > 0, "bad arguments");
+  TP_REQUIRE(jitter != TP_JITTER_GIVEN || rnd != nullptr, "missing rand tensor");
+  if (n == 0) return 0;
+  int64_t blocks = (n * N + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(sample_depth_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, near, far, rnd,
+                     jitter, seed, offset, n, N, depth);
+  return tp::check_launch("tp_sample_depth");
+}

@@ -1,0 +1,271 @@
+"""Thin torch-facing wrappers over the C ABI (include/texpose_amd.h).
+
+PyTorch is plumbing here: it owns device memory and the HIP stream; every computation on the hot
+path is a hand-written gfx950 kernel in texpose_amd/csrc reached through ctypes.  All functions
+require CUDA (ROCm) float32 tensors and raise if the library is unavailable -- there is no CPU or
+eager fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import (CompositeArgs, CompositeBwdArgs, MlpFwdArgs, MlpWeights, PatchGatherArgs, RaygenArgs, check)
+
+Tensor = torch.Tensor
+
+PIX_COORDS, PIX_INDEX = 0, 1
+BOUNDS_MAP, BOUNDS_AABB, BOUNDS_NONE = 0, 1, 2
+JITTER_MID, JITTER_GIVEN, JITTER_PHILOX = 0, 1, 2
+PACK_TRUNK, PACK_HEADS, PACK_ALL = 1, 2, 3
+
+COMPOSITE_RAY_FIELDS = (("rgb", 0, 3), ("rgb_static", 3, 6), ("rgb_transient", 6, 9), ("depth", 9, 10),
+                        ("opacity", 10, 11), ("opacity_static", 11, 12), ("opacity_transient", 12, 13),
+                        ("uncert", 13, 14))
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _f32(t: Tensor, name: str) -> Tensor:
+    if not t.is_cuda:
+        raise _lib.TexposeLibraryError(f"{name} must live on the GPU (texpose_amd has no CPU path)")
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def _ptr(t: Optional[Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+# ------------------------------------------------------------------------------------------ K1
+def raygen(intr: Tensor, pose: Tensor, *, H: int, W: int, n_samples: int = 0, coords: Optional[Tensor] = None,
+           ray_idx: Optional[Tensor] = None, z_near: Optional[Tensor] = None, z_far: Optional[Tensor] = None,
+           aabb: Optional[Tuple[Tuple[float, float, float], Tuple[float, float, float]]] = None,
+           bg_range: Tuple[float, float] = (0.0, 30.0), rand: Optional[Tensor] = None,
+           jitter: int = JITTER_MID, seed: int = 0, offset: int = 0):
+    """Fused ray-gen + bounds + stratified depths.  Returns (center, ray, near, far, depth);
+    near/far/depth are None when no bounds source is given, depth is [B,R,N]."""
+    lib = _lib.load()
+    intr, pose = _f32(intr, "intr"), _f32(pose, "pose")
+    B = pose.shape[0]
+    a = RaygenArgs()
+    if coords is not None:
+        coords = _f32(coords, "coords")
+        R = coords.numel() // (2 * B)
+        a.pixel_mode, a.coords = PIX_COORDS, coords.data_ptr()
+    else:
+        ray_idx = ray_idx.to(torch.int64).contiguous()
+        R = ray_idx.numel() // B
+        a.pixel_mode, a.ray_idx = PIX_INDEX, ray_idx.data_ptr()
+    dev = pose.device
+    center = torch.empty(B, R, 3, device=dev)
+    ray = torch.empty(B, R, 3, device=dev)
+    near = far = depth = None
+    if aabb is not None:
+        a.bounds_mode = BOUNDS_AABB
+        a.aabb_min = (C.c_float * 3)(*[float(v) for v in aabb[0]])
+        a.aabb_max = (C.c_float * 3)(*[float(v) for v in aabb[1]])
+        a.bg_near, a.bg_far = float(bg_range[0]), float(bg_range[1])
+    elif z_near is not None:
+        z_near, z_far = _f32(z_near, "z_near"), _f32(z_far, "z_far")
+        assert z_near.numel() == B * H * W and z_far.numel() == B * H * W
+        a.bounds_mode, a.z_near, a.z_far = BOUNDS_MAP, z_near.data_ptr(), z_far.data_ptr()
+    else:
+        a.bounds_mode = BOUNDS_NONE
+    if a.bounds_mode != BOUNDS_NONE:
+        near = torch.empty(B, R, device=dev)
+        far = torch.empty(B, R, device=dev)
+        a.near, a.far = near.data_ptr(), far.data_ptr()
+        if n_samples > 0:
+            depth = torch.empty(B, R, n_samples, device=dev)
+            a.depth = depth.data_ptr()
+    if rand is not None:
+        rand = _f32(rand, "rand")
+        assert rand.numel() == B * R * n_samples
+        jitter = JITTER_GIVEN
+        a.rand = rand.data_ptr()
+    a.jitter_mode, a.seed, a.offset = jitter, seed, offset
+    a.intr, a.pose = intr.data_ptr(), pose.data_ptr()
+    a.B, a.R, a.H, a.W, a.N = B, R, H, W, n_samples
+    a.center, a.ray = center.data_ptr(), ray.data_ptr()
+    check(lib.tp_raygen(C.byref(a), _stream()), "tp_raygen")
+    return center, ray, near, far, depth
+
+
+def aabb_intersect(aabb_min, aabb_max, o: Tensor, d: Tensor):
+    lib = _lib.load()
+    o, d = _f32(o, "ray_o"), _f32(d, "ray_d")
+    n = o.numel() // 3
+    tn = torch.empty(o.shape[:-1], device=o.device)
+    tf = torch.empty_like(tn)
+    ok = torch.empty(o.shape[:-1], device=o.device, dtype=torch.uint8)
+    lo = (C.c_float * 3)(*[float(v) for v in torch.as_tensor(aabb_min).flatten().tolist()])
+    hi = (C.c_float * 3)(*[float(v) for v in torch.as_tensor(aabb_max).flatten().tolist()])
+    check(lib.tp_aabb(lo, hi, o.data_ptr(), d.data_ptr(), n, tn.data_ptr(), tf.data_ptr(), ok.data_ptr(), _stream()),
+          "tp_aabb")
+    return tn, tf, ok.bool()
+
+
+def sample_depth(near: Tensor, far: Tensor, n_samples: int, rand: Optional[Tensor] = None, jitter: int = JITTER_MID,
+                 seed: int = 0, offset: int = 0) -> Tensor:
+    lib = _lib.load()
+    near, far = _f32(near, "near"), _f32(far, "far")
+    if rand is not None:
+        rand, jitter = _f32(rand, "rand"), JITTER_GIVEN
+    depth = torch.empty(*near.shape, n_samples, device=near.device)
+    check(lib.tp_sample_depth(near.data_ptr(), far.data_ptr(), _ptr(rand), jitter, seed, offset, near.numel(),
+                              n_samples, depth.data_ptr(), _stream()), "tp_sample_depth")
+    return depth
+
+
+# ------------------------------------------------------------------------------------------ K2
+def packed_bytes() -> int:
+    return int(_lib.load().tp_mlp_packed_bytes())
+
+
+def pack_weights(state: Dict[str, Tensor], packed: Optional[Tensor] = None, parts: int = PACK_ALL,
+                 prefix: str = "") -> Tensor:
+    """state: reference state-dict style mapping (``mlp_feat.0.weight`` ...) of CUDA tensors."""
+    lib = _lib.load()
+    w = MlpWeights()
+    keep = []
+
+    def put(arr_w, arr_b, name, n):
+        for i in range(n):
+            wt, bt = _f32(state[f"{prefix}{name}.{i}.weight"], name), _f32(state[f"{prefix}{name}.{i}.bias"], name)
+            keep.extend((wt, bt))
+            arr_w[i], arr_b[i] = wt.data_ptr(), bt.data_ptr()
+
+    if parts & PACK_TRUNK:
+        put(w.feat_w, w.feat_b, "mlp_feat", 8)
+    if parts & PACK_HEADS:
+        put(w.rgb_w, w.rgb_b, "mlp_rgb", 4)
+        put(w.trans_w, w.trans_b, "mlp_trans", 4)
+    dev = keep[0].device
+    if packed is None:
+        packed = torch.empty(packed_bytes() // 4, device=dev)
+    check(lib.tp_mlp_pack(C.byref(w), parts, packed.data_ptr(), _stream()), "tp_mlp_pack")
+    return packed
+
+
+_workspaces: Dict[Tuple[int, int], Tensor] = {}
+
+
+def _workspace(n_samples: int, dev: torch.device) -> Tensor:
+    need = int(_lib.load().tp_mlp_workspace_bytes(n_samples)) // 4
+    key = (dev.index or 0, torch.cuda.current_stream().cuda_stream)
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, device=dev)
+        _workspaces[key] = ws
+    return ws
+
+
+def mlp_forward(packed: Tensor, lat_trans: Tensor, lat_light: Tensor, *, center: Optional[Tensor] = None,
+                ray: Optional[Tensor] = None, depth: Optional[Tensor] = None, points: Optional[Tensor] = None,
+                ray_unit: Optional[Tensor] = None, save: bool = False):
+    """Returns rgb [B,R,N,3,2], density [B,R,N,2], uncert [B,R,N,1] (+ saved activations if save)."""
+    lib = _lib.load()
+    a = MlpFwdArgs()
+    if center is not None:
+        center, ray, depth = _f32(center, "center"), _f32(ray, "ray"), _f32(depth, "depth")
+        B, R = center.shape[0], center.shape[1]
+        N = depth.numel() // (B * R)
+        a.center, a.ray, a.depth = center.data_ptr(), ray.data_ptr(), depth.data_ptr()
+    else:
+        points, ray_unit = _f32(points, "points"), _f32(ray_unit, "ray_unit")
+        B, R, N = points.shape[0], points.shape[1], points.shape[2]
+        a.points, a.ray_unit = points.data_ptr(), ray_unit.data_ptr()
+    lat_trans, lat_light = _f32(lat_trans, "lat_trans"), _f32(lat_light, "lat_light")
+    assert lat_trans.shape == (B, 16) and lat_light.shape == (B, 48), (lat_trans.shape, lat_light.shape)
+    dev = lat_trans.device
+    S = B * R * N
+    rgb = torch.empty(B, R, N, 3, 2, device=dev)
+    density = torch.empty(B, R, N, 2, device=dev)
+    uncert = torch.empty(B, R, N, 1, device=dev)
+    saved = torch.empty(int(lib.tp_mlp_saved_bytes(S)) // 4, device=dev) if save else None
+    ws = _workspace(S, dev)
+    a.packed, a.lat_trans, a.lat_light = packed.data_ptr(), lat_trans.data_ptr(), lat_light.data_ptr()
+    a.B, a.R, a.N = B, R, N
+    a.rgb, a.density, a.uncert = rgb.data_ptr(), density.data_ptr(), uncert.data_ptr()
+    a.saved, a.workspace = _ptr(saved), ws.data_ptr()
+    check(lib.tp_mlp_fwd(C.byref(a), _stream()), "tp_mlp_fwd")
+    return (rgb, density, uncert, saved) if save else (rgb, density, uncert)
+
+
+def posenc(x: Tensor, L: int) -> Tensor:
+    lib = _lib.load()
+    x = _f32(x, "x")
+    Cn = x.shape[-1]
+    out = torch.empty(*x.shape[:-1], 2 * Cn * L, device=x.device)
+    check(lib.tp_posenc(x.data_ptr(), x.numel() // Cn, Cn, L, out.data_ptr(), _stream()), "tp_posenc")
+    return out
+
+
+# ------------------------------------------------------------------------------------------ K4
+def _composite_args(ray, rgb, density, depth, uncert, min_uncert) -> Tuple[CompositeArgs, tuple]:
+    ray, rgb, density = _f32(ray, "ray"), _f32(rgb, "rgb_samples"), _f32(density, "density_samples")
+    depth, uncert = _f32(depth, "depth_samples"), _f32(uncert, "uncert_samples")
+    n = ray.numel() // 3
+    N = depth.numel() // n
+    a = CompositeArgs()
+    a.ray, a.rgb, a.density, a.depth, a.uncert = (ray.data_ptr(), rgb.data_ptr(), density.data_ptr(),
+                                                  depth.data_ptr(), uncert.data_ptr())
+    a.n, a.N, a.min_uncert = n, N, float(min_uncert)
+    return a, (ray, rgb, density, depth, uncert)
+
+
+def composite_fwd(ray, rgb, density, depth, uncert, min_uncert: float = 0.05, per_sample: bool = True,
+                  want_prob: bool = True):
+    """-> out_ray [..,14], alpha_static, alpha_transient, prob ([..,N] or None)."""
+    lib = _lib.load()
+    a, keep = _composite_args(ray, rgb, density, depth, uncert, min_uncert)
+    lead = keep[0].shape[:-1]
+    dev = keep[0].device
+    out = torch.empty(*lead, 14, device=dev)
+    a_s = torch.empty(*lead, a.N, device=dev) if per_sample else None
+    a_t = torch.empty(*lead, a.N, device=dev) if per_sample else None
+    prob = torch.empty(*lead, a.N, device=dev) if want_prob else None
+    a.out_ray, a.alpha_static, a.alpha_transient, a.prob = out.data_ptr(), _ptr(a_s), _ptr(a_t), _ptr(prob)
+    check(lib.tp_composite_fwd(C.byref(a), _stream()), "tp_composite_fwd")
+    return out, a_s, a_t, prob
+
+
+def composite_bwd(ray, rgb, density, depth, uncert, g_out: Tensor, g_alpha_s: Optional[Tensor] = None,
+                  g_alpha_t: Optional[Tensor] = None, g_prob: Optional[Tensor] = None, min_uncert: float = 0.05):
+    lib = _lib.load()
+    b = CompositeBwdArgs()
+    fa, keep = _composite_args(ray, rgb, density, depth, uncert, min_uncert)
+    b.fwd = fa
+    g_out = _f32(g_out, "g_out")
+    opt = [None if g is None else _f32(g, "g") for g in (g_alpha_s, g_alpha_t, g_prob)]
+    g_rgb, g_den, g_unc = torch.empty_like(keep[1]), torch.empty_like(keep[2]), torch.empty_like(keep[4])
+    b.g_out_ray = g_out.data_ptr()
+    b.g_alpha_static, b.g_alpha_transient, b.g_prob = _ptr(opt[0]), _ptr(opt[1]), _ptr(opt[2])
+    b.g_rgb, b.g_density, b.g_uncert = g_rgb.data_ptr(), g_den.data_ptr(), g_unc.data_ptr()
+    check(lib.tp_composite_bwd(C.byref(b), _stream()), "tp_composite_bwd")
+    return g_rgb, g_den, g_unc
+
+
+# ------------------------------------------------------------------------------------------ K5
+def patch_gather(coords: Tensor, image: Tensor, image_syn: Tensor, nocs: Tensor, normal: Tensor, obj_mask: Tensor,
+                 mask_syn: Tensor) -> Tensor:
+    """-> [B,14,p,p]: image3, image_syn3, nocs3*mask_syn, normal3*mask_syn, mask, mask_syn."""
+    lib = _lib.load()
+    coords = _f32(coords, "coords")
+    B, ph, pw, _ = coords.shape
+    ts = [_f32(t, "image") for t in (image, image_syn, nocs, normal, obj_mask, mask_syn)]
+    H, W = ts[0].shape[-2:]
+    out = torch.empty(B, 14, ph, pw, device=coords.device)
+    a = PatchGatherArgs()
+    a.coords = coords.data_ptr()
+    a.image, a.image_syn, a.nocs, a.normal, a.obj_mask, a.mask_syn = [t.data_ptr() for t in ts]
+    a.B, a.P, a.H, a.W, a.out = B, ph * pw, H, W, out.data_ptr()
+    check(lib.tp_patch_gather(C.byref(a), _stream()), "tp_patch_gather")
+    return out
