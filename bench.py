@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""Headline benchmark: rendered rays/s of the ray-marching hot path at 480x640 x 128 samples.
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+
+A step = one pass of the hot path over one full 480x640 image per GPU through the product API
+(Graph.render_by_slices, mode='val': fused ray-gen + bounds + stratified samples -> fused
+posenc + static/transient/light MLP -> per-ray composite), synthetic Duck-like scene, inputs
+resident in HBM.  Images shard by batch across GPUs (weak scaling, no data-path collective: rays
+are independent).  Rank 0 prints ONE JSON line with the contract fields plus
+  roofline     : the dominant kernel (fused MLP, MFMA-bound), algorithmic FLOP / HIP-event time
+  cpu_baseline : the CPU oracle ("port" of the reference path) timed on this box's host cores on a
+                 bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+H, W, N_SAMPLES = 480, 640, 128
+MLP_FLOP_PER_SAMPLE = 1_821_184          # 2 x 910,592 MAC
+FP32_MFMA_PEAK_TFLOPS = 157.3            # MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
+
+
+def build_scene(device, seed):
+    from oracle import texpose_oracle as O          # only the synthetic-scene recipe + weight recipe (data, not compute)
+    sc = O.synthetic_scene(H, W, B=1, seed=seed)
+    params = O.make_params(0, bias_scale=0.0)
+    rs = np.random.RandomState(1)
+    emb_t = torch.from_numpy(rs.normal(size=(189, 16)).astype(np.float32))
+    emb_l = torch.from_numpy(rs.normal(size=(189, 48)).astype(np.float32))
+    return sc, params, emb_t, emb_l
+
+
+def make_graph(device, params, emb_t, emb_l):
+    from texpose_amd.graph import Graph
+    from texpose_amd.options import default_options
+    opt = default_options(H=H, W=W, device=str(device))
+    opt.nerf.sample_intvs = N_SAMPLES
+    opt.batch_size = 1
+    g = Graph(opt).to(device)
+    g.nerf.load_state_dict({**g.nerf.state_dict(), **{k: v.to(device) for k, v in params.items()}})
+    g.attach_latents(189, opt)
+    with torch.no_grad():
+        g.latent_vars_trans.weight.copy_(emb_t)
+        g.latent_vars_light.weight.copy_(emb_l)
+    g.eval()
+    return g, opt
+
+
+def cpu_baseline(sc, params, emb_t, emb_l, budget_s=20.0, chunk=2048):
+    """CPU oracle (plain PyTorch restatement of the reference path) on 2048-ray chunks of the same image."""
+    from oracle import texpose_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    dr = (sc["z_near"][:, :, None], sc["z_far"][:, :, None])
+    centre_row = (H // 2) * W
+    done, t_used, n_chunks = 0, 0.0, 0
+    with torch.no_grad():
+        for i in range(64):
+            idx = torch.arange(centre_row + i * chunk, centre_row + (i + 1) * chunk)[None] % (H * W)
+            rand = torch.rand(1, chunk, N_SAMPLES, 1)
+            t0 = time.perf_counter()
+            O.render(params, emb_t, emb_l, sc["pose"], sc["intr"], idx, dr, None, "val", H, W, N_SAMPLES, rand=rand)
+            dt = time.perf_counter() - t0
+            if i == 0:
+                continue                      # warm-up chunk
+            done += chunk
+            t_used += dt
+            n_chunks += 1
+            if t_used > budget_s:
+                break
+    return dict(value=done / t_used, unit="rays/s", cores=cores, kind="port",
+                sample="%d chunks of %d rays x %d samples of the 480x640 image, torch %s CPU fp32, %d threads"
+                       % (n_chunks, chunk, N_SAMPLES, torch.__version__, cores))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..."
+                         % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+
+    sc, params, emb_t, emb_l = build_scene(device, seed=rank)       # one image per rank
+    graph, opt = make_graph(device, params, emb_t, emb_l)
+    pose, intr = sc["pose"].to(device), sc["intr"].to(device)
+    dr = (sc["z_near"].to(device)[:, :, None], sc["z_far"].to(device)[:, :, None])
+    mask = torch.ones(1, H, W, device=device)
+
+    # time the dominant kernel with HIP events on the stream it is launched on
+    from texpose_amd import ops
+    mlp_events = []
+    orig_mlp = ops.mlp_forward
+
+    def timed_mlp(*a, **k):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = orig_mlp(*a, **k)
+        e1.record()
+        mlp_events.append((e0, e1))
+        return out
+
+    def step():
+        with torch.no_grad():
+            return graph.render_by_slices(opt, pose, intr=intr, depth_range=dr, object_mask=mask, sample_idx=None,
+                                          mode="val")
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        ret = step()
+    ops.mlp_forward = timed_mlp
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ret = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    ops.mlp_forward = orig_mlp
+    assert torch.isfinite(ret.rgb).all() and ret.rgb.shape == (1, H * W, 3)
+
+    t = torch.tensor([dt], device=device, dtype=torch.float64)
+    if world > 1:
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    dt = float(t.item())
+    mlp_ms = float(np.mean([a.elapsed_time(b) for a, b in mlp_events]))
+    launches_per_step = len(mlp_events) / args.steps
+    samples_per_launch = H * W * N_SAMPLES / launches_per_step
+
+    if rank == 0:
+        achieved = MLP_FLOP_PER_SAMPLE * samples_per_launch / (mlp_ms * 1e-3) / 1e12
+        line = {
+            "metric": "rendered rays/sec (480x640x128 samples)",
+            "value": world * H * W * args.steps / dt,
+            "unit": "rays/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "Duck-like synthetic scene 480x640, 128 samples/ray, batch=1 image per GPU, "
+                                   "forward render (render_by_slices mode='val', all pixels), per-sample outputs "
+                                   "materialised", "rays_per_step_per_gpu": H * W, "samples_per_ray": N_SAMPLES,
+                       "parallelism": "images sharded across %d GPU(s), no collective" % world},
+            "roofline": {"kernel": "mlp_fwd_kernel", "bound": "mfma", "achieved": achieved,
+                         "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
+                         "traffic": None, "kernel_ms": mlp_ms, "samples_per_launch": samples_per_launch,
+                         "flop_per_sample": MLP_FLOP_PER_SAMPLE},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(sc, params, emb_t, emb_l)
+            line["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]
+        print(json.dumps(line))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

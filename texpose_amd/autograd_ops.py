@@ -1,0 +1,64 @@
+"""torch.autograd glue between the module API and the HIP kernels.
+
+Gradient topology follows the reference: the trunk runs under no_grad
+(layers/nerf_static_transient_light.py:87-100), so only mlp_rgb / mlp_trans parameters and the two
+latent rows receive gradients; sample positions and view directions come from the no_grad ray
+sampler and get none.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+
+
+class _Composite(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ray, rgb, density, depth, uncert, min_uncert):
+        out, a_s, a_t, prob = ops.composite_fwd(ray, rgb, density, depth, uncert, min_uncert)
+        ctx.save_for_backward(ray, rgb, density, depth, uncert)
+        ctx.min_uncert = min_uncert
+        return out, a_s, a_t, prob
+
+    @staticmethod
+    def backward(ctx, g_out, g_as, g_at, g_prob):
+        ray, rgb, density, depth, uncert = ctx.saved_tensors
+        if g_out is None:
+            g_out = torch.zeros(*ray.shape[:-1], 14, device=ray.device)
+        g_rgb, g_den, g_unc = ops.composite_bwd(ray, rgb, density, depth, uncert, g_out, g_as, g_at, g_prob,
+                                                ctx.min_uncert)
+        return None, g_rgb, g_den, g_unc.view_as(uncert), None, None
+
+
+def composite(ray, rgb, density, depth, uncert, min_uncert):
+    return _Composite.apply(ray, rgb, density, depth, uncert, float(min_uncert))
+
+
+class _Mlp(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, nerf, lat_trans, lat_light, center, ray, depth, points, ray_unit, *head_params):
+        need_grad = torch.is_grad_enabled() and (any(p.requires_grad for p in head_params)
+                                                 or lat_trans.requires_grad or lat_light.requires_grad)
+        packed = nerf.packed_weights()
+        res = ops.mlp_forward(packed, lat_trans, lat_light, center=center, ray=ray, depth=depth, points=points,
+                              ray_unit=ray_unit, save=need_grad)
+        if need_grad:
+            rgb, density, uncert, saved = res
+            ctx.nerf = nerf
+            ctx.geom = (center, ray, depth, points, ray_unit)
+            ctx.save_for_backward(lat_trans, lat_light, saved, rgb, density, uncert)
+        else:
+            rgb, density, uncert = res
+        return rgb, density, uncert
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_density, g_uncert):
+        lat_trans, lat_light, saved, rgb, density, uncert = ctx.saved_tensors
+        grads = ops.mlp_backward(ctx.nerf, lat_trans, lat_light, ctx.geom, saved, rgb, density, uncert, g_rgb,
+                                 g_density, g_uncert)
+        return (None, grads["lat_trans"], grads["lat_light"], None, None, None, None, None) + tuple(grads["params"])
+
+
+def mlp(nerf, lat_trans, lat_light, center=None, ray=None, depth=None, points=None, ray_unit=None):
+    head_params = [p for k, p in nerf.named_parameters() if k.startswith(("mlp_rgb", "mlp_trans"))]
+    return _Mlp.apply(nerf, lat_trans, lat_light, center, ray, depth, points, ray_unit, *head_params)

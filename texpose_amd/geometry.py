@@ -1,0 +1,154 @@
+"""Camera / ray helpers of the hot path, mirroring the call signatures of the reference's
+camera.py (:292-322, :345-350, :415-440) and tools/ray_sampler.py (:13-69) on top of the HIP kernels.
+
+Only what Graph.render needs is here; the reference's Lie / quaternion / NDC / Procrustes utilities
+are unused by the adapt_st_gan path and are out of scope.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from . import ops
+
+
+# ----------------------------------------------------------------------------- rigid transforms
+def make_pose(R=None, t=None):
+    """[R|t] as a [...,3,4] tensor; either part may be omitted (identity / zero)."""
+    if R is None and t is None:
+        raise ValueError("make_pose needs R and/or t")
+    if R is None:
+        t = torch.as_tensor(t, dtype=torch.float32)
+        R = torch.eye(3, device=t.device).expand(*t.shape[:-1], 3, 3)
+    R = torch.as_tensor(R, dtype=torch.float32)
+    t = torch.zeros(R.shape[:-1], device=R.device) if t is None else torch.as_tensor(t, dtype=torch.float32)
+    if R.shape[-2:] != (3, 3) or R.shape[:-1] != t.shape:
+        raise ValueError(f"bad pose parts {tuple(R.shape)} / {tuple(t.shape)}")
+    return torch.cat([R, t.unsqueeze(-1)], dim=-1)
+
+
+def invert_pose(p):
+    """Inverse of a rigid [R|t]: [R^T | -R^T t] (what the reference's cam2world applies, camera.py:38-44)."""
+    Rt = p[..., :3].transpose(-1, -2)
+    return make_pose(Rt, (-Rt @ p[..., 3:]).squeeze(-1))
+
+
+def compose_poses(*poses):
+    """x -> p_n(...p_2(p_1(x)))."""
+    out = poses[0]
+    for nxt in poses[1:]:
+        out = make_pose(nxt[..., :3] @ out[..., :3], (nxt[..., :3] @ out[..., 3:] + nxt[..., 3:]).squeeze(-1))
+    return out
+
+
+def rotation_distance(R1, R2, eps=1e-7):
+    """Geodesic angle between rotation matrices; evaluate_full uses it to pick the light latent of the
+    nearest training view (reference camera.py:345-350, model/nerf_adapt_st_gan.py:489-494)."""
+    cos = ((R1 @ R2.transpose(-2, -1)).diagonal(dim1=-2, dim2=-1).sum(-1) - 1) / 2
+    return torch.acos(cos.clamp(-1 + eps, 1 - eps))
+
+
+# ----------------------------------------------------------------------------- rays
+def get_center_and_ray(opt, pose, intr=None, H=None, W=None):
+    """Every pixel-centre ray of an H x W image -> center, ray [B,HW,3] (reference camera.py:292-314)."""
+    if opt.camera.model != "perspective":
+        raise NotImplementedError(opt.camera.model)
+    hh, ww = (opt.H, opt.W) if H is None and W is None else (H, W)
+    every = torch.arange(hh * ww, device=pose.device).expand(len(pose), -1).contiguous()
+    center, ray, _, _, _ = ops.raygen(intr, pose, H=hh, W=ww, ray_idx=every)
+    return center, ray
+
+
+def get_3D_points_from_depth(opt, center, ray, depth, multi_samples=False):
+    """c + d z (reference camera.py:317-322).  Graph.render never calls this: the sample positions are
+    formed inside the fused MLP kernel.  Kept as a one-line torch expression for callers that want points."""
+    if multi_samples:
+        center, ray = center.unsqueeze(2), ray.unsqueeze(2)
+    return center + ray * depth
+
+
+def aabb_ray_intersection(aabb_min, aabb_max, ray_o, ray_d):
+    """Slab test (reference camera.py:415-433) -> t_near, t_far [B,HW], valid [B,HW] bool."""
+    return ops.aabb_intersect(aabb_min, aabb_max, ray_o, ray_d)
+
+
+def enlarge_diagonal(aabb_min, aabb_max, alpha=0.25):
+    """Grow a box by alpha of its diagonal, half on each side (reference camera.py:436-440)."""
+    pad = (aabb_max - aabb_min) * (alpha / 2)
+    return aabb_min - pad, aabb_max + pad
+
+
+class RaySampler:
+    """Train-mode ray source (reference tools/ray_sampler.py): continuous patch coordinates in [-1,1]
+    -> rays, bilinear near/far bounds, bilinear image taps.  All three are static in the reference."""
+
+    def __init__(self, opt=None, intrinsics=None):
+        self.intrinsics = intrinsics
+
+    @staticmethod
+    def _size(opt, H, W):
+        return (opt.H, opt.W) if H is None and W is None else (H, W)
+
+    @staticmethod
+    def get_rays(opt, intrinsics, coords, pose, H=None, W=None):
+        hh, ww = RaySampler._size(opt, H, W)
+        center, ray, _, _, _ = ops.raygen(intrinsics, pose, H=hh, W=ww, coords=coords)
+        return center.view(*coords.shape[:3], 3), ray.view(*coords.shape[:3], 3)
+
+    @staticmethod
+    def get_bounds(opt, coords, z_near, z_far, H=None, W=None):
+        hh, ww = RaySampler._size(opt, H, W)
+        B = coords.shape[0]
+        # the bounds lookup does not depend on the camera: run the fused kernel with an identity one
+        k = torch.eye(3, device=coords.device).expand(B, 3, 3)
+        p = torch.eye(3, 4, device=coords.device).expand(B, 3, 4)
+        _, _, near, far, _ = ops.raygen(k, p, H=hh, W=ww, coords=coords, z_near=z_near, z_far=z_far)
+        return near.view(coords.shape[:3]), far.view(coords.shape[:3])
+
+    @staticmethod
+    def get_image(opt, coords, image, H=None, W=None):
+        if image.shape[1] != 3:
+            raise NotImplementedError("get_image gathers 3-channel images")
+        blank = image.new_zeros(image.shape[0], *image.shape[-2:])
+        return ops.patch_gather(coords, image, image, image, image, blank, blank)[:, :3]
+
+
+# ----------------------------------------------------------------------------- patch coordinates
+class FlexPatchSampler:
+    """Random-scale / random-shift p x p coordinate grids (reference tools/patch_sampler.py:64-114).
+
+    Per image: s ~ U[lo, hi) with lo annealed as min(0.8, max(min_scale, hi * exp(-it * anneal))), then the
+    [-1,1] lattice is scaled by s and shifted by U[-1,1) * (1 - s) per axis.  Returns (coords [B,p,p,2]
+    in grid_sample (x, y) order, scales [B,1,1,1]).  Host-side torch plumbing: 3 B random numbers.
+    """
+
+    def __init__(self, random_shift=True, random_scale=True, min_scale=0.25, max_scale=1., scale_anneal=-1):
+        self.random_shift, self.random_scale = random_shift, random_scale
+        self.min_scale, self.max_scale, self.scale_anneal = min_scale, max_scale, scale_anneal
+        self.iterations = 0
+        self.scales_curr = (min_scale, max_scale)
+        self.full_indices = False
+
+    def scale_range(self):
+        lo = self.min_scale
+        if self.scale_anneal > 0:
+            lo = min(0.8, max(lo, self.max_scale * math.exp(-self.iterations * self.scale_anneal)))
+        return lo, self.max_scale
+
+    def __call__(self, nbatch, patch_size, device="cuda", u=None):
+        """``u`` ([3,B,1,1,1] uniforms: scale, x-shift, y-shift) replaces the internal draw in parity tests."""
+        lo, hi = self.scales_curr = self.scale_range()
+        if u is None:
+            u = torch.rand(3, nbatch, 1, 1, 1, device=device)
+        s = u[0] * (hi - lo) + lo if self.random_scale else torch.full((nbatch, 1, 1, 1), lo, device=device)
+        lattice = torch.linspace(-1, 1, patch_size, device=device)
+        xs = lattice.view(1, 1, patch_size, 1) * s          # varies along the patch width  -> grid x
+        ys = lattice.view(1, patch_size, 1, 1) * s          # varies along the patch height -> grid y
+        if self.random_shift:
+            room = 1 - s
+            xs = xs + (u[1] * 2.0 - 1.0) * room
+            ys = ys + (u[2] * 2.0 - 1.0) * room
+        coords = torch.cat([xs.expand(nbatch, patch_size, patch_size, 1), ys.expand(nbatch, patch_size, patch_size, 1)],
+                           dim=-1)
+        return coords.contiguous(), s.contiguous()

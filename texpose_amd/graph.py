@@ -1,0 +1,324 @@
+"""Graph mirror: the reference's model/nerf_adapt_st_gan.py:412-835 computation graph for the
+ray-marching path, with the same method names / signatures / returned keys, on the HIP kernels.
+
+What differs by design (documented in DESIGN.md):
+  * eval rays are generated only for the requested pixels (the reference builds all H*W rays per
+    2048-ray chunk and gathers, :573-579), and render_by_slices may use larger slices than
+    nerf.rand_rays since results do not depend on the slice size;
+  * ray-gen + bounds + stratified samples are one kernel, positions + encodings + 16 layers another,
+    the composite a third; per-sample intermediates other than the 9 MLP outputs never reach HBM;
+  * the NaN-retry host syncs (:554,569) are gone (the kernels produce NaN only from NaN inputs);
+  * stratified jitter comes from an in-kernel Philox stream seeded from torch's seed (the reference's
+    own CPU and CUDA torch.rand streams already differ); ``rand=`` injects a tensor for parity tests.
+The discriminator / perceptual / Lab modules are the reference's stock PyTorch modules and are
+injected, not re-implemented.
+"""
+from __future__ import annotations
+
+import itertools
+
+import torch
+import torch.nn.functional as torch_F
+
+from . import ops
+from .geometry import FlexPatchSampler, RaySampler, rotation_distance
+from .nerf import NeRF
+from .options import AttrDict as edict
+
+RENDER_KEYS = ("rgb", "rgb_static", "rgb_transient", "opacity", "opacity_static", "opacity_transient", "uncert",
+               "depth", "alpha_static", "alpha_transient", "density")
+
+_philox_calls = itertools.count()
+
+
+class Graph(torch.nn.Module):
+
+    def __init__(self, opt, discriminator=None, perceptual_loss=None, lab_loss=None):
+        super().__init__()
+        self.nerf = NeRF(opt)
+        if discriminator is not None:
+            self.discriminator = discriminator
+        if perceptual_loss is not None:
+            self.perceptual_loss = perceptual_loss
+        self.lab_loss = lab_loss
+        self.ray_sampler = RaySampler(opt)
+        # the reference passes `opt` into the random_shift slot (:424); truthy => default behaviour
+        self.patch_sampler = FlexPatchSampler(True, scale_anneal=0.0002)
+
+    def attach_latents(self, n_train, opt):
+        """Per-image appearance embeddings (Model.build_networks, reference :56-59)."""
+        self.latent_vars_trans = torch.nn.Embedding(n_train, opt.nerf.N_latent_trans).to(opt.device)
+        self.latent_vars_light = torch.nn.Embedding(n_train, opt.nerf.N_latent_light).to(opt.device)
+        torch.nn.init.normal_(self.latent_vars_trans.weight)
+        torch.nn.init.normal_(self.latent_vars_light.weight)
+
+    # ------------------------------------------------------------------ ray / sample selection
+    def get_ray_idx(self, opt, var):
+        var.ray_idx, var.ray_scales = self.patch_sampler(nbatch=opt.batch_size, patch_size=opt.patch_size,
+                                                         device=opt.device)
+        return var
+
+    @staticmethod
+    def get_pose(opt, var, mode=None):
+        if mode == "train":
+            return dict(gt=var.pose, predicted=var.pose_init)[opt.data.pose_source]
+        return var.pose
+
+    @staticmethod
+    def _jitter(opt, rand):
+        if rand is not None:
+            return dict(rand=rand)
+        if opt.nerf.sample_stratified:
+            return dict(jitter=ops.JITTER_PHILOX, seed=torch.initial_seed() & (2 ** 64 - 1), offset=next(_philox_calls))
+        return dict(jitter=ops.JITTER_MID)
+
+    @staticmethod
+    def sample_depth(opt, batch_size, depth_range, num_rays=None, rand=None):
+        """(near, far) [B,R] -> stratified depths [B,R,N,1] (reference :683-700)."""
+        if opt.nerf.depth.param != "metric":
+            raise NotImplementedError("nerf.depth.param=%r (the reference config uses 'metric')" % opt.nerf.depth.param)
+        near, far = depth_range
+        return ops.sample_depth(near, far, opt.nerf.sample_intvs, **Graph._jitter(opt, rand))[..., None]
+
+    @staticmethod
+    def ray_batch_sample(ray_identity, ray_idx):
+        """[B,HW,C] rows at ray_idx [B,R] (reference :702-710)."""
+        assert ray_identity.shape[0] == ray_idx.shape[0]
+        C = ray_identity.shape[-1]
+        return torch.gather(ray_identity, 1, ray_idx[..., None].expand(-1, -1, C))
+
+    # ------------------------------------------------------------------ rendering (the hot path)
+    def render(self, opt, pose, intr=None, ray_idx=None, depth_range=None, sample_idx=None, mode=None, rand=None):
+        if opt.camera.ndc:
+            raise NotImplementedError("camera.ndc (false in the reference config)")
+        if opt.nerf.depth.param != "metric":
+            raise NotImplementedError("nerf.depth.param != 'metric'")
+        N = opt.nerf.sample_intvs
+        z_near, z_far = depth_range
+        batch_size = len(pose)
+        src = dict(coords=ray_idx) if mode == "train" else dict(ray_idx=ray_idx)
+        center, ray, _, _, depth = ops.raygen(intr, pose, H=opt.H, W=opt.W, n_samples=N, z_near=z_near, z_far=z_far,
+                                              **src, **self._jitter(opt, rand))
+        depth_samples = depth[..., None]                                     # [B,R,N,1]
+        if mode == "train":
+            lat_t = self.latent_vars_trans.weight[sample_idx]
+            lat_l = self.latent_vars_light.weight[sample_idx]
+        elif mode == "val":
+            lat_t = self.latent_vars_trans.weight[0][None]
+            lat_l = self.latent_vars_light.weight[0][None]
+        else:
+            if opt.render.transient == "zero":
+                lat_t = torch.zeros(batch_size, opt.nerf.N_latent_trans, device=pose.device)
+            elif opt.render.transient == "sample":
+                lat_t = self.latent_vars_trans.weight[sample_idx][None]
+            else:
+                raise NotImplementedError
+            lat_l = self.latent_vars_light.weight[sample_idx][None]
+        rgb_s, density_s, uncert_s = self.nerf.forward_samples(opt, center=center, ray=ray, depth_samples=depth_samples,
+                                                               latent_variable_trans=lat_t, latent_variable_light=lat_l,
+                                                               mode=mode)
+        (rgb, rgb_static, rgb_transient, depth_map, opacity, opacity_static, opacity_transient, _prob, uncert,
+         alpha_static, alpha_transient) = self.nerf.composite(opt, ray, rgb_s, density_s, depth_samples, uncert_s)
+        return edict(rgb=rgb, rgb_static=rgb_static, rgb_transient=rgb_transient, opacity=opacity,
+                     opacity_static=opacity_static, opacity_transient=opacity_transient, uncert=uncert,
+                     depth=depth_map, alpha_static=alpha_static, alpha_transient=alpha_transient, density=density_s)
+
+    @staticmethod
+    def _slice_rays(opt):
+        # result-invariant chunk size: at least the reference's rand_rays, by default a whole image per launch
+        return int(opt.nerf.get("slice_rays") or max(opt.nerf.rand_rays, min(opt.H * opt.W, 1 << 20)))
+
+    def render_by_slices(self, opt, pose, intr=None, depth_range=None, object_mask=None, sample_idx=None, mode=None):
+        HW = opt.H * opt.W
+        step = self._slice_rays(opt)
+        if mode == "val":
+            parts = {k: [] for k in RENDER_KEYS}
+            for c in range(0, HW, step):
+                idx = torch.arange(c, min(c + step, HW), device=pose.device)[None]
+                ret = self.render(opt, pose, intr=intr, ray_idx=idx, depth_range=depth_range, sample_idx=sample_idx,
+                                  mode=mode)
+                for k in RENDER_KEYS:
+                    parts[k].append(ret[k])
+            return edict({k: (v[0] if len(v) == 1 else torch.cat(v, dim=1)) for k, v in parts.items()})
+        # eval: only object pixels are rendered and scattered into default-filled maps (reference :652-680; B == 1)
+        dev, N = pose.device, opt.nerf.sample_intvs
+        obj = (object_mask.reshape(HW) > 0).nonzero(as_tuple=True)[0]
+        out = edict()
+        for k in RENDER_KEYS:
+            if k == "uncert":
+                out[k] = torch.full((1, HW, 1), float(opt.nerf.min_uncert), device=dev)
+            elif k == "density":
+                out[k] = torch.ones(1, HW, N, 2, device=dev)
+            elif "rgb" in k:
+                out[k] = torch.zeros(1, HW, 3, device=dev)
+            elif "alpha" in k:
+                out[k] = torch.ones(1, HW, N, device=dev)
+            else:
+                out[k] = torch.zeros(1, HW, 1, device=dev)
+        for c in range(0, len(obj), step):
+            idx = obj[c:c + step][None]
+            ret = self.render(opt, pose, intr=intr, ray_idx=idx, depth_range=depth_range, sample_idx=sample_idx,
+                              mode=mode)
+            for k in RENDER_KEYS:
+                out[k][:, idx[0]] = ret[k][0]
+        return out
+
+    # ------------------------------------------------------------------ consumers of render()
+    def gather_patches(self, opt, var):
+        """One fused gather for everything compute_loss / sample_geometry / disc_forward sample at var.ray_idx."""
+        B = len(var.idx)
+        g = ops.patch_gather(var.ray_idx, var.image, var.get("image_syn", var.image),
+                             var.get("nocs_pred", var.image), var.get("normal_pred", var.image),
+                             var.obj_mask.view(B, opt.H, opt.W), var.get("mask_syn", var.obj_mask).view(B, opt.H, opt.W))
+        var.image_sample, var.image_syn_sample = g[:, 0:3], g[:, 3:6]
+        var.nocs_sample, var.normal_sample = g[:, 6:9], g[:, 9:12]
+        var.mask_sample, var.mask_syn_sample = g[:, 12:13], g[:, 13:14]
+        return var
+
+    def sample_geometry(self, opt, var, mode=None):
+        """nocs / normal patches masked by the synthetic mask (reference :444-461)."""
+        if mode == "train":
+            if "nocs_sample" not in var:
+                var = self.gather_patches(opt, var)
+            return var
+        B = len(var.idx)
+        ms = (var.mask_syn > 0).float().view(B, 1, opt.H, opt.W)
+        var.nocs_sample, var.normal_sample = var.nocs_pred * ms, var.normal_pred * ms
+        return var
+
+    def nerf_forward(self, opt, var, mode=None):
+        pose = self.get_pose(opt, var, mode=mode)
+        depth_range = (var.z_near[:, :, None], var.z_far[:, :, None])
+        if opt.nerf.rand_rays and mode == "train":
+            ret = self.render(opt, pose, intr=var.intr, ray_idx=var.ray_idx, depth_range=depth_range,
+                              sample_idx=var.idx, mode=mode)
+        elif mode == "val":
+            ret = self.render_by_slices(opt, pose, intr=var.intr, depth_range=depth_range, object_mask=var.obj_mask,
+                                        sample_idx=None, mode=mode)
+        else:
+            R_dist = rotation_distance(var.pose[..., :3, :3], var.pose_anchor[..., :3, :3]).unsqueeze(-1)
+            cand = torch.topk(R_dist, k=int(opt.render.N_candidate), dim=0, largest=False, sorted=True)[1]
+            light_idx = cand[torch.randperm(len(cand))[0]][0]
+            ret = self.render_by_slices(opt, pose, intr=var.intr, depth_range=depth_range, object_mask=var.obj_mask,
+                                        sample_idx=light_idx, mode=mode)
+        var.update(ret)
+        if mode == "train" and opt.gan is not None and hasattr(self, "discriminator"):
+            if opt.gan.geo_conditional:
+                var = self.sample_geometry(opt, var, mode)
+            B, h, w, _ = var.ray_idx.shape
+            patch_fake = var.rgb.view(B, h, w, 3).permute(0, 3, 1, 2)
+            if opt.gan.geo_conditional:
+                patch_fake = torch.cat([patch_fake, var.nocs_sample, var.normal_sample], dim=1)
+            var.d_fake_nerf = self.discriminator(opt, patch_fake, var.ray_scales)
+        return var
+
+    def disc_forward(self, opt, var, mode):
+        if mode != "train":
+            raise Exception("No use of discriminator in val/testing phase of NeRF!")
+        B, h, w, _ = var.ray_idx.shape
+        rgb = var.rgb.view(B, h, w, 3).permute(0, 3, 1, 2).contiguous()
+        mask_pad = torch.logical_and(var.mask_syn_sample == 1, var.mask_sample == 0).float()
+        real = (var.image_sample * var.mask_sample + rgb * mask_pad).detach()
+        fake = rgb.detach()
+        if opt.gan.geo_conditional:
+            var = self.sample_geometry(opt, var, mode)
+            real = torch.cat([real, var.nocs_sample, var.normal_sample], dim=1)
+            fake = torch.cat([fake, var.nocs_sample, var.normal_sample], dim=1)
+        var.patch_real, var.patch_fake = real.requires_grad_(), fake.requires_grad_()
+        var.d_real_disc = self.discriminator(opt, var.patch_real, var.ray_scales)
+        var.d_fake_disc = self.discriminator(opt, var.patch_fake, var.ray_scales)
+        return var
+
+    @staticmethod
+    def MSE_loss(pred, label, mask=None):
+        loss = (pred.contiguous() - label) ** 2
+        return loss.mean() if mask is None else (loss * mask).sum() / (mask.sum() + 1e-5)
+
+    def compute_loss(self, opt, var, mode=None, train_step="nerf"):
+        """Photometric / uncertainty / transient-regulariser / feature / GAN terms (reference :712-776)."""
+        loss = edict()
+        B = len(var.idx)
+        if opt.nerf.rand_rays and mode in ["train", "test-optim"]:
+            _, h, w, _ = var.ray_idx.shape
+            var = self.gather_patches(opt, var)
+            image, obj_mask = var.image_sample, var.mask_sample
+            image_syn, mask_syn = var.image_syn_sample, var.mask_syn_sample
+            rgb = var.rgb.view(B, h, w, 3).permute(0, 3, 1, 2)
+            uncert = var.uncert.view(B, h, w, 1).permute(0, 3, 1, 2)
+        else:
+            image = var.image.view(B, 3, opt.H, opt.W)
+            obj_mask = (var.obj_mask > 0).float().view(B, 1, opt.H, opt.W)
+            image_syn = var.get("image_syn", var.image).view(B, 3, opt.H, opt.W)
+            mask_syn = (var.get("mask_syn", var.obj_mask) > 0).float().view(B, 1, opt.H, opt.W)
+            rgb = var.rgb.view(B, opt.H, opt.W, 3).permute(0, 3, 1, 2)
+            uncert = var.uncert.view(B, opt.H, opt.W, 1).permute(0, 3, 1, 2)
+            var.image_syn_sample, var.image_sample, var.mask_sample, var.mask_syn_sample = (image_syn, image, obj_mask,
+                                                                                            mask_syn)
+        lw = opt.loss_weight
+        if train_step == "nerf":
+            if lw.render is not None:
+                if opt.nerf.mask_obj:
+                    loss.render = (obj_mask * ((image - rgb) ** 2 / uncert ** 2)).sum() / (obj_mask.sum() + 1e-5)
+                else:
+                    loss.render = self.MSE_loss(rgb, image)
+            if lw.mask is not None:
+                loss.mask = self.MSE_loss(obj_mask, var.opacity[..., None])
+            if lw.uncert is not None:
+                loss.uncert = 5 + torch.log(var.uncert ** 2).mean() / 2
+            if lw.trans_reg is not None:
+                loss.trans_reg = var.density[..., -1].mean()
+            if lw.feat is not None:
+                if not hasattr(self, "perceptual_loss"):
+                    raise RuntimeError("loss_weight.feat is set but no perceptual_loss module was injected")
+                mask_pad = torch.logical_and(mask_syn == 1, obj_mask == 0).float()
+                loss.feat = self.perceptual_loss(rgb, image * obj_mask + image_syn * mask_pad) + \
+                    5 * self.perceptual_loss(rgb * obj_mask + image * (1 - obj_mask), image)
+            if lw.lab is not None:
+                loss.lab, var.rgb_lab, var.img_syn_lab = self.lab_loss(rgb, image_syn, mask=mask_syn)
+            if opt.gan is not None and lw.gan_nerf is not None and mode == "train":
+                loss.gan_nerf = self.compute_gan_loss(opt, d_outs=var.d_fake_nerf, target=1)
+        elif train_step == "disc":
+            if lw.gan_disc_real is not None:
+                loss.gan_disc_real = self.compute_gan_loss(opt, d_outs=var.d_real_disc, target=1)
+            if lw.gan_disc_fake is not None:
+                loss.gan_disc_fake = self.compute_gan_loss(opt, d_outs=var.d_fake_disc, target=0)
+        else:
+            raise NotImplementedError
+        return loss
+
+    @staticmethod
+    def compute_grad2(opt, d_outs, x_in):
+        """R1 penalty: squared gradient norm of D wrt its input (reference :794-807)."""
+        d_outs = d_outs if isinstance(d_outs, list) else [d_outs]
+        reg = 0
+        for d_out in d_outs:
+            g = torch.autograd.grad(outputs=d_out.sum(), inputs=x_in, create_graph=True, retain_graph=True,
+                                    only_inputs=True)[0]
+            reg = reg + g.pow(2).view(x_in.size(0), -1).sum(1)
+        return reg / len(d_outs)
+
+    @staticmethod
+    def compute_gan_loss(opt, d_outs, target):
+        d_outs = d_outs if isinstance(d_outs, list) else [d_outs]
+        loss = torch.tensor(0.0, device=d_outs[0].device)
+        for d_out in d_outs:
+            if opt.gan.type == "standard":
+                loss = loss + torch_F.binary_cross_entropy_with_logits(d_out, torch.full_like(d_out, float(target)))
+            elif opt.gan.type == "wgan":
+                loss = loss + (2 * target - 1) * d_out.mean()
+            else:
+                raise NotImplementedError
+        return loss / len(d_outs)
+
+
+def summarize_loss(opt, loss):
+    """total = sum 10^w * loss (reference model/base.py:145-157) with the NaN/Inf checks done ONCE on the
+    weighted sum (one host sync per step instead of one per term)."""
+    assert "all" not in loss
+    total = 0.
+    for key in loss:
+        assert key in opt.loss_weight and loss[key].shape == ()
+        if opt.loss_weight[key] is not None:
+            total = total + 10 ** float(opt.loss_weight[key]) * loss[key]
+    loss.update(all=total)
+    return loss

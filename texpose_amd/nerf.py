@@ -1,0 +1,143 @@
+"""NeRF (static + transient + light) module mirroring reference layers/nerf_static_transient_light.py.
+
+Same constructor, parameter names / shapes (state-dict compatible: ``mlp_feat.{0..7}``,
+``mlp_rgb.{0..3}``, ``mlp_trans.{0..3}``, ``progress``) and method signatures; the arithmetic runs in
+the fused HIP kernels (csrc/mlp_fwd.hip, mlp_bwd.hip, composite.hip).  Only the reference's default
+architecture is compiled into the kernels; anything else raises instead of silently falling back.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+
+from . import autograd_ops, ops
+
+
+def _layer_dims(layers):
+    return list(zip(layers[:-1], layers[1:]))
+
+
+class NeRF(torch.nn.Module):
+    WIDTH, L_3D, L_VIEW, N_TRANS, N_LIGHT = 256, 10, 4, 16, 48
+
+    def __init__(self, opt):
+        super().__init__()
+        self._check_arch(opt)
+        d3 = 3 + 6 * opt.arch.posenc.L_3D
+        dv = 3 + 6 * opt.arch.posenc.L_view
+        feat_dim = opt.arch.layers_feat[-1]
+
+        def stack(layers, first_in, skip=(), extra_out_last=0, last_init="all"):
+            mods = torch.nn.ModuleList()
+            dims = _layer_dims(layers)
+            for li, (k_in, k_out) in enumerate(dims):
+                if li == 0:
+                    k_in = first_in
+                if li in skip:
+                    k_in += d3
+                last = li == len(dims) - 1
+                lin = torch.nn.Linear(k_in, k_out + (extra_out_last if last else 0))
+                if opt.arch.tf_init:
+                    self.tensorflow_init_weights(lin, out=last_init if last else None)
+                mods.append(lin)
+            return mods
+
+        # frozen geometry trunk: 63 -> 256 x8 (+63 skip at layer 4) -> 1 density + 256 feature
+        self.mlp_feat = stack(opt.arch.layers_feat, d3, skip=opt.arch.skip, extra_out_last=1, last_init="first")
+        for q in self.mlp_feat.parameters():
+            q.requires_grad = False
+        # static colour head: [feat, view enc, x, light latent] -> 3
+        self.mlp_rgb = stack(opt.arch.layers_rgb, feat_dim + dv + 3 + opt.nerf.N_latent_light)
+        # transient head: [feat, transient latent] -> rgb(3), sigma, uncertainty
+        self.mlp_trans = stack(opt.arch.layers_trans, feat_dim + opt.nerf.N_latent_trans)
+        if opt.c2f is not None:
+            self.progress = torch.nn.Parameter(torch.tensor(0.))
+        self._packed: Optional[torch.Tensor] = None
+        self._packed_T: Optional[torch.Tensor] = None
+        self._versions = {"trunk": None, "heads": None, "heads_T": None}
+
+    # ------------------------------------------------------------------ construction helpers
+    @classmethod
+    def _check_arch(cls, opt):
+        a = opt.arch
+        ok = (list(a.layers_feat[1:]) == [cls.WIDTH] * 8 and list(a.layers_rgb[1:]) == [cls.WIDTH] * 3 + [3]
+              and list(a.layers_trans[1:]) == [cls.WIDTH] * 3 + [5] and list(a.skip) == [4]
+              and a.posenc and a.posenc.L_3D == cls.L_3D and a.posenc.L_view == cls.L_VIEW
+              and a.density_activ == "softplus" and opt.nerf.view_dep
+              and opt.nerf.N_latent_trans == cls.N_TRANS and opt.nerf.N_latent_light == cls.N_LIGHT)
+        if not ok:
+            raise NotImplementedError("the gfx950 MLP kernels are built for the reference default architecture "
+                                      "(options/nerf_lm_adapt_gan.yaml:9-17,37-40); got " + repr(dict(a)))
+        if opt.c2f is not None and opt.c2f.range is not None:
+            raise NotImplementedError("coarse-to-fine posenc weighting (c2f.range) is off in the reference config")
+        if opt.nerf.density_noise_reg:
+            raise NotImplementedError("nerf.density_noise_reg is None in the reference config")
+
+    @staticmethod
+    def tensorflow_init_weights(linear, out=None):
+        """Xavier-uniform as in the reference (layers/...light.py:63-74): ReLU gain for hidden layers, gain 1
+        for output layers ("all") and for the density row of the trunk's last layer ("first")."""
+        g = torch.nn.init.calculate_gain("relu")
+        if out == "all":
+            torch.nn.init.xavier_uniform_(linear.weight)
+        elif out == "first":
+            torch.nn.init.xavier_uniform_(linear.weight[:1])
+            torch.nn.init.xavier_uniform_(linear.weight[1:], gain=g)
+        else:
+            torch.nn.init.xavier_uniform_(linear.weight, gain=g)
+        torch.nn.init.zeros_(linear.bias)
+
+    # ------------------------------------------------------------------ packed weight image
+    def _state(self):
+        return {k: v for k, v in self.named_parameters() if k.startswith("mlp_")}
+
+    def packed_weights(self) -> torch.Tensor:
+        """MFMA-ordered weight stream, re-packed lazily: trunk once (frozen), heads when an optimiser step or a
+        load_state_dict bumped a parameter version."""
+        st = self._state()
+        vt = tuple((p.data_ptr(), p._version) for k, p in st.items() if k.startswith("mlp_feat"))
+        vh = tuple((p.data_ptr(), p._version) for k, p in st.items() if not k.startswith("mlp_feat"))
+        dev = next(self.parameters()).device
+        if self._packed is None or self._packed.device != dev:
+            self._packed = torch.empty(ops.packed_bytes() // 4, device=dev)
+            self._versions["trunk"] = self._versions["heads"] = None
+        with torch.no_grad():
+            if self._versions["trunk"] != vt:
+                ops.pack_weights(st, packed=self._packed, parts=ops.PACK_TRUNK)
+                self._versions["trunk"] = vt
+            if self._versions["heads"] != vh:
+                ops.pack_weights(st, packed=self._packed, parts=ops.PACK_HEADS)
+                self._versions["heads"] = vh
+        return self._packed
+
+    # ------------------------------------------------------------------ reference API
+    def forward(self, opt, points_3D, ray_unit=None, latent_variable_trans=None, latent_variable_light=None,
+                mode=None):
+        """points_3D, ray_unit [B,R,N,3] -> rgb [B,R,N,3,2], density [B,R,N,2], uncert [B,R,N,1]
+        (reference layers/...light.py:76-145)."""
+        assert ray_unit is not None, "view_dep=True needs ray_unit"
+        return autograd_ops.mlp(self, latent_variable_trans, latent_variable_light, points=points_3D,
+                                ray_unit=ray_unit)
+
+    def forward_samples(self, opt, center, ray, depth_samples, latent_variable_trans=None,
+                        latent_variable_light=None, mode=None):
+        """center, ray [B,R,3], depth_samples [B,R,N,1]: points and unit view directions are formed inside the
+        kernel (reference layers/...light.py:147-166)."""
+        return autograd_ops.mlp(self, latent_variable_trans, latent_variable_light, center=center, ray=ray,
+                                depth=depth_samples)
+
+    @staticmethod
+    def composite(opt, ray, rgb_samples, density_samples, depth_samples, uncert_samples=None):
+        """11-tuple of the reference (layers/...light.py:168-212): rgb, rgb_static, rgb_transient, depth, opacity,
+        opacity_static, opacity_transient, prob [B,R,N,1], uncert, alpha_static, alpha_transient [B,R,N]."""
+        out, a_s, a_t, prob = autograd_ops.composite(ray, rgb_samples, density_samples, depth_samples,
+                                                     uncert_samples, opt.nerf.min_uncert)
+        f = {name: out[..., lo:hi] for name, lo, hi in ops.COMPOSITE_RAY_FIELDS}
+        return (f["rgb"], f["rgb_static"], f["rgb_transient"], f["depth"], f["opacity"], f["opacity_static"],
+                f["opacity_transient"], prob[..., None], f["uncert"], a_s, a_t)
+
+    def positional_encoding(self, opt, x, L, c2f=False):
+        """[..., C] -> [..., 2 C L], index c*2L + s*L + l (reference layers/...light.py:217-234)."""
+        return ops.posenc(x, L)
