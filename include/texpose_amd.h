@@ -131,6 +131,32 @@ typedef struct tp_mlp_fwd_args {
 
 int tp_mlp_fwd(const tp_mlp_fwd_args* args, tp_stream_t stream);
 
+/* Backward of the two trainable heads (autograd of layers/...light.py:102-137; the trunk is frozen,
+ * :34,87-100).  Consumes the activation record of a forward run with `saved` != NULL on the same
+ * (B,R,N).  When B*R*N is not a multiple of 128 the caller must zero the last tile's part of `saved`
+ * BEFORE the forward (the weight-gradient GEMM contracts whole 32-sample groups).  At most 32 images
+ * per call.  All gradient outputs are overwritten (not accumulated); results are deterministic
+ * (fixed-order split-K reduction, no float atomics). */
+size_t tp_mlp_packed_t_bytes(void);                 /* scratch for the transposed head-weight stream */
+size_t tp_mlp_bwd_workspace_bytes(int64_t n_samples);
+typedef struct tp_mlp_bwd_args {
+  tp_mlp_weights weights;  /* rgb_w[0..3], trans_w[0..3] are read (device pointers) */
+  void* packed_t;          /* tp_mlp_packed_t_bytes; rebuilt from `weights` when repack != 0 */
+  int repack;
+  const float* saved;      /* record written by tp_mlp_fwd */
+  const float* rgb; const float* density; const float* uncert;        /* forward outputs */
+  const float* g_rgb; const float* g_density; const float* g_uncert;  /* their cotangents */
+  const float* lat_trans;  /* [B,16] */
+  const float* lat_light;  /* [B,48] */
+  int B, R, N;
+  float* g_rgb_w[4];   float* g_rgb_b[4];     /* out: same shapes as mlp_rgb.{i}.weight / bias   */
+  float* g_trans_w[4]; float* g_trans_b[4];   /* out: same shapes as mlp_trans.{i}.weight / bias */
+  float* g_lat_trans;  /* [B,16] out */
+  float* g_lat_light;  /* [B,48] out */
+  void* workspace;         /* tp_mlp_bwd_workspace_bytes */
+} tp_mlp_bwd_args;
+int tp_mlp_bwd(const tp_mlp_bwd_args* args, tp_stream_t stream);
+
 /* Standalone positional encoding (layers/...light.py:217-234): x [n,C] -> [n, 2*C*L]. */
 int tp_posenc(const float* x, int64_t n, int C, int L, float* out, tp_stream_t stream);
 

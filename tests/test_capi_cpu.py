@@ -53,7 +53,7 @@ def test_argument_validation_without_gpu():
     assert lib.tp_mlp_fwd(C.byref(m), None) < 0
     assert lib.tp_mlp_packed_bytes() == (115 * 8192 + 14 * 256 + 16) * 4
     assert lib.tp_mlp_workspace_bytes(128) == 128 * 256 * 4
-    assert lib.tp_mlp_saved_bytes(129) == 8 * 7 * 256 * 32 * 4
+    assert lib.tp_mlp_saved_bytes(129) == 8 * (7 * 8192 + 1024 + 6 * 4 * 64) * 4
 
 
 def test_ops_refuse_cpu_tensors():

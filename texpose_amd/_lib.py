@@ -18,7 +18,7 @@ SYMBOLS = (
     "tp_abi_version", "tp_last_error",
     "tp_raygen", "tp_aabb", "tp_sample_depth",
     "tp_mlp_packed_bytes", "tp_mlp_pack", "tp_mlp_pack_host", "tp_mlp_workspace_bytes", "tp_mlp_fwd", "tp_posenc",
-    "tp_mlp_saved_bytes",
+    "tp_mlp_saved_bytes", "tp_mlp_packed_t_bytes", "tp_mlp_bwd_workspace_bytes", "tp_mlp_bwd",
     "tp_composite_fwd", "tp_composite_bwd",
     "tp_patch_gather",
 )
@@ -45,6 +45,14 @@ class MlpFwdArgs(C.Structure):
                 ("ray_unit", vp), ("lat_trans", vp), ("lat_light", vp),
                 ("B", C.c_int), ("R", C.c_int), ("N", C.c_int),
                 ("rgb", vp), ("density", vp), ("uncert", vp), ("saved", vp), ("workspace", vp)]
+
+
+class MlpBwdArgs(C.Structure):
+    _fields_ = [("weights", MlpWeights), ("packed_t", vp), ("repack", C.c_int), ("saved", vp), ("rgb", vp),
+                ("density", vp), ("uncert", vp), ("g_rgb", vp), ("g_density", vp), ("g_uncert", vp),
+                ("lat_trans", vp), ("lat_light", vp), ("B", C.c_int), ("R", C.c_int), ("N", C.c_int),
+                ("g_rgb_w", vp * 4), ("g_rgb_b", vp * 4), ("g_trans_w", vp * 4), ("g_trans_b", vp * 4),
+                ("g_lat_trans", vp), ("g_lat_light", vp), ("workspace", vp)]
 
 
 class CompositeArgs(C.Structure):
@@ -101,6 +109,9 @@ def load() -> C.CDLL:
     sig("tp_mlp_packed_bytes", [], C.c_size_t)
     sig("tp_mlp_workspace_bytes", [C.c_int64], C.c_size_t)
     sig("tp_mlp_saved_bytes", [C.c_int64], C.c_size_t)
+    sig("tp_mlp_packed_t_bytes", [], C.c_size_t)
+    sig("tp_mlp_bwd_workspace_bytes", [C.c_int64], C.c_size_t)
+    sig("tp_mlp_bwd", [C.POINTER(MlpBwdArgs), vp])
     sig("tp_mlp_pack", [C.POINTER(MlpWeights), C.c_int, vp, vp])
     sig("tp_mlp_pack_host", [C.POINTER(MlpWeights), vp])
     sig("tp_mlp_fwd", [C.POINTER(MlpFwdArgs), vp])

@@ -45,7 +45,6 @@ class _Mlp(torch.autograd.Function):
         if need_grad:
             rgb, density, uncert, saved = res
             ctx.nerf = nerf
-            ctx.geom = (center, ray, depth, points, ray_unit)
             ctx.save_for_backward(lat_trans, lat_light, saved, rgb, density, uncert)
         else:
             rgb, density, uncert = res
@@ -54,11 +53,11 @@ class _Mlp(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_rgb, g_density, g_uncert):
         lat_trans, lat_light, saved, rgb, density, uncert = ctx.saved_tensors
-        grads = ops.mlp_backward(ctx.nerf, lat_trans, lat_light, ctx.geom, saved, rgb, density, uncert, g_rgb,
-                                 g_density, g_uncert)
+        grads = ops.mlp_backward(ctx.nerf, lat_trans, lat_light, saved, rgb, density, uncert, g_rgb, g_density,
+                                 g_uncert)
         return (None, grads["lat_trans"], grads["lat_light"], None, None, None, None, None) + tuple(grads["params"])
 
 
 def mlp(nerf, lat_trans, lat_light, center=None, ray=None, depth=None, points=None, ray_unit=None):
-    head_params = [p for k, p in nerf.named_parameters() if k.startswith(("mlp_rgb", "mlp_trans"))]
+    head_params = [p for _, p in nerf.head_parameters()]
     return _Mlp.apply(nerf, lat_trans, lat_light, center, ray, depth, points, ray_unit, *head_params)

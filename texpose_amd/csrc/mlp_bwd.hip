@@ -1,0 +1,369 @@
+// K3: backward of the two trainable heads (mlp_rgb, mlp_trans) and the per-image latents (gfx950).
+//
+// Replaces torch autograd through layers/nerf_static_transient_light.py:102-137.  The trunk is
+// frozen and evaluated under no_grad in the reference (:34,87-100,236-239), so nothing flows into
+// mlp_feat; gradients are produced for mlp_rgb.{0..3}, mlp_trans.{0..3} and the latent rows only.
+//
+// Three kernels on one stream:
+//  1. mlp_dgrad_kernel -- same register-resident structure as the forward (samples on MFMA lanes,
+//     transposed weights streamed L2->LDS as the A operand): dz3 from the output activations'
+//     derivatives, then dz_l = (W_{l+1}^T dz_{l+1}) * [h_l > 0] for l = 2,1,0 of each head, written
+//     as [256 feature][32 sample] blocks (XOR-swizzled sample quads).
+//  2. mlp_wgrad_kernel -- dW_l = sum_s dz_l[:,s] in_l[:,s]^T as fp32-MFMA GEMMs whose k axis is
+//     the SAMPLE axis: both operands are lane-linear LDS copies (LDS-DMA) of the recorded blocks,
+//     fragments are conflict-free ds_read_b128 thanks to the swizzle; split-K over workgroups,
+//     128 output rows x 10 column tiles per workgroup.  Two extra column tiles ride along: a
+//     one-hot "image id" tile that yields per-image sums of dz (bias gradients, and through
+//     linearity everything that multiplies a per-image latent) and, for mlp_rgb.0, the recorded
+//     [view encoding, x] columns.
+//  3. mlp_wgrad_finalize -- fixed-order reduction of the split-K partials into the reference
+//     parameter layouts (deterministic: no float atomics), plus the latent-row gradients
+//     dlat[b] = W0[:,latent cols]^T (sum_{s in b} dz0[:,s]).
+#include "mlp_mma.h"
+
+namespace {
+using namespace tp_layout;
+using namespace tp_mma;
+
+// ------------------------------------------------------------------------------------------------
+struct WPtrs { const float* w[16]; };
+
+__global__ void packT_kernel(WPtrs w, float* __restrict__ out) {
+  const int64_t n = (int64_t)kNumChunksT * kChunkFloats;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+    int mat, o, f;
+    chunkT_src((int)(e / kChunkFloats), (int)(e % kChunkFloats), mat, o, f);
+    out[e] = o < 0 ? 0.0f : w.w[mat][(int64_t)o * 256 + f];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+struct DgParams {
+  const float* packed_t; const float* saved;
+  const float* rgb; const float* density; const float* uncert;
+  const float* g_rgb; const float* g_density; const float* g_uncert;
+  int64_t n_samples, n_tiles;
+  float* dz;
+};
+
+__global__ __launch_bounds__(kThreads, 1) void mlp_dgrad_kernel(DgParams P) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 31, hh = lane >> 5;
+  Pipe p;
+  p.stream = P.packed_t; p.lds = lds; p.chunk = 0; p.buf = 0; p.wave = wave; p.lane = lane;
+  dma_chunk(p, 0, 0);
+  __syncthreads();
+
+  for (int64_t tile = blockIdx.x; tile < P.n_tiles; tile += gridDim.x) {
+    const int64_t s_raw = tile * 128 + wave * 32 + j;
+    const bool live = s_raw < P.n_samples;
+    const int64_t s = live ? s_raw : P.n_samples - 1;
+    const int64_t gidx = tile * 4 + wave;
+    const float* sv = P.saved + gidx * (int64_t)kSavedGroupFloats;
+    float* dzg = P.dz + gidx * (int64_t)kDzGroupFloats;
+    f32x16 h[8], acc[8];
+    int o16[16];
+    lane_block_offsets(j, hh, o16);
+
+#pragma nounroll
+    for (int st = 0; st < 6; ++st) {
+      const int head = st / 3, k = st - head * 3;
+      // ReLU sign bits of the activation this step's result is masked with (recorded by the forward)
+      const int slot = (head == 0 ? SV_T2 : SV_R2) - k;
+      const uint32_t* mk = reinterpret_cast<const uint32_t*>(sv + kMaskOff) + (slot - 1) * 256 + lane;
+      uint32_t mask[4];
+#pragma unroll
+      for (int w = 0; w < 4; ++w) mask[w] = mk[w * 64];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) acc[t] = f32x16{0};
+      if (k == 0) {
+        // derivative of the output non-linearities (sigmoid: y(1-y); softplus: 1-exp(-y))
+        float d[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (live) {
+          const int sel = head == 0 ? 1 : 0;          // head 0 = transient (last dim 1), head 1 = static rgb
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            const float y = P.rgb[s * 6 + c * 2 + sel];
+            d[c] = P.g_rgb[s * 6 + c * 2 + sel] * y * (1.0f - y);
+          }
+          if (head == 0) {
+            d[3] = P.g_density[s * 2 + 1] * (1.0f - expf(-P.density[s * 2 + 1]));
+            d[4] = P.g_uncert[s] * (1.0f - expf(-P.uncert[s]));
+          }
+        }
+        float* nb = dzg + (head == 0 ? kDzT3Off : kDzR3Off);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) nb[blk_off(r + 16 * hh, j)] = (hh == 0 && r < 6) ? d[r < 6 ? r : 0] : 0.0f;
+        chunk_begin(p, kNumChunksT);
+        mma_wide<3, 2>(acc, chunk_ptr(p), [&](int s_) { return hh ? d[2 * s_ + 1] : d[2 * s_]; });
+        chunk_end(p, kNumChunksT);
+      } else {
+        part_gen(p, acc, h, kNumChunksT);
+      }
+      // ReLU mask from the recorded activation; the result is both the next B operand and the wgrad A operand
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const bool on = (mask[t >> 1] >> ((t & 1) * 16 + r)) & 1u;
+          h[t][r] = (live && on) ? acc[t][r] : 0.0f;
+        }
+      store_block(dzg + st * kBlockFloats, h, o16);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+constexpr int kWgItems = 14;     // 6 wide GEMMs x 2 row halves + 2 narrow (output-layer) GEMMs
+constexpr int kWgTiles = 10;     // 8 input-feature tiles + image one-hot tile + [view enc, x] tile
+constexpr int kWgBufFloats = 4096 + 8192 + 1024;
+
+struct WgParams {
+  const float* saved; const float* dz;
+  int64_t n_samples, n_groups, rn;   // rn = samples per image (R*N)
+  int n_slices, groups_per_slice;
+  float* partial;
+};
+
+__device__ __forceinline__ void wg_dma(const WgParams& P, int64_t g, float* buf, int a_off, int a_pieces, int b_slot,
+                                       bool has_ex, int wave, int lane) {
+  const float* dzg = P.dz + g * (int64_t)kDzGroupFloats + a_off;
+  const float* svg = P.saved + g * (int64_t)kSavedGroupFloats;
+  for (int pc = wave; pc < a_pieces; pc += 4)
+    __builtin_amdgcn_global_load_lds(AS1(dzg + pc * 256 + lane * 4), AS3(buf + pc * 256), 16, 0, 0);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int pc = wave * 8 + k;
+    __builtin_amdgcn_global_load_lds(AS1(svg + b_slot * kBlockFloats + pc * 256 + lane * 4),
+                                     AS3(buf + 4096 + pc * 256), 16, 0, 0);
+  }
+  if (has_ex)
+    __builtin_amdgcn_global_load_lds(AS1(svg + SV_EX * kBlockFloats + wave * 256 + lane * 4),
+                                     AS3(buf + 4096 + 8192 + wave * 256), 16, 0, 0);
+}
+
+__global__ __launch_bounds__(kThreads, 1) void mlp_wgrad_kernel(WgParams P) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 31, hh = lane >> 5;
+  const int item = blockIdx.x % kWgItems, slice = blockIdx.x / kWgItems;
+  const bool big = item < 12;
+  const int gemm = item >> 1, quad = item & 1;
+  const int a_off = big ? gemm * kBlockFloats + quad * 4096 : (item == 12 ? kDzT3Off : kDzR3Off);
+  const int a_pieces = big ? 16 : 4;
+  int b_slot;
+  if (big) {
+    b_slot = gemm == 0 ? SV_T1 : gemm == 1 ? SV_T0 : gemm == 2 ? SV_FEAT : gemm == 3 ? SV_R1 : gemm == 4 ? SV_R0 : SV_FEAT;
+  } else {
+    b_slot = item == 12 ? SV_T2 : SV_R2;
+  }
+  const bool has_ex = big && gemm == 5;
+  const int64_t g0 = (int64_t)slice * P.groups_per_slice;
+  const int64_t g1 = g0 + P.groups_per_slice < P.n_groups ? g0 + P.groups_per_slice : P.n_groups;
+
+  // narrow items reuse the wide code path with a 128-row A block whose rows 32.. are zero
+  if (!big)
+    for (int e = tid; e < 2 * 3072; e += kThreads) lds[(e / 3072) * kWgBufFloats + 1024 + (e % 3072)] = 0.0f;
+
+  f32x16 acc[kWgTiles];
+#pragma unroll
+  for (int t = 0; t < kWgTiles; ++t) acc[t] = f32x16{0};
+
+  // A rows of this wave: feature index (for the swizzle) and LDS row
+  const int fa = (big ? quad * 128 : 0) + wave * 32 + i;
+  const int a_row = wave * 32 + i;
+  const int64_t lo = (int64_t)i * P.rn;                       // sample range of image `i` (one-hot tile column)
+  const int64_t hi = lo + P.rn < P.n_samples ? lo + P.rn : P.n_samples;
+
+  int buf = 0;
+  if (g0 < g1) wg_dma(P, g0, lds, a_off, a_pieces, b_slot, has_ex, wave, lane);
+  __syncthreads();
+  for (int64_t g = g0; g < g1; ++g) {
+    if (g + 1 < g1) wg_dma(P, g + 1, lds + (buf ^ 1) * kWgBufFloats, a_off, a_pieces, b_slot, has_ex, wave, lane);
+    const float* A = lds + buf * kWgBufFloats;
+    const float* Bm = A + 4096;
+    const float* Ex = Bm + 8192;
+    const int64_t sbase = g * 32 + 4 * hh;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int sq = 2 * q + hh;                               // sample quad of this lane half
+      const f32x4 a4 = *reinterpret_cast<const f32x4*>(A + a_row * 32 + ((sq ^ ((fa >> 1) & 7)) << 2));
+      f32x4 b4[8];
+#pragma unroll
+      for (int ft = 0; ft < 8; ++ft) {
+        const int f = ft * 32 + i;
+        b4[ft] = *reinterpret_cast<const f32x4*>(Bm + f * 32 + ((sq ^ ((f >> 1) & 7)) << 2));
+      }
+      f32x4 e4 = {0.f, 0.f, 0.f, 0.f};
+      if (has_ex) e4 = *reinterpret_cast<const f32x4*>(Ex + i * 32 + ((sq ^ ((i >> 1) & 7)) << 2));
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int64_t smp = sbase + 8 * q + m;
+        const float onehot = (smp >= lo && smp < hi) ? 1.0f : 0.0f;
+#pragma unroll
+        for (int ft = 0; ft < 8; ++ft) acc[ft] = mfma(a4[m], b4[ft][m], acc[ft]);
+        acc[8] = mfma(a4[m], onehot, acc[8]);
+        if (has_ex) acc[9] = mfma(a4[m], e4[m], acc[9]);
+      }
+    }
+    __syncthreads();
+    buf ^= 1;
+  }
+  float* out = P.partial + (((int64_t)item * P.n_slices + slice) * 4 + wave) * (kWgTiles * 1024);
+#pragma unroll
+  for (int t = 0; t < kWgTiles; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) out[(t * 16 + r) * 64 + lane] = acc[t][r];
+}
+
+// ------------------------------------------------------------------------------------------------
+enum { SEG_W = 0, SEG_B = 1, SEG_LAT = 2 };
+struct Seg {
+  float* out;
+  int kind, gemm;      // gemm 0..5 wide (T2,T1,T0,R2,R1,R0), 6 = T3, 7 = R3
+  int rows, cols;      // output tensor shape ([rows] for biases; [B][n_lat] for latents)
+  int64_t start;       // prefix offset in the flattened element space
+};
+struct FinParams {
+  Seg seg[18];
+  int n_seg; int64_t total;
+  const float* partial; int n_slices; int B;
+  const float* lat_trans; const float* lat_light;   // [B,16], [B,48]
+  const float* w_t0; const float* w_r0;              // mlp_trans.0.weight [256,272], mlp_rgb.0.weight [256,334]
+};
+
+__device__ __forceinline__ float part_sum(const FinParams& P, int gemm, int o, int ft, int col) {
+  const int item = gemm < 6 ? 2 * gemm + (o >> 7) : 12 + (gemm - 6);
+  const int wave = gemm < 6 ? (o & 127) >> 5 : 0;
+  const int ii = o & 31, h = (ii >> 2) & 1, r = (ii & 3) | ((ii >> 3) << 2);
+  const float* p = P.partial + ((((int64_t)item * P.n_slices) * 4 + wave) * kWgTiles + ft) * 1024 + r * 64 + h * 32 + col;
+  float s = 0.0f;
+  for (int sl = 0; sl < P.n_slices; ++sl) s += p[(int64_t)sl * 4 * kWgTiles * 1024];
+  return s;
+}
+
+__global__ void mlp_wgrad_finalize(FinParams P) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < P.total; e += (int64_t)gridDim.x * blockDim.x) {
+    int si = 0;
+    while (si + 1 < P.n_seg && e >= P.seg[si + 1].start) ++si;
+    const Seg& sg = P.seg[si];
+    const int64_t le = e - sg.start;
+    float v = 0.0f;
+    if (sg.kind == SEG_W) {
+      const int o = (int)(le / sg.cols), c = (int)(le % sg.cols);
+      if (c < 256) {
+        v = part_sum(P, sg.gemm, o, c >> 5, c & 31);
+      } else if (sg.gemm == 2) {                       // mlp_trans.0: transient-latent columns
+        for (int b = 0; b < P.B; ++b) v += part_sum(P, 2, o, 8, b) * P.lat_trans[b * 16 + (c - 256)];
+      } else if (c < 286) {                            // mlp_rgb.0: [view enc, x] columns
+        v = part_sum(P, 5, o, 9, c - 256);
+      } else {                                         // mlp_rgb.0: light-latent columns
+        for (int b = 0; b < P.B; ++b) v += part_sum(P, 5, o, 8, b) * P.lat_light[b * 48 + (c - 286)];
+      }
+    } else if (sg.kind == SEG_B) {
+      for (int b = 0; b < P.B; ++b) v += part_sum(P, sg.gemm, (int)le, 8, b);
+    } else {
+      const int b = (int)(le / sg.cols), c = (int)(le % sg.cols);
+      if (sg.gemm == 2) { for (int o = 0; o < 256; ++o) v += P.w_t0[o * 272 + 256 + c] * part_sum(P, 2, o, 8, b); }
+      else { for (int o = 0; o < 256; ++o) v += P.w_r0[o * 334 + 286 + c] * part_sum(P, 5, o, 8, b); }
+    }
+    sg.out[le] = v;
+  }
+}
+
+int num_cus() {
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+    cus = 256;
+  return cus;
+}
+
+int64_t n_groups_of(int64_t n_samples) { return ((n_samples + 127) / 128) * 4; }
+int slices_for(int64_t n_groups) {
+  int s = num_cus() / kWgItems;
+  if (s < 1) s = 1;
+  return (int)(n_groups < s ? n_groups : s);
+}
+size_t align256(size_t x) { return (x + 255) / 256 * 256; }
+
+}  // namespace
+
+extern "C" size_t tp_mlp_packed_t_bytes(void) { return (size_t)kPackedTFloats * sizeof(float); }
+
+extern "C" size_t tp_mlp_bwd_workspace_bytes(int64_t n_samples) {
+  const int64_t ng = n_groups_of(n_samples);
+  // dz record + split-K partials (sized for the largest slice count any device could ask for: 64)
+  return align256((size_t)ng * kDzGroupFloats * sizeof(float)) +
+         align256((size_t)kWgItems * 64 * 4 * kWgTiles * 1024 * sizeof(float));
+}
+
+extern "C" int tp_mlp_bwd(const tp_mlp_bwd_args* a, tp_stream_t stream_) {
+  TP_REQUIRE(a && a->packed_t && a->saved && a->rgb && a->density && a->uncert && a->g_rgb && a->g_density &&
+                 a->g_uncert && a->lat_trans && a->lat_light && a->workspace, "null pointer");
+  TP_REQUIRE(a->B > 0 && a->B <= 32 && a->R > 0 && a->N > 0, "bad sizes (at most 32 images per call)");
+  for (int i = 0; i < 4; ++i)
+    TP_REQUIRE(a->weights.rgb_w[i] && a->weights.trans_w[i] && a->g_rgb_w[i] && a->g_rgb_b[i] && a->g_trans_w[i] &&
+                   a->g_trans_b[i], "null weight / gradient pointer");
+  TP_REQUIRE(a->g_lat_trans && a->g_lat_light, "null latent gradient pointer");
+  hipStream_t stream = (hipStream_t)stream_;
+  const int64_t S = (int64_t)a->B * a->R * a->N;
+  const int64_t n_tiles = (S + 127) / 128, ng = n_tiles * 4;
+  float* dz = (float*)a->workspace;
+  float* partial = (float*)((char*)a->workspace + align256((size_t)ng * kDzGroupFloats * sizeof(float)));
+
+  if (a->repack) {
+    WPtrs w;
+    for (int i = 0; i < 16; ++i) w.w[i] = nullptr;
+    for (int i = 0; i < 4; ++i) { w.w[W_RGB0 + i] = a->weights.rgb_w[i]; w.w[W_TRANS0 + i] = a->weights.trans_w[i]; }
+    hipLaunchKernelGGL(packT_kernel, dim3(512), dim3(256), 0, stream, w, (float*)a->packed_t);
+  }
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)mlp_dgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       2 * kChunkFloats * (int)sizeof(float));
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void*)mlp_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              2 * kWgBufFloats * (int)sizeof(float));
+    if (e != hipSuccess) { tp::set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+    attr_set = true;
+  }
+  const int cus = num_cus();
+  DgParams D;
+  D.packed_t = (const float*)a->packed_t; D.saved = a->saved; D.rgb = a->rgb; D.density = a->density;
+  D.uncert = a->uncert; D.g_rgb = a->g_rgb; D.g_density = a->g_density; D.g_uncert = a->g_uncert;
+  D.n_samples = S; D.n_tiles = n_tiles; D.dz = dz;
+  hipLaunchKernelGGL(mlp_dgrad_kernel, dim3((unsigned)(n_tiles < cus ? n_tiles : cus)), dim3(kThreads),
+                     2 * kChunkFloats * sizeof(float), stream, D);
+
+  WgParams Wg;
+  Wg.saved = a->saved; Wg.dz = dz; Wg.n_samples = S; Wg.n_groups = ng; Wg.rn = (int64_t)a->R * a->N;
+  Wg.n_slices = slices_for(ng);
+  Wg.groups_per_slice = (int)((ng + Wg.n_slices - 1) / Wg.n_slices);
+  Wg.partial = partial;
+  hipLaunchKernelGGL(mlp_wgrad_kernel, dim3(kWgItems * Wg.n_slices), dim3(kThreads), 2 * kWgBufFloats * sizeof(float),
+                     stream, Wg);
+
+  FinParams F;
+  int n = 0; int64_t off = 0;
+  auto add = [&](float* out, int kind, int gemm, int rows, int cols) {
+    F.seg[n] = Seg{out, kind, gemm, rows, cols, off};
+    off += (int64_t)rows * cols; ++n;
+  };
+  // gemm ids: 0..2 = mlp_trans.{2,1,0}, 3..5 = mlp_rgb.{2,1,0}, 6 = mlp_trans.3, 7 = mlp_rgb.3
+  add(a->g_trans_w[3], SEG_W, 6, 5, 256);  add(a->g_trans_b[3], SEG_B, 6, 5, 1);
+  add(a->g_trans_w[2], SEG_W, 0, 256, 256); add(a->g_trans_b[2], SEG_B, 0, 256, 1);
+  add(a->g_trans_w[1], SEG_W, 1, 256, 256); add(a->g_trans_b[1], SEG_B, 1, 256, 1);
+  add(a->g_trans_w[0], SEG_W, 2, 256, 272); add(a->g_trans_b[0], SEG_B, 2, 256, 1);
+  add(a->g_rgb_w[3], SEG_W, 7, 3, 256);    add(a->g_rgb_b[3], SEG_B, 7, 3, 1);
+  add(a->g_rgb_w[2], SEG_W, 3, 256, 256);  add(a->g_rgb_b[2], SEG_B, 3, 256, 1);
+  add(a->g_rgb_w[1], SEG_W, 4, 256, 256);  add(a->g_rgb_b[1], SEG_B, 4, 256, 1);
+  add(a->g_rgb_w[0], SEG_W, 5, 256, 334);  add(a->g_rgb_b[0], SEG_B, 5, 256, 1);
+  add(a->g_lat_trans, SEG_LAT, 2, a->B, 16);
+  add(a->g_lat_light, SEG_LAT, 5, a->B, 48);
+  F.n_seg = n; F.total = off; F.partial = partial; F.n_slices = Wg.n_slices; F.B = a->B;
+  F.lat_trans = a->lat_trans; F.lat_light = a->lat_light;
+  F.w_t0 = a->weights.trans_w[0]; F.w_r0 = a->weights.rgb_w[0];
+  hipLaunchKernelGGL(mlp_wgrad_finalize, dim3((unsigned)((off + 255) / 256)), dim3(256), 0, stream, F);
+  return tp::check_launch("tp_mlp_bwd");
+}

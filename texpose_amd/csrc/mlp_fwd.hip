@@ -23,108 +23,24 @@
 //    out per sample against 1.82 MFLOP of work.
 //  * persistent workgroups (grid <= CUs) walk sample tiles; the trunk feature needed by both
 //    heads is parked in a per-workgroup scratch slab (each lane re-reads only what it wrote).
-#include "tp_common.h"
-#include "mlp_layout.h"
+#include "mlp_mma.h"
 
 namespace {
 using namespace tp_layout;
 
-using f32x16 = __attribute__((ext_vector_type(16))) float;
-using f32x4 = __attribute__((ext_vector_type(4))) float;
+using namespace tp_mma;
 
-constexpr int kThreads = 256;
 constexpr int kTileSamples = 128;
 constexpr int kBiasPad = (kBiasFloats + 63) / 64 * 64;
 constexpr int kEncFloats = 32 * kThreads;                     // per-lane [x, PE(x)] B operands
 constexpr int kExFloats = 40 * kThreads;                      // per-lane head extras (latents, view encoding)
 // 2 x 32 KiB weight buffers + biases + the per-lane "extra input" B operands = 150 KiB of the 160 KiB LDS
 constexpr int kLdsFloats = 2 * kChunkFloats + kBiasPad + kEncFloats + kExFloats;
-constexpr int kSavedSlots = 7;                                // feat, T0,T1,T2, R0,R1,R2 activations
-
-#define AS1(p) ((const __attribute__((address_space(1))) void*)(p))
-#define AS3(p) ((__attribute__((address_space(3))) void*)(p))
-
-__device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) {
-  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
-}
-
-struct Pipe {
-  const float* stream;  // packed chunks (global)
-  float* lds;           // two chunk buffers
-  int chunk;            // chunk resident in buffer `buf`
-  int buf;
-  int wave, lane;
-};
-
-__device__ __forceinline__ void dma_chunk(const Pipe& p, int chunk, int buf) {
-  const float* src = p.stream + (size_t)chunk * kChunkFloats + p.wave * 2048 + p.lane * 4;
-  float* dst = p.lds + buf * kChunkFloats + p.wave * 2048;
-#pragma unroll
-  for (int k = 0; k < 8; ++k) __builtin_amdgcn_global_load_lds(AS1(src + k * 256), AS3(dst + k * 256), 16, 0, 0);
-}
-
-// prefetch the next chunk of the stream (wrapping to the next tile's first chunk)
-__device__ __forceinline__ void chunk_begin(Pipe& p) {
-  int nxt = p.chunk + 1;
-  if (nxt == kNumChunks) nxt = 0;
-  dma_chunk(p, nxt, p.buf ^ 1);
-}
-// all waves are done with the current buffer and the prefetch has landed (syncthreads drains vmcnt)
-__device__ __forceinline__ void chunk_end(Pipe& p) {
-  __syncthreads();
-  p.chunk = (p.chunk + 1 == kNumChunks) ? 0 : p.chunk + 1;
-  p.buf ^= 1;
-}
-__device__ __forceinline__ const float* chunk_ptr(const Pipe& p) { return p.lds + p.buf * kChunkFloats + p.lane * 4; }
-
-// KS k-steps of an 8-tile (256-output) layer; B operand of k-step s is b(s).
-// The A fragments (and an LDS-resident B operand) of k-step s+1 are fetched before the 8 MFMAs of
-// k-step s; sched_group_barrier pins that order (hipcc otherwise sinks each ds_read to just before
-// its first use and stalls one wave per SIMD on lgkmcnt(0) every 4 MFMAs).
-template <int KS, int NDS, class BFn>
-__device__ __forceinline__ void mma_wide(f32x16 (&acc)[8], const float* l, BFn b) {
-  f32x4 a0 = *reinterpret_cast<const f32x4*>(l);
-  f32x4 a1 = *reinterpret_cast<const f32x4*>(l + 256);
-  float bv = b(0);
-  __builtin_amdgcn_sched_group_barrier(0x100, NDS, 0);
-#pragma unroll
-  for (int s = 0; s < KS; ++s) {
-    f32x4 n0 = a0, n1 = a1;
-    float nb = bv;
-    if (s + 1 < KS) {
-      n0 = *reinterpret_cast<const f32x4*>(l + (s * 2 + 2) * 256);
-      n1 = *reinterpret_cast<const f32x4*>(l + (s * 2 + 3) * 256);
-      nb = b(s + 1);
-    }
-    acc[0] = mfma(a0.x, bv, acc[0]);
-    acc[1] = mfma(a0.y, bv, acc[1]);
-    acc[2] = mfma(a0.z, bv, acc[2]);
-    acc[3] = mfma(a0.w, bv, acc[3]);
-    acc[4] = mfma(a1.x, bv, acc[4]);
-    acc[5] = mfma(a1.y, bv, acc[5]);
-    acc[6] = mfma(a1.z, bv, acc[6]);
-    acc[7] = mfma(a1.w, bv, acc[7]);
-    if (s + 1 < KS) __builtin_amdgcn_sched_group_barrier(0x100, NDS, 0);
-    __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
-    a0 = n0; a1 = n1; bv = nb;
-  }
-}
-
-// one generic 256->256 part: 8 chunks, chunk ts contracts the 32 features of tile ts of `h`
-__device__ __forceinline__ void part_gen(Pipe& p, f32x16 (&acc)[8], const f32x16 (&h)[8]) {
-#pragma unroll
-  for (int ts = 0; ts < 8; ++ts) {
-    chunk_begin(p);
-    const f32x16 hv = h[ts];
-    mma_wide<16, 2>(acc, chunk_ptr(p), [&](int s) { return hv[s]; });
-    chunk_end(p);
-  }
-}
 
 // 1..5-row head: one chunk, 128 k-steps over all of `h`, single accumulator tile
 __device__ __forceinline__ f32x16 part_head(Pipe& p, const f32x16 (&h)[8]) {
   f32x16 acc = {0};
-  chunk_begin(p);
+  chunk_begin(p, kNumChunks);
   const float* l = chunk_ptr(p);
   f32x4 a = *reinterpret_cast<const f32x4*>(l);
   __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
@@ -141,7 +57,7 @@ __device__ __forceinline__ f32x16 part_head(Pipe& p, const f32x16 (&h)[8]) {
     __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
     a = n;
   }
-  chunk_end(p);
+  chunk_end(p, kNumChunks);
   return acc;
 }
 
@@ -158,6 +74,7 @@ struct Params {
   float* rgb; float* density; float* uncert; float* saved; float* workspace;
 };
 
+template <bool SAVE>
 __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_kernel(Params P) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -235,21 +152,21 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_kernel(Params P) {
 #pragma unroll
       for (int t = 0; t < 8; ++t) acc[t] = f32x16{0};
 
-      if (li != L0) part_gen(p, acc, h);
+      if (li != L0) part_gen(p, acc, h, kNumChunks);
 
       if (li == L0 || li == L4) {          // [x, PE(x)] columns (layers/...light.py:81-82,90-91)
 #pragma unroll
         for (int qd = 0; qd < 2; ++qd) {
-          chunk_begin(p);
+          chunk_begin(p, kNumChunks);
           mma_wide<16, 3>(acc, chunk_ptr(p), [&](int s_) { return enc_lds[(qd * 16 + s_) * kThreads]; });
-          chunk_end(p);
+          chunk_end(p, kNumChunks);
         }
       } else if (li == T0) {               // transient latent (layers/...light.py:126-128)
 #pragma unroll
         for (int r = 0; r < 8; ++r) ex_lds[r * kThreads] = P.lat_trans[b * 16 + r + 8 * hh];
-        chunk_begin(p);
+        chunk_begin(p, kNumChunks);
         mma_wide<8, 3>(acc, chunk_ptr(p), [&](int s_) { return ex_lds[s_ * kThreads]; });
-        chunk_end(p);
+        chunk_end(p, kNumChunks);
       } else if (li == R0) {               // [ray_unit, PE(ray_unit), x, light] (layers/...light.py:104-117)
 #pragma nounroll
         for (int r = 0; r < 12; ++r) {
@@ -261,15 +178,20 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_kernel(Params P) {
         ex_lds[12 * kThreads] = hh ? vu[1] : vu[0];
         ex_lds[13 * kThreads] = hh ? x[0] : vu[2];
         ex_lds[14 * kThreads] = hh ? x[2] : x[1];
+        if (SAVE && live) {   // mlp_rgb.0 input columns 256..285 for the weight gradient
+          float* sx = P.saved + (tile * 4 + wave) * (int64_t)kSavedGroupFloats + SV_EX * kBlockFloats;
+#pragma unroll
+          for (int r = 0; r < 15; ++r) sx[blk_off(x40_col(r, hh), j)] = ex_lds[r * kThreads];
+        }
 #pragma unroll
         for (int r = 15; r < 39; ++r) ex_lds[r * kThreads] = P.lat_light[b * 48 + (r - 15) + 24 * hh];
         ex_lds[39 * kThreads] = 0.0f;
 #pragma unroll
         for (int qd = 0; qd < 3; ++qd) {
-          chunk_begin(p);
+          chunk_begin(p, kNumChunks);
           if (qd < 2) mma_wide<16, 3>(acc, chunk_ptr(p), [&](int s_) { return ex_lds[(qd * 16 + s_) * kThreads]; });
           else mma_wide<8, 3>(acc, chunk_ptr(p), [&](int s_) { return ex_lds[(32 + s_) * kThreads]; });
-          chunk_end(p);
+          chunk_end(p, kNumChunks);
         }
       }
 
@@ -286,13 +208,22 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_kernel(Params P) {
           h[t][g * 4 + 3] = fmaxf(acc[t][g * 4 + 3] + bv.w, 0.0f);
         }
 
-      if (P.saved != nullptr && li >= L7 && live) {
-        // activations for the backward: [32-sample group][slot][feature][sample]
-        float* sv = P.saved + (((tile * 4 + wave) * kSavedSlots + (li - L7)) * 256) * 32 + j;
+      if (SAVE && li >= L7 && live) {
+        // activations for the backward (layout: mlp_layout.h "Training record")
+        float* grp = P.saved + (tile * 4 + wave) * (int64_t)kSavedGroupFloats;
+        int o16[16];
+        lane_block_offsets(j, hh, o16);
+        store_block(grp + (li - L7) * kBlockFloats, h, o16);
+        if (li >= T0) {   // ReLU sign bits for the dgrad kernel
+          uint32_t* mk = reinterpret_cast<uint32_t*>(grp + kMaskOff) + (li - T0) * 256 + lane;
 #pragma unroll
-        for (int t = 0; t < 8; ++t)
+          for (int w = 0; w < 4; ++w) {
+            uint32_t m = 0;
 #pragma unroll
-          for (int r = 0; r < 16; ++r) sv[feat_of(t, r, hh) * 32] = h[t][r];
+            for (int bt = 0; bt < 32; ++bt) m |= (h[2 * w + (bt >> 4)][bt & 15] > 0.0f ? 1u : 0u) << bt;
+            mk[w * 64] = m;
+          }
+        }
       }
       if (li == L7) {   // park the trunk feature for the second head
 #pragma unroll
@@ -345,7 +276,7 @@ __global__ void posenc_kernel(const float* __restrict__ x, int64_t n, int C, int
 
 int persistent_grid(int64_t n_tiles) {
   int dev = 0, cus = 256;
-  if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
   return (int)(n_tiles < cus ? n_tiles : cus);
 }
 
@@ -359,7 +290,7 @@ extern "C" size_t tp_mlp_workspace_bytes(int64_t n_samples) {
 
 extern "C" size_t tp_mlp_saved_bytes(int64_t n_samples) {
   const int64_t groups = ((n_samples + kTileSamples - 1) / kTileSamples) * 4;
-  return (size_t)groups * kSavedSlots * 256 * 32 * sizeof(float);
+  return (size_t)groups * kSavedGroupFloats * sizeof(float);
 }
 
 extern "C" int tp_mlp_fwd(const tp_mlp_fwd_args* a, tp_stream_t stream) {
@@ -377,13 +308,19 @@ extern "C" int tp_mlp_fwd(const tp_mlp_fwd_args* a, tp_stream_t stream) {
   P.rgb = a->rgb; P.density = a->density; P.uncert = a->uncert; P.saved = a->saved; P.workspace = (float*)a->workspace;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)mlp_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+    hipError_t e = hipFuncSetAttribute((const void*)mlp_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        kLdsFloats * (int)sizeof(float));
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void*)mlp_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              kLdsFloats * (int)sizeof(float));
     if (e != hipSuccess) { tp::set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
     attr_set = true;
   }
   const int grid = persistent_grid(P.n_tiles);
-  hipLaunchKernelGGL(mlp_fwd_kernel, dim3(grid), dim3(kThreads), kLdsFloats * sizeof(float), (hipStream_t)stream, P);
+  if (P.saved != nullptr)
+    hipLaunchKernelGGL(mlp_fwd_kernel<true>, dim3(grid), dim3(kThreads), kLdsFloats * sizeof(float), (hipStream_t)stream, P);
+  else
+    hipLaunchKernelGGL(mlp_fwd_kernel<false>, dim3(grid), dim3(kThreads), kLdsFloats * sizeof(float), (hipStream_t)stream, P);
   return tp::check_launch("tp_mlp_fwd");
 }
 

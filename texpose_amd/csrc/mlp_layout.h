@@ -120,3 +120,60 @@ TP_HD int bias_index(int wide, int h, int t, int r) { return ((wide * 2 + h) * 8
 constexpr int kHeadBiasOff = kNumWide * 256;
 
 }  // namespace tp_layout
+
+// ================================================================================================
+// Training record + backward layouts
+// ================================================================================================
+// The forward (train mode) records, per group of 32 consecutive samples (one wave's tile), seven
+// post-ReLU activations and the per-sample non-feature inputs of the rgb head:
+//   block b of group g at   saved + g * kSavedGroupFloats + b * 8192,   [256 features][32 samples]
+//   slot 0: trunk feature   1..3: transient head h0,h1,h2   4..6: rgb head h0,h1,h2
+//   slot 7 (32 rows only): rows 0..26 = [ray_unit, PE(ray_unit)], 27..29 = x   (mlp_rgb.0 columns 256..285)
+//   then the ReLU sign bits of slots 1..6 (what the dgrad kernel needs of them)
+// Inside a 128-byte feature row the eight 16-byte sample quads are XOR-swizzled with (f>>1)&7 so that the
+// weight-gradient GEMM (samples = MFMA k) can ds_read_b128 its A/B fragments from a lane-linear LDS copy
+// of the block without bank conflicts.  The backward writes its dz blocks in the same format.
+namespace tp_layout {
+
+constexpr int kBlockFloats = 8192;                        // [256][32]
+constexpr int kSavedSlots = 7;
+// after the 7 blocks + the narrow block: ReLU masks of slots 1..6 as per-lane bit words,
+// word w (0..3) of slot sl for lane l at kMaskOff + (((sl-1)*4 + w)*64 + l); bit b <-> tile 2w + b/16, register b%16
+constexpr int kMaskOff = kSavedSlots * kBlockFloats + 1024;
+constexpr int kSavedGroupFloats = kMaskOff + 6 * 4 * 64;
+enum { SV_FEAT = 0, SV_T0 = 1, SV_T1 = 2, SV_T2 = 3, SV_R0 = 4, SV_R1 = 5, SV_R2 = 6, SV_EX = 7 };
+
+TP_HD int blk_off(int f, int j) { return f * 32 + ((((j >> 2) ^ ((f >> 1) & 7)) << 2) | (j & 3)); }
+
+// dz record written by the dgrad kernel: per group 6 wide blocks + 2 narrow (32-row) blocks
+//   0: dzT2  1: dzT1  2: dzT0  3: dzR2  4: dzR1  5: dzR0   then  dzT3 (5 rows), dzR3 (3 rows)
+constexpr int kDzGroupFloats = 6 * kBlockFloats + 2 * 1024;
+enum { DZ_T2 = 0, DZ_T1 = 1, DZ_T0 = 2, DZ_R2 = 3, DZ_R1 = 4, DZ_R0 = 5 };
+constexpr int kDzT3Off = 6 * kBlockFloats, kDzR3Off = 6 * kBlockFloats + 1024;
+
+// Transposed weight stream of the dgrad kernel (dh_in = W^T dz_out), same chunk format as the forward:
+//   head T: [W3^T: 1 chunk, 3 k-steps] [W2^T: 8 chunks] [W1^T: 8 chunks]   then the same for head R
+constexpr int kNumChunksT = 34;
+constexpr int64_t kPackedTFloats = (int64_t)kNumChunksT * kChunkFloats;
+
+// (matrix id, ts or -1 for the narrow chunk) of transposed chunk c
+TP_HD void chunkT_desc(int c, int& mat, int& ts, int& rows) {
+  const int head = c / 17, k = c % 17;
+  const int base = head == 0 ? W_TRANS0 : W_RGB0;
+  if (k == 0) { mat = base + 3; ts = -1; rows = head == 0 ? 5 : 3; return; }
+  mat = base + (k <= 8 ? 2 : 1);
+  ts = (k - 1) % 8;
+  rows = 256;
+}
+// source element of packed float idx of transposed chunk c: value = W[mat][o][f]; o<0 => zero
+TP_HD void chunkT_src(int c, int idx, int& mat, int& o, int& f) {
+  int ts, rows;
+  chunkT_desc(c, mat, ts, rows);
+  const int sub = idx & 3, lane = (idx >> 2) & 63, i = lane & 31, h = lane >> 5;
+  const int g = (idx >> 8) & 1, rr = idx >> 9, t = g * 4 + sub;
+  f = 32 * t + i;                                   // output (input-feature) row of this fragment
+  if (ts < 0) { o = 2 * rr + h; if (o >= rows) o = -1; }   // narrow: k-step rr contracts outputs 2rr, 2rr+1
+  else o = feat_of(ts, rr, h);
+}
+
+}  // namespace tp_layout

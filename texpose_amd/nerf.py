@@ -93,6 +93,10 @@ class NeRF(torch.nn.Module):
     def _state(self):
         return {k: v for k, v in self.named_parameters() if k.startswith("mlp_")}
 
+    def head_parameters(self):
+        """(name, parameter) of the trainable heads, in a fixed order shared by forward and backward."""
+        return [(k, p) for k, p in self.named_parameters() if k.startswith(("mlp_rgb", "mlp_trans"))]
+
     def packed_weights(self) -> torch.Tensor:
         """MFMA-ordered weight stream, re-packed lazily: trunk once (frozen), heads when an optimiser step or a
         load_state_dict bumped a parameter version."""

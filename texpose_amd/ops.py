@@ -13,7 +13,8 @@ from typing import Dict, Optional, Tuple
 import torch
 
 from . import _lib
-from ._lib import (CompositeArgs, CompositeBwdArgs, MlpFwdArgs, MlpWeights, PatchGatherArgs, RaygenArgs, check)
+from ._lib import (CompositeArgs, CompositeBwdArgs, MlpBwdArgs, MlpFwdArgs, MlpWeights, PatchGatherArgs, RaygenArgs,
+                   check)
 
 Tensor = torch.Tensor
 
@@ -189,7 +190,11 @@ def mlp_forward(packed: Tensor, lat_trans: Tensor, lat_light: Tensor, *, center:
     rgb = torch.empty(B, R, N, 3, 2, device=dev)
     density = torch.empty(B, R, N, 2, device=dev)
     uncert = torch.empty(B, R, N, 1, device=dev)
-    saved = torch.empty(int(lib.tp_mlp_saved_bytes(S)) // 4, device=dev) if save else None
+    saved = None
+    if save:
+        saved = torch.empty(int(lib.tp_mlp_saved_bytes(S)) // 4, device=dev)
+        if S % 128:        # the weight-gradient GEMM contracts whole 32-sample groups: padding must be zero
+            saved[-(int(lib.tp_mlp_saved_bytes(128)) // 4):].zero_()
     ws = _workspace(S, dev)
     a.packed, a.lat_trans, a.lat_light = packed.data_ptr(), lat_trans.data_ptr(), lat_light.data_ptr()
     a.B, a.R, a.N = B, R, N
@@ -197,6 +202,55 @@ def mlp_forward(packed: Tensor, lat_trans: Tensor, lat_light: Tensor, *, center:
     a.saved, a.workspace = _ptr(saved), ws.data_ptr()
     check(lib.tp_mlp_fwd(C.byref(a), _stream()), "tp_mlp_fwd")
     return (rgb, density, uncert, saved) if save else (rgb, density, uncert)
+
+
+_bwd_scratch: Dict[Tuple[int, int], Dict[str, Tensor]] = {}
+
+
+def mlp_backward(nerf, lat_trans: Tensor, lat_light: Tensor, saved: Tensor, rgb: Tensor, density: Tensor,
+                 uncert: Tensor, g_rgb: Optional[Tensor], g_density: Optional[Tensor], g_uncert: Optional[Tensor]):
+    """Gradients of the two heads and the latent rows.  Returns dict(params=[...] in the order of
+    ``nerf.head_parameters()``, lat_trans=[B,16], lat_light=[B,48])."""
+    lib = _lib.load()
+    B, R, N = rgb.shape[0], rgb.shape[1], rgb.shape[2]
+    if B > 32:
+        raise _lib.TexposeLibraryError("tp_mlp_bwd handles at most 32 images per call")
+    dev = rgb.device
+    S = B * R * N
+    z = lambda like: torch.zeros_like(like)
+    g_rgb = z(rgb) if g_rgb is None else _f32(g_rgb, "g_rgb")
+    g_density = z(density) if g_density is None else _f32(g_density, "g_density")
+    g_uncert = z(uncert) if g_uncert is None else _f32(g_uncert, "g_uncert")
+    names, params = zip(*nerf.head_parameters())
+    grads = [torch.empty_like(p) for p in params]
+    by_name = dict(zip(names, zip(params, grads)))
+    a = MlpBwdArgs()
+    keep = []
+    for i in range(4):
+        for head, wf, gwf, gbf in (("mlp_rgb", a.weights.rgb_w, a.g_rgb_w, a.g_rgb_b),
+                                   ("mlp_trans", a.weights.trans_w, a.g_trans_w, a.g_trans_b)):
+            w, gw = by_name[f"{head}.{i}.weight"]
+            _, gb = by_name[f"{head}.{i}.bias"]
+            w = _f32(w.detach(), "weight")
+            keep.append(w)
+            wf[i], gwf[i], gbf[i] = w.data_ptr(), gw.data_ptr(), gb.data_ptr()
+    key = (dev.index or 0, torch.cuda.current_stream().cuda_stream)
+    sc = _bwd_scratch.setdefault(key, {})
+    if "packed_t" not in sc:
+        sc["packed_t"] = torch.empty(int(lib.tp_mlp_packed_t_bytes()) // 4, device=dev)
+    need = int(lib.tp_mlp_bwd_workspace_bytes(S)) // 4
+    if "ws" not in sc or sc["ws"].numel() < need:
+        sc["ws"] = torch.empty(need, device=dev)
+    lat_trans, lat_light = _f32(lat_trans.detach(), "lat_trans"), _f32(lat_light.detach(), "lat_light")
+    g_lt, g_ll = torch.empty(B, 16, device=dev), torch.empty(B, 48, device=dev)
+    a.packed_t, a.repack = sc["packed_t"].data_ptr(), 1
+    a.saved, a.rgb, a.density, a.uncert = saved.data_ptr(), rgb.data_ptr(), density.data_ptr(), uncert.data_ptr()
+    a.g_rgb, a.g_density, a.g_uncert = g_rgb.data_ptr(), g_density.data_ptr(), g_uncert.data_ptr()
+    a.lat_trans, a.lat_light = lat_trans.data_ptr(), lat_light.data_ptr()
+    a.B, a.R, a.N = B, R, N
+    a.g_lat_trans, a.g_lat_light, a.workspace = g_lt.data_ptr(), g_ll.data_ptr(), sc["ws"].data_ptr()
+    check(lib.tp_mlp_bwd(C.byref(a), _stream()), "tp_mlp_bwd")
+    return dict(params=grads, lat_trans=g_lt, lat_light=g_ll)
 
 
 def posenc(x: Tensor, L: int) -> Tensor:
