@@ -27,7 +27,7 @@ class _Composite(torch.autograd.Function):
             g_out = torch.zeros(*ray.shape[:-1], 14, device=ray.device)
         g_rgb, g_den, g_unc = ops.composite_bwd(ray, rgb, density, depth, uncert, g_out, g_as, g_at, g_prob,
                                                 ctx.min_uncert)
-        return None, g_rgb, g_den, g_unc.view_as(uncert), None, None
+        return None, g_rgb, g_den, None, g_unc.view_as(uncert), None      # (ray, rgb, density, depth, uncert, min_uncert)
 
 
 def composite(ray, rgb, density, depth, uncert, min_uncert):
@@ -37,8 +37,7 @@ def composite(ray, rgb, density, depth, uncert, min_uncert):
 class _Mlp(torch.autograd.Function):
     @staticmethod
     def forward(ctx, nerf, lat_trans, lat_light, center, ray, depth, points, ray_unit, *head_params):
-        need_grad = torch.is_grad_enabled() and (any(p.requires_grad for p in head_params)
-                                                 or lat_trans.requires_grad or lat_light.requires_grad)
+        need_grad = any(ctx.needs_input_grad)      # (grad mode is always off inside Function.forward)
         packed = nerf.packed_weights()
         res = ops.mlp_forward(packed, lat_trans, lat_light, center=center, ray=ray, depth=depth, points=points,
                               ray_unit=ray_unit, save=need_grad)

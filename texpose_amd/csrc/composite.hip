@@ -122,58 +122,74 @@ __global__ __launch_bounds__(kWaves * 64) void composite_fwd_kernel(tp_composite
   }
 }
 
+__device__ __forceinline__ float wave_rev_incl_scan(float v, int lane) {
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const float t = __shfl_down(v, off, 64);
+    if (lane + off < 64) v += t;
+  }
+  return v;
+}
+
+constexpr int kMaxChunks = 32;   // backward supports N <= 2048 samples per ray
+
 // Backward.  With w_i = T_i a_i, T_i = exp(-sum_{j<i} tau_j):  d(sum_i w_i v_i)/d tau_k =
 // T_k exp(-tau_k) v_k - sum_{i>k} w_i v_i, applied to the joint / static-only / transient-only
-// families; the suffix sums are (total - inclusive prefix), so the ray is walked twice.
+// families.  The suffix sums are built by walking the ray BACKWARDS with a reverse wave scan: forming
+// them as (total - prefix) leaves a rounding residue that the 1e10-long last interval multiplies into
+// O(1e3) garbage, whereas the reference's autograd gives the last sample an exactly-zero suffix.
+// Pass 0 walks forward only to record the transmittance carry at each 64-sample chunk start.
 __global__ __launch_bounds__(kWaves * 64) void composite_bwd_kernel(tp_composite_bwd_args b) {
+  __shared__ float s_carry[kWaves][3][kMaxChunks];
   const tp_composite_args& p = b.fwd;
-  const int lane = threadIdx.x & 63;
-  const int64_t wave0 = (int64_t)blockIdx.x * kWaves + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t wave0 = (int64_t)blockIdx.x * kWaves + wv;
   const int64_t stride = (int64_t)gridDim.x * kWaves;
+  const int n_chunks = (p.N + 63) / 64;
   for (int64_t q = wave0; q < p.n; q += stride) {
     const float len = ray_len(p.ray, q);
     float g[14];
 #pragma unroll
     for (int k = 0; k < 14; ++k) g[k] = b.g_out_ray[q * 14 + k];
-    float tot1 = 0.f, tot2 = 0.f, tot3 = 0.f;
-    for (int pass = 0; pass < 2; ++pass) {
-      Carry carry = {0.f, 0.f, 0.f};
-      float run1 = 0.f, run2 = 0.f, run3 = 0.f;  // inclusive prefix carried between chunks
-      for (int base = 0; base < p.N; base += 64) {
-        const int i = base + lane;
-        const bool ok = i < p.N;
-        const int64_t e = q * p.N + (ok ? i : 0);
-        const Sample s = load_sample(p, q, i, lane, len, carry);
-        const float gp = (b.g_prob && ok) ? b.g_prob[e] : 0.f;
-        const float A = g[0] * s.cs[0] + g[1] * s.cs[1] + g[2] * s.cs[2];
-        const float Bv = g[0] * s.ct[0] + g[1] * s.ct[1] + g[2] * s.ct[2] + g[13] * s.u;
-        const float C = g[10] + gp;
-        const float D = g[3] * s.cs[0] + g[4] * s.cs[1] + g[5] * s.cs[2] + g[9] * s.z + g[11];
-        const float E = g[6] * s.ct[0] + g[7] * s.ct[1] + g[8] * s.ct[2] + g[12];
-        const float P1 = s.T * (s.as * A + s.at * Bv + s.a * C);
-        const float P2 = s.Ts * s.as * D;
-        const float P3 = s.Tt * s.at * E;
-        if (pass == 0) {
-          tot1 += P1; tot2 += P2; tot3 += P3;
-          continue;
-        }
-        const float i1 = wave_incl_scan(P1, lane) + run1, i2 = wave_incl_scan(P2, lane) + run2,
-                    i3 = wave_incl_scan(P3, lane) + run3;
-        run1 = __shfl(i1, 63, 64); run2 = __shfl(i2, 63, 64); run3 = __shfl(i3, 63, 64);
-        if (!ok) continue;
-        const float gas = b.g_alpha_static ? b.g_alpha_static[e] : 0.f;
-        const float gat = b.g_alpha_transient ? b.g_alpha_transient[e] : 0.f;
-        const float suf1 = tot1 - i1, suf2 = tot2 - i2, suf3 = tot3 - i3;
-        const float dts = s.T * (s.es * A + s.e * C) - suf1 + s.Ts * s.es * D - suf2 + gas * s.es;
-        const float dtt = s.T * (s.et * Bv + s.e * C) - suf1 + s.Tt * s.et * E - suf3 + gat * s.et;
-        *reinterpret_cast<float2*>(b.g_density + e * 2) = make_float2(dts * s.dist, dtt * s.dist);
-        const float ws = s.T * s.as, wt = s.T * s.at, os = s.Ts * s.as, ot = s.Tt * s.at;
-        float2* gr = reinterpret_cast<float2*>(b.g_rgb + e * 6);
+    Carry carry = {0.f, 0.f, 0.f};
+    for (int c = 0; c < n_chunks; ++c) {
+      if (lane == 0) { s_carry[wv][0][c] = carry.s; s_carry[wv][1][c] = carry.t; s_carry[wv][2][c] = carry.j; }
+      (void)load_sample(p, q, c * 64 + lane, lane, len, carry);
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the wave's own LDS writes are visible to its reads
+    float run1 = 0.f, run2 = 0.f, run3 = 0.f;    // suffix sums carried in from the chunks behind
+    for (int c = n_chunks - 1; c >= 0; --c) {
+      const int i = c * 64 + lane;
+      const bool ok = i < p.N;
+      const int64_t e = q * p.N + (ok ? i : 0);
+      Carry cc = {s_carry[wv][0][c], s_carry[wv][1][c], s_carry[wv][2][c]};
+      const Sample s = load_sample(p, q, i, lane, len, cc);
+      const float gp = (b.g_prob && ok) ? b.g_prob[e] : 0.f;
+      const float A = g[0] * s.cs[0] + g[1] * s.cs[1] + g[2] * s.cs[2];
+      const float Bv = g[0] * s.ct[0] + g[1] * s.ct[1] + g[2] * s.ct[2] + g[13] * s.u;
+      const float C = g[10] + gp;
+      const float D = g[3] * s.cs[0] + g[4] * s.cs[1] + g[5] * s.cs[2] + g[9] * s.z + g[11];
+      const float E = g[6] * s.ct[0] + g[7] * s.ct[1] + g[8] * s.ct[2] + g[12];
+      const float P1 = s.T * (s.as * A + s.at * Bv + s.a * C);     // padding lanes: T = 0 -> 0
+      const float P2 = s.Ts * s.as * D;
+      const float P3 = s.Tt * s.at * E;
+      const float r1 = wave_rev_incl_scan(P1, lane), r2 = wave_rev_incl_scan(P2, lane),
+                  r3 = wave_rev_incl_scan(P3, lane);
+      float suf1 = __shfl_down(r1, 1, 64), suf2 = __shfl_down(r2, 1, 64), suf3 = __shfl_down(r3, 1, 64);
+      if (lane == 63) { suf1 = 0.f; suf2 = 0.f; suf3 = 0.f; }
+      suf1 += run1; suf2 += run2; suf3 += run3;
+      run1 += __shfl(r1, 0, 64); run2 += __shfl(r2, 0, 64); run3 += __shfl(r3, 0, 64);
+      if (!ok) continue;
+      const float gas = b.g_alpha_static ? b.g_alpha_static[e] : 0.f;
+      const float gat = b.g_alpha_transient ? b.g_alpha_transient[e] : 0.f;
+      const float dts = s.T * (s.es * A + s.e * C) - suf1 + s.Ts * s.es * D - suf2 + gas * s.es;
+      const float dtt = s.T * (s.et * Bv + s.e * C) - suf1 + s.Tt * s.et * E - suf3 + gat * s.et;
+      *reinterpret_cast<float2*>(b.g_density + e * 2) = make_float2(dts * s.dist, dtt * s.dist);
+      const float ws = s.T * s.as, wt = s.T * s.at, os = s.Ts * s.as, ot = s.Tt * s.at;
+      float2* gr = reinterpret_cast<float2*>(b.g_rgb + e * 6);
 #pragma unroll
-        for (int c = 0; c < 3; ++c) gr[c] = make_float2(ws * g[c] + os * g[3 + c], wt * g[c] + ot * g[6 + c]);
-        b.g_uncert[e] = wt * g[13];
-      }
-      if (pass == 0) { tot1 = wave_sum(tot1); tot2 = wave_sum(tot2); tot3 = wave_sum(tot3); }
+      for (int ch = 0; ch < 3; ++ch) gr[ch] = make_float2(ws * g[ch] + os * g[3 + ch], wt * g[ch] + ot * g[6 + ch]);
+      b.g_uncert[e] = wt * g[13];
     }
   }
 }
@@ -198,6 +214,7 @@ extern "C" int tp_composite_bwd(const tp_composite_bwd_args* a, tp_stream_t stre
   TP_REQUIRE(a && a->fwd.ray && a->fwd.rgb && a->fwd.density && a->fwd.depth && a->fwd.uncert, "null forward input");
   TP_REQUIRE(a->g_out_ray && a->g_rgb && a->g_density && a->g_uncert, "null gradient pointer");
   TP_REQUIRE(a->fwd.N > 0 && a->fwd.n >= 0, "bad sizes");
+  TP_REQUIRE(a->fwd.N <= 64 * kMaxChunks, "composite backward supports at most 2048 samples per ray");
   if (a->fwd.n == 0) return 0;
   hipLaunchKernelGGL(composite_bwd_kernel, dim3(grid_for(a->fwd.n)), dim3(kWaves * 64), 0, (hipStream_t)stream, *a);
   return tp::check_launch("tp_composite_bwd");
