@@ -1,0 +1,116 @@
+"""CPU, world_size 2, gloo: the data-parallel layer (texpose_amd/dist.py).  Each rank renders its shard of the
+image batch with the CPU oracle (test infrastructure; the HIP kernels need a GPU), back-propagates a per-image
+loss, and the single flat all-reduce must reproduce the gradients of the full batch computed in one process."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+
+from oracle import texpose_oracle as O          # noqa: E402
+from texpose_amd import dist as tdist           # noqa: E402
+
+B, P, N, H, W, N_TRAIN = 4, 3, 4, 12, 12, 6
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _setup(width=32):
+    params = O.make_params(5, width=width)
+    rs = np.random.RandomState(2)
+    emb_t = torch.from_numpy(rs.normal(size=(N_TRAIN, 16)).astype(np.float32))
+    emb_l = torch.from_numpy(rs.normal(size=(N_TRAIN, 48)).astype(np.float32))
+    sc = O.synthetic_scene(H, W, B=B, seed=4)
+    K = sc["intr"].clone()
+    K[:, 0, 0] = K[:, 1, 1] = 700.0 * H / 128.0
+    K[:, 0, 2], K[:, 1, 2] = W / 2.0, H / 2.0
+    coords = torch.from_numpy(rs.uniform(-0.8, 0.8, size=(B, P, P, 2)).astype(np.float32))
+    rand = torch.from_numpy(rs.uniform(size=(B, P * P, N, 1)).astype(np.float32))
+    target = torch.from_numpy(rs.uniform(size=(B, P * P, 3)).astype(np.float32))
+    idx = torch.tensor([1, 4, 0, 3])
+    return params, emb_t, emb_l, sc, K, coords, rand, target, idx
+
+
+def _loss_and_grads(images, params, emb_t, emb_l, sc, K, coords, rand, target, idx, denom):
+    p = {k: v.clone().requires_grad_(not k.startswith("mlp_feat")) for k, v in params.items()}
+    et, el = emb_t.clone().requires_grad_(), emb_l.clone().requires_grad_()
+    sel = torch.tensor(list(images))
+    ret = O.render(p, et, el, sc["pose"][sel], K[sel], coords[sel],
+                   (sc["z_near"][sel][:, :, None], sc["z_far"][sel][:, :, None]), idx[sel], "train", H, W, N,
+                   rand=rand[sel])
+    loss = ((ret["rgb"] - target[sel]) ** 2).sum() / denom + ret["density"][..., 1].sum() / denom
+    loss.backward()
+    named = [(k, v) for k, v in p.items() if v.requires_grad] + [("emb_t", et), ("emb_l", el)]
+    return named
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    r, w, _ = tdist.init_distributed("gloo")
+    assert (r, w) == (rank, world)
+    setup = _setup()
+    shard = tdist.shard_batch(B, rank, world)
+    # per-rank loss is normalised by the LOCAL element count; averaging the ranks' gradients then equals the
+    # full-batch mean because the shards are equal-sized
+    named = _loss_and_grads(shard, *setup, denom=float(len(shard) * P * P))
+    params = [torch.nn.Parameter(v.detach().clone()) for _, v in named]
+    for q, (_, v) in zip(params, named):
+        q.grad = None if v.grad is None else v.grad.clone()
+    if rank == 1:
+        params[0].grad = None                       # a rank without a gradient contributes zeros
+    red = tdist.FlatGradAllReducer(params)
+    red.reduce()
+    bufs = torch.nn.Linear(2, 2)
+    with torch.no_grad():
+        bufs.weight.fill_(float(rank))
+    tdist.broadcast_module_state(bufs, src=0)
+    s = tdist.all_reduce_scalars(torch.tensor(float(rank + 1)), torch.tensor(2.0))
+    torch.save(dict(grads=[q.grad for q in params], nbytes=red.nbytes, w=bufs.weight.clone(), s=s,
+                    first_local=None if rank == 1 else named[0][1].grad.clone()),
+               os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_flat_allreduce_matches_full_batch(tmp_path):
+    world = 2
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r0 = torch.load(tmp_path / "rank0.pt")
+    r1 = torch.load(tmp_path / "rank1.pt")
+    full = _loss_and_grads(range(B), *_setup(), denom=float(B * P * P))
+    assert r0["nbytes"] == sum(v.numel() for _, v in full) * 4
+    for i, ((name, v), g0, g1) in enumerate(zip(full, r0["grads"], r1["grads"])):
+        assert torch.equal(g0, g1), name                      # identical on every rank after the collective
+        if i == 0:
+            torch.testing.assert_close(g0, r0["first_local"] / 2, rtol=1e-6, atol=1e-8)   # rank 1 had None -> zeros
+            continue
+        torch.testing.assert_close(g0, v.grad, rtol=2e-4, atol=1e-6, msg=name)
+    # embedding rows: only the rows of the images some rank rendered are non-zero
+    emb_l_grad = r0["grads"][-1]
+    assert set(torch.nonzero(emb_l_grad.abs().sum(1)).flatten().tolist()) == {0, 1, 3, 4}
+    assert torch.all(r1["w"] == 0) and torch.all(r0["w"] == 0)
+    assert [float(x) for x in r0["s"]] == [3.0, 4.0]
+
+
+def test_shard_batch_partitions():
+    for n in (1, 4, 7, 32, 307200):
+        for world in (1, 2, 3, 8):
+            parts = [tdist.shard_batch(n, r, world) for r in range(world)]
+            flat = [i for p in parts for i in p]
+            assert flat == list(range(n))
+            assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
