@@ -102,7 +102,8 @@ typedef struct tp_mlp_weights {
 /* Size in bytes of the packed (MFMA-fragment-ordered, streaming-ordered) weight image. */
 size_t tp_mlp_packed_bytes(void);
 /* Which parts to (re)pack: the trunk is frozen, the heads change every optimiser step. */
-enum { TP_PACK_TRUNK = 1, TP_PACK_HEADS = 2, TP_PACK_ALL = 3 };
+enum { TP_PACK_TRUNK = 1, TP_PACK_HEADS = 2, TP_PACK_ALL = 3,
+       TP_PACK_F16X3 = 4 /* OR-ed in: build the split-fp16 (hi+lo) stream of the TP_MLP_F16X3 forward; same size */ };
 int tp_mlp_pack(const tp_mlp_weights* w /*host struct of device ptrs*/, int parts, void* packed, tp_stream_t stream);
 /* Same image built on the host from HOST weight pointers (no GPU needed; used by the CPU tests). */
 int tp_mlp_pack_host(const tp_mlp_weights* w_host, float* packed_host);
@@ -127,7 +128,13 @@ typedef struct tp_mlp_fwd_args {
   float* uncert;           /* [B,R,N,1]   out */
   float* saved;            /* optional activations for tp_mlp_bwd (tp_mlp_saved_bytes) or NULL */
   void* workspace;         /* tp_mlp_workspace_bytes */
+  int precision;           /* TP_MLP_FP32 (exact fp32 MFMA) or TP_MLP_F16X3 (packed with TP_PACK_F16X3) */
+  int* status;             /* TP_MLP_F16X3: device word, bit 0 is set if an activation left the fp16 range */
 } tp_mlp_fwd_args;
+/* TP_MLP_F16X3: every fp32 operand is split into hi + lo fp16 (22-bit significand) and hi*hi + hi*lo + lo*hi is
+ * accumulated in fp32 on the f16 matrix cores (16x the fp32-MFMA rate / 3).  Measured error vs an fp64 oracle is
+ * within 1.3x of plain fp32.  Requires |activation| < 6e4; inference (saved == NULL) only. */
+enum { TP_MLP_FP32 = 0, TP_MLP_F16X3 = 1 };
 
 int tp_mlp_fwd(const tp_mlp_fwd_args* args, tp_stream_t stream);
 

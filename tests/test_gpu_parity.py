@@ -444,3 +444,67 @@ def test_losses_and_patch_pipeline_g10(ops):
     pad = torch.logical_and(var.mask_syn_sample == 1, var.mask_sample == 0).float()
     real = torch.cat([var.image_sample * var.mask_sample + rgb_img * pad, var.nocs_sample, var.normal_sample], 1)
     torch.testing.assert_close(real.cpu(), g["patch_real"], rtol=1e-6, atol=1e-7)
+
+
+# ------------------------------------------------------------------------------------------ f16x3 fast path
+def test_mlp_f16x3_matches_oracle(ops):
+    """Split-fp16 forward (hi*hi + hi*lo + lo*hi on the f16 matrix cores): same 1e-4 bar as the fp32 kernel, and
+    its error against an fp64 evaluation stays within 4x of torch-fp32's own error."""
+    rs = np.random.RandomState(3)
+    params = O.make_params(31)
+    cparams = {k: cu(v) for k, v in params.items()}
+    p32 = ops.pack_weights(cparams)
+    p16 = ops.pack_weights(cparams, precision="f16x3")
+    B, R, N = 2, 40, 64
+    pts = torch.from_numpy(rs.uniform(-1.2, 1.2, size=(B, R, N, 3)).astype(np.float32))
+    unit = torch.nn.functional.normalize(torch.from_numpy(rs.normal(size=(B, R, 1, 3)).astype(np.float32)),
+                                         dim=-1).expand(B, R, N, 3).contiguous()
+    lt = torch.from_numpy(rs.normal(size=(B, 16)).astype(np.float32))
+    ll = torch.from_numpy(rs.normal(size=(B, 48)).astype(np.float32))
+    ops.mlp_status(dev()).zero_()
+    out16 = ops.mlp_forward(p16, cu(lt), cu(ll), points=cu(pts), ray_unit=cu(unit), precision="f16x3")
+    out32 = ops.mlp_forward(p32, cu(lt), cu(ll), points=cu(pts), ray_unit=cu(unit))
+    ops.check_mlp_status(dev())
+    with torch.no_grad():
+        ref = O.mlp_forward(params, pts, unit, lt, ll)
+        p64 = {k: v.double() for k, v in params.items()}
+        saved_posenc = O.posenc
+
+        def posenc64(x, L):
+            freq = (2 ** torch.arange(L, dtype=torch.float32)) * np.pi
+            spec = (x.float()[..., None] * freq).double()          # the reference's fp32-rounded argument
+            return torch.stack([spec.sin(), spec.cos()], dim=-2).reshape(*x.shape[:-1], -1)
+        O.posenc = posenc64
+        try:
+            ref64 = O.mlp_forward(p64, pts.double(), unit.double(), lt.double(), ll.double())
+        finally:
+            O.posenc = saved_posenc
+    for a16, a32, r32, r64, name in zip(out16, out32, ref, ref64, ("rgb", "density", "uncert")):
+        torch.testing.assert_close(a16.cpu(), r32, rtol=1e-4, atol=1e-6)
+        e16, e32 = rel_l2(a16, r64), rel_l2(r32, r64)
+        assert e16 < 4 * e32 + 1e-7, (name, e16, e32)
+    # form A + ragged tiles
+    center = torch.from_numpy(rs.uniform(-1, 1, size=(1, 7, 3)).astype(np.float32)) + torch.tensor([0., 0., -8.])
+    ray = torch.from_numpy(rs.normal(scale=0.2, size=(1, 7, 3)).astype(np.float32))
+    ray[..., 2] = 1.0
+    depth = torch.sort(torch.from_numpy(rs.uniform(7, 9, size=(1, 7, 20, 1)).astype(np.float32)), dim=2).values
+    with torch.no_grad():
+        ref = O.forward_samples(params, center, ray, depth, lt[:1], ll[:1])
+    out = ops.mlp_forward(p16, cu(lt[:1]), cu(ll[:1]), center=cu(center), ray=cu(ray), depth=cu(depth), precision="f16x3")
+    for a, r in zip(out, ref):
+        torch.testing.assert_close(a.cpu(), r, rtol=1e-4, atol=1e-6)
+
+
+def test_mlp_f16x3_range_flag(ops):
+    params = O.make_params(31)
+    big = {k: (v * 300.0 if k == "mlp_feat.3.weight" else v) for k, v in params.items()}
+    p16 = ops.pack_weights({k: cu(v) for k, v in big.items()}, precision="f16x3")
+    pts = torch.rand(1, 4, 32, 3) * 2 - 1
+    unit = torch.nn.functional.normalize(torch.randn(1, 4, 1, 3), dim=-1).expand(1, 4, 32, 3).contiguous()
+    ops.mlp_status(dev()).zero_()
+    ops.mlp_forward(p16, cu(torch.zeros(1, 16)), cu(torch.zeros(1, 48)), points=cu(pts), ray_unit=cu(unit),
+                    precision="f16x3")
+    from texpose_amd._lib import TexposeLibraryError
+    with pytest.raises(TexposeLibraryError):
+        ops.check_mlp_status(dev())
+    ops.mlp_status(dev()).zero_()

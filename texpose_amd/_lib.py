@@ -44,7 +44,8 @@ class MlpFwdArgs(C.Structure):
     _fields_ = [("packed", vp), ("center", vp), ("ray", vp), ("depth", vp), ("points", vp),
                 ("ray_unit", vp), ("lat_trans", vp), ("lat_light", vp),
                 ("B", C.c_int), ("R", C.c_int), ("N", C.c_int),
-                ("rgb", vp), ("density", vp), ("uncert", vp), ("saved", vp), ("workspace", vp)]
+                ("rgb", vp), ("density", vp), ("uncert", vp), ("saved", vp), ("workspace", vp),
+                ("precision", C.c_int), ("status", vp)]
 
 
 class MlpBwdArgs(C.Structure):

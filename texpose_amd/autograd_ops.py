@@ -38,9 +38,10 @@ class _Mlp(torch.autograd.Function):
     @staticmethod
     def forward(ctx, nerf, lat_trans, lat_light, center, ray, depth, points, ray_unit, *head_params):
         need_grad = any(ctx.needs_input_grad)      # (grad mode is always off inside Function.forward)
-        packed = nerf.packed_weights()
+        precision = "fp32" if need_grad else nerf.precision
+        packed = nerf.packed_weights(precision)
         res = ops.mlp_forward(packed, lat_trans, lat_light, center=center, ray=ray, depth=depth, points=points,
-                              ray_unit=ray_unit, save=need_grad)
+                              ray_unit=ray_unit, save=need_grad, precision=precision)
         if need_grad:
             rgb, density, uncert, saved = res
             ctx.nerf = nerf

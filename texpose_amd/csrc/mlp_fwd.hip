@@ -282,6 +282,8 @@ int persistent_grid(int64_t n_tiles) {
 
 }  // namespace
 
+int tp_launch_mlp_fwd_f16x3(const tp_mlp_fwd_args* a, int grid, hipStream_t stream);   // mlp_fwd_f16x3.hip
+
 extern "C" size_t tp_mlp_workspace_bytes(int64_t n_samples) {
   const int64_t tiles = (n_samples + kTileSamples - 1) / kTileSamples;
   const int64_t wgs = tiles < 1024 ? tiles : 1024;   // upper bound on the persistent grid
@@ -298,6 +300,12 @@ extern "C" int tp_mlp_fwd(const tp_mlp_fwd_args* a, tp_stream_t stream) {
              "null pointer");
   TP_REQUIRE(a->B > 0 && a->R > 0 && a->N > 0, "bad sizes");
   TP_REQUIRE((a->center && a->ray && a->depth) || (a->points && a->ray_unit), "need (center,ray,depth) or (points,ray_unit)");
+  TP_REQUIRE(a->precision == TP_MLP_FP32 || a->precision == TP_MLP_F16X3, "unknown precision");
+  if (a->precision == TP_MLP_F16X3) {
+    TP_REQUIRE(a->saved == nullptr, "TP_MLP_F16X3 is inference-only (no activation record)");
+    const int64_t tiles = ((int64_t)a->B * a->R * a->N + kTileSamples - 1) / kTileSamples;
+    return tp_launch_mlp_fwd_f16x3(a, persistent_grid(tiles), (hipStream_t)stream);
+  }
   Params P;
   P.packed = (const float*)a->packed;
   P.center = a->center; P.ray = a->ray; P.depth = a->depth; P.points = a->points; P.ray_unit = a->ray_unit;

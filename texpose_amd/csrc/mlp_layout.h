@@ -177,3 +177,49 @@ TP_HD void chunkT_src(int c, int idx, int& mat, int& o, int& f) {
 }
 
 }  // namespace tp_layout
+
+// ================================================================================================
+// f16x3 stream: every fp32 weight is carried as an unevaluated sum hi + lo of two fp16 numbers
+// (22-bit significand) of W * 2^kF16WeightShift; the kernel forms hi*hi + hi*lo + lo*hi on the f16 matrix
+// cores with fp32 accumulation (products of two fp16 are exact in fp32).  Same 115-chunk schedule as the fp32
+// stream; a 32 KiB chunk holds 2 k-steps of 16 features:
+//     half index = ((((s*8 + t)*2 + part)*64 + lane)*8 + j),  part 0 = hi, 1 = lo,
+//     lane = (i = out row in tile t, h),  k (feature within the 16) = 8h + j for "extra" inputs, and
+//     feature 32*ts + 16 s + 8 (j>>2) + 4 h + (j&3) when the B operand is a previous accumulator tile ts
+// (the MFMA C/D register r = 8 s + j of lane half h is row (r&3) + 8 (r>>2) + 4 h).
+// Head chunks hold 16 k-steps of one tile: half index = (((s16*2 + part)*64 + lane)*8 + j).
+// ================================================================================================
+namespace tp_layout {
+
+constexpr int kF16WeightShift = 8;
+constexpr int kChunkHalves = 16384;
+
+TP_HD int acc_feat16(int ts, int s, int h, int j) { return 32 * ts + 16 * s + 8 * (j >> 2) + 4 * h + (j & 3); }
+
+// "extra" inputs in natural column order, 16 per k-step: slot = 16 s' + 8 h + j
+TP_HD int enc_slot_col(int slot) { return slot < 60 ? 3 + slot : (slot < 63 ? slot - 60 : -1); }   // [PE(x) | x | pad]
+TP_HD int x40_slot_col(int slot) { return slot < 78 ? slot : -1; }                                   // natural order
+TP_HD int x8_slot_col(int slot) { return slot < 16 ? slot : -1; }
+
+// (row, col) of the weight matrix for half `idx` (0..16383) of chunk c (part is decoded by the caller)
+TP_HD void chunk16_src(const ChunkDesc& d, int idx, int& part, int& row, int& col) {
+  const int j = idx & 7, lane = (idx >> 3) & 63, i = lane & 31, h = lane >> 5;
+  part = (idx >> 9) & 1;
+  row = -1; col = 0;
+  if (d.kind == CK_HEAD) {
+    const int s16 = idx >> 10;
+    if (i < d.sub) { row = i; col = acc_feat16(s16 >> 1, s16 & 1, h, j); }
+    return;
+  }
+  const int t = (idx >> 10) & 7, s = idx >> 13;
+  int k;
+  if (d.kind == CK_GEN) k = acc_feat16(d.sub, s, h, j);
+  else if (d.kind == CK_ENC) k = enc_slot_col((d.sub * 2 + s) * 16 + 8 * h + j);
+  else if (d.kind == CK_X8) k = s == 0 ? x8_slot_col(8 * h + j) : -1;
+  else k = x40_slot_col((d.sub * 2 + s) * 16 + 8 * h + j);
+  if (k < 0) return;
+  row = d.row_off + 32 * t + i;
+  col = d.col_off + k;
+}
+
+}  // namespace tp_layout

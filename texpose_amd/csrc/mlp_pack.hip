@@ -24,6 +24,21 @@ __global__ void pack_kernel(W w, int chunk0, int chunk1, float* __restrict__ out
   }
 }
 
+// f16x3 stream (mlp_layout.h): hi = fp16(W * 2^shift), lo = fp16(W * 2^shift - hi)
+__global__ void pack16_kernel(W w, int chunk0, int chunk1, _Float16* __restrict__ out) {
+  const int64_t n = (int64_t)(chunk1 - chunk0) * kChunkHalves;
+  const float scale = (float)(1 << kF16WeightShift);
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+    const int c = chunk0 + (int)(e / kChunkHalves), idx = (int)(e % kChunkHalves);
+    const ChunkDesc d = chunk_desc(c);
+    int part, row, col;
+    chunk16_src(d, idx, part, row, col);
+    float v = row < 0 ? 0.0f : w.w[d.mat][(int64_t)row * d.in_dim + col] * scale;
+    const _Float16 hi = (_Float16)v;
+    out[(int64_t)c * kChunkHalves + idx] = part == 0 ? hi : (_Float16)(v - (float)hi);
+  }
+}
+
 __global__ void pack_bias_kernel(W w, int wide0, int wide1, float* __restrict__ out) {
   float* bias = out + (int64_t)kNumChunks * kChunkFloats;
   const int n = (wide1 - wide0) * 256;
@@ -82,7 +97,7 @@ extern "C" size_t tp_mlp_packed_bytes(void) { return (size_t)tp_layout::kPackedF
 
 extern "C" int tp_mlp_pack(const tp_mlp_weights* p, int parts, void* packed, tp_stream_t stream) {
   TP_REQUIRE(p && packed, "null pointer");
-  TP_REQUIRE((parts & ~TP_PACK_ALL) == 0 && parts != 0, "bad parts mask");
+  TP_REQUIRE((parts & ~(TP_PACK_ALL | TP_PACK_F16X3)) == 0 && (parts & TP_PACK_ALL) != 0, "bad parts mask");
   W w;
   for (int i = 0; i < 8; ++i) { w.w[W_FEAT0 + i] = p->feat_w[i]; w.b[W_FEAT0 + i] = p->feat_b[i]; }
   for (int i = 0; i < 4; ++i) {
@@ -96,7 +111,10 @@ extern "C" int tp_mlp_pack(const tp_mlp_weights* p, int parts, void* packed, tp_
   }
   const int c0 = trunk ? 0 : kFirstHeadChunk, c1 = heads ? kNumChunks : kFirstHeadChunk;
   const int w0 = trunk ? 0 : kFirstHeadWide, w1 = heads ? kNumWide : kFirstHeadWide;
-  hipLaunchKernelGGL(pack_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, w, c0, c1, (float*)packed);
+  if (parts & TP_PACK_F16X3)
+    hipLaunchKernelGGL(pack16_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, w, c0, c1, (_Float16*)packed);
+  else
+    hipLaunchKernelGGL(pack_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, w, c0, c1, (float*)packed);
   hipLaunchKernelGGL(pack_bias_kernel, dim3(((w1 - w0) * 256 + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, w0,
                      w1, (float*)packed);
   return tp::check_launch("tp_mlp_pack");

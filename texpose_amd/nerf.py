@@ -54,9 +54,13 @@ class NeRF(torch.nn.Module):
         self.mlp_trans = stack(opt.arch.layers_trans, feat_dim + opt.nerf.N_latent_trans)
         if opt.c2f is not None:
             self.progress = torch.nn.Parameter(torch.tensor(0.))
-        self._packed: Optional[torch.Tensor] = None
-        self._packed_T: Optional[torch.Tensor] = None
-        self._versions = {"trunk": None, "heads": None, "heads_T": None}
+        # inference arithmetic: "f16x3" (split-fp16 products on the f16 matrix cores, fp32-grade accuracy) or
+        # "fp32" (exact fp32 MFMA); training always records activations with the fp32 kernel
+        self.precision = opt.arch.get("mlp_precision", "f16x3")
+        if self.precision not in ops.PRECISIONS:
+            raise ValueError("arch.mlp_precision must be one of %s" % list(ops.PRECISIONS))
+        self._packed = {}
+        self._versions = {}
 
     # ------------------------------------------------------------------ construction helpers
     @classmethod
@@ -97,24 +101,26 @@ class NeRF(torch.nn.Module):
         """(name, parameter) of the trainable heads, in a fixed order shared by forward and backward."""
         return [(k, p) for k, p in self.named_parameters() if k.startswith(("mlp_rgb", "mlp_trans"))]
 
-    def packed_weights(self) -> torch.Tensor:
-        """MFMA-ordered weight stream, re-packed lazily: trunk once (frozen), heads when an optimiser step or a
-        load_state_dict bumped a parameter version."""
+    def packed_weights(self, precision: str = "fp32") -> torch.Tensor:
+        """MFMA-ordered weight stream for ``precision``, re-packed lazily: trunk once (frozen), heads when an
+        optimiser step or a load_state_dict bumped a parameter version."""
         st = self._state()
         vt = tuple((p.data_ptr(), p._version) for k, p in st.items() if k.startswith("mlp_feat"))
         vh = tuple((p.data_ptr(), p._version) for k, p in st.items() if not k.startswith("mlp_feat"))
         dev = next(self.parameters()).device
-        if self._packed is None or self._packed.device != dev:
-            self._packed = torch.empty(ops.packed_bytes() // 4, device=dev)
-            self._versions["trunk"] = self._versions["heads"] = None
+        buf = self._packed.get(precision)
+        if buf is None or buf.device != dev:
+            buf = self._packed[precision] = torch.empty(ops.packed_bytes() // 4, device=dev)
+            self._versions[precision] = [None, None]
+        ver = self._versions[precision]
         with torch.no_grad():
-            if self._versions["trunk"] != vt:
-                ops.pack_weights(st, packed=self._packed, parts=ops.PACK_TRUNK)
-                self._versions["trunk"] = vt
-            if self._versions["heads"] != vh:
-                ops.pack_weights(st, packed=self._packed, parts=ops.PACK_HEADS)
-                self._versions["heads"] = vh
-        return self._packed
+            if ver[0] != vt:
+                ops.pack_weights(st, packed=buf, parts=ops.PACK_TRUNK, precision=precision)
+                ver[0] = vt
+            if ver[1] != vh:
+                ops.pack_weights(st, packed=buf, parts=ops.PACK_HEADS, precision=precision)
+                ver[1] = vh
+        return buf
 
     # ------------------------------------------------------------------ reference API
     def forward(self, opt, points_3D, ray_unit=None, latent_variable_trans=None, latent_variable_light=None,

@@ -21,7 +21,9 @@ Tensor = torch.Tensor
 PIX_COORDS, PIX_INDEX = 0, 1
 BOUNDS_MAP, BOUNDS_AABB, BOUNDS_NONE = 0, 1, 2
 JITTER_MID, JITTER_GIVEN, JITTER_PHILOX = 0, 1, 2
-PACK_TRUNK, PACK_HEADS, PACK_ALL = 1, 2, 3
+PACK_TRUNK, PACK_HEADS, PACK_ALL, PACK_F16X3 = 1, 2, 3, 4
+MLP_FP32, MLP_F16X3 = 0, 1
+PRECISIONS = {"fp32": MLP_FP32, "f16x3": MLP_F16X3}
 
 COMPOSITE_RAY_FIELDS = (("rgb", 0, 3), ("rgb_static", 3, 6), ("rgb_transient", 6, 9), ("depth", 9, 10),
                         ("opacity", 10, 11), ("opacity_static", 11, 12), ("opacity_transient", 12, 13),
@@ -131,8 +133,9 @@ def packed_bytes() -> int:
 
 
 def pack_weights(state: Dict[str, Tensor], packed: Optional[Tensor] = None, parts: int = PACK_ALL,
-                 prefix: str = "") -> Tensor:
-    """state: reference state-dict style mapping (``mlp_feat.0.weight`` ...) of CUDA tensors."""
+                 prefix: str = "", precision: str = "fp32") -> Tensor:
+    """state: reference state-dict style mapping (``mlp_feat.0.weight`` ...) of CUDA tensors.
+    precision 'f16x3' builds the split-fp16 stream for the fast forward (same size)."""
     lib = _lib.load()
     w = MlpWeights()
     keep = []
@@ -151,7 +154,8 @@ def pack_weights(state: Dict[str, Tensor], packed: Optional[Tensor] = None, part
     dev = keep[0].device
     if packed is None:
         packed = torch.empty(packed_bytes() // 4, device=dev)
-    check(lib.tp_mlp_pack(C.byref(w), parts, packed.data_ptr(), _stream()), "tp_mlp_pack")
+    flags = parts | (PACK_F16X3 if PRECISIONS[precision] == MLP_F16X3 else 0)
+    check(lib.tp_mlp_pack(C.byref(w), flags, packed.data_ptr(), _stream()), "tp_mlp_pack")
     return packed
 
 
@@ -168,10 +172,29 @@ def _workspace(n_samples: int, dev: torch.device) -> Tensor:
     return ws
 
 
+_status_words: Dict[int, Tensor] = {}
+
+
+def mlp_status(device) -> Tensor:
+    """int32 device word; bit 0 is raised by the f16x3 forward if an activation left the fp16 range."""
+    key = torch.device(device).index or 0
+    if key not in _status_words:
+        _status_words[key] = torch.zeros(1, dtype=torch.int32, device=device)
+    return _status_words[key]
+
+
+def check_mlp_status(device) -> None:
+    """Host-synchronising check of the f16x3 range flag (call it outside the hot loop)."""
+    if int(mlp_status(device).item()) & 1:
+        raise _lib.TexposeLibraryError("f16x3 MLP: an activation exceeded the fp16 range (6e4); render with "
+                                       "precision='fp32'")
+
+
 def mlp_forward(packed: Tensor, lat_trans: Tensor, lat_light: Tensor, *, center: Optional[Tensor] = None,
                 ray: Optional[Tensor] = None, depth: Optional[Tensor] = None, points: Optional[Tensor] = None,
-                ray_unit: Optional[Tensor] = None, save: bool = False):
-    """Returns rgb [B,R,N,3,2], density [B,R,N,2], uncert [B,R,N,1] (+ saved activations if save)."""
+                ray_unit: Optional[Tensor] = None, save: bool = False, precision: str = "fp32"):
+    """Returns rgb [B,R,N,3,2], density [B,R,N,2], uncert [B,R,N,1] (+ saved activations if save).
+    ``packed`` must have been built with the same ``precision``."""
     lib = _lib.load()
     a = MlpFwdArgs()
     if center is not None:
@@ -200,6 +223,11 @@ def mlp_forward(packed: Tensor, lat_trans: Tensor, lat_light: Tensor, *, center:
     a.B, a.R, a.N = B, R, N
     a.rgb, a.density, a.uncert = rgb.data_ptr(), density.data_ptr(), uncert.data_ptr()
     a.saved, a.workspace = _ptr(saved), ws.data_ptr()
+    a.precision = PRECISIONS[precision]
+    if a.precision == MLP_F16X3:
+        if save:
+            raise _lib.TexposeLibraryError("the f16x3 forward is inference-only; train with precision='fp32'")
+        a.status = mlp_status(dev).data_ptr()
     check(lib.tp_mlp_fwd(C.byref(a), _stream()), "tp_mlp_fwd")
     return (rgb, density, uncert, saved) if save else (rgb, density, uncert)
 
