@@ -26,7 +26,9 @@ sys.path.insert(0, REPO)
 
 H, W, N_SAMPLES = 480, 640, 128
 MLP_FLOP_PER_SAMPLE = 1_821_184          # 2 x 910,592 MAC
-FP32_MFMA_PEAK_TFLOPS = 157.3            # MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
+# dense MFMA peaks (MI355X_MICROARCH.md): exact-fp32 v_mfma_f32_32x32x2_f32, and f16 v_mfma_f32_32x32x16_f16
+MFMA_PEAK_TFLOPS = {"fp32": 157.3, "f16x3": 2500.0}
+ISSUED_PER_ALGORITHMIC = {"fp32": 1, "f16x3": 3}    # f16x3 issues hi*hi + hi*lo + lo*hi per product
 
 
 def build_scene(device, seed):
@@ -39,7 +41,7 @@ def build_scene(device, seed):
     return sc, params, emb_t, emb_l
 
 
-def make_graph(device, params, emb_t, emb_l):
+def make_graph(device, params, emb_t, emb_l, precision=None):
     from texpose_amd.graph import Graph
     from texpose_amd.options import default_options
     opt = default_options(H=H, W=W, device=str(device))
@@ -51,6 +53,8 @@ def make_graph(device, params, emb_t, emb_l):
     with torch.no_grad():
         g.latent_vars_trans.weight.copy_(emb_t)
         g.latent_vars_light.weight.copy_(emb_l)
+    if precision is not None:
+        g.nerf.precision = precision
     g.eval()
     return g, opt
 
@@ -100,6 +104,9 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", choices=["f16x3", "fp32"], default="f16x3",
+                    help="MLP arithmetic: f16x3 = split-fp16 products on the f16 matrix cores (fp32-grade accuracy, "
+                         "default); fp32 = exact fp32 MFMA")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -115,7 +122,7 @@ def main():
         dist.init_process_group("nccl", device_id=device)
 
     sc, params, emb_t, emb_l = build_scene(device, seed=rank)       # one image per rank
-    graph, opt = make_graph(device, params, emb_t, emb_l)
+    graph, opt = make_graph(device, params, emb_t, emb_l, args.precision)
     pose, intr = sc["pose"].to(device), sc["intr"].to(device)
     dr = (sc["z_near"].to(device)[:, :, None], sc["z_far"].to(device)[:, :, None])
     mask = torch.ones(1, H, W, device=device)
@@ -163,8 +170,36 @@ def main():
     launches_per_step = len(mlp_events) / args.steps
     samples_per_launch = H * W * N_SAMPLES / launches_per_step
 
+    def roofline(precision, ms, samples):
+        achieved = MLP_FLOP_PER_SAMPLE * samples / (ms * 1e-3) / 1e12
+        peak = MFMA_PEAK_TFLOPS[precision]
+        k = ISSUED_PER_ALGORITHMIC[precision]
+        return {"kernel": "mlp_fwd_kernel" if precision == "fp32" else "mlp_fwd_f16x3_kernel", "bound": "mfma",
+                "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
+                "kernel_ms": ms, "samples_per_launch": samples, "flop_per_sample": MLP_FLOP_PER_SAMPLE,
+                "mfma_issued_per_algorithmic": k, "issued_frac": k * achieved / peak,
+                "note": "achieved = ALGORITHMIC FLOP / HIP-event time; f16x3 issues 3 f16 MFMAs per algorithmic product"}
+
+    # secondary leg (outside the timed region, rank 0 only): the exact-fp32 kernel on the same image
+    exact = None
+    if rank == 0 and world == 1 and args.precision != "fp32":
+        graph.nerf.precision = "fp32"
+        step()
+        ev = []
+        ops.mlp_forward = lambda *a, **k: (ev.append(torch.cuda.Event(enable_timing=True)) or ev[-1].record()) or \
+            _record_after(orig_mlp(*a, **k), ev)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        step()
+        torch.cuda.synchronize()
+        dt1 = time.perf_counter() - t1
+        ops.mlp_forward = orig_mlp
+        graph.nerf.precision = args.precision
+        ms1 = float(np.mean([ev[i].elapsed_time(ev[i + 1]) for i in range(0, len(ev), 2)]))
+        exact = {"value": H * W / dt1, "unit": "rays/s", "roofline": roofline("fp32", ms1, H * W * N_SAMPLES / (len(ev) / 2))}
+    ops.check_mlp_status(device)
+
     if rank == 0:
-        achieved = MLP_FLOP_PER_SAMPLE * samples_per_launch / (mlp_ms * 1e-3) / 1e12
         line = {
             "metric": "rendered rays/sec (480x640x128 samples)",
             "value": world * H * W * args.steps / dt,
@@ -176,23 +211,30 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32" if args.precision == "fp32" else "f32 carried as 2xf16 (f16x3 products, f32 accumulate)",
             "data": "synthetic",
             "config": {"workload": "Duck-like synthetic scene 480x640, 128 samples/ray, batch=1 image per GPU, "
                                    "forward render (render_by_slices mode='val', all pixels), per-sample outputs "
                                    "materialised", "rays_per_step_per_gpu": H * W, "samples_per_ray": N_SAMPLES,
+                       "mlp_precision": args.precision,
                        "parallelism": "images sharded across %d GPU(s), no collective" % world},
-            "roofline": {"kernel": "mlp_fwd_kernel", "bound": "mfma", "achieved": achieved,
-                         "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
-                         "traffic": None, "kernel_ms": mlp_ms, "samples_per_launch": samples_per_launch,
-                         "flop_per_sample": MLP_FLOP_PER_SAMPLE},
+            "roofline": roofline(args.precision, mlp_ms, samples_per_launch),
         }
+        if exact is not None:
+            line["exact_fp32_kernel"] = exact
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(sc, params, emb_t, emb_l)
             line["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]
         print(json.dumps(line))
     if world > 1:
         torch.distributed.destroy_process_group()
+
+
+def _record_after(out, ev):
+    e = torch.cuda.Event(enable_timing=True)
+    e.record()
+    ev.append(e)
+    return out
 
 
 if __name__ == "__main__":

@@ -497,7 +497,7 @@ def test_mlp_f16x3_matches_oracle(ops):
 
 def test_mlp_f16x3_range_flag(ops):
     params = O.make_params(31)
-    big = {k: (v * 300.0 if k == "mlp_feat.3.weight" else v) for k, v in params.items()}
+    big = {k: (v * 300.0 if k in ("mlp_feat.2.weight", "mlp_feat.3.weight") else v) for k, v in params.items()}
     p16 = ops.pack_weights({k: cu(v) for k, v in big.items()}, precision="f16x3")
     pts = torch.rand(1, 4, 32, 3) * 2 - 1
     unit = torch.nn.functional.normalize(torch.randn(1, 4, 1, 3), dim=-1).expand(1, 4, 32, 3).contiguous()

@@ -36,8 +36,7 @@ def composite(ray, rgb, density, depth, uncert, min_uncert):
 
 class _Mlp(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, nerf, lat_trans, lat_light, center, ray, depth, points, ray_unit, *head_params):
-        need_grad = any(ctx.needs_input_grad)      # (grad mode is always off inside Function.forward)
+    def forward(ctx, nerf, need_grad, lat_trans, lat_light, center, ray, depth, points, ray_unit, *head_params):
         precision = "fp32" if need_grad else nerf.precision
         packed = nerf.packed_weights(precision)
         res = ops.mlp_forward(packed, lat_trans, lat_light, center=center, ray=ray, depth=depth, points=points,
@@ -55,9 +54,12 @@ class _Mlp(torch.autograd.Function):
         lat_trans, lat_light, saved, rgb, density, uncert = ctx.saved_tensors
         grads = ops.mlp_backward(ctx.nerf, lat_trans, lat_light, saved, rgb, density, uncert, g_rgb, g_density,
                                  g_uncert)
-        return (None, grads["lat_trans"], grads["lat_light"], None, None, None, None, None) + tuple(grads["params"])
+        return (None, None, grads["lat_trans"], grads["lat_light"], None, None, None, None, None) + tuple(grads["params"])
 
 
 def mlp(nerf, lat_trans, lat_light, center=None, ray=None, depth=None, points=None, ray_unit=None):
     head_params = [p for _, p in nerf.head_parameters()]
-    return _Mlp.apply(nerf, lat_trans, lat_light, center, ray, depth, points, ray_unit, *head_params)
+    # decided here: inside Function.forward grad mode is always off and needs_input_grad ignores no_grad()
+    need_grad = torch.is_grad_enabled() and (lat_trans.requires_grad or lat_light.requires_grad
+                                             or any(p.requires_grad for p in head_params))
+    return _Mlp.apply(nerf, need_grad, lat_trans, lat_light, center, ray, depth, points, ray_unit, *head_params)

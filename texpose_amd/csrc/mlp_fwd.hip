@@ -126,7 +126,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_kernel(Params P) {
       const int c = r / 10;
       const float xc = c == 0 ? x[0] : (c == 1 ? x[1] : x[2]);
       const float arg = tp::mul_rn(xc, ldexpf(3.14159274101257324f, r - c * 10));
-      enc_lds[r * kThreads] = hh ? cosf(arg) : sinf(arg);
+      enc_lds[r * kThreads] = tp::sincos_sel(arg, hh);
     }
     enc_lds[30 * kThreads] = hh ? x[1] : x[0];
     enc_lds[31 * kThreads] = hh ? 0.0f : x[2];
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_kernel(Params P) {
           const int c = r >> 2;
           const float vc = c == 0 ? vu[0] : (c == 1 ? vu[1] : vu[2]);
           const float arg = tp::mul_rn(vc, ldexpf(3.14159274101257324f, r & 3));
-          ex_lds[r * kThreads] = hh ? cosf(arg) : sinf(arg);
+          ex_lds[r * kThreads] = tp::sincos_sel(arg, hh);
         }
         ex_lds[12 * kThreads] = hh ? vu[1] : vu[0];
         ex_lds[13 * kThreads] = hh ? x[0] : vu[2];
@@ -270,7 +270,7 @@ __global__ void posenc_kernel(const float* __restrict__ x, int64_t n, int C, int
     const int l = (int)(e % L), sc = (int)((e / L) % 2), c = (int)((e / (2 * L)) % C);
     const int64_t i = e / (2 * L * C);
     const float arg = tp::mul_rn(x[i * C + c], ldexpf(3.14159274101257324f, l));
-    out[e] = sc ? cosf(arg) : sinf(arg);
+    out[e] = tp::sincos_sel(arg, sc);
   }
 }
 
