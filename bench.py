@@ -132,13 +132,15 @@ def main():
     mlp_events = []
     orig_mlp = ops.mlp_forward
 
-    def timed_mlp(*a, **k):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        out = orig_mlp(*a, **k)
-        e1.record()
-        mlp_events.append((e0, e1))
-        return out
+    def timing_into(store):
+        def timed_mlp(*a, **k):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = orig_mlp(*a, **k)
+            e1.record()
+            store.append((e0, e1))
+            return out
+        return timed_mlp
 
     def step():
         with torch.no_grad():
@@ -152,7 +154,7 @@ def main():
 
     for _ in range(args.warmup):
         ret = step()
-    ops.mlp_forward = timed_mlp
+    ops.mlp_forward = timing_into(mlp_events)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -186,8 +188,7 @@ def main():
         graph.nerf.precision = "fp32"
         step()
         ev = []
-        ops.mlp_forward = lambda *a, **k: (ev.append(torch.cuda.Event(enable_timing=True)) or ev[-1].record()) or \
-            _record_after(orig_mlp(*a, **k), ev)
+        ops.mlp_forward = timing_into(ev)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         step()
@@ -195,8 +196,8 @@ def main():
         dt1 = time.perf_counter() - t1
         ops.mlp_forward = orig_mlp
         graph.nerf.precision = args.precision
-        ms1 = float(np.mean([ev[i].elapsed_time(ev[i + 1]) for i in range(0, len(ev), 2)]))
-        exact = {"value": H * W / dt1, "unit": "rays/s", "roofline": roofline("fp32", ms1, H * W * N_SAMPLES / (len(ev) / 2))}
+        ms1 = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+        exact = {"value": H * W / dt1, "unit": "rays/s", "roofline": roofline("fp32", ms1, H * W * N_SAMPLES / len(ev))}
     ops.check_mlp_status(device)
 
     if rank == 0:
@@ -228,13 +229,6 @@ def main():
         print(json.dumps(line))
     if world > 1:
         torch.distributed.destroy_process_group()
-
-
-def _record_after(out, ev):
-    e = torch.cuda.Event(enable_timing=True)
-    e.record()
-    ev.append(e)
-    return out
 
 
 if __name__ == "__main__":

@@ -15,7 +15,6 @@
 // An accumulator tile is reused as the next layer's B operand exactly as in the fp32 kernel: registers
 // 8s..8s+7 of a 32x32 tile, converted to fp16, ARE the B fragment of k-step s (rows 16s + 8(j>>2) + 4h + (j&3)),
 // and the packed weights absorb that row permutation (mlp_layout.h, "f16x3 stream").
-#include <stdlib.h>
 #include "mlp_mma.h"
 
 namespace {
@@ -54,7 +53,6 @@ struct XF {
 // outstanding, everything older -- chunk c+1 -- has landed) + raw s_barrier; __syncthreads() would drain vmcnt(0).
 
 __device__ __forceinline__ void ring_begin(Pipe& p) {
-  if (p.abl & 1) return;
   int nxt = p.chunk + 2;
   if (nxt >= kNumChunks) nxt -= kNumChunks;
   int slot = p.buf + 2;
@@ -62,10 +60,8 @@ __device__ __forceinline__ void ring_begin(Pipe& p) {
   dma_chunk(p, nxt, slot);
 }
 __device__ __forceinline__ void ring_end(Pipe& p) {
-  if (!(p.abl & 2)) {
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-  }
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   p.chunk = (p.chunk + 1 == kNumChunks) ? 0 : p.chunk + 1;
   p.buf = (p.buf + 1 == kBufs) ? 0 : p.buf + 1;
@@ -161,7 +157,7 @@ struct Params {
   const float* lat_trans; const float* lat_light;
   int B, R, N;
   int64_t n_samples, n_tiles;
-  float* rgb; float* density; float* uncert; float* workspace; int* status; int abl;
+  float* rgb; float* density; float* uncert; float* workspace; int* status;
 };
 
 // stage one "extra input" value as hi/lo halves: slot = 16 ks + 8 h + j of this lane
@@ -179,7 +175,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_f16x3_kernel(Params P) {
   _Float16* st = reinterpret_cast<_Float16*>(bias_lds + kBiasPad);
 
   Pipe p;
-  p.stream = P.packed; p.lds = lds; p.chunk = 0; p.buf = 0; p.wave = wave; p.lane = lane; p.abl = P.abl;
+  p.stream = P.packed; p.lds = lds; p.chunk = 0; p.buf = 0; p.wave = wave; p.lane = lane;
   for (int i = tid; i < kBiasFloats; i += kThreads) bias_lds[i] = P.packed[(size_t)kNumChunks * kChunkFloats + i];
   dma_chunk(p, 0, 0);
   dma_chunk(p, 1, 1);
@@ -305,7 +301,6 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_f16x3_kernel(Params P) {
       // subnormal grid costs < 6e-8 absolute), lo = v - hi is exact in fp32; both are packed with
       // v_cvt_pkrtz_f16_f32 (hi converts exactly, lo keeps 11 more bits).
       const float* bl = bias_lds + (li * 2 + hh) * 128;
-      if (!((P.abl & 4) && li > 0))
 #pragma unroll
       for (int t = 0; t < 8; ++t)
 #pragma unroll
@@ -382,8 +377,6 @@ int tp_launch_mlp_fwd_f16x3(const tp_mlp_fwd_args* a, int grid, hipStream_t stre
   P.n_samples = (int64_t)a->B * a->R * a->N;
   P.n_tiles = (P.n_samples + 127) / 128;
   P.rgb = a->rgb; P.density = a->density; P.uncert = a->uncert; P.workspace = (float*)a->workspace; P.status = a->status;
-  const char* abl = getenv("TP_ABL");
-  P.abl = abl ? atoi(abl) : 0;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)mlp_fwd_f16x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);

@@ -25,7 +25,6 @@ struct Pipe {
   int chunk;            // chunk resident in buffer `buf`
   int buf;
   int wave, lane;
-  int abl = 0;          // profiling ablation bits (0 in production)
 };
 
 __device__ __forceinline__ void dma_chunk(const Pipe& p, int chunk, int buf) {
