@@ -1,0 +1,80 @@
+"""One GAN training iteration of the adapt_st_gan stage on the HIP path, following the reference's
+``Model.train_iteration`` (model/nerf_adapt_st_gan.py:108-202): patch coordinates -> nerf step (render,
+gathers, discriminator on the fake patch, photometric / uncertainty / transient / feature / GAN losses,
+Adam) -> discriminator step (real + R1 penalty + fake, RMSprop).  Used by bench.py and the tests; the
+reference's own engine runs unchanged against texpose_amd.graph.Graph.
+
+Data parallel: pass ``world_size > 1`` after texpose_amd.dist.init_distributed(); gradients of each
+optimiser are averaged with ONE flat all-reduce after all backward calls of that step.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import dist as tdist
+from .graph import Graph, summarize_loss
+from .options import AttrDict
+
+
+class GanTrainer:
+    def __init__(self, opt, graph: Graph, n_train: int, max_iter: int = 6000 * 189 // 8):
+        self.opt, self.graph, self.max_iter, self.it = opt, graph, max_iter, 0
+        if not hasattr(graph, "latent_vars_trans"):
+            graph.attach_latents(n_train, opt)
+        nerf_params = [p for p in graph.nerf.parameters() if p.requires_grad]
+        self.nerf_group = nerf_params + list(graph.latent_vars_light.parameters()) + \
+            list(graph.latent_vars_trans.parameters())
+        self.optim_nerf = torch.optim.Adam([dict(params=nerf_params, lr=opt.optim.lr),
+                                            dict(params=graph.latent_vars_light.parameters(), lr=opt.optim.lr),
+                                            dict(params=graph.latent_vars_trans.parameters(), lr=opt.optim.lr)])
+        self.has_disc = hasattr(graph, "discriminator") and opt.gan is not None
+        if self.has_disc:
+            self.disc_group = [p for p in graph.discriminator.parameters()]
+            self.optim_disc = torch.optim.RMSprop([dict(params=self.disc_group, lr=opt.optim_disc.lr)])
+        self.red_nerf = tdist.FlatGradAllReducer(self.nerf_group)
+        self.red_disc = tdist.FlatGradAllReducer(self.disc_group) if self.has_disc else None
+
+    @staticmethod
+    def _toggle(module, flag):
+        for p in module.parameters():
+            p.requires_grad_(flag)
+
+    def nerf_step(self, var):
+        opt, g = self.opt, self.graph
+        if self.has_disc:
+            self._toggle(g.discriminator, False)
+        self.optim_nerf.zero_grad(set_to_none=True)
+        var = g.nerf_forward(opt, var, mode="train")
+        loss = summarize_loss(opt, g.compute_loss(opt, var, mode="train", train_step="nerf"))
+        loss.all.backward()
+        self.red_nerf.reduce()
+        self.optim_nerf.step()
+        return var, loss
+
+    def disc_step(self, var):
+        opt, g = self.opt, self.graph
+        self._toggle(g.discriminator, True)
+        self.optim_disc.zero_grad(set_to_none=True)
+        var = g.disc_forward(opt, var, mode="train")
+        loss = g.compute_loss(opt, var, mode="train", train_step="disc")
+        w = lambda k: 10 ** float(opt.loss_weight[k])
+        (w("gan_disc_real") * loss.gan_disc_real).backward(retain_graph=True)
+        if opt.loss_weight.gan_reg_real is not None:          # R1: double backward through the discriminator
+            reg = g.compute_grad2(opt, var.d_real_disc, var.patch_real).mean()
+            (w("gan_reg_real") * reg).backward()
+            loss.gan_reg_real = reg.detach()
+        (w("gan_disc_fake") * loss.gan_disc_fake).backward()
+        self.red_disc.reduce()
+        self.optim_disc.step()
+        return var, loss
+
+    def train_iteration(self, var: AttrDict):
+        var = self.graph.get_ray_idx(self.opt, var)
+        var, loss = self.nerf_step(var)
+        if self.has_disc:
+            var, dloss = self.disc_step(var)
+            loss.update({k: v for k, v in dloss.items() if k != "all"})
+            self.graph.discriminator.progress.data.fill_(self.it / self.max_iter)
+        self.it += 1
+        self.graph.patch_sampler.iterations = self.it
+        return var, loss

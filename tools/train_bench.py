@@ -1,0 +1,40 @@
+"""GPU box: training iterations / s of the full GAN loop (config C3: B images, 16x16 patches of 128x128 crops, N=64)."""
+import os, sys, time, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from texpose_amd.gan_modules import Discriminator, PerceptualLoss
+from texpose_amd.graph import Graph
+from texpose_amd.options import default_options, AttrDict
+from texpose_amd.synthetic import training_batch
+from texpose_amd.trainer import GanTrainer
+
+
+def run(B=4, iters=20, warm=3, full=True, device="cuda:0"):
+    torch.manual_seed(0)
+    opt = default_options(H=128, W=128, device=device)
+    opt.batch_size, opt.patch_size, opt.nerf.sample_intvs = B, 16, 64
+    if not full:
+        opt.loss_weight.feat = None
+        opt.loss_weight.gan_nerf = None
+        opt.gan = None
+    graph = Graph(opt, discriminator=Discriminator(opt) if full else None,
+                  perceptual_loss=PerceptualLoss() if full else None).to(device)
+    tr = GanTrainer(opt, graph, n_train=189)
+    var = training_batch(B, 128, 128, device=device)
+    for _ in range(warm):
+        tr.train_iteration(AttrDict(dict(var)))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        tr.train_iteration(AttrDict(dict(var)))
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / iters
+    return dict(iters_per_s=1 / dt, ms_per_iter=dt * 1e3, batch=B, rays_per_iter=B * 256, samples_per_iter=B * 256 * 64,
+                loop="full GAN (render fwd+bwd, gathers, random-init VGG19[:15] feature loss, PatchGAN + R1, Adam + RMSprop)"
+                if full else "nerf step only (render fwd+bwd, photometric/uncert/trans_reg losses, Adam)")
+
+
+if __name__ == "__main__":
+    for B in (4, 32):
+        for full in (True, False):
+            print(json.dumps(run(B=B, full=full)))
