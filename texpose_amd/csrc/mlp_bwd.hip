@@ -17,8 +17,8 @@
 //     linearity everything that multiplies a per-image latent) and, for mlp_rgb.0, the recorded
 //     [view encoding, x] columns.
 //  3. mlp_wgrad_finalize -- fixed-order reduction of the split-K partials into the reference
-//     parameter layouts (deterministic: no float atomics), plus the latent-row gradients
-//     dlat[b] = W0[:,latent cols]^T (sum_{s in b} dz0[:,s]).
+//     parameter layouts (deterministic: no float atomics); mlp_latent_grad then forms the latent-row
+//     gradients dlat[b] = W0[:,latent cols]^T (sum_{s in b} dz0[:,s]), one wave per element.
 #include "mlp_mma.h"
 
 namespace {
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_wgrad_kernel(WgParams P) {
 }
 
 // ------------------------------------------------------------------------------------------------
-enum { SEG_W = 0, SEG_B = 1, SEG_LAT = 2 };
+enum { SEG_W = 0, SEG_B = 1, SEG_DZSUM = 2 };
 struct Seg {
   float* out;
   int kind, gemm;      // gemm 0..5 wide (T2,T1,T0,R2,R1,R0), 6 = T3, 7 = R3
@@ -226,7 +226,7 @@ struct Seg {
   int64_t start;       // prefix offset in the flattened element space
 };
 struct FinParams {
-  Seg seg[18];
+  Seg seg[20];
   int n_seg; int64_t total;
   const float* partial; int n_slices; int B;
   const float* lat_trans; const float* lat_light;   // [B,16], [B,48]
@@ -263,13 +263,31 @@ __global__ void mlp_wgrad_finalize(FinParams P) {
       }
     } else if (sg.kind == SEG_B) {
       for (int b = 0; b < P.B; ++b) v += part_sum(P, sg.gemm, (int)le, 8, b);
-    } else {
-      const int b = (int)(le / sg.cols), c = (int)(le % sg.cols);
-      if (sg.gemm == 2) { for (int o = 0; o < 256; ++o) v += P.w_t0[o * 272 + 256 + c] * part_sum(P, 2, o, 8, b); }
-      else { for (int o = 0; o < 256; ++o) v += P.w_r0[o * 334 + 286 + c] * part_sum(P, 5, o, 8, b); }
+    } else {                                             // per-image sum of dz0: [B][256] scratch for the latent rows
+      v = part_sum(P, sg.gemm, (int)(le % 256), 8, (int)(le / 256));
     }
     sg.out[le] = v;
   }
+}
+
+// dlat[b][c] = sum_o W0[o][col0 + c] * dzsum[b][o]: one wave per output element, lanes over o, butterfly reduction
+__global__ void mlp_latent_grad(const float* __restrict__ dzsum_t, const float* __restrict__ dzsum_r,
+                                const float* __restrict__ w_t0, const float* __restrict__ w_r0, int B,
+                                float* __restrict__ g_lat_trans, float* __restrict__ g_lat_light) {
+  const int lane = threadIdx.x & 63;
+  const int e = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (e >= B * 64) return;
+  const int b = e / 64, c = e % 64;
+  const bool tr = c < 16;
+  const float* dz = (tr ? dzsum_t : dzsum_r) + b * 256;
+  const float* w = tr ? w_t0 + 256 + c : w_r0 + 286 + (c - 16);
+  const int ld = tr ? 272 : 334;
+  float v = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { const int o = lane + 64 * k; v += w[o * ld] * dz[o]; }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  if (lane == 0) { if (tr) g_lat_trans[b * 16 + c] = v; else g_lat_light[b * 48 + (c - 16)] = v; }
 }
 
 int num_cus() {
@@ -295,7 +313,7 @@ extern "C" size_t tp_mlp_bwd_workspace_bytes(int64_t n_samples) {
   const int64_t ng = n_groups_of(n_samples);
   // dz record + split-K partials (sized for the largest slice count any device could ask for: 64)
   return align256((size_t)ng * kDzGroupFloats * sizeof(float)) +
-         align256((size_t)kWgItems * 64 * 4 * kWgTiles * 1024 * sizeof(float));
+         align256((size_t)kWgItems * 64 * 4 * kWgTiles * 1024 * sizeof(float)) + align256(2 * 32 * 256 * sizeof(float));
 }
 
 extern "C" int tp_mlp_bwd(const tp_mlp_bwd_args* a, tp_stream_t stream_) {
@@ -311,6 +329,7 @@ extern "C" int tp_mlp_bwd(const tp_mlp_bwd_args* a, tp_stream_t stream_) {
   const int64_t n_tiles = (S + 127) / 128, ng = n_tiles * 4;
   float* dz = (float*)a->workspace;
   float* partial = (float*)((char*)a->workspace + align256((size_t)ng * kDzGroupFloats * sizeof(float)));
+  float* dzsum = (float*)((char*)partial + align256((size_t)kWgItems * 64 * 4 * kWgTiles * 1024 * sizeof(float)));
 
   if (a->repack) {
     WPtrs w;
@@ -359,11 +378,13 @@ extern "C" int tp_mlp_bwd(const tp_mlp_bwd_args* a, tp_stream_t stream_) {
   add(a->g_rgb_w[2], SEG_W, 3, 256, 256);  add(a->g_rgb_b[2], SEG_B, 3, 256, 1);
   add(a->g_rgb_w[1], SEG_W, 4, 256, 256);  add(a->g_rgb_b[1], SEG_B, 4, 256, 1);
   add(a->g_rgb_w[0], SEG_W, 5, 256, 334);  add(a->g_rgb_b[0], SEG_B, 5, 256, 1);
-  add(a->g_lat_trans, SEG_LAT, 2, a->B, 16);
-  add(a->g_lat_light, SEG_LAT, 5, a->B, 48);
+  add(dzsum, SEG_DZSUM, 2, a->B, 256);
+  add(dzsum + 32 * 256, SEG_DZSUM, 5, a->B, 256);
   F.n_seg = n; F.total = off; F.partial = partial; F.n_slices = Wg.n_slices; F.B = a->B;
   F.lat_trans = a->lat_trans; F.lat_light = a->lat_light;
   F.w_t0 = a->weights.trans_w[0]; F.w_r0 = a->weights.rgb_w[0];
   hipLaunchKernelGGL(mlp_wgrad_finalize, dim3((unsigned)((off + 255) / 256)), dim3(256), 0, stream, F);
+  hipLaunchKernelGGL(mlp_latent_grad, dim3((unsigned)((a->B * 64 + 3) / 4)), dim3(256), 0, stream, dzsum,
+                     dzsum + 32 * 256, a->weights.trans_w[0], a->weights.rgb_w[0], a->B, a->g_lat_trans, a->g_lat_light);
   return tp::check_launch("tp_mlp_bwd");
 }
