@@ -123,6 +123,12 @@ class Graph(torch.nn.Module):
                      opacity_static=opacity_static, opacity_transient=opacity_transient, uncert=uncert,
                      depth=depth_map, alpha_static=alpha_static, alpha_transient=alpha_transient, density=density_s)
 
+    def _check_range(self, device):
+        """One host sync per rendered image: the f16x3 MLP raises a device flag if an activation left the fp16
+        range (then the image must be re-rendered with arch.mlp_precision='fp32')."""
+        if self.nerf.precision == "f16x3" and not torch.is_grad_enabled():
+            ops.check_mlp_status(device)
+
     @staticmethod
     def _slice_rays(opt):
         # result-invariant chunk size: at least the reference's rand_rays, by default a whole image per launch
@@ -139,6 +145,7 @@ class Graph(torch.nn.Module):
                                   mode=mode)
                 for k in RENDER_KEYS:
                     parts[k].append(ret[k])
+            self._check_range(pose.device)
             return edict({k: (v[0] if len(v) == 1 else torch.cat(v, dim=1)) for k, v in parts.items()})
         # eval: only object pixels are rendered and scattered into default-filled maps (reference :652-680; B == 1)
         dev, N = pose.device, opt.nerf.sample_intvs
@@ -161,6 +168,7 @@ class Graph(torch.nn.Module):
                               mode=mode)
             for k in RENDER_KEYS:
                 out[k][:, idx[0]] = ret[k][0]
+        self._check_range(pose.device)
         return out
 
     # ------------------------------------------------------------------ consumers of render()
