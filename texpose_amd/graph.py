@@ -124,10 +124,11 @@ class Graph(torch.nn.Module):
                      depth=depth_map, alpha_static=alpha_static, alpha_transient=alpha_transient, density=density_s)
 
     def _check_range(self, device):
-        """One host sync per rendered image: the f16x3 MLP raises a device flag if an activation left the fp16
-        range (then the image must be re-rendered with arch.mlp_precision='fp32')."""
+        """The f16x3 MLP raises a device flag if an activation left the fp16 range (then images must be re-rendered
+        with arch.mlp_precision='fp32').  Polled without a host sync: a violation surfaces at the next image at
+        the latest; ops.check_mlp_status(device) is the blocking form."""
         if self.nerf.precision == "f16x3" and not torch.is_grad_enabled():
-            ops.check_mlp_status(device)
+            ops.poll_mlp_status(device)
 
     @staticmethod
     def _slice_rays(opt):

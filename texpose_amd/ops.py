@@ -190,6 +190,27 @@ def check_mlp_status(device) -> None:
                                        "precision='fp32'")
 
 
+_status_polls: Dict[int, tuple] = {}
+
+
+def poll_mlp_status(device) -> None:
+    """Non-blocking variant for per-image use: looks at the copy requested by the PREVIOUS poll if it has
+    completed (raising if the flag was set) and queues a new asynchronous copy of the flag."""
+    key = torch.device(device).index or 0
+    prev = _status_polls.get(key)
+    if prev is not None and prev[1].query():
+        if int(prev[0][0]) & 1:
+            raise _lib.TexposeLibraryError("f16x3 MLP: an activation exceeded the fp16 range (6e4); render with "
+                                           "precision='fp32'")
+        prev = None
+    if prev is None:
+        host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+        host.copy_(mlp_status(device), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        _status_polls[key] = (host, ev)
+
+
 def mlp_forward(packed: Tensor, lat_trans: Tensor, lat_light: Tensor, *, center: Optional[Tensor] = None,
                 ray: Optional[Tensor] = None, depth: Optional[Tensor] = None, points: Optional[Tensor] = None,
                 ray_unit: Optional[Tensor] = None, save: bool = False, precision: str = "fp32"):
