@@ -172,12 +172,21 @@ def main():
     launches_per_step = len(mlp_events) / args.steps
     samples_per_launch = H * W * N_SAMPLES / launches_per_step
 
+    def measured_traffic(precision, samples):
+        """Fabric bytes per launch from the committed PMC profile (bench.py cannot run rocprofv3 on itself)."""
+        try:
+            t = json.load(open(os.path.join(REPO, "profiles", "traffic.json")))[precision]
+            return t["total"] * samples / (H * W * N_SAMPLES)
+        except Exception:
+            return None
+
     def roofline(precision, ms, samples):
         achieved = MLP_FLOP_PER_SAMPLE * samples / (ms * 1e-3) / 1e12
         peak = MFMA_PEAK_TFLOPS[precision]
         k = ISSUED_PER_ALGORITHMIC[precision]
         return {"kernel": "mlp_fwd_kernel" if precision == "fp32" else "mlp_fwd_f16x3_kernel", "bound": "mfma",
-                "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
+                "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": measured_traffic(precision, samples),
+                "traffic_unit": "bytes/launch, L2<->fabric (FETCH_SIZE x2 + WRITE_SIZE, profiles/traffic.json)",
                 "kernel_ms": ms, "samples_per_launch": samples, "flop_per_sample": MLP_FLOP_PER_SAMPLE,
                 "mfma_issued_per_algorithmic": k, "issued_frac": k * achieved / peak,
                 "note": "achieved = ALGORITHMIC FLOP / HIP-event time; f16x3 issues 3 f16 MFMAs per algorithmic product"}

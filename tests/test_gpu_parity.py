@@ -548,3 +548,42 @@ def test_gan_train_iteration_runs_and_learns(ops):
 def edict_copy(var):
     from texpose_amd.options import AttrDict
     return AttrDict({k: v for k, v in var.items()})
+
+
+# ------------------------------------------------------------------------------------------ full-size properties
+def test_full_size_render_properties(ops):
+    """BASELINE config C2 (480x640, 128 samples/ray, all pixels): size-independent properties of the render --
+    run-to-run determinism, slice-size invariance (2048-ray chunks == whole image, bit for bit), opacity == 1,
+    depth inside [near, far], colours in [0,1], and f16x3 vs exact-fp32 agreement at the 1e-4 bar."""
+    import bench
+    sc, params, emb_t, emb_l = bench.build_scene(dev(), 0)
+    H, W = bench.H, bench.W
+    pose, intr = cu(sc["pose"]), cu(sc["intr"])
+    dr = (cu(sc["z_near"])[:, :, None], cu(sc["z_far"])[:, :, None])
+    mask = torch.ones(1, H, W, device=dev())
+    outs = {}
+    for prec in ("fp32", "f16x3"):
+        g, opt = bench.make_graph(dev(), params, emb_t, emb_l, prec)
+        opt.nerf.sample_stratified = False
+        with torch.no_grad():
+            whole = g.render_by_slices(opt, pose, intr=intr, depth_range=dr, object_mask=mask, sample_idx=None, mode="val")
+            keep = {k: whole[k].clone() for k in ("rgb", "rgb_static", "depth", "uncert", "opacity", "opacity_static")}
+            again = g.render_by_slices(opt, pose, intr=intr, depth_range=dr, object_mask=mask, sample_idx=None, mode="val")
+            for k in keep:
+                assert torch.equal(keep[k], again[k]), (prec, k)
+            del again, whole
+            opt.nerf.slice_rays = 2048 * 16
+            sliced = g.render_by_slices(opt, pose, intr=intr, depth_range=dr, object_mask=mask, sample_idx=None, mode="val")
+            for k in keep:
+                assert torch.equal(keep[k], sliced[k]), (prec, k)
+            del sliced
+        outs[prec] = keep
+        ops.check_mlp_status(dev())
+        assert float((keep["opacity"] - 1).abs().max()) < 1e-5 and float((keep["opacity_static"] - 1).abs().max()) < 1e-5
+        assert float(keep["rgb"].min()) >= 0 and float(keep["rgb"].max()) <= 1 + 1e-6
+        zn, zf = cu(sc["z_near"]), cu(sc["z_far"])
+        d = keep["depth"][0, :, 0]
+        assert bool(((d >= zn[0] - 1e-4) & (d <= zf[0] + 1e-4)).all())
+        assert float(keep["uncert"].min()) >= 0.05
+    for k in ("rgb", "rgb_static", "depth", "uncert"):
+        torch.testing.assert_close(outs["f16x3"][k], outs["fp32"][k], rtol=1e-4, atol=1e-6)
