@@ -1,0 +1,103 @@
+"""CPU: host-side logic of the mirror (no kernels): patch sampler vs the reference golden, pose algebra, module
+construction / state-dict contract, option container, loud failure without the library."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import texpose_oracle as O
+from texpose_amd import _lib
+from texpose_amd.geometry import FlexPatchSampler, compose_poses, enlarge_diagonal, invert_pose, make_pose, rotation_distance
+from texpose_amd.options import AttrDict, default_options
+
+
+def test_flex_patch_sampler_matches_reference_g0():
+    g = load_golden("g0_patch_sampler")
+    ps = FlexPatchSampler(True, scale_anneal=0.0002)
+    ps.iterations = g["iterations"]
+    u = torch.stack([g["u_scale"], g["u_hoff"], g["u_woff"]]).view(3, 4, 1, 1, 1)
+    coords, scales = ps(4, g["patch_size"], device="cpu", u=u)
+    assert torch.equal(coords, g["coords"]) and torch.equal(scales, g["scales"])
+    assert abs(ps.scales_curr[0] - float(g["scales_curr"][0])) < 1e-12
+    # annealing schedule: min(0.8, max(0.25, exp(-it * 2e-4)))
+    for it, want in ((0, 0.8), (3000, float(np.exp(-0.6))), (100000, 0.25)):
+        ps.iterations = it
+        assert abs(ps.scale_range()[0] - want) < 1e-12
+    c, s = FlexPatchSampler(True, scale_anneal=0.0002)(3, 16, device="cpu")
+    assert c.shape == (3, 16, 16, 2) and s.shape == (3, 1, 1, 1) and float(c.abs().max()) <= 1.0 + 1e-6
+
+
+def test_pose_algebra():
+    rs = np.random.RandomState(0)
+    R = torch.from_numpy(np.stack([O.rotation_from_axis_angle(rs.normal(size=3)) for _ in range(3)]).astype(np.float32))
+    t = torch.from_numpy(rs.normal(size=(3, 3)).astype(np.float32))
+    p = make_pose(R, t)
+    assert p.shape == (3, 3, 4)
+    torch.testing.assert_close(invert_pose(p), O.pose_inverse(p))
+    ident = compose_poses(p, invert_pose(p))
+    torch.testing.assert_close(ident[..., :3], torch.eye(3).expand(3, 3, 3), atol=1e-6, rtol=0)
+    torch.testing.assert_close(ident[..., 3], torch.zeros(3, 3), atol=1e-6, rtol=0)
+    ang = rotation_distance(R, R.roll(1, 0))
+    assert ang.shape == (3,) and bool((ang >= 0).all()) and float(rotation_distance(R, R).max()) < 1e-3
+    lo, hi = enlarge_diagonal(torch.tensor([[-1.0, -2.0, 0.0]]), torch.tensor([[1.0, 2.0, 4.0]]))
+    torch.testing.assert_close(hi - lo, torch.tensor([[2.5, 5.0, 5.0]]))
+    with pytest.raises(ValueError):
+        make_pose()
+
+
+def test_nerf_module_contract():
+    from texpose_amd.graph import Graph
+    opt = default_options(device="cpu")
+    g = Graph(opt)
+    g.attach_latents(189, opt)
+    sd = g.state_dict()
+    shapes = {k: tuple(v.shape) for k, v in sd.items()}
+    assert sum(p.numel() for p in g.nerf.parameters()) == 914186
+    assert shapes["nerf.progress"] == ()
+    assert [shapes[f"nerf.mlp_feat.{i}.weight"] for i in range(8)] == \
+        [(256, 63), (256, 256), (256, 256), (256, 256), (256, 319), (256, 256), (256, 256), (257, 256)]
+    assert [shapes[f"nerf.mlp_rgb.{i}.weight"] for i in range(4)] == [(256, 334), (256, 256), (256, 256), (3, 256)]
+    assert [shapes[f"nerf.mlp_trans.{i}.weight"] for i in range(4)] == [(256, 272), (256, 256), (256, 256), (5, 256)]
+    assert shapes["latent_vars_trans.weight"] == (189, 16) and shapes["latent_vars_light.weight"] == (189, 48)
+    assert all(not p.requires_grad for p in g.nerf.mlp_feat.parameters())
+    assert all(p.requires_grad for p in g.nerf.mlp_rgb.parameters())
+    assert float(g.nerf.mlp_feat[0].bias.abs().max()) == 0.0                           # tf_init zeroes biases
+    bad = default_options(device="cpu")
+    bad.arch.layers_rgb = [None, 128, 128, 3]
+    with pytest.raises(NotImplementedError):
+        Graph(bad)
+
+
+def test_discriminator_contract():
+    from texpose_amd.gan_modules import Discriminator
+    opt = default_options(device="cpu")
+    d = Discriminator(opt)
+    assert sum(p.numel() for p in d.parameters()) == 2667137
+    keys = set(d.state_dict())
+    for k in ("main.0", "main.3", "main.6", "final.1", "final.3", "final.5"):
+        assert {f"{k}.weight_orig", f"{k}.weight_u", f"{k}.weight_v"} <= keys
+    assert d.state_dict()["main.0.weight_orig"].shape == (256, 9, 4, 4)
+    assert d.state_dict()["final.1.weight_orig"].shape == (64, 73, 1, 1)
+    assert d(opt, torch.rand(2, 9, 16, 16), torch.rand(2, 1, 1, 1)).shape == (2,)
+    opt.patch_size = 64
+    assert sum(p.numel() for p in Discriminator(opt).parameters()) == 3294849
+
+
+def test_options_container():
+    o = AttrDict(a=dict(b=1), c=None)
+    assert o.a.b == 1 and o.get("zzz") is None
+    o.update(a=dict(b=2, d=[1, 2]))
+    assert o.a.d == [1, 2]
+    with pytest.raises(AttributeError):
+        _ = o.nope
+    d = default_options(H=480, W=640)
+    assert d.nerf.sample_intvs == 64 and d.nerf.rand_rays == 2048 and d.loss_weight.trans_reg == -2
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", os.path.join(os.path.dirname(_lib.LIB_PATH), "no_such_lib.so"))
+    with pytest.raises(_lib.TexposeLibraryError, match="no CPU or eager fallback"):
+        _lib.load()
