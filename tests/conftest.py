@@ -14,6 +14,13 @@ GOLDEN = os.path.join(REPO, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the C-ABI library is a build product (git-ignored): build it once if a fresh checkout lacks it
+    lib = os.path.join(REPO, "texpose_amd", "libtexpose_amd.so")
+    if not os.path.exists(lib):
+        import shutil
+        import subprocess
+        if shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc"):
+            subprocess.run(["make", "-C", os.path.join(REPO, "texpose_amd", "csrc"), "-j", "8"], check=False)
 
 
 def load_golden(name):

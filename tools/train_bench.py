@@ -9,8 +9,9 @@ from texpose_amd.synthetic import training_batch
 from texpose_amd.trainer import GanTrainer
 
 
-def run(B=4, iters=20, warm=3, full=True, device="cuda:0"):
+def run(B=4, iters=20, warm=6, full=True, device="cuda:0"):
     torch.manual_seed(0)
+    torch.backends.cudnn.benchmark = os.environ.get("TP_MIOPEN_FIND", "1") == "1"   # let MIOpen search conv solvers
     opt = default_options(H=128, W=128, device=device)
     opt.batch_size, opt.patch_size, opt.nerf.sample_intvs = B, 16, 64
     if not full:
