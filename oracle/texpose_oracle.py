@@ -604,3 +604,27 @@ def synthetic_scene(H: int, W: int, B: int = 1, seed: int = 0, depth_scale: floa
     c, r = rays_eval(pose, intr, H, W)
     zn, zf = box_bounds(lo, hi, c, r, bg[0], bg[1])
     return dict(intr=intr, pose=pose, z_near=zn, z_far=zf, aabb_min=lo, aabb_max=hi)
+
+
+# ----------------------------------------------------------------------------
+# Deterministic state for a spectral-norm PatchGAN (used to pin the stock Discriminator module, SURVEY 8f-1,
+# against the reference's layers/discriminator.py through golden g12): weights by SORTED key from a
+# RandomState, u / v from one power-iteration step started at ones (so sigma is well-conditioned).
+# ----------------------------------------------------------------------------
+
+def seed_spectral_module(module: torch.nn.Module, seed: int, scale: float = 0.05) -> None:
+    rs = np.random.RandomState(seed)
+    sd = module.state_dict()
+    with torch.no_grad():
+        for k in sorted(sd):
+            if k.endswith("weight_orig"):
+                sd[k].copy_(torch.from_numpy(rs.normal(scale=scale, size=tuple(sd[k].shape)).astype(np.float32)))
+        for k in sorted(sd):
+            if k.endswith("weight_orig"):
+                w2 = sd[k].reshape(sd[k].shape[0], -1)
+                v = torch.nn.functional.normalize(w2.t() @ torch.ones(w2.shape[0]), dim=0)
+                u = torch.nn.functional.normalize(w2 @ v, dim=0)
+                sd[k[:-5] + "_u"].copy_(u)
+                sd[k[:-5] + "_v"].copy_(v)
+            elif sd[k].ndim == 0:
+                sd[k].fill_(0.25)

@@ -376,6 +376,19 @@ def main():
           normal_sample=var.normal_sample, patch_real=patch_real, patch_fake=patch_fake,
           loss_render=loss.render, loss_uncert=loss.uncert, loss_trans_reg=loss.trans_reg, loss_all=tot.all,
           w_render=opt.loss_weight.render, w_uncert=opt.loss_weight.uncert, w_trans_reg=opt.loss_weight.trans_reg)
+    # ---------------------------------------------------------------- G12 discriminator fwd + R1 (f1, stock module)
+    from layers.discriminator import Discriminator
+    opt.patch_size = 16
+    disc = Discriminator(opt)
+    drs = np.random.RandomState(321)
+    O.seed_spectral_module(disc, 321)                          # seeded weights + deterministic spectral-norm u / v
+    disc.eval()                                                # eval: no power iteration -> deterministic u / v
+    xin = T(drs.uniform(size=(3, 9, 16, 16))).requires_grad_()
+    scale = T(drs.uniform(0.25, 1.0, size=(3, 1, 1, 1)))
+    d_out = disc(opt, xin, scale)
+    reg = M.Graph.compute_grad2(opt, d_out, xin)
+    bce1 = M.Graph.compute_gan_loss(opt, d_outs=d_out, target=1)
+    _save("g12_discriminator", seed=321, x=xin, scale=scale, d_out=d_out, grad2=reg, bce_real=bce1)
     print("done")
 
 

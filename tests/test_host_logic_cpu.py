@@ -101,3 +101,53 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(_lib, "LIB_PATH", os.path.join(os.path.dirname(_lib.LIB_PATH), "no_such_lib.so"))
     with pytest.raises(_lib.TexposeLibraryError, match="no CPU or eager fallback"):
         _lib.load()
+
+
+def test_checkpoint_wire_format(tmp_path):
+    """Reference-format checkpoint round trip, per-child restore and the mlp_feat-only pre-training restore."""
+    from texpose_amd import checkpoint as ck
+    from texpose_amd.graph import Graph
+    opt = default_options(device="cpu")
+    torch.manual_seed(1)
+    a = Graph(opt)
+    a.attach_latents(7, opt)
+    optim = torch.optim.Adam(a.nerf.mlp_rgb.parameters(), lr=1e-3)
+    path = str(tmp_path / "model.ckpt")
+    ck.save_checkpoint(path, a, epoch=3, it=1234, optim_nerf=optim, not_saved=object())
+    blob = torch.load(path, weights_only=False)
+    assert set(blob) == {"epoch", "iter", "graph", "optim_nerf"} and blob["iter"] == 1234
+    assert "nerf.mlp_feat.7.weight" in blob["graph"] and "latent_vars_light.weight" in blob["graph"]
+    torch.manual_seed(2)
+    b = Graph(opt)
+    b.attach_latents(7, opt)
+    assert not torch.equal(a.nerf.mlp_rgb[0].weight, b.nerf.mlp_rgb[0].weight)
+    ep, it = ck.restore_checkpoint(b, blob, optim_nerf=torch.optim.Adam(b.nerf.mlp_rgb.parameters(), lr=1e-3))
+    assert (ep, it) == (3, 1234)
+    for (k, v), (_, w) in zip(a.state_dict().items(), b.state_dict().items()):
+        assert torch.equal(v, w), k
+    torch.manual_seed(3)
+    c = Graph(opt)
+    c.attach_latents(7, opt)
+    head_before = c.nerf.mlp_rgb[0].weight.clone()
+    assert ck.restore_pretrained_trunk(c, blob) == 16                      # 8 weights + 8 biases
+    assert torch.equal(c.nerf.mlp_feat[4].weight, a.nerf.mlp_feat[4].weight)
+    assert torch.equal(c.nerf.mlp_rgb[0].weight, head_before)              # heads untouched
+
+
+def test_discriminator_matches_reference_g12():
+    """The stock PatchGAN module against a golden captured from the reference's Discriminator:
+    forward logits, the R1 squared-gradient penalty (double backward) and the BCE loss."""
+    from texpose_amd.gan_modules import Discriminator
+    from texpose_amd.graph import Graph
+    g = load_golden("g12_discriminator")
+    opt = default_options(device="cpu")
+    d = Discriminator(opt)
+    O.seed_spectral_module(d, g["seed"])
+    d.eval()
+    x = g["x"].clone().requires_grad_()
+    out = d(opt, x, g["scale"])
+    torch.testing.assert_close(out.detach(), g["d_out"], rtol=1e-4, atol=1e-6)
+    reg = Graph.compute_grad2(opt, out, x)
+    torch.testing.assert_close(reg.detach(), g["grad2"], rtol=1e-3, atol=1e-8)
+    torch.testing.assert_close(Graph.compute_gan_loss(opt, out, 1).detach(), torch.as_tensor(g["bce_real"]), rtol=1e-5,
+                               atol=1e-6)
