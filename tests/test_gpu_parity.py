@@ -580,7 +580,7 @@ def test_full_size_render_properties(ops):
         outs[prec] = keep
         ops.check_mlp_status(dev())
         assert float((keep["opacity"] - 1).abs().max()) < 1e-5 and float((keep["opacity_static"] - 1).abs().max()) < 1e-5
-        assert float(keep["rgb"].min()) >= 0 and float(keep["rgb"].max()) <= 1 + 1e-6
+        assert float(keep["rgb"].min()) >= 0 and float(keep["rgb"].max()) <= 1 + 1e-5      # opacity itself is 1 +- 1e-5
         zn, zf = cu(sc["z_near"]), cu(sc["z_far"])
         d = keep["depth"][0, :, 0]
         assert bool(((d >= zn[0] - 1e-4) & (d <= zf[0] + 1e-4)).all())

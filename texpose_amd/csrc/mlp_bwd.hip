@@ -51,7 +51,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_dgrad_kernel(DgParams P) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 31, hh = lane >> 5;
   Pipe p;
-  p.stream = P.packed_t; p.lds = lds; p.chunk = 0; p.buf = 0; p.wave = wave; p.lane = lane;
+  p.stream = P.packed_t; p.lds = lds; p.chunk = 0; p.buf = 0; p.wave = __builtin_amdgcn_readfirstlane(wave); p.lane = lane;
   dma_chunk(p, 0, 0);
   __syncthreads();
 

@@ -87,7 +87,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_kernel(Params P) {
   float* ex_lds = bias_lds + kBiasPad + kEncFloats + tid;
 
   Pipe p;
-  p.stream = P.packed; p.lds = lds; p.chunk = 0; p.buf = 0; p.wave = wave; p.lane = lane;
+  p.stream = P.packed; p.lds = lds; p.chunk = 0; p.buf = 0; p.wave = __builtin_amdgcn_readfirstlane(wave); p.lane = lane;
   // biases -> LDS once per workgroup; first weight chunk -> buffer 0
   for (int i = tid; i < kBiasFloats; i += kThreads) bias_lds[i] = P.packed[(size_t)kNumChunks * kChunkFloats + i];
   dma_chunk(p, 0, 0);

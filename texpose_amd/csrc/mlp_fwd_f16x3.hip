@@ -41,54 +41,108 @@ __device__ __forceinline__ f32x16 mfma16(half8 a, half8 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
 
-// B operands of one 256-feature activation: [source tile][k-step of 16 features]
-struct XF {
-  half8 hi[8][2];
-  half8 lo[8][2];
-};
-
 // Three-slot ring instead of the fp32 kernel's double buffer: a chunk is only 48 MFMAs (1536 cycles, ~0.65 us)
 // here, shorter than an L2->LDS DMA round trip, so the prefetch runs TWO chunks ahead.  The DMA of chunk c+2 stays
 // in flight across the barrier: counted `s_waitcnt vmcnt(8)` (the 8 DMA instructions of the newest chunk may be
 // outstanding, everything older -- chunk c+1 -- has landed) + raw s_barrier; __syncthreads() would drain vmcnt(0).
+//
+// The A-fragment fetch (LDS -> VGPR, kDepth pairs ahead of the MFMAs that use them) is ONE continuous pipeline
+// across chunks: the barrier that publishes chunk c+1 sits kDepth pairs before the END of chunk c, and the last
+// iterations of chunk c already fetch the first pairs of chunk c+1.  With one wave per SIMD nothing else would hide
+// the LDS latency of a per-chunk prologue.  Slot safety: the DMA issued at the start of chunk c+1 (chunk c+3)
+// overwrites the slot of chunk c, and every wave has completed (lgkmcnt(0)) all its reads of chunk c before it
+// arrives at chunk c's barrier, which every wave passes before it starts chunk c+1.
+constexpr int kDepth = 4;
+constexpr int kPairHalves = 1024;                  // one (k-step, tile) pair: 512 halves hi + 512 halves lo
+struct Frag { half8 h[kDepth], l[kDepth]; };
 
+#ifdef TP_TRACE
+__device__ __forceinline__ long long tick() {
+  long long t;
+  asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  return t;
+}
+#endif
 __device__ __forceinline__ void ring_begin(Pipe& p) {
+#ifdef TP_TRACE
+  const long long t0 = tick();
+#endif
   int nxt = p.chunk + 2;
   if (nxt >= kNumChunks) nxt -= kNumChunks;
   int slot = p.buf + 2;
   if (slot >= kBufs) slot -= kBufs;
   dma_chunk(p, nxt, slot);
+#ifdef TP_TRACE
+  p.tr_dma += tick() - t0;
+#endif
 }
-__device__ __forceinline__ void ring_end(Pipe& p) {
-  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+__device__ __forceinline__ void ring_publish(Pipe& tr) {
+#ifdef TP_TRACE
+  const long long t0 = tick();
+  asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+  const long long t1 = tick();
   __builtin_amdgcn_s_barrier();
+  const long long t2 = tick();
+  tr.tr_vm += t1 - t0; tr.tr_bar += t2 - t1; tr.tr_n += 1;
+#else
+  asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+#endif
   asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ void ring_advance(Pipe& p) {
   p.chunk = (p.chunk + 1 == kNumChunks) ? 0 : p.chunk + 1;
   p.buf = (p.buf + 1 == kBufs) ? 0 : p.buf + 1;
 }
 __device__ __forceinline__ const _Float16* chunk_ptr16(const Pipe& p) {
   return reinterpret_cast<const _Float16*>(p.lds + p.buf * kChunkFloats) + p.lane * 8;
 }
-
-// (k-step, tile) pairs of a wide chunk; pair q = s*8 + t.  The hi/lo A fragments are fetched kDepth pairs
-// (kDepth x 96 MFMA cycles) ahead of their use: with one wave per SIMD nothing else hides the LDS latency.
-constexpr int kDepth = 4;
-template <int KS, class BFn>
-__device__ __forceinline__ void mma_wide16(f32x16 (&acc)[8], const _Float16* l, BFn b) {
-  constexpr int NP = KS * 8;
-  half8 fh[kDepth], fl[kDepth];
+__device__ __forceinline__ const _Float16* next_chunk_ptr16(const Pipe& p) {
+  const int nb = (p.buf + 1 == kBufs) ? 0 : p.buf + 1;
+  return reinterpret_cast<const _Float16*>(p.lds + nb * kChunkFloats) + p.lane * 8;
+}
+__device__ __forceinline__ void frag_fetch(Frag& f, int slot, const _Float16* src) {
+  f.h[slot] = *reinterpret_cast<const half8*>(src);
+  f.l[slot] = *reinterpret_cast<const half8*>(src + 512);
+}
+// pairs 0..kDepth-1 of the current chunk (kernel start only; afterwards the pipeline never drains)
+__device__ __forceinline__ void frag_prime(const Pipe& p, Frag& f) {
+  const _Float16* l = chunk_ptr16(p);
 #pragma unroll
-  for (int q = 0; q < kDepth && q < NP; ++q) {
-    fh[q] = *reinterpret_cast<const half8*>(l + (q * 2 + 0) * 512);
-    fl[q] = *reinterpret_cast<const half8*>(l + (q * 2 + 1) * 512);
+  for (int q = 0; q < kDepth; ++q) frag_fetch(f, q, l + q * kPairHalves);
+}
+// after the MFMAs of pairs q, q+1 of an NP-pair chunk: publish the next chunk when it is about to be fetched from,
+// then fetch pairs q+kDepth, q+kDepth+1 (of this chunk or the next)
+template <int NP>
+__device__ __forceinline__ void frag_step(Pipe& p, Frag& f, int q, const _Float16* l, const _Float16* ln) {
+  if (q == NP - kDepth) ring_publish(p);
+#pragma unroll
+  for (int d = 0; d < 2; ++d) {
+    const int g = q + d + kDepth;
+    frag_fetch(f, (q + d) % kDepth, g < NP ? l + g * kPairHalves : ln + (g - NP) * kPairHalves);
   }
-  __builtin_amdgcn_sched_group_barrier(0x100, 2 * (kDepth < NP ? kDepth : NP), 0);
-  // two tiles at a time with their three products interleaved: consecutive MFMAs never share an accumulator
+  // the next fetches issue right AFTER the first MFMA of the group (not before it): the lgkmcnt wait hipcc places
+  // before that MFMA then covers only fetches that are already >= 5 MFMAs old
+  __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+  __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+  __builtin_amdgcn_sched_group_barrier(0x008, 5, 0);
+}
+
+// (k-step, tile) pairs of a wide chunk; pair q = s*8 + t, two tiles at a time with their three products
+// interleaved: consecutive MFMAs never share an accumulator
+template <int KS, class BFn, class PostFn>
+__device__ __forceinline__ void mma_wide16(Pipe& p, Frag& f, f32x16 (&acc)[8], BFn b, PostFn post) {
+  constexpr int NP = KS * 8;
+  const _Float16* l = chunk_ptr16(p);
+  const _Float16* ln = next_chunk_ptr16(p);
+#ifdef TP_TRACE
+  const long long t0 = tick();
+#endif
 #pragma unroll
   for (int q = 0; q < NP; q += 2) {
     const int s = q >> 3, t = q & 7;
-    const half8 wh0 = fh[q % kDepth], wl0 = fl[q % kDepth];
-    const half8 wh1 = fh[(q + 1) % kDepth], wl1 = fl[(q + 1) % kDepth];
+    const half8 wh0 = f.h[q % kDepth], wl0 = f.l[q % kDepth];
+    const half8 wh1 = f.h[(q + 1) % kDepth], wl1 = f.l[(q + 1) % kDepth];
     half8 xh, xl;
     b(s, xh, xl);
     acc[t] = mfma16(wh0, xh, acc[t]);
@@ -97,53 +151,88 @@ __device__ __forceinline__ void mma_wide16(f32x16 (&acc)[8], const _Float16* l, 
     acc[t + 1] = mfma16(wh1, xl, acc[t + 1]);
     acc[t] = mfma16(wl0, xh, acc[t]);
     acc[t + 1] = mfma16(wl1, xh, acc[t + 1]);
-#pragma unroll
-    for (int d = 0; d < 2; ++d)
-      if (q + d + kDepth < NP) {
-        fh[(q + d) % kDepth] = *reinterpret_cast<const half8*>(l + ((q + d + kDepth) * 2 + 0) * 512);
-        fl[(q + d) % kDepth] = *reinterpret_cast<const half8*>(l + ((q + d + kDepth) * 2 + 1) * 512);
-      }
-    // hipcc waits with lgkmcnt(0) before the first MFMA that consumes a fragment; issuing the next fetches right
-    // AFTER that MFMA (not before it) makes the wait cover only fetches that are already >= 5 MFMAs old
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-    if (q + kDepth < NP) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-    __builtin_amdgcn_sched_group_barrier(0x008, 5, 0);
+    post(q);                   // VALU work that rides in the issue gaps of the six MFMAs above
+    frag_step<NP>(p, f, q, l, ln);
   }
+#ifdef TP_TRACE
+  p.tr_loop += tick() - t0;
+#endif
+  ring_advance(p);
 }
 
-__device__ __forceinline__ void part_gen16(Pipe& p, f32x16 (&acc)[8], const XF& X) {
+// ---------------------------------------------------------------------------------------------- operand conversion
+// A layer's raw accumulators (bias included: they start at bias * 2^8) are copied once to VGPRs (`V`) and the next
+// layer's B operands are produced from them on the fly: ReLU, 2^-8, hi/lo split, pack for source tile ts+1 while the
+// MFMAs of source tile ts issue.
+struct Xop { half8 h[2], l[2]; };     // B operands of one source tile (2 k-steps of 16 features)
+struct XBuild { half2v hp[8], lp[8]; };
+
+__device__ __forceinline__ void convert2(const f32x16& a, int e0, half2v& hp, half2v& lp, float& amax) {
+  const float v0 = fmaxf(a[e0] * kInvScale, 0.0f);         // mul first: its result is canonical, so the max
+  const float v1 = fmaxf(a[e0 + 1] * kInvScale, 0.0f);     // needs no extra canonicalising v_max
+  amax = fmaxf(amax, fmaxf(v0, v1));
+  const float h0 = __uint_as_float(__float_as_uint(v0) & 0xFFFFE000u);   // 11 significant bits: exact in fp16
+  const float h1 = __uint_as_float(__float_as_uint(v1) & 0xFFFFE000u);
+  hp = __builtin_amdgcn_cvt_pkrtz(h0, h1);
+  lp = __builtin_amdgcn_cvt_pkrtz(v0 - h0, v1 - h1);
+}
+__device__ __forceinline__ Xop finish(const XBuild& b) {
+  Xop x;
+  const half2v h0[4] = {b.hp[0], b.hp[1], b.hp[2], b.hp[3]}, h1[4] = {b.hp[4], b.hp[5], b.hp[6], b.hp[7]};
+  const half2v l0[4] = {b.lp[0], b.lp[1], b.lp[2], b.lp[3]}, l1[4] = {b.lp[4], b.lp[5], b.lp[6], b.lp[7]};
+  x.h[0] = pack8(h0); x.h[1] = pack8(h1); x.l[0] = pack8(l0); x.l[1] = pack8(l1);
+  return x;
+}
+__device__ __forceinline__ Xop convert_tile(const f32x16& a, float& amax) {
+  XBuild xb;
+#pragma unroll
+  for (int e = 0; e < 16; e += 2) convert2(a, e, xb.hp[e >> 1], xb.lp[e >> 1], amax);
+  return finish(xb);
+}
+// accumulators start at bias * 2^8 (pre-scaled in LDS): `bl` = bias block of the layer being computed (this lane half)
+__device__ __forceinline__ void init_acc(f32x16 (&acc)[8], const float* bl) {
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(bl + t * 16 + g * 4);
+      acc[t][g * 4 + 0] = v.x; acc[t][g * 4 + 1] = v.y; acc[t][g * 4 + 2] = v.z; acc[t][g * 4 + 3] = v.w;
+    }
+}
+
+__device__ __forceinline__ void part_gen16(Pipe& p, Frag& f, f32x16 (&acc)[8], const f32x16 (&V)[8], float& amax) {
+  Xop X = convert_tile(V[0], amax);
 #pragma unroll
   for (int ts = 0; ts < 8; ++ts) {
+    XBuild xb;
     ring_begin(p);
-    mma_wide16<2>(acc, chunk_ptr16(p), [&](int s, half8& xh, half8& xl) { xh = X.hi[ts][s]; xl = X.lo[ts][s]; });
-    ring_end(p);
+    mma_wide16<2>(p, f, acc, [&](int s, half8& xh, half8& xl) { xh = X.h[s]; xl = X.l[s]; },
+                  [&](int q) { if (ts < 7) convert2(V[ts < 7 ? ts + 1 : 0], q, xb.hp[q >> 1], xb.lp[q >> 1], amax); });
+    if (ts < 7) X = finish(xb);
   }
 }
 
-// 1..5-row output layer: one chunk, 16 k-steps, one accumulator tile
-__device__ __forceinline__ f32x16 part_head16(Pipe& p, const XF& X) {
+// 1..5-row output layer over relu(V): one chunk, 16 k-steps, one accumulator tile, operands converted just in time
+__device__ __forceinline__ f32x16 part_head16(Pipe& p, Frag& f, const f32x16 (&V)[8], float& amax) {
   f32x16 acc = {0};
   ring_begin(p);
   const _Float16* l = chunk_ptr16(p);
-  half8 wh = *reinterpret_cast<const half8*>(l);
-  half8 wl = *reinterpret_cast<const half8*>(l + 512);
-  __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+  const _Float16* ln = next_chunk_ptr16(p);
 #pragma unroll
-  for (int s16 = 0; s16 < 16; ++s16) {
-    half8 nh = wh, nl = wl;
-    if (s16 + 1 < 16) {
-      nh = *reinterpret_cast<const half8*>(l + ((s16 + 1) * 2 + 0) * 512);
-      nl = *reinterpret_cast<const half8*>(l + ((s16 + 1) * 2 + 1) * 512);
-    }
-    const half8 xh = X.hi[s16 >> 1][s16 & 1], xl = X.lo[s16 >> 1][s16 & 1];
-    acc = mfma16(wh, xh, acc);
-    acc = mfma16(wh, xl, acc);
-    acc = mfma16(wl, xh, acc);
-    if (s16 + 1 < 16) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
-    wh = nh; wl = nl;
+  for (int ts = 0; ts < 8; ++ts) {
+    const Xop X = convert_tile(V[ts], amax);
+    const int q = ts * 2;                          // pair q = k-step 2 ts, pair q+1 = k-step 2 ts + 1
+    const half8 wh0 = f.h[q % kDepth], wl0 = f.l[q % kDepth];
+    const half8 wh1 = f.h[(q + 1) % kDepth], wl1 = f.l[(q + 1) % kDepth];
+    acc = mfma16(wh0, X.h[0], acc);
+    acc = mfma16(wh0, X.l[0], acc);
+    acc = mfma16(wl0, X.h[0], acc);
+    acc = mfma16(wh1, X.h[1], acc);
+    acc = mfma16(wh1, X.l[1], acc);
+    acc = mfma16(wl1, X.h[1], acc);
+    frag_step<16>(p, f, q, l, ln);
   }
-  ring_end(p);
+  ring_advance(p);
   return acc;
 }
 
@@ -175,13 +264,20 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_f16x3_kernel(Params P) {
   _Float16* st = reinterpret_cast<_Float16*>(bias_lds + kBiasPad);
 
   Pipe p;
-  p.stream = P.packed; p.lds = lds; p.chunk = 0; p.buf = 0; p.wave = wave; p.lane = lane;
-  for (int i = tid; i < kBiasFloats; i += kThreads) bias_lds[i] = P.packed[(size_t)kNumChunks * kChunkFloats + i];
+  p.stream = P.packed; p.lds = lds; p.chunk = 0; p.buf = 0; p.wave = __builtin_amdgcn_readfirstlane(wave); p.lane = lane;
+  // wide-layer biases are kept pre-scaled by 2^8 (exact): they seed the accumulators of the scaled products
+  for (int i = tid; i < kBiasFloats; i += kThreads)
+    bias_lds[i] = P.packed[(size_t)kNumChunks * kChunkFloats + i] * (i < kHeadBiasOff ? (float)(1 << kF16WeightShift) : 1.0f);
   dma_chunk(p, 0, 0);
   dma_chunk(p, 1, 1);
   __syncthreads();
+  Frag frag;
+  frag_prime(p, frag);
+#ifdef TP_TRACE
+  const long long tr_start = tick();
+#endif
 
-  half8* ws = reinterpret_cast<half8*>(P.workspace + (size_t)blockIdx.x * (128 * 256)) + tid;
+  f32x4* ws = reinterpret_cast<f32x4*>(P.workspace + (size_t)blockIdx.x * (128 * 256)) + tid;
   const auto staged = [&](int s, half8& xh, half8& xl, int ks0) {
     xh = *reinterpret_cast<const half8*>(st + (((ks0 + s) * 2 + 0) * kThreads + tid) * 8);
     xl = *reinterpret_cast<const half8*>(st + (((ks0 + s) * 2 + 1) * kThreads + tid) * 8);
@@ -212,7 +308,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_f16x3_kernel(Params P) {
       for (int c = 0; c < 3; ++c) { x[c] = P.points[3 * s + c]; vu[c] = P.ray_unit[3 * s + c]; }
     }
 
-    XF X;
+    f32x16 V[8];                // raw accumulators of the previous layer (bias included, scaled 2^8)
     f32x16 acc[8];
     float amax = 0.f;
     float sig_s = 0.f, sig_t = 0.f, unc = 0.f, rgb_t[3] = {0.f, 0.f, 0.f}, rgb_s[3] = {0.f, 0.f, 0.f};
@@ -220,27 +316,27 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_f16x3_kernel(Params P) {
 #pragma nounroll
     for (int li = 0; li < kNumWide; ++li) {
       if (li == L7) {
-        const f32x16 a = part_head16(p, X);
+        const f32x16 a = part_head16(p, frag, V, amax);
         sig_s = softplus(fmaf(a[0], kInvScale, bias_lds[kHeadBiasOff + 0]));
       }
       if (li == R0) {
 #pragma unroll
         for (int t = 0; t < 8; ++t)
 #pragma unroll
-          for (int k = 0; k < 2; ++k) {
-            X.hi[t][k] = ws[((t * 2 + k) * 2 + 0) * kThreads];
-            X.lo[t][k] = ws[((t * 2 + k) * 2 + 1) * kThreads];
+          for (int g = 0; g < 4; ++g) {
+            const f32x4 v = ws[(t * 4 + g) * kThreads];
+            V[t][g * 4 + 0] = v.x; V[t][g * 4 + 1] = v.y; V[t][g * 4 + 2] = v.z; V[t][g * 4 + 3] = v.w;
           }
       }
-#pragma unroll
-      for (int t = 0; t < 8; ++t) acc[t] = f32x16{0};
+      init_acc(acc, bias_lds + (li * 2 + hh) * 128);
 
-      if (li != L0) part_gen16(p, acc, X);
+      if (li != L0) part_gen16(p, frag, acc, V, amax);
 
       if (li == L0 || li == L4) {
-        // [PE(x) | x | pad] in natural column order; this lane stages slots 16 ks + 8 h + jj
+        // [PE(x) | x | pad] in natural column order; this lane stages slots 16 ks + 8 h + jj.  Staged once per tile:
+        // the skip connection (L4) re-reads what L0 staged, nothing overwrites it before T0
 #pragma nounroll
-        for (int e = 0; e < 32; ++e) {
+        for (int e = 0; e < (li == L0 ? 32 : 0); ++e) {
           const int ks = e >> 3, jj = e & 7, slot = 16 * ks + 8 * hh + jj;
           float v;
           if (slot < 60) {
@@ -256,15 +352,13 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_f16x3_kernel(Params P) {
 #pragma unroll
         for (int qd = 0; qd < 2; ++qd) {
           ring_begin(p);
-          mma_wide16<2>(acc, chunk_ptr16(p), [&](int s_, half8& xh, half8& xl) { staged(s_, xh, xl, qd * 2); });
-          ring_end(p);
+          mma_wide16<2>(p, frag, acc, [&](int s_, half8& xh, half8& xl) { staged(s_, xh, xl, qd * 2); }, [](int) {});
         }
       } else if (li == T0) {
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) stage(st, tid, 0, jj, P.lat_trans[b * 16 + 8 * hh + jj]);
         ring_begin(p);
-        mma_wide16<1>(acc, chunk_ptr16(p), [&](int s_, half8& xh, half8& xl) { staged(s_, xh, xl, 0); });
-        ring_end(p);
+        mma_wide16<1>(p, frag, acc, [&](int s_, half8& xh, half8& xl) { staged(s_, xh, xl, 0); }, [](int) {});
       } else if (li == R0) {
         // [ray_unit | PE(ray_unit) | x | light] in natural column order, 78 of 80 slots
 #pragma nounroll
@@ -290,50 +384,25 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_f16x3_kernel(Params P) {
 #pragma unroll
         for (int qd = 0; qd < 3; ++qd) {
           ring_begin(p);
-          if (qd < 2) mma_wide16<2>(acc, chunk_ptr16(p), [&](int s_, half8& xh, half8& xl) { staged(s_, xh, xl, qd * 2); });
-          else mma_wide16<1>(acc, chunk_ptr16(p), [&](int s_, half8& xh, half8& xl) { staged(s_, xh, xl, 4); });
-          ring_end(p);
+          if (qd < 2) mma_wide16<2>(p, frag, acc, [&](int s_, half8& xh, half8& xl) { staged(s_, xh, xl, qd * 2); }, [](int) {});
+          else mma_wide16<1>(p, frag, acc, [&](int s_, half8& xh, half8& xl) { staged(s_, xh, xl, 4); }, [](int) {});
         }
       }
 
-      // un-scale, bias, ReLU, split into hi + lo fp16: the next layer's B operands.  hi = v truncated to 11
-      // significant bits (one AND; exactly representable in fp16 for |v| >= 2^-14, below that the fp16
-      // subnormal grid costs < 6e-8 absolute), lo = v - hi is exact in fp32; both are packed with
-      // v_cvt_pkrtz_f16_f32 (hi converts exactly, lo keeps 11 more bits).
-      const float* bl = bias_lds + (li * 2 + hh) * 128;
+      // the raw accumulators become the next layer's input; un-scale / ReLU / hi+lo split happen where they are
+      // consumed (convert2), overlapped with that layer's MFMAs
 #pragma unroll
-      for (int t = 0; t < 8; ++t)
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-          const f32x4 b0 = *reinterpret_cast<const f32x4*>(bl + t * 16 + k * 8);
-          const f32x4 b1 = *reinterpret_cast<const f32x4*>(bl + t * 16 + k * 8 + 4);
-          const float bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-          half2v hp[4], lp[4];
-#pragma unroll
-          for (int e = 0; e < 8; e += 2) {
-            const float v0 = fmaxf(fmaf(acc[t][k * 8 + e], kInvScale, bv[e]), 0.0f);
-            const float v1 = fmaxf(fmaf(acc[t][k * 8 + e + 1], kInvScale, bv[e + 1]), 0.0f);
-            amax = fmaxf(amax, fmaxf(v0, v1));
-            const float h0 = __uint_as_float(__float_as_uint(v0) & 0xFFFFE000u);
-            const float h1 = __uint_as_float(__float_as_uint(v1) & 0xFFFFE000u);
-            hp[e >> 1] = __builtin_amdgcn_cvt_pkrtz(h0, h1);
-            lp[e >> 1] = __builtin_amdgcn_cvt_pkrtz(v0 - h0, v1 - h1);
-          }
-          X.hi[t][k] = pack8(hp);
-          X.lo[t][k] = pack8(lp);
-        }
+      for (int t = 0; t < 8; ++t) V[t] = acc[t];
 
       if (li == L7) {
 #pragma unroll
         for (int t = 0; t < 8; ++t)
 #pragma unroll
-          for (int k = 0; k < 2; ++k) {
-            ws[((t * 2 + k) * 2 + 0) * kThreads] = X.hi[t][k];
-            ws[((t * 2 + k) * 2 + 1) * kThreads] = X.lo[t][k];
-          }
+          for (int g = 0; g < 4; ++g)
+            ws[(t * 4 + g) * kThreads] = f32x4{V[t][g * 4 + 0], V[t][g * 4 + 1], V[t][g * 4 + 2], V[t][g * 4 + 3]};
       }
       if (li == T2) {
-        const f32x16 a = part_head16(p, X);
+        const f32x16 a = part_head16(p, frag, V, amax);
         const float* hb = bias_lds + kHeadBiasOff + 1;
         rgb_t[0] = sigmoid(fmaf(a[0], kInvScale, hb[0]));
         rgb_t[1] = sigmoid(fmaf(a[1], kInvScale, hb[1]));
@@ -342,7 +411,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_f16x3_kernel(Params P) {
         unc = softplus(fmaf(a[0], kInvScale, hb[4]));      // row 4 = register 0 of the upper lane half
       }
       if (li == R2) {
-        const f32x16 a = part_head16(p, X);
+        const f32x16 a = part_head16(p, frag, V, amax);
         const float* hb = bias_lds + kHeadBiasOff + 6;
         rgb_s[0] = sigmoid(fmaf(a[0], kInvScale, hb[0]));
         rgb_s[1] = sigmoid(fmaf(a[1], kInvScale, hb[1]));
@@ -363,6 +432,11 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_f16x3_kernel(Params P) {
     }
     if (P.status != nullptr && !(amax < 6.0e4f)) atomicOr(P.status, 1);
   }
+#ifdef TP_TRACE
+  if (lane == 0 && (blockIdx.x == 0 || blockIdx.x == 100) && P.n_tiles > 1000)
+    printf("trace wg %d wave %d: total %lld ticks, %lld chunks, vmcnt wait %lld, barrier wait %lld, dma issue %lld, wide loops %lld\n", (int)blockIdx.x, wave,
+           tick() - tr_start, p.tr_n, p.tr_vm, p.tr_bar, p.tr_dma, p.tr_loop);
+#endif
 }
 
 }  // namespace

@@ -25,13 +25,26 @@ struct Pipe {
   int chunk;            // chunk resident in buffer `buf`
   int buf;
   int wave, lane;
+#ifdef TP_TRACE
+  long long tr_vm = 0, tr_bar = 0, tr_n = 0, tr_dma = 0, tr_loop = 0;   // diagnostic build only: wait ticks at the chunk barrier
+#endif
 };
 
 __device__ __forceinline__ void dma_chunk(const Pipe& p, int chunk, int buf) {
-  const float* src = p.stream + (size_t)chunk * kChunkFloats + p.wave * 2048 + p.lane * 4;
+  // wave-uniform base (SGPR pair) + 32-bit lane offset: the saddr form of global_load_lds, no 64-bit VALU address math;
+  // the LDS destination is wave-uniform as well (p.wave must be a readfirstlane value) so M0 is set by SALU
+  const float* base = p.stream + (size_t)chunk * kChunkFloats + p.wave * 2048;
   float* dst = p.lds + buf * kChunkFloats + p.wave * 2048;
+  const unsigned lane_off = (unsigned)p.lane * 16u;
+  // the instruction's immediate offset advances BOTH addresses: one address pair + one M0 per four 1 KiB pieces
 #pragma unroll
-  for (int k = 0; k < 8; ++k) __builtin_amdgcn_global_load_lds(AS1(src + k * 256), AS3(dst + k * 256), 16, 0, 0);
+  for (int g = 0; g < 2; ++g) {
+    const char* src = reinterpret_cast<const char*>(base + g * 1024) + lane_off;
+    __builtin_amdgcn_global_load_lds(AS1(src), AS3(dst + g * 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds(AS1(src), AS3(dst + g * 1024), 16, 1024, 0);
+    __builtin_amdgcn_global_load_lds(AS1(src), AS3(dst + g * 1024), 16, 2048, 0);
+    __builtin_amdgcn_global_load_lds(AS1(src), AS3(dst + g * 1024), 16, 3072, 0);
+  }
 }
 
 // prefetch the next chunk of the stream (wrapping to the next tile's first chunk)
