@@ -16,6 +16,7 @@
 // 8s..8s+7 of a 32x32 tile, converted to fp16, ARE the B fragment of k-step s (rows 16s + 8(j>>2) + 4h + (j&3)),
 // and the packed weights absorb that row permutation (mlp_layout.h, "f16x3 stream").
 #include "mlp_mma.h"
+#include <type_traits>
 
 namespace {
 using namespace tp_layout;
@@ -62,19 +63,20 @@ __device__ __forceinline__ long long tick() {
   asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
   return t;
 }
+#define TR_BEGIN(a) const long long tr_##a = tick()
+#define TR_END(k, a) p.tr[k] += tick() - tr_##a
+#else
+#define TR_BEGIN(a)
+#define TR_END(k, a)
 #endif
 __device__ __forceinline__ void ring_begin(Pipe& p) {
-#ifdef TP_TRACE
-  const long long t0 = tick();
-#endif
+  TR_BEGIN(d);
   int nxt = p.chunk + 2;
   if (nxt >= kNumChunks) nxt -= kNumChunks;
   int slot = p.buf + 2;
   if (slot >= kBufs) slot -= kBufs;
   dma_chunk(p, nxt, slot);
-#ifdef TP_TRACE
-  p.tr_dma += tick() - t0;
-#endif
+  TR_END(0, d);
 }
 __device__ __forceinline__ void ring_publish(Pipe& tr) {
 #ifdef TP_TRACE
@@ -83,7 +85,7 @@ __device__ __forceinline__ void ring_publish(Pipe& tr) {
   const long long t1 = tick();
   __builtin_amdgcn_s_barrier();
   const long long t2 = tick();
-  tr.tr_vm += t1 - t0; tr.tr_bar += t2 - t1; tr.tr_n += 1;
+  tr.tr[1] += t1 - t0; tr.tr[2] += t2 - t1;
 #else
   asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -135,9 +137,7 @@ __device__ __forceinline__ void mma_wide16(Pipe& p, Frag& f, f32x16 (&acc)[8], B
   constexpr int NP = KS * 8;
   const _Float16* l = chunk_ptr16(p);
   const _Float16* ln = next_chunk_ptr16(p);
-#ifdef TP_TRACE
-  const long long t0 = tick();
-#endif
+  TR_BEGIN(w);
 #pragma unroll
   for (int q = 0; q < NP; q += 2) {
     const int s = q >> 3, t = q & 7;
@@ -154,16 +154,16 @@ __device__ __forceinline__ void mma_wide16(Pipe& p, Frag& f, f32x16 (&acc)[8], B
     post(q);                   // VALU work that rides in the issue gaps of the six MFMAs above
     frag_step<NP>(p, f, q, l, ln);
   }
-#ifdef TP_TRACE
-  p.tr_loop += tick() - t0;
-#endif
+  TR_END(3, w);
   ring_advance(p);
 }
 
 // ---------------------------------------------------------------------------------------------- operand conversion
-// A layer's raw accumulators (bias included: they start at bias * 2^8) are copied once to VGPRs (`V`) and the next
-// layer's B operands are produced from them on the fly: ReLU, 2^-8, hi/lo split, pack for source tile ts+1 while the
-// MFMAs of source tile ts issue.
+// Two accumulator sets P and Q alternate: even layers read Q and accumulate into P, odd layers read P and
+// accumulate into Q (the layer loop is unrolled by two so that both roles are fixed registers -- no copy between
+// layers).  A set holds the raw accumulators, bias included (they start at bias * 2^8); the next layer's B operands
+// are produced from it on the fly: 2^-8, ReLU, hi/lo split, pack for source tile ts+1 while the MFMAs of source
+// tile ts issue.
 struct Xop { half8 h[2], l[2]; };     // B operands of one source tile (2 k-steps of 16 features)
 struct XBuild { half2v hp[8], lp[8]; };
 
@@ -206,8 +206,9 @@ __device__ __forceinline__ void part_gen16(Pipe& p, Frag& f, f32x16 (&acc)[8], c
   for (int ts = 0; ts < 8; ++ts) {
     XBuild xb;
     ring_begin(p);
-    mma_wide16<2>(p, f, acc, [&](int s, half8& xh, half8& xl) { xh = X.h[s]; xl = X.l[s]; },
-                  [&](int q) { if (ts < 7) convert2(V[ts < 7 ? ts + 1 : 0], q, xb.hp[q >> 1], xb.lp[q >> 1], amax); });
+    const auto bop = [&](int s, half8& xh, half8& xl) { xh = X.h[s]; xl = X.l[s]; };
+    const auto cvt = [&](int q) { if (ts < 7) convert2(V[ts < 7 ? ts + 1 : 0], q, xb.hp[q >> 1], xb.lp[q >> 1], amax); };
+    mma_wide16<2>(p, f, acc, bop, cvt);
     if (ts < 7) X = finish(xb);
   }
 }
@@ -273,17 +274,23 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_f16x3_kernel(Params P) {
   __syncthreads();
   Frag frag;
   frag_prime(p, frag);
+  // Persistent workgroups that start together stay in lockstep, so every CU would park / reload its 128 KB trunk
+  // feature (and miss on the same weight chunks) at the same instant.  Spread the start phases over ~one tile.
+  for (int i = (blockIdx.x * 37) & 63; i > 0; --i) __builtin_amdgcn_s_sleep(127);
 #ifdef TP_TRACE
   const long long tr_start = tick();
 #endif
 
-  f32x4* ws = reinterpret_cast<f32x4*>(P.workspace + (size_t)blockIdx.x * (128 * 256)) + tid;
+  // park buffer of this workgroup (128 KiB) as a buffer resource: lane offset in a VGPR, the 4 KiB row offsets in
+  // SGPRs -- 64-bit per-row VGPR addresses would be spilled and reloaded one by one
+  const __amdgpu_buffer_rsrc_t ws = __builtin_amdgcn_make_buffer_rsrc(P.workspace + (size_t)blockIdx.x * (128 * 256), 0, 128 * 256 * 4, 0x00020000);
   const auto staged = [&](int s, half8& xh, half8& xl, int ks0) {
     xh = *reinterpret_cast<const half8*>(st + (((ks0 + s) * 2 + 0) * kThreads + tid) * 8);
     xl = *reinterpret_cast<const half8*>(st + (((ks0 + s) * 2 + 1) * kThreads + tid) * 8);
   };
 
   for (int64_t tile = blockIdx.x; tile < P.n_tiles; tile += gridDim.x) {
+    TR_BEGIN(pro);
     const int64_t s_raw = tile * 128 + wave * 32 + j;
     const bool live = s_raw < P.n_samples;
     const int64_t s = live ? s_raw : P.n_samples - 1;
@@ -308,33 +315,62 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_f16x3_kernel(Params P) {
       for (int c = 0; c < 3; ++c) { x[c] = P.points[3 * s + c]; vu[c] = P.ray_unit[3 * s + c]; }
     }
 
-    f32x16 V[8];                // raw accumulators of the previous layer (bias included, scaled 2^8)
-    f32x16 acc[8];
+    asm volatile("" :: "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(vu[0]), "v"(vu[1]), "v"(vu[2]));
+    TR_END(4, pro);
+    f32x16 SP[8], SQ[8];        // the two accumulator sets (see "operand conversion")
     float amax = 0.f;
     float sig_s = 0.f, sig_t = 0.f, unc = 0.f, rgb_t[3] = {0.f, 0.f, 0.f}, rgb_s[3] = {0.f, 0.f, 0.f};
 
-#pragma nounroll
-    for (int li = 0; li < kNumWide; ++li) {
-      if (li == L7) {
-        const f32x16 a = part_head16(p, frag, V, amax);
-        sig_s = softplus(fmaf(a[0], kInvScale, bias_lds[kHeadBiasOff + 0]));
+    // a narrow output layer over relu(S); which == 0: sigma (reads L6), 1: transient head (reads T2), 2: static rgb
+    const auto head = [&](const f32x16 (&S)[8], int which) {
+      TR_BEGIN(h);
+      const f32x16 a = part_head16(p, frag, S, amax);
+      asm volatile("" :: "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]));
+      TR_END(7, h);
+      const float* hb = bias_lds + kHeadBiasOff + (which == 0 ? 0 : (which == 1 ? 1 : 6));
+      const float h0 = fmaf(a[0], kInvScale, hb[0]), h1 = fmaf(a[1], kInvScale, hb[1]), h2 = fmaf(a[2], kInvScale, hb[2]);
+      if (which == 0) {
+        sig_s = softplus(h0);
+      } else {
+        const float r0 = sigmoid(h0), r1 = sigmoid(h1), r2 = sigmoid(h2);
+        if (which == 1) {
+          rgb_t[0] = r0; rgb_t[1] = r1; rgb_t[2] = r2;
+          sig_t = softplus(fmaf(a[3], kInvScale, hb[3]));
+          unc = softplus(fmaf(a[0], kInvScale, hb[4]));      // row 4 = register 0 of the upper lane half
+        } else {
+          rgb_s[0] = r0; rgb_s[1] = r1; rgb_s[2] = r2;
+        }
       }
-      if (li == R0) {
+    };
+
+    // one wide layer: reads set S (the previous layer's accumulators), accumulates into set D
+    const auto layer = [&](auto even_tag, int li, f32x16 (&S)[8], f32x16 (&D)[8]) {
+      constexpr bool EVEN = decltype(even_tag)::value;
+      if (!EVEN && (li == L7 || li == R0)) head(S, li == L7 ? 0 : 1);     // both heads read set P
+      if (!EVEN && li == R0) {
+        // the trunk feature (L7's accumulators, parked below) comes back into the set the transient head just freed
+        TR_BEGIN(rl);
 #pragma unroll
         for (int t = 0; t < 8; ++t)
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
-            const f32x4 v = ws[(t * 4 + g) * kThreads];
-            V[t][g * 4 + 0] = v.x; V[t][g * 4 + 1] = v.y; V[t][g * 4 + 2] = v.z; V[t][g * 4 + 3] = v.w;
+            const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ws, tid * 16, (t * 4 + g) * 4096, 0));
+            S[t][g * 4 + 0] = v.x; S[t][g * 4 + 1] = v.y; S[t][g * 4 + 2] = v.z; S[t][g * 4 + 3] = v.w;
           }
+        asm volatile("" :: "v"(S[7][15]), "v"(S[0][0]));
+        TR_END(10, rl);
       }
-      init_acc(acc, bias_lds + (li * 2 + hh) * 128);
+      TR_BEGIN(ia);
+      init_acc(D, bias_lds + (li * 2 + hh) * 128);
+      asm volatile("" :: "v"(D[7][15]), "v"(D[0][0]), "v"(D[3][3]));
+      TR_END(8, ia);
 
-      if (li != L0) part_gen16(p, frag, acc, V, amax);
+      if (li != L0) part_gen16(p, frag, D, S, amax);
 
-      if (li == L0 || li == L4) {
+      if (EVEN && (li == L0 || li == L4)) {
         // [PE(x) | x | pad] in natural column order; this lane stages slots 16 ks + 8 h + jj.  Staged once per tile:
         // the skip connection (L4) re-reads what L0 staged, nothing overwrites it before T0
+        TR_BEGIN(pe);
 #pragma nounroll
         for (int e = 0; e < (li == L0 ? 32 : 0); ++e) {
           const int ks = e >> 3, jj = e & 7, slot = 16 * ks + 8 * hh + jj;
@@ -349,20 +385,22 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_f16x3_kernel(Params P) {
           }
           stage(st, tid, ks, jj, v);
         }
+        TR_END(5, pe);
 #pragma unroll
         for (int qd = 0; qd < 2; ++qd) {
           ring_begin(p);
-          mma_wide16<2>(p, frag, acc, [&](int s_, half8& xh, half8& xl) { staged(s_, xh, xl, qd * 2); }, [](int) {});
+          mma_wide16<2>(p, frag, D, [&](int s_, half8& xh, half8& xl) { staged(s_, xh, xl, qd * 2); }, [](int) {});
         }
-      } else if (li == T0) {
+      } else if (EVEN && li == T0) {
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) stage(st, tid, 0, jj, P.lat_trans[b * 16 + 8 * hh + jj]);
         ring_begin(p);
-        mma_wide16<1>(p, frag, acc, [&](int s_, half8& xh, half8& xl) { staged(s_, xh, xl, 0); }, [](int) {});
-      } else if (li == R0) {
+        mma_wide16<1>(p, frag, D, [&](int s_, half8& xh, half8& xl) { staged(s_, xh, xl, 0); }, [](int) {});
+      } else if (!EVEN && li == R0) {
         // [ray_unit | PE(ray_unit) | x | light] in natural column order, 78 of 80 slots
+        TR_BEGIN(r0s);
 #pragma nounroll
-        for (int e = 0; e < 40; ++e) {
+        for (int e = 0; e < 16; ++e) {
           const int ks = e >> 3, jj = e & 7, slot = 16 * ks + 8 * hh + jj;
           float v;
           if (slot < 3) {
@@ -374,51 +412,60 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_f16x3_kernel(Params P) {
             v = tp::sincos_sel(arg, sc);
           } else if (slot < 30) {
             v = slot == 27 ? x[0] : (slot == 28 ? x[1] : x[2]);
-          } else if (slot < 78) {
-            v = P.lat_light[b * 48 + slot - 30];
           } else {
-            v = 0.0f;
+            v = P.lat_light[b * 48 + slot - 30];
           }
           stage(st, tid, ks, jj, v);
         }
+        // k-steps 2..4 are latent-code slots only: 8 loads at a time (one latency per k-step), one 16-byte store per
+        // (k-step, hi/lo)
+#pragma unroll
+        for (int ks = 2; ks < 5; ++ks) {
+          float lv[8];
+#pragma unroll
+          for (int jj = 0; jj < 8; ++jj) {
+            const int slot = 16 * ks + 8 * hh + jj;
+            lv[jj] = slot < 78 ? P.lat_light[b * 48 + slot - 30] : 0.0f;
+          }
+          half8 hi8, lo8;
+#pragma unroll
+          for (int jj = 0; jj < 8; ++jj) {
+            hi8[jj] = (_Float16)lv[jj];
+            lo8[jj] = (_Float16)(lv[jj] - (float)hi8[jj]);
+          }
+          *reinterpret_cast<half8*>(st + ((ks * 2 + 0) * kThreads + tid) * 8) = hi8;
+          *reinterpret_cast<half8*>(st + ((ks * 2 + 1) * kThreads + tid) * 8) = lo8;
+        }
+        TR_END(6, r0s);
 #pragma unroll
         for (int qd = 0; qd < 3; ++qd) {
           ring_begin(p);
-          if (qd < 2) mma_wide16<2>(p, frag, acc, [&](int s_, half8& xh, half8& xl) { staged(s_, xh, xl, qd * 2); }, [](int) {});
-          else mma_wide16<1>(p, frag, acc, [&](int s_, half8& xh, half8& xl) { staged(s_, xh, xl, 4); }, [](int) {});
+          if (qd < 2) mma_wide16<2>(p, frag, D, [&](int s_, half8& xh, half8& xl) { staged(s_, xh, xl, qd * 2); }, [](int) {});
+          else mma_wide16<1>(p, frag, D, [&](int s_, half8& xh, half8& xl) { staged(s_, xh, xl, 4); }, [](int) {});
         }
       }
 
-      // the raw accumulators become the next layer's input; un-scale / ReLU / hi+lo split happen where they are
-      // consumed (convert2), overlapped with that layer's MFMAs
-#pragma unroll
-      for (int t = 0; t < 8; ++t) V[t] = acc[t];
-
-      if (li == L7) {
+      if (!EVEN && li == L7) {
+        // park the trunk feature (raw accumulators) for R0: T1 overwrites this set
+        TR_BEGIN(vc);
 #pragma unroll
         for (int t = 0; t < 8; ++t)
 #pragma unroll
           for (int g = 0; g < 4; ++g)
-            ws[(t * 4 + g) * kThreads] = f32x4{V[t][g * 4 + 0], V[t][g * 4 + 1], V[t][g * 4 + 2], V[t][g * 4 + 3]};
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{D[t][g * 4 + 0], D[t][g * 4 + 1], D[t][g * 4 + 2], D[t][g * 4 + 3]}),
+                                                   ws, tid * 16, (t * 4 + g) * 4096, 0);
+        TR_END(9, vc);
       }
-      if (li == T2) {
-        const f32x16 a = part_head16(p, frag, V, amax);
-        const float* hb = bias_lds + kHeadBiasOff + 1;
-        rgb_t[0] = sigmoid(fmaf(a[0], kInvScale, hb[0]));
-        rgb_t[1] = sigmoid(fmaf(a[1], kInvScale, hb[1]));
-        rgb_t[2] = sigmoid(fmaf(a[2], kInvScale, hb[2]));
-        sig_t = softplus(fmaf(a[3], kInvScale, hb[3]));
-        unc = softplus(fmaf(a[0], kInvScale, hb[4]));      // row 4 = register 0 of the upper lane half
-      }
-      if (li == R2) {
-        const f32x16 a = part_head16(p, frag, V, amax);
-        const float* hb = bias_lds + kHeadBiasOff + 6;
-        rgb_s[0] = sigmoid(fmaf(a[0], kInvScale, hb[0]));
-        rgb_s[1] = sigmoid(fmaf(a[1], kInvScale, hb[1]));
-        rgb_s[2] = sigmoid(fmaf(a[2], kInvScale, hb[2]));
-      }
-    }
+    };
 
+#pragma nounroll
+    for (int pr = 0; pr < kNumWide / 2; ++pr) {
+      layer(std::true_type{}, 2 * pr, SQ, SP);
+      layer(std::false_type{}, 2 * pr + 1, SP, SQ);
+    }
+    head(SQ, 2);
+
+    TR_BEGIN(o);
     if (live) {
       if (hh == 0) {
         float2* o = reinterpret_cast<float2*>(P.rgb + s * 6);
@@ -431,11 +478,14 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_f16x3_kernel(Params P) {
       }
     }
     if (P.status != nullptr && !(amax < 6.0e4f)) atomicOr(P.status, 1);
+    TR_END(11, o);
   }
 #ifdef TP_TRACE
-  if (lane == 0 && (blockIdx.x == 0 || blockIdx.x == 100) && P.n_tiles > 1000)
-    printf("trace wg %d wave %d: total %lld ticks, %lld chunks, vmcnt wait %lld, barrier wait %lld, dma issue %lld, wide loops %lld\n", (int)blockIdx.x, wave,
-           tick() - tr_start, p.tr_n, p.tr_vm, p.tr_bar, p.tr_dma, p.tr_loop);
+  if (lane == 0 && blockIdx.x == 100 && wave == 1 && P.n_tiles > 1000) {
+    const long long tot = tick() - tr_start;
+    printf("trace total %lld | dma %lld vm %lld bar %lld wide %lld | pro %lld pe %lld r0 %lld heads %lld | - %lld vcopy %lld reload %lld out %lld\n",
+           tot, p.tr[0], p.tr[1], p.tr[2], p.tr[3], p.tr[4], p.tr[5], p.tr[6], p.tr[7], p.tr[8], p.tr[9], p.tr[10], p.tr[11]);
+  }
 #endif
 }
 

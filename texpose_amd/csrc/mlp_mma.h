@@ -26,7 +26,7 @@ struct Pipe {
   int buf;
   int wave, lane;
 #ifdef TP_TRACE
-  long long tr_vm = 0, tr_bar = 0, tr_n = 0, tr_dma = 0, tr_loop = 0;   // diagnostic build only: wait ticks at the chunk barrier
+  long long tr[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // diagnostic build only: cycles per kernel section
 #endif
 };
 
