@@ -167,14 +167,19 @@ __device__ __forceinline__ void mma_wide16(Pipe& p, Frag& f, f32x16 (&acc)[8], B
 struct Xop { half8 h[2], l[2]; };     // B operands of one source tile (2 k-steps of 16 features)
 struct XBuild { half2v hp[8], lp[8]; };
 
-__device__ __forceinline__ void convert2(const f32x16& a, int e0, half2v& hp, half2v& lp, float& amax) {
-  const float v0 = fmaxf(a[e0] * kInvScale, 0.0f);         // mul first: its result is canonical, so the max
-  const float v1 = fmaxf(a[e0 + 1] * kInvScale, 0.0f);     // needs no extra canonicalising v_max
-  amax = fmaxf(amax, fmaxf(v0, v1));
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+// range guard: running maximum of the packed hi halves (v_pk_max_f16, two elements per instruction).  Round-to-zero
+// conversion saturates at 65504, so "amax >= 6e4" still detects every out-of-range activation.
+struct Guard { half2v m = {(__fp16)0.0f, (__fp16)0.0f}; };
+__device__ __forceinline__ void convert2(const f32x16& a, int e0, half2v& hp, half2v& lp, Guard& g) {
+  const f32x2 sc = f32x2{a[e0], a[e0 + 1]} * kInvScale;      // v_pk_mul_f32; its result is canonical, so the max
+  const float v0 = fmaxf(sc.x, 0.0f);                         // needs no extra canonicalising v_max
+  const float v1 = fmaxf(sc.y, 0.0f);
   const float h0 = __uint_as_float(__float_as_uint(v0) & 0xFFFFE000u);   // 11 significant bits: exact in fp16
   const float h1 = __uint_as_float(__float_as_uint(v1) & 0xFFFFE000u);
   hp = __builtin_amdgcn_cvt_pkrtz(h0, h1);
   lp = __builtin_amdgcn_cvt_pkrtz(v0 - h0, v1 - h1);
+  g.m = __builtin_elementwise_max(g.m, hp);
 }
 __device__ __forceinline__ Xop finish(const XBuild& b) {
   Xop x;
@@ -183,7 +188,7 @@ __device__ __forceinline__ Xop finish(const XBuild& b) {
   x.h[0] = pack8(h0); x.h[1] = pack8(h1); x.l[0] = pack8(l0); x.l[1] = pack8(l1);
   return x;
 }
-__device__ __forceinline__ Xop convert_tile(const f32x16& a, float& amax) {
+__device__ __forceinline__ Xop convert_tile(const f32x16& a, Guard& amax) {
   XBuild xb;
 #pragma unroll
   for (int e = 0; e < 16; e += 2) convert2(a, e, xb.hp[e >> 1], xb.lp[e >> 1], amax);
@@ -200,7 +205,7 @@ __device__ __forceinline__ void init_acc(f32x16 (&acc)[8], const float* bl) {
     }
 }
 
-__device__ __forceinline__ void part_gen16(Pipe& p, Frag& f, f32x16 (&acc)[8], const f32x16 (&V)[8], float& amax) {
+__device__ __forceinline__ void part_gen16(Pipe& p, Frag& f, f32x16 (&acc)[8], const f32x16 (&V)[8], Guard& amax) {
   Xop X = convert_tile(V[0], amax);
 #pragma unroll
   for (int ts = 0; ts < 8; ++ts) {
@@ -214,7 +219,7 @@ __device__ __forceinline__ void part_gen16(Pipe& p, Frag& f, f32x16 (&acc)[8], c
 }
 
 // 1..5-row output layer over relu(V): one chunk, 16 k-steps, one accumulator tile, operands converted just in time
-__device__ __forceinline__ f32x16 part_head16(Pipe& p, Frag& f, const f32x16 (&V)[8], float& amax) {
+__device__ __forceinline__ f32x16 part_head16(Pipe& p, Frag& f, const f32x16 (&V)[8], Guard& amax) {
   f32x16 acc = {0};
   ring_begin(p);
   const _Float16* l = chunk_ptr16(p);
@@ -318,7 +323,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_f16x3_kernel(Params P) {
     asm volatile("" :: "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(vu[0]), "v"(vu[1]), "v"(vu[2]));
     TR_END(4, pro);
     f32x16 SP[8], SQ[8];        // the two accumulator sets (see "operand conversion")
-    float amax = 0.f;
+    Guard amax;
     float sig_s = 0.f, sig_t = 0.f, unc = 0.f, rgb_t[3] = {0.f, 0.f, 0.f}, rgb_s[3] = {0.f, 0.f, 0.f};
 
     // a narrow output layer over relu(S); which == 0: sigma (reads L6), 1: transient head (reads T2), 2: static rgb
@@ -477,7 +482,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_f16x3_kernel(Params P) {
         P.uncert[s] = unc;
       }
     }
-    if (P.status != nullptr && !(amax < 6.0e4f)) atomicOr(P.status, 1);
+    if (P.status != nullptr && !(fmaxf((float)amax.m[0], (float)amax.m[1]) < 6.0e4f)) atomicOr(P.status, 1);
     TR_END(11, o);
   }
 #ifdef TP_TRACE
