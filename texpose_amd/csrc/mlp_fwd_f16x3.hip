@@ -66,8 +66,11 @@ __device__ __forceinline__ long long tick() {
 #define TR_BEGIN(a) const long long tr_##a = tick()
 #define TR_END(k, a) p.tr[k] += tick() - tr_##a
 #else
-#define TR_BEGIN(a)
-#define TR_END(k, a)
+// product build: the section marks stay compiler fences.  They keep hipcc from moving LDS / memory operations of
+// one section into another (e.g. hoisting the 32 bias reads of init_acc across a head), which lengthens live ranges
+// past what the 512-register budget next to two accumulator sets allows and ends in scratch spills.
+#define TR_BEGIN(a) asm volatile("" ::: "memory")
+#define TR_END(k, a) asm volatile("" ::: "memory")
 #endif
 __device__ __forceinline__ void ring_begin(Pipe& p) {
   TR_BEGIN(d);
@@ -262,6 +265,14 @@ __device__ __forceinline__ void stage(_Float16* st, int tid, int ks, int j, floa
   st[((ks * 2 + 1) * kThreads + tid) * 8 + j] = (_Float16)(v - (float)hi);
 }
 
+// the same for an arbitrary slot of this SAMPLE (either lane of the sample's lane pair may own it): tid_lo = tid & ~32
+__device__ __forceinline__ void stage_slot(_Float16* st, int tid_lo, int slot, float v) {
+  const int ks = slot >> 4, owner = tid_lo | ((slot & 8) << 2), jj = slot & 7;
+  const _Float16 hi = (_Float16)v;
+  st[((ks * 2 + 0) * kThreads + owner) * 8 + jj] = hi;
+  st[((ks * 2 + 1) * kThreads + owner) * 8 + jj] = (_Float16)(v - (float)hi);
+}
+
 __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_f16x3_kernel(Params P) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -366,6 +377,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_f16x3_kernel(Params P) {
         TR_END(10, rl);
       }
       TR_BEGIN(ia);
+      asm volatile("" ::: "memory");     // keep the 32 bias reads below the head / reload (hoisted, they get spilled)
       init_acc(D, bias_lds + (li * 2 + hh) * 128);
       asm volatile("" :: "v"(D[7][15]), "v"(D[0][0]), "v"(D[3][3]));
       TR_END(8, ia);
@@ -376,19 +388,21 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_f16x3_kernel(Params P) {
         // [PE(x) | x | pad] in natural column order; this lane stages slots 16 ks + 8 h + jj.  Staged once per tile:
         // the skip connection (L4) re-reads what L0 staged, nothing overwrites it before T0
         TR_BEGIN(pe);
+        // 30 (coordinate, octave) pairs, 15 per lane of the sample's lane pair: one range reduction yields the sin AND
+        // the cos entry (slots 20 c + l and 20 c + 10 + l, whichever lane's operand registers they belong to)
+        if (li == L0) {
 #pragma nounroll
-        for (int e = 0; e < (li == L0 ? 32 : 0); ++e) {
-          const int ks = e >> 3, jj = e & 7, slot = 16 * ks + 8 * hh + jj;
-          float v;
-          if (slot < 60) {
-            const int c = slot / 20, rem = slot - c * 20, sc = rem / 10, l = rem - sc * 10;
+          for (int i = 0; i < 15; ++i) {
+            const int pi_ = hh * 15 + i, c = (pi_ * 205) >> 11, l = pi_ - c * 10;
             const float xc = c == 0 ? x[0] : (c == 1 ? x[1] : x[2]);
-            const float arg = tp::mul_rn(xc, ldexpf(3.14159274101257324f, l));
-            v = tp::sincos_sel(arg, sc);
-          } else {
-            v = slot == 60 ? x[0] : (slot == 61 ? x[1] : (slot == 62 ? x[2] : 0.0f));
+            float sv, cv;
+            tp::sincos_both(tp::mul_rn(xc, ldexpf(3.14159274101257324f, l)), sv, cv);
+            stage_slot(st, tid & ~32, 20 * c + l, sv);
+            stage_slot(st, tid & ~32, 20 * c + 10 + l, cv);
           }
-          stage(st, tid, ks, jj, v);
+          if (hh) {
+            stage(st, tid, 3, 4, x[0]); stage(st, tid, 3, 5, x[1]); stage(st, tid, 3, 6, x[2]); stage(st, tid, 3, 7, 0.0f);
+          }
         }
         TR_END(5, pe);
 #pragma unroll
@@ -404,23 +418,22 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_f16x3_kernel(Params P) {
       } else if (!EVEN && li == R0) {
         // [ray_unit | PE(ray_unit) | x | light] in natural column order, 78 of 80 slots
         TR_BEGIN(r0s);
+        // slots 0..31: ray_unit (0..2), PE(ray_unit) (3 + 8 c + 4 sc + l: 12 sin/cos pairs, 6 per lane), x (27..29),
+        // the first two latent entries (30, 31)
 #pragma nounroll
-        for (int e = 0; e < 16; ++e) {
-          const int ks = e >> 3, jj = e & 7, slot = 16 * ks + 8 * hh + jj;
-          float v;
-          if (slot < 3) {
-            v = slot == 0 ? vu[0] : (slot == 1 ? vu[1] : vu[2]);
-          } else if (slot < 27) {
-            const int qq = slot - 3, c = qq >> 3, sc = (qq >> 2) & 1, l = qq & 3;
-            const float vc = c == 0 ? vu[0] : (c == 1 ? vu[1] : vu[2]);
-            const float arg = tp::mul_rn(vc, ldexpf(3.14159274101257324f, l));
-            v = tp::sincos_sel(arg, sc);
-          } else if (slot < 30) {
-            v = slot == 27 ? x[0] : (slot == 28 ? x[1] : x[2]);
-          } else {
-            v = P.lat_light[b * 48 + slot - 30];
-          }
-          stage(st, tid, ks, jj, v);
+        for (int i = 0; i < 6; ++i) {
+          const int pi_ = hh * 6 + i, c = pi_ >> 2, l = pi_ & 3;
+          const float vc = c == 0 ? vu[0] : (c == 1 ? vu[1] : vu[2]);
+          float sv, cv;
+          tp::sincos_both(tp::mul_rn(vc, ldexpf(3.14159274101257324f, l)), sv, cv);
+          stage_slot(st, tid & ~32, 3 + 8 * c + l, sv);
+          stage_slot(st, tid & ~32, 3 + 8 * c + 4 + l, cv);
+        }
+        if (hh == 0) {
+          stage(st, tid, 0, 0, vu[0]); stage(st, tid, 0, 1, vu[1]); stage(st, tid, 0, 2, vu[2]);
+        } else {
+          stage(st, tid, 1, 3, x[0]); stage(st, tid, 1, 4, x[1]); stage(st, tid, 1, 5, x[2]);
+          stage(st, tid, 1, 6, P.lat_light[b * 48 + 0]); stage(st, tid, 1, 7, P.lat_light[b * 48 + 1]);
         }
         // k-steps 2..4 are latent-code slots only: 8 loads at a time (one latency per k-step), one 16-byte store per
         // (k-step, hi/lo)

@@ -37,25 +37,40 @@ __device__ __forceinline__ float sub_rn(float a, float b) { return __fsub_rn(a, 
 __device__ __forceinline__ float div_rn(float a, float b) { return __fdiv_rn(a, b); }
 __device__ __forceinline__ float fma_rn(float a, float b, float c) { return __fmaf_rn(a, b, c); }
 
-// sin(a) (quad = 0) or cos(a) (quad = 1) of the fp32 value `a`, accurate to ~1 ulp for |a| < 2^17 (the positional
-// encoding evaluates x * 2^l * pi with |x| of a few units, i.e. arguments up to ~1e4 rad).  One branch-free path
-// for both functions: Cody-Waite reduction by pi/2 with a 3-term split and FMAs (the first product is exact inside
-// the FMA), then the Cephes single-precision minimax polynomials on [-pi/4, pi/4]; cos is the same code one
-// quadrant later, so a wave whose lanes mix sin and cos entries does not evaluate both.  ocml's sinf/cosf cost
-// ~4x more instructions and were 20 % of the f16x3 forward.
+// sin / cos of the fp32 value `a`, accurate to ~1 ulp (the positional encoding evaluates x * 2^l * pi with |x| of a
+// few units, i.e. arguments up to ~1e4 rad).  Branch-free, no libm: the reduction by pi/2 runs in fp64 (two-term
+// split, exact for |a| far beyond any encodable coordinate; Inf/NaN give NaN like sinf/cosf), then the Cephes
+// single-precision minimax polynomials on [-pi/4, pi/4].  ocml's sinf/cosf cost ~4x more instructions and were 20 %
+// of the f16x3 forward; their inlined slow paths also cost registers next to the 256-register accumulator sets.
+struct Reduced { float r, sp, cp; int q; };
+__device__ __forceinline__ Reduced reduce_pio2(float a) {
+  const double ad = (double)a;
+  const double kd = rint(ad * 0.63661977236758138);
+  double rd = __fma_rn(-kd, 1.5707963267948966, ad);
+  rd = __fma_rn(-kd, 6.123233995736766e-17, rd);
+  Reduced o;
+  o.r = (float)rd;
+  o.q = (int)(long long)kd;            // only the two low bits matter
+  const float r = o.r, z = r * r;
+  o.sp = __fmaf_rn(__fmaf_rn(__fmaf_rn(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f) * z, r, r);
+  o.cp = __fmaf_rn(__fmaf_rn(__fmaf_rn(2.443315711809948e-5f, z, -1.388731625493765e-3f), z,
+                              4.166664568298827e-2f) * z, z, __fmaf_rn(-0.5f, z, 1.0f));
+  return o;
+}
+// sin(a) (quad = 0) or cos(a) (quad = 1): cos is the same code one quadrant later
 __device__ __forceinline__ float sincos_sel(float a, int quad) {
-  if (__builtin_expect(!(fabsf(a) < 131072.0f), 0)) return quad ? cosf(a) : sinf(a);
-  const float kf = rintf(a * 0.6366197466850281f);
-  float r = __fmaf_rn(-kf, 1.5707963705062866f, a);
-  r = __fmaf_rn(-kf, -4.371138828673793e-08f, r);
-  r = __fmaf_rn(-kf, -1.7151245100058819e-15f, r);
-  const int q = (int)kf + quad;
-  const float z = r * r;
-  const float sp = __fmaf_rn(__fmaf_rn(__fmaf_rn(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f) * z, r, r);
-  const float cp = __fmaf_rn(__fmaf_rn(__fmaf_rn(2.443315711809948e-5f, z, -1.388731625493765e-3f), z,
-                                       4.166664568298827e-2f) * z, z, __fmaf_rn(-0.5f, z, 1.0f));
-  const float v = (q & 1) ? cp : sp;
+  const Reduced o = reduce_pio2(a);
+  const int q = o.q + quad;
+  const float v = (q & 1) ? o.cp : o.sp;
   return (q & 2) ? -v : v;
+}
+// both from one reduction: bit-identical to sincos_sel(a, 0) / sincos_sel(a, 1)
+__device__ __forceinline__ void sincos_both(float a, float& s, float& c) {
+  const Reduced o = reduce_pio2(a);
+  const float vs = (o.q & 1) ? o.cp : o.sp;
+  const float vc = (o.q & 1) ? o.sp : o.cp;
+  s = (o.q & 2) ? -vs : vs;
+  c = ((o.q + 1) & 2) ? -vc : vc;
 }
 
 }  // namespace tp
