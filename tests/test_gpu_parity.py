@@ -580,7 +580,11 @@ def test_full_size_render_properties(ops):
         outs[prec] = keep
         ops.check_mlp_status(dev())
         assert float((keep["opacity"] - 1).abs().max()) < 1e-5 and float((keep["opacity_static"] - 1).abs().max()) < 1e-5
-        assert float(keep["rgb"].min()) >= 0 and float(keep["rgb"].max()) <= 1 + 1e-5      # opacity itself is 1 +- 1e-5
+        # the static-only composite is a convex combination of colours in [0,1] (opacity itself is 1 +- 1e-5); the
+        # combined colour sums static AND transient weights (reference composite, nerf_static_transient_light.py:196-203)
+        # and may legitimately exceed 1
+        assert float(keep["rgb_static"].min()) >= 0 and float(keep["rgb_static"].max()) <= 1 + 1e-5
+        assert float(keep["rgb"].min()) >= 0 and bool(torch.isfinite(keep["rgb"]).all())
         zn, zf = cu(sc["z_near"]), cu(sc["z_far"])
         d = keep["depth"][0, :, 0]
         assert bool(((d >= zn[0] - 1e-4) & (d <= zf[0] + 1e-4)).all())

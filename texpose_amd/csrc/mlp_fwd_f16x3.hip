@@ -209,7 +209,10 @@ __device__ __forceinline__ void init_acc(f32x16 (&acc)[8], const float* bl) {
 }
 
 __device__ __forceinline__ void part_gen16(Pipe& p, Frag& f, f32x16 (&acc)[8], const f32x16 (&V)[8], Guard& amax) {
+  TR_BEGIN(g0);
   Xop X = convert_tile(V[0], amax);
+  asm volatile("" :: "v"(X.h[0]), "v"(X.l[1]));
+  TR_END(12, g0);
 #pragma unroll
   for (int ts = 0; ts < 8; ++ts) {
     XBuild xb;
@@ -411,8 +414,10 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_f16x3_kernel(Params P) {
           mma_wide16<2>(p, frag, D, [&](int s_, half8& xh, half8& xl) { staged(s_, xh, xl, qd * 2); }, [](int) {});
         }
       } else if (EVEN && li == T0) {
+        TR_BEGIN(t0s);
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) stage(st, tid, 0, jj, P.lat_trans[b * 16 + 8 * hh + jj]);
+        TR_END(13, t0s);
         ring_begin(p);
         mma_wide16<1>(p, frag, D, [&](int s_, half8& xh, half8& xl) { staged(s_, xh, xl, 0); }, [](int) {});
       } else if (!EVEN && li == R0) {
@@ -501,8 +506,8 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_f16x3_kernel(Params P) {
 #ifdef TP_TRACE
   if (lane == 0 && blockIdx.x == 100 && wave == 1 && P.n_tiles > 1000) {
     const long long tot = tick() - tr_start;
-    printf("trace total %lld | dma %lld vm %lld bar %lld wide %lld | pro %lld pe %lld r0 %lld heads %lld | - %lld vcopy %lld reload %lld out %lld\n",
-           tot, p.tr[0], p.tr[1], p.tr[2], p.tr[3], p.tr[4], p.tr[5], p.tr[6], p.tr[7], p.tr[8], p.tr[9], p.tr[10], p.tr[11]);
+    printf("trace total %lld | dma %lld vm %lld bar %lld wide %lld | pro %lld pe %lld r0 %lld heads %lld | init %lld park %lld reload %lld out %lld | gen0 %lld t0stage %lld\n",
+           tot, p.tr[0], p.tr[1], p.tr[2], p.tr[3], p.tr[4], p.tr[5], p.tr[6], p.tr[7], p.tr[8], p.tr[9], p.tr[10], p.tr[11], p.tr[12], p.tr[13]);
   }
 #endif
 }

@@ -26,7 +26,7 @@ struct Pipe {
   int buf;
   int wave, lane;
 #ifdef TP_TRACE
-  long long tr[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // diagnostic build only: cycles per kernel section
+  long long tr[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // diagnostic build only: cycles per kernel section
 #endif
 };
 

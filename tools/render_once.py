@@ -12,8 +12,12 @@ g.nerf.precision = prec
 pose, intr = sc["pose"].to(dev), sc["intr"].to(dev)
 dr = (sc["z_near"].to(dev)[:, :, None], sc["z_far"].to(dev)[:, :, None])
 mask = torch.ones(1, 480, 640, device=dev)
+import time
 with torch.no_grad():
     for _ in range(n):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
         ret = g.render_by_slices(opt, pose, intr=intr, depth_range=dr, object_mask=mask, sample_idx=None, mode="val")
-torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        print("image ms", (time.perf_counter() - t0) * 1e3)
 print("done", float(ret.rgb.mean()))

@@ -1,0 +1,29 @@
+"""Collapse the rocprofv3 output of tools/profile_mlp.sh into one JSON: per pass, the counters of the LAST mlp_fwd
+dispatch (the second image: caches warm) and its duration; plus the kernel-stats table of the bench run."""
+import csv, glob, json, os, sys
+
+out = sys.argv[1]
+res = {}
+for d in sorted(glob.glob(os.path.join(out, "*"))):
+    if not os.path.isdir(d):
+        continue
+    name = os.path.basename(d)
+    if name == "stats":
+        for f in glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True):
+            rows = list(csv.DictReader(open(f)))
+            res["kernel_stats"] = [{k: r[k] for k in ("Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage") if k in r}
+                                   for r in rows[:12]]
+        continue
+    cnt, disp = {}, None
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        rows = list(csv.DictReader(open(f)))
+        if not rows:
+            continue
+        disp = max(int(r["Dispatch_Id"]) for r in rows)
+        for r in rows:
+            if int(r["Dispatch_Id"]) == disp:
+                cnt[r["Counter_Name"]] = cnt.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+                if "Start_Timestamp" in r and "End_Timestamp" in r:
+                    cnt["kernel_ms"] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
+    res[name] = cnt
+print(json.dumps(res, indent=1))
