@@ -188,6 +188,81 @@ def test_patch_gather_and_losses_g10():
     assert s["mask"][0, 0, 0, 0] == 0          # x=y=+1 rounds to tap 16 -> out of range (quirk 10)
 
 
+def test_train_iteration_g13_oracle():
+    """First iteration of G13 (real reference nerf_trainstep + disc_trainstep) re-done with the CPU oracle for the
+    render / gathers / losses and stock torch for the discriminator: losses, head gradients, discriminator gradients
+    (R1 double backward included)."""
+    from texpose_amd.gan_modules import Discriminator
+    from texpose_amd.options import default_options
+    from texpose_amd.synthetic import training_batch
+    g = load_golden("g13_train_iterations")
+    B, H, W, P, N, n_train, stride = (g[k] for k in ("B", "H", "W", "P", "N", "n_train", "stride"))
+    p = {k: v.clone() for k, v in O.make_params(g["seed_w"]).items()}
+    for k, v in p.items():
+        if not k.startswith("mlp_feat"):
+            v.requires_grad_()
+    et, el = _embeddings(n_train, g["seed_e"])
+    et.requires_grad_()
+    el.requires_grad_()
+    var = training_batch(B, H, W, n_train=n_train, seed=g["seed_b"], device="cpu")
+    coords, scales = g["it0.ray_idx"], g["it0.ray_scales"]
+    ret = O.render(p, et, el, var.pose_init, var.intr, coords, (var.z_near[:, :, None], var.z_far[:, :, None]),
+                   var.idx, "train", H, W, N, rand=g["it0.rand"])
+    close(ret["rgb"], g["it0.rgb"], rtol=2e-5, atol=2e-6)
+    smp = O.patch_gather(coords, var.image, var.image_syn, var.nocs_pred, var.normal_pred, var.obj_mask, var.mask_syn)
+    L = O.nerf_losses(ret["rgb"], ret["uncert"], ret["density"], smp)
+    opt = default_options(H=H, W=W, device="cpu")
+    opt.patch_size = P
+    disc = Discriminator(opt)
+    O.seed_spectral_module(disc, g["seed_d"])
+    disc.train()
+    for q in disc.parameters():
+        q.requires_grad_(False)
+    real, fake = O.disc_patches(ret["rgb"], smp)
+    bce = torch.nn.functional.binary_cross_entropy_with_logits
+    d_fake_nerf = disc(opt, fake, scales)
+    L["gan_nerf"] = bce(d_fake_nerf, torch.ones_like(d_fake_nerf))
+    for k in ("render", "uncert", "trans_reg", "gan_nerf"):
+        close(L[k], torch.as_tensor(g["it0.gloss." + k], dtype=torch.float32), rtol=1e-4, atol=1e-6)
+    w = dict(render=0, uncert=0, trans_reg=-2, gan_nerf=-1)
+    tot = O.summarize(L, w)
+    close(tot, torch.as_tensor(g["it0.gloss.all"], dtype=torch.float32), rtol=1e-4, atol=1e-6)
+    tot.backward()
+
+    def rel(name, t):
+        t = t.reshape(-1).double()
+        ref = g[name].double() if name in g else g[name + ".sub"].double()
+        if name not in g:
+            t = t[::stride]
+        return float((t - ref).norm() / ref.norm())
+
+    for k, v in p.items():
+        if k.startswith("mlp_feat"):
+            assert v.grad is None
+        else:
+            assert rel("it0.grad.nerf." + k, v.grad) < 2e-3, k
+    assert rel("it0.grad.latent_vars_light.weight", el.grad) < 2e-3 and rel("it0.grad.latent_vars_trans.weight", et.grad) < 2e-3
+    # discriminator step (stock torch; the spectral-norm state has advanced by the generator-step forward, as in the
+    # reference where the same module instance serves both steps)
+    for q in disc.parameters():
+        q.requires_grad_(True)
+    real, fake = real.detach().requires_grad_(), fake.detach().requires_grad_()
+    d_real, d_fake = disc(opt, real, scales), disc(opt, fake, scales)
+    close(d_real, g["it0.d_real"], rtol=1e-4, atol=1e-5)
+    l_real, l_fake = bce(d_real, torch.ones_like(d_real)), bce(d_fake, torch.zeros_like(d_fake))
+    close(l_real, torch.as_tensor(g["it0.dloss.gan_disc_real"], dtype=torch.float32), rtol=1e-4, atol=1e-6)
+    close(l_fake, torch.as_tensor(g["it0.dloss.gan_disc_fake"], dtype=torch.float32), rtol=1e-4, atol=1e-6)
+    l_real.backward(retain_graph=True)
+    gx = torch.autograd.grad(d_real.sum(), real, create_graph=True)[0]
+    reg = gx.pow(2).reshape(B, -1).sum(1).mean()
+    close(10.0 * reg, torch.as_tensor(g["it0.dloss.gan_reg_real"], dtype=torch.float32), rtol=1e-4, atol=1e-6)
+    (10.0 * reg).backward()
+    l_fake.backward()
+    for name, q in disc.named_parameters():
+        if q.grad is not None:
+            assert rel("it0.grad.discriminator." + name, q.grad) < 1e-3, name
+
+
 def test_philox_known_answer():
     # Random123 known-answer vectors for philox4x32-10
     z = O.philox4x32(np.zeros((1, 4), dtype=np.uint32), (0, 0))[0]

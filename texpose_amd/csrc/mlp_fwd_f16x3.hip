@@ -3,13 +3,13 @@
 // mlp_fwd.hip; what changes is the arithmetic of each product:
 //
 //   gfx950 has no TF32/xf32, and v_mfma_f32_32x32x2_f32 runs at 1/16 of the f16 MFMA rate.  Here every
-//   fp32 operand (weights offline, activations in the layer epilogue) is carried as an unevaluated sum
+//   fp32 operand (weights offline, activations while the consuming layer's MFMAs issue) is carried as an unevaluated sum
 //   hi + lo of two fp16 numbers (11 + 11 significand bits), and   W x  ~=  Whi xhi + Whi xlo + Wlo xhi
 //   is issued as three v_mfma_f32_32x32x16_f16 with fp32 accumulation.  Products of two fp16 values are
 //   exact in fp32, the dropped lo*lo term is 2^-22 relative, so the result is as accurate as an fp32
 //   FMA chain (measured vs an fp64 oracle: within 1.3x of torch fp32) at 16/3 = 5.3x
 //   the fp32-MFMA throughput.  Weights are pre-scaled by 2^8 (exact) so that their lo parts stay in the
-//   fp16 normal range; the epilogue folds the 2^-8 into the bias FMA.  Activations must stay below 6e4
+//   fp16 normal range; the accumulators are seeded with bias * 2^8 and the 2^-8 is applied when they are converted.  Activations must stay below 6e4
 //   (NeRF activations are O(1..100)); the kernel raises bit 0 of a status word otherwise.
 //
 // An accumulator tile is reused as the next layer's B operand exactly as in the fp32 kernel: registers

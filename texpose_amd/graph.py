@@ -199,8 +199,9 @@ class Graph(torch.nn.Module):
         pose = self.get_pose(opt, var, mode=mode)
         depth_range = (var.z_near[:, :, None], var.z_far[:, :, None])
         if opt.nerf.rand_rays and mode == "train":
+            # var.jitter_rand (optional, [B,R,N,1]) pins the stratified draw for parity tests
             ret = self.render(opt, pose, intr=var.intr, ray_idx=var.ray_idx, depth_range=depth_range,
-                              sample_idx=var.idx, mode=mode)
+                              sample_idx=var.idx, mode=mode, rand=var.get("jitter_rand"))
         elif mode == "val":
             ret = self.render_by_slices(opt, pose, intr=var.intr, depth_range=depth_range, object_mask=var.obj_mask,
                                         sample_idx=None, mode=mode)

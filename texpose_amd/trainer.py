@@ -62,7 +62,8 @@ class GanTrainer:
         if opt.loss_weight.gan_reg_real is not None:          # R1: double backward through the discriminator
             reg = g.compute_grad2(opt, var.d_real_disc, var.patch_real).mean()
             (w("gan_reg_real") * reg).backward()
-            loss.gan_reg_real = reg.detach()
+            # the reference logs the WEIGHTED penalty: it scales the tensor it has just stored, in place (:151-153)
+            loss.gan_reg_real = (w("gan_reg_real") * reg).detach()
         (w("gan_disc_fake") * loss.gan_disc_fake).backward()
         self.red_disc.reduce()
         self.optim_disc.step()
