@@ -635,6 +635,95 @@ def test_train_iterations_match_reference_g13(ops):
         assert float(((d - ref).abs() > 0.25 * step).double().mean()) < 0.03, k
 
 
+def test_graph_captured_training_matches_eager(ops):
+    """GraphedGanTrainer (one hipGraph replay per iteration) against the eager GanTrainer: identical weights, batch,
+    optimiser arithmetic and (externally supplied) random numbers -> the same losses and parameters after several
+    iterations; with its own in-graph random stream every replay draws new patches."""
+    from texpose_amd.gan_modules import Discriminator
+    from texpose_amd.graph import Graph
+    from texpose_amd.options import default_options, AttrDict
+    from texpose_amd.synthetic import training_batch
+    from texpose_amd.trainer import GanTrainer, GraphedGanTrainer
+    B, H, W, n_train, N, steps = 2, 32, 32, 5, 8, 3
+
+    def build(cls):
+        opt = default_options(H=H, W=W, device="cuda:0")
+        opt.batch_size, opt.patch_size, opt.nerf.sample_intvs = B, 16, N
+        opt.loss_weight.feat = None
+        graph = Graph(opt, discriminator=Discriminator(opt)).to(dev())
+        graph.train()
+        graph.nerf.precision = "fp32"
+        return cls(opt, graph, n_train=n_train), graph
+
+    def reset(tr, graph, snap):
+        graph.load_state_dict(snap)                              # in place: captured addresses stay valid
+        for o in (tr.optim_nerf, tr.optim_disc):
+            for st in o.state.values():
+                for v in st.values():
+                    if torch.is_tensor(v):
+                        v.zero_()
+        tr.it = 0
+        graph.patch_sampler.iterations = 0
+        graph.nerf.mark_heads_dirty()
+
+    eager, g_e = build(type("EagerCapturable", (GanTrainer,), dict(capturable=True)))
+    g_e.nerf.load_state_dict({**g_e.nerf.state_dict(), **{k: cu(v) for k, v in O.make_params(5).items()}})
+    dcpu = Discriminator(eager.opt)
+    O.seed_spectral_module(dcpu, 9)
+    g_e.discriminator.load_state_dict(dcpu.state_dict())
+    snap = {k: v.detach().clone() for k, v in g_e.state_dict().items()}
+    batch = training_batch(B, H, W, n_train=n_train, seed=1, device="cuda:0")
+    rnd = [(torch.rand(3, B, 1, 1, 1, device=dev()), torch.rand(B, 256, N, 1, device=dev())) for _ in range(steps)]
+
+    graphed, g_g = build(GraphedGanTrainer)
+    g_g.load_state_dict(snap)
+    ex = AttrDict(dict(batch))
+    ex.patch_u, ex.jitter_rand = rnd[0]
+    graphed.capture(ex, warmup=2)                                # the warm-up iterations train: rewind afterwards
+    reset(graphed, g_g, snap)
+
+    le, lg = [], []
+    for u, jit in rnd:
+        v = AttrDict(dict(batch))
+        v.patch_u, v.jitter_rand = u, jit
+        _, l = eager.train_iteration(v)
+        le.append({k: float(x.detach()) for k, x in l.items() if torch.is_tensor(x)})
+        v = AttrDict(dict(batch))
+        v.patch_u, v.jitter_rand = u, jit
+        _, l = graphed.train_iteration(v)
+        lg.append({k: float(x) for k, x in l.items()})
+    for it, (a, b_) in enumerate(zip(le, lg)):
+        tol = (1e-3, 5e-3, 2e-2)[it]          # MIOpen solver choice may differ; later iterations inherit the difference
+        for k in ("render", "uncert", "trans_reg", "gan_nerf", "gan_disc_real", "gan_disc_fake", "gan_reg_real"):
+            assert abs(a[k] - b_[k]) <= tol * abs(a[k]) + 1e-6, (it, k, a[k], b_[k])
+    sd_e, sd_g = g_e.state_dict(), g_g.state_dict()
+    for k in sd_e:
+        if not sd_e[k].dtype.is_floating_point or torch.equal(sd_e[k], snap[k]):
+            continue
+        # Adam / RMSprop normalise every entry, so a gradient entry at the noise floor can take a different +-lr step:
+        # compare the bulk of the update and bound the fraction of entries that moved differently (by more than a
+        # typical step)
+        de, dg = (sd_e[k] - snap[k]).double().flatten(), (sd_g[k] - snap[k]).double().flatten()
+        assert float((de - dg).norm() / de.norm()) < 0.05, (k, float((de - dg).norm() / de.norm()))
+        if not (k.endswith("_u") or k.endswith("_v")):
+            typical = 0.25 * float(de.abs().max())
+            assert float(((de - dg).abs() > typical).double().mean()) < 0.01, k
+    assert all(torch.equal(sd_g[k], snap[k]) for k in sd_g if k.startswith("nerf.mlp_feat"))
+    assert not torch.equal(sd_g["nerf.mlp_rgb.0.weight"], snap["nerf.mlp_rgb.0.weight"])
+    assert not torch.equal(sd_g["discriminator.main.0.weight_orig"], snap["discriminator.main.0.weight_orig"])
+
+    # own random stream: a second graphed trainer without external tensors draws new patches on every replay
+    own, g_o = build(GraphedGanTrainer)
+    g_o.load_state_dict(snap)
+    own.capture(AttrDict(dict(batch)), warmup=2)
+    seen = set()
+    for _ in range(3):
+        v, l = own.train_iteration(AttrDict(dict(batch)))
+        assert all(np.isfinite(float(x)) for x in l.values())
+        seen.add(round(float(l["render"]), 6))
+    assert len(seen) == 3
+
+
 def edict_copy(var):
     from texpose_amd.options import AttrDict
     return AttrDict({k: v for k, v in var.items()})

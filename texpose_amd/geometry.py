@@ -129,19 +129,28 @@ class FlexPatchSampler:
         self.iterations = 0
         self.scales_curr = (min_scale, max_scale)
         self.full_indices = False
+        self.device_lo = None                # 0-dim device tensor while a hipGraph-captured step owns the sampler
 
-    def scale_range(self):
+    def _host_range(self):
         lo = self.min_scale
         if self.scale_anneal > 0:
             lo = min(0.8, max(lo, self.max_scale * math.exp(-self.iterations * self.scale_anneal)))
         return lo, self.max_scale
+
+    def scale_range(self):
+        if self.device_lo is not None:       # captured training step: the annealed bound lives in device memory and is
+            return self.device_lo, self.max_scale      # refreshed OUTSIDE the graph by update_device_bound()
+        return self._host_range()
+
+    def update_device_bound(self):
+        self.device_lo.fill_(self._host_range()[0])
 
     def __call__(self, nbatch, patch_size, device="cuda", u=None):
         """``u`` ([3,B,1,1,1] uniforms: scale, x-shift, y-shift) replaces the internal draw in parity tests."""
         lo, hi = self.scales_curr = self.scale_range()
         if u is None:
             u = torch.rand(3, nbatch, 1, 1, 1, device=device)
-        s = u[0] * (hi - lo) + lo if self.random_scale else torch.full((nbatch, 1, 1, 1), lo, device=device)
+        s = u[0] * (hi - lo) + lo if self.random_scale else torch.zeros(nbatch, 1, 1, 1, device=device) + lo
         lattice = torch.linspace(-1, 1, patch_size, device=device)
         xs = lattice.view(1, 1, patch_size, 1) * s          # varies along the patch width  -> grid x
         ys = lattice.view(1, patch_size, 1, 1) * s          # varies along the patch height -> grid y

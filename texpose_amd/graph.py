@@ -54,8 +54,9 @@ class Graph(torch.nn.Module):
 
     # ------------------------------------------------------------------ ray / sample selection
     def get_ray_idx(self, opt, var):
+        # var.patch_u (optional, [3,B,1,1,1] uniforms) pins the scale / shift draw for parity tests
         var.ray_idx, var.ray_scales = self.patch_sampler(nbatch=opt.batch_size, patch_size=opt.patch_size,
-                                                         device=opt.device)
+                                                         device=opt.device, u=var.get("patch_u"))
         return var
 
     @staticmethod
@@ -310,7 +311,7 @@ class Graph(torch.nn.Module):
     @staticmethod
     def compute_gan_loss(opt, d_outs, target):
         d_outs = d_outs if isinstance(d_outs, list) else [d_outs]
-        loss = torch.tensor(0.0, device=d_outs[0].device)
+        loss = d_outs[0].new_zeros(())                       # (no host-to-device copy: the step is hipGraph-capturable)
         for d_out in d_outs:
             if opt.gan.type == "standard":
                 loss = loss + torch_F.binary_cross_entropy_with_logits(d_out, torch.full_like(d_out, float(target)))

@@ -122,6 +122,12 @@ class NeRF(torch.nn.Module):
                 ver[1] = vh
         return buf
 
+    def mark_heads_dirty(self):
+        """Force a re-pack of the head weights at the next forward.  Needed after parameter updates that Python did
+        not see (a replayed hipGraph step does not bump tensor versions)."""
+        for ver in self._versions.values():
+            ver[1] = None
+
     # ------------------------------------------------------------------ reference API
     def forward(self, opt, points_3D, ray_unit=None, latent_variable_trans=None, latent_variable_light=None,
                 mode=None):

@@ -17,6 +17,8 @@ from .options import AttrDict
 
 
 class GanTrainer:
+    capturable = False                       # optimiser state on the device (required inside a hipGraph)
+
     def __init__(self, opt, graph: Graph, n_train: int, max_iter: int = 6000 * 189 // 8):
         self.opt, self.graph, self.max_iter, self.it = opt, graph, max_iter, 0
         if not hasattr(graph, "latent_vars_trans"):
@@ -26,11 +28,13 @@ class GanTrainer:
             list(graph.latent_vars_trans.parameters())
         self.optim_nerf = torch.optim.Adam([dict(params=nerf_params, lr=opt.optim.lr),
                                             dict(params=graph.latent_vars_light.parameters(), lr=opt.optim.lr),
-                                            dict(params=graph.latent_vars_trans.parameters(), lr=opt.optim.lr)])
+                                            dict(params=graph.latent_vars_trans.parameters(), lr=opt.optim.lr)],
+                                           capturable=self.capturable)
         self.has_disc = hasattr(graph, "discriminator") and opt.gan is not None
         if self.has_disc:
             self.disc_group = [p for p in graph.discriminator.parameters()]
-            self.optim_disc = torch.optim.RMSprop([dict(params=self.disc_group, lr=opt.optim_disc.lr)])
+            self.optim_disc = torch.optim.RMSprop([dict(params=self.disc_group, lr=opt.optim_disc.lr)],
+                                                  capturable=self.capturable)
         self.red_nerf = tdist.FlatGradAllReducer(self.nerf_group)
         self.red_disc = tdist.FlatGradAllReducer(self.disc_group) if self.has_disc else None
 
@@ -79,3 +83,78 @@ class GanTrainer:
         self.it += 1
         self.graph.patch_sampler.iterations = self.it
         return var, loss
+
+
+class GraphedGanTrainer(GanTrainer):
+    """The same iteration captured ONCE into a hipGraph and replayed.
+
+    A training iteration at the reference's batch sizes is launch-bound: ~1,350 kernel launches (autograd through the
+    PatchGAN incl. the R1 double backward, spectral-norm power iterations, VGG, optimisers) for ~8 ms of GPU work
+    (profiles/r1).  Everything in it is static in shape, so the whole step -- patch coordinates, stratified jitter,
+    render forward / backward (the ctypes launches enqueue on the capturing stream), gathers, both optimiser steps,
+    the data-parallel all-reduces -- is recorded once and replayed with one launch.
+
+    Per-iteration host state goes through device memory: the batch is copied into static input tensors, the annealed
+    patch-scale bound is a 0-dim device tensor, the jitter comes from torch's graph-safe Philox stream, the optimisers
+    are ``capturable``.  Losses come back as static tensors (read them only when logging: that is the one sync).
+    """
+    capturable = True
+
+    def __init__(self, opt, graph: Graph, n_train: int, max_iter: int = 6000 * 189 // 8):
+        super().__init__(opt, graph, n_train, max_iter)
+        self._graph = None
+        self._static_in = None
+        self._static_loss = None
+
+    def _body(self, var):
+        opt = self.opt
+        B, R = opt.batch_size, opt.patch_size ** 2
+        var = self.graph.get_ray_idx(opt, var)
+        if opt.nerf.sample_stratified and "jitter_rand" not in var:   # (a caller-supplied static tensor wins: tests)
+            var.jitter_rand = torch.rand(B, R, opt.nerf.sample_intvs, 1, device=var.ray_idx.device)
+        var, loss = self.nerf_step(var)
+        if self.has_disc:
+            var, dloss = self.disc_step(var)
+            loss.update({k: v for k, v in dloss.items() if k != "all"})
+        return {k: v.detach() for k, v in loss.items() if torch.is_tensor(v)}
+
+    def capture(self, var: AttrDict, warmup: int = 3):
+        """Warm up eagerly on a side stream (lazy inits: MIOpen solver search, weight packing, optimiser state), then
+        record the step.  ``var`` fixes the shapes; its values are used for the warm-up iterations."""
+        dev = var.image.device
+        self.graph.patch_sampler.device_lo = torch.zeros((), device=dev)
+        self._static_in = AttrDict({k: v.clone() for k, v in var.items() if torch.is_tensor(v)})
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self.graph.patch_sampler.update_device_bound()
+                self._body(AttrDict(dict(self._static_in)))
+                self._after_step()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self._graph = torch.cuda.CUDAGraph()
+        self.optim_nerf.zero_grad(set_to_none=True)
+        if self.has_disc:
+            self.optim_disc.zero_grad(set_to_none=True)
+        self.graph.patch_sampler.update_device_bound()          # outside the capture
+        with torch.cuda.graph(self._graph):
+            self._static_loss = self._body(AttrDict(dict(self._static_in)))
+        return self
+
+    def _after_step(self):
+        if self.has_disc:
+            self.graph.discriminator.progress.data.fill_(self.it / self.max_iter)
+        self.it += 1
+        self.graph.patch_sampler.iterations = self.it
+        self.graph.nerf.mark_heads_dirty()
+
+    def train_iteration(self, var: AttrDict):
+        if self._graph is None:
+            self.capture(var)
+        for k, dst in self._static_in.items():
+            dst.copy_(var[k], non_blocking=True)
+        self.graph.patch_sampler.update_device_bound()          # one fill_ of the annealed bound
+        self._graph.replay()
+        self._after_step()
+        return self._static_in, AttrDict(self._static_loss)
