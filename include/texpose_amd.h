@@ -214,6 +214,23 @@ typedef struct tp_patch_gather_args {
 } tp_patch_gather_args;
 int tp_patch_gather(const tp_patch_gather_args* args, tp_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * K6  evaluation metrics after the render: squared-error and SSIM sums (PSNR / SSIM of evaluate_full)
+ * ref: model/nerf_adapt_st_gan.py:340-362, external/pohsun_ssim/pytorch_ssim/__init__.py:7-37
+ *      (the optional 480x640 resize of :346-350 is fused: bilinear align_corners=False / nearest)
+ * ------------------------------------------------------------------------------------------ */
+typedef struct tp_eval_metrics_args {
+  const float* rgb_static; /* [B,h*w,3] the render (channels last, as Graph.render returns it) */
+  const float* image;      /* [B,3,h,w] */
+  const float* obj_mask;   /* [B,h,w]   multiplies the image (NOT binarised: the reference uses it as is) */
+  int B, h, w;
+  int out_h, out_w;        /* metric resolution; == (h, w) for no resize */
+  void* workspace;         /* tp_eval_metrics_workspace_bytes(B, out_h, out_w) */
+  double* out;             /* [B,2]: sum over 3*out_h*out_w of squared error, of the SSIM map */
+} tp_eval_metrics_args;
+int64_t tp_eval_metrics_workspace_bytes(int B, int out_h, int out_w);
+int tp_eval_metrics(const tp_eval_metrics_args* args, tp_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

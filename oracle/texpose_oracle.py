@@ -559,6 +559,45 @@ def nerf_losses(rgb: Tensor, uncert: Tensor, density: Tensor, g: Dict[str, Tenso
                 trans_reg=density[..., -1].mean())
 
 
+# ---------------------------------------------------------------------------------------------- f4: eval metrics
+def ssim_window(window_size: int = 11, sigma: float = 1.5) -> Tensor:
+    """Normalised 1-D Gaussian of the reference's SSIM (external/pohsun_ssim/pytorch_ssim/__init__.py:7-9)."""
+    g = torch.tensor([math.exp(-(x - window_size // 2) ** 2 / float(2 * sigma ** 2)) for x in range(window_size)])
+    return g / g.sum()
+
+
+def ssim_map(img1: Tensor, img2: Tensor, window_size: int = 11) -> Tensor:
+    """Per-pixel SSIM [B,C,H,W]: depthwise 11x11 Gaussian (outer product of the 1-D window), zero padding,
+    C1 = 0.01^2, C2 = 0.03^2 (pytorch_ssim/__init__.py:17-37)."""
+    C = img1.shape[1]
+    w1 = ssim_window(window_size).unsqueeze(1)
+    win = w1.mm(w1.t()).float()[None, None].expand(C, 1, window_size, window_size).contiguous()
+    conv = lambda x: torch.nn.functional.conv2d(x, win, padding=window_size // 2, groups=C)
+    mu1, mu2 = conv(img1), conv(img2)
+    mu1_sq, mu2_sq, mu12 = mu1.pow(2), mu2.pow(2), mu1 * mu2
+    s1, s2, s12 = conv(img1 * img1) - mu1_sq, conv(img2 * img2) - mu2_sq, conv(img1 * img2) - mu12
+    C1, C2 = 0.01 ** 2, 0.03 ** 2
+    return ((2 * mu12 + C1) * (2 * s12 + C2)) / ((mu1_sq + mu2_sq + C1) * (s1 + s2 + C2))
+
+
+def eval_metrics(rgb_static: Tensor, image: Tensor, obj_mask: Tensor, H: int, W: int,
+                 out_hw: Optional[Tuple[int, int]] = None) -> Dict[str, Tensor]:
+    """PSNR / SSIM of evaluate_full (model/nerf_adapt_st_gan.py:340-362): the static render [B,HW,3] against the
+    MASKED image; when the data is not the 128x128 crop both are first resized to ``out_hw`` (480x640 in the
+    reference): bilinear align_corners=False for the colours, nearest for the mask."""
+    B = image.shape[0]
+    rgb_map = rgb_static.view(B, H, W, 3).permute(0, 3, 1, 2)
+    mask_map = obj_mask.view(B, H, W, 1).permute(0, 3, 1, 2)
+    if out_hw is not None:
+        F = torch.nn.functional
+        image = F.interpolate(image, size=list(out_hw), mode="bilinear", align_corners=False)
+        rgb_map = F.interpolate(rgb_map, size=list(out_hw), mode="bilinear", align_corners=False)
+        mask_map = F.interpolate(mask_map, size=list(out_hw), mode="nearest")
+    image_masked = image * mask_map
+    mse = ((rgb_map.contiguous() - image_masked) ** 2).mean()
+    return dict(mse=mse, psnr=-10 * mse.log10(), ssim=ssim_map(rgb_map, image_masked).mean())
+
+
 def summarize(losses: Dict[str, Tensor], weights: Dict[str, Optional[float]]) -> Tensor:
     total = 0.0
     for k, v in losses.items():

@@ -25,7 +25,7 @@ def _raw():
 def test_exports_match_header():
     lib = _raw()
     header = open(os.path.join(REPO, "include", "texpose_amd.h")).read()
-    declared = set(re.findall(r"^(?:int|size_t|const char\*)\s+(tp_[a-z0-9_]+)\s*\(", header, flags=re.M))
+    declared = set(re.findall(r"^(?:int|int64_t|size_t|const char\*)\s+(tp_[a-z0-9_]+)\s*\(", header, flags=re.M))
     assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
     for name in declared:
         assert hasattr(lib, name), name
@@ -39,6 +39,7 @@ def test_struct_sizes_match_header():
     assert C.sizeof(_lib.MlpFwdArgs) == 8 * 8 + 3 * 4 + 4 + 5 * 8 + 4 + 4 + 8
     assert C.sizeof(_lib.MlpWeights) == 32 * 8
     assert C.sizeof(_lib.PatchGatherArgs) == 7 * 8 + 4 * 4 + 8
+    assert C.sizeof(_lib.EvalMetricsArgs) == 3 * 8 + 5 * 4 + 4 + 2 * 8
 
 
 def test_argument_validation_without_gpu():

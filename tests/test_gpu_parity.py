@@ -724,6 +724,36 @@ def test_graph_captured_training_matches_eager(ops):
     assert len(seen) == 3
 
 
+# ------------------------------------------------------------------------------------------ eval metrics (f4)
+def test_eval_metrics_g14_and_oracle(ops):
+    """tp_eval_metrics against the reference's MSE_loss / pytorch_ssim values (G14) and against the CPU oracle on
+    ragged sizes (tiles with partial rows / columns, batch > 1) and the 480x640 resize path."""
+    g = load_golden("g14_eval_metrics")
+    for name in ("native", "resized", "big"):
+        H, W, oh, ow = (g[f"{name}.{k}"] for k in ("H", "W", "out_h", "out_w"))
+        psnr, ssim, mse = ops.eval_metrics(cu(g[f"{name}.rgb_static"]), cu(g[f"{name}.image"]), cu(g[f"{name}.obj_mask"]), H, W,
+                                           out_hw=(oh, ow) if oh else None)
+        assert abs(float(mse) - g[f"{name}.mse"]) < 1e-5 * g[f"{name}.mse"], name
+        assert abs(float(psnr) - g[f"{name}.psnr"]) < 1e-4, name
+        assert abs(float(ssim) - g[f"{name}.ssim"]) < 2e-5, name
+    rs = np.random.RandomState(4)
+    for (B, H, W, out_hw) in ((3, 37, 70, None), (1, 120, 160, (480, 640)), (2, 128, 128, None)):
+        image = torch.from_numpy(rs.uniform(size=(B, 3, H, W)).astype(np.float32))
+        rgb = (0.8 * image + 0.2 * torch.from_numpy(rs.uniform(size=(B, 3, H, W)).astype(np.float32))).permute(0, 2, 3, 1).reshape(B, H * W, 3).contiguous()
+        mask = torch.from_numpy((rs.uniform(size=(B, H, W)) > 0.3).astype(np.float32))
+        ref = O.eval_metrics(rgb, image, mask, H, W, out_hw=out_hw)
+        psnr, ssim, mse = ops.eval_metrics(cu(rgb), cu(image), cu(mask), H, W, out_hw=out_hw)
+        assert abs(float(mse) - float(ref["mse"])) < 1e-5 * float(ref["mse"])
+        assert abs(float(psnr) - float(ref["psnr"])) < 1e-4 and abs(float(ssim) - float(ref["ssim"])) < 2e-5
+    # through the Graph mirror (128x128 crop: no resize)
+    from texpose_amd.graph import Graph
+    from texpose_amd.options import default_options, AttrDict
+    opt = default_options(H=128, W=128, device="cuda:0")
+    var = AttrDict(rgb_static=cu(rgb), image=cu(image), obj_mask=cu(mask))
+    m = Graph(opt).evaluate_metrics(opt, var)
+    assert abs(float(m.psnr) - float(ref["psnr"])) < 1e-4 and abs(float(m.ssim) - float(ref["ssim"])) < 2e-5
+
+
 def edict_copy(var):
     from texpose_amd.options import AttrDict
     return AttrDict({k: v for k, v in var.items()})

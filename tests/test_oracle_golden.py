@@ -263,6 +263,17 @@ def test_train_iteration_g13_oracle():
             assert rel("it0.grad.discriminator." + name, q.grad) < 1e-3, name
 
 
+def test_eval_metrics_g14():
+    g = load_golden("g14_eval_metrics")
+    for name in ("native", "resized", "big"):
+        H, W, oh, ow = (g[f"{name}.{k}"] for k in ("H", "W", "out_h", "out_w"))
+        r = O.eval_metrics(g[f"{name}.rgb_static"], g[f"{name}.image"], g[f"{name}.obj_mask"], H, W,
+                           out_hw=(oh, ow) if oh else None)
+        assert abs(float(r["mse"]) - g[f"{name}.mse"]) < 1e-6 * g[f"{name}.mse"] + 1e-9
+        assert abs(float(r["psnr"]) - g[f"{name}.psnr"]) < 1e-5
+        assert abs(float(r["ssim"]) - g[f"{name}.ssim"]) < 1e-6
+
+
 def test_philox_known_answer():
     # Random123 known-answer vectors for philox4x32-10
     z = O.philox4x32(np.zeros((1, 4), dtype=np.uint32), (0, 0))[0]

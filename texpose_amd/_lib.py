@@ -22,6 +22,7 @@ SYMBOLS = (
     "tp_mlp_saved_bytes", "tp_mlp_packed_t_bytes", "tp_mlp_bwd_workspace_bytes", "tp_mlp_bwd",
     "tp_composite_fwd", "tp_composite_bwd",
     "tp_patch_gather",
+    "tp_eval_metrics_workspace_bytes", "tp_eval_metrics",
 )
 
 vp = C.c_void_p
@@ -75,6 +76,11 @@ class PatchGatherArgs(C.Structure):
                 ("W", C.c_int), ("out", vp)]
 
 
+class EvalMetricsArgs(C.Structure):
+    _fields_ = [("rgb_static", vp), ("image", vp), ("obj_mask", vp), ("B", C.c_int), ("h", C.c_int), ("w", C.c_int),
+                ("out_h", C.c_int), ("out_w", C.c_int), ("workspace", vp), ("out", vp)]
+
+
 class TexposeLibraryError(RuntimeError):
     pass
 
@@ -119,6 +125,8 @@ def load() -> C.CDLL:
     sig("tp_mlp_fwd", [C.POINTER(MlpFwdArgs), vp])
     sig("tp_posenc", [vp, C.c_int64, C.c_int, C.c_int, vp, vp])
     sig("tp_patch_gather", [C.POINTER(PatchGatherArgs), vp])
+    sig("tp_eval_metrics_workspace_bytes", [C.c_int, C.c_int, C.c_int], C.c_int64)
+    sig("tp_eval_metrics", [C.POINTER(EvalMetricsArgs), vp])
     _lib = lib
     return lib
 

@@ -240,6 +240,14 @@ class Graph(torch.nn.Module):
         var.d_fake_disc = self.discriminator(opt, var.patch_fake, var.ray_scales)
         return var
 
+    def evaluate_metrics(self, opt, var):
+        """PSNR / SSIM of ``Model.evaluate_full`` (reference :340-362) for a rendered ``var`` (mode 'eval_*'): static
+        render vs masked image, resized to 480x640 when the data is not the 128x128 crop.  LPIPS (AlexNet weights
+        unavailable offline) is not computed.  Returns 0-dim device tensors."""
+        out_hw = None if list(opt.data.image_size) == [128, 128] else (480, 640)
+        psnr, ssim, _ = ops.eval_metrics(var.rgb_static, var.image, var.obj_mask, opt.H, opt.W, out_hw=out_hw)
+        return edict(psnr=psnr, ssim=ssim)
+
     @staticmethod
     def MSE_loss(pred, label, mask=None):
         loss = (pred.contiguous() - label) ** 2

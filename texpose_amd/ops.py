@@ -372,3 +372,25 @@ def patch_gather(coords: Tensor, image: Tensor, image_syn: Tensor, nocs: Tensor,
     a.B, a.P, a.H, a.W, a.out = B, ph * pw, H, W, out.data_ptr()
     check(lib.tp_patch_gather(C.byref(a), _stream()), "tp_patch_gather")
     return out
+
+
+def eval_metrics(rgb_static: Tensor, image: Tensor, obj_mask: Tensor, H: int, W: int, out_hw=None):
+    """PSNR / SSIM of the static render against the masked image (reference evaluate_full, :340-362).
+    rgb_static [B,H*W,3], image [B,3,H,W], obj_mask [B,H,W]; ``out_hw`` = (480, 640) reproduces the resize the
+    reference applies to non-crop data.  Returns (psnr, ssim, mse) as 0-dim fp64 device tensors (no host sync)."""
+    lib = _lib.load()
+    rgb_static, image, obj_mask = _f32(rgb_static, "rgb_static"), _f32(image, "image"), _f32(obj_mask, "obj_mask")
+    B = image.shape[0]
+    if rgb_static.numel() != B * H * W * 3 or image.shape[1:] != (3, H, W) or obj_mask.numel() != B * H * W:
+        raise ValueError("eval_metrics: rgb_static [B,H*W,3], image [B,3,H,W], obj_mask [B,H,W] expected")
+    oh, ow = (H, W) if out_hw is None else (int(out_hw[0]), int(out_hw[1]))
+    ws = torch.empty(max(1, lib.tp_eval_metrics_workspace_bytes(B, oh, ow) // 4), device=image.device)
+    out = torch.empty(B, 2, dtype=torch.float64, device=image.device)
+    a = _lib.EvalMetricsArgs()
+    a.rgb_static, a.image, a.obj_mask = rgb_static.data_ptr(), image.data_ptr(), obj_mask.data_ptr()
+    a.B, a.h, a.w, a.out_h, a.out_w = B, H, W, oh, ow
+    a.workspace, a.out = ws.data_ptr(), out.data_ptr()
+    check(lib.tp_eval_metrics(C.byref(a), _stream()), "tp_eval_metrics")
+    n = float(B * 3 * oh * ow)
+    mse = out[:, 0].sum() / n
+    return -10.0 * torch.log10(mse), out[:, 1].sum() / n, mse
