@@ -231,6 +231,28 @@ typedef struct tp_eval_metrics_args {
 int64_t tp_eval_metrics_workspace_bytes(int B, int out_h, int out_w);
 int tp_eval_metrics(const tp_eval_metrics_args* args, tp_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * K7  spectral-norm weight normalisation for all convolutions of the PatchGAN at once
+ * ref: torch.nn.utils.spectral_norm as applied in layers/discriminator.py:45-115 (one power iteration per forward in
+ *      training mode: v <- normalize(W^T u), u <- normalize(W v), sigma = u.(W v), W_sn = W / sigma; u, v in place)
+ * ------------------------------------------------------------------------------------------ */
+#define TP_SN_MAX_WEIGHTS 8
+#define TP_SN_MAX_SLABS 8        /* rows <= 512 */
+typedef struct tp_sn_weight {
+  const float* weight;     /* [rows,cols] = weight_orig.view(out, -1); fwd only */
+  float* u;                /* [rows]  updated in place when training */
+  float* v;                /* [cols]  updated in place when training */
+  float* weight_sn;        /* [rows,cols] fwd: out; bwd: in */
+  float* sigma;            /* [1]     fwd: out; bwd: in */
+  const float* grad_sn;    /* [rows,cols] bwd: gradient wrt weight_sn */
+  float* grad;             /* [rows,cols] bwd: out, gradient wrt weight */
+  float* work;             /* tp_sn_work_floats(rows, cols) floats of scratch */
+  int rows, cols;
+} tp_sn_weight;
+int64_t tp_sn_work_floats(int rows, int cols);
+int tp_sn_fwd(const tp_sn_weight* weights, int n, int training, tp_stream_t stream);
+int tp_sn_bwd(const tp_sn_weight* weights, int n, tp_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

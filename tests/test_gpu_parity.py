@@ -754,6 +754,48 @@ def test_eval_metrics_g14_and_oracle(ops):
     assert abs(float(m.psnr) - float(ref["psnr"])) < 1e-4 and abs(float(m.ssim) - float(ref["ssim"])) < 2e-5
 
 
+# ------------------------------------------------------------------------------------------ spectral norm (f1)
+def test_spectral_weights_match_torch(ops):
+    """tp_sn_fwd / tp_sn_bwd against torch.nn.utils.spectral_norm on the six PatchGAN weight shapes: normalised weight,
+    in-place u / v after the power iteration (training) and untouched (eval), sigma, and the gradient wrt weight_orig."""
+    from texpose_amd.gan_modules import Discriminator, spectral_weights, SNConv2d
+    from texpose_amd.options import default_options
+    opt = default_options(H=32, W=32, device="cuda:0")
+    opt.patch_size = 16
+    torch.manual_seed(5)
+    disc = Discriminator(opt)
+    O.seed_spectral_module(disc, 77)
+    convs = [m for m in list(disc.main) + list(disc.final) if isinstance(m, SNConv2d)]
+    assert [tuple(c.weight_orig.shape) for c in convs] == [(256, 9, 4, 4), (512, 256, 4, 4), (64, 512, 4, 4), (64, 73, 1, 1),
+                                                           (64, 64, 1, 1), (1, 64, 1, 1)]
+    rs = np.random.RandomState(3)
+    cots = [torch.from_numpy(rs.normal(size=tuple(c.weight_orig.shape)).astype(np.float32)) for c in convs]
+    for training in (True, False):
+        # stock torch on CPU
+        ref = []
+        for c, cot in zip(convs, cots):
+            conv = torch.nn.Conv2d(c.weight_orig.shape[1], c.weight_orig.shape[0], c.weight_orig.shape[2:], bias=False)
+            sn = torch.nn.utils.spectral_norm(conv)
+            with torch.no_grad():
+                sn.weight_orig.copy_(c.weight_orig)
+                sn.weight_u.copy_(c.weight_u)
+                sn.weight_v.copy_(c.weight_v)
+            sn.train(training)
+            sn(torch.zeros(1, c.weight_orig.shape[1], 4, 4))                  # the pre-forward hook computes .weight
+            (sn.weight * cot).sum().backward()
+            ref.append((sn.weight.detach().clone(), sn.weight_u.clone(), sn.weight_v.clone(), sn.weight_orig.grad.clone()))
+        gd = Discriminator(opt).to(dev())
+        gd.load_state_dict(disc.state_dict())
+        gconvs = [m for m in list(gd.main) + list(gd.final) if isinstance(m, SNConv2d)]
+        ws = spectral_weights(gconvs, training)
+        sum((w * cu(cot)).sum() for w, cot in zip(ws, cots)).backward()
+        for c, w, (rw, ru, rv, rg) in zip(gconvs, ws, ref):
+            torch.testing.assert_close(w.detach().cpu(), rw, rtol=2e-5, atol=1e-7)
+            torch.testing.assert_close(c.weight_u.cpu(), ru, rtol=2e-5, atol=1e-7)
+            torch.testing.assert_close(c.weight_v.cpu(), rv, rtol=2e-5, atol=1e-7)
+            torch.testing.assert_close(c.weight_orig.grad.cpu(), rg, rtol=1e-4, atol=1e-6)
+
+
 def edict_copy(var):
     from texpose_amd.options import AttrDict
     return AttrDict({k: v for k, v in var.items()})

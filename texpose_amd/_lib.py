@@ -23,6 +23,7 @@ SYMBOLS = (
     "tp_composite_fwd", "tp_composite_bwd",
     "tp_patch_gather",
     "tp_eval_metrics_workspace_bytes", "tp_eval_metrics",
+    "tp_sn_work_floats", "tp_sn_fwd", "tp_sn_bwd",
 )
 
 vp = C.c_void_p
@@ -81,6 +82,14 @@ class EvalMetricsArgs(C.Structure):
                 ("out_h", C.c_int), ("out_w", C.c_int), ("workspace", vp), ("out", vp)]
 
 
+class SnWeight(C.Structure):
+    _fields_ = [("weight", vp), ("u", vp), ("v", vp), ("weight_sn", vp), ("sigma", vp), ("grad_sn", vp), ("grad", vp),
+                ("work", vp), ("rows", C.c_int), ("cols", C.c_int)]
+
+
+SN_MAX_WEIGHTS = 8
+
+
 class TexposeLibraryError(RuntimeError):
     pass
 
@@ -127,6 +136,9 @@ def load() -> C.CDLL:
     sig("tp_patch_gather", [C.POINTER(PatchGatherArgs), vp])
     sig("tp_eval_metrics_workspace_bytes", [C.c_int, C.c_int, C.c_int], C.c_int64)
     sig("tp_eval_metrics", [C.POINTER(EvalMetricsArgs), vp])
+    sig("tp_sn_work_floats", [C.c_int, C.c_int], C.c_int64)
+    sig("tp_sn_fwd", [C.POINTER(SnWeight), C.c_int, C.c_int, vp])
+    sig("tp_sn_bwd", [C.POINTER(SnWeight), C.c_int, vp])
     _lib = lib
     return lib
 

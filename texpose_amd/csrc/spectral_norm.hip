@@ -1,0 +1,202 @@
+// K7: spectral-norm weight normalisation of the PatchGAN's six convolutions in a handful of launches.
+//
+// The reference wraps every discriminator conv in torch.nn.utils.spectral_norm (layers/discriminator.py:45-115).  In
+// training mode every forward runs one power iteration per weight,
+//     v <- normalize(W^T u),  u <- normalize(W v),  sigma = u . (W v),  W_sn = W / sigma       (W = weight.view(out, -1))
+// which PyTorch issues as ~15 tiny kernels per weight (mv, norm, clamp, div, dot, clones), i.e. ~90 per discriminator
+// forward and as many again in the backward -- ~600 of the ~1,350 launches of a training iteration.  Here all weights
+// of the module are processed together: five launches per forward (two in eval mode + scale), two per backward,
+//     fwd :  A  t_part[slab] = W[slab rows]^T u      (column blocks x row slabs, coalesced rows)
+//            A2 v = normalize(sum_slabs t_part)       (one workgroup per weight; updates the module's v buffer)
+//            B  s = W v                               (one wave per row, lanes stride the columns)
+//            B2 u = normalize(s), sigma = u . s       (one workgroup per weight; updates the module's u buffer)
+//            C  W_sn = W / sigma
+//     bwd :  D  partial sums of <G, W_sn>;   E  dW = (G - <G, W_sn> u v^T) / sigma        (u, v constants, as in torch)
+// All reductions run in a fixed order (no atomics): the training run is reproducible.
+#include "tp_common.h"
+
+namespace {
+constexpr int kMaxW = TP_SN_MAX_WEIGHTS;
+constexpr int kSlabRows = 64;
+
+struct Batch {
+  tp_sn_weight w[kMaxW];
+  int n;
+  int blk_a[kMaxW + 1];   // prefix sums of workgroups per weight for the kernel being launched
+};
+
+__device__ __forceinline__ int find_weight(const Batch& b, int blk, int& local) {
+  int i = 0;
+  while (i + 1 < b.n && blk >= b.blk_a[i + 1]) ++i;
+  local = blk - b.blk_a[i];
+  return i;
+}
+
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  const int tid = threadIdx.x;
+  red[tid] = v;
+  __syncthreads();
+  for (int s = blockDim.x >> 1; s > 0; s >>= 1) {
+    if (tid < s) red[tid] += red[tid + s];
+    __syncthreads();
+  }
+  const float r = red[0];
+  __syncthreads();
+  return r;
+}
+
+// A: t_part[slab][c] = sum_{r in slab} W[r][c] u[r]
+__global__ __launch_bounds__(256) void sn_wtu_kernel(Batch b) {
+  __shared__ float us[kSlabRows];
+  int local;
+  const tp_sn_weight& w = b.w[find_weight(b, blockIdx.x, local)];
+  const int cblocks = (w.cols + 255) / 256;
+  const int slab = local / cblocks, cb = local - slab * cblocks;
+  const int r0 = slab * kSlabRows, nr = min(kSlabRows, w.rows - r0);
+  if (threadIdx.x < nr) us[threadIdx.x] = w.u[r0 + threadIdx.x];
+  __syncthreads();
+  const int c = cb * 256 + threadIdx.x;
+  if (c >= w.cols) return;
+  float acc = 0.0f;
+  for (int r = 0; r < nr; ++r) acc = fmaf(w.weight[(int64_t)(r0 + r) * w.cols + c], us[r], acc);
+  w.work[(int64_t)slab * w.cols + c] = acc;
+}
+
+// A2: v = normalize(sum_slabs t_part)
+__global__ __launch_bounds__(256) void sn_v_kernel(Batch b) {
+  __shared__ float red[256];
+  const tp_sn_weight& w = b.w[blockIdx.x];
+  const int slabs = (w.rows + kSlabRows - 1) / kSlabRows;
+  float ss = 0.0f;
+  for (int c = threadIdx.x; c < w.cols; c += 256) {
+    float t = 0.0f;
+    for (int s = 0; s < slabs; ++s) t += w.work[(int64_t)s * w.cols + c];
+    w.v[c] = t;
+    ss = fmaf(t, t, ss);
+  }
+  const float nrm = fmaxf(sqrtf(block_sum(ss, red)), 1e-12f);
+  for (int c = threadIdx.x; c < w.cols; c += 256) w.v[c] = w.v[c] / nrm;
+}
+
+// B: s[r] = sum_c W[r][c] v[c]   (one wave per row)
+__global__ __launch_bounds__(256) void sn_wv_kernel(Batch b) {
+  int local;
+  const tp_sn_weight& w = b.w[find_weight(b, blockIdx.x, local)];
+  const int r = local * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (r >= w.rows) return;
+  const float* row = w.weight + (int64_t)r * w.cols;
+  float acc = 0.0f;
+  for (int c = lane; c < w.cols; c += 64) acc = fmaf(row[c], w.v[c], acc);
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if (lane == 0) w.work[(int64_t)TP_SN_MAX_SLABS * w.cols + r] = acc;
+}
+
+// B2: u = normalize(s) (training) ; sigma = u . s
+__global__ __launch_bounds__(256) void sn_u_kernel(Batch b, int training) {
+  __shared__ float red[256];
+  const tp_sn_weight& w = b.w[blockIdx.x];
+  const float* s = w.work + (int64_t)TP_SN_MAX_SLABS * w.cols;
+  if (training) {
+    float ss = 0.0f;
+    for (int r = threadIdx.x; r < w.rows; r += 256) ss = fmaf(s[r], s[r], ss);
+    const float nrm = fmaxf(sqrtf(block_sum(ss, red)), 1e-12f);
+    for (int r = threadIdx.x; r < w.rows; r += 256) w.u[r] = s[r] / nrm;
+    __syncthreads();
+  }
+  float d = 0.0f;
+  for (int r = threadIdx.x; r < w.rows; r += 256) d = fmaf(w.u[r], s[r], d);
+  d = block_sum(d, red);
+  if (threadIdx.x == 0) *w.sigma = d;
+}
+
+// C: W_sn = W / sigma
+__global__ __launch_bounds__(256) void sn_scale_kernel(Batch b) {
+  int local;
+  const tp_sn_weight& w = b.w[find_weight(b, blockIdx.x, local)];
+  const int64_t n = (int64_t)w.rows * w.cols;
+  const float sg = *w.sigma;
+  for (int64_t i = (int64_t)local * 1024 + threadIdx.x; i < min(n, (int64_t)(local + 1) * 1024); i += 256)
+    w.weight_sn[i] = w.weight[i] / sg;
+}
+
+// D: per-workgroup partial of <G, W_sn>
+__global__ __launch_bounds__(256) void sn_dot_kernel(Batch b) {
+  __shared__ float red[256];
+  int local;
+  const tp_sn_weight& w = b.w[find_weight(b, blockIdx.x, local)];
+  const int64_t n = (int64_t)w.rows * w.cols;
+  float acc = 0.0f;
+  for (int64_t i = (int64_t)local * 4096 + threadIdx.x; i < min(n, (int64_t)(local + 1) * 4096); i += 256)
+    acc = fmaf(w.grad_sn[i], w.weight_sn[i], acc);
+  acc = block_sum(acc, red);
+  if (threadIdx.x == 0) w.work[local] = acc;
+}
+
+// E: dW = (G - <G, W_sn> u v^T) / sigma
+__global__ __launch_bounds__(256) void sn_grad_kernel(Batch b) {
+  __shared__ float red[256];
+  int local;
+  const tp_sn_weight& w = b.w[find_weight(b, blockIdx.x, local)];
+  const int64_t n = (int64_t)w.rows * w.cols;
+  const int parts = (int)((n + 4095) / 4096);
+  float d = 0.0f;
+  for (int i = threadIdx.x; i < parts; i += 256) d += w.work[i];
+  d = block_sum(d, red);
+  const float sg = *w.sigma;
+  for (int64_t i = (int64_t)local * 1024 + threadIdx.x; i < min(n, (int64_t)(local + 1) * 1024); i += 256) {
+    const int r = (int)(i / w.cols), c = (int)(i - (int64_t)r * w.cols);
+    w.grad[i] = (w.grad_sn[i] - d * w.u[r] * w.v[c]) / sg;
+  }
+}
+
+int fill(Batch& b, const tp_sn_weight* ws, int n, int (*blocks)(const tp_sn_weight&)) {
+  b.n = n;
+  b.blk_a[0] = 0;
+  for (int i = 0; i < n; ++i) { b.w[i] = ws[i]; b.blk_a[i + 1] = b.blk_a[i] + blocks(ws[i]); }
+  return b.blk_a[n];
+}
+int check(const tp_sn_weight* ws, int n, bool bwd, const char* what) {
+  if (ws == nullptr || n <= 0 || n > kMaxW) { tp::set_error("%s: 1..%d weights expected", what, kMaxW); return -1; }
+  for (int i = 0; i < n; ++i) {
+    const tp_sn_weight& w = ws[i];
+    if (w.rows <= 0 || w.cols <= 0 || w.rows > TP_SN_MAX_SLABS * kSlabRows) { tp::set_error("%s: bad sizes (rows <= %d)", what, TP_SN_MAX_SLABS * kSlabRows); return -1; }
+    if (!w.u || !w.v || !w.sigma || !w.weight_sn || !w.work) { tp::set_error("%s: null pointer", what); return -1; }
+    if (!bwd && !w.weight) { tp::set_error("%s: null weight", what); return -1; }
+    if (bwd && (!w.grad_sn || !w.grad)) { tp::set_error("%s: null gradient pointer", what); return -1; }
+  }
+  return 0;
+}
+}  // namespace
+
+extern "C" int64_t tp_sn_work_floats(int rows, int cols) {
+  const int64_t fwd = (int64_t)TP_SN_MAX_SLABS * cols + rows, bwd = ((int64_t)rows * cols + 4095) / 4096;
+  return fwd > bwd ? fwd : bwd;
+}
+
+extern "C" int tp_sn_fwd(const tp_sn_weight* ws, int n, int training, tp_stream_t stream) {
+  if (int rc = check(ws, n, false, "tp_sn_fwd")) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  Batch b;
+  if (training) {
+    int g = fill(b, ws, n, [](const tp_sn_weight& w) { return ((w.cols + 255) / 256) * ((w.rows + kSlabRows - 1) / kSlabRows); });
+    hipLaunchKernelGGL(sn_wtu_kernel, dim3(g), dim3(256), 0, st, b);
+    hipLaunchKernelGGL(sn_v_kernel, dim3(n), dim3(256), 0, st, b);
+  }
+  int g = fill(b, ws, n, [](const tp_sn_weight& w) { return (w.rows + 3) / 4; });
+  hipLaunchKernelGGL(sn_wv_kernel, dim3(g), dim3(256), 0, st, b);
+  hipLaunchKernelGGL(sn_u_kernel, dim3(n), dim3(256), 0, st, b, training);
+  g = fill(b, ws, n, [](const tp_sn_weight& w) { return (int)(((int64_t)w.rows * w.cols + 1023) / 1024); });
+  hipLaunchKernelGGL(sn_scale_kernel, dim3(g), dim3(256), 0, st, b);
+  return tp::check_launch("tp_sn_fwd");
+}
+
+extern "C" int tp_sn_bwd(const tp_sn_weight* ws, int n, tp_stream_t stream) {
+  if (int rc = check(ws, n, true, "tp_sn_bwd")) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  Batch b;
+  int g = fill(b, ws, n, [](const tp_sn_weight& w) { return (int)(((int64_t)w.rows * w.cols + 4095) / 4096); });
+  hipLaunchKernelGGL(sn_dot_kernel, dim3(g), dim3(256), 0, st, b);
+  g = fill(b, ws, n, [](const tp_sn_weight& w) { return (int)(((int64_t)w.rows * w.cols + 1023) / 1024); });
+  hipLaunchKernelGGL(sn_grad_kernel, dim3(g), dim3(256), 0, st, b);
+  return tp::check_launch("tp_sn_bwd");
+}

@@ -1,6 +1,7 @@
-"""Stock PyTorch modules that sit NEXT to the hot path in a training iteration: the PatchGAN
-discriminator and the VGG perceptual loss.  They run on MIOpen / rocBLAS through PyTorch-ROCm; only their
-inputs (the patch gather) are hand-written kernels.  Written from the reference's architecture description
+"""Modules that sit NEXT to the hot path in a training iteration: the PatchGAN discriminator
+and the VGG perceptual loss.  Convolutions / norms run on MIOpen / rocBLAS through PyTorch-ROCm (autograd incl. the
+R1 double backward); the spectral normalisation of the six discriminator weights -- ~600 of the ~1,350 kernel
+launches of an iteration in stock PyTorch -- goes through the fused tp_sn_fwd / tp_sn_bwd kernels.  Written from the reference's architecture description
 (layers/discriminator.py:8-173, layers/perceptual_loss.py:8-45), state-dict compatible with it:
 ``main.{0,3,6}.weight_{orig,u,v}``, ``final.{1,3,5}.weight_{orig,u,v}``, ``progress`` for patch_size 16.
 
@@ -14,6 +15,72 @@ import math
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+
+
+class SNConv2d(nn.Module):
+    """Conv2d (no bias) under spectral normalisation with the state-dict layout of
+    ``torch.nn.utils.spectral_norm(nn.Conv2d(...))``: ``weight_orig`` (parameter), ``weight_u`` / ``weight_v``
+    (buffers).  The normalised weight is NOT computed here: ``spectral_weights`` does it for all convolutions of a
+    module at once (five launches instead of ~15 per convolution)."""
+
+    def __init__(self, c_in, c_out, k, stride, pad):
+        super().__init__()
+        conv = nn.Conv2d(c_in, c_out, (k, k), (stride, stride), (pad, pad), bias=False)   # same init + RNG order as stock
+        self.weight_orig = nn.Parameter(conv.weight.detach().clone())
+        w2 = self.weight_orig.detach().reshape(c_out, -1)
+        self.register_buffer("weight_u", F.normalize(w2.new_empty(w2.shape[0]).normal_(0, 1), dim=0, eps=1e-12))
+        self.register_buffer("weight_v", F.normalize(w2.new_empty(w2.shape[1]).normal_(0, 1), dim=0, eps=1e-12))
+        self.stride, self.padding = (stride, stride), (pad, pad)
+
+    def forward(self, x, weight):
+        return F.conv2d(x, weight, None, self.stride, self.padding)
+
+
+class _SpectralWeightsHip(torch.autograd.Function):
+    """W_sn = W / sigma for a list of SNConv2d modules through tp_sn_fwd / tp_sn_bwd (u, v constants in the backward,
+    as in torch).  First-order only: the R1 double backward reaches W_sn through the convolutions, never through here."""
+
+    @staticmethod
+    def forward(ctx, convs, training, *weights):
+        from . import ops
+        us, vs = [c.weight_u for c in convs], [c.weight_v for c in convs]
+        outs, sigmas = ops.spectral_norm_fwd([w.detach() for w in weights], us, vs, training)
+        # later forwards of the same iteration advance u / v in place: keep this forward's copies for its backward
+        ctx.us = [u.clone() for u in us] if training else us
+        ctx.vs = [v.clone() for v in vs] if training else vs
+        ctx.sigmas = sigmas
+        ctx.save_for_backward(*outs)
+        return tuple(outs)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, *grads):
+        from . import ops
+        outs = ctx.saved_tensors
+        grads = [g if g is not None else torch.zeros_like(o) for g, o in zip(grads, outs)]
+        gw = ops.spectral_norm_bwd(grads, outs, ctx.us, ctx.vs, ctx.sigmas)
+        return (None, None) + tuple(gw)
+
+
+def spectral_weights(convs, training: bool):
+    """Normalised weights of ``convs`` (SNConv2d list) with torch.nn.utils.spectral_norm semantics: in training mode
+    one power iteration per call updates weight_u / weight_v in place.  GPU tensors go through the fused HIP kernels;
+    CPU tensors (state-dict / contract tests, golden generation) use the same arithmetic in plain torch ops."""
+    ws = [c.weight_orig for c in convs]
+    if ws[0].is_cuda:
+        return list(_SpectralWeightsHip.apply(convs, bool(training), *ws))
+    outs = []
+    for c in convs:
+        w2 = c.weight_orig.reshape(c.weight_orig.shape[0], -1)
+        u, v = c.weight_u, c.weight_v
+        if training:
+            with torch.no_grad():
+                v.copy_(F.normalize(torch.mv(w2.t(), u), dim=0, eps=1e-12))
+                u.copy_(F.normalize(torch.mv(w2, v), dim=0, eps=1e-12))
+            u, v = u.clone(), v.clone()
+        sigma = torch.dot(u, torch.mv(w2, v))
+        outs.append(c.weight_orig / sigma)
+    return outs
 
 
 class Discriminator(nn.Module):
@@ -31,8 +98,7 @@ class Discriminator(nn.Module):
         if p not in (16, 32, 64, 128):
             raise ValueError("patch_size must be 16, 32, 64 or 128")
         self.progress = nn.Parameter(torch.tensor(0.))
-        SN = nn.utils.spectral_norm
-        conv = lambda i, o, k, s, pad: SN(nn.Conv2d(i, o, (k, k), (s, s), (pad, pad), bias=False))
+        conv = SNConv2d
         # stride-2 ladder down to 8x8 with 256 channels; the first stage of the 64/128 ladders has no norm
         widths = {16: [ndf * 4], 32: [ndf * 2, ndf * 4], 64: [ndf, ndf * 2, ndf * 4],
                   128: [ndf // 2, ndf, ndf * 2, ndf * 4]}[p]
@@ -52,13 +118,21 @@ class Discriminator(nn.Module):
             self.final = nn.Sequential(nn.LeakyReLU(0.2), conv(c, ndf, 1, 1, 0), nn.LeakyReLU(0.2, inplace=True),
                                        conv(ndf, ndf, 1, 1, 0), nn.LeakyReLU(0.2, inplace=True), conv(ndf, 1, 1, 1, 0))
 
+    @staticmethod
+    def _run(seq, x, weights):
+        for m in seq:
+            x = m(x, weights.pop(0)) if isinstance(m, SNConv2d) else m(x)
+        return x
+
     def forward(self, opt, x, scale=None):
-        out = self.main(x)                                            # [B, c, 1, 1]
+        convs = [m for m in list(self.main) + (list(self.final) if self.scale_conditional else []) if isinstance(m, SNConv2d)]
+        weights = spectral_weights(convs, self.training)              # all power iterations / normalisations at once
+        out = self._run(self.main, x, weights)                        # [B, c, 1, 1]
         if self.scale_conditional:
             freq = (2 ** torch.arange(self.L_scale, dtype=torch.float32, device=x.device)) * math.pi
             spec = scale.view(-1, 1) * freq                           # [B, L]
             enc = torch.cat([spec.sin(), spec.cos()], dim=1)[:, :, None, None]
-            out = self.final(torch.cat((out, enc, scale), 1)).flatten()
+            out = self._run(self.final, torch.cat((out, enc, scale), 1), weights).flatten()
         return out
 
     __call__ = forward

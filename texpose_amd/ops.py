@@ -394,3 +394,44 @@ def eval_metrics(rgb_static: Tensor, image: Tensor, obj_mask: Tensor, H: int, W:
     n = float(B * 3 * oh * ow)
     mse = out[:, 0].sum() / n
     return -10.0 * torch.log10(mse), out[:, 1].sum() / n, mse
+
+
+def spectral_norm_fwd(weights, us, vs, training: bool):
+    """weights[i] [out, ...] (contiguous), us[i] [out], vs[i] [K]: one power iteration per weight when ``training``
+    (u, v updated IN PLACE, like torch.nn.utils.spectral_norm), then W_sn = W / sigma.  Returns (W_sn list, sigma
+    list of 1-element tensors).  All weights of a module in five launches."""
+    lib = _lib.load()
+    n = len(weights)
+    arr = (_lib.SnWeight * n)()
+    outs, sigmas, keep = [], [], []
+    for i, (w, u, v) in enumerate(zip(weights, us, vs)):
+        w = _f32(w, "weight")
+        rows, cols = w.shape[0], w.numel() // w.shape[0]
+        o, sg = torch.empty_like(w), torch.empty(1, device=w.device)
+        wk = torch.empty(lib.tp_sn_work_floats(rows, cols), device=w.device)
+        a = arr[i]
+        a.weight, a.u, a.v, a.weight_sn, a.sigma, a.work = w.data_ptr(), u.data_ptr(), v.data_ptr(), o.data_ptr(), sg.data_ptr(), wk.data_ptr()
+        a.rows, a.cols = rows, cols
+        outs.append(o); sigmas.append(sg); keep += [w, wk]
+    check(lib.tp_sn_fwd(arr, n, int(bool(training)), _stream()), "tp_sn_fwd")
+    return outs, sigmas
+
+
+def spectral_norm_bwd(grads_sn, weights_sn, us, vs, sigmas):
+    """dL/dW from dL/dW_sn with u, v treated as constants (torch's convention): (G - <G, W_sn> u v^T) / sigma."""
+    lib = _lib.load()
+    n = len(grads_sn)
+    arr = (_lib.SnWeight * n)()
+    outs, keep = [], []
+    for i, (g, ws, u, v, sg) in enumerate(zip(grads_sn, weights_sn, us, vs, sigmas)):
+        g = _f32(g, "grad")
+        rows, cols = ws.shape[0], ws.numel() // ws.shape[0]
+        o = torch.empty_like(ws)
+        wk = torch.empty(lib.tp_sn_work_floats(rows, cols), device=ws.device)
+        a = arr[i]
+        a.u, a.v, a.weight_sn, a.sigma, a.grad_sn, a.grad, a.work = (u.data_ptr(), v.data_ptr(), ws.data_ptr(), sg.data_ptr(),
+                                                                       g.data_ptr(), o.data_ptr(), wk.data_ptr())
+        a.rows, a.cols = rows, cols
+        outs.append(o); keep += [g, wk]
+    check(lib.tp_sn_bwd(arr, n, _stream()), "tp_sn_bwd")
+    return outs
