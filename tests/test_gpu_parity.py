@@ -6,6 +6,8 @@ randoms; per-sample alpha / prob / density rel-L2 <= 1e-4; integer / index work 
 The end-to-end test additionally documents the fp32 conditioning of the reference itself: a 1-ulp
 change of a sample position moves the 2^9*pi positional-encoding band by ~1e-3 rad.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -794,6 +796,64 @@ def test_spectral_weights_match_torch(ops):
             torch.testing.assert_close(c.weight_u.cpu(), ru, rtol=2e-5, atol=1e-7)
             torch.testing.assert_close(c.weight_v.cpu(), rv, rtol=2e-5, atol=1e-7)
             torch.testing.assert_close(c.weight_orig.grad.cpu(), rg, rtol=1e-4, atol=1e-6)
+
+
+def test_graph_capture_with_rccl_all_reduce(ops):
+    """The data-parallel gradient all-reduce (RCCL) inside the captured iteration: a 1-rank NCCL group on this GPU with
+    the collective forced on.  Replays must run and give the same parameters as the capture without the collective."""
+    import torch.distributed as dist
+    from texpose_amd.gan_modules import Discriminator
+    from texpose_amd.graph import Graph
+    from texpose_amd.options import default_options, AttrDict
+    from texpose_amd.synthetic import training_batch
+    from texpose_amd.trainer import GraphedGanTrainer
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev())
+    try:
+        B, H, W, N = 2, 32, 32, 8
+        batch = training_batch(B, H, W, n_train=5, seed=2, device="cuda:0")
+        rnd = (torch.rand(3, B, 1, 1, 1, device=dev()), torch.rand(B, 256, N, 1, device=dev()))
+        results = []
+        for forced in (False, True):
+            opt = default_options(H=H, W=W, device="cuda:0")
+            opt.batch_size, opt.patch_size, opt.nerf.sample_intvs = B, 16, N
+            opt.loss_weight.feat = None
+            graph = Graph(opt, discriminator=Discriminator(opt)).to(dev())
+            graph.nerf.load_state_dict({**graph.nerf.state_dict(), **{k: cu(v) for k, v in O.make_params(6).items()}})
+            dcpu = Discriminator(opt)
+            O.seed_spectral_module(dcpu, 10)
+            graph.discriminator.load_state_dict(dcpu.state_dict())
+            graph.train()
+            graph.nerf.precision = "fp32"
+            tr = GraphedGanTrainer(opt, graph, n_train=5)
+            with torch.no_grad():
+                graph.latent_vars_trans.weight.fill_(0.1)
+                graph.latent_vars_light.weight.fill_(-0.2)
+            tr.red_nerf.single_rank_collective = tr.red_disc.single_rank_collective = forced
+            snap = {k: v.detach().clone() for k, v in graph.state_dict().items()}
+            ex = AttrDict(dict(batch))
+            ex.patch_u, ex.jitter_rand = rnd
+            tr.capture(ex, warmup=2)
+            graph.load_state_dict(snap)
+            for o in (tr.optim_nerf, tr.optim_disc):
+                for st in o.state.values():
+                    for v in st.values():
+                        if torch.is_tensor(v):
+                            v.zero_()
+            graph.nerf.mark_heads_dirty()
+            for _ in range(2):
+                v = AttrDict(dict(batch))
+                v.patch_u, v.jitter_rand = rnd
+                _, loss = tr.train_iteration(v)
+            assert all(np.isfinite(float(x)) for x in loss.values())
+            results.append({k: v.detach().clone() for k, v in graph.state_dict().items()})
+        for k in results[0]:
+            if results[0][k].dtype.is_floating_point:
+                torch.testing.assert_close(results[1][k], results[0][k], rtol=1e-3, atol=1e-5, msg=k)
+    finally:
+        dist.destroy_process_group()
 
 
 def edict_copy(var):

@@ -50,9 +50,11 @@ class FlatGradAllReducer:
     which is checked once).
     """
 
-    def __init__(self, params: Iterable[torch.nn.Parameter], group=None):
+    def __init__(self, params: Iterable[torch.nn.Parameter], group=None, single_rank_collective: bool = False):
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         self.group = group
+        # tests only: issue the collective even in a 1-rank group (exercises RCCL under hipGraph capture on one GPU)
+        self.single_rank_collective = single_rank_collective
         n = sum(p.numel() for p in self.params)
         dev = self.params[0].device if self.params else torch.device("cpu")
         self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
@@ -67,7 +69,9 @@ class FlatGradAllReducer:
         return self.flat.numel() * 4
 
     def reduce(self, average: bool = True) -> None:
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.group) == 1:
+        if not (dist.is_available() and dist.is_initialized()):
+            return
+        if dist.get_world_size(self.group) == 1 and not self.single_rank_collective:
             return
         world = dist.get_world_size(self.group)
         for p, v in zip(self.params, self.views):
