@@ -27,6 +27,9 @@ using half2v = __attribute__((ext_vector_type(2))) __fp16;
 
 constexpr int kBiasPad = (kBiasFloats + 63) / 64 * 64;
 constexpr int kStageHalves = 5 * 2 * kThreads * 8;             // 5 k-steps x (hi, lo) x 256 lanes x 8 halves = 40 KiB
+// cache policy of the park / reload of the trunk feature: nt (streaming) keeps the once-written, once-read 128 KiB per
+// workgroup and tile from evicting the 3.7 MB weight stream out of the XCD's 4 MiB L2
+constexpr int kParkAux = 2;
 constexpr int kBufs = 3;                                         // weight-chunk ring: two chunks (3072 cycles) ahead
 constexpr int kLdsBytes = kBufs * kChunkFloats * 4 + kBiasPad * 4 + kStageHalves * 2;
 constexpr float kInvScale = 1.0f / (float)(1 << kF16WeightShift);
@@ -373,7 +376,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_f16x3_kernel(Params P) {
         for (int t = 0; t < 8; ++t)
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
-            const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ws, tid * 16, (t * 4 + g) * 4096, 0));
+            const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ws, tid * 16, (t * 4 + g) * 4096, kParkAux));
             S[t][g * 4 + 0] = v.x; S[t][g * 4 + 1] = v.y; S[t][g * 4 + 2] = v.z; S[t][g * 4 + 3] = v.w;
           }
         asm volatile("" :: "v"(S[7][15]), "v"(S[0][0]));
@@ -476,7 +479,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_f16x3_kernel(Params P) {
 #pragma unroll
           for (int g = 0; g < 4; ++g)
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{D[t][g * 4 + 0], D[t][g * 4 + 1], D[t][g * 4 + 2], D[t][g * 4 + 3]}),
-                                                   ws, tid * 16, (t * 4 + g) * 4096, 0);
+                                                   ws, tid * 16, (t * 4 + g) * 4096, kParkAux);
         TR_END(9, vc);
       }
     };
