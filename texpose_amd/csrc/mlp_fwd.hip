@@ -145,7 +145,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_kernel(Params P) {
         for (int t = 0; t < 8; ++t)
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(ws + ((t * 4 + g) * kThreads + tid) * 4);
+            const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(ws + ((t * 4 + g) * kThreads + tid) * 4));
             h[t][g * 4 + 0] = v.x; h[t][g * 4 + 1] = v.y; h[t][g * 4 + 2] = v.z; h[t][g * 4 + 3] = v.w;
           }
       }
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_kernel(Params P) {
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
             f32x4 v = {h[t][g * 4 + 0], h[t][g * 4 + 1], h[t][g * 4 + 2], h[t][g * 4 + 3]};
-            *reinterpret_cast<f32x4*>(ws + ((t * 4 + g) * kThreads + tid) * 4) = v;
+            __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(ws + ((t * 4 + g) * kThreads + tid) * 4));   // streaming: keep the weights in L2
           }
       }
       if (li == T2) {   // transient head: rgb_t (sigmoid), sigma_t, uncert (softplus) (layers/...light.py:135-137)
