@@ -133,7 +133,8 @@ typedef struct tp_mlp_fwd_args {
 } tp_mlp_fwd_args;
 /* TP_MLP_F16X3: every fp32 operand is split into hi + lo fp16 (22-bit significand) and hi*hi + hi*lo + lo*hi is
  * accumulated in fp32 on the f16 matrix cores (16x the fp32-MFMA rate / 3).  Measured error vs an fp64 oracle is
- * within 1.3x of plain fp32.  Requires |activation| < 6e4; inference (saved == NULL) only. */
+ * within 1.3x of plain fp32.  Requires |activation| < 6e4 (see `status`).  With `saved` it writes
+ * the same fp32 activation record as TP_MLP_FP32 (the backward kernels do not depend on how the forward was computed). */
 enum { TP_MLP_FP32 = 0, TP_MLP_F16X3 = 1 };
 
 int tp_mlp_fwd(const tp_mlp_fwd_args* args, tp_stream_t stream);

@@ -281,8 +281,9 @@ def _graph(params, n_train=5, emb_seed=77, H=16, W=16, N=8):
     return g, opt
 
 
+@pytest.mark.parametrize("train_precision", ["fp32", "f16x3"])
 @pytest.mark.parametrize("B,R,N", [(2, 16, 8), (1, 50, 20), (3, 64, 64)])
-def test_mlp_backward_vs_oracle_autograd(ops, B, R, N):
+def test_mlp_backward_vs_oracle_autograd(ops, B, R, N, train_precision):
     """dL/d(mlp_rgb, mlp_trans, latents) for a random linear functional of the MLP outputs, vs torch autograd
     through the CPU oracle on identical inputs.
 
@@ -295,6 +296,7 @@ def test_mlp_backward_vs_oracle_autograd(ops, B, R, N):
     rs = np.random.RandomState(7 * B + R)
     params = O.make_params(21)
     g, opt = _graph(params, N=N)
+    g.nerf.train_precision = train_precision           # recording forward: exact fp32 MFMA or f16x3 (same record layout)
     pts = torch.from_numpy(rs.uniform(-1.2, 1.2, size=(B, R, N, 3)).astype(np.float32))
     unit = torch.nn.functional.normalize(torch.from_numpy(rs.normal(size=(B, R, 1, 3)).astype(np.float32)),
                                          dim=-1).expand(B, R, N, 3).contiguous()
@@ -311,6 +313,8 @@ def test_mlp_backward_vs_oracle_autograd(ops, B, R, N):
     outd = g.nerf.forward(opt, cu(pts), ray_unit=cu(unit), latent_variable_trans=ltd, latent_variable_light=lld,
                           mode="train")
     sum((o * cu(c)).sum() for o, c in zip(outd, cots)).backward()
+    for o, r in zip(outd, out):
+        torch.testing.assert_close(o.detach().cpu(), r.detach(), rtol=1e-4, atol=1e-6)
     for k, p in g.nerf.named_parameters():
         if k.startswith("mlp_feat") or k == "progress":
             assert p.grad is None
@@ -637,6 +641,19 @@ def test_train_iterations_match_reference_g13(ops):
         assert float(((d - ref).abs() > 0.25 * step).double().mean()) < 0.03, k
 
 
+def assert_updates_close(sd_a, sd_b, snap):
+    """Parameter UPDATES of two training runs that should agree up to fp32 noise.  Adam / RMSprop normalise every entry,
+    so a gradient entry at the noise floor can take a different +-lr step: compare the bulk of each update (relative L2)
+    and bound the fraction of entries that moved differently by more than a quarter of the largest step."""
+    for k in sd_a:
+        if not sd_a[k].dtype.is_floating_point or torch.equal(sd_a[k], snap[k]):
+            continue
+        da, db = (sd_a[k] - snap[k]).double().flatten(), (sd_b[k] - snap[k]).double().flatten()
+        assert float((da - db).norm() / da.norm()) < 0.05, (k, float((da - db).norm() / da.norm()))
+        if not (k.endswith("_u") or k.endswith("_v")):
+            assert float(((da - db).abs() > 0.25 * float(da.abs().max())).double().mean()) < 0.01, k
+
+
 def test_graph_captured_training_matches_eager(ops):
     """GraphedGanTrainer (one hipGraph replay per iteration) against the eager GanTrainer: identical weights, batch,
     optimiser arithmetic and (externally supplied) random numbers -> the same losses and parameters after several
@@ -699,17 +716,7 @@ def test_graph_captured_training_matches_eager(ops):
         for k in ("render", "uncert", "trans_reg", "gan_nerf", "gan_disc_real", "gan_disc_fake", "gan_reg_real"):
             assert abs(a[k] - b_[k]) <= tol * abs(a[k]) + 1e-6, (it, k, a[k], b_[k])
     sd_e, sd_g = g_e.state_dict(), g_g.state_dict()
-    for k in sd_e:
-        if not sd_e[k].dtype.is_floating_point or torch.equal(sd_e[k], snap[k]):
-            continue
-        # Adam / RMSprop normalise every entry, so a gradient entry at the noise floor can take a different +-lr step:
-        # compare the bulk of the update and bound the fraction of entries that moved differently (by more than a
-        # typical step)
-        de, dg = (sd_e[k] - snap[k]).double().flatten(), (sd_g[k] - snap[k]).double().flatten()
-        assert float((de - dg).norm() / de.norm()) < 0.05, (k, float((de - dg).norm() / de.norm()))
-        if not (k.endswith("_u") or k.endswith("_v")):
-            typical = 0.25 * float(de.abs().max())
-            assert float(((de - dg).abs() > typical).double().mean()) < 0.01, k
+    assert_updates_close(sd_e, sd_g, snap)
     assert all(torch.equal(sd_g[k], snap[k]) for k in sd_g if k.startswith("nerf.mlp_feat"))
     assert not torch.equal(sd_g["nerf.mlp_rgb.0.weight"], snap["nerf.mlp_rgb.0.weight"])
     assert not torch.equal(sd_g["discriminator.main.0.weight_orig"], snap["discriminator.main.0.weight_orig"])
@@ -849,9 +856,7 @@ def test_graph_capture_with_rccl_all_reduce(ops):
                 _, loss = tr.train_iteration(v)
             assert all(np.isfinite(float(x)) for x in loss.values())
             results.append({k: v.detach().clone() for k, v in graph.state_dict().items()})
-        for k in results[0]:
-            if results[0][k].dtype.is_floating_point:
-                torch.testing.assert_close(results[1][k], results[0][k], rtol=1e-3, atol=1e-5, msg=k)
+        assert_updates_close(results[0], results[1], snap)
     finally:
         dist.destroy_process_group()
 

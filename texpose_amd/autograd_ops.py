@@ -37,7 +37,7 @@ def composite(ray, rgb, density, depth, uncert, min_uncert):
 class _Mlp(torch.autograd.Function):
     @staticmethod
     def forward(ctx, nerf, need_grad, lat_trans, lat_light, center, ray, depth, points, ray_unit, *head_params):
-        precision = "fp32" if need_grad else nerf.precision
+        precision = nerf.train_precision if need_grad else nerf.precision
         packed = nerf.packed_weights(precision)
         res = ops.mlp_forward(packed, lat_trans, lat_light, center=center, ray=ray, depth=depth, points=points,
                               ray_unit=ray_unit, save=need_grad, precision=precision)

@@ -302,7 +302,6 @@ extern "C" int tp_mlp_fwd(const tp_mlp_fwd_args* a, tp_stream_t stream) {
   TP_REQUIRE((a->center && a->ray && a->depth) || (a->points && a->ray_unit), "need (center,ray,depth) or (points,ray_unit)");
   TP_REQUIRE(a->precision == TP_MLP_FP32 || a->precision == TP_MLP_F16X3, "unknown precision");
   if (a->precision == TP_MLP_F16X3) {
-    TP_REQUIRE(a->saved == nullptr, "TP_MLP_F16X3 is inference-only (no activation record)");
     const int64_t tiles = ((int64_t)a->B * a->R * a->N + kTileSamples - 1) / kTileSamples;
     return tp_launch_mlp_fwd_f16x3(a, persistent_grid(tiles), (hipStream_t)stream);
   }

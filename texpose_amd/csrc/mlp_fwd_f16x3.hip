@@ -261,7 +261,7 @@ struct Params {
   const float* lat_trans; const float* lat_light;
   int B, R, N;
   int64_t n_samples, n_tiles;
-  float* rgb; float* density; float* uncert; float* workspace; int* status;
+  float* rgb; float* density; float* uncert; float* saved; float* workspace; int* status;
 };
 
 // stage one "extra input" value as hi/lo halves: slot = 16 ks + 8 h + j of this lane
@@ -279,6 +279,7 @@ __device__ __forceinline__ void stage_slot(_Float16* st, int tid_lo, int slot, f
   st[((ks * 2 + 1) * kThreads + owner) * 8 + jj] = (_Float16)(v - (float)hi);
 }
 
+template <bool SAVE>
 __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_f16x3_kernel(Params P) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -427,7 +428,9 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_f16x3_kernel(Params P) {
         // [ray_unit | PE(ray_unit) | x | light] in natural column order, 78 of 80 slots
         TR_BEGIN(r0s);
         // slots 0..31: ray_unit (0..2), PE(ray_unit) (3 + 8 c + 4 sc + l: 12 sin/cos pairs, 6 per lane), x (27..29),
-        // the first two latent entries (30, 31)
+        // the first two latent entries (30, 31).  Training: slots 0..29 (mlp_rgb.0 input columns 256..285) also go
+        // to the activation record as fp32 for the weight gradient
+        float* sx = SAVE ? P.saved + (tile * 4 + wave) * (int64_t)kSavedGroupFloats + SV_EX * kBlockFloats : nullptr;
 #pragma nounroll
         for (int i = 0; i < 6; ++i) {
           const int pi_ = hh * 6 + i, c = pi_ >> 2, l = pi_ & 3;
@@ -436,12 +439,15 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_f16x3_kernel(Params P) {
           tp::sincos_both(tp::mul_rn(vc, ldexpf(3.14159274101257324f, l)), sv, cv);
           stage_slot(st, tid & ~32, 3 + 8 * c + l, sv);
           stage_slot(st, tid & ~32, 3 + 8 * c + 4 + l, cv);
+          if (SAVE && live) { sx[blk_off(3 + 8 * c + l, j)] = sv; sx[blk_off(3 + 8 * c + 4 + l, j)] = cv; }
         }
         if (hh == 0) {
           stage(st, tid, 0, 0, vu[0]); stage(st, tid, 0, 1, vu[1]); stage(st, tid, 0, 2, vu[2]);
+          if (SAVE && live) { sx[blk_off(0, j)] = vu[0]; sx[blk_off(1, j)] = vu[1]; sx[blk_off(2, j)] = vu[2]; }
         } else {
           stage(st, tid, 1, 3, x[0]); stage(st, tid, 1, 4, x[1]); stage(st, tid, 1, 5, x[2]);
           stage(st, tid, 1, 6, P.lat_light[b * 48 + 0]); stage(st, tid, 1, 7, P.lat_light[b * 48 + 1]);
+          if (SAVE && live) { sx[blk_off(27, j)] = x[0]; sx[blk_off(28, j)] = x[1]; sx[blk_off(29, j)] = x[2]; }
         }
         // k-steps 2..4 are latent-code slots only: 8 loads at a time (one latency per k-step), one 16-byte store per
         // (k-step, hi/lo)
@@ -471,6 +477,27 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_f16x3_kernel(Params P) {
         }
       }
 
+      if (SAVE && li >= L7 && live) {
+        // activations for the backward (layout: mlp_layout.h "Training record"): post-ReLU values as fp32 + ReLU
+        // sign bits for the dgrad kernel
+        float* grp = P.saved + (tile * 4 + wave) * (int64_t)kSavedGroupFloats;
+        float* blk = grp + (li - L7) * kBlockFloats;
+        int o16[16];
+        lane_block_offsets(j, hh, o16);
+        uint32_t* mk = reinterpret_cast<uint32_t*>(grp + kMaskOff) + (li - T0) * 256 + lane;
+#pragma unroll
+        for (int w4 = 0; w4 < 4; ++w4) {
+          uint32_t m = 0;
+#pragma unroll
+          for (int bt = 0; bt < 32; ++bt) {
+            const int t = 2 * w4 + (bt >> 4), r = bt & 15;
+            const float hv = fmaxf(D[t][r] * kInvScale, 0.0f);
+            blk[t * 1024 + o16[r]] = hv;
+            m |= (hv > 0.0f ? 1u : 0u) << bt;
+          }
+          if (li >= T0) mk[w4 * 64] = m;
+        }
+      }
       if (!EVEN && li == L7) {
         // park the trunk feature (raw accumulators) for R0: T1 overwrites this set
         TR_BEGIN(vc);
@@ -526,13 +553,19 @@ int tp_launch_mlp_fwd_f16x3(const tp_mlp_fwd_args* a, int grid, hipStream_t stre
   P.B = a->B; P.R = a->R; P.N = a->N;
   P.n_samples = (int64_t)a->B * a->R * a->N;
   P.n_tiles = (P.n_samples + 127) / 128;
-  P.rgb = a->rgb; P.density = a->density; P.uncert = a->uncert; P.workspace = (float*)a->workspace; P.status = a->status;
+  P.rgb = a->rgb; P.density = a->density; P.uncert = a->uncert; P.saved = a->saved; P.workspace = (float*)a->workspace;
+  P.status = a->status;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)mlp_fwd_f16x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+    hipError_t e = hipFuncSetAttribute((const void*)mlp_fwd_f16x3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void*)mlp_fwd_f16x3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
     if (e != hipSuccess) { tp::set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
     attr_set = true;
   }
-  hipLaunchKernelGGL(mlp_fwd_f16x3_kernel, dim3(grid), dim3(kThreads), kLdsBytes, stream, P);
+  if (P.saved != nullptr)
+    hipLaunchKernelGGL(mlp_fwd_f16x3_kernel<true>, dim3(grid), dim3(kThreads), kLdsBytes, stream, P);
+  else
+    hipLaunchKernelGGL(mlp_fwd_f16x3_kernel<false>, dim3(grid), dim3(kThreads), kLdsBytes, stream, P);
   return tp::check_launch("tp_mlp_fwd(f16x3)");
 }

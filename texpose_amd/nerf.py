@@ -54,11 +54,13 @@ class NeRF(torch.nn.Module):
         self.mlp_trans = stack(opt.arch.layers_trans, feat_dim + opt.nerf.N_latent_trans)
         if opt.c2f is not None:
             self.progress = torch.nn.Parameter(torch.tensor(0.))
-        # inference arithmetic: "f16x3" (split-fp16 products on the f16 matrix cores, fp32-grade accuracy) or
-        # "fp32" (exact fp32 MFMA); training always records activations with the fp32 kernel
+        # forward arithmetic: "f16x3" (split-fp16 products on the f16 matrix cores, fp32-grade accuracy) or "fp32"
+        # (exact fp32 MFMA).  `precision` is used without autograd, `train_precision` for the recording forward of a
+        # training step (the backward kernels are fp32 MFMA either way and consume the same activation record)
         self.precision = opt.arch.get("mlp_precision", "f16x3")
-        if self.precision not in ops.PRECISIONS:
-            raise ValueError("arch.mlp_precision must be one of %s" % list(ops.PRECISIONS))
+        self.train_precision = opt.arch.get("mlp_train_precision", "f16x3")
+        if self.precision not in ops.PRECISIONS or self.train_precision not in ops.PRECISIONS:
+            raise ValueError("arch.mlp_precision / mlp_train_precision must be one of %s" % list(ops.PRECISIONS))
         self._packed = {}
         self._versions = {}
 

@@ -246,8 +246,6 @@ def mlp_forward(packed: Tensor, lat_trans: Tensor, lat_light: Tensor, *, center:
     a.saved, a.workspace = _ptr(saved), ws.data_ptr()
     a.precision = PRECISIONS[precision]
     if a.precision == MLP_F16X3:
-        if save:
-            raise _lib.TexposeLibraryError("the f16x3 forward is inference-only; train with precision='fp32'")
         a.status = mlp_status(dev).data_ptr()
     check(lib.tp_mlp_fwd(C.byref(a), _stream()), "tp_mlp_fwd")
     return (rgb, density, uncert, saved) if save else (rgb, density, uncert)

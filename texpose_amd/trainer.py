@@ -12,6 +12,7 @@ from __future__ import annotations
 import torch
 
 from . import dist as tdist
+from . import ops
 from .graph import Graph, summarize_loss
 from .options import AttrDict
 
@@ -73,6 +74,12 @@ class GanTrainer:
         self.optim_disc.step()
         return var, loss
 
+    def _poll_range(self, device):
+        """f16x3 recording forward: surface a raised range flag (an activation beyond 6e4) without a host sync; it
+        shows up one or two iterations late at most.  Remedy: arch.mlp_train_precision = 'fp32'."""
+        if self.graph.nerf.train_precision == "f16x3":
+            ops.poll_mlp_status(device)
+
     def train_iteration(self, var: AttrDict):
         var = self.graph.get_ray_idx(self.opt, var)
         var, loss = self.nerf_step(var)
@@ -82,6 +89,7 @@ class GanTrainer:
             self.graph.discriminator.progress.data.fill_(self.it / self.max_iter)
         self.it += 1
         self.graph.patch_sampler.iterations = self.it
+        self._poll_range(var.image.device)
         return var, loss
 
 
@@ -157,4 +165,5 @@ class GraphedGanTrainer(GanTrainer):
         self.graph.patch_sampler.update_device_bound()          # one fill_ of the annealed bound
         self._graph.replay()
         self._after_step()
+        self._poll_range(var.image.device)                      # outside the graph: event query + pinned copy
         return self._static_in, AttrDict(self._static_loss)
