@@ -32,9 +32,13 @@ ISSUED_PER_ALGORITHMIC = {"fp32": 1, "f16x3": 3}    # f16x3 issues hi*hi + hi*lo
 
 
 def build_scene(device, seed):
-    from oracle import texpose_oracle as O          # only the synthetic-scene recipe + weight recipe (data, not compute)
-    sc = O.synthetic_scene(H, W, B=1, seed=seed)
-    params = O.make_params(0, bias_scale=0.0)
+    """Synthetic evaluation scene through the PRODUCT path only: numpy recipes for intrinsics / pose / box / weights
+    (texpose_amd.synthetic) and per-pixel depth bounds from the HIP ray-gen + slab test.  Returns CPU tensors."""
+    from texpose_amd import synthetic
+    sc = synthetic.eval_scene(H, W, B=1, seed=seed)
+    near, far = synthetic.scene_bounds(sc, H, W, device)
+    sc["z_near"], sc["z_far"] = near.cpu(), far.cpu()
+    params = synthetic.network_weights(0, bias_scale=0.0)
     rs = np.random.RandomState(1)
     emb_t = torch.from_numpy(rs.normal(size=(189, 16)).astype(np.float32))
     emb_l = torch.from_numpy(rs.normal(size=(189, 48)).astype(np.float32))
@@ -60,7 +64,8 @@ def make_graph(device, params, emb_t, emb_l, precision=None):
 
 
 def cpu_baseline(sc, params, emb_t, emb_l, budget_s=20.0, chunk=2048):
-    """CPU oracle (plain PyTorch restatement of the reference path) on 2048-ray chunks of the same image.
+    """CPU oracle (plain PyTorch restatement of the reference path; the ONLY place this file touches oracle/) on
+    2048-ray chunks of the same image.
     The thread count is picked by a short trial (all hardware threads is usually NOT the fastest for
     256-wide GEMMs); `cores` reports the count actually used."""
     from oracle import texpose_oracle as O

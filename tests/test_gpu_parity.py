@@ -861,6 +861,19 @@ def test_graph_capture_with_rccl_all_reduce(ops):
         dist.destroy_process_group()
 
 
+def test_bench_scene_bounds_match_oracle(ops):
+    """The scene bench.py renders (texpose_amd.synthetic: numpy recipes + HIP slab-test bounds) equals the oracle's
+    synthetic scene that the cpu_baseline leg renders."""
+    from texpose_amd import synthetic as S
+    H, W = 96, 128
+    sc = S.eval_scene(H, W, B=2, seed=4)
+    near, far = S.scene_bounds(sc, H, W, dev())
+    ref = O.synthetic_scene(H, W, B=2, seed=4)
+    torch.testing.assert_close(near.cpu(), ref["z_near"], rtol=2e-5, atol=2e-5)
+    torch.testing.assert_close(far.cpu(), ref["z_far"], rtol=2e-5, atol=2e-5)
+    assert float((near.cpu() != 0).float().mean()) > 0.02         # the box is hit (near = bg_near = 0 elsewhere)
+
+
 def edict_copy(var):
     from texpose_amd.options import AttrDict
     return AttrDict({k: v for k, v in var.items()})

@@ -151,3 +151,17 @@ def test_discriminator_matches_reference_g12():
     torch.testing.assert_close(reg.detach(), g["grad2"], rtol=1e-3, atol=1e-8)
     torch.testing.assert_close(Graph.compute_gan_loss(opt, out, 1).detach(), torch.as_tensor(g["bce_real"]), rtol=1e-5,
                                atol=1e-6)
+
+
+def test_synthetic_recipes_match_oracle_copies():
+    """bench.py builds its scene from texpose_amd.synthetic only (the oracle is reserved for the cpu_baseline leg and
+    the tests); the oracle keeps its own copy of the recipes -- both must generate identical data."""
+    from oracle import texpose_oracle as O
+    from texpose_amd import synthetic as S
+    for seed, bs in ((3, 0.05), (0, 0.0)):
+        a, b = O.make_params(seed, bias_scale=bs), S.network_weights(seed, bias_scale=bs)
+        assert a.keys() == b.keys() and all(torch.equal(a[k], b[k]) for k in a)
+    so, sp = O.synthetic_scene(48, 64, B=2, seed=5), S.eval_scene(48, 64, B=2, seed=5)
+    for k in ("intr", "pose", "aabb_min", "aabb_max"):
+        assert torch.equal(so[k], sp[k]), k
+    assert S.LINEMOD_K == O.LINEMOD_K
