@@ -1,8 +1,9 @@
 """Diagnostic (GPU box): is the HIP-vs-oracle gradient gap fp32 noise?  Compares HIP fp32, oracle fp32 and
 oracle fp64 on the same inputs."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+_REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, _REPO)
+sys.path.insert(0, os.path.join(_REPO, "tests"))
 import numpy as np, torch
 from oracle import texpose_oracle as O
 from test_gpu_parity import _graph, cu, rel_l2

@@ -1,5 +1,5 @@
 import sys, os
-R_=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R_=os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, R_); sys.path.insert(0, os.path.join(R_, "tests"))
 import numpy as np, torch
 from oracle import texpose_oracle as O

@@ -291,7 +291,7 @@ def test_mlp_backward_vs_oracle_autograd(ops, B, R, N, train_precision):
     output / third-layer gradients to ~1e-6, but ReLU gates are discontinuous: a single (sample, unit) whose
     pre-activation lies within fp32 rounding of zero flips its gate and moves the first-layer gradients by
     ~1e-3 in rel-L2.  The reference's own fp32-vs-fp64 gap on mlp_rgb.0.weight is 6e-4 on these inputs
-    (profiles/r1/03_bwd_noise_vs_fp64.txt, tools/diag_bwd_noise.py), so 1e-3 is not attainable by any fp32 path."""
+    (profiles/r1/03_bwd_noise_vs_fp64.txt, tests/diag/diag_bwd_noise.py), so 1e-3 is not attainable by any fp32 path."""
     GRAD_TOL = 5e-3
     rs = np.random.RandomState(7 * B + R)
     params = O.make_params(21)
