@@ -1,0 +1,185 @@
+"""GPU parity, randomised: every small C-ABI entry point against the CPU oracle on seeded random shapes and values
+(ragged sizes, single elements, out-of-range coordinates, rays that miss / graze / start inside the box, zero densities,
+sizes that straddle the kernels' 64-lane / 256-thread / 32-pixel tiling).  Complements the golden-vector tests in
+test_gpu_parity.py; integer / index work is compared bit-exactly, floating point at the SURVEY 8d bars."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import texpose_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+CASES = list(range(8))
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def cu(t):
+    return t.to(dev())
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a, dtype=np.float32))
+
+
+def rel_l2(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from texpose_amd import ops as _ops
+    return _ops
+
+
+def _scene(rs, B, H, W):
+    from texpose_amd import synthetic as S
+    sc = S.eval_scene(H, W, B=B, seed=int(rs.randint(1 << 30)))
+    K = sc["intr"].clone()
+    K[:, 0, 0] = K[:, 1, 1] = float(rs.uniform(0.8, 2.0)) * H
+    K[:, 0, 2], K[:, 1, 2] = W / 2 + float(rs.uniform(-2, 2)), H / 2 + float(rs.uniform(-2, 2))
+    sc["intr"] = K
+    return sc
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_fuzz_raygen_train_and_eval(ops, case):
+    rs = np.random.RandomState(100 + case)
+    B, H, W = int(rs.randint(1, 4)), int(rs.randint(5, 40)), int(rs.randint(5, 40))
+    p = int(rs.randint(1, 9))
+    sc = _scene(rs, B, H, W)
+    coords = T(rs.uniform(-1.15, 1.15, size=(B, p, p, 2)))            # slightly out of range: zero-padded bounds taps
+    zn, zf = T(rs.uniform(5, 7, size=(B, H * W))), T(rs.uniform(8, 10, size=(B, H * W)))
+    c, r, n_, f_, _ = ops.raygen(cu(sc["intr"]), cu(sc["pose"]), H=H, W=W, coords=cu(coords), z_near=cu(zn), z_far=cu(zf))
+    c_o, r_o = O.rays_train(sc["intr"], coords, sc["pose"], H, W)
+    torch.testing.assert_close(c.cpu().view_as(c_o), c_o, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(r.cpu().view_as(r_o), r_o, rtol=1e-5, atol=3e-6)
+    n_o = O.bilinear_gather(zn.view(B, 1, H, W), coords)[:, 0]
+    torch.testing.assert_close(n_.cpu().view_as(n_o), n_o, rtol=1e-6, atol=1e-6)
+    # eval: random subset of pixel indices (with repeats)
+    R = int(rs.randint(1, 300))
+    idx = torch.from_numpy(rs.randint(0, H * W, size=(B, R)).astype(np.int64))
+    c, r, n_, f_, _ = ops.raygen(cu(sc["intr"]), cu(sc["pose"]), H=H, W=W, ray_idx=cu(idx), z_near=cu(zn), z_far=cu(zf))
+    c_all, r_all = O.rays_eval(sc["pose"], sc["intr"], H, W)
+    g = lambda t: torch.gather(t, 1, idx[..., None].expand(-1, -1, t.shape[-1]))
+    torch.testing.assert_close(r.cpu(), g(r_all), rtol=1e-5, atol=3e-6)
+    assert torch.equal(n_.cpu(), torch.gather(zn, 1, idx)) and torch.equal(f_.cpu(), torch.gather(zf, 1, idx))
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_fuzz_aabb_and_depths(ops, case):
+    rs = np.random.RandomState(200 + case)
+    n = int(rs.choice([1, 63, 64, 65, 257, 1000]))
+    lo, hi = T(rs.uniform(-1.0, -0.2, size=(1, 1, 3))), T(rs.uniform(0.2, 1.0, size=(1, 1, 3)))
+    o = T(rs.uniform(-3, 3, size=(1, n, 3)))
+    d = T(rs.normal(size=(1, n, 3)))
+    o[0, : n // 4] = T(rs.uniform(-0.1, 0.1, size=(n // 4, 3)))       # origins inside the box
+    d[0, n // 2: n // 2 + n // 8, int(rs.randint(3))] = 0.0            # axis-parallel rays (division by zero lanes)
+    tn, tf, ok = ops.aabb_intersect(lo, hi, cu(o), cu(d))
+    tn_o, tf_o, ok_o = O.aabb_slab(lo, hi, o, d)
+    assert torch.equal(ok.cpu().bool(), ok_o.bool())
+    m = ok_o.bool()
+    torch.testing.assert_close(tn.cpu()[m], tn_o[m], rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(tf.cpu()[m], tf_o[m], rtol=1e-6, atol=1e-6)
+    # stratified depths: bit-exact with and without an injected uniform tensor
+    N = int(rs.choice([1, 3, 4, 7, 64, 129]))
+    near, far = T(rs.uniform(0, 5, size=(2, n))), T(rs.uniform(6, 30, size=(2, n)))
+    u = T(rs.uniform(size=(2, n, N, 1)))
+    assert torch.equal(ops.sample_depth(cu(near), cu(far), N).cpu()[..., None], O.stratified_depths(near, far, N))
+    assert torch.equal(ops.sample_depth(cu(near), cu(far), N, rand=cu(u)).cpu()[..., None], O.stratified_depths(near, far, N, u))
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_fuzz_posenc(ops, case):
+    rs = np.random.RandomState(300 + case)
+    n, L = int(rs.choice([1, 100, 257])), int(rs.choice([1, 4, 10]))
+    x = T(rs.uniform(-9, 9, size=(n, 3)))
+    torch.testing.assert_close(ops.posenc(cu(x), L).cpu(), O.posenc(x, L), rtol=1e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_fuzz_composite_fwd_bwd(ops, case):
+    rs = np.random.RandomState(400 + case)
+    n = int(rs.choice([1, 2, 7, 33]))
+    N = int(rs.choice([1, 2, 63, 64, 65, 127, 200, 513]))
+    ray = T(rs.normal(size=(1, n, 3)))
+    rgb = T(rs.uniform(size=(1, n, N, 3, 2)))
+    den = T(rs.gamma(0.5, 0.3, size=(1, n, N, 2)))
+    den[0, :, : N // 3] = 0.0                                           # empty space in front
+    z = torch.sort(T(rs.uniform(5, 8, size=(1, n, N, 1))), dim=2).values
+    unc = T(rs.gamma(1.0, 0.5, size=(1, n, N, 1)))
+    leaves = [t.clone().requires_grad_() for t in (rgb, den, unc)]
+    ref = O.composite(ray, leaves[0], leaves[1], z, leaves[2], 0.05)
+    names = ("rgb", "rgb_static", "rgb_transient", "depth", "opacity", "opacity_static", "opacity_transient",
+             "prob", "uncert", "alpha_static", "alpha_transient")
+    r = dict(zip(names, ref))
+    out, a_s, a_t, prob = ops.composite_fwd(cu(ray), cu(rgb), cu(den), cu(z), cu(unc), 0.05)
+    for name, lo, hi in ops.COMPOSITE_RAY_FIELDS:
+        torch.testing.assert_close(out.cpu()[..., lo:hi], r[name].detach(), rtol=1e-4, atol=1e-6)
+    assert rel_l2(a_t, r["alpha_transient"]) < 1e-4 and rel_l2(prob, r["prob"][..., 0]) < 1e-4
+    # backward of a random linear functional of the per-ray outputs (the last interval is 1e10 long: exclude the density
+    # gradient of the last sample from the relative norm, it is either exactly 0 or O(1e10))
+    cot = {k: T(rs.normal(size=tuple(r[k].shape))) for k in ("rgb", "rgb_static", "rgb_transient", "depth", "uncert")}
+    sum((r[k] * cot[k]).sum() for k in cot).backward()
+    g_out = torch.zeros(1, n, 14)
+    for name, lo, hi in ops.COMPOSITE_RAY_FIELDS:
+        if name in cot:
+            g_out[..., lo:hi] = cot[name]
+    g_rgb, g_den, g_unc = ops.composite_bwd(cu(ray), cu(rgb), cu(den), cu(z), cu(unc), cu(g_out), None, None, None, 0.05)
+    assert rel_l2(g_rgb, leaves[0].grad) < 1e-4 and rel_l2(g_unc, leaves[2].grad) < 1e-4
+    if N > 1:
+        assert rel_l2(g_den[:, :, :-1], leaves[1].grad[:, :, :-1]) < 2e-4
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_fuzz_patch_gather(ops, case):
+    rs = np.random.RandomState(500 + case)
+    B, H, W, p = int(rs.randint(1, 4)), int(rs.randint(4, 50)), int(rs.randint(4, 50)), int(rs.randint(1, 20))
+    imgs = [T(rs.uniform(-1, 1, size=(B, 3, H, W))) for _ in range(4)]
+    m1, m2 = T((rs.uniform(size=(B, H, W)) > 0.4).astype(np.float32)), T(rs.uniform(-1, 1, size=(B, H, W)))   # non-binary mask: > 0 rule
+    coords = T(rs.uniform(-1.2, 1.2, size=(B, p, p, 2)))
+    coords[0, 0, 0] = torch.tensor([1.0, 1.0])
+    coords[0, -1, -1] = torch.tensor([-1.0, -1.0])
+    out = ops.patch_gather(cu(coords), *[cu(t) for t in imgs], cu(m1), cu(m2)).cpu()
+    s = O.patch_gather(coords, *imgs, m1, m2)
+    torch.testing.assert_close(out[:, 0:3], s["image"], rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(out[:, 3:6], s["image_syn"], rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(out[:, 6:9], s["nocs_sample"], rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(out[:, 9:12], s["normal_sample"], rtol=1e-6, atol=1e-6)
+    assert torch.equal(out[:, 12:13], s["mask"]) and torch.equal(out[:, 13:14], s["mask_syn"])
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_fuzz_eval_metrics(ops, case):
+    rs = np.random.RandomState(600 + case)
+    B, H, W = int(rs.randint(1, 4)), int(rs.randint(3, 90)), int(rs.randint(3, 90))
+    out_hw = None if case % 2 == 0 else (int(rs.randint(H, 3 * H)), int(rs.randint(W, 3 * W)))
+    image = T(rs.uniform(size=(B, 3, H, W)))
+    rgb = (0.6 * image + 0.4 * T(rs.uniform(size=(B, 3, H, W)))).permute(0, 2, 3, 1).reshape(B, H * W, 3).contiguous()
+    mask = T((rs.uniform(size=(B, H, W)) > 0.3).astype(np.float32))
+    ref = O.eval_metrics(rgb, image, mask, H, W, out_hw=out_hw)
+    psnr, ssim, mse = ops.eval_metrics(cu(rgb), cu(image), cu(mask), H, W, out_hw=out_hw)
+    assert abs(float(mse) - float(ref["mse"])) < 2e-5 * float(ref["mse"]) + 1e-9
+    assert abs(float(ssim) - float(ref["ssim"])) < 5e-5
+
+
+@pytest.mark.parametrize("case", CASES[:5])
+def test_fuzz_mlp_forward_both_precisions(ops, case):
+    rs = np.random.RandomState(700 + case)
+    B, R, N = int(rs.randint(1, 4)), int(rs.randint(1, 40)), int(rs.choice([1, 5, 32, 64, 100]))
+    params = O.make_params(40 + case)
+    pts = T(rs.uniform(-1.5, 1.5, size=(B, R, N, 3)))
+    unit = torch.nn.functional.normalize(T(rs.normal(size=(B, R, 1, 3))), dim=-1).expand(B, R, N, 3).contiguous()
+    lt, ll = T(rs.normal(size=(B, 16))), T(rs.normal(size=(B, 48)))
+    with torch.no_grad():
+        ref = O.mlp_forward(params, pts, unit, lt, ll)
+    for prec in ("fp32", "f16x3"):
+        packed = ops.pack_weights({k: cu(v) for k, v in params.items()}, precision=prec)
+        out = ops.mlp_forward(packed, cu(lt), cu(ll), points=cu(pts), ray_unit=cu(unit), precision=prec)
+        for a, r in zip(out, ref):
+            torch.testing.assert_close(a.cpu(), r, rtol=1e-4, atol=1e-6)
+    ops.check_mlp_status(dev())
