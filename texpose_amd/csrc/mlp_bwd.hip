@@ -337,15 +337,14 @@ extern "C" int tp_mlp_bwd(const tp_mlp_bwd_args* a, tp_stream_t stream_) {
     for (int i = 0; i < 4; ++i) { w.w[W_RGB0 + i] = a->weights.rgb_w[i]; w.w[W_TRANS0 + i] = a->weights.trans_w[i]; }
     hipLaunchKernelGGL(packT_kernel, dim3(512), dim3(256), 0, stream, w, (float*)a->packed_t);
   }
-  static bool attr_set = false;
-  if (!attr_set) {
+  static unsigned long long attr_devices = 0;
+  if (tp::first_use_on_device(attr_devices)) {
     hipError_t e = hipFuncSetAttribute((const void*)mlp_dgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        2 * kChunkFloats * (int)sizeof(float));
     if (e == hipSuccess)
       e = hipFuncSetAttribute((const void*)mlp_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                               2 * kWgBufFloats * (int)sizeof(float));
     if (e != hipSuccess) { tp::set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
-    attr_set = true;
   }
   const int cus = num_cus();
   DgParams D;

@@ -313,15 +313,14 @@ extern "C" int tp_mlp_fwd(const tp_mlp_fwd_args* a, tp_stream_t stream) {
   P.n_samples = (int64_t)a->B * a->R * a->N;
   P.n_tiles = (P.n_samples + kTileSamples - 1) / kTileSamples;
   P.rgb = a->rgb; P.density = a->density; P.uncert = a->uncert; P.saved = a->saved; P.workspace = (float*)a->workspace;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static unsigned long long attr_devices = 0;
+  if (tp::first_use_on_device(attr_devices)) {
     hipError_t e = hipFuncSetAttribute((const void*)mlp_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        kLdsFloats * (int)sizeof(float));
     if (e == hipSuccess)
       e = hipFuncSetAttribute((const void*)mlp_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               kLdsFloats * (int)sizeof(float));
     if (e != hipSuccess) { tp::set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
-    attr_set = true;
   }
   const int grid = persistent_grid(P.n_tiles);
   if (P.saved != nullptr)

@@ -555,13 +555,12 @@ int tp_launch_mlp_fwd_f16x3(const tp_mlp_fwd_args* a, int grid, hipStream_t stre
   P.n_tiles = (P.n_samples + 127) / 128;
   P.rgb = a->rgb; P.density = a->density; P.uncert = a->uncert; P.saved = a->saved; P.workspace = (float*)a->workspace;
   P.status = a->status;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static unsigned long long attr_devices = 0;
+  if (tp::first_use_on_device(attr_devices)) {
     hipError_t e = hipFuncSetAttribute((const void*)mlp_fwd_f16x3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
     if (e == hipSuccess)
       e = hipFuncSetAttribute((const void*)mlp_fwd_f16x3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
     if (e != hipSuccess) { tp::set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
-    attr_set = true;
   }
   if (P.saved != nullptr)
     hipLaunchKernelGGL(mlp_fwd_f16x3_kernel<true>, dim3(grid), dim3(kThreads), kLdsBytes, stream, P);

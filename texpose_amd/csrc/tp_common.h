@@ -9,6 +9,15 @@ namespace tp {
 
 void set_error(const char* fmt, ...);
 
+// true the first time `flags` (one bit per device, a function-local static of the caller) sees the current device:
+// per-device kernel attributes (large dynamic LDS) must be set on every GPU a process drives, not once per process
+inline bool first_use_on_device(unsigned long long& flags) {
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0 || d > 63) return true;
+  const bool first = !((flags >> d) & 1ull);
+  flags |= 1ull << d;
+  return first;
+}
 inline int check_launch(const char* what) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
