@@ -75,25 +75,62 @@ __device__ __forceinline__ long long tick() {
 #define TR_BEGIN(a) asm volatile("" ::: "memory")
 #define TR_END(k, a) asm volatile("" ::: "memory")
 #endif
-__device__ __forceinline__ void ring_begin(Pipe& p) {
-  TR_BEGIN(d);
+// The DMA of chunk c+2 is not issued as one burst at the start of chunk c (eight LDS-DMA instructions cost ~30 issue
+// cycles each while the matrix pipe drains) but spread over the chunk's MFMA groups, one or two 1 KiB pieces per
+// group, so that each issue hides under the 6 MFMAs in flight.  `Dma` = where the pieces of the chunk being
+// prefetched go; piece k: global base + k KiB -> LDS slot base + k KiB (instruction immediates for k mod 4).
+struct Dma { const char* src[2]; float* dst[2]; };
+__device__ __forceinline__ Dma ring_begin(Pipe& p) {
   int nxt = p.chunk + 2;
   if (nxt >= kNumChunks) nxt -= kNumChunks;
   int slot = p.buf + 2;
   if (slot >= kBufs) slot -= kBufs;
-  dma_chunk(p, nxt, slot);
-  TR_END(0, d);
+  const float* base = p.stream + (size_t)nxt * kChunkFloats + p.wave * 2048;
+  float* dst = p.lds + slot * kChunkFloats + p.wave * 2048;
+  const unsigned lane_off = (unsigned)p.lane * 16u;
+  Dma d;
+  d.src[0] = reinterpret_cast<const char*>(base) + lane_off;
+  d.src[1] = reinterpret_cast<const char*>(base + 1024) + lane_off;
+  d.dst[0] = dst;
+  d.dst[1] = dst + 1024;
+  return d;
 }
+template <int K>
+__device__ __forceinline__ void dma_piece(const Dma& d) {
+  __builtin_amdgcn_global_load_lds(AS1(d.src[K >> 2]), AS3(d.dst[K >> 2]), 16, (K & 3) * 1024, 0);
+}
+// pieces issued at the start of MFMA group `it` of a chunk with NG groups (8 pieces per chunk and wave); `it` is a
+// constant after unrolling, so the switch folds away
+template <int NG>
+__device__ __forceinline__ void dma_step(const Dma& d, int it) {
+  constexpr int PPI = 8 / NG;
+  static_assert(PPI * NG == 8, "8 pieces over NG groups");
+#pragma unroll
+  for (int k = 0; k < PPI; ++k)
+    switch (it * PPI + k) {
+      case 0: dma_piece<0>(d); break;
+      case 1: dma_piece<1>(d); break;
+      case 2: dma_piece<2>(d); break;
+      case 3: dma_piece<3>(d); break;
+      case 4: dma_piece<4>(d); break;
+      case 5: dma_piece<5>(d); break;
+      case 6: dma_piece<6>(d); break;
+      default: dma_piece<7>(d); break;
+    }
+}
+// YOUNG = DMA pieces of the chunk being prefetched that this chunk has issued before the publish point: they may stay
+// in flight, everything older (the next chunk, which is about to be read) has landed
+template <int YOUNG>
 __device__ __forceinline__ void ring_publish(Pipe& tr) {
 #ifdef TP_TRACE
   const long long t0 = tick();
-  asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(YOUNG) : "memory");
   const long long t1 = tick();
   __builtin_amdgcn_s_barrier();
   const long long t2 = tick();
   tr.tr[1] += t1 - t0; tr.tr[2] += t2 - t1;
 #else
-  asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(YOUNG) : "memory");
   __builtin_amdgcn_s_barrier();
 #endif
   asm volatile("" ::: "memory");
@@ -123,7 +160,8 @@ __device__ __forceinline__ void frag_prime(const Pipe& p, Frag& f) {
 // then fetch pairs q+kDepth, q+kDepth+1 (of this chunk or the next)
 template <int NP>
 __device__ __forceinline__ void frag_step(Pipe& p, Frag& f, int q, const _Float16* l, const _Float16* ln) {
-  if (q == NP - kDepth) ring_publish(p);
+  // groups 0 .. (NP - kDepth) / 2 have issued their DMA pieces by now
+  if (q == NP - kDepth) ring_publish<((NP - kDepth) / 2 + 1) * (8 / (NP / 2))>(p);
 #pragma unroll
   for (int d = 0; d < 2; ++d) {
     const int g = q + d + kDepth;
@@ -141,6 +179,7 @@ __device__ __forceinline__ void frag_step(Pipe& p, Frag& f, int q, const _Float1
 template <int KS, class BFn, class PostFn>
 __device__ __forceinline__ void mma_wide16(Pipe& p, Frag& f, f32x16 (&acc)[8], BFn b, PostFn post) {
   constexpr int NP = KS * 8;
+  const Dma dma = ring_begin(p);
   const _Float16* l = chunk_ptr16(p);
   const _Float16* ln = next_chunk_ptr16(p);
   TR_BEGIN(w);
@@ -151,6 +190,7 @@ __device__ __forceinline__ void mma_wide16(Pipe& p, Frag& f, f32x16 (&acc)[8], B
     const half8 wh1 = f.h[(q + 1) % kDepth], wl1 = f.l[(q + 1) % kDepth];
     half8 xh, xl;
     b(s, xh, xl);
+    dma_step<NP / 2>(dma, q >> 1);
     acc[t] = mfma16(wh0, xh, acc[t]);
     acc[t + 1] = mfma16(wh1, xh, acc[t + 1]);
     acc[t] = mfma16(wh0, xl, acc[t]);
@@ -219,7 +259,6 @@ __device__ __forceinline__ void part_gen16(Pipe& p, Frag& f, f32x16 (&acc)[8], c
 #pragma unroll
   for (int ts = 0; ts < 8; ++ts) {
     XBuild xb;
-    ring_begin(p);
     const auto bop = [&](int s, half8& xh, half8& xl) { xh = X.h[s]; xl = X.l[s]; };
     const auto cvt = [&](int q) { if (ts < 7) convert2(V[ts < 7 ? ts + 1 : 0], q, xb.hp[q >> 1], xb.lp[q >> 1], amax); };
     mma_wide16<2>(p, f, acc, bop, cvt);
@@ -230,7 +269,7 @@ __device__ __forceinline__ void part_gen16(Pipe& p, Frag& f, f32x16 (&acc)[8], c
 // 1..5-row output layer over relu(V): one chunk, 16 k-steps, one accumulator tile, operands converted just in time
 __device__ __forceinline__ f32x16 part_head16(Pipe& p, Frag& f, const f32x16 (&V)[8], Guard& amax) {
   f32x16 acc = {0};
-  ring_begin(p);
+  const Dma dma = ring_begin(p);
   const _Float16* l = chunk_ptr16(p);
   const _Float16* ln = next_chunk_ptr16(p);
 #pragma unroll
@@ -239,6 +278,7 @@ __device__ __forceinline__ f32x16 part_head16(Pipe& p, Frag& f, const f32x16 (&V
     const int q = ts * 2;                          // pair q = k-step 2 ts, pair q+1 = k-step 2 ts + 1
     const half8 wh0 = f.h[q % kDepth], wl0 = f.l[q % kDepth];
     const half8 wh1 = f.h[(q + 1) % kDepth], wl1 = f.l[(q + 1) % kDepth];
+    dma_step<8>(dma, ts);
     acc = mfma16(wh0, X.h[0], acc);
     acc = mfma16(wh0, X.l[0], acc);
     acc = mfma16(wl0, X.h[0], acc);
@@ -414,7 +454,6 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_f16x3_kernel(Params P) {
         TR_END(5, pe);
 #pragma unroll
         for (int qd = 0; qd < 2; ++qd) {
-          ring_begin(p);
           mma_wide16<2>(p, frag, D, [&](int s_, half8& xh, half8& xl) { staged(s_, xh, xl, qd * 2); }, [](int) {});
         }
       } else if (EVEN && li == T0) {
@@ -422,7 +461,6 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_f16x3_kernel(Params P) {
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) stage(st, tid, 0, jj, P.lat_trans[b * 16 + 8 * hh + jj]);
         TR_END(13, t0s);
-        ring_begin(p);
         mma_wide16<1>(p, frag, D, [&](int s_, half8& xh, half8& xl) { staged(s_, xh, xl, 0); }, [](int) {});
       } else if (!EVEN && li == R0) {
         // [ray_unit | PE(ray_unit) | x | light] in natural column order, 78 of 80 slots
@@ -471,7 +509,6 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_f16x3_kernel(Params P) {
         TR_END(6, r0s);
 #pragma unroll
         for (int qd = 0; qd < 3; ++qd) {
-          ring_begin(p);
           if (qd < 2) mma_wide16<2>(p, frag, D, [&](int s_, half8& xh, half8& xl) { staged(s_, xh, xl, qd * 2); }, [](int) {});
           else mma_wide16<1>(p, frag, D, [&](int s_, half8& xh, half8& xl) { staged(s_, xh, xl, 4); }, [](int) {});
         }
