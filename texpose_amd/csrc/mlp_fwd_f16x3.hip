@@ -47,8 +47,9 @@ __device__ __forceinline__ f32x16 mfma16(half8 a, half8 b, f32x16 c) {
 
 // Three-slot ring instead of the fp32 kernel's double buffer: a chunk is only 48 MFMAs (1536 cycles, ~0.65 us)
 // here, shorter than an L2->LDS DMA round trip, so the prefetch runs TWO chunks ahead.  The DMA of chunk c+2 stays
-// in flight across the barrier: counted `s_waitcnt vmcnt(8)` (the 8 DMA instructions of the newest chunk may be
-// outstanding, everything older -- chunk c+1 -- has landed) + raw s_barrier; __syncthreads() would drain vmcnt(0).
+// in flight across the barrier: counted `s_waitcnt vmcnt(n)` (the n DMA instructions of the newest chunk issued so
+// far may be outstanding, everything older -- chunk c+1 -- has landed) + raw s_barrier; __syncthreads() would drain
+// vmcnt(0).
 //
 // The A-fragment fetch (LDS -> VGPR, kDepth pairs ahead of the MFMAs that use them) is ONE continuous pipeline
 // across chunks: the barrier that publishes chunk c+1 sits kDepth pairs before the END of chunk c, and the last
