@@ -337,6 +337,34 @@ def test_mlp_backward_vs_oracle_autograd(ops, B, R, N, train_precision):
             assert torch.equal(p.grad, g2[k]), k
 
 
+def test_mlp_backward_more_than_32_images(ops):
+    """B = 40 images in one training forward: the backward runs per group of 32 images and autograd sums the head
+    gradients; compare with the oracle."""
+    B, R, N = 40, 3, 4
+    rs = np.random.RandomState(12)
+    params = O.make_params(22)
+    g, opt = _graph(params, N=N)
+    pts = torch.from_numpy(rs.uniform(-1.2, 1.2, size=(B, R, N, 3)).astype(np.float32))
+    unit = torch.nn.functional.normalize(torch.from_numpy(rs.normal(size=(B, R, 1, 3)).astype(np.float32)),
+                                         dim=-1).expand(B, R, N, 3).contiguous()
+    lt = torch.from_numpy(rs.normal(size=(B, 16)).astype(np.float32))
+    ll = torch.from_numpy(rs.normal(size=(B, 48)).astype(np.float32))
+    cots = [torch.from_numpy(rs.normal(size=s).astype(np.float32)) for s in ((B, R, N, 3, 2), (B, R, N, 2), (B, R, N, 1))]
+    po = {k: v.clone().requires_grad_(not k.startswith("mlp_feat")) for k, v in params.items()}
+    lto, llo = lt.clone().requires_grad_(), ll.clone().requires_grad_()
+    out = O.mlp_forward(po, pts, unit, lto, llo)
+    sum((o * c).sum() for o, c in zip(out, cots)).backward()
+    ltd, lld = cu(lt).requires_grad_(), cu(ll).requires_grad_()
+    outd = g.nerf.forward(opt, cu(pts), ray_unit=cu(unit), latent_variable_trans=ltd, latent_variable_light=lld, mode="train")
+    sum((o * cu(c)).sum() for o, c in zip(outd, cots)).backward()
+    for o, r in zip(outd, out):
+        torch.testing.assert_close(o.detach().cpu(), r.detach(), rtol=1e-4, atol=1e-6)
+    for k, p in g.nerf.named_parameters():
+        if p.grad is not None:
+            assert rel_l2(p.grad, po[k].grad) < 5e-3, (k, rel_l2(p.grad, po[k].grad))
+    assert rel_l2(ltd.grad, lto.grad) < 5e-3 and rel_l2(lld.grad, llo.grad) < 5e-3
+
+
 def test_render_train_end_to_end_g9(ops):
     """Graph.render(mode='train') forward + backward against the golden captured from the reference."""
     g9 = load_golden("g9_render_train")

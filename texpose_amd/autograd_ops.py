@@ -57,9 +57,23 @@ class _Mlp(torch.autograd.Function):
         return (None, None, grads["lat_trans"], grads["lat_light"], None, None, None, None, None) + tuple(grads["params"])
 
 
+MAX_IMAGES_PER_BACKWARD = 32     # tp_mlp_bwd: the one-hot "image id" tile of the weight-gradient GEMM has 32 columns
+
+
 def mlp(nerf, lat_trans, lat_light, center=None, ray=None, depth=None, points=None, ray_unit=None):
     head_params = [p for _, p in nerf.head_parameters()]
     # decided here: inside Function.forward grad mode is always off and needs_input_grad ignores no_grad()
     need_grad = torch.is_grad_enabled() and (lat_trans.requires_grad or lat_light.requires_grad
                                              or any(p.requires_grad for p in head_params))
+    B = lat_trans.shape[0]
+    if need_grad and B > MAX_IMAGES_PER_BACKWARD:
+        # more images than one backward call takes: run the recording forward / backward per group of 32 images (autograd
+        # sums the head gradients of the groups)
+        outs = []
+        for b0 in range(0, B, MAX_IMAGES_PER_BACKWARD):
+            sl = slice(b0, min(B, b0 + MAX_IMAGES_PER_BACKWARD))
+            part = lambda t: None if t is None else t[sl]
+            outs.append(_Mlp.apply(nerf, True, lat_trans[sl], lat_light[sl], part(center), part(ray), part(depth),
+                                   part(points), part(ray_unit), *head_params))
+        return tuple(torch.cat(o, dim=0) for o in zip(*outs))
     return _Mlp.apply(nerf, need_grad, lat_trans, lat_light, center, ray, depth, points, ray_unit, *head_params)
