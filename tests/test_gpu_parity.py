@@ -529,6 +529,36 @@ def test_mlp_f16x3_matches_oracle(ops):
         torch.testing.assert_close(a.cpu(), r, rtol=1e-4, atol=1e-6)
 
 
+def test_both_mlp_kernels_are_fp32_grade_vs_fp64(ops, monkeypatch):
+    """What "f32 carried as 2 x f16" means in numbers: against an fp64 evaluation of the same network (same fp32-rounded
+    encoding arguments, as the reference computes them) the f16x3 kernel and the exact-fp32 kernel must both be as
+    accurate as torch's own fp32 forward -- within 2x of its error, which is ~3e-7 rel-L2."""
+    B, R, N = 2, 64, 64
+    rs = np.random.RandomState(77)
+    params = O.make_params(23)
+    pts = torch.from_numpy(rs.uniform(-1.2, 1.2, size=(B, R, N, 3)).astype(np.float32))
+    unit = torch.nn.functional.normalize(torch.from_numpy(rs.normal(size=(B, R, 1, 3)).astype(np.float32)),
+                                         dim=-1).expand(B, R, N, 3).contiguous()
+    lt = torch.from_numpy(rs.normal(size=(B, 16)).astype(np.float32))
+    ll = torch.from_numpy(rs.normal(size=(B, 48)).astype(np.float32))
+    with torch.no_grad():
+        o32 = O.mlp_forward(params, pts, unit, lt, ll)
+
+        def posenc64(x, L):
+            freq = (2 ** torch.arange(L, dtype=torch.float32)) * np.pi
+            spec = (x.float()[..., None] * freq).double()             # the fp32-rounded argument, evaluated in fp64
+            return torch.stack([spec.sin(), spec.cos()], dim=-2).reshape(*x.shape[:-1], -1)
+        monkeypatch.setattr(O, "posenc", posenc64)
+        o64 = O.mlp_forward({k: v.double() for k, v in params.items()}, pts.double(), unit.double(), lt.double(), ll.double())
+    for prec in ("fp32", "f16x3"):
+        packed = ops.pack_weights({k: cu(v) for k, v in params.items()}, precision=prec)
+        out = ops.mlp_forward(packed, cu(lt), cu(ll), points=cu(pts), ray_unit=cu(unit), precision=prec)
+        for a, t32, t64, name in zip(out, o32, o64, ("rgb", "density", "uncert")):
+            e_hip, e_torch = rel_l2(a, t64), rel_l2(t32, t64)
+            assert e_torch < 2e-6 and e_hip < 2 * e_torch + 1e-7, (prec, name, e_hip, e_torch)
+    ops.check_mlp_status(dev())
+
+
 def test_mlp_f16x3_range_flag(ops):
     params = O.make_params(31)
     big = {k: (v * 300.0 if k in ("mlp_feat.2.weight", "mlp_feat.3.weight") else v) for k, v in params.items()}
