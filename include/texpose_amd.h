@@ -254,6 +254,24 @@ int64_t tp_sn_work_floats(int rows, int cols);
 int tp_sn_fwd(const tp_sn_weight* weights, int n, int training, tp_stream_t stream);
 int tp_sn_bwd(const tp_sn_weight* weights, int n, tp_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * K8  render-consuming loss terms of the generator step (render, uncert, trans_reg) and their gradients
+ * ref: model/nerf_adapt_st_gan.py:712-776 (compute_loss, train_step == 'nerf', nerf.mask_obj)
+ * ------------------------------------------------------------------------------------------ */
+#define TP_NERF_LOSSES_MAX_BLOCKS 1024
+typedef struct tp_nerf_losses_args {
+  const float* rgb;        /* [B,P,3]   composite output */
+  const float* uncert;     /* [B,P]     composite output (>= min_uncert) */
+  const float* density;    /* [B,P,N,2] MLP output; [...,1] = sigma_transient */
+  const float* gathered;   /* [B,14,P]  tp_patch_gather output: image = channels 0..2, object mask = channel 12 */
+  int B, P, N;
+  void* workspace;         /* 4 * TP_NERF_LOSSES_MAX_BLOCKS floats */
+  double* sums;            /* [4]: sum m*se/u^2, sum m, sum log u^2, sum sigma_t  (fwd: out, bwd: in) */
+} tp_nerf_losses_args;
+int tp_nerf_losses_fwd(const tp_nerf_losses_args* args, tp_stream_t stream);
+int tp_nerf_losses_bwd(const tp_nerf_losses_args* args, const float* g_losses /* [3] device */, float* g_rgb,
+                       float* g_uncert, float* g_density, tp_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -183,3 +183,28 @@ def test_fuzz_mlp_forward_both_precisions(ops, case):
         for a, r in zip(out, ref):
             torch.testing.assert_close(a.cpu(), r, rtol=1e-4, atol=1e-6)
     ops.check_mlp_status(dev())
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_fuzz_nerf_losses_fwd_bwd(ops, case):
+    """K8 (render / uncert / trans_reg terms + gradients) against torch autograd through the oracle's nerf_losses."""
+    from texpose_amd import autograd_ops
+    rs = np.random.RandomState(800 + case)
+    B, p, N = int(rs.randint(1, 5)), int(rs.choice([1, 3, 16, 20])), int(rs.choice([1, 8, 64, 100]))
+    P = p * p
+    gathered = T(rs.uniform(size=(B, 14, p, p)))
+    gathered[:, 12] = T((rs.uniform(size=(B, p, p)) > 0.4).astype(np.float32))
+    rgb, unc = T(rs.uniform(size=(B, P, 3))), T(rs.uniform(0.05, 1.5, size=(B, P, 1)))
+    den = T(rs.gamma(1.0, 1.0, size=(B, P, N, 2)))
+    leaves = [t.clone().requires_grad_() for t in (rgb, unc, den)]
+    L = O.nerf_losses(leaves[0], leaves[1], leaves[2], dict(image=gathered[:, 0:3], mask=gathered[:, 12:13]))
+    w = T(rs.uniform(0.5, 2.0, size=(3,)))
+    (w[0] * L["render"] + w[1] * L["uncert"] + w[2] * L["trans_reg"]).backward()
+    dl = [cu(t).requires_grad_() for t in (rgb, unc, den)]
+    out = autograd_ops.nerf_losses(dl[0], dl[1], dl[2], cu(gathered))
+    for a, k in zip(out, ("render", "uncert", "trans_reg")):
+        assert abs(float(a) - float(L[k])) <= 2e-5 * abs(float(L[k])) + 1e-6, (k, float(a), float(L[k]))
+    wd = cu(w)
+    (wd[0] * out[0] + wd[1] * out[1] + wd[2] * out[2]).backward()
+    for a, r in zip(dl, leaves):
+        assert rel_l2(a.grad, r.grad) < 2e-5

@@ -24,6 +24,7 @@ SYMBOLS = (
     "tp_patch_gather",
     "tp_eval_metrics_workspace_bytes", "tp_eval_metrics",
     "tp_sn_work_floats", "tp_sn_fwd", "tp_sn_bwd",
+    "tp_nerf_losses_fwd", "tp_nerf_losses_bwd",
 )
 
 vp = C.c_void_p
@@ -90,6 +91,14 @@ class SnWeight(C.Structure):
 SN_MAX_WEIGHTS = 8
 
 
+class NerfLossesArgs(C.Structure):
+    _fields_ = [("rgb", vp), ("uncert", vp), ("density", vp), ("gathered", vp), ("B", C.c_int), ("P", C.c_int),
+                ("N", C.c_int), ("workspace", vp), ("sums", vp)]
+
+
+NERF_LOSSES_MAX_BLOCKS = 1024
+
+
 class TexposeLibraryError(RuntimeError):
     pass
 
@@ -139,6 +148,8 @@ def load() -> C.CDLL:
     sig("tp_sn_work_floats", [C.c_int, C.c_int], C.c_int64)
     sig("tp_sn_fwd", [C.POINTER(SnWeight), C.c_int, C.c_int, vp])
     sig("tp_sn_bwd", [C.POINTER(SnWeight), C.c_int, vp])
+    sig("tp_nerf_losses_fwd", [C.POINTER(NerfLossesArgs), vp])
+    sig("tp_nerf_losses_bwd", [C.POINTER(NerfLossesArgs), vp, vp, vp, vp, vp])
     _lib = lib
     return lib
 

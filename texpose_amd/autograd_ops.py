@@ -77,3 +77,31 @@ def mlp(nerf, lat_trans, lat_light, center=None, ray=None, depth=None, points=No
                                    part(points), part(ray_unit), *head_params))
         return tuple(torch.cat(o, dim=0) for o in zip(*outs))
     return _Mlp.apply(nerf, need_grad, lat_trans, lat_light, center, ray, depth, points, ray_unit, *head_params)
+
+
+class _NerfLosses(torch.autograd.Function):
+    """(render, uncert, trans_reg) of the generator step from the render outputs and the gathered patches: one forward
+    and one backward launch instead of ~60 elementwise / reduction kernels (reference compute_loss :747-760)."""
+
+    @staticmethod
+    def forward(ctx, rgb, uncert, density, gathered):
+        sums = ops.nerf_losses_fwd(rgb, uncert, density, gathered)
+        B, P, N = rgb.shape[0], rgb.shape[1], density.shape[2]
+        ctx.save_for_backward(rgb, uncert, density, gathered, sums)
+        s = sums.float()
+        render = s[0] / (s[1] + 1e-5)
+        unc = 5 + s[2] / (B * P) / 2
+        trans = s[3] / (B * P * N)
+        return render, unc, trans
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_render, g_unc, g_trans):
+        rgb, uncert, density, gathered, sums = ctx.saved_tensors
+        g = torch.stack([g_render, g_unc, g_trans]).float()
+        g_rgb, g_u, g_d = ops.nerf_losses_bwd(rgb, uncert, density, gathered, sums, g)
+        return g_rgb, g_u.view_as(uncert), g_d, None
+
+
+def nerf_losses(rgb, uncert, density, gathered):
+    return _NerfLosses.apply(rgb, uncert, density, gathered)

@@ -1,0 +1,117 @@
+// K8: the three render-consuming loss terms of the generator step in one launch each way:
+//   render    = sum mask (image - rgb)^2 / uncert^2 / (sum mask + 1e-5)        (nerf.mask_obj, :747-752)
+//   uncert    = 5 + mean(log uncert^2) / 2                                      (:757-758)
+//   trans_reg = mean sigma_transient                                            (:759-760)
+// reference model/nerf_adapt_st_gan.py:712-776 (compute_loss, train_step == 'nerf').  PyTorch issues ~30 elementwise /
+// reduction kernels for the forward and as many for the backward; here: one pass producing four sums (fixed-order
+// two-stage reduction: deterministic), and one pass producing d/d rgb, d/d uncert, d/d density.
+// Inputs are read where the render and the patch gather left them: rgb [B,P,3] / uncert [B,P] / density [B,P,N,2]
+// from the composite / MLP outputs, image and mask as channels 0..2 and 12 of the gather output [B,14,P].
+#include "tp_common.h"
+
+namespace {
+constexpr int kBlock = 256;
+
+__device__ __forceinline__ void block_reduce4(float (&v)[4], float* red) {   // red: [4][kBlock]
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) red[k * kBlock + tid] = v[k];
+  __syncthreads();
+  for (int s = kBlock >> 1; s > 0; s >>= 1) {
+    if (tid < s) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) red[k * kBlock + tid] += red[k * kBlock + tid + s];
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) v[k] = red[k * kBlock];
+}
+
+__global__ __launch_bounds__(kBlock) void nerf_losses_fwd_kernel(tp_nerf_losses_args a, float* partial) {
+  __shared__ float red[4 * kBlock];
+  const int64_t n_pix = (int64_t)a.B * a.P, n_den = n_pix * a.N;
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x; q < n_pix; q += (int64_t)gridDim.x * kBlock) {
+    const int64_t b = q / a.P, p = q - b * a.P;
+    const float* gp = a.gathered + b * 14 * a.P + p;
+    const float m = gp[12 * (int64_t)a.P], u = a.uncert[q];
+    float se = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float d = gp[c * (int64_t)a.P] - a.rgb[q * 3 + c];
+      se += d * d;
+    }
+    v[0] += m * (se / (u * u));
+    v[1] += m;
+    v[2] += logf(u * u);
+  }
+  const float2* den = reinterpret_cast<const float2*>(a.density);
+  for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < n_den; e += (int64_t)gridDim.x * kBlock) v[3] += den[e].y;
+  block_reduce4(v, red);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) partial[blockIdx.x * 4 + k] = v[k];
+  }
+}
+
+__global__ void nerf_losses_finalize(const float* partial, int n_blocks, double* sums) {
+  if (threadIdx.x < 4) {
+    double s = 0.0;
+    for (int i = 0; i < n_blocks; ++i) s += partial[i * 4 + threadIdx.x];
+    sums[threadIdx.x] = s;
+  }
+}
+
+// g[0..2]: upstream gradients of (render, uncert, trans_reg)
+__global__ __launch_bounds__(kBlock) void nerf_losses_bwd_kernel(tp_nerf_losses_args a, const double* sums, const float* g,
+                                                                 float* g_rgb, float* g_uncert, float* g_density) {
+  const int64_t n_pix = (int64_t)a.B * a.P, n_den = n_pix * a.N;
+  const float inv_den = (float)(1.0 / (sums[1] + 1e-5));
+  const float gr = g[0] * inv_den, gu = g[1] / (float)n_pix, gt = g[2] / (float)n_den;
+  for (int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x; q < n_pix; q += (int64_t)gridDim.x * kBlock) {
+    const int64_t b = q / a.P, p = q - b * a.P;
+    const float* gp = a.gathered + b * 14 * a.P + p;
+    const float m = gp[12 * (int64_t)a.P], u = a.uncert[q];
+    const float iu2 = 1.0f / (u * u);
+    float se = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float d = a.rgb[q * 3 + c] - gp[c * (int64_t)a.P];
+      se += d * d;
+      g_rgb[q * 3 + c] = gr * 2.0f * m * d * iu2;
+    }
+    g_uncert[q] = -2.0f * gr * m * se * iu2 / u + gu / u;
+  }
+  float2* gd = reinterpret_cast<float2*>(g_density);
+  for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < n_den; e += (int64_t)gridDim.x * kBlock) gd[e] = make_float2(0.0f, gt);
+}
+
+int grid_for(const tp_nerf_losses_args* a) {
+  const int64_t n = (int64_t)a->B * a->P * a->N;
+  const int64_t g = (n + kBlock - 1) / kBlock;
+  return (int)(g < 1 ? 1 : (g > TP_NERF_LOSSES_MAX_BLOCKS ? TP_NERF_LOSSES_MAX_BLOCKS : g));
+}
+int check(const tp_nerf_losses_args* a, const char* what) {
+  if (!a || !a->rgb || !a->uncert || !a->density || !a->gathered || !a->workspace || !a->sums) { tp::set_error("%s: null pointer", what); return -1; }
+  if (a->B <= 0 || a->P <= 0 || a->N <= 0) { tp::set_error("%s: bad sizes", what); return -1; }
+  return 0;
+}
+}  // namespace
+
+extern "C" int tp_nerf_losses_fwd(const tp_nerf_losses_args* a, tp_stream_t stream) {
+  if (int rc = check(a, "tp_nerf_losses_fwd")) return rc;
+  const int g = grid_for(a);
+  hipLaunchKernelGGL(nerf_losses_fwd_kernel, dim3(g), dim3(kBlock), 0, (hipStream_t)stream, *a, (float*)a->workspace);
+  hipLaunchKernelGGL(nerf_losses_finalize, dim3(1), dim3(64), 0, (hipStream_t)stream, (const float*)a->workspace, g, a->sums);
+  return tp::check_launch("tp_nerf_losses_fwd");
+}
+
+extern "C" int tp_nerf_losses_bwd(const tp_nerf_losses_args* a, const float* g_losses, float* g_rgb, float* g_uncert,
+                                  float* g_density, tp_stream_t stream) {
+  if (int rc = check(a, "tp_nerf_losses_bwd")) return rc;
+  if (!g_losses || !g_rgb || !g_uncert || !g_density) { tp::set_error("tp_nerf_losses_bwd: null gradient pointer"); return -1; }
+  hipLaunchKernelGGL(nerf_losses_bwd_kernel, dim3(grid_for(a)), dim3(kBlock), 0, (hipStream_t)stream, *a, (const double*)a->sums,
+                     g_losses, g_rgb, g_uncert, g_density);
+  return tp::check_launch("tp_nerf_losses_bwd");
+}

@@ -20,7 +20,7 @@ import itertools
 import torch
 import torch.nn.functional as torch_F
 
-from . import ops
+from . import autograd_ops, ops
 from .geometry import FlexPatchSampler, RaySampler, rotation_distance
 from .nerf import NeRF
 from .options import AttrDict as edict
@@ -180,6 +180,7 @@ class Graph(torch.nn.Module):
         g = ops.patch_gather(var.ray_idx, var.image, var.get("image_syn", var.image),
                              var.get("nocs_pred", var.image), var.get("normal_pred", var.image),
                              var.obj_mask.view(B, opt.H, opt.W), var.get("mask_syn", var.obj_mask).view(B, opt.H, opt.W))
+        var.gathered = g
         var.image_sample, var.image_syn_sample = g[:, 0:3], g[:, 3:6]
         var.nocs_sample, var.normal_sample = g[:, 6:9], g[:, 9:12]
         var.mask_sample, var.mask_syn_sample = g[:, 12:13], g[:, 13:14]
@@ -275,16 +276,22 @@ class Graph(torch.nn.Module):
                                                                                             mask_syn)
         lw = opt.loss_weight
         if train_step == "nerf":
-            if lw.render is not None:
+            # default configuration: the three render-consuming terms and their gradients in one launch each way (K8)
+            fused = ("gathered" in var and opt.nerf.mask_obj and lw.render is not None and lw.uncert is not None
+                     and lw.trans_reg is not None and lw.mask is None and var.rgb.is_cuda)
+            if fused:
+                loss.render, loss.uncert, loss.trans_reg = autograd_ops.nerf_losses(var.rgb, var.uncert, var.density,
+                                                                                     var.gathered)
+            if not fused and lw.render is not None:
                 if opt.nerf.mask_obj:
                     loss.render = (obj_mask * ((image - rgb) ** 2 / uncert ** 2)).sum() / (obj_mask.sum() + 1e-5)
                 else:
                     loss.render = self.MSE_loss(rgb, image)
             if lw.mask is not None:
                 loss.mask = self.MSE_loss(obj_mask, var.opacity[..., None])
-            if lw.uncert is not None:
+            if not fused and lw.uncert is not None:
                 loss.uncert = 5 + torch.log(var.uncert ** 2).mean() / 2
-            if lw.trans_reg is not None:
+            if not fused and lw.trans_reg is not None:
                 loss.trans_reg = var.density[..., -1].mean()
             if lw.feat is not None:
                 if not hasattr(self, "perceptual_loss"):

@@ -433,3 +433,40 @@ def spectral_norm_bwd(grads_sn, weights_sn, us, vs, sigmas):
         outs.append(o); keep += [g, wk]
     check(lib.tp_sn_bwd(arr, n, _stream()), "tp_sn_bwd")
     return outs
+
+
+def _nerf_losses_args(rgb, uncert, density, gathered):
+    lib = _lib.load()
+    rgb, uncert, density, gathered = (_f32(rgb, "rgb"), _f32(uncert, "uncert"), _f32(density, "density"),
+                                      _f32(gathered, "gathered"))
+    B, P = rgb.shape[0], rgb.shape[1]
+    N = density.shape[2]
+    if rgb.shape != (B, P, 3) or uncert.numel() != B * P or density.shape != (B, P, N, 2) or gathered.numel() != B * 14 * P:
+        raise ValueError("nerf_losses: rgb [B,P,3], uncert [B,P,1], density [B,P,N,2], gathered [B,14,p,p] expected")
+    a = _lib.NerfLossesArgs()
+    a.rgb, a.uncert, a.density, a.gathered = rgb.data_ptr(), uncert.data_ptr(), density.data_ptr(), gathered.data_ptr()
+    a.B, a.P, a.N = B, P, N
+    return lib, a, (rgb, uncert, density, gathered)
+
+
+def nerf_losses_fwd(rgb: Tensor, uncert: Tensor, density: Tensor, gathered: Tensor):
+    """Four fp64 sums [sum m*se/u^2, sum m, sum log u^2, sum sigma_t] (device tensor) for the render / uncert /
+    trans_reg terms of the generator step (reference compute_loss :747-760)."""
+    lib, a, keep = _nerf_losses_args(rgb, uncert, density, gathered)
+    ws = torch.empty(4 * _lib.NERF_LOSSES_MAX_BLOCKS, device=rgb.device)
+    sums = torch.empty(4, dtype=torch.float64, device=rgb.device)
+    a.workspace, a.sums = ws.data_ptr(), sums.data_ptr()
+    check(lib.tp_nerf_losses_fwd(C.byref(a), _stream()), "tp_nerf_losses_fwd")
+    return sums
+
+
+def nerf_losses_bwd(rgb: Tensor, uncert: Tensor, density: Tensor, gathered: Tensor, sums: Tensor, g_losses: Tensor):
+    """Gradients wrt rgb, uncert, density for upstream gradients g_losses [3] (render, uncert, trans_reg)."""
+    lib, a, keep = _nerf_losses_args(rgb, uncert, density, gathered)
+    ws = torch.empty(4, device=rgb.device)
+    a.workspace, a.sums = ws.data_ptr(), sums.data_ptr()
+    g_losses = _f32(g_losses, "g_losses")
+    g_rgb, g_unc, g_den = torch.empty_like(keep[0]), torch.empty_like(keep[1]), torch.empty_like(keep[2])
+    check(lib.tp_nerf_losses_bwd(C.byref(a), g_losses.data_ptr(), g_rgb.data_ptr(), g_unc.data_ptr(), g_den.data_ptr(),
+                                 _stream()), "tp_nerf_losses_bwd")
+    return g_rgb, g_unc, g_den
