@@ -320,7 +320,7 @@ class Graph(torch.nn.Module):
         for d_out in d_outs:
             g = torch.autograd.grad(outputs=d_out.sum(), inputs=x_in, create_graph=True, retain_graph=True,
                                     only_inputs=True)[0]
-            reg = reg + g.pow(2).view(x_in.size(0), -1).sum(1)
+            reg = reg + g.pow(2).reshape(x_in.size(0), -1).sum(1)
         return reg / len(d_outs)
 
     @staticmethod

@@ -1,11 +1,11 @@
 """GPU box: kernel launches of ONE steady-state training iteration from a rocprofv3 --kernel-trace CSV
-(tools/launch_histogram.py <dir>): count + busy time per kernel family, using mlp_fwd_kernel<true> as the iteration
-marker."""
+(tools/launch_histogram.py <dir>): count + busy time per kernel family, using the recording MLP forward (mlp_fwd*_kernel<true>) as the
+iteration marker."""
 import collections, csv, glob, re, sys
 
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
-it = [i for i, r in enumerate(rows) if "mlp_fwd_kernel<true>" in r["Kernel_Name"]]
+it = [i for i, r in enumerate(rows) if "mlp_fwd" in r["Kernel_Name"] and "<true>" in r["Kernel_Name"]]   # recording forward
 seg = rows[it[-3]:it[-2]]
 busy = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in seg) / 1e6
 print(len(seg), "launches in one iteration; GPU busy %.3f ms; wall %.3f ms" %
