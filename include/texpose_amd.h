@@ -26,7 +26,7 @@ extern "C" {
 
 typedef void* tp_stream_t; /* hipStream_t */
 
-#define TP_ABI_VERSION 1
+#define TP_ABI_VERSION 2
 
 int tp_abi_version(void);
 const char* tp_last_error(void);
@@ -162,6 +162,9 @@ typedef struct tp_mlp_bwd_args {
   float* g_lat_trans;  /* [B,16] out */
   float* g_lat_light;  /* [B,48] out */
   void* workspace;         /* tp_mlp_bwd_workspace_bytes */
+  int wgrad_precision;     /* TP_MLP_FP32: exact fp32 MFMA; TP_MLP_F16X3: split-fp16 products for the weight-gradient GEMM
+                              (fp32-grade; requires |activation| < 6e4, i.e. a record written by a TP_MLP_F16X3 forward
+                              whose status word stayed clear) */
 } tp_mlp_bwd_args;
 int tp_mlp_bwd(const tp_mlp_bwd_args* args, tp_stream_t stream);
 

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # TEXPOSE_AMD_LIB selects another build of the SAME library (e.g. the `make trace` diagnostic build); never a fallback
 LIB_PATH = os.environ.get("TEXPOSE_AMD_LIB") or os.path.join(_HERE, "libtexpose_amd.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # Every symbol include/texpose_amd.h declares (checked by tests/test_capi_cpu.py).
 SYMBOLS = (
@@ -57,7 +57,7 @@ class MlpBwdArgs(C.Structure):
                 ("density", vp), ("uncert", vp), ("g_rgb", vp), ("g_density", vp), ("g_uncert", vp),
                 ("lat_trans", vp), ("lat_light", vp), ("B", C.c_int), ("R", C.c_int), ("N", C.c_int),
                 ("g_rgb_w", vp * 4), ("g_rgb_b", vp * 4), ("g_trans_w", vp * 4), ("g_trans_b", vp * 4),
-                ("g_lat_trans", vp), ("g_lat_light", vp), ("workspace", vp)]
+                ("g_lat_trans", vp), ("g_lat_light", vp), ("workspace", vp), ("wgrad_precision", C.c_int)]
 
 
 class CompositeArgs(C.Structure):

@@ -44,6 +44,9 @@ class _Mlp(torch.autograd.Function):
         if need_grad:
             rgb, density, uncert, saved = res
             ctx.nerf = nerf
+            # the split-fp16 weight-gradient GEMM needs activations inside the fp16 range: guaranteed (flagged) by
+            # the f16x3 recording forward only
+            ctx.wgrad_precision = precision
             ctx.save_for_backward(lat_trans, lat_light, saved, rgb, density, uncert)
         else:
             rgb, density, uncert = res
@@ -53,7 +56,7 @@ class _Mlp(torch.autograd.Function):
     def backward(ctx, g_rgb, g_density, g_uncert):
         lat_trans, lat_light, saved, rgb, density, uncert = ctx.saved_tensors
         grads = ops.mlp_backward(ctx.nerf, lat_trans, lat_light, saved, rgb, density, uncert, g_rgb, g_density,
-                                 g_uncert)
+                                 g_uncert, wgrad_precision=ctx.wgrad_precision)
         return (None, None, grads["lat_trans"], grads["lat_light"], None, None, None, None, None) + tuple(grads["params"])
 
 

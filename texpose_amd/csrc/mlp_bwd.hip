@@ -44,6 +44,7 @@ struct DgParams {
   const float* g_rgb; const float* g_density; const float* g_uncert;
   int64_t n_samples, n_tiles;
   float* dz;
+  unsigned int* dz_max;    // bits of max |dz| over the call (atomicMax; non-negative floats order like their bits)
 };
 
 __global__ __launch_bounds__(kThreads, 1) void mlp_dgrad_kernel(DgParams P) {
@@ -65,6 +66,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_dgrad_kernel(DgParams P) {
     f32x16 h[8], acc[8];
     int o16[16];
     lane_block_offsets(j, hh, o16);
+    float dzm = 0.0f;
 
 #pragma nounroll
     for (int st = 0; st < 6; ++st) {
@@ -108,9 +110,13 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_dgrad_kernel(DgParams P) {
         for (int r = 0; r < 16; ++r) {
           const bool on = (mask[t >> 1] >> ((t & 1) * 16 + r)) & 1u;
           h[t][r] = (live && on) ? acc[t][r] : 0.0f;
+          dzm = fmaxf(dzm, fabsf(h[t][r]));
         }
       store_block(dzg + st * kBlockFloats, h, o16);
     }
+    // range of the gradient record for the split-fp16 weight-gradient GEMM (one atomic per wave and tile)
+    for (int off = 32; off >= 1; off >>= 1) dzm = fmaxf(dzm, __shfl_xor(dzm, off, 64));
+    if (lane == 0 && P.dz_max != nullptr && dzm == dzm && dzm < 3.0e38f) atomicMax(P.dz_max, __float_as_uint(dzm));
   }
 }
 
@@ -119,8 +125,33 @@ constexpr int kWgItems = 14;     // 6 wide GEMMs x 2 row halves + 2 narrow (outp
 constexpr int kWgTiles = 10;     // 8 input-feature tiles + image one-hot tile + [view enc, x] tile
 constexpr int kWgBufFloats = 4096 + 8192 + 1024;
 
+using half8w = __attribute__((ext_vector_type(8))) _Float16;
+using half2w = __attribute__((ext_vector_type(2))) __fp16;
+using u32x4w = __attribute__((ext_vector_type(4))) unsigned int;
+
+// 8 fp32 values (two sample quads) * scale -> hi + lo fp16 operands: hi = value truncated to 11 significant bits
+// (exact in fp16), lo = value - hi (exact in fp32, rounded toward zero to fp16)
+__device__ __forceinline__ void split8(const f32x4& q0, const f32x4& q1, float scale, half8w& hi, half8w& lo) {
+  const float v[8] = {q0[0] * scale, q0[1] * scale, q0[2] * scale, q0[3] * scale,
+                      q1[0] * scale, q1[1] * scale, q1[2] * scale, q1[3] * scale};
+  u32x4w hw, lw;
+#pragma unroll
+  for (int e = 0; e < 8; e += 2) {
+    const float h0 = __uint_as_float(__float_as_uint(v[e]) & 0xFFFFE000u);
+    const float h1 = __uint_as_float(__float_as_uint(v[e + 1]) & 0xFFFFE000u);
+    hw[e >> 1] = __builtin_bit_cast(unsigned int, __builtin_amdgcn_cvt_pkrtz(h0, h1));
+    lw[e >> 1] = __builtin_bit_cast(unsigned int, __builtin_amdgcn_cvt_pkrtz(v[e] - h0, v[e + 1] - h1));
+  }
+  hi = __builtin_bit_cast(half8w, hw);
+  lo = __builtin_bit_cast(half8w, lw);
+}
+__device__ __forceinline__ f32x16 mfma16w(half8w a, half8w b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
 struct WgParams {
   const float* saved; const float* dz;
+  const unsigned int* dz_max;   // F16X3 only
   int64_t n_samples, n_groups, rn;   // rn = samples per image (R*N)
   int n_slices, groups_per_slice;
   float* partial;
@@ -143,6 +174,10 @@ __device__ __forceinline__ void wg_dma(const WgParams& P, int64_t g, float* buf,
                                      AS3(buf + 4096 + 8192 + wave * 256), 16, 0, 0);
 }
 
+// F16X3: the products run on the f16 matrix cores as hi*hi + hi*lo + lo*hi with both operands split on the fly (the
+// gradient record is first scaled by a power of two so that its largest entry sits at 2^13: exact, undone in the
+// epilogue); 16 samples per MFMA instead of 2, 3 instead of 8 instructions per 16 samples, fp32-grade accuracy.
+template <bool F16X3>
 __global__ __launch_bounds__(kThreads, 1) void mlp_wgrad_kernel(WgParams P) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -176,6 +211,16 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_wgrad_kernel(WgParams P) {
   const int64_t lo = (int64_t)i * P.rn;                       // sample range of image `i` (one-hot tile column)
   const int64_t hi = lo + P.rn < P.n_samples ? lo + P.rn : P.n_samples;
 
+  float dz_scale = 1.0f, out_scale = 1.0f;
+  if constexpr (F16X3) {
+    const float mx = __uint_as_float(*P.dz_max);
+    if (mx > 0.0f) {
+      int e;
+      (void)frexpf(mx, &e);                       // mx = m * 2^e, m in [0.5, 1)
+      dz_scale = ldexpf(1.0f, 14 - e);            // largest |dz| lands in [2^13, 2^14)
+      out_scale = ldexpf(1.0f, e - 14);
+    }
+  }
   int buf = 0;
   if (g0 < g1) wg_dma(P, g0, lds, a_off, a_pieces, b_slot, has_ex, wave, lane);
   __syncthreads();
@@ -184,6 +229,43 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_wgrad_kernel(WgParams P) {
     const float* A = lds + buf * kWgBufFloats;
     const float* Bm = A + 4096;
     const float* Ex = Bm + 8192;
+    if constexpr (F16X3) {
+#pragma unroll
+      for (int Q = 0; Q < 2; ++Q) {
+        const int sq0 = 4 * Q + 2 * hh, sq1 = sq0 + 1;            // this lane half: samples 16 Q + 8 hh .. + 7
+        const int sa = (fa >> 1) & 7;
+        half8w ah, al;
+        split8(*reinterpret_cast<const f32x4*>(A + a_row * 32 + ((sq0 ^ sa) << 2)),
+               *reinterpret_cast<const f32x4*>(A + a_row * 32 + ((sq1 ^ sa) << 2)), dz_scale, ah, al);
+#pragma unroll
+        for (int ft = 0; ft < 8; ++ft) {
+          const int f = ft * 32 + i, sb = (f >> 1) & 7;
+          half8w bh, bl;
+          split8(*reinterpret_cast<const f32x4*>(Bm + f * 32 + ((sq0 ^ sb) << 2)),
+                 *reinterpret_cast<const f32x4*>(Bm + f * 32 + ((sq1 ^ sb) << 2)), 1.0f, bh, bl);
+          acc[ft] = mfma16w(ah, bh, acc[ft]);
+          acc[ft] = mfma16w(ah, bl, acc[ft]);
+          acc[ft] = mfma16w(al, bh, acc[ft]);
+        }
+        half8w oh;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+          const int64_t smp = g * 32 + 16 * Q + 8 * hh + m;
+          oh[m] = (smp >= lo && smp < hi) ? (_Float16)1.0f : (_Float16)0.0f;
+        }
+        acc[8] = mfma16w(ah, oh, acc[8]);
+        acc[8] = mfma16w(al, oh, acc[8]);
+        if (has_ex) {
+          const int se = (i >> 1) & 7;
+          half8w eh, el;
+          split8(*reinterpret_cast<const f32x4*>(Ex + i * 32 + ((sq0 ^ se) << 2)),
+                 *reinterpret_cast<const f32x4*>(Ex + i * 32 + ((sq1 ^ se) << 2)), 1.0f, eh, el);
+          acc[9] = mfma16w(ah, eh, acc[9]);
+          acc[9] = mfma16w(ah, el, acc[9]);
+          acc[9] = mfma16w(al, eh, acc[9]);
+        }
+      }
+    } else {
     const int64_t sbase = g * 32 + 4 * hh;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -207,6 +289,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_wgrad_kernel(WgParams P) {
         if (has_ex) acc[9] = mfma(a4[m], e4[m], acc[9]);
       }
     }
+    }
     __syncthreads();
     buf ^= 1;
   }
@@ -214,7 +297,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_wgrad_kernel(WgParams P) {
 #pragma unroll
   for (int t = 0; t < kWgTiles; ++t)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) out[(t * 16 + r) * 64 + lane] = acc[t][r];
+    for (int r = 0; r < 16; ++r) out[(t * 16 + r) * 64 + lane] = acc[t][r] * out_scale;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -313,7 +396,7 @@ extern "C" size_t tp_mlp_bwd_workspace_bytes(int64_t n_samples) {
   const int64_t ng = n_groups_of(n_samples);
   // dz record + split-K partials (sized for the largest slice count any device could ask for: 64)
   return align256((size_t)ng * kDzGroupFloats * sizeof(float)) +
-         align256((size_t)kWgItems * 64 * 4 * kWgTiles * 1024 * sizeof(float)) + align256(2 * 32 * 256 * sizeof(float));
+         align256((size_t)kWgItems * 64 * 4 * kWgTiles * 1024 * sizeof(float)) + align256(2 * 32 * 256 * sizeof(float)) + 256;
 }
 
 extern "C" int tp_mlp_bwd(const tp_mlp_bwd_args* a, tp_stream_t stream_) {
@@ -324,12 +407,14 @@ extern "C" int tp_mlp_bwd(const tp_mlp_bwd_args* a, tp_stream_t stream_) {
     TP_REQUIRE(a->weights.rgb_w[i] && a->weights.trans_w[i] && a->g_rgb_w[i] && a->g_rgb_b[i] && a->g_trans_w[i] &&
                    a->g_trans_b[i], "null weight / gradient pointer");
   TP_REQUIRE(a->g_lat_trans && a->g_lat_light, "null latent gradient pointer");
+  TP_REQUIRE(a->wgrad_precision == TP_MLP_FP32 || a->wgrad_precision == TP_MLP_F16X3, "unknown wgrad_precision");
   hipStream_t stream = (hipStream_t)stream_;
   const int64_t S = (int64_t)a->B * a->R * a->N;
   const int64_t n_tiles = (S + 127) / 128, ng = n_tiles * 4;
   float* dz = (float*)a->workspace;
   float* partial = (float*)((char*)a->workspace + align256((size_t)ng * kDzGroupFloats * sizeof(float)));
   float* dzsum = (float*)((char*)partial + align256((size_t)kWgItems * 64 * 4 * kWgTiles * 1024 * sizeof(float)));
+  unsigned int* dz_max = (unsigned int*)((char*)dzsum + align256(2 * 32 * 256 * sizeof(float)));
 
   if (a->repack) {
     WPtrs w;
@@ -342,7 +427,10 @@ extern "C" int tp_mlp_bwd(const tp_mlp_bwd_args* a, tp_stream_t stream_) {
     hipError_t e = hipFuncSetAttribute((const void*)mlp_dgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        2 * kChunkFloats * (int)sizeof(float));
     if (e == hipSuccess)
-      e = hipFuncSetAttribute((const void*)mlp_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+      e = hipFuncSetAttribute((const void*)mlp_wgrad_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              2 * kWgBufFloats * (int)sizeof(float));
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void*)mlp_wgrad_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               2 * kWgBufFloats * (int)sizeof(float));
     if (e != hipSuccess) { tp::set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
   }
@@ -351,6 +439,12 @@ extern "C" int tp_mlp_bwd(const tp_mlp_bwd_args* a, tp_stream_t stream_) {
   D.packed_t = (const float*)a->packed_t; D.saved = a->saved; D.rgb = a->rgb; D.density = a->density;
   D.uncert = a->uncert; D.g_rgb = a->g_rgb; D.g_density = a->g_density; D.g_uncert = a->g_uncert;
   D.n_samples = S; D.n_tiles = n_tiles; D.dz = dz;
+  const bool f16 = a->wgrad_precision == TP_MLP_F16X3;
+  D.dz_max = f16 ? dz_max : nullptr;
+  if (f16) {
+    hipError_t e = hipMemsetAsync(dz_max, 0, sizeof(unsigned int), stream);
+    if (e != hipSuccess) { tp::set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return (int)e; }
+  }
   hipLaunchKernelGGL(mlp_dgrad_kernel, dim3((unsigned)(n_tiles < cus ? n_tiles : cus)), dim3(kThreads),
                      2 * kChunkFloats * sizeof(float), stream, D);
 
@@ -359,8 +453,13 @@ extern "C" int tp_mlp_bwd(const tp_mlp_bwd_args* a, tp_stream_t stream_) {
   Wg.n_slices = slices_for(ng);
   Wg.groups_per_slice = (int)((ng + Wg.n_slices - 1) / Wg.n_slices);
   Wg.partial = partial;
-  hipLaunchKernelGGL(mlp_wgrad_kernel, dim3(kWgItems * Wg.n_slices), dim3(kThreads), 2 * kWgBufFloats * sizeof(float),
-                     stream, Wg);
+  Wg.dz_max = dz_max;
+  if (f16)
+    hipLaunchKernelGGL(mlp_wgrad_kernel<true>, dim3(kWgItems * Wg.n_slices), dim3(kThreads), 2 * kWgBufFloats * sizeof(float),
+                       stream, Wg);
+  else
+    hipLaunchKernelGGL(mlp_wgrad_kernel<false>, dim3(kWgItems * Wg.n_slices), dim3(kThreads), 2 * kWgBufFloats * sizeof(float),
+                       stream, Wg);
 
   FinParams F;
   int n = 0; int64_t off = 0;

@@ -255,9 +255,11 @@ _bwd_scratch: Dict[Tuple[int, int], Dict[str, Tensor]] = {}
 
 
 def mlp_backward(nerf, lat_trans: Tensor, lat_light: Tensor, saved: Tensor, rgb: Tensor, density: Tensor,
-                 uncert: Tensor, g_rgb: Optional[Tensor], g_density: Optional[Tensor], g_uncert: Optional[Tensor]):
+                 uncert: Tensor, g_rgb: Optional[Tensor], g_density: Optional[Tensor], g_uncert: Optional[Tensor],
+                 wgrad_precision: str = "fp32"):
     """Gradients of the two heads and the latent rows.  Returns dict(params=[...] in the order of
-    ``nerf.head_parameters()``, lat_trans=[B,16], lat_light=[B,48])."""
+    ``nerf.head_parameters()``, lat_trans=[B,16], lat_light=[B,48]).  ``wgrad_precision='f16x3'`` runs the
+    weight-gradient GEMM as split-fp16 products (fp32-grade); only for records of a range-checked f16x3 forward."""
     lib = _lib.load()
     B, R, N = rgb.shape[0], rgb.shape[1], rgb.shape[2]
     if B > 32:
@@ -296,6 +298,7 @@ def mlp_backward(nerf, lat_trans: Tensor, lat_light: Tensor, saved: Tensor, rgb:
     a.lat_trans, a.lat_light = lat_trans.data_ptr(), lat_light.data_ptr()
     a.B, a.R, a.N = B, R, N
     a.g_lat_trans, a.g_lat_light, a.workspace = g_lt.data_ptr(), g_ll.data_ptr(), sc["ws"].data_ptr()
+    a.wgrad_precision = PRECISIONS[wgrad_precision]
     check(lib.tp_mlp_bwd(C.byref(a), _stream()), "tp_mlp_bwd")
     return dict(params=grads, lat_trans=g_lt, lat_light=g_ll)
 
