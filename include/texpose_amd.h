@@ -162,9 +162,10 @@ typedef struct tp_mlp_bwd_args {
   float* g_lat_trans;  /* [B,16] out */
   float* g_lat_light;  /* [B,48] out */
   void* workspace;         /* tp_mlp_bwd_workspace_bytes */
-  int wgrad_precision;     /* TP_MLP_FP32: exact fp32 MFMA; TP_MLP_F16X3: split-fp16 products for the weight-gradient GEMM
-                              (fp32-grade; requires |activation| < 6e4, i.e. a record written by a TP_MLP_F16X3 forward
-                              whose status word stayed clear) */
+  int wgrad_precision;     /* arithmetic of the backward GEMMs (dgrad and wgrad).  TP_MLP_FP32: exact fp32 MFMA;
+                              TP_MLP_F16X3: split-fp16 products with power-of-two scaling of the gradients (fp32-grade;
+                              requires |activation| < 6e4, i.e. a record written by a TP_MLP_F16X3 forward whose status
+                              word stayed clear; `packed_t` is then built in the transposed f16x3 format) */
 } tp_mlp_bwd_args;
 int tp_mlp_bwd(const tp_mlp_bwd_args* args, tp_stream_t stream);
 

@@ -390,6 +390,8 @@ size_t align256(size_t x) { return (x + 255) / 256 * 256; }
 
 }  // namespace
 
+int tp_launch_mlp_dgrad_f16x3(const tp_mlp_bwd_args* a, float* dz, unsigned int* dz_max, int grid, hipStream_t stream);  // mlp_fwd_f16x3.hip
+
 extern "C" size_t tp_mlp_packed_t_bytes(void) { return (size_t)kPackedTFloats * sizeof(float); }
 
 extern "C" size_t tp_mlp_bwd_workspace_bytes(int64_t n_samples) {
@@ -416,12 +418,7 @@ extern "C" int tp_mlp_bwd(const tp_mlp_bwd_args* a, tp_stream_t stream_) {
   float* dzsum = (float*)((char*)partial + align256((size_t)kWgItems * 64 * 4 * kWgTiles * 1024 * sizeof(float)));
   unsigned int* dz_max = (unsigned int*)((char*)dzsum + align256(2 * 32 * 256 * sizeof(float)));
 
-  if (a->repack) {
-    WPtrs w;
-    for (int i = 0; i < 16; ++i) w.w[i] = nullptr;
-    for (int i = 0; i < 4; ++i) { w.w[W_RGB0 + i] = a->weights.rgb_w[i]; w.w[W_TRANS0 + i] = a->weights.trans_w[i]; }
-    hipLaunchKernelGGL(packT_kernel, dim3(512), dim3(256), 0, stream, w, (float*)a->packed_t);
-  }
+  const bool f16 = a->wgrad_precision == TP_MLP_F16X3;
   static unsigned long long attr_devices = 0;
   if (tp::first_use_on_device(attr_devices)) {
     hipError_t e = hipFuncSetAttribute((const void*)mlp_dgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -435,18 +432,24 @@ extern "C" int tp_mlp_bwd(const tp_mlp_bwd_args* a, tp_stream_t stream_) {
     if (e != hipSuccess) { tp::set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
   }
   const int cus = num_cus();
-  DgParams D;
-  D.packed_t = (const float*)a->packed_t; D.saved = a->saved; D.rgb = a->rgb; D.density = a->density;
-  D.uncert = a->uncert; D.g_rgb = a->g_rgb; D.g_density = a->g_density; D.g_uncert = a->g_uncert;
-  D.n_samples = S; D.n_tiles = n_tiles; D.dz = dz;
-  const bool f16 = a->wgrad_precision == TP_MLP_F16X3;
-  D.dz_max = f16 ? dz_max : nullptr;
+  const int dg_grid = (int)(n_tiles < cus ? n_tiles : cus);
   if (f16) {
     hipError_t e = hipMemsetAsync(dz_max, 0, sizeof(unsigned int), stream);
     if (e != hipSuccess) { tp::set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return (int)e; }
+    if (int rc = tp_launch_mlp_dgrad_f16x3(a, dz, dz_max, dg_grid, stream)) return rc;
+  } else {
+    if (a->repack) {
+      WPtrs w;
+      for (int i = 0; i < 16; ++i) w.w[i] = nullptr;
+      for (int i = 0; i < 4; ++i) { w.w[W_RGB0 + i] = a->weights.rgb_w[i]; w.w[W_TRANS0 + i] = a->weights.trans_w[i]; }
+      hipLaunchKernelGGL(packT_kernel, dim3(512), dim3(256), 0, stream, w, (float*)a->packed_t);
+    }
+    DgParams D;
+    D.packed_t = (const float*)a->packed_t; D.saved = a->saved; D.rgb = a->rgb; D.density = a->density;
+    D.uncert = a->uncert; D.g_rgb = a->g_rgb; D.g_density = a->g_density; D.g_uncert = a->g_uncert;
+    D.n_samples = S; D.n_tiles = n_tiles; D.dz = dz; D.dz_max = nullptr;
+    hipLaunchKernelGGL(mlp_dgrad_kernel, dim3((unsigned)dg_grid), dim3(kThreads), 2 * kChunkFloats * sizeof(float), stream, D);
   }
-  hipLaunchKernelGGL(mlp_dgrad_kernel, dim3((unsigned)(n_tiles < cus ? n_tiles : cus)), dim3(kThreads),
-                     2 * kChunkFloats * sizeof(float), stream, D);
 
   WgParams Wg;
   Wg.saved = a->saved; Wg.dz = dz; Wg.n_samples = S; Wg.n_groups = ng; Wg.rn = (int64_t)a->R * a->N;

@@ -81,9 +81,10 @@ __device__ __forceinline__ long long tick() {
 // group, so that each issue hides under the 6 MFMAs in flight.  `Dma` = where the pieces of the chunk being
 // prefetched go; piece k: global base + k KiB -> LDS slot base + k KiB (instruction immediates for k mod 4).
 struct Dma { const char* src[2]; float* dst[2]; };
+template <int NCH = kNumChunks>
 __device__ __forceinline__ Dma ring_begin(Pipe& p) {
   int nxt = p.chunk + 2;
-  if (nxt >= kNumChunks) nxt -= kNumChunks;
+  if (nxt >= NCH) nxt -= NCH;
   int slot = p.buf + 2;
   if (slot >= kBufs) slot -= kBufs;
   const float* base = p.stream + (size_t)nxt * kChunkFloats + p.wave * 2048;
@@ -136,8 +137,9 @@ __device__ __forceinline__ void ring_publish(Pipe& tr) {
 #endif
   asm volatile("" ::: "memory");
 }
+template <int NCH = kNumChunks>
 __device__ __forceinline__ void ring_advance(Pipe& p) {
-  p.chunk = (p.chunk + 1 == kNumChunks) ? 0 : p.chunk + 1;
+  p.chunk = (p.chunk + 1 == NCH) ? 0 : p.chunk + 1;
   p.buf = (p.buf + 1 == kBufs) ? 0 : p.buf + 1;
 }
 __device__ __forceinline__ const _Float16* chunk_ptr16(const Pipe& p) {
@@ -177,10 +179,10 @@ __device__ __forceinline__ void frag_step(Pipe& p, Frag& f, int q, const _Float1
 
 // (k-step, tile) pairs of a wide chunk; pair q = s*8 + t, two tiles at a time with their three products
 // interleaved: consecutive MFMAs never share an accumulator
-template <int KS, class BFn, class PostFn>
+template <int KS, int NCH = kNumChunks, class BFn, class PostFn>
 __device__ __forceinline__ void mma_wide16(Pipe& p, Frag& f, f32x16 (&acc)[8], BFn b, PostFn post) {
   constexpr int NP = KS * 8;
-  const Dma dma = ring_begin(p);
+  const Dma dma = ring_begin<NCH>(p);
   const _Float16* l = chunk_ptr16(p);
   const _Float16* ln = next_chunk_ptr16(p);
   TR_BEGIN(w);
@@ -202,7 +204,7 @@ __device__ __forceinline__ void mma_wide16(Pipe& p, Frag& f, f32x16 (&acc)[8], B
     frag_step<NP>(p, f, q, l, ln);
   }
   TR_END(3, w);
-  ring_advance(p);
+  ring_advance<NCH>(p);
 }
 
 // ---------------------------------------------------------------------------------------------- operand conversion
@@ -580,7 +582,210 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_f16x3_kernel(Params P) {
 #endif
 }
 
+// =====================================================================================================================
+// Split-fp16 dgrad (backward of the two heads wrt their hidden activations): the structure of mlp_dgrad_kernel
+// (mlp_bwd.hip) -- dh = W^T dz layer by layer, ReLU gates from the recorded sign bits, every dz block written to the
+// gradient record for the weight-gradient GEMM -- on the f16 matrix cores with the machinery of the forward above:
+// transposed f16x3 weight stream (34 chunks, chunkT16_src), two accumulator sets in ping-pong, operands converted in
+// the MFMA issue gaps.  Gradients are tiny (1e-9 .. 1e-2), far below the fp16 normal range, so each sample's chain is
+// scaled by a power of two chosen from its own output-layer derivatives (both lanes of a sample compute the same
+// factor): exact, linear through the masked chain, undone when a dz block is stored.
+// =====================================================================================================================
+struct WT { const float* w[16]; };
+
+__global__ void packT16_kernel(WT w, _Float16* __restrict__ out) {
+  const int64_t n = (int64_t)kNumChunksT * kChunkHalves;
+  const float scale = (float)(1 << kF16WeightShift);
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+    int part, mat, o, f;
+    chunkT16_src((int)(e / kChunkHalves), (int)(e % kChunkHalves), part, mat, o, f);
+    const float v = o < 0 ? 0.0f : w.w[mat][(int64_t)o * 256 + f] * scale;
+    const _Float16 hi = (_Float16)v;
+    out[e] = part == 0 ? hi : (_Float16)(v - (float)hi);
+  }
+}
+
+struct DgP {
+  const float* packed_t; const float* saved;
+  const float* rgb; const float* density; const float* uncert;
+  const float* g_rgb; const float* g_density; const float* g_uncert;
+  int64_t n_samples, n_tiles;
+  float* dz;
+  unsigned int* dz_max;
+};
+
+// gate bit of (tile t, register r) in the recorded ReLU sign words
+__device__ __forceinline__ bool gate(const uint32_t (&mask)[4], int t, int r) { return (mask[t >> 1] >> ((t & 1) * 16 + r)) & 1u; }
+
+__device__ __forceinline__ void convert2m(const f32x16& a, int t, int e0, const uint32_t (&mask)[4], half2v& hp, half2v& lp) {
+  const f32x2 sc = f32x2{a[e0], a[e0 + 1]} * kInvScale;
+  const float v0 = gate(mask, t, e0) ? sc.x : 0.0f, v1 = gate(mask, t, e0 + 1) ? sc.y : 0.0f;
+  const float h0 = __uint_as_float(__float_as_uint(v0) & 0xFFFFE000u);
+  const float h1 = __uint_as_float(__float_as_uint(v1) & 0xFFFFE000u);
+  hp = __builtin_amdgcn_cvt_pkrtz(h0, h1);
+  lp = __builtin_amdgcn_cvt_pkrtz(v0 - h0, v1 - h1);
+}
+__device__ __forceinline__ Xop convert_tile_m(const f32x16& a, int t, const uint32_t (&mask)[4]) {
+  XBuild xb;
+#pragma unroll
+  for (int e = 0; e < 16; e += 2) convert2m(a, t, e, mask, xb.hp[e >> 1], xb.lp[e >> 1]);
+  return finish(xb);
+}
+// one 256 -> 256 transposed layer: acc += W^T (gated S * 2^-8)
+__device__ __forceinline__ void part_gen16m(Pipe& p, Frag& f, f32x16 (&acc)[8], const f32x16 (&S)[8], const uint32_t (&mask)[4]) {
+  Xop X = convert_tile_m(S[0], 0, mask);
+#pragma unroll
+  for (int ts = 0; ts < 8; ++ts) {
+    XBuild xb;
+    const auto bop = [&](int s, half8& xh, half8& xl) { xh = X.h[s]; xl = X.l[s]; };
+    const auto cvt = [&](int q) { if (ts < 7) convert2m(S[ts < 7 ? ts + 1 : 0], ts + 1, q, mask, xb.hp[q >> 1], xb.lp[q >> 1]); };
+    mma_wide16<2, kNumChunksT>(p, f, acc, bop, cvt);
+    if (ts < 7) X = finish(xb);
+  }
+}
+
+__global__ __launch_bounds__(kThreads, 1) void mlp_dgrad_f16x3_kernel(DgP P) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 31, hh = lane >> 5;
+  Pipe p;
+  p.stream = P.packed_t; p.lds = lds; p.chunk = 0; p.buf = 0; p.wave = __builtin_amdgcn_readfirstlane(wave); p.lane = lane;
+  dma_chunk(p, 0, 0);
+  dma_chunk(p, 1, 1);
+  __syncthreads();
+  Frag frag;
+  frag_prime(p, frag);
+
+  for (int64_t tile = blockIdx.x; tile < P.n_tiles; tile += gridDim.x) {
+    const int64_t s_raw = tile * 128 + wave * 32 + j;
+    const bool live = s_raw < P.n_samples;
+    const int64_t s = live ? s_raw : P.n_samples - 1;
+    const int64_t gidx = tile * 4 + wave;
+    const float* sv = P.saved + gidx * (int64_t)kSavedGroupFloats;
+    float* dzg = P.dz + gidx * (int64_t)kDzGroupFloats;
+    int o16[16];
+    lane_block_offsets(j, hh, o16);
+    float dzm = 0.0f;
+    f32x16 SP[8], SQ[8];
+
+    // gate + un-scale + store one dz block; returns nothing, tracks max |dz|
+    const auto finish_step = [&](const f32x16 (&D)[8], const uint32_t (&mask)[4], float factor, int st) {
+      float* blk = dzg + st * kBlockFloats;
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = (live && gate(mask, t, r)) ? D[t][r] * factor : 0.0f;
+          blk[t * 1024 + o16[r]] = v;
+          dzm = fmaxf(dzm, fabsf(v));
+        }
+    };
+    const auto load_mask = [&](int slot, uint32_t (&mask)[4]) {
+      const uint32_t* mk = reinterpret_cast<const uint32_t*>(sv + kMaskOff) + (slot - 1) * 256 + lane;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) mask[w] = mk[w * 64];
+    };
+
+#pragma nounroll
+    for (int head = 0; head < 2; ++head) {
+      // derivative of the output non-linearities (sigmoid: y(1-y); softplus: 1-exp(-y))
+      float d[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (live) {
+        const int sel = head == 0 ? 1 : 0;          // head 0 = transient (last dim 1), head 1 = static rgb
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const float y = P.rgb[s * 6 + c * 2 + sel];
+          d[c] = P.g_rgb[s * 6 + c * 2 + sel] * y * (1.0f - y);
+        }
+        if (head == 0) {
+          d[3] = P.g_density[s * 2 + 1] * (1.0f - expf(-P.density[s * 2 + 1]));
+          d[4] = P.g_uncert[s] * (1.0f - expf(-P.uncert[s]));
+        }
+      }
+      float* nb = dzg + (head == 0 ? kDzT3Off : kDzR3Off);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) nb[blk_off(r + 16 * hh, j)] = (hh == 0 && r < 6) ? d[r < 6 ? r : 0] : 0.0f;
+      // per-sample power-of-two scale: largest |d| -> [2^5, 2^6)
+      float dmax = 0.0f;
+#pragma unroll
+      for (int c = 0; c < 6; ++c) dmax = fmaxf(dmax, fabsf(d[c]));
+      float sc = 1.0f, isc = 1.0f;
+      if (dmax > 0.0f && dmax < 3.0e38f) {
+        int e;
+        (void)frexpf(dmax, &e);
+        sc = ldexpf(1.0f, 6 - e);
+        isc = ldexpf(1.0f, e - 6);
+      }
+      const float factor = isc * kInvScale;
+      // B operand of the narrow chunk: slots 8 h + j of k-step 0 = d[0..5] (lane half 0), zeros elsewhere
+      half8 dh, dl;
+      {
+        half2v hp[4], lp[4];
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+          const float v0 = (hh == 0 && e < 6) ? d[e < 6 ? e : 0] * sc : 0.0f;
+          const float v1 = (hh == 0 && e + 1 < 6) ? d[e + 1 < 6 ? e + 1 : 0] * sc : 0.0f;
+          const float h0 = __uint_as_float(__float_as_uint(v0) & 0xFFFFE000u);
+          const float h1 = __uint_as_float(__float_as_uint(v1) & 0xFFFFE000u);
+          hp[e >> 1] = __builtin_amdgcn_cvt_pkrtz(h0, h1);
+          lp[e >> 1] = __builtin_amdgcn_cvt_pkrtz(v0 - h0, v1 - h1);
+        }
+        dh = pack8(hp);
+        dl = pack8(lp);
+      }
+      const int slot0 = head == 0 ? SV_T2 : SV_R2;
+      uint32_t m0[4], m1[4], m2[4];
+      load_mask(slot0, m0);
+      load_mask(slot0 - 1, m1);
+      load_mask(slot0 - 2, m2);
+      asm volatile("" ::: "memory");
+      // step 0: output layer (5 or 3 rows) -> dz of the last hidden layer
+#pragma unroll
+      for (int t = 0; t < 8; ++t) SP[t] = f32x16{0};
+      mma_wide16<1, kNumChunksT>(p, frag, SP, [&](int, half8& xh, half8& xl) { xh = dh; xl = dl; }, [](int) {});
+      finish_step(SP, m0, factor, head * 3 + 0);
+      asm volatile("" ::: "memory");
+      // step 1
+#pragma unroll
+      for (int t = 0; t < 8; ++t) SQ[t] = f32x16{0};
+      part_gen16m(p, frag, SQ, SP, m0);
+      finish_step(SQ, m1, factor, head * 3 + 1);
+      asm volatile("" ::: "memory");
+      // step 2
+#pragma unroll
+      for (int t = 0; t < 8; ++t) SP[t] = f32x16{0};
+      part_gen16m(p, frag, SP, SQ, m1);
+      finish_step(SP, m2, factor, head * 3 + 2);
+      asm volatile("" ::: "memory");
+    }
+    for (int off = 32; off >= 1; off >>= 1) dzm = fmaxf(dzm, __shfl_xor(dzm, off, 64));
+    if (lane == 0 && P.dz_max != nullptr && dzm == dzm && dzm < 3.0e38f) atomicMax(P.dz_max, __float_as_uint(dzm));
+  }
+}
+
 }  // namespace
+
+// launched by tp_mlp_bwd (mlp_bwd.hip) when args->wgrad_precision == TP_MLP_F16X3
+int tp_launch_mlp_dgrad_f16x3(const tp_mlp_bwd_args* a, float* dz, unsigned int* dz_max, int grid, hipStream_t stream) {
+  if (a->repack) {
+    WT w;
+    for (int i = 0; i < 16; ++i) w.w[i] = nullptr;
+    for (int i = 0; i < 4; ++i) { w.w[W_RGB0 + i] = a->weights.rgb_w[i]; w.w[W_TRANS0 + i] = a->weights.trans_w[i]; }
+    hipLaunchKernelGGL(packT16_kernel, dim3(512), dim3(256), 0, stream, w, (_Float16*)a->packed_t);
+  }
+  constexpr int kDgLds = kBufs * kChunkFloats * 4;
+  static unsigned long long attr_devices = 0;
+  if (tp::first_use_on_device(attr_devices)) {
+    hipError_t e = hipFuncSetAttribute((const void*)mlp_dgrad_f16x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kDgLds);
+    if (e != hipSuccess) { tp::set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+  }
+  DgP D;
+  D.packed_t = (const float*)a->packed_t; D.saved = a->saved; D.rgb = a->rgb; D.density = a->density; D.uncert = a->uncert;
+  D.g_rgb = a->g_rgb; D.g_density = a->g_density; D.g_uncert = a->g_uncert;
+  D.n_samples = (int64_t)a->B * a->R * a->N; D.n_tiles = (D.n_samples + 127) / 128; D.dz = dz; D.dz_max = dz_max;
+  hipLaunchKernelGGL(mlp_dgrad_f16x3_kernel, dim3(grid), dim3(kThreads), kDgLds, stream, D);
+  return tp::check_launch("tp_mlp_bwd(dgrad f16x3)");
+}
 
 // launched by tp_mlp_fwd (mlp_fwd.hip) when args->precision == TP_MLP_F16X3
 int tp_launch_mlp_fwd_f16x3(const tp_mlp_fwd_args* a, int grid, hipStream_t stream) {

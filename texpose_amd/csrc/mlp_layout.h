@@ -194,6 +194,20 @@ namespace tp_layout {
 constexpr int kF16WeightShift = 8;
 constexpr int kChunkHalves = 16384;
 
+// Transposed f16x3 stream of the split-fp16 dgrad kernel: the 34 chunks of chunkT_desc in the f16x3 chunk format
+// (2 k-steps of 16 contracted OUTPUT features o, 8 tiles of 32 input-feature rows f).  value = W[mat][o][f] * 2^shift.
+// The narrow chunks carry their 5 / 3 outputs in k-step 0, slots 8 h + j.
+TP_HD void chunkT16_src(int c, int idx, int& part, int& mat, int& o, int& f) {
+  int ts, rows;
+  chunkT_desc(c, mat, ts, rows);
+  const int j = idx & 7, lane = (idx >> 3) & 63, i = lane & 31, h = lane >> 5;
+  part = (idx >> 9) & 1;
+  const int t = (idx >> 10) & 7, s = idx >> 13;
+  f = 32 * t + i;
+  if (ts < 0) { o = s == 0 ? 8 * h + j : -1; if (o >= rows) o = -1; }
+  else o = 32 * ts + 16 * s + 8 * (j >> 2) + 4 * h + (j & 3);          // acc_feat16(ts, s, h, j)
+}
+
 TP_HD int acc_feat16(int ts, int s, int h, int j) { return 32 * ts + 16 * s + 8 * (j >> 2) + 4 * h + (j & 3); }
 
 // "extra" inputs in natural column order, 16 per k-step: slot = 16 s' + 8 h + j
