@@ -55,12 +55,26 @@ __global__ __launch_bounds__(kBlock) void nerf_losses_fwd_kernel(tp_nerf_losses_
   }
 }
 
-__global__ void nerf_losses_finalize(const float* partial, int n_blocks, double* sums) {
-  if (threadIdx.x < 4) {
-    double s = 0.0;
-    for (int i = 0; i < n_blocks; ++i) s += partial[i * 4 + threadIdx.x];
-    sums[threadIdx.x] = s;
+// fixed-order reduction of the per-block partials: thread t adds partials t, t+256, ... in order, then a block tree
+__global__ __launch_bounds__(kBlock) void nerf_losses_finalize(const float* partial, int n_blocks, double* sums) {
+  __shared__ double red[4][kBlock];
+  const int tid = threadIdx.x;
+  double v[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int i = tid; i < n_blocks; i += kBlock) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] += (double)partial[i * 4 + k];
   }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) red[k][tid] = v[k];
+  __syncthreads();
+  for (int s = kBlock >> 1; s > 0; s >>= 1) {
+    if (tid < s) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) red[k][tid] += red[k][tid + s];
+    }
+    __syncthreads();
+  }
+  if (tid < 4) sums[tid] = red[tid][0];
 }
 
 // g[0..2]: upstream gradients of (render, uncert, trans_reg)
@@ -103,7 +117,7 @@ extern "C" int tp_nerf_losses_fwd(const tp_nerf_losses_args* a, tp_stream_t stre
   if (int rc = check(a, "tp_nerf_losses_fwd")) return rc;
   const int g = grid_for(a);
   hipLaunchKernelGGL(nerf_losses_fwd_kernel, dim3(g), dim3(kBlock), 0, (hipStream_t)stream, *a, (float*)a->workspace);
-  hipLaunchKernelGGL(nerf_losses_finalize, dim3(1), dim3(64), 0, (hipStream_t)stream, (const float*)a->workspace, g, a->sums);
+  hipLaunchKernelGGL(nerf_losses_finalize, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, (const float*)a->workspace, g, a->sums);
   return tp::check_launch("tp_nerf_losses_fwd");
 }
 
