@@ -182,7 +182,14 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_wgrad_kernel(WgParams P) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 31, hh = lane >> 5;
-  const int item = blockIdx.x % kWgItems, slice = blockIdx.x / kWgItems;
+  // Workgroup -> (item, slice).  The two row halves of a wide GEMM read the same activation blocks; consecutive
+  // workgroup ids go round-robin over the 8 XCDs, so the halves are placed 8 ids apart (same XCD, same L2, same time):
+  // the second read of every block is then an L2 hit instead of a second trip over the fabric.
+  const int xcd = blockIdx.x & 7, kk = blockIdx.x >> 3;
+  const int pair = (kk >> 1) * 8 + xcd, quad_sel = kk & 1;
+  if (pair >= (kWgItems / 2) * P.n_slices) return;          // padding workgroups of the last round
+  const int gp = pair % (kWgItems / 2), slice = pair / (kWgItems / 2);
+  const int item = gp < 6 ? 2 * gp + quad_sel : 12 + quad_sel;
   const bool big = item < 12;
   const int gemm = item >> 1, quad = item & 1;
   const int a_off = big ? gemm * kBlockFloats + quad * 4096 : (item == 12 ? kDzT3Off : kDzR3Off);
@@ -457,12 +464,11 @@ extern "C" int tp_mlp_bwd(const tp_mlp_bwd_args* a, tp_stream_t stream_) {
   Wg.groups_per_slice = (int)((ng + Wg.n_slices - 1) / Wg.n_slices);
   Wg.partial = partial;
   Wg.dz_max = dz_max;
+  const unsigned wg_grid = (unsigned)((kWgItems * Wg.n_slices + 15) / 16 * 16);   // whole rounds of 2 x 8 XCDs
   if (f16)
-    hipLaunchKernelGGL(mlp_wgrad_kernel<true>, dim3(kWgItems * Wg.n_slices), dim3(kThreads), 2 * kWgBufFloats * sizeof(float),
-                       stream, Wg);
+    hipLaunchKernelGGL(mlp_wgrad_kernel<true>, dim3(wg_grid), dim3(kThreads), 2 * kWgBufFloats * sizeof(float), stream, Wg);
   else
-    hipLaunchKernelGGL(mlp_wgrad_kernel<false>, dim3(kWgItems * Wg.n_slices), dim3(kThreads), 2 * kWgBufFloats * sizeof(float),
-                       stream, Wg);
+    hipLaunchKernelGGL(mlp_wgrad_kernel<false>, dim3(wg_grid), dim3(kThreads), 2 * kWgBufFloats * sizeof(float), stream, Wg);
 
   FinParams F;
   int n = 0; int64_t off = 0;
