@@ -337,6 +337,33 @@ def test_mlp_backward_vs_oracle_autograd(ops, B, R, N, train_precision):
             assert torch.equal(p.grad, g2[k]), k
 
 
+@pytest.mark.parametrize("scale", [1e-24, 1.0, 1e18])
+def test_split_fp16_backward_is_scale_invariant(ops, scale):
+    """The split-fp16 backward scales gradients by powers of two internally (per sample in dgrad, per call in wgrad):
+    cotangents of any magnitude must give the fp32-MFMA backward's gradients, scaled."""
+    B, R, N = 2, 24, 16
+    rs = np.random.RandomState(31)
+    params = O.make_params(24)
+    pts = torch.from_numpy(rs.uniform(-1.2, 1.2, size=(B, R, N, 3)).astype(np.float32))
+    unit = torch.nn.functional.normalize(torch.from_numpy(rs.normal(size=(B, R, 1, 3)).astype(np.float32)),
+                                         dim=-1).expand(B, R, N, 3).contiguous()
+    lt = torch.from_numpy(rs.normal(size=(B, 16)).astype(np.float32))
+    ll = torch.from_numpy(rs.normal(size=(B, 48)).astype(np.float32))
+    cots = [torch.from_numpy(rs.normal(size=s).astype(np.float32)) for s in ((B, R, N, 3, 2), (B, R, N, 2), (B, R, N, 1))]
+    grads = {}
+    for prec, sc in (("fp32", 1.0), ("f16x3", scale)):
+        g, opt = _graph(params, N=N)
+        g.nerf.train_precision = prec
+        ltd, lld = cu(lt).requires_grad_(), cu(ll).requires_grad_()
+        out = g.nerf.forward(opt, cu(pts), ray_unit=cu(unit), latent_variable_trans=ltd, latent_variable_light=lld, mode="train")
+        sum((o * (cu(c) * sc)).sum() for o, c in zip(out, cots)).backward()
+        grads[prec] = {k: p.grad.double() / sc for k, p in g.nerf.named_parameters() if p.grad is not None}
+        grads[prec]["lt"], grads[prec]["ll"] = ltd.grad.double() / sc, lld.grad.double() / sc
+    for k in grads["fp32"]:
+        assert torch.isfinite(grads["f16x3"][k]).all(), k
+        assert rel_l2(grads["f16x3"][k], grads["fp32"][k]) < 5e-3, (k, rel_l2(grads["f16x3"][k], grads["fp32"][k]))
+
+
 def test_mlp_backward_more_than_32_images(ops):
     """B = 40 images in one training forward: the backward runs per group of 32 images and autograd sums the head
     gradients; compare with the oracle."""

@@ -221,7 +221,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_wgrad_kernel(WgParams P) {
   float dz_scale = 1.0f, out_scale = 1.0f;
   if constexpr (F16X3) {
     const float mx = __uint_as_float(*P.dz_max);
-    if (mx > 0.0f) {
+    if (mx > 1.0e-30f && mx < 1.0e30f) {
       int e;
       (void)frexpf(mx, &e);                       // mx = m * 2^e, m in [0.5, 1)
       dz_scale = ldexpf(1.0f, 14 - e);            // largest |dz| lands in [2^13, 2^14)

@@ -710,7 +710,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_dgrad_f16x3_kernel(DgP P) {
 #pragma unroll
       for (int c = 0; c < 6; ++c) dmax = fmaxf(dmax, fabsf(d[c]));
       float sc = 1.0f, isc = 1.0f;
-      if (dmax > 0.0f && dmax < 3.0e38f) {
+      if (dmax > 1.0e-30f && dmax < 1.0e30f) {     // (outside: no scaling -- such gradients are lost or infinite anyway)
         int e;
         (void)frexpf(dmax, &e);
         sc = ldexpf(1.0f, 6 - e);
