@@ -806,6 +806,19 @@ def test_graph_captured_training_matches_eager(ops):
     assert not torch.equal(sd_g["nerf.mlp_rgb.0.weight"], snap["nerf.mlp_rgb.0.weight"])
     assert not torch.equal(sd_g["discriminator.main.0.weight_orig"], snap["discriminator.main.0.weight_orig"])
 
+    # learning rates live in device memory: a scheduler can change them between replays
+    before = {k: v.detach().clone() for k, v in g_g.state_dict().items()}
+    graphed.set_lr(nerf=0.0, disc=0.0)
+    v = AttrDict(dict(batch))
+    v.patch_u, v.jitter_rand = rnd[0]
+    graphed.train_iteration(v)
+    after = g_g.state_dict()
+    assert torch.equal(after["nerf.mlp_rgb.0.weight"], before["nerf.mlp_rgb.0.weight"])
+    assert torch.equal(after["discriminator.main.0.weight_orig"], before["discriminator.main.0.weight_orig"])
+    graphed.set_lr(nerf=1e-3, disc=1e-4)
+    graphed.train_iteration(v)
+    assert not torch.equal(g_g.state_dict()["nerf.mlp_rgb.0.weight"], before["nerf.mlp_rgb.0.weight"])
+
     # own random stream: a second graphed trainer without external tensors draws new patches on every replay
     own, g_o = build(GraphedGanTrainer)
     g_o.load_state_dict(snap)

@@ -27,14 +27,19 @@ class GanTrainer:
         nerf_params = [p for p in graph.nerf.parameters() if p.requires_grad]
         self.nerf_group = nerf_params + list(graph.latent_vars_light.parameters()) + \
             list(graph.latent_vars_trans.parameters())
-        self.optim_nerf = torch.optim.Adam([dict(params=nerf_params, lr=opt.optim.lr),
-                                            dict(params=graph.latent_vars_light.parameters(), lr=opt.optim.lr),
-                                            dict(params=graph.latent_vars_trans.parameters(), lr=opt.optim.lr)],
+        # a captured step reads its learning rates from device memory, so that a scheduler (the reference decays the
+        # nerf rate per epoch, ExponentialLR, model/nerf_adapt_st_gan.py:73-84) can change them between replays
+        dev = nerf_params[0].device
+        self.lr_nerf = torch.tensor(float(opt.optim.lr), device=dev) if self.capturable else float(opt.optim.lr)
+        self.optim_nerf = torch.optim.Adam([dict(params=nerf_params, lr=self.lr_nerf),
+                                            dict(params=graph.latent_vars_light.parameters(), lr=self.lr_nerf),
+                                            dict(params=graph.latent_vars_trans.parameters(), lr=self.lr_nerf)],
                                            capturable=self.capturable)
         self.has_disc = hasattr(graph, "discriminator") and opt.gan is not None
         if self.has_disc:
             self.disc_group = [p for p in graph.discriminator.parameters()]
-            self.optim_disc = torch.optim.RMSprop([dict(params=self.disc_group, lr=opt.optim_disc.lr)],
+            self.lr_disc = torch.tensor(float(opt.optim_disc.lr), device=dev) if self.capturable else float(opt.optim_disc.lr)
+            self.optim_disc = torch.optim.RMSprop([dict(params=self.disc_group, lr=self.lr_disc)],
                                                   capturable=self.capturable)
         self.red_nerf = tdist.FlatGradAllReducer(self.nerf_group)
         self.red_disc = tdist.FlatGradAllReducer(self.disc_group) if self.has_disc else None
@@ -73,6 +78,18 @@ class GanTrainer:
         self.red_disc.reduce()
         self.optim_disc.step()
         return var, loss
+
+    def set_lr(self, nerf: float = None, disc: float = None):
+        """Learning rates for the following iterations (eager: param groups; captured: the device scalars the graph reads)."""
+        for value, name, optim in ((nerf, "lr_nerf", self.optim_nerf), (disc, "lr_disc", getattr(self, "optim_disc", None))):
+            if value is None or optim is None:
+                continue
+            if self.capturable:
+                getattr(self, name).fill_(float(value))
+            else:
+                setattr(self, name, float(value))
+                for g in optim.param_groups:
+                    g["lr"] = float(value)
 
     def _poll_range(self, device):
         """f16x3 recording forward: surface a raised range flag (an activation beyond 6e4) without a host sync; it
