@@ -58,24 +58,25 @@ __global__ __launch_bounds__(256) void sn_wtu_kernel(Batch b) {
   const int c = cb * 256 + threadIdx.x;
   if (c >= w.cols) return;
   float acc = 0.0f;
-  for (int r = 0; r < nr; ++r) acc = fmaf(w.weight[(int64_t)(r0 + r) * w.cols + c], us[r], acc);
+#pragma unroll 8
+  for (int r = 0; r < nr; ++r) acc = fmaf(w.weight[(int64_t)(r0 + r) * w.cols + c], us[r], acc);   // 8 loads in flight
   w.work[(int64_t)slab * w.cols + c] = acc;
 }
 
 // A2: v = normalize(sum_slabs t_part)
-__global__ __launch_bounds__(256) void sn_v_kernel(Batch b) {
-  __shared__ float red[256];
+__global__ __launch_bounds__(1024) void sn_v_kernel(Batch b) {
+  __shared__ float red[1024];
   const tp_sn_weight& w = b.w[blockIdx.x];
   const int slabs = (w.rows + kSlabRows - 1) / kSlabRows;
   float ss = 0.0f;
-  for (int c = threadIdx.x; c < w.cols; c += 256) {
+  for (int c = threadIdx.x; c < w.cols; c += 1024) {
     float t = 0.0f;
     for (int s = 0; s < slabs; ++s) t += w.work[(int64_t)s * w.cols + c];
     w.v[c] = t;
     ss = fmaf(t, t, ss);
   }
   const float nrm = fmaxf(sqrtf(block_sum(ss, red)), 1e-12f);
-  for (int c = threadIdx.x; c < w.cols; c += 256) w.v[c] = w.v[c] / nrm;
+  for (int c = threadIdx.x; c < w.cols; c += 1024) w.v[c] = w.v[c] / nrm;
 }
 
 // B: s[r] = sum_c W[r][c] v[c]   (one wave per row)
@@ -86,7 +87,8 @@ __global__ __launch_bounds__(256) void sn_wv_kernel(Batch b) {
   if (r >= w.rows) return;
   const float* row = w.weight + (int64_t)r * w.cols;
   float acc = 0.0f;
-  for (int c = lane; c < w.cols; c += 64) acc = fmaf(row[c], w.v[c], acc);
+#pragma unroll 8
+  for (int c = lane; c < w.cols; c += 64) acc = fmaf(row[c], w.v[c], acc);                          // 16 loads in flight
   for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
   if (lane == 0) w.work[(int64_t)TP_SN_MAX_SLABS * w.cols + r] = acc;
 }
@@ -180,7 +182,7 @@ extern "C" int tp_sn_fwd(const tp_sn_weight* ws, int n, int training, tp_stream_
   if (training) {
     int g = fill(b, ws, n, [](const tp_sn_weight& w) { return ((w.cols + 255) / 256) * ((w.rows + kSlabRows - 1) / kSlabRows); });
     hipLaunchKernelGGL(sn_wtu_kernel, dim3(g), dim3(256), 0, st, b);
-    hipLaunchKernelGGL(sn_v_kernel, dim3(n), dim3(256), 0, st, b);
+    hipLaunchKernelGGL(sn_v_kernel, dim3(n), dim3(1024), 0, st, b);
   }
   int g = fill(b, ws, n, [](const tp_sn_weight& w) { return (w.rows + 3) / 4; });
   hipLaunchKernelGGL(sn_wv_kernel, dim3(g), dim3(256), 0, st, b);
