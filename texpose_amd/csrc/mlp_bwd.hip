@@ -329,7 +329,8 @@ __device__ __forceinline__ float part_sum(const FinParams& P, int gemm, int o, i
   const int ii = o & 31, h = (ii >> 2) & 1, r = (ii & 3) | ((ii >> 3) << 2);
   const float* p = P.partial + ((((int64_t)item * P.n_slices) * 4 + wave) * kWgTiles + ft) * 1024 + r * 64 + h * 32 + col;
   float s = 0.0f;
-  for (int sl = 0; sl < P.n_slices; ++sl) s += p[(int64_t)sl * 4 * kWgTiles * 1024];
+#pragma unroll 6
+  for (int sl = 0; sl < P.n_slices; ++sl) s += p[(int64_t)sl * 4 * kWgTiles * 1024];   // (fixed order; 6 loads in flight)
   return s;
 }
 
