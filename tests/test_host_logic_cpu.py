@@ -165,3 +165,21 @@ def test_synthetic_recipes_match_oracle_copies():
     for k in ("intr", "pose", "aabb_min", "aabb_max"):
         assert torch.equal(so[k], sp[k]), k
     assert S.LINEMOD_K == O.LINEMOD_K
+
+
+def test_perceptual_pairs_equal_separate_passes():
+    """PerceptualLoss.pairs (one pass over the feature network for both terms of the feature loss) gives the losses and
+    gradients of the reference's four separate passes."""
+    from texpose_amd.gan_modules import PerceptualLoss
+    torch.manual_seed(0)
+    P = PerceptualLoss()
+    a, c = torch.rand(2, 3, 16, 16, requires_grad=True), torch.rand(2, 3, 16, 16, requires_grad=True)
+    b, d = torch.rand(2, 3, 16, 16), torch.rand(2, 3, 16, 16)
+    l1, l2 = P(a, b), P(c, d)
+    (l1 + 5 * l2).backward()
+    g1, g2 = a.grad.clone(), c.grad.clone()
+    a.grad = c.grad = None
+    m1, m2 = P.pairs((a, b), (c, d))
+    (m1 + 5 * m2).backward()
+    assert torch.allclose(m1, l1, rtol=1e-6, atol=0) and torch.allclose(m2, l2, rtol=1e-6, atol=0)
+    assert torch.allclose(a.grad, g1, rtol=1e-5, atol=1e-9) and torch.allclose(c.grad, g2, rtol=1e-5, atol=1e-9)

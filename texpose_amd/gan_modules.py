@@ -165,3 +165,15 @@ class PerceptualLoss(nn.Module):
         f = self.model((fake - self.mean) / self.std)
         r = self.model((real - self.mean) / self.std)
         return F.mse_loss(f, r.detach())
+
+    def pairs(self, *fake_real):
+        """[MSE(feat(fake_i), feat(real_i))] for several (fake, real) pairs through ONE pass over the feature network
+        (the two terms of the reference's feature loss are four passes, :763-766): the same per-sample arithmetic --
+        convolutions do not mix samples -- in a quarter of the launches.  Targets carry no gradient."""
+        fakes, reals = [p[0] for p in fake_real], [p[1].detach() for p in fake_real]
+        n = [t.shape[0] for t in fakes]
+        x = torch.cat(fakes + reals, dim=0)
+        feat = self.model((x - self.mean) / self.std)
+        parts = torch.split(feat, n + n, dim=0)
+        k = len(fakes)
+        return [F.mse_loss(parts[i], parts[k + i].detach()) for i in range(k)]

@@ -297,8 +297,13 @@ class Graph(torch.nn.Module):
                 if not hasattr(self, "perceptual_loss"):
                     raise RuntimeError("loss_weight.feat is set but no perceptual_loss module was injected")
                 mask_pad = torch.logical_and(mask_syn == 1, obj_mask == 0).float()
-                loss.feat = self.perceptual_loss(rgb, image * obj_mask + image_syn * mask_pad) + \
-                    5 * self.perceptual_loss(rgb * obj_mask + image * (1 - obj_mask), image)
+                pair1 = (rgb, image * obj_mask + image_syn * mask_pad)
+                pair2 = (rgb * obj_mask + image * (1 - obj_mask), image)
+                if hasattr(self.perceptual_loss, "pairs"):            # both terms through one pass of the feature network
+                    l1, l2 = self.perceptual_loss.pairs(pair1, pair2)
+                else:                                                  # any injected module with the reference's call signature
+                    l1, l2 = self.perceptual_loss(*pair1), self.perceptual_loss(*pair2)
+                loss.feat = l1 + 5 * l2
             if lw.lab is not None:
                 loss.lab, var.rgb_lab, var.img_syn_lab = self.lab_loss(rgb, image_syn, mask=mask_syn)
             if opt.gan is not None and lw.gan_nerf is not None and mode == "train":
