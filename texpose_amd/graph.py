@@ -177,10 +177,12 @@ class Graph(torch.nn.Module):
     def gather_patches(self, opt, var):
         """One fused gather for everything compute_loss / sample_geometry / disc_forward sample at var.ray_idx."""
         B = len(var.idx)
+        if var.get("gathered_for") is var.ray_idx:          # same coordinates, same images: the gather is pure
+            return var
         g = ops.patch_gather(var.ray_idx, var.image, var.get("image_syn", var.image),
                              var.get("nocs_pred", var.image), var.get("normal_pred", var.image),
                              var.obj_mask.view(B, opt.H, opt.W), var.get("mask_syn", var.obj_mask).view(B, opt.H, opt.W))
-        var.gathered = g
+        var.gathered, var.gathered_for = g, var.ray_idx
         var.image_sample, var.image_syn_sample = g[:, 0:3], g[:, 3:6]
         var.nocs_sample, var.normal_sample = g[:, 6:9], g[:, 9:12]
         var.mask_sample, var.mask_syn_sample = g[:, 12:13], g[:, 13:14]
