@@ -114,6 +114,9 @@ class Discriminator(nn.Module):
                    conv(ndf * 8, final_dim, 4, 1, 0)]
         self.main = nn.Sequential(*blocks)
         if self.scale_conditional:
+            # 2^l pi, l < L_scale (a constant: kept as a non-persistent buffer instead of three launches per forward)
+            self.register_buffer("scale_freq", (2 ** torch.arange(self.L_scale, dtype=torch.float32)) * math.pi,
+                                 persistent=False)
             c = ndf + 2 * self.L_scale + 1
             self.final = nn.Sequential(nn.LeakyReLU(0.2), conv(c, ndf, 1, 1, 0), nn.LeakyReLU(0.2, inplace=True),
                                        conv(ndf, ndf, 1, 1, 0), nn.LeakyReLU(0.2, inplace=True), conv(ndf, 1, 1, 1, 0))
@@ -129,8 +132,7 @@ class Discriminator(nn.Module):
         weights = spectral_weights(convs, self.training)              # all power iterations / normalisations at once
         out = self._run(self.main, x, weights)                        # [B, c, 1, 1]
         if self.scale_conditional:
-            freq = (2 ** torch.arange(self.L_scale, dtype=torch.float32, device=x.device)) * math.pi
-            spec = scale.view(-1, 1) * freq                           # [B, L]
+            spec = scale.view(-1, 1) * self.scale_freq                # [B, L]
             enc = torch.cat([spec.sin(), spec.cos()], dim=1)[:, :, None, None]
             out = self._run(self.final, torch.cat((out, enc, scale), 1), weights).flatten()
         return out
