@@ -119,15 +119,21 @@ __global__ __launch_bounds__(256) void eval_metrics_kernel(tp_eval_metrics_args 
   }
 }
 
-// fixed-order reduction of the per-tile partials: out[b] = (sum sq. error, sum ssim) in fp64
-__global__ void eval_metrics_finalize(const float* partial, int tiles, double* out) {
-  const int b = blockIdx.x;
-  if (threadIdx.x == 0) {
-    double s0 = 0.0, s1 = 0.0;
-    for (int t = 0; t < tiles; ++t) { s0 += partial[2 * ((int64_t)b * tiles + t)]; s1 += partial[2 * ((int64_t)b * tiles + t) + 1]; }
-    out[2 * b] = s0;
-    out[2 * b + 1] = s1;
+// fixed-order reduction of the per-tile partials: out[b] = (sum sq. error, sum ssim) in fp64 (thread t adds tiles
+// t, t+64, ... in order, then a tree over the 64 lanes)
+__global__ __launch_bounds__(64) void eval_metrics_finalize(const float* partial, int tiles, double* out) {
+  __shared__ double red[2][64];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  double s0 = 0.0, s1 = 0.0;
+  for (int t = tid; t < tiles; t += 64) { s0 += partial[2 * ((int64_t)b * tiles + t)]; s1 += partial[2 * ((int64_t)b * tiles + t) + 1]; }
+  red[0][tid] = s0;
+  red[1][tid] = s1;
+  __syncthreads();
+  for (int s = 32; s > 0; s >>= 1) {
+    if (tid < s) { red[0][tid] += red[0][tid + s]; red[1][tid] += red[1][tid + s]; }
+    __syncthreads();
   }
+  if (tid == 0) { out[2 * b] = red[0][0]; out[2 * b + 1] = red[1][0]; }
 }
 
 }  // namespace
