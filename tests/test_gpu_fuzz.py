@@ -208,3 +208,31 @@ def test_fuzz_nerf_losses_fwd_bwd(ops, case):
     (wd[0] * out[0] + wd[1] * out[1] + wd[2] * out[2]).backward()
     for a, r in zip(dl, leaves):
         assert rel_l2(a.grad, r.grad) < 2e-5
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_fuzz_split_fp16_backward_equals_fp32_mfma_backward(ops, case):
+    """The same activation record (written by one f16x3 recording forward) through the fp32-MFMA backward and through
+    the split-fp16 backward: identical ReLU gates, so the two differ only by arithmetic -- they must agree to ~1e-5,
+    for random shapes (single sample, ragged tiles, up to 32 images) and cotangent magnitudes."""
+    from texpose_amd.graph import Graph
+    from texpose_amd.options import default_options
+    rs = np.random.RandomState(900 + case)
+    B, R, N = int(rs.choice([1, 2, 5, 32])), int(rs.choice([1, 3, 17, 40])), int(rs.choice([1, 4, 31, 64]))
+    params = O.make_params(60 + case)
+    opt = default_options(H=16, W=16, device="cuda:0")
+    g = Graph(opt).to(dev())
+    g.nerf.load_state_dict({**g.nerf.state_dict(), **{k: cu(v) for k, v in params.items()}})
+    pts = cu(T(rs.uniform(-1.5, 1.5, size=(B, R, N, 3))))
+    unit = cu(torch.nn.functional.normalize(T(rs.normal(size=(B, R, 1, 3))), dim=-1).expand(B, R, N, 3).contiguous())
+    lt, ll = cu(T(rs.normal(size=(B, 16)))), cu(T(rs.normal(size=(B, 48))))
+    mag = float(10.0 ** rs.uniform(-8, 4))
+    cots = [cu(T(rs.normal(size=s))) * mag for s in ((B, R, N, 3, 2), (B, R, N, 2), (B, R, N, 1))]
+    packed = g.nerf.packed_weights("f16x3")
+    rgb, den, unc, saved = ops.mlp_forward(packed, lt, ll, points=pts, ray_unit=unit, save=True, precision="f16x3")
+    ops.check_mlp_status(dev())
+    res = {p: ops.mlp_backward(g.nerf, lt, ll, saved, rgb, den, unc, *cots, wgrad_precision=p) for p in ("fp32", "f16x3")}
+    for a, b in zip(res["f16x3"]["params"], res["fp32"]["params"]):
+        assert torch.isfinite(a).all() and rel_l2(a, b) < 2e-5, rel_l2(a, b)
+    for k in ("lat_trans", "lat_light"):
+        assert rel_l2(res["f16x3"][k], res["fp32"][k]) < 2e-5
