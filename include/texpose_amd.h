@@ -203,6 +203,26 @@ typedef struct tp_composite_bwd_args {
 int tp_composite_bwd(const tp_composite_bwd_args* args, tp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * One-call evaluation render: tp_raygen -> tp_mlp_fwd -> tp_composite_fwd on one stream
+ * ref: Graph.render with mode != 'train', model/nerf_adapt_st_gan.py:547-631 (latent rows chosen by the caller, :589-605)
+ * ------------------------------------------------------------------------------------------ */
+typedef struct tp_render_eval_args {
+  tp_raygen_args raygen;   /* inputs, sizes and modes as for tp_raygen (N > 0); its output pointers are ignored */
+  const void* packed;      /* tp_mlp_pack output for `precision` */
+  const float* lat_trans;  /* [B,16] */
+  const float* lat_light;  /* [B,48] */
+  int precision;           /* TP_MLP_FP32 or TP_MLP_F16X3 */
+  int* status;             /* as in tp_mlp_fwd_args (may be NULL) */
+  float min_uncert;
+  void* workspace;         /* tp_render_eval_workspace_bytes(B, R, N) */
+  float* out_ray;          /* [B*R,14] out, layout of tp_composite_args.out_ray */
+  float* alpha_static;     /* [B*R,N] out or NULL */
+  float* alpha_transient;  /* [B*R,N] out or NULL */
+} tp_render_eval_args;
+size_t tp_render_eval_workspace_bytes(int B, int R, int N);
+int tp_render_eval(const tp_render_eval_args* args, tp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * K5  patch gather for the photometric / PatchGAN inputs
  * ref: model/nerf_adapt_st_gan.py:444-461,516-545,726-745 (8 grid_sample calls per step)
  * ------------------------------------------------------------------------------------------ */

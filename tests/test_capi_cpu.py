@@ -42,6 +42,7 @@ def test_struct_sizes_match_header():
     assert C.sizeof(_lib.EvalMetricsArgs) == 3 * 8 + 5 * 4 + 4 + 2 * 8
     assert C.sizeof(_lib.SnWeight) == 8 * 8 + 2 * 4
     assert C.sizeof(_lib.NerfLossesArgs) == 4 * 8 + 3 * 4 + 4 + 2 * 8
+    assert C.sizeof(_lib.RenderEvalArgs) == C.sizeof(_lib.RaygenArgs) + 3 * 8 + 4 + 4 + 8 + 4 + 4 + 4 * 8
 
 
 def test_argument_validation_without_gpu():

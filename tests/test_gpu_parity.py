@@ -457,6 +457,31 @@ def test_render_train_matches_oracle_on_same_rays(ops):
     assert rel_l2(graph.latent_vars_trans.weight.grad, et.grad) < 5e-3
 
 
+def test_render_eval_one_call_equals_mirror(ops):
+    """tp_render_eval (the C ABI's ray-gen + MLP + composite in one call) is bit-identical to what Graph.render launches,
+    for both MLP arithmetics and an arbitrary subset of pixels."""
+    rs = np.random.RandomState(8)
+    H, W, N, B = 24, 32, 16, 2
+    sc = O.synthetic_scene(H, W, B=B, seed=6)
+    params = O.make_params(25)
+    g, opt = _graph(params, H=H, W=W, N=N)
+    opt.nerf.sample_stratified = False
+    idx = torch.from_numpy(rs.randint(0, H * W, size=(B, 301)).astype(np.int64))
+    lat_t = g.latent_vars_trans.weight[0][None].expand(B, -1).contiguous()
+    lat_l = g.latent_vars_light.weight[0][None].expand(B, -1).contiguous()
+    for prec in ("fp32", "f16x3"):
+        g.nerf.precision = prec
+        with torch.no_grad():
+            ref = g.render(opt, cu(sc["pose"]), intr=cu(sc["intr"]), ray_idx=cu(idx),
+                           depth_range=(cu(sc["z_near"])[:, :, None], cu(sc["z_far"])[:, :, None]), sample_idx=None, mode="val")
+            out, (a_s, a_t) = ops.render_eval(g.nerf.packed_weights(prec), cu(sc["intr"]), cu(sc["pose"]), cu(idx), cu(sc["z_near"]),
+                                              cu(sc["z_far"]), lat_t, lat_l, H=H, W=W, n_samples=N, precision=prec, with_alphas=True)
+        for name, lo, hi in ops.COMPOSITE_RAY_FIELDS:
+            assert torch.equal(out[..., lo:hi], ref[name]), (prec, name)
+        assert torch.equal(a_s, ref["alpha_static"]) and torch.equal(a_t, ref["alpha_transient"])
+    ops.check_mlp_status(dev())
+
+
 def test_render_by_slices_g9(ops):
     g9 = load_golden("g9_render_slices")
     graph, opt = _graph(O.make_params(g9["seed"]), n_train=g9["n_train"], emb_seed=g9["emb_seed"], H=g9["H"],

@@ -25,6 +25,7 @@ SYMBOLS = (
     "tp_eval_metrics_workspace_bytes", "tp_eval_metrics",
     "tp_sn_work_floats", "tp_sn_fwd", "tp_sn_bwd",
     "tp_nerf_losses_fwd", "tp_nerf_losses_bwd",
+    "tp_render_eval_workspace_bytes", "tp_render_eval",
 )
 
 vp = C.c_void_p
@@ -99,6 +100,12 @@ class NerfLossesArgs(C.Structure):
 NERF_LOSSES_MAX_BLOCKS = 1024
 
 
+class RenderEvalArgs(C.Structure):
+    _fields_ = [("raygen", RaygenArgs), ("packed", vp), ("lat_trans", vp), ("lat_light", vp), ("precision", C.c_int),
+                ("status", vp), ("min_uncert", C.c_float), ("workspace", vp), ("out_ray", vp), ("alpha_static", vp),
+                ("alpha_transient", vp)]
+
+
 class TexposeLibraryError(RuntimeError):
     pass
 
@@ -150,6 +157,8 @@ def load() -> C.CDLL:
     sig("tp_sn_bwd", [C.POINTER(SnWeight), C.c_int, vp])
     sig("tp_nerf_losses_fwd", [C.POINTER(NerfLossesArgs), vp])
     sig("tp_nerf_losses_bwd", [C.POINTER(NerfLossesArgs), vp, vp, vp, vp, vp])
+    sig("tp_render_eval_workspace_bytes", [C.c_int, C.c_int, C.c_int], C.c_size_t)
+    sig("tp_render_eval", [C.POINTER(RenderEvalArgs), vp])
     _lib = lib
     return lib
 

@@ -136,15 +136,24 @@ class NeRF(torch.nn.Module):
         """points_3D, ray_unit [B,R,N,3] -> rgb [B,R,N,3,2], density [B,R,N,2], uncert [B,R,N,1]
         (reference layers/...light.py:76-145)."""
         assert ray_unit is not None, "view_dep=True needs ray_unit"
-        return autograd_ops.mlp(self, latent_variable_trans, latent_variable_light, points=points_3D,
-                                ray_unit=ray_unit)
+        lt, ll = self._per_image(latent_variable_trans, latent_variable_light, points_3D.shape[0])
+        return autograd_ops.mlp(self, lt, ll, points=points_3D, ray_unit=ray_unit)
 
     def forward_samples(self, opt, center, ray, depth_samples, latent_variable_trans=None,
                         latent_variable_light=None, mode=None):
         """center, ray [B,R,3], depth_samples [B,R,N,1]: points and unit view directions are formed inside the
         kernel (reference layers/...light.py:147-166)."""
-        return autograd_ops.mlp(self, latent_variable_trans, latent_variable_light, center=center, ray=ray,
-                                depth=depth_samples)
+        lt, ll = self._per_image(latent_variable_trans, latent_variable_light, center.shape[0])
+        return autograd_ops.mlp(self, lt, ll, center=center, ray=ray, depth=depth_samples)
+
+    @staticmethod
+    def _per_image(lat_trans, lat_light, B):
+        """The reference broadcasts a single latent row over the batch (val mode passes weight[0][None], :594-596)."""
+        if lat_trans.shape[0] == 1 and B > 1:
+            lat_trans = lat_trans.expand(B, -1)
+        if lat_light.shape[0] == 1 and B > 1:
+            lat_light = lat_light.expand(B, -1)
+        return lat_trans, lat_light
 
     @staticmethod
     def composite(opt, ray, rgb_samples, density_samples, depth_samples, uncert_samples=None):

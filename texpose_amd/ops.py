@@ -473,3 +473,40 @@ def nerf_losses_bwd(rgb: Tensor, uncert: Tensor, density: Tensor, gathered: Tens
     check(lib.tp_nerf_losses_bwd(C.byref(a), g_losses.data_ptr(), g_rgb.data_ptr(), g_unc.data_ptr(), g_den.data_ptr(),
                                  _stream()), "tp_nerf_losses_bwd")
     return g_rgb, g_unc, g_den
+
+
+def render_eval(packed: Tensor, intr: Tensor, pose: Tensor, ray_idx: Tensor, z_near: Tensor, z_far: Tensor, lat_trans: Tensor,
+                lat_light: Tensor, *, H: int, W: int, n_samples: int, precision: str = "f16x3", min_uncert: float = 0.05,
+                rand: Optional[Tensor] = None, with_alphas: bool = False):
+    """The C ABI's one-call evaluation render (tp_render_eval: ray-gen + MLP + composite, intermediates in one workspace).
+    Returns out_ray [B,R,14] (COMPOSITE_RAY_FIELDS) and, if asked, (alpha_static, alpha_transient) [B,R,N].  The Python
+    mirror (Graph.render) launches the same three kernels itself; this entry point exists for non-Python hosts."""
+    lib = _lib.load()
+    intr, pose = _f32(intr, "intr"), _f32(pose, "pose")
+    z_near, z_far = _f32(z_near, "z_near"), _f32(z_far, "z_far")
+    lat_trans, lat_light = _f32(lat_trans, "lat_trans"), _f32(lat_light, "lat_light")
+    ray_idx = ray_idx.to(torch.int64).contiguous()
+    B, R = ray_idx.shape
+    dev = pose.device
+    a = _lib.RenderEvalArgs()
+    rg = a.raygen
+    rg.intr, rg.pose, rg.ray_idx, rg.z_near, rg.z_far = intr.data_ptr(), pose.data_ptr(), ray_idx.data_ptr(), z_near.data_ptr(), z_far.data_ptr()
+    rg.B, rg.R, rg.H, rg.W, rg.N = B, R, H, W, n_samples
+    rg.pixel_mode, rg.bounds_mode = PIX_INDEX, BOUNDS_MAP
+    if rand is not None:
+        rand = _f32(rand, "rand")
+        rg.rand, rg.jitter_mode = rand.data_ptr(), JITTER_GIVEN
+    else:
+        rg.jitter_mode = JITTER_MID
+    a.packed, a.lat_trans, a.lat_light = packed.data_ptr(), lat_trans.data_ptr(), lat_light.data_ptr()
+    a.precision, a.min_uncert = PRECISIONS[precision], float(min_uncert)
+    a.status = mlp_status(dev).data_ptr() if precision == "f16x3" else None
+    ws = torch.empty(int(lib.tp_render_eval_workspace_bytes(B, R, n_samples)) // 4 + 64, device=dev)
+    out = torch.empty(B, R, 14, device=dev)
+    a.workspace, a.out_ray = ws.data_ptr(), out.data_ptr()
+    alphas = None
+    if with_alphas:
+        alphas = (torch.empty(B, R, n_samples, device=dev), torch.empty(B, R, n_samples, device=dev))
+        a.alpha_static, a.alpha_transient = alphas[0].data_ptr(), alphas[1].data_ptr()
+    check(lib.tp_render_eval(C.byref(a), _stream()), "tp_render_eval")
+    return (out, alphas) if with_alphas else out
