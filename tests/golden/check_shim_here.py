@@ -62,6 +62,24 @@ def main():
         b = [p for p in inspect.signature(getattr(Graph, name)).parameters if p != "self"]
         assert a == b[:len(a)], (name, a, b)
         print("signature ok:", name, a)
+    # the other classes / functions of the boundary: same argument names, same order
+    import camera as Rcam
+    from texpose_amd import geometry as G
+    from texpose_amd.nerf import NeRF as ANeRF
+    def args(f):
+        return [p for p in inspect.signature(f).parameters if p != "self"]
+    for ref_f, our_f, name in (
+            (NeRF.forward, ANeRF.forward, "NeRF.forward"), (NeRF.forward_samples, ANeRF.forward_samples, "NeRF.forward_samples"),
+            (NeRF.composite, ANeRF.composite, "NeRF.composite"), (NeRF.positional_encoding, ANeRF.positional_encoding, "NeRF.positional_encoding"),
+            (RaySampler.get_rays, G.RaySampler.get_rays, "RaySampler.get_rays"), (RaySampler.get_bounds, G.RaySampler.get_bounds, "RaySampler.get_bounds"),
+            (RaySampler.get_image, G.RaySampler.get_image, "RaySampler.get_image"),
+            (FlexPatchSampler.__call__, G.FlexPatchSampler.__call__, "FlexPatchSampler.__call__"),
+            (Rcam.get_center_and_ray, G.get_center_and_ray, "camera.get_center_and_ray"),
+            (Rcam.aabb_ray_intersection, G.aabb_ray_intersection, "camera.aabb_ray_intersection"),
+            (M.Graph.sample_depth, AmdGraph.sample_depth, "Graph.sample_depth"), (M.Graph.ray_batch_sample, AmdGraph.ray_batch_sample, "Graph.ray_batch_sample")):
+        a, b = args(ref_f), args(our_f)
+        assert a == b[:len(a)], (name, a, b)
+        print("signature ok:", name, a)
     print("shim check passed")
 
 
