@@ -1,0 +1,27 @@
+"""GPU box: 600 hipGraph-replayed GAN iterations (f16x3 recording forward, split-fp16 backward): finite losses and
+parameters, range flag clear."""
+import sys, os, json, torch
+sys.path.insert(0, os.getcwd())
+from texpose_amd.gan_modules import Discriminator, PerceptualLoss
+from texpose_amd.graph import Graph
+from texpose_amd.options import default_options, AttrDict
+from texpose_amd.synthetic import training_batch
+from texpose_amd.trainer import GraphedGanTrainer
+from texpose_amd import ops
+torch.manual_seed(0)
+opt = default_options(H=128, W=128, device="cuda:0")
+opt.batch_size, opt.patch_size, opt.nerf.sample_intvs = 4, 16, 64
+graph = Graph(opt, discriminator=Discriminator(opt), perceptual_loss=PerceptualLoss()).to("cuda:0")
+tr = GraphedGanTrainer(opt, graph, n_train=189)
+var = training_batch(4, 128, 128, device="cuda:0")
+hist = []
+for it in range(600):
+    _, loss = tr.train_iteration(AttrDict(dict(var)))
+    if it % 100 == 0 or it == 599:
+        hist.append({k: round(float(v), 5) for k, v in loss.items()})
+        print(it, hist[-1], flush=True)
+ops.check_mlp_status("cuda:0")
+sd = graph.state_dict()
+assert all(torch.isfinite(v).all() for v in sd.values() if v.dtype.is_floating_point)
+assert all(all(abs(v) < 1e6 for v in h.values()) for h in hist)      # (random-noise target images: no loss trend to expect)
+print("soak ok; patch sampler iterations", graph.patch_sampler.iterations, "progress", float(graph.discriminator.progress))
