@@ -30,7 +30,8 @@ def main():
         render_by_slices = AmdGraph.render_by_slices
         _slice_rays = staticmethod(AmdGraph._slice_rays)
         _jitter = staticmethod(AmdGraph._jitter)
-        _check_range = AmdGraph._check_range
+        _render_by_slices = AmdGraph._render_by_slices
+        _range_guarded = AmdGraph._range_guarded
         sample_depth = staticmethod(AmdGraph.sample_depth)
         ray_batch_sample = staticmethod(AmdGraph.ray_batch_sample)
         gather_patches = AmdGraph.gather_patches

@@ -1,0 +1,208 @@
+"""GPU tests at the literal sizes of BASELINE.json's configs (round-1 verdict: C3, the 480x640x256 leg of C5) and the
+device-side parity of the patch sampler.  Everything goes through the product API -> C ABI."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import texpose_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+RAY = dict(rtol=1e-4, atol=1e-6)
+
+
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a ROCm device"
+    return torch.device("cuda:0")
+
+
+def cu(t):
+    return t.to(dev())
+
+
+def rel_l2(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+# ------------------------------------------------------------------------------------------ a1 on the device
+def test_flex_patch_sampler_on_device_matches_oracle_and_golden():
+    """FlexPatchSampler.__call__ (reference tools/patch_sampler.py:80-114) evaluated on cuda:0: against the golden G0
+    captured from the reference (same uniforms), against the oracle for other batch / patch sizes, and the annealed
+    lower bound of the scale at several iteration counts (host float and the device scalar a captured step reads)."""
+    from texpose_amd.geometry import FlexPatchSampler
+    g = load_golden("g0_patch_sampler")
+    ps = FlexPatchSampler(True, scale_anneal=0.0002)
+    ps.iterations = g["iterations"]
+    u = torch.stack([g["u_scale"], g["u_hoff"], g["u_woff"]]).view(3, 4, 1, 1, 1)
+    coords, scales = ps(4, g["patch_size"], device=dev(), u=cu(u))
+    assert coords.is_cuda and scales.is_cuda
+    # the device evaluates the same mul / add chain: at most one ulp of fp32 (FMA contraction of s*lattice + shift)
+    torch.testing.assert_close(coords.cpu(), g["coords"], rtol=0, atol=1.2e-7)
+    torch.testing.assert_close(scales.cpu(), g["scales"], rtol=0, atol=6e-8)
+    rs = np.random.RandomState(3)
+    for B, p, it in ((1, 16, 0), (4, 16, 2500), (7, 32, 9000), (3, 64, 40000)):
+        ps.iterations = it
+        lo = O.patch_min_scale(it)
+        assert abs(ps.scale_range()[0] - lo) < 1e-12
+        uu = torch.from_numpy(rs.uniform(size=(3, B)).astype(np.float32))
+        c, s = ps(B, p, device=dev(), u=cu(uu).view(3, B, 1, 1, 1))
+        c_o, s_o = O.patch_coords(p, uu[0], uu[1], uu[2], lo)
+        torch.testing.assert_close(c.cpu(), c_o, rtol=0, atol=1.2e-7)
+        torch.testing.assert_close(s.cpu(), s_o, rtol=0, atol=6e-8)
+        assert float(c.abs().max()) <= 1.0 + 1e-6
+        # captured-step form: the bound comes from a 0-dim device tensor refreshed outside the graph
+        ps.device_lo = torch.zeros((), device=dev())
+        ps.update_device_bound()
+        c2, s2 = ps(B, p, device=dev(), u=cu(uu).view(3, B, 1, 1, 1))
+        torch.testing.assert_close(c2.cpu(), c_o, rtol=0, atol=1.2e-7)
+        assert abs(float(ps.device_lo) - lo) < 1e-7
+        ps.device_lo = None
+    # own draw: scales inside [lo, hi), coordinates inside the image
+    ps.iterations = 1000
+    c, s = ps(64, 16, device=dev())
+    lo = O.patch_min_scale(1000)
+    assert float(s.min()) >= lo - 1e-6 and float(s.max()) < 1.0 and float(c.abs().max()) <= 1.0 + 1e-6
+
+
+# ------------------------------------------------------------------------------------------ C3 at its literal size
+def _c3(graphed, train_precision="f16x3", seed=0):
+    from texpose_amd.gan_modules import Discriminator, PerceptualLoss
+    from texpose_amd.graph import Graph
+    from texpose_amd.options import default_options
+    from texpose_amd.trainer import GanTrainer, GraphedGanTrainer
+    torch.manual_seed(seed)
+    opt = default_options(H=128, W=128, device="cuda:0")
+    opt.batch_size, opt.patch_size, opt.nerf.sample_intvs = 4, 16, 64
+    graph = Graph(opt, discriminator=Discriminator(opt), perceptual_loss=PerceptualLoss()).to(dev())
+    graph.nerf.load_state_dict({**graph.nerf.state_dict(), **{k: cu(v) for k, v in O.make_params(41).items()}})
+    graph.nerf.train_precision = train_precision
+    graph.train()
+    tr = (GraphedGanTrainer if graphed else GanTrainer)(opt, graph, n_train=189)
+    return opt, graph, tr
+
+
+def test_c3_literal_size_train_iteration_eager_and_graphed():
+    """BASELINE config C3 as written (options/nerf_lm_adapt_gan.yaml:28,117-118 with batch 4): 4 images of 128x128,
+    16x16 patches, 64 samples per ray, full GAN loop (render fwd+bwd, gathers, feature loss, PatchGAN + R1, Adam +
+    RMSprop): one eager and one hipGraph-replayed iteration -- finite losses, frozen trunk untouched, heads /
+    latents / discriminator updated -- and the training-mode render forward at this size against the CPU oracle on
+    the rays the HIP ray-gen produced (1e-4)."""
+    from texpose_amd import ops
+    from texpose_amd.options import AttrDict
+    from texpose_amd.synthetic import training_batch
+    batch = training_batch(4, 128, 128, n_train=189, seed=3, device="cuda:0")
+    for graphed in (False, True):
+        opt, graph, tr = _c3(graphed)
+        trunk0 = [p.detach().clone() for p in graph.nerf.mlp_feat.parameters()]
+        head0 = graph.nerf.mlp_trans[1].weight.detach().clone()
+        disc0 = graph.discriminator.main[3].weight_orig.detach().clone()
+        emb0 = graph.latent_vars_trans.weight.detach().clone()
+        for _ in range(2):
+            var, loss = tr.train_iteration(AttrDict(dict(batch)))
+        vals = {k: float(v) for k, v in loss.items() if torch.is_tensor(v)}
+        assert all(np.isfinite(v) for v in vals.values()), vals
+        for k in ("render", "uncert", "trans_reg", "feat", "gan_nerf", "gan_disc_real", "gan_disc_fake", "gan_reg_real"):
+            assert k in vals, (graphed, sorted(vals))
+        assert var.ray_idx.shape == (4, 16, 16, 2)
+        ops.check_mlp_status(dev())
+        for p, q in zip(graph.nerf.mlp_feat.parameters(), trunk0):
+            assert torch.equal(p, q)
+        assert not torch.equal(graph.nerf.mlp_trans[1].weight, head0)
+        assert not torch.equal(graph.discriminator.main[3].weight_orig, disc0)
+        changed = (graph.latent_vars_trans.weight != emb0).any(dim=1)
+        assert set(torch.nonzero(changed).flatten().tolist()) <= set(batch.idx.tolist()) and changed.any()
+
+    # forward parity at this size: oracle on the HIP rays (identical sample positions, SURVEY 8d tolerances)
+    opt, graph, tr = _c3(False)
+    params = {k: v.detach().cpu() for k, v in graph.nerf.state_dict().items() if k.startswith("mlp_")}
+    var = AttrDict(dict(batch))
+    var = graph.get_ray_idx(opt, var)
+    rand = torch.rand(4, 256, 64, 1, device=dev())
+    dr = (batch.z_near[:, :, None], batch.z_far[:, :, None])
+    for prec in ("fp32", "f16x3"):
+        graph.nerf.train_precision = prec
+        ret = graph.render(opt, batch.pose_init, intr=batch.intr, ray_idx=var.ray_idx, depth_range=dr, sample_idx=batch.idx,
+                           mode="train", rand=rand)
+        c, r, _, _, depth = ops.raygen(batch.intr, batch.pose_init, H=128, W=128, n_samples=64, coords=var.ray_idx,
+                                       z_near=batch.z_near, z_far=batch.z_far, rand=rand)
+        et, el = graph.latent_vars_trans.weight.detach().cpu(), graph.latent_vars_light.weight.detach().cpu()
+        idx = batch.idx.cpu()
+        with torch.no_grad():
+            rgb_o, den_o, unc_o = O.forward_samples(params, c.cpu(), r.cpu(), depth.cpu()[..., None], et[idx], el[idx])
+            ref = O.composite(r.cpu(), rgb_o, den_o, depth.cpu()[..., None], unc_o, 0.05)
+        for k, o in (("rgb", ref[0]), ("rgb_static", ref[1]), ("rgb_transient", ref[2]), ("depth", ref[3]), ("uncert", ref[8])):
+            torch.testing.assert_close(ret[k].detach().cpu(), o, **RAY)
+        assert rel_l2(ret.density, den_o) < 1e-4 and rel_l2(ret.alpha_static, ref[9]) < 1e-4
+    ops.check_mlp_status(dev())
+
+
+# ------------------------------------------------------------------------------------------ C5, 480x640 x 256 samples
+def test_c5_config_480x640_n256():
+    """BASELINE config C5, the full-resolution leg (480x640, 256 samples per ray, all pixels = 78.6 M samples per
+    image): determinism, slice-size invariance (bit for bit), f16x3 == exact fp32 at the 1e-4 bar, and a 4096-ray
+    strip against the CPU oracle."""
+    from texpose_amd import ops
+    from texpose_amd import synthetic as S
+    from texpose_amd.graph import Graph
+    from texpose_amd.options import default_options
+    H, W, N = 480, 640, 256
+    sc = S.eval_scene(H, W, B=1, seed=12)
+    near, far = S.scene_bounds(sc, H, W, dev())
+    params = S.network_weights(3)
+    rs = np.random.RandomState(6)
+    emb_t = torch.from_numpy(rs.normal(size=(189, 16)).astype(np.float32))
+    emb_l = torch.from_numpy(rs.normal(size=(189, 48)).astype(np.float32))
+    pose, intr = cu(sc["pose"]), cu(sc["intr"])
+    dr = (near[:, :, None], far[:, :, None])
+    mask = torch.ones(1, H, W, device=dev())
+    keys = ("rgb", "rgb_static", "depth", "uncert", "opacity")
+    outs = {}
+    for prec in ("fp32", "f16x3"):
+        opt = default_options(H=H, W=W, device="cuda:0")
+        opt.nerf.sample_intvs, opt.batch_size, opt.nerf.sample_stratified = N, 1, False
+        g = Graph(opt).to(dev())
+        g.nerf.load_state_dict({**g.nerf.state_dict(), **{k: cu(v) for k, v in params.items()}})
+        g.attach_latents(189, opt)
+        with torch.no_grad():
+            g.latent_vars_trans.weight.copy_(emb_t)
+            g.latent_vars_light.weight.copy_(emb_l)
+        g.nerf.precision = prec
+        g.eval()
+        with torch.no_grad():
+            whole = g.render_by_slices(opt, pose, intr=intr, depth_range=dr, object_mask=mask, sample_idx=None, mode="val")
+            keep = {k: whole[k].clone() for k in keys}
+            assert whole.density.shape == (1, H * W, N, 2) and whole.alpha_static.shape == (1, H * W, N)
+            del whole
+            if prec == "f16x3":
+                again = g.render_by_slices(opt, pose, intr=intr, depth_range=dr, object_mask=mask, sample_idx=None, mode="val")
+                for k in keys:
+                    assert torch.equal(keep[k], again[k]), (prec, k)
+                del again
+            opt.nerf.slice_rays = 50000                     # ragged: 307200 = 6 * 50000 + 7200
+            sliced = g.render_by_slices(opt, pose, intr=intr, depth_range=dr, object_mask=mask, sample_idx=None, mode="val")
+            for k in keys:
+                assert torch.equal(keep[k], sliced[k]), (prec, k)
+            del sliced
+        ops.check_mlp_status(dev())
+        assert float((keep["opacity"] - 1).abs().max()) < 2e-5
+        d = keep["depth"][0, :, 0]
+        assert bool(((d >= near[0] - 1e-4) & (d <= far[0] + 1e-4)).all())
+        outs[prec] = keep
+        torch.cuda.empty_cache()
+    for k in ("rgb", "rgb_static", "depth", "uncert"):
+        torch.testing.assert_close(outs["f16x3"][k], outs["fp32"][k], rtol=1e-4, atol=1e-6)
+    row = 240
+    idx = torch.arange(row * W, row * W + 4096)[None]
+    with torch.no_grad():
+        ref = O.render(params, emb_t, emb_l, sc["pose"], sc["intr"], idx, (near.cpu()[:, :, None], far.cpu()[:, :, None]), None,
+                       "val", H, W, N)
+    # (a handful of rays sit on the reference's own fp32 conditioning limit at 256 samples per ray -- a 1-ulp change of
+    # a sample position moves the 2^9 pi encoding band by 1e-3 rad -- so the per-element bar is statistical here, as in
+    # test_c5_config_240x320_n256)
+    for k in ("rgb", "rgb_static", "depth", "uncert"):
+        a, r = outs["fp32"][k][:, row * W:row * W + 4096].cpu(), ref[k]
+        assert rel_l2(a, r) < 2e-5, (k, rel_l2(a, r))
+        bad = ((a - r).abs() > 2e-4 * r.abs() + 2e-5).float().mean()
+        assert float(bad) < 2e-3 and float((a - r).abs().max()) < 2e-3, (k, float(bad), float((a - r).abs().max()))

@@ -623,6 +623,133 @@ def test_mlp_f16x3_range_flag(ops):
     from texpose_amd._lib import TexposeLibraryError
     with pytest.raises(TexposeLibraryError):
         ops.check_mlp_status(dev())
+    ops.check_mlp_status(dev())                        # a reported violation is cleared: later renders start clean
+    assert int(ops.mlp_status(dev()).item()) == 0
+
+
+def _big_activation_params(seed=31):
+    params = O.make_params(seed)
+    return {k: (v * 300.0 if k in ("mlp_feat.2.weight", "mlp_feat.3.weight") else v) for k, v in params.items()}
+
+
+def test_f16x3_range_flag_falls_back_to_fp32_in_render_by_slices(ops):
+    """A network whose activations leave the fp16 range renders through Graph.render_by_slices WITHOUT raising: the
+    flagged image is rendered again by the exact-fp32 kernel in the same call (bit-identical to selecting
+    arch.mlp_precision='fp32'), for the val and the eval path, and the flag is left clean."""
+    import warnings
+    H, W, N = 16, 16, 32
+    sc = O.synthetic_scene(H, W, B=1, seed=1)
+    K = sc["intr"].clone()
+    K[:, 0, 0] = K[:, 1, 1] = 700.0 * H / 128.0
+    K[:, 0, 2], K[:, 1, 2] = W / 2.0, H / 2.0
+    graph, opt = _graph(_big_activation_params(), H=H, W=W, N=N)
+    opt.nerf.sample_stratified = False
+    graph.eval()
+    dr = (cu(sc["z_near"])[:, :, None], cu(sc["z_far"])[:, :, None])
+    mask = torch.ones(1, H, W, device=dev())
+    mask[0, :3] = 0
+    ops.mlp_status(dev()).zero_()
+    for mode, sidx in (("val", None), ("eval_noalign", torch.tensor(2, device=dev()))):
+        graph.nerf.precision = "fp32"
+        with torch.no_grad():
+            want = graph.render_by_slices(opt, cu(sc["pose"]), intr=cu(K), depth_range=dr, object_mask=mask, sample_idx=sidx, mode=mode)
+        graph.nerf.precision = "f16x3"
+        graph.range_fallbacks = 0
+        with torch.no_grad(), warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            got = graph.render_by_slices(opt, cu(sc["pose"]), intr=cu(K), depth_range=dr, object_mask=mask, sample_idx=sidx, mode=mode)
+        assert graph.range_fallbacks == 1 and graph.nerf.precision == "f16x3"
+        for k in ("rgb", "rgb_static", "depth", "uncert", "density", "alpha_static"):
+            assert torch.equal(got[k], want[k]), (mode, k)
+        assert int(ops.mlp_status(dev()).item()) == 0
+    # an in-range network does not fall back
+    graph2, opt2 = _graph(O.make_params(31), H=H, W=W, N=N)
+    graph2.eval()
+    with torch.no_grad():
+        graph2.render_by_slices(opt2, cu(sc["pose"]), intr=cu(K), depth_range=dr, object_mask=mask, sample_idx=None, mode="val")
+    assert getattr(graph2, "range_fallbacks", 0) == 0
+
+
+@pytest.mark.parametrize("graphed", [False, True])
+def test_flagged_training_iteration_applies_no_update(ops, graphed):
+    """A training iteration whose f16x3 recording forward raises the range flag must not move any parameter from that
+    forward: the eager trainer repeats the step with the fp32 recording forward (and equals a trainer that used fp32
+    from the start); the captured trainer withholds the flagged updates on the device (parameters bit-for-bit
+    unchanged) and re-captures with fp32."""
+    import warnings
+    from texpose_amd.gan_modules import Discriminator
+    from texpose_amd.graph import Graph
+    from texpose_amd.options import default_options, AttrDict
+    from texpose_amd.synthetic import training_batch
+    from texpose_amd.trainer import GanTrainer, GraphedGanTrainer
+    B, H, W, N = 2, 32, 32, 8
+    batch = training_batch(B, H, W, n_train=5, seed=2, device="cuda:0")
+    rnd = (torch.rand(3, B, 1, 1, 1, device=dev()), torch.rand(B, 256, N, 1, device=dev()))
+
+    def build(cls, train_precision):
+        opt = default_options(H=H, W=W, device="cuda:0")
+        opt.batch_size, opt.patch_size, opt.nerf.sample_intvs = B, 16, N
+        opt.loss_weight.feat = None
+        graph = Graph(opt, discriminator=Discriminator(opt)).to(dev())
+        graph.nerf.load_state_dict({**graph.nerf.state_dict(), **{k: cu(v) for k, v in _big_activation_params(6).items()}})
+        dcpu = Discriminator(opt)
+        O.seed_spectral_module(dcpu, 10)
+        graph.discriminator.load_state_dict(dcpu.state_dict())
+        graph.train()
+        graph.nerf.train_precision = train_precision
+        tr = cls(opt, graph, n_train=5)
+        with torch.no_grad():
+            graph.latent_vars_trans.weight.fill_(0.1)
+            graph.latent_vars_light.weight.fill_(-0.2)
+        return tr, graph
+
+    def batch_var():
+        v = AttrDict(dict(batch))
+        v.patch_u, v.jitter_rand = rnd
+        return v
+
+    ops.mlp_status(dev()).zero_()
+    if not graphed:
+        ref_tr, ref_g = build(GanTrainer, "fp32")
+        snap = {k: v.detach().clone() for k, v in ref_g.state_dict().items()}
+        ref_tr.train_iteration(batch_var())
+        tr, g = build(GanTrainer, "f16x3")
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            _, loss = tr.train_iteration(batch_var())
+        assert tr.skipped_steps == 1 and g.nerf.train_precision == "fp32"
+        assert all(np.isfinite(float(x)) for x in loss.values())
+        # same weights, batch and random numbers: the repeated step is the fp32 trainer's step (up to the one extra
+        # spectral-norm power iteration the dropped attempt ran inside the discriminator)
+        pick = lambda sd: {k: v for k, v in sd.items() if k.startswith(("nerf.", "latent"))}
+        assert_updates_close(pick(g.state_dict()), pick(ref_g.state_dict()), snap)
+        assert not torch.equal(g.state_dict()["nerf.mlp_rgb.0.weight"], snap["nerf.mlp_rgb.0.weight"])
+    else:
+        tr, g = build(GraphedGanTrainer, "f16x3")
+        snap = {k: v.detach().clone() for k, v in g.state_dict().items()}
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            tr.capture(batch_var(), warmup=2)          # warm-up iterations are flagged: rolled back, re-captured in fp32
+        assert g.nerf.train_precision == "fp32" and tr.skipped_steps >= 1
+        for k, v in g.state_dict().items():
+            if not (k.endswith("weight_u") or k.endswith("weight_v")):
+                assert torch.equal(v, snap[k]), k
+        # the device-side gate itself: force the flag while an f16x3 capture is live -> replays change nothing
+        tr2, g2 = build(GraphedGanTrainer, "fp32")
+        tr2.capture(batch_var(), warmup=2)
+        tr2.train_iteration(batch_var())
+        torch.cuda.synchronize()
+        before = {k: v.detach().clone() for k, v in g2.state_dict().items()}
+        tr2._bad[0] = 1                                  # what a raised range flag leaves in the gate word
+        tr2._graph.replay()
+        torch.cuda.synchronize()
+        for k, v in g2.state_dict().items():
+            if k.startswith(("nerf.", "latent")) or "weight_orig" in k:
+                assert torch.equal(v, before[k]), k
+        tr2._bad.zero_()
+        tr2._graph.replay()
+        torch.cuda.synchronize()
+        assert not torch.equal(g2.state_dict()["nerf.mlp_rgb.0.weight"], before["nerf.mlp_rgb.0.weight"])
     ops.mlp_status(dev()).zero_()
 
 

@@ -160,8 +160,10 @@ class PerceptualLoss(nn.Module):
         for q in self.model.parameters():
             q.requires_grad = False
         self.model.eval()
-        self.register_buffer("mean", torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1))
-        self.register_buffer("std", torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1))
+        # ImageNet normalisation constants: NOT part of the state dict (the reference uses transforms.Normalize and has
+        # no such keys, layers/perceptual_loss.py:19-20), otherwise reference checkpoints would not load strictly
+        self.register_buffer("mean", torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1), persistent=False)
+        self.register_buffer("std", torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1), persistent=False)
 
     def forward(self, fake, real):
         f = self.model((fake - self.mean) / self.std)

@@ -16,6 +16,7 @@ injected, not re-implemented.
 from __future__ import annotations
 
 import itertools
+import warnings
 
 import torch
 import torch.nn.functional as torch_F
@@ -124,12 +125,29 @@ class Graph(torch.nn.Module):
                      opacity_static=opacity_static, opacity_transient=opacity_transient, uncert=uncert,
                      depth=depth_map, alpha_static=alpha_static, alpha_transient=alpha_transient, density=density_s)
 
-    def _check_range(self, device):
-        """The f16x3 MLP raises a device flag if an activation left the fp16 range (then images must be re-rendered
-        with arch.mlp_precision='fp32').  Polled without a host sync: a violation surfaces at the next image at
-        the latest; ops.check_mlp_status(device) is the blocking form."""
-        if self.nerf.precision == "f16x3" and not torch.is_grad_enabled():
-            ops.poll_mlp_status(device)
+    def _range_guarded(self, opt, device, render_image):
+        """``render_image()`` renders one whole image with the MLP kernel currently selected.  The f16x3 kernel raises a
+        device flag if an activation left the fp16 range; the flag is read (and cleared) once per image -- one host
+        sync per ~0.2 s image -- and a flagged image is rendered again, in the same call, with the exact-fp32 kernel.
+        The caller never has to catch and retry.  ``opt.arch.mlp_range_check = 'off'`` skips the read (the flag then
+        stays set for ops.check_mlp_status)."""
+        out = render_image()
+        nerf = self.nerf
+        if "f16x3" not in (nerf.precision, nerf.train_precision) or opt.arch.get("mlp_range_check", "sync") == "off" \
+                or torch.cuda.is_current_stream_capturing():
+            return out
+        if ops.take_mlp_status(device) & 1:
+            self.range_fallbacks = getattr(self, "range_fallbacks", 0) + 1
+            if self.range_fallbacks == 1:
+                warnings.warn("texpose_amd: an activation left the fp16 range of the f16x3 MLP kernel; the image was "
+                              "re-rendered with the exact-fp32 kernel (arch.mlp_precision='fp32' avoids the double work)")
+            keep = nerf.precision, nerf.train_precision
+            nerf.precision = nerf.train_precision = "fp32"
+            try:
+                out = render_image()
+            finally:
+                nerf.precision, nerf.train_precision = keep
+        return out
 
     @staticmethod
     def _slice_rays(opt):
@@ -137,6 +155,10 @@ class Graph(torch.nn.Module):
         return int(opt.nerf.get("slice_rays") or max(opt.nerf.rand_rays, min(opt.H * opt.W, 1 << 20)))
 
     def render_by_slices(self, opt, pose, intr=None, depth_range=None, object_mask=None, sample_idx=None, mode=None):
+        return self._range_guarded(opt, pose.device, lambda: self._render_by_slices(
+            opt, pose, intr=intr, depth_range=depth_range, object_mask=object_mask, sample_idx=sample_idx, mode=mode))
+
+    def _render_by_slices(self, opt, pose, intr=None, depth_range=None, object_mask=None, sample_idx=None, mode=None):
         HW = opt.H * opt.W
         step = self._slice_rays(opt)
         if mode == "val":
@@ -147,7 +169,6 @@ class Graph(torch.nn.Module):
                                   mode=mode)
                 for k in RENDER_KEYS:
                     parts[k].append(ret[k])
-            self._check_range(pose.device)
             return edict({k: (v[0] if len(v) == 1 else torch.cat(v, dim=1)) for k, v in parts.items()})
         # eval: only object pixels are rendered and scattered into default-filled maps (reference :652-680; B == 1)
         dev, N = pose.device, opt.nerf.sample_intvs
@@ -170,7 +191,6 @@ class Graph(torch.nn.Module):
                               mode=mode)
             for k in RENDER_KEYS:
                 out[k][:, idx[0]] = ret[k][0]
-        self._check_range(pose.device)
         return out
 
     # ------------------------------------------------------------------ consumers of render()
@@ -344,14 +364,18 @@ class Graph(torch.nn.Module):
         return loss / len(d_outs)
 
 
-def summarize_loss(opt, loss):
-    """total = sum 10^w * loss (reference model/base.py:145-157) with the NaN/Inf checks done ONCE on the
-    weighted sum (one host sync per step instead of one per term)."""
+def summarize_loss(opt, loss, check_finite: bool = False):
+    """total = sum 10^w * loss (reference model/base.py:145-157).  The reference asserts every weighted term finite
+    (:153-154: one host sync per term); ``check_finite=True`` does it ONCE on the weighted sum (a non-finite term makes
+    the sum non-finite) and raises FloatingPointError before anything is back-propagated.  The trainers leave it off and
+    fold the check into the read they already do before the optimiser step (texpose_amd/trainer.py)."""
     assert "all" not in loss
     total = 0.
     for key in loss:
         assert key in opt.loss_weight and loss[key].shape == ()
         if opt.loss_weight[key] is not None:
             total = total + 10 ** float(opt.loss_weight[key]) * loss[key]
+    if check_finite and torch.is_tensor(total) and not bool(torch.isfinite(total)):
+        raise FloatingPointError("non-finite loss: " + ", ".join("%s=%g" % (k, float(v)) for k, v in loss.items()))
     loss.update(all=total)
     return loss

@@ -8,6 +8,7 @@ eager fallback.
 from __future__ import annotations
 
 import ctypes as C
+import functools
 from typing import Dict, Optional, Tuple
 
 import torch
@@ -34,6 +35,35 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+def _tensors(objs):
+    for o in objs:
+        if isinstance(o, torch.Tensor):
+            yield o
+        elif isinstance(o, (list, tuple)):
+            yield from _tensors(o)
+        elif isinstance(o, dict):
+            yield from _tensors(o.values())
+
+
+def _on_tensor_device(fn):
+    """The C entry points launch on the CURRENT HIP device and stream (and keep per-device kernel attributes): make the
+    tensors' own device current for the call, and refuse arguments that live on different devices."""
+    @functools.wraps(fn)
+    def wrapped(*args, **kwargs):
+        dev = None
+        for t in _tensors(args + tuple(kwargs.values())):
+            if t.is_cuda:
+                if dev is None:
+                    dev = t.device
+                elif t.device != dev:
+                    raise _lib.TexposeLibraryError(f"{fn.__name__}: tensors on different devices ({dev} and {t.device})")
+        if dev is None or dev.index == torch.cuda.current_device():
+            return fn(*args, **kwargs)
+        with torch.cuda.device(dev):
+            return fn(*args, **kwargs)
+    return wrapped
+
+
 def _f32(t: Tensor, name: str) -> Tensor:
     if not t.is_cuda:
         raise _lib.TexposeLibraryError(f"{name} must live on the GPU (texpose_amd has no CPU path)")
@@ -47,6 +77,7 @@ def _ptr(t: Optional[Tensor]) -> Optional[int]:
 
 
 # ------------------------------------------------------------------------------------------ K1
+@_on_tensor_device
 def raygen(intr: Tensor, pose: Tensor, *, H: int, W: int, n_samples: int = 0, coords: Optional[Tensor] = None,
            ray_idx: Optional[Tensor] = None, z_near: Optional[Tensor] = None, z_far: Optional[Tensor] = None,
            aabb: Optional[Tuple[Tuple[float, float, float], Tuple[float, float, float]]] = None,
@@ -101,6 +132,7 @@ def raygen(intr: Tensor, pose: Tensor, *, H: int, W: int, n_samples: int = 0, co
     return center, ray, near, far, depth
 
 
+@_on_tensor_device
 def aabb_intersect(aabb_min, aabb_max, o: Tensor, d: Tensor):
     lib = _lib.load()
     o, d = _f32(o, "ray_o"), _f32(d, "ray_d")
@@ -115,6 +147,7 @@ def aabb_intersect(aabb_min, aabb_max, o: Tensor, d: Tensor):
     return tn, tf, ok.bool()
 
 
+@_on_tensor_device
 def sample_depth(near: Tensor, far: Tensor, n_samples: int, rand: Optional[Tensor] = None, jitter: int = JITTER_MID,
                  seed: int = 0, offset: int = 0) -> Tensor:
     lib = _lib.load()
@@ -132,6 +165,7 @@ def packed_bytes() -> int:
     return int(_lib.load().tp_mlp_packed_bytes())
 
 
+@_on_tensor_device
 def pack_weights(state: Dict[str, Tensor], packed: Optional[Tensor] = None, parts: int = PACK_ALL,
                  prefix: str = "", precision: str = "fp32") -> Tensor:
     """state: reference state-dict style mapping (``mlp_feat.0.weight`` ...) of CUDA tensors.
@@ -173,6 +207,8 @@ def _workspace(n_samples: int, dev: torch.device) -> Tensor:
 
 
 _status_words: Dict[int, Tensor] = {}
+RANGE_MESSAGE = ("f16x3 MLP: an activation exceeded the fp16 range (6e4); render with precision='fp32' "
+                 "(Graph.render_by_slices and the trainers do that by themselves)")
 
 
 def mlp_status(device) -> Tensor:
@@ -183,34 +219,49 @@ def mlp_status(device) -> Tensor:
     return _status_words[key]
 
 
+def take_mlp_status(device) -> int:
+    """Blocking read-and-clear of the status word: what was raised since the last take.  One host sync."""
+    word = mlp_status(device)
+    value = int(word.item())
+    if value:
+        word.zero_()
+    return value
+
+
 def check_mlp_status(device) -> None:
-    """Host-synchronising check of the f16x3 range flag (call it outside the hot loop)."""
-    if int(mlp_status(device).item()) & 1:
-        raise _lib.TexposeLibraryError("f16x3 MLP: an activation exceeded the fp16 range (6e4); render with "
-                                       "precision='fp32'")
+    """Host-synchronising check of the f16x3 range flag; a reported violation is cleared (later renders start clean)."""
+    if take_mlp_status(device) & 1:
+        raise _lib.TexposeLibraryError(RANGE_MESSAGE)
 
 
 _status_polls: Dict[int, tuple] = {}
 
 
-def poll_mlp_status(device) -> None:
-    """Non-blocking variant for per-image use: looks at the copy requested by the PREVIOUS poll if it has
-    completed (raising if the flag was set) and queues a new asynchronous copy of the flag."""
+def poll_mlp_status(device, raise_on_flag: bool = True) -> bool:
+    """Non-blocking variant: looks at the copy requested by the PREVIOUS poll if it has completed and queues a new
+    asynchronous copy of the flag.  A seen violation is cleared on the device (queued on the current stream) and
+    either raised or returned as True."""
     key = torch.device(device).index or 0
     prev = _status_polls.get(key)
+    seen = False
     if prev is not None and prev[1].query():
-        if int(prev[0][0]) & 1:
-            raise _lib.TexposeLibraryError("f16x3 MLP: an activation exceeded the fp16 range (6e4); render with "
-                                           "precision='fp32'")
+        seen = bool(int(prev[0][0]) & 1)
         prev = None
+        _status_polls.pop(key, None)
+        if seen:
+            mlp_status(device).zero_()
+            if raise_on_flag:
+                raise _lib.TexposeLibraryError(RANGE_MESSAGE)
     if prev is None:
         host = torch.empty(1, dtype=torch.int32, pin_memory=True)
         host.copy_(mlp_status(device), non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
         _status_polls[key] = (host, ev)
+    return seen
 
 
+@_on_tensor_device
 def mlp_forward(packed: Tensor, lat_trans: Tensor, lat_light: Tensor, *, center: Optional[Tensor] = None,
                 ray: Optional[Tensor] = None, depth: Optional[Tensor] = None, points: Optional[Tensor] = None,
                 ray_unit: Optional[Tensor] = None, save: bool = False, precision: str = "fp32"):
@@ -254,6 +305,7 @@ def mlp_forward(packed: Tensor, lat_trans: Tensor, lat_light: Tensor, *, center:
 _bwd_scratch: Dict[Tuple[int, int], Dict[str, Tensor]] = {}
 
 
+@_on_tensor_device
 def mlp_backward(nerf, lat_trans: Tensor, lat_light: Tensor, saved: Tensor, rgb: Tensor, density: Tensor,
                  uncert: Tensor, g_rgb: Optional[Tensor], g_density: Optional[Tensor], g_uncert: Optional[Tensor],
                  wgrad_precision: str = "fp32"):
@@ -303,6 +355,7 @@ def mlp_backward(nerf, lat_trans: Tensor, lat_light: Tensor, saved: Tensor, rgb:
     return dict(params=grads, lat_trans=g_lt, lat_light=g_ll)
 
 
+@_on_tensor_device
 def posenc(x: Tensor, L: int) -> Tensor:
     lib = _lib.load()
     x = _f32(x, "x")
@@ -325,6 +378,7 @@ def _composite_args(ray, rgb, density, depth, uncert, min_uncert) -> Tuple[Compo
     return a, (ray, rgb, density, depth, uncert)
 
 
+@_on_tensor_device
 def composite_fwd(ray, rgb, density, depth, uncert, min_uncert: float = 0.05, per_sample: bool = True,
                   want_prob: bool = True):
     """-> out_ray [..,14], alpha_static, alpha_transient, prob ([..,N] or None)."""
@@ -341,6 +395,7 @@ def composite_fwd(ray, rgb, density, depth, uncert, min_uncert: float = 0.05, pe
     return out, a_s, a_t, prob
 
 
+@_on_tensor_device
 def composite_bwd(ray, rgb, density, depth, uncert, g_out: Tensor, g_alpha_s: Optional[Tensor] = None,
                   g_alpha_t: Optional[Tensor] = None, g_prob: Optional[Tensor] = None, min_uncert: float = 0.05):
     lib = _lib.load()
@@ -358,6 +413,7 @@ def composite_bwd(ray, rgb, density, depth, uncert, g_out: Tensor, g_alpha_s: Op
 
 
 # ------------------------------------------------------------------------------------------ K5
+@_on_tensor_device
 def patch_gather(coords: Tensor, image: Tensor, image_syn: Tensor, nocs: Tensor, normal: Tensor, obj_mask: Tensor,
                  mask_syn: Tensor) -> Tensor:
     """-> [B,14,p,p]: image3, image_syn3, nocs3*mask_syn, normal3*mask_syn, mask, mask_syn."""
@@ -375,6 +431,7 @@ def patch_gather(coords: Tensor, image: Tensor, image_syn: Tensor, nocs: Tensor,
     return out
 
 
+@_on_tensor_device
 def eval_metrics(rgb_static: Tensor, image: Tensor, obj_mask: Tensor, H: int, W: int, out_hw=None):
     """PSNR / SSIM of the static render against the masked image (reference evaluate_full, :340-362).
     rgb_static [B,H*W,3], image [B,3,H,W], obj_mask [B,H,W]; ``out_hw`` = (480, 640) reproduces the resize the
@@ -397,6 +454,7 @@ def eval_metrics(rgb_static: Tensor, image: Tensor, obj_mask: Tensor, H: int, W:
     return -10.0 * torch.log10(mse), out[:, 1].sum() / n, mse
 
 
+@_on_tensor_device
 def spectral_norm_fwd(weights, us, vs, training: bool):
     """weights[i] [out, ...] (contiguous), us[i] [out], vs[i] [K]: one power iteration per weight when ``training``
     (u, v updated IN PLACE, like torch.nn.utils.spectral_norm), then W_sn = W / sigma.  Returns (W_sn list, sigma
@@ -418,6 +476,7 @@ def spectral_norm_fwd(weights, us, vs, training: bool):
     return outs, sigmas
 
 
+@_on_tensor_device
 def spectral_norm_bwd(grads_sn, weights_sn, us, vs, sigmas):
     """dL/dW from dL/dW_sn with u, v treated as constants (torch's convention): (G - <G, W_sn> u v^T) / sigma."""
     lib = _lib.load()
@@ -452,6 +511,7 @@ def _nerf_losses_args(rgb, uncert, density, gathered):
     return lib, a, (rgb, uncert, density, gathered)
 
 
+@_on_tensor_device
 def nerf_losses_fwd(rgb: Tensor, uncert: Tensor, density: Tensor, gathered: Tensor):
     """Four fp64 sums [sum m*se/u^2, sum m, sum log u^2, sum sigma_t] (device tensor) for the render / uncert /
     trans_reg terms of the generator step (reference compute_loss :747-760)."""
@@ -463,6 +523,7 @@ def nerf_losses_fwd(rgb: Tensor, uncert: Tensor, density: Tensor, gathered: Tens
     return sums
 
 
+@_on_tensor_device
 def nerf_losses_bwd(rgb: Tensor, uncert: Tensor, density: Tensor, gathered: Tensor, sums: Tensor, g_losses: Tensor):
     """Gradients wrt rgb, uncert, density for upstream gradients g_losses [3] (render, uncert, trans_reg)."""
     lib, a, keep = _nerf_losses_args(rgb, uncert, density, gathered)
@@ -475,6 +536,7 @@ def nerf_losses_bwd(rgb: Tensor, uncert: Tensor, density: Tensor, gathered: Tens
     return g_rgb, g_unc, g_den
 
 
+@_on_tensor_device
 def render_eval(packed: Tensor, intr: Tensor, pose: Tensor, ray_idx: Tensor, z_near: Tensor, z_far: Tensor, lat_trans: Tensor,
                 lat_light: Tensor, *, H: int, W: int, n_samples: int, precision: str = "f16x3", min_uncert: float = 0.05,
                 rand: Optional[Tensor] = None, with_alphas: bool = False):

@@ -4,10 +4,24 @@ gathers, discriminator on the fake patch, photometric / uncertainty / transient 
 Adam) -> discriminator step (real + R1 penalty + fake, RMSprop).  Used by bench.py and the tests; the
 reference's own engine runs unchanged against texpose_amd.graph.Graph.
 
-Data parallel: pass ``world_size > 1`` after texpose_amd.dist.init_distributed(); gradients of each
-optimiser are averaged with ONE flat all-reduce after all backward calls of that step.
+No optimiser step is ever applied from a bad forward.  The reference asserts every loss term finite before
+``backward`` (model/base.py:153-154); here the check sits before ``optimizer.step()`` and also covers the range
+flag of the f16x3 recording forward (an activation beyond the fp16 range):
+  * eager trainer: one blocking read per optimiser step of [range flag, isfinite(loss)].  A raised range flag
+    drops the gradients, switches the recording forward to the exact-fp32 kernel for good and repeats the step;
+    a non-finite loss raises FloatingPointError with the parameters untouched;
+  * hipGraph trainer: the same predicate is evaluated on the device inside the captured step and gates the
+    update (gradients and learning rate multiplied by 0/1: Adam and RMSprop then leave every parameter bit-for-bit
+    unchanged); the host learns about it from an asynchronous copy one or two replays later, and either
+    re-captures with the fp32 recording forward (range flag) or raises (non-finite loss).
+
+Data parallel: pass a process group after texpose_amd.dist.init_distributed(); gradients of each optimiser
+are averaged with ONE flat all-reduce after all backward calls of that step (tools/train_dp.py is the entry point).
 """
 from __future__ import annotations
+
+import copy
+import warnings
 
 import torch
 
@@ -20,46 +34,87 @@ from .options import AttrDict
 class GanTrainer:
     capturable = False                       # optimiser state on the device (required inside a hipGraph)
 
-    def __init__(self, opt, graph: Graph, n_train: int, max_iter: int = 6000 * 189 // 8):
+    def __init__(self, opt, graph: Graph, n_train: int, max_iter: int = 6000 * 189 // 8, group=None):
         self.opt, self.graph, self.max_iter, self.it = opt, graph, max_iter, 0
         if not hasattr(graph, "latent_vars_trans"):
             graph.attach_latents(n_train, opt)
-        nerf_params = [p for p in graph.nerf.parameters() if p.requires_grad]
-        self.nerf_group = nerf_params + list(graph.latent_vars_light.parameters()) + \
+        # group 0 holds EVERY nerf parameter like the reference's optimiser (model/nerf_adapt_st_gan.py:62-68: the frozen
+        # trunk and `progress` never get a gradient and are skipped by Adam), so that a saved `optim_nerf` state has
+        # the reference's group sizes (33 / 1 / 1) and loads on resume in either direction
+        nerf_params = list(graph.nerf.parameters())
+        self.nerf_group = [p for p in nerf_params if p.requires_grad] + list(graph.latent_vars_light.parameters()) + \
             list(graph.latent_vars_trans.parameters())
         # a captured step reads its learning rates from device memory, so that a scheduler (the reference decays the
         # nerf rate per epoch, ExponentialLR, model/nerf_adapt_st_gan.py:73-84) can change them between replays
         dev = nerf_params[0].device
-        self.lr_nerf = torch.tensor(float(opt.optim.lr), device=dev) if self.capturable else float(opt.optim.lr)
-        self.optim_nerf = torch.optim.Adam([dict(params=nerf_params, lr=self.lr_nerf),
-                                            dict(params=graph.latent_vars_light.parameters(), lr=self.lr_nerf),
-                                            dict(params=graph.latent_vars_trans.parameters(), lr=self.lr_nerf)],
+        mk = (lambda v: torch.tensor(float(v), device=dev)) if self.capturable else float
+        self.lr_nerf = mk(opt.optim.lr)
+        self.lr_nerf_used = mk(opt.optim.lr)               # what the optimiser reads (captured: lr x the step gate)
+        self.optim_nerf = torch.optim.Adam([dict(params=nerf_params, lr=self.lr_nerf_used),
+                                            dict(params=graph.latent_vars_light.parameters(), lr=self.lr_nerf_used),
+                                            dict(params=graph.latent_vars_trans.parameters(), lr=self.lr_nerf_used)],
                                            capturable=self.capturable)
         self.has_disc = hasattr(graph, "discriminator") and opt.gan is not None
         if self.has_disc:
             self.disc_group = [p for p in graph.discriminator.parameters()]
-            self.lr_disc = torch.tensor(float(opt.optim_disc.lr), device=dev) if self.capturable else float(opt.optim_disc.lr)
-            self.optim_disc = torch.optim.RMSprop([dict(params=self.disc_group, lr=self.lr_disc)],
+            self.lr_disc = mk(opt.optim_disc.lr)
+            self.lr_disc_used = mk(opt.optim_disc.lr)
+            self.optim_disc = torch.optim.RMSprop([dict(params=self.disc_group, lr=self.lr_disc_used)],
                                                   capturable=self.capturable)
-        self.red_nerf = tdist.FlatGradAllReducer(self.nerf_group)
-        self.red_disc = tdist.FlatGradAllReducer(self.disc_group) if self.has_disc else None
+        self.red_nerf = tdist.FlatGradAllReducer(self.nerf_group, group=group)
+        self.red_disc = tdist.FlatGradAllReducer(self.disc_group, group=group) if self.has_disc else None
+        self.skipped_steps = 0                   # optimiser steps withheld because the forward was flagged
 
     @staticmethod
     def _toggle(module, flag):
         for p in module.parameters():
             p.requires_grad_(flag)
 
+    # ------------------------------------------------------------------ guards (see the module docstring)
+    def _uses_f16x3(self):
+        return self.graph.nerf.train_precision == "f16x3"
+
+    def _guard_nerf(self, var, loss):
+        """Eager: True = apply the step.  Blocking read of [range flag, isfinite(total)] (the reference syncs once per
+        loss term at this point)."""
+        dev = loss.all.device
+        fin = torch.isfinite(loss.all.detach()).to(torch.int32).reshape(1)
+        word = torch.cat([ops.mlp_status(dev), fin]) if self._uses_f16x3() else torch.cat([torch.zeros_like(fin), fin])
+        flag, finite = word.tolist()
+        if flag & 1:
+            ops.mlp_status(dev).zero_()
+            return False
+        if not finite:
+            raise FloatingPointError("non-finite nerf loss (no update applied): " +
+                                     ", ".join("%s=%g" % (k, float(v)) for k, v in loss.items()))
+        return True
+
+    def _guard_disc(self, total):
+        if not bool(torch.isfinite(total.detach())):
+            raise FloatingPointError("non-finite discriminator loss (no update applied): %g" % float(total))
+        return True
+
     def nerf_step(self, var):
         opt, g = self.opt, self.graph
         if self.has_disc:
             self._toggle(g.discriminator, False)
-        self.optim_nerf.zero_grad(set_to_none=True)
-        var = g.nerf_forward(opt, var, mode="train")
-        loss = summarize_loss(opt, g.compute_loss(opt, var, mode="train", train_step="nerf"))
-        loss.all.backward()
+        for attempt in range(2):
+            self.optim_nerf.zero_grad(set_to_none=True)
+            v = g.nerf_forward(opt, var, mode="train")
+            loss = summarize_loss(opt, g.compute_loss(opt, v, mode="train", train_step="nerf"))
+            loss.all.backward()
+            if self._guard_nerf(v, loss):
+                break
+            # range flag of the f16x3 recording forward: nothing of this forward / backward is used
+            self.skipped_steps += 1
+            if attempt == 1:
+                raise ops._lib.TexposeLibraryError("the f16x3 range flag is raised although the fp32 recording forward is selected")
+            warnings.warn("texpose_amd: an activation left the fp16 range of the f16x3 recording forward; the step was "
+                          "repeated and training continues with arch.mlp_train_precision='fp32'")
+            g.nerf.train_precision = "fp32"
         self.red_nerf.reduce()
         self.optim_nerf.step()
-        return var, loss
+        return v, loss
 
     def disc_step(self, var):
         opt, g = self.opt, self.graph
@@ -68,13 +123,16 @@ class GanTrainer:
         var = g.disc_forward(opt, var, mode="train")
         loss = g.compute_loss(opt, var, mode="train", train_step="disc")
         w = lambda k: 10 ** float(opt.loss_weight[k])
+        total = w("gan_disc_real") * loss.gan_disc_real.detach() + w("gan_disc_fake") * loss.gan_disc_fake.detach()
         (w("gan_disc_real") * loss.gan_disc_real).backward(retain_graph=True)
         if opt.loss_weight.gan_reg_real is not None:          # R1: double backward through the discriminator
             reg = g.compute_grad2(opt, var.d_real_disc, var.patch_real).mean()
             (w("gan_reg_real") * reg).backward()
             # the reference logs the WEIGHTED penalty: it scales the tensor it has just stored, in place (:151-153)
             loss.gan_reg_real = (w("gan_reg_real") * reg).detach()
+            total = total + loss.gan_reg_real
         (w("gan_disc_fake") * loss.gan_disc_fake).backward()
+        self._guard_disc(total)
         self.red_disc.reduce()
         self.optim_disc.step()
         return var, loss
@@ -86,16 +144,35 @@ class GanTrainer:
                 continue
             if self.capturable:
                 getattr(self, name).fill_(float(value))
+                getattr(self, name + "_used").fill_(float(value))
             else:
                 setattr(self, name, float(value))
+                setattr(self, name + "_used", float(value))
                 for g in optim.param_groups:
                     g["lr"] = float(value)
 
-    def _poll_range(self, device):
-        """f16x3 recording forward: surface a raised range flag (an activation beyond 6e4) without a host sync; it
-        shows up one or two iterations late at most.  Remedy: arch.mlp_train_precision = 'fp32'."""
-        if self.graph.nerf.train_precision == "f16x3":
-            ops.poll_mlp_status(device)
+    def load_optim_state(self, optim_nerf=None, optim_disc=None):
+        """Resume: optimiser state dicts of a checkpoint (texpose_amd.checkpoint.restore_checkpoint passes them on).
+        ``Optimizer.load_state_dict`` replaces each group's ``lr`` by the saved value; a captured step reads the rate
+        from ``lr_*_used``, so the loaded value is copied there and the groups are pointed back at it."""
+        for sd, name, optim in ((optim_nerf, "lr_nerf", self.optim_nerf), (optim_disc, "lr_disc", getattr(self, "optim_disc", None))):
+            if sd is None or optim is None:
+                continue
+            optim.load_state_dict(sd)
+            self._adopt_group_lr(name, optim)
+
+    def _adopt_group_lr(self, name, optim):
+        used = getattr(self, name + "_used")
+        for g in optim.param_groups:
+            if g["lr"] is not used:
+                value = float(g["lr"])
+                if self.capturable:
+                    getattr(self, name).fill_(value)
+                    used.fill_(value)
+                    g["lr"] = used
+                else:
+                    setattr(self, name, value)
+                    setattr(self, name + "_used", value)
 
     def train_iteration(self, var: AttrDict):
         var = self.graph.get_ray_idx(self.opt, var)
@@ -106,7 +183,6 @@ class GanTrainer:
             self.graph.discriminator.progress.data.fill_(self.it / self.max_iter)
         self.it += 1
         self.graph.patch_sampler.iterations = self.it
-        self._poll_range(var.image.device)
         return var, loss
 
 
@@ -125,11 +201,38 @@ class GraphedGanTrainer(GanTrainer):
     """
     capturable = True
 
-    def __init__(self, opt, graph: Graph, n_train: int, max_iter: int = 6000 * 189 // 8):
-        super().__init__(opt, graph, n_train, max_iter)
+    def __init__(self, opt, graph: Graph, n_train: int, max_iter: int = 6000 * 189 // 8, group=None):
+        super().__init__(opt, graph, n_train, max_iter, group=group)
         self._graph = None
         self._static_in = None
         self._static_loss = None
+        dev = self.lr_nerf.device
+        # sticky device words of the step gate: [range flag seen, non-finite loss seen]; the gate is 1 only while both are 0
+        self._bad = torch.zeros(2, dtype=torch.int32, device=dev)
+        self._bad_poll = None
+
+    # the guards run INSIDE the captured step: no host read, the update is multiplied by the 0/1 gate
+    def _gate(self, ok, grads, lr, lr_used):
+        gate = ok.to(torch.float32)
+        grads = [g for g in grads if g is not None]
+        torch._foreach_mul_(grads, gate)
+        for g in grads:
+            torch.nan_to_num_(g, nan=0.0, posinf=0.0, neginf=0.0)       # (inf or nan) * 0
+        lr_used.copy_(lr * gate)
+
+    def _guard_nerf(self, var, loss):
+        dev = loss.all.device
+        finite = torch.isfinite(loss.all.detach())
+        flag = (ops.mlp_status(dev)[0] & 1) != 0 if self._uses_f16x3() else torch.zeros((), dtype=torch.bool, device=dev)
+        self._bad.bitwise_or_(torch.stack([flag, ~finite]).to(torch.int32))
+        self._ok = self._bad.sum() == 0
+        self._gate(self._ok, [p.grad for p in self.nerf_group], self.lr_nerf, self.lr_nerf_used)
+        return True
+
+    def _guard_disc(self, total):
+        self._bad[1:2].bitwise_or_((~torch.isfinite(total.detach())).to(torch.int32).reshape(1))
+        self._gate(self._bad.sum() == 0, [p.grad for p in self.disc_group], self.lr_disc, self.lr_disc_used)
+        return True
 
     def _body(self, var):
         opt = self.opt
@@ -143,12 +246,45 @@ class GraphedGanTrainer(GanTrainer):
             loss.update({k: v for k, v in dloss.items() if k != "all"})
         return {k: v.detach() for k, v in loss.items() if torch.is_tensor(v)}
 
+    # ------------------------------------------------------------------ capture
+    def _snapshot(self):
+        optims = [self.optim_nerf] + ([self.optim_disc] if self.has_disc else [])
+        return dict(graph={k: v.detach().clone() for k, v in self.graph.state_dict().items()},
+                    optim=[copy.deepcopy(o.state_dict()["state"]) for o in optims], it=self.it,
+                    sampler_it=self.graph.patch_sampler.iterations)
+
+    def _restore(self, snap):
+        """Undo the warm-up iterations IN PLACE (the captured graph keeps the addresses): parameters, buffers (spectral
+        norm u / v, progress), optimiser moments and step counters, iteration counters."""
+        with torch.no_grad():
+            for k, v in self.graph.state_dict().items():
+                v.copy_(snap["graph"][k])
+        optims = [self.optim_nerf] + ([self.optim_disc] if self.has_disc else [])
+        for o, saved in zip(optims, snap["optim"]):
+            index = {id(p): i for i, p in enumerate(p for g in o.param_groups for p in g["params"])}
+            for p, st in o.state.items():
+                old = saved.get(index[id(p)])
+                for name, t in st.items():
+                    if torch.is_tensor(t):
+                        if old is None:
+                            t.zero_()
+                        else:
+                            t.copy_(old[name])
+        self.it = snap["it"]
+        self.graph.patch_sampler.iterations = snap["sampler_it"]
+        self.graph.nerf.mark_heads_dirty()
+
     def capture(self, var: AttrDict, warmup: int = 3):
         """Warm up eagerly on a side stream (lazy inits: MIOpen solver search, weight packing, optimiser state), then
-        record the step.  ``var`` fixes the shapes; its values are used for the warm-up iterations."""
+        record the step.  ``var`` fixes the shapes.  The warm-up iterations are real optimiser steps on ``var``; they
+        are rolled back afterwards, so that a captured run starts from the same state as an eager one."""
         dev = var.image.device
+        for name, optim in (("lr_nerf", self.optim_nerf), ("lr_disc", getattr(self, "optim_disc", None))):
+            if optim is not None:
+                self._adopt_group_lr(name, optim)             # (a load_state_dict before the capture replaced the tensors)
         self.graph.patch_sampler.device_lo = torch.zeros((), device=dev)
         self._static_in = AttrDict({k: v.clone() for k, v in var.items() if torch.is_tensor(v)})
+        snap = self._snapshot()
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
@@ -165,6 +301,12 @@ class GraphedGanTrainer(GanTrainer):
         self.graph.patch_sampler.update_device_bound()          # outside the capture
         with torch.cuda.graph(self._graph):
             self._static_loss = self._body(AttrDict(dict(self._static_in)))
+        self._restore(snap)
+        flagged = self._read_bad(blocking=True)
+        if flagged[0] and self._uses_f16x3():
+            return self._fall_back_to_fp32(var, warmup)
+        if flagged[1]:
+            raise FloatingPointError("non-finite loss during the warm-up iterations of the captured step")
         return self
 
     def _after_step(self):
@@ -174,13 +316,51 @@ class GraphedGanTrainer(GanTrainer):
         self.graph.patch_sampler.iterations = self.it
         self.graph.nerf.mark_heads_dirty()
 
+    # ------------------------------------------------------------------ host side of the step gate
+    def _read_bad(self, blocking=False):
+        """[range flag, non-finite] seen by the gate; blocking, or from the asynchronous copy queued by the previous call."""
+        if blocking:
+            self._bad_poll = None
+            return self._bad.tolist()
+        seen = [0, 0]
+        prev = self._bad_poll
+        if prev is not None and prev[1].query():
+            seen = prev[0].tolist()
+            prev = None
+        if prev is None:
+            host = torch.empty(2, dtype=torch.int32, pin_memory=True)
+            host.copy_(self._bad, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            prev = (host, ev)
+        self._bad_poll = prev
+        return seen
+
+    def _fall_back_to_fp32(self, var, warmup=3):
+        warnings.warn("texpose_amd: an activation left the fp16 range of the f16x3 recording forward; the flagged steps "
+                      "were withheld on the device and the step is re-captured with arch.mlp_train_precision='fp32'")
+        torch.cuda.synchronize()
+        self.skipped_steps += 1
+        self.graph.nerf.train_precision = "fp32"
+        self._bad.zero_()
+        ops.mlp_status(self._bad.device).zero_()
+        self._bad_poll = None
+        return self.capture(var, warmup=warmup)
+
     def train_iteration(self, var: AttrDict):
         if self._graph is None:
             self.capture(var)
         for k, dst in self._static_in.items():
             dst.copy_(var[k], non_blocking=True)
+        for name, optim in (("lr_nerf", self.optim_nerf), ("lr_disc", getattr(self, "optim_disc", None))):
+            if optim is not None and any(g["lr"] is not getattr(self, name + "_used") for g in optim.param_groups):
+                self._adopt_group_lr(name, optim)             # an Optimizer.load_state_dict since the last replay
         self.graph.patch_sampler.update_device_bound()          # one fill_ of the annealed bound
         self._graph.replay()
         self._after_step()
-        self._poll_range(var.image.device)                      # outside the graph: event query + pinned copy
+        flagged = self._read_bad()                              # outside the graph: event query + pinned copy
+        if flagged[0] and self._uses_f16x3():
+            self._fall_back_to_fp32(AttrDict(dict(self._static_in)))
+        elif flagged[1]:
+            raise FloatingPointError("non-finite loss in a captured training step (the update was withheld on the device)")
         return self._static_in, AttrDict(self._static_loss)
