@@ -28,6 +28,7 @@ H, W, N_SAMPLES = 480, 640, 128
 MLP_FLOP_PER_SAMPLE = 1_821_184          # 2 x 910,592 MAC
 # dense MFMA peaks (MI355X_MICROARCH.md): exact-fp32 v_mfma_f32_32x32x2_f32, and f16 v_mfma_f32_32x32x16_f16
 MFMA_PEAK_TFLOPS = {"fp32": 157.3, "f16x3": 2500.0}
+TRAIN_FLOP_PER_SAMPLE = 3_220_992        # recording forward (1,821,184) + backward of the two heads (SURVEY 8d / DESIGN 4)
 ISSUED_PER_ALGORITHMIC = {"fp32": 1, "f16x3": 3}    # f16x3 issues hi*hi + hi*lo + lo*hi per product
 
 
@@ -103,12 +104,66 @@ def cpu_baseline(sc, params, emb_t, emb_l, budget_s=20.0, chunk=2048):
                        % (n_chunks, chunk, N_SAMPLES, torch.__version__, best, avail))
 
 
+def train_leg(device, rank, world):
+    """BASELINE's metric has a second half, "train iters/sec" (config C3: full GAN loop, batch 4, 128x128 crops, 16x16
+    patches, 64 samples per ray; C4 = the same per-GPU batch sharded over the GPUs with one RCCL all-reduce per
+    optimiser step).  Measured OUTSIDE the rays/s timed region with tools/train_dp.measure (the training entry point's
+    own loop); at N=1 also the nerf step alone (B=4, B=32) and a roofline of the training MLP kernels from HIP events
+    around tp_mlp_fwd (recording) and tp_mlp_bwd (dgrad + wgrad + finalize) on the stream they run on."""
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import train_dp
+    from texpose_amd import ops
+    out = {"workload": "C3/C4: Duck-like synthetic crops 128x128, 16x16 patches, 64 samples/ray, 4 images per GPU, "
+                       "hipGraph-replayed iteration; random-init VGG19[:15] feature network (weights unavailable offline)"}
+    full = train_dp.measure(device, rank, world, global_batch=4 * world, iters=40, warm=4, graphed=True, full=True)
+    out["full_gan_loop"] = {k: full[k] for k in ("value", "ms_per_iter", "global_batch", "per_gpu_batch", "launch",
+                                                 "recording_forward", "collective", "loop", "finite", "skipped_steps")}
+    out["unit"] = "iterations/s"
+    if world == 1:
+        for B in (4, 32):
+            r = train_dp.measure(device, 0, 1, global_batch=B, iters=40, warm=4, graphed=True, full=False)
+            out["nerf_step_b%d" % B] = {k: r[k] for k in ("value", "ms_per_iter", "global_batch", "launch", "recording_forward")}
+        # kernel-level: eager nerf step at B=32 with events around the two C-ABI calls
+        ev = {"fwd": [], "bwd": []}
+        orig_f, orig_b = ops.mlp_forward, ops.mlp_backward
+
+        def timed(fn, store):
+            def call(*a, **k):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                res = fn(*a, **k)
+                e1.record()
+                store.append((e0, e1))
+                return res
+            return call
+
+        ops.mlp_forward, ops.mlp_backward = timed(orig_f, ev["fwd"]), timed(orig_b, ev["bwd"])
+        try:
+            r = train_dp.measure(device, 0, 1, global_batch=32, iters=12, warm=3, graphed=False, full=False)
+        finally:
+            ops.mlp_forward, ops.mlp_backward = orig_f, orig_b
+        torch.cuda.synchronize()
+        samples = 32 * 256 * 64
+        f_ms = float(np.mean([a.elapsed_time(b) for a, b in ev["fwd"][3:]]))
+        b_ms = float(np.mean([a.elapsed_time(b) for a, b in ev["bwd"][3:]]))
+        achieved = TRAIN_FLOP_PER_SAMPLE * samples / ((f_ms + b_ms) * 1e-3) / 1e12
+        out["roofline"] = {"kernels": "mlp_fwd_f16x3_kernel<recording> + mlp_dgrad_f16x3_kernel + mlp_wgrad_kernel<f16x3> + "
+                                      "mlp_wgrad_finalize", "bound": "mfma", "achieved": achieved, "peak": MFMA_PEAK_TFLOPS["f16x3"],
+                           "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TFLOPS["f16x3"],
+                           "issued_frac": 3 * achieved / MFMA_PEAK_TFLOPS["f16x3"], "fwd_ms": f_ms, "bwd_ms": b_ms,
+                           "samples_per_launch": samples, "flop_per_sample": TRAIN_FLOP_PER_SAMPLE, "traffic": None,
+                           "note": "B=32 nerf step, eager; ALGORITHMIC FLOP (recording forward + head backward) / HIP-event "
+                                   "time of tp_mlp_fwd + tp_mlp_bwd; every product is three f16 MFMAs"}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train", action="store_true", help="skip the training leg (train iters/s)")
     ap.add_argument("--precision", choices=["f16x3", "fp32"], default="f16x3",
                     help="MLP arithmetic: f16x3 = split-fp16 products on the f16 matrix cores (fp32-grade accuracy, "
                          "default); fp32 = exact fp32 MFMA")
@@ -213,10 +268,13 @@ def main():
         ms1 = float(np.mean([a.elapsed_time(b) for a, b in ev]))
         exact = {"value": H * W / dt1, "unit": "rays/s", "roofline": roofline("fp32", ms1, H * W * N_SAMPLES / len(ev))}
     ops.check_mlp_status(device)
+    del ret
+    torch.cuda.empty_cache()
+    train = None if args.no_train else train_leg(device, rank, world)
 
     if rank == 0:
         line = {
-            "metric": "rendered rays/sec (480x640x128 samples)",
+            "metric": "rendered rays/sec (480x640x128 samples) + train iters/sec",
             "value": world * H * W * args.steps / dt,
             "unit": "rays/s",
             "n_gpus": world,
@@ -237,6 +295,8 @@ def main():
         }
         if exact is not None:
             line["exact_fp32_kernel"] = exact
+        if train is not None:
+            line["train"] = train
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(sc, params, emb_t, emb_l)
             line["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]

@@ -26,7 +26,7 @@ extern "C" {
 
 typedef void* tp_stream_t; /* hipStream_t */
 
-#define TP_ABI_VERSION 2
+#define TP_ABI_VERSION 3
 
 int tp_abi_version(void);
 const char* tp_last_error(void);
@@ -64,6 +64,10 @@ typedef struct tp_raygen_args {
   float aabb_min[3];      /* TP_BOUNDS_AABB (host values) */
   float aabb_max[3];
   float bg_near, bg_far;  /* TP_BOUNDS_AABB fallback range */
+  const float* valid_rect; /* TP_BOUNDS_AABB, optional: [B,4] device (x0,y0,x1,y1) in pixel coordinates of the H x W image;
+                            * pixels whose centre (col+0.5,row+0.5 / bilinear coordinate) lies outside get the fallback
+                            * range.  Reproduces the zero padding of the stored bound maps when a detection crop leaves
+                            * the camera frame (data/lm.py:455-495 Crop_by_Pad, :349-350).  NULL = no rectangle. */
   uint64_t seed, offset;  /* TP_JITTER_PHILOX */
   int B, R, H, W, N;      /* N = samples per ray (0: no depth output) */
   int pixel_mode, bounds_mode, jitter_mode;

@@ -667,3 +667,169 @@ def seed_spectral_module(module: torch.nn.Module, seed: int, scale: float = 0.05
                 sd[k[:-5] + "_v"].copy_(v)
             elif sd[k].ndim == 0:
                 sd[k].fill_(0.25)
+
+
+# ----------------------------------------------------------------------------
+# f2  checkpoint wire format (util.py:172-263): test helpers shared by the golden generator and the tests
+# ----------------------------------------------------------------------------
+
+def _key_rng(key: str, salt: int) -> np.random.RandomState:
+    import zlib
+    return np.random.RandomState((zlib.crc32(key.encode()) ^ (salt * 2654435761)) & 0x7FFFFFFF)
+
+
+def seeded_state(state: Dict[str, Tensor], salt: int, scale: float = 0.05) -> Dict[str, Tensor]:
+    """Every floating-point tensor of a state dict as a function of its KEY (and ``salt``): the reference (generator) and
+    the mirror (tests) fill their graphs with identical contents without shipping a blob."""
+    out = {}
+    for k, v in state.items():
+        if v.dtype.is_floating_point:
+            t = torch.from_numpy(_key_rng(k, salt).standard_normal(tuple(v.shape)).astype(np.float32)) * scale
+            if k.endswith(("weight_u", "weight_v")):
+                t = torch.nn.functional.normalize(t, dim=0, eps=1e-12)
+            out[k] = t.to(v.dtype)
+        else:
+            out[k] = v.clone()
+    return out
+
+
+def seeded_grads(optim: torch.optim.Optimizer, salt: int, scale: float = 1e-3) -> None:
+    """Key-free seeded gradients for every trainable parameter of an optimiser (index within its group as the key)."""
+    for gi, g in enumerate(optim.param_groups):
+        for pi, p in enumerate(g["params"]):
+            if p.requires_grad:
+                rs = _key_rng("g%d.p%d" % (gi, pi), salt)
+                p.grad = torch.from_numpy(rs.standard_normal(tuple(p.shape)).astype(np.float32)).to(p.device) * scale
+            else:
+                p.grad = None
+
+
+def _tensor_summary(t: Tensor):
+    d = t.detach().double().cpu()
+    return dict(shape=list(t.shape), dtype=str(t.dtype).replace("torch.", ""), sum=float(d.sum()), abssum=float(d.abs().sum()))
+
+
+def state_summary(state: Dict[str, Tensor]):
+    return {k: _tensor_summary(v) for k, v in state.items()}
+
+
+def optim_summary(sd: dict):
+    groups = [{k: (list(v) if isinstance(v, (list, tuple)) else (float(v) if isinstance(v, (int, float)) and not isinstance(v, bool) else v))
+               for k, v in g.items()} for g in sd["param_groups"]]
+    for g in groups:
+        for k, v in list(g.items()):
+            if torch.is_tensor(v):
+                g[k] = float(v)
+    state = {str(i): {n: (_tensor_summary(t) if torch.is_tensor(t) else t) for n, t in st.items()} for i, st in sd["state"].items()}
+    return dict(param_groups=groups, state=state)
+
+
+def checkpoint_manifest(blob: dict):
+    """What a checkpoint file of the reference layout contains, in comparable form."""
+    m = dict(top_level=sorted(blob.keys()), epoch=blob.get("epoch"), iter=blob.get("iter"), graph=state_summary(blob["graph"]))
+    for k, v in blob.items():
+        if k.startswith("optim"):
+            m[k] = optim_summary(v)
+        elif k.startswith("sched"):
+            m[k] = {n: (x if isinstance(x, (int, float, bool, str, type(None))) else [float(y) for y in x] if isinstance(x, (list, tuple)) else str(type(x)))
+                    for n, x in v.items()}
+    return m
+
+
+# ----------------------------------------------------------------------------
+# f3  stored box-bound maps -> per-crop depth range        data/lm.py:316-350,412-495
+# ----------------------------------------------------------------------------
+# The reference stores the slab-test result of EVERY frame as a [2,480,640] map in millimetres (compute_box.py:262-283)
+# and, at load time, crops it around the detection box, resizes the crop to the network resolution with
+# cv2.resize(INTER_LINEAR), pads it into a square, converts mm -> depth.scale units and replaces non-positive entries
+# by the background range.  cv2 (opencv-python, no version pinned by the reference) is not available offline: its
+# float32 INTER_LINEAR resize is restated here from OpenCV's documented algorithm (pixel-centre alignment, border
+# replicate, horizontal then vertical two-tap passes in float).
+
+def resize_linear(img: np.ndarray, out_w: int, out_h: int) -> np.ndarray:
+    """cv2.resize(img, (out_w, out_h), interpolation=cv2.INTER_LINEAR) for float32 [h, w] or [h, w, c]."""
+    src = np.asarray(img, dtype=np.float32)
+    squeeze = src.ndim == 2
+    if squeeze:
+        src = src[:, :, None]
+    h, w, _ = src.shape
+
+    def taps(n_out, n_in):
+        scale = n_in / float(n_out)
+        f = ((np.arange(n_out, dtype=np.float64) + 0.5) * scale - 0.5).astype(np.float32)
+        i0 = np.floor(f).astype(np.int64)
+        frac = (f - i0.astype(np.float32)).astype(np.float32)
+        lo = i0 < 0
+        frac[lo], i0[lo] = 0.0, 0
+        hi = i0 >= n_in - 1
+        frac[hi], i0[hi] = 0.0, n_in - 1
+        i1 = np.minimum(i0 + 1, n_in - 1)
+        return i0, i1, frac
+
+    x0, x1, fx = taps(out_w, w)
+    y0, y1, fy = taps(out_h, h)
+    rows = src[:, x0, :] * (np.float32(1.0) - fx)[None, :, None] + src[:, x1, :] * fx[None, :, None]      # horizontal pass
+    out = rows[y0] * (np.float32(1.0) - fy)[:, None, None] + rows[y1] * fy[:, None, None]                 # vertical pass
+    out = out.astype(np.float32)
+    return out[:, :, 0] if squeeze else out
+
+
+def crop_by_pad(img: np.ndarray, center, scale: int, res: int) -> np.ndarray:
+    """Dataset.Crop_by_Pad(img, center, scale, res, channel<=3, resize=True) (data/lm.py:455-495): crop the square of side
+    ``scale`` around ``center`` = (row, col) clipped to the image, resize the longer side to ``res`` keeping the aspect,
+    paste centred into a zero [res, res, c] canvas."""
+    ht, wd = img.shape[0], img.shape[1]
+    up0, le0 = int(center[0] - scale / 2. + 0.5), int(center[1] - scale / 2. + 0.5)
+    upper, left = max(0, up0), max(0, le0)
+    bottom, right = min(ht, up0 + int(scale)), min(wd, le0 + int(scale))
+    crop_ht, crop_wd = float(bottom - upper), float(right - left)
+    if crop_ht > crop_wd:
+        resize_ht, resize_wd = res, int(res / crop_ht * crop_wd + 0.5)
+    elif crop_ht < crop_wd:
+        resize_wd, resize_ht = res, int(res / crop_wd * crop_ht + 0.5)
+    else:
+        resize_wd = resize_ht = int(res)
+    tmp = resize_linear(img[upper:bottom, left:right], resize_wd, resize_ht)
+    if tmp.ndim < 3:
+        tmp = tmp[:, :, None]
+    out = np.zeros((res, res, img.shape[2] if img.ndim == 3 else 1))
+    r0, c0 = int(res / 2.0 - resize_ht / 2.0 + 0.5), int(res / 2.0 - resize_wd / 2.0 + 0.5)
+    out[r0:r0 + resize_ht, c0:c0 + resize_wd, :] = tmp
+    return out
+
+
+def crop_center_offset(center, scale: int, ht: int, wd: int) -> np.ndarray:
+    """Dataset.get_center_offset (data/lm.py:431-451): shift of the effective crop centre when the square is clipped."""
+    up0, le0 = int(center[0] - scale / 2. + 0.5), int(center[1] - scale / 2. + 0.5)
+    upper, left = max(0, up0), max(0, le0)
+    bottom, right = min(ht, up0 + int(scale)), min(wd, le0 + int(scale))
+    h_off = -up0 / 2 if upper == 0 else (-(up0 + int(scale) - ht) / 2 if bottom == ht else 0)
+    w_off = -le0 / 2 if left == 0 else (-(le0 + int(scale) - wd) / 2 if right == wd else 0)
+    return np.array([h_off, w_off])
+
+
+def crop_intrinsics(K: Tensor, resize: float, crop_center, res: int) -> Tensor:
+    """Dataset.preprocess_intrinsics (data/lm.py:412-428): intrinsics of the resized, cropped image."""
+    K = K.clone()
+    K[0, 0], K[1, 1] = K[0, 0] * resize, K[1, 1] * resize
+    K[0, 2] = (K[0, 2] + 0.5) * resize - 0.5
+    K[1, 2] = (K[1, 2] + 0.5) * resize - 0.5
+    top_left = np.asarray(crop_center, dtype=np.float64) * resize - res / 2
+    K[0, 2] = K[0, 2] - top_left[1]
+    K[1, 2] = K[1, 2] - top_left[0]
+    return K
+
+
+def range_from_box_map(box_map_mm: np.ndarray, center, scale: int, res: int, depth_scale: float = 10.0,
+                       bg_range_m=(0.0, 3.0), mask: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
+    """Dataset.get_range, range_source == 'box' (data/lm.py:316-350): [2,H0,W0] map in mm -> (z_near, z_far) [res*res] in
+    depth.scale units, non-positive entries replaced by the background range."""
+    m = crop_by_pad(np.asarray(box_map_mm, dtype=np.float32).transpose(1, 2, 0), center, scale, res).astype(np.float32)
+    r = torch.from_numpy(m)
+    if mask is not None:
+        r = r * mask[..., None]
+    r = r.permute(2, 0, 1).reshape(2, res * res)
+    r = (r / 1000) * depth_scale
+    lo = torch.full((res * res,), float(bg_range_m[0] * depth_scale))
+    hi = torch.full((res * res,), float(bg_range_m[1] * depth_scale))
+    return torch.where(r[0] > 0, r[0], lo), torch.where(r[1] > 0, r[1], hi)

@@ -114,3 +114,103 @@ def test_shard_batch_partitions():
             flat = [i for p in parts for i in p]
             assert flat == list(range(n))
             assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# trainer-level glue (texpose_amd.trainer.GanTrainer + dist.setup_data_parallel / shard_training_batch), world size 2.
+# The HIP render and the HIP patch gather are replaced by the CPU oracle IN THIS TEST ONLY (the product has no CPU path).
+# ---------------------------------------------------------------------------------------------------------------------
+TB, TH, TN = 4, 32, 4          # global batch, crop size, samples per ray
+
+
+def _oracle_backed_graph(opt):
+    from texpose_amd.gan_modules import Discriminator
+    from texpose_amd.graph import Graph
+    from texpose_amd.options import AttrDict
+
+    class CpuGraph(Graph):
+        def render(self, opt, pose, intr=None, ray_idx=None, depth_range=None, sample_idx=None, mode=None, rand=None):
+            p = {k: v for k, v in self.nerf.named_parameters() if k.startswith("mlp_")}
+            if rand is None:
+                rand = torch.rand(pose.shape[0], ray_idx.shape[1] * ray_idx.shape[2], opt.nerf.sample_intvs, 1)
+            return AttrDict(O.render(p, self.latent_vars_trans.weight, self.latent_vars_light.weight, pose, intr, ray_idx,
+                                     depth_range, sample_idx, mode, opt.H, opt.W, opt.nerf.sample_intvs, rand=rand))
+
+        def gather_patches(self, opt, var):
+            B = len(var.idx)
+            g = O.patch_gather(var.ray_idx, var.image, var.image_syn, var.nocs_pred, var.normal_pred,
+                               var.obj_mask.view(B, opt.H, opt.W), var.mask_syn.view(B, opt.H, opt.W))
+            var.image_sample, var.image_syn_sample = g["image"], g["image_syn"]
+            var.nocs_sample, var.normal_sample = g["nocs_sample"], g["normal_sample"]
+            var.mask_sample, var.mask_syn_sample = g["mask"], g["mask_syn"]
+            return var
+
+    return CpuGraph(opt, discriminator=Discriminator(opt))
+
+
+def _trainer_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    from texpose_amd.options import AttrDict, default_options
+    from texpose_amd.synthetic import training_batch
+    from texpose_amd.trainer import GanTrainer
+    tdist.init_distributed("gloo")
+    opt = default_options(H=TH, W=TH, device="cpu")
+    opt.batch_size, opt.patch_size, opt.nerf.sample_intvs = TB // world, 16, TN
+    opt.loss_weight.feat = None
+    torch.manual_seed(100 + rank)                    # ranks start from DIFFERENT weights: the broadcast must fix that
+    graph = _oracle_backed_graph(opt)
+    graph.attach_latents(6, opt)
+    graph.train()
+    before = graph.nerf.mlp_rgb[0].weight.detach().clone()
+    r, w = tdist.setup_data_parallel(graph, seed=7)
+    assert (r, w) == (rank, world)
+    tr = GanTrainer(opt, graph, n_train=6, max_iter=10)
+    calls = []
+    for name, red in (("nerf", tr.red_nerf), ("disc", tr.red_disc)):
+        def wrapped(orig=red.reduce, name=name, red=red):
+            calls.append((name, [p.grad is not None for p in red.params].count(True)))
+            return orig()
+        red.reduce = wrapped
+    full = training_batch(TB, TH, TH, n_train=6, seed=3, device="cpu")
+    mine = tdist.shard_training_batch(full, rank, world)
+    start = {k: v.detach().clone() for k, v in graph.state_dict().items()}
+    coords = []
+    for _ in range(2):
+        var, loss = tr.train_iteration(AttrDict(dict(mine)))
+        coords.append(var.ray_idx.detach().clone())
+        assert all(bool(torch.isfinite(v)) for v in loss.values() if torch.is_tensor(v))
+    torch.save(dict(start=start, end={k: v.detach().clone() for k, v in graph.state_dict().items()}, calls=calls,
+                    coords=coords, idx=mine.idx.clone(), changed_by_broadcast=not torch.equal(before, start["nerf.mlp_rgb.0.weight"]),
+                    frame=mine.frame_index.clone()), os.path.join(out_dir, f"trainer_rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_data_parallel_trainer_glue(tmp_path):
+    """Two ranks, two full GAN iterations each on its half of a global batch of 4: identical start (broadcast), different
+    patch draws per rank, disjoint images, one gradient all-reduce per optimiser step issued after ALL backward passes of
+    the step (nerf: 1; discriminator: real + R1 + fake), identical parameters and buffers on both ranks afterwards."""
+    world = 2
+    mp.spawn(_trainer_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r0 = torch.load(tmp_path / "trainer_rank0.pt")
+    r1 = torch.load(tmp_path / "trainer_rank1.pt")
+    assert not r0["changed_by_broadcast"] and r1["changed_by_broadcast"]
+    for k in r0["start"]:
+        assert torch.equal(r0["start"][k], r1["start"][k]), k
+    assert set(r0["frame"].tolist()).isdisjoint(r1["frame"].tolist()) and len(r0["idx"]) == len(r1["idx"]) == 2
+    assert not torch.equal(r0["coords"][0], r1["coords"][0])               # per-rank random streams
+    # per iteration: one reduce for the nerf step, then one for the discriminator step, every trainable parameter
+    # holding a gradient at that point (discriminator: the real, R1 and fake backward have all run)
+    assert [c[0] for c in r0["calls"]] == ["nerf", "disc", "nerf", "disc"] == [c[0] for c in r1["calls"]]
+    n_heads = 16 + 2
+    assert all(c[1] == n_heads for c in r0["calls"] if c[0] == "nerf")
+    assert all(c[1] == 6 for c in r0["calls"] if c[0] == "disc")
+    moved = 0
+    for k in r0["end"]:
+        assert torch.equal(r0["end"][k], r1["end"][k]), k                  # same averaged gradients -> same updates
+        moved += int(not torch.equal(r0["end"][k], r0["start"][k]))
+    assert moved >= n_heads + 6
+    assert all(torch.equal(r0["end"][k], r0["start"][k]) for k in r0["end"] if k.startswith("nerf.mlp_feat"))

@@ -723,7 +723,7 @@ def test_flagged_training_iteration_applies_no_update(ops, graphed):
         # spectral-norm power iteration the dropped attempt ran inside the discriminator)
         pick = lambda sd: {k: v for k, v in sd.items() if k.startswith(("nerf.", "latent"))}
         assert_updates_close(pick(g.state_dict()), pick(ref_g.state_dict()), snap)
-        assert not torch.equal(g.state_dict()["nerf.mlp_rgb.0.weight"], snap["nerf.mlp_rgb.0.weight"])
+        assert tr.it == 1 and any(not torch.equal(v, snap[k]) for k, v in pick(g.state_dict()).items())
     else:
         tr, g = build(GraphedGanTrainer, "f16x3")
         snap = {k: v.detach().clone() for k, v in g.state_dict().items()}
@@ -749,7 +749,7 @@ def test_flagged_training_iteration_applies_no_update(ops, graphed):
         tr2._bad.zero_()
         tr2._graph.replay()
         torch.cuda.synchronize()
-        assert not torch.equal(g2.state_dict()["nerf.mlp_rgb.0.weight"], before["nerf.mlp_rgb.0.weight"])
+        assert any(not torch.equal(v, before[k]) for k, v in g2.state_dict().items() if k.startswith(("nerf.mlp_", "latent")))
     ops.mlp_status(dev()).zero_()
 
 

@@ -183,3 +183,10 @@ def test_perceptual_pairs_equal_separate_passes():
     (m1 + 5 * m2).backward()
     assert torch.allclose(m1, l1, rtol=1e-6, atol=0) and torch.allclose(m2, l2, rtol=1e-6, atol=0)
     assert torch.allclose(a.grad, g1, rtol=1e-5, atol=1e-9) and torch.allclose(c.grad, g2, rtol=1e-5, atol=1e-9)
+
+
+def test_checkpoint_wire_format_matches_reference_written_file(tmp_path):
+    """G15: texpose_amd writes / resumes / trunk-restores checkpoints exactly as the reference's util.save_checkpoint /
+    restore_checkpoint / restore_pretrain_partial_checkpoint do (manifest captured from the reference)."""
+    import checkpoint_contract
+    checkpoint_contract.run(torch.device("cpu"), tmp_path)

@@ -283,3 +283,37 @@ def test_philox_known_answer():
     assert [hex(int(v)) for v in z] == ["0x408f276d", "0x41c83b0e", "0xa20bc7c6", "0x6d5451fd"]
     u = O.philox_uniform(4096, seed=123, offset=5)
     assert u.dtype == np.float32 and u.min() >= 0 and u.max() < 1 and abs(u.mean() - 0.5) < 0.02
+
+
+def test_box_range_restatement_matches_reference_g16():
+    """the oracle's restatement of the stored-map pipeline (slab-test map in mm as compute_box.py:262-283
+    writes it -> Crop_by_Pad -> mm to depth.scale units -> background fallback, data/lm.py:316-350,412-495) against the
+    golden G16 the reference's own Dataset.Crop_by_Pad / preprocess_intrinsics / get_center_offset produced (cv2.resize
+    restated: OpenCV float32 INTER_LINEAR), and the product's host-side crop camera against the same golden."""
+    from conftest import load_golden
+    from texpose_amd.geometry import crop_camera
+    g = load_golden("g16_box_range")
+    res = g["res"]
+    for c in (0, 1):
+        pre = "c%d_" % c
+        K, R, t = g[pre + "K"], g[pre + "R"], g[pre + "t_mm"]
+        pose_mm = torch.cat([R, t[:, None]], 1)[None]
+        o, d = O.rays_eval(pose_mm, K[None], 480, 640)
+        tn, tf, ok = O.aabb_slab(g[pre + "aabb_min_mm"].view(1, 1, 3), g[pre + "aabb_max_mm"].view(1, 1, 3), o, d)
+        tn = torch.where(ok, tn, torch.zeros_like(tn)).view(480, 640)
+        tf = torch.where(ok, tf, torch.zeros_like(tf)).view(480, 640)
+        center, scale = g[pre + "center"].numpy(), g[pre + "scale"]
+        zn, zf = O.range_from_box_map(torch.stack([tn, tf]).numpy(), center, scale, res, g["depth_scale"], (g["bg_lo"], g["bg_hi"]))
+        assert torch.equal(zn, g[pre + "z_near"]) and torch.equal(zf, g[pre + "z_far"])
+        off = O.crop_center_offset(center, scale, 480, 640)
+        assert np.array_equal(off.astype(np.float32), g[pre + "center_offset"].numpy())
+        assert torch.equal(O.crop_intrinsics(K, res / scale, center + off, res), g[pre + "intr_crop"])
+        Kc, rect = crop_camera(K, center, scale, res)
+        torch.testing.assert_close(Kc, g[pre + "intr_crop"], rtol=0, atol=2e-5)
+        # the rectangle is exactly where the golden's padding ends: outside it every pixel has the background range
+        x0, y0, x1, y1 = [int(v) for v in rect]
+        far_img = g[pre + "z_far"].view(res, res)
+        outside = torch.ones(res, res, dtype=torch.bool)
+        outside[y0:y1, x0:x1] = False
+        assert bool((far_img[outside] == g["bg_hi"] * g["depth_scale"]).all())
+        assert c == 0 or outside.any()

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # TEXPOSE_AMD_LIB selects another build of the SAME library (e.g. the `make trace` diagnostic build); never a fallback
 LIB_PATH = os.environ.get("TEXPOSE_AMD_LIB") or os.path.join(_HERE, "libtexpose_amd.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # Every symbol include/texpose_amd.h declares (checked by tests/test_capi_cpu.py).
 SYMBOLS = (
@@ -34,7 +34,7 @@ vp = C.c_void_p
 class RaygenArgs(C.Structure):
     _fields_ = [("intr", vp), ("pose", vp), ("coords", vp), ("ray_idx", vp), ("z_near", vp),
                 ("z_far", vp), ("rand", vp), ("aabb_min", C.c_float * 3), ("aabb_max", C.c_float * 3),
-                ("bg_near", C.c_float), ("bg_far", C.c_float), ("seed", C.c_uint64), ("offset", C.c_uint64),
+                ("bg_near", C.c_float), ("bg_far", C.c_float), ("valid_rect", vp), ("seed", C.c_uint64), ("offset", C.c_uint64),
                 ("B", C.c_int), ("R", C.c_int), ("H", C.c_int), ("W", C.c_int), ("N", C.c_int),
                 ("pixel_mode", C.c_int), ("bounds_mode", C.c_int), ("jitter_mode", C.c_int),
                 ("center", vp), ("ray", vp), ("near", vp), ("far", vp), ("depth", vp)]

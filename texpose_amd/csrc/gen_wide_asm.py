@@ -1,0 +1,362 @@
+#!/usr/bin/env python3
+"""Generates wide_asm.inc.h: every piece of the f16x3 MLP forward that touches the two accumulator sets, as
+hand-scheduled gfx950 inline-asm blocks with FIXED registers:
+
+    set P = a[0:127], set Q = a[128:255]   (8 tiles of 32 features x 32 samples, 16 registers each)
+    v[160:191]  A-fragment ring: 4 (k-step, tile) pair slots x (hi 4 + lo 4 registers)
+    v[192:223]  two banks of B operands (xh0 xh1 xl0 xl1, 4 registers each), also scratch of the seeding block
+    v[224:227]  conversion temporaries      v[228:230]  LDS read address per ring slot
+    v[232:247]  accumulator tile of a narrow head
+
+Why asm: with one wave per SIMD every issue slot that is not an MFMA is exposed, and the kernel needs all 512
+registers.  hipcc's schedule of the C++ version clusters the operand-conversion VALU work unevenly, waits for LDS with
+lgkmcnt(0), moves the sets between AGPRs and VGPRs and cannot keep a third 128-register set (the trunk feature, held
+from L7 to R0) next to them without spilling it.  Here every MFMA gap carries at most four VALU instructions, or one
+LDS-DMA piece, or two ds_read_b128; a ring slot is refilled as soon as its last MFMA has issued; waits are counted.
+
+Blocks (C++ wrappers in mlp_fwd_f16x3.hip), each for both set roles:
+    WIDE   256 -> 256 layer body: 8 chunks, 384 MFMAs; B operands converted from the source set in the gaps
+           (2^-8, ReLU, hi = v & 0xFFFFE000, lo = v - hi, two v_cvt_pkrtz, range guard)
+    EXTRA  one chunk of "extra input" k-steps (positional encodings, latents): B operands read from the LDS stage
+    HEAD   1..5-row output layer over relu(source set): one chunk, 16 k-steps, one accumulator tile in VGPRs
+    INIT   seed a set with bias * 2^8 from LDS
+Arithmetic and accumulation order are those of the C++ version (mma_wide16 / part_gen16 / part_head16): results are
+bit-identical.
+
+Ring protocol (shared by all blocks): three 32 KiB LDS slots; on entry chunk c is published and its pairs 0..3 are in
+the fragment registers, the DMA of c+1 is fully issued, that of c+2 not started; a block issues the 8 DMA pieces of c+2
+spread over its MFMA groups, publishes c+1 (counted vmcnt: only the pieces of c+2 issued so far may be in flight,
+lgkmcnt(0), s_barrier) 4 pairs before the end of c and leaves with pairs 0..3 of c+1 in the fragment registers.
+
+    python3 gen_wide_asm.py > wide_asm.inc.h        (the Makefile does this)
+"""
+import sys
+
+NCH = 115
+
+VB = 160
+def F_hi(slot): return VB + 8 * slot
+def F_lo(slot): return VB + 8 * slot + 4
+XB = [VB + 32, VB + 48]
+T = VB + 64
+VR = VB + 68
+HACC = VB + 72                # head accumulator tile v[232:247]
+CLOBBER_V = list(range(XB[0], VR + 3))
+BA, BB = 92, 94               # fixed SGPR pairs: global base of the DMA pieces 0..3 / 4..7
+CLOBBER_S = [BA, BA + 1, BB, BB + 1]
+SET = {"P": 0, "Q": 128}
+
+
+def vr(lo, n=4):
+    return "v[%d:%d]" % (lo, lo + n - 1)
+
+
+def ar(set_base, tile):
+    lo = set_base + 16 * tile
+    return "a[%d:%d]" % (lo, lo + 15)
+
+
+def mfma(dst, a, b, c=None):
+    return "v_mfma_f32_32x32x16_f16 %s, %s, %s, %s" % (dst, a, b, dst if c is None else c)
+
+
+def conv(src_base, tile, g, bank):
+    """13 VALU instructions: elements 2g, 2g+1 of source tile `tile` -> packed word g of the hi / lo operands in `bank`"""
+    xh = XB[bank] + (g >> 2) * 4 + (g & 3)
+    xl = XB[bank] + 8 + (g >> 2) * 4 + (g & 3)
+    t0, t1, h0, h1 = T, T + 1, T + 2, T + 3
+    a = src_base + 16 * tile + 2 * g
+    return ["v_accvgpr_read_b32 v%d, a%d" % (t0, a),
+            "v_accvgpr_read_b32 v%d, a%d" % (t1, a + 1),
+            "v_mul_f32 v%d, %%[kinv], v%d" % (t0, t0),
+            "v_mul_f32 v%d, %%[kinv], v%d" % (t1, t1),
+            "v_max_f32 v%d, 0, v%d" % (t0, t0),
+            "v_max_f32 v%d, 0, v%d" % (t1, t1),
+            "v_and_b32 v%d, %%[mask], v%d" % (h0, t0),
+            "v_and_b32 v%d, %%[mask], v%d" % (h1, t1),
+            "v_sub_f32 v%d, v%d, v%d" % (t0, t0, h0),
+            "v_sub_f32 v%d, v%d, v%d" % (t1, t1, h1),
+            "v_cvt_pkrtz_f16_f32 v%d, v%d, v%d" % (xh, h0, h1),
+            "v_cvt_pkrtz_f16_f32 v%d, v%d, v%d" % (xl, t0, t1),
+            "v_pk_max_f16 %%[amax], %%[amax], v%d" % xh]
+
+
+def ring_prologue(e):
+    """slot byte offsets r0 r1 r2 = slots of (current, next, DMA target) chunk; read addresses; DMA LDS bases; dch."""
+    e("s_waitcnt lgkmcnt(0)")
+    e("s_nop 7")                                     # (sets / operands may have been written just before the block)
+    e("s_nop 7")
+    e("s_lshl_b32 %[r0], %[buf], 15")
+    for k, r in ((1, "r1"), (2, "r2")):
+        e("s_add_i32 %%[t0], %%[buf], %d" % k)
+        e("s_cmp_ge_i32 %[t0], 3")
+        e("s_cselect_b32 %%[%s], 3, 0" % r)
+        e("s_sub_i32 %%[t0], %%[t0], %%[%s]" % r)
+        e("s_lshl_b32 %%[%s], %%[t0], 15" % r)
+    for i, r in enumerate(("r0", "r1", "r2")):
+        e("v_add_u32 v%d, %%[%s], %%[lane16]" % (VR + i, r))
+        e("s_add_i32 %%[m%da], %%[ldswave], %%[%s]" % (i, r))
+    e("s_add_i32 %[dch], %[chunk], 2")
+    e("s_cmp_ge_i32 %[dch], " + str(NCH))
+    e("s_cselect_b32 %[t0], " + str(NCH) + ", 0")
+    e("s_sub_i32 %[dch], %[dch], %[t0]")
+
+
+def dma_base():
+    return ["s_lshl_b32 %[t0], %[dch], 15",
+            "s_add_u32 s%d, %%[stream_lo], %%[t0]" % BA,
+            "s_addc_u32 s%d, %%[stream_hi], 0" % (BA + 1),
+            "s_add_u32 s%d, s%d, 0x1000" % (BB, BA),
+            "s_addc_u32 s%d, s%d, 0" % (BB + 1, BA + 1)]
+
+
+def dma_piece(e, k, dma_slot):
+    if k == 0:
+        e("s_mov_b32 m0, %%[m%da]" % dma_slot)
+        e("s_nop 0")                                 # (M0 write -> LDS-DMA: one wait state)
+    elif k == 4:
+        e("s_add_i32 m0, %%[m%da], 0x1000" % dma_slot)
+        e("s_nop 0")
+    base = "s[%d:%d]" % ((BA, BA + 1) if k < 4 else (BB, BB + 1))
+    e("global_load_lds_dwordx4 %%[laneoff], %s offset:%d" % (base, (k & 3) * 1024))
+
+
+def ring_epilogue(e, n_chunks):
+    e("s_waitcnt lgkmcnt(0)")
+    e("s_add_i32 %%[chunk], %%[chunk], %d" % n_chunks)
+    e("s_cmp_ge_i32 %[chunk], " + str(NCH))
+    e("s_cselect_b32 %[t0], " + str(NCH) + ", 0")
+    e("s_sub_i32 %[chunk], %[chunk], %[t0]")
+    e("s_add_i32 %%[buf], %%[buf], %d" % (n_chunks % 3))
+    e("s_cmp_ge_i32 %[buf], 3")
+    e("s_cselect_b32 %[t0], 3, 0")
+    e("s_sub_i32 %[buf], %[buf], %[t0]")
+
+
+def refill(e, slot, pair, npairs, cur, nxt):
+    addr, off = (VR + cur, pair * 2048) if pair < npairs else (VR + nxt, (pair - npairs) * 2048)
+    e("ds_read_b128 %s, v%d offset:%d" % (vr(F_hi(slot)), addr, off))
+    e("ds_read_b128 %s, v%d offset:%d" % (vr(F_lo(slot)), addr, off + 1024))
+
+
+def publish(e, young):
+    e("s_waitcnt vmcnt(%d) lgkmcnt(0)" % young)
+    e("s_barrier")
+
+
+def chunk_groups(e, npairs, ts, mf, fill, free_after, pieces_per_group, tail=None):
+    """One chunk of npairs (k-step, tile) pairs = npairs/2 groups of six MFMAs.
+      mf(g)          -> the six MFMA lines of group g (they use ring slots (2g)%4 and (2g+1)%4)
+      fill(g)        -> five lists of gap instructions (after MFMA 1..5)
+      free_after     -> (i, j), i < j: slot a is free after MFMA i, slot b after MFMA j (1-based)
+      tail(g)        -> extra SALU lines at the very end of group g
+    Before a group's first MFMA all LDS reads but the four youngest (the refills issued during the previous group) have
+    landed: the refills of the group before that one are this group's fragments."""
+    ngroups = npairs // 2
+    cur, nxt, dma = ts % 3, (ts + 1) % 3, (ts + 2) % 3
+    pub_group = (npairs - 4) // 2
+    for g in range(ngroups):
+        q = 2 * g
+        sa, sb = q % 4, (q + 1) % 4
+        lines = mf(g)
+        gaps = fill(g)
+        e("s_waitcnt lgkmcnt(4)")
+        for i in range(6):
+            e(lines[i])
+            if i == 0:
+                for k in range(pieces_per_group):
+                    dma_piece(e, g * pieces_per_group + k, dma)
+            if i < 5:
+                for ins in gaps[i]:
+                    e(ins)
+            if i + 1 == free_after[0]:
+                if g == pub_group:
+                    publish(e, (g + 1) * pieces_per_group)
+                refill(e, sa, q + 4, npairs, cur, nxt)
+            if i + 1 == free_after[1]:
+                refill(e, sb, q + 5, npairs, cur, nxt)
+        if tail is not None:
+            for ins in tail(g):
+                e(ins)
+
+
+def advance_dch():
+    return ["s_add_i32 %[dch], %[dch], 1", "s_cmp_eq_u32 %[dch], " + str(NCH), "s_cselect_b32 %[dch], 0, %[dch]"]
+
+
+# ------------------------------------------------------------------------------------------------------ WIDE
+def gen_wide(src, dst):
+    L = []
+    e = L.append
+    ring_prologue(e)
+    for g in range(8):
+        for ins in conv(src, 0, g, 0):
+            e(ins)
+    for ins in dma_base():
+        e(ins)
+    for ts in range(8):
+        bank = ts & 1
+
+        def mf(g, bank=bank):
+            s, t = g >> 2, (2 * g) & 7
+            sa, sb = (2 * g) % 4, (2 * g + 1) % 4
+            xh, xl = vr(XB[bank] + s * 4), vr(XB[bank] + 8 + s * 4)
+            d0, d1 = ar(dst, t), ar(dst, t + 1)
+            return [mfma(d0, vr(F_hi(sa)), xh), mfma(d1, vr(F_hi(sb)), xh), mfma(d0, vr(F_hi(sa)), xl),
+                    mfma(d1, vr(F_hi(sb)), xl), mfma(d0, vr(F_lo(sa)), xh), mfma(d1, vr(F_lo(sb)), xh)]
+
+        def fill(g, ts=ts, bank=bank):
+            if ts == 7:
+                return [[], [], [], [], []]
+            cv = conv(src, ts + 1, g, bank ^ 1)
+            return [[], cv[0:4], cv[4:8], cv[8:12], cv[12:13]]
+
+        def tail(g, ts=ts):
+            if ts == 7:
+                return []
+            if 1 <= g <= 3:
+                return [advance_dch()[g - 1]]
+            return dma_base() if g == 7 else []
+
+        chunk_groups(e, 16, ts, mf, fill, (5, 6), 1, tail)
+    ring_epilogue(e, 8)
+    return L
+
+
+# ------------------------------------------------------------------------------------------------------ EXTRA
+def gen_extra(dst, ks):
+    """one chunk of ks (1 or 2) extra k-steps; B operands at %[stage] (this lane's 16 bytes of k-step 0 hi): hi of k-step
+    s at + s*8192, lo at + s*8192 + 4096 (stage layout of mlp_fwd_f16x3.hip)"""
+    L = []
+    e = L.append
+    ring_prologue(e)
+    for s in range(ks):
+        e("ds_read_b128 %s, %%[stage] offset:%d" % (vr(XB[0] + s * 4), s * 8192))
+        e("ds_read_b128 %s, %%[stage] offset:%d" % (vr(XB[0] + 8 + s * 4), s * 8192 + 4096))
+    for ins in dma_base():
+        e(ins)
+    e("s_waitcnt lgkmcnt(0)")
+
+    def mf(g):
+        s, t = g >> 2, (2 * g) & 7
+        sa, sb = (2 * g) % 4, (2 * g + 1) % 4
+        xh, xl = vr(XB[0] + s * 4), vr(XB[0] + 8 + s * 4)
+        d0, d1 = ar(dst, t), ar(dst, t + 1)
+        return [mfma(d0, vr(F_hi(sa)), xh), mfma(d1, vr(F_hi(sb)), xh), mfma(d0, vr(F_hi(sa)), xl),
+                mfma(d1, vr(F_hi(sb)), xl), mfma(d0, vr(F_lo(sa)), xh), mfma(d1, vr(F_lo(sb)), xh)]
+
+    chunk_groups(e, 8 * ks, 0, mf, lambda g: [[], [], [], [], []], (5, 6), 2 // ks)
+    ring_epilogue(e, 1)
+    return L
+
+
+# ------------------------------------------------------------------------------------------------------ HEAD
+def gen_head(src):
+    """acc (v[HACC:HACC+15]) = W_head * relu(src set): 16 k-steps of one tile; group ts contracts source tile ts
+    (k-steps 2 ts, 2 ts + 1), operands of tile ts+1 converted while its six MFMAs issue"""
+    L = []
+    e = L.append
+    ring_prologue(e)
+    for g in range(8):
+        for ins in conv(src, 0, g, 0):
+            e(ins)
+    for ins in dma_base():
+        e(ins)
+    acc = vr(HACC, 16)
+
+    def mf(g):
+        bank = g & 1
+        sa, sb = (2 * g) % 4, (2 * g + 1) % 4
+        xh0, xh1 = vr(XB[bank]), vr(XB[bank] + 4)
+        xl0, xl1 = vr(XB[bank] + 8), vr(XB[bank] + 12)
+        first = mfma(acc, vr(F_hi(sa)), xh0, "0") if g == 0 else mfma(acc, vr(F_hi(sa)), xh0)
+        return [first, mfma(acc, vr(F_hi(sa)), xl0), mfma(acc, vr(F_lo(sa)), xh0),
+                mfma(acc, vr(F_hi(sb)), xh1), mfma(acc, vr(F_hi(sb)), xl1), mfma(acc, vr(F_lo(sb)), xh1)]
+
+    def fill(g):
+        if g == 7:
+            return [[], [], [], [], []]
+        cv = []
+        for k in range(8):
+            cv += conv(src, g + 1, k, (g & 1) ^ 1)
+        # 104 VALU instructions over five gaps: the head is conversion-bound (one tile per six MFMAs)
+        return [cv[0:21], cv[21:42], cv[42:63], cv[63:84], cv[84:104]]
+
+    chunk_groups(e, 16, 0, mf, fill, (3, 6), 1)
+    ring_epilogue(e, 1)
+    e("s_nop 15")                                    # the accumulator tile is read by compiled code after the block
+    e("s_nop 7")
+    return L
+
+
+# ------------------------------------------------------------------------------------------------------ INIT
+def gen_init(dst):
+    """dst set = 128 floats at LDS address %[bias] (this lane half's bias block of the layer, already * 2^8)"""
+    L = []
+    e = L.append
+    e("s_nop 7")
+    bank = [XB[0], XB[1]]
+
+    def reads(rnd):
+        for k in range(4):
+            e("ds_read_b128 %s, %%[bias] offset:%d" % (vr(bank[rnd & 1] + 4 * k), (rnd * 4 + k) * 16))
+
+    def writes(rnd):
+        for k in range(16):
+            e("v_accvgpr_write_b32 a%d, v%d" % (dst + rnd * 16 + k, bank[rnd & 1] + k))
+
+    reads(0)
+    reads(1)
+    for rnd in range(8):
+        e("s_waitcnt lgkmcnt(%d)" % (4 if rnd < 7 else 0))
+        writes(rnd)
+        if rnd + 2 < 8:
+            reads(rnd + 2)
+    e("s_nop 3")
+    return L
+
+
+# ------------------------------------------------------------------------------------------------------ STASH / RESTORE
+SF = 32                       # the trunk feature is held in v[32:159] from L7 to R0
+
+
+def gen_stash(src):
+    return ["s_nop 7", "s_nop 7"] + ["v_accvgpr_read_b32 v%d, a%d" % (SF + k, src + k) for k in range(128)]
+
+
+def gen_restore(dst):
+    return ["v_accvgpr_write_b32 a%d, v%d" % (dst + k, SF + k) for k in range(128)] + ["s_nop 3"]
+
+
+def gen_read_tile(src, tile):
+    """16 accumulators of one tile -> v[232:247] (training: the activation record is written by compiled code)"""
+    return ["s_nop 7", "s_nop 7"] + ["v_accvgpr_read_b32 v%d, a%d" % (HACC + k, src + 16 * tile + k) for k in range(16)]
+
+
+def emit_macro(out, name, comment, lines):
+    out.append("// " + comment)
+    out.append("#define %s \\" % name)
+    out.append(" \\\n".join('    "%s\\n"' % l for l in lines))
+    out.append("")
+
+
+def main():
+    out = ["// GENERATED by gen_wide_asm.py -- do not edit.  See that file for the schedule.", "#pragma once",
+           "#define TP_ASM_CLOBBERS " + ", ".join(['"v%d"' % v for v in CLOBBER_V] + ['"s%d"' % r for r in CLOBBER_S] + ['"a%d"' % a for a in range(256)]),
+           "#define TP_ASM_ALL_AGPRS " + ", ".join('"a%d"' % a for a in range(256))]
+    for s, d in (("Q", "P"), ("P", "Q")):
+        emit_macro(out, "TP_ASM_WIDE_%s%s" % (s, d), "256 -> 256 layer: set %s -> set %s" % (s, d), gen_wide(SET[s], SET[d]))
+    for d in ("P", "Q"):
+        for ks in (1, 2):
+            emit_macro(out, "TP_ASM_EXTRA%d_%s" % (ks, d), "%d extra k-step(s) into set %s" % (ks, d), gen_extra(SET[d], ks))
+        emit_macro(out, "TP_ASM_HEAD_%s" % d, "narrow head over relu(set %s)" % d, gen_head(SET[d]))
+        emit_macro(out, "TP_ASM_INIT_%s" % d, "seed set %s with the bias block" % d, gen_init(SET[d]))
+        for t in range(8):
+            emit_macro(out, "TP_ASM_READ_%s%d" % (d, t), "tile %d of set %s -> v[232:247]" % (t, d), gen_read_tile(SET[d], t))
+    emit_macro(out, "TP_ASM_STASH_Q", "set Q -> v[32:159]", gen_stash(SET["Q"]))
+    emit_macro(out, "TP_ASM_RESTORE_P", "v[32:159] -> set P", gen_restore(SET["P"]))
+    sys.stdout.write("\n".join(out) + "\n")
+
+
+if __name__ == "__main__":
+    main()

@@ -16,6 +16,7 @@
 // 8s..8s+7 of a 32x32 tile, converted to fp16, ARE the B fragment of k-step s (rows 16s + 8(j>>2) + 4h + (j&3)),
 // and the packed weights absorb that row permutation (mlp_layout.h, "f16x3 stream").
 #include "mlp_mma.h"
+#include "wide_asm.inc.h"
 #include <type_traits>
 
 namespace {
@@ -27,9 +28,7 @@ using half2v = __attribute__((ext_vector_type(2))) __fp16;
 
 constexpr int kBiasPad = (kBiasFloats + 63) / 64 * 64;
 constexpr int kStageHalves = 5 * 2 * kThreads * 8;             // 5 k-steps x (hi, lo) x 256 lanes x 8 halves = 40 KiB
-// cache policy of the park / reload of the trunk feature: nt (streaming) keeps the once-written, once-read 128 KiB per
-// workgroup and tile from evicting the 3.7 MB weight stream out of the XCD's 4 MiB L2
-constexpr int kParkAux = 2;
+
 constexpr int kBufs = 3;                                         // weight-chunk ring: two chunks (3072 cycles) ahead
 constexpr int kLdsBytes = kBufs * kChunkFloats * 4 + kBiasPad * 4 + kStageHalves * 2;
 constexpr float kInvScale = 1.0f / (float)(1 << kF16WeightShift);
@@ -297,6 +296,132 @@ __device__ __forceinline__ f32x16 part_head16(Pipe& p, Frag& f, const f32x16 (&V
 __device__ __forceinline__ float softplus(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
 __device__ __forceinline__ float sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+
+// =====================================================================================================================
+// Everything of the FORWARD kernel that touches the two accumulator sets runs in the hand-scheduled asm blocks of
+// wide_asm.inc.h (generated by gen_wide_asm.py; the register map and the ring protocol are documented there): set P is
+// pinned to a[0:127], set Q to a[128:255], the fragment ring to v[160:191].  The C++ around them stages inputs, applies
+// the output non-linearities and stores.  (The dgrad kernel further down still uses the C++ layer body above.)
+// =====================================================================================================================
+struct AsmCtx { unsigned lane16, laneoff, ldswave, stream_lo, stream_hi, bias0, stage0; };
+__device__ __forceinline__ AsmCtx asm_ctx(const Pipe& p, const float* bias_lds, const _Float16* st, int tid, int hh) {
+  AsmCtx c;
+  const unsigned lds0 = (unsigned)(uintptr_t)AS3(p.lds);
+  c.lane16 = lds0 + (unsigned)p.lane * 16u;
+  c.laneoff = (unsigned)p.lane * 16u;
+  c.ldswave = lds0 + (unsigned)p.wave * 8192u;
+  const uint64_t sw = (uint64_t)(uintptr_t)(p.stream + p.wave * 2048);
+  c.stream_lo = (unsigned)sw;
+  c.stream_hi = (unsigned)(sw >> 32);
+  c.bias0 = (unsigned)(uintptr_t)AS3(bias_lds) + (unsigned)hh * 512u;     // + li * 1024: bias block of wide layer li
+  c.stage0 = (unsigned)(uintptr_t)AS3(st) + (unsigned)tid * 16u;          // + ks * 8192: staged k-step ks (hi; lo at + 4096)
+  return c;
+}
+
+#define TP_RING(f)                                                                                                     \
+  "+{v[160:163]}"(f.h[0]), "+{v[164:167]}"(f.l[0]), "+{v[168:171]}"(f.h[1]), "+{v[172:175]}"(f.l[1]),                  \
+      "+{v[176:179]}"(f.h[2]), "+{v[180:183]}"(f.l[2]), "+{v[184:187]}"(f.h[3]), "+{v[188:191]}"(f.l[3])
+#define TP_RING_STATE                                                                                                  \
+  [chunk] "+s"(chunk), [buf] "+s"(buf), [r0] "=&s"(r0), [r1] "=&s"(r1), [r2] "=&s"(r2), [m0a] "=&s"(m0a),              \
+      [m1a] "=&s"(m1a), [m2a] "=&s"(m2a), [dch] "=&s"(dch), [t0] "=&s"(t0)
+#define TP_RING_INPUTS(c)                                                                                              \
+  [lane16] "v"(c.lane16), [laneoff] "v"(c.laneoff), [ldswave] "s"(__builtin_amdgcn_readfirstlane(c.ldswave)),         \
+      [stream_lo] "s"(__builtin_amdgcn_readfirstlane(c.stream_lo)),                                                    \
+      [stream_hi] "s"(__builtin_amdgcn_readfirstlane(c.stream_hi))
+#define TP_RING_LOCALS                                                                                                 \
+  int chunk = __builtin_amdgcn_readfirstlane(p.chunk), buf = __builtin_amdgcn_readfirstlane(p.buf);                    \
+  int r0, r1, r2, m0a, m1a, m2a, dch, t0
+#define TP_RING_DONE                                                                                                   \
+  p.chunk = chunk;                                                                                                     \
+  p.buf = buf
+
+// The sets are NOT C++ values: the blocks address a[0:255] directly and the compiled code in between must never touch
+// an AGPR (check_asm_ownership.py verifies that on the generated assembly; "a0" / "a255" in the clobber lists make the
+// kernel allocate all 256).  Stash / restore of the trunk feature (set Q after L7 -> 128 VGPR values -> set P before R0):
+#define TP_SF_OUT(F)                                                                                                   \
+  "={v[32:47]}"(F[0]), "={v[48:63]}"(F[1]), "={v[64:79]}"(F[2]), "={v[80:95]}"(F[3]), "={v[96:111]}"(F[4]),            \
+      "={v[112:127]}"(F[5]), "={v[128:143]}"(F[6]), "={v[144:159]}"(F[7])
+#define TP_SF_IN(F)                                                                                                    \
+  "{v[32:47]}"(F[0]), "{v[48:63]}"(F[1]), "{v[64:79]}"(F[2]), "{v[80:95]}"(F[3]), "{v[96:111]}"(F[4]),                 \
+      "{v[112:127]}"(F[5]), "{v[128:143]}"(F[6]), "{v[144:159]}"(F[7])
+__device__ __forceinline__ void asm_stash_q(f32x16 (&F)[8]) { asm volatile(TP_ASM_STASH_Q : TP_SF_OUT(F) : : TP_ASM_ALL_AGPRS); }
+__device__ __forceinline__ void asm_restore_p(const f32x16 (&F)[8]) { asm volatile(TP_ASM_RESTORE_P : : TP_SF_IN(F) : TP_ASM_ALL_AGPRS); }
+// one tile of a set as a value (the training variant writes the activation record from compiled code)
+template <bool SET_P, int T>
+__device__ __forceinline__ f32x16 asm_read_tile() {
+  f32x16 v;
+#define TP_RD(NAME) asm volatile(NAME : "={v[232:247]}"(v) : : TP_ASM_ALL_AGPRS)
+  if constexpr (SET_P) {
+    if constexpr (T == 0) TP_RD(TP_ASM_READ_P0); else if constexpr (T == 1) TP_RD(TP_ASM_READ_P1);
+    else if constexpr (T == 2) TP_RD(TP_ASM_READ_P2); else if constexpr (T == 3) TP_RD(TP_ASM_READ_P3);
+    else if constexpr (T == 4) TP_RD(TP_ASM_READ_P4); else if constexpr (T == 5) TP_RD(TP_ASM_READ_P5);
+    else if constexpr (T == 6) TP_RD(TP_ASM_READ_P6); else TP_RD(TP_ASM_READ_P7);
+  } else {
+    if constexpr (T == 0) TP_RD(TP_ASM_READ_Q0); else if constexpr (T == 1) TP_RD(TP_ASM_READ_Q1);
+    else if constexpr (T == 2) TP_RD(TP_ASM_READ_Q2); else if constexpr (T == 3) TP_RD(TP_ASM_READ_Q3);
+    else if constexpr (T == 4) TP_RD(TP_ASM_READ_Q4); else if constexpr (T == 5) TP_RD(TP_ASM_READ_Q5);
+    else if constexpr (T == 6) TP_RD(TP_ASM_READ_Q6); else TP_RD(TP_ASM_READ_Q7);
+  }
+#undef TP_RD
+  return v;
+}
+
+// 256 -> 256 layer body; SRC_Q: read set Q, accumulate into set P, else the reverse
+template <bool SRC_Q>
+__device__ __forceinline__ void asm_wide(Pipe& p, Frag& f, Guard& amax, const AsmCtx& c) {
+  TP_RING_LOCALS;
+  const float kinv = kInvScale;
+  const unsigned mask = 0xFFFFE000u;
+  if constexpr (SRC_Q)
+    asm volatile(TP_ASM_WIDE_QP : TP_RING(f), TP_RING_STATE, [amax] "+v"(amax.m)
+                 : TP_RING_INPUTS(c), [kinv] "s"(kinv), [mask] "s"(mask) : TP_ASM_CLOBBERS, "memory", "scc");
+  else
+    asm volatile(TP_ASM_WIDE_PQ : TP_RING(f), TP_RING_STATE, [amax] "+v"(amax.m)
+                 : TP_RING_INPUTS(c), [kinv] "s"(kinv), [mask] "s"(mask) : TP_ASM_CLOBBERS, "memory", "scc");
+  TP_RING_DONE;
+}
+
+// one chunk of KS extra k-steps (staged inputs ks0 .. ks0+KS-1) into set P (DST_P) or Q
+template <int KS, bool DST_P>
+__device__ __forceinline__ void asm_extra(Pipe& p, Frag& f, const AsmCtx& c, int ks0) {
+  TP_RING_LOCALS;
+  const unsigned stage = c.stage0 + (unsigned)ks0 * 8192u;
+#define TP_EXTRA(TXT)                                                                                                  \
+  asm volatile(TXT : TP_RING(f), TP_RING_STATE : TP_RING_INPUTS(c), [stage] "v"(stage)                  \
+               : TP_ASM_CLOBBERS, "memory", "scc")
+  if constexpr (KS == 1 && DST_P) TP_EXTRA(TP_ASM_EXTRA1_P);
+  else if constexpr (KS == 2 && DST_P) TP_EXTRA(TP_ASM_EXTRA2_P);
+  else if constexpr (KS == 1) TP_EXTRA(TP_ASM_EXTRA1_Q);
+  else TP_EXTRA(TP_ASM_EXTRA2_Q);
+#undef TP_EXTRA
+  TP_RING_DONE;
+}
+
+// narrow output layer over relu(set P) (SRC_P) or relu(set Q): accumulator tile (still scaled by 2^8)
+template <bool SRC_P>
+__device__ __forceinline__ f32x16 asm_head(Pipe& p, Frag& f, Guard& amax, const AsmCtx& c) {
+  TP_RING_LOCALS;
+  const float kinv = kInvScale;
+  const unsigned mask = 0xFFFFE000u;
+  f32x16 acc;
+  if constexpr (SRC_P)
+    asm volatile(TP_ASM_HEAD_P : TP_RING(f), TP_RING_STATE, [amax] "+v"(amax.m), "=&{v[232:247]}"(acc)
+                 : TP_RING_INPUTS(c), [kinv] "s"(kinv), [mask] "s"(mask) : TP_ASM_CLOBBERS, "memory", "scc");
+  else
+    asm volatile(TP_ASM_HEAD_Q : TP_RING(f), TP_RING_STATE, [amax] "+v"(amax.m), "=&{v[232:247]}"(acc)
+                 : TP_RING_INPUTS(c), [kinv] "s"(kinv), [mask] "s"(mask) : TP_ASM_CLOBBERS, "memory", "scc");
+  TP_RING_DONE;
+  return acc;
+}
+
+// seed set P (DST_P) or Q with the bias block of wide layer li (bias * 2^8 in LDS)
+template <bool DST_P>
+__device__ __forceinline__ void asm_init(const AsmCtx& c, int li) {
+  const unsigned bias = c.bias0 + (unsigned)li * 1024u;
+  if constexpr (DST_P) asm volatile(TP_ASM_INIT_P :: [bias] "v"(bias) : TP_ASM_CLOBBERS, "memory");
+  else asm volatile(TP_ASM_INIT_Q :: [bias] "v"(bias) : TP_ASM_CLOBBERS, "memory");
+}
+
 struct Params {
   const float* packed;
   const float* center; const float* ray; const float* depth;
@@ -322,6 +447,13 @@ __device__ __forceinline__ void stage_slot(_Float16* st, int tid_lo, int slot, f
   st[((ks * 2 + 1) * kThreads + owner) * 8 + jj] = (_Float16)(v - (float)hi);
 }
 
+// a[c] for a run-time c in 0..2 as pure ALU work (a three-way select of VARIABLES is rewritten by the optimiser into an
+// indexed load, which demotes them -- and everything captured next to them -- to scratch memory)
+__device__ __forceinline__ float pick3(int c, float a0, float a1, float a2) {
+  const uint32_t m0 = c == 0 ? 0xFFFFFFFFu : 0u, m1 = c == 1 ? 0xFFFFFFFFu : 0u, m2 = c == 2 ? 0xFFFFFFFFu : 0u;
+  return __uint_as_float((__float_as_uint(a0) & m0) | (__float_as_uint(a1) & m1) | (__float_as_uint(a2) & m2));
+}
+
 template <bool SAVE>
 __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_f16x3_kernel(Params P) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -340,20 +472,13 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_f16x3_kernel(Params P) {
   __syncthreads();
   Frag frag;
   frag_prime(p, frag);
-  // Persistent workgroups that start together stay in lockstep, so every CU would park / reload its 128 KB trunk
-  // feature (and miss on the same weight chunks) at the same instant.  Spread the start phases over ~one tile.
+  // Persistent workgroups that start together stay in lockstep, so every CU would miss on the same weight chunks at
+  // the same instant.  Spread the start phases over ~one tile.
   for (int i = (blockIdx.x * 37) & 63; i > 0; --i) __builtin_amdgcn_s_sleep(127);
 #ifdef TP_TRACE
   const long long tr_start = tick();
 #endif
-
-  // park buffer of this workgroup (128 KiB) as a buffer resource: lane offset in a VGPR, the 4 KiB row offsets in
-  // SGPRs -- 64-bit per-row VGPR addresses would be spilled and reloaded one by one
-  const __amdgpu_buffer_rsrc_t ws = __builtin_amdgcn_make_buffer_rsrc(P.workspace + (size_t)blockIdx.x * (128 * 256), 0, 128 * 256 * 4, 0x00020000);
-  const auto staged = [&](int s, half8& xh, half8& xl, int ks0) {
-    xh = *reinterpret_cast<const half8*>(st + (((ks0 + s) * 2 + 0) * kThreads + tid) * 8);
-    xl = *reinterpret_cast<const half8*>(st + (((ks0 + s) * 2 + 1) * kThreads + tid) * 8);
-  };
+  const AsmCtx cx = asm_ctx(p, bias_lds, st, tid, hh);
 
   for (int64_t tile = blockIdx.x; tile < P.n_tiles; tile += gridDim.x) {
     TR_BEGIN(pro);
@@ -362,77 +487,71 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_f16x3_kernel(Params P) {
     const int64_t s = live ? s_raw : P.n_samples - 1;
     const int64_t q = s / P.N;
     const int b = (int)(q / P.R);
-    float x[3], vu[3];
+    // (six scalars, not two arrays: the staging loops pick a coordinate by a run-time index, and an ARRAY picked that way
+    // is demoted to scratch memory)
+    struct { float x0, x1, x2, vu0, vu1, vu2, raw_s, raw_t0, raw_t1, raw_t2, raw_t3, raw_r0, raw_r1, raw_r2; } ts;
     if (P.center != nullptr) {
       const float z = P.depth[s];
-      float nrm = 0.f;
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const float d = P.ray[3 * q + c];
-        x[c] = tp::add_rn(P.center[3 * q + c], tp::mul_rn(d, z));
-        nrm = tp::add_rn(nrm, tp::mul_rn(d, d));
-        vu[c] = d;
-      }
+      const float d0 = P.ray[3 * q + 0], d1 = P.ray[3 * q + 1], d2 = P.ray[3 * q + 2];
+      ts.x0 = tp::add_rn(P.center[3 * q + 0], tp::mul_rn(d0, z));
+      ts.x1 = tp::add_rn(P.center[3 * q + 1], tp::mul_rn(d1, z));
+      ts.x2 = tp::add_rn(P.center[3 * q + 2], tp::mul_rn(d2, z));
+      float nrm = tp::add_rn(0.f, tp::mul_rn(d0, d0));
+      nrm = tp::add_rn(nrm, tp::mul_rn(d1, d1));
+      nrm = tp::add_rn(nrm, tp::mul_rn(d2, d2));
       const float den = fmaxf(sqrtf(nrm), 1e-12f);
-#pragma unroll
-      for (int c = 0; c < 3; ++c) vu[c] = tp::div_rn(vu[c], den);
+      ts.vu0 = tp::div_rn(d0, den); ts.vu1 = tp::div_rn(d1, den); ts.vu2 = tp::div_rn(d2, den);
     } else {
-#pragma unroll
-      for (int c = 0; c < 3; ++c) { x[c] = P.points[3 * s + c]; vu[c] = P.ray_unit[3 * s + c]; }
+      ts.x0 = P.points[3 * s + 0]; ts.x1 = P.points[3 * s + 1]; ts.x2 = P.points[3 * s + 2];
+      ts.vu0 = P.ray_unit[3 * s + 0]; ts.vu1 = P.ray_unit[3 * s + 1]; ts.vu2 = P.ray_unit[3 * s + 2];
     }
 
-    asm volatile("" :: "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(vu[0]), "v"(vu[1]), "v"(vu[2]));
+    asm volatile("" :: "v"(ts.x0), "v"(ts.x1), "v"(ts.x2), "v"(ts.vu0), "v"(ts.vu1), "v"(ts.vu2));
     TR_END(4, pro);
-    f32x16 SP[8], SQ[8];        // the two accumulator sets (see "operand conversion")
+    // The two accumulator sets: even layers read Q and accumulate into P, odd layers the reverse (the layer loop is
+    // unrolled by two, so both roles are fixed registers).  A set holds raw accumulators, bias included (seeded with
+    // bias * 2^8); the next layer's B operands are produced from it inside the asm blocks.
+    f32x16 SF[8];               // the trunk feature (L7's accumulators), held in v[32:159] from L7 to R0
     Guard amax;
-    float sig_s = 0.f, sig_t = 0.f, unc = 0.f, rgb_t[3] = {0.f, 0.f, 0.f}, rgb_s[3] = {0.f, 0.f, 0.f};
+    // raw outputs of the three narrow heads (still scaled by 2^8, bias not added): the non-linearities run in the output
+    // section at the end of the tile, so that no transcendental code sits between the blocks while the trunk feature
+    // occupies 128 VGPRs
+    ts.raw_s = ts.raw_t0 = ts.raw_t1 = ts.raw_t2 = ts.raw_t3 = ts.raw_r0 = ts.raw_r1 = ts.raw_r2 = 0.f;
 
-    // a narrow output layer over relu(S); which == 0: sigma (reads L6), 1: transient head (reads T2), 2: static rgb
-    const auto head = [&](const f32x16 (&S)[8], int which) {
+    // a narrow output layer; which == 0: sigma (reads L6 = set P), 1: transient head (reads T2 = set P), 2: static
+    // rgb (reads R2 = set Q)
+    const auto head = [&](int which) {
       TR_BEGIN(h);
-      const f32x16 a = part_head16(p, frag, S, amax);
-      asm volatile("" :: "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]));
+      const f32x16 a = which == 2 ? asm_head<false>(p, frag, amax, cx) : asm_head<true>(p, frag, amax, cx);
       TR_END(7, h);
-      const float* hb = bias_lds + kHeadBiasOff + (which == 0 ? 0 : (which == 1 ? 1 : 6));
-      const float h0 = fmaf(a[0], kInvScale, hb[0]), h1 = fmaf(a[1], kInvScale, hb[1]), h2 = fmaf(a[2], kInvScale, hb[2]);
       if (which == 0) {
-        sig_s = softplus(h0);
+        ts.raw_s = a[0];
+      } else if (which == 1) {
+        ts.raw_t0 = a[0]; ts.raw_t1 = a[1]; ts.raw_t2 = a[2]; ts.raw_t3 = a[3];   // (upper lane half: a[0] is row 4 = uncertainty)
       } else {
-        const float r0 = sigmoid(h0), r1 = sigmoid(h1), r2 = sigmoid(h2);
-        if (which == 1) {
-          rgb_t[0] = r0; rgb_t[1] = r1; rgb_t[2] = r2;
-          sig_t = softplus(fmaf(a[3], kInvScale, hb[3]));
-          unc = softplus(fmaf(a[0], kInvScale, hb[4]));      // row 4 = register 0 of the upper lane half
-        } else {
-          rgb_s[0] = r0; rgb_s[1] = r1; rgb_s[2] = r2;
-        }
+        ts.raw_r0 = a[0]; ts.raw_r1 = a[1]; ts.raw_r2 = a[2];
       }
     };
 
-    // one wide layer: reads set S (the previous layer's accumulators), accumulates into set D
-    const auto layer = [&](auto even_tag, int li, f32x16 (&S)[8], f32x16 (&D)[8]) {
+    // one wide layer: EVEN layers read set Q and accumulate into set P, odd layers the reverse
+    const auto layer = [&](auto even_tag, int li) {
       constexpr bool EVEN = decltype(even_tag)::value;
-      if (!EVEN && (li == L7 || li == R0)) head(S, li == L7 ? 0 : 1);     // both heads read set P
+      if (!EVEN && (li == L7 || li == R0)) head(li == L7 ? 0 : 1);       // both heads read set P
       if (!EVEN && li == R0) {
-        // the trunk feature (L7's accumulators, parked below) comes back into the set the transient head just freed
+        // the trunk feature comes back into the set the transient head just freed
         TR_BEGIN(rl);
-#pragma unroll
-        for (int t = 0; t < 8; ++t)
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ws, tid * 16, (t * 4 + g) * 4096, kParkAux));
-            S[t][g * 4 + 0] = v.x; S[t][g * 4 + 1] = v.y; S[t][g * 4 + 2] = v.z; S[t][g * 4 + 3] = v.w;
-          }
-        asm volatile("" :: "v"(S[7][15]), "v"(S[0][0]));
+        asm_restore_p(SF);
         TR_END(10, rl);
       }
       TR_BEGIN(ia);
-      asm volatile("" ::: "memory");     // keep the 32 bias reads below the head / reload (hoisted, they get spilled)
-      init_acc(D, bias_lds + (li * 2 + hh) * 128);
-      asm volatile("" :: "v"(D[7][15]), "v"(D[0][0]), "v"(D[3][3]));
+      asm_init<EVEN>(cx, li);
       TR_END(8, ia);
 
-      if (li != L0) part_gen16(p, frag, D, S, amax);
+      if (li != L0) {
+        TR_BEGIN(w);
+        asm_wide<EVEN>(p, frag, amax, cx);
+        TR_END(3, w);
+      }
 
       if (EVEN && (li == L0 || li == L4)) {
         // [PE(x) | x | pad] in natural column order; this lane stages slots 16 ks + 8 h + jj.  Staged once per tile:
@@ -444,27 +563,29 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_f16x3_kernel(Params P) {
 #pragma nounroll
           for (int i = 0; i < 15; ++i) {
             const int pi_ = hh * 15 + i, c = (pi_ * 205) >> 11, l = pi_ - c * 10;
-            const float xc = c == 0 ? x[0] : (c == 1 ? x[1] : x[2]);
+            const float xc = pick3(c, ts.x0, ts.x1, ts.x2);
             float sv, cv;
             tp::sincos_both(tp::mul_rn(xc, ldexpf(3.14159274101257324f, l)), sv, cv);
             stage_slot(st, tid & ~32, 20 * c + l, sv);
             stage_slot(st, tid & ~32, 20 * c + 10 + l, cv);
           }
           if (hh) {
-            stage(st, tid, 3, 4, x[0]); stage(st, tid, 3, 5, x[1]); stage(st, tid, 3, 6, x[2]); stage(st, tid, 3, 7, 0.0f);
+            stage(st, tid, 3, 4, ts.x0); stage(st, tid, 3, 5, ts.x1); stage(st, tid, 3, 6, ts.x2); stage(st, tid, 3, 7, 0.0f);
           }
         }
         TR_END(5, pe);
-#pragma unroll
-        for (int qd = 0; qd < 2; ++qd) {
-          mma_wide16<2>(p, frag, D, [&](int s_, half8& xh, half8& xl) { staged(s_, xh, xl, qd * 2); }, [](int) {});
-        }
+        TR_BEGIN(w);
+        asm_extra<2, true>(p, frag, cx, 0);
+        asm_extra<2, true>(p, frag, cx, 2);
+        TR_END(3, w);
       } else if (EVEN && li == T0) {
         TR_BEGIN(t0s);
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) stage(st, tid, 0, jj, P.lat_trans[b * 16 + 8 * hh + jj]);
         TR_END(13, t0s);
-        mma_wide16<1>(p, frag, D, [&](int s_, half8& xh, half8& xl) { staged(s_, xh, xl, 0); }, [](int) {});
+        TR_BEGIN(w);
+        asm_extra<1, true>(p, frag, cx, 0);
+        TR_END(3, w);
       } else if (!EVEN && li == R0) {
         // [ray_unit | PE(ray_unit) | x | light] in natural column order, 78 of 80 slots
         TR_BEGIN(r0s);
@@ -475,7 +596,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_f16x3_kernel(Params P) {
 #pragma nounroll
         for (int i = 0; i < 6; ++i) {
           const int pi_ = hh * 6 + i, c = pi_ >> 2, l = pi_ & 3;
-          const float vc = c == 0 ? vu[0] : (c == 1 ? vu[1] : vu[2]);
+          const float vc = pick3(c, ts.vu0, ts.vu1, ts.vu2);
           float sv, cv;
           tp::sincos_both(tp::mul_rn(vc, ldexpf(3.14159274101257324f, l)), sv, cv);
           stage_slot(st, tid & ~32, 3 + 8 * c + l, sv);
@@ -483,12 +604,12 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_f16x3_kernel(Params P) {
           if (SAVE && live) { sx[blk_off(3 + 8 * c + l, j)] = sv; sx[blk_off(3 + 8 * c + 4 + l, j)] = cv; }
         }
         if (hh == 0) {
-          stage(st, tid, 0, 0, vu[0]); stage(st, tid, 0, 1, vu[1]); stage(st, tid, 0, 2, vu[2]);
-          if (SAVE && live) { sx[blk_off(0, j)] = vu[0]; sx[blk_off(1, j)] = vu[1]; sx[blk_off(2, j)] = vu[2]; }
+          stage(st, tid, 0, 0, ts.vu0); stage(st, tid, 0, 1, ts.vu1); stage(st, tid, 0, 2, ts.vu2);
+          if (SAVE && live) { sx[blk_off(0, j)] = ts.vu0; sx[blk_off(1, j)] = ts.vu1; sx[blk_off(2, j)] = ts.vu2; }
         } else {
-          stage(st, tid, 1, 3, x[0]); stage(st, tid, 1, 4, x[1]); stage(st, tid, 1, 5, x[2]);
+          stage(st, tid, 1, 3, ts.x0); stage(st, tid, 1, 4, ts.x1); stage(st, tid, 1, 5, ts.x2);
           stage(st, tid, 1, 6, P.lat_light[b * 48 + 0]); stage(st, tid, 1, 7, P.lat_light[b * 48 + 1]);
-          if (SAVE && live) { sx[blk_off(27, j)] = x[0]; sx[blk_off(28, j)] = x[1]; sx[blk_off(29, j)] = x[2]; }
+          if (SAVE && live) { sx[blk_off(27, j)] = ts.x0; sx[blk_off(28, j)] = ts.x1; sx[blk_off(29, j)] = ts.x2; }
         }
         // k-steps 2..4 are latent-code slots only: 8 loads at a time (one latency per k-step), one 16-byte store per
         // (k-step, hi/lo)
@@ -510,11 +631,11 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_f16x3_kernel(Params P) {
           *reinterpret_cast<half8*>(st + ((ks * 2 + 1) * kThreads + tid) * 8) = lo8;
         }
         TR_END(6, r0s);
-#pragma unroll
-        for (int qd = 0; qd < 3; ++qd) {
-          if (qd < 2) mma_wide16<2>(p, frag, D, [&](int s_, half8& xh, half8& xl) { staged(s_, xh, xl, qd * 2); }, [](int) {});
-          else mma_wide16<1>(p, frag, D, [&](int s_, half8& xh, half8& xl) { staged(s_, xh, xl, 4); }, [](int) {});
-        }
+        TR_BEGIN(w);
+        asm_extra<2, false>(p, frag, cx, 0);
+        asm_extra<2, false>(p, frag, cx, 2);
+        asm_extra<1, false>(p, frag, cx, 4);
+        TR_END(3, w);
       }
 
       if (SAVE && li >= L7 && live) {
@@ -525,49 +646,73 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_f16x3_kernel(Params P) {
         int o16[16];
         lane_block_offsets(j, hh, o16);
         uint32_t* mk = reinterpret_cast<uint32_t*>(grp + kMaskOff) + (li - T0) * 256 + lane;
-#pragma unroll
-        for (int w4 = 0; w4 < 4; ++w4) {
+        const auto two_tiles = [&](auto w4_tag) {
+          constexpr int w4 = decltype(w4_tag)::value;
+          const f32x16 d0 = asm_read_tile<EVEN, 2 * w4>();
           uint32_t m = 0;
 #pragma unroll
-          for (int bt = 0; bt < 32; ++bt) {
-            const int t = 2 * w4 + (bt >> 4), r = bt & 15;
-            const float hv = fmaxf(D[t][r] * kInvScale, 0.0f);
-            blk[t * 1024 + o16[r]] = hv;
-            m |= (hv > 0.0f ? 1u : 0u) << bt;
+          for (int r = 0; r < 16; ++r) {
+            const float hv = fmaxf(d0[r] * kInvScale, 0.0f);
+            blk[(2 * w4) * 1024 + o16[r]] = hv;
+            m |= (hv > 0.0f ? 1u : 0u) << r;
+          }
+          const f32x16 d1 = asm_read_tile<EVEN, 2 * w4 + 1>();
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float hv = fmaxf(d1[r] * kInvScale, 0.0f);
+            blk[(2 * w4 + 1) * 1024 + o16[r]] = hv;
+            m |= (hv > 0.0f ? 1u : 0u) << (16 + r);
           }
           if (li >= T0) mk[w4 * 64] = m;
-        }
+        };
+        two_tiles(std::integral_constant<int, 0>{});
+        two_tiles(std::integral_constant<int, 1>{});
+        two_tiles(std::integral_constant<int, 2>{});
+        two_tiles(std::integral_constant<int, 3>{});
       }
       if (!EVEN && li == L7) {
-        // park the trunk feature (raw accumulators) for R0: T1 overwrites this set
+        // keep the trunk feature (raw accumulators of L7, set Q) for R0: T1 overwrites set Q
         TR_BEGIN(vc);
-#pragma unroll
-        for (int t = 0; t < 8; ++t)
-#pragma unroll
-          for (int g = 0; g < 4; ++g)
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{D[t][g * 4 + 0], D[t][g * 4 + 1], D[t][g * 4 + 2], D[t][g * 4 + 3]}),
-                                                   ws, tid * 16, (t * 4 + g) * 4096, kParkAux);
+        asm_stash_q(SF);
         TR_END(9, vc);
       }
     };
 
 #pragma nounroll
     for (int pr = 0; pr < kNumWide / 2; ++pr) {
-      layer(std::true_type{}, 2 * pr, SQ, SP);
-      layer(std::false_type{}, 2 * pr + 1, SP, SQ);
+      layer(std::true_type{}, 2 * pr);
+      layer(std::false_type{}, 2 * pr + 1);
     }
-    head(SQ, 2);
+    head(2);
 
     TR_BEGIN(o);
-    if (live) {
-      if (hh == 0) {
-        float2* o = reinterpret_cast<float2*>(P.rgb + s * 6);
-        o[0] = make_float2(rgb_s[0], rgb_t[0]);
-        o[1] = make_float2(rgb_s[1], rgb_t[1]);
-        o[2] = make_float2(rgb_s[2], rgb_t[2]);
-        *reinterpret_cast<float2*>(P.density + s * 2) = make_float2(sig_s, sig_t);
-      } else {
-        P.uncert[s] = unc;
+    {
+      // output section: sample index recomputed here (and hidden from the optimiser: addresses formed at the top of the
+      // tile would have to live through every block, i.e. in scratch memory)
+      int64_t so = tile * 128 + wave * 32 + j;
+      asm volatile("" : "+v"(so));
+      const bool live_o = so < P.n_samples;
+      const float* hb = bias_lds + kHeadBiasOff;          // [b7[0], T3 bias 0..4, R3 bias 0..2]
+      if (live_o) {
+        if (hh == 0) {
+          const float sig_s = softplus(fmaf(ts.raw_s, kInvScale, hb[0]));
+          const float sig_t = softplus(fmaf(ts.raw_t3, kInvScale, hb[4]));
+          const float rt[3] = {sigmoid(fmaf(ts.raw_t0, kInvScale, hb[1])), sigmoid(fmaf(ts.raw_t1, kInvScale, hb[2])),
+                               sigmoid(fmaf(ts.raw_t2, kInvScale, hb[3]))};
+          const float rs[3] = {sigmoid(fmaf(ts.raw_r0, kInvScale, hb[6])), sigmoid(fmaf(ts.raw_r1, kInvScale, hb[7])),
+                               sigmoid(fmaf(ts.raw_r2, kInvScale, hb[8]))};
+          // streaming stores: the outputs are never read by this kernel and must not evict the weight stream from L2
+          float* o = P.rgb + so * 6;
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            __builtin_nontemporal_store(rs[c], o + 2 * c);
+            __builtin_nontemporal_store(rt[c], o + 2 * c + 1);
+          }
+          __builtin_nontemporal_store(sig_s, P.density + so * 2);
+          __builtin_nontemporal_store(sig_t, P.density + so * 2 + 1);
+        } else {
+          __builtin_nontemporal_store(softplus(fmaf(ts.raw_t0, kInvScale, hb[5])), P.uncert + so);   // row 4 = register 0 of the upper lane half
+        }
       }
     }
     if (P.status != nullptr && !(fmaxf((float)amax.m[0], (float)amax.m[1]) < 6.0e4f)) atomicOr(P.status, 1);

@@ -113,6 +113,7 @@ struct Args {
   const float* intr; const float* pose; const float* coords; const int64_t* ray_idx;
   const float* z_near; const float* z_far; const float* rnd;
   float amin[3], amax[3], bg_near, bg_far;
+  const float* valid_rect;
   uint64_t seed, offset;
   int B, R, H, W, N, pixel_mode, bounds_mode, jitter_mode;
   float* center; float* ray; float* near; float* far; float* depth;
@@ -199,6 +200,11 @@ __global__ __launch_bounds__(kTile) void raygen_kernel(Args a) {
       tf = ok ? tf : 0.0f;
       near = tn > 0.0f ? tn : a.bg_near;
       far = tf > 0.0f ? tf : a.bg_far;
+      if (a.valid_rect != nullptr) {
+        // crop pixels without a source pixel in the camera frame: the stored maps are zero-padded there -> fallback range
+        const float* vr = a.valid_rect + 4 * b;
+        if (!(u >= vr[0] && u < vr[2] && v >= vr[1] && v < vr[3])) { near = a.bg_near; far = a.bg_far; }
+      }
     }
     if (a.bounds_mode != TP_BOUNDS_NONE) {
       if (a.near) a.near[q] = near;
@@ -299,7 +305,7 @@ extern "C" int tp_raygen(const tp_raygen_args* p, tp_stream_t stream) {
   a.intr = p->intr; a.pose = p->pose; a.coords = p->coords; a.ray_idx = p->ray_idx;
   a.z_near = p->z_near; a.z_far = p->z_far; a.rnd = p->rand;
   for (int i = 0; i < 3; ++i) { a.amin[i] = p->aabb_min[i]; a.amax[i] = p->aabb_max[i]; }
-  a.bg_near = p->bg_near; a.bg_far = p->bg_far; a.seed = p->seed; a.offset = p->offset;
+  a.bg_near = p->bg_near; a.bg_far = p->bg_far; a.valid_rect = p->valid_rect; a.seed = p->seed; a.offset = p->offset;
   a.B = p->B; a.R = p->R; a.H = p->H; a.W = p->W; a.N = p->N;
   a.pixel_mode = p->pixel_mode; a.bounds_mode = p->bounds_mode; a.jitter_mode = p->jitter_mode;
   a.center = p->center; a.ray = p->ray; a.near = p->near; a.far = p->far; a.depth = p->depth;

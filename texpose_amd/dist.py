@@ -105,3 +105,30 @@ def all_reduce_scalars(*values: torch.Tensor, group=None) -> List[torch.Tensor]:
     buf = torch.stack([v.detach().reshape(()) for v in values])
     dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
     return list(buf.unbind(0))
+
+
+def setup_data_parallel(graph: torch.nn.Module, seed: int = 0, group=None) -> tuple:
+    """What a data-parallel training process does once, before it builds its trainer (texpose_amd.trainer):
+      1. every rank starts from rank 0's state: parameters AND buffers (spectral-norm u / v, ``progress``) are broadcast;
+      2. per-rank random streams: patch scale / shift draws (torch.rand) and the in-kernel Philox jitter (seeded from
+         torch.initial_seed(), texpose_amd/graph.py) must differ between ranks, so rank r seeds with ``seed + r``.
+    Returns (rank, world).  Normaliser note: the photometric term divides by THIS rank's mask
+    count (reference model/nerf_adapt_st_gan.py:750); averaging the ranks' gradients therefore weights every image by
+    1 / (world * sum_rank(mask)) instead of 1 / sum_all(mask) -- identical when the ranks' mask counts agree, and at
+    most the relative spread of the counts otherwise.  ``all_reduce_scalars`` is there for callers who want the exact
+    global normaliser."""
+    rank = dist.get_rank(group) if dist.is_available() and dist.is_initialized() else 0
+    world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+    broadcast_module_state(graph, src=0, group=group)
+    torch.manual_seed(seed + rank)
+    return rank, world
+
+
+def shard_training_batch(var, rank: int, world: int):
+    """This rank's images of a collated batch (every tensor whose leading dimension is the batch size)."""
+    B = len(var["idx"])
+    sl = shard_batch(B, rank, world)
+    out = type(var)()
+    for k, v in var.items():
+        out[k] = v[sl.start:sl.stop] if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == B else v
+    return out

@@ -99,6 +99,16 @@ class Discriminator(nn.Module):
             raise ValueError("patch_size must be 16, 32, 64 or 128")
         self.progress = nn.Parameter(torch.tensor(0.))
         conv = SNConv2d
+        final_dim = ndf if self.scale_conditional else 1
+        if self.scale_conditional:
+            # registered BEFORE ``main``, as in the reference (layers/discriminator.py:30-39): parameters() -- and with it the
+            # parameter numbering inside a saved ``optim_disc`` state -- runs progress, final.{1,3,5}, main.{0,3,6}
+            # 2^l pi, l < L_scale (a constant: kept as a non-persistent buffer instead of three launches per forward)
+            self.register_buffer("scale_freq", (2 ** torch.arange(self.L_scale, dtype=torch.float32)) * math.pi,
+                                 persistent=False)
+            c = ndf + 2 * self.L_scale + 1
+            self.final = nn.Sequential(nn.LeakyReLU(0.2), conv(c, ndf, 1, 1, 0), nn.LeakyReLU(0.2, inplace=True),
+                                       conv(ndf, ndf, 1, 1, 0), nn.LeakyReLU(0.2, inplace=True), conv(ndf, 1, 1, 1, 0))
         # stride-2 ladder down to 8x8 with 256 channels; the first stage of the 64/128 ladders has no norm
         widths = {16: [ndf * 4], 32: [ndf * 2, ndf * 4], 64: [ndf, ndf * 2, ndf * 4],
                   128: [ndf // 2, ndf, ndf * 2, ndf * 4]}[p]
@@ -109,17 +119,9 @@ class Discriminator(nn.Module):
                 blocks.append(nn.InstanceNorm2d(w))
             blocks.append(nn.LeakyReLU(0.2, inplace=True))
             c_in = w
-        final_dim = ndf if self.scale_conditional else 1
         blocks += [conv(c_in, ndf * 8, 4, 2, 1), nn.InstanceNorm2d(ndf * 8), nn.LeakyReLU(0.2, inplace=True),
                    conv(ndf * 8, final_dim, 4, 1, 0)]
         self.main = nn.Sequential(*blocks)
-        if self.scale_conditional:
-            # 2^l pi, l < L_scale (a constant: kept as a non-persistent buffer instead of three launches per forward)
-            self.register_buffer("scale_freq", (2 ** torch.arange(self.L_scale, dtype=torch.float32)) * math.pi,
-                                 persistent=False)
-            c = ndf + 2 * self.L_scale + 1
-            self.final = nn.Sequential(nn.LeakyReLU(0.2), conv(c, ndf, 1, 1, 0), nn.LeakyReLU(0.2, inplace=True),
-                                       conv(ndf, ndf, 1, 1, 0), nn.LeakyReLU(0.2, inplace=True), conv(ndf, 1, 1, 1, 0))
 
     @staticmethod
     def _run(seq, x, weights):

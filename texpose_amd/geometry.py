@@ -79,6 +79,59 @@ def enlarge_diagonal(aabb_min, aabb_max, alpha=0.25):
     return aabb_min - pad, aabb_max + pad
 
 
+# ----------------------------------------------------------------------------- detection crops
+def crop_camera(cam_K, center, scale, res, raw_hw=(480, 640), stored_map_convention=False):
+    """Camera of the ``res`` x ``res`` network input cut around a detection box, as the reference's data layer defines it:
+    ``center`` = (row, col) and ``scale`` (side of the square in raw pixels) from ``get_2d_bbox`` (data/lm.py:161-180).
+    Returns (intr [3,3], rect (x0, y0, x1, y1)): the intrinsics of ``preprocess_intrinsics`` applied at
+    ``center + get_center_offset`` (data/lm.py:373-378,412-451) and the rectangle of crop pixels that have a source pixel
+    inside the raw frame -- ``Crop_by_Pad`` (data/lm.py:455-495) resizes the clipped square keeping its aspect and pastes it
+    centred into a zero canvas, so everything outside ``rect`` is padding.  Host arithmetic (a few scalars per image).
+
+    ``stored_map_convention=True`` returns the camera under which the ON-THE-FLY slab test reproduces the reference's STORED
+    bound maps: those are resampled with cv2's pixel-centre alignment from a map built with +0.5 ray centres
+    (camera.py:301-302), which puts their samples 0.5 * (resize - 1) crop pixels off the rays the resized intrinsics
+    define.  Use it for ``online_box_range`` only when bit-for-bit continuity with bounds loaded from
+    the old npz files matters; the default evaluates the bounds on exactly the rays that are rendered."""
+    ht, wd = raw_hw
+    up0, le0 = int(center[0] - scale / 2. + 0.5), int(center[1] - scale / 2. + 0.5)
+    upper, left = max(0, up0), max(0, le0)
+    bottom, right = min(ht, up0 + int(scale)), min(wd, le0 + int(scale))
+    h_off = -up0 / 2 if upper == 0 else (-(up0 + int(scale) - ht) / 2 if bottom == ht else 0)
+    w_off = -le0 / 2 if left == 0 else (-(le0 + int(scale) - wd) / 2 if right == wd else 0)
+    resize = res / scale
+    K = torch.as_tensor(cam_K, dtype=torch.float32).clone()
+    K[0, 0], K[1, 1] = K[0, 0] * resize, K[1, 1] * resize
+    K[0, 2] = (K[0, 2] + 0.5) * resize - 0.5
+    K[1, 2] = (K[1, 2] + 0.5) * resize - 0.5
+    K[0, 2] = K[0, 2] - ((center[1] + w_off) * resize - res / 2)
+    K[1, 2] = K[1, 2] - ((center[0] + h_off) * resize - res / 2)
+    if stored_map_convention:
+        K[0, 2] = K[0, 2] - (0.5 * resize - 0.5)
+        K[1, 2] = K[1, 2] - (0.5 * resize - 0.5)
+    crop_ht, crop_wd = float(bottom - upper), float(right - left)
+    if crop_ht > crop_wd:
+        rh, rw = res, int(res / crop_ht * crop_wd + 0.5)
+    elif crop_ht < crop_wd:
+        rw, rh = res, int(res / crop_wd * crop_ht + 0.5)
+    else:
+        rw = rh = int(res)
+    r0, c0 = int(res / 2.0 - rh / 2.0 + 0.5), int(res / 2.0 - rw / 2.0 + 0.5)
+    return K, (float(c0), float(r0), float(c0 + rw), float(r0 + rh))
+
+
+def online_box_range(intr, pose, aabb_min, aabb_max, H, W, bg_range=(0.0, 30.0), valid_rect=None):
+    """Per-pixel (z_near, z_far) [B,HW] of an object box seen by (intr, pose), computed on the fly by the fused ray-gen
+    kernel -- the replacement of the per-frame ``pred_box_*.npz`` maps (compute_box.py:232-283 -> data/lm.py:316-350).
+    ``valid_rect`` [B,4] (from ``crop_camera``) reproduces the padding of clipped crops; units follow ``pose`` / the box."""
+    B = pose.shape[0]
+    every = torch.arange(H * W, device=pose.device).expand(B, -1).contiguous()
+    lo, hi = [float(v) for v in torch.as_tensor(aabb_min).flatten()], [float(v) for v in torch.as_tensor(aabb_max).flatten()]
+    _, _, near, far, _ = ops.raygen(intr, pose, H=H, W=W, ray_idx=every, aabb=(lo, hi), bg_range=bg_range,
+                                    valid_rect=valid_rect)
+    return near, far
+
+
 class RaySampler:
     """Train-mode ray source (reference tools/ray_sampler.py): continuous patch coordinates in [-1,1]
     -> rays, bilinear near/far bounds, bilinear image taps.  All three are static in the reference."""

@@ -82,7 +82,7 @@ def raygen(intr: Tensor, pose: Tensor, *, H: int, W: int, n_samples: int = 0, co
            ray_idx: Optional[Tensor] = None, z_near: Optional[Tensor] = None, z_far: Optional[Tensor] = None,
            aabb: Optional[Tuple[Tuple[float, float, float], Tuple[float, float, float]]] = None,
            bg_range: Tuple[float, float] = (0.0, 30.0), rand: Optional[Tensor] = None,
-           jitter: int = JITTER_MID, seed: int = 0, offset: int = 0):
+           jitter: int = JITTER_MID, seed: int = 0, offset: int = 0, valid_rect: Optional[Tensor] = None):
     """Fused ray-gen + bounds + stratified depths.  Returns (center, ray, near, far, depth);
     near/far/depth are None when no bounds source is given, depth is [B,R,N]."""
     lib = _lib.load()
@@ -106,6 +106,10 @@ def raygen(intr: Tensor, pose: Tensor, *, H: int, W: int, n_samples: int = 0, co
         a.aabb_min = (C.c_float * 3)(*[float(v) for v in aabb[0]])
         a.aabb_max = (C.c_float * 3)(*[float(v) for v in aabb[1]])
         a.bg_near, a.bg_far = float(bg_range[0]), float(bg_range[1])
+        if valid_rect is not None:                      # [B,4] (x0,y0,x1,y1): pixels outside get the fallback range
+            valid_rect = _f32(valid_rect, "valid_rect")
+            assert valid_rect.shape == (B, 4)
+            a.valid_rect = valid_rect.data_ptr()
     elif z_near is not None:
         z_near, z_far = _f32(z_near, "z_near"), _f32(z_far, "z_far")
         assert z_near.numel() == B * H * W and z_far.numel() == B * H * W
