@@ -144,12 +144,12 @@ def publish(e, young):
     e("s_barrier")
 
 
-def chunk_groups(e, npairs, ts, mf, fill, free_after, pieces_per_group, tail=None):
+def chunk_groups(e, npairs, ts, mf, fill, free_after, pieces_per_group, tail=None, head=None):
     """One chunk of npairs (k-step, tile) pairs = npairs/2 groups of six MFMAs.
       mf(g)          -> the six MFMA lines of group g (they use ring slots (2g)%4 and (2g+1)%4)
       fill(g)        -> five lists of gap instructions (after MFMA 1..5)
       free_after     -> (i, j), i < j: slot a is free after MFMA i, slot b after MFMA j (1-based)
-      tail(g)        -> extra SALU lines at the very end of group g
+      tail(g)        -> extra lines at the very end of group g;  head(g) -> extra LDS reads right after MFMA 1
     Before a group's first MFMA all LDS reads but the four youngest (the refills issued during the previous group) have
     landed: the refills of the group before that one are this group's fragments."""
     ngroups = npairs // 2
@@ -166,6 +166,9 @@ def chunk_groups(e, npairs, ts, mf, fill, free_after, pieces_per_group, tail=Non
             if i == 0:
                 for k in range(pieces_per_group):
                     dma_piece(e, g * pieces_per_group + k, dma)
+                if head is not None:
+                    for ins in head(g):
+                        e(ins)
             if i < 5:
                 for ins in gaps[i]:
                     e(ins)
@@ -212,13 +215,27 @@ def gen_wide(src, dst):
             return [[], cv[0:4], cv[4:8], cv[8:12], cv[12:13]]
 
         def tail(g, ts=ts):
-            if ts == 7:
-                return []
-            if 1 <= g <= 3:
-                return [advance_dch()[g - 1]]
-            return dma_base() if g == 7 else []
+            # seed tile ts of the SOURCE set (its operands were converted during the previous chunk) with the next
+            # layer's bias: that set is the next layer's destination.  The four bias reads are issued in group 0 BEFORE
+            # this group's ring refills (so the counted waits of the following groups cover them), the sixteen
+            # v_accvgpr_write ride in the gaps after MFMA 6 of groups 1..7
+            out = []
+            if g >= 1:
+                ks = [2 * (g - 1), 2 * (g - 1) + 1] + ([14, 15] if g == 7 else [])
+                out += ["v_accvgpr_write_b32 a%d, v%d" % (src + 16 * ts + k, HACC + k) for k in ks]
+            if ts < 7:
+                if 1 <= g <= 3:
+                    out.append(advance_dch()[g - 1])
+                if g == 7:
+                    out += dma_base()
+            return out
 
-        chunk_groups(e, 16, ts, mf, fill, (5, 6), 1, tail)
+        def head(g, ts=ts):
+            if g != 0:
+                return []
+            return ["ds_read_b128 %s, %%[nbias] offset:%d" % (vr(HACC + 4 * k), ts * 64 + k * 16) for k in range(4)]
+
+        chunk_groups(e, 16, ts, mf, fill, (5, 6), 1, tail, head)
     ring_epilogue(e, 8)
     return L
 

@@ -30,7 +30,8 @@ constexpr int kBiasPad = (kBiasFloats + 63) / 64 * 64;
 constexpr int kStageHalves = 5 * 2 * kThreads * 8;             // 5 k-steps x (hi, lo) x 256 lanes x 8 halves = 40 KiB
 
 constexpr int kBufs = 3;                                         // weight-chunk ring: two chunks (3072 cycles) ahead
-constexpr int kLdsBytes = kBufs * kChunkFloats * 4 + kBiasPad * 4 + kStageHalves * 2;
+constexpr int kSaveFloats = 8 * kThreads;                       // forward: 8 lane-private floats kept in LDS across the blocks
+constexpr int kLdsBytes = kBufs * kChunkFloats * 4 + kBiasPad * 4 + kStageHalves * 2 + kSaveFloats * 4;
 constexpr float kInvScale = 1.0f / (float)(1 << kF16WeightShift);
 
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
@@ -328,6 +329,7 @@ __device__ __forceinline__ AsmCtx asm_ctx(const Pipe& p, const float* bias_lds, 
   [lane16] "v"(c.lane16), [laneoff] "v"(c.laneoff), [ldswave] "s"(__builtin_amdgcn_readfirstlane(c.ldswave)),         \
       [stream_lo] "s"(__builtin_amdgcn_readfirstlane(c.stream_lo)),                                                    \
       [stream_hi] "s"(__builtin_amdgcn_readfirstlane(c.stream_hi))
+#define TP_ASM_HACC "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247"
 #define TP_RING_LOCALS                                                                                                 \
   int chunk = __builtin_amdgcn_readfirstlane(p.chunk), buf = __builtin_amdgcn_readfirstlane(p.buf);                    \
   int r0, r1, r2, m0a, m1a, m2a, dch, t0
@@ -368,16 +370,19 @@ __device__ __forceinline__ f32x16 asm_read_tile() {
 
 // 256 -> 256 layer body; SRC_Q: read set Q, accumulate into set P, else the reverse
 template <bool SRC_Q>
-__device__ __forceinline__ void asm_wide(Pipe& p, Frag& f, Guard& amax, const AsmCtx& c) {
+__device__ __forceinline__ void asm_wide(Pipe& p, Frag& f, Guard& amax, const AsmCtx& c, int next_li) {
   TP_RING_LOCALS;
   const float kinv = kInvScale;
   const unsigned mask = 0xFFFFE000u;
+  const unsigned nbias = c.bias0 + (unsigned)next_li * 1024u;       // the source set is re-seeded for the next layer
   if constexpr (SRC_Q)
     asm volatile(TP_ASM_WIDE_QP : TP_RING(f), TP_RING_STATE, [amax] "+v"(amax.m)
-                 : TP_RING_INPUTS(c), [kinv] "s"(kinv), [mask] "s"(mask) : TP_ASM_CLOBBERS, "memory", "scc");
+                 : TP_RING_INPUTS(c), [kinv] "s"(kinv), [mask] "s"(mask), [nbias] "v"(nbias)
+                 : TP_ASM_CLOBBERS, TP_ASM_HACC, "memory", "scc");
   else
     asm volatile(TP_ASM_WIDE_PQ : TP_RING(f), TP_RING_STATE, [amax] "+v"(amax.m)
-                 : TP_RING_INPUTS(c), [kinv] "s"(kinv), [mask] "s"(mask) : TP_ASM_CLOBBERS, "memory", "scc");
+                 : TP_RING_INPUTS(c), [kinv] "s"(kinv), [mask] "s"(mask), [nbias] "v"(nbias)
+                 : TP_ASM_CLOBBERS, TP_ASM_HACC, "memory", "scc");
   TP_RING_DONE;
 }
 
@@ -461,6 +466,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_f16x3_kernel(Params P) {
   const int j = lane & 31, hh = lane >> 5;
   float* bias_lds = lds + kBufs * kChunkFloats;
   _Float16* st = reinterpret_cast<_Float16*>(bias_lds + kBiasPad);
+  float* save = reinterpret_cast<float*>(st + kStageHalves) + tid;      // lane-private: save[k * kThreads], k < 8
 
   Pipe p;
   p.stream = P.packed; p.lds = lds; p.chunk = 0; p.buf = 0; p.wave = __builtin_amdgcn_readfirstlane(wave); p.lane = lane;
@@ -479,6 +485,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_f16x3_kernel(Params P) {
   const long long tr_start = tick();
 #endif
   const AsmCtx cx = asm_ctx(p, bias_lds, st, tid, hh);
+  asm_init<true>(cx, L0);        // set P starts as L0's bias; from then on every wide layer re-seeds its source set
 
   for (int64_t tile = blockIdx.x; tile < P.n_tiles; tile += gridDim.x) {
     TR_BEGIN(pro);
@@ -487,69 +494,76 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_f16x3_kernel(Params P) {
     const int64_t s = live ? s_raw : P.n_samples - 1;
     const int64_t q = s / P.N;
     const int b = (int)(q / P.R);
-    // (six scalars, not two arrays: the staging loops pick a coordinate by a run-time index, and an ARRAY picked that way
-    // is demoted to scratch memory)
-    struct { float x0, x1, x2, vu0, vu1, vu2, raw_s, raw_t0, raw_t1, raw_t2, raw_t3, raw_r0, raw_r1, raw_r2; } ts;
-    if (P.center != nullptr) {
-      const float z = P.depth[s];
-      const float d0 = P.ray[3 * q + 0], d1 = P.ray[3 * q + 1], d2 = P.ray[3 * q + 2];
-      ts.x0 = tp::add_rn(P.center[3 * q + 0], tp::mul_rn(d0, z));
-      ts.x1 = tp::add_rn(P.center[3 * q + 1], tp::mul_rn(d1, z));
-      ts.x2 = tp::add_rn(P.center[3 * q + 2], tp::mul_rn(d2, z));
-      float nrm = tp::add_rn(0.f, tp::mul_rn(d0, d0));
-      nrm = tp::add_rn(nrm, tp::mul_rn(d1, d1));
-      nrm = tp::add_rn(nrm, tp::mul_rn(d2, d2));
-      const float den = fmaxf(sqrtf(nrm), 1e-12f);
-      ts.vu0 = tp::div_rn(d0, den); ts.vu1 = tp::div_rn(d1, den); ts.vu2 = tp::div_rn(d2, den);
-    } else {
-      ts.x0 = P.points[3 * s + 0]; ts.x1 = P.points[3 * s + 1]; ts.x2 = P.points[3 * s + 2];
-      ts.vu0 = P.ray_unit[3 * s + 0]; ts.vu1 = P.ray_unit[3 * s + 1]; ts.vu2 = P.ray_unit[3 * s + 2];
+    // Everything the later staging steps need of this sample goes to a lane-private LDS area, not through registers:
+    // between the asm blocks the compiler owns few VGPRs (the blocks' working set, the fragment ring and, from L7 to
+    // R0, the trunk feature are fixed), and values carried across them would end up in scratch memory
+    {
+      float x0, x1, x2, vu0, vu1, vu2;
+      if (P.center != nullptr) {
+        const float z = P.depth[s];
+        const float d0 = P.ray[3 * q + 0], d1 = P.ray[3 * q + 1], d2 = P.ray[3 * q + 2];
+        x0 = tp::add_rn(P.center[3 * q + 0], tp::mul_rn(d0, z));
+        x1 = tp::add_rn(P.center[3 * q + 1], tp::mul_rn(d1, z));
+        x2 = tp::add_rn(P.center[3 * q + 2], tp::mul_rn(d2, z));
+        float nrm = tp::add_rn(0.f, tp::mul_rn(d0, d0));
+        nrm = tp::add_rn(nrm, tp::mul_rn(d1, d1));
+        nrm = tp::add_rn(nrm, tp::mul_rn(d2, d2));
+        const float den = fmaxf(sqrtf(nrm), 1e-12f);
+        vu0 = tp::div_rn(d0, den); vu1 = tp::div_rn(d1, den); vu2 = tp::div_rn(d2, den);
+      } else {
+        x0 = P.points[3 * s + 0]; x1 = P.points[3 * s + 1]; x2 = P.points[3 * s + 2];
+        vu0 = P.ray_unit[3 * s + 0]; vu1 = P.ray_unit[3 * s + 1]; vu2 = P.ray_unit[3 * s + 2];
+      }
+      save[0 * kThreads] = x0; save[1 * kThreads] = x1; save[2 * kThreads] = x2;
+      save[3 * kThreads] = vu0; save[4 * kThreads] = vu1; save[5 * kThreads] = vu2;
+      save[6 * kThreads] = __int_as_float(b);
     }
-
-    asm volatile("" :: "v"(ts.x0), "v"(ts.x1), "v"(ts.x2), "v"(ts.vu0), "v"(ts.vu1), "v"(ts.vu2));
+    asm_init<false>(cx, L1);       // set Q for L1 (set P was re-seeded for L0 by the previous tile's last layer)
     TR_END(4, pro);
     // The two accumulator sets: even layers read Q and accumulate into P, odd layers the reverse (the layer loop is
     // unrolled by two, so both roles are fixed registers).  A set holds raw accumulators, bias included (seeded with
     // bias * 2^8); the next layer's B operands are produced from it inside the asm blocks.
     f32x16 SF[8];               // the trunk feature (L7's accumulators), held in v[32:159] from L7 to R0
     Guard amax;
-    // raw outputs of the three narrow heads (still scaled by 2^8, bias not added): the non-linearities run in the output
-    // section at the end of the tile, so that no transcendental code sits between the blocks while the trunk feature
-    // occupies 128 VGPRs
-    ts.raw_s = ts.raw_t0 = ts.raw_t1 = ts.raw_t2 = ts.raw_t3 = ts.raw_r0 = ts.raw_r1 = ts.raw_r2 = 0.f;
+    float sig_s = 0.f, sig_t = 0.f, unc = 0.f, rgb_t[3] = {0.f, 0.f, 0.f}, rgb_s[3] = {0.f, 0.f, 0.f};
+    const float* hbias = bias_lds + kHeadBiasOff;          // [b7[0], T3 bias 0..4, R3 bias 0..2]
 
     // a narrow output layer; which == 0: sigma (reads L6 = set P), 1: transient head (reads T2 = set P), 2: static
-    // rgb (reads R2 = set Q)
-    const auto head = [&](int which) {
+    // rgb (reads R2 = set Q).  The transient head's result comes back while the trunk feature still occupies 128 VGPRs:
+    // its non-linearities run after the feature has been restored into set P (`after`)
+    const auto head = [&](int which, auto after) {
       TR_BEGIN(h);
       const f32x16 a = which == 2 ? asm_head<false>(p, frag, amax, cx) : asm_head<true>(p, frag, amax, cx);
       TR_END(7, h);
+      const float a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3];
+      after();
       if (which == 0) {
-        ts.raw_s = a[0];
+        sig_s = softplus(fmaf(a0, kInvScale, hbias[0]));
       } else if (which == 1) {
-        ts.raw_t0 = a[0]; ts.raw_t1 = a[1]; ts.raw_t2 = a[2]; ts.raw_t3 = a[3];   // (upper lane half: a[0] is row 4 = uncertainty)
+        rgb_t[0] = sigmoid(fmaf(a0, kInvScale, hbias[1])); rgb_t[1] = sigmoid(fmaf(a1, kInvScale, hbias[2]));
+        rgb_t[2] = sigmoid(fmaf(a2, kInvScale, hbias[3]));
+        sig_t = softplus(fmaf(a3, kInvScale, hbias[4]));
+        unc = softplus(fmaf(a0, kInvScale, hbias[5]));       // row 4 = register 0 of the upper lane half
       } else {
-        ts.raw_r0 = a[0]; ts.raw_r1 = a[1]; ts.raw_r2 = a[2];
+        rgb_s[0] = sigmoid(fmaf(a0, kInvScale, hbias[6])); rgb_s[1] = sigmoid(fmaf(a1, kInvScale, hbias[7]));
+        rgb_s[2] = sigmoid(fmaf(a2, kInvScale, hbias[8]));
       }
     };
 
     // one wide layer: EVEN layers read set Q and accumulate into set P, odd layers the reverse
     const auto layer = [&](auto even_tag, int li) {
       constexpr bool EVEN = decltype(even_tag)::value;
-      if (!EVEN && (li == L7 || li == R0)) head(li == L7 ? 0 : 1);       // both heads read set P
-      if (!EVEN && li == R0) {
-        // the trunk feature comes back into the set the transient head just freed
-        TR_BEGIN(rl);
-        asm_restore_p(SF);
-        TR_END(10, rl);
-      }
-      TR_BEGIN(ia);
-      asm_init<EVEN>(cx, li);
-      TR_END(8, ia);
+      if (!EVEN && li == L7) head(0, [] {});                              // sigma: reads set P (L6)
+      if (!EVEN && li == R0)                                               // transient head: reads set P (T2); then the
+        head(1, [&] {                                                      // trunk feature comes back into that set
+          TR_BEGIN(rl);
+          asm_restore_p(SF);
+          TR_END(10, rl);
+        });
 
       if (li != L0) {
         TR_BEGIN(w);
-        asm_wide<EVEN>(p, frag, amax, cx);
+        asm_wide<EVEN>(p, frag, amax, cx, li + 1 == kNumWide ? 0 : li + 1);
         TR_END(3, w);
       }
 
@@ -560,17 +574,18 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_f16x3_kernel(Params P) {
         // 30 (coordinate, octave) pairs, 15 per lane of the sample's lane pair: one range reduction yields the sin AND
         // the cos entry (slots 20 c + l and 20 c + 10 + l, whichever lane's operand registers they belong to)
         if (li == L0) {
+          const float x0 = save[0 * kThreads], x1 = save[1 * kThreads], x2 = save[2 * kThreads];
 #pragma nounroll
           for (int i = 0; i < 15; ++i) {
             const int pi_ = hh * 15 + i, c = (pi_ * 205) >> 11, l = pi_ - c * 10;
-            const float xc = pick3(c, ts.x0, ts.x1, ts.x2);
+            const float xc = pick3(c, x0, x1, x2);
             float sv, cv;
             tp::sincos_both(tp::mul_rn(xc, ldexpf(3.14159274101257324f, l)), sv, cv);
             stage_slot(st, tid & ~32, 20 * c + l, sv);
             stage_slot(st, tid & ~32, 20 * c + 10 + l, cv);
           }
           if (hh) {
-            stage(st, tid, 3, 4, ts.x0); stage(st, tid, 3, 5, ts.x1); stage(st, tid, 3, 6, ts.x2); stage(st, tid, 3, 7, 0.0f);
+            stage(st, tid, 3, 4, x0); stage(st, tid, 3, 5, x1); stage(st, tid, 3, 6, x2); stage(st, tid, 3, 7, 0.0f);
           }
         }
         TR_END(5, pe);
@@ -580,8 +595,9 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_f16x3_kernel(Params P) {
         TR_END(3, w);
       } else if (EVEN && li == T0) {
         TR_BEGIN(t0s);
+        const int bt = __float_as_int(save[6 * kThreads]);
 #pragma unroll
-        for (int jj = 0; jj < 8; ++jj) stage(st, tid, 0, jj, P.lat_trans[b * 16 + 8 * hh + jj]);
+        for (int jj = 0; jj < 8; ++jj) stage(st, tid, 0, jj, P.lat_trans[bt * 16 + 8 * hh + jj]);
         TR_END(13, t0s);
         TR_BEGIN(w);
         asm_extra<1, true>(p, frag, cx, 0);
@@ -593,10 +609,13 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_f16x3_kernel(Params P) {
         // the first two latent entries (30, 31).  Training: slots 0..29 (mlp_rgb.0 input columns 256..285) also go
         // to the activation record as fp32 for the weight gradient
         float* sx = SAVE ? P.saved + (tile * 4 + wave) * (int64_t)kSavedGroupFloats + SV_EX * kBlockFloats : nullptr;
+        const float x0 = save[0 * kThreads], x1 = save[1 * kThreads], x2 = save[2 * kThreads];
+        const float vu0 = save[3 * kThreads], vu1 = save[4 * kThreads], vu2 = save[5 * kThreads];
+        const int br = __float_as_int(save[6 * kThreads]);
 #pragma nounroll
         for (int i = 0; i < 6; ++i) {
           const int pi_ = hh * 6 + i, c = pi_ >> 2, l = pi_ & 3;
-          const float vc = pick3(c, ts.vu0, ts.vu1, ts.vu2);
+          const float vc = pick3(c, vu0, vu1, vu2);
           float sv, cv;
           tp::sincos_both(tp::mul_rn(vc, ldexpf(3.14159274101257324f, l)), sv, cv);
           stage_slot(st, tid & ~32, 3 + 8 * c + l, sv);
@@ -604,12 +623,12 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_f16x3_kernel(Params P) {
           if (SAVE && live) { sx[blk_off(3 + 8 * c + l, j)] = sv; sx[blk_off(3 + 8 * c + 4 + l, j)] = cv; }
         }
         if (hh == 0) {
-          stage(st, tid, 0, 0, ts.vu0); stage(st, tid, 0, 1, ts.vu1); stage(st, tid, 0, 2, ts.vu2);
-          if (SAVE && live) { sx[blk_off(0, j)] = ts.vu0; sx[blk_off(1, j)] = ts.vu1; sx[blk_off(2, j)] = ts.vu2; }
+          stage(st, tid, 0, 0, vu0); stage(st, tid, 0, 1, vu1); stage(st, tid, 0, 2, vu2);
+          if (SAVE && live) { sx[blk_off(0, j)] = vu0; sx[blk_off(1, j)] = vu1; sx[blk_off(2, j)] = vu2; }
         } else {
-          stage(st, tid, 1, 3, ts.x0); stage(st, tid, 1, 4, ts.x1); stage(st, tid, 1, 5, ts.x2);
-          stage(st, tid, 1, 6, P.lat_light[b * 48 + 0]); stage(st, tid, 1, 7, P.lat_light[b * 48 + 1]);
-          if (SAVE && live) { sx[blk_off(27, j)] = ts.x0; sx[blk_off(28, j)] = ts.x1; sx[blk_off(29, j)] = ts.x2; }
+          stage(st, tid, 1, 3, x0); stage(st, tid, 1, 4, x1); stage(st, tid, 1, 5, x2);
+          stage(st, tid, 1, 6, P.lat_light[br * 48 + 0]); stage(st, tid, 1, 7, P.lat_light[br * 48 + 1]);
+          if (SAVE && live) { sx[blk_off(27, j)] = x0; sx[blk_off(28, j)] = x1; sx[blk_off(29, j)] = x2; }
         }
         // k-steps 2..4 are latent-code slots only: 8 loads at a time (one latency per k-step), one 16-byte store per
         // (k-step, hi/lo)
@@ -619,7 +638,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_f16x3_kernel(Params P) {
 #pragma unroll
           for (int jj = 0; jj < 8; ++jj) {
             const int slot = 16 * ks + 8 * hh + jj;
-            lv[jj] = slot < 78 ? P.lat_light[b * 48 + slot - 30] : 0.0f;
+            lv[jj] = slot < 78 ? P.lat_light[br * 48 + slot - 30] : 0.0f;
           }
           half8 hi8, lo8;
 #pragma unroll
@@ -683,7 +702,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_f16x3_kernel(Params P) {
       layer(std::true_type{}, 2 * pr);
       layer(std::false_type{}, 2 * pr + 1);
     }
-    head(2);
+    head(2, [] {});
 
     TR_BEGIN(o);
     {
@@ -691,27 +710,19 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_f16x3_kernel(Params P) {
       // tile would have to live through every block, i.e. in scratch memory)
       int64_t so = tile * 128 + wave * 32 + j;
       asm volatile("" : "+v"(so));
-      const bool live_o = so < P.n_samples;
-      const float* hb = bias_lds + kHeadBiasOff;          // [b7[0], T3 bias 0..4, R3 bias 0..2]
-      if (live_o) {
+      if (so < P.n_samples) {
         if (hh == 0) {
-          const float sig_s = softplus(fmaf(ts.raw_s, kInvScale, hb[0]));
-          const float sig_t = softplus(fmaf(ts.raw_t3, kInvScale, hb[4]));
-          const float rt[3] = {sigmoid(fmaf(ts.raw_t0, kInvScale, hb[1])), sigmoid(fmaf(ts.raw_t1, kInvScale, hb[2])),
-                               sigmoid(fmaf(ts.raw_t2, kInvScale, hb[3]))};
-          const float rs[3] = {sigmoid(fmaf(ts.raw_r0, kInvScale, hb[6])), sigmoid(fmaf(ts.raw_r1, kInvScale, hb[7])),
-                               sigmoid(fmaf(ts.raw_r2, kInvScale, hb[8]))};
           // streaming stores: the outputs are never read by this kernel and must not evict the weight stream from L2
           float* o = P.rgb + so * 6;
 #pragma unroll
           for (int c = 0; c < 3; ++c) {
-            __builtin_nontemporal_store(rs[c], o + 2 * c);
-            __builtin_nontemporal_store(rt[c], o + 2 * c + 1);
+            __builtin_nontemporal_store(rgb_s[c], o + 2 * c);
+            __builtin_nontemporal_store(rgb_t[c], o + 2 * c + 1);
           }
           __builtin_nontemporal_store(sig_s, P.density + so * 2);
           __builtin_nontemporal_store(sig_t, P.density + so * 2 + 1);
         } else {
-          __builtin_nontemporal_store(softplus(fmaf(ts.raw_t0, kInvScale, hb[5])), P.uncert + so);   // row 4 = register 0 of the upper lane half
+          __builtin_nontemporal_store(unc, P.uncert + so);
         }
       }
     }
