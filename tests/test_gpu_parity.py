@@ -457,6 +457,50 @@ def test_render_train_matches_oracle_on_same_rays(ops):
     assert rel_l2(graph.latent_vars_trans.weight.grad, et.grad) < 5e-3
 
 
+def test_reference_rays_reproduce_reference_render_g9b(ops):
+    """North-star bar "outputs match the reference renderer on identical rays / weights to 1e-4": the rays, depth samples
+    and latent rows the REFERENCE fed to its own NeRF.forward_samples while producing G9 (golden G9b) go through the HIP
+    MLP + composite; per-ray outputs equal the reference's at rtol 1e-4 / atol 1e-6, per-sample ones at rel-L2 1e-4, for
+    both MLP arithmetics, train (with gradients) and val.  (The end-to-end tests above start from intrinsics / poses and
+    carry the ray-gen difference: torch's CPU inverse is not correctly rounded, tests/golden/make_golden_g9b.py.)"""
+    g9, g9s, gb = load_golden("g9_render_train"), load_golden("g9_render_slices"), load_golden("g9b_reference_rays")
+    for prec in ("fp32", "f16x3"):
+        graph, opt = _graph(O.make_params(g9["seed"]), n_train=g9["n_train"], emb_seed=g9["emb_seed"], H=g9["H"], W=g9["W"], N=g9["N"])
+        graph.nerf.precision = graph.nerf.train_precision = prec
+        # ---- val: no gradients
+        with torch.no_grad():
+            rgb_s, den_s, unc_s = graph.nerf.forward_samples(opt, cu(gb["val_center"]), cu(gb["val_ray"]), cu(gb["val_depth"]),
+                                                             latent_variable_trans=cu(gb["val_lat_t"]),
+                                                             latent_variable_light=cu(gb["val_lat_l"]), mode="val")
+            out = graph.nerf.composite(opt, cu(gb["val_ray"]), rgb_s, den_s, cu(gb["val_depth"]), unc_s)
+        names = ("rgb", "rgb_static", "rgb_transient", "depth", "opacity", "opacity_static", "opacity_transient")
+        for name, o in zip(names, out[:7]):
+            torch.testing.assert_close(o.cpu(), g9s["val_" + name], **RAY)
+        torch.testing.assert_close(out[8].cpu(), g9s["val_uncert"], **RAY)
+        assert rel_l2(den_s, g9s["val_density"]) < 1e-4 and rel_l2(out[9], g9s["val_alpha_static"]) < 1e-4
+        # ---- train: the latent rows as leaves (the reference indexes its embedding tables with sample_idx)
+        lt, ll = cu(gb["train_lat_t"]).requires_grad_(), cu(gb["train_lat_l"]).requires_grad_()
+        rgb_s, den_s, unc_s = graph.nerf.forward_samples(opt, cu(gb["train_center"]), cu(gb["train_ray"]), cu(gb["train_depth"]),
+                                                         latent_variable_trans=lt, latent_variable_light=ll, mode="train")
+        out = graph.nerf.composite(opt, cu(gb["train_ray"]), rgb_s, den_s, cu(gb["train_depth"]), unc_s)
+        ret = dict(zip(names, out[:7]), uncert=out[8], density=den_s)
+        for k in ("rgb", "rgb_static", "rgb_transient", "depth", "opacity", "uncert"):
+            torch.testing.assert_close(ret[k].detach().cpu(), g9["out_" + k], **RAY)
+        assert rel_l2(den_s, g9["out_density"]) < 1e-4 and rel_l2(out[9], g9["out_alpha_static"]) < 1e-4
+        cot = {k[4:]: v for k, v in g9.items() if k.startswith("cot_")}
+        sum((ret[k] * cu(cot[k])).sum() for k in cot).backward()
+        errs = {}
+        for name in ("mlp_rgb", "mlp_trans"):
+            for li in range(4):
+                for kind in ("weight", "bias"):
+                    errs[(name, li, kind)] = rel_l2(getattr(getattr(graph.nerf, name)[li], kind).grad, g9[f"g.{name}.{li}.{kind}"])
+        idx = g9["sample_idx"]
+        errs["light"] = rel_l2(ll.grad.cpu(), g9["g.latent_vars_light"][idx])
+        errs["trans"] = rel_l2(lt.grad.cpu(), g9["g.latent_vars_trans"][idx])
+        assert max(errs.values()) < 5e-3, (prec, errs)
+    ops.check_mlp_status(dev())
+
+
 def test_render_eval_one_call_equals_mirror(ops):
     """tp_render_eval (the C ABI's ray-gen + MLP + composite in one call) is bit-identical to what Graph.render launches,
     for both MLP arithmetics and an arbitrary subset of pixels."""

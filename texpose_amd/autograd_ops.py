@@ -14,8 +14,9 @@ from . import ops
 
 class _Composite(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, ray, rgb, density, depth, uncert, min_uncert):
-        out, a_s, a_t, prob = ops.composite_fwd(ray, rgb, density, depth, uncert, min_uncert)
+    def forward(ctx, ray, rgb, density, depth, uncert, min_uncert, per_sample, want_prob):
+        out, a_s, a_t, prob = ops.composite_fwd(ray, rgb, density, depth, uncert, min_uncert, per_sample=per_sample,
+                                                want_prob=want_prob)
         ctx.save_for_backward(ray, rgb, density, depth, uncert)
         ctx.min_uncert = min_uncert
         return out, a_s, a_t, prob
@@ -27,11 +28,13 @@ class _Composite(torch.autograd.Function):
             g_out = torch.zeros(*ray.shape[:-1], 14, device=ray.device)
         g_rgb, g_den, g_unc = ops.composite_bwd(ray, rgb, density, depth, uncert, g_out, g_as, g_at, g_prob,
                                                 ctx.min_uncert)
-        return None, g_rgb, g_den, None, g_unc.view_as(uncert), None      # (ray, rgb, density, depth, uncert, min_uncert)
+        return None, g_rgb, g_den, None, g_unc.view_as(uncert), None, None, None   # (ray, rgb, density, depth, uncert, ...)
 
 
-def composite(ray, rgb, density, depth, uncert, min_uncert):
-    return _Composite.apply(ray, rgb, density, depth, uncert, float(min_uncert))
+def composite(ray, rgb, density, depth, uncert, min_uncert, per_sample=True, want_prob=True):
+    """``per_sample`` / ``want_prob`` = False skip writing alpha_static / alpha_transient / prob ([B,R,N] each; the
+    per-ray sums do not need them): the returned entries are then None."""
+    return _Composite.apply(ray, rgb, density, depth, uncert, float(min_uncert), bool(per_sample), bool(want_prob))
 
 
 class _Mlp(torch.autograd.Function):

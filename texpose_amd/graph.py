@@ -119,8 +119,13 @@ class Graph(torch.nn.Module):
         rgb_s, density_s, uncert_s = self.nerf.forward_samples(opt, center=center, ray=ray, depth_samples=depth_samples,
                                                                latent_variable_trans=lat_t, latent_variable_light=lat_l,
                                                                mode=mode)
+        # `prob` is never written (the reference computes and discards it, :599-606); with opt.render.per_sample = False
+        # (not a reference option; default True keeps the reference's returned keys populated) alpha_static /
+        # alpha_transient are not materialised either -- evaluate_full and validate only read per-ray maps
+        per_sample = bool(opt.render.get("per_sample", True)) or torch.is_grad_enabled()
         (rgb, rgb_static, rgb_transient, depth_map, opacity, opacity_static, opacity_transient, _prob, uncert,
-         alpha_static, alpha_transient) = self.nerf.composite(opt, ray, rgb_s, density_s, depth_samples, uncert_s)
+         alpha_static, alpha_transient) = self.nerf.composite(opt, ray, rgb_s, density_s, depth_samples, uncert_s,
+                                                              per_sample=per_sample, want_prob=False)
         return edict(rgb=rgb, rgb_static=rgb_static, rgb_transient=rgb_transient, opacity=opacity,
                      opacity_static=opacity_static, opacity_transient=opacity_transient, uncert=uncert,
                      depth=depth_map, alpha_static=alpha_static, alpha_transient=alpha_transient, density=density_s)
@@ -169,13 +174,16 @@ class Graph(torch.nn.Module):
                                   mode=mode)
                 for k in RENDER_KEYS:
                     parts[k].append(ret[k])
-            return edict({k: (v[0] if len(v) == 1 else torch.cat(v, dim=1)) for k, v in parts.items()})
+            return edict({k: (None if v[0] is None else (v[0] if len(v) == 1 else torch.cat(v, dim=1))) for k, v in parts.items()})
         # eval: only object pixels are rendered and scattered into default-filled maps (reference :652-680; B == 1)
         dev, N = pose.device, opt.nerf.sample_intvs
         obj = (object_mask.reshape(HW) > 0).nonzero(as_tuple=True)[0]
         out = edict()
+        lazy = not bool(opt.render.get("per_sample", True))
         for k in RENDER_KEYS:
-            if k == "uncert":
+            if lazy and "alpha" in k:
+                out[k] = None                                   # (per_sample = False: not materialised)
+            elif k == "uncert":
                 out[k] = torch.full((1, HW, 1), float(opt.nerf.min_uncert), device=dev)
             elif k == "density":
                 out[k] = torch.ones(1, HW, N, 2, device=dev)
@@ -190,7 +198,8 @@ class Graph(torch.nn.Module):
             ret = self.render(opt, pose, intr=intr, ray_idx=idx, depth_range=depth_range, sample_idx=sample_idx,
                               mode=mode)
             for k in RENDER_KEYS:
-                out[k][:, idx[0]] = ret[k][0]
+                if out[k] is not None:
+                    out[k][:, idx[0]] = ret[k][0]
         return out
 
     # ------------------------------------------------------------------ consumers of render()
