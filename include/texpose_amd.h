@@ -300,6 +300,20 @@ int tp_nerf_losses_fwd(const tp_nerf_losses_args* args, tp_stream_t stream);
 int tp_nerf_losses_bwd(const tp_nerf_losses_args* args, const float* g_losses /* [3] device */, float* g_rgb,
                        float* g_uncert, float* g_density, tp_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * K9  InstanceNorm2d (affine = False) + LeakyReLU of the PatchGAN ladder, one launch per derivative order
+ * ref: layers/discriminator.py:94-115 (IN(c) + LeakyReLU(0.2) after each stride-2 SN-conv);
+ *      the double backward serves the R1 penalty, model/nerf_adapt_st_gan.py:794-807 (compute_grad2).
+ * x, y, xhat, gy, gx, ggx: [n_inst, hw] (n_inst = images x channels, hw = H*W), rstd: [n_inst].
+ * ------------------------------------------------------------------------------------------ */
+int tp_inorm_lrelu_fwd(const float* x, int64_t n_inst, int hw, float eps, float slope, float* y, float* xhat, float* rstd,
+                       tp_stream_t stream);
+int tp_inorm_lrelu_bwd(const float* xhat, const float* rstd, const float* gy, int64_t n_inst, int hw, float slope,
+                       float* gx, tp_stream_t stream);
+/* cotangent ggx of gx -> gradients wrt gy and wrt x (through xhat and rstd) */
+int tp_inorm_lrelu_bwd_bwd(const float* xhat, const float* rstd, const float* gy, const float* ggx, int64_t n_inst, int hw,
+                           float slope, float* g_gy, float* g_x, tp_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

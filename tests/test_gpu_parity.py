@@ -1267,3 +1267,29 @@ def test_full_size_render_properties(ops):
         assert float(keep["uncert"].min()) >= 0.05
     for k in ("rgb", "rgb_static", "depth", "uncert"):
         torch.testing.assert_close(outs["f16x3"][k], outs["fp32"][k], rtol=1e-4, atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------ K9 (f1)
+@pytest.mark.parametrize("shape", [(4, 256, 8, 8), (3, 512, 4, 4), (2, 64, 16, 16), (1, 5, 3, 7)])
+def test_inorm_lrelu_matches_torch_up_to_second_order(ops, shape):
+    """K9 (fused InstanceNorm2d + LeakyReLU, csrc/inorm_lrelu.hip) against the stock modules on the same device: forward,
+    gradient, and the R1-style second-order gradient (gradient of |d out / d x|^2 wrt x and wrt an upstream weight)."""
+    from texpose_amd import autograd_ops
+    torch.manual_seed(sum(shape))
+    x0 = torch.randn(*shape, device=dev())
+    w0 = torch.randn(*shape, device=dev())
+    cot = torch.randn(*shape, device=dev())
+    stock = torch.nn.Sequential(torch.nn.InstanceNorm2d(shape[1]), torch.nn.LeakyReLU(0.2))
+    res = []
+    for fused in (False, True):
+        x, w = x0.clone().requires_grad_(), w0.clone().requires_grad_()
+        h = x * w                                         # an upstream op with a parameter, like the SN-conv in front
+        y = autograd_ops.inorm_lrelu(h) if fused else stock(h)
+        out = (y * cot).sum()
+        gx, = torch.autograd.grad(out, x, create_graph=True)
+        reg = gx.pow(2).sum()
+        ggx, ggw = torch.autograd.grad(reg, (x, w))
+        res.append((y.detach(), gx.detach(), ggx, ggw))
+    for a, b, name in zip(res[1], res[0], ("y", "gx", "d reg / d x", "d reg / d w")):
+        assert rel_l2(a, b) < 2e-5, (shape, name, rel_l2(a, b))
+        torch.testing.assert_close(a, b, rtol=2e-3, atol=2e-4 * float(b.abs().max()))

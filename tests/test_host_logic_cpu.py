@@ -190,3 +190,27 @@ def test_checkpoint_wire_format_matches_reference_written_file(tmp_path):
     restore_checkpoint / restore_pretrain_partial_checkpoint do (manifest captured from the reference)."""
     import checkpoint_contract
     checkpoint_contract.run(torch.device("cpu"), tmp_path)
+
+
+def test_inorm_lrelu_second_order_formulas_fp64():
+    """The closed forms csrc/inorm_lrelu.hip implements (header comment) against torch autograd in fp64."""
+    torch.manual_seed(0)
+    n, eps, slope = 16, 1e-5, 0.2
+    x = torch.randn(3, n, dtype=torch.float64, requires_grad=True)
+    gy = torch.randn(3, n, dtype=torch.float64, requires_grad=True)
+    u = torch.randn(3, n, dtype=torch.float64)
+    y = torch.nn.functional.leaky_relu(torch.nn.functional.instance_norm(x.view(1, 3, 4, 4), eps=eps).view(3, n), slope)
+    gx, = torch.autograd.grad(y, x, gy, create_graph=True)
+    g_x, g_gy = torch.autograd.grad((gx * u).sum(), (x, gy))
+    xd = x.detach()
+    mu = xd.mean(1, keepdim=True)
+    r = 1 / torch.sqrt(((xd - mu) ** 2).mean(1, keepdim=True) + eps)
+    xh = (xd - mu) * r
+    s = torch.where(xh > 0, torch.ones_like(xh), torch.full_like(xh, slope))
+    a = gy.detach() * s
+    P = lambda v: v - v.mean(1, keepdim=True) - xh * (v * xh).mean(1, keepdim=True)
+    A = (u * a).sum(1, keepdim=True) - n * u.mean(1, keepdim=True) * a.mean(1, keepdim=True)
+    C, D = (u * xh).mean(1, keepdim=True), (a * xh).mean(1, keepdim=True)
+    g_x_a = -(r * r / n) * xh * (A - n * C * D) - r * r * (D * (u - u.mean(1, keepdim=True)) + C * (a - a.mean(1, keepdim=True)) - 2 * C * D * xh)
+    assert float((r * P(a) - gx.detach()).abs().max()) < 1e-12
+    assert float((s * r * P(u) - g_gy).abs().max()) < 1e-12 and float((g_x_a - g_x).abs().max()) < 1e-12

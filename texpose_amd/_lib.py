@@ -26,6 +26,7 @@ SYMBOLS = (
     "tp_sn_work_floats", "tp_sn_fwd", "tp_sn_bwd",
     "tp_nerf_losses_fwd", "tp_nerf_losses_bwd",
     "tp_render_eval_workspace_bytes", "tp_render_eval",
+    "tp_inorm_lrelu_fwd", "tp_inorm_lrelu_bwd", "tp_inorm_lrelu_bwd_bwd",
 )
 
 vp = C.c_void_p
@@ -159,6 +160,9 @@ def load() -> C.CDLL:
     sig("tp_nerf_losses_bwd", [C.POINTER(NerfLossesArgs), vp, vp, vp, vp, vp])
     sig("tp_render_eval_workspace_bytes", [C.c_int, C.c_int, C.c_int], C.c_size_t)
     sig("tp_render_eval", [C.POINTER(RenderEvalArgs), vp])
+    sig("tp_inorm_lrelu_fwd", [vp, C.c_int64, C.c_int, C.c_float, C.c_float, vp, vp, vp, vp])
+    sig("tp_inorm_lrelu_bwd", [vp, vp, vp, C.c_int64, C.c_int, C.c_float, vp, vp])
+    sig("tp_inorm_lrelu_bwd_bwd", [vp, vp, vp, vp, C.c_int64, C.c_int, C.c_float, vp, vp, vp])
     _lib = lib
     return lib
 

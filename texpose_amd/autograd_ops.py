@@ -111,3 +111,41 @@ class _NerfLosses(torch.autograd.Function):
 
 def nerf_losses(rgb, uncert, density, gathered):
     return _NerfLosses.apply(rgb, uncert, density, gathered)
+
+
+class _InormLreluBackward(torch.autograd.Function):
+    """gx of the fused InstanceNorm + LeakyReLU, itself differentiable (the R1 penalty back-propagates through the
+    gradient wrt the discriminator input, reference model/nerf_adapt_st_gan.py:794-807).  ``x`` is only the handle
+    autograd routes the second-order gradient to; the arithmetic uses xhat / rstd of the forward."""
+
+    @staticmethod
+    def forward(ctx, x, xhat, rstd, gy, slope):
+        ctx.save_for_backward(xhat, rstd, gy)
+        ctx.slope = slope
+        return ops.inorm_lrelu_bwd(xhat, rstd, gy, slope)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, ggx):
+        xhat, rstd, gy = ctx.saved_tensors
+        g_gy, g_x = ops.inorm_lrelu_bwd_bwd(xhat, rstd, gy, ggx.contiguous(), ctx.slope)
+        return g_x, None, None, g_gy, None
+
+
+class _InormLrelu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, eps, slope):
+        y, xhat, rstd = ops.inorm_lrelu_fwd(x, eps, slope)
+        ctx.save_for_backward(x, xhat, rstd)
+        ctx.slope = slope
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, xhat, rstd = ctx.saved_tensors
+        return _InormLreluBackward.apply(x, xhat, rstd, gy.contiguous(), ctx.slope), None, None
+
+
+def inorm_lrelu(x, eps: float = 1e-5, slope: float = 0.2):
+    """LeakyReLU(InstanceNorm2d(x)) (affine = False) with first and second derivatives as single launches (K9)."""
+    return _InormLrelu.apply(x.contiguous(), float(eps), float(slope))

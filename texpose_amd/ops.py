@@ -540,6 +540,42 @@ def nerf_losses_bwd(rgb: Tensor, uncert: Tensor, density: Tensor, gathered: Tens
     return g_rgb, g_unc, g_den
 
 
+# ------------------------------------------------------------------------------------------ K9
+@_on_tensor_device
+def inorm_lrelu_fwd(x: Tensor, eps: float, slope: float):
+    """x [B,C,H,W] -> (y, xhat, rstd [B*C]) = LeakyReLU(InstanceNorm2d(x)) and what its derivatives need."""
+    lib = _lib.load()
+    x = _f32(x, "x")
+    n_inst, hw = x.shape[0] * x.shape[1], x.shape[2] * x.shape[3]
+    y, xhat = torch.empty_like(x), torch.empty_like(x)
+    rstd = torch.empty(n_inst, device=x.device)
+    check(lib.tp_inorm_lrelu_fwd(x.data_ptr(), n_inst, hw, float(eps), float(slope), y.data_ptr(), xhat.data_ptr(),
+                                 rstd.data_ptr(), _stream()), "tp_inorm_lrelu_fwd")
+    return y, xhat, rstd
+
+
+@_on_tensor_device
+def inorm_lrelu_bwd(xhat: Tensor, rstd: Tensor, gy: Tensor, slope: float) -> Tensor:
+    lib = _lib.load()
+    gy = _f32(gy, "gy")
+    gx = torch.empty_like(xhat)
+    check(lib.tp_inorm_lrelu_bwd(xhat.data_ptr(), rstd.data_ptr(), gy.data_ptr(), rstd.numel(), xhat.numel() // rstd.numel(),
+                                 float(slope), gx.data_ptr(), _stream()), "tp_inorm_lrelu_bwd")
+    return gx
+
+
+@_on_tensor_device
+def inorm_lrelu_bwd_bwd(xhat: Tensor, rstd: Tensor, gy: Tensor, ggx: Tensor, slope: float):
+    """cotangent ggx of the backward's output gx -> (grad wrt gy, grad wrt x)."""
+    lib = _lib.load()
+    gy, ggx = _f32(gy, "gy"), _f32(ggx, "ggx")
+    g_gy, g_x = torch.empty_like(xhat), torch.empty_like(xhat)
+    check(lib.tp_inorm_lrelu_bwd_bwd(xhat.data_ptr(), rstd.data_ptr(), gy.data_ptr(), ggx.data_ptr(), rstd.numel(),
+                                     xhat.numel() // rstd.numel(), float(slope), g_gy.data_ptr(), g_x.data_ptr(), _stream()),
+          "tp_inorm_lrelu_bwd_bwd")
+    return g_gy, g_x
+
+
 @_on_tensor_device
 def render_eval(packed: Tensor, intr: Tensor, pose: Tensor, ray_idx: Tensor, z_near: Tensor, z_far: Tensor, lat_trans: Tensor,
                 lat_light: Tensor, *, H: int, W: int, n_samples: int, precision: str = "f16x3", min_uncert: float = 0.05,
