@@ -98,7 +98,15 @@ def cpu_baseline(sc, params, emb_t, emb_l, budget_s=20.0, chunk=2048):
             n_chunks += 1
             if t_used > budget_s:
                 break
-    return dict(value=done / t_used, unit="rays/s", cores=best, kind="port",
+    cpu_model = "unknown"
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                cpu_model = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return dict(value=done / t_used, unit="rays/s", cores=best, kind="port", cpu_model=cpu_model,
                 sample="%d chunks of %d rays x %d samples of the 480x640 image, torch %s CPU fp32, %d threads "
                        "(fastest of a short trial; %d hardware threads available)"
                        % (n_chunks, chunk, N_SAMPLES, torch.__version__, best, avail))

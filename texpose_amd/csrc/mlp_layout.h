@@ -22,7 +22,7 @@
 #pragma once
 #include <stdint.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define TP_HD __host__ __device__ __forceinline__
 #else
 #define TP_HD inline

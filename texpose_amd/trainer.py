@@ -213,12 +213,13 @@ class GraphedGanTrainer(GanTrainer):
 
     # the guards run INSIDE the captured step: no host read, the update is multiplied by the 0/1 gate
     def _gate(self, ok, grads, lr, lr_used):
-        gate = ok.to(torch.float32)
+        """grads <- ok ? grads : 0 (non-finite entries included) and lr_used <- ok ? lr : 0, in four launches whatever the
+        number of parameters: one flat copy, one select, one scatter back, one scalar product."""
         grads = [g for g in grads if g is not None]
-        torch._foreach_mul_(grads, gate)
-        for g in grads:
-            torch.nan_to_num_(g, nan=0.0, posinf=0.0, neginf=0.0)       # (inf or nan) * 0
-        lr_used.copy_(lr * gate)
+        flat = torch.cat([g.reshape(-1) for g in grads])
+        flat = torch.where(ok, flat, torch.zeros((), device=flat.device))
+        torch._foreach_copy_(grads, [v.view_as(g) for v, g in zip(flat.split([g.numel() for g in grads]), grads)])
+        lr_used.copy_(lr * ok.to(torch.float32))
 
     def _guard_nerf(self, var, loss):
         dev = loss.all.device
