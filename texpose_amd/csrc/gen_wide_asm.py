@@ -30,9 +30,12 @@ lgkmcnt(0), s_barrier) 4 pairs before the end of c and leaves with pairs 0..3 of
 
     python3 gen_wide_asm.py > wide_asm.inc.h        (the Makefile does this)
 """
+import os
 import sys
 
 NCH = 115
+# timing experiments only (results are WRONG): TP_ASM_EXPERIMENT = nodma | nobarrier | noconv
+EXPERIMENT = os.environ.get("TP_ASM_EXPERIMENT", "")
 
 VB = 160
 def F_hi(slot): return VB + 8 * slot
@@ -118,7 +121,8 @@ def dma_piece(e, k, dma_slot):
         e("s_add_i32 m0, %%[m%da], 0x1000" % dma_slot)
         e("s_nop 0")
     base = "s[%d:%d]" % ((BA, BA + 1) if k < 4 else (BB, BB + 1))
-    e("global_load_lds_dwordx4 %%[laneoff], %s offset:%d" % (base, (k & 3) * 1024))
+    if EXPERIMENT != "nodma":
+        e("global_load_lds_dwordx4 %%[laneoff], %s offset:%d" % (base, (k & 3) * 1024))
 
 
 def ring_epilogue(e, n_chunks):
@@ -140,8 +144,9 @@ def refill(e, slot, pair, npairs, cur, nxt):
 
 
 def publish(e, young):
-    e("s_waitcnt vmcnt(%d) lgkmcnt(0)" % young)
-    e("s_barrier")
+    e("s_waitcnt vmcnt(%d) lgkmcnt(0)" % (0 if EXPERIMENT == "nodma" else young))
+    if EXPERIMENT != "nobarrier":
+        e("s_barrier")
 
 
 def chunk_groups(e, npairs, ts, mf, fill, free_after, pieces_per_group, tail=None, head=None):
@@ -212,6 +217,8 @@ def gen_wide(src, dst):
             if ts == 7:
                 return [[], [], [], [], []]
             cv = conv(src, ts + 1, g, bank ^ 1)
+            if EXPERIMENT == "noconv":
+                return [[], [], [], [], []]
             return [[], cv[0:4], cv[4:8], cv[8:12], cv[12:13]]
 
         def tail(g, ts=ts):

@@ -575,7 +575,9 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_f16x3_kernel(Params P) {
         // the cos entry (slots 20 c + l and 20 c + 10 + l, whichever lane's operand registers they belong to)
         if (li == L0) {
           const float x0 = save[0 * kThreads], x1 = save[1 * kThreads], x2 = save[2 * kThreads];
-#pragma nounroll
+          // five independent range reductions / polynomials in flight: with one wave per SIMD a rolled loop is a single
+          // dependent chain of ~30 instructions per iteration and runs at its latency
+#pragma unroll 5
           for (int i = 0; i < 15; ++i) {
             const int pi_ = hh * 15 + i, c = (pi_ * 205) >> 11, l = pi_ - c * 10;
             const float xc = pick3(c, x0, x1, x2);
@@ -612,7 +614,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_f16x3_kernel(Params P) {
         const float x0 = save[0 * kThreads], x1 = save[1 * kThreads], x2 = save[2 * kThreads];
         const float vu0 = save[3 * kThreads], vu1 = save[4 * kThreads], vu2 = save[5 * kThreads];
         const int br = __float_as_int(save[6 * kThreads]);
-#pragma nounroll
+#pragma unroll 3
         for (int i = 0; i < 6; ++i) {
           const int pi_ = hh * 6 + i, c = pi_ >> 2, l = pi_ & 3;
           const float vc = pick3(c, vu0, vu1, vu2);

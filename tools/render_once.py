@@ -9,6 +9,8 @@ dev = torch.device("cuda:0")
 sc, params, emb_t, emb_l = bench.build_scene(dev, 0)
 g, opt = bench.make_graph(dev, params, emb_t, emb_l)
 g.nerf.precision = prec
+if os.environ.get("TP_RANGE_CHECK_OFF"):            # timing experiments with deliberately wrong arithmetic
+    opt.arch.mlp_range_check = "off"
 pose, intr = sc["pose"].to(dev), sc["intr"].to(dev)
 dr = (sc["z_near"].to(dev)[:, :, None], sc["z_far"].to(dev)[:, :, None])
 mask = torch.ones(1, 480, 640, device=dev)
