@@ -38,17 +38,6 @@ class SNConv2d(nn.Module):
             # on its 4x4 map): a plain GEMM -- one launch in each derivative order instead of MIOpen's conv + layout
             # transposes (and its naive double-backward fallbacks)
             return F.linear(x.flatten(1), weight.flatten(1))[:, :, None, None]
-        if x.is_cuda:
-            # the two stride-2 4x4 convolutions of the 16x16 ladder (9 -> 256 on 8x8, 256 -> 512 on 4x4) as im2col + GEMM:
-            # every derivative order (the R1 penalty differentiates the input gradient) is then unfold / fold / GEMM
-            # launches instead of MIOpen's implicit-GEMM kernels with their layout transposes and naive
-            # double-backward fallbacks (profiles/r1/12: 88 transposes + 20 naive_conv launches per iteration)
-            B, _, H, W = x.shape
-            k = weight.shape[-1]
-            oh = (H + 2 * self.padding[0] - k) // self.stride[0] + 1
-            ow = (W + 2 * self.padding[1] - k) // self.stride[1] + 1
-            cols = F.unfold(x, (k, k), padding=self.padding, stride=self.stride)          # [B, C*k*k, oh*ow]
-            return torch.matmul(weight.flatten(1), cols).view(B, weight.shape[0], oh, ow)
         return F.conv2d(x, weight, None, self.stride, self.padding)
 
 
