@@ -123,7 +123,15 @@ def train_leg(device, rank, world):
     from texpose_amd import ops
     out = {"workload": "C3/C4: Duck-like synthetic crops 128x128, 16x16 patches, 64 samples/ray, 4 images per GPU, "
                        "hipGraph-replayed iteration; random-init VGG19[:15] feature network (weights unavailable offline)"}
-    full = train_dp.measure(device, rank, world, global_batch=4 * world, iters=40, warm=4, graphed=True, full=True)
+    graphed = os.environ.get("TP_BENCH_TRAIN_EAGER", "0") != "1"
+    try:
+        full = train_dp.measure(device, rank, world, global_batch=4 * world, iters=40, warm=4, graphed=graphed, full=True)
+    except Exception as exc:                       # (e.g. a collective that cannot be captured on this stack): eager loop
+        if not graphed:
+            raise
+        out["graph_capture_error"] = repr(exc)[:300]
+        torch.cuda.synchronize()
+        full = train_dp.measure(device, rank, world, global_batch=4 * world, iters=40, warm=4, graphed=False, full=True)
     out["full_gan_loop"] = {k: full[k] for k in ("value", "ms_per_iter", "global_batch", "per_gpu_batch", "launch",
                                                  "recording_forward", "collective", "loop", "finite", "skipped_steps")}
     out["unit"] = "iterations/s"
@@ -296,7 +304,12 @@ def main():
     ops.check_mlp_status(device)
     del ret
     torch.cuda.empty_cache()
-    train = None if args.no_train else train_leg(device, rank, world)
+    train = None
+    if not args.no_train:
+        try:
+            train = train_leg(device, rank, world)
+        except Exception as exc:                   # the rays/s line must come out whatever happens to the untimed legs
+            train = {"error": repr(exc)[:400]}
 
     if rank == 0:
         line = {
