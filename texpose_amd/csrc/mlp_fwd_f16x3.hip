@@ -478,9 +478,9 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_f16x3_kernel(Params P) {
   __syncthreads();
   Frag frag;
   frag_prime(p, frag);
-  // Persistent workgroups that start together stay in lockstep, so every CU would miss on the same weight chunks at
-  // the same instant.  Spread the start phases over ~one tile.
-  for (int i = (blockIdx.x * 37) & 63; i > 0; --i) __builtin_amdgcn_s_sleep(127);
+  // (round 1 staggered the start phases of the persistent workgroups by up to 256 us so that they would not park their
+  // trunk features at the same instant; with the feature held in registers the stagger buys nothing on a full image and
+  // cost 9 % of a B=4 training step, whose recording forward is only two tiles per CU)
 #ifdef TP_TRACE
   const long long tr_start = tick();
 #endif
