@@ -53,7 +53,7 @@ class GanTrainer:
         self.optim_nerf = torch.optim.Adam([dict(params=nerf_params, lr=self.lr_nerf_used),
                                             dict(params=graph.latent_vars_light.parameters(), lr=self.lr_nerf_used),
                                             dict(params=graph.latent_vars_trans.parameters(), lr=self.lr_nerf_used)],
-                                           capturable=self.capturable)
+                                           capturable=self.capturable, **self.adam_kwargs(dev))
         self.has_disc = hasattr(graph, "discriminator") and opt.gan is not None
         if self.has_disc:
             self.disc_group = [p for p in graph.discriminator.parameters()]
@@ -64,6 +64,12 @@ class GanTrainer:
         self.red_nerf = tdist.FlatGradAllReducer(self.nerf_group, group=group)
         self.red_disc = tdist.FlatGradAllReducer(self.disc_group, group=group) if self.has_disc else None
         self.skipped_steps = 0                   # optimiser steps withheld because the forward was flagged
+
+    def adam_kwargs(self, dev):
+        """Captured trainer: torch's FUSED Adam (one launch; it reads the tensor learning rate on the device).  The
+        foreach implementation handles a tensor lr with two per-parameter elementwise launches on 0-dim tensors plus
+        ~40 multi-tensor launches per step: 0.35 of the 1.5 ms of a B=4 nerf step.  Same state-dict layout."""
+        return dict(fused=True) if self.capturable and dev.type == "cuda" else {}
 
     @staticmethod
     def _toggle(module, flag):
