@@ -314,6 +314,21 @@ int tp_inorm_lrelu_bwd(const float* xhat, const float* rstd, const float* gy, in
 int tp_inorm_lrelu_bwd_bwd(const float* xhat, const float* rstd, const float* gy, const float* ggx, int64_t n_inst, int hw,
                            float slope, float* g_gy, float* g_x, tp_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * K10  RMSprop step of the PatchGAN parameters in one launch (reference optim_disc.step(),
+ * model/nerf_adapt_st_gan.py:168, torch.optim.RMSprop: alpha 0.99, eps 1e-8, no momentum / centring / weight decay).
+ * lr_dev != NULL: the learning rate is read from device memory (a hipGraph-captured step); else lr_host.
+ * ------------------------------------------------------------------------------------------ */
+#define TP_RMSPROP_MAX_TENSORS 16
+typedef struct tp_rmsprop_tensor {
+  float* param;            /* [numel] updated in place */
+  const float* grad;       /* [numel] */
+  float* square_avg;       /* [numel] updated in place */
+  int64_t numel;
+} tp_rmsprop_tensor;
+int tp_rmsprop_step(const tp_rmsprop_tensor* tensors /* host array */, int n, const float* lr_dev, float lr_host, float alpha,
+                    float eps, tp_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1293,3 +1293,31 @@ def test_inorm_lrelu_matches_torch_up_to_second_order(ops, shape):
     for a, b, name in zip(res[1], res[0], ("y", "gx", "d reg / d x", "d reg / d w")):
         assert rel_l2(a, b) < 2e-5, (shape, name, rel_l2(a, b))
         torch.testing.assert_close(a, b, rtol=2e-3, atol=2e-4 * float(b.abs().max()))
+
+
+def test_fused_rmsprop_matches_torch(ops):
+    """K10 (csrc/rmsprop.hip, trainer.FusedRMSprop) against torch.optim.RMSprop: parameters, square_avg and step after
+    three steps, float and device-tensor learning rate, and the state dict loads into the stock optimiser and back."""
+    from texpose_amd.trainer import FusedRMSprop
+    torch.manual_seed(3)
+    shapes = [(256, 9, 4, 4), (64, 73, 1, 1), (1, 64, 1, 1), ()]
+    for lr in (1e-4, torch.tensor(3e-4, device=dev())):
+        pa = [torch.nn.Parameter(torch.randn(*s, device=dev())) for s in shapes]
+        pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+        oa = FusedRMSprop([dict(params=pa, lr=lr)], capturable=torch.is_tensor(lr))
+        ob = torch.optim.RMSprop([dict(params=pb, lr=lr.clone() if torch.is_tensor(lr) else lr)], capturable=torch.is_tensor(lr))
+        for it in range(3):
+            for a, b in zip(pa[:3], pb[:3]):                      # (the 0-dim parameter never gets a gradient, like `progress`)
+                g = torch.randn_like(a) * 10 ** (it - 2)
+                a.grad, b.grad = g.clone(), g.clone()
+            oa.step()
+            ob.step()
+        for a, b in zip(pa, pb):
+            torch.testing.assert_close(a, b, rtol=1e-6, atol=1e-7)
+        sa, sb = oa.state_dict(), ob.state_dict()
+        assert sorted(sa["state"]) == sorted(sb["state"]) == [0, 1, 2]
+        for i in sa["state"]:
+            torch.testing.assert_close(sa["state"][i]["square_avg"], sb["state"][i]["square_avg"], rtol=1e-6, atol=0)
+            assert float(sa["state"][i]["step"]) == float(sb["state"][i]["step"]) == 3.0
+        ob.load_state_dict(sa)
+        oa.load_state_dict(sb)

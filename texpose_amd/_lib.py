@@ -27,6 +27,7 @@ SYMBOLS = (
     "tp_nerf_losses_fwd", "tp_nerf_losses_bwd",
     "tp_render_eval_workspace_bytes", "tp_render_eval",
     "tp_inorm_lrelu_fwd", "tp_inorm_lrelu_bwd", "tp_inorm_lrelu_bwd_bwd",
+    "tp_rmsprop_step",
 )
 
 vp = C.c_void_p
@@ -91,6 +92,13 @@ class SnWeight(C.Structure):
 
 
 SN_MAX_WEIGHTS = 8
+
+
+class RmspropTensor(C.Structure):
+    _fields_ = [("param", vp), ("grad", vp), ("square_avg", vp), ("numel", C.c_int64)]
+
+
+RMSPROP_MAX_TENSORS = 16
 
 
 class NerfLossesArgs(C.Structure):
@@ -163,6 +171,7 @@ def load() -> C.CDLL:
     sig("tp_inorm_lrelu_fwd", [vp, C.c_int64, C.c_int, C.c_float, C.c_float, vp, vp, vp, vp])
     sig("tp_inorm_lrelu_bwd", [vp, vp, vp, C.c_int64, C.c_int, C.c_float, vp, vp])
     sig("tp_inorm_lrelu_bwd_bwd", [vp, vp, vp, vp, C.c_int64, C.c_int, C.c_float, vp, vp, vp])
+    sig("tp_rmsprop_step", [C.POINTER(RmspropTensor), C.c_int, vp, C.c_float, C.c_float, C.c_float, vp])
     _lib = lib
     return lib
 

@@ -576,6 +576,24 @@ def inorm_lrelu_bwd_bwd(xhat: Tensor, rstd: Tensor, gy: Tensor, ggx: Tensor, slo
     return g_gy, g_x
 
 
+# ------------------------------------------------------------------------------------------ K10
+@_on_tensor_device
+def rmsprop_step(params, grads, square_avgs, lr, alpha: float = 0.99, eps: float = 1e-8) -> None:
+    """One launch: sq = alpha sq + (1 - alpha) g^2;  p -= lr g / (sqrt(sq) + eps) for up to 16 tensors per call.
+    ``lr``: python float, or a 0-dim CUDA tensor read on the device (captured training step)."""
+    lib = _lib.load()
+    lr_dev = lr.data_ptr() if isinstance(lr, torch.Tensor) else None
+    lr_host = 0.0 if isinstance(lr, torch.Tensor) else float(lr)
+    for i0 in range(0, len(params), _lib.RMSPROP_MAX_TENSORS):
+        chunk = list(zip(params, grads, square_avgs))[i0:i0 + _lib.RMSPROP_MAX_TENSORS]
+        arr = (_lib.RmspropTensor * len(chunk))()
+        for a, (p, g, sq) in zip(arr, chunk):
+            if not (p.is_contiguous() and g.is_contiguous() and sq.is_contiguous() and p.dtype == g.dtype == sq.dtype == torch.float32):
+                raise _lib.TexposeLibraryError("rmsprop_step needs contiguous float32 tensors")
+            a.param, a.grad, a.square_avg, a.numel = p.data_ptr(), g.data_ptr(), sq.data_ptr(), p.numel()
+        check(lib.tp_rmsprop_step(arr, len(chunk), lr_dev, lr_host, float(alpha), float(eps), _stream()), "tp_rmsprop_step")
+
+
 @_on_tensor_device
 def render_eval(packed: Tensor, intr: Tensor, pose: Tensor, ray_idx: Tensor, z_near: Tensor, z_far: Tensor, lat_trans: Tensor,
                 lat_light: Tensor, *, H: int, W: int, n_samples: int, precision: str = "f16x3", min_uncert: float = 0.05,

@@ -31,6 +31,33 @@ from .graph import Graph, summarize_loss
 from .options import AttrDict
 
 
+class FusedRMSprop(torch.optim.RMSprop):
+    """torch.optim.RMSprop with the reference's settings (no momentum, not centred, no weight decay), its state-dict
+    layout (``square_avg``, ``step``) and its arithmetic, but the whole step as ONE launch (K10, csrc/rmsprop.hip) that
+    reads a tensor learning rate on the device.  CUDA float32 parameters only; anything else uses the stock step."""
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        if closure is not None:
+            raise NotImplementedError("closure")
+        for group in self.param_groups:
+            ps = [p for p in group["params"] if p.grad is not None]
+            plain = (group["momentum"] == 0 and not group["centered"] and group["weight_decay"] == 0 and not group["maximize"]
+                     and all(p.is_cuda and p.dtype == torch.float32 and not p.grad.is_sparse for p in ps))
+            if not plain:
+                return super().step()
+            for p in ps:
+                st = self.state[p]
+                if len(st) == 0:
+                    st["step"] = torch.zeros((), dtype=torch.float32, device=p.device) if group["capturable"] else torch.tensor(0.0)
+                    st["square_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            if ps:
+                ops.rmsprop_step([p.data for p in ps], [p.grad.contiguous() for p in ps], [self.state[p]["square_avg"] for p in ps],
+                                 group["lr"], group["alpha"], group["eps"])
+                torch._foreach_add_([self.state[p]["step"] for p in ps], 1)
+        return None
+
+
 class GanTrainer:
     capturable = False                       # optimiser state on the device (required inside a hipGraph)
 
@@ -59,8 +86,8 @@ class GanTrainer:
             self.disc_group = [p for p in graph.discriminator.parameters()]
             self.lr_disc = mk(opt.optim_disc.lr)
             self.lr_disc_used = mk(opt.optim_disc.lr)
-            self.optim_disc = torch.optim.RMSprop([dict(params=self.disc_group, lr=self.lr_disc_used)],
-                                                  capturable=self.capturable)
+            rms = FusedRMSprop if self.capturable and dev.type == "cuda" else torch.optim.RMSprop
+            self.optim_disc = rms([dict(params=self.disc_group, lr=self.lr_disc_used)], capturable=self.capturable)
         self.red_nerf = tdist.FlatGradAllReducer(self.nerf_group, group=group)
         self.red_disc = tdist.FlatGradAllReducer(self.disc_group, group=group) if self.has_disc else None
         self.skipped_steps = 0                   # optimiser steps withheld because the forward was flagged
