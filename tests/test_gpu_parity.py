@@ -1302,7 +1302,7 @@ def test_fused_rmsprop_matches_torch(ops):
     torch.manual_seed(3)
     shapes = [(256, 9, 4, 4), (64, 73, 1, 1), (1, 64, 1, 1), ()]
     for lr in (1e-4, torch.tensor(3e-4, device=dev())):
-        pa = [torch.nn.Parameter(torch.randn(*s, device=dev())) for s in shapes]
+        pa = [torch.nn.Parameter(torch.randn(s, device=dev())) for s in shapes]
         pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
         oa = FusedRMSprop([dict(params=pa, lr=lr)], capturable=torch.is_tensor(lr))
         ob = torch.optim.RMSprop([dict(params=pb, lr=lr.clone() if torch.is_tensor(lr) else lr)], capturable=torch.is_tensor(lr))

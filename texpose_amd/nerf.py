@@ -125,8 +125,10 @@ class NeRF(torch.nn.Module):
         return buf
 
     def mark_heads_dirty(self):
-        """Force a re-pack of the head weights at the next forward.  Needed after parameter updates that Python did
-        not see (a replayed hipGraph step does not bump tensor versions)."""
+        """Force a re-pack of the head weights at the next forward.  Needed after parameter updates that do not bump
+        tensor versions: a replayed hipGraph step, and torch's FUSED optimisers (``Adam(fused=True)`` leaves
+        ``p._version`` unchanged; the default foreach / single-tensor implementations bump it).  The trainers of
+        texpose_amd.trainer call this after every optimiser step."""
         for ver in self._versions.values():
             ver[1] = None
 

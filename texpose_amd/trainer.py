@@ -21,6 +21,7 @@ are averaged with ONE flat all-reduce after all backward calls of that step (too
 from __future__ import annotations
 
 import copy
+import os
 import warnings
 
 import torch
@@ -86,7 +87,7 @@ class GanTrainer:
             self.disc_group = [p for p in graph.discriminator.parameters()]
             self.lr_disc = mk(opt.optim_disc.lr)
             self.lr_disc_used = mk(opt.optim_disc.lr)
-            rms = FusedRMSprop if self.capturable and dev.type == "cuda" else torch.optim.RMSprop
+            rms = FusedRMSprop if self.capturable and dev.type == "cuda" and not os.environ.get("TP_NO_FUSED_RMSPROP") else torch.optim.RMSprop
             self.optim_disc = rms([dict(params=self.disc_group, lr=self.lr_disc_used)], capturable=self.capturable)
         self.red_nerf = tdist.FlatGradAllReducer(self.nerf_group, group=group)
         self.red_disc = tdist.FlatGradAllReducer(self.disc_group, group=group) if self.has_disc else None
@@ -96,7 +97,7 @@ class GanTrainer:
         """Captured trainer: torch's FUSED Adam (one launch; it reads the tensor learning rate on the device).  The
         foreach implementation handles a tensor lr with two per-parameter elementwise launches on 0-dim tensors plus
         ~40 multi-tensor launches per step: 0.35 of the 1.5 ms of a B=4 nerf step.  Same state-dict layout."""
-        return dict(fused=True) if self.capturable and dev.type == "cuda" else {}
+        return dict(fused=True) if self.capturable and dev.type == "cuda" and not os.environ.get("TP_NO_FUSED_ADAM") else {}
 
     @staticmethod
     def _toggle(module, flag):
@@ -147,6 +148,9 @@ class GanTrainer:
             g.nerf.train_precision = "fp32"
         self.red_nerf.reduce()
         self.optim_nerf.step()
+        # the packed weight image is re-built when a head parameter's version changes; fused optimiser kernels (and a
+        # replayed hipGraph) update parameters WITHOUT bumping tensor versions, so say it explicitly
+        g.nerf.mark_heads_dirty()
         return v, loss
 
     def disc_step(self, var):
