@@ -659,32 +659,35 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_f16x3_kernel(Params P) {
         TR_END(3, w);
       }
 
-      if (SAVE && li >= L7 && live) {
+      if (SAVE && li >= L7) {
         // activations for the backward (layout: mlp_layout.h "Training record"): post-ReLU values as fp32 + ReLU
-        // sign bits for the dgrad kernel
+        // sign bits for the dgrad kernel.  Every lane takes part (16-byte stores after a quad transpose, mlp_mma.h);
+        // samples past the end of the launch record zeros (the weight-gradient GEMM contracts whole groups)
         float* grp = P.saved + (tile * 4 + wave) * (int64_t)kSavedGroupFloats;
         float* blk = grp + (li - L7) * kBlockFloats;
-        int o16[16];
-        lane_block_offsets(j, hh, o16);
+        int o4[4];
+        lane_quad_offsets(j, hh, o4);
         uint32_t* mk = reinterpret_cast<uint32_t*>(grp + kMaskOff) + (li - T0) * 256 + lane;
         const auto two_tiles = [&](auto w4_tag) {
           constexpr int w4 = decltype(w4_tag)::value;
-          const f32x16 d0 = asm_read_tile<EVEN, 2 * w4>();
           uint32_t m = 0;
+          const f32x16 d0 = asm_read_tile<EVEN, 2 * w4>();
+          float h0[16];
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            const float hv = fmaxf(d0[r] * kInvScale, 0.0f);
-            blk[(2 * w4) * 1024 + o16[r]] = hv;
-            m |= (hv > 0.0f ? 1u : 0u) << r;
+            h0[r] = live ? fmaxf(d0[r] * kInvScale, 0.0f) : 0.0f;
+            m |= (h0[r] > 0.0f ? 1u : 0u) << r;
           }
+          store_tile_quads(blk + (2 * w4) * 1024, h0, j, o4);
           const f32x16 d1 = asm_read_tile<EVEN, 2 * w4 + 1>();
+          float h1[16];
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            const float hv = fmaxf(d1[r] * kInvScale, 0.0f);
-            blk[(2 * w4 + 1) * 1024 + o16[r]] = hv;
-            m |= (hv > 0.0f ? 1u : 0u) << (16 + r);
+            h1[r] = live ? fmaxf(d1[r] * kInvScale, 0.0f) : 0.0f;
+            m |= (h1[r] > 0.0f ? 1u : 0u) << (16 + r);
           }
-          if (li >= T0) mk[w4 * 64] = m;
+          store_tile_quads(blk + (2 * w4 + 1) * 1024, h1, j, o4);
+          if (li >= T0 && live) mk[w4 * 64] = m;
         };
         two_tiles(std::integral_constant<int, 0>{});
         two_tiles(std::integral_constant<int, 1>{});
@@ -821,8 +824,8 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_dgrad_f16x3_kernel(DgP P) {
     const int64_t gidx = tile * 4 + wave;
     const float* sv = P.saved + gidx * (int64_t)kSavedGroupFloats;
     float* dzg = P.dz + gidx * (int64_t)kDzGroupFloats;
-    int o16[16];
-    lane_block_offsets(j, hh, o16);
+    int o4[4];
+    lane_quad_offsets(j, hh, o4);
     float dzm = 0.0f;
     f32x16 SP[8], SQ[8];
 
@@ -830,13 +833,15 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_dgrad_f16x3_kernel(DgP P) {
     const auto finish_step = [&](const f32x16 (&D)[8], const uint32_t (&mask)[4], float factor, int st) {
       float* blk = dzg + st * kBlockFloats;
 #pragma unroll
-      for (int t = 0; t < 8; ++t)
+      for (int t = 0; t < 8; ++t) {
+        float v[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float v = (live && gate(mask, t, r)) ? D[t][r] * factor : 0.0f;
-          blk[t * 1024 + o16[r]] = v;
-          dzm = fmaxf(dzm, fabsf(v));
+          v[r] = (live && gate(mask, t, r)) ? D[t][r] * factor : 0.0f;
+          dzm = fmaxf(dzm, fabsf(v[r]));
         }
+        store_tile_quads(blk + t * 1024, v, j, o4);
+      }
     };
     const auto load_mask = [&](int slot, uint32_t (&mask)[4]) {
       const uint32_t* mk = reinterpret_cast<const uint32_t*>(sv + kMaskOff) + (slot - 1) * 256 + lane;

@@ -101,6 +101,40 @@ __device__ __forceinline__ void lane_block_offsets(int j, int hh, int (&o16)[16]
 #pragma unroll
   for (int r = 0; r < 16; ++r) o16[r] = blk_off(feat_of(0, r, hh), j);
 }
+// ---- 16-byte record stores -------------------------------------------------------------------------------------------
+// A lane owns ONE sample and, per accumulator tile, four groups of four consecutive FEATURES (registers 4g..4g+3 <->
+// features 8g + 4hh + 0..3); the record keeps a feature's 32 samples contiguous, so storing register by register is a
+// 4-byte store per lane and instruction -- and the store path is ISSUE-bound (~140 cycles per store instruction measured in
+// the recording forward: 125 k of 382 k cycles per tile).  Transposing each 4x4 (feature, sample) block inside its quad of
+// lanes first (16 DPP / select instructions) turns four 4-byte stores into one 16-byte store of four consecutive samples
+// of one feature: lane (j & 3) = i ends up with feature i of samples 4q..4q+3.  ALL lanes of the wave must take part.
+__device__ __forceinline__ float quad_dpp(float x, bool swap2) {
+  const int v = __float_as_int(x);
+  return __int_as_float(swap2 ? __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true)      // quad_perm [2,3,0,1]
+                              : __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+}
+__device__ __forceinline__ void quad_transpose(float (&v)[4], bool odd, bool hi) {
+  const float x1 = quad_dpp(v[1], false), y0 = quad_dpp(v[0], false), x3 = quad_dpp(v[3], false), y2 = quad_dpp(v[2], false);
+  const float c0 = odd ? x1 : v[0], c1 = odd ? v[1] : y0, c2 = odd ? x3 : v[2], c3 = odd ? v[3] : y2;
+  const float z0 = quad_dpp(c0, true), z1 = quad_dpp(c1, true), z2 = quad_dpp(c2, true), z3 = quad_dpp(c3, true);
+  v[0] = hi ? z2 : c0; v[1] = hi ? z3 : c1; v[2] = hi ? c2 : z0; v[3] = hi ? c3 : z1;
+}
+// float offsets (inside a tile's 1024 floats of a [256][32] block) of the four 16-byte stores of this lane: group g holds
+// feature 8g + 4hh + (j & 3), samples (j & ~3) .. +3
+__device__ __forceinline__ void lane_quad_offsets(int j, int hh, int (&o4)[4]) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) o4[g] = blk_off(8 * g + 4 * hh + (j & 3), j & ~3);
+}
+// one accumulator tile (16 values of this lane's sample) -> its 1024 floats of the block; all 64 lanes must call it
+__device__ __forceinline__ void store_tile_quads(float* tile_base, const float (&h)[16], int j, const int (&o4)[4]) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    float v[4] = {h[4 * g + 0], h[4 * g + 1], h[4 * g + 2], h[4 * g + 3]};
+    quad_transpose(v, (j & 1) != 0, (j & 2) != 0);
+    *reinterpret_cast<f32x4*>(tile_base + o4[g]) = f32x4{v[0], v[1], v[2], v[3]};
+  }
+}
+
 __device__ __forceinline__ void store_block(float* blk, const f32x16 (&h)[8], const int (&o16)[16]) {
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
