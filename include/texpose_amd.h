@@ -26,7 +26,7 @@ extern "C" {
 
 typedef void* tp_stream_t; /* hipStream_t */
 
-#define TP_ABI_VERSION 3
+#define TP_ABI_VERSION 4
 
 int tp_abi_version(void);
 const char* tp_last_error(void);
@@ -328,6 +328,36 @@ typedef struct tp_rmsprop_tensor {
 } tp_rmsprop_tensor;
 int tp_rmsprop_step(const tp_rmsprop_tensor* tensors /* host array */, int n, const float* lr_dev, float lr_host, float alpha,
                     float eps, tp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K11  The stride-2 4x4 convolutions of the PatchGAN ladder (reference layers/discriminator.py:94-115:
+ *      Conv2d(c_in, c_out, (4,4), (2,2), (1,1), bias=False) under spectral_norm, called through
+ *      model/nerf_adapt_st_gan.py:129-171 and differentiated twice by compute_grad2, :794-807).  Three implicit-GEMM
+ *      kernels on the fp32 matrix cores, closed under differentiation (a convolution is bilinear in input and weight):
+ *        tp_conv4s2_fwd    out = y  [N,Co,H/2,W/2] = conv(x, w)
+ *        tp_conv4s2_dgrad  out = gx [N,C,H,W]      = conv_transpose(gy, w)     (every element written)
+ *        tp_conv4s2_wgrad  out = gw [Co,C,4,4]     = sum over images and positions of gy (x) window(x)
+ *      Dense fp32 NCHW / OIHW tensors; H, W powers of two >= 8.  `workspace` holds split-K partial sums
+ *      (tp_conv4s2_workspace floats, may be NULL when that is 0), `counters` one zero-initialised uint32 per output
+ *      tile (n_counters of tp_conv4s2_workspace; the kernels leave them zero).  Fixed summation order: deterministic.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct tp_conv4s2_args {
+  const float* x;          /* [N,C,H,W]        fwd, wgrad */
+  const float* w;          /* [Co,C,4,4]       fwd, dgrad */
+  const float* gy;         /* [N,Co,H/2,W/2]   dgrad, wgrad */
+  float* out;
+  float* workspace;
+  void* counters;
+  int32_t N, C, H, W, Co;
+} tp_conv4s2_args;
+#define TP_CONV_FWD 0
+#define TP_CONV_DGRAD 1
+#define TP_CONV_WGRAD 2
+/* floats of workspace the operation `op` (TP_CONV_*) needs for these sizes; *n_counters = number of uint32 counters */
+int64_t tp_conv4s2_workspace(const tp_conv4s2_args* args, int op, int64_t* n_counters);
+int tp_conv4s2_fwd(const tp_conv4s2_args* args, tp_stream_t stream);
+int tp_conv4s2_dgrad(const tp_conv4s2_args* args, tp_stream_t stream);
+int tp_conv4s2_wgrad(const tp_conv4s2_args* args, tp_stream_t stream);
 
 #ifdef __cplusplus
 }

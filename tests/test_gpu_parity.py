@@ -11,6 +11,7 @@ import os
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 from conftest import load_golden
 from oracle import texpose_oracle as O
@@ -1321,3 +1322,70 @@ def test_fused_rmsprop_matches_torch(ops):
             assert float(sa["state"][i]["step"]) == float(sb["state"][i]["step"]) == 3.0
         ob.load_state_dict(sa)
         oa.load_state_dict(sb)
+
+
+# ------------------------------------------------------------------------------------------ K11 (f1)
+@pytest.mark.parametrize("shape", [(4, 9, 16, 16, 256), (4, 256, 8, 8, 512), (8, 256, 8, 8, 512), (3, 5, 8, 16, 40),
+                                   (1, 3, 32, 32, 64), (2, 64, 16, 16, 128), (32, 9, 16, 16, 256)])
+def test_conv4s2_matches_torch_up_to_second_order(ops, shape):
+    """K11 (csrc/patch_conv.hip: forward, data-gradient and weight-gradient implicit GEMMs of the PatchGAN's stride-2 4x4
+    convolutions) against torch's conv2d evaluated in fp64: the three kernels one by one, then the autograd composition up
+    to the R1-style second order (gradient of |d out / d x|^2 wrt the weight and wrt x), and run-to-run determinism."""
+    from texpose_amd import autograd_ops
+    N, C_in, H, W, Co = shape
+    torch.manual_seed(sum(shape))
+    x0 = torch.randn(N, C_in, H, W, device=dev())
+    w0 = torch.randn(Co, C_in, 4, 4, device=dev()) / (4 * C_in ** 0.5)
+    gy0 = torch.randn(N, Co, H // 2, W // 2, device=dev())
+    xd, wd, gd = (t.double().cpu().requires_grad_() for t in (x0, w0, gy0))
+    yd = F.conv2d(xd, wd, None, 2, 1)
+    gxd, gwd = torch.autograd.grad(yd, (xd, wd), gd)
+    for got, want, name in ((ops.conv4s2_fwd(x0, w0), yd, "fwd"), (ops.conv4s2_dgrad(gy0, w0), gxd, "dgrad"),
+                            (ops.conv4s2_wgrad(gy0, x0), gwd, "wgrad")):
+        assert got.shape == want.shape
+        assert rel_l2(got.double().cpu(), want.detach()) < 2e-6, (shape, name, rel_l2(got.double().cpu(), want.detach()))
+    # the split-K hand-over between workgroups (device-scope stores / counter, no fences): same bits on every one of 40
+    # back-to-back launches
+    for fn, a, b in ((ops.conv4s2_fwd, x0, w0), (ops.conv4s2_dgrad, gy0, w0), (ops.conv4s2_wgrad, gy0, x0)):
+        first = fn(a, b)
+        runs = [fn(a, b) for _ in range(40)]
+        assert all(torch.equal(first, r) for r in runs), fn.__name__
+    res = []
+    for mine in (False, True):
+        x = (x0 if mine else x0.double().cpu()).clone().requires_grad_()
+        w = (w0 if mine else w0.double().cpu()).clone().requires_grad_()
+        cot = gy0 if mine else gy0.double().cpu()
+        y = autograd_ops.conv4s2(x, w) if mine else F.conv2d(x, w, None, 2, 1)
+        out = (torch.tanh(y) * cot).sum()                  # a nonlinearity behind the convolution, like IN + LeakyReLU
+        gx, = torch.autograd.grad(out, x, create_graph=True)
+        reg = gx.pow(2).sum()
+        ggx, ggw = torch.autograd.grad(reg, (x, w))
+        res.append([t.detach().double().cpu() for t in (y, gx, ggx, ggw)])
+    for a, b, name in zip(res[1], res[0], ("y", "gx", "d reg / d x", "d reg / d w")):
+        assert rel_l2(a, b) < 5e-6, (shape, name, rel_l2(a, b))
+
+
+def test_discriminator_with_native_convs_matches_stock(ops):
+    """The PatchGAN forward, its gradients and the R1 double backward through K11 + K9 + K7 against the same module with
+    stock conv2d / InstanceNorm / LeakyReLU (CPU, fp64 copy of the parameters)."""
+    import copy
+    from texpose_amd.gan_modules import Discriminator
+    from texpose_amd.options import default_options
+    torch.manual_seed(5)
+    opt = default_options(H=128, W=128, device=dev())
+    opt.patch_size = 16
+    d_gpu = Discriminator(opt).to(dev()).eval()            # eval: u / v fixed, so both copies normalise identically
+    d_cpu = copy.deepcopy(d_gpu).cpu().double().eval()
+    x0 = torch.rand(4, 9 if opt.gan.geo_conditional else 3, 16, 16, device=dev())
+    sc = torch.rand(4, 1, 1, 1, device=dev()) * 0.5 + 0.25
+    res = []
+    for d, cast in ((d_cpu, lambda t: t.double().cpu()), (d_gpu, lambda t: t)):
+        x = cast(x0).clone().requires_grad_()
+        out = d(opt, x, cast(sc))
+        g, = torch.autograd.grad(out.sum(), x, create_graph=True)
+        reg = g.pow(2).reshape(4, -1).sum(1).mean()
+        params = [p for p in d.parameters() if p.requires_grad and p.dim() > 0]
+        grads = torch.autograd.grad(reg + out.mean(), params)
+        res.append([out.detach().double().cpu(), g.detach().double().cpu()] + [q.double().cpu() for q in grads])
+    for i, (a, b) in enumerate(zip(res[1], res[0])):
+        assert rel_l2(a, b) < 2e-4, (i, rel_l2(a, b))

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # TEXPOSE_AMD_LIB selects another build of the SAME library (e.g. the `make trace` diagnostic build); never a fallback
 LIB_PATH = os.environ.get("TEXPOSE_AMD_LIB") or os.path.join(_HERE, "libtexpose_amd.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # Every symbol include/texpose_amd.h declares (checked by tests/test_capi_cpu.py).
 SYMBOLS = (
@@ -28,6 +28,7 @@ SYMBOLS = (
     "tp_render_eval_workspace_bytes", "tp_render_eval",
     "tp_inorm_lrelu_fwd", "tp_inorm_lrelu_bwd", "tp_inorm_lrelu_bwd_bwd",
     "tp_rmsprop_step",
+    "tp_conv4s2_workspace", "tp_conv4s2_fwd", "tp_conv4s2_dgrad", "tp_conv4s2_wgrad",
 )
 
 vp = C.c_void_p
@@ -99,6 +100,12 @@ class RmspropTensor(C.Structure):
 
 
 RMSPROP_MAX_TENSORS = 16
+CONV_FWD, CONV_DGRAD, CONV_WGRAD = 0, 1, 2
+
+
+class Conv4s2Args(C.Structure):
+    _fields_ = [("x", vp), ("w", vp), ("gy", vp), ("out", vp), ("workspace", vp), ("counters", vp),
+                ("N", C.c_int32), ("C", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Co", C.c_int32)]
 
 
 class NerfLossesArgs(C.Structure):
@@ -172,6 +179,9 @@ def load() -> C.CDLL:
     sig("tp_inorm_lrelu_bwd", [vp, vp, vp, C.c_int64, C.c_int, C.c_float, vp, vp])
     sig("tp_inorm_lrelu_bwd_bwd", [vp, vp, vp, vp, C.c_int64, C.c_int, C.c_float, vp, vp, vp])
     sig("tp_rmsprop_step", [C.POINTER(RmspropTensor), C.c_int, vp, C.c_float, C.c_float, C.c_float, vp])
+    sig("tp_conv4s2_workspace", [C.POINTER(Conv4s2Args), C.c_int, C.POINTER(C.c_int64)], C.c_int64)
+    for name in ("tp_conv4s2_fwd", "tp_conv4s2_dgrad", "tp_conv4s2_wgrad"):
+        sig(name, [C.POINTER(Conv4s2Args), vp])
     _lib = lib
     return lib
 

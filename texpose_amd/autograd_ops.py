@@ -149,3 +149,56 @@ class _InormLrelu(torch.autograd.Function):
 def inorm_lrelu(x, eps: float = 1e-5, slope: float = 0.2):
     """LeakyReLU(InstanceNorm2d(x)) (affine = False) with first and second derivatives as single launches (K9)."""
     return _InormLrelu.apply(x.contiguous(), float(eps), float(slope))
+
+
+# ---- K11: the stride-2 4x4 convolutions of the PatchGAN ladder.  A convolution is bilinear in (x, w): its three kernels
+# (forward F, data gradient D, weight gradient G) are closed under differentiation, so these three Functions differentiate
+# to any order (the R1 penalty needs the second) with one launch per node and no MIOpen layout transposes.
+class _Conv4s2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        return ops.conv4s2_fwd(x, w)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gy = gy.contiguous()
+        gx = _Conv4s2Dgrad.apply(gy, w) if ctx.needs_input_grad[0] else None
+        gw = _Conv4s2Wgrad.apply(gy, x) if ctx.needs_input_grad[1] else None
+        return gx, gw
+
+
+class _Conv4s2Dgrad(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, gy, w):
+        ctx.save_for_backward(gy, w)
+        return ops.conv4s2_dgrad(gy, w)
+
+    @staticmethod
+    def backward(ctx, ggx):
+        gy, w = ctx.saved_tensors
+        ggx = ggx.contiguous()
+        g_gy = _Conv4s2.apply(ggx, w) if ctx.needs_input_grad[0] else None
+        g_w = _Conv4s2Wgrad.apply(gy, ggx) if ctx.needs_input_grad[1] else None
+        return g_gy, g_w
+
+
+class _Conv4s2Wgrad(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, gy, x):
+        ctx.save_for_backward(gy, x)
+        return ops.conv4s2_wgrad(gy, x)
+
+    @staticmethod
+    def backward(ctx, ggw):
+        gy, x = ctx.saved_tensors
+        ggw = ggw.contiguous()
+        g_gy = _Conv4s2.apply(x, ggw) if ctx.needs_input_grad[0] else None
+        g_x = _Conv4s2Dgrad.apply(gy, ggw) if ctx.needs_input_grad[1] else None
+        return g_gy, g_x
+
+
+def conv4s2(x, w):
+    """conv2d(x, w, stride 2, padding 1) for a [Co,C,4,4] weight (K11), differentiable to any order."""
+    return _Conv4s2.apply(x.contiguous(), w.contiguous())

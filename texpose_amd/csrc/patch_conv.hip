@@ -1,0 +1,354 @@
+// K11: the stride-2 4x4 convolutions of the PatchGAN ladder as implicit GEMMs on the fp32 matrix cores.
+// reference layers/discriminator.py:94-115 (spectral_norm(Conv2d(c_in, c_out, (4,4), (2,2), (1,1), bias=False)) per ladder
+// stage) and model/nerf_adapt_st_gan.py:129-171, 794-807 (disc_trainstep, compute_grad2: the R1 penalty differentiates the
+// data gradient once more).  A convolution is bilinear in (x, W), so three kernels are closed under differentiation:
+//     F  y  = conv(x, W)            y [n,co,oy,ox] = sum_{ci,ky,kx} W[co,ci,ky,kx] x[n,ci,2oy-1+ky,2ox-1+kx]
+//     D  gx = conv^T(gy, W)         gx[n,ci,iy,ix] = sum_{co,ky,kx} W[co,ci,ky,kx] gy[n,co,(iy+1-ky)/2,(ix+1-kx)/2]
+//     G  gW = corr(gy, x)           gW[co,ci,ky,kx] = sum_{n,oy,ox} gy[n,co,oy,ox] x[n,ci,2oy-1+ky,2ox-1+kx]
+// (d F = F(dx, W) + F(x, dW); the backward of D wrt (gy, W) is (F, G); of G wrt (gy, x) is (F, D)): texpose_amd/autograd_ops.py
+// composes them to any order.  MIOpen runs each of these as three layout transposes + an NHWC igemm (or a naive fallback in
+// the double backward): 90 launches and 0.6 ms of a 3.5 ms B=4 iteration; here each is ONE launch.
+//
+// All three are v_mfma_f32_32x32x2f32 GEMMs (exact fp32 products, fp32 accumulation) with the im2col gather folded into the
+// operand loads -- every lane loads its own A and B element straight from the NCHW tensors (L2-resident: the largest operand,
+// the 256->512 weight, is 8 MB) in an order that makes the loads 16-byte or contiguous across lanes:
+//   F: rows = output positions, columns = co, k = (ci, tap): per ci the lower lane half contracts taps ky in {0,1}, the upper
+//      half ky in {2,3}: 8 gathered x values + W[co,ci,2h..2h+1,:] (two 16-byte loads) feed 8 MFMAs.
+//   D: rows = positions (a,b) of ONE parity class of input pixels (iy,ix) = (2a+py, 2b+px), four classes = four accumulator
+//      tiles sharing the loads; k = (co, 2x2 taps of the class); the lane halves take even / odd co: the 3x3 neighbourhood of
+//      gy (9 loads) + the 16 taps of W[co,ci] (four 16-byte loads) feed 16 MFMAs.
+//   G: rows = co, columns = (ci, tap), k = positions: gy as 16-byte loads along a row of the map, x gathered.
+// One workgroup = 4 wavefronts on ONE output tile, each with a quarter of the k range; tiles with a long k are further split
+// over S workgroups whose partial sums meet in a workspace, the last one to arrive (device-scope counter) adds them in
+// slice order: fixed summation order, run-to-run deterministic, no float atomics.
+#include "tp_common.h"
+
+namespace {
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+__device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+
+struct ConvP {
+  const float* x;      // F, G: input [N,C,H,W];        D: unused
+  const float* w;      // F, D: weight [Co,C,4,4];      G: unused
+  const float* gy;     // D, G: output-side tensor [N,Co,OH,OW]
+  float* out;          // F: y [N,Co,OH,OW]; D: gx [N,C,H,W]; G: gW [Co,C,4,4]
+  float* ws;           // split-K partial sums
+  unsigned* cnt;       // one arrival counter per tile (zero between launches)
+  int N, C, H, W, Co, OH, OW;
+  int lw, low;         // log2(W), log2(OW)
+  int lp;              // log2(OH * OW)
+  int S;               // workgroups per tile
+  int tiles_n;         // column tiles
+};
+
+// Sum NT accumulator tiles over the 4 wavefronts of the workgroup and over the S workgroups of the tile.  True in the one
+// workgroup that ends up with the totals: thread (w, lane) then holds registers 4w..4w+3 of each tile, i.e. tile rows
+// 8w + 4(lane>>5) + 0..3 of column lane & 31.
+template <int NT>
+__device__ __forceinline__ bool reduce_tiles(const f32x16 (&acc)[NT], float (&out)[NT][4], float* lds, const ConvP& p, int tile, int s) {
+  const int t = threadIdx.x, w = t >> 6, lane = t & 63;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) lds[((nt * 16 + r) * 4 + w) * 64 + lane] = acc[nt][r];
+  __syncthreads();
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float* q = lds + ((nt * 16 + 4 * w + i) * 4) * 64 + lane;
+      out[nt][i] = ((q[0] + q[64]) + q[128]) + q[192];
+    }
+  if (p.S == 1) return true;
+  // Cross-workgroup hand-over WITHOUT device-scope fences: on gfx950 a fence is buffer_wbl2 + buffer_inv of the XCD's whole
+  // L2 (it threw the other workgroups' weight lines away; an 18-MFLOP convolution took 100 us).  Instead every access to
+  // shared words is itself device-scope (sc1: partial sums are written through to memory and read past the L2, the counter is
+  // a device-scope atomic), and a workgroup counts itself in only after all of its stores have been acknowledged (vmcnt 0).
+  float* mine = p.ws + ((size_t)tile * p.S + s) * (NT * 4 * 256);
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) __hip_atomic_store(mine + (nt * 4 + i) * 256 + t, out[nt][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this thread's stores are complete
+  __syncthreads();
+  __shared__ int last;
+  if (t == 0) last = (__hip_atomic_fetch_add(&p.cnt[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(p.S - 1));
+  __syncthreads();
+  if (!last) return false;
+  const float* all = p.ws + (size_t)tile * p.S * (NT * 4 * 256);
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) out[nt][i] = 0.f;
+  for (int k0 = 0; k0 < p.S; k0 += 4) {              // four slices' loads in flight, added in slice order
+    float part[4][NT * 4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int e = 0; e < NT * 4; ++e)
+        part[u][e] = __hip_atomic_load(all + ((size_t)min(k0 + u, p.S - 1) * NT * 4 + e) * 256 + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (k0 + u < p.S)
+#pragma unroll
+        for (int e = 0; e < NT * 4; ++e) out[e >> 2][e & 3] += part[u][e];
+  }
+  if (t == 0) __hip_atomic_store(&p.cnt[tile], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+  return true;
+}
+
+// this wavefront's part [b, e) of the k units [0, n) of slice s of S, the slice again split over the 4 wavefronts
+__device__ __forceinline__ void k_range(int n, int S, int s, int w, int& b, int& e) {
+  const int per_s = (n + S - 1) / S;
+  const int s0 = min(n, s * per_s), s1 = min(n, s0 + per_s);
+  const int per_w = (s1 - s0 + 3) >> 2;
+  b = min(s1, s0 + w * per_w);
+  e = min(s1, b + per_w);
+}
+
+// ---------------------------------------------------------------------------------------------------------------- F
+__global__ __launch_bounds__(256) void conv4s2_fwd_kernel(ConvP p) {
+  __shared__ float lds[16 * 4 * 64];
+  const int t = threadIdx.x, w = t >> 6, lane = t & 63, col = lane & 31, h = lane >> 5;
+  const int s = blockIdx.x % p.S, tile = blockIdx.x / p.S, nt = tile % p.tiles_n, mt = tile / p.tiles_n;
+  const int P = 1 << p.lp, M = p.N << p.lp, HW = p.H * p.W;
+  // A operand: position m = (n, oy, ox); this lane half gathers rows ky = 2h, 2h+1 of the 4x4 window
+  const int m = mt * 32 + col, mc = min(m, M - 1);
+  const int n = mc >> p.lp, pp = mc & (P - 1), oy = pp >> p.low, ox = pp & (p.OW - 1);
+  int off[8];
+  bool ok[8];
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int iy = 2 * oy - 1 + 2 * h + r, ix = 2 * ox - 1 + j;
+      ok[r * 4 + j] = m < M && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+      off[r * 4 + j] = ok[r * 4 + j] ? iy * p.W + ix : 0;
+    }
+  const float* xa = p.x + (size_t)n * p.C * HW;
+  // B operand: W[co, ci, 2h..2h+1, 0..3]
+  const int co = min(nt * 32 + col, p.Co - 1);
+  const float* wb = p.w + (size_t)co * p.C * 16 + 8 * h;
+  int cb, ce;
+  k_range(p.C, p.S, s, w, cb, ce);
+  f32x16 acc[1] = {};
+  for (int c0 = cb; c0 < ce; c0 += 4) {
+    float a[4][8];
+    f32x4 b[4][2];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int ci = min(c0 + u, ce - 1);
+      const float* xc = xa + (size_t)ci * HW;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) a[u][q] = xc[off[q]];
+      b[u][0] = *reinterpret_cast<const f32x4*>(wb + (size_t)ci * 16);
+      b[u][1] = *reinterpret_cast<const f32x4*>(wb + (size_t)ci * 16 + 4);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float live = c0 + u < ce ? 1.f : 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) acc[0] = mfma(ok[q] ? a[u][q] : 0.f, b[u][q >> 2][q & 3] * live, acc[0]);
+    }
+  }
+  float out[1][4];
+  if (!reduce_tiles<1>(acc, out, lds, p, tile, s)) return;
+  // thread: rows m0 .. m0+3 (four consecutive positions of one image), column co
+  const int m0 = mt * 32 + 8 * w + 4 * h, oc = nt * 32 + col;
+  if (m0 < M && oc < p.Co) {
+    const int n0 = m0 >> p.lp, p0 = m0 & (P - 1);
+    *reinterpret_cast<f32x4*>(p.out + ((size_t)n0 * p.Co + oc) * P + p0) = f32x4{out[0][0], out[0][1], out[0][2], out[0][3]};
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------- D
+__global__ __launch_bounds__(256) void conv4s2_dgrad_kernel(ConvP p) {
+  __shared__ float lds[4 * 16 * 4 * 64];
+  const int t = threadIdx.x, w = t >> 6, lane = t & 63, col = lane & 31, h = lane >> 5;
+  const int s = blockIdx.x % p.S, tile = blockIdx.x / p.S, nt = tile % p.tiles_n, mt = tile / p.tiles_n;
+  const int P = 1 << p.lp, M = p.N << p.lp;
+  // A operand: gy in the 3x3 neighbourhood of (a, b), channel co = 2q + h
+  const int m = mt * 32 + col, mc = min(m, M - 1);
+  const int n = mc >> p.lp, pp = mc & (P - 1), a0 = pp >> p.low, b0 = pp & (p.OW - 1);
+  int off[9];
+  bool ok[9];
+#pragma unroll
+  for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      const int oy = a0 + dy - 1, ox = b0 + dx - 1;
+      ok[dy * 3 + dx] = m < M && oy >= 0 && oy < p.OH && ox >= 0 && ox < p.OW;
+      off[dy * 3 + dx] = ok[dy * 3 + dx] ? oy * p.OW + ox : 0;
+    }
+  const float* ga = p.gy + (size_t)n * p.Co * P;
+  // B operand: the 16 taps of W[co, ci]
+  const int ci = min(nt * 32 + col, p.C - 1);
+  const float* wb = p.w + (size_t)ci * 16;
+  int qb, qe;
+  k_range((p.Co + 1) >> 1, p.S, s, w, qb, qe);
+  f32x16 acc[4] = {};
+  for (int q0 = qb; q0 < qe; q0 += 2) {
+    float g[2][9];
+    f32x4 wv[2][4];
+    float live[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int co = 2 * min(q0 + u, qe - 1) + h, cc = min(co, p.Co - 1);
+      live[u] = (q0 + u < qe && co < p.Co) ? 1.f : 0.f;
+      const float* gc = ga + (size_t)cc * P;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) g[u][k] = gc[off[k]];
+      const float* wc = wb + (size_t)cc * p.C * 16;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) wv[u][k] = *reinterpret_cast<const f32x4*>(wc + 4 * k);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int py = 0; py < 2; ++py)
+#pragma unroll
+        for (int px = 0; px < 2; ++px)
+#pragma unroll
+          for (int jy = 0; jy < 2; ++jy)
+#pragma unroll
+            for (int jx = 0; jx < 2; ++jx) {
+              // pixel row 2a+py receives output row a (ky = 1+py) and output row a-1 (py = 0, ky = 3) / a+1 (py = 1, ky = 0)
+              const int dy = jy == 0 ? 1 : (py == 0 ? 0 : 2), ky = jy == 0 ? 1 + py : (py == 0 ? 3 : 0);
+              const int dx = jx == 0 ? 1 : (px == 0 ? 0 : 2), kx = jx == 0 ? 1 + px : (px == 0 ? 3 : 0);
+              const float av = ok[dy * 3 + dx] ? g[u][dy * 3 + dx] : 0.f;
+              acc[py * 2 + px] = mfma(av, wv[u][ky][kx] * live[u], acc[py * 2 + px]);
+            }
+  }
+  float out[4][4];
+  if (!reduce_tiles<4>(acc, out, lds, p, tile, s)) return;
+  // thread: positions (a, b..b+3) of one image, channel ci -> pixels (2a+py, 2b .. 2b+7)
+  const int m0 = mt * 32 + 8 * w + 4 * h, oc = nt * 32 + col;
+  if (m0 < M && oc < p.C) {
+    const int n0 = m0 >> p.lp, p0 = m0 & (P - 1), a = p0 >> p.low, b = p0 & (p.OW - 1);
+#pragma unroll
+    for (int py = 0; py < 2; ++py) {
+      float* dst = p.out + (((size_t)n0 * p.C + oc) * p.H + 2 * a + py) * p.W + 2 * b;
+      *reinterpret_cast<f32x4*>(dst) = f32x4{out[py * 2][0], out[py * 2 + 1][0], out[py * 2][1], out[py * 2 + 1][1]};
+      *reinterpret_cast<f32x4*>(dst + 4) = f32x4{out[py * 2][2], out[py * 2 + 1][2], out[py * 2][3], out[py * 2 + 1][3]};
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------- G
+__global__ __launch_bounds__(256) void conv4s2_wgrad_kernel(ConvP p) {
+  __shared__ float lds[16 * 4 * 64];
+  const int t = threadIdx.x, w = t >> 6, lane = t & 63, col = lane & 31, h = lane >> 5;
+  const int s = blockIdx.x % p.S, tile = blockIdx.x / p.S, nt = tile % p.tiles_n, mt = tile / p.tiles_n;
+  const int P = 1 << p.lp, M = p.N << p.lp, HW = p.H * p.W, KW = p.C * 16;
+  // A operand: gy[n, co, p .. p+3]  (rows = co);  B operand: x gathered at (ci, ky, kx) = column j
+  const int co = min(mt * 32 + col, p.Co - 1);
+  const int j = min(nt * 32 + col, KW - 1), ci = j >> 4, ky = (j >> 2) & 3, kx = j & 3;
+  const float* xb = p.x + (size_t)ci * HW;
+  int bb, be;                                        // blocks of 8 positions: this half takes positions 8*blk + 4h + 0..3
+  k_range((M + 7) >> 3, p.S, s, w, bb, be);
+  f32x16 acc[1] = {};
+  for (int k0 = bb; k0 < be; k0 += 2) {
+    f32x4 g[2];
+    float xv[2][4];
+    bool okx[2][4];
+    float live[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int blk = min(k0 + u, be - 1), m0 = blk * 8 + 4 * h, mc = min(m0, M - 4);
+      live[u] = (k0 + u < be && m0 < M) ? 1.f : 0.f;
+      const int n = mc >> p.lp, pp = mc & (P - 1), oy = pp >> p.low, ox = pp & (p.OW - 1);
+      g[u] = *reinterpret_cast<const f32x4*>(p.gy + ((size_t)n * p.Co + co) * P + pp);
+      const int iy = 2 * oy - 1 + ky;
+      const float* xr = xb + (size_t)n * p.C * HW;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int ix = 2 * (ox + i) - 1 + kx;
+        okx[u][i] = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        xv[u][i] = xr[okx[u][i] ? iy * p.W + ix : 0];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[0] = mfma(g[u][i] * live[u], okx[u][i] ? xv[u][i] : 0.f, acc[0]);
+  }
+  float out[1][4];
+  if (!reduce_tiles<1>(acc, out, lds, p, tile, s)) return;
+  const int r0 = mt * 32 + 8 * w + 4 * h, oc = nt * 32 + col;
+  if (oc < KW)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (r0 + i < p.Co) p.out[(size_t)(r0 + i) * KW + oc] = out[0][i];
+}
+
+int ilog2(int v) {
+  int l = 0;
+  while ((1 << l) < v) ++l;
+  return (1 << l) == v ? l : -1;
+}
+
+// workspace floats per (tile, slice): NT * 4 * 256
+struct Plan { int tiles_m, tiles_n, S, nt; size_t ws_floats; };
+
+Plan plan(int rows, int cols, int k_units, int nt, int target_wgs, int min_units_per_wave) {
+  Plan q;
+  q.tiles_m = (rows + 31) / 32;
+  q.tiles_n = (cols + 31) / 32;
+  q.nt = nt;
+  const int tiles = q.tiles_m * q.tiles_n;
+  int S = tiles >= target_wgs ? 1 : (target_wgs + tiles - 1) / tiles;
+  const int max_s = (k_units + 4 * min_units_per_wave - 1) / (4 * min_units_per_wave);
+  if (S > max_s) S = max_s;
+  if (S < 1) S = 1;
+  q.S = S;
+  q.ws_floats = S > 1 ? (size_t)tiles * S * nt * 4 * 256 : 0;
+  return q;
+}
+}  // namespace
+
+extern "C" {
+
+static int conv_plan(const tp_conv4s2_args* a, int op, Plan* q, ConvP* p) {
+  TP_REQUIRE(a && a->N > 0 && a->C > 0 && a->Co > 0, "bad sizes");
+  const int OH = a->H / 2, OW = a->W / 2;
+  const int lw = ilog2(a->W), low = ilog2(OW), lh = ilog2(OH);
+  TP_REQUIRE(a->H >= 8 && a->W >= 8 && lw >= 0 && low >= 0 && lh >= 0 && ilog2(a->H) >= 0, "H and W must be powers of two >= 8");
+  TP_REQUIRE((int64_t)a->N * OH * OW <= (int64_t)1 << 28, "too many positions");
+  p->N = a->N; p->C = a->C; p->H = a->H; p->W = a->W; p->Co = a->Co; p->OH = OH; p->OW = OW;
+  p->lw = lw; p->low = low; p->lp = lh + low;
+  const int M = a->N * OH * OW;
+  if (op == 0) *q = plan(M, a->Co, a->C, 1, 256, 4);                    // k unit: one ci (8 MFMAs)
+  else if (op == 1) *q = plan(M, a->C, (a->Co + 1) / 2, 4, 256, 2);     // k unit: a co pair (16 MFMAs)
+  else *q = plan(a->Co, a->C * 16, (M + 7) / 8, 1, 256, 8);             // k unit: 8 positions (4 MFMAs)
+  p->S = q->S; p->tiles_n = q->tiles_n;
+  return 0;
+}
+
+int64_t tp_conv4s2_workspace(const tp_conv4s2_args* a, int op, int64_t* n_counters) {
+  Plan q; ConvP p;
+  if (conv_plan(a, op, &q, &p) != 0) return -1;
+  if (n_counters) *n_counters = (int64_t)q.tiles_m * q.tiles_n;
+  return (int64_t)q.ws_floats;
+}
+
+static int conv_launch(const tp_conv4s2_args* a, int op, tp_stream_t stream) {
+  Plan q; ConvP p;
+  const int rc = conv_plan(a, op, &q, &p);
+  if (rc != 0) return rc;
+  TP_REQUIRE(a->out && a->counters && (!q.ws_floats || a->workspace), "out / counters / workspace missing");
+  TP_REQUIRE((op == 1 || a->x) && (op == 2 || a->w) && (op == 0 || a->gy), "operand missing");
+  p.x = a->x; p.w = a->w; p.gy = a->gy; p.out = a->out; p.ws = a->workspace; p.cnt = (unsigned*)a->counters;
+  const dim3 grid((unsigned)(q.tiles_m * q.tiles_n * q.S)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (op == 0) hipLaunchKernelGGL(conv4s2_fwd_kernel, grid, block, 0, st, p);
+  else if (op == 1) hipLaunchKernelGGL(conv4s2_dgrad_kernel, grid, block, 0, st, p);
+  else hipLaunchKernelGGL(conv4s2_wgrad_kernel, grid, block, 0, st, p);
+  return tp::check_launch(op == 0 ? "tp_conv4s2_fwd" : op == 1 ? "tp_conv4s2_dgrad" : "tp_conv4s2_wgrad");
+}
+
+int tp_conv4s2_fwd(const tp_conv4s2_args* a, tp_stream_t stream) { return conv_launch(a, 0, stream); }
+int tp_conv4s2_dgrad(const tp_conv4s2_args* a, tp_stream_t stream) { return conv_launch(a, 1, stream); }
+int tp_conv4s2_wgrad(const tp_conv4s2_args* a, tp_stream_t stream) { return conv_launch(a, 2, stream); }
+}

@@ -17,6 +17,10 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 
+def _pow2_map(n: int) -> bool:
+    return n >= 8 and (n & (n - 1)) == 0
+
+
 class SNConv2d(nn.Module):
     """Conv2d (no bias) under spectral normalisation with the state-dict layout of
     ``torch.nn.utils.spectral_norm(nn.Conv2d(...))``: ``weight_orig`` (parameter), ``weight_u`` / ``weight_v``
@@ -38,6 +42,10 @@ class SNConv2d(nn.Module):
             # on its 4x4 map): a plain GEMM -- one launch in each derivative order instead of MIOpen's conv + layout
             # transposes (and its naive double-backward fallbacks)
             return F.linear(x.flatten(1), weight.flatten(1))[:, :, None, None]
+        if (x.is_cuda and tuple(weight.shape[-2:]) == (4, 4) and self.stride == (2, 2) and self.padding == (1, 1)
+                and _pow2_map(x.shape[-2]) and _pow2_map(x.shape[-1])):
+            from . import autograd_ops                                 # K11: one launch per derivative node
+            return autograd_ops.conv4s2(x, weight)
         return F.conv2d(x, weight, None, self.stride, self.padding)
 
 

@@ -630,3 +630,60 @@ def render_eval(packed: Tensor, intr: Tensor, pose: Tensor, ray_idx: Tensor, z_n
         a.alpha_static, a.alpha_transient = alphas[0].data_ptr(), alphas[1].data_ptr()
     check(lib.tp_render_eval(C.byref(a), _stream()), "tp_render_eval")
     return (out, alphas) if with_alphas else out
+
+
+# ------------------------------------------------------------------------------------------ K11
+_conv_counters = {}          # device index -> zero-filled int32 tensor (the kernels leave it zero)
+
+
+def _conv4s2(op: int, name: str, x, w, gy, out, N, C_in, H, W, Co):
+    lib = _lib.load()
+    a = _lib.Conv4s2Args()
+    a.N, a.C, a.H, a.W, a.Co = int(N), int(C_in), int(H), int(W), int(Co)
+    n_cnt = C.c_int64(0)
+    ws_floats = lib.tp_conv4s2_workspace(C.byref(a), op, C.byref(n_cnt))
+    if ws_floats < 0:
+        check(-1, "tp_conv4s2_workspace")
+    dev = out.device
+    cnt = _conv_counters.get(dev.index)
+    if cnt is None or cnt.numel() < n_cnt.value:
+        if torch.cuda.is_current_stream_capturing():
+            raise _lib.TexposeLibraryError("tp_conv4s2: the tile counters must exist before a hipGraph capture (run one "
+                                           "eager step first)")
+        cnt = torch.zeros(max(int(n_cnt.value), 1 << 14), dtype=torch.int32, device=dev)
+        _conv_counters[dev.index] = cnt
+    ws = torch.empty(int(ws_floats), device=dev) if ws_floats else None
+    a.x = x.data_ptr() if x is not None else None
+    a.w = w.data_ptr() if w is not None else None
+    a.gy = gy.data_ptr() if gy is not None else None
+    a.out, a.counters = out.data_ptr(), cnt.data_ptr()
+    a.workspace = ws.data_ptr() if ws is not None else None
+    check(getattr(lib, name)(C.byref(a), _stream()), name)
+    return out
+
+
+@_on_tensor_device
+def conv4s2_fwd(x: Tensor, w: Tensor) -> Tensor:
+    """conv2d(x [N,C,H,W], w [Co,C,4,4], stride 2, padding 1) -> [N,Co,H/2,W/2]."""
+    x, w = _f32(x, "x"), _f32(w, "w")
+    N, C_in, H, W = x.shape
+    y = torch.empty(N, w.shape[0], H // 2, W // 2, device=x.device)
+    return _conv4s2(_lib.CONV_FWD, "tp_conv4s2_fwd", x, w, None, y, N, C_in, H, W, w.shape[0])
+
+
+@_on_tensor_device
+def conv4s2_dgrad(gy: Tensor, w: Tensor) -> Tensor:
+    """gradient of conv4s2_fwd wrt x: gy [N,Co,H/2,W/2], w [Co,C,4,4] -> [N,C,H,W]."""
+    gy, w = _f32(gy, "gy"), _f32(w, "w")
+    N, Co, OH, OW = gy.shape
+    gx = torch.empty(N, w.shape[1], 2 * OH, 2 * OW, device=gy.device)
+    return _conv4s2(_lib.CONV_DGRAD, "tp_conv4s2_dgrad", None, w, gy, gx, N, w.shape[1], 2 * OH, 2 * OW, Co)
+
+
+@_on_tensor_device
+def conv4s2_wgrad(gy: Tensor, x: Tensor) -> Tensor:
+    """gradient of conv4s2_fwd wrt w: gy [N,Co,H/2,W/2], x [N,C,H,W] -> [Co,C,4,4]."""
+    gy, x = _f32(gy, "gy"), _f32(x, "x")
+    N, C_in, H, W = x.shape
+    gw = torch.empty(gy.shape[1], C_in, 4, 4, device=x.device)
+    return _conv4s2(_lib.CONV_WGRAD, "tp_conv4s2_wgrad", x, None, gy, gw, N, C_in, H, W, gy.shape[1])
