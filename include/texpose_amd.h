@@ -359,6 +359,29 @@ int tp_conv4s2_fwd(const tp_conv4s2_args* args, tp_stream_t stream);
 int tp_conv4s2_dgrad(const tp_conv4s2_args* args, tp_stream_t stream);
 int tp_conv4s2_wgrad(const tp_conv4s2_args* args, tp_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * K12  3x3 / stride 1 / padding 1 convolution (+ bias, + ReLU) of the frozen perceptual-loss feature network
+ *      (reference layers/perceptual_loss.py:8-45, torchvision VGG19 features[:15]; model/nerf_adapt_st_gan.py:758-766).
+ *        tp_conv3s1_fwd    out [N,Co,H,W] = relu?(conv(in [N,C,H,W], w [Co,C,3,3]) + bias)
+ *        tp_conv3s1_dgrad  out [N,C,H,W]  = conv_transpose(in [N,Co,H,W] * (mask > 0), w)    (mask = the forward output of a
+ *                          ReLU layer, or NULL)
+ *      H, W powers of two >= 4.  Workspace / counters as for K11 (tp_conv3s1_workspace, op TP_CONV_FWD / TP_CONV_DGRAD).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct tp_conv3s1_args {
+  const float* in;
+  const float* w;
+  const float* bias;       /* fwd: [Co] or NULL */
+  const float* mask;       /* dgrad: [N,Co,H,W] or NULL */
+  float* out;
+  float* workspace;
+  void* counters;
+  int32_t N, C, H, W, Co;
+  int32_t relu;            /* fwd: apply max(., 0) */
+} tp_conv3s1_args;
+int64_t tp_conv3s1_workspace(const tp_conv3s1_args* args, int op, int64_t* n_counters);
+int tp_conv3s1_fwd(const tp_conv3s1_args* args, tp_stream_t stream);
+int tp_conv3s1_dgrad(const tp_conv3s1_args* args, tp_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1389,3 +1389,56 @@ def test_discriminator_with_native_convs_matches_stock(ops):
         res.append([out.detach().double().cpu(), g.detach().double().cpu()] + [q.double().cpu() for q in grads])
     for i, (a, b) in enumerate(zip(res[1], res[0])):
         assert rel_l2(a, b) < 2e-4, (i, rel_l2(a, b))
+
+
+# ------------------------------------------------------------------------------------------ K12
+@pytest.mark.parametrize("shape", [(16, 3, 16, 16, 64), (16, 64, 16, 16, 64), (16, 128, 8, 8, 128), (16, 256, 4, 4, 256),
+                                   (3, 5, 4, 8, 33), (64, 64, 8, 8, 128)])
+@pytest.mark.parametrize("relu", [True, False])
+def test_conv3s1_matches_torch(ops, shape, relu):
+    """K12 (csrc/patch_conv.hip conv3s1_kernel: 3x3 convolution + bias + ReLU and its data gradient with the ReLU derivative
+    fused) against torch in fp64."""
+    from texpose_amd import autograd_ops
+    N, C_in, H, W, Co = shape
+    torch.manual_seed(sum(shape))
+    x0 = torch.randn(N, C_in, H, W, device=dev())
+    w0 = torch.randn(Co, C_in, 3, 3, device=dev()) / (3 * C_in ** 0.5)
+    b0 = torch.randn(Co, device=dev())
+    cot = torch.randn(N, Co, H, W, device=dev())
+    res = []
+    for mine in (False, True):
+        cast = (lambda t: t) if mine else (lambda t: t.double().cpu())
+        x = cast(x0).clone().requires_grad_()
+        if mine:
+            y = autograd_ops.conv3s1_bias_relu(x, w0, b0, relu)
+        else:
+            y = F.conv2d(x, cast(w0), cast(b0), 1, 1)
+            y = torch.relu(y) if relu else y
+        gx, = torch.autograd.grad((y * cast(cot)).sum(), x)
+        res.append((y.detach().double().cpu(), gx.double().cpu()))
+    for a, b, name in zip(res[1], res[0], ("y", "gx")):
+        assert rel_l2(a, b) < 2e-6, (shape, relu, name, rel_l2(a, b))
+    assert torch.equal(ops.conv3s1_fwd(x0, w0, b0, relu), ops.conv3s1_fwd(x0, w0, b0, relu))
+
+
+def test_perceptual_loss_native_convs_match_stock(ops):
+    """PerceptualLoss.pairs through K12 against the same (random-init) network through torch's conv2d on the CPU in fp64:
+    the two loss values and the gradient wrt the rendered patch."""
+    import copy
+    from texpose_amd.gan_modules import PerceptualLoss
+    torch.manual_seed(9)
+    net = PerceptualLoss().to(dev())
+    ref = copy.deepcopy(net).cpu().double()
+    fake0, real0 = torch.rand(4, 3, 16, 16, device=dev()), torch.rand(4, 3, 16, 16, device=dev())
+    out = []
+    for m, cast in ((ref, lambda t: t.double().cpu()), (net, lambda t: t)):
+        fake = cast(fake0).clone().requires_grad_()
+        if m is ref:                                         # the stock path: nn.Sequential on the CPU
+            l1 = F.mse_loss(m.model((fake - m.mean) / m.std), m.model((cast(real0) - m.mean) / m.std))
+            l2 = F.mse_loss(m.model((fake * 0.5 - m.mean) / m.std), m.model((cast(real0) - m.mean) / m.std))
+        else:
+            l1, l2 = m.pairs((fake, real0), (fake * 0.5, real0))
+        g, = torch.autograd.grad(l1 + 5 * l2, fake)
+        out.append((l1.detach().double().cpu(), l2.detach().double().cpu(), g.double().cpu()))
+    for a, b, name in zip(out[1], out[0], ("l1", "l2", "grad")):
+        assert rel_l2(a, b) < 1e-5, (name, rel_l2(a, b))

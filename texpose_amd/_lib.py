@@ -29,6 +29,7 @@ SYMBOLS = (
     "tp_inorm_lrelu_fwd", "tp_inorm_lrelu_bwd", "tp_inorm_lrelu_bwd_bwd",
     "tp_rmsprop_step",
     "tp_conv4s2_workspace", "tp_conv4s2_fwd", "tp_conv4s2_dgrad", "tp_conv4s2_wgrad",
+    "tp_conv3s1_workspace", "tp_conv3s1_fwd", "tp_conv3s1_dgrad",
 )
 
 vp = C.c_void_p
@@ -101,6 +102,11 @@ class RmspropTensor(C.Structure):
 
 RMSPROP_MAX_TENSORS = 16
 CONV_FWD, CONV_DGRAD, CONV_WGRAD = 0, 1, 2
+
+
+class Conv3s1Args(C.Structure):
+    _fields_ = [("inp", vp), ("w", vp), ("bias", vp), ("mask", vp), ("out", vp), ("workspace", vp), ("counters", vp),
+                ("N", C.c_int32), ("C", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Co", C.c_int32), ("relu", C.c_int32)]
 
 
 class Conv4s2Args(C.Structure):
@@ -182,6 +188,9 @@ def load() -> C.CDLL:
     sig("tp_conv4s2_workspace", [C.POINTER(Conv4s2Args), C.c_int, C.POINTER(C.c_int64)], C.c_int64)
     for name in ("tp_conv4s2_fwd", "tp_conv4s2_dgrad", "tp_conv4s2_wgrad"):
         sig(name, [C.POINTER(Conv4s2Args), vp])
+    sig("tp_conv3s1_workspace", [C.POINTER(Conv3s1Args), C.c_int, C.POINTER(C.c_int64)], C.c_int64)
+    for name in ("tp_conv3s1_fwd", "tp_conv3s1_dgrad"):
+        sig(name, [C.POINTER(Conv3s1Args), vp])
     _lib = lib
     return lib
 

@@ -202,3 +202,25 @@ class _Conv4s2Wgrad(torch.autograd.Function):
 def conv4s2(x, w):
     """conv2d(x, w, stride 2, padding 1) for a [Co,C,4,4] weight (K11), differentiable to any order."""
     return _Conv4s2.apply(x.contiguous(), w.contiguous())
+
+
+# ---- K12: 3x3 convolution + bias + ReLU of the frozen perceptual-loss network: one launch forward, one backward (data
+# gradient with the ReLU derivative applied while the cotangent is gathered).  No weight gradient: callers check that.
+class _Conv3s1BiasRelu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, bias, relu):
+        y = ops.conv3s1_fwd(x, w, bias, relu)
+        ctx.relu = relu
+        ctx.save_for_backward(w, y if relu else None)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gy):
+        w, y = ctx.saved_tensors
+        return ops.conv3s1_dgrad(gy.contiguous(), w, y if ctx.relu else None), None, None, None
+
+
+def conv3s1_bias_relu(x, w, bias, relu: bool):
+    """relu?(conv2d(x, w, bias, padding 1)) for a frozen [Co,C,3,3] weight (K12)."""
+    return _Conv3s1BiasRelu.apply(x.contiguous(), w, bias, bool(relu))

@@ -283,6 +283,94 @@ __global__ __launch_bounds__(256) void conv4s2_wgrad_kernel(ConvP p) {
       if (r0 + i < p.Co) p.out[(size_t)(r0 + i) * KW + oc] = out[0][i];
 }
 
+// ---------------------------------------------------------------------------------------------------------------- K12
+// 3x3 / stride 1 / padding 1 convolution + bias + ReLU of the perceptual-loss feature network (reference
+// layers/perceptual_loss.py:8-45: torchvision VGG19 features[:15], frozen; model/nerf_adapt_st_gan.py:758-766 calls it on the
+// rendered and the real patches).  Same machinery: rows = positions, columns = output channels, k = (channel pair, 9 taps),
+// the lane halves take the even / odd channel of a pair.  T = false: y = relu?(conv(x, w) + bias).  T = true: the data
+// gradient gx = conv^T(gy * (mask > 0), w) -- the weight is read transposed and flipped, and the ReLU derivative of the
+// layer's own output is applied while the cotangent is gathered.  (No weight gradient: the network is frozen.)
+struct Conv3P {
+  const float* in;     // F: x [N,C,H,W];  T: gy [N,Co,H,W]
+  const float* w;      // [Co,C,3,3]
+  const float* bias;   // F: [Co] or null
+  const float* mask;   // T: forward output [N,Co,H,W] (gy counts where mask > 0) or null
+  float* out;          // F: [N,Co,H,W];  T: [N,C,H,W]
+  float* ws;
+  unsigned* cnt;
+  int N, C, H, W, Co;
+  int lw, lp;          // log2(W), log2(H * W)
+  int S, tiles_n, relu;
+};
+
+template <bool T>
+__global__ __launch_bounds__(256) void conv3s1_kernel(Conv3P p) {
+  __shared__ float lds[16 * 4 * 64];
+  const int t = threadIdx.x, w = t >> 6, lane = t & 63, col = lane & 31, h = lane >> 5;
+  const int s = blockIdx.x % p.S, tile = blockIdx.x / p.S, nt = tile % p.tiles_n, mt = tile / p.tiles_n;
+  const int P = 1 << p.lp, M = p.N << p.lp;
+  const int CK = T ? p.Co : p.C, CN = T ? p.C : p.Co;          // contracted / produced channels
+  const int m = mt * 32 + col, mc = min(m, M - 1);
+  const int n = mc >> p.lp, pp = mc & (P - 1), y0 = pp >> p.lw, x0 = pp & (p.W - 1);
+  int off[9];
+  bool ok[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    const int yy = y0 + k / 3 - 1, xx = x0 + k % 3 - 1;
+    ok[k] = m < M && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
+    off[k] = ok[k] ? yy * p.W + xx : 0;
+  }
+  const float* ia = p.in + (size_t)n * CK * P;
+  const float* ma = T && p.mask ? p.mask + (size_t)n * CK * P : nullptr;
+  const int cn = min(nt * 32 + col, CN - 1);
+  // weight element of (produced channel cn, contracted channel ck, neighbourhood index k)
+  const size_t wbase = T ? (size_t)cn * 9 + 8 : (size_t)cn * p.C * 9;
+  const size_t wstep = T ? (size_t)p.C * 9 : 9;                 // per contracted channel
+  int qb, qe;
+  k_range((CK + 1) >> 1, p.S, s, w, qb, qe);
+  f32x16 acc[1] = {};
+  for (int q0 = qb; q0 < qe; q0 += 2) {
+    float a[2][9], b[2][9], mk[2][9];
+    float live[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int ck = 2 * min(q0 + u, qe - 1) + h, cc = min(ck, CK - 1);
+      live[u] = (q0 + u < qe && ck < CK) ? 1.f : 0.f;
+      const float* ic = ia + (size_t)cc * P;
+      const float* wc = p.w + wbase + wstep * cc;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        a[u][k] = ic[off[k]];
+        b[u][k] = T ? *(wc - k) : wc[k];
+        if (T) mk[u][k] = ma ? ma[(size_t)cc * P + off[k]] : 1.f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        const bool on = T ? (ok[k] && mk[u][k] > 0.f) : ok[k];
+        acc[0] = mfma(on ? a[u][k] : 0.f, b[u][k] * live[u], acc[0]);
+      }
+  }
+  float out[1][4];
+  ConvP rp;
+  rp.ws = p.ws; rp.cnt = p.cnt; rp.S = p.S;
+  if (!reduce_tiles<1>(acc, out, lds, rp, tile, s)) return;
+  const int m0 = mt * 32 + 8 * w + 4 * h, oc = nt * 32 + col;
+  if (m0 < M && oc < CN) {
+    f32x4 v = {out[0][0], out[0][1], out[0][2], out[0][3]};
+    if (!T) {
+      if (p.bias) v += p.bias[oc];
+      if (p.relu)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
+    }
+    const int n0 = m0 >> p.lp, p0 = m0 & (P - 1);
+    *reinterpret_cast<f32x4*>(p.out + ((size_t)n0 * CN + oc) * P + p0) = v;
+  }
+}
+
 int ilog2(int v) {
   int l = 0;
   while ((1 << l) < v) ++l;
@@ -351,4 +439,41 @@ static int conv_launch(const tp_conv4s2_args* a, int op, tp_stream_t stream) {
 int tp_conv4s2_fwd(const tp_conv4s2_args* a, tp_stream_t stream) { return conv_launch(a, 0, stream); }
 int tp_conv4s2_dgrad(const tp_conv4s2_args* a, tp_stream_t stream) { return conv_launch(a, 1, stream); }
 int tp_conv4s2_wgrad(const tp_conv4s2_args* a, tp_stream_t stream) { return conv_launch(a, 2, stream); }
+
+static int conv3_plan(const tp_conv3s1_args* a, int transposed, Plan* q, Conv3P* p) {
+  TP_REQUIRE(a && a->N > 0 && a->C > 0 && a->Co > 0, "bad sizes");
+  const int lw = ilog2(a->W), lh = ilog2(a->H);
+  TP_REQUIRE(a->H >= 4 && a->W >= 4 && lw >= 0 && lh >= 0, "H and W must be powers of two >= 4");
+  TP_REQUIRE((int64_t)a->N * a->H * a->W <= (int64_t)1 << 28, "too many positions");
+  p->N = a->N; p->C = a->C; p->H = a->H; p->W = a->W; p->Co = a->Co; p->lw = lw; p->lp = lw + lh; p->relu = a->relu;
+  const int M = a->N * a->H * a->W;
+  *q = plan(M, transposed ? a->C : a->Co, ((transposed ? a->Co : a->C) + 1) / 2, 1, 256, 2);   // k unit: a channel pair (9 MFMAs)
+  p->S = q->S; p->tiles_n = q->tiles_n;
+  return 0;
+}
+
+int64_t tp_conv3s1_workspace(const tp_conv3s1_args* a, int op, int64_t* n_counters) {
+  Plan q; Conv3P p;
+  if (op != TP_CONV_FWD && op != TP_CONV_DGRAD) return -1;
+  if (conv3_plan(a, op == TP_CONV_DGRAD, &q, &p) != 0) return -1;
+  if (n_counters) *n_counters = (int64_t)q.tiles_m * q.tiles_n;
+  return (int64_t)q.ws_floats;
+}
+
+static int conv3_launch(const tp_conv3s1_args* a, int transposed, tp_stream_t stream) {
+  Plan q; Conv3P p;
+  const int rc = conv3_plan(a, transposed, &q, &p);
+  if (rc != 0) return rc;
+  TP_REQUIRE(a->in && a->w && a->out && a->counters && (!q.ws_floats || a->workspace), "operand / counters / workspace missing");
+  p.in = a->in; p.w = a->w; p.bias = transposed ? nullptr : a->bias; p.mask = transposed ? a->mask : nullptr; p.out = a->out;
+  p.ws = a->workspace; p.cnt = (unsigned*)a->counters;
+  const dim3 grid((unsigned)(q.tiles_m * q.tiles_n * q.S)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (transposed) hipLaunchKernelGGL(conv3s1_kernel<true>, grid, block, 0, st, p);
+  else hipLaunchKernelGGL(conv3s1_kernel<false>, grid, block, 0, st, p);
+  return tp::check_launch(transposed ? "tp_conv3s1_dgrad" : "tp_conv3s1_fwd");
+}
+
+int tp_conv3s1_fwd(const tp_conv3s1_args* a, tp_stream_t stream) { return conv3_launch(a, 0, stream); }
+int tp_conv3s1_dgrad(const tp_conv3s1_args* a, tp_stream_t stream) { return conv3_launch(a, 1, stream); }
 }

@@ -193,9 +193,26 @@ class PerceptualLoss(nn.Module):
         self.register_buffer("mean", torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1), persistent=False)
         self.register_buffer("std", torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1), persistent=False)
 
+    def features(self, x):
+        """``self.model(x)``; on the GPU every convolution (+ bias + ReLU) of the frozen network is one K12 launch in each
+        direction (csrc/patch_conv.hip) instead of MIOpen's conv / layout transposes + bias + ReLU kernels."""
+        from . import autograd_ops, ops
+        mods, i = list(self.model), 0
+        while i < len(mods):
+            m = mods[i]
+            if (isinstance(m, nn.Conv2d) and ops.conv3s1_supported(x) and not m.weight.requires_grad
+                    and m.kernel_size == (3, 3) and m.stride == (1, 1) and m.padding == (1, 1)):
+                relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
+                x = autograd_ops.conv3s1_bias_relu(x, m.weight, m.bias, relu)
+                i += 2 if relu else 1
+            else:
+                x = m(x)
+                i += 1
+        return x
+
     def forward(self, fake, real):
-        f = self.model((fake - self.mean) / self.std)
-        r = self.model((real - self.mean) / self.std)
+        f = self.features((fake - self.mean) / self.std)
+        r = self.features((real - self.mean) / self.std)
         return F.mse_loss(f, r.detach())
 
     def pairs(self, *fake_real):
@@ -205,7 +222,7 @@ class PerceptualLoss(nn.Module):
         fakes, reals = [p[0] for p in fake_real], [p[1].detach() for p in fake_real]
         n = [t.shape[0] for t in fakes]
         x = torch.cat(fakes + reals, dim=0)
-        feat = self.model((x - self.mean) / self.std)
+        feat = self.features((x - self.mean) / self.std)
         parts = torch.split(feat, n + n, dim=0)
         k = len(fakes)
         return [F.mse_loss(parts[i], parts[k + i].detach()) for i in range(k)]

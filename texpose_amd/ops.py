@@ -636,28 +636,29 @@ def render_eval(packed: Tensor, intr: Tensor, pose: Tensor, ray_idx: Tensor, z_n
 _conv_counters = {}          # device index -> zero-filled int32 tensor (the kernels leave it zero)
 
 
+def _conv_scratch(lib, ws_fn, a, op: int, dev):
+    """(workspace tensor or None, counters tensor) for a K11 / K12 launch described by the argument struct ``a``."""
+    n_cnt = C.c_int64(0)
+    ws_floats = ws_fn(C.byref(a), op, C.byref(n_cnt))
+    if ws_floats < 0:
+        check(-1, "tp_conv_workspace")
+    cnt = _conv_counters.get(dev.index)
+    if cnt is None or cnt.numel() < n_cnt.value:
+        if torch.cuda.is_current_stream_capturing():
+            raise _lib.TexposeLibraryError("tp_conv: the tile counters must exist before a hipGraph capture (run one "
+                                           "eager step first)")
+        cnt = torch.zeros(max(int(n_cnt.value), 1 << 14), dtype=torch.int32, device=dev)
+        _conv_counters[dev.index] = cnt
+    return (torch.empty(int(ws_floats), device=dev) if ws_floats else None), cnt
+
+
 def _conv4s2(op: int, name: str, x, w, gy, out, N, C_in, H, W, Co):
     lib = _lib.load()
     a = _lib.Conv4s2Args()
     a.N, a.C, a.H, a.W, a.Co = int(N), int(C_in), int(H), int(W), int(Co)
-    n_cnt = C.c_int64(0)
-    ws_floats = lib.tp_conv4s2_workspace(C.byref(a), op, C.byref(n_cnt))
-    if ws_floats < 0:
-        check(-1, "tp_conv4s2_workspace")
-    dev = out.device
-    cnt = _conv_counters.get(dev.index)
-    if cnt is None or cnt.numel() < n_cnt.value:
-        if torch.cuda.is_current_stream_capturing():
-            raise _lib.TexposeLibraryError("tp_conv4s2: the tile counters must exist before a hipGraph capture (run one "
-                                           "eager step first)")
-        cnt = torch.zeros(max(int(n_cnt.value), 1 << 14), dtype=torch.int32, device=dev)
-        _conv_counters[dev.index] = cnt
-    ws = torch.empty(int(ws_floats), device=dev) if ws_floats else None
-    a.x = x.data_ptr() if x is not None else None
-    a.w = w.data_ptr() if w is not None else None
-    a.gy = gy.data_ptr() if gy is not None else None
-    a.out, a.counters = out.data_ptr(), cnt.data_ptr()
-    a.workspace = ws.data_ptr() if ws is not None else None
+    ws, cnt = _conv_scratch(lib, lib.tp_conv4s2_workspace, a, op, out.device)
+    a.x, a.w, a.gy = _ptr(x), _ptr(w), _ptr(gy)
+    a.out, a.counters, a.workspace = out.data_ptr(), cnt.data_ptr(), _ptr(ws)
     check(getattr(lib, name)(C.byref(a), _stream()), name)
     return out
 
@@ -687,3 +688,41 @@ def conv4s2_wgrad(gy: Tensor, x: Tensor) -> Tensor:
     N, C_in, H, W = x.shape
     gw = torch.empty(gy.shape[1], C_in, 4, 4, device=x.device)
     return _conv4s2(_lib.CONV_WGRAD, "tp_conv4s2_wgrad", x, None, gy, gw, N, C_in, H, W, gy.shape[1])
+
+
+# ------------------------------------------------------------------------------------------ K12
+def conv3s1_supported(x: Tensor) -> bool:
+    H, W = x.shape[-2:]
+    return x.is_cuda and x.dtype == torch.float32 and H >= 4 and W >= 4 and (H & (H - 1)) == 0 and (W & (W - 1)) == 0
+
+
+@_on_tensor_device
+def conv3s1_fwd(x: Tensor, w: Tensor, bias: Optional[Tensor], relu: bool) -> Tensor:
+    """relu?(conv2d(x [N,C,H,W], w [Co,C,3,3], bias, stride 1, padding 1))."""
+    lib = _lib.load()
+    x, w = _f32(x, "x"), _f32(w, "w")
+    bias = _f32(bias, "bias") if bias is not None else None
+    N, C_in, H, W = x.shape
+    y = torch.empty(N, w.shape[0], H, W, device=x.device)
+    a = _lib.Conv3s1Args()
+    a.N, a.C, a.H, a.W, a.Co, a.relu = N, C_in, H, W, w.shape[0], int(bool(relu))
+    ws, cnt = _conv_scratch(lib, lib.tp_conv3s1_workspace, a, _lib.CONV_FWD, x.device)
+    a.inp, a.w, a.bias, a.out, a.counters, a.workspace = x.data_ptr(), w.data_ptr(), _ptr(bias), y.data_ptr(), cnt.data_ptr(), _ptr(ws)
+    check(lib.tp_conv3s1_fwd(C.byref(a), _stream()), "tp_conv3s1_fwd")
+    return y
+
+
+@_on_tensor_device
+def conv3s1_dgrad(gy: Tensor, w: Tensor, mask: Optional[Tensor]) -> Tensor:
+    """gradient of conv3s1_fwd wrt x; ``mask`` = the forward output of a ReLU layer (gy counts where it is > 0)."""
+    lib = _lib.load()
+    gy, w = _f32(gy, "gy"), _f32(w, "w")
+    mask = _f32(mask, "mask") if mask is not None else None
+    N, Co, H, W = gy.shape
+    gx = torch.empty(N, w.shape[1], H, W, device=gy.device)
+    a = _lib.Conv3s1Args()
+    a.N, a.C, a.H, a.W, a.Co, a.relu = N, w.shape[1], H, W, Co, 0
+    ws, cnt = _conv_scratch(lib, lib.tp_conv3s1_workspace, a, _lib.CONV_DGRAD, gy.device)
+    a.inp, a.w, a.mask, a.out, a.counters, a.workspace = gy.data_ptr(), w.data_ptr(), _ptr(mask), gx.data_ptr(), cnt.data_ptr(), _ptr(ws)
+    check(lib.tp_conv3s1_dgrad(C.byref(a), _stream()), "tp_conv3s1_dgrad")
+    return gx
