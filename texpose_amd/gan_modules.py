@@ -58,9 +58,14 @@ class _SpectralWeightsHip(torch.autograd.Function):
         from . import ops
         us, vs = [c.weight_u for c in convs], [c.weight_v for c in convs]
         outs, sigmas = ops.spectral_norm_fwd([w.detach() for w in weights], us, vs, training)
-        # later forwards of the same iteration advance u / v in place: keep this forward's copies for its backward
-        ctx.us = [u.clone() for u in us] if training else us
-        ctx.vs = [v.clone() for v in vs] if training else vs
+        # later forwards of the same iteration advance u / v in place: keep this forward's copies for its backward (one
+        # launch for all twelve vectors; none when no weight wants a gradient, e.g. the nerf step)
+        if training and any(ctx.needs_input_grad):
+            flat = torch.cat([t.reshape(-1) for t in us + vs])
+            parts = flat.split([t.numel() for t in us + vs])
+            ctx.us, ctx.vs = list(parts[:len(us)]), list(parts[len(us):])
+        else:
+            ctx.us, ctx.vs = us, vs
         ctx.sigmas = sigmas
         ctx.save_for_backward(*outs)
         return tuple(outs)
@@ -150,6 +155,10 @@ class Discriminator(nn.Module):
                 from . import autograd_ops
                 x = autograd_ops.inorm_lrelu(x, m.eps, mods[i + 1].negative_slope)
                 i += 1
+            elif isinstance(m, nn.LeakyReLU):
+                # out of place even where the module says inplace: the input is a view of a GEMM output, and an in-place
+                # op on a view costs autograd a CopySlices + AsStridedBackward pair (6 launches) per derivative order
+                x = F.leaky_relu(x, m.negative_slope)
             else:
                 x = m(x)
             i += 1

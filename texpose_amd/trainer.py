@@ -30,6 +30,12 @@ from . import dist as tdist
 from . import ops
 from .graph import Graph, summarize_loss
 from .options import AttrDict
+from .options import AttrDict as edict
+
+
+def _finite(t):
+    """isfinite of a tensor in two launches instead of torch's four: x - x is 0 exactly for finite x, NaN otherwise."""
+    return (t - t) == 0
 
 
 class FusedRMSprop(torch.optim.RMSprop):
@@ -128,6 +134,33 @@ class GanTrainer:
             raise FloatingPointError("non-finite discriminator loss (no update applied): %g" % float(total))
         return True
 
+    def _weight(self, exponent, dev):
+        """10^exponent as a 0-dim tensor on ``dev``, made once (a captured step may not create tensors from host values)."""
+        cache = self.__dict__.setdefault("_weights", {})
+        key = (float(exponent), str(dev))
+        if key not in cache:
+            cache[key] = torch.tensor(10 ** float(exponent), device=dev)
+        return cache[key]
+
+    def _backward_weighted(self, loss):
+        """Back-propagate sum 10^w_k loss_k (reference model/base.py:145-157 + ``loss.all.backward()``) without building the
+        scalar graph: the terms are the roots and the weights their cotangents (no mul / add / MulBackward launches per
+        term).  ``loss.all`` is filled with the detached weighted sum (logging, the finite check)."""
+        opt = self.opt
+        keys = [k for k in loss if k != "all" and opt.loss_weight[k] is not None]
+        for k in loss:
+            assert k in opt.loss_weight and loss[k].shape == (), k
+        dev = loss[keys[0]].device
+        ws = [self._weight(opt.loss_weight[k], dev) for k in keys]
+        torch.autograd.backward([loss[k] for k in keys], ws)
+        cache = self.__dict__.setdefault("_weight_vectors", {})
+        vec_key = (tuple(keys), str(dev))
+        if vec_key not in cache:
+            cache[vec_key] = torch.stack(ws)
+        with torch.no_grad():
+            loss.all = torch.dot(torch.stack([loss[k].detach() for k in keys]), cache[vec_key])
+        return loss
+
     def nerf_step(self, var):
         opt, g = self.opt, self.graph
         if self.has_disc:
@@ -135,8 +168,8 @@ class GanTrainer:
         for attempt in range(2):
             self.optim_nerf.zero_grad(set_to_none=True)
             v = g.nerf_forward(opt, var, mode="train")
-            loss = summarize_loss(opt, g.compute_loss(opt, v, mode="train", train_step="nerf"))
-            loss.all.backward()
+            loss = g.compute_loss(opt, v, mode="train", train_step="nerf")
+            self._backward_weighted(loss)
             if self._guard_nerf(v, loss):
                 break
             # range flag of the f16x3 recording forward: nothing of this forward / backward is used
@@ -159,16 +192,17 @@ class GanTrainer:
         self.optim_disc.zero_grad(set_to_none=True)
         var = g.disc_forward(opt, var, mode="train")
         loss = g.compute_loss(opt, var, mode="train", train_step="disc")
-        w = lambda k: 10 ** float(opt.loss_weight[k])
-        total = w("gan_disc_real") * loss.gan_disc_real.detach() + w("gan_disc_fake") * loss.gan_disc_fake.detach()
-        (w("gan_disc_real") * loss.gan_disc_real).backward(retain_graph=True)
+        # The reference back-propagates the three terms one after the other (real, R1 penalty, fake: :139-160).  The sum of
+        # the three gradients is the gradient of the weighted sum: ONE traversal with three roots visits the real-patch
+        # graph once instead of twice and accumulates into every parameter once instead of three times.
+        terms = edict(gan_disc_real=loss.gan_disc_real)
         if opt.loss_weight.gan_reg_real is not None:          # R1: double backward through the discriminator
-            reg = g.compute_grad2(opt, var.d_real_disc, var.patch_real).mean()
-            (w("gan_reg_real") * reg).backward()
+            terms.gan_reg_real = g.compute_grad2(opt, var.d_real_disc, var.patch_real).mean()
+        terms.gan_disc_fake = loss.gan_disc_fake
+        total = self._backward_weighted(terms).all
+        if "gan_reg_real" in terms:
             # the reference logs the WEIGHTED penalty: it scales the tensor it has just stored, in place (:151-153)
-            loss.gan_reg_real = (w("gan_reg_real") * reg).detach()
-            total = total + loss.gan_reg_real
-        (w("gan_disc_fake") * loss.gan_disc_fake).backward()
+            loss.gan_reg_real = self._weight(opt.loss_weight.gan_reg_real, total.device) * terms.gan_reg_real.detach()
         self._guard_disc(total)
         self.red_disc.reduce()
         self.optim_disc.step()
@@ -260,7 +294,7 @@ class GraphedGanTrainer(GanTrainer):
 
     def _guard_nerf(self, var, loss):
         dev = loss.all.device
-        finite = torch.isfinite(loss.all.detach())
+        finite = _finite(loss.all.detach())
         flag = (ops.mlp_status(dev)[0] & 1) != 0 if self._uses_f16x3() else torch.zeros((), dtype=torch.bool, device=dev)
         self._bad.bitwise_or_(torch.stack([flag, ~finite]).to(torch.int32))
         self._ok = self._bad.sum() == 0
@@ -268,7 +302,7 @@ class GraphedGanTrainer(GanTrainer):
         return True
 
     def _guard_disc(self, total):
-        self._bad[1:2].bitwise_or_((~torch.isfinite(total.detach())).to(torch.int32).reshape(1))
+        self._bad[1:2].bitwise_or_((~_finite(total.detach())).to(torch.int32).reshape(1))
         self._gate(self._bad.sum() == 0, [p.grad for p in self.disc_group], self.lr_disc, self.lr_disc_used)
         return True
 
