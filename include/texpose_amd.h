@@ -295,6 +295,8 @@ typedef struct tp_nerf_losses_args {
   int B, P, N;
   void* workspace;         /* 4 * TP_NERF_LOSSES_MAX_BLOCKS floats */
   double* sums;            /* [4]: sum m*se/u^2, sum m, sum log u^2, sum sigma_t  (fwd: out, bwd: in) */
+  float* losses;           /* fwd, optional [3]: render = s0 / (s1 + 1e-5), uncert = 5 + s2 / (B P) / 2, trans_reg = s3 / (B P N)
+                              in fp32 from the fp32-rounded sums, the reference's operation order */
 } tp_nerf_losses_args;
 int tp_nerf_losses_fwd(const tp_nerf_losses_args* args, tp_stream_t stream);
 int tp_nerf_losses_bwd(const tp_nerf_losses_args* args, const float* g_losses /* [3] device */, float* g_rgb,
@@ -381,6 +383,35 @@ typedef struct tp_conv3s1_args {
 int64_t tp_conv3s1_workspace(const tp_conv3s1_args* args, int op, int64_t* n_counters);
 int tp_conv3s1_fwd(const tp_conv3s1_args* args, tp_stream_t stream);
 int tp_conv3s1_dgrad(const tp_conv3s1_args* args, tp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K13  Small per-iteration pieces of the training step, one launch each (csrc/train_misc.hip)
+ * ------------------------------------------------------------------------------------------ */
+/* FlexPatchSampler.__call__ (reference tools/patch_sampler.py:80-114).  u [3,B] uniforms (scale, x shift,
+ * y shift), lattice [p] = linspace(-1, 1, p); the annealed lower scale bound from device memory (lo_dev, a captured step)
+ * or from the host (lo_host, span_host = (float)(hi - lo) formed in double like the reference's Python arithmetic).
+ * coords [B,p,p,2] in grid_sample (x, y) order, scales [B]. */
+int tp_patch_coords(const float* u, int B, int p, const float* lattice, const float* lo_dev, float lo_host, float span_host,
+                    float hi, int random_scale, int random_shift, float* coords, float* scales, tp_stream_t stream);
+/* mean binary_cross_entropy_with_logits(x [n], target) for a constant target (compute_gan_loss 'standard',
+ * model/nerf_adapt_st_gan.py:809-823): out [1]; backward gx [n] = g[0] (sigmoid(x) - target) / n. */
+int tp_bce_logits_fwd(const float* x, int n, float target, float* out, tp_stream_t stream);
+int tp_bce_logits_bwd(const float* x, int n, float target, const float* g, float* gx, tp_stream_t stream);
+/* The four image batches of the feature loss (model/nerf_adapt_st_gan.py:758-766), ImageNet-normalised
+ * (layers/perceptual_loss.py:19-20): out [4B,3,P] = [rgb | rgb m + image (1-m) | image m + image_syn pad | image],
+ * pad = (mask_syn == 1 and m == 0); backward: g_rgb [B,P,3] from g_out [4B,3,P] (only the first 2B images count). */
+typedef struct tp_feat_inputs_args {
+  const float* rgb;        /* [B,P,3] rendered colours */
+  const float* gathered;   /* [B,n_channels,P] tp_patch_gather output */
+  int32_t B, P, n_channels;
+  int32_t c_image, c_image_syn, c_mask, c_mask_syn;   /* first channel of each in `gathered` */
+  float mean[3], std[3];
+} tp_feat_inputs_args;
+int tp_feat_inputs_fwd(const tp_feat_inputs_args* args, float* out, tp_stream_t stream);
+int tp_feat_inputs_bwd(const tp_feat_inputs_args* args, const float* g_out, float* g_rgb, tp_stream_t stream);
+/* The discriminator step's inputs (model/nerf_adapt_st_gan.py:478-497, no gradient): real [B,nc,P] = image m + rgb pad,
+ * fake [B,nc,P] = rgb, nc = 3 or (geo) 9 with the masked nocs / normal channels 6..11 of `gathered` [B,14,P] appended. */
+int tp_disc_inputs(const float* rgb, const float* gathered, int B, int P, int geo, float* real, float* fake, tp_stream_t stream);
 
 #ifdef __cplusplus
 }

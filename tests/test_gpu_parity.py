@@ -1442,3 +1442,79 @@ def test_perceptual_loss_native_convs_match_stock(ops):
         out.append((l1.detach().double().cpu(), l2.detach().double().cpu(), g.double().cpu()))
     for a, b, name in zip(out[1], out[0], ("l1", "l2", "grad")):
         assert rel_l2(a, b) < 1e-5, (name, rel_l2(a, b))
+
+
+# ------------------------------------------------------------------------------------------ K13
+def test_patch_coords_kernel_matches_host_sampler(ops):
+    """tp_patch_coords (FlexPatchSampler on the device) against the same sampler's torch arithmetic on the CPU:
+    bit-for-bit, for a host bound and for the device-resident bound of a captured step, at several annealing stages."""
+    from texpose_amd.geometry import FlexPatchSampler
+    torch.manual_seed(11)
+    for it in (0, 500, 20000, 10 ** 6):
+        for shift, scale in ((True, True), (False, True), (True, False)):
+            s_cpu = FlexPatchSampler(random_shift=shift, random_scale=scale, min_scale=0.25, max_scale=1.0, scale_anneal=0.0025)
+            s_gpu = FlexPatchSampler(random_shift=shift, random_scale=scale, min_scale=0.25, max_scale=1.0, scale_anneal=0.0025)
+            s_cpu.iterations = s_gpu.iterations = it
+            u = torch.rand(3, 5, 1, 1, 1)
+            c0, sc0 = s_cpu(5, 16, device="cpu", u=u)
+            c1, sc1 = s_gpu(5, 16, device=dev(), u=cu(u))
+            assert torch.equal(c1.cpu(), c0) and torch.equal(sc1.cpu(), sc0), (it, shift, scale)
+            # device-resident bound (what a captured step uses): fp32 subtraction of the bound, as torch does on tensors
+            s_gpu.device_lo = torch.tensor(s_gpu._host_range()[0], device=dev())
+            s_cpu.device_lo = s_gpu.device_lo.cpu()
+            c0, sc0 = s_cpu(5, 16, device="cpu", u=u)
+            c1, sc1 = s_gpu(5, 16, device=dev(), u=cu(u))
+            assert torch.equal(c1.cpu(), c0) and torch.equal(sc1.cpu(), sc0), (it, shift, scale, "device bound")
+
+
+@pytest.mark.parametrize("n", [4, 32, 1000])
+def test_bce_logits_kernel_matches_torch(ops, n):
+    from texpose_amd import autograd_ops
+    torch.manual_seed(n)
+    x0 = torch.randn(n, device=dev()) * 4
+    for target in (0.0, 1.0):
+        xa, xb = x0.clone().requires_grad_(), x0.clone().requires_grad_()
+        la = autograd_ops.bce_logits_mean(xa, target)
+        lb = F.binary_cross_entropy_with_logits(xb, torch.full_like(xb, target))
+        ga, = torch.autograd.grad(la * 3.0, xa)
+        gb, = torch.autograd.grad(lb * 3.0, xb)
+        torch.testing.assert_close(la, lb, rtol=2e-6, atol=1e-7)
+        torch.testing.assert_close(ga, gb, rtol=2e-6, atol=1e-9)
+
+
+def test_feat_and_disc_input_kernels_match_torch(ops):
+    """tp_feat_inputs (+ its gradient wrt rgb) and tp_disc_inputs against the torch expressions of compute_loss / disc_forward."""
+    from texpose_amd import autograd_ops
+    torch.manual_seed(21)
+    B, h, w = 3, 16, 16
+    P = h * w
+    rgb0 = torch.rand(B, P, 3, device=dev())
+    g = torch.rand(B, 14, h, w, device=dev())
+    g[:, 12] = (g[:, 12] > 0.4).float()
+    g[:, 13] = (g[:, 13] > 0.3).float()
+    mean, std = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+    mt, st = torch.tensor(mean, device=dev()).view(1, 3, 1, 1), torch.tensor(std, device=dev()).view(1, 3, 1, 1)
+    image, image_syn, obj_mask, mask_syn = g[:, 0:3], g[:, 3:6], g[:, 12:13], g[:, 13:14]
+    cot = torch.randn(4 * B, 3, h, w, device=dev())
+    outs = []
+    for mine in (False, True):
+        r = rgb0.clone().requires_grad_()
+        if mine:
+            x = autograd_ops.feat_inputs(r, g, mt.flatten().tolist(), st.flatten().tolist(), (h, w))
+        else:
+            rgb = r.view(B, h, w, 3).permute(0, 3, 1, 2)
+            pad = torch.logical_and(mask_syn == 1, obj_mask == 0).float()
+            x = torch.cat([rgb, rgb * obj_mask + image * (1 - obj_mask), image * obj_mask + image_syn * pad, image], 0)
+            x = (x - mt) / st
+        gr, = torch.autograd.grad((x * cot).sum(), r)
+        outs.append((x.detach(), gr))
+    assert torch.equal(outs[1][0], outs[0][0])
+    torch.testing.assert_close(outs[1][1], outs[0][1], rtol=1e-6, atol=1e-7)
+    for geo in (True, False):
+        real, fake = ops.disc_inputs(rgb0, g, (h, w), geo)
+        rgb = rgb0.view(B, h, w, 3).permute(0, 3, 1, 2)
+        pad = torch.logical_and(mask_syn == 1, obj_mask == 0).float()
+        real_t, fake_t = image * obj_mask + rgb * pad, rgb
+        if geo:
+            real_t, fake_t = torch.cat([real_t, g[:, 6:9], g[:, 9:12]], 1), torch.cat([fake_t, g[:, 6:9], g[:, 9:12]], 1)
+        assert torch.equal(real, real_t) and torch.equal(fake, fake_t.contiguous())

@@ -30,6 +30,7 @@ SYMBOLS = (
     "tp_rmsprop_step",
     "tp_conv4s2_workspace", "tp_conv4s2_fwd", "tp_conv4s2_dgrad", "tp_conv4s2_wgrad",
     "tp_conv3s1_workspace", "tp_conv3s1_fwd", "tp_conv3s1_dgrad",
+    "tp_patch_coords", "tp_bce_logits_fwd", "tp_bce_logits_bwd", "tp_feat_inputs_fwd", "tp_feat_inputs_bwd", "tp_disc_inputs",
 )
 
 vp = C.c_void_p
@@ -104,6 +105,12 @@ RMSPROP_MAX_TENSORS = 16
 CONV_FWD, CONV_DGRAD, CONV_WGRAD = 0, 1, 2
 
 
+class FeatInputsArgs(C.Structure):
+    _fields_ = [("rgb", vp), ("gathered", vp), ("B", C.c_int32), ("P", C.c_int32), ("n_channels", C.c_int32),
+                ("c_image", C.c_int32), ("c_image_syn", C.c_int32), ("c_mask", C.c_int32), ("c_mask_syn", C.c_int32),
+                ("mean", C.c_float * 3), ("std", C.c_float * 3)]
+
+
 class Conv3s1Args(C.Structure):
     _fields_ = [("inp", vp), ("w", vp), ("bias", vp), ("mask", vp), ("out", vp), ("workspace", vp), ("counters", vp),
                 ("N", C.c_int32), ("C", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Co", C.c_int32), ("relu", C.c_int32)]
@@ -116,7 +123,7 @@ class Conv4s2Args(C.Structure):
 
 class NerfLossesArgs(C.Structure):
     _fields_ = [("rgb", vp), ("uncert", vp), ("density", vp), ("gathered", vp), ("B", C.c_int), ("P", C.c_int),
-                ("N", C.c_int), ("workspace", vp), ("sums", vp)]
+                ("N", C.c_int), ("workspace", vp), ("sums", vp), ("losses", vp)]
 
 
 NERF_LOSSES_MAX_BLOCKS = 1024
@@ -191,6 +198,12 @@ def load() -> C.CDLL:
     sig("tp_conv3s1_workspace", [C.POINTER(Conv3s1Args), C.c_int, C.POINTER(C.c_int64)], C.c_int64)
     for name in ("tp_conv3s1_fwd", "tp_conv3s1_dgrad"):
         sig(name, [C.POINTER(Conv3s1Args), vp])
+    sig("tp_patch_coords", [vp, C.c_int, C.c_int, vp, vp, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, vp, vp, vp])
+    sig("tp_bce_logits_fwd", [vp, C.c_int, C.c_float, vp, vp])
+    sig("tp_bce_logits_bwd", [vp, C.c_int, C.c_float, vp, vp, vp])
+    sig("tp_feat_inputs_fwd", [C.POINTER(FeatInputsArgs), vp, vp])
+    sig("tp_feat_inputs_bwd", [C.POINTER(FeatInputsArgs), vp, vp, vp])
+    sig("tp_disc_inputs", [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp])
     _lib = lib
     return lib
 

@@ -91,14 +91,9 @@ class _NerfLosses(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, rgb, uncert, density, gathered):
-        sums = ops.nerf_losses_fwd(rgb, uncert, density, gathered)
-        B, P, N = rgb.shape[0], rgb.shape[1], density.shape[2]
+        sums, losses = ops.nerf_losses_fwd(rgb, uncert, density, gathered, want_losses=True)
         ctx.save_for_backward(rgb, uncert, density, gathered, sums)
-        s = sums.float()
-        render = s[0] / (s[1] + 1e-5)
-        unc = 5 + s[2] / (B * P) / 2
-        trans = s[3] / (B * P * N)
-        return render, unc, trans
+        return losses[0], losses[1], losses[2]
 
     @staticmethod
     @torch.autograd.function.once_differentiable
@@ -224,3 +219,44 @@ class _Conv3s1BiasRelu(torch.autograd.Function):
 def conv3s1_bias_relu(x, w, bias, relu: bool):
     """relu?(conv2d(x, w, bias, padding 1)) for a frozen [Co,C,3,3] weight (K12)."""
     return _Conv3s1BiasRelu.apply(x.contiguous(), w, bias, bool(relu))
+
+
+# ---- K13 pieces
+class _BceLogitsMean(torch.autograd.Function):
+    """mean binary_cross_entropy_with_logits(x, constant target): one launch each way (first order only: the R1 penalty
+    differentiates d_out.sum(), never this loss)."""
+
+    @staticmethod
+    def forward(ctx, x, target):
+        ctx.save_for_backward(x)
+        ctx.target = target
+        return ops.bce_logits_fwd(x, target)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        x, = ctx.saved_tensors
+        return ops.bce_logits_bwd(x, ctx.target, g).view_as(x), None
+
+
+def bce_logits_mean(x, target: float):
+    return _BceLogitsMean.apply(x.contiguous(), float(target))
+
+
+class _FeatInputs(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rgb, gathered, mean, std, hw):
+        ctx.save_for_backward(rgb, gathered)
+        ctx.consts = (mean, std)
+        return ops.feat_inputs_fwd(rgb, gathered, mean, std, hw)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        rgb, gathered = ctx.saved_tensors
+        return ops.feat_inputs_bwd(rgb, gathered, ctx.consts[0], ctx.consts[1], g.contiguous()), None, None, None, None
+
+
+def feat_inputs(rgb, gathered, mean, std, hw):
+    """rgb [B,P,3] + the gathered patches -> the normalised [4B,3,h,w] input of the feature network; gradient wrt rgb only."""
+    return _FeatInputs.apply(rgb.contiguous(), gathered, tuple(mean), tuple(std), tuple(hw))

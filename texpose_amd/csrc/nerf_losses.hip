@@ -56,7 +56,8 @@ __global__ __launch_bounds__(kBlock) void nerf_losses_fwd_kernel(tp_nerf_losses_
 }
 
 // fixed-order reduction of the per-block partials: thread t adds partials t, t+256, ... in order, then a block tree
-__global__ __launch_bounds__(kBlock) void nerf_losses_finalize(const float* partial, int n_blocks, double* sums) {
+__global__ __launch_bounds__(kBlock) void nerf_losses_finalize(const float* partial, int n_blocks, double* sums, float* losses,
+                                                               float n_pix, float n_den) {
   __shared__ double red[4][kBlock];
   const int tid = threadIdx.x;
   double v[4] = {0.0, 0.0, 0.0, 0.0};
@@ -75,6 +76,12 @@ __global__ __launch_bounds__(kBlock) void nerf_losses_finalize(const float* part
     __syncthreads();
   }
   if (tid < 4) sums[tid] = red[tid][0];
+  if (tid == 0 && losses != nullptr) {
+    const float s0 = (float)red[0][0], s1 = (float)red[1][0], s2 = (float)red[2][0], s3 = (float)red[3][0];
+    losses[0] = tp::div_rn(s0, tp::add_rn(s1, 1e-5f));
+    losses[1] = tp::add_rn(5.f, tp::div_rn(tp::div_rn(s2, n_pix), 2.f));
+    losses[2] = tp::div_rn(s3, n_den);
+  }
 }
 
 // g[0..2]: upstream gradients of (render, uncert, trans_reg)
@@ -117,7 +124,8 @@ extern "C" int tp_nerf_losses_fwd(const tp_nerf_losses_args* a, tp_stream_t stre
   if (int rc = check(a, "tp_nerf_losses_fwd")) return rc;
   const int g = grid_for(a);
   hipLaunchKernelGGL(nerf_losses_fwd_kernel, dim3(g), dim3(kBlock), 0, (hipStream_t)stream, *a, (float*)a->workspace);
-  hipLaunchKernelGGL(nerf_losses_finalize, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, (const float*)a->workspace, g, a->sums);
+  hipLaunchKernelGGL(nerf_losses_finalize, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, (const float*)a->workspace, g, a->sums, a->losses,
+                     (float)((int64_t)a->B * a->P), (float)((int64_t)a->B * a->P * a->N));
   return tp::check_launch("tp_nerf_losses_fwd");
 }
 

@@ -1,0 +1,177 @@
+// K13: the small per-iteration pieces of a training step that PyTorch spreads over dozens of 1-5 us launches each.  In a
+// hipGraph replay of the B=4 GAN iteration every launch costs ~4 us whatever it computes, and 385 of 579 launches were such
+// elementwise / fill / copy kernels on a few hundred values (profiles/r2): these kernels replace the longest chains, one
+// launch per direction, reproducing torch's fp32 operation order where a golden pins the values.
+//   tp_patch_coords      FlexPatchSampler.__call__ (reference tools/patch_sampler.py:80-114): 17 launches
+//   tp_bce_logits_*      binary_cross_entropy_with_logits(d, const target), mean (model/nerf_adapt_st_gan.py:809-823,
+//                        compute_gan_loss 'standard'): 8 launches forward, 4 backward, three times per iteration
+//   tp_feat_inputs_*     the two (fake, real) pairs of the feature loss, masked, concatenated and ImageNet-normalised
+//                        (model/nerf_adapt_st_gan.py:758-766 + layers/perceptual_loss.py:19-20,31-37): 14 + 4 launches
+//   tp_disc_inputs       the real / fake patch stacks of the discriminator step (model/nerf_adapt_st_gan.py:478-497): 10 launches
+#include "tp_common.h"
+
+namespace {
+constexpr int kBlock = 256;
+
+// ---- patch coordinates: s = u0 * (hi - lo) + lo;  x = lattice_j * s + (u1 * 2 - 1) * (1 - s);  y likewise with u2
+__global__ __launch_bounds__(kBlock) void patch_coords_kernel(const float* __restrict__ u, int B, int p, const float* __restrict__ lattice,
+                                                              const float* lo_dev, float lo_host, float span_host, float hi,
+                                                              int random_scale, int random_shift, float* __restrict__ coords,
+                                                              float* __restrict__ scales) {
+  const int e = blockIdx.x * kBlock + threadIdx.x;
+  if (e >= B * p * p) return;
+  const int b = e / (p * p), r = e - b * p * p, i = r / p, j = r - i * p;
+  const float lo = lo_dev ? *lo_dev : lo_host;
+  const float span = lo_dev ? tp::sub_rn(hi, lo) : span_host;      // (a device-side bound is subtracted in fp32, like torch)
+  const float s = random_scale ? tp::add_rn(tp::mul_rn(u[b], span), lo) : tp::add_rn(0.f, lo);
+  float x = tp::mul_rn(lattice[j], s), y = tp::mul_rn(lattice[i], s);
+  if (random_shift) {
+    const float room = tp::sub_rn(1.f, s);
+    x = tp::add_rn(x, tp::mul_rn(tp::sub_rn(tp::mul_rn(u[B + b], 2.0f), 1.0f), room));
+    y = tp::add_rn(y, tp::mul_rn(tp::sub_rn(tp::mul_rn(u[2 * B + b], 2.0f), 1.0f), room));
+  }
+  coords[2 * (size_t)e] = x;
+  coords[2 * (size_t)e + 1] = y;
+  if (r == 0) scales[b] = s;
+}
+
+// ---- mean_i [ (1 - t) x_i - log_sigmoid(x_i) ]  (torch's formula), one workgroup, fixed-order tree
+__global__ __launch_bounds__(kBlock) void bce_logits_fwd_kernel(const float* __restrict__ x, int n, float target, float* __restrict__ out) {
+  __shared__ float red[kBlock];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < n; i += kBlock) {
+    const float v = x[i];
+    const float ls = fminf(v, 0.f) - log1pf(expf(-fabsf(v)));      // log_sigmoid
+    acc += (1.f - target) * v - ls;
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = kBlock >> 1; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = red[0] / (float)n;
+}
+__global__ __launch_bounds__(kBlock) void bce_logits_bwd_kernel(const float* __restrict__ x, int n, float target, const float* __restrict__ g,
+                                                                 float* __restrict__ gx) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const float sg = 1.f / (1.f + expf(-x[i]));
+  gx[i] = (sg - target) * g[0] / (float)n;
+}
+
+// ---- feature-loss inputs.  rgb [B,P,3] (render layout), gathered [B,14,P] (patch gather: image 0..2, synthetic image 3..5,
+// object mask 12, synthetic mask 13).  out [4B,3,P]: rows 0..B-1 fake1 = rgb, B..2B-1 fake2 = rgb m + image (1 - m),
+// 2B..3B-1 real1 = image m + image_syn pad, 3B..4B-1 real2 = image;  pad = (mask_syn == 1 && m == 0);  then (v - mean) / std.
+struct FeatP { const float* rgb; const float* gathered; float* out; const float* g_out; float* g_rgb; int B, P, c_img, c_syn, c_mask, c_msyn, n_ch;
+               float mean[3], stdv[3]; };
+__global__ __launch_bounds__(kBlock) void feat_inputs_fwd_kernel(FeatP a) {
+  const int e = blockIdx.x * kBlock + threadIdx.x;
+  if (e >= a.B * a.P) return;
+  const int b = e / a.P, p = e - b * a.P;
+  const float* gp = a.gathered + (size_t)b * a.n_ch * a.P + p;
+  const float m = gp[(size_t)a.c_mask * a.P], ms = gp[(size_t)a.c_msyn * a.P];
+  const float pad = (ms == 1.f && m == 0.f) ? 1.f : 0.f;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float r = a.rgb[(size_t)e * 3 + c], im = gp[(size_t)(a.c_img + c) * a.P], sy = gp[(size_t)(a.c_syn + c) * a.P];
+    const float v[4] = {r, tp::add_rn(tp::mul_rn(r, m), tp::mul_rn(im, tp::sub_rn(1.f, m))),
+                        tp::add_rn(tp::mul_rn(im, m), tp::mul_rn(sy, pad)), im};
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      a.out[((size_t)(k * a.B + b) * 3 + c) * a.P + p] = tp::div_rn(tp::sub_rn(v[k], a.mean[c]), a.stdv[c]);
+  }
+}
+// d/d rgb = (g[fake1] + g[fake2] * m) / std
+__global__ __launch_bounds__(kBlock) void feat_inputs_bwd_kernel(FeatP a) {
+  const int e = blockIdx.x * kBlock + threadIdx.x;
+  if (e >= a.B * a.P) return;
+  const int b = e / a.P, p = e - b * a.P;
+  const float m = a.gathered[((size_t)b * a.n_ch + a.c_mask) * a.P + p];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float g1 = tp::div_rn(a.g_out[((size_t)b * 3 + c) * a.P + p], a.stdv[c]);
+    const float g2 = tp::div_rn(a.g_out[((size_t)(a.B + b) * 3 + c) * a.P + p], a.stdv[c]);
+    a.g_rgb[(size_t)e * 3 + c] = tp::add_rn(g1, tp::mul_rn(g2, m));
+  }
+}
+
+// ---- discriminator inputs (no gradient): real = image m + rgb pad, fake = rgb, both followed by the six geometry channels
+__global__ __launch_bounds__(kBlock) void disc_inputs_kernel(const float* __restrict__ rgb, const float* __restrict__ gathered, int B, int P,
+                                                             int geo, float* __restrict__ real, float* __restrict__ fake) {
+  const int e = blockIdx.x * kBlock + threadIdx.x;
+  if (e >= B * P) return;
+  const int b = e / P, p = e - b * P, nc = geo ? 9 : 3;
+  const float* gp = gathered + (size_t)b * 14 * P + p;
+  const float m = gp[12 * (size_t)P], ms = gp[13 * (size_t)P];
+  const float pad = (ms == 1.f && m == 0.f) ? 1.f : 0.f;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float r = rgb[(size_t)e * 3 + c];
+    real[((size_t)b * nc + c) * P + p] = tp::add_rn(tp::mul_rn(gp[(size_t)c * P], m), tp::mul_rn(r, pad));
+    fake[((size_t)b * nc + c) * P + p] = r;
+  }
+  if (geo)
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      const float v = gp[(size_t)(6 + c) * P];
+      real[((size_t)b * nc + 3 + c) * P + p] = v;
+      fake[((size_t)b * nc + 3 + c) * P + p] = v;
+    }
+}
+}  // namespace
+
+extern "C" {
+int tp_disc_inputs(const float* rgb, const float* gathered, int B, int P, int geo, float* real, float* fake, tp_stream_t stream) {
+  TP_REQUIRE(rgb && gathered && real && fake && B > 0 && P > 0, "bad arguments");
+  const int n = B * P;
+  hipLaunchKernelGGL(disc_inputs_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, (hipStream_t)stream, rgb, gathered, B, P, geo, real, fake);
+  return tp::check_launch("tp_disc_inputs");
+}
+
+int tp_patch_coords(const float* u, int B, int p, const float* lattice, const float* lo_dev, float lo_host, float span_host, float hi,
+                    int random_scale, int random_shift, float* coords, float* scales, tp_stream_t stream) {
+  TP_REQUIRE(u && lattice && coords && scales && B > 0 && p > 0, "bad arguments");
+  const int n = B * p * p;
+  hipLaunchKernelGGL(patch_coords_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, (hipStream_t)stream, u, B, p, lattice, lo_dev,
+                     lo_host, span_host, hi, random_scale, random_shift, coords, scales);
+  return tp::check_launch("tp_patch_coords");
+}
+
+int tp_bce_logits_fwd(const float* x, int n, float target, float* out, tp_stream_t stream) {
+  TP_REQUIRE(x && out && n > 0, "bad arguments");
+  hipLaunchKernelGGL(bce_logits_fwd_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, x, n, target, out);
+  return tp::check_launch("tp_bce_logits_fwd");
+}
+int tp_bce_logits_bwd(const float* x, int n, float target, const float* g, float* gx, tp_stream_t stream) {
+  TP_REQUIRE(x && g && gx && n > 0, "bad arguments");
+  hipLaunchKernelGGL(bce_logits_bwd_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, (hipStream_t)stream, x, n, target, g, gx);
+  return tp::check_launch("tp_bce_logits_bwd");
+}
+
+static int feat_fill(FeatP* q, const tp_feat_inputs_args* a) {
+  TP_REQUIRE(a && a->rgb && a->gathered && a->B > 0 && a->P > 0 && a->n_channels > 0, "bad arguments");
+  q->rgb = a->rgb; q->gathered = a->gathered; q->B = a->B; q->P = a->P; q->n_ch = a->n_channels;
+  q->c_img = a->c_image; q->c_syn = a->c_image_syn; q->c_mask = a->c_mask; q->c_msyn = a->c_mask_syn;
+  for (int c = 0; c < 3; ++c) { q->mean[c] = a->mean[c]; q->stdv[c] = a->std[c]; }
+  return 0;
+}
+int tp_feat_inputs_fwd(const tp_feat_inputs_args* a, float* out, tp_stream_t stream) {
+  FeatP q{};
+  if (int rc = feat_fill(&q, a)) return rc;
+  TP_REQUIRE(out, "out missing");
+  q.out = out;
+  const int n = a->B * a->P;
+  hipLaunchKernelGGL(feat_inputs_fwd_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, (hipStream_t)stream, q);
+  return tp::check_launch("tp_feat_inputs_fwd");
+}
+int tp_feat_inputs_bwd(const tp_feat_inputs_args* a, const float* g_out, float* g_rgb, tp_stream_t stream) {
+  FeatP q{};
+  if (int rc = feat_fill(&q, a)) return rc;
+  TP_REQUIRE(g_out && g_rgb, "gradient pointers missing");
+  q.g_out = g_out; q.g_rgb = g_rgb;
+  const int n = a->B * a->P;
+  hipLaunchKernelGGL(feat_inputs_bwd_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, (hipStream_t)stream, q);
+  return tp::check_launch("tp_feat_inputs_bwd");
+}
+}

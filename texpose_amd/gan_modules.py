@@ -201,6 +201,9 @@ class PerceptualLoss(nn.Module):
         # no such keys, layers/perceptual_loss.py:19-20), otherwise reference checkpoints would not load strictly
         self.register_buffer("mean", torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1), persistent=False)
         self.register_buffer("std", torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1), persistent=False)
+        # host copies of the constants (fp32-rounded, as the buffers hold them) for the fused input kernel: no device read
+        self._mean_host = self.mean.flatten().tolist()
+        self._std_host = self.std.flatten().tolist()
 
     def features(self, x):
         """``self.model(x)``; on the GPU every convolution (+ bias + ReLU) of the frozen network is one K12 launch in each
@@ -223,6 +226,17 @@ class PerceptualLoss(nn.Module):
         f = self.features((fake - self.mean) / self.std)
         r = self.features((real - self.mean) / self.std)
         return F.mse_loss(f, r.detach())
+
+    def pairs_from_patches(self, rgb, gathered, hw):
+        """The two feature-loss terms of the generator step (reference model/nerf_adapt_st_gan.py:758-766) from the render
+        output rgb [B,P,3] and the gathered patches [B,14,h,w]: masking, concatenation and ImageNet normalisation of the
+        four image batches in one launch (K13 tp_feat_inputs), then one pass through the feature network."""
+        from . import autograd_ops
+        B = rgb.shape[0]
+        x = autograd_ops.feat_inputs(rgb, gathered, self._mean_host, self._std_host, hw)
+        feat = self.features(x)
+        f1, f2, r1, r2 = torch.split(feat, B, dim=0)
+        return F.mse_loss(f1, r1.detach()), F.mse_loss(f2, r2.detach())
 
     def pairs(self, *fake_real):
         """[MSE(feat(fake_i), feat(real_i))] for several (fake, real) pairs through ONE pass over the feature network

@@ -203,6 +203,9 @@ class FlexPatchSampler:
         lo, hi = self.scales_curr = self.scale_range()
         if u is None:
             u = torch.rand(3, nbatch, 1, 1, 1, device=device)
+        if u.is_cuda:                                        # one launch (K13 tp_patch_coords), same fp32 operation order
+            from . import ops
+            return ops.patch_coords(u, patch_size, lo, hi, self.random_scale, self.random_shift)
         s = u[0] * (hi - lo) + lo if self.random_scale else torch.zeros(nbatch, 1, 1, 1, device=device) + lo
         lattice = torch.linspace(-1, 1, patch_size, device=device)
         xs = lattice.view(1, 1, patch_size, 1) * s          # varies along the patch width  -> grid x

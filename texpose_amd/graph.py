@@ -102,7 +102,11 @@ class Graph(torch.nn.Module):
         center, ray, _, _, depth = ops.raygen(intr, pose, H=opt.H, W=opt.W, n_samples=N, z_near=z_near, z_far=z_far,
                                               **src, **self._jitter(opt, rand))
         depth_samples = depth[..., None]                                     # [B,R,N,1]
-        if mode == "train":
+        if mode == "train" and torch.is_tensor(sample_idx) and sample_idx.dim() == 1:
+            # (index_select: its backward is zeros + index_add_, two launches; indexing's is a seven-launch index_put_)
+            lat_t = self.latent_vars_trans.weight.index_select(0, sample_idx)
+            lat_l = self.latent_vars_light.weight.index_select(0, sample_idx)
+        elif mode == "train":
             lat_t = self.latent_vars_trans.weight[sample_idx]
             lat_l = self.latent_vars_light.weight[sample_idx]
         elif mode == "val":
@@ -259,14 +263,17 @@ class Graph(torch.nn.Module):
         if mode != "train":
             raise Exception("No use of discriminator in val/testing phase of NeRF!")
         B, h, w, _ = var.ray_idx.shape
-        rgb = var.rgb.view(B, h, w, 3).permute(0, 3, 1, 2).contiguous()
-        mask_pad = torch.logical_and(var.mask_syn_sample == 1, var.mask_sample == 0).float()
-        real = (var.image_sample * var.mask_sample + rgb * mask_pad).detach()
-        fake = rgb.detach()
-        if opt.gan.geo_conditional:
-            var = self.sample_geometry(opt, var, mode)
-            real = torch.cat([real, var.nocs_sample, var.normal_sample], dim=1)
-            fake = torch.cat([fake, var.nocs_sample, var.normal_sample], dim=1)
+        if "gathered" in var and var.rgb.is_cuda and var.get("gathered_for") is var.ray_idx:
+            real, fake = ops.disc_inputs(var.rgb, var.gathered, (h, w), bool(opt.gan.geo_conditional))     # K13: one launch
+        else:
+            rgb = var.rgb.view(B, h, w, 3).permute(0, 3, 1, 2).contiguous()
+            mask_pad = torch.logical_and(var.mask_syn_sample == 1, var.mask_sample == 0).float()
+            real = (var.image_sample * var.mask_sample + rgb * mask_pad).detach()
+            fake = rgb.detach()
+            if opt.gan.geo_conditional:
+                var = self.sample_geometry(opt, var, mode)
+                real = torch.cat([real, var.nocs_sample, var.normal_sample], dim=1)
+                fake = torch.cat([fake, var.nocs_sample, var.normal_sample], dim=1)
         var.patch_real, var.patch_fake = real.requires_grad_(), fake.requires_grad_()
         var.d_real_disc = self.discriminator(opt, var.patch_real, var.ray_scales)
         var.d_fake_disc = self.discriminator(opt, var.patch_fake, var.ray_scales)
@@ -327,13 +334,18 @@ class Graph(torch.nn.Module):
             if lw.feat is not None:
                 if not hasattr(self, "perceptual_loss"):
                     raise RuntimeError("loss_weight.feat is set but no perceptual_loss module was injected")
-                mask_pad = torch.logical_and(mask_syn == 1, obj_mask == 0).float()
-                pair1 = (rgb, image * obj_mask + image_syn * mask_pad)
-                pair2 = (rgb * obj_mask + image * (1 - obj_mask), image)
-                if hasattr(self.perceptual_loss, "pairs"):            # both terms through one pass of the feature network
-                    l1, l2 = self.perceptual_loss.pairs(pair1, pair2)
-                else:                                                  # any injected module with the reference's call signature
-                    l1, l2 = self.perceptual_loss(*pair1), self.perceptual_loss(*pair2)
+                fused_feat = ("gathered" in var and var.rgb.is_cuda and hasattr(self.perceptual_loss, "pairs_from_patches")
+                              and opt.nerf.rand_rays and mode in ["train", "test-optim"])
+                if fused_feat:              # K13 + K12: masking, concatenation and normalisation of the four batches in one launch
+                    l1, l2 = self.perceptual_loss.pairs_from_patches(var.rgb, var.gathered, (h, w))
+                else:
+                    mask_pad = torch.logical_and(mask_syn == 1, obj_mask == 0).float()
+                    pair1 = (rgb, image * obj_mask + image_syn * mask_pad)
+                    pair2 = (rgb * obj_mask + image * (1 - obj_mask), image)
+                    if hasattr(self.perceptual_loss, "pairs"):        # both terms through one pass of the feature network
+                        l1, l2 = self.perceptual_loss.pairs(pair1, pair2)
+                    else:                                              # any injected module with the reference's call signature
+                        l1, l2 = self.perceptual_loss(*pair1), self.perceptual_loss(*pair2)
                 loss.feat = l1 + 5 * l2
             if lw.lab is not None:
                 loss.lab, var.rgb_lab, var.img_syn_lab = self.lab_loss(rgb, image_syn, mask=mask_syn)
@@ -364,6 +376,8 @@ class Graph(torch.nn.Module):
         d_outs = d_outs if isinstance(d_outs, list) else [d_outs]
         loss = d_outs[0].new_zeros(())                       # (no host-to-device copy: the step is hipGraph-capturable)
         for d_out in d_outs:
+            if opt.gan.type == "standard" and d_out.is_cuda and len(d_outs) == 1:
+                return autograd_ops.bce_logits_mean(d_out, float(target))      # K13: one launch each way
             if opt.gan.type == "standard":
                 loss = loss + torch_F.binary_cross_entropy_with_logits(d_out, torch.full_like(d_out, float(target)))
             elif opt.gan.type == "wgan":

@@ -516,15 +516,17 @@ def _nerf_losses_args(rgb, uncert, density, gathered):
 
 
 @_on_tensor_device
-def nerf_losses_fwd(rgb: Tensor, uncert: Tensor, density: Tensor, gathered: Tensor):
+def nerf_losses_fwd(rgb: Tensor, uncert: Tensor, density: Tensor, gathered: Tensor, want_losses: bool = False):
     """Four fp64 sums [sum m*se/u^2, sum m, sum log u^2, sum sigma_t] (device tensor) for the render / uncert /
-    trans_reg terms of the generator step (reference compute_loss :747-760)."""
+    trans_reg terms of the generator step (reference compute_loss :747-760); with ``want_losses`` also the three fp32 loss
+    values [render, uncert, trans_reg] formed by the same launch."""
     lib, a, keep = _nerf_losses_args(rgb, uncert, density, gathered)
     ws = torch.empty(4 * _lib.NERF_LOSSES_MAX_BLOCKS, device=rgb.device)
     sums = torch.empty(4, dtype=torch.float64, device=rgb.device)
-    a.workspace, a.sums = ws.data_ptr(), sums.data_ptr()
+    losses = torch.empty(3, device=rgb.device) if want_losses else None
+    a.workspace, a.sums, a.losses = ws.data_ptr(), sums.data_ptr(), _ptr(losses)
     check(lib.tp_nerf_losses_fwd(C.byref(a), _stream()), "tp_nerf_losses_fwd")
-    return sums
+    return (sums, losses) if want_losses else sums
 
 
 @_on_tensor_device
@@ -726,3 +728,92 @@ def conv3s1_dgrad(gy: Tensor, w: Tensor, mask: Optional[Tensor]) -> Tensor:
     a.inp, a.w, a.mask, a.out, a.counters, a.workspace = gy.data_ptr(), w.data_ptr(), _ptr(mask), gx.data_ptr(), cnt.data_ptr(), _ptr(ws)
     check(lib.tp_conv3s1_dgrad(C.byref(a), _stream()), "tp_conv3s1_dgrad")
     return gx
+
+
+# ------------------------------------------------------------------------------------------ K13
+_lattices = {}
+
+
+@_on_tensor_device
+def patch_coords(u: Tensor, patch_size: int, lo, hi: float, random_scale: bool = True, random_shift: bool = True):
+    """FlexPatchSampler in one launch: u [3,B,...] uniforms -> (coords [B,p,p,2], scales [B,1,1,1]); ``lo`` is a float or a
+    0-dim device tensor (the annealed bound of a captured step)."""
+    lib = _lib.load()
+    u = _f32(u, "u")
+    B, p = u.numel() // 3, int(patch_size)
+    key = (p, u.device.index)
+    if key not in _lattices:
+        _lattices[key] = torch.linspace(-1, 1, p, device=u.device)
+    coords = torch.empty(B, p, p, 2, device=u.device)
+    scales = torch.empty(B, 1, 1, 1, device=u.device)
+    lo_dev = lo.data_ptr() if torch.is_tensor(lo) else None
+    lo_host = 0.0 if torch.is_tensor(lo) else float(lo)
+    check(lib.tp_patch_coords(u.data_ptr(), B, p, _lattices[key].data_ptr(), lo_dev, lo_host, float(hi) - lo_host, float(hi),
+                              int(bool(random_scale)), int(bool(random_shift)), coords.data_ptr(), scales.data_ptr(), _stream()),
+          "tp_patch_coords")
+    return coords, scales
+
+
+@_on_tensor_device
+def bce_logits_fwd(x: Tensor, target: float) -> Tensor:
+    lib = _lib.load()
+    x = _f32(x, "x")
+    out = torch.empty((), device=x.device)
+    check(lib.tp_bce_logits_fwd(x.data_ptr(), x.numel(), float(target), out.data_ptr(), _stream()), "tp_bce_logits_fwd")
+    return out
+
+
+@_on_tensor_device
+def bce_logits_bwd(x: Tensor, target: float, g: Tensor) -> Tensor:
+    lib = _lib.load()
+    x, g = _f32(x, "x"), _f32(g, "g")
+    gx = torch.empty_like(x)
+    check(lib.tp_bce_logits_bwd(x.data_ptr(), x.numel(), float(target), g.data_ptr(), gx.data_ptr(), _stream()), "tp_bce_logits_bwd")
+    return gx
+
+
+def _feat_args(rgb, gathered, mean, std):
+    a = _lib.FeatInputsArgs()
+    B, P = rgb.shape[0], rgb.shape[1]
+    if rgb.shape != (B, P, 3) or gathered.shape[0] != B or gathered.numel() != B * 14 * P:
+        raise ValueError("feat_inputs: rgb [B,P,3] and gathered [B,14,p,p] expected")
+    a.rgb, a.gathered, a.B, a.P, a.n_channels = rgb.data_ptr(), gathered.data_ptr(), B, P, 14
+    a.c_image, a.c_image_syn, a.c_mask, a.c_mask_syn = 0, 3, 12, 13
+    for c in range(3):
+        a.mean[c], a.std[c] = float(mean[c]), float(std[c])
+    return a
+
+
+@_on_tensor_device
+def feat_inputs_fwd(rgb: Tensor, gathered: Tensor, mean, std, hw) -> Tensor:
+    """-> [4B,3,h,w]: the (fake, real) pairs of the feature loss, masked and ImageNet-normalised (K13)."""
+    lib = _lib.load()
+    rgb, gathered = _f32(rgb, "rgb"), _f32(gathered, "gathered")
+    out = torch.empty(4 * rgb.shape[0], 3, hw[0], hw[1], device=rgb.device)
+    check(lib.tp_feat_inputs_fwd(C.byref(_feat_args(rgb, gathered, mean, std)), out.data_ptr(), _stream()), "tp_feat_inputs_fwd")
+    return out
+
+
+@_on_tensor_device
+def feat_inputs_bwd(rgb: Tensor, gathered: Tensor, mean, std, g_out: Tensor) -> Tensor:
+    lib = _lib.load()
+    g_out = _f32(g_out, "g_out")
+    g_rgb = torch.empty_like(rgb)
+    check(lib.tp_feat_inputs_bwd(C.byref(_feat_args(rgb, gathered, mean, std)), g_out.data_ptr(), g_rgb.data_ptr(), _stream()),
+          "tp_feat_inputs_bwd")
+    return g_rgb
+
+
+@_on_tensor_device
+def disc_inputs(rgb: Tensor, gathered: Tensor, hw, geo: bool):
+    """(real, fake) [B, 3 or 9, h, w] of the discriminator step from the render output and the gathered patches (K13)."""
+    lib = _lib.load()
+    rgb, gathered = _f32(rgb.detach(), "rgb"), _f32(gathered, "gathered")
+    B, P = rgb.shape[0], rgb.shape[1]
+    if gathered.numel() != B * 14 * P:
+        raise ValueError("disc_inputs: gathered [B,14,h,w] expected")
+    nc = 9 if geo else 3
+    real, fake = torch.empty(B, nc, hw[0], hw[1], device=rgb.device), torch.empty(B, nc, hw[0], hw[1], device=rgb.device)
+    check(lib.tp_disc_inputs(rgb.data_ptr(), gathered.data_ptr(), B, P, int(bool(geo)), real.data_ptr(), fake.data_ptr(), _stream()),
+          "tp_disc_inputs")
+    return real, fake
