@@ -635,7 +635,7 @@ def render_eval(packed: Tensor, intr: Tensor, pose: Tensor, ray_idx: Tensor, z_n
 
 
 # ------------------------------------------------------------------------------------------ K11
-_conv_counters = {}          # device index -> zero-filled int32 tensor (the kernels leave it zero)
+_conv_counters = {}          # (device index, stream) -> zero-filled int32 tensor (the kernels leave it zero)
 
 
 def _conv_scratch(lib, ws_fn, a, op: int, dev):
@@ -644,13 +644,16 @@ def _conv_scratch(lib, ws_fn, a, op: int, dev):
     ws_floats = ws_fn(C.byref(a), op, C.byref(n_cnt))
     if ws_floats < 0:
         check(-1, "tp_conv_workspace")
-    cnt = _conv_counters.get(dev.index)
+    # one counter array per (device, stream): launches on different streams may run concurrently (the two branches of the
+    # captured training step) and must not see each other's tile arrivals
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    cnt = _conv_counters.get(key)
     if cnt is None or cnt.numel() < n_cnt.value:
         if torch.cuda.is_current_stream_capturing():
             raise _lib.TexposeLibraryError("tp_conv: the tile counters must exist before a hipGraph capture (run one "
                                            "eager step first)")
         cnt = torch.zeros(max(int(n_cnt.value), 1 << 14), dtype=torch.int32, device=dev)
-        _conv_counters[dev.index] = cnt
+        _conv_counters[key] = cnt
     return (torch.empty(int(ws_floats), device=dev) if ws_floats else None), cnt
 
 
