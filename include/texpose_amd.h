@@ -328,8 +328,10 @@ typedef struct tp_rmsprop_tensor {
   float* square_avg;       /* [numel] updated in place */
   int64_t numel;
 } tp_rmsprop_tensor;
-int tp_rmsprop_step(const tp_rmsprop_tensor* tensors /* host array */, int n, const float* lr_dev, float lr_host, float alpha,
-                    float eps, tp_stream_t stream);
+/* gate: n_gate int32 device words (or 0): if any is non-zero the launch changes nothing (a flagged step, see tp_step_flags) */
+/* hyper-parameters as doubles: 1 - alpha is formed in double and then rounded, like torch's scalar arithmetic */
+int tp_rmsprop_step(const tp_rmsprop_tensor* tensors /* host array */, int n, const float* lr_dev, double lr_host, double alpha,
+                    double eps, const int32_t* gate, int n_gate, tp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * K11  The stride-2 4x4 convolutions of the PatchGAN ladder (reference layers/discriminator.py:94-115:
@@ -411,6 +413,25 @@ int tp_feat_inputs_fwd(const tp_feat_inputs_args* args, float* out, tp_stream_t 
 int tp_feat_inputs_bwd(const tp_feat_inputs_args* args, const float* g_out, float* g_rgb, tp_stream_t stream);
 /* The discriminator step's inputs (model/nerf_adapt_st_gan.py:478-497, no gradient): real [B,nc,P] = image m + rgb pad,
  * fake [B,nc,P] = rgb, nc = 3 or (geo) 9 with the masked nocs / normal channels 6..11 of `gathered` [B,14,P] appended. */
+/* Step gate of a captured training step (the reference asserts every weighted loss term finite on the host,
+ * model/base.py:153-154): bad[word_status] |= mlp_status[0] & 1 (mlp_status may be NULL), bad[word_finite] |= !isfinite(total[0]),
+ * then snapshot[0..n_bad) = bad[0..n_bad) -- the words the optimiser launch of this step reads as its gate. */
+int tp_step_flags(const int32_t* mlp_status, const float* total, int32_t* bad, int n_bad, int word_status, int word_finite,
+                  int32_t* snapshot, tp_stream_t stream);
+/* torch.optim.Adam step (reference optim_nerf, model/nerf_adapt_st_gan.py:62-68,125; no weight decay, no amsgrad) for up to
+ * TP_ADAM_MAX_TENSORS tensors in one launch; `step` = 0-dim float tensor holding the steps taken so far (a second, one-wave
+ * launch adds 1 to each afterwards); learning rate from device memory (lr_dev) or the host; gate as for tp_rmsprop_step. */
+#define TP_ADAM_MAX_TENSORS 32
+typedef struct tp_adam_tensor {
+  float* param;
+  const float* grad;
+  float* exp_avg;
+  float* exp_avg_sq;
+  float* step;
+  int64_t numel;
+} tp_adam_tensor;
+int tp_adam_step(const tp_adam_tensor* tensors /* host array */, int n, const float* lr_dev, double lr_host, double beta1, double beta2,
+                 double eps, const int32_t* gate, int n_gate, tp_stream_t stream);
 int tp_disc_inputs(const float* rgb, const float* gathered, int B, int P, int geo, float* real, float* fake, tp_stream_t stream);
 
 #ifdef __cplusplus

@@ -1318,7 +1318,7 @@ def test_fused_rmsprop_matches_torch(ops):
         sa, sb = oa.state_dict(), ob.state_dict()
         assert sorted(sa["state"]) == sorted(sb["state"]) == [0, 1, 2]
         for i in sa["state"]:
-            torch.testing.assert_close(sa["state"][i]["square_avg"], sb["state"][i]["square_avg"], rtol=5e-6, atol=0)    # (torch fuses mul + addcmul differently)
+            torch.testing.assert_close(sa["state"][i]["square_avg"], sb["state"][i]["square_avg"], rtol=1e-6, atol=0)
             assert float(sa["state"][i]["step"]) == float(sb["state"][i]["step"]) == 3.0
         ob.load_state_dict(sa)
         oa.load_state_dict(sb)
@@ -1518,3 +1518,48 @@ def test_feat_and_disc_input_kernels_match_torch(ops):
         if geo:
             real_t, fake_t = torch.cat([real_t, g[:, 6:9], g[:, 9:12]], 1), torch.cat([fake_t, g[:, 6:9], g[:, 9:12]], 1)
         assert torch.equal(real, real_t) and torch.equal(fake, fake_t.contiguous())
+
+
+def test_fused_adam_matches_torch_and_honours_the_gate(ops):
+    """trainer.FusedAdam (K13 tp_adam_step) against torch.optim.Adam (capturable, tensor learning rate) over five steps, the
+    state dict both ways, and the step gate: a non-zero gate word leaves parameters, moments and step counters untouched."""
+    from texpose_amd.trainer import FusedAdam
+    torch.manual_seed(4)
+    shapes = [(256, 334), (256,), (3, 128), (189, 48), (189, 16)]
+    lr = torch.tensor(5e-4, device=dev())
+    pa = [torch.nn.Parameter(torch.randn(s, device=dev())) for s in shapes]
+    pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    oa = FusedAdam([dict(params=pa[:3], lr=lr), dict(params=pa[3:4], lr=lr), dict(params=pa[4:], lr=lr)], capturable=True)
+    ob = torch.optim.Adam([dict(params=pb[:3], lr=lr.clone()), dict(params=pb[3:4], lr=lr.clone()), dict(params=pb[4:], lr=lr.clone())],
+                          capturable=True)
+    for it in range(5):
+        for a, b in zip(pa, pb):
+            g = torch.randn_like(a) * 10 ** (it - 3)
+            a.grad, b.grad = g.clone(), g.clone()
+        oa.step()
+        ob.step()
+    for a, b in zip(pa, pb):
+        torch.testing.assert_close(a, b, rtol=2e-6, atol=1e-7)
+    sa, sb = oa.state_dict(), ob.state_dict()
+    for i in sa["state"]:
+        for key in ("exp_avg", "exp_avg_sq"):              # (sums of differently rounded terms: absolute error ~ 1 ulp of the largest)
+            ref = sb["state"][i][key]
+            torch.testing.assert_close(sa["state"][i][key], ref, rtol=1e-5, atol=3e-7 * float(ref.abs().max()))
+        assert float(sa["state"][i]["step"]) == float(sb["state"][i]["step"]) == 5.0
+    ob.load_state_dict(sa)
+    oa.load_state_dict(sb)
+    # gate
+    gate = torch.zeros(3, dtype=torch.int32, device=dev())
+    oa.gate = gate
+    before = [p.detach().clone() for p in pa]
+    state_before = {i: {k: v.clone() for k, v in st.items()} for i, st in oa.state_dict()["state"].items()}
+    gate[2] = 1
+    oa.step()
+    for p, q in zip(pa, before):
+        assert torch.equal(p, q)
+    for i, st in oa.state_dict()["state"].items():
+        for k, v in st.items():
+            assert torch.equal(v, state_before[i][k]), (i, k)
+    gate.zero_()
+    oa.step()
+    assert not torch.equal(pa[0], before[0]) and float(oa.state_dict()["state"][0]["step"]) == 6.0

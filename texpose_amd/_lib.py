@@ -30,7 +30,7 @@ SYMBOLS = (
     "tp_rmsprop_step",
     "tp_conv4s2_workspace", "tp_conv4s2_fwd", "tp_conv4s2_dgrad", "tp_conv4s2_wgrad",
     "tp_conv3s1_workspace", "tp_conv3s1_fwd", "tp_conv3s1_dgrad",
-    "tp_patch_coords", "tp_bce_logits_fwd", "tp_bce_logits_bwd", "tp_feat_inputs_fwd", "tp_feat_inputs_bwd", "tp_disc_inputs",
+    "tp_patch_coords", "tp_bce_logits_fwd", "tp_bce_logits_bwd", "tp_feat_inputs_fwd", "tp_feat_inputs_bwd", "tp_disc_inputs", "tp_step_flags", "tp_adam_step",
 )
 
 vp = C.c_void_p
@@ -102,6 +102,13 @@ class RmspropTensor(C.Structure):
 
 
 RMSPROP_MAX_TENSORS = 16
+
+
+class AdamTensor(C.Structure):
+    _fields_ = [("param", vp), ("grad", vp), ("exp_avg", vp), ("exp_avg_sq", vp), ("step", vp), ("numel", C.c_int64)]
+
+
+ADAM_MAX_TENSORS = 32
 CONV_FWD, CONV_DGRAD, CONV_WGRAD = 0, 1, 2
 
 
@@ -191,7 +198,9 @@ def load() -> C.CDLL:
     sig("tp_inorm_lrelu_fwd", [vp, C.c_int64, C.c_int, C.c_float, C.c_float, vp, vp, vp, vp])
     sig("tp_inorm_lrelu_bwd", [vp, vp, vp, C.c_int64, C.c_int, C.c_float, vp, vp])
     sig("tp_inorm_lrelu_bwd_bwd", [vp, vp, vp, vp, C.c_int64, C.c_int, C.c_float, vp, vp, vp])
-    sig("tp_rmsprop_step", [C.POINTER(RmspropTensor), C.c_int, vp, C.c_float, C.c_float, C.c_float, vp])
+    sig("tp_rmsprop_step", [C.POINTER(RmspropTensor), C.c_int, vp, C.c_double, C.c_double, C.c_double, vp, C.c_int, vp])
+    sig("tp_step_flags", [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp])
+    sig("tp_adam_step", [C.POINTER(AdamTensor), C.c_int, vp, C.c_double, C.c_double, C.c_double, C.c_double, vp, C.c_int, vp])
     sig("tp_conv4s2_workspace", [C.POINTER(Conv4s2Args), C.c_int, C.POINTER(C.c_int64)], C.c_int64)
     for name in ("tp_conv4s2_fwd", "tp_conv4s2_dgrad", "tp_conv4s2_wgrad"):
         sig(name, [C.POINTER(Conv4s2Args), vp])

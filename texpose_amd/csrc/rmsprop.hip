@@ -15,8 +15,10 @@ struct Table {
   int n;
 };
 
-__global__ __launch_bounds__(256) void rmsprop_kernel(Table t, const float* lr_dev, float lr_host, float alpha, float eps,
-                                                      int64_t total) {
+__global__ __launch_bounds__(256) void rmsprop_kernel(Table t, const float* lr_dev, float lr_host, float alpha, float one_minus_alpha,
+                                                      float eps, int64_t total, const int* gate, int n_gate) {
+  for (int k = 0; k < n_gate; ++k)
+    if (gate[k] != 0) return;                       // a flagged step: parameters and statistics stay bit-for-bit as they are
   const float lr = lr_dev != nullptr ? *lr_dev : lr_host;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
     int k = 0;
@@ -24,7 +26,7 @@ __global__ __launch_bounds__(256) void rmsprop_kernel(Table t, const float* lr_d
     const int64_t i = e - (k == 0 ? 0 : t.end[k - 1]);
     const float g = t.g[k][i];
     float sq = t.sq[k][i];
-    sq = __fadd_rn(__fmul_rn(sq, alpha), __fmul_rn(__fmul_rn(g, g), 1.0f - alpha));     // mul_(alpha).addcmul_(g, g, 1 - alpha)
+    sq = __fadd_rn(__fmul_rn(sq, alpha), __fmul_rn(__fmul_rn(one_minus_alpha, g), g));     // mul_(alpha).addcmul_(g, g, 1 - alpha)
     t.sq[k][i] = sq;
     const float avg = __fadd_rn(sqrtf(sq), eps);
     t.p[k][i] = __fadd_rn(t.p[k][i], __fmul_rn(-lr, __fdiv_rn(g, avg)));                // addcdiv_(g, avg, value = -lr)
@@ -32,8 +34,9 @@ __global__ __launch_bounds__(256) void rmsprop_kernel(Table t, const float* lr_d
 }
 }  // namespace
 
-extern "C" int tp_rmsprop_step(const tp_rmsprop_tensor* tensors, int n, const float* lr_dev, float lr_host, float alpha, float eps,
-                               tp_stream_t stream) {
+extern "C" int tp_rmsprop_step(const tp_rmsprop_tensor* tensors, int n, const float* lr_dev, double lr_host, double alpha, double eps,
+                               const int32_t* gate, int n_gate, tp_stream_t stream) {
+  TP_REQUIRE(n_gate == 0 || gate != nullptr, "gate words missing");
   TP_REQUIRE(tensors != nullptr && n > 0 && n <= TP_RMSPROP_MAX_TENSORS, "bad tensor table");
   Table t;
   int64_t total = 0;
@@ -47,6 +50,7 @@ extern "C" int tp_rmsprop_step(const tp_rmsprop_tensor* tensors, int n, const fl
   t.n = n;
   int64_t blocks = (total + 255) / 256;
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(rmsprop_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, t, lr_dev, lr_host, alpha, eps, total);
+  hipLaunchKernelGGL(rmsprop_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, t, lr_dev, (float)lr_host, (float)alpha,
+                     (float)(1.0 - alpha), (float)eps, total, gate, n_gate);
   return tp::check_launch("tp_rmsprop_step");
 }

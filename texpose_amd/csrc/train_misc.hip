@@ -7,6 +7,8 @@
 //                        compute_gan_loss 'standard'): 8 launches forward, 4 backward, three times per iteration
 //   tp_feat_inputs_*     the two (fake, real) pairs of the feature loss, masked, concatenated and ImageNet-normalised
 //                        (model/nerf_adapt_st_gan.py:758-766 + layers/perceptual_loss.py:19-20,31-37): 14 + 4 launches
+//   tp_step_flags        range flag + loss finiteness -> sticky gate words (reference model/base.py:153-154 asserts per term)
+//   tp_adam_step         optim_nerf.step() (model/nerf_adapt_st_gan.py:62-68,125: torch.optim.Adam) for every tensor at once, gated
 //   tp_disc_inputs       the real / fake patch stacks of the discriminator step (model/nerf_adapt_st_gan.py:478-497): 10 launches
 #include "tp_common.h"
 
@@ -119,9 +121,94 @@ __global__ __launch_bounds__(kBlock) void disc_inputs_kernel(const float* __rest
       fake[((size_t)b * nc + 3 + c) * P + p] = v;
     }
 }
+
+// ---- step gate: fold this step's range flag / loss finiteness into the sticky words, then snapshot them for the optimiser
+__global__ void step_flags_kernel(const int* status, const float* total, int* bad, int n_bad, int word_status, int word_finite, int* snapshot) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (status != nullptr && (status[0] & 1)) bad[word_status] |= 1;
+  const float v = total[0];
+  if (!(v - v == 0.f)) bad[word_finite] |= 1;                  // NaN or +-Inf
+  for (int k = 0; k < n_bad; ++k) snapshot[k] = bad[k];
+}
+
+// ---- Adam (torch.optim.Adam: no weight decay, no amsgrad), every tensor of the step in one launch.  Scalars in double like
+// the reference's single-tensor implementation (bias_correction = 1 - beta^step, step_size = lr / bias_correction1); the
+// weights 1 - beta are formed in double and THEN rounded (1.0f - 0.999f is off by 1.3e-5 relative).
+struct AdamTable {
+  float* p[TP_ADAM_MAX_TENSORS];
+  const float* g[TP_ADAM_MAX_TENSORS];
+  float* m[TP_ADAM_MAX_TENSORS];
+  float* v[TP_ADAM_MAX_TENSORS];
+  float* step[TP_ADAM_MAX_TENSORS];          // steps taken BEFORE this one (adam_bump_kernel adds 1 afterwards)
+  int64_t end[TP_ADAM_MAX_TENSORS];
+  int n;
+};
+__global__ __launch_bounds__(kBlock) void adam_kernel(AdamTable t, const float* lr_dev, double lr_host, double beta1, double beta2, float eps,
+                                                      float w1, float w2, int64_t total, const int* gate, int n_gate) {
+  for (int k = 0; k < n_gate; ++k)
+    if (gate[k] != 0) return;
+  const double lr = lr_dev != nullptr ? (double)*lr_dev : lr_host;
+  const float b2 = (float)beta2;
+  int k = 0;
+  for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < total; e += (int64_t)gridDim.x * kBlock) {
+    while (e >= t.end[k]) ++k;
+    const int64_t i = e - (k == 0 ? 0 : t.end[k - 1]);
+    const double step = (double)t.step[k][0] + 1.0;
+    const double bc1 = 1.0 - pow(beta1, step), bc2 = 1.0 - pow(beta2, step);
+    const float step_size = (float)(lr / bc1), bc2_sqrt = (float)sqrt(bc2);
+    const float g = t.g[k][i];
+    float m = t.m[k][i], v = t.v[k][i];
+    m = tp::add_rn(m, tp::mul_rn(tp::sub_rn(g, m), w1));                      // exp_avg.lerp_(grad, 1 - beta1): w1 = (float)(1 - beta1)
+    v = tp::add_rn(tp::mul_rn(v, b2), tp::mul_rn(tp::mul_rn(w2, g), g));      // mul_(beta2).addcmul_(g, g, 1 - beta2): w2 = (float)(1 - beta2)
+    t.m[k][i] = m;
+    t.v[k][i] = v;
+    const float denom = tp::add_rn(tp::div_rn(sqrtf(v), bc2_sqrt), eps);
+    t.p[k][i] = tp::add_rn(t.p[k][i], tp::mul_rn(-step_size, tp::div_rn(m, denom)));    // addcdiv_(exp_avg, denom, value = -step_size)
+  }
+}
+__global__ void adam_bump_kernel(AdamTable t, const int* gate, int n_gate) {
+  for (int k = 0; k < n_gate; ++k)
+    if (gate[k] != 0) return;
+  // (tensors of one optimiser usually share nothing, but two entries may name the same counter: add once per distinct pointer)
+  for (int k = threadIdx.x; k < t.n; k += blockDim.x) {
+    bool first = true;
+    for (int j = 0; j < k; ++j) first = first && t.step[j] != t.step[k];
+    if (first) t.step[k][0] += 1.0f;
+  }
+}
 }  // namespace
 
 extern "C" {
+int tp_step_flags(const int32_t* mlp_status, const float* total, int32_t* bad, int n_bad, int word_status, int word_finite,
+                  int32_t* snapshot, tp_stream_t stream) {
+  TP_REQUIRE(total && bad && snapshot && n_bad > 0 && word_finite >= 0 && word_finite < n_bad && (!mlp_status || (word_status >= 0 && word_status < n_bad)),
+             "bad arguments");
+  hipLaunchKernelGGL(step_flags_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, mlp_status, total, bad, n_bad, word_status, word_finite, snapshot);
+  return tp::check_launch("tp_step_flags");
+}
+
+int tp_adam_step(const tp_adam_tensor* tensors, int n, const float* lr_dev, double lr_host, double beta1, double beta2, double eps,
+                 const int32_t* gate, int n_gate, tp_stream_t stream) {
+  TP_REQUIRE(tensors != nullptr && n > 0 && n <= TP_ADAM_MAX_TENSORS, "bad tensor table");
+  TP_REQUIRE(n_gate == 0 || gate != nullptr, "gate words missing");
+  AdamTable t;
+  int64_t total = 0;
+  for (int k = 0; k < n; ++k) {
+    TP_REQUIRE(tensors[k].param && tensors[k].grad && tensors[k].exp_avg && tensors[k].exp_avg_sq && tensors[k].step && tensors[k].numel > 0, "null tensor");
+    t.p[k] = tensors[k].param; t.g[k] = tensors[k].grad; t.m[k] = tensors[k].exp_avg; t.v[k] = tensors[k].exp_avg_sq; t.step[k] = tensors[k].step;
+    total += tensors[k].numel;
+    t.end[k] = total;
+  }
+  for (int k = n; k < TP_ADAM_MAX_TENSORS; ++k) { t.p[k] = nullptr; t.g[k] = nullptr; t.m[k] = nullptr; t.v[k] = nullptr; t.step[k] = nullptr; t.end[k] = total; }
+  t.n = n;
+  int64_t blocks = (total + kBlock - 1) / kBlock;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, t, lr_dev, lr_host, beta1, beta2, (float)eps,
+                     (float)(1.0 - beta1), (float)(1.0 - beta2), total, gate, n_gate);
+  hipLaunchKernelGGL(adam_bump_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, t, gate, n_gate);
+  return tp::check_launch("tp_adam_step");
+}
+
 int tp_disc_inputs(const float* rgb, const float* gathered, int B, int P, int geo, float* real, float* fake, tp_stream_t stream) {
   TP_REQUIRE(rgb && gathered && real && fake && B > 0 && P > 0, "bad arguments");
   const int n = B * P;

@@ -580,9 +580,10 @@ def inorm_lrelu_bwd_bwd(xhat: Tensor, rstd: Tensor, gy: Tensor, ggx: Tensor, slo
 
 # ------------------------------------------------------------------------------------------ K10
 @_on_tensor_device
-def rmsprop_step(params, grads, square_avgs, lr, alpha: float = 0.99, eps: float = 1e-8) -> None:
+def rmsprop_step(params, grads, square_avgs, lr, alpha: float = 0.99, eps: float = 1e-8, gate: Optional[Tensor] = None) -> None:
     """One launch: sq = alpha sq + (1 - alpha) g^2;  p -= lr g / (sqrt(sq) + eps) for up to 16 tensors per call.
-    ``lr``: python float, or a 0-dim CUDA tensor read on the device (captured training step)."""
+    ``lr``: python float, or a 0-dim CUDA tensor read on the device (captured training step).  ``gate``: int32 device words;
+    if any is non-zero nothing is changed."""
     lib = _lib.load()
     lr_dev = lr.data_ptr() if isinstance(lr, torch.Tensor) else None
     lr_host = 0.0 if isinstance(lr, torch.Tensor) else float(lr)
@@ -593,7 +594,8 @@ def rmsprop_step(params, grads, square_avgs, lr, alpha: float = 0.99, eps: float
             if not (p.is_contiguous() and g.is_contiguous() and sq.is_contiguous() and p.dtype == g.dtype == sq.dtype == torch.float32):
                 raise _lib.TexposeLibraryError("rmsprop_step needs contiguous float32 tensors")
             a.param, a.grad, a.square_avg, a.numel = p.data_ptr(), g.data_ptr(), sq.data_ptr(), p.numel()
-        check(lib.tp_rmsprop_step(arr, len(chunk), lr_dev, lr_host, float(alpha), float(eps), _stream()), "tp_rmsprop_step")
+        check(lib.tp_rmsprop_step(arr, len(chunk), lr_dev, lr_host, float(alpha), float(eps), _ptr(gate), gate.numel() if gate is not None else 0,
+                                  _stream()), "tp_rmsprop_step")
 
 
 @_on_tensor_device
@@ -820,3 +822,29 @@ def disc_inputs(rgb: Tensor, gathered: Tensor, hw, geo: bool):
     check(lib.tp_disc_inputs(rgb.data_ptr(), gathered.data_ptr(), B, P, int(bool(geo)), real.data_ptr(), fake.data_ptr(), _stream()),
           "tp_disc_inputs")
     return real, fake
+
+
+def step_flags(total: Tensor, bad: Tensor, word_finite: int, snapshot: Tensor, status: Optional[Tensor] = None, word_status: int = 0) -> None:
+    """bad[word_status] |= status & 1; bad[word_finite] |= !isfinite(total); snapshot = bad (K13 tp_step_flags, one launch)."""
+    lib = _lib.load()
+    check(lib.tp_step_flags(_ptr(status), total.data_ptr(), bad.data_ptr(), bad.numel(), int(word_status), int(word_finite),
+                            snapshot.data_ptr(), _stream()), "tp_step_flags")
+
+
+def adam_step(params, grads, exp_avgs, exp_avg_sqs, steps, lr, beta1: float, beta2: float, eps: float, gate: Optional[Tensor] = None) -> None:
+    """torch.optim.Adam's update of all tensors in one launch per 32 (K13 tp_adam_step); ``steps``: 0-dim float tensors with
+    the step count BEFORE this update; a gated one-wave launch inside the same call adds 1 to each afterwards."""
+    lib = _lib.load()
+    lr_dev = lr.data_ptr() if isinstance(lr, torch.Tensor) else None
+    lr_host = 0.0 if isinstance(lr, torch.Tensor) else float(lr)
+    rows = list(zip(params, grads, exp_avgs, exp_avg_sqs, steps))
+    for i0 in range(0, len(rows), _lib.ADAM_MAX_TENSORS):
+        chunk = rows[i0:i0 + _lib.ADAM_MAX_TENSORS]
+        arr = (_lib.AdamTensor * len(chunk))()
+        for a, (p, g, m, v, st) in zip(arr, chunk):
+            if not (p.is_contiguous() and g.is_contiguous() and m.is_contiguous() and v.is_contiguous()
+                    and p.dtype == g.dtype == m.dtype == v.dtype == st.dtype == torch.float32 and st.is_cuda):
+                raise _lib.TexposeLibraryError("adam_step needs contiguous float32 tensors and device step counters")
+            a.param, a.grad, a.exp_avg, a.exp_avg_sq, a.step, a.numel = p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), st.data_ptr(), p.numel()
+        check(lib.tp_adam_step(arr, len(chunk), lr_dev, lr_host, float(beta1), float(beta2), float(eps), _ptr(gate),
+                               gate.numel() if gate is not None else 0, _stream()), "tp_adam_step")

@@ -42,6 +42,7 @@ class FusedRMSprop(torch.optim.RMSprop):
     """torch.optim.RMSprop with the reference's settings (no momentum, not centred, no weight decay), its state-dict
     layout (``square_avg``, ``step``) and its arithmetic, but the whole step as ONE launch (K10, csrc/rmsprop.hip) that
     reads a tensor learning rate on the device.  CUDA float32 parameters only; anything else uses the stock step."""
+    gate = None                              # int32 device words: a non-zero word withholds the update
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -60,8 +61,46 @@ class FusedRMSprop(torch.optim.RMSprop):
                     st["square_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
             if ps:
                 ops.rmsprop_step([p.data for p in ps], [p.grad.contiguous() for p in ps], [self.state[p]["square_avg"] for p in ps],
-                                 group["lr"], group["alpha"], group["eps"])
+                                 group["lr"], group["alpha"], group["eps"], gate=self.gate)
                 torch._foreach_add_([self.state[p]["step"] for p in ps], 1)
+        return None
+
+
+class FusedAdam(torch.optim.Adam):
+    """torch.optim.Adam (no weight decay, no amsgrad) with its state-dict layout (``step``, ``exp_avg``, ``exp_avg_sq``),
+    but every tensor of the step in ONE launch (K13 tp_adam_step) that reads a tensor learning rate and the step gate on
+    the device.  Capturable CUDA float32 groups only; anything else uses the stock step."""
+    gate = None                              # int32 device words: a non-zero word withholds the whole step
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        if closure is not None:
+            raise NotImplementedError("closure")
+        todo = []
+        for group in self.param_groups:
+            ps = [p for p in group["params"] if p.grad is not None]
+            plain = (group["capturable"] and not group["amsgrad"] and group["weight_decay"] == 0 and not group["maximize"]
+                     and all(p.is_cuda and p.dtype == torch.float32 and not p.grad.is_sparse for p in ps))
+            if not plain:
+                return super().step()
+            for p in ps:
+                st = self.state[p]
+                if len(st) == 0:
+                    st["step"] = torch.zeros((), dtype=torch.float32, device=p.device)
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            todo.append((group, ps))
+        # groups with the same hyper-parameters (the reference's three groups share them) go into one launch
+        merged = {}
+        for group, ps in todo:
+            lr = group["lr"]
+            key = (lr.data_ptr() if torch.is_tensor(lr) else float(lr), tuple(group["betas"]), group["eps"])
+            merged.setdefault(key, (group, []))[1].extend(ps)
+        for group, ps in merged.values():
+            if ps:
+                ops.adam_step([p.data for p in ps], [p.grad.contiguous() for p in ps], [self.state[p]["exp_avg"] for p in ps],
+                              [self.state[p]["exp_avg_sq"] for p in ps], [self.state[p]["step"] for p in ps], group["lr"],
+                              group["betas"][0], group["betas"][1], group["eps"], gate=self.gate)
         return None
 
 
@@ -84,10 +123,14 @@ class GanTrainer:
         mk = (lambda v: torch.tensor(float(v), device=dev)) if self.capturable else float
         self.lr_nerf = mk(opt.optim.lr)
         self.lr_nerf_used = mk(opt.optim.lr)               # what the optimiser reads (captured: lr x the step gate)
-        self.optim_nerf = torch.optim.Adam([dict(params=nerf_params, lr=self.lr_nerf_used),
-                                            dict(params=graph.latent_vars_light.parameters(), lr=self.lr_nerf_used),
-                                            dict(params=graph.latent_vars_trans.parameters(), lr=self.lr_nerf_used)],
-                                           capturable=self.capturable, **self.adam_kwargs(dev))
+        # captured trainer: every tensor of the Adam step in one launch (torch's foreach implementation with a tensor learning
+        # rate is ~40 multi-tensor + 2 per-parameter launches, its fused one 4 launches / 60 us for these 25 small tensors)
+        fused_own = self.capturable and dev.type == "cuda" and not os.environ.get("TP_NO_FUSED_ADAM")
+        adam = FusedAdam if fused_own else torch.optim.Adam
+        self.optim_nerf = adam([dict(params=nerf_params, lr=self.lr_nerf_used),
+                                dict(params=graph.latent_vars_light.parameters(), lr=self.lr_nerf_used),
+                                dict(params=graph.latent_vars_trans.parameters(), lr=self.lr_nerf_used)],
+                               capturable=self.capturable)
         self.has_disc = hasattr(graph, "discriminator") and opt.gan is not None
         if self.has_disc:
             self.disc_group = [p for p in graph.discriminator.parameters()]
@@ -98,12 +141,6 @@ class GanTrainer:
         self.red_nerf = tdist.FlatGradAllReducer(self.nerf_group, group=group)
         self.red_disc = tdist.FlatGradAllReducer(self.disc_group, group=group) if self.has_disc else None
         self.skipped_steps = 0                   # optimiser steps withheld because the forward was flagged
-
-    def adam_kwargs(self, dev):
-        """Captured trainer: torch's FUSED Adam (one launch; it reads the tensor learning rate on the device).  The
-        foreach implementation handles a tensor lr with two per-parameter elementwise launches on 0-dim tensors plus
-        ~40 multi-tensor launches per step: 0.35 of the 1.5 ms of a B=4 nerf step.  Same state-dict layout."""
-        return dict(fused=True) if self.capturable and dev.type == "cuda" and not os.environ.get("TP_NO_FUSED_ADAM") else {}
 
     @staticmethod
     def _toggle(module, flag):
@@ -296,6 +333,12 @@ class GraphedGanTrainer(GanTrainer):
         # gates are 1 only while all are 0 (separate words: the two branches of the captured step never write the same one)
         self._bad = torch.zeros(3, dtype=torch.int32, device=dev)
         self._side = None                        # second stream of the captured step (discriminator branch)
+        # what the optimiser launches read: the words as they stood when the step's own flags had been folded in
+        self._gate_nerf, self._gate_disc = torch.zeros_like(self._bad), torch.zeros_like(self._bad)
+        if isinstance(self.optim_nerf, FusedAdam):
+            self.optim_nerf.gate = self._gate_nerf
+        if self.has_disc and isinstance(self.optim_disc, FusedRMSprop):
+            self.optim_disc.gate = self._gate_disc
         self._bad_poll = None
 
     # the guards run INSIDE the captured step: no host read, the update is multiplied by the 0/1 gate
@@ -310,20 +353,20 @@ class GraphedGanTrainer(GanTrainer):
 
     def _flag_nerf(self, loss):
         """Before the backward (and before the branches of the step fork): fold this forward's range flag and the finiteness
-        of its loss into the sticky words and form the nerf gate (which also sees a discriminator flag of EARLIER steps)."""
-        dev = loss.all.device
-        finite = _finite(loss.all.detach())
-        flag = (ops.mlp_status(dev)[0] & 1) != 0 if self._uses_f16x3() else torch.zeros((), dtype=torch.bool, device=dev)
-        self._bad[0:2].bitwise_or_(torch.stack([flag, ~finite]).to(torch.int32))
-        self._ok = self._bad.sum() == 0
+        of its loss into the sticky words and snapshot them as the nerf gate (which so also sees a discriminator flag of
+        EARLIER steps, never a concurrent write of this one).  One launch (K13 tp_step_flags)."""
+        status = ops.mlp_status(loss.all.device) if self._uses_f16x3() else None
+        ops.step_flags(loss.all, self._bad, 1, self._gate_nerf, status=status, word_status=0)
 
     def _guard_nerf(self, var, loss):
-        self._gate(self._ok, [p.grad for p in self.nerf_group], self.lr_nerf, self.lr_nerf_used)
+        if getattr(self.optim_nerf, "gate", None) is None:       # a stock optimiser: zero the gradients and the rate instead
+            self._gate(self._gate_nerf.sum() == 0, [p.grad for p in self.nerf_group], self.lr_nerf, self.lr_nerf_used)
         return True
 
     def _guard_disc(self, total):
-        self._bad[2:3].bitwise_or_((~_finite(total.detach())).to(torch.int32).reshape(1))
-        self._gate(self._bad.sum() == 0, [p.grad for p in self.disc_group], self.lr_disc, self.lr_disc_used)
+        ops.step_flags(total, self._bad, 2, self._gate_disc)
+        if getattr(self.optim_disc, "gate", None) is None:
+            self._gate(self._gate_disc.sum() == 0, [p.grad for p in self.disc_group], self.lr_disc, self.lr_disc_used)
         return True
 
     def _body(self, var):
