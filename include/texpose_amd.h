@@ -434,6 +434,32 @@ int tp_adam_step(const tp_adam_tensor* tensors /* host array */, int n, const fl
                  double eps, const int32_t* gate, int n_gate, tp_stream_t stream);
 int tp_disc_inputs(const float* rgb, const float* gathered, int B, int P, int geo, float* real, float* fake, tp_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * K14  Scale-conditioned head of the PatchGAN (reference layers/discriminator.py:30-40,112-115):
+ *      a = [z, sin(s 2^l pi), cos(s 2^l pi) (l < L), s];  out = W3 lrelu(W2 lrelu(W1 lrelu(a)))   (1x1 SN-convs, no bias)
+ *      one launch each for the forward, the backward (gz, gW1..3) and the R1 double backward (cotangent c_gz of gz ->
+ *      d/d g_out and d/d W1..3; model/nerf_adapt_st_gan.py:794-807).  t0 [B,Cin] / t1 / t2 [B,H] are the saved activations
+ *      (Cin = C + 2L + 1), e1 / e2 [B,H] the backward's intermediates the double backward re-uses.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct tp_disc_head_args {
+  const float* z;          /* [B,C]   fwd */
+  const float* scale;      /* [B]     fwd */
+  const float* W1;         /* [H,Cin] */
+  const float* W2;         /* [H,H] */
+  const float* W3;         /* [H] */
+  const float* g_out;      /* [B]     bwd, bwd_bwd */
+  const float* c_gz;       /* [B,C]   bwd_bwd */
+  float* t0; float* t1; float* t2;   /* fwd: written; bwd, bwd_bwd: read */
+  float* e1; float* e2;              /* bwd: written; bwd_bwd: read */
+  float* out;              /* fwd: [B];  bwd: gz [B,C];  bwd_bwd: d/d g_out [B] */
+  float* gW1; float* gW2; float* gW3;   /* bwd, bwd_bwd: [H,Cin], [H,H], [H] */
+  int32_t B, C, L, H;
+  float slope;
+} tp_disc_head_args;
+int tp_disc_head_fwd(const tp_disc_head_args* args, tp_stream_t stream);
+int tp_disc_head_bwd(const tp_disc_head_args* args, tp_stream_t stream);
+int tp_disc_head_bwd_bwd(const tp_disc_head_args* args, tp_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1563,3 +1563,39 @@ def test_fused_adam_matches_torch_and_honours_the_gate(ops):
     gate.zero_()
     oa.step()
     assert not torch.equal(pa[0], before[0]) and float(oa.state_dict()["state"][0]["step"]) == 6.0
+
+
+# ------------------------------------------------------------------------------------------ K14
+@pytest.mark.parametrize("B,C_z,H,L", [(4, 64, 64, 4), (1, 64, 64, 4), (7, 16, 16, 2), (33, 64, 64, 4), (5, 32, 48, 0)])
+def test_disc_head_matches_torch_up_to_second_order(ops, B, C_z, H, L):
+    """K14 (csrc/disc_head.hip) against the torch expression of the PatchGAN head in fp64: output, first-order gradients wrt z
+    and the three weights, and the R1-style gradient of |d out / d z|^2 wrt the weights."""
+    import math
+    from texpose_amd import autograd_ops
+    torch.manual_seed(B + C_z + L)
+    z0 = torch.randn(B, C_z, device=dev())
+    s0 = torch.rand(B, device=dev()) * 0.75 + 0.25
+    Ws = [torch.randn(H, C_z + 2 * L + 1, device=dev()) / 8, torch.randn(H, H, device=dev()) / 8, torch.randn(1, H, device=dev()) / 8]
+    res = []
+    for mine in (False, True):
+        cast = (lambda t: t.clone()) if mine else (lambda t: t.double().cpu())
+        z = cast(z0).requires_grad_()
+        W = [cast(w).requires_grad_() for w in Ws]
+        s = cast(s0)
+        if mine:
+            out = autograd_ops.disc_head(z, s, W[0], W[1], W[2], L, 0.2)
+        else:
+            freq = (2 ** torch.arange(L, dtype=torch.float32)).double() * float(torch.tensor(math.pi, dtype=torch.float32))
+            spec = s.float().double().view(-1, 1) * freq
+            a = torch.cat([z, spec.sin(), spec.cos(), s.view(-1, 1)], 1)
+            t = F.leaky_relu(a, 0.2)
+            t = F.leaky_relu(t @ W[0].t(), 0.2)
+            t = F.leaky_relu(t @ W[1].t(), 0.2)
+            out = (t @ W[2].t()).flatten()
+        gz, = torch.autograd.grad(out.sum(), z, create_graph=True)
+        reg = gz.pow(2).sum(1).mean()
+        cot = torch.linspace(-1, 1, B, dtype=out.dtype, device=out.device)
+        grads = torch.autograd.grad(reg + (out * cot).sum(), [z] + W)
+        res.append([t.detach().double().cpu() for t in (out, gz) + tuple(grads)])
+    for i, (a, b) in enumerate(zip(res[1], res[0])):
+        assert rel_l2(a, b) < 2e-5, (i, rel_l2(a, b))

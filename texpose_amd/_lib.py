@@ -31,6 +31,7 @@ SYMBOLS = (
     "tp_conv4s2_workspace", "tp_conv4s2_fwd", "tp_conv4s2_dgrad", "tp_conv4s2_wgrad",
     "tp_conv3s1_workspace", "tp_conv3s1_fwd", "tp_conv3s1_dgrad",
     "tp_patch_coords", "tp_bce_logits_fwd", "tp_bce_logits_bwd", "tp_feat_inputs_fwd", "tp_feat_inputs_bwd", "tp_disc_inputs", "tp_step_flags", "tp_adam_step",
+    "tp_disc_head_fwd", "tp_disc_head_bwd", "tp_disc_head_bwd_bwd",
 )
 
 vp = C.c_void_p
@@ -110,6 +111,11 @@ class AdamTensor(C.Structure):
 
 ADAM_MAX_TENSORS = 32
 CONV_FWD, CONV_DGRAD, CONV_WGRAD = 0, 1, 2
+
+
+class DiscHeadArgs(C.Structure):
+    _fields_ = [(k, vp) for k in ("z", "scale", "W1", "W2", "W3", "g_out", "c_gz", "t0", "t1", "t2", "e1", "e2", "out", "gW1", "gW2",
+                                  "gW3")] + [("B", C.c_int32), ("C", C.c_int32), ("L", C.c_int32), ("H", C.c_int32), ("slope", C.c_float)]
 
 
 class FeatInputsArgs(C.Structure):
@@ -213,6 +219,8 @@ def load() -> C.CDLL:
     sig("tp_feat_inputs_fwd", [C.POINTER(FeatInputsArgs), vp, vp])
     sig("tp_feat_inputs_bwd", [C.POINTER(FeatInputsArgs), vp, vp, vp])
     sig("tp_disc_inputs", [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp])
+    for name in ("tp_disc_head_fwd", "tp_disc_head_bwd", "tp_disc_head_bwd_bwd"):
+        sig(name, [C.POINTER(DiscHeadArgs), vp])
     _lib = lib
     return lib
 

@@ -260,3 +260,48 @@ class _FeatInputs(torch.autograd.Function):
 def feat_inputs(rgb, gathered, mean, std, hw):
     """rgb [B,P,3] + the gathered patches -> the normalised [4B,3,h,w] input of the feature network; gradient wrt rgb only."""
     return _FeatInputs.apply(rgb.contiguous(), gathered, tuple(mean), tuple(std), tuple(hw))
+
+
+# ---- K14: the scale-conditioned head of the PatchGAN, one launch per derivative order
+class _DiscHeadBackward(torch.autograd.Function):
+    """(gz, gW1, gW2, gW3) of the head; differentiable once more for the R1 penalty, whose cotangent reaches gz only (the
+    weight gradients are leaves of the step).  LeakyReLU masks are constants almost everywhere: nothing flows to t0..t2."""
+
+    @staticmethod
+    def forward(ctx, g_out, t0, t1, t2, W1, W2, W3, C_z, L, slope):
+        gz, gW1, gW2, gW3, e1, e2 = ops.disc_head_bwd(g_out, t0, t1, t2, W1, W2, W3, C_z, L, slope)
+        ctx.save_for_backward(g_out, t0, t1, t2, e1, e2, W1, W2, W3)
+        ctx.consts = (L, slope)
+        ctx.set_materialize_grads(False)
+        return gz, gW1, gW2, gW3
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, c_gz, c_W1, c_W2, c_W3):
+        if c_W1 is not None or c_W2 is not None or c_W3 is not None:
+            raise NotImplementedError("second-order terms through the head's weight gradients")
+        if c_gz is None:
+            return (None,) * 10
+        g_out, t0, t1, t2, e1, e2, W1, W2, W3 = ctx.saved_tensors
+        gg, gW1, gW2, gW3 = ops.disc_head_bwd_bwd(c_gz.contiguous(), g_out, t0, t1, t2, e1, e2, W1, W2, W3, *ctx.consts)
+        return gg, None, None, None, gW1, gW2, gW3, None, None, None
+
+
+class _DiscHead(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, scale, W1, W2, W3, L, slope):
+        out, t0, t1, t2 = ops.disc_head_fwd(z, scale, W1, W2, W3, L, slope)
+        ctx.save_for_backward(t0, t1, t2, W1, W2, W3)
+        ctx.consts = (z.shape[1], L, slope)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        t0, t1, t2, W1, W2, W3 = ctx.saved_tensors
+        gz, gW1, gW2, gW3 = _DiscHeadBackward.apply(g_out.contiguous(), t0, t1, t2, W1, W2, W3, *ctx.consts)
+        return gz, None, gW1, gW2, gW3, None, None
+
+
+def disc_head(z, scale, W1, W2, W3, L: int, slope: float = 0.2):
+    """out [B] = W3 lrelu(W2 lrelu(W1 lrelu([z, enc(scale), scale]))) with W1 [H,C+2L+1], W2 [H,H], W3 [1,H] (K14)."""
+    return _DiscHead.apply(z.contiguous(), scale.contiguous(), W1.contiguous(), W2.contiguous(), W3.contiguous(), int(L), float(slope))

@@ -164,10 +164,23 @@ class Discriminator(nn.Module):
             i += 1
         return x
 
+    def _plain_head(self):
+        """``final`` is LeakyReLU, 1x1, LeakyReLU, 1x1, LeakyReLU, 1x1 with one slope (what __init__ builds)."""
+        mods = list(self.final)
+        return (len(mods) == 6 and all(isinstance(m, nn.LeakyReLU) for m in mods[0::2])
+                and len({m.negative_slope for m in mods[0::2]}) == 1
+                and all(isinstance(m, SNConv2d) and tuple(m.weight_orig.shape[-2:]) == (1, 1) for m in mods[1::2]))
+
     def forward(self, opt, x, scale=None):
         convs = [m for m in list(self.main) + (list(self.final) if self.scale_conditional else []) if isinstance(m, SNConv2d)]
         weights = spectral_weights(convs, self.training)              # all power iterations / normalisations at once
         out = self._run(self.main, x, weights)                        # [B, c, 1, 1]
+        if self.scale_conditional and out.is_cuda and self._plain_head():
+            # K14: encoding, concatenation and the three 1x1 layers in one launch per derivative order
+            from . import autograd_ops
+            w1, w2, w3 = weights
+            return autograd_ops.disc_head(out.flatten(1), scale.reshape(-1), w1.flatten(1), w2.flatten(1), w3.flatten(1),
+                                          self.L_scale, self.final[0].negative_slope)
         if self.scale_conditional:
             spec = scale.view(-1, 1) * self.scale_freq                # [B, L]
             enc = torch.cat([spec.sin(), spec.cos()], dim=1)[:, :, None, None]

@@ -848,3 +848,62 @@ def adam_step(params, grads, exp_avgs, exp_avg_sqs, steps, lr, beta1: float, bet
             a.param, a.grad, a.exp_avg, a.exp_avg_sq, a.step, a.numel = p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), st.data_ptr(), p.numel()
         check(lib.tp_adam_step(arr, len(chunk), lr_dev, lr_host, float(beta1), float(beta2), float(eps), _ptr(gate),
                                gate.numel() if gate is not None else 0, _stream()), "tp_adam_step")
+
+
+# ------------------------------------------------------------------------------------------ K14
+def _head_args(W1, W2, W3, B, C_z, L, slope):
+    a = _lib.DiscHeadArgs()
+    H = W2.shape[0]
+    if W1.shape != (H, C_z + 2 * L + 1) or W2.shape != (H, H) or W3.numel() != H:
+        raise ValueError("disc_head: W1 [H,C+2L+1], W2 [H,H], W3 [1,H] expected")
+    a.W1, a.W2, a.W3 = W1.data_ptr(), W2.data_ptr(), W3.data_ptr()
+    a.B, a.C, a.L, a.H, a.slope = int(B), int(C_z), int(L), int(H), float(slope)
+    return a
+
+
+@_on_tensor_device
+def disc_head_fwd(z: Tensor, scale: Tensor, W1: Tensor, W2: Tensor, W3: Tensor, L: int, slope: float):
+    """-> (out [B], t0 [B,C+2L+1], t1 [B,H], t2 [B,H]): the scale-conditioned head of the PatchGAN in one launch."""
+    lib = _lib.load()
+    z, scale, W1, W2, W3 = (_f32(t, n) for t, n in ((z, "z"), (scale, "scale"), (W1, "W1"), (W2, "W2"), (W3, "W3")))
+    B, C_z = z.shape
+    a = _head_args(W1, W2, W3, B, C_z, L, slope)
+    dev, H = z.device, W2.shape[0]
+    out, t0, t1, t2 = (torch.empty(B, device=dev), torch.empty(B, C_z + 2 * L + 1, device=dev), torch.empty(B, H, device=dev),
+                       torch.empty(B, H, device=dev))
+    a.z, a.scale, a.out, a.t0, a.t1, a.t2 = z.data_ptr(), scale.data_ptr(), out.data_ptr(), t0.data_ptr(), t1.data_ptr(), t2.data_ptr()
+    check(lib.tp_disc_head_fwd(C.byref(a), _stream()), "tp_disc_head_fwd")
+    return out, t0, t1, t2
+
+
+@_on_tensor_device
+def disc_head_bwd(g_out: Tensor, t0: Tensor, t1: Tensor, t2: Tensor, W1: Tensor, W2: Tensor, W3: Tensor, C_z: int, L: int, slope: float):
+    """-> (gz [B,C], gW1, gW2, gW3, e1, e2)."""
+    lib = _lib.load()
+    g_out, W1, W2, W3 = _f32(g_out, "g_out"), _f32(W1, "W1"), _f32(W2, "W2"), _f32(W3, "W3")
+    B, H, dev = t1.shape[0], t1.shape[1], t1.device
+    a = _head_args(W1, W2, W3, B, C_z, L, slope)
+    gz, e1, e2 = torch.empty(B, C_z, device=dev), torch.empty(B, H, device=dev), torch.empty(B, H, device=dev)
+    gW1, gW2, gW3 = torch.empty_like(W1), torch.empty_like(W2), torch.empty_like(W3)
+    a.g_out, a.t0, a.t1, a.t2, a.e1, a.e2, a.out = (g_out.data_ptr(), t0.data_ptr(), t1.data_ptr(), t2.data_ptr(), e1.data_ptr(),
+                                                    e2.data_ptr(), gz.data_ptr())
+    a.gW1, a.gW2, a.gW3 = gW1.data_ptr(), gW2.data_ptr(), gW3.data_ptr()
+    check(lib.tp_disc_head_bwd(C.byref(a), _stream()), "tp_disc_head_bwd")
+    return gz, gW1, gW2, gW3, e1, e2
+
+
+@_on_tensor_device
+def disc_head_bwd_bwd(c_gz: Tensor, g_out: Tensor, t0: Tensor, t1: Tensor, t2: Tensor, e1: Tensor, e2: Tensor, W1: Tensor, W2: Tensor,
+                      W3: Tensor, L: int, slope: float):
+    """cotangent c_gz [B,C] of the backward's gz -> (d/d g_out [B], d/d W1, d/d W2, d/d W3)."""
+    lib = _lib.load()
+    c_gz, g_out, W1, W2, W3 = _f32(c_gz, "c_gz"), _f32(g_out, "g_out"), _f32(W1, "W1"), _f32(W2, "W2"), _f32(W3, "W3")
+    B, C_z = c_gz.shape
+    a = _head_args(W1, W2, W3, B, C_z, L, slope)
+    gg = torch.empty(B, device=c_gz.device)
+    gW1, gW2, gW3 = torch.empty_like(W1), torch.empty_like(W2), torch.empty_like(W3)
+    a.c_gz, a.g_out, a.t0, a.t1, a.t2, a.e1, a.e2, a.out = (c_gz.data_ptr(), g_out.data_ptr(), t0.data_ptr(), t1.data_ptr(),
+                                                            t2.data_ptr(), e1.data_ptr(), e2.data_ptr(), gg.data_ptr())
+    a.gW1, a.gW2, a.gW3 = gW1.data_ptr(), gW2.data_ptr(), gW3.data_ptr()
+    check(lib.tp_disc_head_bwd_bwd(C.byref(a), _stream()), "tp_disc_head_bwd_bwd")
+    return gg, gW1, gW2, gW3
