@@ -134,11 +134,12 @@ __global__ __launch_bounds__(256) void conv4s2_fwd_kernel(ConvP p) {
   int cb, ce;
   k_range(p.C, p.S, s, w, cb, ce);
   f32x16 acc[1] = {};
-  for (int c0 = cb; c0 < ce; c0 += 4) {
-    float a[4][8];
-    f32x4 b[4][2];
+  constexpr int kU = 8;                              // channels whose operands are in flight together (one load latency per batch)
+  for (int c0 = cb; c0 < ce; c0 += kU) {
+    float a[kU][8];
+    f32x4 b[kU][2];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < kU; ++u) {
       const int ci = min(c0 + u, ce - 1);
       const float* xc = xa + (size_t)ci * HW;
 #pragma unroll
@@ -147,10 +148,11 @@ __global__ __launch_bounds__(256) void conv4s2_fwd_kernel(ConvP p) {
       b[u][1] = *reinterpret_cast<const f32x4*>(wb + (size_t)ci * 16 + 4);
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const float live = c0 + u < ce ? 1.f : 0.f;
+    for (int u = 0; u < kU; ++u) {
+      if (c0 + u < ce) {                              // (wave-uniform; the loads above stay clamped and unconditional)
 #pragma unroll
-      for (int q = 0; q < 8; ++q) acc[0] = mfma(ok[q] ? a[u][q] : 0.f, b[u][q >> 2][q & 3] * live, acc[0]);
+        for (int q = 0; q < 8; ++q) acc[0] = mfma(ok[q] ? a[u][q] : 0.f, b[u][q >> 2][q & 3], acc[0]);
+      }
     }
   }
   float out[1][4];
@@ -189,12 +191,13 @@ __global__ __launch_bounds__(256) void conv4s2_dgrad_kernel(ConvP p) {
   int qb, qe;
   k_range((p.Co + 1) >> 1, p.S, s, w, qb, qe);
   f32x16 acc[4] = {};
-  for (int q0 = qb; q0 < qe; q0 += 2) {
-    float g[2][9];
-    f32x4 wv[2][4];
-    float live[2];
+  constexpr int kQ = 4;                              // channel pairs in flight together
+  for (int q0 = qb; q0 < qe; q0 += kQ) {
+    float g[kQ][9];
+    f32x4 wv[kQ][4];
+    float live[kQ];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < kQ; ++u) {
       const int co = 2 * min(q0 + u, qe - 1) + h, cc = min(co, p.Co - 1);
       live[u] = (q0 + u < qe && co < p.Co) ? 1.f : 0.f;
       const float* gc = ga + (size_t)cc * P;
@@ -205,7 +208,8 @@ __global__ __launch_bounds__(256) void conv4s2_dgrad_kernel(ConvP p) {
       for (int k = 0; k < 4; ++k) wv[u][k] = *reinterpret_cast<const f32x4*>(wc + 4 * k);
     }
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int u = 0; u < kQ; ++u) {
+      if (q0 + u >= qe) continue;                    // (wave-uniform; the loads above stay clamped and unconditional)
 #pragma unroll
       for (int py = 0; py < 2; ++py)
 #pragma unroll
@@ -220,6 +224,7 @@ __global__ __launch_bounds__(256) void conv4s2_dgrad_kernel(ConvP p) {
               const float av = ok[dy * 3 + dx] ? g[u][dy * 3 + dx] : 0.f;
               acc[py * 2 + px] = mfma(av, wv[u][ky][kx] * live[u], acc[py * 2 + px]);
             }
+    }
   }
   float out[4][4];
   if (!reduce_tiles<4>(acc, out, lds, p, tile, s)) return;

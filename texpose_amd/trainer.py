@@ -512,8 +512,14 @@ class GraphedGanTrainer(GanTrainer):
     def train_iteration(self, var: AttrDict):
         if self._graph is None:
             self.capture(var)
-        for k, dst in self._static_in.items():
-            dst.copy_(var[k], non_blocking=True)
+        # the batch into the static input tensors: one multi-tensor launch per dtype instead of one copy per tensor
+        pairs = [(dst, var[k]) for k, dst in self._static_in.items() if var[k] is not dst]
+        same = [(d, s) for d, s in pairs if torch.is_tensor(s) and s.device == d.device and s.dtype == d.dtype and s.shape == d.shape]
+        for d, s in pairs:
+            if not any(d is d2 for d2, _ in same):
+                d.copy_(s, non_blocking=True)
+        for dt in {d.dtype for d, _ in same}:
+            torch._foreach_copy_([d for d, _ in same if d.dtype == dt], [s for d, s in same if d.dtype == dt])
         for name, optim in (("lr_nerf", self.optim_nerf), ("lr_disc", getattr(self, "optim_disc", None))):
             if optim is not None and any(g["lr"] is not getattr(self, name + "_used") for g in optim.param_groups):
                 self._adopt_group_lr(name, optim)             # an Optimizer.load_state_dict since the last replay
