@@ -305,20 +305,29 @@ __device__ __forceinline__ float sigmoid(float x) { return 1.0f / (1.0f + expf(-
 // the output non-linearities and stores.  (The dgrad kernel further down still uses the C++ layer body above.)
 // =====================================================================================================================
 struct AsmCtx { unsigned lane16, laneoff, ldswave, stream_lo, stream_hi, bias0, stage0; };
-__device__ __forceinline__ AsmCtx asm_ctx(const Pipe& p, const float* bias_lds, const _Float16* st, int tid, int hh) {
+// The context is RE-DERIVED from the hardware thread id at every block instead of being carried in registers: the compiler
+// owns ~40 VGPRs while the trunk feature is stashed, and seven context values kept live across the whole tile loop went to
+// scratch memory (whose lines, re-read every tile, then competed with the 3.6 MiB weight stream for the 4 MiB L2).  The
+// empty volatile asm makes each derivation opaque, so nothing of it is hoisted or shared between blocks.
+__device__ __forceinline__ AsmCtx asm_ctx_now(const float* packed) {
+  extern __shared__ __attribute__((aligned(16))) float lds_base[];
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
+  const unsigned lane = (unsigned)tid & 63u, hh = ((unsigned)tid >> 5) & 1u;
+  const unsigned wave = (unsigned)__builtin_amdgcn_readfirstlane(tid >> 6);
   AsmCtx c;
-  const unsigned lds0 = (unsigned)(uintptr_t)AS3(p.lds);
-  c.lane16 = lds0 + (unsigned)p.lane * 16u;
-  c.laneoff = (unsigned)p.lane * 16u;
-  c.ldswave = lds0 + (unsigned)p.wave * 8192u;
-  const uint64_t sw = (uint64_t)(uintptr_t)(p.stream + p.wave * 2048);
+  const unsigned lds0 = (unsigned)(uintptr_t)AS3(lds_base);
+  c.lane16 = lds0 + lane * 16u;
+  c.laneoff = lane * 16u;
+  c.ldswave = lds0 + wave * 8192u;
+  const uint64_t sw = (uint64_t)(uintptr_t)(packed + wave * 2048);
   c.stream_lo = (unsigned)sw;
   c.stream_hi = (unsigned)(sw >> 32);
-  c.bias0 = (unsigned)(uintptr_t)AS3(bias_lds) + (unsigned)hh * 512u;     // + li * 1024: bias block of wide layer li
-  c.stage0 = (unsigned)(uintptr_t)AS3(st) + (unsigned)tid * 16u;          // + ks * 8192: staged k-step ks (hi; lo at + 4096)
+  const unsigned bias_lds = lds0 + (unsigned)(kBufs * kChunkFloats) * 4u;
+  c.bias0 = bias_lds + hh * 512u;                                          // + li * 1024: bias block of wide layer li
+  c.stage0 = bias_lds + (unsigned)kBiasPad * 4u + (unsigned)tid * 16u;     // + ks * 8192: staged k-step ks (hi; lo at + 4096)
   return c;
 }
-
 #define TP_RING(f)                                                                                                     \
   "+{v[160:163]}"(f.h[0]), "+{v[164:167]}"(f.l[0]), "+{v[168:171]}"(f.h[1]), "+{v[172:175]}"(f.l[1]),                  \
       "+{v[176:179]}"(f.h[2]), "+{v[180:183]}"(f.l[2]), "+{v[184:187]}"(f.h[3]), "+{v[188:191]}"(f.l[3])
@@ -459,14 +468,22 @@ __device__ __forceinline__ float pick3(int c, float a0, float a1, float a2) {
   return __uint_as_float((__float_as_uint(a0) & m0) | (__float_as_uint(a1) & m1) | (__float_as_uint(a2) & m2));
 }
 
+// Thread coordinates are RE-DERIVED from the hardware id at the top of every section of the tile loop (the empty volatile asm
+// keeps the derivations apart): carried through the asm blocks they lived in scratch memory, like the block context above.
+#define TP_THREAD_IDS                                                                                                  \
+  int tid = threadIdx.x;                                                                                               \
+  asm volatile("" : "+v"(tid));                                                                                        \
+  const int lane = tid & 63, j = tid & 31, hh = (tid >> 5) & 1;                                                        \
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);                                                           \
+  float* save = reinterpret_cast<float*>(st + kStageHalves) + tid;                                                     \
+  (void)lane; (void)j; (void)hh; (void)wave; (void)save
+
 template <bool SAVE>
 __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_f16x3_kernel(Params P) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int j = lane & 31, hh = lane >> 5;
   float* bias_lds = lds + kBufs * kChunkFloats;
-  _Float16* st = reinterpret_cast<_Float16*>(bias_lds + kBiasPad);
-  float* save = reinterpret_cast<float*>(st + kStageHalves) + tid;      // lane-private: save[k * kThreads], k < 8
+  _Float16* st = reinterpret_cast<_Float16*>(bias_lds + kBiasPad);     // then the lane-private save area: save[k * kThreads], k < 8
 
   Pipe p;
   p.stream = P.packed; p.lds = lds; p.chunk = 0; p.buf = 0; p.wave = __builtin_amdgcn_readfirstlane(wave); p.lane = lane;
@@ -484,11 +501,11 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_f16x3_kernel(Params P) {
 #ifdef TP_TRACE
   const long long tr_start = tick();
 #endif
-  const AsmCtx cx = asm_ctx(p, bias_lds, st, tid, hh);
-  asm_init<true>(cx, L0);        // set P starts as L0's bias; from then on every wide layer re-seeds its source set
+  asm_init<true>(asm_ctx_now(P.packed), L0);        // set P starts as L0's bias; from then on every wide layer re-seeds its source set
 
   for (int64_t tile = blockIdx.x; tile < P.n_tiles; tile += gridDim.x) {
     TR_BEGIN(pro);
+    TP_THREAD_IDS;
     const int64_t s_raw = tile * 128 + wave * 32 + j;
     const bool live = s_raw < P.n_samples;
     const int64_t s = live ? s_raw : P.n_samples - 1;
@@ -518,14 +535,14 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_f16x3_kernel(Params P) {
       save[3 * kThreads] = vu0; save[4 * kThreads] = vu1; save[5 * kThreads] = vu2;
       save[6 * kThreads] = __int_as_float(b);
     }
-    asm_init<false>(cx, L1);       // set Q for L1 (set P was re-seeded for L0 by the previous tile's last layer)
+    asm_init<false>(asm_ctx_now(P.packed), L1);       // set Q for L1 (set P was re-seeded for L0 by the previous tile's last layer)
     TR_END(4, pro);
     // The two accumulator sets: even layers read Q and accumulate into P, odd layers the reverse (the layer loop is
     // unrolled by two, so both roles are fixed registers).  A set holds raw accumulators, bias included (seeded with
     // bias * 2^8); the next layer's B operands are produced from it inside the asm blocks.
     f32x16 SF[8];               // the trunk feature (L7's accumulators), held in v[32:159] from L7 to R0
     Guard amax;
-    float sig_s = 0.f, sig_t = 0.f, unc = 0.f, rgb_t[3] = {0.f, 0.f, 0.f}, rgb_s[3] = {0.f, 0.f, 0.f};
+    float sig_s, sig_t, unc, rgb_t[3], rgb_s[3];          // (no initial values: they would be live through every block)
     const float* hbias = bias_lds + kHeadBiasOff;          // [b7[0], T3 bias 0..4, R3 bias 0..2]
 
     // a narrow output layer; which == 0: sigma (reads L6 = set P), 1: transient head (reads T2 = set P), 2: static
@@ -533,7 +550,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_f16x3_kernel(Params P) {
     // its non-linearities run after the feature has been restored into set P (`after`)
     const auto head = [&](int which, auto after) {
       TR_BEGIN(h);
-      const f32x16 a = which == 2 ? asm_head<false>(p, frag, amax, cx) : asm_head<true>(p, frag, amax, cx);
+      const f32x16 a = which == 2 ? asm_head<false>(p, frag, amax, asm_ctx_now(P.packed)) : asm_head<true>(p, frag, amax, asm_ctx_now(P.packed));
       TR_END(7, h);
       const float a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3];
       after();
@@ -563,7 +580,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_f16x3_kernel(Params P) {
 
       if (li != L0) {
         TR_BEGIN(w);
-        asm_wide<EVEN>(p, frag, amax, cx, li + 1 == kNumWide ? 0 : li + 1);
+        asm_wide<EVEN>(p, frag, amax, asm_ctx_now(P.packed), li + 1 == kNumWide ? 0 : li + 1);
         TR_END(3, w);
       }
 
@@ -574,6 +591,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_f16x3_kernel(Params P) {
         // 30 (coordinate, octave) pairs, 15 per lane of the sample's lane pair: one range reduction yields the sin AND
         // the cos entry (slots 20 c + l and 20 c + 10 + l, whichever lane's operand registers they belong to)
         if (li == L0) {
+          TP_THREAD_IDS;
           const float x0 = save[0 * kThreads], x1 = save[1 * kThreads], x2 = save[2 * kThreads];
           // five independent range reductions / polynomials in flight: with one wave per SIMD a rolled loop is a single
           // dependent chain of ~30 instructions per iteration and runs at its latency
@@ -592,21 +610,23 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_f16x3_kernel(Params P) {
         }
         TR_END(5, pe);
         TR_BEGIN(w);
-        asm_extra<2, true>(p, frag, cx, 0);
-        asm_extra<2, true>(p, frag, cx, 2);
+        asm_extra<2, true>(p, frag, asm_ctx_now(P.packed), 0);
+        asm_extra<2, true>(p, frag, asm_ctx_now(P.packed), 2);
         TR_END(3, w);
       } else if (EVEN && li == T0) {
         TR_BEGIN(t0s);
+        TP_THREAD_IDS;
         const int bt = __float_as_int(save[6 * kThreads]);
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) stage(st, tid, 0, jj, P.lat_trans[bt * 16 + 8 * hh + jj]);
         TR_END(13, t0s);
         TR_BEGIN(w);
-        asm_extra<1, true>(p, frag, cx, 0);
+        asm_extra<1, true>(p, frag, asm_ctx_now(P.packed), 0);
         TR_END(3, w);
       } else if (!EVEN && li == R0) {
         // [ray_unit | PE(ray_unit) | x | light] in natural column order, 78 of 80 slots
         TR_BEGIN(r0s);
+        TP_THREAD_IDS;
         // slots 0..31: ray_unit (0..2), PE(ray_unit) (3 + 8 c + 4 sc + l: 12 sin/cos pairs, 6 per lane), x (27..29),
         // the first two latent entries (30, 31).  Training: slots 0..29 (mlp_rgb.0 input columns 256..285) also go
         // to the activation record as fp32 for the weight gradient
@@ -653,9 +673,9 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_f16x3_kernel(Params P) {
         }
         TR_END(6, r0s);
         TR_BEGIN(w);
-        asm_extra<2, false>(p, frag, cx, 0);
-        asm_extra<2, false>(p, frag, cx, 2);
-        asm_extra<1, false>(p, frag, cx, 4);
+        asm_extra<2, false>(p, frag, asm_ctx_now(P.packed), 0);
+        asm_extra<2, false>(p, frag, asm_ctx_now(P.packed), 2);
+        asm_extra<1, false>(p, frag, asm_ctx_now(P.packed), 4);
         TR_END(3, w);
       }
 
@@ -663,6 +683,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_f16x3_kernel(Params P) {
         // activations for the backward (layout: mlp_layout.h "Training record"): post-ReLU values as fp32 + ReLU
         // sign bits for the dgrad kernel.  Every lane takes part (16-byte stores after a quad transpose, mlp_mma.h);
         // samples past the end of the launch record zeros (the weight-gradient GEMM contracts whole groups)
+        TP_THREAD_IDS;
         float* grp = P.saved + (tile * 4 + wave) * (int64_t)kSavedGroupFloats;
         float* blk = grp + (li - L7) * kBlockFloats;
         int o4[4];
@@ -713,6 +734,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_f16x3_kernel(Params P) {
     {
       // output section: sample index recomputed here (and hidden from the optimiser: addresses formed at the top of the
       // tile would have to live through every block, i.e. in scratch memory)
+      TP_THREAD_IDS;
       int64_t so = tile * 128 + wave * 32 + j;
       asm volatile("" : "+v"(so));
       if (so < P.n_samples) {
