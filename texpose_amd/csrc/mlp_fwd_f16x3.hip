@@ -508,7 +508,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_f16x3_kernel(Params P) {
     TP_THREAD_IDS;
     const int64_t s_raw = tile * 128 + wave * 32 + j;
     const bool live = s_raw < P.n_samples;
-    const int64_t s = live ? s_raw : P.n_samples - 1;
+    const int64_t s = live ? s_raw : 0;            // (dead lanes recompute sample 0: any valid index; a literal needs no register)
     const int64_t q = s / P.N;
     const int b = (int)(q / P.R);
     // Everything the later staging steps need of this sample goes to a lane-private LDS area, not through registers:
@@ -542,7 +542,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_f16x3_kernel(Params P) {
     // bias * 2^8); the next layer's B operands are produced from it inside the asm blocks.
     f32x16 SF[8];               // the trunk feature (L7's accumulators), held in v[32:159] from L7 to R0
     Guard amax;
-    float sig_s, sig_t, unc, rgb_t[3], rgb_s[3];          // (no initial values: they would be live through every block)
+    float sig_s, rgb_s[3], ta0, ta1, ta2, ta3;          // (no initial values: they would be live through every block)
     const float* hbias = bias_lds + kHeadBiasOff;          // [b7[0], T3 bias 0..4, R3 bias 0..2]
 
     // a narrow output layer; which == 0: sigma (reads L6 = set P), 1: transient head (reads T2 = set P), 2: static
@@ -557,10 +557,10 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_f16x3_kernel(Params P) {
       if (which == 0) {
         sig_s = softplus(fmaf(a0, kInvScale, hbias[0]));
       } else if (which == 1) {
-        rgb_t[0] = sigmoid(fmaf(a0, kInvScale, hbias[1])); rgb_t[1] = sigmoid(fmaf(a1, kInvScale, hbias[2]));
-        rgb_t[2] = sigmoid(fmaf(a2, kInvScale, hbias[3]));
-        sig_t = softplus(fmaf(a3, kInvScale, hbias[4]));
-        unc = softplus(fmaf(a0, kInvScale, hbias[5]));       // row 4 = register 0 of the upper lane half
+        // raw accumulators only: the non-linearities run at the end of the R0 staging section (no asm block in between),
+        // whose results go to the lane-private LDS area -- held in registers until the output section they crossed R0..R2
+        // in scratch memory, and stored early as 4-byte pieces they doubled the write traffic
+        ta0 = a0; ta1 = a1; ta2 = a2; ta3 = a3;
       } else {
         rgb_s[0] = sigmoid(fmaf(a0, kInvScale, hbias[6])); rgb_s[1] = sigmoid(fmaf(a1, kInvScale, hbias[7]));
         rgb_s[2] = sigmoid(fmaf(a2, kInvScale, hbias[8]));
@@ -671,6 +671,16 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_f16x3_kernel(Params P) {
           *reinterpret_cast<half8*>(st + ((ks * 2 + 0) * kThreads + tid) * 8) = hi8;
           *reinterpret_cast<half8*>(st + ((ks * 2 + 1) * kThreads + tid) * 8) = lo8;
         }
+        // the transient head's non-linearities (its raw accumulators came through the staging code above in registers);
+        // x / view direction / image index have been consumed: their LDS slots carry the results to the output section
+        if (hh == 0) {
+          save[0 * kThreads] = sigmoid(fmaf(ta0, kInvScale, hbias[1]));
+          save[1 * kThreads] = sigmoid(fmaf(ta1, kInvScale, hbias[2]));
+          save[2 * kThreads] = sigmoid(fmaf(ta2, kInvScale, hbias[3]));
+          save[3 * kThreads] = softplus(fmaf(ta3, kInvScale, hbias[4]));
+        } else {
+          save[0 * kThreads] = softplus(fmaf(ta0, kInvScale, hbias[5]));       // row 4 = register 0 of the upper lane half
+        }
         TR_END(6, r0s);
         TR_BEGIN(w);
         asm_extra<2, false>(p, frag, asm_ctx_now(P.packed), 0);
@@ -739,17 +749,17 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_f16x3_kernel(Params P) {
       asm volatile("" : "+v"(so));
       if (so < P.n_samples) {
         if (hh == 0) {
-          // streaming stores: the outputs are never read by this kernel and must not evict the weight stream from L2
+          // streaming stores (the outputs are never read by this kernel); the transient head's values come back from LDS
           float* o = P.rgb + so * 6;
 #pragma unroll
           for (int c = 0; c < 3; ++c) {
             __builtin_nontemporal_store(rgb_s[c], o + 2 * c);
-            __builtin_nontemporal_store(rgb_t[c], o + 2 * c + 1);
+            __builtin_nontemporal_store(save[c * kThreads], o + 2 * c + 1);
           }
           __builtin_nontemporal_store(sig_s, P.density + so * 2);
-          __builtin_nontemporal_store(sig_t, P.density + so * 2 + 1);
+          __builtin_nontemporal_store(save[3 * kThreads], P.density + so * 2 + 1);
         } else {
-          __builtin_nontemporal_store(unc, P.uncert + so);
+          __builtin_nontemporal_store(save[0 * kThreads], P.uncert + so);
         }
       }
     }
@@ -842,7 +852,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_dgrad_f16x3_kernel(DgP P) {
   for (int64_t tile = blockIdx.x; tile < P.n_tiles; tile += gridDim.x) {
     const int64_t s_raw = tile * 128 + wave * 32 + j;
     const bool live = s_raw < P.n_samples;
-    const int64_t s = live ? s_raw : P.n_samples - 1;
+    const int64_t s = live ? s_raw : 0;            // (dead lanes recompute sample 0: any valid index; a literal needs no register)
     const int64_t gidx = tile * 4 + wave;
     const float* sv = P.saved + gidx * (int64_t)kSavedGroupFloats;
     float* dzg = P.dz + gidx * (int64_t)kDzGroupFloats;

@@ -68,25 +68,30 @@ class FlatGradAllReducer:
     def nbytes(self) -> int:
         return self.flat.numel() * 4
 
+    @property
+    def world_size(self) -> int:
+        return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
+
     def reduce(self, average: bool = True) -> None:
         if not (dist.is_available() and dist.is_initialized()):
             return
         if dist.get_world_size(self.group) == 1 and not self.single_rank_collective:
             return
         world = dist.get_world_size(self.group)
+        have = [(p, v) for p, v in zip(self.params, self.views) if p.grad is not None]
         for p, v in zip(self.params, self.views):
             if p.grad is None:
                 v.zero_()
-            else:
-                v.copy_(p.grad)
+        if have:                                           # one multi-tensor launch each way instead of one copy per tensor
+            torch._foreach_copy_([v for _, v in have], [p.grad for p, _ in have])
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
         if average:
             self.flat.mul_(1.0 / world)
+        if have:
+            torch._foreach_copy_([p.grad for p, _ in have], [v for _, v in have])
         for p, v in zip(self.params, self.views):
             if p.grad is None:
                 p.grad = v.clone()
-            else:
-                p.grad.copy_(v)
 
 
 def broadcast_module_state(module: torch.nn.Module, src: int = 0, group=None) -> None:

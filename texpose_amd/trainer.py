@@ -237,7 +237,7 @@ class GanTrainer:
         self.nerf_apply()
         return v, loss
 
-    def disc_step(self, var):
+    def disc_step(self, var, apply=True):
         opt, g = self.opt, self.graph
         self._toggle(g.discriminator, True)
         self.optim_disc.zero_grad(set_to_none=True)
@@ -254,10 +254,16 @@ class GanTrainer:
         if "gan_reg_real" in terms:
             # the reference logs the WEIGHTED penalty: it scales the tensor it has just stored, in place (:151-153)
             loss.gan_reg_real = self._weight(opt.loss_weight.gan_reg_real, total.device) * terms.gan_reg_real.detach()
+        if apply:
+            self.disc_apply(total)
+        else:
+            self._disc_total = total
+        return var, loss
+
+    def disc_apply(self, total):
         self._guard_disc(total)
         self.red_disc.reduce()
         self.optim_disc.step()
-        return var, loss
 
     def set_lr(self, nerf: float = None, disc: float = None):
         """Learning rates for the following iterations (eager: param groups; captured: the device scalars the graph reads)."""
@@ -391,13 +397,18 @@ class GraphedGanTrainer(GanTrainer):
             if self._side is None:
                 self._side = torch.cuda.Stream(device=var.rgb.device)
             self._side.wait_stream(main)                          # fork
+            # data parallel: both all-reduces are issued from the capturing stream after the join, in one fixed order on every
+            # rank (two collectives of one communicator in unordered branches of a graph could meet in different orders)
+            serial_tail = self.red_disc is not None and self.red_disc.world_size > 1
             with torch.cuda.stream(self._side):
-                var, dloss = self.disc_step(var)
+                var, dloss = self.disc_step(var, apply=not serial_tail)
         torch.autograd.backward(terms, ws)
         self._guard_nerf(var, loss)
         self.nerf_apply()
         if overlap:
             main.wait_stream(self._side)                          # join
+            if serial_tail:
+                self.disc_apply(self._disc_total)
         elif self.has_disc:
             var, dloss = self.disc_step(var)
         if dloss is not None:
