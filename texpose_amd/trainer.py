@@ -399,7 +399,7 @@ class GraphedGanTrainer(GanTrainer):
             self._side.wait_stream(main)                          # fork
             # data parallel: both all-reduces are issued from the capturing stream after the join, in one fixed order on every
             # rank (two collectives of one communicator in unordered branches of a graph could meet in different orders)
-            serial_tail = self.red_disc is not None and self.red_disc.world_size > 1
+            serial_tail = self.red_disc is not None and (self.red_disc.world_size > 1 or self.red_disc.single_rank_collective)
             with torch.cuda.stream(self._side):
                 var, dloss = self.disc_step(var, apply=not serial_tail)
         torch.autograd.backward(terms, ws)
