@@ -460,6 +460,14 @@ int tp_disc_head_fwd(const tp_disc_head_args* args, tp_stream_t stream);
 int tp_disc_head_bwd(const tp_disc_head_args* args, tp_stream_t stream);
 int tp_disc_head_bwd_bwd(const tp_disc_head_args* args, tp_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * K15  y = x W^T for a handful of rows: the PatchGAN's last ladder convolution covers its whole map (reference
+ *      layers/discriminator.py:110-111), i.e. [B, 8192] x [8192, 64] with B = 4 .. 32.  Forward and weight gradient
+ *      (gW = gy^T x); the data gradient gx = gy W is a library GEMM.  x [M,K], w [N,K], y [M,N].
+ * ------------------------------------------------------------------------------------------ */
+int tp_skinny_linear_fwd(const float* x, const float* w, float* y, int M, int N, int K, tp_stream_t stream);
+int tp_skinny_linear_wgrad(const float* gy, const float* x, float* gw, int M, int N, int K, tp_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1599,3 +1599,30 @@ def test_disc_head_matches_torch_up_to_second_order(ops, B, C_z, H, L):
         res.append([t.detach().double().cpu() for t in (out, gz) + tuple(grads)])
     for i, (a, b) in enumerate(zip(res[1], res[0])):
         assert rel_l2(a, b) < 2e-5, (i, rel_l2(a, b))
+
+
+# ------------------------------------------------------------------------------------------ K15
+@pytest.mark.parametrize("M,K,N", [(4, 8192, 64), (32, 8192, 64), (3, 1024, 5), (9, 2048, 17), (1, 8192, 64)])
+def test_skinny_linear_matches_torch_up_to_second_order(ops, M, K, N):
+    """K15 (csrc/skinny_linear.hip: the PatchGAN's full-map convolution as x W^T for a handful of rows) against torch in fp64:
+    the three kernels and their autograd composition incl. an R1-style second-order gradient."""
+    from texpose_amd import autograd_ops
+    torch.manual_seed(M + K + N)
+    x0 = torch.randn(M, K, device=dev())
+    w0 = torch.randn(N, K, device=dev()) / K ** 0.5
+    g0 = torch.randn(M, N, device=dev())
+    xd, wd, gd = x0.double().cpu(), w0.double().cpu(), g0.double().cpu()
+    for got, want, name in ((ops.skinny_linear_fwd(x0, w0), xd @ wd.t(), "fwd"), (ops.skinny_linear_dgrad(g0, w0), gd @ wd, "dgrad"),
+                            (ops.skinny_linear_wgrad(g0, x0), gd.t() @ xd, "wgrad")):
+        assert got.shape == want.shape and rel_l2(got, want) < 2e-6, (name, rel_l2(got, want))
+    res = []
+    for mine in (False, True):
+        x = (x0 if mine else xd).clone().requires_grad_()
+        w = (w0 if mine else wd).clone().requires_grad_()
+        y = autograd_ops.skinny_linear(x, w) if mine else x @ w.t()
+        out = (torch.tanh(y) * (g0 if mine else gd)).sum()
+        gx, = torch.autograd.grad(out, x, create_graph=True)
+        ggx, ggw = torch.autograd.grad(gx.pow(2).sum(), (x, w))
+        res.append([t.detach().double().cpu() for t in (y, gx, ggx, ggw)])
+    for a, b, name in zip(res[1], res[0], ("y", "gx", "d reg / d x", "d reg / d w")):
+        assert rel_l2(a, b) < 5e-6, (name, rel_l2(a, b))

@@ -32,6 +32,7 @@ SYMBOLS = (
     "tp_conv3s1_workspace", "tp_conv3s1_fwd", "tp_conv3s1_dgrad",
     "tp_patch_coords", "tp_bce_logits_fwd", "tp_bce_logits_bwd", "tp_feat_inputs_fwd", "tp_feat_inputs_bwd", "tp_disc_inputs", "tp_step_flags", "tp_adam_step",
     "tp_disc_head_fwd", "tp_disc_head_bwd", "tp_disc_head_bwd_bwd",
+    "tp_skinny_linear_fwd", "tp_skinny_linear_wgrad",
 )
 
 vp = C.c_void_p
@@ -221,6 +222,8 @@ def load() -> C.CDLL:
     sig("tp_disc_inputs", [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp])
     for name in ("tp_disc_head_fwd", "tp_disc_head_bwd", "tp_disc_head_bwd_bwd"):
         sig(name, [C.POINTER(DiscHeadArgs), vp])
+    for name in ("tp_skinny_linear_fwd", "tp_skinny_linear_wgrad"):
+        sig(name, [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp])
     _lib = lib
     return lib
 

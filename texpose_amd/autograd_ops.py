@@ -305,3 +305,54 @@ class _DiscHead(torch.autograd.Function):
 def disc_head(z, scale, W1, W2, W3, L: int, slope: float = 0.2):
     """out [B] = W3 lrelu(W2 lrelu(W1 lrelu([z, enc(scale), scale]))) with W1 [H,C+2L+1], W2 [H,H], W3 [1,H] (K14)."""
     return _DiscHead.apply(z.contiguous(), scale.contiguous(), W1.contiguous(), W2.contiguous(), W3.contiguous(), int(L), float(slope))
+
+
+# ---- K15: y = x W^T for a handful of rows (the PatchGAN's full-map convolution), closed under differentiation like K11
+class _SkinnyLinear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        return ops.skinny_linear_fwd(x, w)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gy = gy.contiguous()
+        gx = _SkinnyLinearDgrad.apply(gy, w) if ctx.needs_input_grad[0] else None
+        gw = _SkinnyLinearWgrad.apply(gy, x) if ctx.needs_input_grad[1] else None
+        return gx, gw
+
+
+class _SkinnyLinearDgrad(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, gy, w):
+        ctx.save_for_backward(gy, w)
+        return ops.skinny_linear_dgrad(gy, w)
+
+    @staticmethod
+    def backward(ctx, ggx):
+        gy, w = ctx.saved_tensors
+        ggx = ggx.contiguous()
+        g_gy = _SkinnyLinear.apply(ggx, w) if ctx.needs_input_grad[0] else None
+        g_w = _SkinnyLinearWgrad.apply(gy, ggx) if ctx.needs_input_grad[1] else None
+        return g_gy, g_w
+
+
+class _SkinnyLinearWgrad(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, gy, x):
+        ctx.save_for_backward(gy, x)
+        return ops.skinny_linear_wgrad(gy, x)
+
+    @staticmethod
+    def backward(ctx, ggw):
+        gy, x = ctx.saved_tensors
+        ggw = ggw.contiguous()
+        g_gy = _SkinnyLinear.apply(x, ggw) if ctx.needs_input_grad[0] else None
+        g_x = _SkinnyLinearDgrad.apply(gy, ggw) if ctx.needs_input_grad[1] else None
+        return g_gy, g_x
+
+
+def skinny_linear(x, w):
+    """x [M,K] @ w [N,K]^T for M <= 256 rows (K15), differentiable to any order."""
+    return _SkinnyLinear.apply(x.contiguous(), w.contiguous())

@@ -41,7 +41,11 @@ class SNConv2d(nn.Module):
             # the kernel covers the whole map (the three 1x1 layers of ``final`` on a 1x1 map, and main's last 4x4 conv
             # on its 4x4 map): a plain GEMM -- one launch in each derivative order instead of MIOpen's conv + layout
             # transposes (and its naive double-backward fallbacks)
-            return F.linear(x.flatten(1), weight.flatten(1))[:, :, None, None]
+            x2, w2 = x.flatten(1), weight.flatten(1)
+            if x2.shape[0] <= 256 and x2.shape[1] >= 1024:              # K15: one pass over the weight, one launch per node
+                from . import autograd_ops
+                return autograd_ops.skinny_linear(x2, w2)[:, :, None, None]
+            return F.linear(x2, w2)[:, :, None, None]
         if (x.is_cuda and tuple(weight.shape[-2:]) == (4, 4) and self.stride == (2, 2) and self.padding == (1, 1)
                 and _pow2_map(x.shape[-2]) and _pow2_map(x.shape[-1])):
             from . import autograd_ops                                 # K11: one launch per derivative node

@@ -907,3 +907,34 @@ def disc_head_bwd_bwd(c_gz: Tensor, g_out: Tensor, t0: Tensor, t1: Tensor, t2: T
     a.gW1, a.gW2, a.gW3 = gW1.data_ptr(), gW2.data_ptr(), gW3.data_ptr()
     check(lib.tp_disc_head_bwd_bwd(C.byref(a), _stream()), "tp_disc_head_bwd_bwd")
     return gg, gW1, gW2, gW3
+
+
+# ------------------------------------------------------------------------------------------ K15
+SKINNY_MAX_ROWS = 256
+
+
+@_on_tensor_device
+def skinny_linear_fwd(x: Tensor, w: Tensor) -> Tensor:
+    """x [M,K] @ w [N,K]^T -> [M,N] for a handful of rows (K15)."""
+    lib = _lib.load()
+    x, w = _f32(x, "x"), _f32(w, "w")
+    y = torch.empty(x.shape[0], w.shape[0], device=x.device)
+    check(lib.tp_skinny_linear_fwd(x.data_ptr(), w.data_ptr(), y.data_ptr(), x.shape[0], w.shape[0], x.shape[1], _stream()),
+          "tp_skinny_linear_fwd")
+    return y
+
+
+def skinny_linear_dgrad(gy: Tensor, w: Tensor) -> Tensor:
+    """gy [M,N] @ w [N,K] -> [M,K] (a library GEMM: rocBLAS does this shape in 7 us)."""
+    return torch.mm(gy, w)
+
+
+@_on_tensor_device
+def skinny_linear_wgrad(gy: Tensor, x: Tensor) -> Tensor:
+    """gy [M,N]^T @ x [M,K] -> [N,K]."""
+    lib = _lib.load()
+    gy, x = _f32(gy, "gy"), _f32(x, "x")
+    gw = torch.empty(gy.shape[1], x.shape[1], device=x.device)
+    check(lib.tp_skinny_linear_wgrad(gy.data_ptr(), x.data_ptr(), gw.data_ptr(), x.shape[0], gy.shape[1], x.shape[1], _stream()),
+          "tp_skinny_linear_wgrad")
+    return gw
