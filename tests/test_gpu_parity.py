@@ -1371,18 +1371,20 @@ def test_conv4s2_matches_torch_up_to_second_order(ops, shape):
         assert rel_l2(a, b) < 5e-6, (shape, name, rel_l2(a, b))
 
 
-def test_discriminator_with_native_convs_matches_stock(ops):
-    """The PatchGAN forward, its gradients and the R1 double backward through K11 + K9 + K7 against the same module with
-    stock conv2d / InstanceNorm / LeakyReLU (CPU, fp64 copy of the parameters)."""
+@pytest.mark.parametrize("patch", [16, 32, 64])
+def test_discriminator_with_native_convs_matches_stock(ops, patch):
+    """The PatchGAN forward, its gradients and the R1 double backward through K11 + K9 + K7 + K14 + K15 against the same module
+    with stock conv2d / InstanceNorm / LeakyReLU (CPU, fp64 copy of the parameters), for the reference's 16-pixel patches and
+    the deeper ladders of 32 / 64 pixels (64: first stage without a norm)."""
     import copy
     from texpose_amd.gan_modules import Discriminator
     from texpose_amd.options import default_options
     torch.manual_seed(5)
     opt = default_options(H=128, W=128, device=dev())
-    opt.patch_size = 16
+    opt.patch_size = patch
     d_gpu = Discriminator(opt).to(dev()).eval()            # eval: u / v fixed, so both copies normalise identically
     d_cpu = copy.deepcopy(d_gpu).cpu().double().eval()
-    x0 = torch.rand(4, 9 if opt.gan.geo_conditional else 3, 16, 16, device=dev())
+    x0 = torch.rand(4, 9 if opt.gan.geo_conditional else 3, patch, patch, device=dev())
     sc = torch.rand(4, 1, 1, 1, device=dev()) * 0.5 + 0.25
     res = []
     for d, cast in ((d_cpu, lambda t: t.double().cpu()), (d_gpu, lambda t: t)):
