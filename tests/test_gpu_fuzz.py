@@ -236,3 +236,72 @@ def test_fuzz_split_fp16_backward_equals_fp32_mfma_backward(ops, case):
         assert torch.isfinite(a).all() and rel_l2(a, b) < 2e-5, rel_l2(a, b)
     for k in ("lat_trans", "lat_light"):
         assert rel_l2(res["f16x3"][k], res["fp32"][k]) < 2e-5
+
+
+# ------------------------------------------------------------------------------------------ K11 / K12 / K14 / K15 (f1)
+@pytest.mark.parametrize("case", CASES)
+def test_fuzz_patch_convolutions(ops, case):
+    """Random shapes of the PatchGAN / feature-network convolution kernels (csrc/patch_conv.hip) against torch in fp64:
+    image counts that do not fill a 32-row tile, channel counts off the 32-column tile and odd (the dgrad lane halves take
+    even / odd channels), maps from 8x8 to 64x32, split-K and single-workgroup plans."""
+    import torch.nn.functional as F
+    rs = np.random.RandomState(300 + case)
+    N, C_in, Co = int(rs.randint(1, 9)), int(rs.randint(1, 70)), int(rs.randint(1, 90))
+    H, W = int(2 ** rs.randint(3, 7)), int(2 ** rs.randint(3, 6))
+    x = cu(T(rs.normal(size=(N, C_in, H, W))))
+    w = cu(T(rs.normal(size=(Co, C_in, 4, 4)) / (4 * C_in ** 0.5)))
+    gy = cu(T(rs.normal(size=(N, Co, H // 2, W // 2))))
+    xd, wd, gd = (t.double().cpu().requires_grad_() for t in (x, w, gy))
+    yd = F.conv2d(xd, wd, None, 2, 1)
+    gxd, gwd = torch.autograd.grad(yd, (xd, wd), gd)
+    assert rel_l2(ops.conv4s2_fwd(x, w), yd) < 2e-6
+    assert rel_l2(ops.conv4s2_dgrad(gy, w), gxd) < 2e-6
+    assert rel_l2(ops.conv4s2_wgrad(gy, x), gwd) < 2e-6
+    # 3x3 + bias + ReLU and its masked data gradient
+    H3, W3 = int(2 ** rs.randint(2, 6)), int(2 ** rs.randint(2, 6))
+    x3 = cu(T(rs.normal(size=(N, C_in, H3, W3))))
+    w3 = cu(T(rs.normal(size=(Co, C_in, 3, 3)) / (3 * C_in ** 0.5)))
+    b3 = cu(T(rs.normal(size=(Co,))))
+    relu = bool(case & 1)
+    x3d = x3.double().cpu().requires_grad_()
+    y3d = F.conv2d(x3d, w3.double().cpu(), b3.double().cpu(), 1, 1)
+    y3d = torch.relu(y3d) if relu else y3d
+    g3 = cu(T(rs.normal(size=tuple(y3d.shape))))
+    gx3d, = torch.autograd.grad(y3d, x3d, g3.double().cpu())
+    y3 = ops.conv3s1_fwd(x3, w3, b3, relu)
+    assert rel_l2(y3, y3d) < 2e-6
+    assert rel_l2(ops.conv3s1_dgrad(g3, w3, y3 if relu else None), gx3d) < 2e-6
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_fuzz_skinny_linear_and_head(ops, case):
+    """Random sizes of K15 (x W^T for few rows) and K14 (the scale-conditioned head) against torch in fp64."""
+    import torch.nn.functional as F
+    from texpose_amd import autograd_ops
+    rs = np.random.RandomState(400 + case)
+    M, K, N = int(rs.randint(1, 40)), int(rs.randint(1, 3000)), int(rs.randint(1, 80))
+    x, w, g = cu(T(rs.normal(size=(M, K)))), cu(T(rs.normal(size=(N, K)) / K ** 0.5)), cu(T(rs.normal(size=(M, N))))
+    assert rel_l2(ops.skinny_linear_fwd(x, w), x.double().cpu() @ w.double().cpu().t()) < 2e-6
+    assert rel_l2(ops.skinny_linear_wgrad(g, x), g.double().cpu().t() @ x.double().cpu()) < 2e-6
+    B, C_z, H, L = int(rs.randint(1, 20)), int(rs.randint(1, 70)), int(rs.randint(1, 70)), int(rs.randint(0, 6))
+    z0, s0 = cu(T(rs.normal(size=(B, C_z)))), cu(T(rs.uniform(0.25, 1.0, size=(B,))))
+    Ws = [cu(T(rs.normal(size=(H, C_z + 2 * L + 1)) / 4)), cu(T(rs.normal(size=(H, H)) / 4)), cu(T(rs.normal(size=(1, H)) / 4))]
+    outs = []
+    for mine in (False, True):
+        cast = (lambda t: t.clone()) if mine else (lambda t: t.double().cpu())
+        z = cast(z0).requires_grad_()
+        W = [cast(v).requires_grad_() for v in Ws]
+        if mine:
+            out = autograd_ops.disc_head(z, cast(s0), W[0], W[1], W[2], L, 0.2)
+        else:
+            s = cast(s0)
+            freq = (2 ** torch.arange(L, dtype=torch.float32)).double() * float(torch.tensor(np.pi, dtype=torch.float32))
+            spec = s.view(-1, 1) * freq
+            a = torch.cat([z, spec.sin(), spec.cos(), s.view(-1, 1)], 1)
+            t = F.leaky_relu(F.leaky_relu(F.leaky_relu(a, 0.2) @ W[0].t(), 0.2) @ W[1].t(), 0.2)
+            out = (t @ W[2].t()).flatten()
+        gz, = torch.autograd.grad(out.sum(), z, create_graph=True)
+        grads = torch.autograd.grad(gz.pow(2).sum() + out.sum(), [z] + W)
+        outs.append([t.detach().double().cpu() for t in (out, gz) + tuple(grads)])
+    for a, b in zip(outs[1], outs[0]):
+        assert rel_l2(a, b) < 5e-5
