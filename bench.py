@@ -112,6 +112,13 @@ def cpu_baseline(sc, params, emb_t, emb_l, budget_s=20.0, chunk=2048):
                        % (n_chunks, chunk, N_SAMPLES, torch.__version__, best, avail))
 
 
+def _train_traffic():
+    try:
+        return float(json.load(open(os.path.join(REPO, "profiles", "traffic.json")))["train_b32"]["total_per_step"])
+    except Exception:
+        return None
+
+
 def train_leg(device, rank, world):
     """BASELINE's metric has a second half, "train iters/sec" (config C3: full GAN loop, batch 4, 128x128 crops, 16x16
     patches, 64 samples per ray; C4 = the same per-GPU batch sharded over the GPUs with one RCCL all-reduce per
@@ -167,7 +174,9 @@ def train_leg(device, rank, world):
                                       "mlp_wgrad_finalize", "bound": "mfma", "achieved": achieved, "peak": MFMA_PEAK_TFLOPS["f16x3"],
                            "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TFLOPS["f16x3"],
                            "issued_frac": 3 * achieved / MFMA_PEAK_TFLOPS["f16x3"], "fwd_ms": f_ms, "bwd_ms": b_ms,
-                           "samples_per_launch": samples, "flop_per_sample": TRAIN_FLOP_PER_SAMPLE, "traffic": None,
+                           "samples_per_launch": samples, "flop_per_sample": TRAIN_FLOP_PER_SAMPLE, "traffic": _train_traffic(),
+                           "traffic_unit": "bytes per B=32 step over the three MLP kernels, L2<->fabric (profiles/traffic.json: "
+                                           "train_b32; the weight gradient alone reads 7.7 GB = its memory floor of 1.42 ms)",
                            "note": "B=32 nerf step, eager; ALGORITHMIC FLOP (recording forward + head backward) / HIP-event "
                                    "time of tp_mlp_fwd + tp_mlp_bwd; every product is three f16 MFMAs"}
     return out
