@@ -129,12 +129,12 @@ def train_leg(device, rank, world):
     import train_dp
     from texpose_amd import ops
     out = {"workload": "C3/C4: Duck-like synthetic crops 128x128, 16x16 patches, 64 samples/ray, 4 images per GPU, "
-                       "hipGraph-replayed iteration on one GPU / eager data-parallel loop on several; random-init VGG19[:15] "
-                       "feature network (weights unavailable offline)"}
-    # One GPU: the captured two-branch step (tested on hardware).  Several GPUs: the EAGER data-parallel loop unless
-    # TP_BENCH_TRAIN_GRAPH=1 -- RCCL collectives inside a captured hipGraph have only ever run in a 1-rank group here, and
-    # a collective that hangs in a replay would take the rays/s line of this run down with it.
-    graphed = os.environ.get("TP_BENCH_TRAIN_EAGER", "0") != "1" and (world == 1 or os.environ.get("TP_BENCH_TRAIN_GRAPH", "0") == "1")
+                       "hipGraph-replayed iteration (several GPUs: two replays with the gradient all-reduces between them); "
+                       "random-init VGG19[:15] feature network (weights unavailable offline)"}
+    # The captured two-branch step.  On several GPUs the trainer keeps the RCCL all-reduces OUT of the graphs: replay A (render,
+    # losses, all backward passes), two eager stream-ordered collectives, replay B (optimiser steps) -- collectives inside a
+    # replayed hipGraph have only ever run in a 1-rank group here (TP_COLLECTIVES_IN_GRAPH=1 opts in).
+    graphed = os.environ.get("TP_BENCH_TRAIN_EAGER", "0") != "1"
     try:
         full = train_dp.measure(device, rank, world, global_batch=4 * world, iters=40, warm=4, graphed=graphed, full=True)
     except Exception as exc:                       # (e.g. a collective that cannot be captured on this stack): eager loop

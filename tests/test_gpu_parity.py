@@ -1107,8 +1107,9 @@ def test_spectral_weights_match_torch(ops):
 
 
 def test_graph_capture_with_rccl_all_reduce(ops):
-    """The data-parallel gradient all-reduce (RCCL) inside the captured iteration: a 1-rank NCCL group on this GPU with
-    the collective forced on.  Replays must run and give the same parameters as the capture without the collective."""
+    """The data-parallel gradient all-reduce (RCCL) with the captured iteration: a 1-rank NCCL group on this GPU with the
+    collective forced on, (a) inside the single captured graph, (b) eagerly between two replays (gradient graph, optimiser
+    graph: what a real multi-rank group uses).  Both must give the same parameters as the capture without the collective."""
     import torch.distributed as dist
     from texpose_amd.gan_modules import Discriminator
     from texpose_amd.graph import Graph
@@ -1124,7 +1125,11 @@ def test_graph_capture_with_rccl_all_reduce(ops):
         batch = training_batch(B, H, W, n_train=5, seed=2, device="cuda:0")
         rnd = (torch.rand(3, B, 1, 1, 1, device=dev()), torch.rand(B, 256, N, 1, device=dev()))
         results = []
-        for forced in (False, True):
+        for forced, split in ((False, False), (True, False), (True, True)):
+            # split: the multi-GPU default -- the collectives run eagerly BETWEEN two graph replays (gradients, then optimisers)
+            os.environ.pop("TP_SPLIT_GRAPH", None)
+            if split:
+                os.environ["TP_SPLIT_GRAPH"] = "1"
             opt = default_options(H=H, W=W, device="cuda:0")
             opt.batch_size, opt.patch_size, opt.nerf.sample_intvs = B, 16, N
             opt.loss_weight.feat = None
@@ -1157,8 +1162,11 @@ def test_graph_capture_with_rccl_all_reduce(ops):
                 _, loss = tr.train_iteration(v)
             assert all(np.isfinite(float(x)) for x in loss.values())
             results.append({k: v.detach().clone() for k, v in graph.state_dict().items()})
+            assert (tr._graph_b is not None) == split
         assert_updates_close(results[0], results[1], snap)
+        assert_updates_close(results[0], results[2], snap)
     finally:
+        os.environ.pop("TP_SPLIT_GRAPH", None)
         dist.destroy_process_group()
 
 

@@ -332,6 +332,8 @@ class GraphedGanTrainer(GanTrainer):
     def __init__(self, opt, graph: Graph, n_train: int, max_iter: int = 6000 * 189 // 8, group=None):
         super().__init__(opt, graph, n_train, max_iter, group=group)
         self._graph = None
+        self._graph_b = None
+        self._deferred = False
         self._static_in = None
         self._static_loss = None
         dev = self.lr_nerf.device
@@ -375,8 +377,26 @@ class GraphedGanTrainer(GanTrainer):
             self._gate(self._gate_disc.sum() == 0, [p.grad for p in self.disc_group], self.lr_disc, self.lr_disc_used)
         return True
 
+    def _split_around_collectives(self):
+        """Real multi-rank group: the gradient all-reduces stay OUTSIDE the captured graphs (replay A = everything up to the
+        gradients, two eager collectives, replay B = the optimiser steps).  RCCL collectives inside a replayed hipGraph have
+        only been exercised in a 1-rank group (tests); between two replays they are ordinary stream-ordered calls."""
+        if os.environ.get("TP_COLLECTIVES_IN_GRAPH"):
+            return False
+        return (self.red_nerf.world_size > 1 or bool(os.environ.get("TP_SPLIT_GRAPH"))) and self.has_disc \
+            and not os.environ.get("TP_NO_BRANCH_OVERLAP")
+
     def _body(self, var):
-        """One iteration.  After the render and its losses the step forks (reference order kept where it matters: the nerf
+        """One iteration (what is captured as ONE graph; `_body_a` / `_body_b` when the collectives stay outside)."""
+        out = self._body_a(var)
+        if self._deferred:
+            self.red_nerf.reduce()
+            self.red_disc.reduce()
+            self._body_b()
+        return out
+
+    def _body_a(self, var):
+        """After the render and its losses the step forks (reference order kept where it matters: the nerf
         step's discriminator forward -- its power iteration -- comes first): the generator branch (feature-network and
         discriminator backward, composite / MLP backward, Adam) stays on the capturing stream, the discriminator branch
         (real / fake forward, R1 double backward, RMSprop) runs on a second stream.  They share no written state -- nerf
@@ -392,6 +412,7 @@ class GraphedGanTrainer(GanTrainer):
         self._flag_nerf(loss)
         dloss = None
         overlap = self.has_disc and not os.environ.get("TP_NO_BRANCH_OVERLAP")
+        self._deferred = self._split_around_collectives()          # optimiser steps (and reductions) after this function
         if overlap:
             main = torch.cuda.current_stream(var.rgb.device)
             if self._side is None:
@@ -399,21 +420,30 @@ class GraphedGanTrainer(GanTrainer):
             self._side.wait_stream(main)                          # fork
             # data parallel: both all-reduces are issued from the capturing stream after the join, in one fixed order on every
             # rank (two collectives of one communicator in unordered branches of a graph could meet in different orders)
-            serial_tail = self.red_disc is not None and (self.red_disc.world_size > 1 or self.red_disc.single_rank_collective)
+            serial_tail = self._deferred or (self.red_disc is not None and (self.red_disc.world_size > 1 or self.red_disc.single_rank_collective))
             with torch.cuda.stream(self._side):
                 var, dloss = self.disc_step(var, apply=not serial_tail)
         torch.autograd.backward(terms, ws)
-        self._guard_nerf(var, loss)
-        self.nerf_apply()
+        if not self._deferred:
+            self._guard_nerf(var, loss)
+            self.nerf_apply()
         if overlap:
             main.wait_stream(self._side)                          # join
-            if serial_tail:
+            if serial_tail and not self._deferred:
                 self.disc_apply(self._disc_total)
         elif self.has_disc:
             var, dloss = self.disc_step(var)
         if dloss is not None:
             loss.update({k: v for k, v in dloss.items() if k != "all"})
         return {k: v.detach() for k, v in loss.items() if torch.is_tensor(v)}
+
+    def _body_b(self):
+        """The optimiser steps of a step whose reductions ran between two graph replays (gradients are already averaged)."""
+        self._guard_nerf(None, None)
+        self.optim_nerf.step()
+        self.graph.nerf.mark_heads_dirty()
+        self._guard_disc(self._disc_total)
+        self.optim_disc.step()
 
     # ------------------------------------------------------------------ capture
     def _snapshot(self):
@@ -472,8 +502,16 @@ class GraphedGanTrainer(GanTrainer):
         if self.has_disc:
             self.optim_disc.zero_grad(set_to_none=True)
         self.graph.patch_sampler.update_device_bound()          # outside the capture
-        with torch.cuda.graph(self._graph, stream=side):
-            self._static_loss = self._body(AttrDict(dict(self._static_in)))
+        self._graph_b = None
+        if self._split_around_collectives():
+            with torch.cuda.graph(self._graph, stream=side):
+                self._static_loss = self._body_a(AttrDict(dict(self._static_in)))
+            self._graph_b = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph_b, stream=side, pool=self._graph.pool()):
+                self._body_b()
+        else:
+            with torch.cuda.graph(self._graph, stream=side):
+                self._static_loss = self._body(AttrDict(dict(self._static_in)))
         self._restore(snap)
         flagged = self._read_bad(blocking=True)
         if flagged[0] and self._uses_f16x3():
@@ -536,6 +574,10 @@ class GraphedGanTrainer(GanTrainer):
                 self._adopt_group_lr(name, optim)             # an Optimizer.load_state_dict since the last replay
         self.graph.patch_sampler.update_device_bound()          # one fill_ of the annealed bound
         self._graph.replay()
+        if self._graph_b is not None:                            # collectives between the two replays, stream-ordered
+            self.red_nerf.reduce()
+            self.red_disc.reduce()
+            self._graph_b.replay()
         self._after_step()
         flagged = self._read_bad()                              # outside the graph: event query + pinned copy
         if flagged[0] and self._uses_f16x3():

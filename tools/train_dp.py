@@ -80,7 +80,7 @@ def measure(device, rank, world, global_batch=32, iters=50, warm=5, graphed=True
     dt = float(dt) / iters
     return dict(metric="train iters/sec", value=1.0 / dt, ms_per_iter=dt * 1e3, n_gpus=world, global_batch=global_batch,
                 per_gpu_batch=global_batch // world, rays_per_iter=global_batch * 256, samples_per_iter=global_batch * 256 * 64,
-                launch="hipGraph replay" if graphed else "eager", recording_forward=graph.nerf.train_precision,
+                launch=("hipGraph replay" if getattr(trainer, "_graph_b", None) is None else "two hipGraph replays with the gradient all-reduces between them") if graphed else "eager", recording_forward=graph.nerf.train_precision,
                 collective="one flat all-reduce per optimiser step (%.1f MB nerf, %.1f MB discriminator)"
                            % (trainer.red_nerf.nbytes / 1e6, (trainer.red_disc.nbytes if trainer.red_disc else 0) / 1e6),
                 loop="full GAN (render fwd+bwd, gathers, random-init VGG19[:15] feature loss, PatchGAN + R1, Adam + RMSprop)"
