@@ -222,14 +222,12 @@ def gen_wide(src, dst):
             return [[], cv[0:4], cv[4:8], cv[8:12], cv[12:13]]
 
         def tail(g, ts=ts):
-            # seed tile ts of the SOURCE set (its operands were converted during the previous chunk) with the next
-            # layer's bias: that set is the next layer's destination.  The four bias reads are issued in group 0 BEFORE
-            # this group's ring refills (so the counted waits of the following groups cover them), the sixteen
-            # v_accvgpr_write ride in the gaps after MFMA 6 of groups 1..7
+            # (tile ts of the SOURCE set -- its operands were converted during the previous chunk -- is seeded with the next
+            # layer's bias, that set being the next layer's destination: four LDS reads STRAIGHT INTO the accumulator
+            # registers, issued in group 0 BEFORE this group's ring refills so that the counted waits of the following
+            # groups cover them.  Until the end of round 2 they went to VGPRs and sixteen v_accvgpr_write followed in the
+            # MFMA gaps: ~130 cycles per chunk, a write to the accumulator file next to running MFMAs is not free.)
             out = []
-            if g >= 1:
-                ks = [2 * (g - 1), 2 * (g - 1) + 1] + ([14, 15] if g == 7 else [])
-                out += ["v_accvgpr_write_b32 a%d, v%d" % (src + 16 * ts + k, HACC + k) for k in ks]
             if ts < 7:
                 if 1 <= g <= 3:
                     out.append(advance_dch()[g - 1])
@@ -240,7 +238,8 @@ def gen_wide(src, dst):
         def head(g, ts=ts):
             if g != 0:
                 return []
-            return ["ds_read_b128 %s, %%[nbias] offset:%d" % (vr(HACC + 4 * k), ts * 64 + k * 16) for k in range(4)]
+            return ["ds_read_b128 a[%d:%d], %%[nbias] offset:%d" % (src + 16 * ts + 4 * k, src + 16 * ts + 4 * k + 3, ts * 64 + k * 16)
+                    for k in range(4)]
 
         chunk_groups(e, 16, ts, mf, fill, (5, 6), 1, tail, head)
     ring_epilogue(e, 8)
@@ -315,27 +314,14 @@ def gen_head(src):
 
 # ------------------------------------------------------------------------------------------------------ INIT
 def gen_init(dst):
-    """dst set = 128 floats at LDS address %[bias] (this lane half's bias block of the layer, already * 2^8)"""
+    """dst set = 128 floats at LDS address %[bias] (this lane half's bias block of the layer, already * 2^8): 32 LDS reads
+    straight into the accumulator registers"""
     L = []
     e = L.append
     e("s_nop 7")
-    bank = [XB[0], XB[1]]
-
-    def reads(rnd):
-        for k in range(4):
-            e("ds_read_b128 %s, %%[bias] offset:%d" % (vr(bank[rnd & 1] + 4 * k), (rnd * 4 + k) * 16))
-
-    def writes(rnd):
-        for k in range(16):
-            e("v_accvgpr_write_b32 a%d, v%d" % (dst + rnd * 16 + k, bank[rnd & 1] + k))
-
-    reads(0)
-    reads(1)
-    for rnd in range(8):
-        e("s_waitcnt lgkmcnt(%d)" % (4 if rnd < 7 else 0))
-        writes(rnd)
-        if rnd + 2 < 8:
-            reads(rnd + 2)
+    for k in range(32):
+        e("ds_read_b128 a[%d:%d], %%[bias] offset:%d" % (dst + 4 * k, dst + 4 * k + 3, k * 16))
+    e("s_waitcnt lgkmcnt(0)")
     e("s_nop 3")
     return L
 
