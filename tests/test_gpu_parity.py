@@ -1642,3 +1642,31 @@ def test_skinny_linear_matches_torch_up_to_second_order(ops, M, K, N):
         res.append([t.detach().double().cpu() for t in (y, gx, ggx, ggw)])
     for a, b, name in zip(res[1], res[0], ("y", "gx", "d reg / d x", "d reg / d w")):
         assert rel_l2(a, b) < 5e-6, (name, rel_l2(a, b))
+
+
+def test_feature_loss_from_patches_matches_torch(ops):
+    """PerceptualLoss.pairs_from_patches (K13 input stack + K12 network) against the reference's expression through the stock
+    network in fp64: both terms and d / d rgb."""
+    import copy
+    from texpose_amd.gan_modules import PerceptualLoss
+    torch.manual_seed(12)
+    B, h, w = 3, 16, 16
+    net = PerceptualLoss().to(dev())
+    ref = copy.deepcopy(net).cpu().double()
+    rgb0 = torch.rand(B, h * w, 3, device=dev())
+    g = torch.rand(B, 14, h, w, device=dev())
+    g[:, 12] = (g[:, 12] > 0.4).float()
+    g[:, 13] = (g[:, 13] > 0.3).float()
+    r = rgb0.clone().requires_grad_()
+    l1, l2 = net.pairs_from_patches(r, g, (h, w))
+    gr, = torch.autograd.grad(l1 + 5 * l2, r)
+    rd, gd = rgb0.double().cpu().requires_grad_(), g.double().cpu()
+    rgb = rd.view(B, h, w, 3).permute(0, 3, 1, 2)
+    image, image_syn, obj_mask, mask_syn = gd[:, 0:3], gd[:, 3:6], gd[:, 12:13], gd[:, 13:14]
+    pad = torch.logical_and(mask_syn == 1, obj_mask == 0).double()
+    feat = lambda t: ref.model((t - ref.mean) / ref.std)
+    l1d = F.mse_loss(feat(rgb), feat(image * obj_mask + image_syn * pad))
+    l2d = F.mse_loss(feat(rgb * obj_mask + image * (1 - obj_mask)), feat(image))
+    grd, = torch.autograd.grad(l1d + 5 * l2d, rd)
+    assert rel_l2(l1, l1d) < 1e-5 and rel_l2(l2, l2d) < 1e-5
+    assert rel_l2(gr, grd) < 1e-5
