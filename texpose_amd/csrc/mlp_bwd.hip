@@ -17,7 +17,7 @@
 //     linearity everything that multiplies a per-image latent) and, for mlp_rgb.0, the recorded
 //     [view encoding, x] columns.
 //  3. mlp_wgrad_finalize -- fixed-order reduction of the split-K partials into the reference
-//     parameter layouts (deterministic: no float atomics); mlp_latent_grad then forms the latent-row
+//     parameter layouts (deterministic: no float atomics); mlp_wgrad_finalize2 then forms the biases, latent columns and latent-row
 //     gradients dlat[b] = W0[:,latent cols]^T (sum_{s in b} dz0[:,s]), one wave per element.
 #include "mlp_mma.h"
 
@@ -151,7 +151,7 @@ __device__ __forceinline__ f32x16 mfma16w(half8w a, half8w b, f32x16 c) {
 
 struct WgParams {
   const float* saved; const float* dz;
-  const unsigned int* dz_max;   // F16X3 only
+  const unsigned int* dz_max;   // unused
   int64_t n_samples, n_groups, rn;   // rn = samples per image (R*N)
   int n_slices, groups_per_slice;
   float* partial;
@@ -174,10 +174,7 @@ __device__ __forceinline__ void wg_dma(const WgParams& P, int64_t g, float* buf,
                                      AS3(buf + 4096 + 8192 + wave * 256), 16, 0, 0);
 }
 
-// F16X3: the products run on the f16 matrix cores as hi*hi + hi*lo + lo*hi with both operands split on the fly (the
-// gradient record is first scaled by a power of two so that its largest entry sits at 2^13: exact, undone in the
-// epilogue); 16 samples per MFMA instead of 2, 3 instead of 8 instructions per 16 samples, fp32-grade accuracy.
-template <bool F16X3>
+// fp32-MFMA weight gradient (records of the fp32 forward): 128 output rows x 10 column tiles per workgroup.
 __global__ __launch_bounds__(kThreads, 1) void mlp_wgrad_kernel(WgParams P) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -218,16 +215,6 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_wgrad_kernel(WgParams P) {
   const int64_t lo = (int64_t)i * P.rn;                       // sample range of image `i` (one-hot tile column)
   const int64_t hi = lo + P.rn < P.n_samples ? lo + P.rn : P.n_samples;
 
-  float dz_scale = 1.0f, out_scale = 1.0f;
-  if constexpr (F16X3) {
-    const float mx = __uint_as_float(*P.dz_max);
-    if (mx > 1.0e-30f && mx < 1.0e30f) {
-      int e;
-      (void)frexpf(mx, &e);                       // mx = m * 2^e, m in [0.5, 1)
-      dz_scale = ldexpf(1.0f, 14 - e);            // largest |dz| lands in [2^13, 2^14)
-      out_scale = ldexpf(1.0f, e - 14);
-    }
-  }
   int buf = 0;
   if (g0 < g1) wg_dma(P, g0, lds, a_off, a_pieces, b_slot, has_ex, wave, lane);
   __syncthreads();
@@ -236,44 +223,6 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_wgrad_kernel(WgParams P) {
     const float* A = lds + buf * kWgBufFloats;
     const float* Bm = A + 4096;
     const float* Ex = Bm + 8192;
-    if constexpr (F16X3) {
-#pragma unroll
-      for (int Q = 0; Q < 2; ++Q) {
-        const int sq0 = 4 * Q + 2 * hh, sq1 = sq0 + 1;            // this lane half: samples 16 Q + 8 hh .. + 7
-        const int sa = (fa >> 1) & 7;
-        half8w ah, al;
-        split8(*reinterpret_cast<const f32x4*>(A + a_row * 32 + ((sq0 ^ sa) << 2)),
-               *reinterpret_cast<const f32x4*>(A + a_row * 32 + ((sq1 ^ sa) << 2)), dz_scale, ah, al);
-        __builtin_amdgcn_iglp_opt(0);              // LLVM's MFMA / LDS-read interleave for small GEMM loops: 2.5 % on the B=32 step
-#pragma unroll
-        for (int ft = 0; ft < 8; ++ft) {
-          const int f = ft * 32 + i, sb = (f >> 1) & 7;
-          half8w bh, bl;
-          split8(*reinterpret_cast<const f32x4*>(Bm + f * 32 + ((sq0 ^ sb) << 2)),
-                 *reinterpret_cast<const f32x4*>(Bm + f * 32 + ((sq1 ^ sb) << 2)), 1.0f, bh, bl);
-          acc[ft] = mfma16w(ah, bh, acc[ft]);
-          acc[ft] = mfma16w(ah, bl, acc[ft]);
-          acc[ft] = mfma16w(al, bh, acc[ft]);
-        }
-        half8w oh;
-#pragma unroll
-        for (int m = 0; m < 8; ++m) {
-          const int64_t smp = g * 32 + 16 * Q + 8 * hh + m;
-          oh[m] = (smp >= lo && smp < hi) ? (_Float16)1.0f : (_Float16)0.0f;
-        }
-        acc[8] = mfma16w(ah, oh, acc[8]);
-        acc[8] = mfma16w(al, oh, acc[8]);
-        if (has_ex) {
-          const int se = (i >> 1) & 7;
-          half8w eh, el;
-          split8(*reinterpret_cast<const f32x4*>(Ex + i * 32 + ((sq0 ^ se) << 2)),
-                 *reinterpret_cast<const f32x4*>(Ex + i * 32 + ((sq1 ^ se) << 2)), 1.0f, eh, el);
-          acc[9] = mfma16w(ah, eh, acc[9]);
-          acc[9] = mfma16w(ah, el, acc[9]);
-          acc[9] = mfma16w(al, eh, acc[9]);
-        }
-      }
-    } else {
     const int64_t sbase = g * 32 + 4 * hh;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -297,7 +246,6 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_wgrad_kernel(WgParams P) {
         if (has_ex) acc[9] = mfma(a4[m], e4[m], acc[9]);
       }
     }
-    }
     __syncthreads();
     buf ^= 1;
   }
@@ -305,81 +253,331 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_wgrad_kernel(WgParams P) {
 #pragma unroll
   for (int t = 0; t < kWgTiles; ++t)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) out[(t * 16 + r) * 64 + lane] = acc[t][r] * out_scale;
+    for (int r = 0; r < 16; ++r) out[(t * 16 + r) * 64 + lane] = acc[t][r];
 }
 
 // ------------------------------------------------------------------------------------------------
-enum { SEG_W = 0, SEG_B = 1, SEG_DZSUM = 2 };
+// Split-fp16 weight gradient (records of the range-checked f16x3 forward).  The products run on the f16 matrix cores as
+// hi*hi + hi*lo + lo*hi with both operands split on the fly (the gradient record is first scaled by a power of two so
+// that its largest entry sits at 2^13: exact, undone in the epilogue); 16 samples per MFMA, fp32-grade accuracy.
+// One workgroup owns a WHOLE 256 x 256 GEMM of one sample slice: the four waves form a 2 x 2 grid of 128 x 128 quadrants
+// (16 accumulator tiles each), so every recorded block is fetched by exactly one workgroup, an operand fragment is split
+// once per 4 tiles instead of once per tile, and LDS fragment reads per MFMA fall to a third of the 32-row-per-wave
+// layout above.  The one-hot (bias / latent) and [view enc, x] column tiles of a row block ride with one of its two waves.
+// The two output-layer GEMMs (3 and 5 rows) are narrow workgroups: 32 rows, a wave per 64 columns; they move half the
+// bytes per group, so they get proportionally fewer, longer slices.  Partials keep the layout of the kernel above.
+constexpr int kWg2BufFloats = 8192 + 8192 + 1024;
+
+// The 16 quadrant tiles fill the 256 AGPRs (the compiler's MFMA form for this kernel); the extra column tiles must not
+// compete for them, so their MFMAs are issued in the VGPR form by hand.  Hazards the compiler cannot see through the asm:
+// a VALU result needs two wait states before an MFMA reads it (the s_nop; without it the first of these MFMAs read a
+// half-written one-hot operand); dependent MFMAs on one accumulator are interlocked by the hardware; compiled code reads
+// these tiles only in the epilogue, behind wg2_mfma_drain().
+__device__ __forceinline__ void mfma16w_vgpr(f32x16& c, const half8w& a, const half8w& b) {
+  asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void wg2_mfma_drain() { asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); }
+
+struct Wg2Params {
+  const float* saved; const float* dz;
+  const unsigned int* dz_max;
+  int64_t n_samples, n_groups, rn;   // rn = samples per image (R*N)
+  int n_w, n_n, gps_w, gps_n;        // slices / groups per slice of the wide and the narrow GEMMs
+  float* partial;
+};
+
+__device__ __forceinline__ void wg2_dma(const Wg2Params& P, int64_t g, float* buf, int a_off, bool big, int b_slot,
+                                        bool has_ex, int wave, int lane) {
+  const float* dzg = P.dz + g * (int64_t)kDzGroupFloats + a_off;
+  const float* svg = P.saved + g * (int64_t)kSavedGroupFloats;
+  if (big) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int pc = wave * 8 + k;
+      __builtin_amdgcn_global_load_lds(AS1(dzg + pc * 256 + lane * 4), AS3(buf + pc * 256), 16, 0, 0);
+    }
+  } else {
+    __builtin_amdgcn_global_load_lds(AS1(dzg + wave * 256 + lane * 4), AS3(buf + wave * 256), 16, 0, 0);
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int pc = wave * 8 + k;
+    __builtin_amdgcn_global_load_lds(AS1(svg + b_slot * kBlockFloats + pc * 256 + lane * 4),
+                                     AS3(buf + 8192 + pc * 256), 16, 0, 0);
+  }
+  if (has_ex)
+    __builtin_amdgcn_global_load_lds(AS1(svg + SV_EX * kBlockFloats + wave * 256 + lane * 4),
+                                     AS3(buf + 16384 + wave * 256), 16, 0, 0);
+}
+
+// fragment of feature row `f` (its swizzle) at LDS row `row` of a [rows][32 samples] block, sample quads sq0, sq0 + 1
+__device__ __forceinline__ void frag8(const float* blk, int row, int f, int sq0, float scale, half8w& hi, half8w& lo) {
+  const int s = (f >> 1) & 7;
+  split8(*reinterpret_cast<const f32x4*>(blk + row * 32 + ((sq0 ^ s) << 2)),
+         *reinterpret_cast<const f32x4*>(blk + row * 32 + (((sq0 + 1) ^ s) << 2)), scale, hi, lo);
+}
+
+// one (GEMM, slice) of the kernel below; BIG / HAS_EX are compile-time so that each variant is a straight-line loop
+// whose accumulator tiles never change register class
+template <bool BIG, bool HAS_EX>
+__device__ __forceinline__ void wg2_run(const Wg2Params& P, float* lds, int gemm, int slice, int wave, int lane) {
+  const int i = lane & 31, hh = lane >> 5;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int gps = BIG ? P.gps_w : P.gps_n;
+  const int a_off = BIG ? gemm * kBlockFloats : (gemm == 6 ? kDzT3Off : kDzR3Off);
+  const int b_slot = gemm == 0 ? SV_T1 : gemm == 1 ? SV_T0 : gemm == 2 ? SV_FEAT : gemm == 3 ? SV_R1 : gemm == 4 ? SV_R0
+                   : gemm == 5 ? SV_FEAT : gemm == 6 ? SV_T2 : SV_R2;
+  const int64_t g0 = (int64_t)slice * gps;
+  const int64_t g1 = g0 + gps < P.n_groups ? g0 + gps : P.n_groups;
+  constexpr int kMain = BIG ? 16 : 2, kHot = BIG ? 2 : 1, kEx = HAS_EX ? 2 : 0;
+
+  f32x16 acc[kMain], hot[kHot], ex[HAS_EX ? 2 : 1];
+#pragma unroll
+  for (int t = 0; t < kMain; ++t) acc[t] = f32x16{0};
+#pragma unroll
+  for (int t = 0; t < kHot; ++t) hot[t] = f32x16{0};
+  ex[0] = f32x16{0};
+  if constexpr (HAS_EX) ex[1] = f32x16{0};
+  (void)kEx;
+
+  const int64_t lo = (int64_t)i * P.rn;                       // sample range of image `i` (one-hot tile column)
+  const int64_t hi = lo + P.rn < P.n_samples ? lo + P.rn : P.n_samples;
+
+  float dz_scale = 1.0f, out_scale = 1.0f;
+  {
+    const float mx = __uint_as_float(*P.dz_max);
+    if (mx > 1.0e-30f && mx < 1.0e30f) {
+      int e;
+      (void)frexpf(mx, &e);                       // mx = m * 2^e, m in [0.5, 1)
+      dz_scale = ldexpf(1.0f, 14 - e);            // largest |dz| lands in [2^13, 2^14)
+      out_scale = ldexpf(1.0f, e - 14);
+    }
+  }
+  // rows of this wave's extra column tiles: wave column 0 takes row tiles 0, 1 of its row block, wave column 1 tiles 2, 3
+  const int xrow = wr * 128 + wc * 64 + i;
+  int buf = 0;
+  if (g0 < g1) wg2_dma(P, g0, lds, a_off, BIG, b_slot, HAS_EX, wave, lane);
+  __syncthreads();
+  for (int64_t g = g0; g < g1; ++g) {
+    if (g + 1 < g1) wg2_dma(P, g + 1, lds + (buf ^ 1) * kWg2BufFloats, a_off, BIG, b_slot, HAS_EX, wave, lane);
+    const float* A = lds + buf * kWg2BufFloats;
+    const float* Bm = A + 8192;
+    const float* Ex = Bm + 8192;
+#pragma unroll
+    for (int Q = 0; Q < 2; ++Q) {
+      const int sq0 = 4 * Q + 2 * hh;                          // this lane half: samples 16 Q + 8 hh .. + 7
+      half8w oh;
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {
+        const int64_t smp = g * 32 + 16 * Q + 8 * hh + m;
+        oh[m] = (smp >= lo && smp < hi) ? (_Float16)1.0f : (_Float16)0.0f;
+      }
+      if constexpr (BIG) {
+        half8w ah[4], al[4];
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) {
+          const int row = wr * 128 + rt * 32 + i;
+          frag8(A, row, row, sq0, dz_scale, ah[rt], al[rt]);
+        }
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+          const int f = (wc * 4 + ct) * 32 + i;
+          half8w bh, bl;
+          frag8(Bm, f, f, sq0, 1.0f, bh, bl);
+#pragma unroll
+          for (int rt = 0; rt < 4; ++rt) acc[rt * 4 + ct] = mfma16w(ah[rt], bh, acc[rt * 4 + ct]);
+#pragma unroll
+          for (int rt = 0; rt < 4; ++rt) acc[rt * 4 + ct] = mfma16w(ah[rt], bl, acc[rt * 4 + ct]);
+#pragma unroll
+          for (int rt = 0; rt < 4; ++rt) acc[rt * 4 + ct] = mfma16w(al[rt], bh, acc[rt * 4 + ct]);
+        }
+        // the extra column tiles re-read their two A fragments (2 of 72 LDS reads) instead of selecting among ah[]
+        half8w xh[2], xl[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) frag8(A, xrow + 32 * k, xrow + 32 * k, sq0, dz_scale, xh[k], xl[k]);
+        mfma16w_vgpr(hot[0], xh[0], oh);
+        mfma16w_vgpr(hot[1], xh[1], oh);
+        mfma16w_vgpr(hot[0], xl[0], oh);
+        mfma16w_vgpr(hot[1], xl[1], oh);
+        if constexpr (HAS_EX) {
+          half8w eh, el;
+          frag8(Ex, i, i, sq0, 1.0f, eh, el);
+          mfma16w_vgpr(ex[0], xh[0], eh);
+          mfma16w_vgpr(ex[1], xh[1], eh);
+          mfma16w_vgpr(ex[0], xh[0], el);
+          mfma16w_vgpr(ex[1], xh[1], el);
+          mfma16w_vgpr(ex[0], xl[0], eh);
+          mfma16w_vgpr(ex[1], xl[1], eh);
+        }
+      } else {
+        half8w ah, al;
+        frag8(A, i, i, sq0, dz_scale, ah, al);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const int f = (wave * 2 + c) * 32 + i;
+          half8w bh, bl;
+          frag8(Bm, f, f, sq0, 1.0f, bh, bl);
+          acc[c] = mfma16w(ah, bh, acc[c]);
+          acc[c] = mfma16w(ah, bl, acc[c]);
+          acc[c] = mfma16w(al, bh, acc[c]);
+        }
+        if (wave == 0) {
+          mfma16w_vgpr(hot[0], ah, oh);
+          mfma16w_vgpr(hot[0], al, oh);
+        }
+      }
+    }
+    __syncthreads();
+    buf ^= 1;
+  }
+  wg2_mfma_drain();
+  // partials in the layout of the 128-row kernel: chunk (item = 2 gemm + row half | 12 + narrow, slice), then
+  // [row tile within the half][column tile 0..7, 8 = one-hot, 9 = view/x][16 registers][64 lanes]
+  const int64_t chunk_floats = (int64_t)4 * kWgTiles * 1024;
+  if constexpr (BIG) {
+    float* out = P.partial + ((int64_t)(2 * gemm + wr) * P.n_w + slice) * chunk_floats;
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          out[((rt * kWgTiles + wc * 4 + ct) * 16 + r) * 64 + lane] = acc[rt * 4 + ct][r] * out_scale;
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        out[(((2 * wc + k) * kWgTiles + 8) * 16 + r) * 64 + lane] = hot[k][r] * out_scale;
+        if constexpr (HAS_EX) out[(((2 * wc + k) * kWgTiles + 9) * 16 + r) * 64 + lane] = ex[k][r] * out_scale;
+      }
+  } else {
+    float* out = P.partial + ((int64_t)12 * P.n_w + (int64_t)(gemm - 6) * P.n_n + slice) * chunk_floats;
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) out[((wave * 2 + c) * 16 + r) * 64 + lane] = acc[c][r] * out_scale;
+    if (wave == 0)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) out[(8 * 16 + r) * 64 + lane] = hot[0][r] * out_scale;
+  }
+}
+
+__global__ __launch_bounds__(kThreads, 1) void mlp_wgrad_f16x3_kernel(Wg2Params P) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n_wide = 6 * P.n_w;
+  if ((int)blockIdx.x < n_wide) {
+    const int gemm = (int)blockIdx.x % 6, slice = (int)blockIdx.x / 6;       // 0..5: mlp_trans.{2,1,0}, mlp_rgb.{2,1,0}
+    if (gemm == 5) wg2_run<true, true>(P, lds, gemm, slice, wave, lane);
+    else wg2_run<true, false>(P, lds, gemm, slice, wave, lane);
+  } else {
+    const int k = (int)blockIdx.x - n_wide;                                   // 6 = mlp_trans.3, 7 = mlp_rgb.3
+    wg2_run<false, false>(P, lds, 6 + k % 2, k / 2, wave, lane);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+enum { SEG_W = 0, SEG_DZSUM = 2 };
 struct Seg {
   float* out;
   int kind, gemm;      // gemm 0..5 wide (T2,T1,T0,R2,R1,R0), 6 = T3, 7 = R3
-  int rows, cols;      // output tensor shape ([rows] for biases; [B][n_lat] for latents)
+  int rows, cols;      // SEG_W: output tensor shape and its leading dimension in `ld`; SEG_DZSUM: [B][256]
+  int ld;
   int64_t start;       // prefix offset in the flattened element space
 };
 struct FinParams {
   Seg seg[20];
   int n_seg; int64_t total;
-  const float* partial; int n_slices; int B;
-  const float* lat_trans; const float* lat_light;   // [B,16], [B,48]
-  const float* w_t0; const float* w_r0;              // mlp_trans.0.weight [256,272], mlp_rgb.0.weight [256,334]
+  const float* partial; int n_w, n_n; int B;   // slices of the wide / narrow GEMMs
 };
 
 __device__ __forceinline__ float part_sum(const FinParams& P, int gemm, int o, int ft, int col) {
-  const int item = gemm < 6 ? 2 * gemm + (o >> 7) : 12 + (gemm - 6);
-  const int wave = gemm < 6 ? (o & 127) >> 5 : 0;
+  const bool wide = gemm < 6;
+  const int64_t chunk0 = wide ? (int64_t)(2 * gemm + (o >> 7)) * P.n_w : (int64_t)12 * P.n_w + (int64_t)(gemm - 6) * P.n_n;
+  const int ns = wide ? P.n_w : P.n_n;
+  const int wave = wide ? (o & 127) >> 5 : 0;
   const int ii = o & 31, h = (ii >> 2) & 1, r = (ii & 3) | ((ii >> 3) << 2);
-  const float* p = P.partial + ((((int64_t)item * P.n_slices) * 4 + wave) * kWgTiles + ft) * 1024 + r * 64 + h * 32 + col;
+  const float* p = P.partial + ((chunk0 * 4 + wave) * kWgTiles + ft) * 1024 + r * 64 + h * 32 + col;
   float s = 0.0f;
-#pragma unroll 6
-  for (int sl = 0; sl < P.n_slices; ++sl) s += p[(int64_t)sl * 4 * kWgTiles * 1024];   // (fixed order; 6 loads in flight)
+#pragma unroll 12
+  for (int sl = 0; sl < ns; ++sl) s += p[(int64_t)sl * 4 * kWgTiles * 1024];   // (fixed order; 12 loads in flight)
   return s;
 }
 
+// Phase 1 of the fixed-order reduction: one thread per output element sums the split-K slices.  Weight matrices get
+// their recorded-feature columns (and mlp_rgb.0 its [view enc, x] columns); the one-hot tiles become per-image sums of
+// dz, dzsum[gemm][b][o], from which phase 2 forms everything that multiplies a per-image constant.
 __global__ void mlp_wgrad_finalize(FinParams P) {
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < P.total; e += (int64_t)gridDim.x * blockDim.x) {
     int si = 0;
     while (si + 1 < P.n_seg && e >= P.seg[si + 1].start) ++si;
     const Seg& sg = P.seg[si];
     const int64_t le = e - sg.start;
-    float v = 0.0f;
     if (sg.kind == SEG_W) {
       const int o = (int)(le / sg.cols), c = (int)(le % sg.cols);
-      if (c < 256) {
-        v = part_sum(P, sg.gemm, o, c >> 5, c & 31);
-      } else if (sg.gemm == 2) {                       // mlp_trans.0: transient-latent columns
-        for (int b = 0; b < P.B; ++b) v += part_sum(P, 2, o, 8, b) * P.lat_trans[b * 16 + (c - 256)];
-      } else if (c < 286) {                            // mlp_rgb.0: [view enc, x] columns
-        v = part_sum(P, 5, o, 9, c - 256);
-      } else {                                         // mlp_rgb.0: light-latent columns
-        for (int b = 0; b < P.B; ++b) v += part_sum(P, 5, o, 8, b) * P.lat_light[b * 48 + (c - 286)];
-      }
-    } else if (sg.kind == SEG_B) {
-      for (int b = 0; b < P.B; ++b) v += part_sum(P, sg.gemm, (int)le, 8, b);
-    } else {                                             // per-image sum of dz0: [B][256] scratch for the latent rows
-      v = part_sum(P, sg.gemm, (int)(le % 256), 8, (int)(le / 256));
+      sg.out[(int64_t)o * sg.ld + c] = c < 256 ? part_sum(P, sg.gemm, o, c >> 5, c & 31) : part_sum(P, 5, o, 9, c - 256);
+    } else {
+      const int b = (int)(le / sg.cols), o = (int)(le % sg.cols);
+      sg.out[b * 256 + o] = part_sum(P, sg.gemm, o, 8, b);
     }
-    sg.out[le] = v;
   }
 }
 
-// dlat[b][c] = sum_o W0[o][col0 + c] * dzsum[b][o]: one wave per output element, lanes over o, butterfly reduction
-__global__ void mlp_latent_grad(const float* __restrict__ dzsum_t, const float* __restrict__ dzsum_r,
-                                const float* __restrict__ w_t0, const float* __restrict__ w_r0, int B,
-                                float* __restrict__ g_lat_trans, float* __restrict__ g_lat_light) {
+// Phase 2: biases (sum over images of dzsum), the latent columns of the two first-layer weights
+// (dW0[o][col0 + c] = sum_b dzsum[b][o] lat[b][c]) and the latent rows (dlat[b][c] = sum_o W0[o][col0 + c] dzsum[b][o]:
+// one wave per element, lanes over o, butterfly reduction).  Images are added in ascending order everywhere.
+struct Fin2Params {
+  const float* dzsum;                 // [8][32][256]
+  float* bias[8]; int bias_rows[8];   // gemm order of dzsum
+  float* g_w_t0; float* g_w_r0;       // mlp_trans.0.weight [256,272], mlp_rgb.0.weight [256,334] gradients
+  const float* lat_trans; const float* lat_light;   // [B,16], [B,48]
+  const float* w_t0; const float* w_r0;
+  float* g_lat_trans; float* g_lat_light;
+  int B, n_elem_blocks;
+};
+
+__global__ void mlp_wgrad_finalize2(Fin2Params P) {
+  if ((int)blockIdx.x < P.n_elem_blocks) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < 8 * 256) {
+      const int gemm = e >> 8, o = e & 255;
+      if (o >= P.bias_rows[gemm]) return;
+      const float* dz = P.dzsum + (int64_t)gemm * 32 * 256 + o;
+      float v = 0.0f;
+#pragma unroll 8
+      for (int b = 0; b < P.B; ++b) v += dz[b * 256];
+      P.bias[gemm][o] = v;
+    } else if (e < 8 * 256 + 256 * 64) {
+      const int k = e - 8 * 256, o = k >> 6, c = k & 63;
+      const bool tr = c < 16;
+      const float* dz = P.dzsum + (int64_t)(tr ? 2 : 5) * 32 * 256 + o;
+      float v = 0.0f;
+      if (tr) {
+#pragma unroll 8
+        for (int b = 0; b < P.B; ++b) v += dz[b * 256] * P.lat_trans[b * 16 + c];
+        P.g_w_t0[o * 272 + 256 + c] = v;
+      } else {
+#pragma unroll 8
+        for (int b = 0; b < P.B; ++b) v += dz[b * 256] * P.lat_light[b * 48 + (c - 16)];
+        P.g_w_r0[o * 334 + 286 + (c - 16)] = v;
+      }
+    }
+    return;
+  }
   const int lane = threadIdx.x & 63;
-  const int e = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (e >= B * 64) return;
+  const int e = ((int)blockIdx.x - P.n_elem_blocks) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (e >= P.B * 64) return;
   const int b = e / 64, c = e % 64;
   const bool tr = c < 16;
-  const float* dz = (tr ? dzsum_t : dzsum_r) + b * 256;
-  const float* w = tr ? w_t0 + 256 + c : w_r0 + 286 + (c - 16);
+  const float* dz = P.dzsum + (int64_t)(tr ? 2 : 5) * 32 * 256 + b * 256;
+  const float* w = tr ? P.w_t0 + 256 + c : P.w_r0 + 286 + (c - 16);
   const int ld = tr ? 272 : 334;
   float v = 0.0f;
 #pragma unroll
   for (int k = 0; k < 4; ++k) { const int o = lane + 64 * k; v += w[o * ld] * dz[o]; }
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-  if (lane == 0) { if (tr) g_lat_trans[b * 16 + c] = v; else g_lat_light[b * 48 + (c - 16)] = v; }
+  if (lane == 0) { if (tr) P.g_lat_trans[b * 16 + c] = v; else P.g_lat_light[b * 48 + (c - 16)] = v; }
 }
 
 int num_cus() {
@@ -407,7 +605,7 @@ extern "C" size_t tp_mlp_bwd_workspace_bytes(int64_t n_samples) {
   const int64_t ng = n_groups_of(n_samples);
   // dz record + split-K partials (sized for the largest slice count any device could ask for: 64)
   return align256((size_t)ng * kDzGroupFloats * sizeof(float)) +
-         align256((size_t)kWgItems * 64 * 4 * kWgTiles * 1024 * sizeof(float)) + align256(2 * 32 * 256 * sizeof(float)) + 256;
+         align256((size_t)kWgItems * 64 * 4 * kWgTiles * 1024 * sizeof(float)) + align256(8 * 32 * 256 * sizeof(float)) + 256;
 }
 
 extern "C" int tp_mlp_bwd(const tp_mlp_bwd_args* a, tp_stream_t stream_) {
@@ -425,7 +623,7 @@ extern "C" int tp_mlp_bwd(const tp_mlp_bwd_args* a, tp_stream_t stream_) {
   float* dz = (float*)a->workspace;
   float* partial = (float*)((char*)a->workspace + align256((size_t)ng * kDzGroupFloats * sizeof(float)));
   float* dzsum = (float*)((char*)partial + align256((size_t)kWgItems * 64 * 4 * kWgTiles * 1024 * sizeof(float)));
-  unsigned int* dz_max = (unsigned int*)((char*)dzsum + align256(2 * 32 * 256 * sizeof(float)));
+  unsigned int* dz_max = (unsigned int*)((char*)dzsum + align256(8 * 32 * 256 * sizeof(float)));
 
   const bool f16 = a->wgrad_precision == TP_MLP_F16X3;
   static unsigned long long attr_devices = 0;
@@ -433,11 +631,11 @@ extern "C" int tp_mlp_bwd(const tp_mlp_bwd_args* a, tp_stream_t stream_) {
     hipError_t e = hipFuncSetAttribute((const void*)mlp_dgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        2 * kChunkFloats * (int)sizeof(float));
     if (e == hipSuccess)
-      e = hipFuncSetAttribute((const void*)mlp_wgrad_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+      e = hipFuncSetAttribute((const void*)mlp_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                               2 * kWgBufFloats * (int)sizeof(float));
     if (e == hipSuccess)
-      e = hipFuncSetAttribute((const void*)mlp_wgrad_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              2 * kWgBufFloats * (int)sizeof(float));
+      e = hipFuncSetAttribute((const void*)mlp_wgrad_f16x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              2 * kWg2BufFloats * (int)sizeof(float));
     if (e != hipSuccess) { tp::set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
   }
   const int cus = num_cus();
@@ -460,40 +658,65 @@ extern "C" int tp_mlp_bwd(const tp_mlp_bwd_args* a, tp_stream_t stream_) {
     hipLaunchKernelGGL(mlp_dgrad_kernel, dim3((unsigned)dg_grid), dim3(kThreads), 2 * kChunkFloats * sizeof(float), stream, D);
   }
 
-  WgParams Wg;
-  Wg.saved = a->saved; Wg.dz = dz; Wg.n_samples = S; Wg.n_groups = ng; Wg.rn = (int64_t)a->R * a->N;
-  Wg.n_slices = slices_for(ng);
-  Wg.groups_per_slice = (int)((ng + Wg.n_slices - 1) / Wg.n_slices);
-  Wg.partial = partial;
-  Wg.dz_max = dz_max;
-  const unsigned wg_grid = (unsigned)((kWgItems * Wg.n_slices + 15) / 16 * 16);   // whole rounds of 2 x 8 XCDs
-  if (f16)
-    hipLaunchKernelGGL(mlp_wgrad_kernel<true>, dim3(wg_grid), dim3(kThreads), 2 * kWgBufFloats * sizeof(float), stream, Wg);
-  else
-    hipLaunchKernelGGL(mlp_wgrad_kernel<false>, dim3(wg_grid), dim3(kThreads), 2 * kWgBufFloats * sizeof(float), stream, Wg);
+  int n_w, n_n;                                  // split-K slices of the wide / narrow GEMMs (partial layout, finalize)
+  if (f16) {
+    // one workgroup per CU: 6 wide GEMMs x n_w slices + 2 narrow x n_n; a narrow group moves 36 KB against 68 KB
+    n_w = cus * 9 / 64;
+    if (n_w > 64) n_w = 64;
+    if (n_w < 1) n_w = 1;
+    n_n = (cus - 6 * n_w) / 2;
+    if (n_n > 64) n_n = 64;
+    if (n_n < 1) n_n = 1;
+    if (ng < n_w) n_w = (int)ng;
+    if (ng < n_n) n_n = (int)ng;
+    Wg2Params Wg;
+    Wg.saved = a->saved; Wg.dz = dz; Wg.dz_max = dz_max; Wg.n_samples = S; Wg.n_groups = ng; Wg.rn = (int64_t)a->R * a->N;
+    Wg.n_w = n_w; Wg.n_n = n_n;
+    Wg.gps_w = (int)((ng + n_w - 1) / n_w); Wg.gps_n = (int)((ng + n_n - 1) / n_n);
+    Wg.partial = partial;
+    hipLaunchKernelGGL(mlp_wgrad_f16x3_kernel, dim3((unsigned)(6 * n_w + 2 * n_n)), dim3(kThreads),
+                       2 * kWg2BufFloats * sizeof(float), stream, Wg);
+  } else {
+    WgParams Wg;
+    Wg.saved = a->saved; Wg.dz = dz; Wg.n_samples = S; Wg.n_groups = ng; Wg.rn = (int64_t)a->R * a->N;
+    Wg.n_slices = slices_for(ng);
+    Wg.groups_per_slice = (int)((ng + Wg.n_slices - 1) / Wg.n_slices);
+    Wg.partial = partial;
+    Wg.dz_max = dz_max;
+    n_w = n_n = Wg.n_slices;
+    const unsigned wg_grid = (unsigned)((kWgItems * Wg.n_slices + 15) / 16 * 16);   // whole rounds of 2 x 8 XCDs
+    hipLaunchKernelGGL(mlp_wgrad_kernel, dim3(wg_grid), dim3(kThreads), 2 * kWgBufFloats * sizeof(float), stream, Wg);
+  }
 
   FinParams F;
   int n = 0; int64_t off = 0;
-  auto add = [&](float* out, int kind, int gemm, int rows, int cols) {
-    F.seg[n] = Seg{out, kind, gemm, rows, cols, off};
+  auto add = [&](float* out, int kind, int gemm, int rows, int cols, int ld) {
+    F.seg[n] = Seg{out, kind, gemm, rows, cols, ld, off};
     off += (int64_t)rows * cols; ++n;
   };
   // gemm ids: 0..2 = mlp_trans.{2,1,0}, 3..5 = mlp_rgb.{2,1,0}, 6 = mlp_trans.3, 7 = mlp_rgb.3
-  add(a->g_trans_w[3], SEG_W, 6, 5, 256);  add(a->g_trans_b[3], SEG_B, 6, 5, 1);
-  add(a->g_trans_w[2], SEG_W, 0, 256, 256); add(a->g_trans_b[2], SEG_B, 0, 256, 1);
-  add(a->g_trans_w[1], SEG_W, 1, 256, 256); add(a->g_trans_b[1], SEG_B, 1, 256, 1);
-  add(a->g_trans_w[0], SEG_W, 2, 256, 272); add(a->g_trans_b[0], SEG_B, 2, 256, 1);
-  add(a->g_rgb_w[3], SEG_W, 7, 3, 256);    add(a->g_rgb_b[3], SEG_B, 7, 3, 1);
-  add(a->g_rgb_w[2], SEG_W, 3, 256, 256);  add(a->g_rgb_b[2], SEG_B, 3, 256, 1);
-  add(a->g_rgb_w[1], SEG_W, 4, 256, 256);  add(a->g_rgb_b[1], SEG_B, 4, 256, 1);
-  add(a->g_rgb_w[0], SEG_W, 5, 256, 334);  add(a->g_rgb_b[0], SEG_B, 5, 256, 1);
-  add(dzsum, SEG_DZSUM, 2, a->B, 256);
-  add(dzsum + 32 * 256, SEG_DZSUM, 5, a->B, 256);
-  F.n_seg = n; F.total = off; F.partial = partial; F.n_slices = Wg.n_slices; F.B = a->B;
-  F.lat_trans = a->lat_trans; F.lat_light = a->lat_light;
-  F.w_t0 = a->weights.trans_w[0]; F.w_r0 = a->weights.rgb_w[0];
+  add(a->g_trans_w[3], SEG_W, 6, 5, 256, 256);
+  add(a->g_trans_w[2], SEG_W, 0, 256, 256, 256);
+  add(a->g_trans_w[1], SEG_W, 1, 256, 256, 256);
+  add(a->g_trans_w[0], SEG_W, 2, 256, 256, 272);      // (latent columns: phase 2)
+  add(a->g_rgb_w[3], SEG_W, 7, 3, 256, 256);
+  add(a->g_rgb_w[2], SEG_W, 3, 256, 256, 256);
+  add(a->g_rgb_w[1], SEG_W, 4, 256, 256, 256);
+  add(a->g_rgb_w[0], SEG_W, 5, 256, 286, 334);        // recorded features + [view enc, x]
+  for (int g = 0; g < 8; ++g) add(dzsum + g * 32 * 256, SEG_DZSUM, g, a->B, g < 6 ? 256 : (g == 6 ? 5 : 3), 256);
+  F.n_seg = n; F.total = off; F.partial = partial; F.n_w = n_w; F.n_n = n_n; F.B = a->B;
   hipLaunchKernelGGL(mlp_wgrad_finalize, dim3((unsigned)((off + 255) / 256)), dim3(256), 0, stream, F);
-  hipLaunchKernelGGL(mlp_latent_grad, dim3((unsigned)((a->B * 64 + 3) / 4)), dim3(256), 0, stream, dzsum,
-                     dzsum + 32 * 256, a->weights.trans_w[0], a->weights.rgb_w[0], a->B, a->g_lat_trans, a->g_lat_light);
+
+  Fin2Params G;
+  G.dzsum = dzsum;
+  float* const biases[8] = {a->g_trans_b[2], a->g_trans_b[1], a->g_trans_b[0], a->g_rgb_b[2], a->g_rgb_b[1], a->g_rgb_b[0],
+                            a->g_trans_b[3], a->g_rgb_b[3]};
+  for (int g = 0; g < 8; ++g) { G.bias[g] = biases[g]; G.bias_rows[g] = g < 6 ? 256 : (g == 6 ? 5 : 3); }
+  G.g_w_t0 = a->g_trans_w[0]; G.g_w_r0 = a->g_rgb_w[0];
+  G.lat_trans = a->lat_trans; G.lat_light = a->lat_light;
+  G.w_t0 = a->weights.trans_w[0]; G.w_r0 = a->weights.rgb_w[0];
+  G.g_lat_trans = a->g_lat_trans; G.g_lat_light = a->g_lat_light;
+  G.B = a->B; G.n_elem_blocks = (8 * 256 + 256 * 64) / 256;
+  hipLaunchKernelGGL(mlp_wgrad_finalize2, dim3((unsigned)(G.n_elem_blocks + (a->B * 64 + 3) / 4)), dim3(256), 0, stream, G);
   return tp::check_launch("tp_mlp_bwd");
 }
