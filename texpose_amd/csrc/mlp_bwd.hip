@@ -286,28 +286,30 @@ struct Wg2Params {
   float* partial;
 };
 
-__device__ __forceinline__ void wg2_dma(const Wg2Params& P, int64_t g, float* buf, int a_off, bool big, int b_slot,
+// LDS-DMA of one group's operands, in two parts (A block; B block and view/x rows).  A wave keeps at most ~9 of these
+// 1 KB pieces in flight: with all 17 issued at once the same bytes take 1.8x as long to arrive (measured, DMA only).
+template <int PART>
+__device__ __forceinline__ void wg2_dma(const Wg2Params& P, int64_t g, float* buf, int a_off, int b_slot,
                                         bool has_ex, int wave, int lane) {
-  const float* dzg = P.dz + g * (int64_t)kDzGroupFloats + a_off;
-  const float* svg = P.saved + g * (int64_t)kSavedGroupFloats;
-  if (big) {
+  if (PART == 0) {
+    const float* dzg = P.dz + g * (int64_t)kDzGroupFloats + a_off;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const int pc = wave * 8 + k;
       __builtin_amdgcn_global_load_lds(AS1(dzg + pc * 256 + lane * 4), AS3(buf + pc * 256), 16, 0, 0);
     }
   } else {
-    __builtin_amdgcn_global_load_lds(AS1(dzg + wave * 256 + lane * 4), AS3(buf + wave * 256), 16, 0, 0);
-  }
+    const float* svg = P.saved + g * (int64_t)kSavedGroupFloats;
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const int pc = wave * 8 + k;
-    __builtin_amdgcn_global_load_lds(AS1(svg + b_slot * kBlockFloats + pc * 256 + lane * 4),
-                                     AS3(buf + 8192 + pc * 256), 16, 0, 0);
+    for (int k = 0; k < 8; ++k) {
+      const int pc = wave * 8 + k;
+      __builtin_amdgcn_global_load_lds(AS1(svg + b_slot * kBlockFloats + pc * 256 + lane * 4),
+                                       AS3(buf + 8192 + pc * 256), 16, 0, 0);
+    }
+    if (has_ex)
+      __builtin_amdgcn_global_load_lds(AS1(svg + SV_EX * kBlockFloats + wave * 256 + lane * 4),
+                                       AS3(buf + 16384 + wave * 256), 16, 0, 0);
   }
-  if (has_ex)
-    __builtin_amdgcn_global_load_lds(AS1(svg + SV_EX * kBlockFloats + wave * 256 + lane * 4),
-                                     AS3(buf + 16384 + wave * 256), 16, 0, 0);
 }
 
 // fragment of feature row `f` (its swizzle) at LDS row `row` of a [rows][32 samples] block, sample quads sq0, sq0 + 1
@@ -317,99 +319,177 @@ __device__ __forceinline__ void frag8(const float* blk, int row, int f, int sq0,
          *reinterpret_cast<const f32x4*>(blk + row * 32 + (((sq0 + 1) ^ s) << 2)), scale, hi, lo);
 }
 
-// one (GEMM, slice) of the kernel below; BIG / HAS_EX are compile-time so that each variant is a straight-line loop
-// whose accumulator tiles never change register class
-template <bool BIG, bool HAS_EX>
-__device__ __forceinline__ void wg2_run(const Wg2Params& P, float* lds, int gemm, int slice, int wave, int lane) {
+// power-of-two scaling of the gradient record from the largest |dz| of the call
+__device__ __forceinline__ void wg2_scales(const Wg2Params& P, float& dz_scale, float& out_scale) {
+  dz_scale = 1.0f; out_scale = 1.0f;
+  const float mx = __uint_as_float(*P.dz_max);
+  if (mx > 1.0e-30f && mx < 1.0e30f) {
+    int e;
+    (void)frexpf(mx, &e);                       // mx = m * 2^e, m in [0.5, 1)
+    dz_scale = ldexpf(1.0f, 14 - e);            // largest |dz| lands in [2^13, 2^14)
+    out_scale = ldexpf(1.0f, e - 14);
+  }
+}
+
+// one-hot "image id" B fragment of 8 consecutive samples starting at s0: column i is image i
+__device__ __forceinline__ half8w wg2_onehot(int64_t s0, int64_t lo, int64_t hi) {
+  half8w oh;
+#pragma unroll
+  for (int m = 0; m < 8; ++m) oh[m] = (s0 + m >= lo && s0 + m < hi) ? (_Float16)1.0f : (_Float16)0.0f;
+  return oh;
+}
+
+// A wide (256 x 256) GEMM of one sample slice; HAS_EX is compile-time so that each variant is a straight-line loop
+// whose accumulator tiles never change register class.
+template <bool HAS_EX>
+__device__ __forceinline__ void wg2_run_wide(const Wg2Params& P, float* lds, int gemm, int slice, int wave, int lane) {
   const int i = lane & 31, hh = lane >> 5;
   const int wr = wave >> 1, wc = wave & 1;
-  const int gps = BIG ? P.gps_w : P.gps_n;
-  const int a_off = BIG ? gemm * kBlockFloats : (gemm == 6 ? kDzT3Off : kDzR3Off);
-  const int b_slot = gemm == 0 ? SV_T1 : gemm == 1 ? SV_T0 : gemm == 2 ? SV_FEAT : gemm == 3 ? SV_R1 : gemm == 4 ? SV_R0
-                   : gemm == 5 ? SV_FEAT : gemm == 6 ? SV_T2 : SV_R2;
-  const int64_t g0 = (int64_t)slice * gps;
-  const int64_t g1 = g0 + gps < P.n_groups ? g0 + gps : P.n_groups;
-  constexpr int kMain = BIG ? 16 : 2, kHot = BIG ? 2 : 1, kEx = HAS_EX ? 2 : 0;
+  const int a_off = gemm * kBlockFloats;
+  const int b_slot = gemm == 0 ? SV_T1 : gemm == 1 ? SV_T0 : gemm == 2 ? SV_FEAT : gemm == 3 ? SV_R1 : gemm == 4 ? SV_R0 : SV_FEAT;
+  const int64_t g0 = (int64_t)slice * P.gps_w;
+  const int64_t g1 = g0 + P.gps_w < P.n_groups ? g0 + P.gps_w : P.n_groups;
 
-  f32x16 acc[kMain], hot[kHot], ex[HAS_EX ? 2 : 1];
+  f32x16 acc[16], hot[2], ex[2];
 #pragma unroll
-  for (int t = 0; t < kMain; ++t) acc[t] = f32x16{0};
-#pragma unroll
-  for (int t = 0; t < kHot; ++t) hot[t] = f32x16{0};
-  ex[0] = f32x16{0};
-  if constexpr (HAS_EX) ex[1] = f32x16{0};
-  (void)kEx;
+  for (int t = 0; t < 16; ++t) acc[t] = f32x16{0};
+  hot[0] = hot[1] = ex[0] = ex[1] = f32x16{0};
 
   const int64_t lo = (int64_t)i * P.rn;                       // sample range of image `i` (one-hot tile column)
   const int64_t hi = lo + P.rn < P.n_samples ? lo + P.rn : P.n_samples;
-
-  float dz_scale = 1.0f, out_scale = 1.0f;
-  {
-    const float mx = __uint_as_float(*P.dz_max);
-    if (mx > 1.0e-30f && mx < 1.0e30f) {
-      int e;
-      (void)frexpf(mx, &e);                       // mx = m * 2^e, m in [0.5, 1)
-      dz_scale = ldexpf(1.0f, 14 - e);            // largest |dz| lands in [2^13, 2^14)
-      out_scale = ldexpf(1.0f, e - 14);
-    }
-  }
+  float dz_scale, out_scale;
+  wg2_scales(P, dz_scale, out_scale);
   // rows of this wave's extra column tiles: wave column 0 takes row tiles 0, 1 of its row block, wave column 1 tiles 2, 3
   const int xrow = wr * 128 + wc * 64 + i;
   int buf = 0;
-  if (g0 < g1) wg2_dma(P, g0, lds, a_off, BIG, b_slot, HAS_EX, wave, lane);
+  if (g0 < g1) {
+    wg2_dma<0>(P, g0, lds, a_off, b_slot, HAS_EX, wave, lane);
+    wg2_dma<1>(P, g0, lds, a_off, b_slot, HAS_EX, wave, lane);
+  }
   __syncthreads();
   for (int64_t g = g0; g < g1; ++g) {
-    if (g + 1 < g1) wg2_dma(P, g + 1, lds + (buf ^ 1) * kWg2BufFloats, a_off, BIG, b_slot, HAS_EX, wave, lane);
+    float* nxt = lds + (buf ^ 1) * kWg2BufFloats;
     const float* A = lds + buf * kWg2BufFloats;
     const float* Bm = A + 8192;
     const float* Ex = Bm + 8192;
 #pragma unroll
     for (int Q = 0; Q < 2; ++Q) {
-      const int sq0 = 4 * Q + 2 * hh;                          // this lane half: samples 16 Q + 8 hh .. + 7
-      half8w oh;
-#pragma unroll
-      for (int m = 0; m < 8; ++m) {
-        const int64_t smp = g * 32 + 16 * Q + 8 * hh + m;
-        oh[m] = (smp >= lo && smp < hi) ? (_Float16)1.0f : (_Float16)0.0f;
+      if (g + 1 < g1) {                                        // next group's operands, half per sample half
+        if (Q == 0) wg2_dma<0>(P, g + 1, nxt, a_off, b_slot, HAS_EX, wave, lane);
+        else wg2_dma<1>(P, g + 1, nxt, a_off, b_slot, HAS_EX, wave, lane);
       }
-      if constexpr (BIG) {
-        half8w ah[4], al[4];
+      const int sq0 = 4 * Q + 2 * hh;                          // this lane half: samples 16 Q + 8 hh .. + 7
+      const half8w oh = wg2_onehot(g * 32 + 16 * Q + 8 * hh, lo, hi);
+      half8w ah[4], al[4];
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt) {
-          const int row = wr * 128 + rt * 32 + i;
-          frag8(A, row, row, sq0, dz_scale, ah[rt], al[rt]);
-        }
+      for (int rt = 0; rt < 4; ++rt) {
+        const int row = wr * 128 + rt * 32 + i;
+        frag8(A, row, row, sq0, dz_scale, ah[rt], al[rt]);
+      }
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) {
-          const int f = (wc * 4 + ct) * 32 + i;
-          half8w bh, bl;
-          frag8(Bm, f, f, sq0, 1.0f, bh, bl);
+      for (int ct = 0; ct < 4; ++ct) {
+        const int f = (wc * 4 + ct) * 32 + i;
+        half8w bh, bl;
+        frag8(Bm, f, f, sq0, 1.0f, bh, bl);
 #pragma unroll
-          for (int rt = 0; rt < 4; ++rt) acc[rt * 4 + ct] = mfma16w(ah[rt], bh, acc[rt * 4 + ct]);
+        for (int rt = 0; rt < 4; ++rt) acc[rt * 4 + ct] = mfma16w(ah[rt], bh, acc[rt * 4 + ct]);
 #pragma unroll
-          for (int rt = 0; rt < 4; ++rt) acc[rt * 4 + ct] = mfma16w(ah[rt], bl, acc[rt * 4 + ct]);
+        for (int rt = 0; rt < 4; ++rt) acc[rt * 4 + ct] = mfma16w(ah[rt], bl, acc[rt * 4 + ct]);
 #pragma unroll
-          for (int rt = 0; rt < 4; ++rt) acc[rt * 4 + ct] = mfma16w(al[rt], bh, acc[rt * 4 + ct]);
-        }
-        // the extra column tiles re-read their two A fragments (2 of 72 LDS reads) instead of selecting among ah[]
-        half8w xh[2], xl[2];
+        for (int rt = 0; rt < 4; ++rt) acc[rt * 4 + ct] = mfma16w(al[rt], bh, acc[rt * 4 + ct]);
+      }
+      // the extra column tiles re-read their two A fragments (2 of 72 LDS reads) instead of selecting among ah[]
+      half8w xh[2], xl[2];
 #pragma unroll
-        for (int k = 0; k < 2; ++k) frag8(A, xrow + 32 * k, xrow + 32 * k, sq0, dz_scale, xh[k], xl[k]);
-        mfma16w_vgpr(hot[0], xh[0], oh);
-        mfma16w_vgpr(hot[1], xh[1], oh);
-        mfma16w_vgpr(hot[0], xl[0], oh);
-        mfma16w_vgpr(hot[1], xl[1], oh);
-        if constexpr (HAS_EX) {
-          half8w eh, el;
-          frag8(Ex, i, i, sq0, 1.0f, eh, el);
-          mfma16w_vgpr(ex[0], xh[0], eh);
-          mfma16w_vgpr(ex[1], xh[1], eh);
-          mfma16w_vgpr(ex[0], xh[0], el);
-          mfma16w_vgpr(ex[1], xh[1], el);
-          mfma16w_vgpr(ex[0], xl[0], eh);
-          mfma16w_vgpr(ex[1], xl[1], eh);
-        }
-      } else {
+      for (int k = 0; k < 2; ++k) frag8(A, xrow + 32 * k, xrow + 32 * k, sq0, dz_scale, xh[k], xl[k]);
+      mfma16w_vgpr(hot[0], xh[0], oh);
+      mfma16w_vgpr(hot[1], xh[1], oh);
+      mfma16w_vgpr(hot[0], xl[0], oh);
+      mfma16w_vgpr(hot[1], xl[1], oh);
+      if constexpr (HAS_EX) {
+        half8w eh, el;
+        frag8(Ex, i, i, sq0, 1.0f, eh, el);
+        mfma16w_vgpr(ex[0], xh[0], eh);
+        mfma16w_vgpr(ex[1], xh[1], eh);
+        mfma16w_vgpr(ex[0], xh[0], el);
+        mfma16w_vgpr(ex[1], xh[1], el);
+        mfma16w_vgpr(ex[0], xl[0], eh);
+        mfma16w_vgpr(ex[1], xl[1], eh);
+      }
+    }
+    __syncthreads();
+    buf ^= 1;
+  }
+  wg2_mfma_drain();
+  // partials in the layout of the 128-row kernel: chunk (item = 2 gemm + row half, slice), then
+  // [row tile within the half][column tile 0..7, 8 = one-hot, 9 = view/x][16 registers][64 lanes]
+  float* out = P.partial + ((int64_t)(2 * gemm + wr) * P.n_w + slice) * ((int64_t)4 * kWgTiles * 1024);
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        out[((rt * kWgTiles + wc * 4 + ct) * 16 + r) * 64 + lane] = acc[rt * 4 + ct][r] * out_scale;
+#pragma unroll
+  for (int k = 0; k < 2; ++k)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      out[(((2 * wc + k) * kWgTiles + 8) * 16 + r) * 64 + lane] = hot[k][r] * out_scale;
+      if constexpr (HAS_EX) out[(((2 * wc + k) * kWgTiles + 9) * 16 + r) * 64 + lane] = ex[k][r] * out_scale;
+    }
+}
+
+// A narrow GEMM (output layer: 32 A rows of which 5 / 3 are real) of one sample slice: wave w owns column tiles 2w, 2w+1,
+// wave 0 also the one-hot tile.  Its step is fetch latency, not work, so it takes kNarrowGroups groups per barrier.
+constexpr int kNarrowGroups = 2;
+constexpr int kNarrowGroupFloats = 1024 + 8192;          // A [32][32] + B [256][32] of one group
+constexpr int kWg2NarrowBufFloats = kNarrowGroups * kNarrowGroupFloats;
+constexpr int kWg2LdsBytes = 2 * (kWg2BufFloats > kWg2NarrowBufFloats ? kWg2BufFloats : kWg2NarrowBufFloats) * (int)sizeof(float);
+
+// group g of a narrow GEMM into slot j of a buffer (9 pieces per wave)
+__device__ __forceinline__ void wg2_dma_narrow(const Wg2Params& P, int64_t g, float* dst, int a_off, int b_slot,
+                                               int wave, int lane) {
+  const float* dzg = P.dz + g * (int64_t)kDzGroupFloats + a_off;
+  const float* svg = P.saved + g * (int64_t)kSavedGroupFloats + b_slot * kBlockFloats;
+  __builtin_amdgcn_global_load_lds(AS1(dzg + wave * 256 + lane * 4), AS3(dst + wave * 256), 16, 0, 0);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int pc = wave * 8 + k;
+    __builtin_amdgcn_global_load_lds(AS1(svg + pc * 256 + lane * 4), AS3(dst + 1024 + pc * 256), 16, 0, 0);
+  }
+}
+
+__device__ __forceinline__ void wg2_run_narrow(const Wg2Params& P, float* lds, int gemm, int slice, int wave, int lane) {
+  const int i = lane & 31, hh = lane >> 5;
+  const int a_off = gemm == 6 ? kDzT3Off : kDzR3Off;
+  const int b_slot = gemm == 6 ? SV_T2 : SV_R2;
+  const int64_t g0 = (int64_t)slice * P.gps_n;
+  const int64_t g1 = g0 + P.gps_n < P.n_groups ? g0 + P.gps_n : P.n_groups;
+  f32x16 acc[2], hot;
+  acc[0] = acc[1] = hot = f32x16{0};
+  const int64_t lo = (int64_t)i * P.rn;
+  const int64_t hi = lo + P.rn < P.n_samples ? lo + P.rn : P.n_samples;
+  float dz_scale, out_scale;
+  wg2_scales(P, dz_scale, out_scale);
+  int buf = 0;
+#pragma unroll
+  for (int j = 0; j < kNarrowGroups; ++j)
+    if (g0 + j < g1) wg2_dma_narrow(P, g0 + j, lds + j * kNarrowGroupFloats, a_off, b_slot, wave, lane);
+  __syncthreads();
+  for (int64_t g = g0; g < g1; g += kNarrowGroups) {
+#pragma unroll
+    for (int j = 0; j < kNarrowGroups; ++j) {
+      if (g + kNarrowGroups + j < g1)                          // the next step's group j: one group's pieces at a time
+        wg2_dma_narrow(P, g + kNarrowGroups + j, lds + (buf ^ 1) * kWg2NarrowBufFloats + j * kNarrowGroupFloats, a_off,
+                       b_slot, wave, lane);
+      if (g + j >= g1) break;
+      const float* A = lds + buf * kWg2NarrowBufFloats + j * kNarrowGroupFloats;
+      const float* Bm = A + 1024;
+#pragma unroll
+      for (int Q = 0; Q < 2; ++Q) {
+        const int sq0 = 4 * Q + 2 * hh;
+        const half8w oh = wg2_onehot((g + j) * 32 + 16 * Q + 8 * hh, lo, hi);
         half8w ah, al;
         frag8(A, i, i, sq0, dz_scale, ah, al);
 #pragma unroll
@@ -422,8 +502,8 @@ __device__ __forceinline__ void wg2_run(const Wg2Params& P, float* lds, int gemm
           acc[c] = mfma16w(al, bh, acc[c]);
         }
         if (wave == 0) {
-          mfma16w_vgpr(hot[0], ah, oh);
-          mfma16w_vgpr(hot[0], al, oh);
+          mfma16w_vgpr(hot, ah, oh);
+          mfma16w_vgpr(hot, al, oh);
         }
       }
     }
@@ -431,35 +511,14 @@ __device__ __forceinline__ void wg2_run(const Wg2Params& P, float* lds, int gemm
     buf ^= 1;
   }
   wg2_mfma_drain();
-  // partials in the layout of the 128-row kernel: chunk (item = 2 gemm + row half | 12 + narrow, slice), then
-  // [row tile within the half][column tile 0..7, 8 = one-hot, 9 = view/x][16 registers][64 lanes]
-  const int64_t chunk_floats = (int64_t)4 * kWgTiles * 1024;
-  if constexpr (BIG) {
-    float* out = P.partial + ((int64_t)(2 * gemm + wr) * P.n_w + slice) * chunk_floats;
+  float* out = P.partial + ((int64_t)12 * P.n_w + (int64_t)(gemm - 6) * P.n_n + slice) * ((int64_t)4 * kWgTiles * 1024);
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt)
+  for (int c = 0; c < 2; ++c)
 #pragma unroll
-      for (int ct = 0; ct < 4; ++ct)
+    for (int r = 0; r < 16; ++r) out[((wave * 2 + c) * 16 + r) * 64 + lane] = acc[c][r] * out_scale;
+  if (wave == 0)
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          out[((rt * kWgTiles + wc * 4 + ct) * 16 + r) * 64 + lane] = acc[rt * 4 + ct][r] * out_scale;
-#pragma unroll
-    for (int k = 0; k < 2; ++k)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        out[(((2 * wc + k) * kWgTiles + 8) * 16 + r) * 64 + lane] = hot[k][r] * out_scale;
-        if constexpr (HAS_EX) out[(((2 * wc + k) * kWgTiles + 9) * 16 + r) * 64 + lane] = ex[k][r] * out_scale;
-      }
-  } else {
-    float* out = P.partial + ((int64_t)12 * P.n_w + (int64_t)(gemm - 6) * P.n_n + slice) * chunk_floats;
-#pragma unroll
-    for (int c = 0; c < 2; ++c)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) out[((wave * 2 + c) * 16 + r) * 64 + lane] = acc[c][r] * out_scale;
-    if (wave == 0)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) out[(8 * 16 + r) * 64 + lane] = hot[0][r] * out_scale;
-  }
+    for (int r = 0; r < 16; ++r) out[(8 * 16 + r) * 64 + lane] = hot[r] * out_scale;
 }
 
 __global__ __launch_bounds__(kThreads, 1) void mlp_wgrad_f16x3_kernel(Wg2Params P) {
@@ -468,11 +527,11 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_wgrad_f16x3_kernel(Wg2Params 
   const int n_wide = 6 * P.n_w;
   if ((int)blockIdx.x < n_wide) {
     const int gemm = (int)blockIdx.x % 6, slice = (int)blockIdx.x / 6;       // 0..5: mlp_trans.{2,1,0}, mlp_rgb.{2,1,0}
-    if (gemm == 5) wg2_run<true, true>(P, lds, gemm, slice, wave, lane);
-    else wg2_run<true, false>(P, lds, gemm, slice, wave, lane);
+    if (gemm == 5) wg2_run_wide<true>(P, lds, gemm, slice, wave, lane);
+    else wg2_run_wide<false>(P, lds, gemm, slice, wave, lane);
   } else {
     const int k = (int)blockIdx.x - n_wide;                                   // 6 = mlp_trans.3, 7 = mlp_rgb.3
-    wg2_run<false, false>(P, lds, 6 + k % 2, k / 2, wave, lane);
+    wg2_run_narrow(P, lds, 6 + k % 2, k / 2, wave, lane);
   }
 }
 
@@ -635,7 +694,7 @@ extern "C" int tp_mlp_bwd(const tp_mlp_bwd_args* a, tp_stream_t stream_) {
                               2 * kWgBufFloats * (int)sizeof(float));
     if (e == hipSuccess)
       e = hipFuncSetAttribute((const void*)mlp_wgrad_f16x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              2 * kWg2BufFloats * (int)sizeof(float));
+                              kWg2LdsBytes);
     if (e != hipSuccess) { tp::set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
   }
   const int cus = num_cus();
@@ -660,8 +719,9 @@ extern "C" int tp_mlp_bwd(const tp_mlp_bwd_args* a, tp_stream_t stream_) {
 
   int n_w, n_n;                                  // split-K slices of the wide / narrow GEMMs (partial layout, finalize)
   if (f16) {
-    // one workgroup per CU: 6 wide GEMMs x n_w slices + 2 narrow x n_n; a narrow group moves 36 KB against 68 KB
-    n_w = cus * 9 / 64;
+    // one workgroup per CU: 6 wide GEMMs x n_w slices + 2 narrow x n_n.  A narrow step (two groups, 72 KB) is fetch
+    // latency, a wide step (one group) mostly work: 38 + 14 slices level the two kinds on 256 CUs
+    n_w = cus * 19 / 128;
     if (n_w > 64) n_w = 64;
     if (n_w < 1) n_w = 1;
     n_n = (cus - 6 * n_w) / 2;
@@ -675,7 +735,7 @@ extern "C" int tp_mlp_bwd(const tp_mlp_bwd_args* a, tp_stream_t stream_) {
     Wg.gps_w = (int)((ng + n_w - 1) / n_w); Wg.gps_n = (int)((ng + n_n - 1) / n_n);
     Wg.partial = partial;
     hipLaunchKernelGGL(mlp_wgrad_f16x3_kernel, dim3((unsigned)(6 * n_w + 2 * n_n)), dim3(kThreads),
-                       2 * kWg2BufFloats * sizeof(float), stream, Wg);
+                       kWg2LdsBytes, stream, Wg);
   } else {
     WgParams Wg;
     Wg.saved = a->saved; Wg.dz = dz; Wg.n_samples = S; Wg.n_groups = ng; Wg.rn = (int64_t)a->R * a->N;
