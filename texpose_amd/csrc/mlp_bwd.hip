@@ -331,12 +331,43 @@ __device__ __forceinline__ void wg2_scales(const Wg2Params& P, float& dz_scale, 
   }
 }
 
-// one-hot "image id" B fragment of 8 consecutive samples starting at s0: column i is image i
-__device__ __forceinline__ half8w wg2_onehot(int64_t s0, int64_t lo, int64_t hi) {
+// one-hot "image id" B fragment of 8 consecutive samples: column i is image i, whose samples are [lo, hi).  `rel` is the
+// first sample's offset from lo clamped into int range, `len` = hi - lo likewise: sample m is inside iff
+// (unsigned)(rel + m) < (unsigned)len
+__device__ __forceinline__ int wg2_clamp_rel(int64_t d) {
+  return d < -64 ? -64 : (d > (int64_t)1 << 30 ? 1 << 30 : (int)d);
+}
+__device__ __forceinline__ half8w wg2_onehot(int rel, int len) {
   half8w oh;
 #pragma unroll
-  for (int m = 0; m < 8; ++m) oh[m] = (s0 + m >= lo && s0 + m < hi) ? (_Float16)1.0f : (_Float16)0.0f;
+  for (int m = 0; m < 8; ++m) oh[m] = (unsigned)(rel + m) < (unsigned)len ? (_Float16)1.0f : (_Float16)0.0f;
   return oh;
+}
+
+// pipeline pieces of the wide GEMM: a fragment's two raw sample quads as read from LDS, and its hi / lo fp16 operands
+// built two elements at a time (wg2_split2 step k = elements 2k, 2k+1)
+struct Raw { f32x4 q[2]; };
+struct Frag {
+  u32x4w h, l;
+  __device__ __forceinline__ half8w hi() const { return __builtin_bit_cast(half8w, h); }
+  __device__ __forceinline__ half8w lo() const { return __builtin_bit_cast(half8w, l); }
+};
+__device__ __forceinline__ void wg2_raw(const float* blk, int row, int sq0, Raw& r) {
+  const int s = (row >> 1) & 7;
+  r.q[0] = *reinterpret_cast<const f32x4*>(blk + row * 32 + ((sq0 ^ s) << 2));
+  r.q[1] = *reinterpret_cast<const f32x4*>(blk + row * 32 + (((sq0 + 1) ^ s) << 2));
+}
+// hi = round-toward-zero conversion (= the value truncated to 11 significant bits, the same operand split8 builds with a
+// mask, but one instruction for two elements), lo = value - hi (exact in fp32; v_fma_mix_f32 reads hi as fp16), rounded
+// toward zero
+__device__ __forceinline__ void wg2_split2(const Raw& r, int k, float scale, Frag& f) {
+  const float v0 = r.q[k >> 1][(2 * k) & 3] * scale, v1 = r.q[k >> 1][(2 * k + 1) & 3] * scale;
+  const unsigned int h = __builtin_bit_cast(unsigned int, __builtin_amdgcn_cvt_pkrtz(v0, v1));
+  float l0, l1;
+  asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(h), "v"(v0));
+  asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(h), "v"(v1));
+  f.h[k] = h;
+  f.l[k] = __builtin_bit_cast(unsigned int, __builtin_amdgcn_cvt_pkrtz(l0, l1));
 }
 
 // A wide (256 x 256) GEMM of one sample slice; HAS_EX is compile-time so that each variant is a straight-line loop
@@ -357,6 +388,7 @@ __device__ __forceinline__ void wg2_run_wide(const Wg2Params& P, float* lds, int
 
   const int64_t lo = (int64_t)i * P.rn;                       // sample range of image `i` (one-hot tile column)
   const int64_t hi = lo + P.rn < P.n_samples ? lo + P.rn : P.n_samples;
+  const int len = wg2_clamp_rel(hi - lo);
   float dz_scale, out_scale;
   wg2_scales(P, dz_scale, out_scale);
   // rows of this wave's extra column tiles: wave column 0 takes row tiles 0, 1 of its row block, wave column 1 tiles 2, 3
@@ -367,54 +399,88 @@ __device__ __forceinline__ void wg2_run_wide(const Wg2Params& P, float* lds, int
     wg2_dma<1>(P, g0, lds, a_off, b_slot, HAS_EX, wave, lane);
   }
   __syncthreads();
+  Frag fa[4], fan[4], fb[2], fx[2], fe;          // A (this half / the other half), B (ping-pong), extra-tile A, view/x
+  if (g0 < g1) {
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {                // (later groups get these during the previous group's second half)
+      Raw r0;
+      wg2_raw(lds, wr * 128 + rt * 32 + i, 2 * hh, r0);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) wg2_split2(r0, k, dz_scale, fa[rt]);
+    }
+  }
   for (int64_t g = g0; g < g1; ++g) {
     float* nxt = lds + (buf ^ 1) * kWg2BufFloats;
+    const int64_t gn = g + 1 < g1 ? g + 1 : g;
     const float* A = lds + buf * kWg2BufFloats;
     const float* Bm = A + 8192;
     const float* Ex = Bm + 8192;
+    // ---- software pipeline over the 8 (sample half Q, column tile ct) stages of the group ----
+    // Stage s issues 12 MFMAs (4 row tiles x {hi hi, hi lo, lo hi}) for B fragment s; between them, in program order
+    // pinned by sched_barrier, run the LDS reads of stage s + 2's B fragment and the split steps (2 elements each) of
+    // stage s + 1's B fragment, of row tile s of the second half's A fragments (stages 0-3) or of the NEXT group's
+    // first-half A fragments (stages 4-7: its A block was fetched during stages 0-3; the barrier before stage 4 says
+    // it has landed for every wave), and of the extra tiles' fragments.
+    Raw ra[2], rb[2], rx[2], re;
+    wg2_raw(Bm, wc * 128 + i, 2 * hh, rb[0]);
+    wg2_raw(Bm, wc * 128 + 32 + i, 2 * hh, rb[1]);
+    wg2_raw(A, wr * 128 + i, 4 + 2 * hh, ra[0]);
 #pragma unroll
-    for (int Q = 0; Q < 2; ++Q) {
-      if (g + 1 < g1) {                                        // next group's operands, half per sample half
-        if (Q == 0) wg2_dma<0>(P, g + 1, nxt, a_off, b_slot, HAS_EX, wave, lane);
-        else wg2_dma<1>(P, g + 1, nxt, a_off, b_slot, HAS_EX, wave, lane);
+    for (int k = 0; k < 4; ++k) wg2_split2(rb[0], k, 1.0f, fb[0]);
+    const int rel = wg2_clamp_rel(g * 32 + 8 * hh - lo);
+    half8w oh = wg2_onehot(rel, len);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const int Q = s >> 2, ct = s & 3, cur = s & 1;
+      const int sq0 = 4 * Q + 2 * hh;
+      // next group's operands, half per sample half (the last step fetches its own group again: no branch in the body)
+      if (s == 4) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
       }
-      const int sq0 = 4 * Q + 2 * hh;                          // this lane half: samples 16 Q + 8 hh .. + 7
-      const half8w oh = wg2_onehot(g * 32 + 16 * Q + 8 * hh, lo, hi);
-      half8w ah[4], al[4];
+      if (s == 0) wg2_dma<0>(P, gn, nxt, a_off, b_slot, HAS_EX, wave, lane);
+      if (s == 4) wg2_dma<1>(P, gn, nxt, a_off, b_slot, HAS_EX, wave, lane);
+      if (s + 2 < 8) wg2_raw(Bm, (wc * 4 + ((s + 2) & 3)) * 32 + i, 4 * ((s + 2) >> 2) + 2 * hh, rb[cur]);
+      if (s < 3) wg2_raw(A, wr * 128 + (s + 1) * 32 + i, 4 + 2 * hh, ra[(s + 1) & 1]);
+      if (s == 4) wg2_raw(nxt, wr * 128 + i, 2 * hh, ra[0]);
+      if (s >= 4 && s < 7) wg2_raw(nxt, wr * 128 + (s - 3) * 32 + i, 2 * hh, ra[(s + 1) & 1]);
+      if (ct == 0) { wg2_raw(A, xrow, sq0, rx[0]); wg2_raw(A, xrow + 32, sq0, rx[1]); }
+      if (HAS_EX && ct == 2) wg2_raw(Ex, i, sq0, re);
+      if (s == 4) oh = wg2_onehot(rel + 16, len);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int rt = 0; rt < 4; ++rt) {
-        const int row = wr * 128 + rt * 32 + i;
-        frag8(A, row, row, sq0, dz_scale, ah[rt], al[rt]);
+      for (int k = 0; k < 12; ++k) {
+        const int rt = k & 3, term = k >> 2;
+        const half8w av = Q == 0 ? (term < 2 ? fa[rt].hi() : fa[rt].lo()) : (term < 2 ? fan[rt].hi() : fan[rt].lo());
+        const half8w bv = term == 1 ? fb[cur].lo() : fb[cur].hi();
+        acc[rt * 4 + ct] = mfma16w(av, bv, acc[rt * 4 + ct]);
+        if (k < 4) {
+          if (s < 7) wg2_split2(rb[cur ^ 1], k, 1.0f, fb[cur ^ 1]);
+          else if (HAS_EX) wg2_split2(re, k, 1.0f, fe);
+        } else if (k < 8) {
+          if (s < 4) wg2_split2(ra[s & 1], k - 4, dz_scale, fan[s]);
+          else wg2_split2(ra[s & 1], k - 4, dz_scale, fa[s - 4]);
+        } else {
+          if (ct == 1 || ct == 2) wg2_split2(rx[ct - 1], k - 8, dz_scale, fx[ct - 1]);
+          if (HAS_EX && s == 3) wg2_split2(re, k - 8, 1.0f, fe);
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
-#pragma unroll
-      for (int ct = 0; ct < 4; ++ct) {
-        const int f = (wc * 4 + ct) * 32 + i;
-        half8w bh, bl;
-        frag8(Bm, f, f, sq0, 1.0f, bh, bl);
-#pragma unroll
-        for (int rt = 0; rt < 4; ++rt) acc[rt * 4 + ct] = mfma16w(ah[rt], bh, acc[rt * 4 + ct]);
-#pragma unroll
-        for (int rt = 0; rt < 4; ++rt) acc[rt * 4 + ct] = mfma16w(ah[rt], bl, acc[rt * 4 + ct]);
-#pragma unroll
-        for (int rt = 0; rt < 4; ++rt) acc[rt * 4 + ct] = mfma16w(al[rt], bh, acc[rt * 4 + ct]);
-      }
-      // the extra column tiles re-read their two A fragments (2 of 72 LDS reads) instead of selecting among ah[]
-      half8w xh[2], xl[2];
-#pragma unroll
-      for (int k = 0; k < 2; ++k) frag8(A, xrow + 32 * k, xrow + 32 * k, sq0, dz_scale, xh[k], xl[k]);
-      mfma16w_vgpr(hot[0], xh[0], oh);
-      mfma16w_vgpr(hot[1], xh[1], oh);
-      mfma16w_vgpr(hot[0], xl[0], oh);
-      mfma16w_vgpr(hot[1], xl[1], oh);
-      if constexpr (HAS_EX) {
-        half8w eh, el;
-        frag8(Ex, i, i, sq0, 1.0f, eh, el);
-        mfma16w_vgpr(ex[0], xh[0], eh);
-        mfma16w_vgpr(ex[1], xh[1], eh);
-        mfma16w_vgpr(ex[0], xh[0], el);
-        mfma16w_vgpr(ex[1], xh[1], el);
-        mfma16w_vgpr(ex[0], xl[0], eh);
-        mfma16w_vgpr(ex[1], xl[1], eh);
+      if (ct == 3) {                                           // the extra column tiles of this sample half
+        mfma16w_vgpr(hot[0], fx[0].hi(), oh);
+        mfma16w_vgpr(hot[1], fx[1].hi(), oh);
+        mfma16w_vgpr(hot[0], fx[0].lo(), oh);
+        mfma16w_vgpr(hot[1], fx[1].lo(), oh);
+        if constexpr (HAS_EX) {
+          mfma16w_vgpr(ex[0], fx[0].hi(), fe.hi());
+          mfma16w_vgpr(ex[1], fx[1].hi(), fe.hi());
+          mfma16w_vgpr(ex[0], fx[0].hi(), fe.lo());
+          mfma16w_vgpr(ex[1], fx[1].hi(), fe.lo());
+          mfma16w_vgpr(ex[0], fx[0].lo(), fe.hi());
+          mfma16w_vgpr(ex[1], fx[1].lo(), fe.hi());
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
     __syncthreads();
@@ -470,6 +536,7 @@ __device__ __forceinline__ void wg2_run_narrow(const Wg2Params& P, float* lds, i
   acc[0] = acc[1] = hot = f32x16{0};
   const int64_t lo = (int64_t)i * P.rn;
   const int64_t hi = lo + P.rn < P.n_samples ? lo + P.rn : P.n_samples;
+  const int len = wg2_clamp_rel(hi - lo);
   float dz_scale, out_scale;
   wg2_scales(P, dz_scale, out_scale);
   int buf = 0;
@@ -489,7 +556,7 @@ __device__ __forceinline__ void wg2_run_narrow(const Wg2Params& P, float* lds, i
 #pragma unroll
       for (int Q = 0; Q < 2; ++Q) {
         const int sq0 = 4 * Q + 2 * hh;
-        const half8w oh = wg2_onehot((g + j) * 32 + 16 * Q + 8 * hh, lo, hi);
+        const half8w oh = wg2_onehot(wg2_clamp_rel((g + j) * 32 + 16 * Q + 8 * hh - lo), len);
         half8w ah, al;
         frag8(A, i, i, sq0, dz_scale, ah, al);
 #pragma unroll
