@@ -399,6 +399,10 @@ __device__ __forceinline__ void wg2_run_wide(const Wg2Params& P, float* lds, int
     wg2_dma<1>(P, g0, lds, a_off, b_slot, HAS_EX, wave, lane);
   }
   __syncthreads();
+  // Fetch schedule from here on: the A block of group g + 2 is issued at stage 4 of group g (into the A half of the
+  // current buffer, which nobody reads after stage 3), the B block of group g + 1 at stage 0 of group g; each has a whole
+  // group to arrive, and a wave has 16-17 pieces in flight only briefly.  Waits are counted (pieces retire in order).
+  if (g0 < g1) wg2_dma<0>(P, g0 + 1 < g1 ? g0 + 1 : g0, lds + kWg2BufFloats, a_off, b_slot, HAS_EX, wave, lane);
   Frag fa[4], fan[4], fb[2], fx[2], fe;          // A (this half / the other half), B (ping-pong), extra-tile A, view/x
   if (g0 < g1) {
 #pragma unroll
@@ -411,8 +415,8 @@ __device__ __forceinline__ void wg2_run_wide(const Wg2Params& P, float* lds, int
   }
   for (int64_t g = g0; g < g1; ++g) {
     float* nxt = lds + (buf ^ 1) * kWg2BufFloats;
-    const int64_t gn = g + 1 < g1 ? g + 1 : g;
-    const float* A = lds + buf * kWg2BufFloats;
+    const int64_t gn = g + 1 < g1 ? g + 1 : g, gnn = g + 2 < g1 ? g + 2 : g1 - 1;   // (the last steps fetch again: no branch)
+    float* A = lds + buf * kWg2BufFloats;
     const float* Bm = A + 8192;
     const float* Ex = Bm + 8192;
     // ---- software pipeline over the 8 (sample half Q, column tile ct) stages of the group ----
@@ -435,17 +439,21 @@ __device__ __forceinline__ void wg2_run_wide(const Wg2Params& P, float* lds, int
       const int Q = s >> 2, ct = s & 3, cur = s & 1;
       const int sq0 = 4 * Q + 2 * hh;
       // next group's operands, half per sample half (the last step fetches its own group again: no branch in the body)
+      if (s == 0) wg2_dma<1>(P, gn, nxt, a_off, b_slot, HAS_EX, wave, lane);
       if (s == 4) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // A(g + 1) has landed once only this wave's B(g + 1) pieces are outstanding; every wave is past its last read
+        // of A(g) (the extra tiles' second-half rows were read in stage 3)
+        if (HAS_EX) asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        wg2_dma<0>(P, gnn, A, a_off, b_slot, HAS_EX, wave, lane);
       }
-      if (s == 0) wg2_dma<0>(P, gn, nxt, a_off, b_slot, HAS_EX, wave, lane);
-      if (s == 4) wg2_dma<1>(P, gn, nxt, a_off, b_slot, HAS_EX, wave, lane);
       if (s + 2 < 8) wg2_raw(Bm, (wc * 4 + ((s + 2) & 3)) * 32 + i, 4 * ((s + 2) >> 2) + 2 * hh, rb[cur]);
       if (s < 3) wg2_raw(A, wr * 128 + (s + 1) * 32 + i, 4 + 2 * hh, ra[(s + 1) & 1]);
       if (s == 4) wg2_raw(nxt, wr * 128 + i, 2 * hh, ra[0]);
       if (s >= 4 && s < 7) wg2_raw(nxt, wr * 128 + (s - 3) * 32 + i, 2 * hh, ra[(s + 1) & 1]);
-      if (ct == 0) { wg2_raw(A, xrow, sq0, rx[0]); wg2_raw(A, xrow + 32, sq0, rx[1]); }
+      if (s == 0) { wg2_raw(A, xrow, 2 * hh, rx[0]); wg2_raw(A, xrow + 32, 2 * hh, rx[1]); }
+      if (s == 3) { wg2_raw(A, xrow, 4 + 2 * hh, rx[0]); wg2_raw(A, xrow + 32, 4 + 2 * hh, rx[1]); }
       if (HAS_EX && ct == 2) wg2_raw(Ex, i, sq0, re);
       if (s == 4) oh = wg2_onehot(rel + 16, len);
       __builtin_amdgcn_sched_barrier(0);
@@ -483,7 +491,8 @@ __device__ __forceinline__ void wg2_run_wide(const Wg2Params& P, float* lds, int
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    __syncthreads();
+    asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");     // B(g + 1) landed; A(g + 2) may still be in flight
+    __builtin_amdgcn_s_barrier();
     buf ^= 1;
   }
   wg2_mfma_drain();
@@ -507,13 +516,14 @@ __device__ __forceinline__ void wg2_run_wide(const Wg2Params& P, float* lds, int
 }
 
 // A narrow GEMM (output layer: 32 A rows of which 5 / 3 are real) of one sample slice: wave w owns column tiles 2w, 2w+1,
-// wave 0 also the one-hot tile.  Its step is fetch latency, not work, so it takes kNarrowGroups groups per barrier.
-constexpr int kNarrowGroups = 2;
+// wave 0 also the one-hot tile.  Almost no work per byte, so it is a fetch stream: a ring of four group slots with three
+// groups in flight (a wave's 9 pieces per group retire in order, so the wait for the oldest is counted).
+constexpr int kNarrowSlots = 4;
 constexpr int kNarrowGroupFloats = 1024 + 8192;          // A [32][32] + B [256][32] of one group
-constexpr int kWg2NarrowBufFloats = kNarrowGroups * kNarrowGroupFloats;
+constexpr int kWg2NarrowBufFloats = kNarrowSlots * kNarrowGroupFloats / 2;
 constexpr int kWg2LdsBytes = 2 * (kWg2BufFloats > kWg2NarrowBufFloats ? kWg2BufFloats : kWg2NarrowBufFloats) * (int)sizeof(float);
 
-// group g of a narrow GEMM into slot j of a buffer (9 pieces per wave)
+// group g of a narrow GEMM into a slot (9 pieces per wave)
 __device__ __forceinline__ void wg2_dma_narrow(const Wg2Params& P, int64_t g, float* dst, int a_off, int b_slot,
                                                int wave, int lane) {
   const float* dzg = P.dz + g * (int64_t)kDzGroupFloats + a_off;
@@ -539,44 +549,48 @@ __device__ __forceinline__ void wg2_run_narrow(const Wg2Params& P, float* lds, i
   const int len = wg2_clamp_rel(hi - lo);
   float dz_scale, out_scale;
   wg2_scales(P, dz_scale, out_scale);
-  int buf = 0;
+  if (g0 < g1) {
 #pragma unroll
-  for (int j = 0; j < kNarrowGroups; ++j)
-    if (g0 + j < g1) wg2_dma_narrow(P, g0 + j, lds + j * kNarrowGroupFloats, a_off, b_slot, wave, lane);
-  __syncthreads();
-  for (int64_t g = g0; g < g1; g += kNarrowGroups) {
+    for (int j = 0; j < kNarrowSlots - 1; ++j)                // (groups past the end are fetched again: constant counts)
+      wg2_dma_narrow(P, g0 + j < g1 ? g0 + j : g1 - 1, lds + j * kNarrowGroupFloats, a_off, b_slot, wave, lane);
+  }
+  for (int64_t g = g0; g < g1; ++g) {
+    asm volatile("s_waitcnt vmcnt(18) lgkmcnt(0)" ::: "memory");       // group g landed; g + 1, g + 2 may be in flight
+    __builtin_amdgcn_s_barrier();                                      // ... for every wave, and slot g - 1 is read out
+    const int64_t gf = g + kNarrowSlots - 1 < g1 ? g + kNarrowSlots - 1 : g1 - 1;
+    wg2_dma_narrow(P, gf, lds + (int)((g - g0 + kNarrowSlots - 1) % kNarrowSlots) * kNarrowGroupFloats, a_off, b_slot, wave,
+                   lane);
+    const float* A = lds + (int)((g - g0) % kNarrowSlots) * kNarrowGroupFloats;
+    const float* Bm = A + 1024;
+    Raw ra[2], rb[2][2];                                               // all six fragments' reads in flight at once
 #pragma unroll
-    for (int j = 0; j < kNarrowGroups; ++j) {
-      if (g + kNarrowGroups + j < g1)                          // the next step's group j: one group's pieces at a time
-        wg2_dma_narrow(P, g + kNarrowGroups + j, lds + (buf ^ 1) * kWg2NarrowBufFloats + j * kNarrowGroupFloats, a_off,
-                       b_slot, wave, lane);
-      if (g + j >= g1) break;
-      const float* A = lds + buf * kWg2NarrowBufFloats + j * kNarrowGroupFloats;
-      const float* Bm = A + 1024;
+    for (int Q = 0; Q < 2; ++Q) {
+      wg2_raw(A, i, 4 * Q + 2 * hh, ra[Q]);
 #pragma unroll
-      for (int Q = 0; Q < 2; ++Q) {
-        const int sq0 = 4 * Q + 2 * hh;
-        const half8w oh = wg2_onehot(wg2_clamp_rel((g + j) * 32 + 16 * Q + 8 * hh - lo), len);
-        half8w ah, al;
-        frag8(A, i, i, sq0, dz_scale, ah, al);
+      for (int c = 0; c < 2; ++c) wg2_raw(Bm, (wave * 2 + c) * 32 + i, 4 * Q + 2 * hh, rb[Q][c]);
+    }
+    const int rel = wg2_clamp_rel(g * 32 + 8 * hh - lo);
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          const int f = (wave * 2 + c) * 32 + i;
-          half8w bh, bl;
-          frag8(Bm, f, f, sq0, 1.0f, bh, bl);
-          acc[c] = mfma16w(ah, bh, acc[c]);
-          acc[c] = mfma16w(ah, bl, acc[c]);
-          acc[c] = mfma16w(al, bh, acc[c]);
-        }
-        if (wave == 0) {
-          mfma16w_vgpr(hot, ah, oh);
-          mfma16w_vgpr(hot, al, oh);
-        }
+    for (int Q = 0; Q < 2; ++Q) {
+      Frag fa, fb;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) wg2_split2(ra[Q], k, dz_scale, fa);
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) wg2_split2(rb[Q][c], k, 1.0f, fb);
+        acc[c] = mfma16w(fa.hi(), fb.hi(), acc[c]);
+        acc[c] = mfma16w(fa.hi(), fb.lo(), acc[c]);
+        acc[c] = mfma16w(fa.lo(), fb.hi(), acc[c]);
+      }
+      if (wave == 0) {
+        const half8w oh = wg2_onehot(rel + 16 * Q, len);
+        mfma16w_vgpr(hot, fa.hi(), oh);
+        mfma16w_vgpr(hot, fa.lo(), oh);
       }
     }
-    __syncthreads();
-    buf ^= 1;
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   wg2_mfma_drain();
   float* out = P.partial + ((int64_t)12 * P.n_w + (int64_t)(gemm - 6) * P.n_n + slice) * ((int64_t)4 * kWgTiles * 1024);
 #pragma unroll
@@ -592,6 +606,11 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_wgrad_f16x3_kernel(Wg2Params 
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n_wide = 6 * P.n_w;
+#if defined(WG2_ONLY_WIDE)                      // measurement builds: one kind of workgroup alone
+  if ((int)blockIdx.x >= n_wide) return;
+#elif defined(WG2_ONLY_NARROW)
+  if ((int)blockIdx.x < n_wide) return;
+#endif
   if ((int)blockIdx.x < n_wide) {
     const int gemm = (int)blockIdx.x % 6, slice = (int)blockIdx.x / 6;       // 0..5: mlp_trans.{2,1,0}, mlp_rgb.{2,1,0}
     if (gemm == 5) wg2_run_wide<true>(P, lds, gemm, slice, wave, lane);
@@ -786,8 +805,8 @@ extern "C" int tp_mlp_bwd(const tp_mlp_bwd_args* a, tp_stream_t stream_) {
 
   int n_w, n_n;                                  // split-K slices of the wide / narrow GEMMs (partial layout, finalize)
   if (f16) {
-    // one workgroup per CU: 6 wide GEMMs x n_w slices + 2 narrow x n_n.  A narrow step (two groups, 72 KB) is fetch
-    // latency, a wide step (one group) mostly work: 38 + 14 slices level the two kinds on 256 CUs
+    // one workgroup per CU: 6 wide GEMMs x n_w slices + 2 narrow x n_n; 38 + 14 slices level the two kinds on 256 CUs
+    // (measured: 39 + 11 makes the narrow stream the tail, 36 + 20 the wide GEMMs)
     n_w = cus * 19 / 128;
     if (n_w > 64) n_w = 64;
     if (n_w < 1) n_w = 1;
