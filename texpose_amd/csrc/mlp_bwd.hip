@@ -9,16 +9,18 @@
 //     transposed weights streamed L2->LDS as the A operand): dz3 from the output activations'
 //     derivatives, then dz_l = (W_{l+1}^T dz_{l+1}) * [h_l > 0] for l = 2,1,0 of each head, written
 //     as [256 feature][32 sample] blocks (XOR-swizzled sample quads).
-//  2. mlp_wgrad_kernel -- dW_l = sum_s dz_l[:,s] in_l[:,s]^T as fp32-MFMA GEMMs whose k axis is
-//     the SAMPLE axis: both operands are lane-linear LDS copies (LDS-DMA) of the recorded blocks,
-//     fragments are conflict-free ds_read_b128 thanks to the swizzle; split-K over workgroups,
-//     128 output rows x 10 column tiles per workgroup.  Two extra column tiles ride along: a
-//     one-hot "image id" tile that yields per-image sums of dz (bias gradients, and through
-//     linearity everything that multiplies a per-image latent) and, for mlp_rgb.0, the recorded
-//     [view encoding, x] columns.
-//  3. mlp_wgrad_finalize -- fixed-order reduction of the split-K partials into the reference
-//     parameter layouts (deterministic: no float atomics); mlp_wgrad_finalize2 then forms the biases, latent columns and latent-row
-//     gradients dlat[b] = W0[:,latent cols]^T (sum_{s in b} dz0[:,s]), one wave per element.
+//  2. the weight gradient -- dW_l = sum_s dz_l[:,s] in_l[:,s]^T as MFMA GEMMs whose k axis is the SAMPLE axis: both
+//     operands are lane-linear LDS copies (LDS-DMA) of the recorded blocks, fragments are conflict-free
+//     ds_read_b128 thanks to the swizzle; split-K over workgroups.  Two extra column tiles ride along: a one-hot
+//     "image id" tile that yields per-image sums of dz (bias gradients, and through linearity everything that
+//     multiplies a per-image latent) and, for mlp_rgb.0, the recorded [view encoding, x] columns.
+//       mlp_wgrad_kernel        fp32 MFMA, records of the fp32 forward: 128 output rows x 10 column tiles per workgroup;
+//       mlp_wgrad_f16x3_kernel  split-fp16 (hi hi + hi lo + lo hi), records of the range-checked f16x3 forward: one
+//                               workgroup per whole 256 x 256 GEMM of a sample slice, software-pipelined (its header).
+//  3. mlp_wgrad_finalize -- fixed-order reduction of the split-K partials (deterministic: no float atomics): weights
+//     in the reference parameter layouts and per-image dz sums; mlp_wgrad_finalize2 then forms the biases, the latent
+//     columns of the two first-layer weights and the latent-row gradients
+//     dlat[b] = W0[:,latent cols]^T (sum_{s in b} dz0[:,s]).
 #include "mlp_mma.h"
 
 namespace {
@@ -264,8 +266,9 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_wgrad_kernel(WgParams P) {
 // (16 accumulator tiles each), so every recorded block is fetched by exactly one workgroup, an operand fragment is split
 // once per 4 tiles instead of once per tile, and LDS fragment reads per MFMA fall to a third of the 32-row-per-wave
 // layout above.  The one-hot (bias / latent) and [view enc, x] column tiles of a row block ride with one of its two waves.
-// The two output-layer GEMMs (3 and 5 rows) are narrow workgroups: 32 rows, a wave per 64 columns; they move half the
-// bytes per group, so they get proportionally fewer, longer slices.  Partials keep the layout of the kernel above.
+// The two output-layer GEMMs (3 and 5 rows) are narrow workgroups: 32 rows, a wave per 64 columns, a fetch stream with
+// almost no work; they get fewer, longer slices.  Partials keep the layout of the kernel above.  DESIGN.md section 4 K3
+// has the measurements behind each choice (fetch in two parts, pinned pipeline, counted waits).
 constexpr int kWg2BufFloats = 8192 + 8192 + 1024;
 
 // The 16 quadrant tiles fill the 256 AGPRs (the compiler's MFMA form for this kernel); the extra column tiles must not

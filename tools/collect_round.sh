@@ -1,0 +1,20 @@
+#!/bin/bash
+# GPU box: final collection of the round (all from one box and call): bench line, bench under rocprof + PMC of the forward, training kernel stats, training PMC, launch histogram
+T=r5
+mkdir -p gpurun_out/$T
+export TMPDIR=/tmp
+timeout 900 python bench.py > gpurun_out/$T/bench_full.json 2> gpurun_out/$T/bench_full.err
+bash tools/profile_mlp.sh $T > gpurun_out/$T/profile_mlp.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$T/train32 -o t -- python3 tools/train_bench.py 32 0 30 0 f16x3 > gpurun_out/$T/train32.log 2>&1
+bash tools/pmc_train.sh $T > gpurun_out/$T/pmc_train.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d gpurun_out/$T/gan4 -o t -- python3 tools/train_bench.py 4 1 12 1 f16x3 > gpurun_out/$T/gan4.log 2>&1
+python3 tools/launch_histogram.py gpurun_out/$T/gan4 > gpurun_out/$T/launch_histogram.txt 2>&1
+for i in 1 2; do python3 tools/train_bench.py 4 1 200 1 f16x3 2>&1 | tail -1; python3 tools/train_bench.py 4 0 200 1 f16x3 2>&1 | tail -1; python3 tools/train_bench.py 32 0 60 1 f16x3 2>&1 | tail -1; done > gpurun_out/$T/train_lines.txt
+python3 tools/kstats.py gpurun_out/$T/train32 wgrad dgrad mlp_fwd finalize
+cat gpurun_out/$T/train_lines.txt | cut -c1-100
+python3 - <<PY
+import json
+d=json.load(open("gpurun_out/$T/bench_full.json"))
+print(d["value"], d["ms_per_step"], d["roofline"]["kernel_ms"], d["roofline"]["frac"], d["roofline"]["traffic"])
+t=d["train"]; print(t["full_gan_loop"]["value"], t["nerf_step_b4"]["value"], t["nerf_step_b32"]["value"], t["roofline"])
+PY

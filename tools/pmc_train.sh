@@ -7,7 +7,7 @@ OUT=gpurun_out/pmct_$TAG
 mkdir -p $OUT
 for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do
   n=$(echo $c | cut -d' ' -f1)
-  rocprofv3 --pmc $c --kernel-include-regex "wgrad_kernel|dgrad_f16x3|fwd_f16x3" --output-format csv -d $OUT/$n -- python3 tools/train_bench.py 32 0 3 0 f16x3 > $OUT/$n.log 2>&1
+  rocprofv3 --pmc $c --kernel-include-regex "wgrad_f16x3|wgrad_kernel|dgrad_f16x3|fwd_f16x3" --output-format csv -d $OUT/$n -- python3 tools/train_bench.py 32 0 3 0 f16x3 > $OUT/$n.log 2>&1
 done
 python3 - "$OUT" > gpurun_out/pmc_train_$TAG.json <<'PY'
 import collections, csv, glob, json, sys
