@@ -210,23 +210,17 @@ def test_fuzz_nerf_losses_fwd_bwd(ops, case):
         assert rel_l2(a.grad, r.grad) < 2e-5
 
 
-@pytest.mark.parametrize("case", CASES)
-def test_fuzz_split_fp16_backward_equals_fp32_mfma_backward(ops, case):
-    """The same activation record (written by one f16x3 recording forward) through the fp32-MFMA backward and through
-    the split-fp16 backward: identical ReLU gates, so the two differ only by arithmetic -- they must agree to ~1e-5,
-    for random shapes (single sample, ragged tiles, up to 32 images) and cotangent magnitudes."""
+def _split_fp16_vs_fp32_backward(ops, B, R, N, seed, mag):
     from texpose_amd.graph import Graph
     from texpose_amd.options import default_options
-    rs = np.random.RandomState(900 + case)
-    B, R, N = int(rs.choice([1, 2, 5, 32])), int(rs.choice([1, 3, 17, 40])), int(rs.choice([1, 4, 31, 64]))
-    params = O.make_params(60 + case)
+    rs = np.random.RandomState(seed)
+    params = O.make_params(60 + seed % 37)
     opt = default_options(H=16, W=16, device="cuda:0")
     g = Graph(opt).to(dev())
     g.nerf.load_state_dict({**g.nerf.state_dict(), **{k: cu(v) for k, v in params.items()}})
     pts = cu(T(rs.uniform(-1.5, 1.5, size=(B, R, N, 3))))
     unit = cu(torch.nn.functional.normalize(T(rs.normal(size=(B, R, 1, 3))), dim=-1).expand(B, R, N, 3).contiguous())
     lt, ll = cu(T(rs.normal(size=(B, 16)))), cu(T(rs.normal(size=(B, 48))))
-    mag = float(10.0 ** rs.uniform(-8, 4))
     cots = [cu(T(rs.normal(size=s))) * mag for s in ((B, R, N, 3, 2), (B, R, N, 2), (B, R, N, 1))]
     packed = g.nerf.packed_weights("f16x3")
     rgb, den, unc, saved = ops.mlp_forward(packed, lt, ll, points=pts, ray_unit=unit, save=True, precision="f16x3")
@@ -236,6 +230,28 @@ def test_fuzz_split_fp16_backward_equals_fp32_mfma_backward(ops, case):
         assert torch.isfinite(a).all() and rel_l2(a, b) < 2e-5, rel_l2(a, b)
     for k in ("lat_trans", "lat_light"):
         assert rel_l2(res["f16x3"][k], res["fp32"][k]) < 2e-5
+    again = ops.mlp_backward(g.nerf, lt, ll, saved, rgb, den, unc, *cots, wgrad_precision="f16x3")
+    for a, b in zip(res["f16x3"]["params"], again["params"]):          # fixed-order split-K: bit-identical on a re-run
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_fuzz_split_fp16_backward_equals_fp32_mfma_backward(ops, case):
+    """The same activation record (written by one f16x3 recording forward) through the fp32-MFMA backward and through
+    the split-fp16 backward: identical ReLU gates, so the two differ only by arithmetic -- they must agree to ~1e-5,
+    for random shapes (single sample, ragged tiles, up to 32 images) and cotangent magnitudes.  The two weight-gradient
+    kernels also differ in everything else (128-row tiles against whole-GEMM workgroups, slice counts, one against two
+    finalize passes), so this is also the layout test of the partial sums."""
+    rs = np.random.RandomState(900 + case)
+    B, R, N = int(rs.choice([1, 2, 5, 32])), int(rs.choice([1, 3, 17, 40])), int(rs.choice([1, 4, 31, 64]))
+    _split_fp16_vs_fp32_backward(ops, B, R, N, 900 + case, float(10.0 ** rs.uniform(-8, 4)))
+
+
+@pytest.mark.parametrize("B,R,N", [(5, 257, 33), (32, 128, 16), (3, 1024, 64)])
+def test_split_fp16_backward_long_slices(ops, B, R, N):
+    """Sizes at which every workgroup of the pipelined weight gradient walks many groups (42 k - 197 k samples: 9 - 40 groups
+    per wide slice, odd and even counts, a ragged last tile, image boundaries inside a group, 32 one-hot columns)."""
+    _split_fp16_vs_fp32_backward(ops, B, R, N, 4000 + B, 1.0)
 
 
 # ------------------------------------------------------------------------------------------ K11 / K12 / K14 / K15 (f1)
