@@ -810,28 +810,38 @@ struct DgP {
 // gate bit of (tile t, register r) in the recorded ReLU sign words
 __device__ __forceinline__ bool gate(const uint32_t (&mask)[4], int t, int r) { return (mask[t >> 1] >> ((t & 1) * 16 + r)) & 1u; }
 
-__device__ __forceinline__ void convert2m(const f32x16& a, int t, int e0, const uint32_t (&mask)[4], half2v& hp, half2v& lp) {
+// `sink(t, e0, v0, v1)` receives the gated, 2^-8-scaled pair: the dz record of the layer that produced `a` is written from
+// here, i.e. from the issue gaps of the NEXT layer's MFMAs, instead of in a store-only pass between the layers
+template <class Sink>
+__device__ __forceinline__ void convert2m(const f32x16& a, int t, int e0, const uint32_t (&mask)[4], half2v& hp, half2v& lp,
+                                          Sink sink) {
   const f32x2 sc = f32x2{a[e0], a[e0 + 1]} * kInvScale;
   const float v0 = gate(mask, t, e0) ? sc.x : 0.0f, v1 = gate(mask, t, e0 + 1) ? sc.y : 0.0f;
   const float h0 = __uint_as_float(__float_as_uint(v0) & 0xFFFFE000u);
   const float h1 = __uint_as_float(__float_as_uint(v1) & 0xFFFFE000u);
   hp = __builtin_amdgcn_cvt_pkrtz(h0, h1);
   lp = __builtin_amdgcn_cvt_pkrtz(v0 - h0, v1 - h1);
+  sink(t, e0, v0, v1);
 }
-__device__ __forceinline__ Xop convert_tile_m(const f32x16& a, int t, const uint32_t (&mask)[4]) {
+template <class Sink>
+__device__ __forceinline__ Xop convert_tile_m(const f32x16& a, int t, const uint32_t (&mask)[4], Sink sink) {
   XBuild xb;
 #pragma unroll
-  for (int e = 0; e < 16; e += 2) convert2m(a, t, e, mask, xb.hp[e >> 1], xb.lp[e >> 1]);
+  for (int e = 0; e < 16; e += 2) convert2m(a, t, e, mask, xb.hp[e >> 1], xb.lp[e >> 1], sink);
   return finish(xb);
 }
 // one 256 -> 256 transposed layer: acc += W^T (gated S * 2^-8)
-__device__ __forceinline__ void part_gen16m(Pipe& p, Frag& f, f32x16 (&acc)[8], const f32x16 (&S)[8], const uint32_t (&mask)[4]) {
-  Xop X = convert_tile_m(S[0], 0, mask);
+template <class Sink>
+__device__ __forceinline__ void part_gen16m(Pipe& p, Frag& f, f32x16 (&acc)[8], const f32x16 (&S)[8], const uint32_t (&mask)[4],
+                                            Sink sink) {
+  Xop X = convert_tile_m(S[0], 0, mask, sink);
 #pragma unroll
   for (int ts = 0; ts < 8; ++ts) {
     XBuild xb;
     const auto bop = [&](int s, half8& xh, half8& xl) { xh = X.h[s]; xl = X.l[s]; };
-    const auto cvt = [&](int q) { if (ts < 7) convert2m(S[ts < 7 ? ts + 1 : 0], ts + 1, q, mask, xb.hp[q >> 1], xb.lp[q >> 1]); };
+    const auto cvt = [&](int q) {
+      if (ts < 7) convert2m(S[ts < 7 ? ts + 1 : 0], ts + 1, q, mask, xb.hp[q >> 1], xb.lp[q >> 1], sink);
+    };
     mma_wide16<2, kNumChunksT>(p, f, acc, bop, cvt);
     if (ts < 7) X = finish(xb);
   }
@@ -938,18 +948,23 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_dgrad_f16x3_kernel(DgP P) {
 #pragma unroll
       for (int t = 0; t < 8; ++t) SP[t] = f32x16{0};
       mma_wide16<1, kNumChunksT>(p, frag, SP, [&](int, half8& xh, half8& xl) { xh = dh; xl = dl; }, [](int) {});
-      finish_step(SP, m0, factor, head * 3 + 0);
       asm volatile("" ::: "memory");
-      // step 1
+      // steps 1 and 2: the dz block of the previous step is stored from inside the layer that consumes it
+      float* blk = dzg + (head * 3 + 0) * kBlockFloats;
+      const auto sink = [&](int t, int e0, float v0, float v1) {
+        const float a = live ? v0 * isc : 0.0f, b = live ? v1 * isc : 0.0f;
+        blk[t * 1024 + o16[e0]] = a;
+        blk[t * 1024 + o16[e0 + 1]] = b;
+        dzm = fmaxf(dzm, fmaxf(fabsf(a), fabsf(b)));
+      };
 #pragma unroll
       for (int t = 0; t < 8; ++t) SQ[t] = f32x16{0};
-      part_gen16m(p, frag, SQ, SP, m0);
-      finish_step(SQ, m1, factor, head * 3 + 1);
+      part_gen16m(p, frag, SQ, SP, m0, sink);
       asm volatile("" ::: "memory");
-      // step 2
+      blk = dzg + (head * 3 + 1) * kBlockFloats;
 #pragma unroll
       for (int t = 0; t < 8; ++t) SP[t] = f32x16{0};
-      part_gen16m(p, frag, SP, SQ, m1);
+      part_gen16m(p, frag, SP, SQ, m1, sink);
       finish_step(SP, m2, factor, head * 3 + 2);
       asm volatile("" ::: "memory");
     }
