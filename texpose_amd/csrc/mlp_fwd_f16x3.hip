@@ -849,10 +849,10 @@ __device__ __forceinline__ void part_gen16m(Pipe& p, Frag& f, f32x16 (&acc)[8], 
 
 __global__ __launch_bounds__(kThreads, 1) void mlp_dgrad_f16x3_kernel(DgP P) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int j = lane & 31, hh = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (uniform: record
+  const int j = lane & 31, hh = lane >> 5;                        //  addresses become an SGPR base + 32-bit lane offsets)
   Pipe p;
-  p.stream = P.packed_t; p.lds = lds; p.chunk = 0; p.buf = 0; p.wave = __builtin_amdgcn_readfirstlane(wave); p.lane = lane;
+  p.stream = P.packed_t; p.lds = lds; p.chunk = 0; p.buf = 0; p.wave = wave; p.lane = lane;
   dma_chunk(p, 0, 0);
   dma_chunk(p, 1, 1);
   __syncthreads();
