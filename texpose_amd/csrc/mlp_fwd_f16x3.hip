@@ -841,11 +841,41 @@ __device__ __forceinline__ void part_gen16m(Pipe& p, Frag& f, f32x16 (&acc)[8], 
     const auto bop = [&](int s, half8& xh, half8& xl) { xh = X.h[s]; xl = X.l[s]; };
     const auto cvt = [&](int q) {
       if (ts < 7) convert2m(S[ts < 7 ? ts + 1 : 0], ts + 1, q, mask, xb.hp[q >> 1], xb.lp[q >> 1], sink);
+      else if (q == 0) sink.flush(7);
     };
     mma_wide16<2, kNumChunksT>(p, f, acc, bop, cvt);
     if (ts < 7) X = finish(xb);
   }
 }
+
+// Where the gated dz values of a layer go (convert2m's sink): each wave transposes its [32 feature][32 sample] tile through
+// two private 4 KB LDS tiles -- 16 ds_write_b32 of this lane's sample, 4 ds_read_b128 of four consecutive samples of one
+// feature -- so that the record is written with four 16-byte stores per tile and lane instead of sixteen 4-byte ones (the
+// store path is issue-bound: ~140 cycles per store instruction) at no VALU cost.  Tile t - 1 is flushed while tile t is
+// being filled (ping-pong); LDS operations of one wave execute in order, so no wait separates fill and flush.
+struct DzSink {
+  float* stg;            // this wave's two staging tiles
+  float* blk;            // dz block of the step being recorded
+  int o4[4];             // float offsets of this lane's four 16-byte stores inside a tile's 1024 floats
+  int row0, lane;        // staging row of register 0 (4 hh) * 32 + sample j
+  bool live; float isc;
+  float* dzm;
+  __device__ __forceinline__ void flush(int t) const {
+    const float* s = stg + (t & 1) * 1024;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      __builtin_nontemporal_store(*reinterpret_cast<const f32x4*>(s + (k * 64 + lane) * 4),
+                                  reinterpret_cast<f32x4*>(blk + t * 1024 + o4[k]));
+  }
+  __device__ __forceinline__ void operator()(int t, int e0, float v0, float v1) const {
+    const float a = live ? v0 * isc : 0.0f, b = live ? v1 * isc : 0.0f;
+    float* s = stg + (t & 1) * 1024 + row0;
+    s[(8 * (e0 >> 2) + (e0 & 3)) * 32] = a;                    // register r <-> feature 8 (r >> 2) + 4 hh + (r & 3) of the tile
+    s[(8 * ((e0 + 1) >> 2) + ((e0 + 1) & 3)) * 32] = b;
+    *dzm = fmaxf(*dzm, fmaxf(fabsf(a), fabsf(b)));
+    if (e0 == 8 && t > 0) flush(t - 1);
+  }
+};
 
 __global__ __launch_bounds__(kThreads, 1) void mlp_dgrad_f16x3_kernel(DgP P) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -866,24 +896,23 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_dgrad_f16x3_kernel(DgP P) {
     const int64_t gidx = tile * 4 + wave;
     const float* sv = P.saved + gidx * (int64_t)kSavedGroupFloats;
     float* dzg = P.dz + gidx * (int64_t)kDzGroupFloats;
-    int o16[16];
-    lane_block_offsets(j, hh, o16);
     float dzm = 0.0f;
     f32x16 SP[8], SQ[8];
+    DzSink sink;
+    sink.stg = lds + kBufs * kChunkFloats + wave * 2048;
+    sink.row0 = (4 * hh) * 32 + j; sink.lane = lane; sink.live = live; sink.dzm = &dzm;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const int u = k * 64 + lane; sink.o4[k] = blk_off(u >> 3, (u & 7) * 4); }
 
-    // gate + un-scale + store one dz block; returns nothing, tracks max |dz|
-    const auto finish_step = [&](const f32x16 (&D)[8], const uint32_t (&mask)[4], float factor, int st) {
-      // (4-byte stores: the quad-transposed 16-byte form of the forward's record stores costs this kernel its
-      // spill-free register allocation -- measured 1.37 ms instead of 1.19 ms at B=32)
-      float* blk = dzg + st * kBlockFloats;
+    // gate + store the last dz block of a head (no layer follows that could carry it)
+    const auto finish_step = [&](const f32x16 (&D)[8], const uint32_t (&mask)[4]) {
 #pragma unroll
-      for (int t = 0; t < 8; ++t)
+      for (int t = 0; t < 8; ++t) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float v = (live && gate(mask, t, r)) ? D[t][r] * factor : 0.0f;
-          blk[t * 1024 + o16[r]] = v;
-          dzm = fmaxf(dzm, fabsf(v));
-        }
+        for (int r = 0; r < 16; r += 2)
+          sink(t, r, gate(mask, t, r) ? D[t][r] * kInvScale : 0.0f, gate(mask, t, r + 1) ? D[t][r + 1] * kInvScale : 0.0f);
+      }
+      sink.flush(7);
     };
     const auto load_mask = [&](int slot, uint32_t (&mask)[4]) {
       const uint32_t* mk = reinterpret_cast<const uint32_t*>(sv + kMaskOff) + (slot - 1) * 256 + lane;
@@ -921,7 +950,6 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_dgrad_f16x3_kernel(DgP P) {
         sc = ldexpf(1.0f, 6 - e);
         isc = ldexpf(1.0f, e - 6);
       }
-      const float factor = isc * kInvScale;
       // B operand of the narrow chunk: slots 8 h + j of k-step 0 = d[0..5] (lane half 0), zeros elsewhere
       half8 dh, dl;
       {
@@ -950,22 +978,18 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_dgrad_f16x3_kernel(DgP P) {
       mma_wide16<1, kNumChunksT>(p, frag, SP, [&](int, half8& xh, half8& xl) { xh = dh; xl = dl; }, [](int) {});
       asm volatile("" ::: "memory");
       // steps 1 and 2: the dz block of the previous step is stored from inside the layer that consumes it
-      float* blk = dzg + (head * 3 + 0) * kBlockFloats;
-      const auto sink = [&](int t, int e0, float v0, float v1) {
-        const float a = live ? v0 * isc : 0.0f, b = live ? v1 * isc : 0.0f;
-        blk[t * 1024 + o16[e0]] = a;
-        blk[t * 1024 + o16[e0 + 1]] = b;
-        dzm = fmaxf(dzm, fmaxf(fabsf(a), fabsf(b)));
-      };
+      sink.isc = isc;
+      sink.blk = dzg + (head * 3 + 0) * kBlockFloats;
 #pragma unroll
       for (int t = 0; t < 8; ++t) SQ[t] = f32x16{0};
       part_gen16m(p, frag, SQ, SP, m0, sink);
       asm volatile("" ::: "memory");
-      blk = dzg + (head * 3 + 1) * kBlockFloats;
+      sink.blk = dzg + (head * 3 + 1) * kBlockFloats;
 #pragma unroll
       for (int t = 0; t < 8; ++t) SP[t] = f32x16{0};
       part_gen16m(p, frag, SP, SQ, m1, sink);
-      finish_step(SP, m2, factor, head * 3 + 2);
+      sink.blk = dzg + (head * 3 + 2) * kBlockFloats;
+      finish_step(SP, m2);
       asm volatile("" ::: "memory");
     }
     for (int off = 32; off >= 1; off >>= 1) dzm = fmaxf(dzm, __shfl_xor(dzm, off, 64));
@@ -983,7 +1007,7 @@ int tp_launch_mlp_dgrad_f16x3(const tp_mlp_bwd_args* a, float* dz, unsigned int*
     for (int i = 0; i < 4; ++i) { w.w[W_RGB0 + i] = a->weights.rgb_w[i]; w.w[W_TRANS0 + i] = a->weights.trans_w[i]; }
     hipLaunchKernelGGL(packT16_kernel, dim3(512), dim3(256), 0, stream, w, (_Float16*)a->packed_t);
   }
-  constexpr int kDgLds = kBufs * kChunkFloats * 4;
+  constexpr int kDgLds = kBufs * kChunkFloats * 4 + 4 * 2048 * 4;     // weight ring + two staging tiles per wave
   static unsigned long long attr_devices = 0;
   if (tp::first_use_on_device(attr_devices)) {
     hipError_t e = hipFuncSetAttribute((const void*)mlp_dgrad_f16x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kDgLds);
