@@ -131,7 +131,7 @@ __device__ __forceinline__ void store_tile_quads(float* tile_base, const float (
   for (int g = 0; g < 4; ++g) {
     float v[4] = {h[4 * g + 0], h[4 * g + 1], h[4 * g + 2], h[4 * g + 3]};
     quad_transpose(v, (j & 1) != 0, (j & 2) != 0);
-    *reinterpret_cast<f32x4*>(tile_base + o4[g]) = f32x4{v[0], v[1], v[2], v[3]};
+    __builtin_nontemporal_store(f32x4{v[0], v[1], v[2], v[3]}, reinterpret_cast<f32x4*>(tile_base + o4[g]));   // (read once, by other kernels)
   }
 }
 
