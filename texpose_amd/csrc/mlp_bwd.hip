@@ -128,32 +128,14 @@ constexpr int kWgTiles = 10;     // 8 input-feature tiles + image one-hot tile +
 constexpr int kWgBufFloats = 4096 + 8192 + 1024;
 
 using half8w = __attribute__((ext_vector_type(8))) _Float16;
-using half2w = __attribute__((ext_vector_type(2))) __fp16;
 using u32x4w = __attribute__((ext_vector_type(4))) unsigned int;
 
-// 8 fp32 values (two sample quads) * scale -> hi + lo fp16 operands: hi = value truncated to 11 significant bits
-// (exact in fp16), lo = value - hi (exact in fp32, rounded toward zero to fp16)
-__device__ __forceinline__ void split8(const f32x4& q0, const f32x4& q1, float scale, half8w& hi, half8w& lo) {
-  const float v[8] = {q0[0] * scale, q0[1] * scale, q0[2] * scale, q0[3] * scale,
-                      q1[0] * scale, q1[1] * scale, q1[2] * scale, q1[3] * scale};
-  u32x4w hw, lw;
-#pragma unroll
-  for (int e = 0; e < 8; e += 2) {
-    const float h0 = __uint_as_float(__float_as_uint(v[e]) & 0xFFFFE000u);
-    const float h1 = __uint_as_float(__float_as_uint(v[e + 1]) & 0xFFFFE000u);
-    hw[e >> 1] = __builtin_bit_cast(unsigned int, __builtin_amdgcn_cvt_pkrtz(h0, h1));
-    lw[e >> 1] = __builtin_bit_cast(unsigned int, __builtin_amdgcn_cvt_pkrtz(v[e] - h0, v[e + 1] - h1));
-  }
-  hi = __builtin_bit_cast(half8w, hw);
-  lo = __builtin_bit_cast(half8w, lw);
-}
 __device__ __forceinline__ f32x16 mfma16w(half8w a, half8w b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
 
 struct WgParams {
   const float* saved; const float* dz;
-  const unsigned int* dz_max;   // unused
   int64_t n_samples, n_groups, rn;   // rn = samples per image (R*N)
   int n_slices, groups_per_slice;
   float* partial;
@@ -315,13 +297,6 @@ __device__ __forceinline__ void wg2_dma(const Wg2Params& P, int64_t g, float* bu
   }
 }
 
-// fragment of feature row `f` (its swizzle) at LDS row `row` of a [rows][32 samples] block, sample quads sq0, sq0 + 1
-__device__ __forceinline__ void frag8(const float* blk, int row, int f, int sq0, float scale, half8w& hi, half8w& lo) {
-  const int s = (f >> 1) & 7;
-  split8(*reinterpret_cast<const f32x4*>(blk + row * 32 + ((sq0 ^ s) << 2)),
-         *reinterpret_cast<const f32x4*>(blk + row * 32 + (((sq0 + 1) ^ s) << 2)), scale, hi, lo);
-}
-
 // power-of-two scaling of the gradient record from the largest |dz| of the call
 __device__ __forceinline__ void wg2_scales(const Wg2Params& P, float& dz_scale, float& out_scale) {
   dz_scale = 1.0f; out_scale = 1.0f;
@@ -360,8 +335,9 @@ __device__ __forceinline__ void wg2_raw(const float* blk, int row, int sq0, Raw&
   r.q[0] = *reinterpret_cast<const f32x4*>(blk + row * 32 + ((sq0 ^ s) << 2));
   r.q[1] = *reinterpret_cast<const f32x4*>(blk + row * 32 + (((sq0 + 1) ^ s) << 2));
 }
-// hi = round-toward-zero conversion (= the value truncated to 11 significant bits, the same operand split8 builds with a
-// mask, but one instruction for two elements), lo = value - hi (exact in fp32; v_fma_mix_f32 reads hi as fp16), rounded
+// 8 fp32 values (two sample quads) * scale -> hi + lo fp16 operands, two elements per step:
+// hi = round-toward-zero conversion (= the value truncated to 11 significant bits: exact in fp16, one instruction for two
+// elements), lo = value - hi (exact in fp32; v_fma_mix_f32 reads hi as fp16), rounded
 // toward zero
 __device__ __forceinline__ void wg2_split2(const Raw& r, int k, float scale, Frag& f) {
   const float v0 = r.q[k >> 1][(2 * k) & 3] * scale, v1 = r.q[k >> 1][(2 * k + 1) & 3] * scale;
@@ -831,7 +807,6 @@ extern "C" int tp_mlp_bwd(const tp_mlp_bwd_args* a, tp_stream_t stream_) {
     Wg.n_slices = slices_for(ng);
     Wg.groups_per_slice = (int)((ng + Wg.n_slices - 1) / Wg.n_slices);
     Wg.partial = partial;
-    Wg.dz_max = dz_max;
     n_w = n_n = Wg.n_slices;
     const unsigned wg_grid = (unsigned)((kWgItems * Wg.n_slices + 15) / 16 * 16);   // whole rounds of 2 x 8 XCDs
     hipLaunchKernelGGL(mlp_wgrad_kernel, dim3(wg_grid), dim3(kThreads), 2 * kWgBufFloats * sizeof(float), stream, Wg);
