@@ -814,7 +814,7 @@ __device__ __forceinline__ bool gate(const uint32_t (&mask)[4], int t, int r) { 
 // here, i.e. from the issue gaps of the NEXT layer's MFMAs, instead of in a store-only pass between the layers
 template <class Sink>
 __device__ __forceinline__ void convert2m(const f32x16& a, int t, int e0, const uint32_t (&mask)[4], half2v& hp, half2v& lp,
-                                          Sink sink) {
+                                          Sink& sink) {
   const f32x2 sc = f32x2{a[e0], a[e0 + 1]} * kInvScale;
   const float v0 = gate(mask, t, e0) ? sc.x : 0.0f, v1 = gate(mask, t, e0 + 1) ? sc.y : 0.0f;
   const float h0 = __uint_as_float(__float_as_uint(v0) & 0xFFFFE000u);
@@ -824,7 +824,7 @@ __device__ __forceinline__ void convert2m(const f32x16& a, int t, int e0, const 
   sink(t, e0, v0, v1);
 }
 template <class Sink>
-__device__ __forceinline__ Xop convert_tile_m(const f32x16& a, int t, const uint32_t (&mask)[4], Sink sink) {
+__device__ __forceinline__ Xop convert_tile_m(const f32x16& a, int t, const uint32_t (&mask)[4], Sink& sink) {
   XBuild xb;
 #pragma unroll
   for (int e = 0; e < 16; e += 2) convert2m(a, t, e, mask, xb.hp[e >> 1], xb.lp[e >> 1], sink);
@@ -833,7 +833,7 @@ __device__ __forceinline__ Xop convert_tile_m(const f32x16& a, int t, const uint
 // one 256 -> 256 transposed layer: acc += W^T (gated S * 2^-8)
 template <class Sink>
 __device__ __forceinline__ void part_gen16m(Pipe& p, Frag& f, f32x16 (&acc)[8], const f32x16 (&S)[8], const uint32_t (&mask)[4],
-                                            Sink sink) {
+                                            Sink& sink) {
   Xop X = convert_tile_m(S[0], 0, mask, sink);
 #pragma unroll
   for (int ts = 0; ts < 8; ++ts) {
@@ -841,7 +841,8 @@ __device__ __forceinline__ void part_gen16m(Pipe& p, Frag& f, f32x16 (&acc)[8], 
     const auto bop = [&](int s, half8& xh, half8& xl) { xh = X.h[s]; xl = X.l[s]; };
     const auto cvt = [&](int q) {
       if (ts < 7) convert2m(S[ts < 7 ? ts + 1 : 0], ts + 1, q, mask, xb.hp[q >> 1], xb.lp[q >> 1], sink);
-      else if (q == 0) sink.flush(7);
+      else if (q == 0) sink.flush_read(7);
+      else if (q == 8) sink.flush_store(7);
     };
     mma_wide16<2, kNumChunksT>(p, f, acc, bop, cvt);
     if (ts < 7) X = finish(xb);
@@ -852,7 +853,8 @@ __device__ __forceinline__ void part_gen16m(Pipe& p, Frag& f, f32x16 (&acc)[8], 
 // two private 4 KB LDS tiles -- 16 ds_write_b32 of this lane's sample, 4 ds_read_b128 of four consecutive samples of one
 // feature -- so that the record is written with four 16-byte stores per tile and lane instead of sixteen 4-byte ones (the
 // store path is issue-bound: ~140 cycles per store instruction) at no VALU cost.  Tile t - 1 is flushed while tile t is
-// being filled (ping-pong); LDS operations of one wave execute in order, so no wait separates fill and flush.
+// being filled (ping-pong; its reads early, its stores five callbacks later); LDS operations of one wave execute in order,
+// so no wait separates fill and flush.
 struct DzSink {
   float* stg;            // this wave's two staging tiles
   float* blk;            // dz block of the step being recorded
@@ -860,20 +862,24 @@ struct DzSink {
   int row0, lane;        // staging row of register 0 (4 hh) * 32 + sample j
   bool live; float isc;
   float* dzm;
-  __device__ __forceinline__ void flush(int t) const {
+  f32x4 hold[4];         // a flushed tile between its LDS reads and its stores (kept apart: the read latency is not waited for)
+  __device__ __forceinline__ void flush_read(int t) {
     const float* s = stg + (t & 1) * 1024;
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
-      __builtin_nontemporal_store(*reinterpret_cast<const f32x4*>(s + (k * 64 + lane) * 4),
-                                  reinterpret_cast<f32x4*>(blk + t * 1024 + o4[k]));
+    for (int k = 0; k < 4; ++k) hold[k] = *reinterpret_cast<const f32x4*>(s + (k * 64 + lane) * 4);
   }
-  __device__ __forceinline__ void operator()(int t, int e0, float v0, float v1) const {
+  __device__ __forceinline__ void flush_store(int t) const {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) __builtin_nontemporal_store(hold[k], reinterpret_cast<f32x4*>(blk + t * 1024 + o4[k]));
+  }
+  __device__ __forceinline__ void operator()(int t, int e0, float v0, float v1) {
     const float a = live ? v0 * isc : 0.0f, b = live ? v1 * isc : 0.0f;
     float* s = stg + (t & 1) * 1024 + row0;
     s[(8 * (e0 >> 2) + (e0 & 3)) * 32] = a;                    // register r <-> feature 8 (r >> 2) + 4 hh + (r & 3) of the tile
     s[(8 * ((e0 + 1) >> 2) + ((e0 + 1) & 3)) * 32] = b;
     *dzm = fmaxf(*dzm, fmaxf(fabsf(a), fabsf(b)));
-    if (e0 == 8 && t > 0) flush(t - 1);
+    if (t > 0 && e0 == 2) flush_read(t - 1);
+    if (t > 0 && e0 == 12) flush_store(t - 1);
   }
 };
 
@@ -912,7 +918,8 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_dgrad_f16x3_kernel(DgP P) {
         for (int r = 0; r < 16; r += 2)
           sink(t, r, gate(mask, t, r) ? D[t][r] * kInvScale : 0.0f, gate(mask, t, r + 1) ? D[t][r + 1] * kInvScale : 0.0f);
       }
-      sink.flush(7);
+      sink.flush_read(7);
+      sink.flush_store(7);
     };
     const auto load_mask = [&](int slot, uint32_t (&mask)[4]) {
       const uint32_t* mk = reinterpret_cast<const uint32_t*>(sv + kMaskOff) + (slot - 1) * 256 + lane;
