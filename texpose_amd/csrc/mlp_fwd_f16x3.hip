@@ -202,6 +202,9 @@ __device__ __forceinline__ void mma_wide16(Pipe& p, Frag& f, f32x16 (&acc)[8], B
     acc[t + 1] = mfma16(wl1, xh, acc[t + 1]);
     post(q);                   // VALU work that rides in the issue gaps of the six MFMAs above
     frag_step<NP>(p, f, q, l, ln);
+    // keep this pair's fragment refills HERE, two pairs ahead of their use: left alone the scheduler sinks them to just
+    // before the MFMAs that read them and every pair then waits out a full LDS latency (s_waitcnt lgkmcnt(0))
+    __builtin_amdgcn_sched_barrier(0);
   }
   TR_END(3, w);
   ring_advance<NCH>(p);
