@@ -694,14 +694,38 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_f16x3_kernel(Params P) {
 
       if (SAVE && li >= L7) {
         // activations for the backward (layout: mlp_layout.h "Training record"): post-ReLU values as fp32 + ReLU
-        // sign bits for the dgrad kernel.  Every lane takes part (16-byte stores after a quad transpose, mlp_mma.h);
-        // samples past the end of the launch record zeros (the weight-gradient GEMM contracts whole groups)
+        // sign bits for the dgrad kernel.  A lane holds 16 features of ONE sample per tile, the record keeps a feature's
+        // samples contiguous: each wave transposes its tile through LDS -- 16 ds_write_b32, 4 ds_read_b128 of four
+        // consecutive samples of one feature, 4 nontemporal 16-byte stores -- at no VALU cost (the in-register 4 x 4 lane
+        // transpose it replaces took 64 VALU per tile).  The LDS it uses are this wave's OWN input-staging slots (1 KB of
+        // each of the first four 4 KB (k-step, hi/lo) blocks of `st`), dead since the layer's asm_extra consumed them; no
+        // other wave's slots are touched, so a wave already staging the next layer's inputs is not disturbed.  The reads
+        // of tile n are issued right after its writes (LDS operations of a wave execute in order) and stored one tile
+        // later.  Every lane takes part; samples past the end of the launch record zeros (the weight-gradient GEMM
+        // contracts whole groups)
         TP_THREAD_IDS;
         float* grp = P.saved + (tile * 4 + wave) * (int64_t)kSavedGroupFloats;
         float* blk = grp + (li - L7) * kBlockFloats;
+        float* stg = reinterpret_cast<float*>(st) + wave * 256;
+        float* stg_w = stg + (4 * hh) * 32 + j;          // register r -> + (r >> 2) * 1024 + (r & 3) * 32
+        const float* stg_r = stg + lane * 4;             // unit k -> + k * 1024: feature 8 k + (lane >> 3), samples 4 (lane & 7) ..
         int o4[4];
-        lane_quad_offsets(j, hh, o4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o4[k] = blk_off(8 * k + (lane >> 3), (lane & 7) * 4);
         uint32_t* mk = reinterpret_cast<uint32_t*>(grp + kMaskOff) + (li - T0) * 256 + lane;
+        f32x4 hold[4];
+        const auto put = [&](const float (&h)[16]) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) stg_w[(r >> 2) * 1024 + (r & 3) * 32] = h[r];
+        };
+        const auto take = [&]() {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) hold[k] = *reinterpret_cast<const f32x4*>(stg_r + k * 1024);
+        };
+        const auto emit = [&](int t) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) __builtin_nontemporal_store(hold[k], reinterpret_cast<f32x4*>(blk + t * 1024 + o4[k]));
+        };
         const auto two_tiles = [&](auto w4_tag) {
           constexpr int w4 = decltype(w4_tag)::value;
           uint32_t m = 0;
@@ -712,7 +736,9 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_f16x3_kernel(Params P) {
             h0[r] = live ? fmaxf(d0[r] * kInvScale, 0.0f) : 0.0f;
             m |= (h0[r] > 0.0f ? 1u : 0u) << r;
           }
-          store_tile_quads(blk + (2 * w4) * 1024, h0, j, o4);
+          if (w4 > 0) emit(2 * w4 - 1);
+          put(h0);
+          take();
           const f32x16 d1 = asm_read_tile<EVEN, 2 * w4 + 1>();
           float h1[16];
 #pragma unroll
@@ -720,13 +746,16 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_f16x3_kernel(Params P) {
             h1[r] = live ? fmaxf(d1[r] * kInvScale, 0.0f) : 0.0f;
             m |= (h1[r] > 0.0f ? 1u : 0u) << (16 + r);
           }
-          store_tile_quads(blk + (2 * w4 + 1) * 1024, h1, j, o4);
+          emit(2 * w4);
+          put(h1);
+          take();
           if (li >= T0 && live) mk[w4 * 64] = m;
         };
         two_tiles(std::integral_constant<int, 0>{});
         two_tiles(std::integral_constant<int, 1>{});
         two_tiles(std::integral_constant<int, 2>{});
         two_tiles(std::integral_constant<int, 3>{});
+        emit(7);
       }
       if (!EVEN && li == L7) {
         // keep the trunk feature (raw accumulators of L7, set Q) for R0: T1 overwrites set Q
