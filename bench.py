@@ -364,6 +364,8 @@ def main():
     ap.add_argument("--config", choices=["c2", "c5"], default="c2",
                     help="c2 (default): BASELINE's headline workload, one 480x640x128 image per GPU and step; c5: 8 objects, "
                          "mixed 240x320 / 480x640, 256 samples per ray, 64 images (tools/eval_multi_object.py)")
+    ap.add_argument("--spawn-check", action="store_true",
+                    help="launcher self-test without a GPU: the ranks meet in a gloo all-reduce and rank 0 prints the world size")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -375,6 +377,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
         raise SystemExit("--gpus %d but the launcher started %d rank(s)" % (args.gpus, world))
+    if args.spawn_check:
+        import torch.distributed as dist
+        if world > 1:
+            dist.init_process_group("gloo")
+        t = torch.tensor([float(rank + 1)])
+        if world > 1:
+            dist.all_reduce(t)
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"spawn_check": world, "rank_sum": float(t)}))
+        return
     if args.config == "c5":
         sys.path.insert(0, os.path.join(REPO, "tools"))
         import eval_multi_object

@@ -342,9 +342,11 @@ def make_params(seed: int, width: int = 256, n_lat_trans: int = 16, n_lat_light:
 
 def mlp_forward(p: Dict[str, Tensor], points: Tensor, ray_unit: Tensor,
                 lat_trans: Tensor, lat_light: Tensor, L_3D: int = 10, L_view: int = 4,
-                skip: Sequence[int] = (4,)) -> Tuple[Tensor, Tensor, Tensor]:
+                skip: Sequence[int] = (4,), taps: Optional[Dict[str, Tensor]] = None) -> Tuple[Tensor, Tensor, Tensor]:
     """points, ray_unit [B,R,N,3]; lat_trans [B,Lt]; lat_light [B,Ll]
     -> rgb [B,R,N,3,2], density [B,R,N,2], uncert [B,R,N,1].
+    ``taps`` (tests only): filled with the detached PRE-activations of the hidden head layers, ``mlp_rgb.{0,1,2}`` /
+    ``mlp_trans.{0,1,2}`` -> [B,R,N,256] (the ReLU gates whose flips bound gradient parity).
 
     layers/nerf_static_transient_light.py:76-145.  The trunk runs without
     autograd in the reference (:87-100); here the caller decides by detaching.
@@ -371,6 +373,8 @@ def mlp_forward(p: Dict[str, Tensor], points: Tensor, ray_unit: Tensor,
     for li in range(n_rgb):
         g = torch.nn.functional.linear(g, p[f"mlp_rgb.{li}.weight"], p[f"mlp_rgb.{li}.bias"])
         if li != n_rgb - 1:
+            if taps is not None:
+                taps[f"mlp_rgb.{li}"] = g.detach()
             g = torch.relu(g)
     rgb_s = torch.sigmoid(g)
     tr = lat_trans[:, None, None, :].expand(B, R, N, lat_trans.shape[-1])
@@ -378,6 +382,8 @@ def mlp_forward(p: Dict[str, Tensor], points: Tensor, ray_unit: Tensor,
     for li in range(n_tr):
         t = torch.nn.functional.linear(t, p[f"mlp_trans.{li}.weight"], p[f"mlp_trans.{li}.bias"])
         if li != n_tr - 1:
+            if taps is not None:
+                taps[f"mlp_trans.{li}"] = t.detach()
             t = torch.relu(t)
     rgb_t = torch.sigmoid(t[..., :3])
     sigma_t = torch.nn.functional.softplus(t[..., 3])

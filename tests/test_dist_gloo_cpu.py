@@ -73,6 +73,19 @@ def _worker(rank, world, port, out_dir):
         params[0].grad = None                       # a rank without a gradient contributes zeros
     red = tdist.FlatGradAllReducer(params)
     red.reduce()
+    # step-gate words ride in the tail of the same buffer: set on every rank if set on any rank; gradients unaffected even
+    # when another element of the buffer is non-finite
+    keep = [q.grad.clone() for q in params]
+    flags = torch.tensor([1, 0, 0] if rank == 0 else [0, 7, 0], dtype=torch.int32)
+    if rank == 0:
+        params[1].grad.view(-1)[0] = float("nan")
+    red.reduce(flags=flags)
+    assert flags.tolist() == [1, 1, 0], flags
+    assert all(torch.equal(a.grad, b) for i, (a, b) in enumerate(zip(params, keep)) if i != 1)
+    for q, k in zip(params, keep):
+        q.grad = k
+    word = tdist.all_reduce_flags(torch.tensor([0, rank], dtype=torch.int32))
+    assert word.tolist() == [0, 1]
     bufs = torch.nn.Linear(2, 2)
     with torch.no_grad():
         bufs.weight.fill_(float(rank))
@@ -93,7 +106,7 @@ def test_flat_allreduce_matches_full_batch(tmp_path):
     r0 = torch.load(tmp_path / "rank0.pt")
     r1 = torch.load(tmp_path / "rank1.pt")
     full = _loss_and_grads(range(B), *_setup(), denom=float(B * P * P))
-    assert r0["nbytes"] == sum(v.numel() for _, v in full) * 4
+    assert r0["nbytes"] == (sum(v.numel() for _, v in full) + tdist.FlatGradAllReducer.FLAG_WORDS) * 4
     for i, ((name, v), g0, g1) in enumerate(zip(full, r0["grads"], r1["grads"])):
         assert torch.equal(g0, g1), name                      # identical on every rank after the collective
         if i == 0:
@@ -214,3 +227,85 @@ def test_data_parallel_trainer_glue(tmp_path):
         moved += int(not torch.equal(r0["end"][k], r0["start"][k]))
     assert moved >= n_heads + 6
     assert all(torch.equal(r0["end"][k], r0["start"][k]) for k in r0["end"] if k.startswith("nerf.mlp_feat"))
+
+
+def _guard_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    from texpose_amd.options import AttrDict, default_options
+    from texpose_amd.synthetic import training_batch
+    from texpose_amd.trainer import GanTrainer
+    tdist.init_distributed("gloo")
+    opt = default_options(H=TH, W=TH, device="cpu")
+    opt.batch_size, opt.patch_size, opt.nerf.sample_intvs = TB // world, 16, TN
+    opt.loss_weight.feat = None
+    torch.manual_seed(5)
+    graph = _oracle_backed_graph(opt)
+    graph.attach_latents(6, opt)
+    graph.train()
+    tdist.setup_data_parallel(graph, seed=7)
+    tr = GanTrainer(opt, graph, n_train=6, max_iter=10)
+    full = training_batch(TB, TH, TH, n_train=6, seed=3, device="cpu")
+    mine = tdist.shard_training_batch(full, rank, world)
+    tr.train_iteration(AttrDict(dict(mine)))                    # a clean iteration first
+    start = {k: v.detach().clone() for k, v in graph.state_dict().items()}
+    if rank == 1:
+        mine.image = mine.image.clone()
+        mine.image[0, 0, 0, 0] = float("nan")                   # only THIS rank's photometric loss is non-finite
+        mine.image[:] = float("nan")
+    raised = False
+    try:
+        tr.train_iteration(AttrDict(dict(mine)))
+    except FloatingPointError:
+        raised = True
+    # (the spectral-norm vectors move in every discriminator FORWARD, as in the reference: not an update)
+    same = all(torch.equal(v, start[k]) for k, v in graph.state_dict().items() if not k.endswith(("weight_u", "weight_v")))
+    torch.save(dict(raised=raised, untouched=same), os.path.join(out_dir, f"guard_rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_step_gate_decision_is_global(tmp_path):
+    """A non-finite loss on ONE rank: every rank raises FloatingPointError in the same iteration, before any gradient
+    all-reduce or optimiser step -- nobody is left waiting in a collective, no rank applies gradients another one dropped."""
+    world = 2
+    mp.spawn(_guard_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        res = torch.load(tmp_path / f"guard_rank{r}.pt")
+        assert res["raised"] and res["untouched"], (r, res)
+
+
+def test_shard_training_batch_slices_only_per_sample_entries():
+    from texpose_amd.options import AttrDict
+    B = 3
+    var = AttrDict(idx=torch.arange(B), image=torch.zeros(B, 3, 4, 4), intr=torch.zeros(B, 3, 3), pose=torch.zeros(B, 3, 4),
+                   pose_anchor=torch.ones(B, 3, 4), K_shared=torch.eye(3), note="x")
+    out = tdist.shard_training_batch(var, 1, 3)
+    assert out.idx.tolist() == [1] and out.image.shape[0] == 1 and out.intr.shape == (1, 3, 3)
+    assert out.pose_anchor.shape == (B, 3, 4) and out.K_shared.shape == (3, 3) and out.note == "x"    # passed through whole
+    with pytest.raises(ValueError):
+        tdist.shard_training_batch(AttrDict(idx=torch.arange(B), image=torch.zeros(B + 1, 3, 4, 4)), 0, 3)
+
+
+def test_graphed_trainer_selects_two_graphs_and_eager_collectives_for_several_ranks(monkeypatch):
+    """What `world > 1` selects in GraphedGanTrainer (host logic, no GPU): the two-graph form with the gradient all-reduces
+    issued eagerly between the replays; TP_COLLECTIVES_IN_GRAPH is off unless set; a single rank keeps one graph."""
+    from texpose_amd.options import default_options
+    from texpose_amd.graph import Graph
+    from texpose_amd.trainer import GraphedGanTrainer
+    for var in ("TP_COLLECTIVES_IN_GRAPH", "TP_SPLIT_GRAPH", "TP_NO_BRANCH_OVERLAP"):
+        monkeypatch.delenv(var, raising=False)
+    opt = default_options(H=32, W=32, device="cpu")
+    opt.loss_weight.feat = opt.loss_weight.gan_nerf = None
+    opt.gan = None
+    g = Graph(opt)
+    g.attach_latents(4, opt)
+    tr = GraphedGanTrainer(opt, g, n_train=4)
+    assert os.environ.get("TP_COLLECTIVES_IN_GRAPH") is None
+    assert not tr._split_around_collectives() and not tr._has_collective()          # one rank: one graph, no collective
+    monkeypatch.setattr(tdist.FlatGradAllReducer, "world_size", property(lambda self: 2))
+    assert tr._has_collective() and tr._split_around_collectives()                   # several ranks: A | reduce | B
+    monkeypatch.setenv("TP_COLLECTIVES_IN_GRAPH", "1")
+    assert tr._has_collective() and not tr._split_around_collectives()               # opt-in only

@@ -263,3 +263,161 @@ def test_online_box_range_vs_stored_map_pipeline_g16():
                     assert float(d.max()) < 4e-2 and float(d.median()) < 1.5e-3 and float((d > 1.5e-2).float().mean()) < 0.01, stats
                 else:
                     assert float(d.max()) < 8e-2 and float(d.median()) < 8e-3 and float((d > 1.5e-2).float().mean()) < 0.10, stats
+
+
+# ------------------------------------------------------------------------------------------ C1 at its literal size
+def _g17_graph(g, prec):
+    from texpose_amd.graph import Graph
+    from texpose_amd.options import default_options
+    opt = default_options(H=g["H"], W=g["W"], device="cuda:0")
+    opt.nerf.sample_intvs, opt.batch_size, opt.patch_size = g["N"], 1, 64
+    opt.data.image_size = [g["H"], g["W"]]
+    graph = Graph(opt).to(dev())
+    graph.nerf.load_state_dict({**graph.nerf.state_dict(), **{k: cu(v) for k, v in O.make_params(g["seed_w"]).items()}})
+    graph.attach_latents(g["n_train"], opt)
+    ers = np.random.RandomState(g["emb_seed"])
+    with torch.no_grad():
+        graph.latent_vars_trans.weight.copy_(torch.from_numpy(ers.normal(size=(g["n_train"], 16)).astype(np.float32)))
+        graph.latent_vars_light.weight.copy_(torch.from_numpy(ers.normal(size=(g["n_train"], 48)).astype(np.float32)))
+    graph.nerf.precision = graph.nerf.train_precision = prec
+    return graph, opt
+
+
+PER_RAY = ("rgb", "rgb_static", "rgb_transient", "depth", "opacity", "opacity_static", "opacity_transient", "uncert")
+
+
+def test_c1_literal_size_vs_reference_g17():
+    """BASELINE config C1 as written -- LineMOD-Duck-like 64x64 crop, 32 samples per ray, batch 1 -- on the HIP path against
+    the render of the REAL reference at that size (golden G17, tests/golden/make_golden_g17_c1.py):
+      (a) the reference's own rays / stratified depths / latent rows through the HIP MLP + composite: all 4,096 x 14 per-ray
+          values at rtol 1e-4 / atol 1e-6, density and both alphas at rel-L2 1e-4, both MLP arithmetics, train and val;
+      (b) the whole product path from intrinsics and pose: Graph.render_by_slices(mode='val') of all 4,096 pixels and
+          Graph.render(mode='train') at the amplified from-intrinsics bound (ray-gen ulp census: test_gpu_parity)."""
+    from texpose_amd import ops
+    g = load_golden("g17_c1_literal")
+    H, W, N = g["H"], g["W"], g["N"]
+    assert (H, W, N) == (64, 64, 32)
+    mid = ((torch.arange(N, dtype=torch.float32) + 0.5) / N)
+    for prec in ("fp32", "f16x3"):
+        graph, opt = _g17_graph(g, prec)
+        # ---- (a) identical rays
+        lt, ll = cu(g["train_in_lat_t"]), cu(g["train_in_lat_l"])
+        with torch.no_grad():
+            rgb_s, den_s, unc_s = graph.nerf.forward_samples(opt, cu(g["train_in_center"]), cu(g["train_in_ray"]), cu(g["train_in_depth"]),
+                                                             latent_variable_trans=lt, latent_variable_light=ll, mode="train")
+            out = graph.nerf.composite(opt, cu(g["train_in_ray"]), rgb_s, den_s, cu(g["train_in_depth"]), unc_s)
+        got = dict(zip(PER_RAY[:7], out[:7]), uncert=out[8])
+        for k in PER_RAY:
+            torch.testing.assert_close(got[k].cpu(), g["train_" + k], **RAY)
+        assert rel_l2(den_s, g["train_density"]) < 1e-4
+        assert rel_l2(out[9], g["train_alpha_static"]) < 1e-4 and rel_l2(out[10], g["train_alpha_transient"]) < 1e-4
+        # val: mid-point depths of the gathered bounds, the reference's rays
+        near, far = g["z_near"][:, :, None], g["z_far"][:, :, None]
+        depth = (near + (far - near) * mid)[..., None]                 # same expression order as sample_depth: (0.5+i)/N*(f-n)+n
+        depth = ((mid * (far - near)) + near)[..., None].contiguous()
+        with torch.no_grad():
+            rgb_s, den_s, unc_s = graph.nerf.forward_samples(opt, cu(g["val_in_center"]), cu(g["val_in_ray"]), cu(depth),
+                                                             latent_variable_trans=cu(g["val_in_lat_t"]),
+                                                             latent_variable_light=cu(g["val_in_lat_l"]), mode="val")
+            out = graph.nerf.composite(opt, cu(g["val_in_ray"]), rgb_s, den_s, cu(depth), unc_s)
+        got = dict(zip(PER_RAY[:7], out[:7]), uncert=out[8])
+        for k in PER_RAY:
+            torch.testing.assert_close(got[k].cpu(), g["val_" + k], **RAY)
+        # ---- (b) the product path from intrinsics / pose
+        dr = (cu(g["z_near"])[:, :, None], cu(g["z_far"])[:, :, None])
+        opt.nerf.sample_stratified = False
+        with torch.no_grad():
+            val = graph.render_by_slices(opt, cu(g["pose"]), intr=cu(g["intr"]), depth_range=dr, object_mask=torch.ones(1, H, W, device=dev()),
+                                         sample_idx=None, mode="val")
+        assert val.rgb.shape == (1, H * W, 3) and val.density.shape == (1, H * W, N, 2)
+        for k in PER_RAY:
+            torch.testing.assert_close(val[k].cpu(), g["val_" + k], rtol=5e-3, atol=5e-4)
+            assert rel_l2(val[k], g["val_" + k]) < 2e-4, (k, rel_l2(val[k], g["val_" + k]))
+        # train mode from coordinates: the reference's stratified depths are reproduced by injecting its uniforms, recovered
+        # from its depths:  z = (u + i) / N * (far - near) + near
+        c, r, zn, zf, _ = ops.raygen(cu(g["intr"]), cu(g["pose"]), H=H, W=W, coords=cu(g["coords"]), z_near=cu(g["z_near"]), z_far=cu(g["z_far"]))
+        u = ((cu(g["train_in_depth"])[..., 0] - zn[..., None]) / (zf - zn)[..., None] * N - torch.arange(N, device=dev())).clamp(0, 1 - 1e-7)
+        ret = graph.render(opt, cu(g["pose"]), intr=cu(g["intr"]), ray_idx=cu(g["coords"]), depth_range=dr, sample_idx=cu(g["sample_idx"]),
+                           mode="train", rand=u[..., None].contiguous())
+        for k in PER_RAY:
+            assert rel_l2(ret[k], g["train_" + k]) < 2e-3, (k, rel_l2(ret[k], g["train_" + k]))
+        ops.check_mlp_status(dev())
+
+
+# ------------------------------------------------------------------------------------------ C5 through its entry point
+def test_c5_entry_point_two_objects_mixed_resolution():
+    """tools/eval_multi_object.py (BASELINE C5: independent object models, alternating 240x320 / 480x640 images) on one GPU
+    with two objects x two images at 16 samples per ray: every image the entry point renders is bit-identical to the same
+    object's single-image render (own Graph, own call), objects differ from each other, the line carries per-object and
+    aggregate rays / s and the MLP roofline."""
+    import itertools
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import eval_multi_object as E
+    from texpose_amd import graph as graph_mod
+    torch.manual_seed(11)
+    n_obj, n_img, N = 2, 2, 16
+    graph_mod._philox_calls = itertools.count()
+    line, outs = E.measure(dev(), 0, 1, n_objects=n_obj, images_per_object=n_img, n_samples=N, warm=0, steps=1, keep_outputs=True)
+    assert line["config"]["global_batch"] == n_obj * n_img and len(line["per_object"]) == n_obj
+    rays_obj = 240 * 320 + 480 * 640
+    assert line["config"]["rays_per_object"] == rays_obj
+    assert abs(line["value"] - n_obj * rays_obj / (line["ms_per_step"] * 1e-3)) < 1e-6 * line["value"]
+    assert all(p["rays_per_s"] > 0 for p in line["per_object"]) and 0 < line["roofline"]["frac"] < 1
+    assert line["roofline"]["samples_all_ranks"] == n_obj * rays_obj * N
+    # the same images one by one, each through a freshly built Graph; the stratified jitter is a counter-based Philox stream:
+    # replay the entry point's call order
+    graph_mod._philox_calls = itertools.count()
+    for o in range(n_obj):
+        for i in range(n_img):
+            g, opts = E.build_object(o, dev(), N)
+            im = E.build_image(o, i, dev())
+            assert (im["H"], im["W"]) == ((240, 320) if i % 2 == 0 else (480, 640))
+            single = E.render_image(g, opts, im)
+            got = outs[o][i]
+            assert got.rgb.shape == (1, im["H"] * im["W"], 3)
+            for k in ("rgb", "rgb_static", "depth", "uncert", "density", "alpha_static"):
+                assert torch.equal(got[k], single[k]), (o, i, k)
+    assert not torch.equal(outs[0][0].rgb, outs[1][0].rgb)
+
+
+# ------------------------------------------------------------------------------------------ resume across trainer kinds
+def test_optimizer_state_loads_between_eager_and_captured_trainers():
+    """`Optimizer.load_state_dict` takes `capturable` and the step counters from the SAVED state, so an eager
+    (or reference) checkpoint left the captured trainer with capturable=False / CPU step tensors and the capture failed.
+    Save from an eager trainer -> restore into GraphedGanTrainer -> capture + step; and the reverse direction."""
+    from texpose_amd.options import AttrDict
+    from texpose_amd.synthetic import training_batch
+    from texpose_amd.trainer import FusedAdam
+    batch = training_batch(4, 128, 128, n_train=189, seed=5, device="cuda:0")
+    _, g_e, eager = _c3(False)
+    for _ in range(2):
+        eager.train_iteration(AttrDict(dict(batch)))
+    sd_n, sd_d = eager.optim_nerf.state_dict(), eager.optim_disc.state_dict()
+    assert sd_n["param_groups"][0]["capturable"] is False
+    _, g_g, graphed = _c3(True)
+    g_g.load_state_dict(g_e.state_dict())
+    graphed.load_optim_state(optim_nerf=sd_n, optim_disc=sd_d)
+    assert all(g["capturable"] for g in graphed.optim_nerf.param_groups + graphed.optim_disc.param_groups)
+    steps = [st["step"] for st in graphed.optim_nerf.state.values()]
+    assert steps and all(s.is_cuda and s.dtype == torch.float32 and float(s) == 2.0 for s in steps)
+    assert isinstance(graphed.optim_nerf, FusedAdam)
+    w0 = g_g.nerf.mlp_rgb[1].weight.detach().clone()
+    for _ in range(2):
+        _, loss = graphed.train_iteration(AttrDict(dict(batch)))
+    assert all(np.isfinite(float(v)) for v in loss.values())
+    assert not torch.equal(g_g.nerf.mlp_rgb[1].weight, w0)
+    assert all(float(st["step"]) == 4.0 for st in graphed.optim_nerf.state.values())
+    # loading into an already captured trainer re-captures (the moments are new tensors)
+    graphed.load_optim_state(optim_nerf=graphed.optim_nerf.state_dict(), optim_disc=graphed.optim_disc.state_dict())
+    assert graphed._graph is None
+    graphed.train_iteration(AttrDict(dict(batch)))
+    # reverse: captured -> eager
+    _, g_e2, eager2 = _c3(False)
+    g_e2.load_state_dict(g_g.state_dict())
+    eager2.load_optim_state(optim_nerf=graphed.optim_nerf.state_dict(), optim_disc=graphed.optim_disc.state_dict())
+    assert not any(g["capturable"] for g in eager2.optim_nerf.param_groups)
+    _, loss = eager2.train_iteration(AttrDict(dict(batch)))
+    assert all(np.isfinite(float(v)) for v in loss.values() if torch.is_tensor(v))
+    assert all(float(st["step"]) == 6.0 for st in eager2.optim_nerf.state.values())

@@ -294,6 +294,7 @@ def test_mlp_backward_vs_oracle_autograd(ops, B, R, N, train_precision):
     ~1e-3 in rel-L2.  The reference's own fp32-vs-fp64 gap on mlp_rgb.0.weight is 6e-4 on these inputs
     (profiles/r1/03_bwd_noise_vs_fp64.txt, tests/diag/diag_bwd_noise.py), so 1e-3 is not attainable by any fp32 path."""
     GRAD_TOL = 5e-3
+    OUTPUT_LAYER_TOL = 1e-5
     rs = np.random.RandomState(7 * B + R)
     params = O.make_params(21)
     g, opt = _graph(params, N=N)
@@ -320,7 +321,9 @@ def test_mlp_backward_vs_oracle_autograd(ops, B, R, N, train_precision):
         if k.startswith("mlp_feat") or k == "progress":
             assert p.grad is None
             continue
-        assert rel_l2(p.grad, po[k].grad) < GRAD_TOL, (k, rel_l2(p.grad, po[k].grad))
+        # the output layers' gradients (dout^T h3) pass no ReLU gate of the backward and h3 = relu(z3) is continuous: no flips
+        tol = OUTPUT_LAYER_TOL if k.startswith(("mlp_rgb.3", "mlp_trans.3")) else GRAD_TOL
+        assert rel_l2(p.grad, po[k].grad) < tol, (k, rel_l2(p.grad, po[k].grad))
     assert rel_l2(ltd.grad, lto.grad) < GRAD_TOL and rel_l2(lld.grad, llo.grad) < GRAD_TOL
     # deterministic (fixed-order split-K reduction, no float atomics)
     g.nerf.zero_grad()
@@ -336,6 +339,107 @@ def test_mlp_backward_vs_oracle_autograd(ops, B, R, N, train_precision):
     for k, p in g.nerf.named_parameters():
         if p.grad is not None:
             assert torch.equal(p.grad, g2[k]), k
+
+
+def ulp_distance(a, b):
+    """Per-element distance of two fp32 tensors in units in the last place (monotone integer map of the bit patterns)."""
+    def key(t):
+        i = t.detach().cpu().contiguous().view(torch.int32).to(torch.int64)
+        return torch.where(i < 0, -(i & 0x7FFFFFFF), i)
+    return (key(a) - key(b)).abs()
+
+
+@pytest.mark.parametrize("train_precision", ["fp32", "f16x3"])
+def test_mlp_backward_tiers_with_gate_flips_masked(ops, train_precision):
+    """Tiered gradient parity (SURVEY 8d asks rel-L2 <= 1e-3; the blanket 5e-3 of the tests above is the ReLU-gate-flip bound).
+    A hidden unit whose pre-activation lies within fp32 rounding of zero may take the other side of its gate in another fp32
+    evaluation order; that moves the weight gradients of the gated layers (0, 1, 2 of each head) by ~1/sqrt(samples x 256).
+    Here the samples with ANY head pre-activation inside a 64-ulp-of-the-layer-scale band around zero are found from the
+    oracle's own pre-activations and their cotangents are zeroed ON BOTH SIDES (a sample with zero cotangents contributes
+    nothing whatever its gates do).  What is left is flip-free, and every layer must then agree tightly:
+        output layers <= 1e-5, hidden layers and latent rows <= 1e-4 (fp32 record) / 2e-4 (f16x3 record).
+    The count of masked samples is printed (a few % of the samples carry all of the 1e-3-scale disagreement)."""
+    B, R, N = 3, 64, 64
+    rs = np.random.RandomState(91)
+    params = O.make_params(21)
+    g, opt = _graph(params, N=N)
+    g.nerf.train_precision = train_precision
+    pts = torch.from_numpy(rs.uniform(-1.2, 1.2, size=(B, R, N, 3)).astype(np.float32))
+    unit = torch.nn.functional.normalize(torch.from_numpy(rs.normal(size=(B, R, 1, 3)).astype(np.float32)),
+                                         dim=-1).expand(B, R, N, 3).contiguous()
+    lt = torch.from_numpy(rs.normal(size=(B, 16)).astype(np.float32))
+    ll = torch.from_numpy(rs.normal(size=(B, 48)).astype(np.float32))
+    cots = [torch.from_numpy(rs.normal(size=s).astype(np.float32)) for s in ((B, R, N, 3, 2), (B, R, N, 2), (B, R, N, 1))]
+    po = {k: v.clone().requires_grad_(not k.startswith("mlp_feat")) for k, v in params.items()}
+    lto, llo = lt.clone().requires_grad_(), ll.clone().requires_grad_()
+    taps = {}
+    out = O.mlp_forward(po, pts, unit, lto, llo, taps=taps)
+    risky = torch.zeros(B, R, N, dtype=torch.bool)
+    for name, z in taps.items():
+        band = 64 * 2.0 ** -23 * float(z.abs().max())               # 64 ulp of the layer's largest pre-activation
+        risky |= (z.abs() < band).any(dim=-1)
+    n_risky = int(risky.sum())
+    print("gate-flip candidates: %d of %d samples (%.2f %%) masked" % (n_risky, risky.numel(), 100.0 * n_risky / risky.numel()))
+    assert 0 < n_risky < 0.25 * risky.numel()
+    keep = (~risky).float()
+    cots = [c * keep.view(B, R, N, *([1] * (c.dim() - 3))) for c in cots]
+    sum((o * c).sum() for o, c in zip(out, cots)).backward()
+    ltd, lld = cu(lt).requires_grad_(), cu(ll).requires_grad_()
+    outd = g.nerf.forward(opt, cu(pts), ray_unit=cu(unit), latent_variable_trans=ltd, latent_variable_light=lld, mode="train")
+    sum((o * cu(c)).sum() for o, c in zip(outd, cots)).backward()
+    hidden_tol = 1e-4 if train_precision == "fp32" else 2e-4
+    errs = {}
+    for k, p in g.nerf.named_parameters():
+        if p.grad is not None:
+            errs[k] = rel_l2(p.grad, po[k].grad)
+    errs["lat_trans"], errs["lat_light"] = rel_l2(ltd.grad, lto.grad), rel_l2(lld.grad, llo.grad)
+    print("flip-free gradient rel-L2 (%s record):" % train_precision, {k: float("%.2e" % v) for k, v in errs.items()})
+    for k, v in errs.items():
+        tol = 1e-5 if k.startswith(("mlp_rgb.3", "mlp_trans.3")) else hidden_tol
+        assert v < tol, (k, v, tol)
+
+
+def test_raygen_ulp_census_vs_reference_rays(ops):
+    """How far the HIP ray generation is from the REFERENCE's rays, counted in ulp (G1: train rays from patch coordinates;
+    G2: eval rays at pixel centres; G9b / G17: the rays the reference fed to its own MLP while producing the end-to-end
+    goldens).  The 5e-3 end-to-end bound of the from-intrinsics tests is this difference -- a few ulp in a few % of the
+    components, from torch's not-correctly-rounded CPU 3x3 inverse and its matmul summation order -- amplified by the 2^9 pi
+    encoding band; an actual ray-gen error (a wrong half-pixel offset is 7e-4 relative, ~6000 ulp) cannot hide behind it."""
+    census = {}
+
+    def count(name, got, want):
+        d = ulp_distance(got, want)
+        scale = want.abs().amax(dim=-1, keepdim=True).clamp_min(1e-30) if want.shape[-1] == 3 else want.abs().clamp_min(1e-30)
+        rel = float(((got - want).abs() / scale).max()) / 2.0 ** -23        # in ulp of the vector's largest component
+        census[name] = dict(differing=float((d > 0).float().mean()), max_ulp=int(d.max()), max_rel_ulp=round(rel, 2),
+                            n=int(d.numel()))
+
+    g1 = load_golden("g1_rays_train")
+    c, r, _, _, _ = ops.raygen(cu(g1["intr"]), cu(g1["pose"]), H=g1["H"], W=g1["W"], coords=cu(g1["coords"]),
+                               z_near=cu(g1["z_near"]), z_far=cu(g1["z_far"]))
+    count("g1_train_ray", r.cpu().view_as(g1["ray"]), g1["ray"])
+    count("g1_train_center", c.cpu().view_as(g1["center"]), g1["center"])
+    g2 = load_golden("g2_rays_eval")
+    c, r, _, _, _ = ops.raygen(cu(g2["intr"]), cu(g2["pose"]), H=g2["H"], W=g2["W"], ray_idx=cu(g2["ray_idx"]))
+    count("g2_eval_ray", r.cpu(), g2["ray_g"])
+    g9, gb = load_golden("g9_render_train"), load_golden("g9b_reference_rays")
+    c, r, _, _, depth = ops.raygen(cu(g9["intr"]), cu(g9["pose"]), H=g9["H"], W=g9["W"], n_samples=g9["N"], coords=cu(g9["coords"]),
+                                   z_near=cu(g9["z_near"]), z_far=cu(g9["z_far"]), rand=cu(g9["rand"]))
+    count("g9b_train_ray", r.cpu().view_as(gb["train_ray"]), gb["train_ray"])
+    count("g9b_train_depth", depth.cpu().view_as(gb["train_depth"]), gb["train_depth"])
+    g17 = load_golden("g17_c1_literal")
+    c, r, _, _, _ = ops.raygen(cu(g17["intr"]), cu(g17["pose"]), H=64, W=64, coords=cu(g17["coords"]),
+                               z_near=cu(g17["z_near"]), z_far=cu(g17["z_far"]))
+    count("g17_train_ray", r.cpu().view_as(g17["train_in_ray"]), g17["train_in_ray"])
+    idx = torch.arange(64 * 64)[None]
+    c, r, _, _, _ = ops.raygen(cu(g17["intr"]), cu(g17["pose"]), H=64, W=64, ray_idx=cu(idx))
+    count("g17_val_ray", r.cpu(), g17["val_in_ray"])
+    count("g17_val_center", c.cpu(), g17["val_in_center"])
+    print("ray-gen ulp census vs the reference:", census)
+    for name, cz in census.items():
+        # (a component near zero shows a large ulp distance for a tiny absolute difference: max_ulp is reported, the bound
+        # is on the difference in ulp of the vector's largest component)
+        assert cz["differing"] <= 0.75 and cz["max_rel_ulp"] <= 16, (name, cz)
 
 
 @pytest.mark.parametrize("scale", [1e-24, 1.0, 1e18])

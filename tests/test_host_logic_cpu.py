@@ -214,3 +214,40 @@ def test_inorm_lrelu_second_order_formulas_fp64():
     g_x_a = -(r * r / n) * xh * (A - n * C * D) - r * r * (D * (u - u.mean(1, keepdim=True)) + C * (a - a.mean(1, keepdim=True)) - 2 * C * D * xh)
     assert float((r * P(a) - gx.detach()).abs().max()) < 1e-12
     assert float((s * r * P(u) - g_gy).abs().max()) < 1e-12 and float((g_x_a - g_x).abs().max()) < 1e-12
+
+
+def test_bench_spawns_its_own_ranks_for_gpus_n():
+    """`python bench.py --gpus 2` with no torchrun environment: the parent starts two fresh rank processes (before any GPU
+    call), they meet in a collective (gloo here) and rank 0's line comes through; a failing rank gives a non-zero exit code."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--spawn-check"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert lines == [{"spawn_check": 2, "rank_sum": 3.0}]
+    # a rank that dies (no GPU here: the real bench raises in every child) must surface as a non-zero exit code of the parent
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "1", "--no-train",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=300)
+    if not torch.cuda.is_available():
+        assert r.returncode != 0
+
+
+def test_bench_byte_model_and_host_topology():
+    """SURVEY 8d's per-unit bytes as bench.py prices them, and the /proc/cpuinfo census of the cpu_baseline leg."""
+    import importlib.util
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(repo, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    rays = 480 * 640
+    assert bench.hbm_bytes("composite_fwd", 1, 128) == 6212                      # SURVEY 8d: 6,212 B per ray at N=128
+    assert abs(bench.hbm_bytes("composite_fwd", rays, 128) / 1e9 - 1.908) < 1e-3  # 1.91 GB per 480x640 image
+    assert bench.hbm_bytes("raygen", 1, 128) == 544                              # SURVEY 8d: 544 B per ray at N=128
+    assert bench.hbm_bytes("composite_bwd", 1, 64) == 64 * 76 + 68
+    assert bench.hbm_bytes("patch_gather", 0, pixels=1024) == 1024 * 264
+    sockets, phys, avail, model = bench.host_topology()
+    assert sockets >= 1 and 1 <= phys <= avail and isinstance(model, str)

@@ -317,3 +317,32 @@ def test_box_range_restatement_matches_reference_g16():
         outside[y0:y1, x0:x1] = False
         assert bool((far_img[outside] == g["bg_hi"] * g["depth_scale"]).all())
         assert c == 0 or outside.any()
+
+
+def test_c1_literal_size_g17():
+    """BASELINE config C1 at its literal size (64x64 crop, 32 samples per ray, batch 1; golden G17 rendered by the real
+    reference): the oracle from intrinsics / poses reproduces the reference's rays bit for bit and both renders (train: a
+    64x64 patch with the reference's own stratified depths; val: every pixel, mid-point samples) at rtol 2e-5."""
+    g = load_golden("g17_c1_literal")
+    H, W, N = g["H"], g["W"], g["N"]
+    p = O.make_params(g["seed_w"])
+    et, el = _embeddings(g["n_train"], g["emb_seed"])
+    c, r = O.rays_train(g["intr"], g["coords"], g["pose"], H, W)
+    assert torch.equal(c.reshape(1, -1, 3), g["train_in_center"]) and torch.equal(r.reshape(1, -1, 3), g["train_in_ray"])
+    assert torch.equal(et[g["sample_idx"]], g["train_in_lat_t"]) and torch.equal(el[g["sample_idx"]], g["train_in_lat_l"])
+    with torch.no_grad():
+        rgb_s, den_s, unc_s = O.forward_samples(p, g["train_in_center"], g["train_in_ray"], g["train_in_depth"],
+                                                g["train_in_lat_t"], g["train_in_lat_l"])
+        out = O.composite(g["train_in_ray"], rgb_s, den_s, g["train_in_depth"], unc_s, 0.05)
+    names = ("rgb", "rgb_static", "rgb_transient", "depth", "opacity", "opacity_static", "opacity_transient")
+    for name, o in zip(names, out[:7]):
+        close(o, g["train_" + name], rtol=2e-5, atol=2e-6)
+    close(out[8], g["train_uncert"], rtol=2e-5, atol=2e-6)
+    close(den_s, g["train_density"], rtol=2e-5, atol=2e-6)
+    close(out[9], g["train_alpha_static"], rtol=2e-5, atol=2e-6)
+    close(out[10], g["train_alpha_transient"], rtol=2e-5, atol=2e-6)
+    dr = (g["z_near"][:, :, None], g["z_far"][:, :, None])
+    with torch.no_grad():
+        val = O.render_by_slices(p, et, el, g["pose"], g["intr"], dr, torch.ones(1, H, W), None, "val", H, W, N, chunk=H * W)
+    for name in names + ("uncert",):
+        close(val[name], g["val_" + name], rtol=2e-5, atol=2e-6)

@@ -50,6 +50,8 @@ class FlatGradAllReducer:
     which is checked once).
     """
 
+    FLAG_WORDS = 4                      # tail of the flat buffer: step-gate words that must be decided globally
+
     def __init__(self, params: Iterable[torch.nn.Parameter], group=None, single_rank_collective: bool = False):
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         self.group = group
@@ -57,7 +59,8 @@ class FlatGradAllReducer:
         self.single_rank_collective = single_rank_collective
         n = sum(p.numel() for p in self.params)
         dev = self.params[0].device if self.params else torch.device("cpu")
-        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.flat = torch.zeros(n + self.FLAG_WORDS, dtype=torch.float32, device=dev)
+        self.flag_tail = self.flat[n:]
         self.views = []
         off = 0
         for p in self.params:
@@ -72,12 +75,20 @@ class FlatGradAllReducer:
     def world_size(self) -> int:
         return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
 
-    def reduce(self, average: bool = True) -> None:
+    def reduce(self, average: bool = True, flags: Optional[torch.Tensor] = None) -> None:
+        """``flags`` (int32, at most FLAG_WORDS words; e.g. the sticky words of the captured step gate) travel in the tail of
+        the same buffer: after the call every word is non-zero on ALL ranks if it was non-zero on ANY rank -- the gate
+        decision becomes global without a second collective.  (A non-finite gradient entry cannot leak into the tail: the
+        reduction is element-wise.)"""
         if not (dist.is_available() and dist.is_initialized()):
             return
         if dist.get_world_size(self.group) == 1 and not self.single_rank_collective:
             return
         world = dist.get_world_size(self.group)
+        if flags is not None:
+            self.flag_tail[:flags.numel()].copy_(flags != 0)
+        else:
+            self.flag_tail.zero_()
         have = [(p, v) for p, v in zip(self.params, self.views) if p.grad is not None]
         for p, v in zip(self.params, self.views):
             if p.grad is None:
@@ -85,6 +96,8 @@ class FlatGradAllReducer:
         if have:                                           # one multi-tensor launch each way instead of one copy per tensor
             torch._foreach_copy_([v for _, v in have], [p.grad for p, _ in have])
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+        if flags is not None:
+            flags.copy_(self.flag_tail[:flags.numel()] != 0)
         if average:
             self.flat.mul_(1.0 / world)
         if have:
@@ -112,6 +125,16 @@ def all_reduce_scalars(*values: torch.Tensor, group=None) -> List[torch.Tensor]:
     return list(buf.unbind(0))
 
 
+def all_reduce_flags(word: torch.Tensor, group=None) -> torch.Tensor:
+    """MAX over the ranks of a small int32 flag vector (range flag, non-finite loss): what makes a step-gate decision
+    global.  Returns ``word`` itself when there is one rank."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return word
+    word = word.contiguous()
+    dist.all_reduce(word, op=dist.ReduceOp.MAX, group=group)
+    return word
+
+
 def setup_data_parallel(graph: torch.nn.Module, seed: int = 0, group=None) -> tuple:
     """What a data-parallel training process does once, before it builds its trainer (texpose_amd.trainer):
       1. every rank starts from rank 0's state: parameters AND buffers (spectral-norm u / v, ``progress``) are broadcast;
@@ -129,11 +152,23 @@ def setup_data_parallel(graph: torch.nn.Module, seed: int = 0, group=None) -> tu
     return rank, world
 
 
-def shard_training_batch(var, rank: int, world: int):
-    """This rank's images of a collated batch (every tensor whose leading dimension is the batch size)."""
+# per-sample entries of a collated batch (reference data/lm.py:112-159, data/lmsyn2real.py)
+PER_SAMPLE_KEYS = frozenset(("idx", "image", "image_syn", "nocs_pred", "normal_pred", "obj_mask", "mask_syn", "intr", "pose",
+                             "pose_init", "pose_gt", "z_near", "z_far", "frame_index", "depth_gt", "mask_visib", "mask_full"))
+
+
+def shard_training_batch(var, rank: int, world: int, per_sample_keys=PER_SAMPLE_KEYS):
+    """This rank's images of a collated batch.  Only the entries named in ``per_sample_keys`` are sliced (a tensor that merely
+    HAPPENS to have the batch size as its leading dimension -- a 3x3 matrix at B=3, an anchor-pose table -- is passed through);
+    a per-sample key whose leading dimension is not the batch size raises."""
     B = len(var["idx"])
     sl = shard_batch(B, rank, world)
     out = type(var)()
     for k, v in var.items():
-        out[k] = v[sl.start:sl.stop] if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == B else v
+        if k in per_sample_keys and torch.is_tensor(v):
+            if v.dim() == 0 or v.shape[0] != B:
+                raise ValueError("shard_training_batch: %r is a per-sample entry but has shape %s at batch size %d" % (k, tuple(v.shape), B))
+            out[k] = v[sl.start:sl.stop]
+        else:
+            out[k] = v
     return out

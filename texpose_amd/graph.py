@@ -279,13 +279,36 @@ class Graph(torch.nn.Module):
         var.d_fake_disc = self.discriminator(opt, var.patch_fake, var.ray_scales)
         return var
 
-    def evaluate_metrics(self, opt, var):
+    def evaluate_metrics(self, opt, var, lpips_module=None):
         """PSNR / SSIM of ``Model.evaluate_full`` (reference :340-362) for a rendered ``var`` (mode 'eval_*'): static
-        render vs masked image, resized to 480x640 when the data is not the 128x128 crop.  LPIPS (AlexNet weights
-        unavailable offline) is not computed.  Returns 0-dim device tensors."""
+        render vs masked image, resized to 480x640 when the data is not the 128x128 crop.  Returns 0-dim device tensors.
+
+        ``lpips_module``: the STOCK perceptual metric, injected (the reference builds ``lpips.LPIPS(net='alex')`` in
+        ``Model.__init__`` (:31) and calls ``self.lpips_loss(rgb_map * 2 - 1, image_masked * 2 - 1).item()`` (:363-364);
+        SURVEY 8 f4: "VGG / LPIPS stay stock").  When given, it is called exactly like that on the same two images
+        PSNR / SSIM see -- [B,3,h,w], the static render and ``image * obj_mask``, after the reference's optional resize
+        (bilinear ``align_corners=False`` for the images, nearest for the mask) -- and ``lpips`` is added to the result.  The
+        AlexNet weights are not available offline, so the value itself is unpinned; the call contract is tested."""
         out_hw = None if list(opt.data.image_size) == [128, 128] else (480, 640)
         psnr, ssim, _ = ops.eval_metrics(var.rgb_static, var.image, var.obj_mask, opt.H, opt.W, out_hw=out_hw)
-        return edict(psnr=psnr, ssim=ssim)
+        out = edict(psnr=psnr, ssim=ssim)
+        if lpips_module is not None:
+            B = var.image.shape[0]
+            rgb_map = var.rgb_static.view(B, opt.H, opt.W, 3).permute(0, 3, 1, 2)
+            image, mask = var.image.view(B, 3, opt.H, opt.W), var.obj_mask.view(B, 1, opt.H, opt.W).float()
+            if out_hw is not None:                  # reference :344-349
+                rgb_map = torch_F.interpolate(rgb_map, size=list(out_hw), mode="bilinear", align_corners=False)
+                image = torch_F.interpolate(image, size=list(out_hw), mode="bilinear", align_corners=False)
+                mask = torch_F.interpolate(mask, size=list(out_hw), mode="nearest")
+            with torch.no_grad():
+                out.lpips = lpips_module(rgb_map * 2 - 1, (image * mask) * 2 - 1).reshape(-1).mean()
+        return out
+
+    def _warn_once(self, message):
+        seen = self.__dict__.setdefault("_warned", set())
+        if message not in seen:
+            seen.add(message)
+            warnings.warn("texpose_amd: " + message)
 
     @staticmethod
     def MSE_loss(pred, label, mask=None):
@@ -320,6 +343,12 @@ class Graph(torch.nn.Module):
             if fused:
                 loss.render, loss.uncert, loss.trans_reg = autograd_ops.nerf_losses(var.rgb, var.uncert, var.density,
                                                                                      var.gathered)
+            elif var.rgb.is_cuda:
+                # non-reference option combinations (a term switched off, mask_obj = False, full-image losses): the terms are
+                # formed with torch element-wise ops on the render outputs -- same values, many small launches.  Said once.
+                self._warn_once("compute_loss: loss options differ from the reference configuration (render / uncert / "
+                                "trans_reg on, mask off, mask_obj, patch mode): the render-consuming terms run as torch ops "
+                                "instead of the fused K8 launch")
             if not fused and lw.render is not None:
                 if opt.nerf.mask_obj:
                     loss.render = (obj_mask * ((image - rgb) ** 2 / uncert ** 2)).sum() / (obj_mask.sum() + 1e-5)
@@ -345,6 +374,8 @@ class Graph(torch.nn.Module):
                     if hasattr(self.perceptual_loss, "pairs"):        # both terms through one pass of the feature network
                         l1, l2 = self.perceptual_loss.pairs(pair1, pair2)
                     else:                                              # any injected module with the reference's call signature
+                        self._warn_once("compute_loss: the injected perceptual_loss has no fused entry points; calling it "
+                                        "twice like the reference (:762-764)")
                         l1, l2 = self.perceptual_loss(*pair1), self.perceptual_loss(*pair2)
                 loss.feat = l1 + 5 * l2
             if lw.lab is not None:

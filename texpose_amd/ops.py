@@ -638,6 +638,7 @@ def render_eval(packed: Tensor, intr: Tensor, pose: Tensor, ray_idx: Tensor, z_n
 
 # ------------------------------------------------------------------------------------------ K11
 _conv_counters = {}          # (device index, stream) -> zero-filled int32 tensor (the kernels leave it zero)
+_conv_counters_retired = []  # outgrown counter tensors: a captured hipGraph may still hold their address -- never freed
 
 
 def _conv_scratch(lib, ws_fn, a, op: int, dev):
@@ -654,6 +655,8 @@ def _conv_scratch(lib, ws_fn, a, op: int, dev):
         if torch.cuda.is_current_stream_capturing():
             raise _lib.TexposeLibraryError("tp_conv: the tile counters must exist before a hipGraph capture (run one "
                                            "eager step first)")
+        if cnt is not None:
+            _conv_counters_retired.append(cnt)          # a graph captured earlier keeps incrementing / zeroing this one
         cnt = torch.zeros(max(int(n_cnt.value), 1 << 14), dtype=torch.int32, device=dev)
         _conv_counters[key] = cnt
     return (torch.empty(int(ws_floats), device=dev) if ws_floats else None), cnt
@@ -824,6 +827,7 @@ def disc_inputs(rgb: Tensor, gathered: Tensor, hw, geo: bool):
     return real, fake
 
 
+@_on_tensor_device
 def step_flags(total: Tensor, bad: Tensor, word_finite: int, snapshot: Tensor, status: Optional[Tensor] = None, word_status: int = 0) -> None:
     """bad[word_status] |= status & 1; bad[word_finite] |= !isfinite(total); snapshot = bad (K13 tp_step_flags, one launch)."""
     lib = _lib.load()
@@ -831,6 +835,7 @@ def step_flags(total: Tensor, bad: Tensor, word_finite: int, snapshot: Tensor, s
                             snapshot.data_ptr(), _stream()), "tp_step_flags")
 
 
+@_on_tensor_device
 def adam_step(params, grads, exp_avgs, exp_avg_sqs, steps, lr, beta1: float, beta2: float, eps: float, gate: Optional[Tensor] = None) -> None:
     """torch.optim.Adam's update of all tensors in one launch per 32 (K13 tp_adam_step); ``steps``: 0-dim float tensors with
     the step count BEFORE this update; a gated one-wave launch inside the same call adds 1 to each afterwards."""

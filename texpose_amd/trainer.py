@@ -48,12 +48,15 @@ class FusedRMSprop(torch.optim.RMSprop):
     def step(self, closure=None):
         if closure is not None:
             raise NotImplementedError("closure")
-        for group in self.param_groups:
+        todo = []
+        for group in self.param_groups:                    # decide for ALL groups before anything is launched
             ps = [p for p in group["params"] if p.grad is not None]
             plain = (group["momentum"] == 0 and not group["centered"] and group["weight_decay"] == 0 and not group["maximize"]
                      and all(p.is_cuda and p.dtype == torch.float32 and not p.grad.is_sparse for p in ps))
             if not plain:
                 return super().step()
+            todo.append((group, ps))
+        for group, ps in todo:
             for p in ps:
                 st = self.state[p]
                 if len(st) == 0:
@@ -155,20 +158,25 @@ class GanTrainer:
         """Eager: True = apply the step.  Blocking read of [range flag, isfinite(total)] (the reference syncs once per
         loss term at this point)."""
         dev = loss.all.device
-        fin = torch.isfinite(loss.all.detach()).to(torch.int32).reshape(1)
-        word = torch.cat([ops.mlp_status(dev), fin]) if self._uses_f16x3() else torch.cat([torch.zeros_like(fin), fin])
-        flag, finite = word.tolist()
+        bad = (~torch.isfinite(loss.all.detach())).to(torch.int32).reshape(1)
+        word = torch.cat([ops.mlp_status(dev) & 1, bad]) if self._uses_f16x3() else torch.cat([torch.zeros_like(bad), bad])
+        # data parallel: the decision is GLOBAL -- every rank withholds, repeats or raises together (a rank acting alone
+        # would leave the others in the gradient all-reduce, or apply gradients its peers dropped)
+        word = tdist.all_reduce_flags(word, group=self.red_nerf.group)
+        flag, not_finite = word.tolist()
+        finite = not not_finite
         if flag & 1:
             ops.mlp_status(dev).zero_()
             return False
         if not finite:
             raise FloatingPointError("non-finite nerf loss (no update applied): " +
-                                     ", ".join("%s=%g" % (k, float(v)) for k, v in loss.items()))
+                                     ", ".join("%s=%g" % (k, float(v.detach())) for k, v in loss.items()))
         return True
 
     def _guard_disc(self, total):
-        if not bool(torch.isfinite(total.detach())):
-            raise FloatingPointError("non-finite discriminator loss (no update applied): %g" % float(total))
+        bad = (~torch.isfinite(total.detach())).to(torch.int32).reshape(1)
+        if int(tdist.all_reduce_flags(bad, group=self.red_disc.group if self.red_disc else None)):
+            raise FloatingPointError("non-finite discriminator loss on some rank (no update applied); here: %g" % float(total))
         return True
 
     def _weight(self, exponent, dev):
@@ -288,6 +296,25 @@ class GanTrainer:
                 continue
             optim.load_state_dict(sd)
             self._adopt_group_lr(name, optim)
+            self._adopt_capturable(optim)
+
+    def _adopt_capturable(self, optim):
+        """``Optimizer.load_state_dict`` takes ``capturable`` and the step counters from the SAVED groups / state: a checkpoint
+        of an eager trainer (or of the reference) carries capturable=False and CPU ``step`` tensors, one of a captured trainer
+        the opposite.  Put both back to what THIS trainer needs, so that state loads in either direction."""
+        for g in optim.param_groups:
+            if "capturable" in g:
+                g["capturable"] = bool(self.capturable)
+            for p in g["params"]:
+                st = optim.state.get(p)
+                if not st or "step" not in st:
+                    continue
+                step = st["step"]
+                value = float(step)
+                if self.capturable:
+                    st["step"] = torch.tensor(value, dtype=torch.float32, device=p.device)
+                else:
+                    st["step"] = torch.tensor(value, dtype=torch.float32)
 
     def _adopt_group_lr(self, name, optim):
         used = getattr(self, name + "_used")
@@ -371,27 +398,44 @@ class GraphedGanTrainer(GanTrainer):
             self._gate(self._gate_nerf.sum() == 0, [p.grad for p in self.nerf_group], self.lr_nerf, self.lr_nerf_used)
         return True
 
-    def _guard_disc(self, total):
+    def _flag_disc(self, total):
+        """Fold the finiteness of the discriminator loss into the sticky words and snapshot them as the discriminator gate."""
         ops.step_flags(total, self._bad, 2, self._gate_disc)
+
+    def _guard_disc(self, total=None):
+        if total is not None:
+            self._flag_disc(total)
         if getattr(self.optim_disc, "gate", None) is None:
             self._gate(self._gate_disc.sum() == 0, [p.grad for p in self.disc_group], self.lr_disc, self.lr_disc_used)
         return True
 
+    def _has_collective(self):
+        """A gradient all-reduce is part of the step (several ranks, or forced in a 1-rank group by the tests)."""
+        reds = [r for r in (self.red_nerf, self.red_disc) if r is not None]
+        return any(r.world_size > 1 or r.single_rank_collective for r in reds)
+
     def _split_around_collectives(self):
         """Real multi-rank group: the gradient all-reduces stay OUTSIDE the captured graphs (replay A = everything up to the
-        gradients, two eager collectives, replay B = the optimiser steps).  RCCL collectives inside a replayed hipGraph have
-        only been exercised in a 1-rank group (tests); between two replays they are ordinary stream-ordered calls."""
+        gradients, two eager collectives, replay B = the optimiser steps).  This is the DEFAULT whenever there is more than
+        one rank; RCCL collectives inside a replayed hipGraph (TP_COLLECTIVES_IN_GRAPH=1 opts in) have only been exercised in
+        a 1-rank group (tests), and between two replays they are ordinary stream-ordered calls."""
         if os.environ.get("TP_COLLECTIVES_IN_GRAPH"):
             return False
-        return (self.red_nerf.world_size > 1 or bool(os.environ.get("TP_SPLIT_GRAPH"))) and self.has_disc \
-            and not os.environ.get("TP_NO_BRANCH_OVERLAP")
+        return self.red_nerf.world_size > 1 or bool(os.environ.get("TP_SPLIT_GRAPH"))
+
+    def _reduce_all(self):
+        """The step's collectives, in ONE fixed order on every rank, after both branches have joined.  The sticky gate words
+        ride in the tail of the first buffer: afterwards a word is set on every rank if any rank set it, so all ranks
+        withhold (and later re-capture or raise) together."""
+        self.red_nerf.reduce(flags=self._bad)
+        if self.red_disc is not None:
+            self.red_disc.reduce()
 
     def _body(self, var):
         """One iteration (what is captured as ONE graph; `_body_a` / `_body_b` when the collectives stay outside)."""
         out = self._body_a(var)
         if self._deferred:
-            self.red_nerf.reduce()
-            self.red_disc.reduce()
+            self._reduce_all()
             self._body_b()
         return out
 
@@ -401,7 +445,9 @@ class GraphedGanTrainer(GanTrainer):
         discriminator backward, composite / MLP backward, Adam) stays on the capturing stream, the discriminator branch
         (real / fake forward, R1 double backward, RMSprop) runs on a second stream.  They share no written state -- nerf
         vs discriminator parameters, gradients, optimiser moments, separate gate words -- and in the replayed graph the
-        launch gaps of one chain of small dependent kernels are filled by the other: 2.50 -> 2.30 ms at B=4."""
+        launch gaps of one chain of small dependent kernels are filled by the other: 2.50 -> 2.30 ms at B=4.
+        With a gradient all-reduce in the step (`_deferred`) the branches only produce gradients and flags; reductions and
+        both optimiser steps follow after the join (`_reduce_all`, `_body_b`)."""
         opt = self.opt
         B, R = opt.batch_size, opt.patch_size ** 2
         var = self.graph.get_ray_idx(opt, var)
@@ -412,38 +458,44 @@ class GraphedGanTrainer(GanTrainer):
         self._flag_nerf(loss)
         dloss = None
         overlap = self.has_disc and not os.environ.get("TP_NO_BRANCH_OVERLAP")
-        self._deferred = self._split_around_collectives()          # optimiser steps (and reductions) after this function
+        # optimiser steps (and reductions) after this function: whenever a collective is part of the step, or on request
+        self._deferred = self._has_collective() or self._split_around_collectives()
         if overlap:
             main = torch.cuda.current_stream(var.rgb.device)
             if self._side is None:
                 self._side = torch.cuda.Stream(device=var.rgb.device)
             self._side.wait_stream(main)                          # fork
-            # data parallel: both all-reduces are issued from the capturing stream after the join, in one fixed order on every
-            # rank (two collectives of one communicator in unordered branches of a graph could meet in different orders)
-            serial_tail = self._deferred or (self.red_disc is not None and (self.red_disc.world_size > 1 or self.red_disc.single_rank_collective))
             with torch.cuda.stream(self._side):
-                var, dloss = self.disc_step(var, apply=not serial_tail)
+                var, dloss = self.disc_step(var, apply=not self._deferred)
         torch.autograd.backward(terms, ws)
         if not self._deferred:
             self._guard_nerf(var, loss)
             self.nerf_apply()
         if overlap:
             main.wait_stream(self._side)                          # join
-            if serial_tail and not self._deferred:
-                self.disc_apply(self._disc_total)
         elif self.has_disc:
-            var, dloss = self.disc_step(var)
+            var, dloss = self.disc_step(var, apply=not self._deferred)
         if dloss is not None:
             loss.update({k: v for k, v in dloss.items() if k != "all"})
         return {k: v.detach() for k, v in loss.items() if torch.is_tensor(v)}
 
+    def disc_step(self, var, apply=True):
+        var, loss = super().disc_step(var, apply=apply)
+        if not apply:
+            self._flag_disc(self._disc_total)                     # (before the join: the reductions carry the word)
+        return var, loss
+
     def _body_b(self):
-        """The optimiser steps of a step whose reductions ran between two graph replays (gradients are already averaged)."""
+        """The optimiser steps of a step whose reductions ran after the join (gradients are averaged, the gate words global:
+        snapshot them again for the two optimiser launches)."""
+        self._gate_nerf.copy_(self._bad)
         self._guard_nerf(None, None)
         self.optim_nerf.step()
         self.graph.nerf.mark_heads_dirty()
-        self._guard_disc(self._disc_total)
-        self.optim_disc.step()
+        if self.has_disc:
+            self._gate_disc.copy_(self._bad)
+            self._guard_disc()
+            self.optim_disc.step()
 
     # ------------------------------------------------------------------ capture
     def _snapshot(self):
@@ -472,6 +524,12 @@ class GraphedGanTrainer(GanTrainer):
         self.it = snap["it"]
         self.graph.patch_sampler.iterations = snap["sampler_it"]
         self.graph.nerf.mark_heads_dirty()
+
+    def load_optim_state(self, optim_nerf=None, optim_disc=None):
+        """As GanTrainer.load_optim_state; ``Optimizer.load_state_dict`` REPLACES the moment / step tensors, whose addresses a
+        captured step holds: the next train_iteration captures again (from the loaded state)."""
+        super().load_optim_state(optim_nerf=optim_nerf, optim_disc=optim_disc)
+        self._graph = self._graph_b = None
 
     def capture(self, var: AttrDict, warmup: int = 3):
         """Warm up eagerly on a side stream (lazy inits: MIOpen solver search, weight packing, optimiser state), then
@@ -529,12 +587,17 @@ class GraphedGanTrainer(GanTrainer):
 
     # ------------------------------------------------------------------ host side of the step gate
     def _read_bad(self, blocking=False):
-        """[range flag, non-finite] seen by the gate; blocking, or from the asynchronous copy queued by the previous call."""
+        """[range flag, non-finite] seen by the gate; blocking, or from the asynchronous copy queued by the previous call.
+        With several ranks the words are global (`_reduce_all`) and every rank must ACT on them at the same iteration (a
+        re-capture issues collectives): the copy queued by the previous call is then waited for instead of polled -- by then
+        it is one whole iteration old, so the wait only bounds how far the host runs ahead of the GPU."""
         if blocking:
             self._bad_poll = None
             return self._bad.tolist()
         seen = [0, 0, 0]
         prev = self._bad_poll
+        if prev is not None and self.red_nerf.world_size > 1:
+            prev[1].synchronize()
         if prev is not None and prev[1].query():
             seen = prev[0].tolist()
             prev = None
@@ -575,8 +638,7 @@ class GraphedGanTrainer(GanTrainer):
         self.graph.patch_sampler.update_device_bound()          # one fill_ of the annealed bound
         self._graph.replay()
         if self._graph_b is not None:                            # collectives between the two replays, stream-ordered
-            self.red_nerf.reduce()
-            self.red_disc.reduce()
+            self._reduce_all()
             self._graph_b.replay()
         self._after_step()
         flagged = self._read_bad()                              # outside the graph: event query + pinned copy
