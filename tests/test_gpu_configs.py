@@ -313,8 +313,7 @@ def test_c1_literal_size_vs_reference_g17():
         assert rel_l2(out[9], g["train_alpha_static"]) < 1e-4 and rel_l2(out[10], g["train_alpha_transient"]) < 1e-4
         # val: mid-point depths of the gathered bounds, the reference's rays
         near, far = g["z_near"][:, :, None], g["z_far"][:, :, None]
-        depth = (near + (far - near) * mid)[..., None]                 # same expression order as sample_depth: (0.5+i)/N*(f-n)+n
-        depth = ((mid * (far - near)) + near)[..., None].contiguous()
+        depth = ((mid * (far - near)) + near)[..., None].contiguous()   # sample_depth's expression order: (0.5+i)/N*(f-n)+n
         with torch.no_grad():
             rgb_s, den_s, unc_s = graph.nerf.forward_samples(opt, cu(g["val_in_center"]), cu(g["val_in_ray"]), cu(depth),
                                                              latent_variable_trans=cu(g["val_in_lat_t"]),

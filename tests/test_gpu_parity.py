@@ -1166,6 +1166,28 @@ def test_eval_metrics_g14_and_oracle(ops):
     var = AttrDict(rgb_static=cu(rgb), image=cu(image), obj_mask=cu(mask))
     m = Graph(opt).evaluate_metrics(opt, var)
     assert abs(float(m.psnr) - float(ref["psnr"])) < 1e-4 and abs(float(m.ssim) - float(ref["ssim"])) < 2e-5
+    assert "lpips" not in m
+    # LPIPS hook: an injected stock module is called like the reference calls it (model/nerf_adapt_st_gan.py:363):
+    # lpips(rgb_map * 2 - 1, image_masked * 2 - 1) on [B,3,h,w] tensors; 480x640 resize for non-crop data
+    calls = []
+
+    class FakeLpips(torch.nn.Module):
+        def forward(self, a, b):
+            calls.append((a.detach().clone(), b.detach().clone()))
+            return ((a - b) ** 2).mean(dim=(1, 2, 3)).view(-1, 1, 1, 1)
+
+    m = Graph(opt).evaluate_metrics(opt, var, lpips_module=FakeLpips())
+    a, b = calls[-1]
+    Bm = image.shape[0]
+    rgb_map = cu(rgb).view(Bm, 128, 128, 3).permute(0, 3, 1, 2)
+    torch.testing.assert_close(a, rgb_map * 2 - 1)
+    torch.testing.assert_close(b, cu(image) * cu(mask)[:, None] * 2 - 1)
+    assert abs(float(m.lpips) - float(((a - b) ** 2).mean())) < 1e-6 and abs(float(m.psnr) - float(ref["psnr"])) < 1e-4
+    opt2 = default_options(H=128, W=128, device="cuda:0")
+    opt2.data.image_size = [240, 320]                       # not the crop: the reference resizes to 480x640 first (:344-349)
+    m2 = Graph(opt2).evaluate_metrics(opt2, var, lpips_module=FakeLpips())
+    a2, b2 = calls[-1]
+    assert a2.shape == (Bm, 3, 480, 640) and b2.shape == (Bm, 3, 480, 640) and np.isfinite(float(m2.lpips))
 
 
 # ------------------------------------------------------------------------------------------ spectral norm (f1)
