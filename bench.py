@@ -176,12 +176,21 @@ def hbm_bytes(kernel, rays, n=0, pixels=0):
 
 
 def _event_ms(fn, reps):
+    """Average GPU time of `fn` (one C-ABI launch) over `reps` launches REPLAYED from a hipGraph between two HIP events: no
+    host work between the launches (an eager loop of a 6 us kernel measures the ~50 us Python / ctypes call)."""
     fn()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        for _ in range(reps):
+            fn()                                           # (outputs dropped: the graph's pool reuses their memory)
+    graph.replay()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     e0.record()
-    for _ in range(reps):
-        fn()
+    graph.replay()
     e1.record()
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps
@@ -190,8 +199,8 @@ def _event_ms(fn, reps):
 def hbm_rooflines(device, in_situ):
     """HBM-side rooflines of the kernels around the MLP (north_star: "achieved HBM GB/s on ray-gen / composite"): ALGORITHMIC
     bytes / HIP-event time against the 8 TB/s HBM3E peak, at the C2 launch size (one 480x640x128 image) and, for the gather,
-    at the training sizes.  `in_situ_ms`: the same kernel bracketed inside the timed render loop; `ms`: 10-20 launches back to
-    back between two events (no host gaps).  `traffic`: fabric bytes per launch from the committed PMC passes
+    at the training sizes.  `in_situ_ms`: the same kernel bracketed inside the timed render loop; `standalone_ms`: 10-20 launches
+    in one hipGraph replay between two events (no host gaps).  `traffic`: fabric bytes per launch from the committed PMC passes
     (profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate runs of tools/hbm_kernels.py)."""
     from texpose_amd import ops, synthetic
     try:
@@ -212,22 +221,26 @@ def hbm_rooflines(device, in_situ):
     out = {"peak": HBM_PEAK_GBS, "unit": "GB/s", "bound": "hbm",
            "note": "achieved = ALGORITHMIC bytes per launch (bench.hbm_bytes) / HIP-event time; traffic = PMC fabric bytes per launch"}
 
-    def entry(name, kernel, ms, nbytes, workload, extra=None):
-        e = {"kernel": kernel, "ms": ms, "bytes": nbytes, "achieved": nbytes / (ms * 1e-3) / 1e9, "workload": workload,
-             "traffic": (pmc.get(name) or {}).get("total")}
+    def entry(name, kernel, ms, nbytes, workload, in_situ_ms=None):
+        """`ms`: the kernel bracketed inside the timed render loop where it is part of it (composite fwd, ray-gen: what the
+        product path sees, right behind / in front of the MLP kernel), else the graph-replayed figure; both are reported."""
+        used = in_situ_ms if in_situ_ms else ms
+        e = {"kernel": kernel, "ms": used, "bytes": nbytes, "achieved": nbytes / (used * 1e-3) / 1e9, "workload": workload,
+             "traffic": (pmc.get(name) or {}).get("total"), "standalone_ms": ms, "in_situ_ms": in_situ_ms,
+             "timed": "in the timed render loop (HIP events around the launch)" if in_situ_ms else
+                      "hipGraph replay of 10-20 launches between two HIP events"}
         e["frac"] = e["achieved"] / HBM_PEAK_GBS
-        e.update(extra or {})
         out[name] = e
 
     ms = _event_ms(lambda: ops.composite_fwd(ray, rgb, den, depth, unc, 0.05, per_sample=True, want_prob=False), 10)
     entry("composite_fwd", "composite_fwd_kernel", ms, hbm_bytes("composite_fwd", R, N), "480x640 rays x 128 samples, alphas written",
-          {"in_situ_ms": in_situ.get("composite_fwd_ms")})
+          in_situ.get("composite_fwd_ms"))
     ms = _event_ms(lambda: ops.composite_bwd(ray, rgb, den, depth, unc, g_out), 10)
     entry("composite_bwd", "composite_bwd_kernel", ms, hbm_bytes("composite_bwd", R, N), "480x640 rays x 128 samples")
     ms = _event_ms(lambda: ops.raygen(intr, pose, H=H, W=W, n_samples=N, ray_idx=idx, z_near=near, z_far=far,
                                       jitter=ops.JITTER_PHILOX, seed=1, offset=0), 20)
     entry("raygen", "raygen_kernel", ms, hbm_bytes("raygen", R, N), "480x640 rays x 128 depths, Philox jitter, bounds from maps",
-          {"in_situ_ms": in_situ.get("raygen_ms")})
+          in_situ.get("raygen_ms"))
     del rgb, den, unc, depth
     for name, B, p, hw in (("patch_gather", 4, 16, 128), ("patch_gather_b32_p64", 32, 64, 128)):
         var = synthetic.training_batch(B, hw, hw, seed=0, device=device)
@@ -241,7 +254,7 @@ def hbm_rooflines(device, in_situ):
 
 def train_kernel_times(device, B=32, reps=10):
     """(recording forward ms, backward ms) of the training MLP kernels at C4's per-launch size (B images x 256 rays x 64
-    samples): tp_mlp_fwd(save) and tp_mlp_bwd launched `reps` times back to back between two HIP events."""
+    samples): tp_mlp_fwd(save) and tp_mlp_bwd launched alternately `reps` times, each bracketed by HIP events."""
     from texpose_amd import ops
     from texpose_amd.graph import Graph
     from texpose_amd.options import default_options
@@ -267,18 +280,21 @@ def train_kernel_times(device, B=32, reps=10):
     def bwd():
         return ops.mlp_backward(g.nerf, lt, ll, saved, rgb, den, unc, g_rgb, g_den, g_unc, wgrad_precision="f16x3")
 
-    out = []
-    for fn in (fwd, bwd):
-        fn()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize(device)
-        e0.record()
-        for _ in range(reps):
-            fn()
-        e1.record()
-        torch.cuda.synchronize(device)
-        out.append(e0.elapsed_time(e1) / reps)
-    return out[0], out[1]
+    # forward and backward ALTERNATE as in the step (ten of one kind back to back hold a lower clock than the step's mix:
+    # the sum came out ABOVE the replayed step); an event between every two launches, the queue kept full by the host
+    fwd(); bwd()
+    torch.cuda.synchronize(device)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * reps + 1)]
+    ev[0].record()
+    for i in range(reps):
+        fwd()
+        ev[2 * i + 1].record()
+        bwd()
+        ev[2 * i + 2].record()
+    torch.cuda.synchronize(device)
+    f_ms = sum(ev[2 * i].elapsed_time(ev[2 * i + 1]) for i in range(reps)) / reps
+    b_ms = sum(ev[2 * i + 1].elapsed_time(ev[2 * i + 2]) for i in range(reps)) / reps
+    return f_ms, b_ms
 
 
 def train_leg(device, rank, world):
@@ -312,9 +328,9 @@ def train_leg(device, rank, world):
         for B in (4, 32):
             r = train_dp.measure(device, 0, 1, global_batch=B, iters=40, warm=4, graphed=True, full=False)
             out["nerf_step_b%d" % B] = {k: r[k] for k in ("value", "ms_per_iter", "global_batch", "launch", "recording_forward")}
-        # kernel-level: the two C-ABI calls of the B=32 nerf step (recording forward; dgrad + wgrad + finalize), each launched
-        # 10x back to back between two HIP events on the launch stream -- no host launch gaps inside the bracket (round 2
-        # bracketed single eager calls: their sum left the replayed step 7 us for its other kernels)
+        # kernel-level: the two C-ABI calls of the B=32 nerf step (recording forward; dgrad + wgrad + finalize), launched
+        # alternately 10x with a HIP event between every two launches (the queue stays full: no host gaps inside a bracket;
+        # round 2 bracketed single calls of an eager step: their sum left the replayed step 7 us for its other kernels)
         f_ms, b_ms = train_kernel_times(device)
         samples = 32 * 256 * 64
         achieved = TRAIN_FLOP_PER_SAMPLE * samples / ((f_ms + b_ms) * 1e-3) / 1e12
@@ -328,7 +344,7 @@ def train_leg(device, rank, world):
                            "step_ms_replayed": out["nerf_step_b32"]["ms_per_iter"],
                            "other_kernels_ms": out["nerf_step_b32"]["ms_per_iter"] - f_ms - b_ms,
                            "note": "B=32 nerf step; ALGORITHMIC FLOP (recording forward + head backward) / HIP-event time of "
-                                   "tp_mlp_fwd + tp_mlp_bwd, each averaged over 10 back-to-back launches; every product is three "
+                                   "tp_mlp_fwd + tp_mlp_bwd, averaged over 10 alternating launches; every product is three "
                                    "f16 MFMAs; other_kernels_ms = replayed step - these (ray-gen, composite fwd/bwd, losses, "
                                    "gathers, Adam, pack)"}
     return out

@@ -134,6 +134,10 @@ typedef struct tp_mlp_fwd_args {
   void* workspace;         /* tp_mlp_workspace_bytes */
   int precision;           /* TP_MLP_FP32 (exact fp32 MFMA) or TP_MLP_F16X3 (packed with TP_PACK_F16X3) */
   int* status;             /* TP_MLP_F16X3: device word, bit 0 is set if an activation left the fp16 range */
+  unsigned int* act_max;   /* TP_MLP_F16X3, optional (may be NULL): device word that receives, by atomic max, the fp32 bit
+                              pattern of the largest hidden activation handed to the matrix cores in this call (post-ReLU,
+                              its fp16 hi part: 11 significant bits).  The range guard fires at 6e4; this word says how far
+                              below it a network runs.  Zero it before the calls to be covered. */
 } tp_mlp_fwd_args;
 /* TP_MLP_F16X3: every fp32 operand is split into hi + lo fp16 (22-bit significand) and hi*hi + hi*lo + lo*hi is
  * accumulated in fp32 on the f16 matrix cores (16x the fp32-MFMA rate / 3).  Measured error vs an fp64 oracle is

@@ -357,7 +357,7 @@ def test_mlp_backward_tiers_with_gate_flips_masked(ops, train_precision):
     Here the samples with ANY head pre-activation inside a 64-ulp-of-the-layer-scale band around zero are found from the
     oracle's own pre-activations and their cotangents are zeroed ON BOTH SIDES (a sample with zero cotangents contributes
     nothing whatever its gates do).  What is left is flip-free, and every layer must then agree tightly:
-        output layers <= 1e-5, hidden layers and latent rows <= 1e-4 (fp32 record) / 2e-4 (f16x3 record).
+        EVERY layer and the latent rows <= 1e-5 (measured 0.4 - 3e-6 with both record arithmetics).
     The count of masked samples is printed (a few % of the samples carry all of the 1e-3-scale disagreement)."""
     B, R, N = 3, 64, 64
     rs = np.random.RandomState(91)
@@ -387,7 +387,7 @@ def test_mlp_backward_tiers_with_gate_flips_masked(ops, train_precision):
     ltd, lld = cu(lt).requires_grad_(), cu(ll).requires_grad_()
     outd = g.nerf.forward(opt, cu(pts), ray_unit=cu(unit), latent_variable_trans=ltd, latent_variable_light=lld, mode="train")
     sum((o * cu(c)).sum() for o, c in zip(outd, cots)).backward()
-    hidden_tol = 1e-4 if train_precision == "fp32" else 2e-4
+    hidden_tol = 1e-5
     errs = {}
     for k, p in g.nerf.named_parameters():
         if p.grad is not None:
@@ -439,7 +439,8 @@ def test_raygen_ulp_census_vs_reference_rays(ops):
     for name, cz in census.items():
         # (a component near zero shows a large ulp distance for a tiny absolute difference: max_ulp is reported, the bound
         # is on the difference in ulp of the vector's largest component)
-        assert cz["differing"] <= 0.75 and cz["max_rel_ulp"] <= 16, (name, cz)
+        # measured: 0 - 4.3 % of the ray components differ (centres 0 - 11 %), by at most 6 ulp of the largest component
+        assert cz["differing"] <= 0.15 and cz["max_rel_ulp"] <= 8, (name, cz)
 
 
 @pytest.mark.parametrize("scale", [1e-24, 1.0, 1e18])

@@ -447,6 +447,7 @@ struct Params {
   int B, R, N;
   int64_t n_samples, n_tiles;
   float* rgb; float* density; float* uncert; float* saved; float* workspace; int* status;
+  unsigned int* act_max;
 };
 
 // stage one "extra input" value as hi/lo halves: slot = 16 ks + 8 h + j of this lane
@@ -795,7 +796,20 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_f16x3_kernel(Params P) {
         }
       }
     }
-    if (P.status != nullptr && !(fmaxf((float)amax.m[0], (float)amax.m[1]) < 6.0e4f)) atomicOr(P.status, 1);
+    const float tile_max = fmaxf((float)amax.m[0], (float)amax.m[1]);
+    if (P.status != nullptr && !(tile_max < 6.0e4f)) atomicOr(P.status, 1);
+    if (P.act_max != nullptr) {
+      // largest hidden activation of the tile (non-negative floats order like their bit patterns): one atomic per wave.
+      // The lane id comes from a volatile asm (a plain __lane_id() / __shfl_xor is hoisted out of the tile loop and then
+      // lives through every block, i.e. in scratch memory); the butterfly uses ds_bpermute with that id
+      int lid;
+      asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lid));
+      float wmax = tile_max;
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1)
+        wmax = fmaxf(wmax, __int_as_float(__builtin_amdgcn_ds_bpermute((lid ^ off) << 2, __float_as_int(wmax))));
+      if (lid == 0 && wmax == wmax) atomicMax(P.act_max, __float_as_uint(wmax));
+    }
     TR_END(11, o);
   }
 #ifdef TP_TRACE
@@ -1070,7 +1084,7 @@ int tp_launch_mlp_fwd_f16x3(const tp_mlp_fwd_args* a, int grid, hipStream_t stre
   P.n_samples = (int64_t)a->B * a->R * a->N;
   P.n_tiles = (P.n_samples + 127) / 128;
   P.rgb = a->rgb; P.density = a->density; P.uncert = a->uncert; P.saved = a->saved; P.workspace = (float*)a->workspace;
-  P.status = a->status;
+  P.status = a->status; P.act_max = a->act_max;
   static unsigned long long attr_devices = 0;
   if (tp::first_use_on_device(attr_devices)) {
     hipError_t e = hipFuncSetAttribute((const void*)mlp_fwd_f16x3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);

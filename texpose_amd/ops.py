@@ -223,6 +223,38 @@ def mlp_status(device) -> Tensor:
     return _status_words[key]
 
 
+_act_max_words: Dict[int, Tensor] = {}
+_track_act_max = False
+
+
+def track_activation_max(enable: bool = True) -> None:
+    """Diagnostics: let every following f16x3 forward fold its largest hidden activation into a device word
+    (tp_mlp_fwd_args.act_max; one atomic per wave and tile).  Off by default."""
+    global _track_act_max
+    _track_act_max = bool(enable)
+
+
+def take_activation_max(device) -> float:
+    """Largest hidden activation seen by the f16x3 forwards since the last take (blocking read, then cleared).  The range
+    guard fires at 6e4."""
+    key = torch.device(device).index or 0
+    word = _act_max_words.get(key)
+    if word is None:
+        return 0.0
+    value = float(word.view(torch.float32).item())
+    word.zero_()
+    return value
+
+
+def _act_max_ptr(dev):
+    if not _track_act_max:
+        return None
+    key = dev.index or 0
+    if key not in _act_max_words:
+        _act_max_words[key] = torch.zeros(1, dtype=torch.int32, device=dev)
+    return _act_max_words[key].data_ptr()
+
+
 def take_mlp_status(device) -> int:
     """Blocking read-and-clear of the status word: what was raised since the last take.  One host sync."""
     word = mlp_status(device)
@@ -302,6 +334,7 @@ def mlp_forward(packed: Tensor, lat_trans: Tensor, lat_light: Tensor, *, center:
     a.precision = PRECISIONS[precision]
     if a.precision == MLP_F16X3:
         a.status = mlp_status(dev).data_ptr()
+        a.act_max = _act_max_ptr(dev)
     check(lib.tp_mlp_fwd(C.byref(a), _stream()), "tp_mlp_fwd")
     return (rgb, density, uncert, saved) if save else (rgb, density, uncert)
 

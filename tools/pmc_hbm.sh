@@ -15,4 +15,5 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 python3 tools/summarize_hbm_pmc.py $OUT > $OUT/pmc.json
 cat $OUT/pmc.json
+for c in FETCH_SIZE WRITE_SIZE; do cp $(find $OUT/$c -name '*counter_collection.csv' | head -1) $OUT/${c}_counter_collection.csv; done
 rm -rf $OUT/stats $OUT/FETCH_SIZE $OUT/WRITE_SIZE

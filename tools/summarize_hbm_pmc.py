@@ -7,11 +7,11 @@ import collections, csv, glob, json, sys
 root = sys.argv[1]
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-    for f in glob.glob("%s/%s/**/*counter_collection.csv" % (root, counter), recursive=True):
+    for f in glob.glob("%s/%s/**/*counter_collection.csv" % (root, counter), recursive=True) + glob.glob("%s/%s_counter_collection.csv" % (root, counter)):
         per_dispatch = collections.defaultdict(float)
         meta = {}
         for r in csv.DictReader(open(f)):
-            if r["Counter_Name"] != counter:
+            if counter not in r["Counter_Name"]:
                 continue
             per_dispatch[r["Dispatch_Id"]] += float(r["Counter_Value"])
             meta[r["Dispatch_Id"]] = (r["Kernel_Name"].split("(")[0], int(r["Grid_Size"]))
