@@ -542,6 +542,18 @@ def main():
         except Exception as exc:                   # the rays/s line must come out whatever happens to the untimed legs
             train = {"error": repr(exc)[:400]}
 
+    trained = None
+    if rank == 0 and world == 1 and not args.no_train and args.precision == "f16x3":
+        # untimed leg: the f16x3 kernel on a TRAINED network (500 product-trainer iterations) and with the trunk feature
+        # scaled x4 / x16: rays/s, range-flag count, largest hidden activation, f16x3-vs-fp32 error (tools/trained_weights.py)
+        try:
+            sys.path.insert(0, os.path.join(REPO, "tools"))
+            import trained_weights
+            trained = trained_weights.run(device, iters=500)
+        except Exception as exc:
+            trained = {"error": repr(exc)[:400]}
+        torch.cuda.empty_cache()
+
     if rank == 0:
         line = {
             "metric": "rendered rays/sec (480x640x128 samples) + train iters/sec",
@@ -571,6 +583,8 @@ def main():
             line["per_ray_outputs_only"] = per_ray
         if train is not None:
             line["train"] = train
+        if trained is not None:
+            line["trained_weights"] = trained
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(sc, params, emb_t, emb_l)
             line["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]

@@ -420,3 +420,27 @@ def test_optimizer_state_loads_between_eager_and_captured_trainers():
     _, loss = eager2.train_iteration(AttrDict(dict(batch)))
     assert all(np.isfinite(float(v)) for v in loss.values() if torch.is_tensor(v))
     assert all(float(st["step"]) == 6.0 for st in eager2.optim_nerf.state.values())
+
+
+# ------------------------------------------------------------------------------------------ f16x3 on trained weights
+def test_trained_network_renders_unflagged_and_fp32_grade():
+    """The split-fp16 MLP kernel on a network the PRODUCT TRAINER produced (200 full GAN iterations on synthetic crops; every
+    other test uses Xavier-random weights): no step withheld, no range flag on a render, the largest hidden activation far
+    below the 6e4 guard, and per-ray outputs within 1e-4 of the exact-fp32 kernel; with the trunk feature scaled x16 the
+    activation maximum scales along and the kernels still agree."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import trained_weights as TW
+    graph, trainer, losses = TW.train_heads(dev(), iters=200)
+    assert trainer.skipped_steps == 0 and graph.nerf.train_precision == "f16x3"
+    assert all(np.isfinite(v) for v in losses.values()), losses
+    res = TW.compare_kernels(graph, dev(), H=96, W=128, n_samples=64, scales=(1.0, 16.0), images=1)
+    base, big = res
+    print("trained-weights renders:", res)
+    assert base["range_flagged_images"] == 0 and 0 < base["max_hidden_activation"] < 6.0e3
+    for r in res:
+        for k, e in r["f16x3_vs_fp32"].items():
+            assert e["rel_l2"] < 2e-5 and e["max_rel"] < 1e-4, (r["trunk_feature_scale"], k, e)
+        assert r["density"]["rel_l2"] < 1e-4
+    assert big["range_flagged_images"] == 0 and big["max_hidden_activation"] > 2 * base["max_hidden_activation"]
