@@ -240,7 +240,10 @@ def hbm_rooflines(device, in_situ):
     ms = _event_ms(lambda: ops.raygen(intr, pose, H=H, W=W, n_samples=N, ray_idx=idx, z_near=near, z_far=far,
                                       jitter=ops.JITTER_PHILOX, seed=1, offset=0), 20)
     entry("raygen", "raygen_kernel", ms, hbm_bytes("raygen", R, N), "480x640 rays x 128 depths, Philox jitter, bounds from maps",
-          in_situ.get("raygen_ms"))
+          None)
+    out["raygen"]["in_situ_ms"] = in_situ.get("raygen_ms")
+    out["raygen"]["note"] = ("in_situ_ms brackets the FIRST launch of a step on an idle GPU (the previous image ended with the "
+                            "host read of the range flag): it contains the host's launch latency, so the replayed figure is used")
     del rgb, den, unc, depth
     for name, B, p, hw in (("patch_gather", 4, 16, 128), ("patch_gather_b32_p64", 32, 64, 128)):
         var = synthetic.training_batch(B, hw, hw, seed=0, device=device)
@@ -254,7 +257,7 @@ def hbm_rooflines(device, in_situ):
 
 def train_kernel_times(device, B=32, reps=10):
     """(recording forward ms, backward ms) of the training MLP kernels at C4's per-launch size (B images x 256 rays x 64
-    samples): tp_mlp_fwd(save) and tp_mlp_bwd launched alternately `reps` times, each bracketed by HIP events."""
+    samples): tp_mlp_fwd(save) + tp_mlp_bwd replayed `reps` times from a hipGraph (their sum), split by eager brackets."""
     from texpose_amd import ops
     from texpose_amd.graph import Graph
     from texpose_amd.options import default_options
@@ -280,9 +283,11 @@ def train_kernel_times(device, B=32, reps=10):
     def bwd():
         return ops.mlp_backward(g.nerf, lt, ll, saved, rgb, den, unc, g_rgb, g_den, g_unc, wgrad_precision="f16x3")
 
-    # forward and backward ALTERNATE as in the step (ten of one kind back to back hold a lower clock than the step's mix:
-    # the sum came out ABOVE the replayed step); an event between every two launches, the queue kept full by the host
-    fwd(); bwd()
+    # (1) the pair (recording forward, backward) x reps REPLAYED from one hipGraph between two HIP events: the kernels as
+    # the captured training step runs them -- alternating, no host work and no event packets between them;
+    # (2) eager alternating launches with an event after each give the forward : backward split of that time (their sum
+    # comes out ABOVE the replayed step: every event record costs the queue a few us).
+    pair_ms = _event_ms(lambda: (fwd(), bwd()), reps)
     torch.cuda.synchronize(device)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * reps + 1)]
     ev[0].record()
@@ -292,9 +297,9 @@ def train_kernel_times(device, B=32, reps=10):
         bwd()
         ev[2 * i + 2].record()
     torch.cuda.synchronize(device)
-    f_ms = sum(ev[2 * i].elapsed_time(ev[2 * i + 1]) for i in range(reps)) / reps
-    b_ms = sum(ev[2 * i + 1].elapsed_time(ev[2 * i + 2]) for i in range(reps)) / reps
-    return f_ms, b_ms
+    f_ev = sum(ev[2 * i].elapsed_time(ev[2 * i + 1]) for i in range(reps)) / reps
+    b_ev = sum(ev[2 * i + 1].elapsed_time(ev[2 * i + 2]) for i in range(reps)) / reps
+    return pair_ms * f_ev / (f_ev + b_ev), pair_ms * b_ev / (f_ev + b_ev)
 
 
 def train_leg(device, rank, world):
@@ -328,9 +333,9 @@ def train_leg(device, rank, world):
         for B in (4, 32):
             r = train_dp.measure(device, 0, 1, global_batch=B, iters=40, warm=4, graphed=True, full=False)
             out["nerf_step_b%d" % B] = {k: r[k] for k in ("value", "ms_per_iter", "global_batch", "launch", "recording_forward")}
-        # kernel-level: the two C-ABI calls of the B=32 nerf step (recording forward; dgrad + wgrad + finalize), launched
-        # alternately 10x with a HIP event between every two launches (the queue stays full: no host gaps inside a bracket;
-        # round 2 bracketed single calls of an eager step: their sum left the replayed step 7 us for its other kernels)
+        # kernel-level: the two C-ABI calls of the B=32 nerf step (recording forward; dgrad + wgrad + finalize) replayed 10x
+        # from a hipGraph between two HIP events, i.e. timed as the captured step runs them (round 2 bracketed single calls
+        # of an eager step: their sum left the replayed step 7 us for its other kernels)
         f_ms, b_ms = train_kernel_times(device)
         samples = 32 * 256 * 64
         achieved = TRAIN_FLOP_PER_SAMPLE * samples / ((f_ms + b_ms) * 1e-3) / 1e12
@@ -344,7 +349,7 @@ def train_leg(device, rank, world):
                            "step_ms_replayed": out["nerf_step_b32"]["ms_per_iter"],
                            "other_kernels_ms": out["nerf_step_b32"]["ms_per_iter"] - f_ms - b_ms,
                            "note": "B=32 nerf step; ALGORITHMIC FLOP (recording forward + head backward) / HIP-event time of "
-                                   "tp_mlp_fwd + tp_mlp_bwd, averaged over 10 alternating launches; every product is three "
+                                   "tp_mlp_fwd + tp_mlp_bwd, 10 pairs replayed from a hipGraph (split by eager brackets); every product is three "
                                    "f16 MFMAs; other_kernels_ms = replayed step - these (ray-gen, composite fwd/bwd, losses, "
                                    "gathers, Adam, pack)"}
     return out

@@ -14,7 +14,7 @@ for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             if counter not in r["Counter_Name"]:
                 continue
             per_dispatch[r["Dispatch_Id"]] += float(r["Counter_Value"])
-            meta[r["Dispatch_Id"]] = (r["Kernel_Name"].split("(")[0], int(r["Grid_Size"]))
+            meta[r["Dispatch_Id"]] = (r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0], int(r["Grid_Size"]))
         for d, v in per_dispatch.items():
             acc[meta[d]][counter].append(v)
 
