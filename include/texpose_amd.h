@@ -26,7 +26,7 @@ extern "C" {
 
 typedef void* tp_stream_t; /* hipStream_t */
 
-#define TP_ABI_VERSION 4
+#define TP_ABI_VERSION 5
 
 int tp_abi_version(void);
 const char* tp_last_error(void);
@@ -195,18 +195,22 @@ typedef struct tp_composite_args {
   float* alpha_static;   /* [n,N] or NULL */
   float* alpha_transient;/* [n,N] or NULL */
   float* prob;           /* [n,N] or NULL */
+  float* rgb_ray;        /* [n,3] or NULL: compact copy of out_ray[:,0:3] (what the losses and the PatchGAN consume) */
+  float* uncert_ray;     /* [n]   or NULL: compact copy of out_ray[:,13] */
 } tp_composite_args;
 int tp_composite_fwd(const tp_composite_args* args, tp_stream_t stream);
 
 typedef struct tp_composite_bwd_args {
   tp_composite_args fwd;        /* same inputs as the forward (outputs ignored) */
-  const float* g_out_ray;       /* [n,14] cotangent of out_ray */
+  const float* g_out_ray;       /* [n,14] cotangent of out_ray, or NULL (zeros) when g_rgb_ray / g_uncert_ray carry it all */
   const float* g_alpha_static;  /* [n,N] or NULL */
   const float* g_alpha_transient;
   const float* g_prob;
   float* g_rgb;                 /* [n,N,3,2] out */
   float* g_density;             /* [n,N,2]   out */
   float* g_uncert;              /* [n,N]     out */
+  const float* g_rgb_ray;       /* [n,3] or NULL: cotangent of rgb_ray, ADDED to g_out_ray[:,0:3] */
+  const float* g_uncert_ray;    /* [n]   or NULL: cotangent of uncert_ray, ADDED to g_out_ray[:,13] */
 } tp_composite_bwd_args;
 int tp_composite_bwd(const tp_composite_bwd_args* args, tp_stream_t stream);
 
@@ -437,6 +441,24 @@ typedef struct tp_adam_tensor {
 int tp_adam_step(const tp_adam_tensor* tensors /* host array */, int n, const float* lr_dev, double lr_host, double beta1, double beta2,
                  double eps, const int32_t* gate, int n_gate, tp_stream_t stream);
 int tp_disc_inputs(const float* rgb, const float* gathered, int B, int P, int geo, float* real, float* fake, tp_stream_t stream);
+/* Cotangent of the fake stack wrt the rendered colours (the nerf step back-propagates D(fake) into the render):
+ * g_rgb [B,P,3] = g_fake [B,nc,P] channels 0..2, transposed. */
+int tp_fake_patch_bwd(const float* g_fake, int B, int P, int nc, float* g_rgb, tp_stream_t stream);
+/* Feature loss of the generator step (model/nerf_adapt_st_gan.py:762-766; layers/perceptual_loss.py:39-45): feat [4n] = network
+ * features of [fake1 | fake2 | real1 | real2] (n floats each); out3 = {l1 + w2 l2, l1, l2} with l_i = mean((fake_i - real_i)^2);
+ * backward g_feat [4n] for the cotangent g[0] of out3[0] (targets detached: their quarters are zero). */
+int tp_feat_pair_loss_fwd(const float* feat, int64_t n, float w2, float* out3, tp_stream_t stream);
+int tp_feat_pair_loss_bwd(const float* feat, int64_t n, float w2, const float* g, float* g_feat, tp_stream_t stream);
+/* R1 penalty value (model/nerf_adapt_st_gan.py:794-807 and the mean over the batch its caller takes, :149): out[0] = sum(g^2) / B
+ * for g [B,m] (n = B m floats); backward out [n] = 2 g cot[0] / B. */
+int tp_sumsq_mean_fwd(const float* g, int64_t n, int B, float* out, tp_stream_t stream);
+int tp_sumsq_mean_bwd(const float* g, int64_t n, int B, const float* cot, float* out, tp_stream_t stream);
+/* Rows idx[b] of the two latent tables (model/nerf_adapt_st_gan.py:589-593) in one launch, and the dense table gradients
+ * gw [n_rows,C] = sum over b with idx[b] == r of g[b] (ascending b; every element written: no zero-fill needed). */
+int tp_latent_rows_fwd(const float* w_trans, const float* w_light, const int64_t* idx, int B, int C_trans, int C_light, float* out_trans,
+                       float* out_light, tp_stream_t stream);
+int tp_latent_rows_bwd(const float* g_trans, const float* g_light, const int64_t* idx, int B, int n_rows, int C_trans, int C_light,
+                       float* gw_trans, float* gw_light, tp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * K14  Scale-conditioned head of the PatchGAN (reference layers/discriminator.py:30-40,112-115):

@@ -1797,3 +1797,94 @@ def test_feature_loss_from_patches_matches_torch(ops):
     grd, = torch.autograd.grad(l1d + 5 * l2d, rd)
     assert rel_l2(l1, l1d) < 1e-5 and rel_l2(l2, l2d) < 1e-5
     assert rel_l2(gr, grd) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------ round-3 K13 additions
+def test_composite_compact_outputs_and_cotangents(ops):
+    """tp_composite_fwd's compact rgb / uncert copies equal columns 0..2 / 13 of out_ray bit for bit; tp_composite_bwd with the
+    cotangent split over g_out_ray / g_rgb_ray / g_uncert_ray equals the all-in-g_out_ray call bit for bit."""
+    rs = np.random.RandomState(5)
+    n, N = 70, 40
+    ray = cu(torch.from_numpy(rs.normal(size=(1, n, 3)).astype(np.float32)))
+    rgb = cu(torch.from_numpy(rs.uniform(size=(1, n, N, 3, 2)).astype(np.float32)))
+    den = cu(torch.from_numpy(rs.uniform(0, 3, size=(1, n, N, 2)).astype(np.float32)))
+    z = cu(torch.from_numpy(np.sort(rs.uniform(6, 9, size=(1, n, N, 1)), axis=2).astype(np.float32)))
+    unc = cu(torch.from_numpy(rs.uniform(0.1, 1, size=(1, n, N, 1)).astype(np.float32)))
+    out, a_s, a_t, prob, rgb_ray, unc_ray = ops.composite_fwd(ray, rgb, den, z, unc, 0.05, compact=True)
+    assert torch.equal(rgb_ray, out[..., 0:3]) and torch.equal(unc_ray, out[..., 13:14])
+    g = cu(torch.from_numpy(rs.normal(size=(1, n, 14)).astype(np.float32)))
+    ref = ops.composite_bwd(ray, rgb, den, z, unc, g)
+    g_rest = g.clone()
+    g_rest[..., 0:3] = 0
+    g_rest[..., 13] = 0
+    split = ops.composite_bwd(ray, rgb, den, z, unc, g_rest, g_rgb_ray=g[..., 0:3].contiguous(), g_uncert_ray=g[..., 13:14].contiguous())
+    for a, b in zip(ref, split):
+        assert torch.equal(a, b)
+    only = ops.composite_bwd(ray, rgb, den, z, unc, None, g_rgb_ray=g[..., 0:3].contiguous(), g_uncert_ray=g[..., 13:14].contiguous())
+    g_two = torch.zeros_like(g)
+    g_two[..., 0:3], g_two[..., 13] = g[..., 0:3], g[..., 13]
+    for a, b in zip(ops.composite_bwd(ray, rgb, den, z, unc, g_two), only):
+        assert torch.equal(a, b)
+
+
+def test_round3_glue_kernels_match_torch(ops):
+    """tp_feat_pair_loss, tp_sumsq_mean (incl. its use under a double backward), tp_latent_rows (repeated rows) and the
+    fake-patch cotangent against the torch expressions they replace."""
+    from texpose_amd import autograd_ops
+    rs = np.random.RandomState(9)
+    # feature-pair loss
+    for B, shape in ((4, (256, 4, 4)), (3, (17, 5, 3))):
+        feat = cu(torch.from_numpy(rs.normal(size=(4 * B,) + shape).astype(np.float32))).requires_grad_()
+        loss, parts = autograd_ops.feat_pair_loss(feat, 5.0)
+        f1, f2, r1, r2 = torch.split(feat.detach().clone().requires_grad_(), B, dim=0)
+        fr = torch.cat([f1, f2, r1, r2]).detach().requires_grad_()
+        a, b, c, d = torch.split(fr, B, dim=0)
+        ref = F.mse_loss(a, c.detach()) + 5 * F.mse_loss(b, d.detach())
+        torch.testing.assert_close(loss, ref, rtol=2e-6, atol=1e-7)
+        torch.testing.assert_close(parts[0], F.mse_loss(a, c), rtol=2e-6, atol=1e-7)
+        (loss * 0.7).backward()
+        (ref * 0.7).backward()
+        torch.testing.assert_close(feat.grad, fr.grad, rtol=1e-6, atol=1e-9)
+        assert float(feat.grad[2 * B:].abs().max()) == 0.0
+    # R1 value through a small differentiable map (double backward of a tanh MLP)
+    W = cu(torch.from_numpy(rs.normal(size=(7, 5)).astype(np.float32))).requires_grad_()
+    x = cu(torch.from_numpy(rs.normal(size=(6, 5)).astype(np.float32))).requires_grad_()
+    grads = []
+    for fused in (True, False):
+        W.grad = None
+        d = torch.tanh(x @ W.t()).sum(1)
+        if fused:
+            g = torch.autograd.grad(d, x, grad_outputs=torch.ones_like(d), create_graph=True)[0]
+            reg = autograd_ops.sumsq_mean(g)
+        else:
+            g = torch.autograd.grad(d.sum(), x, create_graph=True)[0]
+            reg = g.pow(2).reshape(6, -1).sum(1).mean()
+        reg.backward()
+        grads.append((float(reg), W.grad.clone()))
+    assert abs(grads[0][0] - grads[1][0]) < 1e-6 * abs(grads[1][0])
+    torch.testing.assert_close(grads[0][1], grads[1][1], rtol=1e-5, atol=1e-7)
+    # latent rows, with a repeated index
+    wt = cu(torch.from_numpy(rs.normal(size=(11, 16)).astype(np.float32))).requires_grad_()
+    wl = cu(torch.from_numpy(rs.normal(size=(11, 48)).astype(np.float32))).requires_grad_()
+    idx = cu(torch.tensor([3, 7, 3, 0, 10]))
+    lt, ll = autograd_ops.latent_rows(wt, wl, idx)
+    assert torch.equal(lt, wt.detach()[idx]) and torch.equal(ll, wl.detach()[idx])
+    ct, cl = cu(torch.from_numpy(rs.normal(size=(5, 16)).astype(np.float32))), cu(torch.from_numpy(rs.normal(size=(5, 48)).astype(np.float32)))
+    ((lt * ct).sum() + (ll * cl).sum()).backward()
+    rt = torch.zeros(11, 16, device=dev()).index_add_(0, idx, ct)
+    rl = torch.zeros(11, 48, device=dev()).index_add_(0, idx, cl)
+    torch.testing.assert_close(wt.grad, rt, rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(wl.grad, rl, rtol=1e-6, atol=1e-7)
+    # fake patch stack: values and cotangent
+    B, p = 3, 8
+    rgb = cu(torch.from_numpy(rs.uniform(size=(B, p * p, 3)).astype(np.float32))).requires_grad_()
+    gathered = cu(torch.from_numpy(rs.uniform(size=(B, 14, p, p)).astype(np.float32)))
+    gathered[:, 12:] = (gathered[:, 12:] > 0.5).float()
+    real, fake = autograd_ops.disc_patches(rgb, gathered, (p, p), True)
+    r2, f2 = ops.disc_inputs(rgb.detach(), gathered, (p, p), True)
+    assert torch.equal(real, r2) and torch.equal(fake, f2) and not real.requires_grad
+    ref_fake = torch.cat([rgb.detach().view(B, p, p, 3).permute(0, 3, 1, 2), gathered[:, 6:12]], 1)
+    torch.testing.assert_close(fake, ref_fake)
+    cot = cu(torch.from_numpy(rs.normal(size=(B, 9, p, p)).astype(np.float32)))
+    (fake * cot).sum().backward()
+    torch.testing.assert_close(rgb.grad, cot[:, :3].permute(0, 2, 3, 1).reshape(B, p * p, 3))

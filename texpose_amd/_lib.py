@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # TEXPOSE_AMD_LIB selects another build of the SAME library (e.g. the `make trace` diagnostic build); never a fallback
 LIB_PATH = os.environ.get("TEXPOSE_AMD_LIB") or os.path.join(_HERE, "libtexpose_amd.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 # Every symbol include/texpose_amd.h declares (checked by tests/test_capi_cpu.py).
 SYMBOLS = (
@@ -31,6 +31,8 @@ SYMBOLS = (
     "tp_conv4s2_workspace", "tp_conv4s2_fwd", "tp_conv4s2_dgrad", "tp_conv4s2_wgrad",
     "tp_conv3s1_workspace", "tp_conv3s1_fwd", "tp_conv3s1_dgrad",
     "tp_patch_coords", "tp_bce_logits_fwd", "tp_bce_logits_bwd", "tp_feat_inputs_fwd", "tp_feat_inputs_bwd", "tp_disc_inputs", "tp_step_flags", "tp_adam_step",
+    "tp_fake_patch_bwd", "tp_feat_pair_loss_fwd", "tp_feat_pair_loss_bwd", "tp_sumsq_mean_fwd", "tp_sumsq_mean_bwd", "tp_latent_rows_fwd",
+    "tp_latent_rows_bwd",
     "tp_disc_head_fwd", "tp_disc_head_bwd", "tp_disc_head_bwd_bwd",
     "tp_skinny_linear_fwd", "tp_skinny_linear_wgrad",
 )
@@ -71,13 +73,14 @@ class MlpBwdArgs(C.Structure):
 class CompositeArgs(C.Structure):
     _fields_ = [("ray", vp), ("rgb", vp), ("density", vp), ("depth", vp), ("uncert", vp),
                 ("n", C.c_int64), ("N", C.c_int), ("min_uncert", C.c_float),
-                ("out_ray", vp), ("alpha_static", vp), ("alpha_transient", vp), ("prob", vp)]
+                ("out_ray", vp), ("alpha_static", vp), ("alpha_transient", vp), ("prob", vp),
+                ("rgb_ray", vp), ("uncert_ray", vp)]
 
 
 class CompositeBwdArgs(C.Structure):
     _fields_ = [("fwd", CompositeArgs), ("g_out_ray", vp), ("g_alpha_static", vp),
                 ("g_alpha_transient", vp), ("g_prob", vp), ("g_rgb", vp), ("g_density", vp),
-                ("g_uncert", vp)]
+                ("g_uncert", vp), ("g_rgb_ray", vp), ("g_uncert_ray", vp)]
 
 
 class PatchGatherArgs(C.Structure):
@@ -220,6 +223,13 @@ def load() -> C.CDLL:
     sig("tp_feat_inputs_fwd", [C.POINTER(FeatInputsArgs), vp, vp])
     sig("tp_feat_inputs_bwd", [C.POINTER(FeatInputsArgs), vp, vp, vp])
     sig("tp_disc_inputs", [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp])
+    sig("tp_fake_patch_bwd", [vp, C.c_int, C.c_int, C.c_int, vp, vp])
+    sig("tp_feat_pair_loss_fwd", [vp, C.c_int64, C.c_float, vp, vp])
+    sig("tp_feat_pair_loss_bwd", [vp, C.c_int64, C.c_float, vp, vp, vp])
+    sig("tp_sumsq_mean_fwd", [vp, C.c_int64, C.c_int, vp, vp])
+    sig("tp_sumsq_mean_bwd", [vp, C.c_int64, C.c_int, vp, vp, vp])
+    sig("tp_latent_rows_fwd", [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp])
+    sig("tp_latent_rows_bwd", [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp])
     for name in ("tp_disc_head_fwd", "tp_disc_head_bwd", "tp_disc_head_bwd_bwd"):
         sig(name, [C.POINTER(DiscHeadArgs), vp])
     for name in ("tp_skinny_linear_fwd", "tp_skinny_linear_wgrad"):

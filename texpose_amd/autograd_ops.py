@@ -13,27 +13,31 @@ from . import ops
 
 
 class _Composite(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, ray, rgb, density, depth, uncert, min_uncert, per_sample, want_prob):
-        out, a_s, a_t, prob = ops.composite_fwd(ray, rgb, density, depth, uncert, min_uncert, per_sample=per_sample,
-                                                want_prob=want_prob)
-        ctx.save_for_backward(ray, rgb, density, depth, uncert)
-        ctx.min_uncert = min_uncert
-        return out, a_s, a_t, prob
+    """out [..,14], alpha_static, alpha_transient, prob, rgb_ray [..,3], uncert_ray [..,1].  The last two are compact copies of
+    columns 0..2 / 13 of `out` written by the same launch: a training step consumes ONLY those two, as contiguous tensors
+    with their own cotangents -- slices of `out` cost a copy per consumer and a zero-fill + copy + add per slice backward."""
 
     @staticmethod
-    def backward(ctx, g_out, g_as, g_at, g_prob):
+    def forward(ctx, ray, rgb, density, depth, uncert, min_uncert, per_sample, want_prob):
+        out, a_s, a_t, prob, rgb_ray, unc_ray = ops.composite_fwd(ray, rgb, density, depth, uncert, min_uncert,
+                                                                  per_sample=per_sample, want_prob=want_prob, compact=True)
+        ctx.save_for_backward(ray, rgb, density, depth, uncert)
+        ctx.min_uncert = min_uncert
+        ctx.set_materialize_grads(False)
+        return out, a_s, a_t, prob, rgb_ray, unc_ray
+
+    @staticmethod
+    def backward(ctx, g_out, g_as, g_at, g_prob, g_rgb_ray, g_unc_ray):
         ray, rgb, density, depth, uncert = ctx.saved_tensors
-        if g_out is None:
-            g_out = torch.zeros(*ray.shape[:-1], 14, device=ray.device)
-        g_rgb, g_den, g_unc = ops.composite_bwd(ray, rgb, density, depth, uncert, g_out, g_as, g_at, g_prob,
-                                                ctx.min_uncert)
+        g_rgb, g_den, g_unc = ops.composite_bwd(ray, rgb, density, depth, uncert, g_out, g_as, g_at, g_prob, ctx.min_uncert,
+                                                g_rgb_ray=g_rgb_ray, g_uncert_ray=g_unc_ray)
         return None, g_rgb, g_den, None, g_unc.view_as(uncert), None, None, None   # (ray, rgb, density, depth, uncert, ...)
 
 
 def composite(ray, rgb, density, depth, uncert, min_uncert, per_sample=True, want_prob=True):
     """``per_sample`` / ``want_prob`` = False skip writing alpha_static / alpha_transient / prob ([B,R,N] each; the
-    per-ray sums do not need them): the returned entries are then None."""
+    per-ray sums do not need them): the returned entries are then None.
+    -> (out [..,14], alpha_static, alpha_transient, prob, rgb_ray [..,3], uncert_ray [..,1])"""
     return _Composite.apply(ray, rgb, density, depth, uncert, float(min_uncert), bool(per_sample), bool(want_prob))
 
 
@@ -356,3 +360,92 @@ class _SkinnyLinearWgrad(torch.autograd.Function):
 def skinny_linear(x, w):
     """x [M,K] @ w [N,K]^T for M <= 256 rows (K15), differentiable to any order."""
     return _SkinnyLinear.apply(x.contiguous(), w.contiguous())
+
+
+# ---- K13 (round 3): the remaining small chains of the GAN step, one launch per direction
+class _DiscPatches(torch.autograd.Function):
+    """(real, fake) [B,nc,h,w] of the PatchGAN from the rendered colours and the gathered patches (tp_disc_inputs).  `fake`
+    carries the gradient back to rgb (the nerf step's D(fake) term), `real` is a constant of the step."""
+
+    @staticmethod
+    def forward(ctx, rgb, gathered, hw, geo):
+        real, fake = ops.disc_inputs(rgb, gathered, hw, geo)
+        ctx.dims = (rgb.shape[0], rgb.shape[1])
+        ctx.mark_non_differentiable(real)
+        ctx.set_materialize_grads(False)
+        return real, fake
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_real, g_fake):
+        if g_fake is None:
+            return None, None, None, None
+        return ops.fake_patch_bwd(g_fake.contiguous(), *ctx.dims), None, None, None
+
+
+def disc_patches(rgb, gathered, hw, geo: bool):
+    return _DiscPatches.apply(rgb, gathered, tuple(hw), bool(geo))
+
+
+class _FeatPairLoss(torch.autograd.Function):
+    """l1 + w2 l2 with l_i = mse(feat(fake_i), feat(real_i).detach()) for feat = features of [fake1 | fake2 | real1 | real2]
+    (reference model/nerf_adapt_st_gan.py:762-766): two mse_loss + mul + add and their backward chains as one launch each."""
+
+    @staticmethod
+    def forward(ctx, feat, w2):
+        out = ops.feat_pair_loss_fwd(feat, w2)
+        ctx.save_for_backward(feat)
+        ctx.w2 = w2
+        return out[0], out[1:].detach()
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g, _g_parts):
+        (feat,) = ctx.saved_tensors
+        return ops.feat_pair_loss_bwd(feat, ctx.w2, g.contiguous()), None
+
+
+def feat_pair_loss(feat, w2: float = 5.0):
+    """-> (loss, [l1, l2]) ."""
+    return _FeatPairLoss.apply(feat.contiguous(), float(w2))
+
+
+class _SumsqMean(torch.autograd.Function):
+    """sum(g^2) / B: the R1 penalty value of a batch (compute_grad2(...).mean() with one discriminator output).  Its backward
+    (2 g cot / B) feeds the double backward of the discriminator; it is itself only needed at first order."""
+
+    @staticmethod
+    def forward(ctx, g):
+        ctx.save_for_backward(g)
+        return ops.sumsq_mean_fwd(g)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, cot):
+        (g,) = ctx.saved_tensors
+        return ops.sumsq_mean_bwd(g, cot.contiguous())
+
+
+def sumsq_mean(g):
+    return _SumsqMean.apply(g.contiguous())
+
+
+class _LatentRows(torch.autograd.Function):
+    """Rows idx of the transient / light latent tables in one launch; dense table gradients in one launch (no zero fill)."""
+
+    @staticmethod
+    def forward(ctx, w_trans, w_light, idx):
+        ctx.save_for_backward(idx)
+        ctx.n_rows = w_trans.shape[0]
+        return ops.latent_rows_fwd(w_trans, w_light, idx)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_trans, g_light):
+        (idx,) = ctx.saved_tensors
+        gwt, gwl = ops.latent_rows_bwd(g_trans.contiguous(), g_light.contiguous(), idx, ctx.n_rows)
+        return gwt, gwl, None
+
+
+def latent_rows(w_trans, w_light, idx):
+    return _LatentRows.apply(w_trans, w_light, idx)

@@ -118,6 +118,8 @@ __global__ __launch_bounds__(kWaves * 64) void composite_fwd_kernel(tp_composite
       float2* o = reinterpret_cast<float2*>(p.out_ray + q * 14);
 #pragma unroll
       for (int k = 0; k < 7; ++k) o[k] = make_float2(acc[2 * k], acc[2 * k + 1]);
+      if (p.rgb_ray) { p.rgb_ray[q * 3] = acc[0]; p.rgb_ray[q * 3 + 1] = acc[1]; p.rgb_ray[q * 3 + 2] = acc[2]; }
+      if (p.uncert_ray) p.uncert_ray[q] = acc[13];
     }
   }
 }
@@ -150,7 +152,9 @@ __global__ __launch_bounds__(kWaves * 64) void composite_bwd_kernel(tp_composite
     const float len = ray_len(p.ray, q);
     float g[14];
 #pragma unroll
-    for (int k = 0; k < 14; ++k) g[k] = b.g_out_ray[q * 14 + k];
+    for (int k = 0; k < 14; ++k) g[k] = b.g_out_ray ? b.g_out_ray[q * 14 + k] : 0.f;
+    if (b.g_rgb_ray) { g[0] += b.g_rgb_ray[q * 3]; g[1] += b.g_rgb_ray[q * 3 + 1]; g[2] += b.g_rgb_ray[q * 3 + 2]; }
+    if (b.g_uncert_ray) g[13] += b.g_uncert_ray[q];
     Carry carry = {0.f, 0.f, 0.f};
     for (int c = 0; c < n_chunks; ++c) {
       if (lane == 0) { s_carry[wv][0][c] = carry.s; s_carry[wv][1][c] = carry.t; s_carry[wv][2][c] = carry.j; }
@@ -212,7 +216,7 @@ extern "C" int tp_composite_fwd(const tp_composite_args* a, tp_stream_t stream) 
 
 extern "C" int tp_composite_bwd(const tp_composite_bwd_args* a, tp_stream_t stream) {
   TP_REQUIRE(a && a->fwd.ray && a->fwd.rgb && a->fwd.density && a->fwd.depth && a->fwd.uncert, "null forward input");
-  TP_REQUIRE(a->g_out_ray && a->g_rgb && a->g_density && a->g_uncert, "null gradient pointer");
+  TP_REQUIRE((a->g_out_ray || a->g_rgb_ray || a->g_uncert_ray) && a->g_rgb && a->g_density && a->g_uncert, "null gradient pointer");
   TP_REQUIRE(a->fwd.N > 0 && a->fwd.n >= 0, "bad sizes");
   TP_REQUIRE(a->fwd.N <= 64 * kMaxChunks, "composite backward supports at most 2048 samples per ray");
   if (a->fwd.n == 0) return 0;

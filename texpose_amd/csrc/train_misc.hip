@@ -176,6 +176,94 @@ __global__ void adam_bump_kernel(AdamTable t, const int* gate, int n_gate) {
     if (first) t.step[k][0] += 1.0f;
   }
 }
+
+// ---- feature loss of the generator step (model/nerf_adapt_st_gan.py:762-766; layers/perceptual_loss.py:39-45):
+// feat [4n] = features of [fake1 | fake2 | real1 | real2]; l1 = mean((fake1 - real1)^2), l2 = mean((fake2 - real2)^2),
+// out = {l1 + w2 l2, l1, l2}.  One workgroup, fixed-order tree (torch: two mse_loss launches x 2 + mul + add).
+constexpr int kRedBlock = 1024;
+__global__ __launch_bounds__(kRedBlock) void feat_pair_loss_fwd_kernel(const float* __restrict__ feat, int64_t n, float w2, float* __restrict__ out) {
+  __shared__ float red[2][kRedBlock];
+  float a1 = 0.f, a2 = 0.f;
+  for (int64_t i = threadIdx.x; i < n; i += kRedBlock) {
+    const float d1 = feat[i] - feat[2 * n + i], d2 = feat[n + i] - feat[3 * n + i];
+    a1 += d1 * d1;
+    a2 += d2 * d2;
+  }
+  red[0][threadIdx.x] = a1; red[1][threadIdx.x] = a2;
+  __syncthreads();
+  for (int s = kRedBlock >> 1; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) { red[0][threadIdx.x] += red[0][threadIdx.x + s]; red[1][threadIdx.x] += red[1][threadIdx.x + s]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const float l1 = red[0][0] / (float)n, l2 = red[1][0] / (float)n;
+    out[0] = l1 + w2 * l2; out[1] = l1; out[2] = l2;
+  }
+}
+// d/d feat: 2 (fake1 - real1) g / n | 2 w2 (fake2 - real2) g / n | 0 | 0   (the targets are detached)
+__global__ __launch_bounds__(kBlock) void feat_pair_loss_bwd_kernel(const float* __restrict__ feat, int64_t n, float w2, const float* __restrict__ g,
+                                                                     float* __restrict__ g_feat) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const float s = 2.f * g[0] / (float)n;
+  g_feat[i] = s * (feat[i] - feat[2 * n + i]);
+  g_feat[n + i] = s * w2 * (feat[n + i] - feat[3 * n + i]);
+  g_feat[2 * n + i] = 0.f;
+  g_feat[3 * n + i] = 0.f;
+}
+
+// ---- cotangent of the fake patch stack wrt the rendered colours: g_rgb [B,P,3] = g_fake [B,nc,P][:, 0:3] transposed
+__global__ __launch_bounds__(kBlock) void fake_patch_bwd_kernel(const float* __restrict__ g_fake, int B, int P, int nc, float* __restrict__ g_rgb) {
+  const int e = blockIdx.x * kBlock + threadIdx.x;
+  if (e >= B * P) return;
+  const int b = e / P, p = e - b * P;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) g_rgb[(size_t)e * 3 + c] = g_fake[((size_t)b * nc + c) * P + p];
+}
+
+// ---- R1 penalty value (model/nerf_adapt_st_gan.py:794-807 + the .mean() of its caller): out = sum(g^2) / B for g [B, m];
+// backward: 2 g cot / B.  One workgroup forward (fixed order).
+__global__ __launch_bounds__(kRedBlock) void sumsq_mean_fwd_kernel(const float* __restrict__ g, int64_t n, int B, float* __restrict__ out) {
+  __shared__ float red[kRedBlock];
+  float a = 0.f;
+  for (int64_t i = threadIdx.x; i < n; i += kRedBlock) a += g[i] * g[i];
+  red[threadIdx.x] = a;
+  __syncthreads();
+  for (int s = kRedBlock >> 1; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = red[0] / (float)B;
+}
+__global__ __launch_bounds__(kBlock) void sumsq_mean_bwd_kernel(const float* __restrict__ g, int64_t n, int B, const float* __restrict__ cot,
+                                                                 float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i < n) out[i] = 2.f * cot[0] / (float)B * g[i];
+}
+
+// ---- per-image latent rows (model/nerf_adapt_st_gan.py:589-593: Embedding.weight[var.idx]) of BOTH tables in one launch,
+// and their gradient: dense [n_rows, C] tables with g[r] = sum over the images b with idx[b] == r, in ascending b (no
+// atomics, no zero-fill launch; torch: index_select x 2 forward, zeros + index_add_ x 2 backward)
+__global__ __launch_bounds__(kBlock) void latent_rows_fwd_kernel(const float* __restrict__ wt, const float* __restrict__ wl, const int64_t* __restrict__ idx,
+                                                                  int B, int Ct, int Cl, float* __restrict__ ot, float* __restrict__ ol) {
+  const int e = blockIdx.x * kBlock + threadIdx.x, C = Ct + Cl;
+  if (e >= B * C) return;
+  const int b = e / C, c = e - b * C;
+  const int64_t r = idx[b];
+  if (c < Ct) ot[b * Ct + c] = wt[r * Ct + c];
+  else ol[b * Cl + (c - Ct)] = wl[r * Cl + (c - Ct)];
+}
+__global__ __launch_bounds__(kBlock) void latent_rows_bwd_kernel(const float* __restrict__ gt, const float* __restrict__ gl, const int64_t* __restrict__ idx,
+                                                                  int B, int n_rows, int Ct, int Cl, float* __restrict__ gwt, float* __restrict__ gwl) {
+  const int e = blockIdx.x * kBlock + threadIdx.x, C = Ct + Cl;
+  if (e >= n_rows * C) return;
+  const int r = e / C, c = e - r * C;
+  float acc = 0.f;
+  for (int b = 0; b < B; ++b)
+    if (idx[b] == r) acc += c < Ct ? gt[b * Ct + c] : gl[b * Cl + (c - Ct)];
+  if (c < Ct) gwt[r * Ct + c] = acc;
+  else gwl[r * Cl + (c - Ct)] = acc;
+}
 }  // namespace
 
 extern "C" {
@@ -260,5 +348,48 @@ int tp_feat_inputs_bwd(const tp_feat_inputs_args* a, const float* g_out, float* 
   const int n = a->B * a->P;
   hipLaunchKernelGGL(feat_inputs_bwd_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, (hipStream_t)stream, q);
   return tp::check_launch("tp_feat_inputs_bwd");
+}
+
+int tp_feat_pair_loss_fwd(const float* feat, int64_t n, float w2, float* out3, tp_stream_t stream) {
+  TP_REQUIRE(feat && out3 && n > 0, "bad arguments");
+  hipLaunchKernelGGL(feat_pair_loss_fwd_kernel, dim3(1), dim3(kRedBlock), 0, (hipStream_t)stream, feat, n, w2, out3);
+  return tp::check_launch("tp_feat_pair_loss_fwd");
+}
+int tp_feat_pair_loss_bwd(const float* feat, int64_t n, float w2, const float* g, float* g_feat, tp_stream_t stream) {
+  TP_REQUIRE(feat && g && g_feat && n > 0, "bad arguments");
+  hipLaunchKernelGGL(feat_pair_loss_bwd_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream, feat, n, w2, g, g_feat);
+  return tp::check_launch("tp_feat_pair_loss_bwd");
+}
+int tp_fake_patch_bwd(const float* g_fake, int B, int P, int nc, float* g_rgb, tp_stream_t stream) {
+  TP_REQUIRE(g_fake && g_rgb && B > 0 && P > 0 && nc >= 3, "bad arguments");
+  const int n = B * P;
+  hipLaunchKernelGGL(fake_patch_bwd_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, (hipStream_t)stream, g_fake, B, P, nc, g_rgb);
+  return tp::check_launch("tp_fake_patch_bwd");
+}
+int tp_sumsq_mean_fwd(const float* g, int64_t n, int B, float* out, tp_stream_t stream) {
+  TP_REQUIRE(g && out && n > 0 && B > 0, "bad arguments");
+  hipLaunchKernelGGL(sumsq_mean_fwd_kernel, dim3(1), dim3(kRedBlock), 0, (hipStream_t)stream, g, n, B, out);
+  return tp::check_launch("tp_sumsq_mean_fwd");
+}
+int tp_sumsq_mean_bwd(const float* g, int64_t n, int B, const float* cot, float* out, tp_stream_t stream) {
+  TP_REQUIRE(g && cot && out && n > 0 && B > 0, "bad arguments");
+  hipLaunchKernelGGL(sumsq_mean_bwd_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream, g, n, B, cot, out);
+  return tp::check_launch("tp_sumsq_mean_bwd");
+}
+int tp_latent_rows_fwd(const float* w_trans, const float* w_light, const int64_t* idx, int B, int C_trans, int C_light, float* out_trans,
+                       float* out_light, tp_stream_t stream) {
+  TP_REQUIRE(w_trans && w_light && idx && out_trans && out_light && B > 0 && C_trans > 0 && C_light > 0, "bad arguments");
+  const int n = B * (C_trans + C_light);
+  hipLaunchKernelGGL(latent_rows_fwd_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, (hipStream_t)stream, w_trans, w_light, idx, B,
+                     C_trans, C_light, out_trans, out_light);
+  return tp::check_launch("tp_latent_rows_fwd");
+}
+int tp_latent_rows_bwd(const float* g_trans, const float* g_light, const int64_t* idx, int B, int n_rows, int C_trans, int C_light,
+                       float* gw_trans, float* gw_light, tp_stream_t stream) {
+  TP_REQUIRE(g_trans && g_light && idx && gw_trans && gw_light && B > 0 && n_rows > 0 && C_trans > 0 && C_light > 0, "bad arguments");
+  const int n = n_rows * (C_trans + C_light);
+  hipLaunchKernelGGL(latent_rows_bwd_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, (hipStream_t)stream, g_trans, g_light, idx, B,
+                     n_rows, C_trans, C_light, gw_trans, gw_light);
+  return tp::check_launch("tp_latent_rows_bwd");
 }
 }

@@ -255,6 +255,15 @@ class PerceptualLoss(nn.Module):
         f1, f2, r1, r2 = torch.split(feat, B, dim=0)
         return F.mse_loss(f1, r1.detach()), F.mse_loss(f2, r2.detach())
 
+    def loss_from_patches(self, rgb, gathered, hw, w2: float = 5.0):
+        """P(fake1, real1) + w2 P(fake2, real2) of the generator step (reference model/nerf_adapt_st_gan.py:762-766) as three
+        launch groups: inputs (K13 tp_feat_inputs), one pass through the feature network (K12), the two mean squared
+        differences and their weighted sum (K13 tp_feat_pair_loss)."""
+        from . import autograd_ops
+        x = autograd_ops.feat_inputs(rgb, gathered, self._mean_host, self._std_host, hw)
+        loss, _parts = autograd_ops.feat_pair_loss(self.features(x), w2)
+        return loss
+
     def pairs(self, *fake_real):
         """[MSE(feat(fake_i), feat(real_i))] for several (fake, real) pairs through ONE pass over the feature network
         (the two terms of the reference's feature loss are four passes, :763-766): the same per-sample arithmetic --

@@ -30,6 +30,15 @@ RENDER_KEYS = ("rgb", "rgb_static", "rgb_transient", "opacity", "opacity_static"
                "depth", "alpha_static", "alpha_transient", "density")
 
 _philox_calls = itertools.count()
+_ones_cache = {}
+
+
+def _ones_like_cached(t):
+    """A constant tensor of ones shaped like ``t`` (made once per shape / device: no fill launch per step, capturable)."""
+    key = (tuple(t.shape), t.dtype, str(t.device))
+    if key not in _ones_cache:
+        _ones_cache[key] = torch.ones_like(t).detach()
+    return _ones_cache[key]
 
 
 class Graph(torch.nn.Module):
@@ -102,8 +111,12 @@ class Graph(torch.nn.Module):
         center, ray, _, _, depth = ops.raygen(intr, pose, H=opt.H, W=opt.W, n_samples=N, z_near=z_near, z_far=z_far,
                                               **src, **self._jitter(opt, rand))
         depth_samples = depth[..., None]                                     # [B,R,N,1]
-        if mode == "train" and torch.is_tensor(sample_idx) and sample_idx.dim() == 1:
-            # (index_select: its backward is zeros + index_add_, two launches; indexing's is a seven-launch index_put_)
+        if (mode == "train" and torch.is_tensor(sample_idx) and sample_idx.dim() == 1 and sample_idx.is_cuda
+                and self.latent_vars_trans.weight.shape[0] == self.latent_vars_light.weight.shape[0]):
+            # K13: the rows of both tables in one launch, their dense gradients in one launch (index_select: two launches
+            # forward, zeros + index_add_ per table backward; indexing's backward is a seven-launch index_put_)
+            lat_t, lat_l = autograd_ops.latent_rows(self.latent_vars_trans.weight, self.latent_vars_light.weight, sample_idx)
+        elif mode == "train" and torch.is_tensor(sample_idx) and sample_idx.dim() == 1:
             lat_t = self.latent_vars_trans.weight.index_select(0, sample_idx)
             lat_l = self.latent_vars_light.weight.index_select(0, sample_idx)
         elif mode == "train":
@@ -253,9 +266,15 @@ class Graph(torch.nn.Module):
             if opt.gan.geo_conditional:
                 var = self.sample_geometry(opt, var, mode)
             B, h, w, _ = var.ray_idx.shape
-            patch_fake = var.rgb.view(B, h, w, 3).permute(0, 3, 1, 2)
-            if opt.gan.geo_conditional:
-                patch_fake = torch.cat([patch_fake, var.nocs_sample, var.normal_sample], dim=1)
+            if "gathered" in var and var.rgb.is_cuda and var.get("gathered_for") is var.ray_idx:
+                # K13: real / fake stacks in one launch (fake differentiable wrt rgb); the discriminator step of the same
+                # iteration re-uses them (same values: it detaches the very same render)
+                var.patch_real_nerf, patch_fake = autograd_ops.disc_patches(var.rgb, var.gathered, (h, w), bool(opt.gan.geo_conditional))
+                var.patch_fake_nerf, var.disc_patches_for = patch_fake, var.ray_idx
+            else:
+                patch_fake = var.rgb.view(B, h, w, 3).permute(0, 3, 1, 2)
+                if opt.gan.geo_conditional:
+                    patch_fake = torch.cat([patch_fake, var.nocs_sample, var.normal_sample], dim=1)
             var.d_fake_nerf = self.discriminator(opt, patch_fake, var.ray_scales)
         return var
 
@@ -263,7 +282,9 @@ class Graph(torch.nn.Module):
         if mode != "train":
             raise Exception("No use of discriminator in val/testing phase of NeRF!")
         B, h, w, _ = var.ray_idx.shape
-        if "gathered" in var and var.rgb.is_cuda and var.get("gathered_for") is var.ray_idx:
+        if var.get("disc_patches_for") is var.ray_idx and var.rgb.is_cuda:
+            real, fake = var.patch_real_nerf.detach(), var.patch_fake_nerf.detach()        # built by the nerf step of this iteration
+        elif "gathered" in var and var.rgb.is_cuda and var.get("gathered_for") is var.ray_idx:
             real, fake = ops.disc_inputs(var.rgb, var.gathered, (h, w), bool(opt.gan.geo_conditional))     # K13: one launch
         else:
             rgb = var.rgb.view(B, h, w, 3).permute(0, 3, 1, 2).contiguous()
@@ -365,7 +386,11 @@ class Graph(torch.nn.Module):
                     raise RuntimeError("loss_weight.feat is set but no perceptual_loss module was injected")
                 fused_feat = ("gathered" in var and var.rgb.is_cuda and hasattr(self.perceptual_loss, "pairs_from_patches")
                               and opt.nerf.rand_rays and mode in ["train", "test-optim"])
-                if fused_feat:              # K13 + K12: masking, concatenation and normalisation of the four batches in one launch
+                if fused_feat and hasattr(self.perceptual_loss, "loss_from_patches"):
+                    # K13 + K12: inputs of the four batches in one launch, one pass through the network, l1 + 5 l2 in one launch
+                    loss.feat = self.perceptual_loss.loss_from_patches(var.rgb, var.gathered, (h, w), 5.0)
+                    l1 = None
+                elif fused_feat:
                     l1, l2 = self.perceptual_loss.pairs_from_patches(var.rgb, var.gathered, (h, w))
                 else:
                     mask_pad = torch.logical_and(mask_syn == 1, obj_mask == 0).float()
@@ -377,7 +402,8 @@ class Graph(torch.nn.Module):
                         self._warn_once("compute_loss: the injected perceptual_loss has no fused entry points; calling it "
                                         "twice like the reference (:762-764)")
                         l1, l2 = self.perceptual_loss(*pair1), self.perceptual_loss(*pair2)
-                loss.feat = l1 + 5 * l2
+                if l1 is not None:
+                    loss.feat = l1 + 5 * l2
             if lw.lab is not None:
                 loss.lab, var.rgb_lab, var.img_syn_lab = self.lab_loss(rgb, image_syn, mask=mask_syn)
             if opt.gan is not None and lw.gan_nerf is not None and mode == "train":
@@ -403,12 +429,25 @@ class Graph(torch.nn.Module):
         return reg / len(d_outs)
 
     @staticmethod
+    def compute_grad2_mean(opt, d_out, x_in):
+        """``compute_grad2(opt, d_out, x_in).mean()`` for ONE discriminator output (what the discriminator step takes,
+        reference :146-149), with the glue fused on the GPU: the cotangent of d_out.sum() is a constant vector of ones (no
+        reduction launch), and sum(g^2) / B with its backward is one launch each way (K13) instead of pow / sum / add / div /
+        mean and their autograd chains."""
+        if not (d_out.is_cuda and torch.is_tensor(d_out)):
+            return Graph.compute_grad2(opt, d_out, x_in).mean()
+        ones = _ones_like_cached(d_out)
+        g = torch.autograd.grad(outputs=d_out, inputs=x_in, grad_outputs=ones, create_graph=True, retain_graph=True,
+                                only_inputs=True)[0]
+        return autograd_ops.sumsq_mean(g)
+
+    @staticmethod
     def compute_gan_loss(opt, d_outs, target):
         d_outs = d_outs if isinstance(d_outs, list) else [d_outs]
+        if opt.gan.type == "standard" and len(d_outs) == 1 and d_outs[0].is_cuda:
+            return autograd_ops.bce_logits_mean(d_outs[0], float(target))      # K13: one launch each way
         loss = d_outs[0].new_zeros(())                       # (no host-to-device copy: the step is hipGraph-capturable)
         for d_out in d_outs:
-            if opt.gan.type == "standard" and d_out.is_cuda and len(d_outs) == 1:
-                return autograd_ops.bce_logits_mean(d_out, float(target))      # K13: one launch each way
             if opt.gan.type == "standard":
                 loss = loss + torch_F.binary_cross_entropy_with_logits(d_out, torch.full_like(d_out, float(target)))
             elif opt.gan.type == "wgan":

@@ -164,11 +164,12 @@ class NeRF(torch.nn.Module):
         opacity_static, opacity_transient, prob [B,R,N,1], uncert, alpha_static, alpha_transient [B,R,N].
         ``want_prob`` / ``per_sample`` = False (not in the reference signature) leave prob / the two alphas unwritten and
         return None in their place: Graph.render never uses ``prob`` (reference :599-606 discards it as well)."""
-        out, a_s, a_t, prob = autograd_ops.composite(ray, rgb_samples, density_samples, depth_samples,
-                                                     uncert_samples, opt.nerf.min_uncert, per_sample, want_prob)
+        out, a_s, a_t, prob, rgb_ray, unc_ray = autograd_ops.composite(ray, rgb_samples, density_samples, depth_samples,
+                                                                       uncert_samples, opt.nerf.min_uncert, per_sample, want_prob)
         f = {name: out[..., lo:hi] for name, lo, hi in ops.COMPOSITE_RAY_FIELDS}
-        return (f["rgb"], f["rgb_static"], f["rgb_transient"], f["depth"], f["opacity"], f["opacity_static"],
-                f["opacity_transient"], None if prob is None else prob[..., None], f["uncert"], a_s, a_t)
+        # rgb / uncert: the compact tensors the kernel wrote next to `out` (same values; contiguous, own cotangents)
+        return (rgb_ray, f["rgb_static"], f["rgb_transient"], f["depth"], f["opacity"], f["opacity_static"],
+                f["opacity_transient"], None if prob is None else prob[..., None], unc_ray, a_s, a_t)
 
     def positional_encoding(self, opt, x, L, c2f=False):
         """[..., C] -> [..., 2 C L], index c*2L + s*L + l (reference layers/...light.py:217-234)."""

@@ -417,32 +417,45 @@ def _composite_args(ray, rgb, density, depth, uncert, min_uncert) -> Tuple[Compo
 
 @_on_tensor_device
 def composite_fwd(ray, rgb, density, depth, uncert, min_uncert: float = 0.05, per_sample: bool = True,
-                  want_prob: bool = True):
-    """-> out_ray [..,14], alpha_static, alpha_transient, prob ([..,N] or None)."""
+                  want_prob: bool = True, compact: bool = False):
+    """-> out_ray [..,14], alpha_static, alpha_transient, prob ([..,N] or None); with ``compact`` also (rgb_ray [..,3],
+    uncert_ray [..,1]): contiguous copies of out_ray[..., 0:3] / [..., 13:14] written by the same launch (the losses, the
+    feature network and the PatchGAN consume these two; slices of out_ray would need a copy each and a slice-backward)."""
     lib = _lib.load()
     a, keep = _composite_args(ray, rgb, density, depth, uncert, min_uncert)
     lead = keep[0].shape[:-1]
     dev = keep[0].device
     out = torch.empty(*lead, 14, device=dev)
+    rgb_ray = unc_ray = None
+    if compact:
+        rgb_ray, unc_ray = torch.empty(*lead, 3, device=dev), torch.empty(*lead, 1, device=dev)
+        a.rgb_ray, a.uncert_ray = rgb_ray.data_ptr(), unc_ray.data_ptr()
     a_s = torch.empty(*lead, a.N, device=dev) if per_sample else None
     a_t = torch.empty(*lead, a.N, device=dev) if per_sample else None
     prob = torch.empty(*lead, a.N, device=dev) if want_prob else None
     a.out_ray, a.alpha_static, a.alpha_transient, a.prob = out.data_ptr(), _ptr(a_s), _ptr(a_t), _ptr(prob)
     check(lib.tp_composite_fwd(C.byref(a), _stream()), "tp_composite_fwd")
-    return out, a_s, a_t, prob
+    return (out, a_s, a_t, prob, rgb_ray, unc_ray) if compact else (out, a_s, a_t, prob)
 
 
 @_on_tensor_device
-def composite_bwd(ray, rgb, density, depth, uncert, g_out: Tensor, g_alpha_s: Optional[Tensor] = None,
-                  g_alpha_t: Optional[Tensor] = None, g_prob: Optional[Tensor] = None, min_uncert: float = 0.05):
+def composite_bwd(ray, rgb, density, depth, uncert, g_out: Optional[Tensor], g_alpha_s: Optional[Tensor] = None,
+                  g_alpha_t: Optional[Tensor] = None, g_prob: Optional[Tensor] = None, min_uncert: float = 0.05,
+                  g_rgb_ray: Optional[Tensor] = None, g_uncert_ray: Optional[Tensor] = None):
+    """``g_out`` [..,14] may be None when the cotangent arrives through ``g_rgb_ray`` [..,3] / ``g_uncert_ray`` [..,1] (they
+    are ADDED to columns 0..2 / 13 of g_out inside the kernel)."""
     lib = _lib.load()
     b = CompositeBwdArgs()
     fa, keep = _composite_args(ray, rgb, density, depth, uncert, min_uncert)
     b.fwd = fa
-    g_out = _f32(g_out, "g_out")
+    if g_out is None and g_rgb_ray is None and g_uncert_ray is None:
+        g_out = torch.zeros(*keep[0].shape[:-1], 14, device=keep[0].device)
+    g_out = None if g_out is None else _f32(g_out, "g_out")
+    g_rgb_ray = None if g_rgb_ray is None else _f32(g_rgb_ray, "g_rgb_ray")
+    g_uncert_ray = None if g_uncert_ray is None else _f32(g_uncert_ray, "g_uncert_ray")
     opt = [None if g is None else _f32(g, "g") for g in (g_alpha_s, g_alpha_t, g_prob)]
     g_rgb, g_den, g_unc = torch.empty_like(keep[1]), torch.empty_like(keep[2]), torch.empty_like(keep[4])
-    b.g_out_ray = g_out.data_ptr()
+    b.g_out_ray, b.g_rgb_ray, b.g_uncert_ray = _ptr(g_out), _ptr(g_rgb_ray), _ptr(g_uncert_ray)
     b.g_alpha_static, b.g_alpha_transient, b.g_prob = _ptr(opt[0]), _ptr(opt[1]), _ptr(opt[2])
     b.g_rgb, b.g_density, b.g_uncert = g_rgb.data_ptr(), g_den.data_ptr(), g_unc.data_ptr()
     check(lib.tp_composite_bwd(C.byref(b), _stream()), "tp_composite_bwd")
@@ -858,6 +871,78 @@ def disc_inputs(rgb: Tensor, gathered: Tensor, hw, geo: bool):
     check(lib.tp_disc_inputs(rgb.data_ptr(), gathered.data_ptr(), B, P, int(bool(geo)), real.data_ptr(), fake.data_ptr(), _stream()),
           "tp_disc_inputs")
     return real, fake
+
+
+@_on_tensor_device
+def fake_patch_bwd(g_fake: Tensor, B: int, P: int) -> Tensor:
+    """g_rgb [B,P,3] from the cotangent of the fake stack [B,nc,h,w] (channels 0..2, transposed)."""
+    lib = _lib.load()
+    g_fake = _f32(g_fake, "g_fake")
+    g_rgb = torch.empty(B, P, 3, device=g_fake.device)
+    check(lib.tp_fake_patch_bwd(g_fake.data_ptr(), B, P, g_fake.shape[1], g_rgb.data_ptr(), _stream()), "tp_fake_patch_bwd")
+    return g_rgb
+
+
+@_on_tensor_device
+def feat_pair_loss_fwd(feat: Tensor, w2: float) -> Tensor:
+    """feat [4B,...] = features of [fake1 | fake2 | real1 | real2] -> [l1 + w2 l2, l1, l2] (one launch)."""
+    lib = _lib.load()
+    feat = _f32(feat, "feat")
+    out = torch.empty(3, device=feat.device)
+    check(lib.tp_feat_pair_loss_fwd(feat.data_ptr(), feat.numel() // 4, float(w2), out.data_ptr(), _stream()), "tp_feat_pair_loss_fwd")
+    return out
+
+
+@_on_tensor_device
+def feat_pair_loss_bwd(feat: Tensor, w2: float, g: Tensor) -> Tensor:
+    lib = _lib.load()
+    g = _f32(g, "g")
+    g_feat = torch.empty_like(feat)
+    check(lib.tp_feat_pair_loss_bwd(feat.data_ptr(), feat.numel() // 4, float(w2), g.data_ptr(), g_feat.data_ptr(), _stream()),
+          "tp_feat_pair_loss_bwd")
+    return g_feat
+
+
+@_on_tensor_device
+def sumsq_mean_fwd(g: Tensor) -> Tensor:
+    """sum(g^2) / B for g [B,...] -> 0-dim tensor."""
+    lib = _lib.load()
+    g = _f32(g, "g")
+    out = torch.empty((), device=g.device)
+    check(lib.tp_sumsq_mean_fwd(g.data_ptr(), g.numel(), g.shape[0], out.data_ptr(), _stream()), "tp_sumsq_mean_fwd")
+    return out
+
+
+@_on_tensor_device
+def sumsq_mean_bwd(g: Tensor, cot: Tensor) -> Tensor:
+    lib = _lib.load()
+    g, cot = _f32(g, "g"), _f32(cot, "cot")
+    out = torch.empty_like(g)
+    check(lib.tp_sumsq_mean_bwd(g.data_ptr(), g.numel(), g.shape[0], cot.data_ptr(), out.data_ptr(), _stream()), "tp_sumsq_mean_bwd")
+    return out
+
+
+@_on_tensor_device
+def latent_rows_fwd(w_trans: Tensor, w_light: Tensor, idx: Tensor):
+    lib = _lib.load()
+    w_trans, w_light = _f32(w_trans, "w_trans"), _f32(w_light, "w_light")
+    idx = idx.to(torch.int64).contiguous()
+    B = idx.numel()
+    ot, ol = torch.empty(B, w_trans.shape[1], device=idx.device), torch.empty(B, w_light.shape[1], device=idx.device)
+    check(lib.tp_latent_rows_fwd(w_trans.data_ptr(), w_light.data_ptr(), idx.data_ptr(), B, w_trans.shape[1], w_light.shape[1], ot.data_ptr(),
+                                 ol.data_ptr(), _stream()), "tp_latent_rows_fwd")
+    return ot, ol
+
+
+@_on_tensor_device
+def latent_rows_bwd(g_trans: Tensor, g_light: Tensor, idx: Tensor, n_rows: int):
+    lib = _lib.load()
+    g_trans, g_light = _f32(g_trans, "g_trans"), _f32(g_light, "g_light")
+    B = idx.numel()
+    gwt, gwl = torch.empty(n_rows, g_trans.shape[1], device=idx.device), torch.empty(n_rows, g_light.shape[1], device=idx.device)
+    check(lib.tp_latent_rows_bwd(g_trans.data_ptr(), g_light.data_ptr(), idx.data_ptr(), B, int(n_rows), g_trans.shape[1], g_light.shape[1],
+                                 gwt.data_ptr(), gwl.data_ptr(), _stream()), "tp_latent_rows_bwd")
+    return gwt, gwl
 
 
 @_on_tensor_device

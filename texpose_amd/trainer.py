@@ -256,7 +256,7 @@ class GanTrainer:
         # graph once instead of twice and accumulates into every parameter once instead of three times.
         terms = edict(gan_disc_real=loss.gan_disc_real)
         if opt.loss_weight.gan_reg_real is not None:          # R1: double backward through the discriminator
-            terms.gan_reg_real = g.compute_grad2(opt, var.d_real_disc, var.patch_real).mean()
+            terms.gan_reg_real = g.compute_grad2_mean(opt, var.d_real_disc, var.patch_real)
         terms.gan_disc_fake = loss.gan_disc_fake
         total = self._backward_weighted(terms).all
         if "gan_reg_real" in terms:
