@@ -84,6 +84,80 @@ def conv(src_base, tile, g, bank):
             "v_pk_max_f16 %%[amax], %%[amax], v%d" % xh]
 
 
+# ------------------------------------------------------------------------------------------------ recording variants
+# Training (mlp_fwd_f16x3_kernel<true>): the activation record of a layer is written by the block that CONSUMES that layer's
+# accumulators -- its conversion already forms h = relu(acc * 2^-8) in t0 / t1 -- instead of a separate pass over the set
+# after the layer (round 2: ~34 of 164 us per tile, compiled code reading the tiles back through v_accvgpr_read).  Per
+# converted element: one ds_write_b32 into the wave's private 4 KB staging tile (features on rows, as the C++ pass did it)
+# and v_cmp + v_addc (sign bit of the ReLU mask word); per 32 x 32 tile: four ds_read_b128 of the transposed tile and four
+# nontemporal 16-byte stores one chunk / group later; per two tiles: one mask word.  All of it rides in MFMA issue gaps.
+#   %[recw] / %[recr]  VGPR: LDS byte address of this lane's writes / 16-byte reads (mlp_fwd_f16x3.hip: rec_ctx)
+#   %[rbase]           SGPR pair: the layer's record block of this wave's group
+#   %[mkoff]           VGPR: byte offset (from %[rbase]) of this lane's first mask word
+#   %[ro0..1]          VGPR: byte offset of read units 0 / 1 inside a 4 KB record tile (blk_off, XOR swizzle)
+# Fixed registers: v231 mask accumulator, s[96:97] running tile base.
+MK = VB + 71                  # v231
+RB = 96                       # s[96:97]
+
+
+def rec_wr_off(r):
+    return (r >> 2) * 4096 + (r & 3) * 128
+
+
+def conv_rec(src_base, tile, g, bank, mask=True):
+    """conv() + record of the two elements, in issue order: 6 (reads, scale, ReLU: t0 / t1 = h), 2 LDS stores, 4 mask
+    instructions (`mask`), 7 (hi / lo split, pack, range guard)"""
+    c = conv(src_base, tile, g, bank)
+    t0, t1 = T, T + 1
+    r0, r1 = 2 * g, 2 * g + 1
+    out = c[0:6]
+    out += ["ds_write_b32 %%[recw], v%d offset:%d" % (t0, rec_wr_off(r0)),
+            "ds_write_b32 %%[recw], v%d offset:%d" % (t1, rec_wr_off(r1))]
+    if mask:
+        out += ["v_cmp_lt_f32_e32 vcc, 0, v%d" % t0,
+                "v_addc_co_u32_e32 v%d, vcc, v%d, v%d, vcc" % (MK, MK, MK),
+                "v_cmp_lt_f32_e32 vcc, 0, v%d" % t1,
+                "v_addc_co_u32_e32 v%d, vcc, v%d, v%d, vcc" % (MK, MK, MK)]
+    out += c[6:13]
+    return out
+
+
+def tile_regs(set_base, tile, k):
+    lo = set_base + 16 * tile + 4 * k
+    return "a[%d:%d]" % (lo, lo + 3)
+
+
+def rec_reads(set_base, tile):
+    """the staged tile back out of LDS, transposed, into the accumulator registers of the SOURCE tile itself: they are dead
+    from the tile's conversion until it is re-seeded (WIDE: moved behind the stores) or for good (HEAD); LDS loads may
+    target AGPRs and vector stores may take their data from them on gfx950 -- no VGPR is spent on the record"""
+    return ["ds_read_b128 %s, %%[recr] offset:%d" % (tile_regs(set_base, tile, k), k * 4096) for k in range(4)]
+
+
+def rec_store(set_base, tile, k):
+    # units 2, 3 sit 16 rows (2 KB) behind units 0, 1 with the same swizzle: two offset registers, an immediate for the rest
+    return "global_store_dwordx4 %%[ro%d], %s, s[%d:%d] offset:%d nt" % (k & 1, tile_regs(set_base, tile, k), RB, RB + 1, (k >> 1) * 2048)
+
+
+def rec_advance():
+    return ["s_add_u32 s%d, s%d, 0x1000" % (RB, RB), "s_addc_u32 s%d, s%d, 0" % (RB + 1, RB + 1)]
+
+
+def rec_mask_store(w4):
+    # bits were pushed MSB-first (tile 2 w4 register 0 first): reverse -> bit b <-> tile 2 w4 + b / 16, register b % 16
+    return ["v_bfrev_b32_e32 v%d, v%d" % (MK, MK),
+            "global_store_dword %%[mkoff], v%d, %%[rbase] offset:%d" % (MK, w4 * 256)]
+
+
+def split_even(instrs, n):
+    k, out, pos = len(instrs), [], 0
+    for i in range(n):
+        take = (k - pos + (n - i) - 1) // (n - i)
+        out.append(instrs[pos:pos + take])
+        pos += take
+    return out
+
+
 def ring_prologue(e):
     """slot byte offsets r0 r1 r2 = slots of (current, next, DMA target) chunk; read addresses; DMA LDS bases; dch."""
     e("s_waitcnt lgkmcnt(0)")
@@ -149,7 +223,7 @@ def publish(e, young):
         e("s_barrier")
 
 
-def chunk_groups(e, npairs, ts, mf, fill, free_after, pieces_per_group, tail=None, head=None):
+def chunk_groups(e, npairs, ts, mf, fill, free_after, pieces_per_group, tail=None, head=None, young_extra=0):
     """One chunk of npairs (k-step, tile) pairs = npairs/2 groups of six MFMAs.
       mf(g)          -> the six MFMA lines of group g (they use ring slots (2g)%4 and (2g+1)%4)
       fill(g)        -> five lists of gap instructions (after MFMA 1..5)
@@ -179,7 +253,11 @@ def chunk_groups(e, npairs, ts, mf, fill, free_after, pieces_per_group, tail=Non
                     e(ins)
             if i + 1 == free_after[0]:
                 if g == pub_group:
-                    publish(e, (g + 1) * pieces_per_group)
+                    # young_extra: vector-memory operations OTHER than DMA pieces (record stores) issued in this chunk
+                    # before this point; they retire in order with the pieces (MI355X_MICROARCH.md: loads, stores and
+                    # LDS-DMA count together, in issue order), so the count must be exact: too small only waits longer,
+                    # too large would let a piece of the chunk being published still be in flight
+                    publish(e, (g + 1) * pieces_per_group + young_extra)
                 refill(e, sa, q + 4, npairs, cur, nxt)
             if i + 1 == free_after[1]:
                 refill(e, sb, q + 5, npairs, cur, nxt)
@@ -193,12 +271,20 @@ def advance_dch():
 
 
 # ------------------------------------------------------------------------------------------------------ WIDE
-def gen_wide(src, dst):
+def gen_wide(src, dst, rec=None):
+    """rec: None (plain), "mask" (record + ReLU sign words) or "nomask" (record only: the trunk feature, whose gates the
+    backward never needs)"""
     L = []
     e = L.append
     ring_prologue(e)
+    cvf = (lambda *a: conv_rec(*a, mask=(rec == "mask"))) if rec else conv
+    if rec:
+        e("s_mov_b64 s[%d:%d], %%[rbase]" % (RB, RB + 1))
     for g in range(8):
-        for ins in conv(src, 0, g, 0):
+        for ins in cvf(src, 0, g, 0):
+            e(ins)
+    if rec:
+        for ins in rec_reads(src, 0):                # tile 0 (the first chunk's counted waits cover these four reads)
             e(ins)
     for ins in dma_base():
         e(ins)
@@ -214,6 +300,33 @@ def gen_wide(src, dst):
                     mfma(d1, vr(F_hi(sb)), xl), mfma(d0, vr(F_lo(sa)), xh), mfma(d1, vr(F_lo(sb)), xh)]
 
         def fill(g, ts=ts, bank=bank):
+            if rec:
+                # Record traffic of this chunk, all in MFMA issue gaps:
+                #   groups 1..4  one 16-byte store each of tile ts (back in its own accumulator registers since the end of the
+                #                previous chunk / the prologue; the counted wait at the top of group 1 covers those LDS reads)
+                #   group 5      tile base += 4 KB
+                #   group 6      tile ts is re-seeded with the next layer's bias (the plain block does that in group 0)
+                #   group 7      tile ts + 1 (its last two values were written in this group's second gap) back out of the
+                #                staging tile into the hold registers -- LDS operations of a wave execute in order, and the
+                #                reads are issued BEFORE the group's ring refills, so the waits' counts are unchanged;
+                #                even chunks: the mask word of tiles ts, ts + 1, complete with this group's last v_addc (it
+                #                is issued after the publish point: the NEXT chunk counts it)
+                first, mid2, mid3, last = [], [], [], []
+                if 1 <= g <= 4:
+                    first = [rec_store(src, ts, g - 1)]
+                elif g == 5:
+                    first = rec_advance()
+                if g == 7 and ts < 7:
+                    rd = rec_reads(src, ts + 1)
+                    mid2, mid3 = rd[0:2], rd[2:4]
+                    if rec == "mask" and not (ts & 1):
+                        last = rec_mask_store(ts >> 1)
+                if ts == 7:
+                    return [first, [], [], [], []]
+                cv = conv_rec(src, ts + 1, g, bank ^ 1, mask=(rec == "mask"))
+                if rec == "mask":      # 19: [reads, scale | ReLU, 2 LDS stores, cmp | addc, cmp, addc, 2 and | 2 sub, 2 cvt | max]
+                    return [first + cv[0:4], cv[4:9], cv[9:14] + mid2, cv[14:18] + mid3, cv[18:19] + last]
+                return [first + cv[0:4], cv[4:8], cv[8:12] + mid2, cv[12:15] + mid3, []]
             if ts == 7:
                 return [[], [], [], [], []]
             cv = conv(src, ts + 1, g, bank ^ 1)
@@ -236,12 +349,15 @@ def gen_wide(src, dst):
             return out
 
         def head(g, ts=ts):
-            if g != 0:
+            if g != (6 if rec else 0):
                 return []
             return ["ds_read_b128 a[%d:%d], %%[nbias] offset:%d" % (src + 16 * ts + 4 * k, src + 16 * ts + 4 * k + 3, ts * 64 + k * 16)
                     for k in range(4)]
 
-        chunk_groups(e, 16, ts, mf, fill, (5, 6), 1, tail, head)
+        extra = 0
+        if rec:        # this chunk's four tile stores + the mask word the previous (even) chunk stored after ITS publish point
+            extra = 4 + (1 if (ts & 1) and rec == "mask" else 0)
+        chunk_groups(e, 16, ts, mf, fill, (5, 6), 1, tail, head, young_extra=extra)
     ring_epilogue(e, 8)
     return L
 
@@ -274,14 +390,27 @@ def gen_extra(dst, ks):
 
 
 # ------------------------------------------------------------------------------------------------------ HEAD
-def gen_head(src):
+def gen_head(src, rec=False):
     """acc (v[HACC:HACC+15]) = W_head * relu(src set): 16 k-steps of one tile; group ts contracts source tile ts
-    (k-steps 2 ts, 2 ts + 1), operands of tile ts+1 converted while its six MFMAs issue"""
+    (k-steps 2 ts, 2 ts + 1), operands of tile ts+1 converted while its six MFMAs issue.
+    rec: also write the activation record of the source set (see "recording variants").  The head accumulator occupies
+    v[232:247], and while the transient head runs the compiler owns ~40 VGPRs (the trunk feature sits in v[32:159]): the tile
+    travels LDS -> the ACCUMULATOR REGISTERS OF THE SOURCE TILE ITSELF -> memory.  They are dead once the tile has been
+    converted (nothing re-seeds the source set of a head: set P is overwritten by the restored feature, set Q by the next
+    tile's L1 seed), LDS loads may target AGPRs and vector stores may take their data from them on gfx950."""
     L = []
     e = L.append
     ring_prologue(e)
+    if rec:
+        e("s_mov_b64 s[%d:%d], %%[rbase]" % (RB, RB + 1))
     for g in range(8):
-        for ins in conv(src, 0, g, 0):
+        for ins in (conv_rec(src, 0, g, 0) if rec else conv(src, 0, g, 0)):
+            e(ins)
+    def hold_reads(t):
+        return rec_reads(src, t)
+
+    if rec:
+        for ins in hold_reads(0):                      # tile 0
             e(ins)
     for ins in dma_base():
         e(ins)
@@ -297,15 +426,32 @@ def gen_head(src):
                 mfma(acc, vr(F_hi(sb)), xh1), mfma(acc, vr(F_hi(sb)), xl1), mfma(acc, vr(F_lo(sb)), xh1)]
 
     def fill(g):
-        if g == 7:
-            return [[], [], [], [], []]
         cv = []
-        for k in range(8):
-            cv += conv(src, g + 1, k, (g & 1) ^ 1)
-        # 104 VALU instructions over five gaps: the head is conversion-bound (one tile per six MFMAs)
-        return [cv[0:21], cv[21:42], cv[42:63], cv[63:84], cv[84:104]]
+        if g < 7:
+            for k in range(8):
+                cv += conv_rec(src, g + 1, k, (g & 1) ^ 1) if rec else conv(src, g + 1, k, (g & 1) ^ 1)
+        if not rec:
+            if g == 7:
+                return [[], [], [], [], []]
+            # 104 VALU instructions over five gaps: the head is conversion-bound (one tile per six MFMAs)
+            return [cv[0:21], cv[21:42], cv[42:63], cv[63:84], cv[84:104]]
+        # tile g sits in its own accumulator registers again (read back at the end of the previous group / the prologue,
+        # after its conversion): wait for those reads -- at
+        # least the two ring refills after them are younger, so "at most two outstanding" covers them --, store the tile,
+        # advance the base; odd groups first store the mask word of tiles g - 1, g.  Then this group's conversions of tile
+        # g + 1 (with their staging-tile writes), and at the end its read-back.
+        store = ["s_waitcnt lgkmcnt(2)"] + [rec_store(src, g, k) for k in range(4)]
+        store += rec_advance()
+        parts = split_even(cv, 5) if cv else [[], [], [], [], []]
+        if g & 1:      # tiles g - 1, g are complete (tile g was converted during the previous group): before this group's pushes
+            parts[0] = rec_mask_store(g >> 1) + parts[0]
+        parts[1] = store + parts[1]
+        if g < 7:
+            parts[4] = parts[4] + hold_reads(g + 1)
+        return parts
 
-    chunk_groups(e, 16, 0, mf, fill, (3, 6), 1)
+    # record stores issued before the publish point (group 6, after its third MFMA): tiles 0..6 and mask words 0..2
+    chunk_groups(e, 16, 0, mf, fill, (3, 6), 1, young_extra=(7 * 4 + 3) if rec else 0)
     ring_epilogue(e, 1)
     e("s_nop 15")                                    # the accumulator tile is read by compiled code after the block
     e("s_nop 7")
@@ -353,13 +499,19 @@ def emit_macro(out, name, comment, lines):
 def main():
     out = ["// GENERATED by gen_wide_asm.py -- do not edit.  See that file for the schedule.", "#pragma once",
            "#define TP_ASM_CLOBBERS " + ", ".join(['"v%d"' % v for v in CLOBBER_V] + ['"s%d"' % r for r in CLOBBER_S] + ['"a%d"' % a for a in range(256)]),
-           "#define TP_ASM_ALL_AGPRS " + ", ".join('"a%d"' % a for a in range(256))]
+           "#define TP_ASM_ALL_AGPRS " + ", ".join('"a%d"' % a for a in range(256)),
+           '#define TP_ASM_REC_CLOBBERS "v%d", "s%d", "s%d", "vcc"' % (MK, RB, RB + 1)]
     for s, d in (("Q", "P"), ("P", "Q")):
         emit_macro(out, "TP_ASM_WIDE_%s%s" % (s, d), "256 -> 256 layer: set %s -> set %s" % (s, d), gen_wide(SET[s], SET[d]))
+        emit_macro(out, "TP_ASM_WIDE_%s%s_REC" % (s, d), "256 -> 256 layer: set %s -> set %s, recording set %s (values + ReLU sign words)" % (s, d, s),
+                   gen_wide(SET[s], SET[d], rec="mask"))
+    emit_macro(out, "TP_ASM_WIDE_QP_RECNM", "256 -> 256 layer: set Q -> set P, recording set Q (values only: the trunk feature)",
+               gen_wide(SET["Q"], SET["P"], rec="nomask"))
     for d in ("P", "Q"):
         for ks in (1, 2):
             emit_macro(out, "TP_ASM_EXTRA%d_%s" % (ks, d), "%d extra k-step(s) into set %s" % (ks, d), gen_extra(SET[d], ks))
         emit_macro(out, "TP_ASM_HEAD_%s" % d, "narrow head over relu(set %s)" % d, gen_head(SET[d]))
+        emit_macro(out, "TP_ASM_HEAD_%s_REC" % d, "narrow head over relu(set %s), recording set %s" % (d, d), gen_head(SET[d], rec=True))
         emit_macro(out, "TP_ASM_INIT_%s" % d, "seed set %s with the bias block" % d, gen_init(SET[d]))
         for t in range(8):
             emit_macro(out, "TP_ASM_READ_%s%d" % (d, t), "tile %d of set %s -> v[232:247]" % (t, d), gen_read_tile(SET[d], t))

@@ -398,6 +398,62 @@ __device__ __forceinline__ void asm_wide(Pipe& p, Frag& f, Guard& amax, const As
   TP_RING_DONE;
 }
 
+// ---- recording variants (training): the block that CONSUMES a layer's accumulators also writes its activation record
+// (gen_wide_asm.py, "recording variants").  Addresses of this lane in the wave's private 4 KB staging tile -- the wave's OWN
+// slices of the first four 4 KB blocks of the input stage, dead while a WIDE / HEAD block runs -- and in the record block.
+struct RecCtx { unsigned recw, recr, ro0, ro1, mkoff; const float* rbase; };
+__device__ __forceinline__ RecCtx rec_ctx_now(float* saved, int64_t tile, int slot) {
+  extern __shared__ __attribute__((aligned(16))) float lds_base[];
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
+  const unsigned lane = (unsigned)tid & 63u, j = (unsigned)tid & 31u, hh = ((unsigned)tid >> 5) & 1u;
+  const unsigned wave = (unsigned)__builtin_amdgcn_readfirstlane(tid >> 6);
+  const unsigned stg = (unsigned)(uintptr_t)AS3(lds_base) + (unsigned)(kBufs * kChunkFloats + kBiasPad) * 4u + wave * 1024u;
+  RecCtx c;
+  c.recw = stg + ((4u * hh) * 32u + j) * 4u;          // register r -> + (r >> 2) * 4096 + (r & 3) * 128
+  c.recr = stg + lane * 16u;                           // unit k -> + k * 4096: feature 8 k + (lane >> 3), samples 4 (lane & 7) ..
+  c.ro0 = (unsigned)blk_off(0 + (int)(lane >> 3), (int)(lane & 7u) * 4) * 4u;
+  c.ro1 = (unsigned)blk_off(8 + (int)(lane >> 3), (int)(lane & 7u) * 4) * 4u;
+  static_assert(blk_off(16 + 3, 12) == blk_off(3, 12) + 512 && blk_off(24 + 6, 20) == blk_off(8 + 6, 20) + 512,
+                "units 2 / 3 of a record tile sit 16 rows behind units 0 / 1 with the same swizzle");
+  // mask words of slot sl (>= 1) for this lane: kMaskOff + ((sl - 1) * 4 + w) * 64 + lane, relative to the slot's block
+  c.mkoff = (unsigned)((kMaskOff + ((slot > 0 ? slot : 1) - 1) * 256 - slot * kBlockFloats) * 4) + lane * 4u;
+  const float* base = saved + (tile * 4 + (int64_t)wave) * (int64_t)kSavedGroupFloats + (int64_t)slot * kBlockFloats;
+  const uint64_t b = (uint64_t)(uintptr_t)base;
+  c.rbase = reinterpret_cast<const float*>((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b) |
+                                           ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b >> 32)) << 32));
+  return c;
+}
+#define TP_REC_INPUTS(r)                                                                                               \
+  [recw] "v"(r.recw), [recr] "v"(r.recr), [ro0] "v"(r.ro0), [ro1] "v"(r.ro1), [mkoff] "v"(r.mkoff), [rbase] "s"(r.rbase)
+
+// which recording variant the wide layer `li` runs in the training kernel (it records its SOURCE set): T0 <- L7 = the trunk
+// feature (values only), T1 <- T0, T2 <- T1, R1 <- R0, R2 <- R1; R0 re-reads the restored feature: plain
+template <class L>
+constexpr int rec_kind_of() {
+  if constexpr (std::is_same_v<L, int>) return 0;
+  else return L::value == T0 ? 2 : (L::value == T1 || L::value == T2 || L::value == R1 || L::value == R2) ? 1 : 0;
+}
+
+// WIDE block that also records its SOURCE set; MASK = false: values only (the trunk feature, set Q)
+template <bool SRC_Q, bool MASK>
+__device__ __forceinline__ void asm_wide_rec(Pipe& p, Frag& f, Guard& amax, const AsmCtx& c, int next_li, const RecCtx& r) {
+  TP_RING_LOCALS;
+  const float kinv = kInvScale;
+  const unsigned mask = 0xFFFFE000u;
+  const unsigned nbias = c.bias0 + (unsigned)next_li * 1024u;
+  static_assert(SRC_Q || MASK, "the mask-free variant exists for set Q only");
+#define TP_WIDE_REC(TXT)                                                                                               \
+  asm volatile(TXT : TP_RING(f), TP_RING_STATE, [amax] "+v"(amax.m)                                                    \
+               : TP_RING_INPUTS(c), [kinv] "s"(kinv), [mask] "s"(mask), [nbias] "v"(nbias), TP_REC_INPUTS(r)           \
+               : TP_ASM_CLOBBERS, TP_ASM_REC_CLOBBERS, "memory", "scc")
+  if constexpr (SRC_Q && MASK) TP_WIDE_REC(TP_ASM_WIDE_QP_REC);
+  else if constexpr (SRC_Q) TP_WIDE_REC(TP_ASM_WIDE_QP_RECNM);
+  else TP_WIDE_REC(TP_ASM_WIDE_PQ_REC);
+#undef TP_WIDE_REC
+  TP_RING_DONE;
+}
+
 // one chunk of KS extra k-steps (staged inputs ks0 .. ks0+KS-1) into set P (DST_P) or Q
 template <int KS, bool DST_P>
 __device__ __forceinline__ void asm_extra(Pipe& p, Frag& f, const AsmCtx& c, int ks0) {
@@ -429,6 +485,29 @@ __device__ __forceinline__ f32x16 asm_head(Pipe& p, Frag& f, Guard& amax, const 
                  : TP_RING_INPUTS(c), [kinv] "s"(kinv), [mask] "s"(mask) : TP_ASM_CLOBBERS, "memory", "scc");
   TP_RING_DONE;
   return acc;
+}
+
+// the same, also recording the source set (values + ReLU sign words).  Only rows 0..3 of the accumulator tile (registers
+// 0..3: rows 0..3 in the lower lane half, 4..7 in the upper) are used by the callers: they come back as four scalars -- as
+// a 16-register value the tile was carried, and spilled, through the following sections
+struct Head4 { float a0, a1, a2, a3; };
+template <bool SRC_P>
+__device__ __forceinline__ Head4 asm_head_rec(Pipe& p, Frag& f, Guard& amax, const AsmCtx& c, const RecCtx& r) {
+  TP_RING_LOCALS;
+  const float kinv = kInvScale;
+  const unsigned mask = 0xFFFFE000u;
+  Head4 h;
+#define TP_HEAD_REC(TXT)                                                                                               \
+  asm volatile(TXT : TP_RING(f), TP_RING_STATE, [amax] "+v"(amax.m), "=&{v232}"(h.a0), "=&{v233}"(h.a1),               \
+                     "=&{v234}"(h.a2), "=&{v235}"(h.a3)                                                                \
+               : TP_RING_INPUTS(c), [kinv] "s"(kinv), [mask] "s"(mask), TP_REC_INPUTS(r)                               \
+               : TP_ASM_CLOBBERS, TP_ASM_REC_CLOBBERS, "v236", "v237", "v238", "v239", "v240", "v241", "v242", "v243", \
+                 "v244", "v245", "v246", "v247", "memory", "scc")
+  if constexpr (SRC_P) TP_HEAD_REC(TP_ASM_HEAD_P_REC);
+  else TP_HEAD_REC(TP_ASM_HEAD_Q_REC);
+#undef TP_HEAD_REC
+  TP_RING_DONE;
+  return h;
 }
 
 // seed set P (DST_P) or Q with the bias block of wide layer li (bias * 2^8 in LDS)
@@ -552,11 +631,24 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_f16x3_kernel(Params P) {
     // a narrow output layer; which == 0: sigma (reads L6 = set P), 1: transient head (reads T2 = set P), 2: static
     // rgb (reads R2 = set Q).  The transient head's result comes back while the trunk feature still occupies 128 VGPRs:
     // its non-linearities run after the feature has been restored into set P (`after`)
-    const auto head = [&](int which, auto after) {
+    const auto head = [&](auto which_tag, auto after) {
+      constexpr int which = decltype(which_tag)::value;
       TR_BEGIN(h);
-      const f32x16 a = which == 2 ? asm_head<false>(p, frag, amax, asm_ctx_now(P.packed)) : asm_head<true>(p, frag, amax, asm_ctx_now(P.packed));
-      TR_END(7, h);
-      const float a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3];
+      // training: the heads over T2 (set P) / R2 (set Q) also write those layers' activation records
+      float a0, a1, a2, a3;
+      if constexpr (SAVE && which != 0) {
+        Head4 h4;
+        if constexpr (which == 2) h4 = asm_head_rec<false>(p, frag, amax, asm_ctx_now(P.packed), rec_ctx_now(P.saved, tile, SV_R2));
+        else h4 = asm_head_rec<true>(p, frag, amax, asm_ctx_now(P.packed), rec_ctx_now(P.saved, tile, SV_T2));
+        a0 = h4.a0; a1 = h4.a1; a2 = h4.a2; a3 = h4.a3;
+        TR_END(7, h);
+      } else {
+        f32x16 a;
+        if constexpr (which == 2) a = asm_head<false>(p, frag, amax, asm_ctx_now(P.packed));
+        else a = asm_head<true>(p, frag, amax, asm_ctx_now(P.packed));
+        TR_END(7, h);
+        a0 = a[0]; a1 = a[1]; a2 = a[2]; a3 = a[3];
+      }
       after();
       if (which == 0) {
         sig_s = softplus(fmaf(a0, kInvScale, hbias[0]));
@@ -572,11 +664,17 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_f16x3_kernel(Params P) {
     };
 
     // one wide layer: EVEN layers read set Q and accumulate into set P, odd layers the reverse
-    const auto layer = [&](auto even_tag, int li) {
+    // `li_arg`: the wide-layer index as a run-time int (the rolled trunk loop) or as an integral_constant (training: the six
+    // head layers are unrolled, so that every asm statement of a recording block sits at a call site of its own -- with the
+    // recording and the plain variant behind a run-time branch on `li` at ONE site the register allocator spilled a
+    // 16-register tile of the stashed trunk feature around it)
+    const auto layer = [&](auto even_tag, auto li_arg) {
       constexpr bool EVEN = decltype(even_tag)::value;
-      if (!EVEN && li == L7) head(0, [] {});                              // sigma: reads set P (L6)
+      const int li = li_arg;
+      constexpr int REC = SAVE ? rec_kind_of<decltype(li_arg)>() : 0;      // 0 plain, 1 values + sign words, 2 values only
+      if (!EVEN && li == L7) head(std::integral_constant<int, 0>{}, [] {});                              // sigma: reads set P (L6)
       if (!EVEN && li == R0)                                               // transient head: reads set P (T2); then the
-        head(1, [&] {                                                      // trunk feature comes back into that set
+        head(std::integral_constant<int, 1>{}, [&] {                                                      // trunk feature comes back into that set
           TR_BEGIN(rl);
           asm_restore_p(SF);
           TR_END(10, rl);
@@ -584,7 +682,12 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_f16x3_kernel(Params P) {
 
       if (li != L0) {
         TR_BEGIN(w);
-        asm_wide<EVEN>(p, frag, amax, asm_ctx_now(P.packed), li + 1 == kNumWide ? 0 : li + 1);
+        const int next_li = li + 1 == kNumWide ? 0 : li + 1;
+        // training: a wide layer whose SOURCE set is a recorded activation writes that record while it converts it
+        // (T0 <- L7 = trunk feature, values only; T1 <- T0; T2 <- T1; R1 <- R0; R2 <- R1.  R0 re-reads the restored feature)
+        if constexpr (REC == 2) asm_wide_rec<true, false>(p, frag, amax, asm_ctx_now(P.packed), next_li, rec_ctx_now(P.saved, tile, SV_FEAT));
+        else if constexpr (REC == 1) asm_wide_rec<EVEN, true>(p, frag, amax, asm_ctx_now(P.packed), next_li, rec_ctx_now(P.saved, tile, li - 1 - L7));
+        else asm_wide<EVEN>(p, frag, amax, asm_ctx_now(P.packed), next_li);
         TR_END(3, w);
       }
 
@@ -693,71 +796,6 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_f16x3_kernel(Params P) {
         TR_END(3, w);
       }
 
-      if (SAVE && li >= L7) {
-        // activations for the backward (layout: mlp_layout.h "Training record"): post-ReLU values as fp32 + ReLU
-        // sign bits for the dgrad kernel.  A lane holds 16 features of ONE sample per tile, the record keeps a feature's
-        // samples contiguous: each wave transposes its tile through LDS -- 16 ds_write_b32, 4 ds_read_b128 of four
-        // consecutive samples of one feature, 4 nontemporal 16-byte stores -- at no VALU cost (the in-register 4 x 4 lane
-        // transpose it replaces took 64 VALU per tile).  The LDS it uses are this wave's OWN input-staging slots (1 KB of
-        // each of the first four 4 KB (k-step, hi/lo) blocks of `st`), dead since the layer's asm_extra consumed them; no
-        // other wave's slots are touched, so a wave already staging the next layer's inputs is not disturbed.  The reads
-        // of tile n are issued right after its writes (LDS operations of a wave execute in order) and stored one tile
-        // later.  Every lane takes part; samples past the end of the launch record zeros (the weight-gradient GEMM
-        // contracts whole groups)
-        TP_THREAD_IDS;
-        float* grp = P.saved + (tile * 4 + wave) * (int64_t)kSavedGroupFloats;
-        float* blk = grp + (li - L7) * kBlockFloats;
-        float* stg = reinterpret_cast<float*>(st) + wave * 256;
-        float* stg_w = stg + (4 * hh) * 32 + j;          // register r -> + (r >> 2) * 1024 + (r & 3) * 32
-        const float* stg_r = stg + lane * 4;             // unit k -> + k * 1024: feature 8 k + (lane >> 3), samples 4 (lane & 7) ..
-        int o4[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) o4[k] = blk_off(8 * k + (lane >> 3), (lane & 7) * 4);
-        uint32_t* mk = reinterpret_cast<uint32_t*>(grp + kMaskOff) + (li - T0) * 256 + lane;
-        f32x4 hold[4];
-        const auto put = [&](const float (&h)[16]) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) stg_w[(r >> 2) * 1024 + (r & 3) * 32] = h[r];
-        };
-        const auto take = [&]() {
-#pragma unroll
-          for (int k = 0; k < 4; ++k) hold[k] = *reinterpret_cast<const f32x4*>(stg_r + k * 1024);
-        };
-        const auto emit = [&](int t) {
-#pragma unroll
-          for (int k = 0; k < 4; ++k) __builtin_nontemporal_store(hold[k], reinterpret_cast<f32x4*>(blk + t * 1024 + o4[k]));
-        };
-        const auto two_tiles = [&](auto w4_tag) {
-          constexpr int w4 = decltype(w4_tag)::value;
-          uint32_t m = 0;
-          const f32x16 d0 = asm_read_tile<EVEN, 2 * w4>();
-          float h0[16];
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            h0[r] = live ? fmaxf(d0[r] * kInvScale, 0.0f) : 0.0f;
-            m |= (h0[r] > 0.0f ? 1u : 0u) << r;
-          }
-          if (w4 > 0) emit(2 * w4 - 1);
-          put(h0);
-          take();
-          const f32x16 d1 = asm_read_tile<EVEN, 2 * w4 + 1>();
-          float h1[16];
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            h1[r] = live ? fmaxf(d1[r] * kInvScale, 0.0f) : 0.0f;
-            m |= (h1[r] > 0.0f ? 1u : 0u) << (16 + r);
-          }
-          emit(2 * w4);
-          put(h1);
-          take();
-          if (li >= T0 && live) mk[w4 * 64] = m;
-        };
-        two_tiles(std::integral_constant<int, 0>{});
-        two_tiles(std::integral_constant<int, 1>{});
-        two_tiles(std::integral_constant<int, 2>{});
-        two_tiles(std::integral_constant<int, 3>{});
-        emit(7);
-      }
       if (!EVEN && li == L7) {
         // keep the trunk feature (raw accumulators of L7, set Q) for R0: T1 overwrites set Q
         TR_BEGIN(vc);
@@ -766,12 +804,26 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_f16x3_kernel(Params P) {
       }
     };
 
+    if constexpr (SAVE) {
 #pragma nounroll
-    for (int pr = 0; pr < kNumWide / 2; ++pr) {
-      layer(std::true_type{}, 2 * pr);
-      layer(std::false_type{}, 2 * pr + 1);
+      for (int pr = 0; pr < 4; ++pr) {                 // L0 .. L7
+        layer(std::true_type{}, 2 * pr);
+        layer(std::false_type{}, 2 * pr + 1);
+      }
+      layer(std::true_type{}, std::integral_constant<int, T0>{});
+      layer(std::false_type{}, std::integral_constant<int, T1>{});
+      layer(std::true_type{}, std::integral_constant<int, T2>{});
+      layer(std::false_type{}, std::integral_constant<int, R0>{});
+      layer(std::true_type{}, std::integral_constant<int, R1>{});
+      layer(std::false_type{}, std::integral_constant<int, R2>{});
+    } else {
+#pragma nounroll
+      for (int pr = 0; pr < kNumWide / 2; ++pr) {
+        layer(std::true_type{}, 2 * pr);
+        layer(std::false_type{}, 2 * pr + 1);
+      }
     }
-    head(2, [] {});
+    head(std::integral_constant<int, 2>{}, [] {});
 
     TR_BEGIN(o);
     {

@@ -143,7 +143,7 @@ constexpr int kMaskOff = kSavedSlots * kBlockFloats + 1024;
 constexpr int kSavedGroupFloats = kMaskOff + 6 * 4 * 64;
 enum { SV_FEAT = 0, SV_T0 = 1, SV_T1 = 2, SV_T2 = 3, SV_R0 = 4, SV_R1 = 5, SV_R2 = 6, SV_EX = 7 };
 
-TP_HD int blk_off(int f, int j) { return f * 32 + ((((j >> 2) ^ ((f >> 1) & 7)) << 2) | (j & 3)); }
+constexpr TP_HD int blk_off(int f, int j) { return f * 32 + ((((j >> 2) ^ ((f >> 1) & 7)) << 2) | (j & 3)); }
 
 // dz record written by the dgrad kernel: per group 6 wide blocks + 2 narrow (32-row) blocks
 //   0: dzT2  1: dzT1  2: dzT0  3: dzR2  4: dzR1  5: dzR0   then  dzT3 (5 rows), dzR3 (3 rows)
