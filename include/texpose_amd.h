@@ -26,7 +26,7 @@ extern "C" {
 
 typedef void* tp_stream_t; /* hipStream_t */
 
-#define TP_ABI_VERSION 5
+#define TP_ABI_VERSION 6
 
 int tp_abi_version(void);
 const char* tp_last_error(void);
@@ -285,6 +285,9 @@ typedef struct tp_sn_weight {
   float* grad;             /* [rows,cols] bwd: out, gradient wrt weight */
   float* work;             /* tp_sn_work_floats(rows, cols) floats of scratch */
   int rows, cols;
+  float* u_out;            /* fwd, optional: copy of u [rows] as it stands AFTER this call's power iteration (the backward of
+                              THIS forward needs it; later forwards of the iteration advance u / v in place) */
+  float* v_out;            /* fwd, optional: copy of v [cols] likewise */
 } tp_sn_weight;
 int64_t tp_sn_work_floats(int rows, int cols);
 int tp_sn_fwd(const tp_sn_weight* weights, int n, int training, tp_stream_t stream);
@@ -455,6 +458,9 @@ int tp_sumsq_mean_fwd(const float* g, int64_t n, int B, float* out, tp_stream_t 
 int tp_sumsq_mean_bwd(const float* g, int64_t n, int B, const float* cot, float* out, tp_stream_t stream);
 /* Rows idx[b] of the two latent tables (model/nerf_adapt_st_gan.py:589-593) in one launch, and the dense table gradients
  * gw [n_rows,C] = sum over b with idx[b] == r of g[b] (ascending b; every element written: no zero-fill needed). */
+/* out[0] = sum_k weights[k] * terms[k][0] (ascending k) for up to 16 scalar device tensors; `terms` and `weights` are HOST
+ * arrays (the weighted loss total of model/base.py:145-157, for logging and the step gate). */
+int tp_weighted_sum(const float* const* terms, const float* weights, int n, float* out, tp_stream_t stream);
 int tp_latent_rows_fwd(const float* w_trans, const float* w_light, const int64_t* idx, int B, int C_trans, int C_light, float* out_trans,
                        float* out_light, tp_stream_t stream);
 int tp_latent_rows_bwd(const float* g_trans, const float* g_light, const int64_t* idx, int B, int n_rows, int C_trans, int C_light,

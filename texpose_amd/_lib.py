@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # TEXPOSE_AMD_LIB selects another build of the SAME library (e.g. the `make trace` diagnostic build); never a fallback
 LIB_PATH = os.environ.get("TEXPOSE_AMD_LIB") or os.path.join(_HERE, "libtexpose_amd.so")
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 # Every symbol include/texpose_amd.h declares (checked by tests/test_capi_cpu.py).
 SYMBOLS = (
@@ -32,7 +32,7 @@ SYMBOLS = (
     "tp_conv3s1_workspace", "tp_conv3s1_fwd", "tp_conv3s1_dgrad",
     "tp_patch_coords", "tp_bce_logits_fwd", "tp_bce_logits_bwd", "tp_feat_inputs_fwd", "tp_feat_inputs_bwd", "tp_disc_inputs", "tp_step_flags", "tp_adam_step",
     "tp_fake_patch_bwd", "tp_feat_pair_loss_fwd", "tp_feat_pair_loss_bwd", "tp_sumsq_mean_fwd", "tp_sumsq_mean_bwd", "tp_latent_rows_fwd",
-    "tp_latent_rows_bwd",
+    "tp_latent_rows_bwd", "tp_weighted_sum",
     "tp_disc_head_fwd", "tp_disc_head_bwd", "tp_disc_head_bwd_bwd",
     "tp_skinny_linear_fwd", "tp_skinny_linear_wgrad",
 )
@@ -96,7 +96,7 @@ class EvalMetricsArgs(C.Structure):
 
 class SnWeight(C.Structure):
     _fields_ = [("weight", vp), ("u", vp), ("v", vp), ("weight_sn", vp), ("sigma", vp), ("grad_sn", vp), ("grad", vp),
-                ("work", vp), ("rows", C.c_int), ("cols", C.c_int)]
+                ("work", vp), ("rows", C.c_int), ("cols", C.c_int), ("u_out", vp), ("v_out", vp)]
 
 
 SN_MAX_WEIGHTS = 8
@@ -228,6 +228,7 @@ def load() -> C.CDLL:
     sig("tp_feat_pair_loss_bwd", [vp, C.c_int64, C.c_float, vp, vp, vp])
     sig("tp_sumsq_mean_fwd", [vp, C.c_int64, C.c_int, vp, vp])
     sig("tp_sumsq_mean_bwd", [vp, C.c_int64, C.c_int, vp, vp, vp])
+    sig("tp_weighted_sum", [C.POINTER(vp), C.POINTER(C.c_float), C.c_int, vp, vp])
     sig("tp_latent_rows_fwd", [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp])
     sig("tp_latent_rows_bwd", [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp])
     for name in ("tp_disc_head_fwd", "tp_disc_head_bwd", "tp_disc_head_bwd_bwd"):

@@ -11,6 +11,12 @@ import torch
 
 from . import ops
 
+# The R1 penalty first differentiates D wrt its INPUT with create_graph=True (Graph.compute_grad2); PyTorch's
+# ctx.needs_input_grad only reflects requires_grad, so the weight-gradient kernels of every convolution would run in that pass
+# although nothing consumes them (the penalty's graph hangs off the data gradients alone).  Graph.compute_grad2_mean sets this
+# flag around that call; the weight gradients proper come from the backward traversal of the optimiser step.
+SKIP_WEIGHT_GRADS = False
+
 
 class _Composite(torch.autograd.Function):
     """out [..,14], alpha_static, alpha_transient, prob, rgb_ray [..,3], uncert_ray [..,1].  The last two are compact copies of
@@ -164,7 +170,7 @@ class _Conv4s2(torch.autograd.Function):
         x, w = ctx.saved_tensors
         gy = gy.contiguous()
         gx = _Conv4s2Dgrad.apply(gy, w) if ctx.needs_input_grad[0] else None
-        gw = _Conv4s2Wgrad.apply(gy, x) if ctx.needs_input_grad[1] else None
+        gw = _Conv4s2Wgrad.apply(gy, x) if ctx.needs_input_grad[1] and not SKIP_WEIGHT_GRADS else None
         return gx, gw
 
 
@@ -323,7 +329,7 @@ class _SkinnyLinear(torch.autograd.Function):
         x, w = ctx.saved_tensors
         gy = gy.contiguous()
         gx = _SkinnyLinearDgrad.apply(gy, w) if ctx.needs_input_grad[0] else None
-        gw = _SkinnyLinearWgrad.apply(gy, x) if ctx.needs_input_grad[1] else None
+        gw = _SkinnyLinearWgrad.apply(gy, x) if ctx.needs_input_grad[1] and not SKIP_WEIGHT_GRADS else None
         return gx, gw
 
 

@@ -119,6 +119,10 @@ __global__ __launch_bounds__(256) void sn_scale_kernel(Batch b) {
   const float sg = *w.sigma;
   for (int64_t i = (int64_t)local * 1024 + threadIdx.x; i < min(n, (int64_t)(local + 1) * 1024); i += 256)
     w.weight_sn[i] = w.weight[i] / sg;
+  if (local == 0) {                     // this forward's u / v for its backward (one workgroup per weight)
+    if (w.u_out) for (int r = threadIdx.x; r < w.rows; r += 256) w.u_out[r] = w.u[r];
+    if (w.v_out) for (int c = threadIdx.x; c < w.cols; c += 256) w.v_out[c] = w.v[c];
+  }
 }
 
 // D: per-workgroup partial of <G, W_sn>

@@ -241,6 +241,15 @@ __global__ __launch_bounds__(kBlock) void sumsq_mean_bwd_kernel(const float* __r
   if (i < n) out[i] = 2.f * cot[0] / (float)B * g[i];
 }
 
+// ---- total = sum_k w_k term_k over up to 16 scalar device tensors (reference model/base.py:145-157: the weighted loss sum)
+struct TermTable { const float* t[16]; float w[16]; int n; };
+__global__ void weighted_sum_kernel(TermTable tb, float* __restrict__ out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float acc = 0.f;
+  for (int k = 0; k < tb.n; ++k) acc += tb.t[k][0] * tb.w[k];          // ascending k, like torch.dot on the stacked terms
+  out[0] = acc;
+}
+
 // ---- per-image latent rows (model/nerf_adapt_st_gan.py:589-593: Embedding.weight[var.idx]) of BOTH tables in one launch,
 // and their gradient: dense [n_rows, C] tables with g[r] = sum over the images b with idx[b] == r, in ascending b (no
 // atomics, no zero-fill launch; torch: index_select x 2 forward, zeros + index_add_ x 2 backward)
@@ -391,5 +400,14 @@ int tp_latent_rows_bwd(const float* g_trans, const float* g_light, const int64_t
   hipLaunchKernelGGL(latent_rows_bwd_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, (hipStream_t)stream, g_trans, g_light, idx, B,
                      n_rows, C_trans, C_light, gw_trans, gw_light);
   return tp::check_launch("tp_latent_rows_bwd");
+}
+int tp_weighted_sum(const float* const* terms, const float* weights, int n, float* out, tp_stream_t stream) {
+  TP_REQUIRE(terms && weights && out && n > 0 && n <= 16, "1..16 terms expected");
+  TermTable tb;
+  for (int k = 0; k < 16; ++k) { tb.t[k] = k < n ? terms[k] : nullptr; tb.w[k] = k < n ? weights[k] : 0.f; }
+  for (int k = 0; k < n; ++k) TP_REQUIRE(terms[k] != nullptr, "null term");
+  tb.n = n;
+  hipLaunchKernelGGL(weighted_sum_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, tb, out);
+  return tp::check_launch("tp_weighted_sum");
 }
 }

@@ -61,14 +61,12 @@ class _SpectralWeightsHip(torch.autograd.Function):
     def forward(ctx, convs, training, *weights):
         from . import ops
         us, vs = [c.weight_u for c in convs], [c.weight_v for c in convs]
-        outs, sigmas = ops.spectral_norm_fwd([w.detach() for w in weights], us, vs, training)
-        # later forwards of the same iteration advance u / v in place: keep this forward's copies for its backward (one
-        # launch for all twelve vectors; none when no weight wants a gradient, e.g. the nerf step)
+        # later forwards of the same iteration advance u / v in place: keep this forward's copies for its backward (written
+        # by the normalisation launch itself; none when no weight wants a gradient, e.g. the nerf step)
         if training and any(ctx.needs_input_grad):
-            flat = torch.cat([t.reshape(-1) for t in us + vs])
-            parts = flat.split([t.numel() for t in us + vs])
-            ctx.us, ctx.vs = list(parts[:len(us)]), list(parts[len(us):])
+            outs, sigmas, ctx.us, ctx.vs = ops.spectral_norm_fwd([w.detach() for w in weights], us, vs, training, keep_uv=True)
         else:
+            outs, sigmas = ops.spectral_norm_fwd([w.detach() for w in weights], us, vs, training)
             ctx.us, ctx.vs = us, vs
         ctx.sigmas = sigmas
         ctx.save_for_backward(*outs)

@@ -437,8 +437,12 @@ class Graph(torch.nn.Module):
         if not (d_out.is_cuda and torch.is_tensor(d_out)):
             return Graph.compute_grad2(opt, d_out, x_in).mean()
         ones = _ones_like_cached(d_out)
-        g = torch.autograd.grad(outputs=d_out, inputs=x_in, grad_outputs=ones, create_graph=True, retain_graph=True,
-                                only_inputs=True)[0]
+        autograd_ops.SKIP_WEIGHT_GRADS = True          # this pass differentiates wrt the INPUT only
+        try:
+            g = torch.autograd.grad(outputs=d_out, inputs=x_in, grad_outputs=ones, create_graph=True, retain_graph=True,
+                                    only_inputs=True)[0]
+        finally:
+            autograd_ops.SKIP_WEIGHT_GRADS = False
         return autograd_ops.sumsq_mean(g)
 
     @staticmethod

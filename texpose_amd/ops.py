@@ -505,14 +505,20 @@ def eval_metrics(rgb_static: Tensor, image: Tensor, obj_mask: Tensor, H: int, W:
 
 
 @_on_tensor_device
-def spectral_norm_fwd(weights, us, vs, training: bool):
+def spectral_norm_fwd(weights, us, vs, training: bool, keep_uv: bool = False):
     """weights[i] [out, ...] (contiguous), us[i] [out], vs[i] [K]: one power iteration per weight when ``training``
     (u, v updated IN PLACE, like torch.nn.utils.spectral_norm), then W_sn = W / sigma.  Returns (W_sn list, sigma
-    list of 1-element tensors).  All weights of a module in five launches."""
+    list of 1-element tensors).  All weights of a module in five launches.  ``keep_uv``: also returns copies of u / v as
+    they stand after this call (written by the last launch) as a third / fourth list."""
     lib = _lib.load()
     n = len(weights)
     arr = (_lib.SnWeight * n)()
     outs, sigmas, keep = [], [], []
+    u_copies = v_copies = None
+    if keep_uv:
+        flat = torch.empty(sum(u.numel() + v.numel() for u, v in zip(us, vs)), device=us[0].device)
+        parts = flat.split([t.numel() for t in list(us) + list(vs)])
+        u_copies, v_copies = list(parts[:n]), list(parts[n:])
     for i, (w, u, v) in enumerate(zip(weights, us, vs)):
         w = _f32(w, "weight")
         rows, cols = w.shape[0], w.numel() // w.shape[0]
@@ -521,9 +527,11 @@ def spectral_norm_fwd(weights, us, vs, training: bool):
         a = arr[i]
         a.weight, a.u, a.v, a.weight_sn, a.sigma, a.work = w.data_ptr(), u.data_ptr(), v.data_ptr(), o.data_ptr(), sg.data_ptr(), wk.data_ptr()
         a.rows, a.cols = rows, cols
+        if keep_uv:
+            a.u_out, a.v_out = u_copies[i].data_ptr(), v_copies[i].data_ptr()
         outs.append(o); sigmas.append(sg); keep += [w, wk]
     check(lib.tp_sn_fwd(arr, n, int(bool(training)), _stream()), "tp_sn_fwd")
-    return outs, sigmas
+    return (outs, sigmas, u_copies, v_copies) if keep_uv else (outs, sigmas)
 
 
 @_on_tensor_device
@@ -919,6 +927,19 @@ def sumsq_mean_bwd(g: Tensor, cot: Tensor) -> Tensor:
     g, cot = _f32(g, "g"), _f32(cot, "cot")
     out = torch.empty_like(g)
     check(lib.tp_sumsq_mean_bwd(g.data_ptr(), g.numel(), g.shape[0], cot.data_ptr(), out.data_ptr(), _stream()), "tp_sumsq_mean_bwd")
+    return out
+
+
+@_on_tensor_device
+def weighted_sum(terms, weights) -> Tensor:
+    """sum_k weights[k] * terms[k] for 0-dim float32 device tensors and host floats, one launch."""
+    lib = _lib.load()
+    n = len(terms)
+    ts = [_f32(t.detach(), "term") for t in terms]
+    ptrs = (C.c_void_p * n)(*[t.data_ptr() for t in ts])
+    ws = (C.c_float * n)(*[float(w) for w in weights])
+    out = torch.empty((), device=ts[0].device)
+    check(lib.tp_weighted_sum(ptrs, ws, n, out.data_ptr(), _stream()), "tp_weighted_sum")
     return out
 
 

@@ -200,7 +200,10 @@ class GanTrainer:
         if vec_key not in cache:
             cache[vec_key] = torch.stack(ws)
         with torch.no_grad():
-            loss.all = torch.dot(torch.stack([loss[k].detach() for k in keys]), cache[vec_key])
+            if dev.type == "cuda" and len(keys) <= 16 and all(loss[k].dtype == torch.float32 for k in keys):
+                loss.all = ops.weighted_sum([loss[k] for k in keys], [10 ** float(opt.loss_weight[k]) for k in keys])   # K13: one launch
+            else:
+                loss.all = torch.dot(torch.stack([loss[k].detach() for k in keys]), cache[vec_key])
         return [loss[k] for k in keys], ws
 
     def _backward_weighted(self, loss):
