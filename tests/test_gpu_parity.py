@@ -1888,3 +1888,25 @@ def test_round3_glue_kernels_match_torch(ops):
     cot = cu(torch.from_numpy(rs.normal(size=(B, 9, p, p)).astype(np.float32)))
     (fake * cot).sum().backward()
     torch.testing.assert_close(rgb.grad, cot[:, :3].permute(0, 2, 3, 1).reshape(B, p * p, 3))
+
+
+def test_weighted_sum_and_sn_uv_copies(ops):
+    """tp_weighted_sum == torch.dot(stack(terms), weights); tp_sn_fwd's u / v copies equal the buffers after the power iteration."""
+    rs = np.random.RandomState(3)
+    terms = [cu(torch.tensor(float(v))) for v in rs.normal(size=7)]
+    ws = [10 ** float(e) for e in (0, 0, -2, -2, -1, 1, 0)]
+    got = ops.weighted_sum(terms, ws)
+    ref = torch.dot(torch.stack(terms), cu(torch.tensor(ws, dtype=torch.float32)))
+    torch.testing.assert_close(got, ref, rtol=1e-6, atol=1e-7)
+    weights = [cu(torch.from_numpy(rs.normal(size=s).astype(np.float32))) for s in ((64, 9, 4, 4), (32, 73, 1, 1), (1, 64, 1, 1))]
+    us = [F.normalize(cu(torch.from_numpy(rs.normal(size=w.shape[0]).astype(np.float32))), dim=0) for w in weights]
+    vs = [F.normalize(cu(torch.from_numpy(rs.normal(size=w[0].numel()).astype(np.float32))), dim=0) for w in weights]
+    us2, vs2 = [u.clone() for u in us], [v.clone() for v in vs]
+    outs, sig = ops.spectral_norm_fwd(weights, us, vs, True)
+    outs2, sig2, uc, vc = ops.spectral_norm_fwd(weights, us2, vs2, True, keep_uv=True)
+    for a, b, c, d in zip(us, us2, uc, outs):
+        assert torch.equal(a, b) and torch.equal(b, c)
+    for a, b, c in zip(vs, vs2, vc):
+        assert torch.equal(a, b) and torch.equal(b, c)
+    for a, b in zip(outs, outs2):
+        assert torch.equal(a, b)

@@ -29,7 +29,7 @@ for i, l in enumerate(open(sys.argv[1]).read().split("\n")):
         stats[cur][0] += 1
     if inasm:
         stats[cur][1] += 1
-    elif "mlp_fwd_f16x3_kernel" in cur and re.search(r"\ba\[?\d", s):
+    elif ("mlp_fwd_f16x3_kernel" in cur or "mlp_dgrad_f16x3_asm_kernel" in cur) and re.search(r"\ba\[?\d", s):
         bad.append("%s:%d: %s" % (cur[:48], i + 1, l.strip()))
 for k, (sc, na) in stats.items():
     print("%-70s scratch instructions %4d, inline-asm instructions %5d" % (k[:70], sc, na))
@@ -37,4 +37,4 @@ if bad:
     print("COMPILED CODE TOUCHES AGPRs (%d places):" % len(bad))
     print("\n".join(bad[:20]))
     sys.exit(1)
-print("ok: compiled code of the forward kernels never touches an AGPR")
+print("ok: compiled code of the forward kernels and the asm data-gradient kernel never touches an AGPR")

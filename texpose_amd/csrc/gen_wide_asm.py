@@ -34,8 +34,10 @@ import os
 import sys
 
 NCH = 115
-# timing experiments only (results are WRONG): TP_ASM_EXPERIMENT = nodma | nobarrier | noconv
+# timing experiments only (results are WRONG): TP_ASM_EXPERIMENT = nodma | nobarrier | noconv | recnostore (recording
+# blocks issue no vector stores) | recnolds (no staging-tile writes / reads either)
 EXPERIMENT = os.environ.get("TP_ASM_EXPERIMENT", "")
+LATE = "late" in EXPERIMENT     # (under test) record stores behind the chunk's last DMA piece
 
 VB = 160
 def F_hi(slot): return VB + 8 * slot
@@ -111,8 +113,11 @@ def conv_rec(src_base, tile, g, bank, mask=True):
     t0, t1 = T, T + 1
     r0, r1 = 2 * g, 2 * g + 1
     out = c[0:6]
-    out += ["ds_write_b32 %%[recw], v%d offset:%d" % (t0, rec_wr_off(r0)),
-            "ds_write_b32 %%[recw], v%d offset:%d" % (t1, rec_wr_off(r1))]
+    if EXPERIMENT != "recnolds":
+        out += ["ds_write_b32 %%[recw], v%d offset:%d" % (t0, rec_wr_off(r0)),
+                "ds_write_b32 %%[recw], v%d offset:%d" % (t1, rec_wr_off(r1))]
+    else:
+        out += ["s_nop 0", "s_nop 0"]
     if mask:
         out += ["v_cmp_lt_f32_e32 vcc, 0, v%d" % t0,
                 "v_addc_co_u32_e32 v%d, vcc, v%d, v%d, vcc" % (MK, MK, MK),
@@ -131,12 +136,17 @@ def rec_reads(set_base, tile):
     """the staged tile back out of LDS, transposed, into the accumulator registers of the SOURCE tile itself: they are dead
     from the tile's conversion until it is re-seeded (WIDE: moved behind the stores) or for good (HEAD); LDS loads may
     target AGPRs and vector stores may take their data from them on gfx950 -- no VGPR is spent on the record"""
+    if EXPERIMENT == "recnolds":
+        return []
     return ["ds_read_b128 %s, %%[recr] offset:%d" % (tile_regs(set_base, tile, k), k * 4096) for k in range(4)]
 
 
 def rec_store(set_base, tile, k):
     # units 2, 3 sit 16 rows (2 KB) behind units 0, 1 with the same swizzle: two offset registers, an immediate for the rest
-    return "global_store_dwordx4 %%[ro%d], %s, s[%d:%d] offset:%d nt" % (k & 1, tile_regs(set_base, tile, k), RB, RB + 1, (k >> 1) * 2048)
+    if EXPERIMENT in ("recnostore", "recnolds"):
+        return "s_nop 0"
+    policy = {"recplain": "", "recsc1": " sc1", "recsc01": " sc0 sc1"}.get(EXPERIMENT.replace("early", ""), " nt")
+    return "global_store_dwordx4 %%[ro%d], %s, s[%d:%d] offset:%d%s" % (k & 1, tile_regs(set_base, tile, k), RB, RB + 1, (k >> 1) * 2048, policy)
 
 
 def rec_advance():
@@ -145,6 +155,8 @@ def rec_advance():
 
 def rec_mask_store(w4):
     # bits were pushed MSB-first (tile 2 w4 register 0 first): reverse -> bit b <-> tile 2 w4 + b / 16, register b % 16
+    if EXPERIMENT in ("recnostore", "recnolds"):
+        return []
     return ["v_bfrev_b32_e32 v%d, v%d" % (MK, MK),
             "global_store_dword %%[mkoff], v%d, %%[rbase] offset:%d" % (MK, w4 * 256)]
 
@@ -177,6 +189,7 @@ def ring_prologue(e):
     e("s_cmp_ge_i32 %[dch], " + str(NCH))
     e("s_cselect_b32 %[t0], " + str(NCH) + ", 0")
     e("s_sub_i32 %[dch], %[dch], %[t0]")
+    # (NCH is read at generation time: main() switches it to the 34-chunk transposed stream for the data-gradient blocks)
 
 
 def dma_base():
@@ -257,7 +270,7 @@ def chunk_groups(e, npairs, ts, mf, fill, free_after, pieces_per_group, tail=Non
                     # before this point; they retire in order with the pieces (MI355X_MICROARCH.md: loads, stores and
                     # LDS-DMA count together, in issue order), so the count must be exact: too small only waits longer,
                     # too large would let a piece of the chunk being published still be in flight
-                    publish(e, (g + 1) * pieces_per_group + young_extra)
+                    publish(e, (g + 1) * pieces_per_group + (0 if EXPERIMENT in ("recnostore", "recnolds") else young_extra))
                 refill(e, sa, q + 4, npairs, cur, nxt)
             if i + 1 == free_after[1]:
                 refill(e, sb, q + 5, npairs, cur, nxt)
@@ -311,22 +324,33 @@ def gen_wide(src, dst, rec=None):
                 #                reads are issued BEFORE the group's ring refills, so the waits' counts are unchanged;
                 #                even chunks: the mask word of tiles ts, ts + 1, complete with this group's last v_addc (it
                 #                is issued after the publish point: the NEXT chunk counts it)
-                first, mid2, mid3, last = [], [], [], []
-                if 1 <= g <= 4:
+                first, mid1, mid2, mid3, last = [], [], [], [], []
+                if LATE:
+                    # the four stores of tile ts in group 7, AFTER the chunk's last DMA piece: the publish of the next chunk
+                    # (which waits for that piece and everything older) then does not wait for them -- they get two chunks to
+                    # retire instead of one (vmcnt retires in issue order; a 16-byte nontemporal store takes > 1 us)
+                    if g == 7:
+                        st = [rec_store(src, ts, k) for k in range(4)]
+                        first, mid1, mid2, mid3 = [st[0]], [st[1]], [st[2]], [st[3]]
+                        last = rec_advance()
+                elif "early" in EXPERIMENT:
+                    if g == 1:
+                        first = [rec_store(src, ts, k) for k in range(4)]
+                elif 1 <= g <= 4:
                     first = [rec_store(src, ts, g - 1)]
-                elif g == 5:
+                if g == 5 and not LATE:
                     first = rec_advance()
                 if g == 7 and ts < 7:
                     rd = rec_reads(src, ts + 1)
-                    mid2, mid3 = rd[0:2], rd[2:4]
+                    mid2, mid3 = mid2 + rd[0:2], mid3 + rd[2:4]
                     if rec == "mask" and not (ts & 1):
-                        last = rec_mask_store(ts >> 1)
+                        last = last + rec_mask_store(ts >> 1)
                 if ts == 7:
-                    return [first, [], [], [], []]
+                    return [first, mid1, mid2, mid3, last]
                 cv = conv_rec(src, ts + 1, g, bank ^ 1, mask=(rec == "mask"))
                 if rec == "mask":      # 19: [reads, scale | ReLU, 2 LDS stores, cmp | addc, cmp, addc, 2 and | 2 sub, 2 cvt | max]
-                    return [first + cv[0:4], cv[4:9], cv[9:14] + mid2, cv[14:18] + mid3, cv[18:19] + last]
-                return [first + cv[0:4], cv[4:8], cv[8:12] + mid2, cv[12:15] + mid3, []]
+                    return [first + cv[0:4], mid1 + cv[4:9], cv[9:14] + mid2, cv[14:18] + mid3, cv[18:19] + last]
+                return [first + cv[0:4], mid1 + cv[4:8], cv[8:12] + mid2, cv[12:15] + mid3, last]
             if ts == 7:
                 return [[], [], [], [], []]
             cv = conv(src, ts + 1, g, bank ^ 1)
@@ -346,16 +370,21 @@ def gen_wide(src, dst, rec=None):
                     out.append(advance_dch()[g - 1])
                 if g == 7:
                     out += dma_base()
+            if rec and LATE and g == 7:        # re-seed tile ts behind its stores
+                out += ["ds_read_b128 a[%d:%d], %%[nbias] offset:%d" % (src + 16 * ts + 4 * k, src + 16 * ts + 4 * k + 3, ts * 64 + k * 16)
+                        for k in range(4)]
             return out
 
         def head(g, ts=ts):
-            if g != (6 if rec else 0):
+            if g != ((-1 if LATE else 6) if rec else 0):
                 return []
             return ["ds_read_b128 a[%d:%d], %%[nbias] offset:%d" % (src + 16 * ts + 4 * k, src + 16 * ts + 4 * k + 3, ts * 64 + k * 16)
                     for k in range(4)]
 
         extra = 0
-        if rec:        # this chunk's four tile stores + the mask word the previous (even) chunk stored after ITS publish point
+        if rec and LATE:   # the previous chunk's four tile stores and (odd chunks) mask word, all issued behind ITS last DMA piece
+            extra = 0 if ts == 0 else 4 + (1 if (ts & 1) and rec == "mask" else 0)
+        elif rec:      # this chunk's four tile stores + the mask word the previous (even) chunk stored after ITS publish point
             extra = 4 + (1 if (ts & 1) and rec == "mask" else 0)
         chunk_groups(e, 16, ts, mf, fill, (5, 6), 1, tail, head, young_extra=extra)
     ring_epilogue(e, 8)
@@ -489,6 +518,157 @@ def gen_read_tile(src, tile):
     return ["s_nop 7", "s_nop 7"] + ["v_accvgpr_read_b32 v%d, a%d" % (HACC + k, src + 16 * tile + k) for k in range(16)]
 
 
+
+# ====================================================================================================== DATA GRADIENT
+# mlp_dgrad_f16x3_kernel (round 3): the backward chain dh = W^T dz of a head on the same blocks -- transposed f16x3 stream of
+# 34 chunks, sets P / Q in ping-pong -- with the GATED conversion of the backward (the recorded ReLU sign words decide, not the
+# value) and the dz record written by the block that consumes the set (as the recording forward does).  No seeding: a
+# destination tile's first MFMA takes C = 0.  Extra operands:
+#   %[g0..3]  VGPR: this layer's four sign words of the lane (bit b of word w <-> tile 2 w + b / 16, register b % 16)
+#   %[isc]    VGPR: 2^-k of the sample's chain (0 for a sample past the end): the record holds unscaled gradients
+#   %[dzm]    VGPR in/out: running max |dz| of the lane (range of the split-fp16 weight-gradient GEMM)
+def conv_gate(src_base, tile, g, bank, xops=True):
+    """elements 2g, 2g+1 of source tile `tile`: v = gate ? acc * 2^-8 : 0; record v * isc (staging tile) and max |.|; with
+    `xops` also the hi / lo operands in `bank`: 21 (13) instructions"""
+    xh = XB[bank] + (g >> 2) * 4 + (g & 3)
+    xl = XB[bank] + 8 + (g >> 2) * 4 + (g & 3)
+    t0, t1, h0, h1 = T, T + 1, T + 2, T + 3
+    a = src_base + 16 * tile + 2 * g
+    r0, r1 = 2 * g, 2 * g + 1
+    w, b0 = tile >> 1, (tile & 1) * 16 + r0
+    out = ["v_accvgpr_read_b32 v%d, a%d" % (t0, a),
+           "v_accvgpr_read_b32 v%d, a%d" % (t1, a + 1),
+           "v_mul_f32 v%d, %%[kinv], v%d" % (t0, t0),
+           "v_mul_f32 v%d, %%[kinv], v%d" % (t1, t1),
+           "v_bfe_i32 v%d, %%[g%d], %d, 1" % (h0, w, b0),
+           "v_bfe_i32 v%d, %%[g%d], %d, 1" % (h1, w, b0 + 1),
+           "v_and_b32 v%d, v%d, v%d" % (t0, t0, h0),
+           "v_and_b32 v%d, v%d, v%d" % (t1, t1, h1),
+           "v_mul_f32 v%d, %%[isc], v%d" % (h0, t0),
+           "v_mul_f32 v%d, %%[isc], v%d" % (h1, t1),
+           "ds_write_b32 %%[recw], v%d offset:%d" % (h0, rec_wr_off(r0)),
+           "ds_write_b32 %%[recw], v%d offset:%d" % (h1, rec_wr_off(r1)),
+           "v_max3_f32 %%[dzm], |v%d|, |v%d|, %%[dzm]" % (h0, h1)]
+    if xops:
+        out += ["v_and_b32 v%d, %%[mask], v%d" % (h0, t0),
+                "v_and_b32 v%d, %%[mask], v%d" % (h1, t1),
+                "v_sub_f32 v%d, v%d, v%d" % (t0, t0, h0),
+                "v_sub_f32 v%d, v%d, v%d" % (t1, t1, h1),
+                "v_cvt_pkrtz_f16_f32 v%d, v%d, v%d" % (xh, h0, h1),
+                "v_cvt_pkrtz_f16_f32 v%d, v%d, v%d" % (xl, t0, t1)]
+    return out
+
+
+def gen_dg_wide(src, dst):
+    """256 -> 256 transposed layer: dst = W^T gated(src * 2^-8); records gated(src) * isc as the dz block at %[rbase]"""
+    L = []
+    e = L.append
+    ring_prologue(e)
+    e("s_mov_b64 s[%d:%d], %%[rbase]" % (RB, RB + 1))
+    for g in range(8):
+        for ins in conv_gate(src, 0, g, 0):
+            e(ins)
+    for ins in rec_reads(src, 0):
+        e(ins)
+    for ins in dma_base():
+        e(ins)
+    for ts in range(8):
+        bank = ts & 1
+
+        def mf(g, bank=bank, ts=ts):
+            s, t = g >> 2, (2 * g) & 7
+            sa, sb = (2 * g) % 4, (2 * g + 1) % 4
+            xh, xl = vr(XB[bank] + s * 4), vr(XB[bank] + 8 + s * 4)
+            d0, d1 = ar(dst, t), ar(dst, t + 1)
+            c0 = "0" if ts == 0 and s == 0 else None          # first touch of a destination tile: C = 0, no seeding pass
+            return [mfma(d0, vr(F_hi(sa)), xh, c0), mfma(d1, vr(F_hi(sb)), xh, c0), mfma(d0, vr(F_hi(sa)), xl),
+                    mfma(d1, vr(F_hi(sb)), xl), mfma(d0, vr(F_lo(sa)), xh), mfma(d1, vr(F_lo(sb)), xh)]
+
+        def fill(g, ts=ts, bank=bank):
+            first, mid1, mid2, mid3, last = [], [], [], [], []
+            if LATE:
+                if g == 7:
+                    st = [rec_store(src, ts, k) for k in range(4)]
+                    first, mid1, mid2, mid3 = [st[0]], [st[1]], [st[2]], [st[3]]
+                    last = rec_advance()
+            elif 1 <= g <= 4:
+                first = [rec_store(src, ts, g - 1)]
+            elif g == 5:
+                first = rec_advance()
+            if g == 7 and ts < 7:
+                rd = rec_reads(src, ts + 1)
+                mid2, mid3 = mid2 + rd[0:2], mid3 + rd[2:4]
+            if ts == 7:
+                return [first, mid1, mid2, mid3, last]
+            cv = conv_gate(src, ts + 1, g, bank ^ 1)       # 19: [reads, scale | 2 bfe, 2 and, mul | mul, 2 LDS stores, max3, and | and, 2 sub, cvt | cvt]
+            return [first + cv[0:4], mid1 + cv[4:9], cv[9:14] + mid2, cv[14:18] + mid3, cv[18:19] + last]
+
+        def tail(g, ts=ts):
+            out = []
+            if ts < 7:
+                if 1 <= g <= 3:
+                    out.append(advance_dch()[g - 1])
+                if g == 7:
+                    out += dma_base()
+            return out
+
+        chunk_groups(e, 16, ts, mf, fill, (5, 6), 1, tail, None, young_extra=(0 if ts == 0 else 4) if LATE else 4)
+    ring_epilogue(e, 8)
+    return L
+
+
+def gen_dg_narrow(dst):
+    """dst = W3^T d: one chunk, one k-step; the 16 + 16 bytes of this lane's B operand (hi / lo) at %[stage] / + 4096"""
+    L = []
+    e = L.append
+    ring_prologue(e)
+    e("ds_read_b128 %s, %%[stage] offset:0" % vr(XB[0]))
+    e("ds_read_b128 %s, %%[stage] offset:4096" % vr(XB[0] + 8))
+    for ins in dma_base():
+        e(ins)
+    e("s_waitcnt lgkmcnt(0)")
+
+    def mf(g):
+        t = (2 * g) & 7
+        sa, sb = (2 * g) % 4, (2 * g + 1) % 4
+        xh, xl = vr(XB[0]), vr(XB[0] + 8)
+        d0, d1 = ar(dst, t), ar(dst, t + 1)
+        return [mfma(d0, vr(F_hi(sa)), xh, "0"), mfma(d1, vr(F_hi(sb)), xh, "0"), mfma(d0, vr(F_hi(sa)), xl),
+                mfma(d1, vr(F_hi(sb)), xl), mfma(d0, vr(F_lo(sa)), xh), mfma(d1, vr(F_lo(sb)), xh)]
+
+    chunk_groups(e, 8, 0, mf, lambda g: [[], [], [], [], []], (5, 6), 2)
+    ring_epilogue(e, 1)
+    return L
+
+
+def gen_dg_finish(src):
+    """the last dz block of a head (no layer follows that could carry it): gate + record of set `src`, no MFMA.  Tile t is
+    read back (into its own, dead accumulator registers) right after its 16 staging-tile writes; it is stored once the NEXT
+    tile's writes have been issued (LDS operations of a wave execute in order: at most those 16 are then outstanding)."""
+    L = []
+    e = L.append
+    e("s_waitcnt lgkmcnt(0)")
+    e("s_nop 7")
+    e("s_nop 7")
+    e("s_mov_b64 s[%d:%d], %%[rbase]" % (RB, RB + 1))
+    for t in range(8):
+        for g in range(8):
+            for ins in conv_gate(src, t, g, 0, xops=False):
+                e(ins)
+        if t > 0:
+            e("s_waitcnt lgkmcnt(15)")          # (4-bit counter: the four reads and one write have retired)
+            for k in range(4):
+                e(rec_store(src, t - 1, k))
+            for ins in rec_advance():
+                e(ins)
+        for ins in rec_reads(src, t):
+            e(ins)
+    e("s_waitcnt lgkmcnt(0)")
+    for k in range(4):
+        e(rec_store(src, 7, k))
+    return L
+
+
 def emit_macro(out, name, comment, lines):
     out.append("// " + comment)
     out.append("#define %s \\" % name)
@@ -517,6 +697,14 @@ def main():
             emit_macro(out, "TP_ASM_READ_%s%d" % (d, t), "tile %d of set %s -> v[232:247]" % (t, d), gen_read_tile(SET[d], t))
     emit_macro(out, "TP_ASM_STASH_Q", "set Q -> v[32:159]", gen_stash(SET["Q"]))
     emit_macro(out, "TP_ASM_RESTORE_P", "v[32:159] -> set P", gen_restore(SET["P"]))
+    # data gradient: the 34-chunk transposed stream
+    global NCH
+    NCH = 34
+    emit_macro(out, "TP_ASM_DG_NARROW_P", "data gradient: set P = W3^T d (one k-step)", gen_dg_narrow(SET["P"]))
+    emit_macro(out, "TP_ASM_DG_WIDE_PQ", "data gradient: set Q = W^T gated(set P), recording gated(set P)", gen_dg_wide(SET["P"], SET["Q"]))
+    emit_macro(out, "TP_ASM_DG_WIDE_QP", "data gradient: set P = W^T gated(set Q), recording gated(set Q)", gen_dg_wide(SET["Q"], SET["P"]))
+    emit_macro(out, "TP_ASM_DG_FINISH_P", "data gradient: record gated(set P)", gen_dg_finish(SET["P"]))
+    NCH = 115
     sys.stdout.write("\n".join(out) + "\n")
 
 

@@ -17,6 +17,7 @@
 // and the packed weights absorb that row permutation (mlp_layout.h, "f16x3 stream").
 #include "mlp_mma.h"
 #include "wide_asm.inc.h"
+#include <cstdlib>
 #include <type_traits>
 
 namespace {
@@ -1102,6 +1103,179 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_dgrad_f16x3_kernel(DgP P) {
   }
 }
 
+
+// =====================================================================================================================
+// The same data gradient on the hand-scheduled blocks of wide_asm.inc.h (round 3; gen_wide_asm.py "DATA GRADIENT"): the
+// compiled layer body above runs the matrix pipe at ~40 % (its gated conversions, staging-tile traffic and record stores are
+// scheduled by hipcc), this one issues every conversion, staging write, read-back and 16-byte store in an MFMA gap of the
+// layer that consumes the set.  Per head: NARROW (W3^T d -> set P), WIDE P->Q (records dz of layer 2), WIDE Q->P (records dz
+// of layer 1), FINISH (records dz of layer 0).  Sets P / Q live in a[0:255]; nothing seeds them (first MFMA of a tile: C = 0).
+// LDS: weight ring 96 KiB | narrow B operand 8 KiB (hi, lo: 16 B per lane each) | four 4 KiB record staging tiles.
+// =====================================================================================================================
+constexpr int kDgStageOff = kBufs * kChunkFloats;              // floats
+constexpr int kDgRecOff = kDgStageOff + 2048;
+constexpr int kDgLdsBytes = (kDgRecOff + 4 * 1024) * 4;
+
+struct DgRec { unsigned recw, recr, ro0, ro1; const float* rbase; };
+__device__ __forceinline__ DgRec dg_rec_now(const float* block) {
+  extern __shared__ __attribute__((aligned(16))) float lds_base[];
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
+  const unsigned lane = (unsigned)tid & 63u, j = (unsigned)tid & 31u, hh = ((unsigned)tid >> 5) & 1u;
+  const unsigned wave = (unsigned)__builtin_amdgcn_readfirstlane(tid >> 6);
+  const unsigned stg = (unsigned)(uintptr_t)AS3(lds_base) + (unsigned)kDgRecOff * 4u + wave * 1024u;
+  DgRec c;
+  c.recw = stg + ((4u * hh) * 32u + j) * 4u;
+  c.recr = stg + lane * 16u;
+  c.ro0 = (unsigned)blk_off(0 + (int)(lane >> 3), (int)(lane & 7u) * 4) * 4u;
+  c.ro1 = (unsigned)blk_off(8 + (int)(lane >> 3), (int)(lane & 7u) * 4) * 4u;
+  const uint64_t b = (uint64_t)(uintptr_t)block;
+  c.rbase = reinterpret_cast<const float*>((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b) |
+                                           ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b >> 32)) << 32));
+  return c;
+}
+__device__ __forceinline__ AsmCtx dg_ctx_now(const float* packed_t) {
+  extern __shared__ __attribute__((aligned(16))) float lds_base[];
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
+  const unsigned lane = (unsigned)tid & 63u;
+  const unsigned wave = (unsigned)__builtin_amdgcn_readfirstlane(tid >> 6);
+  AsmCtx c;
+  const unsigned lds0 = (unsigned)(uintptr_t)AS3(lds_base);
+  c.lane16 = lds0 + lane * 16u;
+  c.laneoff = lane * 16u;
+  c.ldswave = lds0 + wave * 8192u;
+  const uint64_t sw = (uint64_t)(uintptr_t)(packed_t + wave * 2048);
+  c.stream_lo = (unsigned)sw;
+  c.stream_hi = (unsigned)(sw >> 32);
+  c.bias0 = 0;
+  c.stage0 = lds0 + (unsigned)kDgStageOff * 4u + (unsigned)tid * 16u;
+  return c;
+}
+#define TP_DG_INPUTS(m, isc, r)                                                                                        \
+  [g0] "v"(m[0]), [g1] "v"(m[1]), [g2] "v"(m[2]), [g3] "v"(m[3]), [isc] "v"(isc), [recw] "v"(r.recw), [recr] "v"(r.recr), \
+      [ro0] "v"(r.ro0), [ro1] "v"(r.ro1), [rbase] "s"(r.rbase)
+
+__device__ __forceinline__ void asm_dg_narrow(Pipe& p, Frag& f, const AsmCtx& c) {
+  TP_RING_LOCALS;
+  const unsigned stage = c.stage0;
+  asm volatile(TP_ASM_DG_NARROW_P : TP_RING(f), TP_RING_STATE : TP_RING_INPUTS(c), [stage] "v"(stage)
+               : TP_ASM_CLOBBERS, "memory", "scc");
+  TP_RING_DONE;
+}
+template <bool SRC_P>
+__device__ __forceinline__ void asm_dg_wide(Pipe& p, Frag& f, const AsmCtx& c, const uint32_t (&m)[4], float isc, float& dzm,
+                                            const DgRec& r) {
+  TP_RING_LOCALS;
+  const float kinv = kInvScale;
+  const unsigned mask = 0xFFFFE000u;
+  if constexpr (SRC_P)
+    asm volatile(TP_ASM_DG_WIDE_PQ : TP_RING(f), TP_RING_STATE, [dzm] "+v"(dzm)
+                 : TP_RING_INPUTS(c), [kinv] "s"(kinv), [mask] "s"(mask), TP_DG_INPUTS(m, isc, r)
+                 : TP_ASM_CLOBBERS, "s96", "s97", "memory", "scc");
+  else
+    asm volatile(TP_ASM_DG_WIDE_QP : TP_RING(f), TP_RING_STATE, [dzm] "+v"(dzm)
+                 : TP_RING_INPUTS(c), [kinv] "s"(kinv), [mask] "s"(mask), TP_DG_INPUTS(m, isc, r)
+                 : TP_ASM_CLOBBERS, "s96", "s97", "memory", "scc");
+  TP_RING_DONE;
+}
+__device__ __forceinline__ void asm_dg_finish(const uint32_t (&m)[4], float isc, float& dzm, const DgRec& r) {
+  const float kinv = kInvScale;
+  asm volatile(TP_ASM_DG_FINISH_P : [dzm] "+v"(dzm) : [kinv] "s"(kinv), TP_DG_INPUTS(m, isc, r)
+               : TP_ASM_CLOBBERS, "s96", "s97", "memory", "scc");
+}
+
+__global__ __launch_bounds__(kThreads, 1) void mlp_dgrad_f16x3_asm_kernel(DgP P) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31, hh = lane >> 5;
+  Pipe p;
+  p.stream = P.packed_t; p.lds = lds; p.chunk = 0; p.buf = 0; p.wave = wave; p.lane = lane;
+  dma_chunk(p, 0, 0);
+  dma_chunk(p, 1, 1);
+  __syncthreads();
+  Frag frag;
+  frag_prime(p, frag);
+  float dzm = 0.0f;
+
+  for (int64_t tile = blockIdx.x; tile < P.n_tiles; tile += gridDim.x) {
+    const int64_t s_raw = tile * 128 + wave * 32 + j;
+    const bool live = s_raw < P.n_samples;
+    const int64_t s = live ? s_raw : 0;
+    const int64_t gidx = tile * 4 + wave;
+    const float* sv = P.saved + gidx * (int64_t)kSavedGroupFloats;
+    float* dzg = P.dz + gidx * (int64_t)kDzGroupFloats;
+    const auto load_mask = [&](int slot, uint32_t (&mask)[4]) {
+      const uint32_t* mk = reinterpret_cast<const uint32_t*>(sv + kMaskOff) + (slot - 1) * 256 + lane;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) mask[w] = mk[w * 64];
+    };
+
+#pragma nounroll
+    for (int head = 0; head < 2; ++head) {
+      // derivative of the output non-linearities (sigmoid: y(1-y); softplus: 1-exp(-y))
+      float d[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (live) {
+        const int sel = head == 0 ? 1 : 0;          // head 0 = transient (last dim 1), head 1 = static rgb
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const float y = P.rgb[s * 6 + c * 2 + sel];
+          d[c] = P.g_rgb[s * 6 + c * 2 + sel] * y * (1.0f - y);
+        }
+        if (head == 0) {
+          d[3] = P.g_density[s * 2 + 1] * (1.0f - expf(-P.density[s * 2 + 1]));
+          d[4] = P.g_uncert[s] * (1.0f - expf(-P.uncert[s]));
+        }
+      }
+      float* nb = dzg + (head == 0 ? kDzT3Off : kDzR3Off);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) nb[blk_off(r + 16 * hh, j)] = (hh == 0 && r < 6) ? d[r < 6 ? r : 0] : 0.0f;
+      // per-sample power-of-two scale: largest |d| -> [2^5, 2^6)
+      float dmax = 0.0f;
+#pragma unroll
+      for (int c = 0; c < 6; ++c) dmax = fmaxf(dmax, fabsf(d[c]));
+      float sc = 1.0f, isc = 1.0f;
+      if (dmax > 1.0e-30f && dmax < 1.0e30f) {
+        int e;
+        (void)frexpf(dmax, &e);
+        sc = ldexpf(1.0f, 6 - e);
+        isc = ldexpf(1.0f, e - 6);
+      }
+      const float isc_live = live ? isc : 0.0f;      // samples past the end record zeros
+      // B operand of the narrow chunk: slots 8 h + j of k-step 0 = d[0..5] (lane half 0), zeros elsewhere -> this lane's
+      // 16 + 16 bytes of the stage (lane-private: no barrier)
+      {
+        half2v hp[4], lp[4];
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+          const float v0 = (hh == 0 && e < 6) ? d[e < 6 ? e : 0] * sc : 0.0f;
+          const float v1 = (hh == 0 && e + 1 < 6) ? d[e + 1 < 6 ? e + 1 : 0] * sc : 0.0f;
+          const float h0 = __uint_as_float(__float_as_uint(v0) & 0xFFFFE000u);
+          const float h1 = __uint_as_float(__float_as_uint(v1) & 0xFFFFE000u);
+          hp[e >> 1] = __builtin_amdgcn_cvt_pkrtz(h0, h1);
+          lp[e >> 1] = __builtin_amdgcn_cvt_pkrtz(v0 - h0, v1 - h1);
+        }
+        _Float16* stg = reinterpret_cast<_Float16*>(lds + kDgStageOff);
+        *reinterpret_cast<half8*>(stg + tid * 8) = pack8(hp);
+        *reinterpret_cast<half8*>(stg + 2048 + tid * 8) = pack8(lp);
+      }
+      const int slot0 = head == 0 ? SV_T2 : SV_R2;
+      uint32_t m0[4], m1[4], m2[4];
+      load_mask(slot0, m0);
+      load_mask(slot0 - 1, m1);
+      load_mask(slot0 - 2, m2);
+      asm volatile("" ::: "memory");
+      asm_dg_narrow(p, frag, dg_ctx_now(P.packed_t));
+      asm_dg_wide<true>(p, frag, dg_ctx_now(P.packed_t), m0, isc_live, dzm, dg_rec_now(dzg + (head * 3 + 0) * kBlockFloats));
+      asm_dg_wide<false>(p, frag, dg_ctx_now(P.packed_t), m1, isc_live, dzm, dg_rec_now(dzg + (head * 3 + 1) * kBlockFloats));
+      asm_dg_finish(m2, isc_live, dzm, dg_rec_now(dzg + (head * 3 + 2) * kBlockFloats));
+      asm volatile("" ::: "memory");
+    }
+  }
+  for (int off = 32; off >= 1; off >>= 1) dzm = fmaxf(dzm, __shfl_xor(dzm, off, 64));
+  if (lane == 0 && P.dz_max != nullptr && dzm == dzm && dzm < 3.0e38f) atomicMax(P.dz_max, __float_as_uint(dzm));
+}
+
 }  // namespace
 
 // launched by tp_mlp_bwd (mlp_bwd.hip) when args->wgrad_precision == TP_MLP_F16X3
@@ -1116,13 +1290,18 @@ int tp_launch_mlp_dgrad_f16x3(const tp_mlp_bwd_args* a, float* dz, unsigned int*
   static unsigned long long attr_devices = 0;
   if (tp::first_use_on_device(attr_devices)) {
     hipError_t e = hipFuncSetAttribute((const void*)mlp_dgrad_f16x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kDgLds);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void*)mlp_dgrad_f16x3_asm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kDgLdsBytes);
     if (e != hipSuccess) { tp::set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
   }
   DgP D;
   D.packed_t = (const float*)a->packed_t; D.saved = a->saved; D.rgb = a->rgb; D.density = a->density; D.uncert = a->uncert;
   D.g_rgb = a->g_rgb; D.g_density = a->g_density; D.g_uncert = a->g_uncert;
   D.n_samples = (int64_t)a->B * a->R * a->N; D.n_tiles = (D.n_samples + 127) / 128; D.dz = dz; D.dz_max = dz_max;
-  hipLaunchKernelGGL(mlp_dgrad_f16x3_kernel, dim3(grid), dim3(kThreads), kDgLds, stream, D);
+  // TP_DGRAD_CXX=1 (read once): the compiled layer body of round 2, kept for same-device A/B runs
+  static const bool use_cxx = [] { const char* e = getenv("TP_DGRAD_CXX"); return e != nullptr && e[0] == '1'; }();
+  if (use_cxx) hipLaunchKernelGGL(mlp_dgrad_f16x3_kernel, dim3(grid), dim3(kThreads), kDgLds, stream, D);
+  else hipLaunchKernelGGL(mlp_dgrad_f16x3_asm_kernel, dim3(grid), dim3(kThreads), kDgLdsBytes, stream, D);
   return tp::check_launch("tp_mlp_bwd(dgrad f16x3)");
 }
 

@@ -8,8 +8,8 @@ import os
 import subprocess
 import sys
 
-libs = [a for a in sys.argv[1:] if not a.startswith("--")]
 rounds = int(sys.argv[sys.argv.index("--rounds") + 1]) if "--rounds" in sys.argv else 2
+libs = [a for i, a in enumerate(sys.argv[1:], 1) if not a.startswith("--") and sys.argv[i - 1] != "--rounds"]
 here = os.path.dirname(os.path.abspath(__file__))
 cases = (("nerf_b32", ["32", "0", "60", "1", "f16x3"]), ("nerf_b4", ["4", "0", "200", "1", "f16x3"]), ("gan_b4", ["4", "1", "200", "1", "f16x3"]))
 res = {(l, c): [] for l in libs for c, _ in cases}
