@@ -318,12 +318,20 @@ def train_leg(device, rank, world):
     # losses, all backward passes), two eager stream-ordered collectives, replay B (optimiser steps) -- collectives inside a
     # replayed hipGraph have only ever run in a 1-rank group here (TP_COLLECTIVES_IN_GRAPH=1 opts in).
     graphed = os.environ.get("TP_BENCH_TRAIN_EAGER", "0") != "1"
+    full, err = None, None
     try:
         full = train_dp.measure(device, rank, world, global_batch=4 * world, iters=40, warm=4, graphed=graphed, full=True)
-    except Exception as exc:                       # (e.g. a collective that cannot be captured on this stack): eager loop
+    except Exception as exc:                       # (e.g. a collective that cannot be captured on this stack)
         if not graphed:
             raise
-        out["graph_capture_error"] = repr(exc)[:300]
+        err = exc
+    # the fallback to the eager loop is a JOB-wide decision: a rank retrying alone would sit in collectives its peers never
+    # issue (they are still in the captured loop), so the ranks agree on "somebody failed" first
+    failed = torch.tensor([0 if err is None else 1], device=device, dtype=torch.int32)
+    if world > 1:
+        torch.distributed.all_reduce(failed, op=torch.distributed.ReduceOp.MAX)
+    if int(failed):
+        out["graph_capture_error"] = repr(err)[:300] if err is not None else "another rank failed to capture the step"
         torch.cuda.synchronize()
         full = train_dp.measure(device, rank, world, global_batch=4 * world, iters=40, warm=4, graphed=False, full=True)
     out["full_gan_loop"] = {k: full[k] for k in ("value", "ms_per_iter", "global_batch", "per_gpu_batch", "launch",

@@ -37,7 +37,6 @@ NCH = 115
 # timing experiments only (results are WRONG): TP_ASM_EXPERIMENT = nodma | nobarrier | noconv | recnostore (recording
 # blocks issue no vector stores) | recnolds (no staging-tile writes / reads either)
 EXPERIMENT = os.environ.get("TP_ASM_EXPERIMENT", "")
-LATE = "late" in EXPERIMENT     # (under test) record stores behind the chunk's last DMA piece
 
 VB = 160
 def F_hi(slot): return VB + 8 * slot
@@ -145,7 +144,7 @@ def rec_store(set_base, tile, k):
     # units 2, 3 sit 16 rows (2 KB) behind units 0, 1 with the same swizzle: two offset registers, an immediate for the rest
     if EXPERIMENT in ("recnostore", "recnolds"):
         return "s_nop 0"
-    policy = {"recplain": "", "recsc1": " sc1", "recsc01": " sc0 sc1"}.get(EXPERIMENT.replace("early", ""), " nt")
+    policy = {"recplain": "", "recsc1": " sc1", "recsc01": " sc0 sc1"}.get(EXPERIMENT, " nt")
     return "global_store_dwordx4 %%[ro%d], %s, s[%d:%d] offset:%d%s" % (k & 1, tile_regs(set_base, tile, k), RB, RB + 1, (k >> 1) * 2048, policy)
 
 
@@ -324,21 +323,14 @@ def gen_wide(src, dst, rec=None):
                 #                reads are issued BEFORE the group's ring refills, so the waits' counts are unchanged;
                 #                even chunks: the mask word of tiles ts, ts + 1, complete with this group's last v_addc (it
                 #                is issued after the publish point: the NEXT chunk counts it)
+                # (placement of the four stores -- one per group, all in group 1, or behind the chunk's last DMA piece so that
+                # the next publish does not wait for them -- made no difference on one device; nor did plain / sc1 instead of
+                # nt stores, which were slower: profiles/r3.  What the stores cost is CLOCK, not issue cycles: 16 KB of HBM
+                # writes per chunk and CU lower the clock of the MFMA loop by ~8 %, tools/ubench/store_cost.hip)
                 first, mid1, mid2, mid3, last = [], [], [], [], []
-                if LATE:
-                    # the four stores of tile ts in group 7, AFTER the chunk's last DMA piece: the publish of the next chunk
-                    # (which waits for that piece and everything older) then does not wait for them -- they get two chunks to
-                    # retire instead of one (vmcnt retires in issue order; a 16-byte nontemporal store takes > 1 us)
-                    if g == 7:
-                        st = [rec_store(src, ts, k) for k in range(4)]
-                        first, mid1, mid2, mid3 = [st[0]], [st[1]], [st[2]], [st[3]]
-                        last = rec_advance()
-                elif "early" in EXPERIMENT:
-                    if g == 1:
-                        first = [rec_store(src, ts, k) for k in range(4)]
-                elif 1 <= g <= 4:
+                if 1 <= g <= 4:
                     first = [rec_store(src, ts, g - 1)]
-                if g == 5 and not LATE:
+                if g == 5:
                     first = rec_advance()
                 if g == 7 and ts < 7:
                     rd = rec_reads(src, ts + 1)
@@ -370,21 +362,16 @@ def gen_wide(src, dst, rec=None):
                     out.append(advance_dch()[g - 1])
                 if g == 7:
                     out += dma_base()
-            if rec and LATE and g == 7:        # re-seed tile ts behind its stores
-                out += ["ds_read_b128 a[%d:%d], %%[nbias] offset:%d" % (src + 16 * ts + 4 * k, src + 16 * ts + 4 * k + 3, ts * 64 + k * 16)
-                        for k in range(4)]
             return out
 
         def head(g, ts=ts):
-            if g != ((-1 if LATE else 6) if rec else 0):
+            if g != (6 if rec else 0):
                 return []
             return ["ds_read_b128 a[%d:%d], %%[nbias] offset:%d" % (src + 16 * ts + 4 * k, src + 16 * ts + 4 * k + 3, ts * 64 + k * 16)
                     for k in range(4)]
 
         extra = 0
-        if rec and LATE:   # the previous chunk's four tile stores and (odd chunks) mask word, all issued behind ITS last DMA piece
-            extra = 0 if ts == 0 else 4 + (1 if (ts & 1) and rec == "mask" else 0)
-        elif rec:      # this chunk's four tile stores + the mask word the previous (even) chunk stored after ITS publish point
+        if rec:        # this chunk's four tile stores + the mask word the previous (even) chunk stored after ITS publish point
             extra = 4 + (1 if (ts & 1) and rec == "mask" else 0)
         chunk_groups(e, 16, ts, mf, fill, (5, 6), 1, tail, head, young_extra=extra)
     ring_epilogue(e, 8)
@@ -586,12 +573,7 @@ def gen_dg_wide(src, dst):
 
         def fill(g, ts=ts, bank=bank):
             first, mid1, mid2, mid3, last = [], [], [], [], []
-            if LATE:
-                if g == 7:
-                    st = [rec_store(src, ts, k) for k in range(4)]
-                    first, mid1, mid2, mid3 = [st[0]], [st[1]], [st[2]], [st[3]]
-                    last = rec_advance()
-            elif 1 <= g <= 4:
+            if 1 <= g <= 4:
                 first = [rec_store(src, ts, g - 1)]
             elif g == 5:
                 first = rec_advance()
@@ -612,7 +594,7 @@ def gen_dg_wide(src, dst):
                     out += dma_base()
             return out
 
-        chunk_groups(e, 16, ts, mf, fill, (5, 6), 1, tail, None, young_extra=(0 if ts == 0 else 4) if LATE else 4)
+        chunk_groups(e, 16, ts, mf, fill, (5, 6), 1, tail, None, young_extra=4)
     ring_epilogue(e, 8)
     return L
 
