@@ -1,17 +1,26 @@
 #!/bin/bash
-# GPU box: final collection of the round (all from one box and call): bench line, bench under rocprof + PMC of the forward, training kernel stats, training PMC, launch histogram
-T=r5
+# GPU box: final collection of the round, all from ONE box and call (boxes of the pool differ by several %):
+#   bench line; bench under rocprofv3 --kernel-trace --stats + PMC of the eval forward (profile_mlp.sh); B=32 training kernel
+#   stats; training PMC (pmc_train.sh); HBM-bound kernels: stats + PMC (pmc_hbm.sh); launch histogram + ordered launches of a
+#   replayed B=4 GAN iteration; training lines; C5 multi-object line.          Usage: tools/collect_round.sh [tag]
+T=${1:-r3}
 mkdir -p gpurun_out/$T
 export TMPDIR=/tmp
-timeout 900 python bench.py > gpurun_out/$T/bench_full.json 2> gpurun_out/$T/bench_full.err
+( time timeout 1500 python bench.py > gpurun_out/$T/bench_full.json 2> gpurun_out/$T/bench_full.err ) 2> gpurun_out/$T/bench_wall.txt
 bash tools/profile_mlp.sh $T > gpurun_out/$T/profile_mlp.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$T/train32 -o t -- python3 tools/train_bench.py 32 0 30 0 f16x3 > gpurun_out/$T/train32.log 2>&1
+cp $(find gpurun_out/$T/train32 -name '*kernel_stats.csv' | head -1) gpurun_out/$T/train32_kernel_stats.csv
 bash tools/pmc_train.sh $T > gpurun_out/$T/pmc_train.log 2>&1
+bash tools/pmc_hbm.sh $T > gpurun_out/$T/pmc_hbm.log 2>&1
 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/$T/gan4 -o t -- python3 tools/train_bench.py 4 1 12 1 f16x3 > gpurun_out/$T/gan4.log 2>&1
 python3 tools/launch_histogram.py gpurun_out/$T/gan4 > gpurun_out/$T/launch_histogram.txt 2>&1
+python3 tools/launch_sequence.py gpurun_out/$T/gan4 > gpurun_out/$T/launch_sequence.txt 2>&1
 for i in 1 2; do python3 tools/train_bench.py 4 1 200 1 f16x3 2>&1 | tail -1; python3 tools/train_bench.py 4 0 200 1 f16x3 2>&1 | tail -1; python3 tools/train_bench.py 32 0 60 1 f16x3 2>&1 | tail -1; done > gpurun_out/$T/train_lines.txt
+timeout 600 python bench.py --config c5 > gpurun_out/$T/c5.json 2> gpurun_out/$T/c5.err
 python3 tools/kstats.py gpurun_out/$T/train32 wgrad dgrad mlp_fwd finalize
+rm -rf gpurun_out/$T/train32 gpurun_out/$T/gan4
 cat gpurun_out/$T/train_lines.txt | cut -c1-100
+cat gpurun_out/$T/bench_wall.txt
 python3 - <<PY
 import json
 d=json.load(open("gpurun_out/$T/bench_full.json"))
