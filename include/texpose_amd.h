@@ -26,7 +26,7 @@ extern "C" {
 
 typedef void* tp_stream_t; /* hipStream_t */
 
-#define TP_ABI_VERSION 6
+#define TP_ABI_VERSION 7
 
 int tp_abi_version(void);
 const char* tp_last_error(void);
@@ -288,6 +288,7 @@ typedef struct tp_sn_weight {
   float* u_out;            /* fwd, optional: copy of u [rows] as it stands AFTER this call's power iteration (the backward of
                               THIS forward needs it; later forwards of the iteration advance u / v in place) */
   float* v_out;            /* fwd, optional: copy of v [cols] likewise */
+  int32_t accumulate;      /* bwd: grad += (the second normalised instance of the same weight in one optimiser step) */
 } tp_sn_weight;
 int64_t tp_sn_work_floats(int rows, int cols);
 int tp_sn_fwd(const tp_sn_weight* weights, int n, int training, tp_stream_t stream);
@@ -321,8 +322,9 @@ int tp_nerf_losses_bwd(const tp_nerf_losses_args* args, const float* g_losses /*
  * ------------------------------------------------------------------------------------------ */
 int tp_inorm_lrelu_fwd(const float* x, int64_t n_inst, int hw, float eps, float slope, float* y, float* xhat, float* rstd,
                        tp_stream_t stream);
+/* addend (optional, [n_inst, hw]): a second cotangent of x that is added to the result (the R1 path's, K16) */
 int tp_inorm_lrelu_bwd(const float* xhat, const float* rstd, const float* gy, int64_t n_inst, int hw, float slope,
-                       float* gx, tp_stream_t stream);
+                       const float* addend, float* gx, tp_stream_t stream);
 /* cotangent ggx of gx -> gradients wrt gy and wrt x (through xhat and rstd) */
 int tp_inorm_lrelu_bwd_bwd(const float* xhat, const float* rstd, const float* gy, const float* ggx, int64_t n_inst, int hw,
                            float slope, float* g_gy, float* g_x, tp_stream_t stream);
@@ -456,6 +458,13 @@ int tp_feat_pair_loss_bwd(const float* feat, int64_t n, float w2, const float* g
  * for g [B,m] (n = B m floats); backward out [n] = 2 g cot[0] / B. */
 int tp_sumsq_mean_fwd(const float* g, int64_t n, int B, float* out, tp_stream_t stream);
 int tp_sumsq_mean_bwd(const float* g, int64_t n, int B, const float* cot, float* out, tp_stream_t stream);
+/* K16 (the discriminator step as an explicit schedule): value and weighted gradient of the R1 penalty in one launch,
+ * out[0] = sum(g^2) / B, out_g [n] = 2 w g / B (w = the term's loss weight, a host constant);
+ * and both GAN-loss terms of the discriminator step (model/nerf_adapt_st_gan.py:139-160) with their weighted cotangents:
+ * out2 = {bce(d_real, 1), bce(d_fake, 0)}, g_real [n] = w_real (sigmoid(d_real) - 1) / n, g_fake [n] = w_fake sigmoid(d_fake) / n. */
+int tp_sumsq_mean_fwd_bwd(const float* g, int64_t n, int B, float w, float* out, float* out_g, tp_stream_t stream);
+int tp_gan_disc_losses(const float* d_real, const float* d_fake, int n, float w_real, float w_fake, float* out2, float* g_real,
+                       float* g_fake, tp_stream_t stream);
 /* Rows idx[b] of the two latent tables (model/nerf_adapt_st_gan.py:589-593) in one launch, and the dense table gradients
  * gw [n_rows,C] = sum over b with idx[b] == r of g[b] (ascending b; every element written: no zero-fill needed). */
 /* out[0] = sum_k weights[k] * terms[k][0] (ascending k) for up to 16 scalar device tensors; `terms` and `weights` are HOST
@@ -484,9 +493,10 @@ typedef struct tp_disc_head_args {
   float* t0; float* t1; float* t2;   /* fwd: written; bwd, bwd_bwd: read */
   float* e1; float* e2;              /* bwd: written; bwd_bwd: read */
   float* out;              /* fwd: [B];  bwd: gz [B,C];  bwd_bwd: d/d g_out [B] */
-  float* gW1; float* gW2; float* gW3;   /* bwd, bwd_bwd: [H,Cin], [H,H], [H] */
+  float* gW1; float* gW2; float* gW3;   /* bwd, bwd_bwd: [H,Cin], [H,H], [H]; bwd: all three NULL = data gradient only */
   int32_t B, C, L, H;
   float slope;
+  int32_t accumulate_gw;   /* bwd: gW1..3 += (after the double backward wrote its share there) */
 } tp_disc_head_args;
 int tp_disc_head_fwd(const tp_disc_head_args* args, tp_stream_t stream);
 int tp_disc_head_bwd(const tp_disc_head_args* args, tp_stream_t stream);

@@ -1534,6 +1534,67 @@ def test_discriminator_with_native_convs_matches_stock(ops, patch):
         assert rel_l2(a, b) < 2e-4, (i, rel_l2(a, b))
 
 
+@pytest.mark.parametrize("patch,B,with_r1", [(16, 4, True), (16, 3, False), (32, 2, True)])
+def test_disc_step_schedule_matches_autograd_form(ops, patch, B, with_r1, monkeypatch):
+    """K16 (texpose_amd/disc_step.py): the discriminator step as an explicit launch schedule against the autograd form of the
+    same step (GanTrainer.disc_step under TP_DISC_AUTOGRAD=1) on identical weights / power-iteration vectors / patches: the
+    same losses, the same gradient for every weight (two-term sums in another order: 2e-6 relative), the same u / v
+    afterwards, and the same parameters after the RMSprop step."""
+    import copy
+    from texpose_amd.gan_modules import Discriminator
+    from texpose_amd.graph import Graph
+    from texpose_amd.options import default_options, AttrDict
+    from texpose_amd.trainer import GanTrainer
+    torch.manual_seed(11 + patch + B)
+    opt = default_options(H=128, W=128, device="cuda:0")
+    opt.batch_size, opt.patch_size, opt.nerf.sample_intvs = B, patch, 8
+    opt.loss_weight.feat = None
+    if not with_r1:
+        opt.loss_weight.gan_reg_real = None
+    g_a = Graph(opt, discriminator=Discriminator(opt)).to(dev())
+    g_a.attach_latents(5, opt)
+    g_a.train()
+    g_b = copy.deepcopy(g_a)
+    from texpose_amd.synthetic import training_batch
+    batch = training_batch(B, 128, 128, n_train=5, seed=4, device="cuda:0")
+    batch["jitter_rand"] = torch.rand(B, patch * patch, 8, 1, device=dev())     # (the Philox offset is a process-wide counter)
+    out = []
+    for graph, autograd_form in ((g_a, True), (g_b, False)):
+        if autograd_form:
+            monkeypatch.setenv("TP_DISC_AUTOGRAD", "1")
+        else:
+            monkeypatch.delenv("TP_DISC_AUTOGRAD", raising=False)
+        tr = GanTrainer(opt, graph, n_train=5)
+        torch.manual_seed(3)                                   # the same patch draws / jitter for both copies
+        var = graph.get_ray_idx(opt, AttrDict(dict(batch)))
+        var, _ = tr.nerf_forward_loss(var)                     # render, gathers, the nerf step's D(fake) (its power iteration)
+        var, loss = tr.disc_step(var, apply=False)
+        if not autograd_form:
+            assert tr._disc_sched is not None and tr._disc_sched.reason is None, tr._disc_sched.reason
+            assert tr._disc_sched.eligible(opt, var.patch_real)
+        grads = {k: p.grad.detach().clone() for k, p in graph.discriminator.named_parameters() if p.grad is not None}
+        tr.disc_apply(tr._disc_total)
+        torch.cuda.synchronize()
+        out.append((loss, grads, {k: v.detach().clone() for k, v in graph.discriminator.state_dict().items()}, tr._disc_total))
+    (loss_a, grads_a, state_a, tot_a), (loss_b, grads_b, state_b, tot_b) = out
+    assert set(loss_a.keys()) - {"all"} == set(loss_b.keys()) - {"all"} and ("gan_reg_real" in loss_b) == with_r1
+    for k in loss_b:
+        if k != "all":
+            torch.testing.assert_close(loss_b[k].reshape(()), loss_a[k].reshape(()), rtol=2e-6, atol=0)
+    torch.testing.assert_close(tot_b.reshape(()), tot_a.reshape(()), rtol=2e-6, atol=0)
+    assert set(grads_a) == set(grads_b) and len(grads_b) == (6 if patch == 16 else 7)
+    for k in grads_a:
+        assert grads_a[k].shape == grads_b[k].shape
+        assert rel_l2(grads_b[k], grads_a[k]) < 2e-6, (k, rel_l2(grads_b[k], grads_a[k]))
+    for k in state_a:
+        if k.endswith(("weight_u", "weight_v")):
+            assert torch.equal(state_a[k], state_b[k]), k
+        else:
+            # (RMSprop's first step is lr g / (0.1 |g| + eps): a sign function of entries near zero, so a few entries move by a
+            # different amount; the parameters as a whole agree)
+            assert rel_l2(state_b[k], state_a[k]) < 2e-6, (k, rel_l2(state_b[k], state_a[k]))
+
+
 # ------------------------------------------------------------------------------------------ K12
 @pytest.mark.parametrize("shape", [(16, 3, 16, 16, 64), (16, 64, 16, 16, 64), (16, 128, 8, 8, 128), (16, 256, 4, 4, 256),
                                    (3, 5, 4, 8, 33), (64, 64, 8, 8, 128)])
@@ -1880,7 +1941,8 @@ def test_round3_glue_kernels_match_torch(ops):
     rgb = cu(torch.from_numpy(rs.uniform(size=(B, p * p, 3)).astype(np.float32))).requires_grad_()
     gathered = cu(torch.from_numpy(rs.uniform(size=(B, 14, p, p)).astype(np.float32)))
     gathered[:, 12:] = (gathered[:, 12:] > 0.5).float()
-    real, fake = autograd_ops.disc_patches(rgb, gathered, (p, p), True)
+    real, fake, stack = autograd_ops.disc_patches(rgb, gathered, (p, p), True)
+    assert stack.shape[0] == 2 * real.shape[0] and stack.data_ptr() == real.data_ptr()
     r2, f2 = ops.disc_inputs(rgb.detach(), gathered, (p, p), True)
     assert torch.equal(real, r2) and torch.equal(fake, f2) and not real.requires_grad
     ref_fake = torch.cat([rgb.detach().view(B, p, p, 3).permute(0, 3, 1, 2), gathered[:, 6:12]], 1)

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # TEXPOSE_AMD_LIB selects another build of the SAME library (e.g. the `make trace` diagnostic build); never a fallback
 LIB_PATH = os.environ.get("TEXPOSE_AMD_LIB") or os.path.join(_HERE, "libtexpose_amd.so")
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 # Every symbol include/texpose_amd.h declares (checked by tests/test_capi_cpu.py).
 SYMBOLS = (
@@ -31,7 +31,7 @@ SYMBOLS = (
     "tp_conv4s2_workspace", "tp_conv4s2_fwd", "tp_conv4s2_dgrad", "tp_conv4s2_wgrad",
     "tp_conv3s1_workspace", "tp_conv3s1_fwd", "tp_conv3s1_dgrad",
     "tp_patch_coords", "tp_bce_logits_fwd", "tp_bce_logits_bwd", "tp_feat_inputs_fwd", "tp_feat_inputs_bwd", "tp_disc_inputs", "tp_step_flags", "tp_adam_step",
-    "tp_fake_patch_bwd", "tp_feat_pair_loss_fwd", "tp_feat_pair_loss_bwd", "tp_sumsq_mean_fwd", "tp_sumsq_mean_bwd", "tp_latent_rows_fwd",
+    "tp_fake_patch_bwd", "tp_feat_pair_loss_fwd", "tp_feat_pair_loss_bwd", "tp_sumsq_mean_fwd", "tp_sumsq_mean_bwd", "tp_sumsq_mean_fwd_bwd", "tp_gan_disc_losses", "tp_latent_rows_fwd",
     "tp_latent_rows_bwd", "tp_weighted_sum",
     "tp_disc_head_fwd", "tp_disc_head_bwd", "tp_disc_head_bwd_bwd",
     "tp_skinny_linear_fwd", "tp_skinny_linear_wgrad",
@@ -96,7 +96,7 @@ class EvalMetricsArgs(C.Structure):
 
 class SnWeight(C.Structure):
     _fields_ = [("weight", vp), ("u", vp), ("v", vp), ("weight_sn", vp), ("sigma", vp), ("grad_sn", vp), ("grad", vp),
-                ("work", vp), ("rows", C.c_int), ("cols", C.c_int), ("u_out", vp), ("v_out", vp)]
+                ("work", vp), ("rows", C.c_int), ("cols", C.c_int), ("u_out", vp), ("v_out", vp), ("accumulate", C.c_int32)]
 
 
 SN_MAX_WEIGHTS = 8
@@ -119,7 +119,8 @@ CONV_FWD, CONV_DGRAD, CONV_WGRAD = 0, 1, 2
 
 class DiscHeadArgs(C.Structure):
     _fields_ = [(k, vp) for k in ("z", "scale", "W1", "W2", "W3", "g_out", "c_gz", "t0", "t1", "t2", "e1", "e2", "out", "gW1", "gW2",
-                                  "gW3")] + [("B", C.c_int32), ("C", C.c_int32), ("L", C.c_int32), ("H", C.c_int32), ("slope", C.c_float)]
+                                  "gW3")] + [("B", C.c_int32), ("C", C.c_int32), ("L", C.c_int32), ("H", C.c_int32), ("slope", C.c_float),
+                                                 ("accumulate_gw", C.c_int32)]
 
 
 class FeatInputsArgs(C.Structure):
@@ -206,7 +207,7 @@ def load() -> C.CDLL:
     sig("tp_render_eval_workspace_bytes", [C.c_int, C.c_int, C.c_int], C.c_size_t)
     sig("tp_render_eval", [C.POINTER(RenderEvalArgs), vp])
     sig("tp_inorm_lrelu_fwd", [vp, C.c_int64, C.c_int, C.c_float, C.c_float, vp, vp, vp, vp])
-    sig("tp_inorm_lrelu_bwd", [vp, vp, vp, C.c_int64, C.c_int, C.c_float, vp, vp])
+    sig("tp_inorm_lrelu_bwd", [vp, vp, vp, C.c_int64, C.c_int, C.c_float, vp, vp, vp])
     sig("tp_inorm_lrelu_bwd_bwd", [vp, vp, vp, vp, C.c_int64, C.c_int, C.c_float, vp, vp, vp])
     sig("tp_rmsprop_step", [C.POINTER(RmspropTensor), C.c_int, vp, C.c_double, C.c_double, C.c_double, vp, C.c_int, vp])
     sig("tp_step_flags", [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp])
@@ -228,6 +229,8 @@ def load() -> C.CDLL:
     sig("tp_feat_pair_loss_bwd", [vp, C.c_int64, C.c_float, vp, vp, vp])
     sig("tp_sumsq_mean_fwd", [vp, C.c_int64, C.c_int, vp, vp])
     sig("tp_sumsq_mean_bwd", [vp, C.c_int64, C.c_int, vp, vp, vp])
+    sig("tp_sumsq_mean_fwd_bwd", [vp, C.c_int64, C.c_int, C.c_float, vp, vp, vp])
+    sig("tp_gan_disc_losses", [vp, vp, C.c_int, C.c_float, C.c_float, vp, vp, vp, vp])
     sig("tp_weighted_sum", [C.POINTER(vp), C.POINTER(C.c_float), C.c_int, vp, vp])
     sig("tp_latent_rows_fwd", [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp])
     sig("tp_latent_rows_bwd", [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp])

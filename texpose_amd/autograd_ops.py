@@ -279,7 +279,10 @@ class _DiscHeadBackward(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, g_out, t0, t1, t2, W1, W2, W3, C_z, L, slope):
-        gz, gW1, gW2, gW3, e1, e2 = ops.disc_head_bwd(g_out, t0, t1, t2, W1, W2, W3, C_z, L, slope)
+        # weight gradients only when somebody takes them (not for the frozen discriminator of the generator step, not in the R1
+        # penalty's first pass): a third of this launch
+        want_w = any(ctx.needs_input_grad[4:7]) and not SKIP_WEIGHT_GRADS
+        gz, gW1, gW2, gW3, e1, e2 = ops.disc_head_bwd(g_out, t0, t1, t2, W1, W2, W3, C_z, L, slope, weight_grads=want_w)
         ctx.save_for_backward(g_out, t0, t1, t2, e1, e2, W1, W2, W3)
         ctx.consts = (L, slope)
         ctx.set_materialize_grads(False)
@@ -370,12 +373,13 @@ def skinny_linear(x, w):
 
 # ---- K13 (round 3): the remaining small chains of the GAN step, one launch per direction
 class _DiscPatches(torch.autograd.Function):
-    """(real, fake) [B,nc,h,w] of the PatchGAN from the rendered colours and the gathered patches (tp_disc_inputs).  `fake`
-    carries the gradient back to rgb (the nerf step's D(fake) term), `real` is a constant of the step."""
+    """(real stack, fake) of the PatchGAN from the rendered colours and the gathered patches (tp_disc_inputs).  `fake` [B,nc,h,w]
+    carries the gradient back to rgb (the nerf step's D(fake) term); the real stack [2B,nc,h,w] holds `real` in its first half, a
+    constant of the step (the second half belongs to the discriminator step's schedule, texpose_amd/disc_step.py)."""
 
     @staticmethod
     def forward(ctx, rgb, gathered, hw, geo):
-        real, fake = ops.disc_inputs(rgb, gathered, hw, geo)
+        real, fake = ops.disc_inputs(rgb, gathered, hw, geo, stacked=True)
         ctx.dims = (rgb.shape[0], rgb.shape[1])
         ctx.mark_non_differentiable(real)
         ctx.set_materialize_grads(False)
@@ -390,7 +394,9 @@ class _DiscPatches(torch.autograd.Function):
 
 
 def disc_patches(rgb, gathered, hw, geo: bool):
-    return _DiscPatches.apply(rgb, gathered, tuple(hw), bool(geo))
+    """-> (real [B,nc,h,w], fake [B,nc,h,w], real stack [2B,nc,h,w])."""
+    stack, fake = _DiscPatches.apply(rgb, gathered, tuple(hw), bool(geo))
+    return stack[:rgb.shape[0]], fake, stack
 
 
 class _FeatPairLoss(torch.autograd.Function):

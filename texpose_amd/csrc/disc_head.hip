@@ -32,6 +32,7 @@ struct HeadP {
   float* gW1; float* gW2; float* gW3;  // weight gradients (backward / double backward)
   int B, C, L, H, Cin;
   float slope;
+  int accumulate;        // backward: weight gradients are ADDED to gW1..3 (the double backward's were written there first)
 };
 
 __device__ __forceinline__ float lrelu(float v, float s) { return v > 0.f ? v : v * s; }
@@ -94,12 +95,13 @@ __global__ __launch_bounds__(kT) void head_fwd_kernel(HeadP p) {
 }
 
 // weight gradients: out[i][j] = sum_b u[b][i] v[b][j] (rows H, cols n_col), fixed order over b
-__device__ __forceinline__ void outer_sum(float* out, const float* u, int ldu, const float* v, int ldv, int rows, int cols, int B) {
+__device__ __forceinline__ void outer_sum(float* out, const float* u, int ldu, const float* v, int ldv, int rows, int cols, int B,
+                                          bool accumulate) {
   for (int e = threadIdx.x; e < rows * cols; e += kT) {
     const int i = e / cols, j = e - i * cols;
     float acc = 0.f;
     for (int b = 0; b < B; ++b) acc += u[(size_t)b * ldu + i] * v[(size_t)b * ldv + j];
-    out[e] = acc;
+    out[e] = accumulate ? out[e] + acc : acc;
   }
 }
 
@@ -133,15 +135,17 @@ __global__ __launch_bounds__(kT) void head_bwd_kernel(HeadP p) {
       p.out[(size_t)(b0 + b) * p.C + j] = acc * dl(p.t0[(size_t)(b0 + b) * p.Cin + j], p.slope);
     }
   }
+  if (p.gW1 == nullptr) return;                                   // data gradient only (frozen weights; the R1 penalty's first pass)
   __threadfence_block();
   __syncthreads();
+  const bool add = p.accumulate != 0;
   for (int j = threadIdx.x; j < p.H; j += kT) {
     float acc = 0.f;
     for (int b = 0; b < p.B; ++b) acc += p.g[b] * p.t2[(size_t)b * p.H + j];
-    p.gW3[j] = acc;
+    p.gW3[j] = add ? p.gW3[j] + acc : acc;
   }
-  outer_sum(p.gW2, p.e2, p.H, p.t1, p.H, p.H, p.H, p.B);
-  outer_sum(p.gW1, p.e1, p.H, p.t0, p.Cin, p.H, p.Cin, p.B);
+  outer_sum(p.gW2, p.e2, p.H, p.t1, p.H, p.H, p.H, p.B, add);
+  outer_sum(p.gW1, p.e1, p.H, p.t0, p.Cin, p.H, p.Cin, p.B, add);
 }
 
 __global__ __launch_bounds__(kT) void head_bwd_bwd_kernel(HeadP p) {
@@ -204,7 +208,7 @@ int fill(HeadP* q, const tp_disc_head_args* a, const char* what) {
   q->B = a->B; q->C = a->C; q->L = a->L; q->H = a->H; q->Cin = a->C + 2 * a->L + 1; q->slope = a->slope;
   q->z = a->z; q->scale = a->scale; q->W1 = a->W1; q->W2 = a->W2; q->W3 = a->W3; q->g = a->g_out; q->c = a->c_gz;
   q->t0 = a->t0; q->t1 = a->t1; q->t2 = a->t2; q->e1 = a->e1; q->e2 = a->e2; q->out = a->out;
-  q->gW1 = a->gW1; q->gW2 = a->gW2; q->gW3 = a->gW3;
+  q->gW1 = a->gW1; q->gW2 = a->gW2; q->gW3 = a->gW3; q->accumulate = a->accumulate_gw;
   if (!q->W1 || !q->W2 || !q->W3 || !q->t0 || !q->t1 || !q->t2 || !q->out) { tp::set_error("%s: null pointer", what); return -1; }
   if (lds_bytes(*q) > 150 * 1024) { tp::set_error("%s: head too wide for one workgroup's LDS", what); return -1; }
   return 0;
@@ -235,7 +239,8 @@ int tp_disc_head_bwd(const tp_disc_head_args* a, tp_stream_t stream) {
   static unsigned long long flags = 0;
   HeadP q{};
   if (int rc = fill(&q, a, "tp_disc_head_bwd")) return rc;
-  TP_REQUIRE(q.g && q.e1 && q.e2 && q.gW1 && q.gW2 && q.gW3, "operand missing");
+  TP_REQUIRE(q.g && q.e1 && q.e2, "operand missing");
+  TP_REQUIRE((q.gW1 && q.gW2 && q.gW3) || (!q.gW1 && !q.gW2 && !q.gW3), "gW1..3: all or none");
   return launch(head_bwd_kernel, q, stream, "tp_disc_head_bwd", flags);
 }
 int tp_disc_head_bwd_bwd(const tp_disc_head_args* a, tp_stream_t stream) {

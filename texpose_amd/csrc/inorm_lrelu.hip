@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void inorm_lrelu_fwd_kernel(const float* __res
 
 __global__ __launch_bounds__(256) void inorm_lrelu_bwd_kernel(const float* __restrict__ xhat, const float* __restrict__ rstd,
                                                                const float* __restrict__ gy, int64_t n_inst, int hw, float slope,
-                                                               float* __restrict__ gx) {
+                                                               const float* __restrict__ addend, float* __restrict__ gx) {
   const int lane = threadIdx.x & 63;
   const int64_t inst = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (inst >= n_inst) return;
@@ -60,7 +60,8 @@ __global__ __launch_bounds__(256) void inorm_lrelu_bwd_kernel(const float* __res
   const float ma = wave_sum(sa) / (float)hw, mah = wave_sum(sah) / (float)hw, r = rstd[inst];
   for (int e = lane; e < hw; e += kWave) {
     const float a = g[e] * (h[e] > 0.f ? 1.0f : slope);
-    gx[inst * hw + e] = r * (a - ma - h[e] * mah);
+    const float v = r * (a - ma - h[e] * mah);
+    gx[inst * hw + e] = addend ? v + addend[inst * hw + e] : v;     // (a second cotangent of x: the R1 path's, K16)
   }
 }
 
@@ -101,11 +102,11 @@ extern "C" int tp_inorm_lrelu_fwd(const float* x, int64_t n_inst, int hw, float 
 }
 
 extern "C" int tp_inorm_lrelu_bwd(const float* xhat, const float* rstd, const float* gy, int64_t n_inst, int hw, float slope,
-                                  float* gx, tp_stream_t stream) {
+                                  const float* addend, float* gx, tp_stream_t stream) {
   TP_REQUIRE(xhat && rstd && gy && gx, "null pointer");
   TP_REQUIRE(n_inst > 0 && hw > 0, "bad sizes");
   hipLaunchKernelGGL(inorm_lrelu_bwd_kernel, dim3((unsigned)((n_inst + 3) / 4)), dim3(256), 0, (hipStream_t)stream, xhat, rstd, gy,
-                     n_inst, hw, slope, gx);
+                     n_inst, hw, slope, addend, gx);
   return tp::check_launch("tp_inorm_lrelu_bwd");
 }
 

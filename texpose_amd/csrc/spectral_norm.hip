@@ -151,7 +151,8 @@ __global__ __launch_bounds__(256) void sn_grad_kernel(Batch b) {
   const float sg = *w.sigma;
   for (int64_t i = (int64_t)local * 1024 + threadIdx.x; i < min(n, (int64_t)(local + 1) * 1024); i += 256) {
     const int r = (int)(i / w.cols), c = (int)(i - (int64_t)r * w.cols);
-    w.grad[i] = (w.grad_sn[i] - d * w.u[r] * w.v[c]) / sg;
+    const float gv = (w.grad_sn[i] - d * w.u[r] * w.v[c]) / sg;
+    w.grad[i] = w.accumulate ? w.grad[i] + gv : gv;
   }
 }
 

@@ -241,6 +241,55 @@ __global__ __launch_bounds__(kBlock) void sumsq_mean_bwd_kernel(const float* __r
   if (i < n) out[i] = 2.f * cot[0] / (float)B * g[i];
 }
 
+// ---- the same two in ONE launch for the explicit discriminator-step schedule (K16): every block writes its part of
+// out_g = 2 w g / B, block 0 also reduces the value (same fixed-order tree as above)
+__global__ __launch_bounds__(kRedBlock) void sumsq_mean_fwd_bwd_kernel(const float* __restrict__ g, int64_t n, int B, float w,
+                                                                        float* __restrict__ out, float* __restrict__ out_g) {
+  const float k = 2.f * w / (float)B;
+  for (int64_t i = (int64_t)blockIdx.x * kRedBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kRedBlock) out_g[i] = k * g[i];
+  if (blockIdx.x != 0) return;
+  __shared__ float red[kRedBlock];
+  float a = 0.f;
+  for (int64_t i = threadIdx.x; i < n; i += kRedBlock) a += g[i] * g[i];
+  red[threadIdx.x] = a;
+  __syncthreads();
+  for (int s = kRedBlock >> 1; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = red[0] / (float)B;
+}
+
+// ---- both GAN-loss terms of the discriminator step (model/nerf_adapt_st_gan.py:139-160) and their weighted cotangents in one
+// launch: out2 = {bce(d_real, 1), bce(d_fake, 0)} (means), g_real = w_real (sigmoid(d_real) - 1) / n, g_fake = w_fake sigmoid(d_fake) / n.
+// One workgroup: wave-free fixed-order tree per term, exactly bce_logits_fwd_kernel's arithmetic.
+__global__ __launch_bounds__(kBlock) void gan_disc_losses_kernel(const float* __restrict__ d_real, const float* __restrict__ d_fake, int n,
+                                                                  float w_real, float w_fake, float* __restrict__ out2,
+                                                                  float* __restrict__ g_real, float* __restrict__ g_fake) {
+  __shared__ float red[kBlock];
+  for (int term = 0; term < 2; ++term) {
+    const float* x = term == 0 ? d_real : d_fake;
+    const float target = term == 0 ? 1.f : 0.f, w = term == 0 ? w_real : w_fake;
+    float* gx = term == 0 ? g_real : g_fake;
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < n; i += kBlock) {
+      const float v = x[i];
+      const float ls = fminf(v, 0.f) - log1pf(expf(-fabsf(v)));
+      acc += (1.f - target) * v - ls;
+      const float sg = 1.f / (1.f + expf(-v));
+      gx[i] = (sg - target) * w / (float)n;
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = kBlock >> 1; s > 0; s >>= 1) {
+      if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) out2[term] = red[0] / (float)n;
+    __syncthreads();
+  }
+}
+
 // ---- total = sum_k w_k term_k over up to 16 scalar device tensors (reference model/base.py:145-157: the weighted loss sum)
 struct TermTable { const float* t[16]; float w[16]; int n; };
 __global__ void weighted_sum_kernel(TermTable tb, float* __restrict__ out) {
@@ -379,6 +428,20 @@ int tp_sumsq_mean_fwd(const float* g, int64_t n, int B, float* out, tp_stream_t 
   TP_REQUIRE(g && out && n > 0 && B > 0, "bad arguments");
   hipLaunchKernelGGL(sumsq_mean_fwd_kernel, dim3(1), dim3(kRedBlock), 0, (hipStream_t)stream, g, n, B, out);
   return tp::check_launch("tp_sumsq_mean_fwd");
+}
+int tp_sumsq_mean_fwd_bwd(const float* g, int64_t n, int B, float w, float* out, float* out_g, tp_stream_t stream) {
+  TP_REQUIRE(g && out && out_g && n > 0 && B > 0, "bad arguments");
+  const int64_t blocks = (n + kRedBlock - 1) / kRedBlock;
+  hipLaunchKernelGGL(sumsq_mean_fwd_bwd_kernel, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(kRedBlock), 0, (hipStream_t)stream, g, n, B, w,
+                     out, out_g);
+  return tp::check_launch("tp_sumsq_mean_fwd_bwd");
+}
+int tp_gan_disc_losses(const float* d_real, const float* d_fake, int n, float w_real, float w_fake, float* out2, float* g_real,
+                       float* g_fake, tp_stream_t stream) {
+  TP_REQUIRE(d_real && d_fake && out2 && g_real && g_fake && n > 0, "bad arguments");
+  hipLaunchKernelGGL(gan_disc_losses_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, d_real, d_fake, n, w_real, w_fake, out2, g_real,
+                     g_fake);
+  return tp::check_launch("tp_gan_disc_losses");
 }
 int tp_sumsq_mean_bwd(const float* g, int64_t n, int B, const float* cot, float* out, tp_stream_t stream) {
   TP_REQUIRE(g && cot && out && n > 0 && B > 0, "bad arguments");

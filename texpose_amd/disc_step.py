@@ -1,0 +1,229 @@
+"""K16: the discriminator step as an EXPLICIT launch schedule.
+
+Reference: model/nerf_adapt_st_gan.py:129-171 (`disc_trainstep`: D(real) with the BCE term, the R1 penalty of
+`compute_grad2` :794-807 -- a double backward through the discriminator --, D(fake) with its BCE term, one RMSprop step)
+over layers/discriminator.py:45-115 (spectral-normalised stride-2 ladder with InstanceNorm + LeakyReLU, full-map
+convolution, scale-conditioned head).
+
+`trainer.GanTrainer.disc_step` used to build this step with autograd over the K7 / K9 / K11 / K14 / K15 Functions.  The
+derivative structure of the step is fixed, so it is written out here as the list of kernel launches it is, with three
+consequences autograd could not have:
+  * a weight that receives a first-order AND a second-order (R1) contribution gets both from ONE weight-gradient launch: a
+    weight gradient is a sum over samples, so the two (cotangent, input) pairs are stacked along the sample axis in buffers the
+    producing kernels write into directly -- no second launch, no `add` per weight;
+  * the two cotangents of a normalised activation (BCE path, R1 path) are summed inside the InstanceNorm backward launch
+    (`addend`), the head's two weight-gradient shares inside the head kernel, the two spectral-norm instances of a weight
+    (real pass, fake pass: the power iteration advances between them) inside `tp_sn_bwd` (`accumulate`): no engine `add`s, no
+    zero fills, no AccumulateGrad;
+  * nothing is computed that nobody reads (data gradients wrt the real / fake patches, the head's weight gradients in the R1
+    penalty's first pass), both BCE terms and their cotangents are one launch, the R1 value and its cotangent one launch.
+Same arithmetic as the autograd form up to the order of two-term sums (tests/test_gpu_parity.py::test_disc_step_schedule_*:
+gradients agree to 1e-6 relative, losses bit for bit); the golden two-iteration fixture G13 pins it to the reference.
+
+Only the HIP kernels are called (texpose_amd.ops); there is no CPU path: `eligible()` is False for CPU tensors and the caller
+keeps its autograd form for those (golden generation, contract tests).
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .gan_modules import Discriminator, SNConv2d, _pow2_map
+from .options import AttrDict
+
+
+class DiscStepSchedule:
+    def __init__(self, disc: Discriminator):
+        self.disc = disc
+        self.stages: List[tuple] = []           # (SNConv2d stride-2 4x4, InstanceNorm eps) of the ladder
+        self.full: Optional[SNConv2d] = None    # the full-map convolution that ends the ladder
+        self.slope: Optional[float] = None
+        self.reason = self._parse()
+        self._ones = {}
+
+    # ------------------------------------------------------------------ structure
+    def _parse(self) -> Optional[str]:
+        d = self.disc
+        if not isinstance(d, Discriminator) or not d.scale_conditional or not d._plain_head():
+            return "needs the scale-conditioned three-layer head"
+        mods, i, slopes = list(d.main), 0, {d.final[0].negative_slope}
+        while i + 2 < len(mods):
+            c, n, a = mods[i], mods[i + 1], mods[i + 2]
+            if not (isinstance(c, SNConv2d) and tuple(c.weight_orig.shape[-2:]) == (4, 4) and c.stride == (2, 2) and c.padding == (1, 1)
+                    and isinstance(n, nn.InstanceNorm2d) and not n.affine and not n.track_running_stats and isinstance(a, nn.LeakyReLU)):
+                break
+            self.stages.append((c, float(n.eps)))
+            slopes.add(a.negative_slope)
+            i += 3
+        if i != len(mods) - 1 or not self.stages:
+            return "ladder is not [conv4s2, InstanceNorm, LeakyReLU]* + full-map convolution (patch_size 16 / 32)"
+        full = mods[-1]
+        if not (isinstance(full, SNConv2d) and full.padding == (0, 0) and full.stride == (1, 1)):
+            return "last ladder layer is not an unpadded convolution"
+        if len(slopes) != 1:
+            return "different LeakyReLU slopes"
+        self.full, self.slope = full, float(slopes.pop())
+        return None
+
+    def convs(self) -> List[SNConv2d]:
+        """In the order of `Discriminator.forward`: ladder convolutions, then the head's."""
+        d = self.disc
+        return [m for m in list(d.main) + list(d.final) if isinstance(m, SNConv2d)]
+
+    def eligible(self, opt, x: torch.Tensor) -> bool:
+        """The schedule covers: GPU tensors, 'standard' GAN loss, a ladder whose maps the K11 kernels take."""
+        if self.reason is not None or not x.is_cuda or x.dtype != torch.float32 or opt.gan.type != "standard":
+            return False
+        if opt.loss_weight.get("gan_disc_real") is None or opt.loss_weight.get("gan_disc_fake") is None:
+            return False
+        h, w = x.shape[-2:]
+        for _ in self.stages:
+            if not (_pow2_map(h) and _pow2_map(w)):
+                return False
+            h, w = h // 2, w // 2
+        kh, kw = self.full.weight_orig.shape[-2:]
+        k_in = self.full.weight_orig.shape[1] * kh * kw
+        return (h, w) == (kh, kw) and 2 * x.shape[0] <= ops.SKINNY_MAX_ROWS and k_in >= 1024 and self.disc.training
+
+    def _ones_like(self, t):
+        key = (t.device, t.numel())
+        if key not in self._ones:
+            self._ones[key] = torch.ones(t.numel(), device=t.device)
+        return self._ones[key]
+
+    # ------------------------------------------------------------------ pieces
+    def _normalised_weights(self):
+        convs = self.convs()
+        outs, sigmas, us, vs = ops.spectral_norm_fwd([c.weight_orig.detach() for c in convs], [c.weight_u for c in convs],
+                                                     [c.weight_v for c in convs], True, keep_uv=True)
+        return AttrDict(w=outs, sigma=sigmas, u=us, v=vs)
+
+    def _forward(self, x, W, scale, stacks=None):
+        """Ladder + head.  ``stacks[l]`` ([2B, ...], l >= 1): where the input of stage l (the full-map convolution for l = K)
+        goes -- its first half."""
+        K, B, sl = len(self.stages), x.shape[0], self.slope
+        a, saved = x, []
+        for l, (_conv, eps) in enumerate(self.stages):
+            z = ops.conv4s2_fwd(a, W[l])
+            y, xhat, rstd = ops.inorm_lrelu_fwd(z, eps, sl, y_out=None if stacks is None else stacks[l + 1][:B])
+            saved.append(AttrDict(x=a, xhat=xhat, rstd=rstd))
+            a = y
+        z3 = ops.skinny_linear_fwd(a.reshape(B, -1), W[K].flatten(1))
+        out, t0, t1, t2 = ops.disc_head_fwd(z3, scale, W[K + 1].flatten(1), W[K + 2].flatten(1), W[K + 3].flatten(1),
+                                            self.disc.L_scale, sl)
+        return AttrDict(out=out, stages=saved, a_full=a, head=(t0, t1, t2), C_z=z3.shape[1])
+
+    def _head_w(self, W):
+        K = len(self.stages)
+        return W[K + 1].flatten(1), W[K + 2].flatten(1), W[K + 3].flatten(1)
+
+    def _backward_plain(self, f, W, g_out):
+        """First-order weight gradients of one pass (no R1): [ladder..., full-map, head 1..3] in the order of `convs()`."""
+        K, B, sl = len(self.stages), g_out.shape[0], self.slope
+        t0, t1, t2 = f.head
+        c_z3, gW1, gW2, gW3, _, _ = ops.disc_head_bwd(g_out, t0, t1, t2, *self._head_w(W), f.C_z, self.disc.L_scale, sl)
+        gw = [None] * (K + 1)
+        gw[K] = ops.skinny_linear_wgrad(c_z3, f.a_full.reshape(B, -1))
+        c_a = ops.skinny_linear_dgrad(c_z3, W[K].flatten(1)).view_as(f.a_full)
+        for l in range(K - 1, -1, -1):
+            st = f.stages[l]
+            c_z = ops.inorm_lrelu_bwd(st.xhat, st.rstd, c_a, sl)
+            gw[l] = ops.conv4s2_wgrad(c_z, st.x)
+            if l > 0:
+                c_a = ops.conv4s2_dgrad(c_z, W[l])
+        return gw + [gW1, gW2, gW3]
+
+    def _real_pass_with_r1(self, real_stack, W, scale, w_reg, make_g_out):
+        """D(real), the R1 penalty (value, first and second pass) and ALL weight gradients of the real pass.  ``make_g_out(d_real)``
+        returns the weighted BCE cotangent of D(real) (it may need D(fake): the caller runs the fake forward inside it)."""
+        K, B, sl, L = len(self.stages), real_stack.shape[0] // 2, self.slope, self.disc.L_scale
+        dev = real_stack.device
+        x = real_stack[:B]
+        # stacked operands of the weight gradients: xs[l] = [input of layer l | its R1 cotangent], gs[l] = [BCE-path cotangent of
+        # layer l's output | that output's first-pass gradient]   (layer K = the full-map convolution, flattened)
+        xs, gs, shp = [real_stack], [], x.shape
+        for l, (conv, _eps) in enumerate(self.stages):
+            co = conv.weight_orig.shape[0]
+            shp = (B, co, shp[2] // 2, shp[3] // 2)
+            xs.append(torch.empty((2 * B,) + shp[1:], device=dev))
+            gs.append(torch.empty((2 * B,) + shp[1:], device=dev))
+        n_out = self.full.weight_orig.shape[0]
+        gs.append(torch.empty(2 * B, n_out, device=dev))
+        f = self._forward(x, W, scale, stacks=xs)
+        t0, t1, t2 = f.head
+        Wh = self._head_w(W)
+        ones = self._ones_like(f.out)
+        # ---- R1, first pass: g = d D(real).sum() / d real  (reference :796-801)
+        gz3, _, _, _, e1, e2 = ops.disc_head_bwd(ones, t0, t1, t2, *Wh, f.C_z, L, sl, weight_grads=False, gz_out=gs[K][B:])
+        ga, ga_in = ops.skinny_linear_dgrad(gz3, W[K].flatten(1)).view_as(f.a_full), [None] * K
+        for l in range(K - 1, -1, -1):
+            st = f.stages[l]
+            ga_in[l] = ga
+            gz = ops.inorm_lrelu_bwd(st.xhat, st.rstd, ga, sl, out=gs[l][B:])
+            ga = ops.conv4s2_dgrad(gz, W[l])
+        # ---- value and weighted cotangent of the penalty (reference :802-806 and the .mean() of :149)
+        r1, c = ops.sumsq_mean_fwd_bwd(ga, w_reg, out_g=xs[0][B:])
+        # ---- R1, second pass: back through the first pass (every node linear in its cotangent)
+        c_zr = [None] * K
+        for l in range(K):
+            st = f.stages[l]
+            c_gz = ops.conv4s2_fwd(c, W[l])
+            c, c_zr[l] = ops.inorm_lrelu_bwd_bwd(st.xhat, st.rstd, ga_in[l], c_gz, sl, out_gy=xs[l + 1][B:])
+        c_gz3 = ops.skinny_linear_fwd(c.reshape(B, -1), W[K].flatten(1))
+        _gg, gW1, gW2, gW3 = ops.disc_head_bwd_bwd(c_gz3, ones, t0, t1, t2, e1, e2, *Wh, L, sl)
+        # ---- BCE path of the real pass, its cotangents joined with the R1 path's on the way
+        g_out = make_g_out(f.out)
+        c_z3, gW1, gW2, gW3, _, _ = ops.disc_head_bwd(g_out, t0, t1, t2, *Wh, f.C_z, L, sl, accumulate_into=(gW1, gW2, gW3),
+                                                      gz_out=gs[K][:B])
+        gw = [None] * (K + 1)
+        gw[K] = ops.skinny_linear_wgrad(gs[K], xs[K].reshape(2 * B, -1))
+        c_a = ops.skinny_linear_dgrad(c_z3, W[K].flatten(1)).view_as(f.a_full)
+        for l in range(K - 1, -1, -1):
+            st = f.stages[l]
+            c_z = ops.inorm_lrelu_bwd(st.xhat, st.rstd, c_a, sl, addend=c_zr[l], out=gs[l][:B])
+            gw[l] = ops.conv4s2_wgrad(gs[l], xs[l])
+            if l > 0:
+                c_a = ops.conv4s2_dgrad(c_z, W[l])
+        return f, r1.reshape(()), gw + [gW1, gW2, gW3]
+
+    # ------------------------------------------------------------------ the step
+    def run(self, real, fake, scale, w_real: float, w_fake: float, w_reg: Optional[float], real_stack=None):
+        """Gradients of  w_real BCE(D(real), 1) + w_reg R1(real) + w_fake BCE(D(fake), 0)  wrt the discriminator's weights, written
+        to ``.grad`` of the `weight_orig` parameters (replacing what was there), in the reference's order of side effects: power
+        iteration + D(real), [R1], power iteration + D(fake).  ``real_stack`` ([2B, ...], optional): a buffer whose first half IS
+        `real` (ops.disc_inputs(stacked=True)); without it `real` is copied into one.
+        Returns AttrDict(d_real, d_fake, gan_disc_real, gan_disc_fake, gan_reg_real (unweighted, or None))."""
+        B = real.shape[0]
+        scale = scale.reshape(-1).contiguous()
+        res = AttrDict(gan_reg_real=None)
+        n_real = self._normalised_weights()
+        state = {}
+
+        def fake_forward_and_losses(d_real):
+            # (the reference's order: the power iteration of the fake pass follows the whole real pass' forward work)
+            n_fake = self._normalised_weights()
+            f_fake = self._forward(fake.contiguous(), n_fake.w, scale)
+            out2, g_real, g_fake = ops.gan_disc_losses(d_real, f_fake.out, w_real, w_fake)
+            state.update(n_fake=n_fake, f_fake=f_fake, g_fake=g_fake)
+            res.gan_disc_real, res.gan_disc_fake, res.d_fake = out2[0], out2[1], f_fake.out
+            return g_real
+
+        if w_reg is not None:
+            if real_stack is None or real_stack.shape[0] != 2 * B or real_stack.data_ptr() != real.data_ptr():
+                real_stack = torch.empty((2 * B,) + tuple(real.shape[1:]), device=real.device)
+                real_stack[:B].copy_(real)
+            f_real, res.gan_reg_real, gw_real = self._real_pass_with_r1(real_stack, n_real.w, scale, w_reg, fake_forward_and_losses)
+        else:
+            f_real = self._forward(real.contiguous(), n_real.w, scale)
+            gw_real = self._backward_plain(f_real, n_real.w, fake_forward_and_losses(f_real.out))
+        res.d_real = f_real.out
+        gw_fake = self._backward_plain(state["f_fake"], state["n_fake"].w, state["g_fake"])
+        grads = ops.spectral_norm_bwd(gw_real, n_real.w, n_real.u, n_real.v, n_real.sigma)
+        n_fake = state["n_fake"]
+        grads = ops.spectral_norm_bwd(gw_fake, n_fake.w, n_fake.u, n_fake.v, n_fake.sigma, accumulate_into=grads)
+        for conv, g in zip(self.convs(), grads):
+            conv.weight_orig.grad = g
+        return res

@@ -72,6 +72,19 @@ def _f32(t: Tensor, name: str) -> Tensor:
     return t.contiguous()
 
 
+def _out_like(out: Optional[Tensor], like: Tensor, shape=None) -> Tensor:
+    """``out`` (checked: float32, contiguous, on ``like``'s device, of the wanted number of elements) or a fresh tensor."""
+    shape = tuple(like.shape) if shape is None else tuple(shape)
+    if out is None:
+        return torch.empty(shape, device=like.device, dtype=torch.float32)
+    n = 1
+    for d in shape:
+        n *= d
+    if out.dtype != torch.float32 or not out.is_contiguous() or out.device != like.device or out.numel() != n:
+        raise _lib.TexposeLibraryError("out= must be a contiguous float32 tensor of %s elements on %s" % (n, like.device))
+    return out
+
+
 def _ptr(t: Optional[Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
@@ -535,8 +548,10 @@ def spectral_norm_fwd(weights, us, vs, training: bool, keep_uv: bool = False):
 
 
 @_on_tensor_device
-def spectral_norm_bwd(grads_sn, weights_sn, us, vs, sigmas):
-    """dL/dW from dL/dW_sn with u, v treated as constants (torch's convention): (G - <G, W_sn> u v^T) / sigma."""
+def spectral_norm_bwd(grads_sn, weights_sn, us, vs, sigmas, accumulate_into=None):
+    """dL/dW from dL/dW_sn with u, v treated as constants (torch's convention): (G - <G, W_sn> u v^T) / sigma.
+    ``accumulate_into``: a list of tensors the results are ADDED to (the second normalised instance of the same weights in one
+    optimiser step); they are what is returned."""
     lib = _lib.load()
     n = len(grads_sn)
     arr = (_lib.SnWeight * n)()
@@ -544,7 +559,8 @@ def spectral_norm_bwd(grads_sn, weights_sn, us, vs, sigmas):
     for i, (g, ws, u, v, sg) in enumerate(zip(grads_sn, weights_sn, us, vs, sigmas)):
         g = _f32(g, "grad")
         rows, cols = ws.shape[0], ws.numel() // ws.shape[0]
-        o = torch.empty_like(ws)
+        o = torch.empty_like(ws) if accumulate_into is None else _out_like(accumulate_into[i], ws)
+        arr[i].accumulate = 0 if accumulate_into is None else 1
         wk = torch.empty(lib.tp_sn_work_floats(rows, cols), device=ws.device)
         a = arr[i]
         a.u, a.v, a.weight_sn, a.sigma, a.grad_sn, a.grad, a.work = (u.data_ptr(), v.data_ptr(), ws.data_ptr(), sg.data_ptr(),
@@ -598,12 +614,13 @@ def nerf_losses_bwd(rgb: Tensor, uncert: Tensor, density: Tensor, gathered: Tens
 
 # ------------------------------------------------------------------------------------------ K9
 @_on_tensor_device
-def inorm_lrelu_fwd(x: Tensor, eps: float, slope: float):
-    """x [B,C,H,W] -> (y, xhat, rstd [B*C]) = LeakyReLU(InstanceNorm2d(x)) and what its derivatives need."""
+def inorm_lrelu_fwd(x: Tensor, eps: float, slope: float, y_out: Optional[Tensor] = None):
+    """x [B,C,H,W] -> (y, xhat, rstd [B*C]) = LeakyReLU(InstanceNorm2d(x)) and what its derivatives need.  ``y_out``: where y is
+    written (a contiguous view of x's shape, e.g. one half of a stacked buffer)."""
     lib = _lib.load()
     x = _f32(x, "x")
     n_inst, hw = x.shape[0] * x.shape[1], x.shape[2] * x.shape[3]
-    y, xhat = torch.empty_like(x), torch.empty_like(x)
+    y, xhat = _out_like(y_out, x), torch.empty_like(x)
     rstd = torch.empty(n_inst, device=x.device)
     check(lib.tp_inorm_lrelu_fwd(x.data_ptr(), n_inst, hw, float(eps), float(slope), y.data_ptr(), xhat.data_ptr(),
                                  rstd.data_ptr(), _stream()), "tp_inorm_lrelu_fwd")
@@ -611,21 +628,27 @@ def inorm_lrelu_fwd(x: Tensor, eps: float, slope: float):
 
 
 @_on_tensor_device
-def inorm_lrelu_bwd(xhat: Tensor, rstd: Tensor, gy: Tensor, slope: float) -> Tensor:
+def inorm_lrelu_bwd(xhat: Tensor, rstd: Tensor, gy: Tensor, slope: float, addend: Optional[Tensor] = None,
+                    out: Optional[Tensor] = None) -> Tensor:
+    """gx; ``addend`` (same shape) is added to it in the same launch (a second cotangent of x)."""
     lib = _lib.load()
     gy = _f32(gy, "gy")
-    gx = torch.empty_like(xhat)
+    gx = _out_like(out, xhat)
+    if addend is not None:
+        addend = _f32(addend, "addend")
+        if addend.numel() != xhat.numel():
+            raise ValueError("inorm_lrelu_bwd: addend must have the shape of x")
     check(lib.tp_inorm_lrelu_bwd(xhat.data_ptr(), rstd.data_ptr(), gy.data_ptr(), rstd.numel(), xhat.numel() // rstd.numel(),
-                                 float(slope), gx.data_ptr(), _stream()), "tp_inorm_lrelu_bwd")
+                                 float(slope), _ptr(addend), gx.data_ptr(), _stream()), "tp_inorm_lrelu_bwd")
     return gx
 
 
 @_on_tensor_device
-def inorm_lrelu_bwd_bwd(xhat: Tensor, rstd: Tensor, gy: Tensor, ggx: Tensor, slope: float):
+def inorm_lrelu_bwd_bwd(xhat: Tensor, rstd: Tensor, gy: Tensor, ggx: Tensor, slope: float, out_gy: Optional[Tensor] = None):
     """cotangent ggx of the backward's output gx -> (grad wrt gy, grad wrt x)."""
     lib = _lib.load()
     gy, ggx = _f32(gy, "gy"), _f32(ggx, "ggx")
-    g_gy, g_x = torch.empty_like(xhat), torch.empty_like(xhat)
+    g_gy, g_x = _out_like(out_gy, xhat), torch.empty_like(xhat)
     check(lib.tp_inorm_lrelu_bwd_bwd(xhat.data_ptr(), rstd.data_ptr(), gy.data_ptr(), ggx.data_ptr(), rstd.numel(),
                                      xhat.numel() // rstd.numel(), float(slope), g_gy.data_ptr(), g_x.data_ptr(), _stream()),
           "tp_inorm_lrelu_bwd_bwd")
@@ -728,29 +751,30 @@ def _conv4s2(op: int, name: str, x, w, gy, out, N, C_in, H, W, Co):
 
 
 @_on_tensor_device
-def conv4s2_fwd(x: Tensor, w: Tensor) -> Tensor:
+def conv4s2_fwd(x: Tensor, w: Tensor, out: Optional[Tensor] = None) -> Tensor:
     """conv2d(x [N,C,H,W], w [Co,C,4,4], stride 2, padding 1) -> [N,Co,H/2,W/2]."""
     x, w = _f32(x, "x"), _f32(w, "w")
     N, C_in, H, W = x.shape
-    y = torch.empty(N, w.shape[0], H // 2, W // 2, device=x.device)
+    y = _out_like(out, x, (N, w.shape[0], H // 2, W // 2))
     return _conv4s2(_lib.CONV_FWD, "tp_conv4s2_fwd", x, w, None, y, N, C_in, H, W, w.shape[0])
 
 
 @_on_tensor_device
-def conv4s2_dgrad(gy: Tensor, w: Tensor) -> Tensor:
+def conv4s2_dgrad(gy: Tensor, w: Tensor, out: Optional[Tensor] = None) -> Tensor:
     """gradient of conv4s2_fwd wrt x: gy [N,Co,H/2,W/2], w [Co,C,4,4] -> [N,C,H,W]."""
     gy, w = _f32(gy, "gy"), _f32(w, "w")
     N, Co, OH, OW = gy.shape
-    gx = torch.empty(N, w.shape[1], 2 * OH, 2 * OW, device=gy.device)
+    gx = _out_like(out, gy, (N, w.shape[1], 2 * OH, 2 * OW))
     return _conv4s2(_lib.CONV_DGRAD, "tp_conv4s2_dgrad", None, w, gy, gx, N, w.shape[1], 2 * OH, 2 * OW, Co)
 
 
 @_on_tensor_device
-def conv4s2_wgrad(gy: Tensor, x: Tensor) -> Tensor:
-    """gradient of conv4s2_fwd wrt w: gy [N,Co,H/2,W/2], x [N,C,H,W] -> [Co,C,4,4]."""
+def conv4s2_wgrad(gy: Tensor, x: Tensor, out: Optional[Tensor] = None) -> Tensor:
+    """gradient of conv4s2_fwd wrt w: gy [N,Co,H/2,W/2], x [N,C,H,W] -> [Co,C,4,4] (a sum over the N samples: several
+    (gy, x) pairs stacked along N give the sum of their weight gradients in one launch)."""
     gy, x = _f32(gy, "gy"), _f32(x, "x")
     N, C_in, H, W = x.shape
-    gw = torch.empty(gy.shape[1], C_in, 4, 4, device=x.device)
+    gw = _out_like(out, x, (gy.shape[1], C_in, 4, 4))
     return _conv4s2(_lib.CONV_WGRAD, "tp_conv4s2_wgrad", x, None, gy, gw, N, C_in, H, W, gy.shape[1])
 
 
@@ -867,15 +891,17 @@ def feat_inputs_bwd(rgb: Tensor, gathered: Tensor, mean, std, g_out: Tensor) -> 
 
 
 @_on_tensor_device
-def disc_inputs(rgb: Tensor, gathered: Tensor, hw, geo: bool):
-    """(real, fake) [B, 3 or 9, h, w] of the discriminator step from the render output and the gathered patches (K13)."""
+def disc_inputs(rgb: Tensor, gathered: Tensor, hw, geo: bool, stacked: bool = False):
+    """(real, fake) [B, 3 or 9, h, w] of the discriminator step from the render output and the gathered patches (K13).
+    ``stacked``: `real` is returned as the first half of a [2B, ...] buffer (returned in its place) whose second half the
+    explicit discriminator-step schedule fills with the R1 cotangent: its first weight gradient then sums both pairs in one launch."""
     lib = _lib.load()
     rgb, gathered = _f32(rgb.detach(), "rgb"), _f32(gathered, "gathered")
     B, P = rgb.shape[0], rgb.shape[1]
     if gathered.numel() != B * 14 * P:
         raise ValueError("disc_inputs: gathered [B,14,h,w] expected")
     nc = 9 if geo else 3
-    real, fake = torch.empty(B, nc, hw[0], hw[1], device=rgb.device), torch.empty(B, nc, hw[0], hw[1], device=rgb.device)
+    real, fake = torch.empty(2 * B if stacked else B, nc, hw[0], hw[1], device=rgb.device), torch.empty(B, nc, hw[0], hw[1], device=rgb.device)
     check(lib.tp_disc_inputs(rgb.data_ptr(), gathered.data_ptr(), B, P, int(bool(geo)), real.data_ptr(), fake.data_ptr(), _stream()),
           "tp_disc_inputs")
     return real, fake
@@ -928,6 +954,33 @@ def sumsq_mean_bwd(g: Tensor, cot: Tensor) -> Tensor:
     out = torch.empty_like(g)
     check(lib.tp_sumsq_mean_bwd(g.data_ptr(), g.numel(), g.shape[0], cot.data_ptr(), out.data_ptr(), _stream()), "tp_sumsq_mean_bwd")
     return out
+
+
+@_on_tensor_device
+def sumsq_mean_fwd_bwd(g: Tensor, w: float, out_g: Optional[Tensor] = None):
+    """(sum(g^2) / B [1], 2 w g / B) for g [B, ...] in one launch: value and weighted gradient of the R1 penalty (K16)."""
+    lib = _lib.load()
+    g = _f32(g, "g")
+    out, og = torch.empty(1, device=g.device), _out_like(out_g, g)
+    check(lib.tp_sumsq_mean_fwd_bwd(g.data_ptr(), g.numel(), g.shape[0], float(w), out.data_ptr(), og.data_ptr(), _stream()),
+          "tp_sumsq_mean_fwd_bwd")
+    return out, og
+
+
+@_on_tensor_device
+def gan_disc_losses(d_real: Tensor, d_fake: Tensor, w_real: float, w_fake: float, g_real_out: Optional[Tensor] = None,
+                    g_fake_out: Optional[Tensor] = None):
+    """Both GAN-loss terms of the discriminator step and their weighted cotangents in one launch (K16):
+    -> (out2 = [bce(d_real, 1), bce(d_fake, 0)], g_real, g_fake)."""
+    lib = _lib.load()
+    d_real, d_fake = _f32(d_real, "d_real"), _f32(d_fake, "d_fake")
+    if d_real.numel() != d_fake.numel():
+        raise ValueError("gan_disc_losses: d_real and d_fake must have the same number of elements")
+    out2 = torch.empty(2, device=d_real.device)
+    gr, gf = _out_like(g_real_out, d_real), _out_like(g_fake_out, d_fake)
+    check(lib.tp_gan_disc_losses(d_real.data_ptr(), d_fake.data_ptr(), d_real.numel(), float(w_real), float(w_fake), out2.data_ptr(),
+                                 gr.data_ptr(), gf.data_ptr(), _stream()), "tp_gan_disc_losses")
+    return out2, gr, gf
 
 
 @_on_tensor_device
@@ -1021,17 +1074,24 @@ def disc_head_fwd(z: Tensor, scale: Tensor, W1: Tensor, W2: Tensor, W3: Tensor, 
 
 
 @_on_tensor_device
-def disc_head_bwd(g_out: Tensor, t0: Tensor, t1: Tensor, t2: Tensor, W1: Tensor, W2: Tensor, W3: Tensor, C_z: int, L: int, slope: float):
-    """-> (gz [B,C], gW1, gW2, gW3, e1, e2)."""
+def disc_head_bwd(g_out: Tensor, t0: Tensor, t1: Tensor, t2: Tensor, W1: Tensor, W2: Tensor, W3: Tensor, C_z: int, L: int, slope: float,
+                  weight_grads: bool = True, accumulate_into=None, gz_out: Optional[Tensor] = None):
+    """-> (gz [B,C], gW1, gW2, gW3, e1, e2).  ``weight_grads=False``: data gradient only (gW1..3 = None);
+    ``accumulate_into=(gW1, gW2, gW3)``: the weight gradients are ADDED to these tensors (and they are what is returned)."""
     lib = _lib.load()
     g_out, W1, W2, W3 = _f32(g_out, "g_out"), _f32(W1, "W1"), _f32(W2, "W2"), _f32(W3, "W3")
     B, H, dev = t1.shape[0], t1.shape[1], t1.device
     a = _head_args(W1, W2, W3, B, C_z, L, slope)
-    gz, e1, e2 = torch.empty(B, C_z, device=dev), torch.empty(B, H, device=dev), torch.empty(B, H, device=dev)
-    gW1, gW2, gW3 = torch.empty_like(W1), torch.empty_like(W2), torch.empty_like(W3)
+    gz, e1, e2 = _out_like(gz_out, t1, (B, C_z)), torch.empty(B, H, device=dev), torch.empty(B, H, device=dev)
+    gW1 = gW2 = gW3 = None
+    if accumulate_into is not None:
+        gW1, gW2, gW3 = (_out_like(g, W) for g, W in zip(accumulate_into, (W1, W2, W3)))
+        a.accumulate_gw = 1
+    elif weight_grads:
+        gW1, gW2, gW3 = torch.empty_like(W1), torch.empty_like(W2), torch.empty_like(W3)
     a.g_out, a.t0, a.t1, a.t2, a.e1, a.e2, a.out = (g_out.data_ptr(), t0.data_ptr(), t1.data_ptr(), t2.data_ptr(), e1.data_ptr(),
                                                     e2.data_ptr(), gz.data_ptr())
-    a.gW1, a.gW2, a.gW3 = gW1.data_ptr(), gW2.data_ptr(), gW3.data_ptr()
+    a.gW1, a.gW2, a.gW3 = _ptr(gW1), _ptr(gW2), _ptr(gW3)
     check(lib.tp_disc_head_bwd(C.byref(a), _stream()), "tp_disc_head_bwd")
     return gz, gW1, gW2, gW3, e1, e2
 
@@ -1058,27 +1118,29 @@ SKINNY_MAX_ROWS = 256
 
 
 @_on_tensor_device
-def skinny_linear_fwd(x: Tensor, w: Tensor) -> Tensor:
+def skinny_linear_fwd(x: Tensor, w: Tensor, out: Optional[Tensor] = None) -> Tensor:
     """x [M,K] @ w [N,K]^T -> [M,N] for a handful of rows (K15)."""
     lib = _lib.load()
     x, w = _f32(x, "x"), _f32(w, "w")
-    y = torch.empty(x.shape[0], w.shape[0], device=x.device)
+    y = _out_like(out, x, (x.shape[0], w.shape[0]))
     check(lib.tp_skinny_linear_fwd(x.data_ptr(), w.data_ptr(), y.data_ptr(), x.shape[0], w.shape[0], x.shape[1], _stream()),
           "tp_skinny_linear_fwd")
     return y
 
 
-def skinny_linear_dgrad(gy: Tensor, w: Tensor) -> Tensor:
+def skinny_linear_dgrad(gy: Tensor, w: Tensor, out: Optional[Tensor] = None) -> Tensor:
     """gy [M,N] @ w [N,K] -> [M,K] (a library GEMM: rocBLAS does this shape in 7 us)."""
-    return torch.mm(gy, w)
+    return torch.mm(gy, w, out=out) if out is not None else torch.mm(gy, w)
 
 
 @_on_tensor_device
-def skinny_linear_wgrad(gy: Tensor, x: Tensor) -> Tensor:
+def skinny_linear_wgrad(gy: Tensor, x: Tensor, out: Optional[Tensor] = None) -> Tensor:
     """gy [M,N]^T @ x [M,K] -> [N,K]."""
     lib = _lib.load()
     gy, x = _f32(gy, "gy"), _f32(x, "x")
-    gw = torch.empty(gy.shape[1], x.shape[1], device=x.device)
+    if x.shape[0] > SKINNY_MAX_ROWS:
+        raise ValueError("skinny_linear_wgrad: at most %d rows" % SKINNY_MAX_ROWS)
+    gw = _out_like(out, x, (gy.shape[1], x.shape[1]))
     check(lib.tp_skinny_linear_wgrad(gy.data_ptr(), x.data_ptr(), gw.data_ptr(), x.shape[0], gy.shape[1], x.shape[1], _stream()),
           "tp_skinny_linear_wgrad")
     return gw

@@ -248,10 +248,26 @@ class GanTrainer:
         self.nerf_apply()
         return v, loss
 
+    def _disc_schedule(self, x):
+        """The explicit launch schedule of the discriminator step (K16, texpose_amd/disc_step.py) when it covers this
+        discriminator and these tensors, else None (CPU tensors, other ladders / GAN losses: the autograd form below)."""
+        if os.environ.get("TP_DISC_AUTOGRAD") == "1":
+            return None
+        sched = self.__dict__.get("_disc_sched")
+        if sched is None or sched.disc is not self.graph.discriminator:
+            from .disc_step import DiscStepSchedule
+            sched = self._disc_sched = DiscStepSchedule(self.graph.discriminator)
+        return sched if sched.eligible(self.opt, x) else None
+
     def disc_step(self, var, apply=True):
         opt, g = self.opt, self.graph
         self._toggle(g.discriminator, True)
         self.optim_disc.zero_grad(set_to_none=True)
+        if var.rgb.is_cuda and (var.get("disc_patches_for") is var.ray_idx or ("gathered" in var and var.get("gathered_for") is var.ray_idx)):
+            real, fake, stack = g.disc_patch_stacks(opt, var)
+            sched = self._disc_schedule(real)
+            if sched is not None:
+                return self._disc_step_scheduled(sched, var, real, fake, stack, apply)
         var = g.disc_forward(opt, var, mode="train")
         loss = g.compute_loss(opt, var, mode="train", train_step="disc")
         # The reference back-propagates the three terms one after the other (real, R1 penalty, fake: :139-160).  The sum of
@@ -265,6 +281,30 @@ class GanTrainer:
         if "gan_reg_real" in terms:
             # the reference logs the WEIGHTED penalty: it scales the tensor it has just stored, in place (:151-153)
             loss.gan_reg_real = self._weight(opt.loss_weight.gan_reg_real, total.device) * terms.gan_reg_real.detach()
+        if apply:
+            self.disc_apply(total)
+        else:
+            self._disc_total = total
+        return var, loss
+
+    def _disc_step_scheduled(self, sched, var, real, fake, stack, apply):
+        """`disc_step` through the explicit schedule: same losses, same gradients (sums of two terms in another order), about a
+        third fewer launches -- and no autograd graph."""
+        opt = self.opt
+        lw = opt.loss_weight
+        w = lambda k: 10 ** float(lw[k])
+        with torch.no_grad():
+            res = sched.run(real, fake, var.ray_scales, w("gan_disc_real"), w("gan_disc_fake"),
+                            None if lw.gan_reg_real is None else w("gan_reg_real"), real_stack=stack)
+            var.patch_real, var.patch_fake, var.d_real_disc, var.d_fake_disc = real, fake, res.d_real, res.d_fake
+            loss = edict(gan_disc_real=res.gan_disc_real)
+            if res.gan_reg_real is not None:
+                loss.gan_reg_real = res.gan_reg_real
+            loss.gan_disc_fake = res.gan_disc_fake
+            keys = list(loss.keys())                               # (real, R1, fake: the order of the autograd form's total)
+            total = ops.weighted_sum([loss[k] for k in keys], [w(k) for k in keys])
+            if res.gan_reg_real is not None:                       # logged WEIGHTED, as the reference does (:151-153)
+                loss.gan_reg_real = self._weight(lw.gan_reg_real, total.device) * res.gan_reg_real
         if apply:
             self.disc_apply(total)
         else:
