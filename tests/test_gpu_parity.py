@@ -1294,6 +1294,11 @@ def test_graph_capture_with_rccl_all_reduce(ops):
         assert_updates_close(results[0], results[2], snap)
     finally:
         os.environ.pop("TP_SPLIT_GRAPH", None)
+        # the captured graphs that contain RCCL kernels go before the communicator does
+        tr = graph = None
+        import gc
+        gc.collect()
+        torch.cuda.synchronize()
         dist.destroy_process_group()
 
 

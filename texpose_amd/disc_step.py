@@ -96,6 +96,9 @@ class DiscStepSchedule:
 
     # ------------------------------------------------------------------ pieces
     def _normalised_weights(self):
+        pre = self.disc.take_prefetched_weights()
+        if pre is not None:
+            return AttrDict(w=pre[0], sigma=pre[1], u=pre[2], v=pre[3])
         convs = self.convs()
         outs, sigmas, us, vs = ops.spectral_norm_fwd([c.weight_orig.detach() for c in convs], [c.weight_u for c in convs],
                                                      [c.weight_v for c in convs], True, keep_uv=True)

@@ -118,6 +118,7 @@ class Discriminator(nn.Module):
         if p not in (16, 32, 64, 128):
             raise ValueError("patch_size must be 16, 32, 64 or 128")
         self.progress = nn.Parameter(torch.tensor(0.))
+        self._sn_queue = []                      # prefetched normalised weight sets (prefetch_spectral_weights)
         conv = SNConv2d
         final_dim = ndf if self.scale_conditional else 1
         if self.scale_conditional:
@@ -173,9 +174,48 @@ class Discriminator(nn.Module):
                 and len({m.negative_slope for m in mods[0::2]}) == 1
                 and all(isinstance(m, SNConv2d) and tuple(m.weight_orig.shape[-2:]) == (1, 1) for m in mods[1::2]))
 
+    def sn_convs(self):
+        """The spectrally normalised convolutions in the order `forward` uses their weights: ladder, then head."""
+        return [m for m in list(self.main) + (list(self.final) if self.scale_conditional else []) if isinstance(m, SNConv2d)]
+
+    def prefetch_spectral_weights(self, n_calls: int):
+        """Run the power iterations / normalisations of the NEXT ``n_calls`` training-mode forwards now, in order (each advances
+        weight_u / weight_v once, exactly as those forwards would), and queue the results.  They depend on the weights only, not on
+        any input: the captured training step issues the three of an iteration (nerf step's D(fake), D(real), D(fake)) on a side
+        stream while the render's MLP kernel runs, which takes 5 launches off each discriminator pass.  Consumers that do not
+        differentiate through the normalisation take them with `take_prefetched_weights`; an unconsumed queue is an error."""
+        from . import ops
+        if not self.training:
+            raise RuntimeError("prefetch_spectral_weights: training mode only")
+        if self._sn_queue:
+            raise RuntimeError("prefetch_spectral_weights: %d prefetched weight sets were never used" % len(self._sn_queue))
+        convs = self.sn_convs()
+        for _ in range(n_calls):
+            outs, sigmas, us, vs = ops.spectral_norm_fwd([c.weight_orig.detach() for c in convs], [c.weight_u for c in convs],
+                                                         [c.weight_v for c in convs], True, keep_uv=True)
+            self._sn_queue.append((outs, sigmas, us, vs, torch.cuda.current_stream(outs[0].device)))
+
+    def take_prefetched_weights(self):
+        """(W_sn list, sigma list, u copies, v copies) of the oldest prefetched set, or None.  A calling stream other than the one
+        the prefetch was issued on is made to wait for that stream."""
+        if not self._sn_queue:
+            return None
+        outs, sigmas, us, vs, issued_on = self._sn_queue.pop(0)
+        cur = torch.cuda.current_stream(outs[0].device)
+        if cur != issued_on:
+            cur.wait_stream(issued_on)
+        return outs, sigmas, us, vs
+
     def forward(self, opt, x, scale=None):
-        convs = [m for m in list(self.main) + (list(self.final) if self.scale_conditional else []) if isinstance(m, SNConv2d)]
-        weights = spectral_weights(convs, self.training)              # all power iterations / normalisations at once
+        convs = self.sn_convs()
+        pre = None
+        if self._sn_queue:
+            if self.training and not (torch.is_grad_enabled() and any(c.weight_orig.requires_grad for c in convs)):
+                pre = self.take_prefetched_weights()
+            else:
+                raise RuntimeError("Discriminator.forward: prefetched spectral weights pending, but this call differentiates "
+                                   "through the normalisation (or runs in eval mode)")
+        weights = list(pre[0]) if pre is not None else spectral_weights(convs, self.training)   # all power iterations at once
         out = self._run(self.main, x, weights)                        # [B, c, 1, 1]
         if self.scale_conditional and out.is_cuda and self._plain_head():
             # K14: encoding, concatenation and the three 1x1 layers in one launch per derivative order

@@ -276,8 +276,25 @@ class Graph(torch.nn.Module):
                 patch_fake = var.rgb.view(B, h, w, 3).permute(0, 3, 1, 2)
                 if opt.gan.geo_conditional:
                     patch_fake = torch.cat([patch_fake, var.nocs_sample, var.normal_sample], dim=1)
+            self._feature_loss_early(opt, var, (h, w), mode)
             var.d_fake_nerf = self.discriminator(opt, patch_fake, var.ray_scales)
         return var
+
+    def _feature_loss_early(self, opt, var, hw, mode):
+        """With `feat_stream` set (the captured training step does that), the feature loss of the nerf step -- its inputs, the pass
+        through the feature network, the two mean squared differences -- is enqueued on that stream BEFORE the discriminator's
+        pass for the generator: the two chains of small dependent launches only share the render, so they run side by side in
+        the replayed graph (and autograd runs each backward on its forward's stream).  `compute_loss` picks the value up and
+        makes the calling stream wait for it."""
+        fs = getattr(self, "feat_stream", None)
+        if (fs is None or opt.loss_weight.feat is None or not hasattr(self, "perceptual_loss") or "gathered" not in var
+                or not var.rgb.is_cuda or not hasattr(self.perceptual_loss, "loss_from_patches")):
+            return
+        main = torch.cuda.current_stream(var.rgb.device)
+        fs.wait_stream(main)
+        with torch.cuda.stream(fs):
+            var.feat_early = self.perceptual_loss.loss_from_patches(var.rgb, var.gathered, hw, 5.0)
+        var.feat_early_for = var.ray_idx
 
     def disc_patch_stacks(self, opt, var):
         """(real, fake, real stack) of the discriminator step on the GPU, all detached: the stacks the nerf step of this iteration
@@ -397,7 +414,10 @@ class Graph(torch.nn.Module):
                     raise RuntimeError("loss_weight.feat is set but no perceptual_loss module was injected")
                 fused_feat = ("gathered" in var and var.rgb.is_cuda and hasattr(self.perceptual_loss, "pairs_from_patches")
                               and opt.nerf.rand_rays and mode in ["train", "test-optim"])
-                if fused_feat and hasattr(self.perceptual_loss, "loss_from_patches"):
+                if fused_feat and var.get("feat_early_for") is var.ray_idx:
+                    torch.cuda.current_stream(var.rgb.device).wait_stream(self.feat_stream)      # (enqueued by nerf_forward)
+                    loss.feat, l1 = var.feat_early, None
+                elif fused_feat and hasattr(self.perceptual_loss, "loss_from_patches"):
                     # K13 + K12: inputs of the four batches in one launch, one pass through the network, l1 + 5 l2 in one launch
                     loss.feat = self.perceptual_loss.loss_from_patches(var.rgb, var.gathered, (h, w), 5.0)
                     l1 = None

@@ -492,6 +492,14 @@ class GraphedGanTrainer(GanTrainer):
         With a gradient all-reduce in the step (`_deferred`) the branches only produce gradients and flags; reductions and
         both optimiser steps follow after the join (`_reduce_all`, `_body_b`)."""
         opt = self.opt
+        dev = var.idx.device
+        overlap = self.has_disc and not os.environ.get("TP_NO_BRANCH_OVERLAP")
+        if overlap and self._side is None:
+            self._side = torch.cuda.Stream(device=dev)
+        if overlap and getattr(self.graph, "feat_stream", None) is None and os.environ.get("TP_NO_FEAT_BRANCH") != "1":
+            # third chain of the replayed step: the feature network's forward and backward (graph.Graph._feature_loss_early)
+            self.graph.feat_stream = torch.cuda.Stream(device=dev)
+        self._prefetch_spectral_weights(var)                         # (first: it runs beside everything up to the render)
         B, R = opt.batch_size, opt.patch_size ** 2
         var = self.graph.get_ray_idx(opt, var)
         if opt.nerf.sample_stratified and "jitter_rand" not in var:   # (a caller-supplied static tensor wins: tests)
@@ -500,13 +508,10 @@ class GraphedGanTrainer(GanTrainer):
         terms, ws = self._weighted_total(loss)
         self._flag_nerf(loss)
         dloss = None
-        overlap = self.has_disc and not os.environ.get("TP_NO_BRANCH_OVERLAP")
         # optimiser steps (and reductions) after this function: whenever a collective is part of the step, or on request
         self._deferred = self._has_collective() or self._split_around_collectives()
         if overlap:
             main = torch.cuda.current_stream(var.rgb.device)
-            if self._side is None:
-                self._side = torch.cuda.Stream(device=var.rgb.device)
             self._side.wait_stream(main)                          # fork
             with torch.cuda.stream(self._side):
                 var, dloss = self.disc_step(var, apply=not self._deferred)
@@ -521,6 +526,25 @@ class GraphedGanTrainer(GanTrainer):
         if dloss is not None:
             loss.update({k: v for k, v in dloss.items() if k != "all"})
         return {k: v.detach() for k, v in loss.items() if torch.is_tensor(v)}
+
+    def _prefetch_spectral_weights(self, var):
+        """The spectral normalisations of this iteration's three discriminator passes (nerf step's D(fake), D(real), D(fake):
+        the reference's order of power iterations) depend on the weights only: issue them NOW on the discriminator branch's
+        stream, next to the render's MLP kernel, instead of 5 launches in front of each pass (K7; gan_modules.Discriminator.
+        prefetch_spectral_weights).  Only when every consumer of the iteration takes prefetched weights: the frozen
+        discriminator of the nerf step always does, the discriminator step when it runs as the explicit schedule (K16)."""
+        if not self.has_disc or self._side is None or os.environ.get("TP_NO_SN_PREFETCH") == "1":
+            return
+        opt, disc = self.opt, self.graph.discriminator
+        if not (hasattr(disc, "prefetch_spectral_weights") and disc.training and opt.gan is not None):
+            return
+        p, B = int(opt.patch_size), len(var.idx)
+        probe = torch.empty(0, device=var.idx.device).new_empty((B, 0, p, p))          # (shape / device carrier: no data)
+        n = 1 + (2 if self._disc_schedule(probe) is not None else 0)
+        main = torch.cuda.current_stream(probe.device)
+        self._side.wait_stream(main)                 # (after the previous iteration's RMSprop step, whichever stream ran it)
+        with torch.cuda.stream(self._side):
+            disc.prefetch_spectral_weights(n)
 
     def disc_step(self, var, apply=True):
         var, loss = super().disc_step(var, apply=apply)
