@@ -211,6 +211,9 @@ typedef struct tp_composite_bwd_args {
   float* g_uncert;              /* [n,N]     out */
   const float* g_rgb_ray;       /* [n,3] or NULL: cotangent of rgb_ray, ADDED to g_out_ray[:,0:3] */
   const float* g_uncert_ray;    /* [n]   or NULL: cotangent of uncert_ray, ADDED to g_out_ray[:,13] */
+  const float* g_rgb_ray2;      /* [n,3] or NULL: two more cotangents of rgb_ray (one per consumer of the colours), added likewise */
+  const float* g_rgb_ray3;
+  const float* g_density_add;   /* [n,N,2] or NULL: a second cotangent of the densities, ADDED to g_density */
 } tp_composite_bwd_args;
 int tp_composite_bwd(const tp_composite_bwd_args* args, tp_stream_t stream);
 
@@ -311,8 +314,9 @@ typedef struct tp_nerf_losses_args {
                               in fp32 from the fp32-rounded sums, the reference's operation order */
 } tp_nerf_losses_args;
 int tp_nerf_losses_fwd(const tp_nerf_losses_args* args, tp_stream_t stream);
-int tp_nerf_losses_bwd(const tp_nerf_losses_args* args, const float* g_losses /* [3] device */, float* g_rgb,
-                       float* g_uncert, float* g_density, tp_stream_t stream);
+/* g_render / g_unc / g_trans: the upstream gradients of the three terms, one device scalar each (NULL = 0) */
+int tp_nerf_losses_bwd(const tp_nerf_losses_args* args, const float* g_render, const float* g_unc, const float* g_trans,
+                       float* g_rgb, float* g_uncert, float* g_density, tp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * K9  InstanceNorm2d (affine = False) + LeakyReLU of the PatchGAN ladder, one launch per derivative order
@@ -459,10 +463,16 @@ int tp_feat_pair_loss_bwd(const float* feat, int64_t n, float w2, const float* g
 int tp_sumsq_mean_fwd(const float* g, int64_t n, int B, float* out, tp_stream_t stream);
 int tp_sumsq_mean_bwd(const float* g, int64_t n, int B, const float* cot, float* out, tp_stream_t stream);
 /* K16 (the discriminator step as an explicit schedule): value and weighted gradient of the R1 penalty in one launch,
- * out[0] = sum(g^2) / B, out_g [n] = 2 w g / B (w = the term's loss weight, a host constant);
+ * out[0] = sum(g^2) / B, out[1] = w out[0] (what the reference logs), out_g [n] = 2 w g / B (w = the term's loss weight, a host
+ * constant);
  * and both GAN-loss terms of the discriminator step (model/nerf_adapt_st_gan.py:139-160) with their weighted cotangents:
  * out2 = {bce(d_real, 1), bce(d_fake, 0)}, g_real [n] = w_real (sigmoid(d_real) - 1) / n, g_fake [n] = w_fake sigmoid(d_fake) / n. */
 int tp_sumsq_mean_fwd_bwd(const float* g, int64_t n, int B, float w, float* out, float* out_g, tp_stream_t stream);
+/* MaxPool2d(2, 2) of the feature network (layers/perceptual_loss.py:8-18): x [n, H, W] (n = images x channels; H, W even) ->
+ * y [n, H/2, W/2], arg [n, H/2, W/2] = position 0..3 of the maximum inside its window (the first one on ties, NaN wins: torch's
+ * rule); backward gx [n, H, W] from gy and arg, every element written (no zero fill). */
+int tp_maxpool2_fwd(const float* x, int64_t n, int H, int W, float* y, uint8_t* arg, tp_stream_t stream);
+int tp_maxpool2_bwd(const float* gy, const uint8_t* arg, int64_t n, int H, int W, float* gx, tp_stream_t stream);
 int tp_gan_disc_losses(const float* d_real, const float* d_fake, int n, float w_real, float w_fake, float* out2, float* g_real,
                        float* g_fake, tp_stream_t stream);
 /* Rows idx[b] of the two latent tables (model/nerf_adapt_st_gan.py:589-593) in one launch, and the dense table gradients
@@ -470,6 +480,9 @@ int tp_gan_disc_losses(const float* d_real, const float* d_fake, int n, float w_
 /* out[0] = sum_k weights[k] * terms[k][0] (ascending k) for up to 16 scalar device tensors; `terms` and `weights` are HOST
  * arrays (the weighted loss total of model/base.py:145-157, for logging and the step gate). */
 int tp_weighted_sum(const float* const* terms, const float* weights, int n, float* out, tp_stream_t stream);
+/* the same followed by tp_step_flags on the result, in one launch (the captured training step: loss total + step gate) */
+int tp_weighted_sum_flags(const float* const* terms, const float* weights, int n, float* out, const int32_t* mlp_status, int32_t* bad,
+                          int n_bad, int word_status, int word_finite, int32_t* snapshot, tp_stream_t stream);
 int tp_latent_rows_fwd(const float* w_trans, const float* w_light, const int64_t* idx, int B, int C_trans, int C_light, float* out_trans,
                        float* out_light, tp_stream_t stream);
 int tp_latent_rows_bwd(const float* g_trans, const float* g_light, const int64_t* idx, int B, int n_rows, int C_trans, int C_light,

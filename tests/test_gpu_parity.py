@@ -1957,6 +1957,67 @@ def test_round3_glue_kernels_match_torch(ops):
     torch.testing.assert_close(rgb.grad, cot[:, :3].permute(0, 2, 3, 1).reshape(B, p * p, 3))
 
 
+def test_round3_launch_diet_pieces(ops):
+    """Pieces of the launch diet, each against torch: MaxPool2d(2,2) forward / backward (ties after ReLU included), the composite
+    backward with the cotangents of the rgb aliases and the density alias summed inside the launch (== engine adds), the loss total
+    with the step gate folded in, the weighted R1 value."""
+    from texpose_amd import autograd_ops
+    rs = np.random.RandomState(5)
+    # max pool: values with many exact ties (ReLU output)
+    x0 = torch.relu(cu(torch.from_numpy(rs.normal(size=(3, 5, 8, 12)).astype(np.float32))))
+    cot = cu(torch.from_numpy(rs.normal(size=(3, 5, 4, 6)).astype(np.float32)))
+    xa, xb = x0.clone().requires_grad_(), x0.clone().requires_grad_()
+    ya, yb = autograd_ops.maxpool2(xa), F.max_pool2d(xb, 2, 2)
+    assert torch.equal(ya, yb)
+    (ya * cot).sum().backward()
+    (yb * cot).sum().backward()
+    assert torch.equal(xa.grad, xb.grad)
+    # composite fan-out: three consumers of rgb, two of density
+    B, R, N = 2, 24, 16
+    ray = cu(torch.from_numpy(rs.normal(size=(B, R, 3)).astype(np.float32)))
+    depth = cu(torch.from_numpy(np.sort(rs.uniform(0.5, 2.0, size=(B, R, N, 1)), axis=2).astype(np.float32)))
+    rgb_s = cu(torch.from_numpy(rs.uniform(size=(B, R, N, 3, 2)).astype(np.float32)))
+    den_s = cu(torch.from_numpy(rs.uniform(0.0, 3.0, size=(B, R, N, 2)).astype(np.float32)))
+    unc_s = cu(torch.from_numpy(rs.uniform(0.1, 1.0, size=(B, R, N, 1)).astype(np.float32)))
+    c1, c2, c3 = (cu(torch.from_numpy(rs.normal(size=(B, R, 3)).astype(np.float32))) for _ in range(3))
+    cd = cu(torch.from_numpy(rs.normal(size=(B, R, N, 2)).astype(np.float32)))
+    grads = []
+    for fan in (False, True):
+        r, d, u = rgb_s.clone().requires_grad_(), den_s.clone().requires_grad_(), unc_s.clone().requires_grad_()
+        out = autograd_ops.composite(ray, r, d, depth, u, 0.05, True, False, fan)
+        rgb_ray, unc_ray = out[4], out[5]
+        ra, rb, rc, dl = (rgb_ray, out[6], out[7], out[8]) if fan else (rgb_ray, rgb_ray, rgb_ray, d)
+        if fan:
+            assert torch.equal(rb, rgb_ray) and torch.equal(rc, rgb_ray) and torch.equal(dl, d)
+        ((ra * c1).sum() + (rb * c2).sum() + (rc * c3).sum() + (dl * cd).sum() + unc_ray.sum()).backward()
+        grads.append((r.grad.clone(), d.grad.clone(), u.grad.clone()))
+    for a, b in zip(*grads):
+        torch.testing.assert_close(b, a, rtol=2e-6, atol=1e-7)
+    # loss total + gate in one launch
+    terms = [cu(torch.tensor(v)) for v in (0.5, 2.0, float("nan"))]
+    bad, snap = torch.zeros(4, dtype=torch.int32, device=dev()), torch.zeros(4, dtype=torch.int32, device=dev())
+    t = ops.weighted_sum(terms[:2], [3.0, 0.25], flags=dict(bad=bad, word_finite=1, snapshot=snap))
+    assert float(t) == 0.5 * 3.0 + 2.0 * 0.25 and bad.tolist() == [0, 0, 0, 0] and snap.tolist() == [0, 0, 0, 0]
+    status = torch.ones(1, dtype=torch.int32, device=dev())
+    t = ops.weighted_sum(terms, [1.0, 1.0, 1.0], flags=dict(bad=bad, word_finite=2, snapshot=snap, status=status, word_status=0))
+    assert bool(torch.isnan(t)) and bad.tolist() == [1, 0, 1, 0] and snap.tolist() == [1, 0, 1, 0]
+    # R1 value, weighted value, weighted gradient
+    g = cu(torch.from_numpy(rs.normal(size=(4, 9, 16, 16)).astype(np.float32)))
+    out, og = ops.sumsq_mean_fwd_bwd(g, 10.0)
+    ref = g.double().pow(2).sum() / 4
+    assert abs(float(out[0]) - float(ref)) < 1e-5 * float(ref) and abs(float(out[1]) - 10 * float(ref)) < 1e-4 * float(ref)
+    torch.testing.assert_close(og, g * (2 * 10.0 / 4))
+    # both BCE terms and their cotangents
+    dr, df = cu(torch.from_numpy(rs.normal(size=7).astype(np.float32))), cu(torch.from_numpy(rs.normal(size=7).astype(np.float32)))
+    out2, gr, gf = ops.gan_disc_losses(dr, df, 2.0, 0.5)
+    a, b = dr.clone().requires_grad_(), df.clone().requires_grad_()
+    la, lb = F.binary_cross_entropy_with_logits(a, torch.ones_like(a)), F.binary_cross_entropy_with_logits(b, torch.zeros_like(b))
+    (2.0 * la + 0.5 * lb).backward()
+    torch.testing.assert_close(out2, torch.stack([la, lb]).detach(), rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(gr, a.grad, rtol=1e-5, atol=1e-8)
+    torch.testing.assert_close(gf, b.grad, rtol=1e-5, atol=1e-8)
+
+
 def test_weighted_sum_and_sn_uv_copies(ops):
     """tp_weighted_sum == torch.dot(stack(terms), weights); tp_sn_fwd's u / v copies equal the buffers after the power iteration."""
     rs = np.random.RandomState(3)

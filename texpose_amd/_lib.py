@@ -31,8 +31,8 @@ SYMBOLS = (
     "tp_conv4s2_workspace", "tp_conv4s2_fwd", "tp_conv4s2_dgrad", "tp_conv4s2_wgrad",
     "tp_conv3s1_workspace", "tp_conv3s1_fwd", "tp_conv3s1_dgrad",
     "tp_patch_coords", "tp_bce_logits_fwd", "tp_bce_logits_bwd", "tp_feat_inputs_fwd", "tp_feat_inputs_bwd", "tp_disc_inputs", "tp_step_flags", "tp_adam_step",
-    "tp_fake_patch_bwd", "tp_feat_pair_loss_fwd", "tp_feat_pair_loss_bwd", "tp_sumsq_mean_fwd", "tp_sumsq_mean_bwd", "tp_sumsq_mean_fwd_bwd", "tp_gan_disc_losses", "tp_latent_rows_fwd",
-    "tp_latent_rows_bwd", "tp_weighted_sum",
+    "tp_fake_patch_bwd", "tp_feat_pair_loss_fwd", "tp_feat_pair_loss_bwd", "tp_sumsq_mean_fwd", "tp_sumsq_mean_bwd", "tp_sumsq_mean_fwd_bwd", "tp_gan_disc_losses", "tp_maxpool2_fwd", "tp_maxpool2_bwd", "tp_latent_rows_fwd",
+    "tp_latent_rows_bwd", "tp_weighted_sum", "tp_weighted_sum_flags",
     "tp_disc_head_fwd", "tp_disc_head_bwd", "tp_disc_head_bwd_bwd",
     "tp_skinny_linear_fwd", "tp_skinny_linear_wgrad",
 )
@@ -80,7 +80,8 @@ class CompositeArgs(C.Structure):
 class CompositeBwdArgs(C.Structure):
     _fields_ = [("fwd", CompositeArgs), ("g_out_ray", vp), ("g_alpha_static", vp),
                 ("g_alpha_transient", vp), ("g_prob", vp), ("g_rgb", vp), ("g_density", vp),
-                ("g_uncert", vp), ("g_rgb_ray", vp), ("g_uncert_ray", vp)]
+                ("g_uncert", vp), ("g_rgb_ray", vp), ("g_uncert_ray", vp), ("g_rgb_ray2", vp), ("g_rgb_ray3", vp),
+                ("g_density_add", vp)]
 
 
 class PatchGatherArgs(C.Structure):
@@ -203,7 +204,7 @@ def load() -> C.CDLL:
     sig("tp_sn_fwd", [C.POINTER(SnWeight), C.c_int, C.c_int, vp])
     sig("tp_sn_bwd", [C.POINTER(SnWeight), C.c_int, vp])
     sig("tp_nerf_losses_fwd", [C.POINTER(NerfLossesArgs), vp])
-    sig("tp_nerf_losses_bwd", [C.POINTER(NerfLossesArgs), vp, vp, vp, vp, vp])
+    sig("tp_nerf_losses_bwd", [C.POINTER(NerfLossesArgs), vp, vp, vp, vp, vp, vp, vp])
     sig("tp_render_eval_workspace_bytes", [C.c_int, C.c_int, C.c_int], C.c_size_t)
     sig("tp_render_eval", [C.POINTER(RenderEvalArgs), vp])
     sig("tp_inorm_lrelu_fwd", [vp, C.c_int64, C.c_int, C.c_float, C.c_float, vp, vp, vp, vp])
@@ -230,8 +231,11 @@ def load() -> C.CDLL:
     sig("tp_sumsq_mean_fwd", [vp, C.c_int64, C.c_int, vp, vp])
     sig("tp_sumsq_mean_bwd", [vp, C.c_int64, C.c_int, vp, vp, vp])
     sig("tp_sumsq_mean_fwd_bwd", [vp, C.c_int64, C.c_int, C.c_float, vp, vp, vp])
+    sig("tp_maxpool2_fwd", [vp, C.c_int64, C.c_int, C.c_int, vp, vp, vp])
+    sig("tp_maxpool2_bwd", [vp, vp, C.c_int64, C.c_int, C.c_int, vp, vp])
     sig("tp_gan_disc_losses", [vp, vp, C.c_int, C.c_float, C.c_float, vp, vp, vp, vp])
     sig("tp_weighted_sum", [C.POINTER(vp), C.POINTER(C.c_float), C.c_int, vp, vp])
+    sig("tp_weighted_sum_flags", [C.POINTER(vp), C.POINTER(C.c_float), C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp])
     sig("tp_latent_rows_fwd", [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp])
     sig("tp_latent_rows_bwd", [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp])
     for name in ("tp_disc_head_fwd", "tp_disc_head_bwd", "tp_disc_head_bwd_bwd"):

@@ -19,32 +19,40 @@ SKIP_WEIGHT_GRADS = False
 
 
 class _Composite(torch.autograd.Function):
-    """out [..,14], alpha_static, alpha_transient, prob, rgb_ray [..,3], uncert_ray [..,1].  The last two are compact copies of
-    columns 0..2 / 13 of `out` written by the same launch: a training step consumes ONLY those two, as contiguous tensors
-    with their own cotangents -- slices of `out` cost a copy per consumer and a zero-fill + copy + add per slice backward."""
+    """out [..,14], alpha_static, alpha_transient, prob, rgb_ray [..,3], uncert_ray [..,1] (+ fan-out aliases).  rgb_ray /
+    uncert_ray are compact copies of columns 0..2 / 13 of `out` written by the same launch: a training step consumes ONLY those
+    two, as contiguous tensors with their own cotangents -- slices of `out` cost a copy per consumer and a zero-fill + copy +
+    add per slice backward.
+    ``fan_out``: three more outputs -- two aliases of rgb_ray and one of the density input.  A tensor with several consumers
+    costs autograd one `add` launch per extra consumer; a consumer that reads an alias instead sends its cotangent to THIS
+    node, and the composite backward sums all of them while it loads them (tp_composite_bwd_args.g_rgb_ray2/3, g_density_add)."""
 
     @staticmethod
-    def forward(ctx, ray, rgb, density, depth, uncert, min_uncert, per_sample, want_prob):
+    def forward(ctx, ray, rgb, density, depth, uncert, min_uncert, per_sample, want_prob, fan_out):
         out, a_s, a_t, prob, rgb_ray, unc_ray = ops.composite_fwd(ray, rgb, density, depth, uncert, min_uncert,
                                                                   per_sample=per_sample, want_prob=want_prob, compact=True)
         ctx.save_for_backward(ray, rgb, density, depth, uncert)
         ctx.min_uncert = min_uncert
         ctx.set_materialize_grads(False)
-        return out, a_s, a_t, prob, rgb_ray, unc_ray
+        if not fan_out:
+            return out, a_s, a_t, prob, rgb_ray, unc_ray, None, None, None
+        return out, a_s, a_t, prob, rgb_ray, unc_ray, rgb_ray.view_as(rgb_ray), rgb_ray.view_as(rgb_ray), density.view_as(density)
 
     @staticmethod
-    def backward(ctx, g_out, g_as, g_at, g_prob, g_rgb_ray, g_unc_ray):
+    def backward(ctx, g_out, g_as, g_at, g_prob, g_rgb_ray, g_unc_ray, g_rgb_ray2, g_rgb_ray3, g_density_alias):
         ray, rgb, density, depth, uncert = ctx.saved_tensors
         g_rgb, g_den, g_unc = ops.composite_bwd(ray, rgb, density, depth, uncert, g_out, g_as, g_at, g_prob, ctx.min_uncert,
-                                                g_rgb_ray=g_rgb_ray, g_uncert_ray=g_unc_ray)
-        return None, g_rgb, g_den, None, g_unc.view_as(uncert), None, None, None   # (ray, rgb, density, depth, uncert, ...)
+                                                g_rgb_ray=g_rgb_ray, g_uncert_ray=g_unc_ray, g_rgb_ray2=g_rgb_ray2,
+                                                g_rgb_ray3=g_rgb_ray3, g_density_add=g_density_alias)
+        return None, g_rgb, g_den, None, g_unc.view_as(uncert), None, None, None, None  # (ray, rgb, density, depth, uncert, ...)
 
 
-def composite(ray, rgb, density, depth, uncert, min_uncert, per_sample=True, want_prob=True):
+def composite(ray, rgb, density, depth, uncert, min_uncert, per_sample=True, want_prob=True, fan_out=False):
     """``per_sample`` / ``want_prob`` = False skip writing alpha_static / alpha_transient / prob ([B,R,N] each; the
     per-ray sums do not need them): the returned entries are then None.
-    -> (out [..,14], alpha_static, alpha_transient, prob, rgb_ray [..,3], uncert_ray [..,1])"""
-    return _Composite.apply(ray, rgb, density, depth, uncert, float(min_uncert), bool(per_sample), bool(want_prob))
+    -> (out [..,14], alpha_static, alpha_transient, prob, rgb_ray [..,3], uncert_ray [..,1], rgb_ray alias, rgb_ray alias,
+        density alias)   (the aliases None unless ``fan_out``)"""
+    return _Composite.apply(ray, rgb, density, depth, uncert, float(min_uncert), bool(per_sample), bool(want_prob), bool(fan_out))
 
 
 class _Mlp(torch.autograd.Function):
@@ -103,14 +111,16 @@ class _NerfLosses(torch.autograd.Function):
     def forward(ctx, rgb, uncert, density, gathered):
         sums, losses = ops.nerf_losses_fwd(rgb, uncert, density, gathered, want_losses=True)
         ctx.save_for_backward(rgb, uncert, density, gathered, sums)
+        ctx.set_materialize_grads(False)                    # (a term nobody back-propagates arrives as None, not as a zero fill)
         return losses[0], losses[1], losses[2]
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, g_render, g_unc, g_trans):
         rgb, uncert, density, gathered, sums = ctx.saved_tensors
-        g = torch.stack([g_render, g_unc, g_trans]).float()
-        g_rgb, g_u, g_d = ops.nerf_losses_bwd(rgb, uncert, density, gathered, sums, g)
+        if g_render is None and g_unc is None and g_trans is None:
+            return None, None, None, None
+        g_rgb, g_u, g_d = ops.nerf_losses_bwd(rgb, uncert, density, gathered, sums, (g_render, g_unc, g_trans))
         return g_rgb, g_u.view_as(uncert), g_d, None
 
 
@@ -229,6 +239,26 @@ class _Conv3s1BiasRelu(torch.autograd.Function):
 def conv3s1_bias_relu(x, w, bias, relu: bool):
     """relu?(conv2d(x, w, bias, padding 1)) for a frozen [Co,C,3,3] weight (K12)."""
     return _Conv3s1BiasRelu.apply(x.contiguous(), w, bias, bool(relu))
+
+
+class _MaxPool2(torch.autograd.Function):
+    """MaxPool2d(2, 2) with a backward that writes every input element (torch: zero fill + scatter), first order only."""
+
+    @staticmethod
+    def forward(ctx, x):
+        y, arg = ops.maxpool2_fwd(x)
+        ctx.save_for_backward(arg)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gy):
+        (arg,) = ctx.saved_tensors
+        return ops.maxpool2_bwd(gy.contiguous(), arg)
+
+
+def maxpool2(x):
+    return _MaxPool2.apply(x.contiguous())
 
 
 # ---- K13 pieces
@@ -408,12 +438,17 @@ class _FeatPairLoss(torch.autograd.Function):
         out = ops.feat_pair_loss_fwd(feat, w2)
         ctx.save_for_backward(feat)
         ctx.w2 = w2
-        return out[0], out[1:].detach()
+        ctx.set_materialize_grads(False)                    # (no zero fill for the cotangent of the logged parts)
+        parts = out[1:]
+        ctx.mark_non_differentiable(parts)
+        return out[0], parts
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, g, _g_parts):
         (feat,) = ctx.saved_tensors
+        if g is None:
+            return None, None
         return ops.feat_pair_loss_bwd(feat, ctx.w2, g.contiguous()), None
 
 

@@ -154,6 +154,9 @@ __global__ __launch_bounds__(kWaves * 64) void composite_bwd_kernel(tp_composite
 #pragma unroll
     for (int k = 0; k < 14; ++k) g[k] = b.g_out_ray ? b.g_out_ray[q * 14 + k] : 0.f;
     if (b.g_rgb_ray) { g[0] += b.g_rgb_ray[q * 3]; g[1] += b.g_rgb_ray[q * 3 + 1]; g[2] += b.g_rgb_ray[q * 3 + 2]; }
+    // cotangents of the two aliases of rgb_ray (each consumer of the colours back-propagates into its own: no add launches)
+    if (b.g_rgb_ray2) { g[0] += b.g_rgb_ray2[q * 3]; g[1] += b.g_rgb_ray2[q * 3 + 1]; g[2] += b.g_rgb_ray2[q * 3 + 2]; }
+    if (b.g_rgb_ray3) { g[0] += b.g_rgb_ray3[q * 3]; g[1] += b.g_rgb_ray3[q * 3 + 1]; g[2] += b.g_rgb_ray3[q * 3 + 2]; }
     if (b.g_uncert_ray) g[13] += b.g_uncert_ray[q];
     Carry carry = {0.f, 0.f, 0.f};
     for (int c = 0; c < n_chunks; ++c) {
@@ -188,7 +191,12 @@ __global__ __launch_bounds__(kWaves * 64) void composite_bwd_kernel(tp_composite
       const float gat = b.g_alpha_transient ? b.g_alpha_transient[e] : 0.f;
       const float dts = s.T * (s.es * A + s.e * C) - suf1 + s.Ts * s.es * D - suf2 + gas * s.es;
       const float dtt = s.T * (s.et * Bv + s.e * C) - suf1 + s.Tt * s.et * E - suf3 + gat * s.et;
-      *reinterpret_cast<float2*>(b.g_density + e * 2) = make_float2(dts * s.dist, dtt * s.dist);
+      float2 gd = make_float2(dts * s.dist, dtt * s.dist);
+      if (b.g_density_add) {            // a second cotangent of the densities (the transient regulariser's) joins here
+        const float2 ad = *reinterpret_cast<const float2*>(b.g_density_add + e * 2);
+        gd.x += ad.x; gd.y += ad.y;
+      }
+      *reinterpret_cast<float2*>(b.g_density + e * 2) = gd;
       const float ws = s.T * s.as, wt = s.T * s.at, os = s.Ts * s.as, ot = s.Tt * s.at;
       float2* gr = reinterpret_cast<float2*>(b.g_rgb + e * 6);
 #pragma unroll

@@ -84,12 +84,14 @@ __global__ __launch_bounds__(kBlock) void nerf_losses_finalize(const float* part
   }
 }
 
-// g[0..2]: upstream gradients of (render, uncert, trans_reg)
-__global__ __launch_bounds__(kBlock) void nerf_losses_bwd_kernel(tp_nerf_losses_args a, const double* sums, const float* g,
+// g_render / g_unc / g_trans: upstream gradients of (render, uncert, trans_reg), one device scalar each (NULL = 0)
+__global__ __launch_bounds__(kBlock) void nerf_losses_bwd_kernel(tp_nerf_losses_args a, const double* sums, const float* g_render,
+                                                                 const float* g_unc, const float* g_trans,
                                                                  float* g_rgb, float* g_uncert, float* g_density) {
   const int64_t n_pix = (int64_t)a.B * a.P, n_den = n_pix * a.N;
   const float inv_den = (float)(1.0 / (sums[1] + 1e-5));
-  const float gr = g[0] * inv_den, gu = g[1] / (float)n_pix, gt = g[2] / (float)n_den;
+  const float gr = (g_render ? g_render[0] : 0.f) * inv_den, gu = (g_unc ? g_unc[0] : 0.f) / (float)n_pix,
+              gt = (g_trans ? g_trans[0] : 0.f) / (float)n_den;
   for (int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x; q < n_pix; q += (int64_t)gridDim.x * kBlock) {
     const int64_t b = q / a.P, p = q - b * a.P;
     const float* gp = a.gathered + b * 14 * a.P + p;
@@ -129,11 +131,11 @@ extern "C" int tp_nerf_losses_fwd(const tp_nerf_losses_args* a, tp_stream_t stre
   return tp::check_launch("tp_nerf_losses_fwd");
 }
 
-extern "C" int tp_nerf_losses_bwd(const tp_nerf_losses_args* a, const float* g_losses, float* g_rgb, float* g_uncert,
-                                  float* g_density, tp_stream_t stream) {
+extern "C" int tp_nerf_losses_bwd(const tp_nerf_losses_args* a, const float* g_render, const float* g_unc, const float* g_trans,
+                                  float* g_rgb, float* g_uncert, float* g_density, tp_stream_t stream) {
   if (int rc = check(a, "tp_nerf_losses_bwd")) return rc;
-  if (!g_losses || !g_rgb || !g_uncert || !g_density) { tp::set_error("tp_nerf_losses_bwd: null gradient pointer"); return -1; }
+  if (!g_rgb || !g_uncert || !g_density) { tp::set_error("tp_nerf_losses_bwd: null gradient pointer"); return -1; }
   hipLaunchKernelGGL(nerf_losses_bwd_kernel, dim3(grid_for(a)), dim3(kBlock), 0, (hipStream_t)stream, *a, (const double*)a->sums,
-                     g_losses, g_rgb, g_uncert, g_density);
+                     g_render, g_unc, g_trans, g_rgb, g_uncert, g_density);
   return tp::check_launch("tp_nerf_losses_bwd");
 }

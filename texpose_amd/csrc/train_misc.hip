@@ -241,6 +241,40 @@ __global__ __launch_bounds__(kBlock) void sumsq_mean_bwd_kernel(const float* __r
   if (i < n) out[i] = 2.f * cot[0] / (float)B * g[i];
 }
 
+// ---- MaxPool2d(2, 2) of the feature network (layers/perceptual_loss.py:8-18, torchvision VGG19 "M" entries), x [n, H, W] (n = images
+// x channels, H and W even) -> y [n, H/2, W/2] and the window position of the maximum (first one in row-major order on ties, as
+// torch's kernel: strict > and NaN wins).  The backward writes all four inputs of a window: no zero fill before it.
+__global__ __launch_bounds__(kBlock) void maxpool2_fwd_kernel(const float* __restrict__ x, int64_t n_out, int H, int W, float* __restrict__ y,
+                                                               uint8_t* __restrict__ arg) {
+  const int64_t o = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (o >= n_out) return;
+  const int ow = W / 2, oh = H / 2;
+  const int64_t img = o / ((int64_t)oh * ow);
+  const int r = (int)(o - img * oh * ow), oy = r / ow, ox = r - oy * ow;
+  const float* p = x + (img * H + 2 * oy) * W + 2 * ox;
+  float best = p[0];
+  int k = 0;
+  const float v1 = p[1], v2 = p[W], v3 = p[W + 1];
+  if (v1 > best || v1 != v1) { best = v1; k = 1; }
+  if (v2 > best || v2 != v2) { best = v2; k = 2; }
+  if (v3 > best || v3 != v3) { best = v3; k = 3; }
+  y[o] = best;
+  arg[o] = (uint8_t)k;
+}
+__global__ __launch_bounds__(kBlock) void maxpool2_bwd_kernel(const float* __restrict__ gy, const uint8_t* __restrict__ arg, int64_t n_out, int H,
+                                                               int W, float* __restrict__ gx) {
+  const int64_t o = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (o >= n_out) return;
+  const int ow = W / 2, oh = H / 2;
+  const int64_t img = o / ((int64_t)oh * ow);
+  const int r = (int)(o - img * oh * ow), oy = r / ow, ox = r - oy * ow;
+  float* p = gx + (img * H + 2 * oy) * W + 2 * ox;
+  const float g = gy[o];
+  const int k = arg[o];
+  *reinterpret_cast<float2*>(p) = make_float2(k == 0 ? g : 0.f, k == 1 ? g : 0.f);
+  *reinterpret_cast<float2*>(p + W) = make_float2(k == 2 ? g : 0.f, k == 3 ? g : 0.f);
+}
+
 // ---- the same two in ONE launch for the explicit discriminator-step schedule (K16): every block writes its part of
 // out_g = 2 w g / B, block 0 also reduces the value (same fixed-order tree as above)
 __global__ __launch_bounds__(kRedBlock) void sumsq_mean_fwd_bwd_kernel(const float* __restrict__ g, int64_t n, int B, float w,
@@ -257,7 +291,7 @@ __global__ __launch_bounds__(kRedBlock) void sumsq_mean_fwd_bwd_kernel(const flo
     if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
     __syncthreads();
   }
-  if (threadIdx.x == 0) out[0] = red[0] / (float)B;
+  if (threadIdx.x == 0) { out[0] = red[0] / (float)B; out[1] = w * out[0]; }      // (the reference logs the WEIGHTED penalty, :151-153)
 }
 
 // ---- both GAN-loss terms of the discriminator step (model/nerf_adapt_st_gan.py:139-160) and their weighted cotangents in one
@@ -298,6 +332,19 @@ __global__ void weighted_sum_kernel(TermTable tb, float* __restrict__ out) {
   for (int k = 0; k < tb.n; ++k) acc += tb.t[k][0] * tb.w[k];          // ascending k, like torch.dot on the stacked terms
   out[0] = acc;
 }
+
+// ---- the loss total and the step gate in one launch: weighted_sum_kernel followed by step_flags_kernel on its result
+__global__ void weighted_sum_flags_kernel(TermTable tb, float* __restrict__ out, const int* status, int* bad, int n_bad, int word_status,
+                                          int word_finite, int* snapshot) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float acc = 0.f;
+  for (int k = 0; k < tb.n; ++k) acc += tb.t[k][0] * tb.w[k];
+  out[0] = acc;
+  if (status != nullptr && (status[0] & 1)) bad[word_status] |= 1;
+  if (!(acc - acc == 0.f)) bad[word_finite] |= 1;
+  for (int k = 0; k < n_bad; ++k) snapshot[k] = bad[k];
+}
+
 
 // ---- per-image latent rows (model/nerf_adapt_st_gan.py:589-593: Embedding.weight[var.idx]) of BOTH tables in one launch,
 // and their gradient: dense [n_rows, C] tables with g[r] = sum over the images b with idx[b] == r, in ascending b (no
@@ -429,6 +476,18 @@ int tp_sumsq_mean_fwd(const float* g, int64_t n, int B, float* out, tp_stream_t 
   hipLaunchKernelGGL(sumsq_mean_fwd_kernel, dim3(1), dim3(kRedBlock), 0, (hipStream_t)stream, g, n, B, out);
   return tp::check_launch("tp_sumsq_mean_fwd");
 }
+int tp_maxpool2_fwd(const float* x, int64_t n, int H, int W, float* y, uint8_t* arg, tp_stream_t stream) {
+  TP_REQUIRE(x && y && arg && n > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "bad arguments (even H, W)");
+  const int64_t n_out = n * (H / 2) * (W / 2);
+  hipLaunchKernelGGL(maxpool2_fwd_kernel, dim3((unsigned)((n_out + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream, x, n_out, H, W, y, arg);
+  return tp::check_launch("tp_maxpool2_fwd");
+}
+int tp_maxpool2_bwd(const float* gy, const uint8_t* arg, int64_t n, int H, int W, float* gx, tp_stream_t stream) {
+  TP_REQUIRE(gy && gx && arg && n > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "bad arguments (even H, W)");
+  const int64_t n_out = n * (H / 2) * (W / 2);
+  hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3((unsigned)((n_out + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream, gy, arg, n_out, H, W, gx);
+  return tp::check_launch("tp_maxpool2_bwd");
+}
 int tp_sumsq_mean_fwd_bwd(const float* g, int64_t n, int B, float w, float* out, float* out_g, tp_stream_t stream) {
   TP_REQUIRE(g && out && out_g && n > 0 && B > 0, "bad arguments");
   const int64_t blocks = (n + kRedBlock - 1) / kRedBlock;
@@ -463,6 +522,19 @@ int tp_latent_rows_bwd(const float* g_trans, const float* g_light, const int64_t
   hipLaunchKernelGGL(latent_rows_bwd_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, (hipStream_t)stream, g_trans, g_light, idx, B,
                      n_rows, C_trans, C_light, gw_trans, gw_light);
   return tp::check_launch("tp_latent_rows_bwd");
+}
+int tp_weighted_sum_flags(const float* const* terms, const float* weights, int n, float* out, const int32_t* mlp_status, int32_t* bad,
+                          int n_bad, int word_status, int word_finite, int32_t* snapshot, tp_stream_t stream) {
+  TP_REQUIRE(terms && weights && out && n > 0 && n <= 16, "1..16 terms expected");
+  TP_REQUIRE(bad && snapshot && n_bad > 0 && word_finite >= 0 && word_finite < n_bad && (!mlp_status || (word_status >= 0 && word_status < n_bad)),
+             "bad gate arguments");
+  TermTable tb;
+  for (int k = 0; k < 16; ++k) { tb.t[k] = k < n ? terms[k] : nullptr; tb.w[k] = k < n ? weights[k] : 0.f; }
+  for (int k = 0; k < n; ++k) TP_REQUIRE(terms[k] != nullptr, "null term");
+  tb.n = n;
+  hipLaunchKernelGGL(weighted_sum_flags_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, tb, out, mlp_status, bad, n_bad, word_status,
+                     word_finite, snapshot);
+  return tp::check_launch("tp_weighted_sum_flags");
 }
 int tp_weighted_sum(const float* const* terms, const float* weights, int n, float* out, tp_stream_t stream) {
   TP_REQUIRE(terms && weights && out && n > 0 && n <= 16, "1..16 terms expected");

@@ -190,7 +190,7 @@ class DiscStepSchedule:
             gw[l] = ops.conv4s2_wgrad(gs[l], xs[l])
             if l > 0:
                 c_a = ops.conv4s2_dgrad(c_z, W[l])
-        return f, r1.reshape(()), gw + [gW1, gW2, gW3]
+        return f, r1, gw + [gW1, gW2, gW3]
 
     # ------------------------------------------------------------------ the step
     def run(self, real, fake, scale, w_real: float, w_fake: float, w_reg: Optional[float], real_stack=None):
@@ -198,7 +198,7 @@ class DiscStepSchedule:
         to ``.grad`` of the `weight_orig` parameters (replacing what was there), in the reference's order of side effects: power
         iteration + D(real), [R1], power iteration + D(fake).  ``real_stack`` ([2B, ...], optional): a buffer whose first half IS
         `real` (ops.disc_inputs(stacked=True)); without it `real` is copied into one.
-        Returns AttrDict(d_real, d_fake, gan_disc_real, gan_disc_fake, gan_reg_real (unweighted, or None))."""
+        Returns AttrDict(d_real, d_fake, gan_disc_real, gan_disc_fake, gan_reg_real (unweighted, or None), gan_reg_real_weighted)."""
         B = real.shape[0]
         scale = scale.reshape(-1).contiguous()
         res = AttrDict(gan_reg_real=None)
@@ -218,7 +218,8 @@ class DiscStepSchedule:
             if real_stack is None or real_stack.shape[0] != 2 * B or real_stack.data_ptr() != real.data_ptr():
                 real_stack = torch.empty((2 * B,) + tuple(real.shape[1:]), device=real.device)
                 real_stack[:B].copy_(real)
-            f_real, res.gan_reg_real, gw_real = self._real_pass_with_r1(real_stack, n_real.w, scale, w_reg, fake_forward_and_losses)
+            f_real, r1, gw_real = self._real_pass_with_r1(real_stack, n_real.w, scale, w_reg, fake_forward_and_losses)
+            res.gan_reg_real, res.gan_reg_real_weighted = r1[0], r1[1]
         else:
             f_real = self._forward(real.contiguous(), n_real.w, scale)
             gw_real = self._backward_plain(f_real, n_real.w, fake_forward_and_losses(f_real.out))

@@ -272,6 +272,11 @@ class PerceptualLoss(nn.Module):
                 relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
                 x = autograd_ops.conv3s1_bias_relu(x, m.weight, m.bias, relu)
                 i += 2 if relu else 1
+            elif (isinstance(m, nn.MaxPool2d) and x.is_cuda and x.dtype == torch.float32 and m.kernel_size in (2, (2, 2))
+                  and m.stride in (2, (2, 2)) and m.padding in (0, (0, 0)) and m.dilation in (1, (1, 1)) and not m.ceil_mode
+                  and x.shape[-1] % 2 == 0 and x.shape[-2] % 2 == 0):
+                x = autograd_ops.maxpool2(x)                       # K13: the backward writes every element (no zero fill)
+                i += 1
             else:
                 x = m(x)
                 i += 1

@@ -140,12 +140,17 @@ class Graph(torch.nn.Module):
         # (not a reference option; default True keeps the reference's returned keys populated) alpha_static /
         # alpha_transient are not materialised either -- evaluate_full and validate only read per-ray maps
         per_sample = bool(opt.render.get("per_sample", True)) or torch.is_grad_enabled()
+        fan = dict(fan_out={}) if mode == "train" else {}
         (rgb, rgb_static, rgb_transient, depth_map, opacity, opacity_static, opacity_transient, _prob, uncert,
          alpha_static, alpha_transient) = self.nerf.composite(opt, ray, rgb_s, density_s, depth_samples, uncert_s,
-                                                              per_sample=per_sample, want_prob=False)
-        return edict(rgb=rgb, rgb_static=rgb_static, rgb_transient=rgb_transient, opacity=opacity,
-                     opacity_static=opacity_static, opacity_transient=opacity_transient, uncert=uncert,
-                     depth=depth_map, alpha_static=alpha_static, alpha_transient=alpha_transient, density=density_s)
+                                                              per_sample=per_sample, want_prob=False, **fan)
+        ret = edict(rgb=rgb, rgb_static=rgb_static, rgb_transient=rgb_transient, opacity=opacity,
+                    opacity_static=opacity_static, opacity_transient=opacity_transient, uncert=uncert,
+                    depth=depth_map, alpha_static=alpha_static, alpha_transient=alpha_transient, density=density_s)
+        # training: aliases of rgb / density for the feature loss, the discriminator patches and the transient regulariser --
+        # same values, own cotangents (summed inside the composite backward instead of one `add` launch per extra consumer)
+        ret.update(fan.get("fan_out") or {})
+        return ret
 
     def _range_guarded(self, opt, device, render_image):
         """``render_image()`` renders one whole image with the MLP kernel currently selected.  The f16x3 kernel raises a
@@ -269,8 +274,8 @@ class Graph(torch.nn.Module):
             if "gathered" in var and var.rgb.is_cuda and var.get("gathered_for") is var.ray_idx:
                 # K13: real / fake stacks in one launch (fake differentiable wrt rgb); the discriminator step of the same
                 # iteration re-uses them (same values: it detaches the very same render)
-                var.patch_real_nerf, patch_fake, var.patch_real_stack = autograd_ops.disc_patches(var.rgb, var.gathered, (h, w),
-                                                                                                  bool(opt.gan.geo_conditional))
+                var.patch_real_nerf, patch_fake, var.patch_real_stack = autograd_ops.disc_patches(
+                    var.get("rgb_disc", var.rgb), var.gathered, (h, w), bool(opt.gan.geo_conditional))
                 var.patch_fake_nerf, var.disc_patches_for = patch_fake, var.ray_idx
             else:
                 patch_fake = var.rgb.view(B, h, w, 3).permute(0, 3, 1, 2)
@@ -293,7 +298,7 @@ class Graph(torch.nn.Module):
         main = torch.cuda.current_stream(var.rgb.device)
         fs.wait_stream(main)
         with torch.cuda.stream(fs):
-            var.feat_early = self.perceptual_loss.loss_from_patches(var.rgb, var.gathered, hw, 5.0)
+            var.feat_early = self.perceptual_loss.loss_from_patches(var.get("rgb_feat", var.rgb), var.gathered, hw, 5.0)
         var.feat_early_for = var.ray_idx
 
     def disc_patch_stacks(self, opt, var):
@@ -390,8 +395,8 @@ class Graph(torch.nn.Module):
             fused = ("gathered" in var and opt.nerf.mask_obj and lw.render is not None and lw.uncert is not None
                      and lw.trans_reg is not None and lw.mask is None and var.rgb.is_cuda)
             if fused:
-                loss.render, loss.uncert, loss.trans_reg = autograd_ops.nerf_losses(var.rgb, var.uncert, var.density,
-                                                                                     var.gathered)
+                loss.render, loss.uncert, loss.trans_reg = autograd_ops.nerf_losses(var.rgb, var.uncert,
+                                                                                     var.get("density_losses", var.density), var.gathered)
             elif var.rgb.is_cuda:
                 # non-reference option combinations (a term switched off, mask_obj = False, full-image losses): the terms are
                 # formed with torch element-wise ops on the render outputs -- same values, many small launches.  Said once.
@@ -419,7 +424,7 @@ class Graph(torch.nn.Module):
                     loss.feat, l1 = var.feat_early, None
                 elif fused_feat and hasattr(self.perceptual_loss, "loss_from_patches"):
                     # K13 + K12: inputs of the four batches in one launch, one pass through the network, l1 + 5 l2 in one launch
-                    loss.feat = self.perceptual_loss.loss_from_patches(var.rgb, var.gathered, (h, w), 5.0)
+                    loss.feat = self.perceptual_loss.loss_from_patches(var.get("rgb_feat", var.rgb), var.gathered, (h, w), 5.0)
                     l1 = None
                 elif fused_feat:
                     l1, l2 = self.perceptual_loss.pairs_from_patches(var.rgb, var.gathered, (h, w))

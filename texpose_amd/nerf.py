@@ -159,13 +159,18 @@ class NeRF(torch.nn.Module):
 
     @staticmethod
     def composite(opt, ray, rgb_samples, density_samples, depth_samples, uncert_samples=None, per_sample=True,
-                  want_prob=True):
+                  want_prob=True, fan_out=None):
         """11-tuple of the reference (layers/...light.py:168-212): rgb, rgb_static, rgb_transient, depth, opacity,
         opacity_static, opacity_transient, prob [B,R,N,1], uncert, alpha_static, alpha_transient [B,R,N].
         ``want_prob`` / ``per_sample`` = False (not in the reference signature) leave prob / the two alphas unwritten and
-        return None in their place: Graph.render never uses ``prob`` (reference :599-606 discards it as well)."""
-        out, a_s, a_t, prob, rgb_ray, unc_ray = autograd_ops.composite(ray, rgb_samples, density_samples, depth_samples,
-                                                                       uncert_samples, opt.nerf.min_uncert, per_sample, want_prob)
+        return None in their place: Graph.render never uses ``prob`` (reference :599-606 discards it as well).
+        ``fan_out`` (a dict, not in the reference signature): filled with aliases ``rgb_feat`` / ``rgb_disc`` of the rgb output and
+        ``density_losses`` of the density input for the second / third consumer of a training step (autograd_ops._Composite)."""
+        want_fan = fan_out is not None and torch.is_grad_enabled() and rgb_samples.requires_grad
+        out, a_s, a_t, prob, rgb_ray, unc_ray, rgb_b, rgb_c, den_b = autograd_ops.composite(
+            ray, rgb_samples, density_samples, depth_samples, uncert_samples, opt.nerf.min_uncert, per_sample, want_prob, want_fan)
+        if want_fan:
+            fan_out.update(rgb_feat=rgb_b, rgb_disc=rgb_c, density_losses=den_b)
         f = {name: out[..., lo:hi] for name, lo, hi in ops.COMPOSITE_RAY_FIELDS}
         # rgb / uncert: the compact tensors the kernel wrote next to `out` (same values; contiguous, own cotangents)
         return (rgb_ray, f["rgb_static"], f["rgb_transient"], f["depth"], f["opacity"], f["opacity_static"],

@@ -454,14 +454,16 @@ def composite_fwd(ray, rgb, density, depth, uncert, min_uncert: float = 0.05, pe
 @_on_tensor_device
 def composite_bwd(ray, rgb, density, depth, uncert, g_out: Optional[Tensor], g_alpha_s: Optional[Tensor] = None,
                   g_alpha_t: Optional[Tensor] = None, g_prob: Optional[Tensor] = None, min_uncert: float = 0.05,
-                  g_rgb_ray: Optional[Tensor] = None, g_uncert_ray: Optional[Tensor] = None):
+                  g_rgb_ray: Optional[Tensor] = None, g_uncert_ray: Optional[Tensor] = None, g_rgb_ray2: Optional[Tensor] = None,
+                  g_rgb_ray3: Optional[Tensor] = None, g_density_add: Optional[Tensor] = None):
     """``g_out`` [..,14] may be None when the cotangent arrives through ``g_rgb_ray`` [..,3] / ``g_uncert_ray`` [..,1] (they
-    are ADDED to columns 0..2 / 13 of g_out inside the kernel)."""
+    are ADDED to columns 0..2 / 13 of g_out inside the kernel; ``g_rgb_ray2`` / ``g_rgb_ray3`` likewise).  ``g_density_add``
+    [..,N,2] is added to the returned density gradient."""
     lib = _lib.load()
     b = CompositeBwdArgs()
     fa, keep = _composite_args(ray, rgb, density, depth, uncert, min_uncert)
     b.fwd = fa
-    if g_out is None and g_rgb_ray is None and g_uncert_ray is None:
+    if g_out is None and g_rgb_ray is None and g_uncert_ray is None and g_rgb_ray2 is None and g_rgb_ray3 is None:
         g_out = torch.zeros(*keep[0].shape[:-1], 14, device=keep[0].device)
     g_out = None if g_out is None else _f32(g_out, "g_out")
     g_rgb_ray = None if g_rgb_ray is None else _f32(g_rgb_ray, "g_rgb_ray")
@@ -469,6 +471,10 @@ def composite_bwd(ray, rgb, density, depth, uncert, g_out: Optional[Tensor], g_a
     opt = [None if g is None else _f32(g, "g") for g in (g_alpha_s, g_alpha_t, g_prob)]
     g_rgb, g_den, g_unc = torch.empty_like(keep[1]), torch.empty_like(keep[2]), torch.empty_like(keep[4])
     b.g_out_ray, b.g_rgb_ray, b.g_uncert_ray = _ptr(g_out), _ptr(g_rgb_ray), _ptr(g_uncert_ray)
+    extra = [None if g is None else _f32(g, "g") for g in (g_rgb_ray2, g_rgb_ray3, g_density_add)]
+    if extra[2] is not None and extra[2].numel() != keep[2].numel():
+        raise ValueError("composite_bwd: g_density_add must have the shape of density")
+    b.g_rgb_ray2, b.g_rgb_ray3, b.g_density_add = _ptr(extra[0]), _ptr(extra[1]), _ptr(extra[2])
     b.g_alpha_static, b.g_alpha_transient, b.g_prob = _ptr(opt[0]), _ptr(opt[1]), _ptr(opt[2])
     b.g_rgb, b.g_density, b.g_uncert = g_rgb.data_ptr(), g_den.data_ptr(), g_unc.data_ptr()
     check(lib.tp_composite_bwd(C.byref(b), _stream()), "tp_composite_bwd")
@@ -600,14 +606,20 @@ def nerf_losses_fwd(rgb: Tensor, uncert: Tensor, density: Tensor, gathered: Tens
 
 
 @_on_tensor_device
-def nerf_losses_bwd(rgb: Tensor, uncert: Tensor, density: Tensor, gathered: Tensor, sums: Tensor, g_losses: Tensor):
-    """Gradients wrt rgb, uncert, density for upstream gradients g_losses [3] (render, uncert, trans_reg)."""
+def nerf_losses_bwd(rgb: Tensor, uncert: Tensor, density: Tensor, gathered: Tensor, sums: Tensor, g_losses):
+    """Gradients wrt rgb, uncert, density for the upstream gradients of (render, uncert, trans_reg): ``g_losses`` is a [3] tensor or
+    a triple of 0-dim tensors / None (None = zero; no stacking launch)."""
     lib, a, keep = _nerf_losses_args(rgb, uncert, density, gathered)
     ws = torch.empty(4, device=rgb.device)
     a.workspace, a.sums = ws.data_ptr(), sums.data_ptr()
-    g_losses = _f32(g_losses, "g_losses")
+    if torch.is_tensor(g_losses):
+        g_losses = _f32(g_losses, "g_losses")
+        gs = [g_losses[k] for k in range(3)]
+    else:
+        gs = [None if g is None else _f32(g, "g_loss") for g in g_losses]
+    ptrs = [None if g is None else g.data_ptr() for g in gs]
     g_rgb, g_unc, g_den = torch.empty_like(keep[0]), torch.empty_like(keep[1]), torch.empty_like(keep[2])
-    check(lib.tp_nerf_losses_bwd(C.byref(a), g_losses.data_ptr(), g_rgb.data_ptr(), g_unc.data_ptr(), g_den.data_ptr(),
+    check(lib.tp_nerf_losses_bwd(C.byref(a), ptrs[0], ptrs[1], ptrs[2], g_rgb.data_ptr(), g_unc.data_ptr(), g_den.data_ptr(),
                                  _stream()), "tp_nerf_losses_bwd")
     return g_rgb, g_unc, g_den
 
@@ -957,11 +969,34 @@ def sumsq_mean_bwd(g: Tensor, cot: Tensor) -> Tensor:
 
 
 @_on_tensor_device
+def maxpool2_fwd(x: Tensor):
+    """MaxPool2d(2, 2) of x [N,C,H,W] (H, W even) -> (y [N,C,H/2,W/2], arg uint8: window position of the maximum)."""
+    lib = _lib.load()
+    x = _f32(x, "x")
+    N, Cc, H, W = x.shape
+    y = torch.empty(N, Cc, H // 2, W // 2, device=x.device)
+    arg = torch.empty(N, Cc, H // 2, W // 2, device=x.device, dtype=torch.uint8)
+    check(lib.tp_maxpool2_fwd(x.data_ptr(), N * Cc, H, W, y.data_ptr(), arg.data_ptr(), _stream()), "tp_maxpool2_fwd")
+    return y, arg
+
+
+@_on_tensor_device
+def maxpool2_bwd(gy: Tensor, arg: Tensor) -> Tensor:
+    lib = _lib.load()
+    gy = _f32(gy, "gy")
+    N, Cc, oh, ow = gy.shape
+    gx = torch.empty(N, Cc, 2 * oh, 2 * ow, device=gy.device)
+    check(lib.tp_maxpool2_bwd(gy.data_ptr(), arg.data_ptr(), N * Cc, 2 * oh, 2 * ow, gx.data_ptr(), _stream()), "tp_maxpool2_bwd")
+    return gx
+
+
+@_on_tensor_device
 def sumsq_mean_fwd_bwd(g: Tensor, w: float, out_g: Optional[Tensor] = None):
-    """(sum(g^2) / B [1], 2 w g / B) for g [B, ...] in one launch: value and weighted gradient of the R1 penalty (K16)."""
+    """([sum(g^2) / B, w sum(g^2) / B], 2 w g / B) for g [B, ...] in one launch: value, weighted value (what the reference logs) and
+    weighted gradient of the R1 penalty (K16)."""
     lib = _lib.load()
     g = _f32(g, "g")
-    out, og = torch.empty(1, device=g.device), _out_like(out_g, g)
+    out, og = torch.empty(2, device=g.device), _out_like(out_g, g)
     check(lib.tp_sumsq_mean_fwd_bwd(g.data_ptr(), g.numel(), g.shape[0], float(w), out.data_ptr(), og.data_ptr(), _stream()),
           "tp_sumsq_mean_fwd_bwd")
     return out, og
@@ -984,15 +1019,22 @@ def gan_disc_losses(d_real: Tensor, d_fake: Tensor, w_real: float, w_fake: float
 
 
 @_on_tensor_device
-def weighted_sum(terms, weights) -> Tensor:
-    """sum_k weights[k] * terms[k] for 0-dim float32 device tensors and host floats, one launch."""
+def weighted_sum(terms, weights, flags=None) -> Tensor:
+    """sum_k weights[k] * terms[k] for 0-dim float32 device tensors and host floats, one launch.  ``flags`` = dict(bad,
+    word_finite, snapshot[, status, word_status]): `step_flags` on the result in the same launch (tp_weighted_sum_flags)."""
     lib = _lib.load()
     n = len(terms)
     ts = [_f32(t.detach(), "term") for t in terms]
     ptrs = (C.c_void_p * n)(*[t.data_ptr() for t in ts])
     ws = (C.c_float * n)(*[float(w) for w in weights])
     out = torch.empty((), device=ts[0].device)
-    check(lib.tp_weighted_sum(ptrs, ws, n, out.data_ptr(), _stream()), "tp_weighted_sum")
+    if flags is None:
+        check(lib.tp_weighted_sum(ptrs, ws, n, out.data_ptr(), _stream()), "tp_weighted_sum")
+    else:
+        bad = flags["bad"]
+        check(lib.tp_weighted_sum_flags(ptrs, ws, n, out.data_ptr(), _ptr(flags.get("status")), bad.data_ptr(), bad.numel(),
+                                        int(flags.get("word_status", 0)), int(flags["word_finite"]), flags["snapshot"].data_ptr(),
+                                        _stream()), "tp_weighted_sum_flags")
     return out
 
 

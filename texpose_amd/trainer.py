@@ -187,8 +187,9 @@ class GanTrainer:
             cache[key] = torch.tensor(10 ** float(exponent), device=dev)
         return cache[key]
 
-    def _weighted_total(self, loss):
-        """``loss.all`` = detached sum 10^w_k loss_k (logging, the finite check); returns the terms and their weights."""
+    def _weighted_total(self, loss, flags=None):
+        """``loss.all`` = detached sum 10^w_k loss_k (logging, the finite check); returns the terms and their weights.
+        ``flags``: the step-gate update for this total (ops.step_flags arguments), folded into the same launch where possible."""
         opt = self.opt
         keys = [k for k in loss if k != "all" and opt.loss_weight[k] is not None]
         for k in loss:
@@ -201,9 +202,12 @@ class GanTrainer:
             cache[vec_key] = torch.stack(ws)
         with torch.no_grad():
             if dev.type == "cuda" and len(keys) <= 16 and all(loss[k].dtype == torch.float32 for k in keys):
-                loss.all = ops.weighted_sum([loss[k] for k in keys], [10 ** float(opt.loss_weight[k]) for k in keys])   # K13: one launch
+                loss.all = ops.weighted_sum([loss[k] for k in keys], [10 ** float(opt.loss_weight[k]) for k in keys], flags=flags)   # K13: one launch
             else:
                 loss.all = torch.dot(torch.stack([loss[k].detach() for k in keys]), cache[vec_key])
+                if flags is not None:
+                    ops.step_flags(loss.all, flags["bad"], flags["word_finite"], flags["snapshot"], status=flags.get("status"),
+                                   word_status=flags.get("word_status", 0))
         return [loss[k] for k in keys], ws
 
     def _backward_weighted(self, loss):
@@ -302,14 +306,20 @@ class GanTrainer:
                 loss.gan_reg_real = res.gan_reg_real
             loss.gan_disc_fake = res.gan_disc_fake
             keys = list(loss.keys())                               # (real, R1, fake: the order of the autograd form's total)
-            total = ops.weighted_sum([loss[k] for k in keys], [w(k) for k in keys])
+            flags = self._disc_gate_flags()                        # (captured step: the gate update rides in the same launch)
+            total = ops.weighted_sum([loss[k] for k in keys], [w(k) for k in keys], flags=flags)
             if res.gan_reg_real is not None:                       # logged WEIGHTED, as the reference does (:151-153)
-                loss.gan_reg_real = self._weight(lw.gan_reg_real, total.device) * res.gan_reg_real
+                loss.gan_reg_real = res.gan_reg_real_weighted
+        self._disc_flagged = flags is not None
         if apply:
-            self.disc_apply(total)
+            self.disc_apply(None if flags is not None else total)
         else:
             self._disc_total = total
         return var, loss
+
+    def _disc_gate_flags(self):
+        """ops.step_flags arguments of the discriminator gate when the loss total's launch should carry them (captured step)."""
+        return None
 
     def disc_apply(self, total):
         self._guard_disc(total)
@@ -445,6 +455,9 @@ class GraphedGanTrainer(GanTrainer):
         """Fold the finiteness of the discriminator loss into the sticky words and snapshot them as the discriminator gate."""
         ops.step_flags(total, self._bad, 2, self._gate_disc)
 
+    def _disc_gate_flags(self):
+        return dict(bad=self._bad, word_finite=2, snapshot=self._gate_disc)
+
     def _guard_disc(self, total=None):
         if total is not None:
             self._flag_disc(total)
@@ -505,8 +518,12 @@ class GraphedGanTrainer(GanTrainer):
         if opt.nerf.sample_stratified and "jitter_rand" not in var:   # (a caller-supplied static tensor wins: tests)
             var.jitter_rand = torch.rand(B, R, opt.nerf.sample_intvs, 1, device=var.ray_idx.device)
         var, loss = self.nerf_forward_loss(var)
-        terms, ws = self._weighted_total(loss)
-        self._flag_nerf(loss)
+        # loss total + step gate in one launch: this forward's range flag and the finiteness of its loss go into the sticky words,
+        # which are snapshot as the nerf gate BEFORE the backward and before the branches fork (so the gate also sees a
+        # discriminator flag of earlier steps, never a concurrent write of this one)
+        status = ops.mlp_status(dev) if self._uses_f16x3() else None
+        terms, ws = self._weighted_total(loss, flags=dict(bad=self._bad, word_finite=1, snapshot=self._gate_nerf, status=status,
+                                                          word_status=0))
         dloss = None
         # optimiser steps (and reductions) after this function: whenever a collective is part of the step, or on request
         self._deferred = self._has_collective() or self._split_around_collectives()
@@ -547,8 +564,9 @@ class GraphedGanTrainer(GanTrainer):
             disc.prefetch_spectral_weights(n)
 
     def disc_step(self, var, apply=True):
+        self._disc_flagged = False
         var, loss = super().disc_step(var, apply=apply)
-        if not apply:
+        if not apply and not self._disc_flagged:
             self._flag_disc(self._disc_total)                     # (before the join: the reductions carry the word)
         return var, loss
 
