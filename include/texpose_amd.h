@@ -69,6 +69,8 @@ typedef struct tp_raygen_args {
                             * range.  Reproduces the zero padding of the stored bound maps when a detection crop leaves
                             * the camera frame (data/lm.py:455-495 Crop_by_Pad, :349-350).  NULL = no rectangle. */
   uint64_t seed, offset;  /* TP_JITTER_PHILOX */
+  const uint64_t* offset_dev; /* TP_JITTER_PHILOX, optional: a device word ADDED to offset (the step counter of a captured training
+                               * step: the same launch draws different numbers at every replay) */
   int B, R, H, W, N;      /* N = samples per ray (0: no depth output) */
   int pixel_mode, bounds_mode, jitter_mode;
   float* center;          /* [B,R,3] out */
@@ -409,9 +411,12 @@ int tp_conv3s1_dgrad(const tp_conv3s1_args* args, tp_stream_t stream);
 /* FlexPatchSampler.__call__ (reference tools/patch_sampler.py:80-114).  u [3,B] uniforms (scale, x shift,
  * y shift), lattice [p] = linspace(-1, 1, p); the annealed lower scale bound from device memory (lo_dev, a captured step)
  * or from the host (lo_host, span_host = (float)(hi - lo) formed in double like the reference's Python arithmetic).
- * coords [B,p,p,2] in grid_sample (x, y) order, scales [B]. */
+ * coords [B,p,p,2] in grid_sample (x, y) order, scales [B].
+ * u == NULL: the uniforms are drawn inside the kernel -- Philox4x32-10, key = seed, counter (b, c_lo, 'patc', c_hi) with c = *counter
+ * (a device word: the step counter of a captured training step; NULL = 0), words x, y, z -> scale, x shift, y shift of image b. */
 int tp_patch_coords(const float* u, int B, int p, const float* lattice, const float* lo_dev, float lo_host, float span_host,
-                    float hi, int random_scale, int random_shift, float* coords, float* scales, tp_stream_t stream);
+                    float hi, int random_scale, int random_shift, uint64_t seed, const uint64_t* counter, float* coords, float* scales,
+                    tp_stream_t stream);
 /* mean binary_cross_entropy_with_logits(x [n], target) for a constant target (compute_gan_loss 'standard',
  * model/nerf_adapt_st_gan.py:809-823): out [1]; backward gx [n] = g[0] (sigmoid(x) - target) / n. */
 int tp_bce_logits_fwd(const float* x, int n, float target, float* out, tp_stream_t stream);
@@ -482,7 +487,8 @@ int tp_gan_disc_losses(const float* d_real, const float* d_fake, int n, float w_
 int tp_weighted_sum(const float* const* terms, const float* weights, int n, float* out, tp_stream_t stream);
 /* the same followed by tp_step_flags on the result, in one launch (the captured training step: loss total + step gate) */
 int tp_weighted_sum_flags(const float* const* terms, const float* weights, int n, float* out, const int32_t* mlp_status, int32_t* bad,
-                          int n_bad, int word_status, int word_finite, int32_t* snapshot, tp_stream_t stream);
+                          int n_bad, int word_status, int word_finite, int32_t* snapshot, uint64_t* step_counter /* optional: += 1 */,
+                          tp_stream_t stream);
 int tp_latent_rows_fwd(const float* w_trans, const float* w_light, const int64_t* idx, int B, int C_trans, int C_light, float* out_trans,
                        float* out_light, tp_stream_t stream);
 int tp_latent_rows_bwd(const float* g_trans, const float* g_light, const int64_t* idx, int B, int n_rows, int C_trans, int C_light,

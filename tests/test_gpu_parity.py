@@ -1957,6 +1957,39 @@ def test_round3_glue_kernels_match_torch(ops):
     torch.testing.assert_close(rgb.grad, cot[:, :3].permute(0, 2, 3, 1).reshape(B, p * p, 3))
 
 
+def test_device_counter_random_streams(ops):
+    """The random draws of a captured training step: tp_patch_coords with u = NULL equals the same kernel fed the Philox words
+    (key = seed, counter (b, c_lo, 'patc', c_hi)) computed by the oracle's Philox; tp_raygen with offset_dev equals offset passed on
+    the host; the loss-total launch advances the counter."""
+    seed, B, p = 0x1234_5678_9ABC, 5, 16
+    for c in (0, 7, (3 << 32) + 11):
+        counter = torch.tensor([c], dtype=torch.int64, device=dev())
+        ctr = np.zeros((B, 4), dtype=np.uint32)
+        ctr[:, 0], ctr[:, 1], ctr[:, 2], ctr[:, 3] = np.arange(B), c & 0xFFFFFFFF, 0x70617463, (c >> 32) & 0xFFFFFFFF
+        w = O.philox4x32(ctr, (seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF))
+        u = ((w[:, :3] >> np.uint32(8)).astype(np.float32) * np.float32(2.0 ** -24)).T.copy()            # [3, B]
+        want = ops.patch_coords(cu(torch.from_numpy(u)).reshape(3, B, 1, 1, 1), p, 0.25, 1.0)
+        got = ops.patch_coords(None, p, 0.25, 1.0, nbatch=B, seed=seed, counter=counter)
+        assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+    # ray-gen: device offset == host offset
+    rs = np.random.RandomState(2)
+    H = W = 32
+    intr = cu(torch.tensor([[60.0, 0, 16], [0, 60.0, 16], [0, 0, 1]]).repeat(2, 1, 1))
+    pose = cu(torch.eye(4)[:3].repeat(2, 1, 1))
+    zn, zf = cu(torch.full((2, H * W), 0.5)), cu(torch.full((2, H * W), 2.0))
+    coords = cu(torch.from_numpy(rs.uniform(-1, 1, size=(2, 8, 8, 2)).astype(np.float32)))
+    a = ops.raygen(intr, pose, H=H, W=W, n_samples=16, coords=coords, z_near=zn, z_far=zf, jitter=ops.JITTER_PHILOX, seed=9, offset=41)
+    off = torch.tensor([40], dtype=torch.int64, device=dev())
+    b = ops.raygen(intr, pose, H=H, W=W, n_samples=16, coords=coords, z_near=zn, z_far=zf, jitter=ops.JITTER_PHILOX, seed=9, offset=1,
+                   offset_dev=off)
+    assert torch.equal(a[4], b[4])
+    # the counter is advanced by the loss-total launch
+    bad, snap = torch.zeros(4, dtype=torch.int32, device=dev()), torch.zeros(4, dtype=torch.int32, device=dev())
+    for k in range(3):
+        ops.weighted_sum([cu(torch.tensor(1.0))], [1.0], flags=dict(bad=bad, word_finite=1, snapshot=snap, step_counter=off))
+    assert int(off) == 43
+
+
 def test_round3_launch_diet_pieces(ops):
     """Pieces of the launch diet, each against torch: MaxPool2d(2,2) forward / backward (ties after ReLU included), the composite
     backward with the cotangents of the rgb aliases and the density alias summed inside the launch (== engine adds), the loss total

@@ -43,7 +43,7 @@ vp = C.c_void_p
 class RaygenArgs(C.Structure):
     _fields_ = [("intr", vp), ("pose", vp), ("coords", vp), ("ray_idx", vp), ("z_near", vp),
                 ("z_far", vp), ("rand", vp), ("aabb_min", C.c_float * 3), ("aabb_max", C.c_float * 3),
-                ("bg_near", C.c_float), ("bg_far", C.c_float), ("valid_rect", vp), ("seed", C.c_uint64), ("offset", C.c_uint64),
+                ("bg_near", C.c_float), ("bg_far", C.c_float), ("valid_rect", vp), ("seed", C.c_uint64), ("offset", C.c_uint64), ("offset_dev", vp),
                 ("B", C.c_int), ("R", C.c_int), ("H", C.c_int), ("W", C.c_int), ("N", C.c_int),
                 ("pixel_mode", C.c_int), ("bounds_mode", C.c_int), ("jitter_mode", C.c_int),
                 ("center", vp), ("ray", vp), ("near", vp), ("far", vp), ("depth", vp)]
@@ -219,7 +219,7 @@ def load() -> C.CDLL:
     sig("tp_conv3s1_workspace", [C.POINTER(Conv3s1Args), C.c_int, C.POINTER(C.c_int64)], C.c_int64)
     for name in ("tp_conv3s1_fwd", "tp_conv3s1_dgrad"):
         sig(name, [C.POINTER(Conv3s1Args), vp])
-    sig("tp_patch_coords", [vp, C.c_int, C.c_int, vp, vp, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, vp, vp, vp])
+    sig("tp_patch_coords", [vp, C.c_int, C.c_int, vp, vp, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, C.c_uint64, vp, vp, vp, vp])
     sig("tp_bce_logits_fwd", [vp, C.c_int, C.c_float, vp, vp])
     sig("tp_bce_logits_bwd", [vp, C.c_int, C.c_float, vp, vp, vp])
     sig("tp_feat_inputs_fwd", [C.POINTER(FeatInputsArgs), vp, vp])
@@ -235,7 +235,7 @@ def load() -> C.CDLL:
     sig("tp_maxpool2_bwd", [vp, vp, C.c_int64, C.c_int, C.c_int, vp, vp])
     sig("tp_gan_disc_losses", [vp, vp, C.c_int, C.c_float, C.c_float, vp, vp, vp, vp])
     sig("tp_weighted_sum", [C.POINTER(vp), C.POINTER(C.c_float), C.c_int, vp, vp])
-    sig("tp_weighted_sum_flags", [C.POINTER(vp), C.POINTER(C.c_float), C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp])
+    sig("tp_weighted_sum_flags", [C.POINTER(vp), C.POINTER(C.c_float), C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp])
     sig("tp_latent_rows_fwd", [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp])
     sig("tp_latent_rows_bwd", [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp])
     for name in ("tp_disc_head_fwd", "tp_disc_head_bwd", "tp_disc_head_bwd_bwd"):

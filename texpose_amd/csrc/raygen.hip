@@ -91,18 +91,8 @@ __device__ __forceinline__ float bilin_map(const Bilin& b, const float* __restri
   return bilin_apply(b, v00, v10, v01, v11);
 }
 
-// Philox4x32-10 (Salmon et al., SC'11); stream layout documented in oracle.philox_uniform.
-__device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) {
-#pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    const uint32_t hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
-    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
-    c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
-    k.x += 0x9E3779B9u; k.y += 0xBB67AE85u;
-  }
-  return c;
-}
-__device__ __forceinline__ float u01(uint32_t w) { return (float)(w >> 8) * 5.9604644775390625e-08f; }
+using tp::philox4x32_10;
+using tp::u01;
 
 __device__ __forceinline__ float strat(float r, int i, float fN, float span, float near) {
   // ((rand + i) / N) * (far - near) + near, each op rounded as in the reference expression
@@ -115,6 +105,7 @@ struct Args {
   float amin[3], amax[3], bg_near, bg_far;
   const float* valid_rect;
   uint64_t seed, offset;
+  const uint64_t* offset_dev;
   int B, R, H, W, N, pixel_mode, bounds_mode, jitter_mode;
   float* center; float* ray; float* near; float* far; float* depth;
 };
@@ -136,14 +127,18 @@ __device__ __forceinline__ void slab(const float* amin, const float* amax, const
   valid = (tf > 0.0f) && (tf > tn);
 }
 
+// TILE rays per workgroup of kTile threads: 256 for image-sized launches (one ray per thread, then 256 N depths written by the
+// workgroup), 32 for patch-sized ones (a training step has 1,024 rays: 4 workgroups would each walk 16 K depths -- and, with the
+// in-kernel Philox draw, 16 x 10 rounds per thread -- on the step's critical path; 32 workgroups take an eighth of that).
+template <int TILE>
 __global__ __launch_bounds__(kTile) void raygen_kernel(Args a) {
-  __shared__ float s_near[kTile];
-  __shared__ float s_span[kTile];
+  __shared__ float s_near[TILE];
+  __shared__ float s_span[TILE];
   const int64_t total = (int64_t)a.B * a.R;
-  const int64_t tile0 = (int64_t)blockIdx.x * kTile;
+  const int64_t tile0 = (int64_t)blockIdx.x * TILE;
   const int64_t q = tile0 + threadIdx.x;
   float near = 0.0f, far = 0.0f;
-  if (q < total) {
+  if ((int)threadIdx.x < TILE && q < total) {
     const int b = (int)(q / a.R);
     Cam cam;
     load_cam(a.intr, a.pose, b, cam);
@@ -212,14 +207,17 @@ __global__ __launch_bounds__(kTile) void raygen_kernel(Args a) {
     }
   }
   if (a.depth == nullptr || a.N <= 0 || a.bounds_mode == TP_BOUNDS_NONE) return;
-  s_near[threadIdx.x] = near;
-  s_span[threadIdx.x] = tp::sub_rn(far, near);
+  if ((int)threadIdx.x < TILE) {
+    s_near[threadIdx.x] = near;
+    s_span[threadIdx.x] = tp::sub_rn(far, near);
+  }
   __syncthreads();
-  const int64_t rays_here = (total - tile0) < kTile ? (total - tile0) : kTile;
+  const int64_t rays_here = (total - tile0) < TILE ? (total - tile0) : TILE;
   const int64_t n_el = rays_here * a.N;
   const int64_t e0 = tile0 * a.N;  // first global element of this tile
   const float fN = (float)a.N;
   const uint2 key = make_uint2((uint32_t)a.seed, (uint32_t)(a.seed >> 32));
+  const uint64_t off = a.offset + (a.offset_dev ? *a.offset_dev : 0);       // (a captured step: the step counter on the device)
   if ((a.N & 3) == 0) {
     for (int64_t e = (int64_t)threadIdx.x * 4; e < n_el; e += kTile * 4) {
       const int r = (int)(e / a.N), i = (int)(e - (int64_t)r * a.N);
@@ -228,8 +226,7 @@ __global__ __launch_bounds__(kTile) void raygen_kernel(Args a) {
         rr = *reinterpret_cast<const float4*>(a.rnd + e0 + e);
       } else if (a.jitter_mode == TP_JITTER_PHILOX) {
         const uint64_t cnt = (uint64_t)(e0 + e) >> 2;
-        const uint4 w = philox4x32_10(make_uint4((uint32_t)cnt, (uint32_t)a.offset, (uint32_t)(cnt >> 32),
-                                                 (uint32_t)(a.offset >> 32)), key);
+        const uint4 w = philox4x32_10(make_uint4((uint32_t)cnt, (uint32_t)off, (uint32_t)(cnt >> 32), (uint32_t)(off >> 32)), key);
         rr = make_float4(u01(w.x), u01(w.y), u01(w.z), u01(w.w));
       }
       const float nr = s_near[r], sp = s_span[r];
@@ -248,8 +245,7 @@ __global__ __launch_bounds__(kTile) void raygen_kernel(Args a) {
         rr = a.rnd[e0 + e];
       } else if (a.jitter_mode == TP_JITTER_PHILOX) {
         const uint64_t ge = (uint64_t)(e0 + e), cnt = ge >> 2;
-        const uint4 w = philox4x32_10(make_uint4((uint32_t)cnt, (uint32_t)a.offset, (uint32_t)(cnt >> 32),
-                                                 (uint32_t)(a.offset >> 32)), key);
+        const uint4 w = philox4x32_10(make_uint4((uint32_t)cnt, (uint32_t)off, (uint32_t)(cnt >> 32), (uint32_t)(off >> 32)), key);
         const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
         rr = u01(ws[ge & 3]);
       }
@@ -305,14 +301,16 @@ extern "C" int tp_raygen(const tp_raygen_args* p, tp_stream_t stream) {
   a.intr = p->intr; a.pose = p->pose; a.coords = p->coords; a.ray_idx = p->ray_idx;
   a.z_near = p->z_near; a.z_far = p->z_far; a.rnd = p->rand;
   for (int i = 0; i < 3; ++i) { a.amin[i] = p->aabb_min[i]; a.amax[i] = p->aabb_max[i]; }
-  a.bg_near = p->bg_near; a.bg_far = p->bg_far; a.valid_rect = p->valid_rect; a.seed = p->seed; a.offset = p->offset;
+  a.bg_near = p->bg_near; a.bg_far = p->bg_far; a.valid_rect = p->valid_rect; a.seed = p->seed; a.offset = p->offset; a.offset_dev = p->offset_dev;
   a.B = p->B; a.R = p->R; a.H = p->H; a.W = p->W; a.N = p->N;
   a.pixel_mode = p->pixel_mode; a.bounds_mode = p->bounds_mode; a.jitter_mode = p->jitter_mode;
   a.center = p->center; a.ray = p->ray; a.near = p->near; a.far = p->far; a.depth = p->depth;
   const int64_t total = (int64_t)p->B * p->R;
-  const int64_t blocks = (total + kTile - 1) / kTile;
+  const int tile = total <= 16384 ? 32 : kTile;
+  const int64_t blocks = (total + tile - 1) / tile;
   TP_REQUIRE(blocks < (1ll << 31), "too many rays for one launch");
-  hipLaunchKernelGGL(raygen_kernel, dim3((unsigned)blocks), dim3(kTile), 0, (hipStream_t)stream, a);
+  if (tile == 32) hipLaunchKernelGGL(raygen_kernel<32>, dim3((unsigned)blocks), dim3(kTile), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(raygen_kernel<kTile>, dim3((unsigned)blocks), dim3(kTile), 0, (hipStream_t)stream, a);
   return tp::check_launch("tp_raygen");
 }
 

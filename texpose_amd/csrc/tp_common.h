@@ -82,4 +82,18 @@ __device__ __forceinline__ void sincos_both(float a, float& s, float& c) {
   c = ((o.q + 1) & 2) ? -vc : vc;
 }
 
+// Philox4x32-10 (Salmon et al., SC'11); the stream layouts of its users are documented in oracle.philox_uniform (ray-gen jitter)
+// and at tp_patch_coords (patch draws).
+__device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+    c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
+    k.x += 0x9E3779B9u; k.y += 0xBB67AE85u;
+  }
+  return c;
+}
+__device__ __forceinline__ float u01(uint32_t w) { return (float)(w >> 8) * 5.9604644775390625e-08f; }
+
 }  // namespace tp

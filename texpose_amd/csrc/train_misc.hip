@@ -16,21 +16,31 @@ namespace {
 constexpr int kBlock = 256;
 
 // ---- patch coordinates: s = u0 * (hi - lo) + lo;  x = lattice_j * s + (u1 * 2 - 1) * (1 - s);  y likewise with u2
+// u == NULL: the three uniforms of image b are drawn here, Philox4x32-10 with key = seed and counter (b, c_lo, 'patc', c_hi),
+// c = *counter (the step counter of a captured training step) -- words x, y, z -> scale, x shift, y shift.
 __global__ __launch_bounds__(kBlock) void patch_coords_kernel(const float* __restrict__ u, int B, int p, const float* __restrict__ lattice,
                                                               const float* lo_dev, float lo_host, float span_host, float hi,
-                                                              int random_scale, int random_shift, float* __restrict__ coords,
-                                                              float* __restrict__ scales) {
+                                                              int random_scale, int random_shift, uint64_t seed, const uint64_t* counter,
+                                                              float* __restrict__ coords, float* __restrict__ scales) {
   const int e = blockIdx.x * kBlock + threadIdx.x;
   if (e >= B * p * p) return;
   const int b = e / (p * p), r = e - b * p * p, i = r / p, j = r - i * p;
   const float lo = lo_dev ? *lo_dev : lo_host;
   const float span = lo_dev ? tp::sub_rn(hi, lo) : span_host;      // (a device-side bound is subtracted in fp32, like torch)
-  const float s = random_scale ? tp::add_rn(tp::mul_rn(u[b], span), lo) : tp::add_rn(0.f, lo);
+  float u0, u1, u2;
+  if (u != nullptr) { u0 = u[b]; u1 = u[B + b]; u2 = u[2 * B + b]; }
+  else {
+    const uint64_t c = counter ? *counter : 0;
+    const uint4 w = tp::philox4x32_10(make_uint4((uint32_t)b, (uint32_t)c, 0x70617463u, (uint32_t)(c >> 32)),
+                                      make_uint2((uint32_t)seed, (uint32_t)(seed >> 32)));
+    u0 = tp::u01(w.x); u1 = tp::u01(w.y); u2 = tp::u01(w.z);
+  }
+  const float s = random_scale ? tp::add_rn(tp::mul_rn(u0, span), lo) : tp::add_rn(0.f, lo);
   float x = tp::mul_rn(lattice[j], s), y = tp::mul_rn(lattice[i], s);
   if (random_shift) {
     const float room = tp::sub_rn(1.f, s);
-    x = tp::add_rn(x, tp::mul_rn(tp::sub_rn(tp::mul_rn(u[B + b], 2.0f), 1.0f), room));
-    y = tp::add_rn(y, tp::mul_rn(tp::sub_rn(tp::mul_rn(u[2 * B + b], 2.0f), 1.0f), room));
+    x = tp::add_rn(x, tp::mul_rn(tp::sub_rn(tp::mul_rn(u1, 2.0f), 1.0f), room));
+    y = tp::add_rn(y, tp::mul_rn(tp::sub_rn(tp::mul_rn(u2, 2.0f), 1.0f), room));
   }
   coords[2 * (size_t)e] = x;
   coords[2 * (size_t)e + 1] = y;
@@ -335,8 +345,9 @@ __global__ void weighted_sum_kernel(TermTable tb, float* __restrict__ out) {
 
 // ---- the loss total and the step gate in one launch: weighted_sum_kernel followed by step_flags_kernel on its result
 __global__ void weighted_sum_flags_kernel(TermTable tb, float* __restrict__ out, const int* status, int* bad, int n_bad, int word_status,
-                                          int word_finite, int* snapshot) {
+                                          int word_finite, int* snapshot, unsigned long long* step_counter) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (step_counter != nullptr) step_counter[0] += 1;              // this step's random draws are behind us on this stream
   float acc = 0.f;
   for (int k = 0; k < tb.n; ++k) acc += tb.t[k][0] * tb.w[k];
   out[0] = acc;
@@ -410,11 +421,12 @@ int tp_disc_inputs(const float* rgb, const float* gathered, int B, int P, int ge
 }
 
 int tp_patch_coords(const float* u, int B, int p, const float* lattice, const float* lo_dev, float lo_host, float span_host, float hi,
-                    int random_scale, int random_shift, float* coords, float* scales, tp_stream_t stream) {
-  TP_REQUIRE(u && lattice && coords && scales && B > 0 && p > 0, "bad arguments");
+                    int random_scale, int random_shift, uint64_t seed, const uint64_t* counter, float* coords, float* scales,
+                    tp_stream_t stream) {
+  TP_REQUIRE(lattice && coords && scales && B > 0 && p > 0, "bad arguments");
   const int n = B * p * p;
   hipLaunchKernelGGL(patch_coords_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, (hipStream_t)stream, u, B, p, lattice, lo_dev,
-                     lo_host, span_host, hi, random_scale, random_shift, coords, scales);
+                     lo_host, span_host, hi, random_scale, random_shift, seed, counter, coords, scales);
   return tp::check_launch("tp_patch_coords");
 }
 
@@ -524,7 +536,7 @@ int tp_latent_rows_bwd(const float* g_trans, const float* g_light, const int64_t
   return tp::check_launch("tp_latent_rows_bwd");
 }
 int tp_weighted_sum_flags(const float* const* terms, const float* weights, int n, float* out, const int32_t* mlp_status, int32_t* bad,
-                          int n_bad, int word_status, int word_finite, int32_t* snapshot, tp_stream_t stream) {
+                          int n_bad, int word_status, int word_finite, int32_t* snapshot, uint64_t* step_counter, tp_stream_t stream) {
   TP_REQUIRE(terms && weights && out && n > 0 && n <= 16, "1..16 terms expected");
   TP_REQUIRE(bad && snapshot && n_bad > 0 && word_finite >= 0 && word_finite < n_bad && (!mlp_status || (word_status >= 0 && word_status < n_bad)),
              "bad gate arguments");
@@ -533,7 +545,7 @@ int tp_weighted_sum_flags(const float* const* terms, const float* weights, int n
   for (int k = 0; k < n; ++k) TP_REQUIRE(terms[k] != nullptr, "null term");
   tb.n = n;
   hipLaunchKernelGGL(weighted_sum_flags_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, tb, out, mlp_status, bad, n_bad, word_status,
-                     word_finite, snapshot);
+                     word_finite, snapshot, (unsigned long long*)step_counter);
   return tp::check_launch("tp_weighted_sum_flags");
 }
 int tp_weighted_sum(const float* const* terms, const float* weights, int n, float* out, tp_stream_t stream) {

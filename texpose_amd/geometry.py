@@ -183,6 +183,7 @@ class FlexPatchSampler:
         self.scales_curr = (min_scale, max_scale)
         self.full_indices = False
         self.device_lo = None                # 0-dim device tensor while a hipGraph-captured step owns the sampler
+        self.device_counter = None           # int64 [1] device word: draw inside the kernel, keyed by (seed, this counter)
 
     def _host_range(self):
         lo = self.min_scale
@@ -201,6 +202,12 @@ class FlexPatchSampler:
     def __call__(self, nbatch, patch_size, device="cuda", u=None):
         """``u`` ([3,B,1,1,1] uniforms: scale, x-shift, y-shift) replaces the internal draw in parity tests."""
         lo, hi = self.scales_curr = self.scale_range()
+        if u is None and self.device_counter is not None:
+            # captured training step: no torch.rand launch (and no generator-state fills before every replay); the kernel draws
+            # from Philox(seed, step counter) -- the counter lives on the device and is advanced once per step
+            from . import ops
+            return ops.patch_coords(None, patch_size, lo, hi, self.random_scale, self.random_shift, nbatch=nbatch,
+                                    seed=torch.initial_seed(), counter=self.device_counter)
         if u is None:
             u = torch.rand(3, nbatch, 1, 1, 1, device=device)
         if u.is_cuda:                                        # one launch (K13 tp_patch_coords), same fp32 operation order

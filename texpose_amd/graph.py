@@ -76,9 +76,14 @@ class Graph(torch.nn.Module):
         return var.pose
 
     @staticmethod
-    def _jitter(opt, rand):
+    def _jitter(opt, rand, step_counter=None):
+        """ops.raygen / ops.sample_depth arguments of the stratified draw.  ``step_counter`` (int64 [1] on the device, set by the
+        captured training step): the Philox offset is that word, read inside the kernel -- one recorded launch, new numbers at
+        every replay."""
         if rand is not None:
             return dict(rand=rand)
+        if opt.nerf.sample_stratified and step_counter is not None:
+            return dict(jitter=ops.JITTER_PHILOX, seed=torch.initial_seed() & (2 ** 64 - 1), offset=0, offset_dev=step_counter)
         if opt.nerf.sample_stratified:
             return dict(jitter=ops.JITTER_PHILOX, seed=torch.initial_seed() & (2 ** 64 - 1), offset=next(_philox_calls))
         return dict(jitter=ops.JITTER_MID)
@@ -109,7 +114,7 @@ class Graph(torch.nn.Module):
         batch_size = len(pose)
         src = dict(coords=ray_idx) if mode == "train" else dict(ray_idx=ray_idx)
         center, ray, _, _, depth = ops.raygen(intr, pose, H=opt.H, W=opt.W, n_samples=N, z_near=z_near, z_far=z_far,
-                                              **src, **self._jitter(opt, rand))
+                                              **src, **self._jitter(opt, rand, getattr(self, "step_counter", None) if mode == "train" else None))
         depth_samples = depth[..., None]                                     # [B,R,N,1]
         if (mode == "train" and torch.is_tensor(sample_idx) and sample_idx.dim() == 1 and sample_idx.is_cuda
                 and self.latent_vars_trans.weight.shape[0] == self.latent_vars_light.weight.shape[0]):

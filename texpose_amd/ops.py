@@ -95,9 +95,11 @@ def raygen(intr: Tensor, pose: Tensor, *, H: int, W: int, n_samples: int = 0, co
            ray_idx: Optional[Tensor] = None, z_near: Optional[Tensor] = None, z_far: Optional[Tensor] = None,
            aabb: Optional[Tuple[Tuple[float, float, float], Tuple[float, float, float]]] = None,
            bg_range: Tuple[float, float] = (0.0, 30.0), rand: Optional[Tensor] = None,
-           jitter: int = JITTER_MID, seed: int = 0, offset: int = 0, valid_rect: Optional[Tensor] = None):
+           jitter: int = JITTER_MID, seed: int = 0, offset: int = 0, valid_rect: Optional[Tensor] = None,
+           offset_dev: Optional[Tensor] = None):
     """Fused ray-gen + bounds + stratified depths.  Returns (center, ray, near, far, depth);
-    near/far/depth are None when no bounds source is given, depth is [B,R,N]."""
+    near/far/depth are None when no bounds source is given, depth is [B,R,N].  ``offset_dev`` (int64 [1] on the device): added
+    to the Philox ``offset`` inside the kernel (the step counter of a captured training step)."""
     lib = _lib.load()
     intr, pose = _f32(intr, "intr"), _f32(pose, "pose")
     B = pose.shape[0]
@@ -142,6 +144,10 @@ def raygen(intr: Tensor, pose: Tensor, *, H: int, W: int, n_samples: int = 0, co
         jitter = JITTER_GIVEN
         a.rand = rand.data_ptr()
     a.jitter_mode, a.seed, a.offset = jitter, seed, offset
+    if offset_dev is not None:
+        if offset_dev.dtype != torch.int64 or offset_dev.numel() != 1 or offset_dev.device != dev:
+            raise ValueError("raygen: offset_dev must be one int64 word on the device of the inputs")
+        a.offset_dev = offset_dev.data_ptr()
     a.intr, a.pose = intr.data_ptr(), pose.data_ptr()
     a.B, a.R, a.H, a.W, a.N = B, R, H, W, n_samples
     a.center, a.ray = center.data_ptr(), ray.data_ptr()
@@ -833,21 +839,30 @@ _lattices = {}
 
 
 @_on_tensor_device
-def patch_coords(u: Tensor, patch_size: int, lo, hi: float, random_scale: bool = True, random_shift: bool = True):
+def patch_coords(u: Optional[Tensor], patch_size: int, lo, hi: float, random_scale: bool = True, random_shift: bool = True, *,
+                 nbatch: Optional[int] = None, seed: int = 0, counter: Optional[Tensor] = None, device=None):
     """FlexPatchSampler in one launch: u [3,B,...] uniforms -> (coords [B,p,p,2], scales [B,1,1,1]); ``lo`` is a float or a
-    0-dim device tensor (the annealed bound of a captured step)."""
+    0-dim device tensor (the annealed bound of a captured step).  ``u`` None: ``nbatch`` images, the uniforms drawn inside the
+    kernel from (``seed``, the device word ``counter``: int64 [1], the step counter of a captured training step)."""
     lib = _lib.load()
-    u = _f32(u, "u")
-    B, p = u.numel() // 3, int(patch_size)
-    key = (p, u.device.index)
+    if u is not None:
+        u = _f32(u, "u")
+        B, dev = u.numel() // 3, u.device
+    else:
+        B, dev = int(nbatch), (counter.device if counter is not None else torch.device(device))
+        if counter is not None and (counter.dtype != torch.int64 or counter.numel() != 1):
+            raise ValueError("patch_coords: counter must be one int64 device word")
+    p = int(patch_size)
+    key = (p, dev.index)
     if key not in _lattices:
-        _lattices[key] = torch.linspace(-1, 1, p, device=u.device)
-    coords = torch.empty(B, p, p, 2, device=u.device)
-    scales = torch.empty(B, 1, 1, 1, device=u.device)
+        _lattices[key] = torch.linspace(-1, 1, p, device=dev)
+    coords = torch.empty(B, p, p, 2, device=dev)
+    scales = torch.empty(B, 1, 1, 1, device=dev)
     lo_dev = lo.data_ptr() if torch.is_tensor(lo) else None
     lo_host = 0.0 if torch.is_tensor(lo) else float(lo)
-    check(lib.tp_patch_coords(u.data_ptr(), B, p, _lattices[key].data_ptr(), lo_dev, lo_host, float(hi) - lo_host, float(hi),
-                              int(bool(random_scale)), int(bool(random_shift)), coords.data_ptr(), scales.data_ptr(), _stream()),
+    check(lib.tp_patch_coords(_ptr(u), B, p, _lattices[key].data_ptr(), lo_dev, lo_host, float(hi) - lo_host, float(hi),
+                              int(bool(random_scale)), int(bool(random_shift)), int(seed) & (2 ** 64 - 1), _ptr(counter),
+                              coords.data_ptr(), scales.data_ptr(), _stream()),
           "tp_patch_coords")
     return coords, scales
 
@@ -1021,7 +1036,8 @@ def gan_disc_losses(d_real: Tensor, d_fake: Tensor, w_real: float, w_fake: float
 @_on_tensor_device
 def weighted_sum(terms, weights, flags=None) -> Tensor:
     """sum_k weights[k] * terms[k] for 0-dim float32 device tensors and host floats, one launch.  ``flags`` = dict(bad,
-    word_finite, snapshot[, status, word_status]): `step_flags` on the result in the same launch (tp_weighted_sum_flags)."""
+    word_finite, snapshot[, status, word_status, step_counter]): `step_flags` on the result in the same launch
+    (tp_weighted_sum_flags); ``step_counter`` (int64 [1]) is incremented by it."""
     lib = _lib.load()
     n = len(terms)
     ts = [_f32(t.detach(), "term") for t in terms]
@@ -1034,7 +1050,7 @@ def weighted_sum(terms, weights, flags=None) -> Tensor:
         bad = flags["bad"]
         check(lib.tp_weighted_sum_flags(ptrs, ws, n, out.data_ptr(), _ptr(flags.get("status")), bad.data_ptr(), bad.numel(),
                                         int(flags.get("word_status", 0)), int(flags["word_finite"]), flags["snapshot"].data_ptr(),
-                                        _stream()), "tp_weighted_sum_flags")
+                                        _ptr(flags.get("step_counter")), _stream()), "tp_weighted_sum_flags")
     return out
 
 

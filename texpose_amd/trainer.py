@@ -515,15 +515,15 @@ class GraphedGanTrainer(GanTrainer):
         self._prefetch_spectral_weights(var)                         # (first: it runs beside everything up to the render)
         B, R = opt.batch_size, opt.patch_size ** 2
         var = self.graph.get_ray_idx(opt, var)
-        if opt.nerf.sample_stratified and "jitter_rand" not in var:   # (a caller-supplied static tensor wins: tests)
-            var.jitter_rand = torch.rand(B, R, opt.nerf.sample_intvs, 1, device=var.ray_idx.device)
+        if opt.nerf.sample_stratified and "jitter_rand" not in var and getattr(self.graph, "step_counter", None) is None:
+            var.jitter_rand = torch.rand(B, R, opt.nerf.sample_intvs, 1, device=var.ray_idx.device)   # (TP_TORCH_RNG=1)
         var, loss = self.nerf_forward_loss(var)
         # loss total + step gate in one launch: this forward's range flag and the finiteness of its loss go into the sticky words,
         # which are snapshot as the nerf gate BEFORE the backward and before the branches fork (so the gate also sees a
         # discriminator flag of earlier steps, never a concurrent write of this one)
         status = ops.mlp_status(dev) if self._uses_f16x3() else None
         terms, ws = self._weighted_total(loss, flags=dict(bad=self._bad, word_finite=1, snapshot=self._gate_nerf, status=status,
-                                                          word_status=0))
+                                                          word_status=0, step_counter=getattr(self, "_rng_counter", None)))
         dloss = None
         # optimiser steps (and reductions) after this function: whenever a collective is part of the step, or on request
         self._deferred = self._has_collective() or self._split_around_collectives()
@@ -625,6 +625,13 @@ class GraphedGanTrainer(GanTrainer):
             if optim is not None:
                 self._adopt_group_lr(name, optim)             # (a load_state_dict before the capture replaced the tensors)
         self.graph.patch_sampler.device_lo = torch.zeros((), device=dev)
+        if os.environ.get("TP_TORCH_RNG") != "1":
+            # the step's random draws (patch scale / shifts, stratified jitter) come from Philox streams keyed by the seed and a
+            # step counter on the device, read inside tp_patch_coords / tp_raygen and advanced by the loss-total launch: no
+            # torch.rand launches in the step and no generator-state fills before every replay
+            if getattr(self, "_rng_counter", None) is None:
+                self._rng_counter = torch.zeros(1, dtype=torch.int64, device=dev)
+            self.graph.step_counter = self.graph.patch_sampler.device_counter = self._rng_counter
         self._static_in = AttrDict({k: v.clone() for k, v in var.items() if torch.is_tensor(v)})
         snap = self._snapshot()
         # warm up on the stream the capture will use: per-stream state (the tile counters of the convolution kernels,
