@@ -111,6 +111,10 @@ size_t tp_mlp_packed_bytes(void);
 enum { TP_PACK_TRUNK = 1, TP_PACK_HEADS = 2, TP_PACK_ALL = 3,
        TP_PACK_F16X3 = 4 /* OR-ed in: build the split-fp16 (hi+lo) stream of the TP_MLP_F16X3 forward; same size */ };
 int tp_mlp_pack(const tp_mlp_weights* w /*host struct of device ptrs*/, int parts, void* packed, tp_stream_t stream);
+/* Training (TP_MLP_F16X3): everything that is rebuilt from the HEAD weights after an optimiser step, in one launch: the head chunks
+ * and head biases of the f16x3 forward stream `packed` (what tp_mlp_pack(TP_PACK_HEADS | TP_PACK_F16X3) writes) and, when packed_t is
+ * not NULL, the transposed f16x3 image tp_mlp_bwd streams (what it builds itself when called with repack != 0). */
+int tp_mlp_pack_heads_f16x3(const tp_mlp_weights* w, void* packed, void* packed_t, tp_stream_t stream);
 /* Same image built on the host from HOST weight pointers (no GPU needed; used by the CPU tests). */
 int tp_mlp_pack_host(const tp_mlp_weights* w_host, float* packed_host);
 
@@ -176,6 +180,9 @@ typedef struct tp_mlp_bwd_args {
                               TP_MLP_F16X3: split-fp16 products with power-of-two scaling of the gradients (fp32-grade;
                               requires |activation| < 6e4, i.e. a record written by a TP_MLP_F16X3 forward whose status
                               word stayed clear; `packed_t` is then built in the transposed f16x3 format) */
+  int dz_max_is_clear;     /* TP_MLP_F16X3: the scale word inside `workspace` is known to be zero -- true after any completed call
+                              with the same workspace and B*R*N (the call's last kernel clears it) -- so the call does not
+                              memset it.  0 = clear it first (always safe). */
 } tp_mlp_bwd_args;
 int tp_mlp_bwd(const tp_mlp_bwd_args* args, tp_stream_t stream);
 

@@ -18,7 +18,7 @@ ABI_VERSION = 7
 SYMBOLS = (
     "tp_abi_version", "tp_last_error",
     "tp_raygen", "tp_aabb", "tp_sample_depth",
-    "tp_mlp_packed_bytes", "tp_mlp_pack", "tp_mlp_pack_host", "tp_mlp_workspace_bytes", "tp_mlp_fwd", "tp_posenc",
+    "tp_mlp_packed_bytes", "tp_mlp_pack", "tp_mlp_pack_heads_f16x3", "tp_mlp_pack_host", "tp_mlp_workspace_bytes", "tp_mlp_fwd", "tp_posenc",
     "tp_mlp_saved_bytes", "tp_mlp_packed_t_bytes", "tp_mlp_bwd_workspace_bytes", "tp_mlp_bwd",
     "tp_composite_fwd", "tp_composite_bwd",
     "tp_patch_gather",
@@ -67,7 +67,8 @@ class MlpBwdArgs(C.Structure):
                 ("density", vp), ("uncert", vp), ("g_rgb", vp), ("g_density", vp), ("g_uncert", vp),
                 ("lat_trans", vp), ("lat_light", vp), ("B", C.c_int), ("R", C.c_int), ("N", C.c_int),
                 ("g_rgb_w", vp * 4), ("g_rgb_b", vp * 4), ("g_trans_w", vp * 4), ("g_trans_b", vp * 4),
-                ("g_lat_trans", vp), ("g_lat_light", vp), ("workspace", vp), ("wgrad_precision", C.c_int)]
+                ("g_lat_trans", vp), ("g_lat_light", vp), ("workspace", vp), ("wgrad_precision", C.c_int),
+                ("dz_max_is_clear", C.c_int)]
 
 
 class CompositeArgs(C.Structure):
@@ -194,6 +195,7 @@ def load() -> C.CDLL:
     sig("tp_mlp_bwd_workspace_bytes", [C.c_int64], C.c_size_t)
     sig("tp_mlp_bwd", [C.POINTER(MlpBwdArgs), vp])
     sig("tp_mlp_pack", [C.POINTER(MlpWeights), C.c_int, vp, vp])
+    sig("tp_mlp_pack_heads_f16x3", [C.POINTER(MlpWeights), vp, vp, vp])
     sig("tp_mlp_pack_host", [C.POINTER(MlpWeights), vp])
     sig("tp_mlp_fwd", [C.POINTER(MlpFwdArgs), vp])
     sig("tp_posenc", [vp, C.c_int64, C.c_int, C.c_int, vp, vp])

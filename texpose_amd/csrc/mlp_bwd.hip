@@ -658,9 +658,12 @@ struct Fin2Params {
   const float* w_t0; const float* w_r0;
   float* g_lat_trans; float* g_lat_light;
   int B, n_elem_blocks;
+  unsigned int* dz_max;               // cleared here (the call's last kernel; its readers have finished): the next call with this
+                                      // workspace and size finds it zero (tp_mlp_bwd_args.dz_max_is_clear)
 };
 
 __global__ void mlp_wgrad_finalize2(Fin2Params P) {
+  if (blockIdx.x == 0 && threadIdx.x == 0 && P.dz_max != nullptr) *P.dz_max = 0u;
   if ((int)blockIdx.x < P.n_elem_blocks) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e < 8 * 256) {
@@ -765,8 +768,10 @@ extern "C" int tp_mlp_bwd(const tp_mlp_bwd_args* a, tp_stream_t stream_) {
   const int cus = num_cus();
   const int dg_grid = (int)(n_tiles < cus ? n_tiles : cus);
   if (f16) {
-    hipError_t e = hipMemsetAsync(dz_max, 0, sizeof(unsigned int), stream);
-    if (e != hipSuccess) { tp::set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return (int)e; }
+    if (!a->dz_max_is_clear) {
+      hipError_t e = hipMemsetAsync(dz_max, 0, sizeof(unsigned int), stream);
+      if (e != hipSuccess) { tp::set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return (int)e; }
+    }
     if (int rc = tp_launch_mlp_dgrad_f16x3(a, dz, dz_max, dg_grid, stream)) return rc;
   } else {
     if (a->repack) {
@@ -841,6 +846,7 @@ extern "C" int tp_mlp_bwd(const tp_mlp_bwd_args* a, tp_stream_t stream_) {
   G.w_t0 = a->weights.trans_w[0]; G.w_r0 = a->weights.rgb_w[0];
   G.g_lat_trans = a->g_lat_trans; G.g_lat_light = a->g_lat_light;
   G.B = a->B; G.n_elem_blocks = (8 * 256 + 256 * 64) / 256;
+  G.dz_max = f16 ? dz_max : nullptr;
   hipLaunchKernelGGL(mlp_wgrad_finalize2, dim3((unsigned)(G.n_elem_blocks + (a->B * 64 + 3) / 4)), dim3(256), 0, stream, G);
   return tp::check_launch("tp_mlp_bwd");
 }

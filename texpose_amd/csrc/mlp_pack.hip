@@ -57,6 +57,48 @@ __global__ void pack_bias_kernel(W w, int wide0, int wide1, float* __restrict__ 
     bias[kHeadBiasOff + e] = v;
   }
 }
+// Training: everything that has to be rebuilt from the head weights after an optimiser step, in ONE launch -- the f16x3 head chunks of
+// the forward stream (pack16_kernel's part), the head biases (pack_bias_kernel's), and the transposed f16x3 image the data-gradient
+// kernel streams (packT16_kernel of mlp_fwd_f16x3.hip: same arithmetic).  Block ranges: [0, kBiasBlocks) biases,
+// [kBiasBlocks, kBiasBlocks + kTBlocks) transposed image, the rest the forward chunks.
+constexpr int kBiasBlocks = ((kNumWide - kFirstHeadWide) * 256 + 255) / 256;
+constexpr int kTBlocks = 512, kFwdBlocks = 1024;
+__global__ void pack_heads16_kernel(W w, _Float16* __restrict__ out, _Float16* __restrict__ out_t) {
+  const float scale = (float)(1 << kF16WeightShift);
+  if ((int)blockIdx.x < kBiasBlocks) {
+    float* bias = reinterpret_cast<float*>(out) + (int64_t)kNumChunks * kChunkFloats;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < (kNumWide - kFirstHeadWide) * 256) {
+      const int wide = kFirstHeadWide + e / 256, rem = e % 256, h = rem / 128, t = (rem / 16) % 8, r = rem % 16;
+      const int mat = wide <= T2 ? W_TRANS0 + (wide - T0) : W_RGB0 + (wide - R0);
+      bias[bias_index(wide, h, t, r)] = w.b[mat][feat_of(t, r, h)];
+    }
+    if (e >= 1 && e < 9) bias[kHeadBiasOff + e] = e < 6 ? w.b[W_TRANS0 + 3][e - 1] : w.b[W_RGB0 + 3][e - 6];
+    return;
+  }
+  if ((int)blockIdx.x < kBiasBlocks + kTBlocks) {
+    if (out_t == nullptr) return;
+    const int64_t n = (int64_t)kNumChunksT * kChunkHalves;
+    for (int64_t e = (int64_t)(blockIdx.x - kBiasBlocks) * blockDim.x + threadIdx.x; e < n; e += (int64_t)kTBlocks * blockDim.x) {
+      int part, mat, o, f;
+      chunkT16_src((int)(e / kChunkHalves), (int)(e % kChunkHalves), part, mat, o, f);
+      const float v = o < 0 ? 0.0f : w.w[mat][(int64_t)o * 256 + f] * scale;
+      const _Float16 hi = (_Float16)v;
+      out_t[e] = part == 0 ? hi : (_Float16)(v - (float)hi);
+    }
+    return;
+  }
+  const int64_t n = (int64_t)(kNumChunks - kFirstHeadChunk) * kChunkHalves;
+  for (int64_t e = (int64_t)(blockIdx.x - kBiasBlocks - kTBlocks) * blockDim.x + threadIdx.x; e < n; e += (int64_t)kFwdBlocks * blockDim.x) {
+    const int c = kFirstHeadChunk + (int)(e / kChunkHalves), idx = (int)(e % kChunkHalves);
+    const ChunkDesc d = chunk_desc(c);
+    int part, row, col;
+    chunk16_src(d, idx, part, row, col);
+    float v = row < 0 ? 0.0f : w.w[d.mat][(int64_t)row * d.in_dim + col] * scale;
+    const _Float16 hi = (_Float16)v;
+    out[(int64_t)c * kChunkHalves + idx] = part == 0 ? hi : (_Float16)(v - (float)hi);
+  }
+}
 }  // namespace
 
 // Host-side packer (same layout functions, no GPU involved): used by the CPU tests to check the
@@ -94,6 +136,20 @@ extern "C" int tp_mlp_pack_host(const tp_mlp_weights* p, float* out) {
 }
 
 extern "C" size_t tp_mlp_packed_bytes(void) { return (size_t)tp_layout::kPackedFloats * sizeof(float); }
+
+extern "C" int tp_mlp_pack_heads_f16x3(const tp_mlp_weights* p, void* packed, void* packed_t, tp_stream_t stream) {
+  TP_REQUIRE(p && packed, "null pointer");
+  W w;
+  for (int i = 0; i < 16; ++i) { w.w[i] = nullptr; w.b[i] = nullptr; }
+  for (int i = 0; i < 4; ++i) {
+    w.w[W_RGB0 + i] = p->rgb_w[i]; w.b[W_RGB0 + i] = p->rgb_b[i];
+    w.w[W_TRANS0 + i] = p->trans_w[i]; w.b[W_TRANS0 + i] = p->trans_b[i];
+    TP_REQUIRE(p->rgb_w[i] && p->rgb_b[i] && p->trans_w[i] && p->trans_b[i], "null weight pointer");
+  }
+  hipLaunchKernelGGL(pack_heads16_kernel, dim3(kBiasBlocks + kTBlocks + kFwdBlocks), dim3(256), 0, (hipStream_t)stream, w, (_Float16*)packed,
+                     (_Float16*)packed_t);
+  return tp::check_launch("tp_mlp_pack_heads_f16x3");
+}
 
 extern "C" int tp_mlp_pack(const tp_mlp_weights* p, int parts, void* packed, tp_stream_t stream) {
   TP_REQUIRE(p && packed, "null pointer");

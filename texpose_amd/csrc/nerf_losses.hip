@@ -28,37 +28,9 @@ __device__ __forceinline__ void block_reduce4(float (&v)[4], float* red) {   // 
   for (int k = 0; k < 4; ++k) v[k] = red[k * kBlock];
 }
 
-__global__ __launch_bounds__(kBlock) void nerf_losses_fwd_kernel(tp_nerf_losses_args a, float* partial) {
-  __shared__ float red[4 * kBlock];
-  const int64_t n_pix = (int64_t)a.B * a.P, n_den = n_pix * a.N;
-  float v[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x; q < n_pix; q += (int64_t)gridDim.x * kBlock) {
-    const int64_t b = q / a.P, p = q - b * a.P;
-    const float* gp = a.gathered + b * 14 * a.P + p;
-    const float m = gp[12 * (int64_t)a.P], u = a.uncert[q];
-    float se = 0.f;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      const float d = gp[c * (int64_t)a.P] - a.rgb[q * 3 + c];
-      se += d * d;
-    }
-    v[0] += m * (se / (u * u));
-    v[1] += m;
-    v[2] += logf(u * u);
-  }
-  const float2* den = reinterpret_cast<const float2*>(a.density);
-  for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < n_den; e += (int64_t)gridDim.x * kBlock) v[3] += den[e].y;
-  block_reduce4(v, red);
-  if (threadIdx.x == 0) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) partial[blockIdx.x * 4 + k] = v[k];
-  }
-}
-
 // fixed-order reduction of the per-block partials: thread t adds partials t, t+256, ... in order, then a block tree
-__global__ __launch_bounds__(kBlock) void nerf_losses_finalize(const float* partial, int n_blocks, double* sums, float* losses,
-                                                               float n_pix, float n_den) {
-  __shared__ double red[4][kBlock];
+__device__ __forceinline__ void nerf_losses_finalize(const float* partial, int n_blocks, double* sums, float* losses, float n_pix, float n_den,
+                                                     double (*red)[kBlock]) {
   const int tid = threadIdx.x;
   double v[4] = {0.0, 0.0, 0.0, 0.0};
   for (int i = tid; i < n_blocks; i += kBlock) {
@@ -83,6 +55,46 @@ __global__ __launch_bounds__(kBlock) void nerf_losses_finalize(const float* part
     losses[2] = tp::div_rn(s3, n_den);
   }
 }
+
+// The block that finishes LAST reduces the partials of all of them (a ticket in device memory, reset by that block): the forward
+// is one launch, and the order of the final reduction is the same whichever block runs it.
+__device__ unsigned int g_nerf_losses_ticket = 0;
+__global__ __launch_bounds__(kBlock) void nerf_losses_fwd_kernel(tp_nerf_losses_args a, float* partial, float n_pix_f, float n_den_f) {
+  __shared__ float red[4 * kBlock];
+  __shared__ double red_d[4][kBlock];
+  __shared__ bool last;
+  const int64_t n_pix = (int64_t)a.B * a.P, n_den = n_pix * a.N;
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x; q < n_pix; q += (int64_t)gridDim.x * kBlock) {
+    const int64_t b = q / a.P, p = q - b * a.P;
+    const float* gp = a.gathered + b * 14 * a.P + p;
+    const float m = gp[12 * (int64_t)a.P], u = a.uncert[q];
+    float se = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float d = gp[c * (int64_t)a.P] - a.rgb[q * 3 + c];
+      se += d * d;
+    }
+    v[0] += m * (se / (u * u));
+    v[1] += m;
+    v[2] += logf(u * u);
+  }
+  const float2* den = reinterpret_cast<const float2*>(a.density);
+  for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < n_den; e += (int64_t)gridDim.x * kBlock) v[3] += den[e].y;
+  block_reduce4(v, red);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) partial[blockIdx.x * 4 + k] = v[k];
+    __threadfence();                                                          // the partials are visible before the ticket is
+    last = atomicAdd(&g_nerf_losses_ticket, 1u) == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!last) return;
+  if (threadIdx.x == 0) g_nerf_losses_ticket = 0;
+  __threadfence();
+  nerf_losses_finalize(partial, (int)gridDim.x, a.sums, a.losses, n_pix_f, n_den_f, red_d);
+}
+
 
 // g_render / g_unc / g_trans: upstream gradients of (render, uncert, trans_reg), one device scalar each (NULL = 0)
 __global__ __launch_bounds__(kBlock) void nerf_losses_bwd_kernel(tp_nerf_losses_args a, const double* sums, const float* g_render,
@@ -125,8 +137,7 @@ int check(const tp_nerf_losses_args* a, const char* what) {
 extern "C" int tp_nerf_losses_fwd(const tp_nerf_losses_args* a, tp_stream_t stream) {
   if (int rc = check(a, "tp_nerf_losses_fwd")) return rc;
   const int g = grid_for(a);
-  hipLaunchKernelGGL(nerf_losses_fwd_kernel, dim3(g), dim3(kBlock), 0, (hipStream_t)stream, *a, (float*)a->workspace);
-  hipLaunchKernelGGL(nerf_losses_finalize, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, (const float*)a->workspace, g, a->sums, a->losses,
+  hipLaunchKernelGGL(nerf_losses_fwd_kernel, dim3(g), dim3(kBlock), 0, (hipStream_t)stream, *a, (float*)a->workspace,
                      (float)((int64_t)a->B * a->P), (float)((int64_t)a->B * a->P * a->N));
   return tp::check_launch("tp_nerf_losses_fwd");
 }

@@ -149,12 +149,16 @@ struct AdamTable {
   const float* g[TP_ADAM_MAX_TENSORS];
   float* m[TP_ADAM_MAX_TENSORS];
   float* v[TP_ADAM_MAX_TENSORS];
-  float* step[TP_ADAM_MAX_TENSORS];          // steps taken BEFORE this one (adam_bump_kernel adds 1 afterwards)
+  float* step[TP_ADAM_MAX_TENSORS];          // steps taken BEFORE this one (the last block to finish adds 1)
   int64_t end[TP_ADAM_MAX_TENSORS];
   int n;
 };
+// The step counters are read by every block and must advance only after the last of them has: the block that finishes last (a
+// ticket in device memory, reset by that block) adds 1 to each distinct counter.
+__device__ unsigned int g_adam_ticket = 0;
 __global__ __launch_bounds__(kBlock) void adam_kernel(AdamTable t, const float* lr_dev, double lr_host, double beta1, double beta2, float eps,
                                                       float w1, float w2, int64_t total, const int* gate, int n_gate) {
+  __shared__ bool last;
   for (int k = 0; k < n_gate; ++k)
     if (gate[k] != 0) return;
   const double lr = lr_dev != nullptr ? (double)*lr_dev : lr_host;
@@ -175,15 +179,16 @@ __global__ __launch_bounds__(kBlock) void adam_kernel(AdamTable t, const float* 
     const float denom = tp::add_rn(tp::div_rn(sqrtf(v), bc2_sqrt), eps);
     t.p[k][i] = tp::add_rn(t.p[k][i], tp::mul_rn(-step_size, tp::div_rn(m, denom)));    // addcdiv_(exp_avg, denom, value = -step_size)
   }
-}
-__global__ void adam_bump_kernel(AdamTable t, const int* gate, int n_gate) {
-  for (int k = 0; k < n_gate; ++k)
-    if (gate[k] != 0) return;
+  __syncthreads();                                         // every thread of this block has read its counters
+  if (threadIdx.x == 0) last = atomicAdd(&g_adam_ticket, 1u) == gridDim.x - 1;
+  __syncthreads();
+  if (!last) return;
+  if (threadIdx.x == 0) g_adam_ticket = 0;
   // (tensors of one optimiser usually share nothing, but two entries may name the same counter: add once per distinct pointer)
-  for (int k = threadIdx.x; k < t.n; k += blockDim.x) {
+  for (int kk = threadIdx.x; kk < t.n; kk += blockDim.x) {
     bool first = true;
-    for (int j = 0; j < k; ++j) first = first && t.step[j] != t.step[k];
-    if (first) t.step[k][0] += 1.0f;
+    for (int j = 0; j < kk; ++j) first = first && t.step[j] != t.step[kk];
+    if (first) t.step[kk][0] += 1.0f;
   }
 }
 
@@ -409,7 +414,6 @@ int tp_adam_step(const tp_adam_tensor* tensors, int n, const float* lr_dev, doub
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, t, lr_dev, lr_host, beta1, beta2, (float)eps,
                      (float)(1.0 - beta1), (float)(1.0 - beta2), total, gate, n_gate);
-  hipLaunchKernelGGL(adam_bump_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, t, gate, n_gate);
   return tp::check_launch("tp_adam_step");
 }
 

@@ -63,6 +63,7 @@ class NeRF(torch.nn.Module):
             raise ValueError("arch.mlp_precision / mlp_train_precision must be one of %s" % list(ops.PRECISIONS))
         self._packed = {}
         self._versions = {}
+        self._packed_t, self._packed_t_ver = None, None     # transposed f16x3 head image of the backward (packed_weights)
 
     # ------------------------------------------------------------------ construction helpers
     @classmethod
@@ -120,9 +121,24 @@ class NeRF(torch.nn.Module):
                 ops.pack_weights(st, packed=buf, parts=ops.PACK_TRUNK, precision=precision)
                 ver[0] = vt
             if ver[1] != vh:
-                ops.pack_weights(st, packed=buf, parts=ops.PACK_HEADS, precision=precision)
+                if precision == "f16x3" and torch.is_grad_enabled() and any(p.requires_grad for _, p in self.head_parameters()):
+                    # a training step: forward chunks, biases AND the transposed image of this step's data gradient in one launch
+                    if self._packed_t is None or self._packed_t.device != dev:
+                        self._packed_t = torch.empty(ops.packed_t_bytes() // 4, device=dev)
+                    ops.pack_heads_train(st, buf, self._packed_t)
+                    self._packed_t_ver = vh
+                else:
+                    ops.pack_weights(st, packed=buf, parts=ops.PACK_HEADS, precision=precision)
                 ver[1] = vh
         return buf
+
+    def packed_t_current(self):
+        """The transposed f16x3 head image if it was built from the head weights as they are now (by the pack launch of this
+        step's forward), else None."""
+        if self._packed_t is None or self._packed_t_ver is None:
+            return None
+        vh = tuple((p.data_ptr(), p._version) for k, p in self._state().items() if not k.startswith("mlp_feat"))
+        return self._packed_t if vh == self._packed_t_ver else None
 
     def mark_heads_dirty(self):
         """Force a re-pack of the head weights at the next forward.  Needed after parameter updates that do not bump
@@ -131,6 +147,7 @@ class NeRF(torch.nn.Module):
         texpose_amd.trainer call this after every optimiser step."""
         for ver in self._versions.values():
             ver[1] = None
+        self._packed_t_ver = None
 
     # ------------------------------------------------------------------ reference API
     def forward(self, opt, points_3D, ray_unit=None, latent_variable_trans=None, latent_variable_light=None,

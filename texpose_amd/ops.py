@@ -216,6 +216,26 @@ def pack_weights(state: Dict[str, Tensor], packed: Optional[Tensor] = None, part
     return packed
 
 
+def packed_t_bytes() -> int:
+    return int(_lib.load().tp_mlp_packed_t_bytes())
+
+
+@_on_tensor_device
+def pack_heads_train(state: Dict[str, Tensor], packed: Tensor, packed_t: Optional[Tensor], prefix: str = "") -> None:
+    """Training with the f16x3 kernels: the head part of the forward stream ``packed`` (chunks + biases) and the transposed image
+    ``packed_t`` of the data-gradient kernel from the head weights in ONE launch (tp_mlp_pack_heads_f16x3) -- what
+    pack_weights(PACK_HEADS, 'f16x3') and the repack of mlp_backward do in three."""
+    lib = _lib.load()
+    w = MlpWeights()
+    keep = []
+    for name, arr_w, arr_b in (("mlp_rgb", w.rgb_w, w.rgb_b), ("mlp_trans", w.trans_w, w.trans_b)):
+        for i in range(4):
+            wt, bt = _f32(state[f"{prefix}{name}.{i}.weight"], name), _f32(state[f"{prefix}{name}.{i}.bias"], name)
+            keep.extend((wt, bt))
+            arr_w[i], arr_b[i] = wt.data_ptr(), bt.data_ptr()
+    check(lib.tp_mlp_pack_heads_f16x3(C.byref(w), packed.data_ptr(), _ptr(packed_t), _stream()), "tp_mlp_pack_heads_f16x3")
+
+
 _workspaces: Dict[Tuple[int, int], Tensor] = {}
 
 
@@ -393,14 +413,25 @@ def mlp_backward(nerf, lat_trans: Tensor, lat_light: Tensor, saved: Tensor, rgb:
             wf[i], gwf[i], gbf[i] = w.data_ptr(), gw.data_ptr(), gb.data_ptr()
     key = (dev.index or 0, torch.cuda.current_stream().cuda_stream)
     sc = _bwd_scratch.setdefault(key, {})
-    if "packed_t" not in sc:
-        sc["packed_t"] = torch.empty(int(lib.tp_mlp_packed_t_bytes()) // 4, device=dev)
     need = int(lib.tp_mlp_bwd_workspace_bytes(S)) // 4
     if "ws" not in sc or sc["ws"].numel() < need:
         sc["ws"] = torch.empty(need, device=dev)
+        sc.pop("clear_for", None)
     lat_trans, lat_light = _f32(lat_trans.detach(), "lat_trans"), _f32(lat_light.detach(), "lat_light")
     g_lt, g_ll = torch.empty(B, 16, device=dev), torch.empty(B, 48, device=dev)
-    a.packed_t, a.repack = sc["packed_t"].data_ptr(), 1
+    # the transposed weight image: the one the forward's pack launch of this step wrote (NeRF.packed_weights, f16x3 training), else
+    # rebuilt by this call
+    pre = nerf.packed_t_current() if (wgrad_precision == "f16x3" and hasattr(nerf, "packed_t_current")) else None
+    if pre is not None:
+        a.packed_t, a.repack = pre.data_ptr(), 0
+    else:
+        if "packed_t" not in sc:
+            sc["packed_t"] = torch.empty(int(lib.tp_mlp_packed_t_bytes()) // 4, device=dev)
+        a.packed_t, a.repack = sc["packed_t"].data_ptr(), 1
+    # the scale word inside the workspace is cleared by the last kernel of every call: no memset when the previous call used this
+    # workspace with this size
+    a.dz_max_is_clear = 1 if sc.get("clear_for") == (sc["ws"].data_ptr(), S, wgrad_precision) else 0
+    sc["clear_for"] = (sc["ws"].data_ptr(), S, wgrad_precision)
     a.saved, a.rgb, a.density, a.uncert = saved.data_ptr(), rgb.data_ptr(), density.data_ptr(), uncert.data_ptr()
     a.g_rgb, a.g_density, a.g_uncert = g_rgb.data_ptr(), g_density.data_ptr(), g_uncert.data_ptr()
     a.lat_trans, a.lat_light = lat_trans.data_ptr(), lat_light.data_ptr()
