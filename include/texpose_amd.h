@@ -303,7 +303,9 @@ typedef struct tp_sn_weight {
   int32_t accumulate;      /* bwd: grad += (the second normalised instance of the same weight in one optimiser step) */
 } tp_sn_weight;
 int64_t tp_sn_work_floats(int rows, int cols);
-int tp_sn_fwd(const tp_sn_weight* weights, int n, int training, tp_stream_t stream);
+/* tickets: 2 * TP_SN_MAX_WEIGHTS zero-filled device words (the kernels leave them zero; one array per stream that may run the
+ * call concurrently): the forward is then 3 launches (the last-arriving workgroup of a weight normalises), else 5 (NULL). */
+int tp_sn_fwd(const tp_sn_weight* weights, int n, int training, uint32_t* tickets, tp_stream_t stream);
 int tp_sn_bwd(const tp_sn_weight* weights, int n, tp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------

@@ -1990,6 +1990,32 @@ def test_device_counter_random_streams(ops):
     assert int(off) == 43
 
 
+def test_spectral_norm_fused_three_launch_form(ops, monkeypatch):
+    """tp_sn_fwd with arrival counters (TP_SN_FUSED=1: A + A2 and B + B2 fused, the last workgroup of a weight normalises) against the
+    default five-launch form on the PatchGAN's weight shapes, over three consecutive power iterations (the counters must come back
+    to zero): same W_sn / sigma / u / v up to the order of the 256- vs 1024-thread norm reductions."""
+    rs = np.random.RandomState(3)
+    shapes = [(256, 9 * 16), (512, 256 * 16), (64, 512 * 16), (64, 73), (64, 64), (1, 64)]
+    ws = [cu(torch.from_numpy(rs.normal(size=sh).astype(np.float32) * 0.05)) for sh in shapes]
+    res = []
+    for fused in (False, True):
+        if fused:
+            monkeypatch.setenv("TP_SN_FUSED", "1")
+        else:
+            monkeypatch.delenv("TP_SN_FUSED", raising=False)
+        us = [torch.nn.functional.normalize(cu(torch.from_numpy(np.random.RandomState(7 + i).normal(size=sh[0]).astype(np.float32))), dim=0)
+              for i, sh in enumerate(shapes)]
+        vs = [torch.nn.functional.normalize(cu(torch.from_numpy(np.random.RandomState(17 + i).normal(size=sh[1]).astype(np.float32))), dim=0)
+              for i, sh in enumerate(shapes)]
+        for _ in range(3):
+            outs, sig = ops.spectral_norm_fwd(ws, us, vs, True)
+        torch.cuda.synchronize()
+        res.append((outs, sig, [u.clone() for u in us], [v.clone() for v in vs]))
+    for a, b in zip(res[0], res[1]):
+        for x, y in zip(a, b):
+            torch.testing.assert_close(y, x, rtol=2e-6, atol=1e-7)
+
+
 def test_round3_launch_diet_pieces(ops):
     """Pieces of the launch diet, each against torch: MaxPool2d(2,2) forward / backward (ties after ReLU included), the composite
     backward with the cotangents of the rgb aliases and the density alias summed inside the launch (== engine adds), the loss total

@@ -203,7 +203,7 @@ def load() -> C.CDLL:
     sig("tp_eval_metrics_workspace_bytes", [C.c_int, C.c_int, C.c_int], C.c_int64)
     sig("tp_eval_metrics", [C.POINTER(EvalMetricsArgs), vp])
     sig("tp_sn_work_floats", [C.c_int, C.c_int], C.c_int64)
-    sig("tp_sn_fwd", [C.POINTER(SnWeight), C.c_int, C.c_int, vp])
+    sig("tp_sn_fwd", [C.POINTER(SnWeight), C.c_int, C.c_int, vp, vp])
     sig("tp_sn_bwd", [C.POINTER(SnWeight), C.c_int, vp])
     sig("tp_nerf_losses_fwd", [C.POINTER(NerfLossesArgs), vp])
     sig("tp_nerf_losses_bwd", [C.POINTER(NerfLossesArgs), vp, vp, vp, vp, vp, vp, vp])

@@ -35,7 +35,7 @@ __device__ __forceinline__ void nerf_losses_finalize(const float* partial, int n
   double v[4] = {0.0, 0.0, 0.0, 0.0};
   for (int i = tid; i < n_blocks; i += kBlock) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) v[k] += (double)partial[i * 4 + k];
+    for (int k = 0; k < 4; ++k) v[k] += (double)__hip_atomic_load(partial + i * 4 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 #pragma unroll
   for (int k = 0; k < 4; ++k) red[k][tid] = v[k];
@@ -58,6 +58,9 @@ __device__ __forceinline__ void nerf_losses_finalize(const float* partial, int n
 
 // The block that finishes LAST reduces the partials of all of them (a ticket in device memory, reset by that block): the forward
 // is one launch, and the order of the final reduction is the same whichever block runs it.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "the last-block hand-over below relies on the gfx950 agent-scope store / load contract (csrc/patch_conv.hip)"
+#endif
 __device__ unsigned int g_nerf_losses_ticket = 0;
 __global__ __launch_bounds__(kBlock) void nerf_losses_fwd_kernel(tp_nerf_losses_args a, float* partial, float n_pix_f, float n_den_f) {
   __shared__ float red[4 * kBlock];
@@ -82,16 +85,17 @@ __global__ __launch_bounds__(kBlock) void nerf_losses_fwd_kernel(tp_nerf_losses_
   const float2* den = reinterpret_cast<const float2*>(a.density);
   for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < n_den; e += (int64_t)gridDim.x * kBlock) v[3] += den[e].y;
   block_reduce4(v, red);
+  // hand-over without device-scope fences (the gfx950 contract of csrc/patch_conv.hip reduce_tiles: agent-scope stores, the storing
+  // lane drained, ONE agent-scope counter add; the last arriver loads agent-scope)
   if (threadIdx.x == 0) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) partial[blockIdx.x * 4 + k] = v[k];
-    __threadfence();                                                          // the partials are visible before the ticket is
-    last = atomicAdd(&g_nerf_losses_ticket, 1u) == gridDim.x - 1;
+    for (int k = 0; k < 4; ++k) __hip_atomic_store(partial + blockIdx.x * 4 + k, v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    last = __hip_atomic_fetch_add(&g_nerf_losses_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
   }
   __syncthreads();
   if (!last) return;
-  if (threadIdx.x == 0) g_nerf_losses_ticket = 0;
-  __threadfence();
+  if (threadIdx.x == 0) __hip_atomic_store(&g_nerf_losses_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   nerf_losses_finalize(partial, (int)gridDim.x, a.sums, a.losses, n_pix_f, n_den_f, red_d);
 }
 

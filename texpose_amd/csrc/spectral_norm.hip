@@ -5,7 +5,9 @@
 //     v <- normalize(W^T u),  u <- normalize(W v),  sigma = u . (W v),  W_sn = W / sigma       (W = weight.view(out, -1))
 // which PyTorch issues as ~15 tiny kernels per weight (mv, norm, clamp, div, dot, clones), i.e. ~90 per discriminator
 // forward and as many again in the backward -- ~600 of the ~1,350 launches of a training iteration.  Here all weights
-// of the module are processed together: five launches per forward (two in eval mode + scale), two per backward,
+// of the module are processed together: five launches per forward (two in eval mode + scale) -- or three with arrival counters
+// (A + A2, B + B2 fused: the last workgroup of a weight normalises; measured 1.4 % slower per GAN iteration: off by default) --,
+// two per backward,
 //     fwd :  A  t_part[slab] = W[slab rows]^T u      (column blocks x row slabs, coalesced rows)
 //            A2 v = normalize(sum_slabs t_part)       (one workgroup per weight; updates the module's v buffer)
 //            B  s = W v                               (one wave per row, lanes stride the columns)
@@ -23,6 +25,7 @@ struct Batch {
   tp_sn_weight w[kMaxW];
   int n;
   int blk_a[kMaxW + 1];   // prefix sums of workgroups per weight for the kernel being launched
+  unsigned int* tickets;  // fused kernels: [2][kMaxW] arrival counters (A, B), zero between launches
 };
 
 __device__ __forceinline__ int find_weight(const Batch& b, int blk, int& local) {
@@ -111,6 +114,104 @@ __global__ __launch_bounds__(256) void sn_u_kernel(Batch b, int training) {
   if (threadIdx.x == 0) *w.sigma = d;
 }
 
+// ---- A + A2 and B + B2 as ONE launch each (tp_sn_fwd with `tickets`): the workgroup of a weight that arrives LAST normalises.
+// Hand-over by the gfx950 contract of csrc/patch_conv.hip (reduce_tiles): handed-off words are stored and loaded agent-scope,
+// the storing lanes drained, one agent-scope counter add per workgroup behind a barrier; no device-scope fence (on gfx950 that
+// is a write-back + invalidate of the XCD's whole L2).  The reductions keep a fixed order: whichever workgroup is last runs the
+// same code over the same partials.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "the fused spectral-norm kernels rely on the gfx950 agent-scope store / load hand-over (csrc/patch_conv.hip)"
+#endif
+__device__ __forceinline__ bool arrive_last(unsigned int* ticket, int n_blocks) {
+  __shared__ int last;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this thread's stores are complete
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(n_blocks - 1);
+    if (last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
+  }
+  __syncthreads();
+  return last != 0;
+}
+__device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__global__ __launch_bounds__(256) void sn_wtu_v_kernel(Batch b) {
+  __shared__ float us[kSlabRows];
+  __shared__ float red[256];
+  int local;
+  const int wi = find_weight(b, blockIdx.x, local);
+  const tp_sn_weight& w = b.w[wi];
+  const int cblocks = (w.cols + 255) / 256;
+  const int slab = local / cblocks, cb = local - slab * cblocks;
+  const int r0 = slab * kSlabRows, nr = min(kSlabRows, w.rows - r0);
+  if (threadIdx.x < nr) us[threadIdx.x] = w.u[r0 + threadIdx.x];
+  __syncthreads();
+  const int c = cb * 256 + threadIdx.x;
+  if (c < w.cols) {
+    float acc = 0.0f;
+#pragma unroll 8
+    for (int r = 0; r < nr; ++r) acc = fmaf(w.weight[(int64_t)(r0 + r) * w.cols + c], us[r], acc);
+    st_agent(w.work + (int64_t)slab * w.cols + c, acc);
+  }
+  if (!arrive_last(b.tickets + wi, b.blk_a[wi + 1] - b.blk_a[wi])) return;
+  // A2 (one workgroup per weight): v = normalize(sum_slabs t_part).  The agent-scope loads travel past the L2 (~2 us each): 32 of
+  // them (4 columns x 8 slabs) are issued before the first is used; summed slab-ascending as in sn_v_kernel (absent slabs add 0).
+  const int slabs = (w.rows + kSlabRows - 1) / kSlabRows;
+  float ss = 0.0f;
+  for (int c0 = threadIdx.x; c0 < w.cols; c0 += 256 * 4) {
+    float part[4][TP_SN_MAX_SLABS];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int sl = 0; sl < TP_SN_MAX_SLABS; ++sl)
+        part[j][sl] = (c0 + 256 * j < w.cols && sl < slabs) ? ld_agent(w.work + (int64_t)sl * w.cols + c0 + 256 * j) : 0.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (c0 + 256 * j >= w.cols) continue;
+      float t = 0.0f;
+#pragma unroll
+      for (int sl = 0; sl < TP_SN_MAX_SLABS; ++sl) t += part[j][sl];
+      w.v[c0 + 256 * j] = t;
+      ss = fmaf(t, t, ss);
+    }
+  }
+  const float nrm = fmaxf(sqrtf(block_sum(ss, red)), 1e-12f);
+  for (int cc = threadIdx.x; cc < w.cols; cc += 256) w.v[cc] = w.v[cc] / nrm;
+}
+
+__global__ __launch_bounds__(256) void sn_wv_u_kernel(Batch b, int training) {
+  __shared__ float red[256];
+  int local;
+  const int wi = find_weight(b, blockIdx.x, local);
+  const tp_sn_weight& w = b.w[wi];
+  const int r = local * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  float* s = w.work + (int64_t)TP_SN_MAX_SLABS * w.cols;
+  if (r < w.rows) {
+    const float* row = w.weight + (int64_t)r * w.cols;
+    float acc = 0.0f;
+#pragma unroll 8
+    for (int c = lane; c < w.cols; c += 64) acc = fmaf(row[c], w.v[c], acc);
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (lane == 0) st_agent(s + r, acc);
+  }
+  if (!arrive_last(b.tickets + kMaxW + wi, b.blk_a[wi + 1] - b.blk_a[wi])) return;
+  // B2 (one workgroup per weight): u = normalize(s) (training); sigma = u . s   (rows <= 512: two values per thread, loaded once)
+  const int r_a = threadIdx.x, r_b = threadIdx.x + 256;
+  const float s_a = r_a < w.rows ? ld_agent(s + r_a) : 0.0f, s_b = r_b < w.rows ? ld_agent(s + r_b) : 0.0f;
+  float u_a = r_a < w.rows ? w.u[r_a] : 0.0f, u_b = r_b < w.rows ? w.u[r_b] : 0.0f;
+  if (training) {
+    const float ss = fmaf(s_b, s_b, fmaf(s_a, s_a, 0.0f));
+    const float nrm = fmaxf(sqrtf(block_sum(ss, red)), 1e-12f);
+    u_a = s_a / nrm; u_b = s_b / nrm;
+    if (r_a < w.rows) w.u[r_a] = u_a;
+    if (r_b < w.rows) w.u[r_b] = u_b;
+  }
+  float d = fmaf(u_b, s_b, fmaf(u_a, s_a, 0.0f));
+  d = block_sum(d, red);
+  if (threadIdx.x == 0) *w.sigma = d;
+}
+
 // C: W_sn = W / sigma
 __global__ __launch_bounds__(256) void sn_scale_kernel(Batch b) {
   int local;
@@ -180,18 +281,27 @@ extern "C" int64_t tp_sn_work_floats(int rows, int cols) {
   return fwd > bwd ? fwd : bwd;
 }
 
-extern "C" int tp_sn_fwd(const tp_sn_weight* ws, int n, int training, tp_stream_t stream) {
+extern "C" int tp_sn_fwd(const tp_sn_weight* ws, int n, int training, uint32_t* tickets, tp_stream_t stream) {
   if (int rc = check(ws, n, false, "tp_sn_fwd")) return rc;
   hipStream_t st = (hipStream_t)stream;
   Batch b;
+  b.tickets = tickets;
   if (training) {
     int g = fill(b, ws, n, [](const tp_sn_weight& w) { return ((w.cols + 255) / 256) * ((w.rows + kSlabRows - 1) / kSlabRows); });
-    hipLaunchKernelGGL(sn_wtu_kernel, dim3(g), dim3(256), 0, st, b);
-    hipLaunchKernelGGL(sn_v_kernel, dim3(n), dim3(1024), 0, st, b);
+    if (tickets) {
+      hipLaunchKernelGGL(sn_wtu_v_kernel, dim3(g), dim3(256), 0, st, b);
+    } else {
+      hipLaunchKernelGGL(sn_wtu_kernel, dim3(g), dim3(256), 0, st, b);
+      hipLaunchKernelGGL(sn_v_kernel, dim3(n), dim3(1024), 0, st, b);
+    }
   }
   int g = fill(b, ws, n, [](const tp_sn_weight& w) { return (w.rows + 3) / 4; });
-  hipLaunchKernelGGL(sn_wv_kernel, dim3(g), dim3(256), 0, st, b);
-  hipLaunchKernelGGL(sn_u_kernel, dim3(n), dim3(256), 0, st, b, training);
+  if (tickets) {
+    hipLaunchKernelGGL(sn_wv_u_kernel, dim3(g), dim3(256), 0, st, b, training);
+  } else {
+    hipLaunchKernelGGL(sn_wv_kernel, dim3(g), dim3(256), 0, st, b);
+    hipLaunchKernelGGL(sn_u_kernel, dim3(n), dim3(256), 0, st, b, training);
+  }
   g = fill(b, ws, n, [](const tp_sn_weight& w) { return (int)(((int64_t)w.rows * w.cols + 1023) / 1024); });
   hipLaunchKernelGGL(sn_scale_kernel, dim3(g), dim3(256), 0, st, b);
   return tp::check_launch("tp_sn_fwd");
@@ -201,6 +311,7 @@ extern "C" int tp_sn_bwd(const tp_sn_weight* ws, int n, tp_stream_t stream) {
   if (int rc = check(ws, n, true, "tp_sn_bwd")) return rc;
   hipStream_t st = (hipStream_t)stream;
   Batch b;
+  b.tickets = nullptr;
   int g = fill(b, ws, n, [](const tp_sn_weight& w) { return (int)(((int64_t)w.rows * w.cols + 4095) / 4096); });
   hipLaunchKernelGGL(sn_dot_kernel, dim3(g), dim3(256), 0, st, b);
   g = fill(b, ws, n, [](const tp_sn_weight& w) { return (int)(((int64_t)w.rows * w.cols + 1023) / 1024); });

@@ -11,6 +11,8 @@ import ctypes as C
 import functools
 from typing import Dict, Optional, Tuple
 
+import os
+
 import torch
 
 from . import _lib
@@ -560,11 +562,30 @@ def eval_metrics(rgb_static: Tensor, image: Tensor, obj_mask: Tensor, H: int, W:
     return -10.0 * torch.log10(mse), out[:, 1].sum() / n, mse
 
 
+_sn_ticket_arrays = {}       # (device index, stream) -> zero-filled int32 tensor (the kernels leave it zero)
+
+
+def _sn_tickets(dev) -> Optional[int]:
+    """Arrival counters of the fused spectral-norm kernels for the current stream (launches on different streams may overlap and
+    must not share them).  Inside a hipGraph capture on a stream that has none yet: None, i.e. the five-launch form."""
+    # measured (B=4 GAN step, same box, three alternating runs each): 3 launches 657-660 it/s, 5 launches 666-667 it/s -- the
+    # last-arriving workgroup's agent-scope loads (~2 us each, past the L2) cost more than the two launches they replace
+    if os.environ.get("TP_SN_FUSED") != "1":
+        return None
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    t = _sn_ticket_arrays.get(key)
+    if t is None:
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        t = _sn_ticket_arrays[key] = torch.zeros(2 * _lib.SN_MAX_WEIGHTS, dtype=torch.int32, device=dev)
+    return t.data_ptr()
+
+
 @_on_tensor_device
 def spectral_norm_fwd(weights, us, vs, training: bool, keep_uv: bool = False):
     """weights[i] [out, ...] (contiguous), us[i] [out], vs[i] [K]: one power iteration per weight when ``training``
     (u, v updated IN PLACE, like torch.nn.utils.spectral_norm), then W_sn = W / sigma.  Returns (W_sn list, sigma
-    list of 1-element tensors).  All weights of a module in five launches.  ``keep_uv``: also returns copies of u / v as
+    list of 1-element tensors).  All weights of a module in five launches (three with TP_SN_FUSED=1: slower, see _sn_tickets).  ``keep_uv``: also returns copies of u / v as
     they stand after this call (written by the last launch) as a third / fourth list."""
     lib = _lib.load()
     n = len(weights)
@@ -586,7 +607,7 @@ def spectral_norm_fwd(weights, us, vs, training: bool, keep_uv: bool = False):
         if keep_uv:
             a.u_out, a.v_out = u_copies[i].data_ptr(), v_copies[i].data_ptr()
         outs.append(o); sigmas.append(sg); keep += [w, wk]
-    check(lib.tp_sn_fwd(arr, n, int(bool(training)), _stream()), "tp_sn_fwd")
+    check(lib.tp_sn_fwd(arr, n, int(bool(training)), _sn_tickets(weights[0].device), _stream()), "tp_sn_fwd")
     return (outs, sigmas, u_copies, v_copies) if keep_uv else (outs, sigmas)
 
 
