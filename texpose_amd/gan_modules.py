@@ -1,7 +1,10 @@
 """Modules that sit NEXT to the hot path in a training iteration: the PatchGAN discriminator
-and the VGG perceptual loss.  Convolutions / norms run on MIOpen / rocBLAS through PyTorch-ROCm (autograd incl. the
-R1 double backward); the spectral normalisation of the six discriminator weights -- ~600 of the ~1,350 kernel
-launches of an iteration in stock PyTorch -- goes through the fused tp_sn_fwd / tp_sn_bwd kernels.  Written from the reference's architecture description
+and the VGG perceptual loss.  On the GPU every layer runs on this repo's HIP kernels, differentiable to the order the
+step needs (the R1 penalty is a double backward): spectral normalisation (K7: ~600 of the ~1,350 launches of an iteration in
+stock PyTorch), stride-2 4x4 convolutions (K11), InstanceNorm + LeakyReLU (K9), the full-map convolution (K15), the
+scale-conditioned head (K14); the feature network's 3x3 convolutions (K12) and 2x2 max pools (K13).  CPU tensors (goldens,
+contract tests) go through the stock torch modules.  The discriminator STEP of a training iteration does not go through
+autograd at all on the GPU: texpose_amd/disc_step.py (K16).  Written from the reference's architecture description
 (layers/discriminator.py:8-173, layers/perceptual_loss.py:8-45), state-dict compatible with it:
 ``main.{0,3,6}.weight_{orig,u,v}``, ``final.{1,3,5}.weight_{orig,u,v}``, ``progress`` for patch_size 16.
 
