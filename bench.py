@@ -500,7 +500,7 @@ def main():
         achieved = MLP_FLOP_PER_SAMPLE * samples / (ms * 1e-3) / 1e12
         peak = MFMA_PEAK_TFLOPS[precision]
         k = ISSUED_PER_ALGORITHMIC[precision]
-        return {"kernel": "mlp_fwd_kernel" if precision == "fp32" else "mlp_fwd_f16x3_kernel", "bound": "mfma",
+        return {"kernel": "mlp_fwd_exact_asm_kernel" if precision == "fp32" else "mlp_fwd_f16x3_kernel", "bound": "mfma",
                 "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": measured_traffic(precision, samples),
                 "traffic_unit": "bytes/launch, L2<->fabric (FETCH_SIZE x2 + WRITE_SIZE, profiles/traffic.json)",
                 "kernel_ms": ms, "samples_per_launch": samples, "flop_per_sample": MLP_FLOP_PER_SAMPLE,

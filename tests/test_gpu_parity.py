@@ -1957,6 +1957,33 @@ def test_round3_glue_kernels_match_torch(ops):
     torch.testing.assert_close(rgb.grad, cot[:, :3].permute(0, 2, 3, 1).reshape(B, p * p, 3))
 
 
+@pytest.mark.parametrize("B,R,N", [(1, 64, 32), (2, 37, 19), (1, 512, 64)])
+def test_exact_fp32_asm_kernel_bit_identical_to_compiled(ops, monkeypatch, B, R, N):
+    """The exact-fp32 forward on generated blocks (csrc/gen_fp32_asm.py: accumulator sets in AGPRs, B operands read from them, the
+    trunk feature held on the CU) against the compiled kernel it replaces for inference (TP_FP32_CXX=1): the same instructions in
+    the same order, so every output is bit-identical -- ragged sizes, both input forms."""
+    params = {k: cu(v) for k, v in O.make_params(12).items()}
+    packed = ops.pack_weights(params)
+    rs = np.random.RandomState(B * 1000 + R + N)
+    center = cu(torch.from_numpy(rs.normal(size=(B, R, 3)).astype(np.float32)))
+    ray = cu(torch.from_numpy(rs.normal(size=(B, R, 3)).astype(np.float32)))
+    depth = cu(torch.from_numpy(rs.uniform(0.5, 2.0, size=(B, R, N, 1)).astype(np.float32)))
+    lt = cu(torch.from_numpy(rs.normal(size=(B, 16)).astype(np.float32)))
+    ll = cu(torch.from_numpy(rs.normal(size=(B, 48)).astype(np.float32)))
+    pts = center[:, :, None] + ray[:, :, None] * depth
+    unit = torch.nn.functional.normalize(ray, dim=-1)[:, :, None].expand(B, R, N, 3).contiguous()
+    outs = []
+    for cxx in ("1", "0"):
+        monkeypatch.setenv("TP_FP32_CXX", cxx)
+        a = ops.mlp_forward(packed, lt, ll, center=center, ray=ray, depth=depth, precision="fp32")
+        b = ops.mlp_forward(packed, lt, ll, points=pts.contiguous(), ray_unit=unit, precision="fp32")
+        torch.cuda.synchronize()
+        outs.append([t.clone() for t in a] + [t.clone() for t in b])
+    for x, y in zip(*outs):
+        assert torch.equal(x, y)
+    assert float(outs[1][0].abs().sum()) > 0
+
+
 def test_device_counter_random_streams(ops):
     """The random draws of a captured training step: tp_patch_coords with u = NULL equals the same kernel fed the Philox words
     (key = seed, counter (b, c_lo, 'patc', c_hi)) computed by the oracle's Philox; tp_raygen with offset_dev equals offset passed on

@@ -23,6 +23,7 @@
 //    out per sample against 1.82 MFLOP of work.
 //  * persistent workgroups (grid <= CUs) walk sample tiles; the trunk feature needed by both
 //    heads is parked in a per-workgroup scratch slab (each lane re-reads only what it wrote).
+#include <cstdlib>
 #include "mlp_mma.h"
 
 namespace {
@@ -263,6 +264,218 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_kernel(Params P) {
   }
 }
 
+// =====================================================================================================================
+// Round 3: the same forward with the two accumulator sets pinned to the AGPR file and touched only by the generated blocks of
+// fp32_asm.inc.h (gen_fp32_asm.py: register map, operand layout, hazards).  Layer li reads set (li even ? Q : P) as its B operand
+// straight from the accumulators and writes set (li even ? P : Q); bias + ReLU rewrite a set in place.  The compiled code no
+// longer holds h[8] / acc[8] (256 registers), so the trunk feature stays ON THE CU as an ordinary 128-register value between the
+// end of the trunk and the colour head (the compiled kernel above parks it in a global slab: 141 GB of cache traffic per
+// 480x640x128 image, profiles/traffic.json).  Same arithmetic, instruction for instruction: exact fp32 products, k order, bias
+// added last -- bit-identical outputs (tests/test_gpu_parity.py::test_exact_fp32_asm_kernel_bit_identical_to_compiled).
+// Inference only (no record): the recording variant of the exact kernel stays the compiled one.
+// =====================================================================================================================
+#include "fp32_asm.inc.h"
+
+#define TP32_CLOB TP32_ACT_CLOBBERS, TP32_ALL_AGPRS, "memory"
+#define TP32_GEN_CASE(NAME, TS) if constexpr (ts == TS) asm volatile(NAME##TS : : [a] "v"(a) : TP32_CLOB)
+template <bool SRC_P, int ts>
+__device__ __forceinline__ void asm32_gen(unsigned a) {
+  if constexpr (SRC_P) {
+    TP32_GEN_CASE(TP32_GEN_PQ_, 0); TP32_GEN_CASE(TP32_GEN_PQ_, 1); TP32_GEN_CASE(TP32_GEN_PQ_, 2); TP32_GEN_CASE(TP32_GEN_PQ_, 3);
+    TP32_GEN_CASE(TP32_GEN_PQ_, 4); TP32_GEN_CASE(TP32_GEN_PQ_, 5); TP32_GEN_CASE(TP32_GEN_PQ_, 6); TP32_GEN_CASE(TP32_GEN_PQ_, 7);
+  } else {
+    TP32_GEN_CASE(TP32_GEN_QP_, 0); TP32_GEN_CASE(TP32_GEN_QP_, 1); TP32_GEN_CASE(TP32_GEN_QP_, 2); TP32_GEN_CASE(TP32_GEN_QP_, 3);
+    TP32_GEN_CASE(TP32_GEN_QP_, 4); TP32_GEN_CASE(TP32_GEN_QP_, 5); TP32_GEN_CASE(TP32_GEN_QP_, 6); TP32_GEN_CASE(TP32_GEN_QP_, 7);
+  }
+}
+// kind: 0 = 16 k-steps, first with C = 0; 1 = 16 k-steps; 2 = 8 k-steps
+template <bool DST_P, int kind>
+__device__ __forceinline__ void asm32_extra(unsigned a, unsigned b) {
+  if constexpr (DST_P) {
+    if constexpr (kind == 0) asm volatile(TP32_EXTRA16Z_P : : [a] "v"(a), [b] "v"(b) : TP32_CLOB);
+    else if constexpr (kind == 1) asm volatile(TP32_EXTRA16_P : : [a] "v"(a), [b] "v"(b) : TP32_CLOB);
+    else asm volatile(TP32_EXTRA8_P : : [a] "v"(a), [b] "v"(b) : TP32_CLOB);
+  } else {
+    if constexpr (kind == 0) asm volatile(TP32_EXTRA16Z_Q : : [a] "v"(a), [b] "v"(b) : TP32_CLOB);
+    else if constexpr (kind == 1) asm volatile(TP32_EXTRA16_Q : : [a] "v"(a), [b] "v"(b) : TP32_CLOB);
+    else asm volatile(TP32_EXTRA8_Q : : [a] "v"(a), [b] "v"(b) : TP32_CLOB);
+  }
+}
+template <bool SET_P>
+__device__ __forceinline__ void asm32_act(unsigned bl) {
+  if constexpr (SET_P) asm volatile(TP32_ACT_P : : [bl] "v"(bl) : TP32_CLOB);
+  else asm volatile(TP32_ACT_Q : : [bl] "v"(bl) : TP32_CLOB);
+}
+template <bool SET_P>
+__device__ __forceinline__ f32x16 asm32_head(unsigned a) {
+  f32x16 v;
+  if constexpr (SET_P) asm volatile(TP32_HEAD_P : "={v[232:247]}"(v) : [a] "v"(a) : TP32_RING_CLOBBERS, TP32_ALL_AGPRS, "memory");
+  else asm volatile(TP32_HEAD_Q : "={v[232:247]}"(v) : [a] "v"(a) : TP32_RING_CLOBBERS, TP32_ALL_AGPRS, "memory");
+  return v;
+}
+#define TP32_SF_OUT(F)                                                                                                 \
+  "={v[32:47]}"(F[0]), "={v[48:63]}"(F[1]), "={v[64:79]}"(F[2]), "={v[80:95]}"(F[3]), "={v[96:111]}"(F[4]),            \
+      "={v[112:127]}"(F[5]), "={v[128:143]}"(F[6]), "={v[144:159]}"(F[7])
+#define TP32_SF_IN(F)                                                                                                  \
+  "{v[32:47]}"(F[0]), "{v[48:63]}"(F[1]), "{v[64:79]}"(F[2]), "{v[80:95]}"(F[3]), "{v[96:111]}"(F[4]),                 \
+      "{v[112:127]}"(F[5]), "{v[128:143]}"(F[6]), "{v[144:159]}"(F[7])
+
+__device__ __forceinline__ unsigned lds_addr(const float* p) { return (unsigned)(uintptr_t)AS3(p); }
+
+// one 256 -> 256 part: 8 chunks, chunk ts contracts tile ts of the source set
+template <bool SRC_P>
+__device__ __forceinline__ void part_gen_asm(Pipe& p) {
+#define TP32_STEP(TS) chunk_begin(p, kNumChunks); asm32_gen<SRC_P, TS>(lds_addr(chunk_ptr(p))); chunk_end(p, kNumChunks)
+  TP32_STEP(0); TP32_STEP(1); TP32_STEP(2); TP32_STEP(3); TP32_STEP(4); TP32_STEP(5); TP32_STEP(6); TP32_STEP(7);
+#undef TP32_STEP
+}
+template <bool SET_P>
+__device__ __forceinline__ f32x16 part_head_asm(Pipe& p) {
+  chunk_begin(p, kNumChunks);
+  const f32x16 v = asm32_head<SET_P>(lds_addr(chunk_ptr(p)));
+  chunk_end(p, kNumChunks);
+  return v;
+}
+template <bool DST_P, int kind>
+__device__ __forceinline__ void part_extra_asm(Pipe& p, const float* staged) {
+  chunk_begin(p, kNumChunks);
+  asm32_extra<DST_P, kind>(lds_addr(chunk_ptr(p)), lds_addr(staged));
+  chunk_end(p, kNumChunks);
+}
+
+__global__ __launch_bounds__(kThreads, 1) void mlp_fwd_exact_asm_kernel(Params P) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 31, hh = lane >> 5;
+  float* bias_lds = lds + 2 * kChunkFloats;
+  float* enc_lds = bias_lds + kBiasPad + tid;                       // per-lane staging, [k-step][thread] (see the kernel above)
+  float* ex_lds = bias_lds + kBiasPad + kEncFloats + tid;
+
+  Pipe p;
+  p.stream = P.packed; p.lds = lds; p.chunk = 0; p.buf = 0; p.wave = __builtin_amdgcn_readfirstlane(wave); p.lane = lane;
+  for (int i = tid; i < kBiasFloats; i += kThreads) bias_lds[i] = P.packed[(size_t)kNumChunks * kChunkFloats + i];
+  dma_chunk(p, 0, 0);
+  __syncthreads();
+
+  for (int64_t tile = blockIdx.x; tile < P.n_tiles; tile += gridDim.x) {
+    const int64_t s_raw = tile * kTileSamples + wave * 32 + j;
+    const bool live = s_raw < P.n_samples;
+    const int64_t s = live ? s_raw : P.n_samples - 1;
+    const int64_t q = s / P.N;
+    const int b = (int)(q / P.R);
+    float x[3], vu[3];
+    if (P.center != nullptr) {
+      const float z = P.depth[s];
+      float nrm = 0.f;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float d = P.ray[3 * q + c];
+        x[c] = tp::add_rn(P.center[3 * q + c], tp::mul_rn(d, z));
+        nrm = tp::add_rn(nrm, tp::mul_rn(d, d));
+        vu[c] = d;
+      }
+      const float den = fmaxf(sqrtf(nrm), 1e-12f);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) vu[c] = tp::div_rn(vu[c], den);
+    } else {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { x[c] = P.points[3 * s + c]; vu[c] = P.ray_unit[3 * s + c]; }
+    }
+#pragma nounroll
+    for (int r = 0; r < 30; ++r) {
+      const int c = r / 10;
+      const float xc = c == 0 ? x[0] : (c == 1 ? x[1] : x[2]);
+      const float arg = tp::mul_rn(xc, ldexpf(3.14159274101257324f, r - c * 10));
+      enc_lds[r * kThreads] = tp::sincos_sel(arg, hh);
+    }
+    enc_lds[30 * kThreads] = hh ? x[1] : x[0];
+    enc_lds[31 * kThreads] = hh ? 0.0f : x[2];
+    // the colour head's extra inputs do not depend on the network: staged now, so that nothing but the blocks runs between the
+    // trunk and the heads ([ray_unit, PE(ray_unit), x, light], layers/...light.py:104-117)
+#pragma nounroll
+    for (int r = 0; r < 12; ++r) {
+      const int c = r >> 2;
+      const float vc = c == 0 ? vu[0] : (c == 1 ? vu[1] : vu[2]);
+      const float arg = tp::mul_rn(vc, ldexpf(3.14159274101257324f, r & 3));
+      ex_lds[r * kThreads] = tp::sincos_sel(arg, hh);
+    }
+    ex_lds[12 * kThreads] = hh ? vu[1] : vu[0];
+    ex_lds[13 * kThreads] = hh ? x[0] : vu[2];
+    ex_lds[14 * kThreads] = hh ? x[2] : x[1];
+#pragma unroll
+    for (int r = 15; r < 39; ++r) ex_lds[r * kThreads] = P.lat_light[b * 48 + (r - 15) + 24 * hh];
+    ex_lds[39 * kThreads] = 0.0f;
+    const unsigned bias0 = lds_addr(bias_lds) + (unsigned)hh * 512u;            // + li * 1024: bias block of wide layer li
+
+    // ---- trunk: L0 (extras only) .. L7; set parity: even layers write P, odd layers write Q
+    part_extra_asm<true, 0>(p, enc_lds);
+    part_extra_asm<true, 1>(p, enc_lds + 16 * kThreads);
+    asm32_act<true>(bias0 + L0 * 1024u);
+#pragma nounroll
+    for (int li = L1; li <= L6; li += 2) {                                      // (L1, L2), (L3, L4), (L5, L6)
+      part_gen_asm<true>(p);
+      asm32_act<false>(bias0 + (unsigned)li * 1024u);
+      part_gen_asm<false>(p);
+      if (li + 1 == L4) {                                                       // [x, PE(x)] again (layers/...light.py:90-91)
+        part_extra_asm<true, 1>(p, enc_lds);
+        part_extra_asm<true, 1>(p, enc_lds + 16 * kThreads);
+      }
+      asm32_act<true>(bias0 + (unsigned)(li + 1) * 1024u);
+    }
+    const f32x16 hs = part_head_asm<true>(p);                                   // static density = softplus(row 0 of mlp_feat.7)
+    const float sig_s = softplus(hs[0] + bias_lds[kHeadBiasOff + 0]);
+    part_gen_asm<true>(p);                                                      // L7 -> Q
+    asm32_act<false>(bias0 + L7 * 1024u);
+    f32x16 F[8];
+    asm volatile(TP32_STASH_Q : TP32_SF_OUT(F) : : TP32_ALL_AGPRS);            // the trunk feature, held until the colour head
+
+    // ---- transient head: T0 (Q + latent -> P), T1 (-> Q), T2 (-> P)
+    float* lat_lds = enc_lds;                                                   // (the [x, PE(x)] rows are dead after L4)
+#pragma unroll
+    for (int r = 0; r < 8; ++r) lat_lds[r * kThreads] = P.lat_trans[b * 16 + r + 8 * hh];
+    part_gen_asm<false>(p);
+    part_extra_asm<true, 2>(p, lat_lds);
+    asm32_act<true>(bias0 + T0 * 1024u);
+    part_gen_asm<true>(p);
+    asm32_act<false>(bias0 + T1 * 1024u);
+    part_gen_asm<false>(p);
+    asm32_act<true>(bias0 + T2 * 1024u);
+    const f32x16 ht = part_head_asm<true>(p);
+    const float* hb = bias_lds + kHeadBiasOff + 1;
+    const float rgb_t0 = sigmoid(ht[0] + hb[0]), rgb_t1 = sigmoid(ht[1] + hb[1]), rgb_t2 = sigmoid(ht[2] + hb[2]);
+    const float sig_t = softplus(ht[3] + hb[3]);
+    const float unc = softplus(ht[0] + hb[4]);                                  // row 4 lives in register 0 of the upper lane half
+
+    // ---- colour head: R0 (feature restored into P, + extras -> Q), R1 (-> P), R2 (-> Q)
+    asm volatile(TP32_RESTORE_P : : TP32_SF_IN(F) : TP32_ALL_AGPRS);
+    part_gen_asm<true>(p);
+    part_extra_asm<false, 1>(p, ex_lds);
+    part_extra_asm<false, 1>(p, ex_lds + 16 * kThreads);
+    part_extra_asm<false, 2>(p, ex_lds + 32 * kThreads);
+    asm32_act<false>(bias0 + R0 * 1024u);
+    part_gen_asm<false>(p);
+    asm32_act<true>(bias0 + R1 * 1024u);
+    part_gen_asm<true>(p);
+    asm32_act<false>(bias0 + R2 * 1024u);
+    const f32x16 hr = part_head_asm<false>(p);
+    const float* hc = bias_lds + kHeadBiasOff + 6;
+    const float rgb_s0 = sigmoid(hr[0] + hc[0]), rgb_s1 = sigmoid(hr[1] + hc[1]), rgb_s2 = sigmoid(hr[2] + hc[2]);
+
+    if (live) {   // streaming stores: the 3.7 MB weight stream is what should stay in the 4 MB L2, not 36 B per sample of outputs
+      using f32x2 = __attribute__((ext_vector_type(2))) float;
+      if (hh == 0) {
+        f32x2* o = reinterpret_cast<f32x2*>(P.rgb + s * 6);
+        __builtin_nontemporal_store(f32x2{rgb_s0, rgb_t0}, o);
+        __builtin_nontemporal_store(f32x2{rgb_s1, rgb_t1}, o + 1);
+        __builtin_nontemporal_store(f32x2{rgb_s2, rgb_t2}, o + 2);
+        __builtin_nontemporal_store(f32x2{sig_s, sig_t}, reinterpret_cast<f32x2*>(P.density + s * 2));
+      } else {
+        __builtin_nontemporal_store(unc, P.uncert + s);
+      }
+    }
+  }
+}
+
 // standalone positional encoding (API parity with NeRF.positional_encoding)
 __global__ void posenc_kernel(const float* __restrict__ x, int64_t n, int C, int L, float* __restrict__ out) {
   const int64_t total = n * C * 2 * L;
@@ -320,13 +533,21 @@ extern "C" int tp_mlp_fwd(const tp_mlp_fwd_args* a, tp_stream_t stream) {
     if (e == hipSuccess)
       e = hipFuncSetAttribute((const void*)mlp_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               kLdsFloats * (int)sizeof(float));
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void*)mlp_fwd_exact_asm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              kLdsFloats * (int)sizeof(float));
     if (e != hipSuccess) { tp::set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
   }
   const int grid = persistent_grid(P.n_tiles);
+  // inference: the block kernel (trunk feature on the CU); TP_FP32_CXX=1 selects the compiled kernel (A/B, bit-identity test)
+  const char* env_cxx = getenv("TP_FP32_CXX");                      // (read per call: a test switches it inside one process)
+  const bool exact_cxx = env_cxx != nullptr && env_cxx[0] == '1';
   if (P.saved != nullptr)
     hipLaunchKernelGGL(mlp_fwd_kernel<true>, dim3(grid), dim3(kThreads), kLdsFloats * sizeof(float), (hipStream_t)stream, P);
-  else
+  else if (exact_cxx)
     hipLaunchKernelGGL(mlp_fwd_kernel<false>, dim3(grid), dim3(kThreads), kLdsFloats * sizeof(float), (hipStream_t)stream, P);
+  else
+    hipLaunchKernelGGL(mlp_fwd_exact_asm_kernel, dim3(grid), dim3(kThreads), kLdsFloats * sizeof(float), (hipStream_t)stream, P);
   return tp::check_launch("tp_mlp_fwd");
 }
 
