@@ -59,7 +59,7 @@ class _Mlp(torch.autograd.Function):
     @staticmethod
     def forward(ctx, nerf, need_grad, lat_trans, lat_light, center, ray, depth, points, ray_unit, *head_params):
         precision = nerf.train_precision if need_grad else nerf.precision
-        packed = nerf.packed_weights(precision)
+        packed = nerf.packed_weights(precision, for_training=bool(need_grad))       # (grad mode is off in here: the caller decided)
         res = ops.mlp_forward(packed, lat_trans, lat_light, center=center, ray=ray, depth=depth, points=points,
                               ray_unit=ray_unit, save=need_grad, precision=precision)
         if need_grad:

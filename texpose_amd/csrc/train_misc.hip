@@ -163,13 +163,17 @@ __global__ __launch_bounds__(kBlock) void adam_kernel(AdamTable t, const float* 
     if (gate[k] != 0) return;
   const double lr = lr_dev != nullptr ? (double)*lr_dev : lr_host;
   const float b2 = (float)beta2;
-  int k = 0;
+  int k = 0, k_done = -1;
+  float step_size = 0.f, bc2_sqrt = 1.f;
   for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < total; e += (int64_t)gridDim.x * kBlock) {
     while (e >= t.end[k]) ++k;
     const int64_t i = e - (k == 0 ? 0 : t.end[k - 1]);
-    const double step = (double)t.step[k][0] + 1.0;
-    const double bc1 = 1.0 - pow(beta1, step), bc2 = 1.0 - pow(beta2, step);
-    const float step_size = (float)(lr / bc1), bc2_sqrt = (float)sqrt(bc2);
+    if (k != k_done) {                                     // the bias corrections are per tensor: two double pow() once, not per element
+      const double step = (double)t.step[k][0] + 1.0;
+      const double bc1 = 1.0 - pow(beta1, step), bc2 = 1.0 - pow(beta2, step);
+      step_size = (float)(lr / bc1); bc2_sqrt = (float)sqrt(bc2);
+      k_done = k;
+    }
     const float g = t.g[k][i];
     float m = t.m[k][i], v = t.v[k][i];
     m = tp::add_rn(m, tp::mul_rn(tp::sub_rn(g, m), w1));                      // exp_avg.lerp_(grad, 1 - beta1): w1 = (float)(1 - beta1)
@@ -411,7 +415,7 @@ int tp_adam_step(const tp_adam_tensor* tensors, int n, const float* lr_dev, doub
   for (int k = n; k < TP_ADAM_MAX_TENSORS; ++k) { t.p[k] = nullptr; t.g[k] = nullptr; t.m[k] = nullptr; t.v[k] = nullptr; t.step[k] = nullptr; t.end[k] = total; }
   t.n = n;
   int64_t blocks = (total + kBlock - 1) / kBlock;
-  if (blocks > 2048) blocks = 2048;
+  if (blocks > 512) blocks = 512;          // (one arrival per block on ONE counter word: 1,700 same-address atomics cost 16 us)
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, t, lr_dev, lr_host, beta1, beta2, (float)eps,
                      (float)(1.0 - beta1), (float)(1.0 - beta2), total, gate, n_gate);
   return tp::check_launch("tp_adam_step");

@@ -8,6 +8,7 @@ architecture is compiled into the kernels; anything else raises instead of silen
 from __future__ import annotations
 
 import math
+import os
 from typing import Optional
 
 import torch
@@ -104,9 +105,10 @@ class NeRF(torch.nn.Module):
         """(name, parameter) of the trainable heads, in a fixed order shared by forward and backward."""
         return [(k, p) for k, p in self.named_parameters() if k.startswith(("mlp_rgb", "mlp_trans"))]
 
-    def packed_weights(self, precision: str = "fp32") -> torch.Tensor:
+    def packed_weights(self, precision: str = "fp32", for_training: bool = False) -> torch.Tensor:
         """MFMA-ordered weight stream for ``precision``, re-packed lazily: trunk once (frozen), heads when an
-        optimiser step or a load_state_dict bumped a parameter version."""
+        optimiser step or a load_state_dict bumped a parameter version.  ``for_training`` (a recording f16x3 forward whose
+        backward will run): the same launch also writes the transposed head image of that backward."""
         st = self._state()
         vt = tuple((p.data_ptr(), p._version) for k, p in st.items() if k.startswith("mlp_feat"))
         vh = tuple((p.data_ptr(), p._version) for k, p in st.items() if not k.startswith("mlp_feat"))
@@ -121,7 +123,7 @@ class NeRF(torch.nn.Module):
                 ops.pack_weights(st, packed=buf, parts=ops.PACK_TRUNK, precision=precision)
                 ver[0] = vt
             if ver[1] != vh:
-                if precision == "f16x3" and torch.is_grad_enabled() and any(p.requires_grad for _, p in self.head_parameters()):
+                if precision == "f16x3" and for_training and os.environ.get("TP_NO_PACK_MERGE") != "1":
                     # a training step: forward chunks, biases AND the transposed image of this step's data gradient in one launch
                     if self._packed_t is None or self._packed_t.device != dev:
                         self._packed_t = torch.empty(ops.packed_t_bytes() // 4, device=dev)
