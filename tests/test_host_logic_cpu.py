@@ -251,3 +251,37 @@ def test_bench_byte_model_and_host_topology():
     assert bench.hbm_bytes("patch_gather", 0, pixels=1024) == 1024 * 264
     sockets, phys, avail, model = bench.host_topology()
     assert sockets >= 1 and 1 <= phys <= avail and isinstance(model, str)
+
+
+def test_disc_step_schedule_structure_and_eligibility():
+    """texpose_amd/disc_step.py (K16) covers the [conv4s2, InstanceNorm, LeakyReLU]* + full-map ladders (patch 16 / 32) and says
+    why not for the others; it is never eligible for CPU tensors (the caller keeps its autograd form there), and the prefetch
+    queue of the discriminator refuses to be left half-used."""
+    import pytest
+    import torch
+    from texpose_amd.disc_step import DiscStepSchedule
+    from texpose_amd.gan_modules import Discriminator
+    from texpose_amd.options import default_options
+    for patch, stages in ((16, 2), (32, 3)):
+        opt = default_options(H=128, W=128, device="cpu")
+        opt.patch_size = patch
+        d = Discriminator(opt).train()
+        s = DiscStepSchedule(d)
+        assert s.reason is None and len(s.stages) == stages and len(s.convs()) == stages + 4
+        assert [c.weight_orig.shape for c in s.convs()] == [c.weight_orig.shape for c in d.sn_convs()]
+        x = torch.zeros(4, 9 if opt.gan.geo_conditional else 3, patch, patch)
+        assert not s.eligible(opt, x)                                   # CPU tensor
+    for patch in (64, 128):                                               # first stage without a norm
+        opt = default_options(H=128, W=128, device="cpu")
+        opt.patch_size = patch
+        s = DiscStepSchedule(Discriminator(opt))
+        assert s.reason is not None and "ladder" in s.reason
+    opt = default_options(H=128, W=128, device="cpu")
+    d = Discriminator(opt)
+    d.eval()
+    with pytest.raises(RuntimeError):
+        d.prefetch_spectral_weights(1)                                    # training mode only
+    d.train()
+    d._sn_queue.append(("stale",))
+    with pytest.raises(RuntimeError):
+        d.prefetch_spectral_weights(1)                                    # an unconsumed queue is an error
