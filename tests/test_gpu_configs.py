@@ -106,6 +106,9 @@ def test_c3_literal_size_train_iteration_eager_and_graphed():
         for k in ("render", "uncert", "trans_reg", "feat", "gan_nerf", "gan_disc_real", "gan_disc_fake", "gan_reg_real"):
             assert k in vals, (graphed, sorted(vals))
         assert graphed or var.ray_idx.shape == (4, 16, 16, 2)      # (a replayed step hands back its static inputs)
+        # the device step counter of the in-kernel random draws is visible to the Graph only while a captured step is issued
+        assert getattr(graph, "step_counter", None) is None and graph.patch_sampler.device_counter is None
+        assert not graphed or int(tr._rng_counter) >= 2
         ops.check_mlp_status(dev())
         for p, q in zip(graph.nerf.mlp_feat.parameters(), trunk0):
             assert torch.equal(p, q)

@@ -514,10 +514,18 @@ class GraphedGanTrainer(GanTrainer):
             self.graph.feat_stream = torch.cuda.Stream(device=dev)
         self._prefetch_spectral_weights(var)                         # (first: it runs beside everything up to the render)
         B, R = opt.batch_size, opt.patch_size ** 2
-        var = self.graph.get_ray_idx(opt, var)
-        if opt.nerf.sample_stratified and "jitter_rand" not in var and getattr(self.graph, "step_counter", None) is None:
-            var.jitter_rand = torch.rand(B, R, opt.nerf.sample_intvs, 1, device=var.ray_idx.device)   # (TP_TORCH_RNG=1)
-        var, loss = self.nerf_forward_loss(var)
+        # the step counter of the in-kernel random draws belongs to THIS step function (its loss-total launch advances it): the
+        # graph object and its patch sampler see it only while the step is being issued, so that an eager trainer driving the same
+        # Graph afterwards draws from torch's generator as before instead of repeating one jitter pattern
+        counter = getattr(self, "_rng_counter", None)
+        self.graph.step_counter = self.graph.patch_sampler.device_counter = counter
+        try:
+            var = self.graph.get_ray_idx(opt, var)
+            if opt.nerf.sample_stratified and "jitter_rand" not in var and counter is None:
+                var.jitter_rand = torch.rand(B, R, opt.nerf.sample_intvs, 1, device=var.ray_idx.device)   # (TP_TORCH_RNG=1)
+            var, loss = self.nerf_forward_loss(var)
+        finally:
+            self.graph.step_counter = self.graph.patch_sampler.device_counter = None
         # loss total + step gate in one launch: this forward's range flag and the finiteness of its loss go into the sticky words,
         # which are snapshot as the nerf gate BEFORE the backward and before the branches fork (so the gate also sees a
         # discriminator flag of earlier steps, never a concurrent write of this one)
@@ -630,8 +638,7 @@ class GraphedGanTrainer(GanTrainer):
             # step counter on the device, read inside tp_patch_coords / tp_raygen and advanced by the loss-total launch: no
             # torch.rand launches in the step and no generator-state fills before every replay
             if getattr(self, "_rng_counter", None) is None:
-                self._rng_counter = torch.zeros(1, dtype=torch.int64, device=dev)
-            self.graph.step_counter = self.graph.patch_sampler.device_counter = self._rng_counter
+                self._rng_counter = torch.zeros(1, dtype=torch.int64, device=dev)       # (attached to the graph only inside `_body_a`)
         self._static_in = AttrDict({k: v.clone() for k, v in var.items() if torch.is_tensor(v)})
         snap = self._snapshot()
         # warm up on the stream the capture will use: per-stream state (the tile counters of the convolution kernels,
