@@ -533,10 +533,12 @@ int tp_disc_head_bwd_bwd(const tp_disc_head_args* args, tp_stream_t stream);
 /* ------------------------------------------------------------------------------------------
  * K15  y = x W^T for a handful of rows: the PatchGAN's last ladder convolution covers its whole map (reference
  *      layers/discriminator.py:110-111), i.e. [B, 8192] x [8192, 64] with B = 4 .. 32.  Forward and weight gradient
- *      (gW = gy^T x); the data gradient gx = gy W is a library GEMM.  x [M,K], w [N,K], y [M,N].
+ *      (gW = gy^T x) and data gradient gx = gy W (kernel for M <= 16, a library GEMM beyond).  x [M,K], w [N,K], y [M,N].
  * ------------------------------------------------------------------------------------------ */
 int tp_skinny_linear_fwd(const float* x, const float* w, float* y, int M, int N, int K, tp_stream_t stream);
 int tp_skinny_linear_wgrad(const float* gy, const float* x, float* gw, int M, int N, int K, tp_stream_t stream);
+/* gx [M,K] = gy [M,N] w [N,K] for M <= 16 rows (larger M: a library GEMM on the host side) */
+int tp_skinny_linear_dgrad(const float* gy, const float* w, float* gx, int M, int N, int K, tp_stream_t stream);
 
 #ifdef __cplusplus
 }

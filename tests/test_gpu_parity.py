@@ -1812,9 +1812,10 @@ def test_disc_head_matches_torch_up_to_second_order(ops, B, C_z, H, L):
 
 # ------------------------------------------------------------------------------------------ K15
 @pytest.mark.parametrize("M,K,N", [(4, 8192, 64), (32, 8192, 64), (3, 1024, 5), (9, 2048, 17), (1, 8192, 64)])
-def test_skinny_linear_matches_torch_up_to_second_order(ops, M, K, N):
+def test_skinny_linear_matches_torch_up_to_second_order(ops, M, K, N, monkeypatch):
     """K15 (csrc/skinny_linear.hip: the PatchGAN's full-map convolution as x W^T for a handful of rows) against torch in fp64:
     the three kernels and their autograd composition incl. an R1-style second-order gradient."""
+    monkeypatch.setenv("TP_SKINNY_DGRAD_KERNEL", "1")          # (the data-gradient kernel is opt-in: rocBLAS is 0.7 % faster per iteration)
     from texpose_amd import autograd_ops
     torch.manual_seed(M + K + N)
     x0 = torch.randn(M, K, device=dev())

@@ -34,7 +34,7 @@ SYMBOLS = (
     "tp_fake_patch_bwd", "tp_feat_pair_loss_fwd", "tp_feat_pair_loss_bwd", "tp_sumsq_mean_fwd", "tp_sumsq_mean_bwd", "tp_sumsq_mean_fwd_bwd", "tp_gan_disc_losses", "tp_maxpool2_fwd", "tp_maxpool2_bwd", "tp_latent_rows_fwd",
     "tp_latent_rows_bwd", "tp_weighted_sum", "tp_weighted_sum_flags",
     "tp_disc_head_fwd", "tp_disc_head_bwd", "tp_disc_head_bwd_bwd",
-    "tp_skinny_linear_fwd", "tp_skinny_linear_wgrad",
+    "tp_skinny_linear_fwd", "tp_skinny_linear_wgrad", "tp_skinny_linear_dgrad",
 )
 
 vp = C.c_void_p
@@ -242,7 +242,7 @@ def load() -> C.CDLL:
     sig("tp_latent_rows_bwd", [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp])
     for name in ("tp_disc_head_fwd", "tp_disc_head_bwd", "tp_disc_head_bwd_bwd"):
         sig(name, [C.POINTER(DiscHeadArgs), vp])
-    for name in ("tp_skinny_linear_fwd", "tp_skinny_linear_wgrad"):
+    for name in ("tp_skinny_linear_fwd", "tp_skinny_linear_wgrad", "tp_skinny_linear_dgrad"):
         sig(name, [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp])
     _lib = lib
     return lib

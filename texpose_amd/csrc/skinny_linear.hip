@@ -5,8 +5,8 @@
 // A linear map is closed under differentiation like the convolutions of K11:
 //     F  y  [M,N] = x [M,K] W[N,K]^T        D  gx [M,K] = gy [M,N] W[N,K]        G  gW [N,K] = gy[M,N]^T x[M,K]
 // (backward of D wrt (gy, W) = (F, G); of G wrt (gy, x) = (F, D)).  F and G are kernels here (11.8 us / 5 us against 17 / 8 us);
-// D stays a rocBLAS product (7 us: a column-walking kernel of this simple kind measured 18-30 us).  Plain fp32 FMAs, fixed
-// summation order, no atomics.
+// D exists as a kernel too (round 3: up to 16 rows, 64 columns x 4 row runs per workgroup; a first, column-walking attempt in
+// round 2 measured 18-30 us) but rocBLAS' 5 us product stays the default: the kernel costs the iteration 0.7 % (opt-in).  Plain fp32 FMAs, fixed summation order, no atomics.
 #include "tp_common.h"
 
 namespace {
@@ -70,9 +70,47 @@ __global__ __launch_bounds__(kT) void skinny_wgrad_kernel(const float* __restric
     gw[(size_t)(n0 + j) * K + k] = acc;
   }
 }
+// D: gx[m][k] = sum_n gy[m][n] w[n][k].  A workgroup owns 64 columns k; its four waves split the N rows of w into four runs, so a
+// wave reads 64 consecutive floats of one row per load (coalesced), N / 4 loads per thread, all independent and in flight together;
+// gy [M,N] is read with scalar loads (the row run is wave-uniform).  The four partial sums of a column are added in wave order (fixed).  M <= kDgRows.
+constexpr int kDgRows = 16;
+__global__ __launch_bounds__(kT) void skinny_dgrad_kernel(const float* __restrict__ gy, const float* __restrict__ w, float* __restrict__ gx,
+                                                          int M, int N, int K) {
+  extern __shared__ float part[];              // partials [4][M][64]
+  const int t = threadIdx.x, kc = t & 63, k = blockIdx.x * 64 + kc;
+  const int wv = __builtin_amdgcn_readfirstlane(t >> 6);          // wave-uniform: gy is read with scalar loads
+  const int per = (N + 3) / 4, n0 = wv * per, n1 = min(N, n0 + per);
+  float acc[kDgRows];
+#pragma unroll
+  for (int m = 0; m < kDgRows; ++m) acc[m] = 0.f;
+  if (k < K) {
+    const float* wc = w + k;
+#pragma unroll 16
+    for (int n = n0; n < n1; ++n) {
+      const float wv_ = wc[(size_t)n * K];
+#pragma unroll
+      for (int m = 0; m < kDgRows; ++m)
+        if (m < M) acc[m] = fmaf(gy[m * N + n], wv_, acc[m]);
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < kDgRows; ++m)
+    if (m < M) part[(wv * M + m) * 64 + kc] = acc[m];
+  __syncthreads();
+  for (int e = t; e < M * 64; e += kT) {
+    const int m = e >> 6, c = e & 63, kk = blockIdx.x * 64 + c;
+    if (kk < K) gx[(size_t)m * K + kk] = ((part[(0 * M + m) * 64 + c] + part[(1 * M + m) * 64 + c]) + part[(2 * M + m) * 64 + c]) + part[(3 * M + m) * 64 + c];
+  }
+}
 }  // namespace
 
 extern "C" {
+int tp_skinny_linear_dgrad(const float* gy, const float* w, float* gx, int M, int N, int K, tp_stream_t stream) {
+  TP_REQUIRE(gy && w && gx && M > 0 && M <= kDgRows && N > 0 && K > 0, "bad arguments (at most 16 rows)");
+  const size_t lds = (4u * M * 64u) * sizeof(float);
+  hipLaunchKernelGGL(skinny_dgrad_kernel, dim3((K + 63) / 64), dim3(kT), lds, (hipStream_t)stream, gy, w, gx, M, N, K);
+  return tp::check_launch("tp_skinny_linear_dgrad");
+}
 int tp_skinny_linear_fwd(const float* x, const float* w, float* y, int M, int N, int K, tp_stream_t stream) {
   TP_REQUIRE(x && w && y && M > 0 && N > 0 && K > 0, "bad arguments");
   hipLaunchKernelGGL(skinny_fwd_kernel, dim3(N), dim3(kT), 0, (hipStream_t)stream, x, w, y, M, N, K);

@@ -1238,9 +1238,22 @@ def skinny_linear_fwd(x: Tensor, w: Tensor, out: Optional[Tensor] = None) -> Ten
     return y
 
 
+SKINNY_DGRAD_MAX_ROWS = 16
+
+
+@_on_tensor_device
 def skinny_linear_dgrad(gy: Tensor, w: Tensor, out: Optional[Tensor] = None) -> Tensor:
-    """gy [M,N] @ w [N,K] -> [M,K] (a library GEMM: rocBLAS does this shape in 7 us)."""
-    return torch.mm(gy, w, out=out) if out is not None else torch.mm(gy, w)
+    """gy [M,N] @ w [N,K] -> [M,K].  A library GEMM by default (rocBLAS does this shape in ~5 us); TP_SKINNY_DGRAD_KERNEL=1 selects
+    K15's own kernel for up to 16 rows (tp_skinny_linear_dgrad: the step then contains no library kernel, and runs 0.7 % slower --
+    664-669 vs 671-677 it/s, three alternating runs on one box)."""
+    if gy.shape[0] > SKINNY_DGRAD_MAX_ROWS or os.environ.get("TP_SKINNY_DGRAD_KERNEL") != "1":
+        return torch.mm(gy, w, out=out) if out is not None else torch.mm(gy, w)
+    lib = _lib.load()
+    gy, w = _f32(gy, "gy"), _f32(w, "w")
+    gx = _out_like(out, gy, (gy.shape[0], w.shape[1]))
+    check(lib.tp_skinny_linear_dgrad(gy.data_ptr(), w.data_ptr(), gx.data_ptr(), gy.shape[0], w.shape[0], w.shape[1], _stream()),
+          "tp_skinny_linear_dgrad")
+    return gx
 
 
 @_on_tensor_device
