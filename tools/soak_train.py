@@ -1,5 +1,6 @@
-"""GPU box: 600 hipGraph-replayed GAN iterations (f16x3 recording forward, split-fp16 backward): finite losses and
-parameters, range flag clear."""
+"""GPU box: N (default 600) hipGraph-replayed GAN iterations (f16x3 recording forward, split-fp16 backward, explicit discriminator
+schedule, prefetched spectral norms, in-kernel random draws): finite losses and parameters, range flag clear, no withheld step, the
+step counter of the random draws in step with the iteration count.     python tools/soak_train.py [iterations]"""
 import sys, os, json, torch
 sys.path.insert(0, os.getcwd())
 from texpose_amd.gan_modules import Discriminator, PerceptualLoss
@@ -15,13 +16,17 @@ graph = Graph(opt, discriminator=Discriminator(opt), perceptual_loss=PerceptualL
 tr = GraphedGanTrainer(opt, graph, n_train=189)
 var = training_batch(4, 128, 128, device="cuda:0")
 hist = []
-for it in range(600):
+N_IT = int(sys.argv[1]) if len(sys.argv) > 1 else 600
+for it in range(N_IT):
     _, loss = tr.train_iteration(AttrDict(dict(var)))
-    if it % 100 == 0 or it == 599:
+    if it % max(1, N_IT // 6) == 0 or it == N_IT - 1:
         hist.append({k: round(float(v), 5) for k, v in loss.items()})
         print(it, hist[-1], flush=True)
 ops.check_mlp_status("cuda:0")
 sd = graph.state_dict()
 assert all(torch.isfinite(v).all() for v in sd.values() if v.dtype.is_floating_point)
 assert all(all(abs(v) < 1e6 for v in h.values()) for h in hist)      # (random-noise target images: no loss trend to expect)
-print("soak ok; patch sampler iterations", graph.patch_sampler.iterations, "progress", float(graph.discriminator.progress))
+assert tr.skipped_steps == 0 and not graph.discriminator._sn_queue
+counter = int(tr._rng_counter) if getattr(tr, "_rng_counter", None) is not None else None
+assert counter is None or counter >= N_IT, counter            # (+ the warm-up iterations of the capture)
+print("soak ok; step counter", counter, "patch sampler iterations", graph.patch_sampler.iterations, "progress", float(graph.discriminator.progress))
