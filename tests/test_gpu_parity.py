@@ -1985,6 +1985,48 @@ def test_exact_fp32_asm_kernel_bit_identical_to_compiled(ops, monkeypatch, B, R,
     assert float(outs[1][0].abs().sum()) > 0
 
 
+def test_one_launch_head_pack_is_bit_identical_to_the_three_launch_form(ops, monkeypatch):
+    """tp_mlp_pack_heads_f16x3 (forward head chunks + biases + the backward's transposed image in one launch, what a recording
+    forward of a training step uses) against the three launches it replaces (tp_mlp_pack HEADS + the repack inside tp_mlp_bwd,
+    TP_NO_PACK_MERGE=1): the packed stream, the outputs and every gradient bit for bit -- over two consecutive steps with a
+    weight update in between (the scale word of the backward is cleared by its last kernel, not by a memset)."""
+    params = O.make_params(33)
+    rs = np.random.RandomState(4)
+    B, R, N = 2, 48, 16
+    pts = cu(torch.from_numpy(rs.uniform(-1.2, 1.2, size=(B, R, N, 3)).astype(np.float32)))
+    unit = cu(torch.nn.functional.normalize(torch.from_numpy(rs.normal(size=(B, R, 1, 3)).astype(np.float32)), dim=-1)
+              .expand(B, R, N, 3).contiguous())
+    cots = [cu(torch.from_numpy(rs.normal(size=sh).astype(np.float32))) for sh in ((B, R, N, 3, 2), (B, R, N, 2), (B, R, N, 1))]
+    results = []
+    for merged in (False, True):
+        if merged:
+            monkeypatch.delenv("TP_NO_PACK_MERGE", raising=False)
+        else:
+            monkeypatch.setenv("TP_NO_PACK_MERGE", "1")
+        g, opt = _graph(params, N=N)
+        g.nerf.train_precision = "f16x3"
+        lt = cu(torch.from_numpy(np.random.RandomState(8).normal(size=(B, 16)).astype(np.float32))).requires_grad_()
+        ll = cu(torch.from_numpy(np.random.RandomState(9).normal(size=(B, 48)).astype(np.float32))).requires_grad_()
+        steps = []
+        for step in range(2):
+            for p_ in g.nerf.parameters():
+                p_.grad = None
+            lt.grad = ll.grad = None
+            out = g.nerf.forward(opt, pts, ray_unit=unit, latent_variable_trans=lt, latent_variable_light=ll, mode="train")
+            sum((o * c).sum() for o, c in zip(out, cots)).backward()
+            assert (g.nerf.packed_t_current() is not None) == merged
+            steps.append([o.detach().clone() for o in out] + [p_.grad.clone() for _, p_ in g.nerf.head_parameters()]
+                         + [lt.grad.clone(), ll.grad.clone(), g.nerf.packed_weights("f16x3").clone()])
+            with torch.no_grad():                                        # a plain SGD step bumps the parameter versions
+                for _, p_ in g.nerf.head_parameters():
+                    p_.sub_(1e-3 * p_.grad)
+        results.append(steps)
+    for sa, sb in zip(*results):
+        for x, y in zip(sa, sb):
+            assert torch.equal(x, y)
+    ops.check_mlp_status(dev())
+
+
 def test_device_counter_random_streams(ops):
     """The random draws of a captured training step: tp_patch_coords with u = NULL equals the same kernel fed the Philox words
     (key = seed, counter (b, c_lo, 'patc', c_hi)) computed by the oracle's Philox; tp_raygen with offset_dev equals offset passed on
