@@ -1985,6 +1985,43 @@ def test_exact_fp32_asm_kernel_bit_identical_to_compiled(ops, monkeypatch, B, R,
     assert float(outs[1][0].abs().sum()) > 0
 
 
+def test_prefetched_spectral_weights_equal_in_place_normalisation(ops):
+    """Discriminator.prefetch_spectral_weights(n): the power iterations / normalisations of the next n training-mode passes run ahead
+    of time (on another stream, as the captured step does), each pass then takes its set from the queue -- outputs and the u / v
+    buffers afterwards equal those of n passes that normalise in place, bit for bit; a pass that differentiates through the
+    normalisation refuses to take a prefetched set."""
+    import copy
+    from texpose_amd.gan_modules import Discriminator
+    from texpose_amd.options import default_options
+    torch.manual_seed(3)
+    opt = default_options(H=128, W=128, device="cuda:0")
+    d_a = Discriminator(opt).to(dev()).train()
+    d_b = copy.deepcopy(d_a)
+    for d in (d_a, d_b):
+        for p_ in d.parameters():
+            p_.requires_grad_(False)                                    # (the frozen discriminator of the nerf step)
+    xs = [torch.rand(4, 9 if opt.gan.geo_conditional else 3, 16, 16, device=dev()) for _ in range(3)]
+    sc = torch.rand(4, device=dev()) * 0.5 + 0.25
+    outs_a = [d_a(opt, x, sc).clone() for x in xs]
+    side = torch.cuda.Stream(device=dev())
+    side.wait_stream(torch.cuda.current_stream(dev()))
+    with torch.cuda.stream(side):
+        d_b.prefetch_spectral_weights(3)
+    outs_b = [d_b(opt, x, sc).clone() for x in xs]                      # (each pass waits for the producing stream)
+    torch.cuda.synchronize()
+    assert not d_b._sn_queue
+    for a, b in zip(outs_a, outs_b):
+        assert torch.equal(a, b)
+    for (ka, va), (kb, vb) in zip(d_a.state_dict().items(), d_b.state_dict().items()):
+        assert ka == kb and torch.equal(va, vb), ka
+    d_b.prefetch_spectral_weights(1)
+    for p_ in d_b.parameters():
+        p_.requires_grad_(True)
+    with pytest.raises(RuntimeError):
+        d_b(opt, xs[0], sc)
+    d_b._sn_queue.clear()
+
+
 def test_one_launch_head_pack_is_bit_identical_to_the_three_launch_form(ops, monkeypatch):
     """tp_mlp_pack_heads_f16x3 (forward head chunks + biases + the backward's transposed image in one launch, what a recording
     forward of a training step uses) against the three launches it replaces (tp_mlp_pack HEADS + the repack inside tp_mlp_bwd,
