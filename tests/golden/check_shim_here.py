@@ -37,6 +37,7 @@ def main():
         gather_patches = AmdGraph.gather_patches
         sample_geometry = AmdGraph.sample_geometry
         compute_loss = AmdGraph.compute_loss
+        _warn_once = AmdGraph._warn_once                 # (compute_loss says once when it leaves its fused launches)
         evaluate_metrics = AmdGraph.evaluate_metrics
 
     torch.manual_seed(0)
@@ -122,7 +123,8 @@ def run_training_steps(opt, M, ShimGraph):
         p = {k: v for k, v in self.named_parameters() if k.startswith("mlp_")}
         return O.forward_samples(p, center, ray, depth_samples, latent_variable_trans, latent_variable_light)
 
-    def composite(opt_, ray, rgb_samples, density_samples, depth_samples, uncert_samples=None, per_sample=True, want_prob=True):
+    def composite(opt_, ray, rgb_samples, density_samples, depth_samples, uncert_samples=None, per_sample=True, want_prob=True,
+                  fan_out=None):                      # (the oracle stand-in hands out no aliases: every consumer reads rgb / density)
         return O.composite(ray, rgb_samples, density_samples, depth_samples, uncert_samples, opt_.nerf.min_uncert)
 
     def patch_gather(coords, image, image_syn, nocs, normal, obj_mask, mask_syn):
