@@ -145,11 +145,107 @@ def cpu_baseline(sc, params, emb_t, emb_l, min_chunks=20, chunk=2048):
                           all_cores["chunks"]))
 
 
-def _train_traffic():
+def train_cpu_baseline(min_iters=10, B=4, patch=16, n=64, hw=128):
+    """BASELINE.md section 3, second half: "Train: B=4, 16x16 patches, N=64, fwd+bwd, >= 10 iterations" on the host cores --
+    the CPU oracle's render(mode='train') of config C3 with autograd through the two heads and the latent rows (the trunk
+    runs without a graph, as in the reference: layers/nerf_static_transient_light.py:87-100), the photometric / uncertainty /
+    transient terms and their backward (reference path: model/nerf_adapt_st_gan.py:108-127 with the feature and GAN terms
+    off -- VGG / PatchGAN are not part of the oracle's render).  Thread count chosen on a timed iteration like cpu_baseline."""
+    from oracle import texpose_oracle as O
+    from texpose_amd.synthetic import network_weights, training_batch
+    sockets, n_phys, avail, cpu_model = host_topology()
+    params = network_weights(0)
+    leaves = []
+    for k, v in params.items():
+        if k.startswith(("mlp_rgb.", "mlp_trans.")):
+            v.requires_grad_(True)
+            leaves.append(v)
+    rs = np.random.RandomState(1)
+    emb_t = torch.from_numpy(rs.normal(size=(189, 16)).astype(np.float32)).requires_grad_(True)
+    emb_l = torch.from_numpy(rs.normal(size=(189, 48)).astype(np.float32)).requires_grad_(True)
+    leaves += [emb_t, emb_l]
+    var = training_batch(B, hw, hw, seed=0, device="cpu")
+    dr = (var.z_near[:, :, None], var.z_far[:, :, None])
+    weights = dict(render=0, uncert=0, trans_reg=-2)                # options/nerf_lm_adapt_gan.yaml:65-79
+
+    def iteration(it):
+        g = torch.Generator().manual_seed(it)
+        u = torch.rand(3, B, generator=g)
+        coords = O.patch_coords(patch, u[0], u[1], u[2], lo=0.25)[0]
+        rand = torch.rand(B, patch * patch, n, 1, generator=g)
+        t0 = time.perf_counter()
+        out = O.render(params, emb_t, emb_l, var.pose, var.intr, coords, dr, var.idx, "train", hw, hw, n, rand=rand)
+        gath = O.patch_gather(coords, var.image, var.image_syn, var.nocs_pred, var.normal_pred, var.obj_mask, var.mask_syn)
+        total = O.summarize(O.nerf_losses(out["rgb"], out["uncert"], out["density"], gath), weights)
+        t1 = time.perf_counter()
+        grads = torch.autograd.grad(total, leaves)
+        t2 = time.perf_counter()
+        assert all(bool(torch.isfinite(x).all()) for x in grads)
+        return t1 - t0, t2 - t1
+
+    trial = {}
+    for nt in sorted({t for t in (8, 16, 32, 64, n_phys // 2, n_phys) if 1 <= t <= avail}):
+        torch.set_num_threads(nt)
+        iteration(0)
+        trial[nt] = sum(iteration(1))
+    best = min(trial, key=trial.get)
+    torch.set_num_threads(best)
+    iteration(0)
+    ts = [iteration(i) for i in range(2, 2 + min_iters)]
+    fwd, bwd = sum(a for a, _ in ts) / len(ts), sum(b for _, b in ts) / len(ts)
+    return dict(value=1.0 / (fwd + bwd), unit="iterations/s", cores=best, kind="port", fwd_s=fwd, bwd_s=bwd, iterations=min_iters,
+                cpu_model=cpu_model, sockets=sockets, physical_cores=n_phys, hardware_threads=avail,
+                thread_trial={str(k): 1.0 / v for k, v in sorted(trial.items())},
+                sample="%d iterations (after 1 warm one) of the oracle's render(mode='train') fwd + autograd bwd at B=%d, %dx%d patches of "
+                       "%dx%d crops, N=%d (%d samples), photometric / uncert / trans_reg terms; the feature and GAN terms (VGG, "
+                       "PatchGAN) are NOT in this baseline, so it is a render-only lower bound of a reference iteration; torch %s CPU fp32, "
+                       "%d threads = the fastest of %s" % (min_iters, B, patch, patch, hw, hw, n, B * patch * patch * n,
+                                                           torch.__version__, best, sorted(trial)))
+
+
+CSRC = os.path.join("texpose_amd", "csrc")
+# which sources decide the traffic of which profiles/traffic.json entry (the PMC figures are committed measurements: bench.py
+# cannot run rocprofv3 on itself, so every entry carries the sha of the sources it was measured on and a mismatch is reported
+# as "traffic_stale": true instead of silently quoting a figure of another kernel)
+_MLP_COMMON = ["mlp_mma.h", "mlp_layout.h", "tp_common.h", "mlp_pack.hip"]
+TRAFFIC_SOURCES = {
+    "f16x3": ["mlp_fwd_f16x3.hip", "gen_wide_asm.py"] + _MLP_COMMON,
+    "fp32": ["mlp_fwd.hip", "gen_fp32_asm.py"] + _MLP_COMMON,
+    "train_b32": ["mlp_fwd_f16x3.hip", "gen_wide_asm.py", "mlp_bwd.hip"] + _MLP_COMMON,
+    "hbm_kernels.composite_fwd": ["composite.hip", "tp_common.h"],
+    "hbm_kernels.composite_bwd": ["composite.hip", "tp_common.h"],
+    "hbm_kernels.raygen": ["raygen.hip", "tp_common.h"],
+    "hbm_kernels.patch_gather": ["patch_gather.hip", "tp_common.h"],
+    "hbm_kernels.patch_gather_b32_p64": ["patch_gather.hip", "tp_common.h"],
+}
+
+
+def sources_sha16(entry):
+    """sha256 (first 16 hex digits) over the sources named for a traffic.json entry, in the listed order."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in TRAFFIC_SOURCES[entry]:
+        with open(os.path.join(REPO, CSRC, name), "rb") as f:
+            h.update(name.encode() + b"\0" + f.read() + b"\0")
+    return h.hexdigest()[:16]
+
+
+def traffic_entry(entry):
+    """(entry dict of profiles/traffic.json, stale flag): stale = the sources the figure was measured on are not today's
+    (None when the entry carries no sha yet)."""
     try:
-        return float(json.load(open(os.path.join(REPO, "profiles", "traffic.json")))["train_b32"]["total_per_step"])
+        node = json.load(open(os.path.join(REPO, "profiles", "traffic.json")))
+        for part in entry.split("."):
+            node = node[part]
     except Exception:
-        return None
+        return None, None
+    sha = node.get("sources_sha16")
+    return node, (None if sha is None else sha != sources_sha16(entry))
+
+
+def _train_traffic():
+    node, stale = traffic_entry("train_b32")
+    return (None, None) if node is None else (float(node["total_per_step"]), stale)
 
 
 HBM_PEAK_GBS = 8000.0                    # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable by a float4 copy)
@@ -203,10 +299,6 @@ def hbm_rooflines(device, in_situ):
     in one hipGraph replay between two events (no host gaps).  `traffic`: fabric bytes per launch from the committed PMC passes
     (profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate runs of tools/hbm_kernels.py)."""
     from texpose_amd import ops, synthetic
-    try:
-        pmc = json.load(open(os.path.join(REPO, "profiles", "traffic.json"))).get("hbm_kernels", {})
-    except Exception:
-        pmc = {}
     R, N = H * W, N_SAMPLES
     g = torch.Generator(device=device).manual_seed(0)
     rnd = lambda *s: torch.rand(*s, device=device, generator=g)
@@ -225,8 +317,9 @@ def hbm_rooflines(device, in_situ):
         """`ms`: the kernel bracketed inside the timed render loop where it is part of it (composite fwd, ray-gen: what the
         product path sees, right behind / in front of the MLP kernel), else the graph-replayed figure; both are reported."""
         used = in_situ_ms if in_situ_ms else ms
+        node, stale = traffic_entry("hbm_kernels." + name)
         e = {"kernel": kernel, "ms": used, "bytes": nbytes, "achieved": nbytes / (used * 1e-3) / 1e9, "workload": workload,
-             "traffic": (pmc.get(name) or {}).get("total"), "standalone_ms": ms, "in_situ_ms": in_situ_ms,
+             "traffic": (node or {}).get("total"), "traffic_stale": stale, "standalone_ms": ms, "in_situ_ms": in_situ_ms,
              "timed": "in the timed render loop (HIP events around the launch)" if in_situ_ms else
                       "hipGraph replay of 10-20 launches between two HIP events"}
         e["frac"] = e["achieved"] / HBM_PEAK_GBS
@@ -302,6 +395,40 @@ def train_kernel_times(device, B=32, reps=10):
     return pair_ms * f_ev / (f_ev + b_ev), pair_ms * b_ev / (f_ev + b_ev)
 
 
+def run_leg(failed, name, fn):
+    """An untimed leg: its result, or {"error": ...} with ``name`` appended to ``failed`` (-> "legs_failed" in the line and a
+    non-zero exit code after the line is printed) and the traceback on stderr."""
+    try:
+        return fn()
+    except Exception as exc:
+        import traceback
+        traceback.print_exc(file=sys.stderr)
+        failed.append(name)
+        return {"error": repr(exc)[:400]}
+
+
+def captured_or_eager(measure, device, world, graphed=True, sync=None):
+    """``measure(graphed)`` with the captured step, falling back to the eager loop when the capture raised (e.g. a collective
+    that cannot be captured on this stack).  The fallback is a JOB-wide decision: a rank retrying alone would sit in
+    collectives its peers never issue (they are still in the captured loop), so the ranks agree on "somebody failed" first
+    (one MAX all-reduce) and then ALL take the eager retry.  Returns (result, note or None)."""
+    full, err = None, None
+    try:
+        full = measure(graphed)
+    except Exception as exc:
+        if not graphed:
+            raise
+        err = exc
+    failed = torch.tensor([0 if err is None else 1], device=device, dtype=torch.int32)
+    if world > 1:
+        torch.distributed.all_reduce(failed, op=torch.distributed.ReduceOp.MAX)
+    if not int(failed):
+        return full, None
+    if sync is not None:
+        sync()
+    return measure(False), (repr(err)[:300] if err is not None else "another rank failed to capture the step")
+
+
 def train_leg(device, rank, world):
     """BASELINE's metric has a second half, "train iters/sec" (config C3: full GAN loop, batch 4, 128x128 crops, 16x16
     patches, 64 samples per ray; C4 = the same per-GPU batch sharded over the GPUs with one RCCL all-reduce per
@@ -318,29 +445,26 @@ def train_leg(device, rank, world):
     # losses, all backward passes), two eager stream-ordered collectives, replay B (optimiser steps) -- collectives inside a
     # replayed hipGraph have only ever run in a 1-rank group here (TP_COLLECTIVES_IN_GRAPH=1 opts in).
     graphed = os.environ.get("TP_BENCH_TRAIN_EAGER", "0") != "1"
-    full, err = None, None
-    try:
-        full = train_dp.measure(device, rank, world, global_batch=4 * world, iters=40, warm=4, graphed=graphed, full=True)
-    except Exception as exc:                       # (e.g. a collective that cannot be captured on this stack)
-        if not graphed:
-            raise
-        err = exc
-    # the fallback to the eager loop is a JOB-wide decision: a rank retrying alone would sit in collectives its peers never
-    # issue (they are still in the captured loop), so the ranks agree on "somebody failed" first
-    failed = torch.tensor([0 if err is None else 1], device=device, dtype=torch.int32)
-    if world > 1:
-        torch.distributed.all_reduce(failed, op=torch.distributed.ReduceOp.MAX)
-    if int(failed):
-        out["graph_capture_error"] = repr(err)[:300] if err is not None else "another rank failed to capture the step"
-        torch.cuda.synchronize()
-        full = train_dp.measure(device, rank, world, global_batch=4 * world, iters=40, warm=4, graphed=False, full=True)
+    full, note = captured_or_eager(lambda g: train_dp.measure(device, rank, world, global_batch=4 * world, iters=40, warm=4,
+                                                              graphed=g, full=True), device, world, graphed,
+                                   sync=torch.cuda.synchronize)
+    if note is not None:
+        out["graph_capture_error"] = note
     out["full_gan_loop"] = {k: full[k] for k in ("value", "ms_per_iter", "global_batch", "per_gpu_batch", "launch",
                                                  "recording_forward", "collective", "loop", "finite", "skipped_steps")}
     out["unit"] = "iterations/s"
+    # HIP events around the step's two gradient all-reduces (FlatGradAllReducer.reduce x 2 between the two graph replays): the
+    # xGMI figure of C4; None on one GPU (the single-graph form has no collective)
+    out["collective_ms"] = full.get("collective_ms")
     if world == 1:
         for B in (4, 32):
             r = train_dp.measure(device, 0, 1, global_batch=B, iters=40, warm=4, graphed=True, full=False)
             out["nerf_step_b%d" % B] = {k: r[k] for k in ("value", "ms_per_iter", "global_batch", "launch", "recording_forward")}
+        # the same two loops with the REFERENCE-PRECISION recording forward (exact fp32 MFMA products, fp32 backward kernels:
+        # arch.mlp_train_precision = 'fp32'), like `exact_fp32_kernel` beside the rays/s value
+        for name, kw in (("nerf_step_b4_fp32", dict(global_batch=4, full=False)), ("full_gan_loop_fp32", dict(global_batch=4, full=True))):
+            r = train_dp.measure(device, 0, 1, iters=30, warm=4, graphed=True, train_precision="fp32", **kw)
+            out[name] = {k: r[k] for k in ("value", "ms_per_iter", "global_batch", "launch", "recording_forward", "finite", "skipped_steps")}
         # kernel-level: the two C-ABI calls of the B=32 nerf step (recording forward; dgrad + wgrad + finalize) replayed 10x
         # from a hipGraph between two HIP events, i.e. timed as the captured step runs them (round 2 bracketed single calls
         # of an eager step: their sum left the replayed step 7 us for its other kernels)
@@ -358,7 +482,8 @@ def train_leg(device, rank, world):
                            "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TFLOPS["f16x3"],
                            "issued_frac": 3 * achieved / MFMA_PEAK_TFLOPS["f16x3"], "step_ms_replayed": step_ms,
                            "pair_replay": {"fwd_ms": f_ms, "bwd_ms": b_ms},
-                           "samples_per_launch": samples, "flop_per_sample": TRAIN_FLOP_PER_SAMPLE, "traffic": _train_traffic(),
+                           "samples_per_launch": samples, "flop_per_sample": TRAIN_FLOP_PER_SAMPLE, "traffic": _train_traffic()[0],
+                           "traffic_stale": _train_traffic()[1],
                            "traffic_unit": "bytes per B=32 step over the three MLP kernels, L2<->fabric (profiles/traffic.json: "
                                            "train_b32; the weight gradient reads 7.7 GB: it is the HBM-bound one of the three)",
                            "note": "B=32 nerf step; ALGORITHMIC FLOP (recording forward + head backward) / time of the WHOLE hipGraph-"
@@ -366,6 +491,51 @@ def train_leg(device, rank, world):
                                    "MFMAs; pair_replay = tp_mlp_fwd + tp_mlp_bwd alone, 10 pairs replayed from a hipGraph, split by "
                                    "eager HIP-event brackets"}
     return out
+
+
+def eval_masked_leg(device, graph, opt, sc, images=3, mask_frac=0.10):
+    """The path `evaluate.py` takes (reference model/nerf_adapt_st_gan.py:337-364, 652-680): render_by_slices(mode='eval_noalign')
+    on the OBJECT-MASK pixels only (a centred disk covering ~10 % of the 480x640 image), scatter into the default-filled maps,
+    then PSNR / SSIM of the static render against the masked image (Graph.evaluate_metrics = tp_eval_metrics).  Per image: one
+    nonzero() host sync for the pixel list, one blocking read of the range flag, one blocking read of the two metric values
+    (the reference reads them with .item() as well).  rays/s counts OBJECT rays."""
+    from texpose_amd.options import AttrDict
+    yy, xx = np.mgrid[0:H, 0:W]
+    r2 = mask_frac * H * W / np.pi
+    mask = torch.from_numpy((((yy - H / 2 + 0.5) ** 2 + (xx - W / 2 + 0.5) ** 2) < r2).astype(np.float32))[None].to(device)
+    n_obj = int(mask.sum())
+    pose, intr = sc["pose"].to(device), sc["intr"].to(device)
+    dr = (sc["z_near"].to(device)[:, :, None], sc["z_far"].to(device)[:, :, None])
+    image = torch.rand(1, 3, H, W, device=device)
+    light_idx = torch.tensor(3, device=device)
+
+    def one():
+        with torch.no_grad():
+            ret = graph.render_by_slices(opt, pose, intr=intr, depth_range=dr, object_mask=mask, sample_idx=light_idx, mode="eval_noalign")
+            var = AttrDict(dict(ret))
+            var.image, var.obj_mask = image, mask
+            m = graph.evaluate_metrics(opt, var)
+            return float(m.psnr), float(m.ssim)
+
+    res = {}
+    for per_sample in (True, False):                        # reference contract (per-sample maps filled) / per-ray maps only
+        opt.render.per_sample = per_sample
+        one()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(images):
+            psnr, ssim = one()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / images
+        res["per_sample_maps" if per_sample else "per_ray_maps_only"] = dict(value=n_obj / dt, unit="object rays/s", ms_per_image=dt * 1e3,
+                                                                             psnr=psnr, ssim=ssim)
+    opt.render.per_sample = True
+    res.update(object_rays=n_obj, mask="centred disk, %.1f %% of 480x640" % (100.0 * n_obj / (H * W)), images=images,
+               workload="render_by_slices(mode='eval_noalign') on object pixels + scatter into default-filled maps + evaluate_metrics "
+                        "(PSNR / SSIM at 480x640), %d samples per ray" % N_SAMPLES,
+               note="per_sample_maps fills density [1,HW,N,2] and the two alpha maps [1,HW,N] with their defaults for every image as the "
+                    "reference does (:657-667: 630 MB of fills at this size); per_ray_maps_only is opt.render.per_sample=False")
+    return res
 
 
 def spawn_ranks(n_gpus, argv):
@@ -411,6 +581,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
         raise SystemExit("--gpus %d but the launcher started %d rank(s)" % (args.gpus, world))
+    if args.spawn_check and args.config == "c5":
+        # the C5 entry point's sharding and aggregation with a stub renderer, on CPU under gloo (no GPU touched)
+        import torch.distributed as dist
+        sys.path.insert(0, os.path.join(REPO, "tools"))
+        import eval_multi_object
+        line = eval_multi_object.spawn_check(rank, world)
+        if world > 1:
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"spawn_check": world, "config": "c5", "n_gpus": line["n_gpus"],
+                              "per_object_ms": [round(o["ms"], 1) for o in line["per_object"]],
+                              "samples_all_ranks": line["roofline"]["samples_all_ranks"],
+                              "parallelism": line["config"]["parallelism"]}))
+        return
     if args.spawn_check:
         import torch.distributed as dist
         if world > 1:
@@ -489,19 +673,18 @@ def main():
     samples_per_launch = H * W * N_SAMPLES / launches_per_step
 
     def measured_traffic(precision, samples):
-        """Fabric bytes per launch from the committed PMC profile (bench.py cannot run rocprofv3 on itself)."""
-        try:
-            t = json.load(open(os.path.join(REPO, "profiles", "traffic.json")))[precision]
-            return t["total"] * samples / (H * W * N_SAMPLES)
-        except Exception:
-            return None
+        """(fabric bytes per launch from the committed PMC profile, stale flag): bench.py cannot run rocprofv3 on itself; the
+        entry names the sha of the kernel sources it was measured on (traffic_entry)."""
+        node, stale = traffic_entry(precision)
+        return (None, None) if node is None else (node["total"] * samples / (H * W * N_SAMPLES), stale)
 
     def roofline(precision, ms, samples):
         achieved = MLP_FLOP_PER_SAMPLE * samples / (ms * 1e-3) / 1e12
         peak = MFMA_PEAK_TFLOPS[precision]
         k = ISSUED_PER_ALGORITHMIC[precision]
         return {"kernel": "mlp_fwd_exact_asm_kernel" if precision == "fp32" else "mlp_fwd_f16x3_kernel", "bound": "mfma",
-                "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": measured_traffic(precision, samples),
+                "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": measured_traffic(precision, samples)[0],
+                "traffic_stale": measured_traffic(precision, samples)[1],
                 "traffic_unit": "bytes/launch, L2<->fabric (FETCH_SIZE x2 + WRITE_SIZE, profiles/traffic.json)",
                 "kernel_ms": ms, "samples_per_launch": samples, "flop_per_sample": MLP_FLOP_PER_SAMPLE,
                 "mfma_issued_per_algorithmic": k, "issued_frac": k * achieved / peak,
@@ -544,33 +727,47 @@ def main():
     ops.check_mlp_status(device)
     del ret
     torch.cuda.empty_cache()
+    # The untimed legs: the rays/s line must come out whatever happens to them, but a leg that raised is NAMED in the line
+    # ("legs_failed") and makes the process exit non-zero AFTER the line is printed -- a failed leg is never just an "error"
+    # string inside an rc-0 run.
+    legs_failed = []
+    leg = lambda name, fn: run_leg(legs_failed, name, fn)
+
     hbm = None
     if rank == 0:
-        try:
-            in_situ = dict(raygen_ms=float(np.mean([a.elapsed_time(b) for a, b in raygen_events])),
-                           composite_fwd_ms=float(np.mean([a.elapsed_time(b) for a, b in comp_events])))
-            hbm = hbm_rooflines(device, in_situ)
-        except Exception as exc:
-            hbm = {"error": repr(exc)[:400]}
+        hbm = leg("roofline_hbm", lambda: hbm_rooflines(device, dict(
+            raygen_ms=float(np.mean([a.elapsed_time(b) for a, b in raygen_events])),
+            composite_fwd_ms=float(np.mean([a.elapsed_time(b) for a, b in comp_events])))))
+        torch.cuda.empty_cache()
+    eval_masked = None
+    if rank == 0 and world == 1:
+        eval_masked = leg("eval_masked", lambda: eval_masked_leg(device, graph, opt, sc))
         torch.cuda.empty_cache()
     train = None
     if not args.no_train:
-        try:
-            train = train_leg(device, rank, world)
-        except Exception as exc:                   # the rays/s line must come out whatever happens to the untimed legs
-            train = {"error": repr(exc)[:400]}
+        train = leg("train", lambda: train_leg(device, rank, world))
+        if world == 1 and not args.no_cpu_baseline and "error" not in train:
+            train["cpu_baseline"] = leg("train.cpu_baseline", train_cpu_baseline)
+            if "error" not in train["cpu_baseline"]:
+                train["gpu_over_cpu"] = {"full_gan_loop_vs_cpu_render_only": train["full_gan_loop"]["value"] / train["cpu_baseline"]["value"],
+                                         "nerf_step_b4_vs_cpu": train["nerf_step_b4"]["value"] / train["cpu_baseline"]["value"]}
 
     trained = None
     if rank == 0 and world == 1 and not args.no_train and args.precision == "f16x3":
         # untimed leg: the f16x3 kernel on a TRAINED network (500 product-trainer iterations) and with the trunk feature
         # scaled x4 / x16: rays/s, range-flag count, largest hidden activation, f16x3-vs-fp32 error (tools/trained_weights.py)
-        try:
+        def _trained():
             sys.path.insert(0, os.path.join(REPO, "tools"))
             import trained_weights
-            trained = trained_weights.run(device, iters=500)
-        except Exception as exc:
-            trained = {"error": repr(exc)[:400]}
+            return trained_weights.run(device, iters=500)
+        trained = leg("trained_weights", _trained)
         torch.cuda.empty_cache()
+    # a leg that failed on ANOTHER rank must show in rank 0's line and exit code too
+    if world > 1:
+        nf = torch.tensor([len(legs_failed)], device=device, dtype=torch.int32)
+        torch.distributed.all_reduce(nf, op=torch.distributed.ReduceOp.MAX)
+        if int(nf) and not legs_failed:
+            legs_failed.append("a leg on another rank")
 
     if rank == 0:
         line = {
@@ -599,16 +796,23 @@ def main():
             line["exact_fp32_kernel"] = exact
         if per_ray is not None:
             line["per_ray_outputs_only"] = per_ray
+        if eval_masked is not None:
+            line["eval_masked"] = eval_masked
         if train is not None:
             line["train"] = train
         if trained is not None:
             line["trained_weights"] = trained
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(sc, params, emb_t, emb_l)
-            line["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]
+            line["cpu_baseline"] = leg("cpu_baseline", lambda: cpu_baseline(sc, params, emb_t, emb_l))
+            if "error" not in line["cpu_baseline"]:
+                line["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]
+        line["legs_failed"] = list(legs_failed)
         print(json.dumps(line))
+        sys.stdout.flush()
     if world > 1:
         torch.distributed.destroy_process_group()
+    if legs_failed:
+        raise SystemExit(3)                        # (after the line: the driver's rc shows that an untimed leg raised)
 
 
 if __name__ == "__main__":

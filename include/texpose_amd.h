@@ -323,6 +323,9 @@ typedef struct tp_nerf_losses_args {
   double* sums;            /* [4]: sum m*se/u^2, sum m, sum log u^2, sum sigma_t  (fwd: out, bwd: in) */
   float* losses;           /* fwd, optional [3]: render = s0 / (s1 + 1e-5), uncert = 5 + s2 / (B P) / 2, trans_reg = s3 / (B P N)
                               in fp32 from the fp32-rounded sums, the reference's operation order */
+  uint32_t* ticket;        /* fwd: ONE zero-filled device word owned by the calling stream (the arrival counter of the last-block
+                              reduction; the launch leaves it zero).  Launches that may overlap -- different streams of one device --
+                              need different words; launches on one stream may share one.  Unused by the backward. */
 } tp_nerf_losses_args;
 int tp_nerf_losses_fwd(const tp_nerf_losses_args* args, tp_stream_t stream);
 /* g_render / g_unc / g_trans: the upstream gradients of the three terms, one device scalar each (NULL = 0) */
@@ -450,8 +453,10 @@ int tp_feat_inputs_bwd(const tp_feat_inputs_args* args, const float* g_out, floa
 int tp_step_flags(const int32_t* mlp_status, const float* total, int32_t* bad, int n_bad, int word_status, int word_finite,
                   int32_t* snapshot, tp_stream_t stream);
 /* torch.optim.Adam step (reference optim_nerf, model/nerf_adapt_st_gan.py:62-68,125; no weight decay, no amsgrad) for up to
- * TP_ADAM_MAX_TENSORS tensors in one launch; `step` = 0-dim float tensor holding the steps taken so far (a second, one-wave
- * launch adds 1 to each afterwards); learning rate from device memory (lr_dev) or the host; gate as for tp_rmsprop_step. */
+ * TP_ADAM_MAX_TENSORS tensors in one launch; `step` = 0-dim float tensor holding the steps taken so far (the block that finishes last
+ * launch adds 1 to each afterwards); learning rate from device memory (lr_dev) or the host; gate as for tp_rmsprop_step.
+ * ticket: ONE zero-filled device word owned by the calling stream (arrival counter of the block that advances the step counters;
+ * the launch leaves it zero); launches that may overlap on different streams of a device need different words. */
 #define TP_ADAM_MAX_TENSORS 32
 typedef struct tp_adam_tensor {
   float* param;
@@ -462,7 +467,7 @@ typedef struct tp_adam_tensor {
   int64_t numel;
 } tp_adam_tensor;
 int tp_adam_step(const tp_adam_tensor* tensors /* host array */, int n, const float* lr_dev, double lr_host, double beta1, double beta2,
-                 double eps, const int32_t* gate, int n_gate, tp_stream_t stream);
+                 double eps, const int32_t* gate, int n_gate, uint32_t* ticket, tp_stream_t stream);
 int tp_disc_inputs(const float* rgb, const float* gathered, int B, int P, int geo, float* real, float* fake, tp_stream_t stream);
 /* Cotangent of the fake stack wrt the rendered colours (the nerf step back-propagates D(fake) into the render):
  * g_rgb [B,P,3] = g_fake [B,nc,P] channels 0..2, transposed. */

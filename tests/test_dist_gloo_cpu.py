@@ -309,3 +309,86 @@ def test_graphed_trainer_selects_two_graphs_and_eager_collectives_for_several_ra
     assert tr._has_collective() and tr._split_around_collectives()                   # several ranks: A | reduce | B
     monkeypatch.setenv("TP_COLLECTIVES_IN_GRAPH", "1")
     assert tr._has_collective() and not tr._split_around_collectives()               # opt-in only
+
+
+# ------------------------------------------------------------------------------------------ round 4: multi-GPU readiness without hardware
+def _load_by_path(name, rel):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(name, os.path.join(REPO, rel))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _c5_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    emo = _load_by_path("eval_multi_object", "tools/eval_multi_object.py")
+    tdist.init_distributed("gloo")
+    be = emo.StubBackend(n_samples=4)
+    line = emo.measure(torch.device("cpu"), rank, world, n_objects=5, images_per_object=3, n_samples=4, precision="f16x3",
+                       warm=1, steps=2, backend=be)
+    torch.save(dict(line=line, calls=be.calls, mine=emo.objects_of_rank(5, rank, world)), os.path.join(out_dir, f"c5_rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_c5_objects_shard_over_ranks_and_aggregate(tmp_path):
+    """tools/eval_multi_object.measure (BASELINE C5) under gloo, world size 2, with the stub renderer: objects shard
+    contiguously and disjointly (5 objects -> 3 + 2), every rank renders ONLY its objects' images, the per-object times
+    land in their own slots (SUM over disjoint entries), kernel totals add up over the ranks, the wall time is the MAX over the
+    ranks, and both ranks hold the identical line."""
+    world = 2
+    mp.spawn(_c5_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r = [torch.load(tmp_path / f"c5_rank{k}.pt") for k in range(world)]
+    assert r[0]["mine"] == [0, 1, 2] and r[1]["mine"] == [3, 4]
+    for k in range(world):                                     # timed region: steps x (every image of every own object), in order
+        assert r[k]["calls"] == [(o, i) for _ in range(2) for o in r[k]["mine"] for i in range(3)]
+    l0, l1 = r[0]["line"], r[1]["line"]
+    assert l0 == l1
+    ms = [o["ms"] for o in l0["per_object"]]
+    for o, v in enumerate(ms):                                 # stub: (o + 1) ms per render, 3 images per step
+        assert 3.0 * (o + 1) <= v < 3.0 * (o + 1) + 6.0, (o, v)
+    rays_obj = 240 * 320 * 2 + 480 * 640
+    assert l0["config"]["rays_per_object"] == rays_obj and l0["n_gpus"] == 2
+    assert l0["roofline"]["samples_all_ranks"] == 5 * rays_obj * 4              # all ranks' launches, per step
+    assert l0["roofline"]["kernel_ms_total_all_ranks"] == 5 * 3 * 0.5
+    # wall time per step = the slower rank's (rank 0: 3 x (1 + 2 + 3) ms, rank 1: 3 x (4 + 5) ms)
+    assert 27.0 <= l0["ms_per_step"] < 45.0
+    assert abs(l0["value"] - 5 * rays_obj / (l0["ms_per_step"] * 1e-3)) < 1e-6 * l0["value"]
+
+
+def _fallback_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    bench = _load_by_path("bench_mod", "bench.py")
+    tdist.init_distributed("gloo")
+    calls = []
+
+    def measure(graphed):
+        calls.append(graphed)
+        if graphed:
+            if rank == 1:
+                raise RuntimeError("capture failed on this rank only")
+            return dict(value=1.0, launch="graph")             # (rank 0's captured loop "worked": no collective left pending)
+        t = torch.tensor([float(rank + 1)])
+        dist.all_reduce(t)                                     # the eager loop's collectives: BOTH ranks must be in here
+        return dict(value=float(t), launch="eager")
+
+    res, note = bench.captured_or_eager(measure, torch.device("cpu"), world, graphed=True)
+    torch.save(dict(calls=calls, res=res, note=note), os.path.join(out_dir, f"fb_rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_failed_capture_on_one_rank_sends_every_rank_to_the_eager_loop(tmp_path):
+    """bench.train_leg's fallback (bench.captured_or_eager): the capture fails on rank 1 only; the "somebody failed" all-reduce
+    makes BOTH ranks drop the captured result and run the eager loop, whose collective they then meet in."""
+    world = 2
+    mp.spawn(_fallback_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r = [torch.load(tmp_path / f"fb_rank{k}.pt") for k in range(world)]
+    for k in range(world):
+        assert r[k]["calls"] == [True, False] and r[k]["res"] == dict(value=3.0, launch="eager")
+    assert "capture failed" in r[1]["note"] and "another rank" in r[0]["note"]

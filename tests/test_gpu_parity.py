@@ -2204,3 +2204,104 @@ def test_weighted_sum_and_sn_uv_copies(ops):
         assert torch.equal(a, b) and torch.equal(b, c)
     for a, b in zip(outs, outs2):
         assert torch.equal(a, b)
+
+
+# ------------------------------------------------------------------------------------------ round-4: advisor findings of round 3
+def test_last_block_tickets_are_per_stream(ops):
+    """tp_nerf_losses_fwd / tp_adam_step hand over to their last block through a ticket word in CALLER-OWNED memory keyed by
+    (device, stream): launches of one entry point that overlap on two streams must not count each other's arrivals.  Many
+    overlapping pairs on two streams give the single-stream results bit for bit, the step counters advance by exactly one per
+    launch, and every ticket word is left zero."""
+    from texpose_amd.trainer import FusedAdam
+    rs = np.random.RandomState(3)
+    B, p, N = 32, 32, 16                                        # 128 blocks per launch: long enough to overlap
+    mk = lambda *s: cu(torch.from_numpy(rs.uniform(0.1, 1.0, size=s).astype(np.float32)))
+    rgb, unc, den, gath = mk(B, p * p, 3), mk(B, p * p), mk(B, p * p, N, 2), mk(B, 14, p, p)
+    gath[:, 12] = (gath[:, 12] > 0.5).float()
+    ref_sums, ref_losses = ops.nerf_losses_fwd(rgb, unc, den, gath, want_losses=True)
+    shapes = [(256, 334), (256, 256), (256, 256), (189, 48)]
+    def make_opt(seed):
+        torch.manual_seed(seed)
+        ps = [torch.nn.Parameter(torch.randn(s, device=dev())) for s in shapes]
+        return ps, FusedAdam([dict(params=ps, lr=torch.tensor(1e-3, device=dev()))], capturable=True)
+    streams = [torch.cuda.Stream(device=dev()) for _ in range(2)]
+    # single-stream reference trajectories of two optimisers
+    refs = []
+    for k in range(2):
+        ps, o = make_opt(k)
+        torch.manual_seed(100 + k)
+        for it in range(20):
+            for q in ps:
+                q.grad = torch.randn_like(q)
+            o.step()
+        refs.append([q.detach().clone() for q in ps])
+    torch.cuda.synchronize()
+    pairs = [make_opt(k) for k in range(2)]
+    grads = []
+    for k in range(2):
+        torch.manual_seed(100 + k)
+        grads.append([[torch.randn_like(q) for q in pairs[k][0]] for it in range(20)])
+    results = [[], []]
+    torch.cuda.synchronize()
+    for it in range(20):
+        for k, s in enumerate(streams):
+            with torch.cuda.stream(s):
+                for q, g in zip(pairs[k][0], grads[k][it]):
+                    q.grad = g
+                pairs[k][1].step()
+                results[k].append(ops.nerf_losses_fwd(rgb, unc, den, gath, want_losses=True))
+    torch.cuda.synchronize()
+    for k in range(2):
+        for q, r in zip(pairs[k][0], refs[k]):
+            assert torch.equal(q.detach(), r)
+        for st in pairs[k][1].state.values():
+            assert float(st["step"]) == 20.0
+        for sums, losses in results[k]:
+            assert torch.equal(sums, ref_sums) and torch.equal(losses, ref_losses)
+    words = [t for key, t in ops._ticket_words.items() if key[0] == dev().index]
+    assert len({key[1] for key in ops._ticket_words if key[0] == dev().index}) >= 2 and all(int(t) == 0 for t in words)
+
+
+def test_latent_rows_accepts_int32_and_strided_indices(ops):
+    """The latent gather took index_select's place, which accepts int32 indices: forward AND backward must see the converted
+    (int64, contiguous) buffer -- the backward used to read the original one as int64 (garbage rows, silently zero gradients)."""
+    from texpose_amd import autograd_ops
+    rs = np.random.RandomState(2)
+    base = torch.tensor([3, 7, 3, 0, 10, 5, 1, 9])
+    for idx in (cu(base.to(torch.int32)), cu(base)[::2], cu(base.to(torch.int32))[1::2]):
+        wt = cu(torch.from_numpy(rs.normal(size=(11, 16)).astype(np.float32))).requires_grad_()
+        wl = cu(torch.from_numpy(rs.normal(size=(11, 48)).astype(np.float32))).requires_grad_()
+        lt, ll = autograd_ops.latent_rows(wt, wl, idx)
+        i64 = idx.long()
+        assert torch.equal(lt, wt.detach()[i64]) and torch.equal(ll, wl.detach()[i64])
+        ct, cl = torch.randn_like(lt), torch.randn_like(ll)
+        ((lt * ct).sum() + (ll * cl).sum()).backward()
+        torch.testing.assert_close(wt.grad, torch.zeros(11, 16, device=dev()).index_add_(0, i64, ct), rtol=1e-6, atol=1e-7)
+        torch.testing.assert_close(wl.grad, torch.zeros(11, 48, device=dev()).index_add_(0, i64, cl), rtol=1e-6, atol=1e-7)
+    with pytest.raises(Exception):
+        ops.latent_rows_bwd(ct, cl, cu(base.to(torch.int32))[:ct.shape[0]], 11)
+
+
+def test_composite_bwd_with_only_fan_out_cotangents(ops):
+    """A step whose only rgb consumers are the fan-out aliases (rgb_feat / rgb_disc with loss_weight.render = uncert = None)
+    delivers g_rgb_ray2 / g_rgb_ray3 (and possibly g_density_add) and nothing else: tp_composite_bwd must take it."""
+    rs = np.random.RandomState(6)
+    n, N = 50, 24
+    ray = cu(torch.from_numpy(rs.normal(size=(1, n, 3)).astype(np.float32)))
+    rgb = cu(torch.from_numpy(rs.uniform(size=(1, n, N, 3, 2)).astype(np.float32)))
+    den = cu(torch.from_numpy(rs.uniform(0, 3, size=(1, n, N, 2)).astype(np.float32)))
+    z = cu(torch.from_numpy(np.sort(rs.uniform(6, 9, size=(1, n, N, 1)), axis=2).astype(np.float32)))
+    unc = cu(torch.from_numpy(rs.uniform(0.1, 1, size=(1, n, N, 1)).astype(np.float32)))
+    g2 = cu(torch.from_numpy(rs.normal(size=(1, n, 3)).astype(np.float32)))
+    g3 = cu(torch.from_numpy(rs.normal(size=(1, n, 3)).astype(np.float32)))
+    gd = cu(torch.from_numpy(rs.normal(size=(1, n, N, 2)).astype(np.float32)))
+    g_all = torch.zeros(1, n, 14, device=dev())
+    g_all[..., 0:3] = g2 + g3
+    ref = ops.composite_bwd(ray, rgb, den, z, unc, g_all, g_density_add=gd)
+    for kw in (dict(g_rgb_ray2=g2, g_rgb_ray3=g3, g_density_add=gd), ):
+        got = ops.composite_bwd(ray, rgb, den, z, unc, None, **kw)
+        for a, b in zip(ref, got):
+            torch.testing.assert_close(a, b, rtol=1e-6, atol=1e-7)
+    # the density cotangent alone (no per-ray cotangent at all): the gradient IS g_density_add, rgb / uncert gradients are zero
+    got = ops.composite_bwd(ray, rgb, den, z, unc, None, g_density_add=gd)
+    assert float(got[0].abs().max()) == 0.0 and float(got[2].abs().max()) == 0.0 and torch.equal(got[1], gd)

@@ -229,11 +229,52 @@ def test_bench_spawns_its_own_ranks_for_gpus_n():
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert lines == [{"spawn_check": 2, "rank_sum": 3.0}]
+    # the C5 entry point through the same launcher: objects shard over the two ranks (stub renderer, gloo), rank 0's line relayed
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--config", "c5", "--spawn-check"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and lines[0]["spawn_check"] == 2 and lines[0]["config"] == "c5" and lines[0]["n_gpus"] == 2
+    assert lines[0]["parallelism"] == "4 object(s) per GPU on 2 GPU(s)" and len(lines[0]["per_object_ms"]) == 8
+    assert all(ms > 0 for ms in lines[0]["per_object_ms"])            # every object rendered by exactly one of the ranks
     # a rank that dies (no GPU here: the real bench raises in every child) must surface as a non-zero exit code of the parent
     r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "1", "--no-train",
                         "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=300)
     if not torch.cuda.is_available():
         assert r.returncode != 0
+
+
+def test_bench_legs_fail_loudly_and_traffic_figures_carry_their_source_sha(tmp_path, monkeypatch):
+    """bench.run_leg: a leg that raises yields {"error": ...} AND its name in the list the line reports as "legs_failed" (bench.py
+    exits non-zero after printing).  bench.traffic_entry: a committed PMC figure is reported stale as soon as one of the kernel
+    sources it was measured on changes; every entry of the committed profiles/traffic.json carries a sha."""
+    import importlib.util
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(repo, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    failed = []
+    assert bench.run_leg(failed, "ok", lambda: {"v": 1}) == {"v": 1} and failed == []
+    out = bench.run_leg(failed, "train", lambda: (_ for _ in ()).throw(RuntimeError("rccl said no")))
+    assert failed == ["train"] and "rccl said no" in out["error"]
+    for entry in bench.TRAFFIC_SOURCES:
+        node, stale = bench.traffic_entry(entry)
+        assert node is not None and stale is not None, entry           # (stale may be True while a kernel is being worked on)
+        assert len(node["sources_sha16"]) == 16
+    # a changed source flips the flag
+    src = tmp_path / "texpose_amd" / "csrc"
+    src.mkdir(parents=True)
+    (tmp_path / "profiles").mkdir()
+    for name in bench.TRAFFIC_SOURCES["hbm_kernels.raygen"]:
+        (src / name).write_text("// v1 " + name)
+    monkeypatch.setattr(bench, "REPO", str(tmp_path))
+    sha = bench.sources_sha16("hbm_kernels.raygen")
+    import json
+    (tmp_path / "profiles" / "traffic.json").write_text(json.dumps({"hbm_kernels": {"raygen": {"total": 1.0, "sources_sha16": sha}}}))
+    assert bench.traffic_entry("hbm_kernels.raygen")[1] is False
+    (src / "raygen.hip").write_text("// v2")
+    assert bench.traffic_entry("hbm_kernels.raygen")[1] is True
+    assert bench.traffic_entry("f16x3") == (None, None)
 
 
 def test_bench_byte_model_and_host_topology():

@@ -143,7 +143,7 @@ class Conv4s2Args(C.Structure):
 
 class NerfLossesArgs(C.Structure):
     _fields_ = [("rgb", vp), ("uncert", vp), ("density", vp), ("gathered", vp), ("B", C.c_int), ("P", C.c_int),
-                ("N", C.c_int), ("workspace", vp), ("sums", vp), ("losses", vp)]
+                ("N", C.c_int), ("workspace", vp), ("sums", vp), ("losses", vp), ("ticket", vp)]
 
 
 NERF_LOSSES_MAX_BLOCKS = 1024
@@ -214,7 +214,7 @@ def load() -> C.CDLL:
     sig("tp_inorm_lrelu_bwd_bwd", [vp, vp, vp, vp, C.c_int64, C.c_int, C.c_float, vp, vp, vp])
     sig("tp_rmsprop_step", [C.POINTER(RmspropTensor), C.c_int, vp, C.c_double, C.c_double, C.c_double, vp, C.c_int, vp])
     sig("tp_step_flags", [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp])
-    sig("tp_adam_step", [C.POINTER(AdamTensor), C.c_int, vp, C.c_double, C.c_double, C.c_double, C.c_double, vp, C.c_int, vp])
+    sig("tp_adam_step", [C.POINTER(AdamTensor), C.c_int, vp, C.c_double, C.c_double, C.c_double, C.c_double, vp, C.c_int, vp, vp])
     sig("tp_conv4s2_workspace", [C.POINTER(Conv4s2Args), C.c_int, C.POINTER(C.c_int64)], C.c_int64)
     for name in ("tp_conv4s2_fwd", "tp_conv4s2_dgrad", "tp_conv4s2_wgrad"):
         sig(name, [C.POINTER(Conv4s2Args), vp])

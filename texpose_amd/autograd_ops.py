@@ -482,6 +482,9 @@ class _LatentRows(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, w_trans, w_light, idx):
+        # the kernels read int64 rows: save what the forward actually passed down (an int32 or strided idx is accepted, like
+        # index_select's, and converted ONCE here -- the backward must see the same buffer)
+        idx = idx.to(torch.int64).contiguous()
         ctx.save_for_backward(idx)
         ctx.n_rows = w_trans.shape[0]
         return ops.latent_rows_fwd(w_trans, w_light, idx)

@@ -224,7 +224,9 @@ extern "C" int tp_composite_fwd(const tp_composite_args* a, tp_stream_t stream) 
 
 extern "C" int tp_composite_bwd(const tp_composite_bwd_args* a, tp_stream_t stream) {
   TP_REQUIRE(a && a->fwd.ray && a->fwd.rgb && a->fwd.density && a->fwd.depth && a->fwd.uncert, "null forward input");
-  TP_REQUIRE((a->g_out_ray || a->g_rgb_ray || a->g_uncert_ray) && a->g_rgb && a->g_density && a->g_uncert, "null gradient pointer");
+  // every cotangent is optional (the kernel reads a NULL one as zero): a step whose only consumers are the fan-out aliases
+  // (g_rgb_ray2 / 3, g_density_add) is as valid as one with g_out_ray; only the three outputs are required
+  TP_REQUIRE(a->g_rgb && a->g_density && a->g_uncert, "null gradient output pointer");
   TP_REQUIRE(a->fwd.N > 0 && a->fwd.n >= 0, "bad sizes");
   TP_REQUIRE(a->fwd.N <= 64 * kMaxChunks, "composite backward supports at most 2048 samples per ray");
   if (a->fwd.n == 0) return 0;

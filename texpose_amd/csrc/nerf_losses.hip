@@ -56,12 +56,13 @@ __device__ __forceinline__ void nerf_losses_finalize(const float* partial, int n
   }
 }
 
-// The block that finishes LAST reduces the partials of all of them (a ticket in device memory, reset by that block): the forward
-// is one launch, and the order of the final reduction is the same whichever block runs it.
+// The block that finishes LAST reduces the partials of all of them (a ticket in CALLER-OWNED device memory -- `args.ticket`, one
+// word per stream that may run this entry point, zero between launches, reset by that block: two launches that overlap on
+// different streams must not count each other's arrivals): the forward is one launch, and the order of the final reduction is
+// the same whichever block runs it.
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
 #error "the last-block hand-over below relies on the gfx950 agent-scope store / load contract (csrc/patch_conv.hip)"
 #endif
-__device__ unsigned int g_nerf_losses_ticket = 0;
 __global__ __launch_bounds__(kBlock) void nerf_losses_fwd_kernel(tp_nerf_losses_args a, float* partial, float n_pix_f, float n_den_f) {
   __shared__ float red[4 * kBlock];
   __shared__ double red_d[4][kBlock];
@@ -91,11 +92,11 @@ __global__ __launch_bounds__(kBlock) void nerf_losses_fwd_kernel(tp_nerf_losses_
 #pragma unroll
     for (int k = 0; k < 4; ++k) __hip_atomic_store(partial + blockIdx.x * 4 + k, v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    last = __hip_atomic_fetch_add(&g_nerf_losses_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+    last = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
   }
   __syncthreads();
   if (!last) return;
-  if (threadIdx.x == 0) __hip_atomic_store(&g_nerf_losses_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (threadIdx.x == 0) __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   nerf_losses_finalize(partial, (int)gridDim.x, a.sums, a.losses, n_pix_f, n_den_f, red_d);
 }
 
@@ -141,6 +142,7 @@ int check(const tp_nerf_losses_args* a, const char* what) {
 extern "C" int tp_nerf_losses_fwd(const tp_nerf_losses_args* a, tp_stream_t stream) {
   if (int rc = check(a, "tp_nerf_losses_fwd")) return rc;
   const int g = grid_for(a);
+  if (!a->ticket) { tp::set_error("tp_nerf_losses_fwd: args.ticket (a zero-filled device word owned by the calling stream) is required"); return -1; }
   hipLaunchKernelGGL(nerf_losses_fwd_kernel, dim3(g), dim3(kBlock), 0, (hipStream_t)stream, *a, (float*)a->workspace,
                      (float)((int64_t)a->B * a->P), (float)((int64_t)a->B * a->P * a->N));
   return tp::check_launch("tp_nerf_losses_fwd");

@@ -154,10 +154,10 @@ struct AdamTable {
   int n;
 };
 // The step counters are read by every block and must advance only after the last of them has: the block that finishes last (a
-// ticket in device memory, reset by that block) adds 1 to each distinct counter.
-__device__ unsigned int g_adam_ticket = 0;
+// ticket in CALLER-OWNED device memory, one zero-filled word per stream that may run this entry point, reset by that block; agent-scope
+// accesses as in nerf_losses.hip) adds 1 to each distinct counter.
 __global__ __launch_bounds__(kBlock) void adam_kernel(AdamTable t, const float* lr_dev, double lr_host, double beta1, double beta2, float eps,
-                                                      float w1, float w2, int64_t total, const int* gate, int n_gate) {
+                                                      float w1, float w2, int64_t total, const int* gate, int n_gate, unsigned int* ticket) {
   __shared__ bool last;
   for (int k = 0; k < n_gate; ++k)
     if (gate[k] != 0) return;
@@ -184,10 +184,10 @@ __global__ __launch_bounds__(kBlock) void adam_kernel(AdamTable t, const float* 
     t.p[k][i] = tp::add_rn(t.p[k][i], tp::mul_rn(-step_size, tp::div_rn(m, denom)));    // addcdiv_(exp_avg, denom, value = -step_size)
   }
   __syncthreads();                                         // every thread of this block has read its counters
-  if (threadIdx.x == 0) last = atomicAdd(&g_adam_ticket, 1u) == gridDim.x - 1;
+  if (threadIdx.x == 0) last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
   __syncthreads();
   if (!last) return;
-  if (threadIdx.x == 0) g_adam_ticket = 0;
+  if (threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   // (tensors of one optimiser usually share nothing, but two entries may name the same counter: add once per distinct pointer)
   for (int kk = threadIdx.x; kk < t.n; kk += blockDim.x) {
     bool first = true;
@@ -401,8 +401,9 @@ int tp_step_flags(const int32_t* mlp_status, const float* total, int32_t* bad, i
 }
 
 int tp_adam_step(const tp_adam_tensor* tensors, int n, const float* lr_dev, double lr_host, double beta1, double beta2, double eps,
-                 const int32_t* gate, int n_gate, tp_stream_t stream) {
+                 const int32_t* gate, int n_gate, uint32_t* ticket, tp_stream_t stream) {
   TP_REQUIRE(tensors != nullptr && n > 0 && n <= TP_ADAM_MAX_TENSORS, "bad tensor table");
+  TP_REQUIRE(ticket != nullptr, "ticket (a zero-filled device word owned by the calling stream) is required");
   TP_REQUIRE(n_gate == 0 || gate != nullptr, "gate words missing");
   AdamTable t;
   int64_t total = 0;
@@ -417,7 +418,7 @@ int tp_adam_step(const tp_adam_tensor* tensors, int n, const float* lr_dev, doub
   int64_t blocks = (total + kBlock - 1) / kBlock;
   if (blocks > 512) blocks = 512;          // (one arrival per block on ONE counter word: 1,700 same-address atomics cost 16 us)
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, t, lr_dev, lr_host, beta1, beta2, (float)eps,
-                     (float)(1.0 - beta1), (float)(1.0 - beta2), total, gate, n_gate);
+                     (float)(1.0 - beta1), (float)(1.0 - beta2), total, gate, n_gate, ticket);
   return tp::check_launch("tp_adam_step");
 }
 

@@ -154,7 +154,11 @@ def setup_data_parallel(graph: torch.nn.Module, seed: int = 0, group=None) -> tu
 
 # per-sample entries of a collated batch (reference data/lm.py:112-159, data/lmsyn2real.py)
 PER_SAMPLE_KEYS = frozenset(("idx", "image", "image_syn", "nocs_pred", "normal_pred", "obj_mask", "mask_syn", "intr", "pose",
-                             "pose_init", "pose_gt", "z_near", "z_far", "frame_index", "depth_gt", "mask_visib", "mask_full"))
+                             "pose_init", "pose_gt", "z_near", "z_far", "frame_index", "depth_gt", "mask_visib", "mask_full",
+                             "erode_mask"))                # (data/lm.py:148-150, with opt.data.erode_mask_loss)
+
+
+_SHARD_WARNED = set()
 
 
 def shard_training_batch(var, rank: int, world: int, per_sample_keys=PER_SAMPLE_KEYS):
@@ -170,5 +174,12 @@ def shard_training_batch(var, rank: int, world: int, per_sample_keys=PER_SAMPLE_
                 raise ValueError("shard_training_batch: %r is a per-sample entry but has shape %s at batch size %d" % (k, tuple(v.shape), B))
             out[k] = v[sl.start:sl.stop]
         else:
+            # an entry this list does not know that LOOKS per-sample (image-like: >= 4 dimensions, leading one = B) would stay at
+            # the full batch size on every rank; a dataset that adds such a key must name it (per_sample_keys=...)
+            if torch.is_tensor(v) and world > 1 and v.dim() >= 4 and v.shape[0] == B and k not in _SHARD_WARNED:
+                _SHARD_WARNED.add(k)
+                import warnings
+                warnings.warn("shard_training_batch: %r has the batch size as its leading dimension but is not a known per-sample "
+                              "entry; it is passed to every rank UNSLICED (add it to per_sample_keys if it is per-sample)" % (k,))
             out[k] = v
     return out

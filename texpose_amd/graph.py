@@ -475,7 +475,7 @@ class Graph(torch.nn.Module):
         reference :146-149), with the glue fused on the GPU: the cotangent of d_out.sum() is a constant vector of ones (no
         reduction launch), and sum(g^2) / B with its backward is one launch each way (K13) instead of pow / sum / add / div /
         mean and their autograd chains."""
-        if not (d_out.is_cuda and torch.is_tensor(d_out)):
+        if not (torch.is_tensor(d_out) and d_out.is_cuda):
             return Graph.compute_grad2(opt, d_out, x_in).mean()
         ones = _ones_like_cached(d_out)
         autograd_ops.SKIP_WEIGHT_GRADS = True          # this pass differentiates wrt the INPUT only

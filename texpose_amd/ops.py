@@ -432,8 +432,16 @@ def mlp_backward(nerf, lat_trans: Tensor, lat_light: Tensor, saved: Tensor, rgb:
         a.packed_t, a.repack = sc["packed_t"].data_ptr(), 1
     # the scale word inside the workspace is cleared by the last kernel of every call: no memset when the previous call used this
     # workspace with this size
-    a.dz_max_is_clear = 1 if sc.get("clear_for") == (sc["ws"].data_ptr(), S, wgrad_precision) else 0
-    sc["clear_for"] = (sc["ws"].data_ptr(), S, wgrad_precision)
+    # The mark says "the last EXECUTED call on this workspace ran to its end".  An eager call drops it before launching and sets it
+    # only after tp_mlp_bwd has returned without error (a failure after the dgrad kernel leaves the word dirty: the next call
+    # memsets).  A call that is being captured into a hipGraph executes nothing now: it may rely on the mark (at replay time the
+    # word is clean -- the eager call or the replay before it cleared it) but must not touch it, so that a capture which is
+    # discarded without a replay changes nothing for the next eager call.
+    capturing = bool(torch.cuda.is_current_stream_capturing())
+    clear_key = (sc["ws"].data_ptr(), S, wgrad_precision)
+    a.dz_max_is_clear = 1 if sc.get("clear_for") == clear_key else 0
+    if not capturing:
+        sc.pop("clear_for", None)
     a.saved, a.rgb, a.density, a.uncert = saved.data_ptr(), rgb.data_ptr(), density.data_ptr(), uncert.data_ptr()
     a.g_rgb, a.g_density, a.g_uncert = g_rgb.data_ptr(), g_density.data_ptr(), g_uncert.data_ptr()
     a.lat_trans, a.lat_light = lat_trans.data_ptr(), lat_light.data_ptr()
@@ -441,6 +449,8 @@ def mlp_backward(nerf, lat_trans: Tensor, lat_light: Tensor, saved: Tensor, rgb:
     a.g_lat_trans, a.g_lat_light, a.workspace = g_lt.data_ptr(), g_ll.data_ptr(), sc["ws"].data_ptr()
     a.wgrad_precision = PRECISIONS[wgrad_precision]
     check(lib.tp_mlp_bwd(C.byref(a), _stream()), "tp_mlp_bwd")
+    if not capturing:
+        sc["clear_for"] = clear_key
     return dict(params=grads, lat_trans=g_lt, lat_light=g_ll)
 
 
@@ -502,8 +512,7 @@ def composite_bwd(ray, rgb, density, depth, uncert, g_out: Optional[Tensor], g_a
     b = CompositeBwdArgs()
     fa, keep = _composite_args(ray, rgb, density, depth, uncert, min_uncert)
     b.fwd = fa
-    if g_out is None and g_rgb_ray is None and g_uncert_ray is None and g_rgb_ray2 is None and g_rgb_ray3 is None:
-        g_out = torch.zeros(*keep[0].shape[:-1], 14, device=keep[0].device)
+    # (every cotangent is optional: the kernel reads a missing one as zero -- no zero g_out is made up here)
     g_out = None if g_out is None else _f32(g_out, "g_out")
     g_rgb_ray = None if g_rgb_ray is None else _f32(g_rgb_ray, "g_rgb_ray")
     g_uncert_ray = None if g_uncert_ray is None else _f32(g_uncert_ray, "g_uncert_ray")
@@ -563,6 +572,19 @@ def eval_metrics(rgb_static: Tensor, image: Tensor, obj_mask: Tensor, H: int, W:
 
 
 _sn_ticket_arrays = {}       # (device index, stream) -> zero-filled int32 tensor (the kernels leave it zero)
+_ticket_words = {}           # (device index, stream, entry point) -> one zero-filled int32 word (the kernel leaves it zero)
+
+
+def _ticket(dev, name: str) -> int:
+    """The arrival counter of a last-block hand-over (tp_nerf_losses_fwd, tp_adam_step) for the CURRENT stream: launches of one
+    entry point that overlap on different streams of a device must not count each other's arrivals, so the word is owned by
+    (device, stream, entry point).  Made on first use; inside a hipGraph capture on a stream that has none yet the fill that
+    creates it is simply part of the captured step (correct, one launch more: warm up on the capturing stream to avoid it)."""
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream, name)
+    t = _ticket_words.get(key)
+    if t is None:
+        t = _ticket_words[key] = torch.zeros(1, dtype=torch.int32, device=dev)
+    return t.data_ptr()
 
 
 def _sn_tickets(dev) -> Optional[int]:
@@ -659,6 +681,7 @@ def nerf_losses_fwd(rgb: Tensor, uncert: Tensor, density: Tensor, gathered: Tens
     sums = torch.empty(4, dtype=torch.float64, device=rgb.device)
     losses = torch.empty(3, device=rgb.device) if want_losses else None
     a.workspace, a.sums, a.losses = ws.data_ptr(), sums.data_ptr(), _ptr(losses)
+    a.ticket = _ticket(rgb.device, "nerf_losses")
     check(lib.tp_nerf_losses_fwd(C.byref(a), _stream()), "tp_nerf_losses_fwd")
     return (sums, losses) if want_losses else sums
 
@@ -1122,6 +1145,9 @@ def latent_rows_fwd(w_trans: Tensor, w_light: Tensor, idx: Tensor):
 def latent_rows_bwd(g_trans: Tensor, g_light: Tensor, idx: Tensor, n_rows: int):
     lib = _lib.load()
     g_trans, g_light = _f32(g_trans, "g_trans"), _f32(g_light, "g_light")
+    if idx.dtype != torch.int64 or not idx.is_contiguous() or not idx.is_cuda:
+        raise _lib.TexposeLibraryError("latent_rows_bwd: idx must be the contiguous int64 device tensor the forward used (got %s%s)"
+                                       % (idx.dtype, "" if idx.is_contiguous() else ", non-contiguous"))
     B = idx.numel()
     gwt, gwl = torch.empty(n_rows, g_trans.shape[1], device=idx.device), torch.empty(n_rows, g_light.shape[1], device=idx.device)
     check(lib.tp_latent_rows_bwd(g_trans.data_ptr(), g_light.data_ptr(), idx.data_ptr(), B, int(n_rows), g_trans.shape[1], g_light.shape[1],
@@ -1154,7 +1180,7 @@ def adam_step(params, grads, exp_avgs, exp_avg_sqs, steps, lr, beta1: float, bet
                 raise _lib.TexposeLibraryError("adam_step needs contiguous float32 tensors and device step counters")
             a.param, a.grad, a.exp_avg, a.exp_avg_sq, a.step, a.numel = p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), st.data_ptr(), p.numel()
         check(lib.tp_adam_step(arr, len(chunk), lr_dev, lr_host, float(beta1), float(beta2), float(eps), _ptr(gate),
-                               gate.numel() if gate is not None else 0, _stream()), "tp_adam_step")
+                               gate.numel() if gate is not None else 0, _ticket(chunk[0][0].device, "adam"), _stream()), "tp_adam_step")
 
 
 # ------------------------------------------------------------------------------------------ K14

@@ -737,7 +737,14 @@ class GraphedGanTrainer(GanTrainer):
         self.graph.patch_sampler.update_device_bound()          # one fill_ of the annealed bound
         self._graph.replay()
         if self._graph_b is not None:                            # collectives between the two replays, stream-ordered
+            ev = getattr(self, "collective_events", None)        # (a list: HIP-event pairs around the step's reductions, bench.py)
+            if ev is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             self._reduce_all()
+            if ev is not None:
+                e1.record()
+                ev.append((e0, e1))
             self._graph_b.replay()
         self._after_step()
         flagged = self._read_bad()                              # outside the graph: event query + pinned copy

@@ -77,60 +77,62 @@ def render_image(graph, opts, im):
                                       object_mask=im["mask"], sample_idx=None, mode="val")
 
 
-def measure(device, rank: int, world: int, n_objects: int = 8, images_per_object: int = 8, n_samples: int = 256,
-            precision: str = "f16x3", warm: int = 1, steps: int = 1, keep_outputs: bool = False):
-    """One step = every object of this rank renders its whole image batch.  Returns the rank-0 line (dict) on every rank."""
+class HipBackend:
+    """What `measure` needs from the device: builders, the render call, synchronisation and a timer around ops.mlp_forward.
+    tests/test_dist_gloo_cpu.py substitutes a CPU stand-in to exercise the sharding / aggregation logic under gloo."""
+
+    def __init__(self, device, n_samples, precision):
+        self.device, self.n_samples, self.precision = device, n_samples, precision
+        self.events = []
+
+    def build_object(self, o):
+        return build_object(o, self.device, self.n_samples, self.precision)
+
+    def build_image(self, o, i):
+        return build_image(o, i, self.device)
+
+    def render(self, obj, im):
+        return render_image(*obj, im)
+
+    def sync(self):
+        torch.cuda.synchronize(self.device)
+
+    def __enter__(self):
+        from texpose_amd import ops
+        self._ops, self._orig = ops, ops.mlp_forward
+
+        def timed(*a, **k):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = self._orig(*a, **k)
+            e1.record()
+            self.events.append((e0, e1, out[1].numel() // 2))
+            return out
+        ops.mlp_forward = timed
+        return self
+
+    def __exit__(self, *exc):
+        self._ops.mlp_forward = self._orig
+
+    def kernel_totals(self):
+        """(samples, ms) over all MLP launches of the timed region."""
+        return sum(s for _, _, s in self.events), sum(a.elapsed_time(b) for a, b, _ in self.events)
+
+    def finish(self, ret):
+        assert torch.isfinite(ret.rgb).all()
+        self._ops.check_mlp_status(self.device)
+
+
+def objects_of_rank(n_objects: int, rank: int, world: int):
+    """Objects shard contiguously over the ranks (one object per GPU at N = 8); no data-path collective."""
     from texpose_amd import dist as tdist
-    from texpose_amd import ops
-    mine = list(tdist.shard_batch(n_objects, rank, world))
-    objs = {o: build_object(o, device, n_samples, precision) for o in mine}
-    imgs = {o: [build_image(o, i, device) for i in range(images_per_object)] for o in mine}
-    events, orig = [], ops.mlp_forward
+    return list(tdist.shard_batch(n_objects, rank, world))
 
-    def timed(*a, **k):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        out = orig(*a, **k)
-        e1.record()
-        events.append((e0, e1, out[1].numel() // 2))
-        return out
 
-    def barrier():
-        if world > 1:
-            torch.distributed.barrier()
-        torch.cuda.synchronize(device)
-
-    for _ in range(warm):
-        for o in mine:
-            render_image(*objs[o], imgs[o][0])
-            render_image(*objs[o], imgs[o][1 % images_per_object])
-    per_obj_s = {o: 0.0 for o in mine}
-    outputs = {}
-    ops.mlp_forward = timed
-    try:
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            for o in mine:
-                torch.cuda.synchronize(device)
-                t1 = time.perf_counter()
-                for im in imgs[o]:
-                    ret = render_image(*objs[o], im)
-                    if keep_outputs:
-                        outputs.setdefault(o, []).append(ret)
-                torch.cuda.synchronize(device)
-                per_obj_s[o] += time.perf_counter() - t1
-        barrier()
-        dt = time.perf_counter() - t0
-    finally:
-        ops.mlp_forward = orig
-    assert torch.isfinite(ret.rgb).all()
-    ops.check_mlp_status(device)
-    rays_obj = sum(im["H"] * im["W"] for im in imgs[mine[0]]) if mine else 0
-    samples = sum(s for _, _, s in events)
-    mlp_ms = sum(a.elapsed_time(b) for a, b, _ in events)
-    # gather: max wall time over ranks; per-object times and kernel times from every rank
-    stats = torch.zeros(n_objects + 3, dtype=torch.float64, device=device)
+def aggregate(device, world, n_objects, steps, mine, per_obj_s, samples, mlp_ms, dt):
+    """The only exchange of the job: per-object times and kernel totals of every rank (SUM over disjoint slots) and the job's
+    wall time (MAX).  Returns (seconds per step of the slowest rank, per-object seconds [n_objects], samples, kernel ms)."""
+    stats = torch.zeros(n_objects + 2, dtype=torch.float64, device=device)
     for o in mine:
         stats[o] = per_obj_s[o] / steps
     stats[n_objects], stats[n_objects + 1] = samples, mlp_ms
@@ -138,9 +140,51 @@ def measure(device, rank: int, world: int, n_objects: int = 8, images_per_object
     if world > 1:
         torch.distributed.all_reduce(stats, op=torch.distributed.ReduceOp.SUM)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-    dt = float(t) / steps
     stats = stats.tolist()
-    tot_samples, tot_ms = stats[n_objects], stats[n_objects + 1]
+    return float(t) / steps, stats[:n_objects], stats[n_objects], stats[n_objects + 1]
+
+
+def measure(device, rank: int, world: int, n_objects: int = 8, images_per_object: int = 8, n_samples: int = 256,
+            precision: str = "f16x3", warm: int = 1, steps: int = 1, keep_outputs: bool = False, backend=None):
+    """One step = every object of this rank renders its whole image batch.  Returns the rank-0 line (dict) on every rank."""
+    be = backend if backend is not None else HipBackend(device, n_samples, precision)
+    mine = objects_of_rank(n_objects, rank, world)
+    objs = {o: be.build_object(o) for o in mine}
+    imgs = {o: [be.build_image(o, i) for i in range(images_per_object)] for o in mine}
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        be.sync()
+
+    for _ in range(warm):
+        for o in mine:
+            be.render(objs[o], imgs[o][0])
+            be.render(objs[o], imgs[o][1 % images_per_object])
+    per_obj_s = {o: 0.0 for o in mine}
+    outputs = {}
+    ret = None
+    with be:
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            for o in mine:
+                be.sync()
+                t1 = time.perf_counter()
+                for im in imgs[o]:
+                    ret = be.render(objs[o], im)
+                    if keep_outputs:
+                        outputs.setdefault(o, []).append(ret)
+                be.sync()
+                per_obj_s[o] += time.perf_counter() - t1
+        barrier()
+        dt = time.perf_counter() - t0
+    if mine:
+        be.finish(ret)
+    # every object has the same image sizes: rays per object from the resolution sequence (a rank without objects knows it too)
+    rays_obj = sum(h * w for h, w in (image_resolution(i) for i in range(images_per_object)))
+    samples, mlp_ms = be.kernel_totals()
+    dt, stats, tot_samples, tot_ms = aggregate(device, world, n_objects, steps, mine, per_obj_s, samples, mlp_ms, dt)
     achieved = MLP_FLOP_PER_SAMPLE * tot_samples / (tot_ms * 1e-3) / 1e12 if tot_ms else 0.0
     peak = F16_PEAK_TFLOPS if precision == "f16x3" else 157.3
     total_rays = n_objects * rays_obj
@@ -156,14 +200,65 @@ def measure(device, rank: int, world: int, n_objects: int = 8, images_per_object
                     objects=list(LMO_OBJECTS[:n_objects]) if n_objects <= len(LMO_OBJECTS) else n_objects,
                     global_batch=n_objects * images_per_object, samples_per_ray=n_samples, rays_per_object=rays_obj,
                     mlp_precision=precision, parallelism="%d object(s) per GPU on %d GPU(s)" % (-(-n_objects // world), world)),
-        per_object=[dict(object=LMO_OBJECTS[o] if o < len(LMO_OBJECTS) else o, rays_per_s=rays_obj / stats[o], ms=stats[o] * 1e3)
-                    for o in range(n_objects)],
-        roofline=dict(kernel="mlp_fwd_f16x3_kernel" if precision == "f16x3" else "mlp_fwd_kernel", bound="mfma",
+        per_object=[dict(object=LMO_OBJECTS[o] if o < len(LMO_OBJECTS) else o, rays_per_s=rays_obj / stats[o] if stats[o] else None,
+                         ms=stats[o] * 1e3) for o in range(n_objects)],
+        roofline=dict(kernel="mlp_fwd_f16x3_kernel" if precision == "f16x3" else "mlp_fwd_exact_asm_kernel", bound="mfma",
                       achieved=achieved, peak=peak, unit="TFLOP/s", frac=achieved / peak, traffic=None,
                       kernel_ms_total_all_ranks=tot_ms / steps, samples_all_ranks=tot_samples / steps,
                       flop_per_sample=MLP_FLOP_PER_SAMPLE,
                       note="ALGORITHMIC FLOP of all MLP launches of the timed region / their summed HIP-event time (all ranks)"))
     return (line, outputs) if keep_outputs else line
+
+
+class StubBackend:
+    """CPU stand-in of HipBackend for the launcher / sharding self-test (`bench.py --config c5 --spawn-check`, gloo): a render
+    "takes" 1 ms x (object + 1) and "runs" one MLP launch of H*W*n_samples samples in 0.5 ms."""
+
+    def __init__(self, n_samples):
+        self.n_samples, self.samples, self.ms, self.calls = n_samples, 0, 0.0, []
+
+    def build_object(self, o):
+        return o
+
+    def build_image(self, o, i):
+        h, w = image_resolution(i)
+        return dict(H=h, W=w, obj=o, i=i)
+
+    def render(self, obj, im):
+        time.sleep(1e-3 * (obj + 1))
+        if getattr(self, "_timing", False):
+            self.samples += im["H"] * im["W"] * self.n_samples
+            self.ms += 0.5
+            self.calls.append((obj, im["i"]))
+        return im
+
+    def sync(self):
+        pass
+
+    def __enter__(self):
+        self._timing = True
+        return self
+
+    def __exit__(self, *exc):
+        self._timing = False
+
+    def kernel_totals(self):
+        return self.samples, self.ms
+
+    def finish(self, ret):
+        pass
+
+
+def spawn_check(rank: int, world: int, n_objects: int = 8, images_per_object: int = 2, n_samples: int = 4):
+    """`measure` with the stub renderer on CPU under gloo: the objects -> ranks sharding and the SUM / MAX aggregation of the real
+    entry point, without a GPU.  Returns the line (identical on every rank)."""
+    import torch.distributed as dist
+    if world > 1 and not dist.is_initialized():
+        dist.init_process_group("gloo")
+    be = StubBackend(n_samples)
+    line = measure(torch.device("cpu"), rank, world, n_objects, images_per_object, n_samples, "f16x3", warm=0, steps=1, backend=be)
+    line["stub_calls_this_rank"] = be.calls
+    return line
 
 
 def run(argv=None):

@@ -70,6 +70,8 @@ def measure(device, rank, world, global_batch=32, iters=50, warm=5, graphed=True
     for i in range(warm):
         trainer.train_iteration(AttrDict(dict(batches[i % 2])))
     barrier()
+    if graphed and getattr(trainer, "_graph_b", None) is not None:
+        trainer.collective_events = []                     # HIP events around the step's gradient all-reduces (xGMI figure)
     t0 = time.perf_counter()
     for i in range(iters):
         _, loss = trainer.train_iteration(AttrDict(dict(batches[i % 2])))
@@ -78,7 +80,10 @@ def measure(device, rank, world, global_batch=32, iters=50, warm=5, graphed=True
     if world > 1:
         torch.distributed.all_reduce(dt, op=torch.distributed.ReduceOp.MAX)
     dt = float(dt) / iters
-    return dict(metric="train iters/sec", value=1.0 / dt, ms_per_iter=dt * 1e3, n_gpus=world, global_batch=global_batch,
+    coll = None
+    if getattr(trainer, "collective_events", None):
+        coll = sum(a.elapsed_time(b) for a, b in trainer.collective_events) / len(trainer.collective_events)
+    return dict(collective_ms=coll, metric="train iters/sec", value=1.0 / dt, ms_per_iter=dt * 1e3, n_gpus=world, global_batch=global_batch,
                 per_gpu_batch=global_batch // world, rays_per_iter=global_batch * 256, samples_per_iter=global_batch * 256 * 64,
                 launch=("hipGraph replay" if getattr(trainer, "_graph_b", None) is None else "two hipGraph replays with the gradient all-reduces between them") if graphed else "eager", recording_forward=graph.nerf.train_precision,
                 collective="one flat all-reduce per optimiser step (%.1f MB nerf, %.1f MB discriminator)"
