@@ -73,6 +73,102 @@ def main():
         assert np.array_equal(val[k].numpy(), old_s["val_" + k]), k
     out.update({"val_" + k: v for k, v in seen[-1].items()})
     MG._save("g9b_reference_rays", **out)
+    flip_free_gradients(opt, g, tr, old, NeRF, T)
+
+
+def _hook_preactivations(nerf):
+    """Forward hooks on the hidden Linear layers of the reference's two heads (mlp_rgb.0..2, mlp_trans.0..2): their outputs are the
+    PRE-activations whose sign decides the ReLU gates (layers/nerf_static_transient_light.py:118-121,131-134)."""
+    taps, handles = {}, []
+    for name in ("mlp_rgb", "mlp_trans"):
+        layers = getattr(nerf, name)
+        for li in range(len(layers) - 1):
+            def hook(_m, _i, o, key="%s.%d" % (name, li)):
+                taps[key] = o.detach().clone()
+            handles.append(layers[li].register_forward_hook(hook))
+    return taps, handles
+
+
+def _risky(taps, shape):
+    """Samples in which ANY gate lies inside a band of 64 ulp of its layer's largest pre-activation around zero: another fp32
+    evaluation order may take the other side of such a gate (the band of tests/test_gpu_parity.py::
+    test_mlp_backward_tiers_with_gate_flips_masked, here from the REFERENCE's own pre-activations)."""
+    risky = torch.zeros(shape, dtype=torch.bool)
+    for z in taps.values():
+        band = 64 * 2.0 ** -23 * float(z.abs().max())
+        risky |= (z.abs() < band).any(dim=-1).view(shape)
+    return risky
+
+
+def _head_grads(nerf, lat_t, lat_l):
+    grads = {}
+    for name in ("mlp_rgb", "mlp_trans"):
+        for li, layer in enumerate(getattr(nerf, name)):
+            grads[f"g.{name}.{li}.weight"] = layer.weight.grad.clone()
+            grads[f"g.{name}.{li}.bias"] = layer.bias.grad.clone()
+    grads["g.lat_t"], grads["g.lat_l"] = lat_t.grad.clone(), lat_l.grad.clone()
+    return grads
+
+
+def _zero_grads(nerf):
+    for q in nerf.parameters():
+        q.grad = None
+
+
+def flip_free_gradients(opt, g, tr, g9, NeRF, T):
+    """G9c: gradients the REFERENCE's autograd produced on cotangents from which every gate-flip candidate was removed, so that
+    they can be compared at the tight tier (output layers <= 1e-5, hidden layers and latent rows <= 1e-4) instead of the 5e-3
+    gate-flip bound of G9.
+      (a) render level: the reference's own train rays of G9 (G9b), the per-ray cotangents of G9 with every RAY zeroed that holds
+          a flip-candidate sample (a ray with zero cotangents contributes nothing whatever its gates do) -> gradients through
+          NeRF.composite + NeRF.forward_samples;
+      (b) MLP level, more samples: seeded rays / depths / latent rows fed to the reference's forward_samples, per-SAMPLE
+          cotangents with the flip candidates zeroed."""
+    nerf = g.nerf
+    out = {}
+    taps, handles = _hook_preactivations(nerf)
+    try:
+        # ---- (a)
+        lat_t, lat_l = tr["lat_t"].clone().requires_grad_(), tr["lat_l"].clone().requires_grad_()
+        _zero_grads(nerf)
+        rgb_s, den_s, unc_s = nerf.forward_samples(opt, tr["center"], tr["ray"], tr["depth"], latent_variable_trans=lat_t,
+                                                   latent_variable_light=lat_l, mode="train")
+        B, R, N = den_s.shape[:3]
+        risky_ray = _risky(taps, (B, R, N)).any(dim=-1)                                     # [B,R]
+        comp = NeRF.composite(opt, tr["ray"], rgb_s, den_s, tr["depth"], unc_s)
+        names = ("rgb", "rgb_static", "rgb_transient", "depth", "opacity", "opacity_static", "opacity_transient", "prob", "uncert")
+        ret = dict(zip(names, comp[:9]))
+        keep = (~risky_ray).float()[..., None]
+        cot = {k: T(g9["cot_" + k]) * keep for k in ("rgb", "rgb_static", "rgb_transient", "uncert", "depth")}
+        # (G9's sixth cotangent is on the per-sample densities: masked per ray as well)
+        cot_den = T(g9["cot_density"]) * keep[..., None]
+        (sum((ret[k] * cot[k]).sum() for k in cot) + (den_s * cot_den).sum()).backward()
+        out.update({"a_keep_ray": keep[..., 0], "a_cot_density": cot_den, **{"a_cot_" + k: v for k, v in cot.items()},
+                    **{"a_" + k: v for k, v in _head_grads(nerf, lat_t, lat_l).items()}})
+        print("G9c (a): %d of %d rays hold a gate-flip candidate and are masked" % (int(risky_ray.sum()), risky_ray.numel()))
+        # ---- (b)
+        rs = np.random.RandomState(313)
+        B, R, N = 2, 96, 16
+        center = T(rs.normal(size=(B, 1, 3)) * 0.3 + np.array([0.0, 0.0, -8.0])).expand(B, R, 3).contiguous()
+        ray = T(np.concatenate([rs.uniform(-0.12, 0.12, size=(B, R, 2)), np.ones((B, R, 1))], axis=-1))
+        depth = T(np.sort(rs.uniform(7.0, 9.0, size=(B, R, N, 1)), axis=2))
+        lat_t, lat_l = T(rs.normal(size=(B, 16))).requires_grad_(), T(rs.normal(size=(B, 48))).requires_grad_()
+        _zero_grads(nerf)
+        rgb_s, den_s, unc_s = nerf.forward_samples(opt, center, ray, depth, latent_variable_trans=lat_t, latent_variable_light=lat_l,
+                                                   mode="train")
+        risky = _risky(taps, (B, R, N))
+        keep = (~risky).float()
+        cots = [T(rs.normal(size=tuple(o.shape))) * keep.view(B, R, N, *([1] * (o.dim() - 3))) for o in (rgb_s, den_s, unc_s)]
+        sum((o * c).sum() for o, c in zip((rgb_s, den_s, unc_s), cots)).backward()
+        print("G9c (b): %d of %d samples are gate-flip candidates and are masked" % (int(risky.sum()), risky.numel()))
+        assert 0 < int(risky.sum()) < 0.5 * risky.numel()
+        out.update(b_center=center, b_ray=ray, b_depth=depth, b_lat_t=lat_t.detach(), b_lat_l=lat_l.detach(), b_keep=keep,
+                   b_cot_rgb=cots[0], b_cot_density=cots[1], b_cot_uncert=cots[2], b_out_rgb=rgb_s.detach(), b_out_density=den_s.detach(),
+                   b_out_uncert=unc_s.detach(), **{"b_" + k: v for k, v in _head_grads(nerf, lat_t, lat_l).items()})
+    finally:
+        for h in handles:
+            h.remove()
+    MG._save("g9c_flipfree_grads", **out)
 
 
 if __name__ == "__main__":

@@ -604,6 +604,38 @@ def test_reference_rays_reproduce_reference_render_g9b(ops):
         errs["light"] = rel_l2(ll.grad.cpu(), g9["g.latent_vars_light"][idx])
         errs["trans"] = rel_l2(lt.grad.cpu(), g9["g.latent_vars_trans"][idx])
         assert max(errs.values()) < 5e-3, (prec, errs)
+        # ---- the TIGHT tier against the reference's own gradients (golden G9c, tests/golden/make_golden_g9b.py): cotangents from
+        # which every gate-flip candidate was removed (found from the REFERENCE's pre-activations by forward hooks).  (a) the same
+        # rays through MLP + composite with G9's per-ray cotangents, flip-candidate rays zeroed; (b) 3,072 samples at the MLP
+        # level with per-sample cotangents.  Output layers <= 1e-5, hidden layers and latent rows <= 1e-4 (north_star's bar);
+        # measured values are printed.
+        gc = load_golden("g9c_flipfree_grads")
+        for part in ("a", "b"):
+            graph.zero_grad(set_to_none=True)
+            if part == "a":
+                lt, ll = cu(gb["train_lat_t"]).requires_grad_(), cu(gb["train_lat_l"]).requires_grad_()
+                rgb_s, den_s, unc_s = graph.nerf.forward_samples(opt, cu(gb["train_center"]), cu(gb["train_ray"]), cu(gb["train_depth"]),
+                                                                 latent_variable_trans=lt, latent_variable_light=ll, mode="train")
+                out = graph.nerf.composite(opt, cu(gb["train_ray"]), rgb_s, den_s, cu(gb["train_depth"]), unc_s)
+                ret = dict(rgb=out[0], rgb_static=out[1], rgb_transient=out[2], depth=out[3], uncert=out[8])
+                (sum((ret[k] * cu(gc["a_cot_" + k])).sum() for k in ret) + (den_s * cu(gc["a_cot_density"])).sum()).backward()
+            else:
+                lt, ll = cu(gc["b_lat_t"]).requires_grad_(), cu(gc["b_lat_l"]).requires_grad_()
+                outs = graph.nerf.forward_samples(opt, cu(gc["b_center"]), cu(gc["b_ray"]), cu(gc["b_depth"]),
+                                                  latent_variable_trans=lt, latent_variable_light=ll, mode="train")
+                for o, k in zip(outs, ("rgb", "density", "uncert")):
+                    assert rel_l2(o, gc["b_out_" + k]) < 1e-5, (prec, k)
+                sum((o * cu(gc["b_cot_" + k])).sum() for o, k in zip(outs, ("rgb", "density", "uncert"))).backward()
+            errs = {}
+            for name in ("mlp_rgb", "mlp_trans"):
+                for li in range(4):
+                    for kind in ("weight", "bias"):
+                        errs["%s.%d.%s" % (name, li, kind)] = rel_l2(getattr(getattr(graph.nerf, name)[li], kind).grad,
+                                                                     gc["%s_g.%s.%d.%s" % (part, name, li, kind)])
+            errs["lat_t"], errs["lat_l"] = rel_l2(lt.grad, gc[part + "_g.lat_t"]), rel_l2(ll.grad, gc[part + "_g.lat_l"])
+            print("G9c (%s) flip-free gradients vs the REFERENCE, %s record:" % (part, prec), {k: float("%.2e" % v) for k, v in errs.items()})
+            for k, v in errs.items():
+                assert v < (1e-5 if ".3." in k else 1e-4), (prec, part, k, v)
     ops.check_mlp_status(dev())
 
 

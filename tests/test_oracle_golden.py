@@ -346,3 +346,43 @@ def test_c1_literal_size_g17():
         val = O.render_by_slices(p, et, el, g["pose"], g["intr"], dr, torch.ones(1, H, W), None, "val", H, W, N, chunk=H * W)
     for name in names + ("uncert",):
         close(val[name], g["val_" + name], rtol=2e-5, atol=2e-6)
+
+
+def _rel_l2(a, b):
+    a, b = a.detach().double(), b.detach().double()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def test_flip_free_gradients_g9c():
+    """G9c: gradients the REFERENCE's autograd produced on cotangents from which every gate-flip candidate (a sample -- or, at the
+    render level, a ray -- with a head pre-activation inside a 64-ulp band around zero, found from the reference's own
+    pre-activations by forward hooks) was removed.  Without flips the oracle must reproduce them tightly on every layer and on
+    the latent rows: <= 1e-5 (G9's unmasked gradients only hold rtol 1e-3)."""
+    g9, gb, gc = load_golden("g9_render_train"), load_golden("g9b_reference_rays"), load_golden("g9c_flipfree_grads")
+    base = O.make_params(g9["seed"])
+
+    def leaves():
+        p = {k: v.clone().requires_grad_(not k.startswith("mlp_feat")) for k, v in base.items()}
+        return p
+
+    # (a) render level on the reference's own rays
+    p = leaves()
+    lt, ll = gb["train_lat_t"].clone().requires_grad_(), gb["train_lat_l"].clone().requires_grad_()
+    rgb_s, den_s, unc_s = O.forward_samples(p, gb["train_center"], gb["train_ray"], gb["train_depth"], lt, ll)
+    comp = O.composite(gb["train_ray"], rgb_s, den_s, gb["train_depth"], unc_s)
+    ret = dict(rgb=comp[0], rgb_static=comp[1], rgb_transient=comp[2], depth=comp[3], uncert=comp[8])
+    (sum((ret[k] * gc["a_cot_" + k]).sum() for k in ret) + (den_s * gc["a_cot_density"]).sum()).backward()
+    errs = {k: _rel_l2(v.grad, gc["a_g." + k]) for k, v in p.items() if v.requires_grad}
+    errs["lat_t"], errs["lat_l"] = _rel_l2(lt.grad, gc["a_g.lat_t"]), _rel_l2(ll.grad, gc["a_g.lat_l"])
+    assert max(errs.values()) < 1e-5, errs
+    assert 0 < float(gc["a_keep_ray"].sum()) < gc["a_keep_ray"].numel()
+    # (b) MLP level, per-sample cotangents
+    p = leaves()
+    lt, ll = gc["b_lat_t"].clone().requires_grad_(), gc["b_lat_l"].clone().requires_grad_()
+    outs = O.forward_samples(p, gc["b_center"], gc["b_ray"], gc["b_depth"], lt, ll)
+    for o, k in zip(outs, ("rgb", "density", "uncert")):
+        close(o, gc["b_out_" + k], rtol=2e-5, atol=2e-6)
+    sum((o * gc["b_cot_" + k]).sum() for o, k in zip(outs, ("rgb", "density", "uncert"))).backward()
+    errs = {k: _rel_l2(v.grad, gc["b_g." + k]) for k, v in p.items() if v.requires_grad}
+    errs["lat_t"], errs["lat_l"] = _rel_l2(lt.grad, gc["b_g.lat_t"]), _rel_l2(ll.grad, gc["b_g.lat_l"])
+    assert max(errs.values()) < 1e-5, errs

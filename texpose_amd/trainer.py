@@ -535,16 +535,30 @@ class GraphedGanTrainer(GanTrainer):
         dloss = None
         # optimiser steps (and reductions) after this function: whenever a collective is part of the step, or on request
         self._deferred = self._has_collective() or self._split_around_collectives()
-        if overlap:
+        # (diagnostic knobs, tools/gan_timeline.sh: TP_SKIP_DISC_STEP=1 leaves the discriminator step out of the iteration -- NOT a
+        # training step, only to time the generator chain alone; TP_BACKWARD_FIRST=1 issues the generator's backward before the
+        # discriminator branch, which changes the order of the nodes in the captured graph and nothing else)
+        skip_disc = os.environ.get("TP_SKIP_DISC_STEP") == "1"
+        backward_first = os.environ.get("TP_BACKWARD_FIRST") == "1"
+
+        def generator_backward():
+            torch.autograd.backward(terms, ws)
+            if not self._deferred:
+                self._guard_nerf(var, loss)
+                self.nerf_apply()
+
+        if overlap and not skip_disc:
             main = torch.cuda.current_stream(var.rgb.device)
             self._side.wait_stream(main)                          # fork
+            if backward_first:
+                generator_backward()
             with torch.cuda.stream(self._side):
                 var, dloss = self.disc_step(var, apply=not self._deferred)
-        torch.autograd.backward(terms, ws)
-        if not self._deferred:
-            self._guard_nerf(var, loss)
-            self.nerf_apply()
-        if overlap:
+        if not (overlap and not skip_disc and backward_first):
+            generator_backward()
+        if skip_disc:
+            pass
+        elif overlap:
             main.wait_stream(self._side)                          # join
         elif self.has_disc:
             var, dloss = self.disc_step(var, apply=not self._deferred)
@@ -565,7 +579,7 @@ class GraphedGanTrainer(GanTrainer):
             return
         p, B = int(opt.patch_size), len(var.idx)
         probe = torch.empty(0, device=var.idx.device).new_empty((B, 0, p, p))          # (shape / device carrier: no data)
-        n = 1 + (2 if self._disc_schedule(probe) is not None else 0)
+        n = 1 + (2 if self._disc_schedule(probe) is not None and os.environ.get("TP_SKIP_DISC_STEP") != "1" else 0)
         main = torch.cuda.current_stream(probe.device)
         self._side.wait_stream(main)                 # (after the previous iteration's RMSprop step, whichever stream ran it)
         with torch.cuda.stream(self._side):

@@ -10,5 +10,5 @@ t0 = int(seg[0]["Start_Timestamp"])
 for r in seg:
     n = re.sub(r"\(anonymous namespace\)::|void |at::native::|std::array<char\*, \d+ul>|binary_internal::|<unnamed>::", "", r["Kernel_Name"])
     n = re.sub(r"\s+", " ", n)
-    print("%9.1f %7.1f  g%-6s %s" % ((int(r["Start_Timestamp"]) - t0) / 1e3, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3,
-                                    r.get("Grid_Size_X", r.get("Grid_Size", "?")), n[:150]))
+    print("%9.1f %7.1f  q%-3s g%-6s %s" % ((int(r["Start_Timestamp"]) - t0) / 1e3, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3,
+                                          r.get("Queue_Id", "?"), r.get("Grid_Size_X", r.get("Grid_Size", "?")), n[:150]))
