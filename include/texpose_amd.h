@@ -468,6 +468,17 @@ typedef struct tp_adam_tensor {
 } tp_adam_tensor;
 int tp_adam_step(const tp_adam_tensor* tensors /* host array */, int n, const float* lr_dev, double lr_host, double beta1, double beta2,
                  double eps, const int32_t* gate, int n_gate, uint32_t* ticket, tp_stream_t stream);
+/* The per-iteration host -> device state of a replayed training step (reference Model.train_iteration's move_to_device of the
+ * batch, model/nerf_adapt_st_gan.py:212; patch_sampler.iterations :185; discriminator.progress :182) in ONE launch:
+ * n_copies contiguous device-to-device copies (16-byte aligned; the batch into the captured step's static inputs),
+ * n_scalars host values written to device floats, and n_words int32 gate words copied out to device-visible pinned host memory
+ * (words_dst may be NULL). */
+#define TP_STEP_INPUTS_MAX_COPIES 24
+#define TP_STEP_INPUTS_MAX_SCALARS 8
+typedef struct tp_step_copy { void* dst; const void* src; int64_t bytes; } tp_step_copy;
+int tp_step_inputs(const tp_step_copy* copies /* host array */, int n_copies, float* const* scalar_dst /* host array */,
+                   const float* scalar_val /* host array */, int n_scalars, const int32_t* words_src, int32_t* words_dst, int n_words,
+                   tp_stream_t stream);
 int tp_disc_inputs(const float* rgb, const float* gathered, int B, int P, int geo, float* real, float* fake, tp_stream_t stream);
 /* Cotangent of the fake stack wrt the rendered colours (the nerf step back-propagates D(fake) into the render):
  * g_rgb [B,P,3] = g_fake [B,nc,P] channels 0..2, transposed. */
@@ -544,6 +555,45 @@ int tp_skinny_linear_fwd(const float* x, const float* w, float* y, int M, int N,
 int tp_skinny_linear_wgrad(const float* gy, const float* x, float* gw, int M, int N, int K, tp_stream_t stream);
 /* gx [M,K] = gy [M,N] w [N,K] for M <= 16 rows (larger M: a library GEMM on the host side) */
 int tp_skinny_linear_dgrad(const float* gy, const float* w, float* gx, int M, int N, int K, tp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K17  the TAIL of the PatchGAN = K15's full-map convolution + K14's scale-conditioned head in ONE launch per derivative order
+ *      (reference layers/discriminator.py:30-40,110-115; the R1 double backward of model/nerf_adapt_st_gan.py:794-807).
+ *      Up to TP_DISC_TAIL_MAX_ROWS rows per pass; N = C = ndf, Cin = N + 2 L + 1, K a multiple of 4.
+ *      fwd:      a [M,K], W0 [N,K], scale [M], W1..3 -> out [M], t0 [M,Cin], t1, t2 [M,H]
+ *      bwd:      g_out [M], t0..2, W0..3 -> (all optional) gz [M,N], e1, e2 [M,H], c_a [M,K] = gz W0, gW0 [N,K] = sum_rows gz (x) a
+ *                (+ sum over M2 extra rows gy2 [M2,N] (x) a2 [M2,K]: the R1 path's pair of the same weight), gW1..3 (all or none;
+ *                accumulate_gw adds to what is there)
+ *      bwd_bwd:  a = c [M,K] (cotangent of the first pass' c_a), g_out, t0..2, e1, e2, W0..3 -> gW1..3 (the double backward's
+ *                share), out = d/d g_out [M] (optional)
+ *      workspace: tp_disc_tail_workspace_bytes(N) bytes; ticket: one zero-filled device word owned by the calling stream (fwd, bwd_bwd).
+ * ------------------------------------------------------------------------------------------ */
+#define TP_DISC_TAIL_MAX_ROWS 16
+typedef struct tp_disc_tail_args {
+  const float* a;          /* fwd: ladder output [M,K]; bwd: the same (for gW0; may be NULL without gW0); bwd_bwd: c [M,K] */
+  const float* W0;         /* [N,K] */
+  const float* scale;      /* [M]   fwd */
+  const float* W1; const float* W2; const float* W3;   /* [H,Cin], [H,H], [H] */
+  const float* g_out;      /* [M]   bwd, bwd_bwd */
+  float* t0; float* t1; float* t2;   /* fwd: written; bwd, bwd_bwd: read */
+  float* e1; float* e2;              /* bwd: written (optional); bwd_bwd: read */
+  float* out;              /* fwd: [M]; bwd_bwd: d/d g_out [M] (optional) */
+  float* gz;               /* bwd: [M,N] (optional) */
+  float* c_a;              /* bwd: [M,K] (optional) */
+  float* gW0;              /* bwd: [N,K] (optional) */
+  const float* gy2;        /* bwd: [M2,N] extra cotangent rows of gW0 */
+  const float* a2;         /* bwd: [M2,K] their inputs */
+  float* gW1; float* gW2; float* gW3;
+  void* workspace;         /* fwd, bwd_bwd */
+  uint32_t* ticket;        /* fwd, bwd_bwd */
+  int32_t M, M2, K, N, L, H;
+  float slope;
+  int32_t accumulate_gw;
+} tp_disc_tail_args;
+size_t tp_disc_tail_workspace_bytes(int N);
+int tp_disc_tail_fwd(const tp_disc_tail_args* args, tp_stream_t stream);
+int tp_disc_tail_bwd(const tp_disc_tail_args* args, tp_stream_t stream);
+int tp_disc_tail_bwd_bwd(const tp_disc_tail_args* args, tp_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -2337,3 +2337,109 @@ def test_composite_bwd_with_only_fan_out_cotangents(ops):
     # the density cotangent alone (no per-ray cotangent at all): the gradient IS g_density_add, rgb / uncert gradients are zero
     got = ops.composite_bwd(ray, rgb, den, z, unc, None, g_density_add=gd)
     assert float(got[0].abs().max()) == 0.0 and float(got[2].abs().max()) == 0.0 and torch.equal(got[1], gd)
+
+
+# ------------------------------------------------------------------------------------------ round-4 K17: the PatchGAN's tail in one launch
+@pytest.mark.parametrize("M,M2,K,N,H,L", [(4, 4, 8192, 64, 64, 4), (1, 0, 8192, 64, 64, 4), (8, 8, 8192, 64, 64, 4), (16, 16, 2048, 32, 48, 2),
+                                           (5, 3, 1028, 16, 16, 0)])
+def test_disc_tail_kernels_match_the_k15_k14_composition(ops, M, M2, K, N, H, L):
+    """tp_disc_tail_fwd / _bwd / _bwd_bwd (full-map convolution + scale-conditioned head, one launch per derivative order) against
+    the kernels they replace (K15 skinny_linear_* + K14 disc_head_*, each pinned to torch in fp64 by its own test): forward
+    outputs and saved activations, the backward's data gradient / weight gradients incl. the extra (R1-path) rows of the
+    full-map weight and the accumulate form, the double backward's weight gradients.  Two launches in a row give identical bits."""
+    torch.manual_seed(M * 1000 + K + L)
+    d = dev()
+    a, W0 = torch.randn(M, K, device=d), torch.randn(N, K, device=d) / K ** 0.5
+    scale = torch.rand(M, device=d) * 0.75 + 0.25
+    Cin = N + 2 * L + 1
+    W1, W2, W3 = torch.randn(H, Cin, device=d) / 8, torch.randn(H, H, device=d) / 8, torch.randn(1, H, device=d) / 8
+    tol = dict(rtol=2e-5, atol=2e-6)
+    # ---- forward
+    out, t0, t1, t2 = ops.disc_tail_fwd(a, W0, scale, W1, W2, W3, L, 0.2)
+    z = ops.skinny_linear_fwd(a, W0)
+    out_r, t0_r, t1_r, t2_r = ops.disc_head_fwd(z, scale, W1, W2, W3, L, 0.2)
+    for got, ref in ((out, out_r), (t0, t0_r), (t1, t1_r), (t2, t2_r)):
+        torch.testing.assert_close(got, ref, **tol)
+    again = ops.disc_tail_fwd(a, W0, scale, W1, W2, W3, L, 0.2)
+    assert all(torch.equal(x, y) for x, y in zip(again, (out, t0, t1, t2)))
+    # ---- backward (on the reference's saved activations, so that both sides see identical gates)
+    g = torch.randn(M, device=d)
+    gy2 = torch.randn(M2, N, device=d) if M2 else None
+    a2 = torch.randn(M2, K, device=d) if M2 else None
+    r = ops.disc_tail_bwd(g, t0_r, t1_r, t2_r, W0, W1, W2, W3, L, 0.2, a=a, want_e=True, gz_out=torch.empty(M, N, device=d), gy2=gy2, a2=a2)
+    gz_r, gW1_r, gW2_r, gW3_r, e1_r, e2_r = ops.disc_head_bwd(g, t0_r, t1_r, t2_r, W1, W2, W3, N, L, 0.2)
+    c_a_r = gz_r @ W0
+    gW0_r = gz_r.t() @ a + (gy2.t() @ a2 if M2 else 0)
+    for name, ref in (("gz", gz_r), ("e1", e1_r), ("e2", e2_r), ("gW1", gW1_r), ("gW2", gW2_r), ("gW3", gW3_r)):
+        torch.testing.assert_close(r[name], ref.view_as(r[name]), **tol)
+    assert rel_l2(r["c_a"], c_a_r) < 1e-5 and rel_l2(r["gW0"], gW0_r) < 1e-5
+    # data gradient only (frozen weights / R1 first pass); accumulate form
+    r0 = ops.disc_tail_bwd(g, t0_r, t1_r, t2_r, W0, W1, W2, W3, L, 0.2, want_gW0=False, head_weight_grads=False)
+    assert torch.equal(r0["c_a"], r["c_a"]) and r0["gW0"] is None and r0["gW1"] is None
+    base = (torch.randn_like(W1), torch.randn_like(W2), torch.randn_like(W3))
+    keep = [b.clone() for b in base]
+    ra = ops.disc_tail_bwd(g, t0_r, t1_r, t2_r, W0, W1, W2, W3, L, 0.2, a=a, accumulate_into=base)
+    for name, b, ref in zip(("gW1", "gW2", "gW3"), keep, (gW1_r, gW2_r, gW3_r)):
+        assert ra[name].data_ptr() == base[("gW1", "gW2", "gW3").index(name)].data_ptr()
+        torch.testing.assert_close(ra[name], b + ref.view_as(b), **tol)
+    # ---- double backward
+    c = torch.randn(M, K, device=d)
+    ones = torch.ones(M, device=d)
+    _, _, _, _, e1o, e2o = ops.disc_head_bwd(ones, t0_r, t1_r, t2_r, W1, W2, W3, N, L, 0.2, weight_grads=False)
+    gW1b, gW2b, gW3b, gg = ops.disc_tail_bwd_bwd(c, ones, t0_r, t1_r, t2_r, e1o, e2o, W0, W1, W2, W3, L, 0.2, want_gg=True)
+    gg_r, gW1b_r, gW2b_r, gW3b_r = ops.disc_head_bwd_bwd(ops.skinny_linear_fwd(c, W0), ones, t0_r, t1_r, t2_r, e1o, e2o, W1, W2, W3, L, 0.2)
+    for got, ref in ((gg, gg_r), (gW1b, gW1b_r), (gW2b, gW2b_r), (gW3b, gW3b_r)):
+        torch.testing.assert_close(got, ref.view_as(got), **tol)
+
+
+def test_discriminator_forward_takes_the_fused_tail_for_frozen_weights(ops):
+    """Discriminator.forward on the GPU with constant weights (the nerf step's pass: prefetched, detached spectral weights) runs the
+    ladder's full-map convolution + head as K17's one launch each way; value and the gradient wrt the patch equal the unfused
+    composition (TP_NO_DISC_TAIL=1)."""
+    from texpose_amd.gan_modules import Discriminator
+    from texpose_amd.options import default_options
+    opt = default_options(H=128, W=128, device="cuda:0")
+    opt.patch_size = 16
+    torch.manual_seed(3)
+    disc = Discriminator(opt).to(dev()).train()
+    O.seed_spectral_module(disc, 4)
+    for p in disc.parameters():
+        p.requires_grad_(False)
+    x0 = torch.randn(4, 9, 16, 16, device=dev())
+    scale = torch.rand(4, 1, 1, 1, device=dev()) * 0.7 + 0.3
+    res = []
+    state = {k: v.clone() for k, v in disc.state_dict().items()}
+    for env in (None, "1"):
+        disc.load_state_dict(state)
+        if env is None:
+            os.environ.pop("TP_NO_DISC_TAIL", None)
+        else:
+            os.environ["TP_NO_DISC_TAIL"] = env
+        try:
+            disc.prefetch_spectral_weights(1)
+            x = x0.clone().requires_grad_()
+            out = disc(opt, x, scale)
+            (out * torch.arange(1, 5, device=dev())).sum().backward()
+            res.append((out.detach().clone(), x.grad.clone(), type(out.grad_fn).__name__))
+        finally:
+            os.environ.pop("TP_NO_DISC_TAIL", None)
+    assert "DiscTail" in res[0][2] and "DiscTail" not in res[1][2]
+    torch.testing.assert_close(res[0][0], res[1][0], rtol=2e-5, atol=2e-6)
+    assert rel_l2(res[0][1], res[1][1]) < 1e-5
+
+
+def test_step_inputs_one_launch_for_the_per_iteration_host_state(ops):
+    """tp_step_inputs: the batch copies (odd sizes, several dtypes), the host scalars and the gate words -> pinned host memory."""
+    d = dev()
+    srcs = [torch.randn(4, 3, 128, 128, device=d), torch.arange(7, device=d), torch.randn(5, device=d), torch.rand(4, 128 * 128, device=d) > 0.5]
+    dsts = [torch.zeros_like(s) for s in srcs]
+    s0, s1 = torch.zeros((), device=d), torch.zeros((), device=d)
+    words = torch.tensor([1, 0, 7], dtype=torch.int32, device=d)
+    host = torch.zeros(3, dtype=torch.int32).pin_memory()
+    ops.step_inputs(list(zip(dsts, srcs)), [(s0, 0.375), (s1, 2.5e-4)], words=words, words_host=host)
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(dsts, srcs))
+    assert float(s0) == 0.375 and float(s1) == float(torch.tensor(2.5e-4)) and host.tolist() == [1, 0, 7]
+    many = [(torch.zeros(33, device=d), torch.randn(33, device=d)) for _ in range(30)]           # more than one launch's table
+    ops.step_inputs(many)
+    assert all(torch.equal(a, b) for a, b in many)

@@ -30,11 +30,12 @@ SYMBOLS = (
     "tp_rmsprop_step",
     "tp_conv4s2_workspace", "tp_conv4s2_fwd", "tp_conv4s2_dgrad", "tp_conv4s2_wgrad",
     "tp_conv3s1_workspace", "tp_conv3s1_fwd", "tp_conv3s1_dgrad",
-    "tp_patch_coords", "tp_bce_logits_fwd", "tp_bce_logits_bwd", "tp_feat_inputs_fwd", "tp_feat_inputs_bwd", "tp_disc_inputs", "tp_step_flags", "tp_adam_step",
+    "tp_patch_coords", "tp_bce_logits_fwd", "tp_bce_logits_bwd", "tp_feat_inputs_fwd", "tp_feat_inputs_bwd", "tp_disc_inputs", "tp_step_flags", "tp_adam_step", "tp_step_inputs",
     "tp_fake_patch_bwd", "tp_feat_pair_loss_fwd", "tp_feat_pair_loss_bwd", "tp_sumsq_mean_fwd", "tp_sumsq_mean_bwd", "tp_sumsq_mean_fwd_bwd", "tp_gan_disc_losses", "tp_maxpool2_fwd", "tp_maxpool2_bwd", "tp_latent_rows_fwd",
     "tp_latent_rows_bwd", "tp_weighted_sum", "tp_weighted_sum_flags",
     "tp_disc_head_fwd", "tp_disc_head_bwd", "tp_disc_head_bwd_bwd",
     "tp_skinny_linear_fwd", "tp_skinny_linear_wgrad", "tp_skinny_linear_dgrad",
+    "tp_disc_tail_workspace_bytes", "tp_disc_tail_fwd", "tp_disc_tail_bwd", "tp_disc_tail_bwd_bwd",
 )
 
 vp = C.c_void_p
@@ -125,6 +126,15 @@ class DiscHeadArgs(C.Structure):
                                                  ("accumulate_gw", C.c_int32)]
 
 
+DISC_TAIL_MAX_ROWS = 16
+
+
+class DiscTailArgs(C.Structure):
+    _fields_ = [(k, vp) for k in ("a", "W0", "scale", "W1", "W2", "W3", "g_out", "t0", "t1", "t2", "e1", "e2", "out", "gz", "c_a", "gW0",
+                                  "gy2", "a2", "gW1", "gW2", "gW3", "workspace", "ticket")] + \
+               [(k, C.c_int32) for k in ("M", "M2", "K", "N", "L", "H")] + [("slope", C.c_float), ("accumulate_gw", C.c_int32)]
+
+
 class FeatInputsArgs(C.Structure):
     _fields_ = [("rgb", vp), ("gathered", vp), ("B", C.c_int32), ("P", C.c_int32), ("n_channels", C.c_int32),
                 ("c_image", C.c_int32), ("c_image_syn", C.c_int32), ("c_mask", C.c_int32), ("c_mask_syn", C.c_int32),
@@ -147,6 +157,11 @@ class NerfLossesArgs(C.Structure):
 
 
 NERF_LOSSES_MAX_BLOCKS = 1024
+STEP_INPUTS_MAX_COPIES, STEP_INPUTS_MAX_SCALARS = 24, 8
+
+
+class StepCopy(C.Structure):
+    _fields_ = [("dst", vp), ("src", vp), ("bytes", C.c_int64)]
 
 
 class RenderEvalArgs(C.Structure):
@@ -214,6 +229,7 @@ def load() -> C.CDLL:
     sig("tp_inorm_lrelu_bwd_bwd", [vp, vp, vp, vp, C.c_int64, C.c_int, C.c_float, vp, vp, vp])
     sig("tp_rmsprop_step", [C.POINTER(RmspropTensor), C.c_int, vp, C.c_double, C.c_double, C.c_double, vp, C.c_int, vp])
     sig("tp_step_flags", [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp])
+    sig("tp_step_inputs", [C.POINTER(StepCopy), C.c_int, C.POINTER(vp), C.POINTER(C.c_float), C.c_int, vp, vp, C.c_int, vp])
     sig("tp_adam_step", [C.POINTER(AdamTensor), C.c_int, vp, C.c_double, C.c_double, C.c_double, C.c_double, vp, C.c_int, vp, vp])
     sig("tp_conv4s2_workspace", [C.POINTER(Conv4s2Args), C.c_int, C.POINTER(C.c_int64)], C.c_int64)
     for name in ("tp_conv4s2_fwd", "tp_conv4s2_dgrad", "tp_conv4s2_wgrad"):
@@ -244,6 +260,9 @@ def load() -> C.CDLL:
         sig(name, [C.POINTER(DiscHeadArgs), vp])
     for name in ("tp_skinny_linear_fwd", "tp_skinny_linear_wgrad", "tp_skinny_linear_dgrad"):
         sig(name, [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp])
+    sig("tp_disc_tail_workspace_bytes", [C.c_int], C.c_size_t)
+    for name in ("tp_disc_tail_fwd", "tp_disc_tail_bwd", "tp_disc_tail_bwd_bwd"):
+        sig(name, [C.POINTER(DiscTailArgs), vp])
     _lib = lib
     return lib
 

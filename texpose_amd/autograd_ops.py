@@ -350,6 +350,32 @@ def disc_head(z, scale, W1, W2, W3, L: int, slope: float = 0.2):
     return _DiscHead.apply(z.contiguous(), scale.contiguous(), W1.contiguous(), W2.contiguous(), W3.contiguous(), int(L), float(slope))
 
 
+# ---- K17: full-map convolution + head as one launch each way (frozen discriminator of the nerf step: data gradient only)
+class _DiscTail(torch.autograd.Function):
+    """out [B] of the PatchGAN's tail for FROZEN weights: forward tp_disc_tail_fwd, backward tp_disc_tail_bwd (c_a only).  First
+    order in the input; anything else (weight gradients through autograd, the R1 double backward) takes the K15 + K14 nodes."""
+
+    @staticmethod
+    def forward(ctx, a, W0, scale, W1, W2, W3, L, slope):
+        out, t0, t1, t2 = ops.disc_tail_fwd(a, W0, scale, W1, W2, W3, L, slope)
+        ctx.save_for_backward(t0, t1, t2, W0, W1, W2, W3)
+        ctx.consts = (L, slope)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_out):
+        t0, t1, t2, W0, W1, W2, W3 = ctx.saved_tensors
+        r = ops.disc_tail_bwd(g_out.contiguous(), t0, t1, t2, W0, W1, W2, W3, *ctx.consts, want_gW0=False, head_weight_grads=False)
+        return r["c_a"], None, None, None, None, None, None, None
+
+
+def disc_tail(a, W0, scale, W1, W2, W3, L: int, slope: float = 0.2):
+    """a [B,K] (the ladder's last activation, flattened) -> logits [B]; weights are constants (see _DiscTail)."""
+    return _DiscTail.apply(a.contiguous(), W0.contiguous(), scale.contiguous(), W1.contiguous(), W2.contiguous(), W3.contiguous(),
+                           int(L), float(slope))
+
+
 # ---- K15: y = x W^T for a handful of rows (the PatchGAN's full-map convolution), closed under differentiation like K11
 class _SkinnyLinear(torch.autograd.Function):
     @staticmethod

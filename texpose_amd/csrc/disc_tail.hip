@@ -1,0 +1,378 @@
+// K17: the TAIL of the PatchGAN -- the full-map convolution that ends the ladder (K15: a [M, K] x [K, N] product, K = 8192, N = 64,
+// a handful of rows) AND the scale-conditioned head (K14) -- as ONE launch per derivative order.
+// reference layers/discriminator.py:30-40,110-115: z = conv(a, W0) over the whole 4x4 map;  t0 = lrelu([z, enc(s), s]);
+// t1 = lrelu(W1 t0);  t2 = lrelu(W2 t1);  out = W3 t2.
+//
+// Why: in the replayed B=4 iteration the tail was 2 launches forward (skinny_fwd 11-14 us on 64 workgroups + head_fwd 15-20 us on
+// ONE workgroup), 3 backward (head_bwd 9-40 us on one workgroup -- its weight-gradient loops re-read their operands from global
+// memory --, a rocBLAS data gradient, skinny_wgrad) and 2 in the R1 double backward (skinny_fwd + head_bwd_bwd 30 us): 131 us of
+// single-workgroup head kernels and 16 launches on the discriminator step's serial chain (profiles/r4).
+//   F  (tp_disc_tail_fwd):  the K range of z is split over S workgroups per column; the LAST workgroup to arrive (one ticket,
+//       the gfx950 hand-over of patch_conv.hip reduce_tiles) adds the partial sums in slice order and runs the head on the
+//       weights every workgroup prefetched into LDS while its products were in flight.
+//       MODE_R1 (tp_disc_tail_bwd_bwd): the same launch shape for the R1 penalty's second pass: z = c W0^T is the cotangent of the
+//       first pass' gz, the last workgroup runs the head's double backward (formulas: csrc/disc_head.hip).
+//   B  (tp_disc_tail_bwd):  every workgroup owns 64 columns of K, recomputes the head's backward (a few 10^4 MACs on weights in
+//       LDS) and produces its slice of BOTH the data gradient c_a = gz W0 and the weight gradient gW0 = sum_rows gz (x) a; rows of
+//       a second (cotangent, input) pair -- the R1 path's, texpose_amd/disc_step.py -- join the same sum.  Workgroup 0 also writes
+//       gz / e1 / e2 and the head's weight gradients, from LDS.
+// Plain fp32 FMAs, fixed summation orders, no float atomics.
+#include "tp_common.h"
+
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "the last-workgroup hand-over below relies on the gfx950 sc1 write-through contract (csrc/patch_conv.hip reduce_tiles)"
+#endif
+
+namespace {
+constexpr int kT = 256;
+constexpr int kMaxM = TP_DISC_TAIL_MAX_ROWS;       // rows of one pass
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+struct TailP {
+  // ladder side
+  const float* a;        // F: [M,K] ladder output (MODE_R1: the cotangent c [M,K]);  B: [M,K] ladder output (weight gradient), may be NULL
+  const float* W0;       // [N,K]
+  // head
+  const float* scale;    // [M]        F
+  const float* W1; const float* W2; const float* W3;   // [H,Cin], [H,H], [H]
+  const float* g;        // [M]        B, R1: cotangent of out
+  float* t0; float* t1; float* t2;     // [M,Cin], [M,H], [M,H]   F: written;  B, R1: read
+  float* e1; float* e2;                // [M,H]                   B: written (optional);  R1: read
+  float* out;            // F: out [M];  R1: d/d g [M] (optional)
+  float* gz;             // B: [M,N] (optional)
+  float* c_a;            // B: [M,K] data gradient (optional)
+  float* gW0;            // B: [N,K] (optional)
+  const float* gy2;      // B: [M2,N] extra cotangent rows of the weight gradient (optional)
+  const float* a2;       // B: [M2,K] their inputs
+  float* gW1; float* gW2; float* gW3;  // B, R1: head weight gradients (optional in B)
+  float* ws;             // F, R1: partial sums [N][S][M]
+  unsigned* ticket;      // F, R1: one zero word
+  int M, M2, K, N, C, L, H, Cin, S;
+  float slope;
+  int accumulate;        // B: gW1..3 += (the R1 pass wrote its share there first)
+};
+
+__device__ __forceinline__ float lrelu(float v, float s) { return v > 0.f ? v : v * s; }
+__device__ __forceinline__ float dl(float t, float s) { return t > 0.f ? 1.f : s; }
+
+extern __shared__ float smem[];
+
+// W1 | W2 | W3 into LDS (37 KB at ndf = 64; L2 hits for all but the first workgroup)
+__device__ __forceinline__ void stage_head_weights(const TailP& p, float* w1, float* w2, float* w3) {
+  const int n1 = p.H * p.Cin, n2 = p.H * p.H;
+  for (int i = threadIdx.x; i < n1; i += kT) w1[i] = p.W1[i];
+  for (int i = threadIdx.x; i < n2; i += kT) w2[i] = p.W2[i];
+  for (int i = threadIdx.x; i < p.H; i += kT) w3[i] = p.W3[i];
+}
+
+// ---------------------------------------------------------------------------------------------------------------- F / R1
+template <bool R1>
+__global__ __launch_bounds__(kT) void disc_tail_fwd_kernel(TailP p) {
+  float* w1 = smem; float* w2 = w1 + p.H * p.Cin; float* w3 = w2 + p.H * p.H;
+  float* a0 = w3 + p.H; float* a1 = a0 + kMaxM * p.Cin; float* a2 = a1 + kMaxM * p.H;
+  float* red = a2 + kMaxM * p.H;                   // [kMaxM][kT]
+  __shared__ int last;
+  const int t = threadIdx.x, n = blockIdx.x / p.S, s = blockIdx.x % p.S, M = p.M;
+  // ---- this workgroup's slice of z[:, n]: k in [k0, k1), 16-byte loads, all rows' operands in flight together
+  const int per = ((p.K / 4 + p.S - 1) / p.S) * 4, k0 = min(p.K, s * per), k1 = min(p.K, k0 + per);
+  const float* wr = p.W0 + (size_t)n * p.K;
+  float acc[kMaxM];
+#pragma unroll
+  for (int r = 0; r < kMaxM; ++r) acc[r] = 0.f;
+#pragma unroll 2
+  for (int k = k0 + 4 * t; k + 3 < k1; k += 4 * kT) {
+    const f32x4 wv = *reinterpret_cast<const f32x4*>(wr + k);
+#pragma unroll
+    for (int r = 0; r < kMaxM; ++r)
+      if (r < M) {
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(p.a + (size_t)r * p.K + k);
+        acc[r] = fmaf(xv[3], wv[3], fmaf(xv[2], wv[2], fmaf(xv[1], wv[1], fmaf(xv[0], wv[0], acc[r]))));
+      }
+  }
+  stage_head_weights(p, w1, w2, w3);               // (every workgroup: whichever arrives last has them; 37 KB of L2 hits)
+#pragma unroll
+  for (int r = 0; r < kMaxM; ++r)
+    if (r < M) red[r * kT + t] = acc[r];
+  __syncthreads();
+  for (int st = kT >> 1; st > 0; st >>= 1) {
+    if (t < st)
+#pragma unroll
+      for (int r = 0; r < kMaxM; ++r)
+        if (r < M) red[r * kT + t] += red[r * kT + t + st];
+    __syncthreads();
+  }
+  // ---- hand-over (patch_conv.hip reduce_tiles: sc1 stores, the storing wave drained, ONE agent-scope add behind the barrier)
+  if (t < M) __hip_atomic_store(p.ws + ((size_t)n * p.S + s) * kMaxM + t, red[t * kT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (t == 0) last = __hip_atomic_fetch_add(p.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+  __syncthreads();
+  if (!last) return;
+  if (t == 0) __hip_atomic_store(p.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // ready for the next launch
+  // z[m][nn] = sum of the S slices in slice order
+  for (int e = t; e < M * p.N; e += kT) {
+    const int m = e / p.N, nn = e - m * p.N;
+    float z = 0.f;
+    for (int ss = 0; ss < p.S; ++ss)
+      z += __hip_atomic_load(p.ws + ((size_t)nn * p.S + ss) * kMaxM + m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!R1) {
+      a0[m * p.Cin + nn] = z;                      // (activated below)
+    } else {
+      a0[m * p.Cin + nn] = dl(p.t0[(size_t)m * p.Cin + nn], p.slope) * z;        // a0 = d(t0) [c, 0]
+    }
+  }
+  if (R1)
+    for (int e = t; e < M * (p.Cin - p.N); e += kT) a0[(e / (p.Cin - p.N)) * p.Cin + p.N + e % (p.Cin - p.N)] = 0.f;
+  if (!R1) {
+    for (int e = t; e < M * (p.Cin - p.N); e += kT) {
+      const int m = e / (p.Cin - p.N), j = p.N + e % (p.Cin - p.N);
+      const float sc = p.scale[m];
+      float v;
+      if (j < p.C + 2 * p.L) {
+        const int l = (j - p.C) % p.L;
+        const float arg = tp::mul_rn(sc, tp::mul_rn((float)(1 << l), 3.14159265358979323846f));     // s * (2^l pi rounded to fp32)
+        v = tp::sincos_sel(arg, j - p.C >= p.L ? 1 : 0);
+      } else v = sc;
+      a0[m * p.Cin + j] = v;
+    }
+    __syncthreads();
+    for (int e = t; e < M * p.Cin; e += kT) {
+      const float v = lrelu(a0[e], p.slope);
+      a0[e] = v;
+      p.t0[e] = v;
+    }
+  }
+  __syncthreads();
+  const int kin = R1 ? p.C : p.Cin;                // (R1: the encoding / scale entries of a0 are zero)
+  for (int e = t; e < M * p.H; e += kT) {
+    const int m = e / p.H, o = e - m * p.H;
+    float v = 0.f;
+    for (int j = 0; j < kin; ++j) v += w1[o * p.Cin + j] * a0[m * p.Cin + j];
+    if (!R1) { v = lrelu(v, p.slope); p.t1[e] = v; }
+    else v *= dl(p.t1[e], p.slope);
+    a1[e] = v;
+  }
+  __syncthreads();
+  for (int e = t; e < M * p.H; e += kT) {
+    const int m = e / p.H, o = e - m * p.H;
+    float v = 0.f;
+    for (int j = 0; j < p.H; ++j) v += w2[o * p.H + j] * a1[m * p.H + j];
+    if (!R1) { v = lrelu(v, p.slope); p.t2[e] = v; }
+    else v *= dl(p.t2[e], p.slope);
+    a2[e] = v;
+  }
+  __syncthreads();
+  if (t < M && p.out != nullptr) {
+    float v = 0.f;
+    for (int j = 0; j < p.H; ++j) v += w3[j] * a2[t * p.H + j];
+    p.out[t] = v;
+  }
+  if (!R1) return;
+  // ---- R1: weight gradients of the double backward, rows in ascending order: d/dW3 = sum g a2, d/dW2 = sum e2 (x) a1, d/dW1 = sum e1 (x) a0
+  float* e1s = red; float* e2s = red + kMaxM * p.H;                 // the first pass' intermediates, staged once
+  for (int e = t; e < M * p.H; e += kT) { e1s[e] = p.e1[e]; e2s[e] = p.e2[e]; }
+  __syncthreads();
+  for (int j = t; j < p.H; j += kT) {
+    float v = 0.f;
+    for (int m = 0; m < M; ++m) v += p.g[m] * a2[m * p.H + j];
+    p.gW3[j] = v;
+  }
+  for (int e = t; e < p.H * p.H; e += kT) {
+    const int i = e / p.H, j = e - i * p.H;
+    float v = 0.f;
+    for (int m = 0; m < M; ++m) v += e2s[m * p.H + i] * a1[m * p.H + j];
+    p.gW2[e] = v;
+  }
+  for (int e = t; e < p.H * p.Cin; e += kT) {
+    const int i = e / p.Cin, j = e - i * p.Cin;
+    float v = 0.f;
+    for (int m = 0; m < M; ++m) v += e1s[m * p.H + i] * a0[m * p.Cin + j];
+    p.gW1[e] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------- B
+__global__ __launch_bounds__(kT) void disc_tail_bwd_kernel(TailP p) {
+  float* w1 = smem; float* w2 = w1 + p.H * p.Cin; float* w3 = w2 + p.H * p.H;
+  float* s2 = w3 + p.H; float* s1 = s2 + kMaxM * p.H; float* gzs = s1 + kMaxM * p.H;      // e2, e1 [M,H]; gz rows [M + M2][N]
+  float* t0s = gzs + 2 * kMaxM * p.N;              // workgroup 0: t0 / t1 / t2 for the head's weight gradients
+  const int t = threadIdx.x, M = p.M, M2 = p.M2;
+  stage_head_weights(p, w1, w2, w3);
+  __syncthreads();
+  // ---- the head's backward (recomputed by every workgroup: ~M (H + H H + H C) MACs)
+  for (int e = t; e < M * p.H; e += kT) {
+    const int m = e / p.H, o = e - m * p.H;
+    s2[e] = dl(p.t2[e], p.slope) * (w3[o] * p.g[m]);
+  }
+  __syncthreads();
+  for (int e = t; e < M * p.H; e += kT) {
+    const int m = e / p.H, j = e - m * p.H;
+    float v = 0.f;
+    for (int o = 0; o < p.H; ++o) v += w2[o * p.H + j] * s2[m * p.H + o];
+    s1[e] = v * dl(p.t1[e], p.slope);
+  }
+  __syncthreads();
+  for (int e = t; e < M * p.N; e += kT) {          // only the z part of e0 is anybody's gradient (N == C)
+    const int m = e / p.N, j = e - m * p.N;
+    float v = 0.f;
+    for (int o = 0; o < p.H; ++o) v += w1[o * p.Cin + j] * s1[m * p.H + o];
+    gzs[e] = v * dl(p.t0[(size_t)m * p.Cin + j], p.slope);
+  }
+  for (int e = t; e < M2 * p.N; e += kT) gzs[M * p.N + e] = p.gy2[e];
+  __syncthreads();
+  // ---- this workgroup's 64 columns of K: thread (kc, run) -- data gradient: run = quarter of the N rows of W0; weight gradient:
+  // run = quarter of the N rows of gW0
+  const int kc = t & 63, k = blockIdx.x * 64 + kc;
+  const int run = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int per = (p.N + 3) / 4, n0 = run * per, n1 = min(p.N, n0 + per);
+  if (p.c_a != nullptr) {
+    float acc[kMaxM];
+#pragma unroll
+    for (int m = 0; m < kMaxM; ++m) acc[m] = 0.f;
+    if (k < p.K) {
+      const float* wc = p.W0 + k;
+#pragma unroll 16
+      for (int n = n0; n < n1; ++n) {
+        const float wv = wc[(size_t)n * p.K];
+#pragma unroll
+        for (int m = 0; m < kMaxM; ++m)
+          if (m < M) acc[m] = fmaf(gzs[m * p.N + n], wv, acc[m]);
+      }
+    }
+    float* part = t0s + kMaxM * (p.Cin + 2 * p.H);                  // [4][kMaxM][64]
+#pragma unroll
+    for (int m = 0; m < kMaxM; ++m)
+      if (m < M) part[(run * kMaxM + m) * 64 + kc] = acc[m];
+    __syncthreads();
+    for (int e = t; e < M * 64; e += kT) {
+      const int m = e >> 6, c = e & 63, kk = blockIdx.x * 64 + c;
+      if (kk < p.K)
+        p.c_a[(size_t)m * p.K + kk] = ((part[(0 * kMaxM + m) * 64 + c] + part[(1 * kMaxM + m) * 64 + c]) + part[(2 * kMaxM + m) * 64 + c]) +
+                                      part[(3 * kMaxM + m) * 64 + c];
+    }
+  }
+  if (p.gW0 != nullptr && k < p.K) {
+    float xa[kMaxM], xb[kMaxM];
+#pragma unroll
+    for (int m = 0; m < kMaxM; ++m) {
+      xa[m] = m < M ? p.a[(size_t)m * p.K + k] : 0.f;
+      xb[m] = m < M2 ? p.a2[(size_t)m * p.K + k] : 0.f;
+    }
+    for (int n = n0; n < n1; ++n) {
+      float v = 0.f;
+#pragma unroll
+      for (int m = 0; m < kMaxM; ++m)
+        if (m < M) v = fmaf(gzs[m * p.N + n], xa[m], v);
+#pragma unroll
+      for (int m = 0; m < kMaxM; ++m)
+        if (m < M2) v = fmaf(gzs[(M + m) * p.N + n], xb[m], v);
+      p.gW0[(size_t)n * p.K + k] = v;
+    }
+  }
+  if (blockIdx.x != 0) return;
+  // ---- workgroup 0: what the caller keeps of the head's backward, and the head's weight gradients
+  for (int e = t; e < M * p.H; e += kT) {
+    if (p.e1 != nullptr) p.e1[e] = s1[e];
+    if (p.e2 != nullptr) p.e2[e] = s2[e];
+  }
+  if (p.gz != nullptr)
+    for (int e = t; e < M * p.N; e += kT) p.gz[e] = gzs[e];
+  if (p.gW1 == nullptr) return;
+  float* t1s = t0s + kMaxM * p.Cin; float* t2s = t1s + kMaxM * p.H;
+  for (int e = t; e < M * p.Cin; e += kT) t0s[e] = p.t0[e];
+  for (int e = t; e < M * p.H; e += kT) { t1s[e] = p.t1[e]; t2s[e] = p.t2[e]; }
+  __syncthreads();
+  const bool add = p.accumulate != 0;
+  for (int j = t; j < p.H; j += kT) {
+    float v = 0.f;
+    for (int m = 0; m < M; ++m) v += p.g[m] * t2s[m * p.H + j];
+    p.gW3[j] = add ? p.gW3[j] + v : v;
+  }
+  for (int e = t; e < p.H * p.H; e += kT) {
+    const int i = e / p.H, j = e - i * p.H;
+    float v = 0.f;
+    for (int m = 0; m < M; ++m) v += s2[m * p.H + i] * t1s[m * p.H + j];
+    p.gW2[e] = add ? p.gW2[e] + v : v;
+  }
+  for (int e = t; e < p.H * p.Cin; e += kT) {
+    const int i = e / p.Cin, j = e - i * p.Cin;
+    float v = 0.f;
+    for (int m = 0; m < M; ++m) v += s1[m * p.H + i] * t0s[m * p.Cin + j];
+    p.gW1[e] = add ? p.gW1[e] + v : v;
+  }
+}
+
+size_t lds_fwd(const TailP& p) {
+  return sizeof(float) * ((size_t)p.H * p.Cin + (size_t)p.H * p.H + p.H + (size_t)kMaxM * (p.Cin + 2 * p.H) + (size_t)kMaxM * kT);
+}
+size_t lds_bwd(const TailP& p) {
+  return sizeof(float) * ((size_t)p.H * p.Cin + (size_t)p.H * p.H + p.H + (size_t)kMaxM * 2 * p.H + (size_t)2 * kMaxM * p.N +
+                          (size_t)kMaxM * (p.Cin + 2 * p.H) + (size_t)4 * kMaxM * 64);
+}
+
+int fill(TailP* q, const tp_disc_tail_args* a, const char* what) {
+  if (!a || a->M <= 0 || a->M > kMaxM || a->M2 < 0 || a->M2 > kMaxM || a->K <= 0 || a->K % 4 != 0 || a->N <= 0 || a->L < 0 || a->L > 24 || a->H <= 0) {
+    tp::set_error("%s: bad sizes (at most %d rows, K a multiple of 4)", what, kMaxM);
+    return -1;
+  }
+  q->M = a->M; q->M2 = a->M2; q->K = a->K; q->N = a->N; q->C = a->N; q->L = a->L; q->H = a->H; q->Cin = a->N + 2 * a->L + 1; q->slope = a->slope;
+  q->a = a->a; q->W0 = a->W0; q->scale = a->scale; q->W1 = a->W1; q->W2 = a->W2; q->W3 = a->W3; q->g = a->g_out;
+  q->t0 = a->t0; q->t1 = a->t1; q->t2 = a->t2; q->e1 = a->e1; q->e2 = a->e2; q->out = a->out; q->gz = a->gz; q->c_a = a->c_a;
+  q->gW0 = a->gW0; q->gy2 = a->gy2; q->a2 = a->a2; q->gW1 = a->gW1; q->gW2 = a->gW2; q->gW3 = a->gW3;
+  q->ws = (float*)a->workspace; q->ticket = a->ticket; q->accumulate = a->accumulate_gw;
+  if (!q->W0 || !q->W1 || !q->W2 || !q->W3 || !q->t0 || !q->t1 || !q->t2) { tp::set_error("%s: null pointer", what); return -1; }
+  if ((size_t)kMaxM * 2 * q->H > (size_t)kMaxM * kT) { tp::set_error("%s: head too wide", what); return -1; }
+  return 0;
+}
+
+template <class K>
+int launch(K kernel, const TailP& q, int grid, size_t lds, tp_stream_t stream, const char* what, unsigned long long& flags) {
+  if (lds > 150 * 1024) { tp::set_error("%s: head too wide for one workgroup's LDS", what); return -1; }
+  if (lds > 48 * 1024 && tp::first_use_on_device(flags) &&
+      hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) {
+    tp::set_error("%s: cannot raise the LDS limit", what);
+    return -1;
+  }
+  hipLaunchKernelGGL(kernel, dim3(grid), dim3(kT), lds, (hipStream_t)stream, q);
+  return tp::check_launch(what);
+}
+
+int splits_for(const TailP& q) {
+  int S = 256 / q.N;                                // ~256 workgroups
+  if (S < 1) S = 1;
+  if (S > 64) S = 64;
+  while (S > 1 && q.K / S < 4 * kT) S >>= 1;        // at least one 16-byte load per thread and slice
+  return S;
+}
+}  // namespace
+
+extern "C" {
+size_t tp_disc_tail_workspace_bytes(int N) { return (size_t)N * 64 * kMaxM * sizeof(float); }     // [N][S <= 64][kMaxM]
+
+int tp_disc_tail_fwd(const tp_disc_tail_args* a, tp_stream_t stream) {
+  static unsigned long long flags = 0;
+  TailP q{};
+  if (int rc = fill(&q, a, "tp_disc_tail_fwd")) return rc;
+  TP_REQUIRE(q.a && q.scale && q.out && q.ws && q.ticket, "operand missing");
+  q.S = splits_for(q);
+  return launch(disc_tail_fwd_kernel<false>, q, q.N * q.S, lds_fwd(q), stream, "tp_disc_tail_fwd", flags);
+}
+int tp_disc_tail_bwd_bwd(const tp_disc_tail_args* a, tp_stream_t stream) {
+  static unsigned long long flags = 0;
+  TailP q{};
+  if (int rc = fill(&q, a, "tp_disc_tail_bwd_bwd")) return rc;
+  TP_REQUIRE(q.a && q.g && q.e1 && q.e2 && q.gW1 && q.gW2 && q.gW3 && q.ws && q.ticket, "operand missing");
+  q.S = splits_for(q);
+  return launch(disc_tail_fwd_kernel<true>, q, q.N * q.S, lds_fwd(q), stream, "tp_disc_tail_bwd_bwd", flags);
+}
+int tp_disc_tail_bwd(const tp_disc_tail_args* a, tp_stream_t stream) {
+  static unsigned long long flags = 0;
+  TailP q{};
+  if (int rc = fill(&q, a, "tp_disc_tail_bwd")) return rc;
+  TP_REQUIRE(q.g != nullptr, "g_out missing");
+  TP_REQUIRE((q.gW1 && q.gW2 && q.gW3) || (!q.gW1 && !q.gW2 && !q.gW3), "gW1..3: all or none");
+  TP_REQUIRE(q.gW0 == nullptr || q.a != nullptr, "gW0 needs the ladder output a");
+  TP_REQUIRE(q.M2 == 0 || (q.gy2 && q.a2 && q.gW0), "the extra rows belong to the weight gradient gW0");
+  return launch(disc_tail_bwd_kernel, q, (q.K + 63) / 64, lds_bwd(q), stream, "tp_disc_tail_bwd", flags);
+}
+}

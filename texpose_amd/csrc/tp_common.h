@@ -82,6 +82,48 @@ __device__ __forceinline__ void sincos_both(float a, float& s, float& c) {
   c = ((o.q + 1) & 2) ? -vc : vc;
 }
 
+// ---- sin / cos of a * 2^l for l = 0 .. L-1 from ONE range reduction (the positional encoding of the f16x3 forward).
+// The reference encodes fl32(x * fl32(2^l * pi_f32)) (layers/nerf_static_transient_light.py:217-234: `x[..., None] * freq`), and a
+// power of two scales exactly: that argument IS 2^l * a with a = fl32(x * pi_f32).  So a is reduced once in fp64 (a = k pi/2 + r,
+// |r| <= pi/4, two-term pi/2), sin r / cos r come from the fdlibm double-precision kernels (error < 2^-57), the quadrant is
+// applied, and every further octave is an angle doubling in fp64 -- z -> z^2 on the unit circle doubles the absolute error per
+// step, 2^9 * 2e-16 = 1e-13 after nine doublings, where ten independent reductions of a_l each carry |a_l| * 2^-53 ~ 1e-12 in r.
+// The fp32 roundings of the results are within 1 ulp of the correctly rounded sin / cos of the reference's fp32 argument whenever
+// |value| > 2e-6 (absolute error 1e-13 below that).  ~3.5x fewer instructions than per-octave reductions (DESIGN section 4, K2').
+struct SinCos64 { double s, c; };
+__device__ __forceinline__ SinCos64 sincos_f64(float a) {
+  const double ad = (double)a;
+  const double kd = rint(ad * 0.63661977236758138);
+  double r = __fma_rn(-kd, 1.5707963267948966, ad);
+  r = __fma_rn(-kd, 6.123233995736766e-17, r);
+  const double z = r * r;
+  // fdlibm k_sin.c / k_cos.c minimax coefficients on [-pi/4, pi/4]
+  double ps = __fma_rn(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+  ps = __fma_rn(z, ps, 2.75573137070700676789e-06);
+  ps = __fma_rn(z, ps, -1.98412698298579493134e-04);
+  ps = __fma_rn(z, ps, 8.33333333332248946124e-03);
+  ps = __fma_rn(z, ps, -1.66666666666666324348e-01);
+  const double sr = __fma_rn(r * z, ps, r);
+  double pc = __fma_rn(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+  pc = __fma_rn(z, pc, -2.75573143513906633035e-07);
+  pc = __fma_rn(z, pc, 2.48015872894767294178e-05);
+  pc = __fma_rn(z, pc, -1.38888888888741095749e-03);
+  pc = __fma_rn(z, pc, 4.16666666666666019037e-02);
+  const double cr = __fma_rn(z * z, pc, __fma_rn(-0.5, z, 1.0));
+  const int q = (int)kd;                 // only the two low bits matter (|a| < 2^30 for any encodable coordinate)
+  SinCos64 o;
+  const double v_s = (q & 1) ? cr : sr, v_c = (q & 1) ? sr : cr;
+  o.s = (q & 2) ? -v_s : v_s;
+  o.c = ((q + 1) & 2) ? -v_c : v_c;
+  return o;
+}
+__device__ __forceinline__ void sincos_double(SinCos64& v) {
+  const double t = v.s + v.s;
+  const double s2 = t * v.c;
+  v.c = __fma_rn(-t, v.s, 1.0);
+  v.s = s2;
+}
+
 // Philox4x32-10 (Salmon et al., SC'11); the stream layouts of its users are documented in oracle.philox_uniform (ray-gen jitter)
 // and at tp_patch_coords (patch draws).
 __device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) {

@@ -132,6 +132,41 @@ __global__ __launch_bounds__(kBlock) void disc_inputs_kernel(const float* __rest
     }
 }
 
+// ---- the per-iteration host -> device state of a replayed training step in ONE launch: the batch into the static input tensors
+// (up to TP_STEP_INPUTS_MAX_COPIES contiguous copies, 16-byte lanes; torch: one multi-tensor copy per dtype), the host-computed
+// scalars (annealed patch-scale bound, discriminator progress; torch: one fill each) and the sticky gate words out to pinned
+// host memory (torch: a copyBuffer).  Five launches between two replays become one.
+struct StepInputs {
+  char* dst[TP_STEP_INPUTS_MAX_COPIES];
+  const char* src[TP_STEP_INPUTS_MAX_COPIES];
+  int64_t end16[TP_STEP_INPUTS_MAX_COPIES];       // running end of the copies in 16-byte units (every size is padded up to 16)
+  int64_t bytes[TP_STEP_INPUTS_MAX_COPIES];
+  int n;
+  float* sdst[TP_STEP_INPUTS_MAX_SCALARS];
+  float sval[TP_STEP_INPUTS_MAX_SCALARS];
+  int n_scalars;
+  const int* words_src;
+  int* words_dst;                                 // pinned host memory (device-visible), or NULL
+  int n_words;
+};
+__global__ __launch_bounds__(kBlock) void step_inputs_kernel(StepInputs t, int64_t total16) {
+  if (blockIdx.x == 0) {
+    if ((int)threadIdx.x < t.n_scalars) t.sdst[threadIdx.x][0] = t.sval[threadIdx.x];
+    if (t.words_dst != nullptr && (int)threadIdx.x >= 64 && (int)threadIdx.x < 64 + t.n_words)
+      __hip_atomic_store(t.words_dst + (threadIdx.x - 64), t.words_src[threadIdx.x - 64], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  int k = 0;
+  for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < total16; e += (int64_t)gridDim.x * kBlock) {
+    while (e >= t.end16[k]) ++k;
+    const int64_t off = (e - (k == 0 ? 0 : t.end16[k - 1])) * 16;
+    if (off + 16 <= t.bytes[k]) {
+      *reinterpret_cast<uint4*>(t.dst[k] + off) = *reinterpret_cast<const uint4*>(t.src[k] + off);
+    } else {
+      for (int64_t b = off; b < t.bytes[k]; ++b) t.dst[k][b] = t.src[k][b];
+    }
+  }
+}
+
 // ---- step gate: fold this step's range flag / loss finiteness into the sticky words, then snapshot them for the optimiser
 __global__ void step_flags_kernel(const int* status, const float* total, int* bad, int n_bad, int word_status, int word_finite, int* snapshot) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -398,6 +433,31 @@ int tp_step_flags(const int32_t* mlp_status, const float* total, int32_t* bad, i
              "bad arguments");
   hipLaunchKernelGGL(step_flags_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, mlp_status, total, bad, n_bad, word_status, word_finite, snapshot);
   return tp::check_launch("tp_step_flags");
+}
+
+int tp_step_inputs(const tp_step_copy* copies, int n_copies, float* const* scalar_dst, const float* scalar_val, int n_scalars,
+                   const int32_t* words_src, int32_t* words_dst, int n_words, tp_stream_t stream) {
+  TP_REQUIRE(n_copies >= 0 && n_copies <= TP_STEP_INPUTS_MAX_COPIES && n_scalars >= 0 && n_scalars <= TP_STEP_INPUTS_MAX_SCALARS, "too many entries");
+  TP_REQUIRE(n_words >= 0 && n_words <= 64 && (n_words == 0 || words_dst == nullptr || words_src != nullptr), "bad gate-word arguments");
+  StepInputs t{};
+  int64_t total16 = 0;
+  for (int k = 0; k < n_copies; ++k) {
+    TP_REQUIRE(copies[k].dst && copies[k].src && copies[k].bytes > 0, "null copy");
+    TP_REQUIRE(((uintptr_t)copies[k].dst & 15) == 0 && ((uintptr_t)copies[k].src & 15) == 0, "copies must be 16-byte aligned");
+    t.dst[k] = (char*)copies[k].dst; t.src[k] = (const char*)copies[k].src; t.bytes[k] = copies[k].bytes;
+    total16 += (copies[k].bytes + 15) / 16;
+    t.end16[k] = total16;
+  }
+  for (int k = n_copies; k < TP_STEP_INPUTS_MAX_COPIES; ++k) t.end16[k] = total16;
+  t.n = n_copies;
+  for (int k = 0; k < n_scalars; ++k) { TP_REQUIRE(scalar_dst[k] != nullptr, "null scalar"); t.sdst[k] = scalar_dst[k]; t.sval[k] = scalar_val[k]; }
+  t.n_scalars = n_scalars;
+  t.words_src = words_src; t.words_dst = n_words > 0 ? words_dst : nullptr; t.n_words = n_words;
+  int64_t blocks = (total16 + kBlock - 1) / kBlock;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(step_inputs_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, t, total16);
+  return tp::check_launch("tp_step_inputs");
 }
 
 int tp_adam_step(const tp_adam_tensor* tensors, int n, const float* lr_dev, double lr_host, double beta1, double beta2, double eps,

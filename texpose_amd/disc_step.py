@@ -114,10 +114,15 @@ class DiscStepSchedule:
             y, xhat, rstd = ops.inorm_lrelu_fwd(z, eps, sl, y_out=None if stacks is None else stacks[l + 1][:B])
             saved.append(AttrDict(x=a, xhat=xhat, rstd=rstd))
             a = y
-        z3 = ops.skinny_linear_fwd(a.reshape(B, -1), W[K].flatten(1))
+        a2d, W0 = a.reshape(B, -1), W[K].flatten(1)
+        if ops.disc_tail_eligible(a2d, W0, extra_rows=B):
+            # K17: full-map convolution + head in one launch (the split-K partial sums of z meet in the last workgroup, which runs the head)
+            out, t0, t1, t2 = ops.disc_tail_fwd(a2d, W0, scale, *self._head_w(W), self.disc.L_scale, sl)
+            return AttrDict(out=out, stages=saved, a_full=a, head=(t0, t1, t2), C_z=W0.shape[0], tail=True)
+        z3 = ops.skinny_linear_fwd(a2d, W0)
         out, t0, t1, t2 = ops.disc_head_fwd(z3, scale, W[K + 1].flatten(1), W[K + 2].flatten(1), W[K + 3].flatten(1),
                                             self.disc.L_scale, sl)
-        return AttrDict(out=out, stages=saved, a_full=a, head=(t0, t1, t2), C_z=z3.shape[1])
+        return AttrDict(out=out, stages=saved, a_full=a, head=(t0, t1, t2), C_z=z3.shape[1], tail=False)
 
     def _head_w(self, W):
         K = len(self.stages)
@@ -127,10 +132,14 @@ class DiscStepSchedule:
         """First-order weight gradients of one pass (no R1): [ladder..., full-map, head 1..3] in the order of `convs()`."""
         K, B, sl = len(self.stages), g_out.shape[0], self.slope
         t0, t1, t2 = f.head
-        c_z3, gW1, gW2, gW3, _, _ = ops.disc_head_bwd(g_out, t0, t1, t2, *self._head_w(W), f.C_z, self.disc.L_scale, sl)
         gw = [None] * (K + 1)
-        gw[K] = ops.skinny_linear_wgrad(c_z3, f.a_full.reshape(B, -1))
-        c_a = ops.skinny_linear_dgrad(c_z3, W[K].flatten(1)).view_as(f.a_full)
+        if f.tail:
+            r = ops.disc_tail_bwd(g_out, t0, t1, t2, W[K].flatten(1), *self._head_w(W), self.disc.L_scale, sl, a=f.a_full.reshape(B, -1))
+            gw[K], gW1, gW2, gW3, c_a = r["gW0"], r["gW1"], r["gW2"], r["gW3"], r["c_a"].view_as(f.a_full)
+        else:
+            c_z3, gW1, gW2, gW3, _, _ = ops.disc_head_bwd(g_out, t0, t1, t2, *self._head_w(W), f.C_z, self.disc.L_scale, sl)
+            gw[K] = ops.skinny_linear_wgrad(c_z3, f.a_full.reshape(B, -1))
+            c_a = ops.skinny_linear_dgrad(c_z3, W[K].flatten(1)).view_as(f.a_full)
         for l in range(K - 1, -1, -1):
             st = f.stages[l]
             c_z = ops.inorm_lrelu_bwd(st.xhat, st.rstd, c_a, sl)
@@ -160,8 +169,13 @@ class DiscStepSchedule:
         Wh = self._head_w(W)
         ones = self._ones_like(f.out)
         # ---- R1, first pass: g = d D(real).sum() / d real  (reference :796-801)
-        gz3, _, _, _, e1, e2 = ops.disc_head_bwd(ones, t0, t1, t2, *Wh, f.C_z, L, sl, weight_grads=False, gz_out=gs[K][B:])
-        ga, ga_in = ops.skinny_linear_dgrad(gz3, W[K].flatten(1)).view_as(f.a_full), [None] * K
+        W0 = W[K].flatten(1)
+        if f.tail:
+            r = ops.disc_tail_bwd(ones, t0, t1, t2, W0, *Wh, L, sl, want_gW0=False, head_weight_grads=False, want_e=True, gz_out=gs[K][B:])
+            e1, e2, ga, ga_in = r["e1"], r["e2"], r["c_a"].view_as(f.a_full), [None] * K
+        else:
+            gz3, _, _, _, e1, e2 = ops.disc_head_bwd(ones, t0, t1, t2, *Wh, f.C_z, L, sl, weight_grads=False, gz_out=gs[K][B:])
+            ga, ga_in = ops.skinny_linear_dgrad(gz3, W0).view_as(f.a_full), [None] * K
         for l in range(K - 1, -1, -1):
             st = f.stages[l]
             ga_in[l] = ga
@@ -175,15 +189,24 @@ class DiscStepSchedule:
             st = f.stages[l]
             c_gz = ops.conv4s2_fwd(c, W[l])
             c, c_zr[l] = ops.inorm_lrelu_bwd_bwd(st.xhat, st.rstd, ga_in[l], c_gz, sl, out_gy=xs[l + 1][B:])
-        c_gz3 = ops.skinny_linear_fwd(c.reshape(B, -1), W[K].flatten(1))
-        _gg, gW1, gW2, gW3 = ops.disc_head_bwd_bwd(c_gz3, ones, t0, t1, t2, e1, e2, *Wh, L, sl)
-        # ---- BCE path of the real pass, its cotangents joined with the R1 path's on the way
-        g_out = make_g_out(f.out)
-        c_z3, gW1, gW2, gW3, _, _ = ops.disc_head_bwd(g_out, t0, t1, t2, *Wh, f.C_z, L, sl, accumulate_into=(gW1, gW2, gW3),
-                                                      gz_out=gs[K][:B])
         gw = [None] * (K + 1)
-        gw[K] = ops.skinny_linear_wgrad(gs[K], xs[K].reshape(2 * B, -1))
-        c_a = ops.skinny_linear_dgrad(c_z3, W[K].flatten(1)).view_as(f.a_full)
+        if f.tail:
+            gW1, gW2, gW3 = ops.disc_tail_bwd_bwd(c.reshape(B, -1), ones, t0, t1, t2, e1, e2, W0, *Wh, L, sl)
+            # ---- BCE path of the real pass, its cotangents joined with the R1 path's on the way: the R1 pair of the full-map weight
+            # ((first-pass gz, second-pass c) = the second halves of the stacks) joins the weight-gradient sum inside the launch
+            g_out = make_g_out(f.out)
+            r = ops.disc_tail_bwd(g_out, t0, t1, t2, W0, *Wh, L, sl, a=xs[K][:B].reshape(B, -1), accumulate_into=(gW1, gW2, gW3),
+                                  gy2=gs[K][B:], a2=xs[K][B:].reshape(B, -1))
+            gw[K], gW1, gW2, gW3, c_a = r["gW0"], r["gW1"], r["gW2"], r["gW3"], r["c_a"].view_as(f.a_full)
+        else:
+            c_gz3 = ops.skinny_linear_fwd(c.reshape(B, -1), W0)
+            _gg, gW1, gW2, gW3 = ops.disc_head_bwd_bwd(c_gz3, ones, t0, t1, t2, e1, e2, *Wh, L, sl)
+            # ---- BCE path of the real pass, its cotangents joined with the R1 path's on the way
+            g_out = make_g_out(f.out)
+            c_z3, gW1, gW2, gW3, _, _ = ops.disc_head_bwd(g_out, t0, t1, t2, *Wh, f.C_z, L, sl, accumulate_into=(gW1, gW2, gW3),
+                                                          gz_out=gs[K][:B])
+            gw[K] = ops.skinny_linear_wgrad(gs[K], xs[K].reshape(2 * B, -1))
+            c_a = ops.skinny_linear_dgrad(c_z3, W0).view_as(f.a_full)
         for l in range(K - 1, -1, -1):
             st = f.stages[l]
             c_z = ops.inorm_lrelu_bwd(st.xhat, st.rstd, c_a, sl, addend=c_zr[l], out=gs[l][:B])

@@ -14,6 +14,7 @@ PerceptualLoss needs torchvision's ImageNet VGG19 weights, which are not availab
 from __future__ import annotations
 
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -170,6 +171,22 @@ class Discriminator(nn.Module):
             i += 1
         return x
 
+    def _tail_fusable(self, x, weights):
+        """GPU, scale-conditioned plain head, constant weights (no gradient wrt them is being recorded), a last ladder convolution
+        that covers its whole map, at most 16 patches."""
+        from . import ops
+        if not (x.is_cuda and self.scale_conditional and self._plain_head()) or any(w.requires_grad for w in weights):
+            return False
+        last = list(self.main)[-1]
+        if not (isinstance(last, SNConv2d) and last.padding == (0, 0) and last.stride == (1, 1)):
+            return False
+        n_down = len([m for m in self.main if isinstance(m, SNConv2d)]) - 1
+        kh, kw = last.weight_orig.shape[-2:]
+        if (x.shape[-2] >> n_down, x.shape[-1] >> n_down) != (kh, kw):
+            return False
+        k_in = last.weight_orig.shape[1] * kh * kw
+        return x.shape[0] <= ops.DISC_TAIL_MAX_ROWS and k_in % 4 == 0 and k_in >= 1024 and os.environ.get("TP_NO_DISC_TAIL") != "1"
+
     def _plain_head(self):
         """``final`` is LeakyReLU, 1x1, LeakyReLU, 1x1, LeakyReLU, 1x1 with one slope (what __init__ builds)."""
         mods = list(self.final)
@@ -219,6 +236,16 @@ class Discriminator(nn.Module):
                 raise RuntimeError("Discriminator.forward: prefetched spectral weights pending, but this call differentiates "
                                    "through the normalisation (or runs in eval mode)")
         weights = list(pre[0]) if pre is not None else spectral_weights(convs, self.training)   # all power iterations at once
+        if self._tail_fusable(x, weights):
+            # K17: the ladder's full-map convolution + the scale-conditioned head as ONE launch each way (frozen weights: the nerf
+            # step's pass, whose backward needs the data gradient only)
+            from . import autograd_ops
+            n_main = len([m for m in self.main if isinstance(m, SNConv2d)])
+            a = self._run(nn.Sequential(*list(self.main)[:-1]), x, weights)
+            w0, (w1, w2, w3) = weights[0], weights[1:4]
+            assert len(weights) == 4 and n_main >= 1
+            return autograd_ops.disc_tail(a.flatten(1), w0.flatten(1), scale.reshape(-1), w1.flatten(1), w2.flatten(1), w3.flatten(1),
+                                          self.L_scale, self.final[0].negative_slope)
         out = self._run(self.main, x, weights)                        # [B, c, 1, 1]
         if self.scale_conditional and out.is_cuda and self._plain_head():
             # K14: encoding, concatenation and the three 1x1 layers in one launch per derivative order

@@ -1163,6 +1163,40 @@ def step_flags(total: Tensor, bad: Tensor, word_finite: int, snapshot: Tensor, s
                             snapshot.data_ptr(), _stream()), "tp_step_flags")
 
 
+def step_inputs(copies, scalars=(), words=None, words_host=None) -> None:
+    """The per-iteration host -> device state of a replayed step in ONE launch (K13 tp_step_inputs): ``copies`` = [(dst, src)]
+    device tensors of equal byte size (the batch into the static inputs), ``scalars`` = [(0-dim float32 device tensor, value)],
+    ``words`` (int32 device tensor) copied out to ``words_host`` (pinned int32 host tensor of the same length)."""
+    lib = _lib.load()
+    copies, scalars = list(copies), list(scalars)
+    if len(scalars) > _lib.STEP_INPUTS_MAX_SCALARS:
+        raise ValueError("step_inputs: too many scalars")
+    dev = (copies[0][0] if copies else scalars[0][0] if scalars else words).device
+    with torch.cuda.device(dev):
+        first = True
+        for i0 in range(0, max(len(copies), 1), _lib.STEP_INPUTS_MAX_COPIES):
+            chunk = copies[i0:i0 + _lib.STEP_INPUTS_MAX_COPIES]
+            arr = (_lib.StepCopy * max(len(chunk), 1))()
+            for a, (d, s) in zip(arr, chunk):
+                nb = d.numel() * d.element_size()
+                if not (d.is_contiguous() and s.is_contiguous() and s.numel() * s.element_size() == nb and d.device == s.device == dev):
+                    raise _lib.TexposeLibraryError("step_inputs: copies need contiguous same-size tensors on one device")
+                a.dst, a.src, a.bytes = d.data_ptr(), s.data_ptr(), nb
+            sc = scalars if first else []
+            sd = (C.c_void_p * max(len(sc), 1))(*[t.data_ptr() for t, _ in sc])
+            sv = (C.c_float * max(len(sc), 1))(*[float(v) for _, v in sc])
+            for t, _ in sc:
+                if t.dtype != torch.float32 or t.device != dev:
+                    raise _lib.TexposeLibraryError("step_inputs: scalars are float32 tensors on the batch's device")
+            w = words if first else None
+            if w is not None and not (w.dtype == torch.int32 and words_host.dtype == torch.int32 and words_host.is_pinned()
+                                      and words_host.numel() == w.numel()):
+                raise _lib.TexposeLibraryError("step_inputs: gate words need an int32 device tensor and a pinned int32 host tensor")
+            check(lib.tp_step_inputs(arr, len(chunk), sd, sv, len(sc), _ptr(w), None if w is None else words_host.data_ptr(),
+                                     0 if w is None else w.numel(), _stream()), "tp_step_inputs")
+            first = False
+
+
 @_on_tensor_device
 def adam_step(params, grads, exp_avgs, exp_avg_sqs, steps, lr, beta1: float, beta2: float, eps: float, gate: Optional[Tensor] = None) -> None:
     """torch.optim.Adam's update of all tensors in one launch per 32 (K13 tp_adam_step); ``steps``: 0-dim float tensors with
@@ -1247,6 +1281,113 @@ def disc_head_bwd_bwd(c_gz: Tensor, g_out: Tensor, t0: Tensor, t1: Tensor, t2: T
     a.gW1, a.gW2, a.gW3 = gW1.data_ptr(), gW2.data_ptr(), gW3.data_ptr()
     check(lib.tp_disc_head_bwd_bwd(C.byref(a), _stream()), "tp_disc_head_bwd_bwd")
     return gg, gW1, gW2, gW3
+
+
+# ------------------------------------------------------------------------------------------ K17
+DISC_TAIL_MAX_ROWS = _lib.DISC_TAIL_MAX_ROWS
+_tail_ws = {}                # (device index, stream) -> workspace tensor of the split-K partial sums
+
+
+def disc_tail_eligible(a: Tensor, W0: Tensor, extra_rows: int = 0) -> bool:
+    """The fused tail (K17) takes up to 16 rows (and 16 extra weight-gradient rows), K a multiple of 4, fp32 device tensors."""
+    return (a.is_cuda and a.dtype == torch.float32 and a.dim() == 2 and a.shape[0] <= DISC_TAIL_MAX_ROWS and extra_rows <= DISC_TAIL_MAX_ROWS
+            and a.shape[1] % 4 == 0 and W0.shape[1] == a.shape[1] and os.environ.get("TP_NO_DISC_TAIL") != "1")
+
+
+def _tail_args(W0, W1, W2, W3, M, L, slope):
+    a = _lib.DiscTailArgs()
+    N, K = W0.shape
+    H = W2.shape[0]
+    if W1.shape != (H, N + 2 * L + 1) or W2.shape != (H, H) or W3.numel() != H:
+        raise ValueError("disc_tail: W0 [N,K], W1 [H,N+2L+1], W2 [H,H], W3 [1,H] expected")
+    a.W0, a.W1, a.W2, a.W3 = W0.data_ptr(), W1.data_ptr(), W2.data_ptr(), W3.data_ptr()
+    a.M, a.M2, a.K, a.N, a.L, a.H, a.slope = int(M), 0, int(K), int(N), int(L), int(H), float(slope)
+    return a
+
+
+def _tail_workspace(dev, N):
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream, N)
+    ws = _tail_ws.get(key)
+    if ws is None:
+        ws = _tail_ws[key] = torch.empty(int(_lib.load().tp_disc_tail_workspace_bytes(N)) // 4, device=dev)
+    return ws
+
+
+@_on_tensor_device
+def disc_tail_fwd(a: Tensor, W0: Tensor, scale: Tensor, W1: Tensor, W2: Tensor, W3: Tensor, L: int, slope: float):
+    """a [M,K] -> (out [M], t0 [M,N+2L+1], t1 [M,H], t2 [M,H]): full-map convolution + scale-conditioned head, one launch."""
+    lib = _lib.load()
+    a, W0, scale, W1, W2, W3 = (_f32(t, n) for t, n in ((a, "a"), (W0, "W0"), (scale, "scale"), (W1, "W1"), (W2, "W2"), (W3, "W3")))
+    M, dev = a.shape[0], a.device
+    q = _tail_args(W0, W1, W2, W3, M, L, slope)
+    out, t0, t1, t2 = (torch.empty(M, device=dev), torch.empty(M, q.N + 2 * L + 1, device=dev), torch.empty(M, q.H, device=dev),
+                       torch.empty(M, q.H, device=dev))
+    ws = _tail_workspace(dev, q.N)
+    q.a, q.scale, q.out, q.t0, q.t1, q.t2 = a.data_ptr(), scale.data_ptr(), out.data_ptr(), t0.data_ptr(), t1.data_ptr(), t2.data_ptr()
+    q.workspace, q.ticket = ws.data_ptr(), _ticket(dev, "disc_tail")
+    check(lib.tp_disc_tail_fwd(C.byref(q), _stream()), "tp_disc_tail_fwd")
+    return out, t0, t1, t2
+
+
+@_on_tensor_device
+def disc_tail_bwd(g_out: Tensor, t0: Tensor, t1: Tensor, t2: Tensor, W0: Tensor, W1: Tensor, W2: Tensor, W3: Tensor, L: int, slope: float,
+                  a: Optional[Tensor] = None, want_c_a: bool = True, want_gW0: bool = True, head_weight_grads: bool = True,
+                  accumulate_into=None, want_e: bool = False, gz_out: Optional[Tensor] = None, gy2: Optional[Tensor] = None,
+                  a2: Optional[Tensor] = None, c_a_out: Optional[Tensor] = None):
+    """The tail's backward in one launch -> dict(c_a [M,K], gW0 [N,K], gW1, gW2, gW3, gz [M,N], e1, e2) (absent entries None).
+    ``a`` [M,K]: the ladder output (needed for gW0); ``gy2`` [M2,N] / ``a2`` [M2,K]: a second (cotangent, input) pair of the same
+    weight whose rows join gW0's sum; ``accumulate_into=(gW1, gW2, gW3)``: the head's weight gradients are ADDED to these."""
+    lib = _lib.load()
+    g_out, W0, W1, W2, W3 = (_f32(t, n) for t, n in ((g_out, "g_out"), (W0, "W0"), (W1, "W1"), (W2, "W2"), (W3, "W3")))
+    M, dev = t1.shape[0], t1.device
+    q = _tail_args(W0, W1, W2, W3, M, L, slope)
+    res = dict(c_a=None, gW0=None, gW1=None, gW2=None, gW3=None, gz=None, e1=None, e2=None)
+    keep = []
+    if want_c_a:
+        res["c_a"] = _out_like(c_a_out, t1, (M, q.K))
+    if want_gW0:
+        if a is None:
+            raise ValueError("disc_tail_bwd: the weight gradient of the full-map convolution needs the ladder output")
+        a = _f32(a, "a")
+        res["gW0"] = torch.empty(q.N, q.K, device=dev)
+        q.a = a.data_ptr()
+        if gy2 is not None:
+            gy2, a2 = _f32(gy2, "gy2"), _f32(a2, "a2")
+            keep += [gy2, a2]
+            q.gy2, q.a2, q.M2 = gy2.data_ptr(), a2.data_ptr(), gy2.shape[0]
+    if accumulate_into is not None:
+        res["gW1"], res["gW2"], res["gW3"] = (_out_like(g, W) for g, W in zip(accumulate_into, (W1, W2, W3)))
+        q.accumulate_gw = 1
+    elif head_weight_grads:
+        res["gW1"], res["gW2"], res["gW3"] = torch.empty_like(W1), torch.empty_like(W2), torch.empty_like(W3)
+    if want_e:
+        res["e1"], res["e2"] = torch.empty(M, q.H, device=dev), torch.empty(M, q.H, device=dev)
+    if gz_out is not None:
+        res["gz"] = _out_like(gz_out, t1, (M, q.N))
+    q.g_out, q.t0, q.t1, q.t2 = g_out.data_ptr(), t0.data_ptr(), t1.data_ptr(), t2.data_ptr()
+    q.c_a, q.gW0, q.gW1, q.gW2, q.gW3 = (_ptr(res[k]) for k in ("c_a", "gW0", "gW1", "gW2", "gW3"))
+    q.gz, q.e1, q.e2 = _ptr(res["gz"]), _ptr(res["e1"]), _ptr(res["e2"])
+    check(lib.tp_disc_tail_bwd(C.byref(q), _stream()), "tp_disc_tail_bwd")
+    return res
+
+
+@_on_tensor_device
+def disc_tail_bwd_bwd(c: Tensor, g_out: Tensor, t0: Tensor, t1: Tensor, t2: Tensor, e1: Tensor, e2: Tensor, W0: Tensor, W1: Tensor,
+                      W2: Tensor, W3: Tensor, L: int, slope: float, want_gg: bool = False):
+    """R1 second pass through the tail: cotangent c [M,K] of the first pass' data gradient -> (gW1, gW2, gW3[, d/d g_out])."""
+    lib = _lib.load()
+    c, g_out, W0, W1, W2, W3 = (_f32(t, n) for t, n in ((c, "c"), (g_out, "g_out"), (W0, "W0"), (W1, "W1"), (W2, "W2"), (W3, "W3")))
+    M, dev = c.shape[0], c.device
+    q = _tail_args(W0, W1, W2, W3, M, L, slope)
+    gW1, gW2, gW3 = torch.empty_like(W1), torch.empty_like(W2), torch.empty_like(W3)
+    gg = torch.empty(M, device=dev) if want_gg else None
+    ws = _tail_workspace(dev, q.N)
+    q.a, q.g_out, q.t0, q.t1, q.t2, q.e1, q.e2 = (c.data_ptr(), g_out.data_ptr(), t0.data_ptr(), t1.data_ptr(), t2.data_ptr(), e1.data_ptr(),
+                                                  e2.data_ptr())
+    q.gW1, q.gW2, q.gW3, q.out = gW1.data_ptr(), gW2.data_ptr(), gW3.data_ptr(), _ptr(gg)
+    q.workspace, q.ticket = ws.data_ptr(), _ticket(dev, "disc_tail")
+    check(lib.tp_disc_tail_bwd_bwd(C.byref(q), _stream()), "tp_disc_tail_bwd_bwd")
+    return (gW1, gW2, gW3, gg) if want_gg else (gW1, gW2, gW3)
 
 
 # ------------------------------------------------------------------------------------------ K15

@@ -691,8 +691,10 @@ class GraphedGanTrainer(GanTrainer):
             raise FloatingPointError("non-finite loss during the warm-up iterations of the captured step")
         return self
 
-    def _after_step(self):
-        if self.has_disc:
+    def _after_step(self, fill_progress=True):
+        """``fill_progress=False``: the replay loop writes the value with the NEXT iteration's tp_step_inputs launch (nothing reads
+        `progress` in between: the reference's discriminator never uses it in its forward)."""
+        if self.has_disc and fill_progress:
             self.graph.discriminator.progress.data.fill_(self.it / self.max_iter)
         self.it += 1
         self.graph.patch_sampler.iterations = self.it
@@ -713,15 +715,17 @@ class GraphedGanTrainer(GanTrainer):
             prev[1].synchronize()
         if prev is not None and prev[1].query():
             seen = prev[0].tolist()
-            prev = None
-        if prev is None:
-            host = torch.empty(3, dtype=torch.int32, pin_memory=True)
-            host.copy_(self._bad, non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record()
-            prev = (host, ev)
-        self._bad_poll = prev
+            self._bad_poll = None
         return seen
+
+    def _bad_poll_slot(self):
+        """Pinned host words for this iteration's copy of the gate words (written by the tp_step_inputs launch in front of the
+        replay, i.e. the words as the PREVIOUS replay left them), or None while an earlier copy has not been read yet."""
+        if self._bad_poll is not None:
+            return None
+        if getattr(self, "_bad_host", None) is None:
+            self._bad_host = torch.zeros(3, dtype=torch.int32).pin_memory()
+        return self._bad_host
 
     def _fall_back_to_fp32(self, var, warmup=3):
         warnings.warn("texpose_amd: an activation left the fp16 range of the f16x3 recording forward; the flagged steps "
@@ -737,18 +741,29 @@ class GraphedGanTrainer(GanTrainer):
     def train_iteration(self, var: AttrDict):
         if self._graph is None:
             self.capture(var)
-        # the batch into the static input tensors: one multi-tensor launch per dtype instead of one copy per tensor
+        # the batch into the static input tensors, the annealed patch-scale bound, the discriminator's progress value (of the
+        # iteration before, as in the reference :182) and the gate words out to pinned memory: ONE launch (K13 tp_step_inputs;
+        # torch: a multi-tensor copy per dtype, two fills, a copyBuffer)
         pairs = [(dst, var[k]) for k, dst in self._static_in.items() if var[k] is not dst]
-        same = [(d, s) for d, s in pairs if torch.is_tensor(s) and s.device == d.device and s.dtype == d.dtype and s.shape == d.shape]
+        fused = [(d, s) for d, s in pairs if torch.is_tensor(s) and s.device == d.device and s.dtype == d.dtype and s.shape == d.shape
+                 and s.is_contiguous() and d.is_contiguous() and d.data_ptr() % 16 == 0 and s.data_ptr() % 16 == 0]
         for d, s in pairs:
-            if not any(d is d2 for d2, _ in same):
+            if not any(d is d2 for d2, _ in fused):
                 d.copy_(s, non_blocking=True)
-        for dt in {d.dtype for d, _ in same}:
-            torch._foreach_copy_([d for d, _ in same if d.dtype == dt], [s for d, s in same if d.dtype == dt])
         for name, optim in (("lr_nerf", self.optim_nerf), ("lr_disc", getattr(self, "optim_disc", None))):
             if optim is not None and any(g["lr"] is not getattr(self, name + "_used") for g in optim.param_groups):
                 self._adopt_group_lr(name, optim)             # an Optimizer.load_state_dict since the last replay
-        self.graph.patch_sampler.update_device_bound()          # one fill_ of the annealed bound
+        sampler = self.graph.patch_sampler
+        scalars = [(sampler.device_lo, sampler._host_range()[0])]
+        if self.has_disc:
+            # reference :182 leaves it / max_iter in `progress` after iteration `it`; nothing reads it during the iteration
+            scalars.append((self.graph.discriminator.progress.data, self.it / self.max_iter))
+        poll = self._bad_poll_slot()
+        ops.step_inputs(fused, scalars, words=self._bad if poll is not None else None, words_host=poll)
+        if poll is not None:
+            ev = torch.cuda.Event()
+            ev.record()
+            self._bad_poll = (poll, ev)
         self._graph.replay()
         if self._graph_b is not None:                            # collectives between the two replays, stream-ordered
             ev = getattr(self, "collective_events", None)        # (a list: HIP-event pairs around the step's reductions, bench.py)
@@ -760,8 +775,8 @@ class GraphedGanTrainer(GanTrainer):
                 e1.record()
                 ev.append((e0, e1))
             self._graph_b.replay()
-        self._after_step()
-        flagged = self._read_bad()                              # outside the graph: event query + pinned copy
+        self._after_step(fill_progress=False)
+        flagged = self._read_bad()                              # outside the graph: event query of the pinned copy
         if flagged[0] and self._uses_f16x3():
             self._fall_back_to_fp32(AttrDict(dict(self._static_in)))
         elif flagged[1] or flagged[2]:
