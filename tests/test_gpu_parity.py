@@ -1628,8 +1628,9 @@ def test_disc_step_schedule_matches_autograd_form(ops, patch, B, with_r1, monkey
             assert torch.equal(state_a[k], state_b[k]), k
         else:
             # (RMSprop's first step is lr g / (0.1 |g| + eps): a sign function of entries near zero, so a few entries move by a
-            # different amount; the parameters as a whole agree)
-            assert rel_l2(state_b[k], state_a[k]) < 2e-6, (k, rel_l2(state_b[k], state_a[k]))
+            # different amount; the parameters as a whole agree.  Round 4: the schedule's tail (K17) sums the full-map convolution
+            # in split-K order, so more near-zero entries take the other sign than with round 3's kernels: 2.6e-6 / 4.7e-6 measured)
+            assert rel_l2(state_b[k], state_a[k]) < 1e-5, (k, rel_l2(state_b[k], state_a[k]))
 
 
 # ------------------------------------------------------------------------------------------ K12
@@ -2401,8 +2402,9 @@ def test_discriminator_forward_takes_the_fused_tail_for_frozen_weights(ops):
     opt = default_options(H=128, W=128, device="cuda:0")
     opt.patch_size = 16
     torch.manual_seed(3)
-    disc = Discriminator(opt).to(dev()).train()
+    disc = Discriminator(opt)
     O.seed_spectral_module(disc, 4)
+    disc = disc.to(dev()).train()
     for p in disc.parameters():
         p.requires_grad_(False)
     x0 = torch.randn(4, 9, 16, 16, device=dev())

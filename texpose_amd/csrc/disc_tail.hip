@@ -55,14 +55,73 @@ struct TailP {
 __device__ __forceinline__ float lrelu(float v, float s) { return v > 0.f ? v : v * s; }
 __device__ __forceinline__ float dl(float t, float s) { return t > 0.f ? 1.f : s; }
 
-extern __shared__ float smem[];
+extern __shared__ __attribute__((aligned(16))) float smem[];
 
-// W1 | W2 | W3 into LDS (37 KB at ndf = 64; L2 hits for all but the first workgroup)
+// W1 | W2 | W3 into LDS (37 KB at ndf = 64; L2 hits for all but the first workgroup): 16-byte loads, four in flight per thread
 __device__ __forceinline__ void stage_head_weights(const TailP& p, float* w1, float* w2, float* w3) {
-  const int n1 = p.H * p.Cin, n2 = p.H * p.H;
-  for (int i = threadIdx.x; i < n1; i += kT) w1[i] = p.W1[i];
-  for (int i = threadIdx.x; i < n2; i += kT) w2[i] = p.W2[i];
-  for (int i = threadIdx.x; i < p.H; i += kT) w3[i] = p.W3[i];
+  const int n1 = p.H * p.Cin, n2 = p.H * p.H, t = threadIdx.x;
+  const bool vec = (((uintptr_t)p.W1 | (uintptr_t)p.W2) & 15) == 0 && (n1 & 3) == 0 && (n2 & 3) == 0;
+  if (vec) {
+    const f32x4* s1 = reinterpret_cast<const f32x4*>(p.W1);
+    const f32x4* s2 = reinterpret_cast<const f32x4*>(p.W2);
+    f32x4* d1 = reinterpret_cast<f32x4*>(w1);
+    f32x4* d2 = reinterpret_cast<f32x4*>(w2);
+#pragma unroll 4
+    for (int i = t; i < n1 / 4; i += kT) d1[i] = s1[i];
+#pragma unroll 4
+    for (int i = t; i < n2 / 4; i += kT) d2[i] = s2[i];
+  } else {
+    for (int i = t; i < n1; i += kT) w1[i] = p.W1[i];
+    for (int i = t; i < n2; i += kT) w2[i] = p.W2[i];
+  }
+  for (int i = t; i < p.H; i += kT) w3[i] = p.W3[i];
+}
+
+// out[m][o] = f( sum_j W[o * ldw + j] * x[m * ldx + j] ), j < n_in, o < n_out, m < M  (W row-major [n_out][ldw] in LDS, x [M][ldx] in LDS):
+// wave w takes the quarter [w n_in / 4, ...) of j for every o (lanes = o: row stride ldw is odd or the rows are read along j -- no
+// bank conflicts either way), M accumulators per thread, the four partial sums meet in `ps` [4][kMaxM][n_out] and are added in wave
+// order.  TRANS: W is read transposed (W[j * ldw + o]).  `fin(m, o, v)` consumes the total.
+template <bool TRANS, class Fin>
+__device__ __forceinline__ void matvec4(const float* W, int ldw, const float* x, int ldx, int n_in, int n_out, int M, float* ps, Fin fin) {
+  const int t = threadIdx.x, w = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
+  const int per = (n_in + 3) >> 2, j0 = min(n_in, w * per), j1 = min(n_in, j0 + per);
+  for (int o0 = 0; o0 < n_out; o0 += 64) {
+    const int o = o0 + lane;
+    float acc[kMaxM];
+#pragma unroll
+    for (int m = 0; m < kMaxM; ++m) acc[m] = 0.f;
+    if (o < n_out) {
+#pragma unroll 4
+      for (int j = j0; j < j1; ++j) {
+        const float wv = TRANS ? W[j * ldw + o] : W[o * ldw + j];
+#pragma unroll
+        for (int m = 0; m < kMaxM; ++m)
+          if (m < M) acc[m] = fmaf(wv, x[m * ldx + j], acc[m]);
+      }
+#pragma unroll
+      for (int m = 0; m < kMaxM; ++m)
+        if (m < M) ps[(w * kMaxM + m) * n_out + o] = acc[m];
+    }
+  }
+  __syncthreads();
+  for (int e = t; e < M * n_out; e += kT) {
+    const int m = e / n_out, o = e - m * n_out;
+    fin(m, o, ((ps[(0 * kMaxM + m) * n_out + o] + ps[(1 * kMaxM + m) * n_out + o]) + ps[(2 * kMaxM + m) * n_out + o]) + ps[(3 * kMaxM + m) * n_out + o]);
+  }
+  __syncthreads();
+}
+
+// out[i][j] (+)= sum_m u[m * ldu + i] * v[m * ldv + j] for the elements e = i * cols + j in [e0, e1) (u, v in LDS; rows ascending)
+__device__ __forceinline__ void outer_rows(float* out, const float* u, int ldu, const float* v, int ldv, int cols, int e0, int e1, int M, bool add) {
+  for (int e = e0 + (int)threadIdx.x; e < e1; e += kT) {
+    const int i = e / cols, j = e - i * cols;
+    const float old = add ? out[e] : 0.f;
+    float acc = 0.f;
+#pragma unroll
+    for (int m = 0; m < kMaxM; ++m)
+      if (m < M) acc = fmaf(u[m * ldu + i], v[m * ldv + j], acc);
+    out[e] = old + acc;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------- F / R1
@@ -70,9 +129,12 @@ template <bool R1>
 __global__ __launch_bounds__(kT) void disc_tail_fwd_kernel(TailP p) {
   float* w1 = smem; float* w2 = w1 + p.H * p.Cin; float* w3 = w2 + p.H * p.H;
   float* a0 = w3 + p.H; float* a1 = a0 + kMaxM * p.Cin; float* a2 = a1 + kMaxM * p.H;
-  float* red = a2 + kMaxM * p.H;                   // [kMaxM][kT]
+  float* ps = a2 + kMaxM * p.H;                    // [4][kMaxM][max(H, N)] partial sums; R1: then e1 | e2 [M][H] each
   __shared__ int last;
+  __shared__ float wsum[4][kMaxM];
   const int t = threadIdx.x, n = blockIdx.x / p.S, s = blockIdx.x % p.S, M = p.M;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
+  stage_head_weights(p, w1, w2, w3);               // (every workgroup: whichever arrives last has them; issued first, consumed last)
   // ---- this workgroup's slice of z[:, n]: k in [k0, k1), 16-byte loads, all rows' operands in flight together
   const int per = ((p.K / 4 + p.S - 1) / p.S) * 4, k0 = min(p.K, s * per), k1 = min(p.K, k0 + per);
   const float* wr = p.W0 + (size_t)n * p.K;
@@ -89,142 +151,118 @@ __global__ __launch_bounds__(kT) void disc_tail_fwd_kernel(TailP p) {
         acc[r] = fmaf(xv[3], wv[3], fmaf(xv[2], wv[2], fmaf(xv[1], wv[1], fmaf(xv[0], wv[0], acc[r]))));
       }
   }
-  stage_head_weights(p, w1, w2, w3);               // (every workgroup: whichever arrives last has them; 37 KB of L2 hits)
+  // wave butterfly (fixed order), then the four waves in wave order
 #pragma unroll
   for (int r = 0; r < kMaxM; ++r)
-    if (r < M) red[r * kT + t] = acc[r];
-  __syncthreads();
-  for (int st = kT >> 1; st > 0; st >>= 1) {
-    if (t < st)
+    if (r < M) {
+      float v = acc[r];
 #pragma unroll
-      for (int r = 0; r < kMaxM; ++r)
-        if (r < M) red[r * kT + t] += red[r * kT + t + st];
-    __syncthreads();
-  }
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+      if (lane == 0) wsum[wave][r] = v;
+    }
+  __syncthreads();
   // ---- hand-over (patch_conv.hip reduce_tiles: sc1 stores, the storing wave drained, ONE agent-scope add behind the barrier)
-  if (t < M) __hip_atomic_store(p.ws + ((size_t)n * p.S + s) * kMaxM + t, red[t * kT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (t < M) {
+    const float v = ((wsum[0][t] + wsum[1][t]) + wsum[2][t]) + wsum[3][t];
+    __hip_atomic_store(p.ws + ((size_t)n * p.S + s) * kMaxM + t, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (t == 0) last = __hip_atomic_fetch_add(p.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
   __syncthreads();
   if (!last) return;
   if (t == 0) __hip_atomic_store(p.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // ready for the next launch
-  // z[m][nn] = sum of the S slices in slice order
-  for (int e = t; e < M * p.N; e += kT) {
-    const int m = e / p.N, nn = e - m * p.N;
-    float z = 0.f;
-    for (int ss = 0; ss < p.S; ++ss)
-      z += __hip_atomic_load(p.ws + ((size_t)nn * p.S + ss) * kMaxM + m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (!R1) {
-      a0[m * p.Cin + nn] = z;                      // (activated below)
+  // z[m][nn] = sum of the S slices in slice order; the rest of a0
+  for (int e = t; e < M * p.Cin; e += kT) {
+    const int m = e / p.Cin, j = e - m * p.Cin;
+    float v;
+    if (j < p.N) {
+      float z = 0.f;
+      for (int ss = 0; ss < p.S; ++ss)
+        z += __hip_atomic_load(p.ws + ((size_t)j * p.S + ss) * kMaxM + m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      v = R1 ? dl(p.t0[e], p.slope) * z : lrelu(z, p.slope);                 // R1: a0 = d(t0) [c, 0]
+    } else if (R1) {
+      v = 0.f;
     } else {
-      a0[m * p.Cin + nn] = dl(p.t0[(size_t)m * p.Cin + nn], p.slope) * z;        // a0 = d(t0) [c, 0]
-    }
-  }
-  if (R1)
-    for (int e = t; e < M * (p.Cin - p.N); e += kT) a0[(e / (p.Cin - p.N)) * p.Cin + p.N + e % (p.Cin - p.N)] = 0.f;
-  if (!R1) {
-    for (int e = t; e < M * (p.Cin - p.N); e += kT) {
-      const int m = e / (p.Cin - p.N), j = p.N + e % (p.Cin - p.N);
       const float sc = p.scale[m];
-      float v;
       if (j < p.C + 2 * p.L) {
         const int l = (j - p.C) % p.L;
         const float arg = tp::mul_rn(sc, tp::mul_rn((float)(1 << l), 3.14159265358979323846f));     // s * (2^l pi rounded to fp32)
         v = tp::sincos_sel(arg, j - p.C >= p.L ? 1 : 0);
       } else v = sc;
-      a0[m * p.Cin + j] = v;
+      v = lrelu(v, p.slope);
     }
-    __syncthreads();
-    for (int e = t; e < M * p.Cin; e += kT) {
-      const float v = lrelu(a0[e], p.slope);
-      a0[e] = v;
-      p.t0[e] = v;
-    }
+    a0[e] = v;
+    if (!R1) p.t0[e] = v;
   }
   __syncthreads();
   const int kin = R1 ? p.C : p.Cin;                // (R1: the encoding / scale entries of a0 are zero)
-  for (int e = t; e < M * p.H; e += kT) {
-    const int m = e / p.H, o = e - m * p.H;
-    float v = 0.f;
-    for (int j = 0; j < kin; ++j) v += w1[o * p.Cin + j] * a0[m * p.Cin + j];
-    if (!R1) { v = lrelu(v, p.slope); p.t1[e] = v; }
-    else v *= dl(p.t1[e], p.slope);
+  matvec4<false>(w1, p.Cin, a0, p.Cin, kin, p.H, M, ps, [&](int m, int o, float v) {
+    const int e = m * p.H + o;
+    if (!R1) { v = lrelu(v, p.slope); p.t1[e] = v; } else v *= dl(p.t1[e], p.slope);
     a1[e] = v;
-  }
-  __syncthreads();
-  for (int e = t; e < M * p.H; e += kT) {
-    const int m = e / p.H, o = e - m * p.H;
-    float v = 0.f;
-    for (int j = 0; j < p.H; ++j) v += w2[o * p.H + j] * a1[m * p.H + j];
-    if (!R1) { v = lrelu(v, p.slope); p.t2[e] = v; }
-    else v *= dl(p.t2[e], p.slope);
+  });
+  matvec4<false>(w2, p.H, a1, p.H, p.H, p.H, M, ps, [&](int m, int o, float v) {
+    const int e = m * p.H + o;
+    if (!R1) { v = lrelu(v, p.slope); p.t2[e] = v; } else v *= dl(p.t2[e], p.slope);
     a2[e] = v;
-  }
-  __syncthreads();
-  if (t < M && p.out != nullptr) {
-    float v = 0.f;
-    for (int j = 0; j < p.H; ++j) v += w3[j] * a2[t * p.H + j];
-    p.out[t] = v;
-  }
+  });
+  if (p.out != nullptr)
+    for (int m = wave; m < M; m += 4) {
+      float v = 0.f;
+      for (int j = lane; j < p.H; j += 64) v = fmaf(w3[j], a2[m * p.H + j], v);
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+      if (lane == 0) p.out[m] = v;
+    }
   if (!R1) return;
   // ---- R1: weight gradients of the double backward, rows in ascending order: d/dW3 = sum g a2, d/dW2 = sum e2 (x) a1, d/dW1 = sum e1 (x) a0
-  float* e1s = red; float* e2s = red + kMaxM * p.H;                 // the first pass' intermediates, staged once
+  float* e1s = ps; float* e2s = ps + kMaxM * p.H;                   // the first pass' intermediates, staged once
+  float* gs = e2s + kMaxM * p.H;
   for (int e = t; e < M * p.H; e += kT) { e1s[e] = p.e1[e]; e2s[e] = p.e2[e]; }
+  if (t < M) gs[t] = p.g[t];
   __syncthreads();
-  for (int j = t; j < p.H; j += kT) {
-    float v = 0.f;
-    for (int m = 0; m < M; ++m) v += p.g[m] * a2[m * p.H + j];
-    p.gW3[j] = v;
-  }
-  for (int e = t; e < p.H * p.H; e += kT) {
-    const int i = e / p.H, j = e - i * p.H;
-    float v = 0.f;
-    for (int m = 0; m < M; ++m) v += e2s[m * p.H + i] * a1[m * p.H + j];
-    p.gW2[e] = v;
-  }
-  for (int e = t; e < p.H * p.Cin; e += kT) {
-    const int i = e / p.Cin, j = e - i * p.Cin;
-    float v = 0.f;
-    for (int m = 0; m < M; ++m) v += e1s[m * p.H + i] * a0[m * p.Cin + j];
-    p.gW1[e] = v;
-  }
+  outer_rows(p.gW3, gs, 1, a2, p.H, p.H, 0, p.H, M, false);          // (i = 0: u[m * 1 + 0] = g[m])
+  outer_rows(p.gW2, e2s, p.H, a1, p.H, p.H, 0, p.H * p.H, M, false);
+  outer_rows(p.gW1, e1s, p.H, a0, p.Cin, p.Cin, 0, p.H * p.Cin, M, false);
 }
 
 // ---------------------------------------------------------------------------------------------------------------- B
 __global__ __launch_bounds__(kT) void disc_tail_bwd_kernel(TailP p) {
   float* w1 = smem; float* w2 = w1 + p.H * p.Cin; float* w3 = w2 + p.H * p.H;
   float* s2 = w3 + p.H; float* s1 = s2 + kMaxM * p.H; float* gzs = s1 + kMaxM * p.H;      // e2, e1 [M,H]; gz rows [M + M2][N]
-  float* t0s = gzs + 2 * kMaxM * p.N;              // workgroup 0: t0 / t1 / t2 for the head's weight gradients
+  float* t0s = gzs + 2 * kMaxM * p.N; float* t1s = t0s + kMaxM * p.Cin; float* t2s = t1s + kMaxM * p.H;
+  float* gsm = t2s + kMaxM * p.H;                  // g [kMaxM]
+  float* ps = gsm + kMaxM;                         // [4][kMaxM][max(H, N, 64)]: matvec partial sums, then the data gradient's
   const int t = threadIdx.x, M = p.M, M2 = p.M2;
   stage_head_weights(p, w1, w2, w3);
+  for (int e = t; e < M * p.Cin; e += kT) t0s[e] = p.t0[e];
+  for (int e = t; e < M * p.H; e += kT) { t1s[e] = p.t1[e]; t2s[e] = p.t2[e]; }
+  for (int e = t; e < M2 * p.N; e += kT) gzs[M * p.N + e] = p.gy2[e];
+  if (t < M) gsm[t] = p.g[t];
   __syncthreads();
   // ---- the head's backward (recomputed by every workgroup: ~M (H + H H + H C) MACs)
   for (int e = t; e < M * p.H; e += kT) {
     const int m = e / p.H, o = e - m * p.H;
-    s2[e] = dl(p.t2[e], p.slope) * (w3[o] * p.g[m]);
+    s2[e] = dl(t2s[e], p.slope) * (w3[o] * gsm[m]);
   }
   __syncthreads();
-  for (int e = t; e < M * p.H; e += kT) {
-    const int m = e / p.H, j = e - m * p.H;
-    float v = 0.f;
-    for (int o = 0; o < p.H; ++o) v += w2[o * p.H + j] * s2[m * p.H + o];
-    s1[e] = v * dl(p.t1[e], p.slope);
-  }
-  __syncthreads();
-  for (int e = t; e < M * p.N; e += kT) {          // only the z part of e0 is anybody's gradient (N == C)
-    const int m = e / p.N, j = e - m * p.N;
-    float v = 0.f;
-    for (int o = 0; o < p.H; ++o) v += w1[o * p.Cin + j] * s1[m * p.H + o];
-    gzs[e] = v * dl(p.t0[(size_t)m * p.Cin + j], p.slope);
-  }
-  for (int e = t; e < M2 * p.N; e += kT) gzs[M * p.N + e] = p.gy2[e];
-  __syncthreads();
+  matvec4<true>(w2, p.H, s2, p.H, p.H, p.H, M, ps, [&](int m, int j, float v) { s1[m * p.H + j] = v * dl(t1s[m * p.H + j], p.slope); });
+  matvec4<true>(w1, p.Cin, s1, p.H, p.H, p.N, M, ps,                                          // only the z part of e0 is anybody's gradient (N == C)
+                [&](int m, int j, float v) { gzs[m * p.N + j] = v * dl(t0s[m * p.Cin + j], p.slope); });
   // ---- this workgroup's 64 columns of K: thread (kc, run) -- data gradient: run = quarter of the N rows of W0; weight gradient:
   // run = quarter of the N rows of gW0
   const int kc = t & 63, k = blockIdx.x * 64 + kc;
   const int run = __builtin_amdgcn_readfirstlane(t >> 6);
   const int per = (p.N + 3) / 4, n0 = run * per, n1 = min(p.N, n0 + per);
+  float xa[kMaxM], xb[kMaxM];
+  if (p.gW0 != nullptr) {                          // (issued before the data gradient's loop: one latency for both)
+#pragma unroll
+    for (int m = 0; m < kMaxM; ++m) {
+      xa[m] = (m < M && k < p.K) ? p.a[(size_t)m * p.K + k] : 0.f;
+      xb[m] = (m < M2 && k < p.K) ? p.a2[(size_t)m * p.K + k] : 0.f;
+    }
+  }
   if (p.c_a != nullptr) {
     float acc[kMaxM];
 #pragma unroll
@@ -239,25 +277,19 @@ __global__ __launch_bounds__(kT) void disc_tail_bwd_kernel(TailP p) {
           if (m < M) acc[m] = fmaf(gzs[m * p.N + n], wv, acc[m]);
       }
     }
-    float* part = t0s + kMaxM * (p.Cin + 2 * p.H);                  // [4][kMaxM][64]
 #pragma unroll
     for (int m = 0; m < kMaxM; ++m)
-      if (m < M) part[(run * kMaxM + m) * 64 + kc] = acc[m];
+      if (m < M) ps[(run * kMaxM + m) * 64 + kc] = acc[m];
     __syncthreads();
     for (int e = t; e < M * 64; e += kT) {
       const int m = e >> 6, c = e & 63, kk = blockIdx.x * 64 + c;
       if (kk < p.K)
-        p.c_a[(size_t)m * p.K + kk] = ((part[(0 * kMaxM + m) * 64 + c] + part[(1 * kMaxM + m) * 64 + c]) + part[(2 * kMaxM + m) * 64 + c]) +
-                                      part[(3 * kMaxM + m) * 64 + c];
+        p.c_a[(size_t)m * p.K + kk] = ((ps[(0 * kMaxM + m) * 64 + c] + ps[(1 * kMaxM + m) * 64 + c]) + ps[(2 * kMaxM + m) * 64 + c]) +
+                                      ps[(3 * kMaxM + m) * 64 + c];
     }
   }
   if (p.gW0 != nullptr && k < p.K) {
-    float xa[kMaxM], xb[kMaxM];
-#pragma unroll
-    for (int m = 0; m < kMaxM; ++m) {
-      xa[m] = m < M ? p.a[(size_t)m * p.K + k] : 0.f;
-      xb[m] = m < M2 ? p.a2[(size_t)m * p.K + k] : 0.f;
-    }
+#pragma unroll 4
     for (int n = n0; n < n1; ++n) {
       float v = 0.f;
 #pragma unroll
@@ -269,45 +301,32 @@ __global__ __launch_bounds__(kT) void disc_tail_bwd_kernel(TailP p) {
       p.gW0[(size_t)n * p.K + k] = v;
     }
   }
-  if (blockIdx.x != 0) return;
-  // ---- workgroup 0: what the caller keeps of the head's backward, and the head's weight gradients
-  for (int e = t; e < M * p.H; e += kT) {
-    if (p.e1 != nullptr) p.e1[e] = s1[e];
-    if (p.e2 != nullptr) p.e2[e] = s2[e];
+  // ---- what the caller keeps of the head's backward (workgroup 0), and the head's weight gradients, spread over the workgroups
+  if (blockIdx.x == 0) {
+    for (int e = t; e < M * p.H; e += kT) {
+      if (p.e1 != nullptr) p.e1[e] = s1[e];
+      if (p.e2 != nullptr) p.e2[e] = s2[e];
+    }
+    if (p.gz != nullptr)
+      for (int e = t; e < M * p.N; e += kT) p.gz[e] = gzs[e];
   }
-  if (p.gz != nullptr)
-    for (int e = t; e < M * p.N; e += kT) p.gz[e] = gzs[e];
   if (p.gW1 == nullptr) return;
-  float* t1s = t0s + kMaxM * p.Cin; float* t2s = t1s + kMaxM * p.H;
-  for (int e = t; e < M * p.Cin; e += kT) t0s[e] = p.t0[e];
-  for (int e = t; e < M * p.H; e += kT) { t1s[e] = p.t1[e]; t2s[e] = p.t2[e]; }
-  __syncthreads();
   const bool add = p.accumulate != 0;
-  for (int j = t; j < p.H; j += kT) {
-    float v = 0.f;
-    for (int m = 0; m < M; ++m) v += p.g[m] * t2s[m * p.H + j];
-    p.gW3[j] = add ? p.gW3[j] + v : v;
-  }
-  for (int e = t; e < p.H * p.H; e += kT) {
-    const int i = e / p.H, j = e - i * p.H;
-    float v = 0.f;
-    for (int m = 0; m < M; ++m) v += s2[m * p.H + i] * t1s[m * p.H + j];
-    p.gW2[e] = add ? p.gW2[e] + v : v;
-  }
-  for (int e = t; e < p.H * p.Cin; e += kT) {
-    const int i = e / p.Cin, j = e - i * p.Cin;
-    float v = 0.f;
-    for (int m = 0; m < M; ++m) v += s1[m * p.H + i] * t0s[m * p.Cin + j];
-    p.gW1[e] = add ? p.gW1[e] + v : v;
-  }
+  const int G = gridDim.x, b = blockIdx.x;
+  const int n1e = p.H * p.Cin, n2e = p.H * p.H;
+  outer_rows(p.gW1, s1, p.H, t0s, p.Cin, p.Cin, (int)((int64_t)n1e * b / G), (int)((int64_t)n1e * (b + 1) / G), M, add);
+  outer_rows(p.gW2, s2, p.H, t1s, p.H, p.H, (int)((int64_t)n2e * b / G), (int)((int64_t)n2e * (b + 1) / G), M, add);
+  outer_rows(p.gW3, gsm, 1, t2s, p.H, p.H, (int)((int64_t)p.H * b / G), (int)((int64_t)p.H * (b + 1) / G), M, add);
 }
 
+int imax3(int a, int b, int c) { return a > b ? (a > c ? a : c) : (b > c ? b : c); }
 size_t lds_fwd(const TailP& p) {
-  return sizeof(float) * ((size_t)p.H * p.Cin + (size_t)p.H * p.H + p.H + (size_t)kMaxM * (p.Cin + 2 * p.H) + (size_t)kMaxM * kT);
+  const size_t ps = (size_t)4 * kMaxM * imax3(p.H, p.N, 1), r1 = (size_t)2 * kMaxM * p.H + kMaxM;
+  return sizeof(float) * ((size_t)p.H * p.Cin + (size_t)p.H * p.H + p.H + (size_t)kMaxM * (p.Cin + 2 * p.H) + (ps > r1 ? ps : r1));
 }
 size_t lds_bwd(const TailP& p) {
   return sizeof(float) * ((size_t)p.H * p.Cin + (size_t)p.H * p.H + p.H + (size_t)kMaxM * 2 * p.H + (size_t)2 * kMaxM * p.N +
-                          (size_t)kMaxM * (p.Cin + 2 * p.H) + (size_t)4 * kMaxM * 64);
+                          (size_t)kMaxM * (p.Cin + 2 * p.H) + kMaxM + (size_t)4 * kMaxM * imax3(p.H, p.N, 64));
 }
 
 int fill(TailP* q, const tp_disc_tail_args* a, const char* what) {
@@ -321,7 +340,6 @@ int fill(TailP* q, const tp_disc_tail_args* a, const char* what) {
   q->gW0 = a->gW0; q->gy2 = a->gy2; q->a2 = a->a2; q->gW1 = a->gW1; q->gW2 = a->gW2; q->gW3 = a->gW3;
   q->ws = (float*)a->workspace; q->ticket = a->ticket; q->accumulate = a->accumulate_gw;
   if (!q->W0 || !q->W1 || !q->W2 || !q->W3 || !q->t0 || !q->t1 || !q->t2) { tp::set_error("%s: null pointer", what); return -1; }
-  if ((size_t)kMaxM * 2 * q->H > (size_t)kMaxM * kT) { tp::set_error("%s: head too wide", what); return -1; }
   return 0;
 }
 

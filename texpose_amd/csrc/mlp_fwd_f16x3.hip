@@ -701,6 +701,18 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_f16x3_kernel(Params P) {
         if (li == L0) {
           TP_THREAD_IDS;
           const float x0 = save[0 * kThreads], x1 = save[1 * kThreads], x2 = save[2 * kThreads];
+#ifdef TP_PE_PER_OCTAVE
+          // (A/B build, make pe_octave: round 3's staging -- one fp64 range reduction per (coordinate, octave) pair, 15 per lane)
+#pragma unroll 5
+          for (int i = 0; i < 15; ++i) {
+            const int pi_ = hh * 15 + i, c = (pi_ * 205) >> 11, l = pi_ - c * 10;
+            const float xc = pick3(c, x0, x1, x2);
+            float sv, cv;
+            tp::sincos_both(tp::mul_rn(xc, ldexpf(3.14159274101257324f, l)), sv, cv);
+            stage_slot(st, tid & ~32, 20 * c + l, sv);
+            stage_slot(st, tid & ~32, 20 * c + 10 + l, cv);
+          }
+#else
           // ONE fp64 range reduction per coordinate, then the ten octaves by angle doubling (tp::sincos_f64: the argument of octave
           // l is exactly 2^l * fl32(x pi_f32)).  Lane hh of the sample's lane pair runs the chain of coordinate 2 hh and stages its
           // sin AND cos entries (slots 20 c + l, 20 c + 10 + l); both lanes run the chain of coordinate 1, lane 0 stages its sin
@@ -715,6 +727,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_f16x3_kernel(Params P) {
             stage_slot(st, tid & ~32, 20 + 10 * hh + l, (float)(hh ? eb.c : eb.s));
             if (l < 9) { tp::sincos_double(ea); tp::sincos_double(eb); }
           }
+#endif
           if (hh) {
             stage(st, tid, 3, 4, x0); stage(st, tid, 3, 5, x1); stage(st, tid, 3, 6, x2); stage(st, tid, 3, 7, 0.0f);
           }
@@ -745,6 +758,18 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_f16x3_kernel(Params P) {
         const float x0 = save[0 * kThreads], x1 = save[1 * kThreads], x2 = save[2 * kThreads];
         const float vu0 = save[3 * kThreads], vu1 = save[4 * kThreads], vu2 = save[5 * kThreads];
         const int br = __float_as_int(save[6 * kThreads]);
+#ifdef TP_PE_PER_OCTAVE
+#pragma unroll 3
+        for (int i = 0; i < 6; ++i) {
+          const int pi_ = hh * 6 + i, c = pi_ >> 2, l = pi_ & 3;
+          const float vc = pick3(c, vu0, vu1, vu2);
+          float sv, cv;
+          tp::sincos_both(tp::mul_rn(vc, ldexpf(3.14159274101257324f, l)), sv, cv);
+          stage_slot(st, tid & ~32, 3 + 8 * c + l, sv);
+          stage_slot(st, tid & ~32, 3 + 8 * c + 4 + l, cv);
+          if (SAVE && live) { sx[blk_off(3 + 8 * c + l, j)] = sv; sx[blk_off(3 + 8 * c + 4 + l, j)] = cv; }
+        }
+#else
         // the view encoding (4 octaves) the same way: chain of coordinate 2 hh (sin and cos), chain of coordinate 1 (lane 0 its sin
         // entries, lane 1 its cos entries); slot 3 + 8 c + l = sin, + 4 = cos
         {
@@ -762,6 +787,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_f16x3_kernel(Params P) {
             if (l < 3) { tp::sincos_double(ea); tp::sincos_double(eb); }
           }
         }
+#endif
         if (hh == 0) {
           stage(st, tid, 0, 0, vu0); stage(st, tid, 0, 1, vu1); stage(st, tid, 0, 2, vu2);
           if (SAVE && live) { sx[blk_off(0, j)] = vu0; sx[blk_off(1, j)] = vu1; sx[blk_off(2, j)] = vu2; }

@@ -604,25 +604,33 @@ def _sn_tickets(dev) -> Optional[int]:
 
 
 @_on_tensor_device
-def spectral_norm_fwd(weights, us, vs, training: bool, keep_uv: bool = False):
+def spectral_norm_fwd(weights, us, vs, training: bool, keep_uv: bool = False, out=None):
     """weights[i] [out, ...] (contiguous), us[i] [out], vs[i] [K]: one power iteration per weight when ``training``
     (u, v updated IN PLACE, like torch.nn.utils.spectral_norm), then W_sn = W / sigma.  Returns (W_sn list, sigma
     list of 1-element tensors).  All weights of a module in five launches (three with TP_SN_FUSED=1: slower, see _sn_tickets).  ``keep_uv``: also returns copies of u / v as
-    they stand after this call (written by the last launch) as a third / fourth list."""
+    they stand after this call (written by the last launch) as a third / fourth list.
+    ``out`` = (W_sn list, sigma list, u-copy list, v-copy list, work list) of pre-allocated tensors (spectral_norm_buffers): nothing is
+    allocated -- the captured training step writes the NEXT iteration's normalised weights into static buffers."""
     lib = _lib.load()
     n = len(weights)
     arr = (_lib.SnWeight * n)()
     outs, sigmas, keep = [], [], []
     u_copies = v_copies = None
-    if keep_uv:
+    if out is not None:
+        keep_uv = True
+        u_copies, v_copies = list(out[2]), list(out[3])
+    elif keep_uv:
         flat = torch.empty(sum(u.numel() + v.numel() for u, v in zip(us, vs)), device=us[0].device)
         parts = flat.split([t.numel() for t in list(us) + list(vs)])
         u_copies, v_copies = list(parts[:n]), list(parts[n:])
     for i, (w, u, v) in enumerate(zip(weights, us, vs)):
         w = _f32(w, "weight")
         rows, cols = w.shape[0], w.numel() // w.shape[0]
-        o, sg = torch.empty_like(w), torch.empty(1, device=w.device)
-        wk = torch.empty(lib.tp_sn_work_floats(rows, cols), device=w.device)
+        if out is not None:
+            o, sg, wk = _out_like(out[0][i], w), out[1][i], out[4][i]
+        else:
+            o, sg = torch.empty_like(w), torch.empty(1, device=w.device)
+            wk = torch.empty(lib.tp_sn_work_floats(rows, cols), device=w.device)
         a = arr[i]
         a.weight, a.u, a.v, a.weight_sn, a.sigma, a.work = w.data_ptr(), u.data_ptr(), v.data_ptr(), o.data_ptr(), sg.data_ptr(), wk.data_ptr()
         a.rows, a.cols = rows, cols
@@ -631,6 +639,15 @@ def spectral_norm_fwd(weights, us, vs, training: bool, keep_uv: bool = False):
         outs.append(o); sigmas.append(sg); keep += [w, wk]
     check(lib.tp_sn_fwd(arr, n, int(bool(training)), _sn_tickets(weights[0].device), _stream()), "tp_sn_fwd")
     return (outs, sigmas, u_copies, v_copies) if keep_uv else (outs, sigmas)
+
+
+def spectral_norm_buffers(weights, us, vs):
+    """Pre-allocated outputs of one `spectral_norm_fwd(..., out=)` call: (W_sn, sigma, u copies, v copies, work)."""
+    lib = _lib.load()
+    dev = weights[0].device
+    return ([torch.empty_like(w, memory_format=torch.contiguous_format) for w in weights], [torch.empty(1, device=dev) for _ in weights],
+            [torch.empty_like(u) for u in us], [torch.empty_like(v) for v in vs],
+            [torch.empty(lib.tp_sn_work_floats(w.shape[0], w.numel() // w.shape[0]), device=dev) for w in weights])
 
 
 @_on_tensor_device
