@@ -52,55 +52,73 @@ struct TailP {
   int accumulate;        // B: gW1..3 += (the R1 pass wrote its share there first)
 };
 
+__device__ __forceinline__ int imax_dev(int a, int b) { return a > b ? a : b; }
 __device__ __forceinline__ float lrelu(float v, float s) { return v > 0.f ? v : v * s; }
 __device__ __forceinline__ float dl(float t, float s) { return t > 0.f ? 1.f : s; }
 
 extern __shared__ __attribute__((aligned(16))) float smem[];
 
-// W1 | W2 | W3 into LDS (37 KB at ndf = 64; L2 hits for all but the first workgroup): 16-byte loads, four in flight per thread
+// diagnostic build (make tail_timing, tools/tail_bench.py --timing): 100 MHz timestamps of one workgroup's sections
+#ifdef TP_TAIL_TIMING
+__device__ unsigned long long g_tail_stamps[16];
+#define TSTAMP(i, cond) do { __syncthreads(); if ((cond) && threadIdx.x == 0) g_tail_stamps[i] = wall_clock64(); } while (0)
+#else
+#define TSTAMP(i, cond) do { } while (0)
+#endif
+
+// W1 | W2 | W3 into LDS (37 KB at ndf = 64; L2 hits for all but the first workgroup): 16-byte loads, four in flight per thread.
+// W2's rows are stored with stride H + 1: the forward reads W2[o][j] with lanes = o, and a row stride of H = 64 floats puts all 64
+// lanes on one LDS bank (measured: the 64 x 64 product took 2.6 us against 1.2 us for the 64 x 73 one, whose stride is odd).
 __device__ __forceinline__ void stage_head_weights(const TailP& p, float* w1, float* w2, float* w3) {
-  const int n1 = p.H * p.Cin, n2 = p.H * p.H, t = threadIdx.x;
-  const bool vec = (((uintptr_t)p.W1 | (uintptr_t)p.W2) & 15) == 0 && (n1 & 3) == 0 && (n2 & 3) == 0;
+  const int n1 = p.H * p.Cin, n2 = p.H * p.H, t = threadIdx.x, ld2 = p.H + 1;
+  const bool vec = (((uintptr_t)p.W1 | (uintptr_t)p.W2) & 15) == 0 && (n1 & 3) == 0 && (p.H & 3) == 0;
   if (vec) {
     const f32x4* s1 = reinterpret_cast<const f32x4*>(p.W1);
     const f32x4* s2 = reinterpret_cast<const f32x4*>(p.W2);
     f32x4* d1 = reinterpret_cast<f32x4*>(w1);
-    f32x4* d2 = reinterpret_cast<f32x4*>(w2);
 #pragma unroll 4
     for (int i = t; i < n1 / 4; i += kT) d1[i] = s1[i];
 #pragma unroll 4
-    for (int i = t; i < n2 / 4; i += kT) d2[i] = s2[i];
+    for (int i = t; i < n2 / 4; i += kT) {
+      const f32x4 v = s2[i];
+      const int e = 4 * i, r = e / p.H, c = e - r * p.H;              // (H % 4 == 0: the four values share a row)
+      float* d = w2 + r * ld2 + c;
+      d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+    }
   } else {
     for (int i = t; i < n1; i += kT) w1[i] = p.W1[i];
-    for (int i = t; i < n2; i += kT) w2[i] = p.W2[i];
+    for (int i = t; i < n2; i += kT) w2[(i / p.H) * ld2 + i % p.H] = p.W2[i];
   }
   for (int i = t; i < p.H; i += kT) w3[i] = p.W3[i];
 }
 
-// out[m][o] = f( sum_j W[o * ldw + j] * x[m * ldx + j] ), j < n_in, o < n_out, m < M  (W row-major [n_out][ldw] in LDS, x [M][ldx] in LDS):
+// out[m][o] = f( sum_j W[o * ldw + j] * x[m * ldx + j] ), j < n_in, o < n_out, m < M  (W row-major [n_out][ldw] in LDS, x [kMaxM][ldx] in LDS):
 // wave w takes the quarter [w n_in / 4, ...) of j for every o (lanes = o: row stride ldw is odd or the rows are read along j -- no
-// bank conflicts either way), M accumulators per thread, the four partial sums meet in `ps` [4][kMaxM][n_out] and are added in wave
-// order.  TRANS: W is read transposed (W[j * ldw + o]).  `fin(m, o, v)` consumes the total.
-template <bool TRANS, class Fin>
+// bank conflicts either way), MB >= M accumulators per thread (rows beyond M hold whatever the LDS rows hold: never consumed), the
+// four partial sums meet in `ps` [4][kMaxM][n_out] and are added in wave order.  TRANS: W is read transposed (W[j * ldw + o]).
+// Every j step issues its 1 + MB LDS reads before its MB FMAs, four steps unrolled: the loop runs at LDS issue rate, not at LDS
+// latency per FMA (a first version with a run-time row count predicated every FMA: 6.5 us per 64 x 73 product; profiles/r4).
+template <bool TRANS, int MB, class Fin>
 __device__ __forceinline__ void matvec4(const float* W, int ldw, const float* x, int ldx, int n_in, int n_out, int M, float* ps, Fin fin) {
   const int t = threadIdx.x, w = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
   const int per = (n_in + 3) >> 2, j0 = min(n_in, w * per), j1 = min(n_in, j0 + per);
   for (int o0 = 0; o0 < n_out; o0 += 64) {
-    const int o = o0 + lane;
-    float acc[kMaxM];
+    const int o = min(o0 + lane, n_out - 1);
+    float acc[MB];
 #pragma unroll
-    for (int m = 0; m < kMaxM; ++m) acc[m] = 0.f;
-    if (o < n_out) {
+    for (int m = 0; m < MB; ++m) acc[m] = 0.f;
 #pragma unroll 4
-      for (int j = j0; j < j1; ++j) {
-        const float wv = TRANS ? W[j * ldw + o] : W[o * ldw + j];
+    for (int j = j0; j < j1; ++j) {
+      const float wv = TRANS ? W[j * ldw + o] : W[o * ldw + j];
+      float xv[MB];
 #pragma unroll
-        for (int m = 0; m < kMaxM; ++m)
-          if (m < M) acc[m] = fmaf(wv, x[m * ldx + j], acc[m]);
-      }
+      for (int m = 0; m < MB; ++m) xv[m] = x[m * ldx + j];
 #pragma unroll
-      for (int m = 0; m < kMaxM; ++m)
-        if (m < M) ps[(w * kMaxM + m) * n_out + o] = acc[m];
+      for (int m = 0; m < MB; ++m) acc[m] = fmaf(wv, xv[m], acc[m]);
+    }
+    if (o0 + lane < n_out) {
+#pragma unroll
+      for (int m = 0; m < MB; ++m) ps[(w * kMaxM + m) * n_out + o] = acc[m];
     }
   }
   __syncthreads();
@@ -111,55 +129,65 @@ __device__ __forceinline__ void matvec4(const float* W, int ldw, const float* x,
   __syncthreads();
 }
 
-// out[i][j] (+)= sum_m u[m * ldu + i] * v[m * ldv + j] for the elements e = i * cols + j in [e0, e1) (u, v in LDS; rows ascending)
-__device__ __forceinline__ void outer_rows(float* out, const float* u, int ldu, const float* v, int ldv, int cols, int e0, int e1, int M, bool add) {
+// out[i][j] (+)= sum_m u[m * ldu + i] * v[m * ldv + j] for the elements e = i * cols + j in [e0, e1) (u, v in LDS; rows ascending;
+// rows M .. MB-1 of u / v are ZERO or finite garbage times zero: the callers zero-fill u beyond M)
+template <int MB>
+__device__ __forceinline__ void outer_rows(float* out, const float* u, int ldu, const float* v, int ldv, int cols, int e0, int e1, bool add) {
   for (int e = e0 + (int)threadIdx.x; e < e1; e += kT) {
     const int i = e / cols, j = e - i * cols;
     const float old = add ? out[e] : 0.f;
+    float uu[MB], vv[MB];
+#pragma unroll
+    for (int m = 0; m < MB; ++m) { uu[m] = u[m * ldu + i]; vv[m] = v[m * ldv + j]; }
     float acc = 0.f;
 #pragma unroll
-    for (int m = 0; m < kMaxM; ++m)
-      if (m < M) acc = fmaf(u[m * ldu + i], v[m * ldv + j], acc);
+    for (int m = 0; m < MB; ++m) acc = fmaf(uu[m], vv[m], acc);
     out[e] = old + acc;
   }
 }
 
 // ---------------------------------------------------------------------------------------------------------------- F / R1
-template <bool R1>
+// MB: compile-time row bucket (4 / 8 / 16 >= M): the row loops are unrolled without predicates; rows M .. MB-1 of the LDS row arrays
+// are zero (filled at kernel start) or never consumed.
+template <bool R1, int MB>
 __global__ __launch_bounds__(kT) void disc_tail_fwd_kernel(TailP p) {
-  float* w1 = smem; float* w2 = w1 + p.H * p.Cin; float* w3 = w2 + p.H * p.H;
+  float* w1 = smem; float* w2 = w1 + p.H * p.Cin; float* w3 = w2 + p.H * (p.H + 1);
   float* a0 = w3 + p.H; float* a1 = a0 + kMaxM * p.Cin; float* a2 = a1 + kMaxM * p.H;
-  float* ps = a2 + kMaxM * p.H;                    // [4][kMaxM][max(H, N)] partial sums; R1: then e1 | e2 [M][H] each
+  float* ps = a2 + kMaxM * p.H;                    // [4][kMaxM][max(H, N)] partial sums; R1: then e1 | e2 [kMaxM][H] each, g [kMaxM]
   __shared__ int last;
   __shared__ float wsum[4][kMaxM];
   const int t = threadIdx.x, n = blockIdx.x / p.S, s = blockIdx.x % p.S, M = p.M;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
+  TSTAMP(0, blockIdx.x == 0);
+  for (int e = t; e < kMaxM * (p.Cin + 2 * p.H); e += kT) a0[e] = 0.f;                     // a0 | a1 | a2: rows >= M stay zero
+  if (R1)
+    for (int e = t; e < 2 * kMaxM * p.H + kMaxM; e += kT) (ps + 4 * kMaxM * imax_dev(p.H, p.N))[e] = 0.f;      // e1 | e2 | g likewise
   stage_head_weights(p, w1, w2, w3);               // (every workgroup: whichever arrives last has them; issued first, consumed last)
+  TSTAMP(1, blockIdx.x == 0);
   // ---- this workgroup's slice of z[:, n]: k in [k0, k1), 16-byte loads, all rows' operands in flight together
   const int per = ((p.K / 4 + p.S - 1) / p.S) * 4, k0 = min(p.K, s * per), k1 = min(p.K, k0 + per);
   const float* wr = p.W0 + (size_t)n * p.K;
-  float acc[kMaxM];
+  float acc[MB];
 #pragma unroll
-  for (int r = 0; r < kMaxM; ++r) acc[r] = 0.f;
+  for (int r = 0; r < MB; ++r) acc[r] = 0.f;
 #pragma unroll 2
   for (int k = k0 + 4 * t; k + 3 < k1; k += 4 * kT) {
     const f32x4 wv = *reinterpret_cast<const f32x4*>(wr + k);
+    f32x4 xv[MB];
 #pragma unroll
-    for (int r = 0; r < kMaxM; ++r)
-      if (r < M) {
-        const f32x4 xv = *reinterpret_cast<const f32x4*>(p.a + (size_t)r * p.K + k);
-        acc[r] = fmaf(xv[3], wv[3], fmaf(xv[2], wv[2], fmaf(xv[1], wv[1], fmaf(xv[0], wv[0], acc[r]))));
-      }
+    for (int r = 0; r < MB; ++r) xv[r] = *reinterpret_cast<const f32x4*>(p.a + (size_t)min(r, M - 1) * p.K + k);    // (rows >= M: a valid row, unused)
+#pragma unroll
+    for (int r = 0; r < MB; ++r) acc[r] = fmaf(xv[r][3], wv[3], fmaf(xv[r][2], wv[2], fmaf(xv[r][1], wv[1], fmaf(xv[r][0], wv[0], acc[r]))));
   }
+  TSTAMP(2, blockIdx.x == 0);
   // wave butterfly (fixed order), then the four waves in wave order
 #pragma unroll
-  for (int r = 0; r < kMaxM; ++r)
-    if (r < M) {
-      float v = acc[r];
+  for (int r = 0; r < MB; ++r) {
+    float v = acc[r];
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-      if (lane == 0) wsum[wave][r] = v;
-    }
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if (lane == 0) wsum[wave][r] = v;
+  }
   __syncthreads();
   // ---- hand-over (patch_conv.hip reduce_tiles: sc1 stores, the storing wave drained, ONE agent-scope add behind the barrier)
   if (t < M) {
@@ -170,16 +198,30 @@ __global__ __launch_bounds__(kT) void disc_tail_fwd_kernel(TailP p) {
   __syncthreads();
   if (t == 0) last = __hip_atomic_fetch_add(p.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
   __syncthreads();
+  TSTAMP(3, blockIdx.x == 0);
   if (!last) return;
+  TSTAMP(4, true);
   if (t == 0) __hip_atomic_store(p.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // ready for the next launch
   // z[m][nn] = sum of the S slices in slice order; the rest of a0
+  float* e1s = ps + 4 * kMaxM * imax_dev(p.H, p.N); float* e2s = e1s + kMaxM * p.H; float* gs = e2s + kMaxM * p.H;
+  if (R1) {                                        // (the first pass' intermediates: loads in flight beside the z sums)
+    for (int e = t; e < M * p.H; e += kT) { e1s[e] = p.e1[e]; e2s[e] = p.e2[e]; }
+    if (t < M) gs[t] = p.g[t];
+  }
   for (int e = t; e < M * p.Cin; e += kT) {
     const int m = e / p.Cin, j = e - m * p.Cin;
     float v;
     if (j < p.N) {
       float z = 0.f;
-      for (int ss = 0; ss < p.S; ++ss)
-        z += __hip_atomic_load(p.ws + ((size_t)j * p.S + ss) * kMaxM + m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int s0 = 0; s0 < p.S; s0 += 8) {            // eight slices' loads in flight, added in slice order
+        float part[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          part[u] = __hip_atomic_load(p.ws + ((size_t)j * p.S + min(s0 + u, p.S - 1)) * kMaxM + m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (s0 + u < p.S) z += part[u];
+      }
       v = R1 ? dl(p.t0[e], p.slope) * z : lrelu(z, p.slope);                 // R1: a0 = d(t0) [c, 0]
     } else if (R1) {
       v = 0.f;
@@ -197,16 +239,19 @@ __global__ __launch_bounds__(kT) void disc_tail_fwd_kernel(TailP p) {
   }
   __syncthreads();
   const int kin = R1 ? p.C : p.Cin;                // (R1: the encoding / scale entries of a0 are zero)
-  matvec4<false>(w1, p.Cin, a0, p.Cin, kin, p.H, M, ps, [&](int m, int o, float v) {
+  TSTAMP(5, true);
+  matvec4<false, MB>(w1, p.Cin, a0, p.Cin, kin, p.H, M, ps, [&](int m, int o, float v) {
     const int e = m * p.H + o;
     if (!R1) { v = lrelu(v, p.slope); p.t1[e] = v; } else v *= dl(p.t1[e], p.slope);
     a1[e] = v;
   });
-  matvec4<false>(w2, p.H, a1, p.H, p.H, p.H, M, ps, [&](int m, int o, float v) {
+  TSTAMP(6, true);
+  matvec4<false, MB>(w2, p.H + 1, a1, p.H, p.H, p.H, M, ps, [&](int m, int o, float v) {
     const int e = m * p.H + o;
     if (!R1) { v = lrelu(v, p.slope); p.t2[e] = v; } else v *= dl(p.t2[e], p.slope);
     a2[e] = v;
   });
+  TSTAMP(7, true);
   if (p.out != nullptr)
     for (int m = wave; m < M; m += 4) {
       float v = 0.f;
@@ -215,71 +260,77 @@ __global__ __launch_bounds__(kT) void disc_tail_fwd_kernel(TailP p) {
       for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
       if (lane == 0) p.out[m] = v;
     }
+  TSTAMP(8, true);
   if (!R1) return;
   // ---- R1: weight gradients of the double backward, rows in ascending order: d/dW3 = sum g a2, d/dW2 = sum e2 (x) a1, d/dW1 = sum e1 (x) a0
-  float* e1s = ps; float* e2s = ps + kMaxM * p.H;                   // the first pass' intermediates, staged once
-  float* gs = e2s + kMaxM * p.H;
-  for (int e = t; e < M * p.H; e += kT) { e1s[e] = p.e1[e]; e2s[e] = p.e2[e]; }
-  if (t < M) gs[t] = p.g[t];
-  __syncthreads();
-  outer_rows(p.gW3, gs, 1, a2, p.H, p.H, 0, p.H, M, false);          // (i = 0: u[m * 1 + 0] = g[m])
-  outer_rows(p.gW2, e2s, p.H, a1, p.H, p.H, 0, p.H * p.H, M, false);
-  outer_rows(p.gW1, e1s, p.H, a0, p.Cin, p.Cin, 0, p.H * p.Cin, M, false);
+  outer_rows<MB>(p.gW3, gs, 1, a2, p.H, p.H, 0, p.H, false);          // (i = 0: u[m * 1 + 0] = g[m])
+  outer_rows<MB>(p.gW2, e2s, p.H, a1, p.H, p.H, 0, p.H * p.H, false);
+  outer_rows<MB>(p.gW1, e1s, p.H, a0, p.Cin, p.Cin, 0, p.H * p.Cin, false);
+  TSTAMP(9, true);
 }
 
 // ---------------------------------------------------------------------------------------------------------------- B
+template <int MB>
 __global__ __launch_bounds__(kT) void disc_tail_bwd_kernel(TailP p) {
-  float* w1 = smem; float* w2 = w1 + p.H * p.Cin; float* w3 = w2 + p.H * p.H;
-  float* s2 = w3 + p.H; float* s1 = s2 + kMaxM * p.H; float* gzs = s1 + kMaxM * p.H;      // e2, e1 [M,H]; gz rows [M + M2][N]
+  float* w1 = smem; float* w2 = w1 + p.H * p.Cin; float* w3 = w2 + p.H * (p.H + 1);
+  float* s2 = w3 + p.H; float* s1 = s2 + kMaxM * p.H; float* gzs = s1 + kMaxM * p.H;      // e2, e1 [kMaxM,H]; gz rows [2 kMaxM][N]
   float* t0s = gzs + 2 * kMaxM * p.N; float* t1s = t0s + kMaxM * p.Cin; float* t2s = t1s + kMaxM * p.H;
   float* gsm = t2s + kMaxM * p.H;                  // g [kMaxM]
   float* ps = gsm + kMaxM;                         // [4][kMaxM][max(H, N, 64)]: matvec partial sums, then the data gradient's
   const int t = threadIdx.x, M = p.M, M2 = p.M2;
+  TSTAMP(0, blockIdx.x == 0);
+  // rows >= M (>= M2 of the extra rows) of every row array are zero: disjoint from what is written below, no barrier in between
+  for (int e = t + M * p.H; e < kMaxM * p.H; e += kT) { s2[e] = 0.f; s1[e] = 0.f; t1s[e] = 0.f; t2s[e] = 0.f; }
+  for (int e = t + M * p.N; e < kMaxM * p.N; e += kT) gzs[e] = 0.f;
+  for (int e = t + M2 * p.N; e < kMaxM * p.N; e += kT) gzs[kMaxM * p.N + e] = 0.f;
+  for (int e = t + M * p.Cin; e < kMaxM * p.Cin; e += kT) t0s[e] = 0.f;
+  if (t >= M && t < kMaxM) gsm[t] = 0.f;
   stage_head_weights(p, w1, w2, w3);
   for (int e = t; e < M * p.Cin; e += kT) t0s[e] = p.t0[e];
   for (int e = t; e < M * p.H; e += kT) { t1s[e] = p.t1[e]; t2s[e] = p.t2[e]; }
-  for (int e = t; e < M2 * p.N; e += kT) gzs[M * p.N + e] = p.gy2[e];
+  for (int e = t; e < M2 * p.N; e += kT) gzs[kMaxM * p.N + e] = p.gy2[e];       // (the extra rows start at row kMaxM)
   if (t < M) gsm[t] = p.g[t];
   __syncthreads();
+  TSTAMP(1, blockIdx.x == 0);
   // ---- the head's backward (recomputed by every workgroup: ~M (H + H H + H C) MACs)
   for (int e = t; e < M * p.H; e += kT) {
     const int m = e / p.H, o = e - m * p.H;
     s2[e] = dl(t2s[e], p.slope) * (w3[o] * gsm[m]);
   }
   __syncthreads();
-  matvec4<true>(w2, p.H, s2, p.H, p.H, p.H, M, ps, [&](int m, int j, float v) { s1[m * p.H + j] = v * dl(t1s[m * p.H + j], p.slope); });
-  matvec4<true>(w1, p.Cin, s1, p.H, p.H, p.N, M, ps,                                          // only the z part of e0 is anybody's gradient (N == C)
-                [&](int m, int j, float v) { gzs[m * p.N + j] = v * dl(t0s[m * p.Cin + j], p.slope); });
+  matvec4<true, MB>(w2, p.H + 1, s2, p.H, p.H, p.H, M, ps, [&](int m, int j, float v) { s1[m * p.H + j] = v * dl(t1s[m * p.H + j], p.slope); });
+  matvec4<true, MB>(w1, p.Cin, s1, p.H, p.H, p.N, M, ps,                                      // only the z part of e0 is anybody's gradient (N == C)
+                    [&](int m, int j, float v) { gzs[m * p.N + j] = v * dl(t0s[m * p.Cin + j], p.slope); });
+  TSTAMP(2, blockIdx.x == 0);
   // ---- this workgroup's 64 columns of K: thread (kc, run) -- data gradient: run = quarter of the N rows of W0; weight gradient:
   // run = quarter of the N rows of gW0
-  const int kc = t & 63, k = blockIdx.x * 64 + kc;
+  const int kc = t & 63, k = blockIdx.x * 64 + kc, kk0 = min(k, p.K - 1);
   const int run = __builtin_amdgcn_readfirstlane(t >> 6);
   const int per = (p.N + 3) / 4, n0 = run * per, n1 = min(p.N, n0 + per);
-  float xa[kMaxM], xb[kMaxM];
+  float xa[MB], xb[MB];
   if (p.gW0 != nullptr) {                          // (issued before the data gradient's loop: one latency for both)
 #pragma unroll
-    for (int m = 0; m < kMaxM; ++m) {
-      xa[m] = (m < M && k < p.K) ? p.a[(size_t)m * p.K + k] : 0.f;
-      xb[m] = (m < M2 && k < p.K) ? p.a2[(size_t)m * p.K + k] : 0.f;
+    for (int m = 0; m < MB; ++m) {
+      xa[m] = p.a[(size_t)min(m, M - 1) * p.K + kk0];
+      xb[m] = M2 > 0 ? p.a2[(size_t)min(m, M2 - 1) * p.K + kk0] : 0.f;
     }
   }
   if (p.c_a != nullptr) {
-    float acc[kMaxM];
+    float acc[MB];
 #pragma unroll
-    for (int m = 0; m < kMaxM; ++m) acc[m] = 0.f;
-    if (k < p.K) {
-      const float* wc = p.W0 + k;
-#pragma unroll 16
-      for (int n = n0; n < n1; ++n) {
-        const float wv = wc[(size_t)n * p.K];
+    for (int m = 0; m < MB; ++m) acc[m] = 0.f;
+    const float* wc = p.W0 + kk0;
+#pragma unroll 4
+    for (int n = n0; n < n1; ++n) {
+      const float wv = wc[(size_t)n * p.K];
+      float gv[MB];
 #pragma unroll
-        for (int m = 0; m < kMaxM; ++m)
-          if (m < M) acc[m] = fmaf(gzs[m * p.N + n], wv, acc[m]);
-      }
+      for (int m = 0; m < MB; ++m) gv[m] = gzs[m * p.N + n];
+#pragma unroll
+      for (int m = 0; m < MB; ++m) acc[m] = fmaf(gv[m], wv, acc[m]);
     }
 #pragma unroll
-    for (int m = 0; m < kMaxM; ++m)
-      if (m < M) ps[(run * kMaxM + m) * 64 + kc] = acc[m];
+    for (int m = 0; m < MB; ++m) ps[(run * kMaxM + m) * 64 + kc] = acc[m];
     __syncthreads();
     for (int e = t; e < M * 64; e += kT) {
       const int m = e >> 6, c = e & 63, kk = blockIdx.x * 64 + c;
@@ -288,19 +339,22 @@ __global__ __launch_bounds__(kT) void disc_tail_bwd_kernel(TailP p) {
                                       ps[(3 * kMaxM + m) * 64 + c];
     }
   }
+  TSTAMP(3, blockIdx.x == 0);
   if (p.gW0 != nullptr && k < p.K) {
-#pragma unroll 4
+#pragma unroll 2
     for (int n = n0; n < n1; ++n) {
+      float ga[MB], gb[MB];
+#pragma unroll
+      for (int m = 0; m < MB; ++m) { ga[m] = gzs[m * p.N + n]; gb[m] = gzs[(kMaxM + m) * p.N + n]; }      // (rows >= M / M2: zero)
       float v = 0.f;
 #pragma unroll
-      for (int m = 0; m < kMaxM; ++m)
-        if (m < M) v = fmaf(gzs[m * p.N + n], xa[m], v);
+      for (int m = 0; m < MB; ++m) v = fmaf(ga[m], xa[m], v);
 #pragma unroll
-      for (int m = 0; m < kMaxM; ++m)
-        if (m < M2) v = fmaf(gzs[(M + m) * p.N + n], xb[m], v);
+      for (int m = 0; m < MB; ++m) v = fmaf(gb[m], xb[m], v);
       p.gW0[(size_t)n * p.K + k] = v;
     }
   }
+  TSTAMP(4, blockIdx.x == 0);
   // ---- what the caller keeps of the head's backward (workgroup 0), and the head's weight gradients, spread over the workgroups
   if (blockIdx.x == 0) {
     for (int e = t; e < M * p.H; e += kT) {
@@ -314,18 +368,19 @@ __global__ __launch_bounds__(kT) void disc_tail_bwd_kernel(TailP p) {
   const bool add = p.accumulate != 0;
   const int G = gridDim.x, b = blockIdx.x;
   const int n1e = p.H * p.Cin, n2e = p.H * p.H;
-  outer_rows(p.gW1, s1, p.H, t0s, p.Cin, p.Cin, (int)((int64_t)n1e * b / G), (int)((int64_t)n1e * (b + 1) / G), M, add);
-  outer_rows(p.gW2, s2, p.H, t1s, p.H, p.H, (int)((int64_t)n2e * b / G), (int)((int64_t)n2e * (b + 1) / G), M, add);
-  outer_rows(p.gW3, gsm, 1, t2s, p.H, p.H, (int)((int64_t)p.H * b / G), (int)((int64_t)p.H * (b + 1) / G), M, add);
+  outer_rows<MB>(p.gW1, s1, p.H, t0s, p.Cin, p.Cin, (int)((int64_t)n1e * b / G), (int)((int64_t)n1e * (b + 1) / G), add);
+  outer_rows<MB>(p.gW2, s2, p.H, t1s, p.H, p.H, (int)((int64_t)n2e * b / G), (int)((int64_t)n2e * (b + 1) / G), add);
+  outer_rows<MB>(p.gW3, gsm, 1, t2s, p.H, p.H, (int)((int64_t)p.H * b / G), (int)((int64_t)p.H * (b + 1) / G), add);
+  TSTAMP(5, blockIdx.x == 0);
 }
 
 int imax3(int a, int b, int c) { return a > b ? (a > c ? a : c) : (b > c ? b : c); }
 size_t lds_fwd(const TailP& p) {
-  const size_t ps = (size_t)4 * kMaxM * imax3(p.H, p.N, 1), r1 = (size_t)2 * kMaxM * p.H + kMaxM;
-  return sizeof(float) * ((size_t)p.H * p.Cin + (size_t)p.H * p.H + p.H + (size_t)kMaxM * (p.Cin + 2 * p.H) + (ps > r1 ? ps : r1));
+  return sizeof(float) * ((size_t)p.H * p.Cin + (size_t)p.H * (p.H + 1) + p.H + 3 + (size_t)kMaxM * (p.Cin + 2 * p.H) +
+                          (size_t)4 * kMaxM * imax3(p.H, p.N, 1) + (size_t)2 * kMaxM * p.H + kMaxM);
 }
 size_t lds_bwd(const TailP& p) {
-  return sizeof(float) * ((size_t)p.H * p.Cin + (size_t)p.H * p.H + p.H + (size_t)kMaxM * 2 * p.H + (size_t)2 * kMaxM * p.N +
+  return sizeof(float) * ((size_t)p.H * p.Cin + (size_t)p.H * (p.H + 1) + p.H + 3 + (size_t)kMaxM * 2 * p.H + (size_t)2 * kMaxM * p.N +
                           (size_t)kMaxM * (p.Cin + 2 * p.H) + kMaxM + (size_t)4 * kMaxM * imax3(p.H, p.N, 64));
 }
 
@@ -365,32 +420,44 @@ int splits_for(const TailP& q) {
 }  // namespace
 
 extern "C" {
+#ifdef TP_TAIL_TIMING
+int tp_disc_tail_stamps(unsigned long long* host16) {      // (diagnostic build only: not part of the C ABI)
+  return (int)hipMemcpyFromSymbol(host16, HIP_SYMBOL(g_tail_stamps), sizeof(unsigned long long) * 16);
+}
+#endif
 size_t tp_disc_tail_workspace_bytes(int N) { return (size_t)N * 64 * kMaxM * sizeof(float); }     // [N][S <= 64][kMaxM]
 
 int tp_disc_tail_fwd(const tp_disc_tail_args* a, tp_stream_t stream) {
-  static unsigned long long flags = 0;
+  static unsigned long long flags[3] = {0, 0, 0};
   TailP q{};
   if (int rc = fill(&q, a, "tp_disc_tail_fwd")) return rc;
   TP_REQUIRE(q.a && q.scale && q.out && q.ws && q.ticket, "operand missing");
   q.S = splits_for(q);
-  return launch(disc_tail_fwd_kernel<false>, q, q.N * q.S, lds_fwd(q), stream, "tp_disc_tail_fwd", flags);
+  if (q.M <= 4) return launch(disc_tail_fwd_kernel<false, 4>, q, q.N * q.S, lds_fwd(q), stream, "tp_disc_tail_fwd", flags[0]);
+  if (q.M <= 8) return launch(disc_tail_fwd_kernel<false, 8>, q, q.N * q.S, lds_fwd(q), stream, "tp_disc_tail_fwd", flags[1]);
+  return launch(disc_tail_fwd_kernel<false, 16>, q, q.N * q.S, lds_fwd(q), stream, "tp_disc_tail_fwd", flags[2]);
 }
 int tp_disc_tail_bwd_bwd(const tp_disc_tail_args* a, tp_stream_t stream) {
-  static unsigned long long flags = 0;
+  static unsigned long long flags[3] = {0, 0, 0};
   TailP q{};
   if (int rc = fill(&q, a, "tp_disc_tail_bwd_bwd")) return rc;
   TP_REQUIRE(q.a && q.g && q.e1 && q.e2 && q.gW1 && q.gW2 && q.gW3 && q.ws && q.ticket, "operand missing");
   q.S = splits_for(q);
-  return launch(disc_tail_fwd_kernel<true>, q, q.N * q.S, lds_fwd(q), stream, "tp_disc_tail_bwd_bwd", flags);
+  if (q.M <= 4) return launch(disc_tail_fwd_kernel<true, 4>, q, q.N * q.S, lds_fwd(q), stream, "tp_disc_tail_bwd_bwd", flags[0]);
+  if (q.M <= 8) return launch(disc_tail_fwd_kernel<true, 8>, q, q.N * q.S, lds_fwd(q), stream, "tp_disc_tail_bwd_bwd", flags[1]);
+  return launch(disc_tail_fwd_kernel<true, 16>, q, q.N * q.S, lds_fwd(q), stream, "tp_disc_tail_bwd_bwd", flags[2]);
 }
 int tp_disc_tail_bwd(const tp_disc_tail_args* a, tp_stream_t stream) {
-  static unsigned long long flags = 0;
+  static unsigned long long flags[3] = {0, 0, 0};
   TailP q{};
   if (int rc = fill(&q, a, "tp_disc_tail_bwd")) return rc;
   TP_REQUIRE(q.g != nullptr, "g_out missing");
   TP_REQUIRE((q.gW1 && q.gW2 && q.gW3) || (!q.gW1 && !q.gW2 && !q.gW3), "gW1..3: all or none");
   TP_REQUIRE(q.gW0 == nullptr || q.a != nullptr, "gW0 needs the ladder output a");
   TP_REQUIRE(q.M2 == 0 || (q.gy2 && q.a2 && q.gW0), "the extra rows belong to the weight gradient gW0");
-  return launch(disc_tail_bwd_kernel, q, (q.K + 63) / 64, lds_bwd(q), stream, "tp_disc_tail_bwd", flags);
+  const int rows = q.M > q.M2 ? q.M : q.M2, grid = (q.K + 63) / 64;
+  if (rows <= 4) return launch(disc_tail_bwd_kernel<4>, q, grid, lds_bwd(q), stream, "tp_disc_tail_bwd", flags[0]);
+  if (rows <= 8) return launch(disc_tail_bwd_kernel<8>, q, grid, lds_bwd(q), stream, "tp_disc_tail_bwd", flags[1]);
+  return launch(disc_tail_bwd_kernel<16>, q, grid, lds_bwd(q), stream, "tp_disc_tail_bwd", flags[2]);
 }
 }

@@ -198,68 +198,22 @@ class Discriminator(nn.Module):
         """The spectrally normalised convolutions in the order `forward` uses their weights: ladder, then head."""
         return [m for m in list(self.main) + (list(self.final) if self.scale_conditional else []) if isinstance(m, SNConv2d)]
 
-    def prefetch_spectral_weights(self, n_calls: int, static: bool = False):
+    def prefetch_spectral_weights(self, n_calls: int):
         """Run the power iterations / normalisations of the NEXT ``n_calls`` training-mode forwards now, in order (each advances
         weight_u / weight_v once, exactly as those forwards would), and queue the results.  They depend on the weights only, not on
         any input: the captured training step issues the three of an iteration (nerf step's D(fake), D(real), D(fake)) on a side
         stream while the render's MLP kernel runs, which takes 5 launches off each discriminator pass.  Consumers that do not
-        differentiate through the normalisation take them with `take_prefetched_weights`; an unconsumed queue is an error.
-
-        ``static=True`` (the captured step since round 4): the sets are written into buffers that live as long as the module
-        (`_sn_static`), the power iterations run on SHADOW copies of weight_u / weight_v, and nothing is queued: the step issues this
-        at its END, right behind the RMSprop update and in the shadow of the generator's backward, for the NEXT iteration --
-        `queue_static_sets` hands the sets to that iteration's consumers, `commit_spectral_state` copies the shadow vectors into
-        weight_u / weight_v when the iteration that consumed the sets is over (so that the module's buffers hold, at every
-        iteration boundary, exactly what the reference's hold)."""
+        differentiate through the normalisation take them with `take_prefetched_weights`; an unconsumed queue is an error."""
         from . import ops
         if not self.training:
             raise RuntimeError("prefetch_spectral_weights: training mode only")
         if self._sn_queue:
             raise RuntimeError("prefetch_spectral_weights: %d prefetched weight sets were never used" % len(self._sn_queue))
         convs = self.sn_convs()
-        ws = [c.weight_orig.detach() for c in convs]
-        if static:
-            st = self._static_sets(n_calls)
-            for k in range(n_calls):
-                ops.spectral_norm_fwd(ws, st["u"], st["v"], True, out=st["sets"][k])
-            return
         for _ in range(n_calls):
-            outs, sigmas, us, vs = ops.spectral_norm_fwd(ws, [c.weight_u for c in convs], [c.weight_v for c in convs], True, keep_uv=True)
+            outs, sigmas, us, vs = ops.spectral_norm_fwd([c.weight_orig.detach() for c in convs], [c.weight_u for c in convs],
+                                                         [c.weight_v for c in convs], True, keep_uv=True)
             self._sn_queue.append((outs, sigmas, us, vs, torch.cuda.current_stream(outs[0].device)))
-
-    def _static_sets(self, n_calls):
-        from . import ops
-        convs = self.sn_convs()
-        st = getattr(self, "_sn_static", None)
-        if st is None or len(st["sets"]) != n_calls or st["u"][0].device != convs[0].weight_u.device:
-            ws, us, vs = [c.weight_orig.detach() for c in convs], [c.weight_u for c in convs], [c.weight_v for c in convs]
-            st = self._sn_static = dict(sets=[ops.spectral_norm_buffers(ws, us, vs) for _ in range(n_calls)],
-                                        u=[u.detach().clone() for u in us], v=[v.detach().clone() for v in vs])
-        return st
-
-    def sync_spectral_shadow(self):
-        """shadow u / v <- weight_u / weight_v (before the first static prefetch, and after anything replaced the module's state)."""
-        st = getattr(self, "_sn_static", None)
-        if st is not None:
-            with torch.no_grad():
-                for c, u, v in zip(self.sn_convs(), st["u"], st["v"]):
-                    u.copy_(c.weight_u)
-                    v.copy_(c.weight_v)
-
-    def queue_static_sets(self):
-        """The statically prefetched sets become this iteration's queue (no launch; produced by the previous iteration's last
-        launches, or eagerly before the first)."""
-        if self._sn_queue:
-            raise RuntimeError("queue_static_sets: %d prefetched weight sets were never used" % len(self._sn_queue))
-        for outs, sigmas, us, vs, _work in self._sn_static["sets"]:
-            self._sn_queue.append((outs, sigmas, us, vs, None))
-
-    def commit_spectral_state(self):
-        """weight_u / weight_v <- the shadow vectors (= their state after the power iterations of the sets just consumed), one launch."""
-        from . import ops
-        st = self._sn_static
-        convs = self.sn_convs()
-        ops.step_inputs([(c.weight_u, u) for c, u in zip(convs, st["u"])] + [(c.weight_v, v) for c, v in zip(convs, st["v"])])
 
     def take_prefetched_weights(self):
         """(W_sn list, sigma list, u copies, v copies) of the oldest prefetched set, or None.  A calling stream other than the one
@@ -268,7 +222,7 @@ class Discriminator(nn.Module):
             return None
         outs, sigmas, us, vs, issued_on = self._sn_queue.pop(0)
         cur = torch.cuda.current_stream(outs[0].device)
-        if issued_on is not None and cur != issued_on:
+        if cur != issued_on:
             cur.wait_stream(issued_on)
         return outs, sigmas, us, vs
 

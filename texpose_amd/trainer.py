@@ -421,8 +421,6 @@ class GraphedGanTrainer(GanTrainer):
         # gates are 1 only while all are 0 (separate words: the two branches of the captured step never write the same one)
         self._bad = torch.zeros(3, dtype=torch.int32, device=dev)
         self._side = None                        # second stream of the captured step (discriminator branch)
-        self._sn_static_active = False           # spectral-norm sets of the next iteration produced at the end of this one
-        self._sn_primed, self._sn_sets = False, 3
         # what the optimiser launches read: the words as they stood when the step's own flags had been folded in
         self._gate_nerf, self._gate_disc = torch.zeros_like(self._bad), torch.zeros_like(self._bad)
         if isinstance(self.optim_nerf, FusedAdam):
@@ -549,14 +547,6 @@ class GraphedGanTrainer(GanTrainer):
                 self._guard_nerf(var, loss)
                 self.nerf_apply()
 
-        # static spectral-norm prefetch (round 4): the NEXT iteration's three normalised weight sets are produced at the END of this one,
-        # on the discriminator branch right behind the RMSprop update, in the shadow of the generator's backward.  Set 1 is still being
-        # read by the generator's pass through the frozen discriminator (its data gradient) -- the branch waits for an event recorded
-        # when that backward has been issued (a hook on the fake patch's gradient).
-        d_bwd_done = None
-        if self._sn_static_active and "patch_fake_nerf" in var and var.patch_fake_nerf.requires_grad:
-            d_bwd_done = torch.cuda.Event()
-            var.patch_fake_nerf.register_hook(lambda g, ev=d_bwd_done: ev.record(torch.cuda.current_stream(g.device)))
         if overlap and not skip_disc:
             main = torch.cuda.current_stream(var.rgb.device)
             self._side.wait_stream(main)                          # fork
@@ -566,13 +556,6 @@ class GraphedGanTrainer(GanTrainer):
                 var, dloss = self.disc_step(var, apply=not self._deferred)
         if not (overlap and not skip_disc and backward_first):
             generator_backward()
-        if self._sn_static_active and not self._deferred:
-            with torch.cuda.stream(self._side):
-                if d_bwd_done is not None:
-                    self._side.wait_event(d_bwd_done)
-                else:
-                    self._side.wait_stream(torch.cuda.current_stream(var.rgb.device))
-                self._prefetch_next_spectral_weights()
         if skip_disc:
             pass
         elif overlap:
@@ -589,7 +572,6 @@ class GraphedGanTrainer(GanTrainer):
         stream, next to the render's MLP kernel, instead of 5 launches in front of each pass (K7; gan_modules.Discriminator.
         prefetch_spectral_weights).  Only when every consumer of the iteration takes prefetched weights: the frozen
         discriminator of the nerf step always does, the discriminator step when it runs as the explicit schedule (K16)."""
-        self._sn_static_active = False
         if not self.has_disc or self._side is None or os.environ.get("TP_NO_SN_PREFETCH") == "1":
             return
         opt, disc = self.opt, self.graph.discriminator
@@ -597,36 +579,11 @@ class GraphedGanTrainer(GanTrainer):
             return
         p, B = int(opt.patch_size), len(var.idx)
         probe = torch.empty(0, device=var.idx.device).new_empty((B, 0, p, p))          # (shape / device carrier: no data)
-        scheduled = self._disc_schedule(probe) is not None and os.environ.get("TP_SKIP_DISC_STEP") != "1"
-        n = 1 + (2 if scheduled else 0)
-        self._sn_static_active = scheduled and os.environ.get("TP_SN_PREFETCH_AT_START") != "1"
-        if self._sn_static_active:
-            # the sets were produced by the previous iteration's last launches (or eagerly before the first: `_prime_spectral_sets`)
-            self._sn_sets = n
-            if getattr(disc, "_sn_static", None) is None or not getattr(self, "_sn_primed", False):
-                self._prime_spectral_sets()
-            disc.queue_static_sets()
-            return
+        n = 1 + (2 if self._disc_schedule(probe) is not None and os.environ.get("TP_SKIP_DISC_STEP") != "1" else 0)
         main = torch.cuda.current_stream(probe.device)
         self._side.wait_stream(main)                 # (after the previous iteration's RMSprop step, whichever stream ran it)
         with torch.cuda.stream(self._side):
             disc.prefetch_spectral_weights(n)
-
-    def _prime_spectral_sets(self):
-        """Eagerly: shadow u / v <- the module's, then the normalised weight sets of the NEXT iteration into the static buffers
-        (before the first iteration, after the warm-up has been rolled back, after a state dict was loaded)."""
-        disc = self.graph.discriminator
-        disc._static_sets(self._sn_sets)
-        disc.sync_spectral_shadow()
-        disc.prefetch_spectral_weights(self._sn_sets, static=True)
-        self._sn_primed = True
-
-    def _prefetch_next_spectral_weights(self):
-        """End of an iteration (current stream: the one that ran the RMSprop update): weight_u / weight_v <- the shadow vectors (the
-        state after this iteration's three power iterations, what the reference holds now), then the next iteration's sets."""
-        disc = self.graph.discriminator
-        disc.commit_spectral_state()
-        disc.prefetch_spectral_weights(self._sn_sets, static=True)
 
     def disc_step(self, var, apply=True):
         self._disc_flagged = False
@@ -646,8 +603,6 @@ class GraphedGanTrainer(GanTrainer):
             self._gate_disc.copy_(self._bad)
             self._guard_disc()
             self.optim_disc.step()
-            if self._sn_static_active:
-                self._prefetch_next_spectral_weights()
 
     # ------------------------------------------------------------------ capture
     def _snapshot(self):
@@ -699,7 +654,6 @@ class GraphedGanTrainer(GanTrainer):
             if getattr(self, "_rng_counter", None) is None:
                 self._rng_counter = torch.zeros(1, dtype=torch.int64, device=dev)       # (attached to the graph only inside `_body_a`)
         self._static_in = AttrDict({k: v.clone() for k, v in var.items() if torch.is_tensor(v)})
-        self._sn_primed = False                  # (the first warm-up iteration primes the static spectral-norm sets)
         snap = self._snapshot()
         # warm up on the stream the capture will use: per-stream state (the tile counters of the convolution kernels,
         # ops._conv_scratch) must exist before the capture and is keyed by the stream
@@ -730,11 +684,6 @@ class GraphedGanTrainer(GanTrainer):
             with torch.cuda.graph(self._graph, stream=side):
                 self._static_loss = self._body(AttrDict(dict(self._static_in)))
         self._restore(snap)
-        if self._sn_static_active:
-            # the sets in the static buffers are those of the rolled-back warm-up: recompute them from the restored weights / vectors
-            with torch.cuda.stream(side):
-                self._prime_spectral_sets()
-            torch.cuda.current_stream(dev).wait_stream(side)
         flagged = self._read_bad(blocking=True)
         if flagged[0] and self._uses_f16x3():
             return self._fall_back_to_fp32(var, warmup)

@@ -39,3 +39,16 @@ cases = {
 }
 for name, fn in cases.items():
     print("%-40s %7.2f us" % (name, bench._event_ms(fn, 20) * 1e3))
+if "--timing" in sys.argv:                 # TEXPOSE_AMD_LIB=.../libtexpose_amd_tail_timing.so: 100 MHz section stamps of one workgroup
+    import ctypes
+    from texpose_amd import _lib
+    lib = _lib.load()
+    buf = (ctypes.c_ulonglong * 16)()
+    for name in ("tail_fwd", "tail_bwd data-only (+e)", "tail_bwd all + R1 rows + accumulate", "tail_bwd_bwd"):
+        for rep in range(3):
+            torch.cuda.synchronize()
+            cases[name]()
+            torch.cuda.synchronize()
+            lib.tp_disc_tail_stamps(buf)
+            v = list(buf)
+            print("%-40s stamps (us since the first): %s" % (name, ["%.2f" % ((x - v[0]) / 100.0) for x in v[:10]]))
