@@ -300,12 +300,15 @@ typedef struct tp_sn_weight {
   float* u_out;            /* fwd, optional: copy of u [rows] as it stands AFTER this call's power iteration (the backward of
                               THIS forward needs it; later forwards of the iteration advance u / v in place) */
   float* v_out;            /* fwd, optional: copy of v [cols] likewise */
-  int32_t accumulate;      /* bwd: grad += (the second normalised instance of the same weight in one optimiser step) */
+  int32_t accumulate;      /* bwd: grad += */
+  /* bwd, optional: a SECOND normalised instance of the same weight in one optimiser step (the discriminator step's fake pass:
+   * the power iteration advances between the passes) -- grad = f(grad_sn, weight_sn, u, v, sigma) + f(grad_sn2, ...) in the same
+   * two launches; all five or none */
+  const float* grad_sn2; const float* weight_sn2; const float* u2; const float* v2; const float* sigma2;
 } tp_sn_weight;
 int64_t tp_sn_work_floats(int rows, int cols);
-/* tickets: 2 * TP_SN_MAX_WEIGHTS zero-filled device words (the kernels leave them zero; one array per stream that may run the
- * call concurrently): the forward is then 3 launches (the last-arriving workgroup of a weight normalises), else 5 (NULL). */
-int tp_sn_fwd(const tp_sn_weight* weights, int n, int training, uint32_t* tickets, tp_stream_t stream);
+/* three launches (two in eval mode): every workgroup of the consuming kernel normalises v / u for itself */
+int tp_sn_fwd(const tp_sn_weight* weights, int n, int training, tp_stream_t stream);
 int tp_sn_bwd(const tp_sn_weight* weights, int n, tp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
@@ -358,6 +361,7 @@ typedef struct tp_rmsprop_tensor {
   const float* grad;       /* [numel] */
   float* square_avg;       /* [numel] updated in place */
   int64_t numel;
+  float* step;             /* optional 0-dim float device tensor (torch's state "step"): += 1 by the same launch when the step is applied */
 } tp_rmsprop_tensor;
 /* gate: n_gate int32 device words (or 0): if any is non-zero the launch changes nothing (a flagged step, see tp_step_flags) */
 /* hyper-parameters as doubles: 1 - alpha is formed in double and then rounded, like torch's scalar arithmetic */

@@ -2130,30 +2130,45 @@ def test_device_counter_random_streams(ops):
     assert int(off) == 43
 
 
-def test_spectral_norm_fused_three_launch_form(ops, monkeypatch):
-    """tp_sn_fwd with arrival counters (TP_SN_FUSED=1: A + A2 and B + B2 fused, the last workgroup of a weight normalises) against the
-    default five-launch form on the PatchGAN's weight shapes, over three consecutive power iterations (the counters must come back
-    to zero): same W_sn / sigma / u / v up to the order of the 256- vs 1024-thread norm reductions."""
+def test_spectral_norm_three_launch_form_and_paired_backward(ops):
+    """tp_sn_fwd (round 4: three launches, every workgroup of the consuming kernel normalises v / u for itself) against the torch
+    arithmetic of torch.nn.utils.spectral_norm on the PatchGAN's weight shapes over three consecutive power iterations, then in eval
+    mode (no iteration); tp_sn_bwd with a second normalised instance of the weights in the same two launches against two calls."""
     rs = np.random.RandomState(3)
     shapes = [(256, 9 * 16), (512, 256 * 16), (64, 512 * 16), (64, 73), (64, 64), (1, 64)]
     ws = [cu(torch.from_numpy(rs.normal(size=sh).astype(np.float32) * 0.05)) for sh in shapes]
-    res = []
-    for fused in (False, True):
-        if fused:
-            monkeypatch.setenv("TP_SN_FUSED", "1")
-        else:
-            monkeypatch.delenv("TP_SN_FUSED", raising=False)
-        us = [torch.nn.functional.normalize(cu(torch.from_numpy(np.random.RandomState(7 + i).normal(size=sh[0]).astype(np.float32))), dim=0)
-              for i, sh in enumerate(shapes)]
-        vs = [torch.nn.functional.normalize(cu(torch.from_numpy(np.random.RandomState(17 + i).normal(size=sh[1]).astype(np.float32))), dim=0)
-              for i, sh in enumerate(shapes)]
-        for _ in range(3):
-            outs, sig = ops.spectral_norm_fwd(ws, us, vs, True)
-        torch.cuda.synchronize()
-        res.append((outs, sig, [u.clone() for u in us], [v.clone() for v in vs]))
-    for a, b in zip(res[0], res[1]):
-        for x, y in zip(a, b):
-            torch.testing.assert_close(y, x, rtol=2e-6, atol=1e-7)
+    us = [F.normalize(cu(torch.from_numpy(np.random.RandomState(7 + i).normal(size=sh[0]).astype(np.float32))), dim=0) for i, sh in enumerate(shapes)]
+    vs = [F.normalize(cu(torch.from_numpy(np.random.RandomState(17 + i).normal(size=sh[1]).astype(np.float32))), dim=0) for i, sh in enumerate(shapes)]
+    ur, vr = [u.double() for u in us], [v.double() for v in vs]
+    sets = []
+    for _ in range(3):
+        outs, sig, uc, vc = ops.spectral_norm_fwd(ws, us, vs, True, keep_uv=True)
+        sets.append((outs, sig, uc, vc))
+        for i, w in enumerate(ws):
+            wd = w.double()
+            vr[i] = F.normalize(wd.t() @ ur[i], dim=0, eps=1e-12)
+            ur[i] = F.normalize(wd @ vr[i], dim=0, eps=1e-12)
+            sigma = torch.dot(ur[i], wd @ vr[i])
+            torch.testing.assert_close(outs[i].double(), wd / sigma, rtol=1e-5, atol=1e-8)
+            torch.testing.assert_close(sig[i].double().reshape(()), sigma, rtol=1e-5, atol=0)
+            torch.testing.assert_close(us[i].double(), ur[i], rtol=1e-4, atol=1e-6)
+            torch.testing.assert_close(vs[i].double(), vr[i], rtol=1e-4, atol=1e-6)
+            assert torch.equal(uc[i], us[i]) and torch.equal(vc[i], vs[i])
+    keep_u, keep_v = [u.clone() for u in us], [v.clone() for v in vs]
+    outs_e, sig_e = ops.spectral_norm_fwd(ws, us, vs, False)
+    for i, w in enumerate(ws):
+        assert torch.equal(us[i], keep_u[i]) and torch.equal(vs[i], keep_v[i])           # eval mode: no power iteration
+        sigma = torch.dot(us[i].double(), w.double() @ vs[i].double())
+        torch.testing.assert_close(outs_e[i].double(), w.double() / sigma, rtol=1e-5, atol=1e-8)
+    # backward: instance 2 and instance 3 of the same weights, paired vs accumulated
+    g1 = [torch.randn_like(w) for w in ws]
+    g2 = [torch.randn_like(w) for w in ws]
+    (o1, s1, u1, v1), (o2, s2, u2, v2) = sets[1], sets[2]
+    ref = ops.spectral_norm_bwd(g1, o1, u1, v1, s1)
+    ref = ops.spectral_norm_bwd(g2, o2, u2, v2, s2, accumulate_into=ref)
+    got = ops.spectral_norm_bwd(g1, o1, u1, v1, s1, second=(g2, o2, u2, v2, s2))
+    for a, b in zip(got, ref):
+        assert torch.equal(a, b)
 
 
 def test_round3_launch_diet_pieces(ops):

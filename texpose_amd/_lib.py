@@ -99,14 +99,15 @@ class EvalMetricsArgs(C.Structure):
 
 class SnWeight(C.Structure):
     _fields_ = [("weight", vp), ("u", vp), ("v", vp), ("weight_sn", vp), ("sigma", vp), ("grad_sn", vp), ("grad", vp),
-                ("work", vp), ("rows", C.c_int), ("cols", C.c_int), ("u_out", vp), ("v_out", vp), ("accumulate", C.c_int32)]
+                ("work", vp), ("rows", C.c_int), ("cols", C.c_int), ("u_out", vp), ("v_out", vp), ("accumulate", C.c_int32),
+                ("grad_sn2", vp), ("weight_sn2", vp), ("u2", vp), ("v2", vp), ("sigma2", vp)]
 
 
 SN_MAX_WEIGHTS = 8
 
 
 class RmspropTensor(C.Structure):
-    _fields_ = [("param", vp), ("grad", vp), ("square_avg", vp), ("numel", C.c_int64)]
+    _fields_ = [("param", vp), ("grad", vp), ("square_avg", vp), ("numel", C.c_int64), ("step", vp)]
 
 
 RMSPROP_MAX_TENSORS = 16
@@ -218,7 +219,7 @@ def load() -> C.CDLL:
     sig("tp_eval_metrics_workspace_bytes", [C.c_int, C.c_int, C.c_int], C.c_int64)
     sig("tp_eval_metrics", [C.POINTER(EvalMetricsArgs), vp])
     sig("tp_sn_work_floats", [C.c_int, C.c_int], C.c_int64)
-    sig("tp_sn_fwd", [C.POINTER(SnWeight), C.c_int, C.c_int, vp, vp])
+    sig("tp_sn_fwd", [C.POINTER(SnWeight), C.c_int, C.c_int, vp])
     sig("tp_sn_bwd", [C.POINTER(SnWeight), C.c_int, vp])
     sig("tp_nerf_losses_fwd", [C.POINTER(NerfLossesArgs), vp])
     sig("tp_nerf_losses_bwd", [C.POINTER(NerfLossesArgs), vp, vp, vp, vp, vp, vp, vp])

@@ -11,6 +11,7 @@ struct Table {
   float* p[TP_RMSPROP_MAX_TENSORS];
   const float* g[TP_RMSPROP_MAX_TENSORS];
   float* sq[TP_RMSPROP_MAX_TENSORS];
+  float* step[TP_RMSPROP_MAX_TENSORS];       // optional step counters (torch state "step"): +1 per applied step
   int64_t end[TP_RMSPROP_MAX_TENSORS];       // exclusive prefix end of each tensor in the concatenated index space
   int n;
 };
@@ -20,6 +21,11 @@ __global__ __launch_bounds__(256) void rmsprop_kernel(Table t, const float* lr_d
   for (int k = 0; k < n_gate; ++k)
     if (gate[k] != 0) return;                       // a flagged step: parameters and statistics stay bit-for-bit as they are
   const float lr = lr_dev != nullptr ? *lr_dev : lr_host;
+  if (blockIdx.x == 0 && (int)threadIdx.x < t.n && t.step[threadIdx.x] != nullptr) {       // (RMSprop never READS its step counters)
+    bool first = true;
+    for (int j = 0; j < (int)threadIdx.x; ++j) first = first && t.step[j] != t.step[threadIdx.x];
+    if (first) t.step[threadIdx.x][0] += 1.0f;
+  }
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
     int k = 0;
     while (e >= t.end[k]) ++k;
@@ -42,11 +48,11 @@ extern "C" int tp_rmsprop_step(const tp_rmsprop_tensor* tensors, int n, const fl
   int64_t total = 0;
   for (int k = 0; k < n; ++k) {
     TP_REQUIRE(tensors[k].param && tensors[k].grad && tensors[k].square_avg && tensors[k].numel > 0, "null tensor");
-    t.p[k] = tensors[k].param; t.g[k] = tensors[k].grad; t.sq[k] = tensors[k].square_avg;
+    t.p[k] = tensors[k].param; t.g[k] = tensors[k].grad; t.sq[k] = tensors[k].square_avg; t.step[k] = tensors[k].step;
     total += tensors[k].numel;
     t.end[k] = total;
   }
-  for (int k = n; k < TP_RMSPROP_MAX_TENSORS; ++k) { t.p[k] = nullptr; t.g[k] = nullptr; t.sq[k] = nullptr; t.end[k] = total; }
+  for (int k = n; k < TP_RMSPROP_MAX_TENSORS; ++k) { t.p[k] = nullptr; t.g[k] = nullptr; t.sq[k] = nullptr; t.step[k] = nullptr; t.end[k] = total; }
   t.n = n;
   int64_t blocks = (total + 255) / 256;
   if (blocks > 4096) blocks = 4096;

@@ -5,15 +5,17 @@
 //     v <- normalize(W^T u),  u <- normalize(W v),  sigma = u . (W v),  W_sn = W / sigma       (W = weight.view(out, -1))
 // which PyTorch issues as ~15 tiny kernels per weight (mv, norm, clamp, div, dot, clones), i.e. ~90 per discriminator
 // forward and as many again in the backward -- ~600 of the ~1,350 launches of a training iteration.  Here all weights
-// of the module are processed together: five launches per forward (two in eval mode + scale) -- or three with arrival counters
-// (A + A2, B + B2 fused: the last workgroup of a weight normalises; measured 1.4 % slower per GAN iteration: off by default) --,
-// two per backward,
+// of the module are processed together: three launches per forward (two in eval mode), two per backward,
 //     fwd :  A  t_part[slab] = W[slab rows]^T u      (column blocks x row slabs, coalesced rows)
-//            A2 v = normalize(sum_slabs t_part)       (one workgroup per weight; updates the module's v buffer)
-//            B  s = W v                               (one wave per row, lanes stride the columns)
-//            B2 u = normalize(s), sigma = u . s       (one workgroup per weight; updates the module's u buffer)
-//            C  W_sn = W / sigma
+//            B  v = normalize(sum_slabs t_part) in LDS, then s = W v for the workgroup's 8 rows   (every workgroup of a weight
+//               normalises for itself -- the slab sums are L2 hits --; the first one writes the module's v buffer)
+//            C  u = normalize(s), sigma = u . s, then W_sn = W / sigma for the workgroup's 4096 elements   (every workgroup
+//               reduces the <= 512 values of s itself, identically; the first one writes the module's u buffer and sigma)
 //     bwd :  D  partial sums of <G, W_sn>;   E  dW = (G - <G, W_sn> u v^T) / sigma        (u, v constants, as in torch)
+//            a SECOND normalised instance of the same weight (the discriminator step normalises twice per optimiser step: real
+//            pass, fake pass) goes through the same two launches: D forms both dot products, E adds both terms.
+// Rounds 1-3 normalised in launches of their own (A2, B2: one workgroup per weight, 13.6 + 5 us of the 44 us of a set), round 3's
+// variant with arrival counters (the last workgroup of a weight normalises) paid the same in agent-scope loads past the L2.
 // All reductions run in a fixed order (no atomics): the training run is reproducible.
 #include "tp_common.h"
 
@@ -25,7 +27,6 @@ struct Batch {
   tp_sn_weight w[kMaxW];
   int n;
   int blk_a[kMaxW + 1];   // prefix sums of workgroups per weight for the kernel being launched
-  unsigned int* tickets;  // fused kernels: [2][kMaxW] arrival counters (A, B), zero between launches
 };
 
 __device__ __forceinline__ int find_weight(const Batch& b, int blk, int& local) {
@@ -66,193 +67,152 @@ __global__ __launch_bounds__(256) void sn_wtu_kernel(Batch b) {
   w.work[(int64_t)slab * w.cols + c] = acc;
 }
 
-// A2: v = normalize(sum_slabs t_part)
-__global__ __launch_bounds__(1024) void sn_v_kernel(Batch b) {
-  __shared__ float red[1024];
-  const tp_sn_weight& w = b.w[blockIdx.x];
-  const int slabs = (w.rows + kSlabRows - 1) / kSlabRows;
-  float ss = 0.0f;
-  for (int c = threadIdx.x; c < w.cols; c += 1024) {
-    float t = 0.0f;
-    for (int s = 0; s < slabs; ++s) t += w.work[(int64_t)s * w.cols + c];
-    w.v[c] = t;
-    ss = fmaf(t, t, ss);
-  }
-  const float nrm = fmaxf(sqrtf(block_sum(ss, red)), 1e-12f);
-  for (int c = threadIdx.x; c < w.cols; c += 1024) w.v[c] = w.v[c] / nrm;
-}
+constexpr int kWvRows = 4;                     // rows of s per workgroup of kernel B (one per wave)
+using f32x4 = __attribute__((ext_vector_type(4))) float;
 
-// B: s[r] = sum_c W[r][c] v[c]   (one wave per row)
-__global__ __launch_bounds__(256) void sn_wv_kernel(Batch b) {
+// B: v = normalize(sum_slabs t_part) (training; else the module's v) in LDS, then s[r] = sum_c W[r][c] v[c] for 4 rows (a wave per row).
+// 16-byte loads with 16-32 of them in flight per thread: a first version with 4-byte loads, eight in flight, paid one L2 latency per
+// batch, 16 + 16 batches per workgroup of the 512 x 4096 weight (29-36 us per launch; now 2 + 2 batches).
+__global__ __launch_bounds__(256) void sn_wv_kernel(Batch b, int training) {
+  extern __shared__ __attribute__((aligned(16))) float vs[];      // [cols]
+  __shared__ float red[256];
   int local;
   const tp_sn_weight& w = b.w[find_weight(b, blockIdx.x, local)];
-  const int r = local * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const bool vec = (w.cols & 3) == 0 && (((uintptr_t)w.work | (uintptr_t)w.weight | (uintptr_t)w.v) & 15) == 0;
+  if (training) {
+    const int slabs = (w.rows + kSlabRows - 1) / kSlabRows;
+    float ss = 0.0f;
+    if (vec) {
+      const int c4n = w.cols >> 2;
+#pragma unroll 2
+      for (int c4 = t; c4 < c4n; c4 += 256) {
+        f32x4 part[TP_SN_MAX_SLABS];
+#pragma unroll
+        for (int sl = 0; sl < TP_SN_MAX_SLABS; ++sl)
+          part[sl] = sl < slabs ? reinterpret_cast<const f32x4*>(w.work + (int64_t)sl * w.cols)[c4] : f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 tt = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int sl = 0; sl < TP_SN_MAX_SLABS; ++sl) tt += part[sl];            // slab-ascending (absent slabs add 0)
+        reinterpret_cast<f32x4*>(vs)[c4] = tt;
+        ss = fmaf(tt[3], tt[3], fmaf(tt[2], tt[2], fmaf(tt[1], tt[1], fmaf(tt[0], tt[0], ss))));
+      }
+    } else {
+      for (int c = t; c < w.cols; c += 256) {
+        float tt = 0.0f;
+        for (int sl = 0; sl < slabs; ++sl) tt += w.work[(int64_t)sl * w.cols + c];
+        vs[c] = tt;
+        ss = fmaf(tt, tt, ss);
+      }
+    }
+    const float nrm = fmaxf(sqrtf(block_sum(ss, red)), 1e-12f);
+    for (int c = t; c < w.cols; c += 256) {
+      const float v = vs[c] / nrm;
+      vs[c] = v;
+      if (local == 0) {                        // (one workgroup per weight updates the module's buffer and this forward's copy)
+        w.v[c] = v;
+        if (w.v_out) w.v_out[c] = v;
+      }
+    }
+  } else {
+    for (int c = t; c < w.cols; c += 256) {
+      const float v = w.v[c];
+      vs[c] = v;
+      if (local == 0 && w.v_out) w.v_out[c] = v;
+    }
+  }
+  __syncthreads();
+  float* s = w.work + (int64_t)TP_SN_MAX_SLABS * w.cols;
+  const int r = local * kWvRows + wave;
   if (r >= w.rows) return;
   const float* row = w.weight + (int64_t)r * w.cols;
   float acc = 0.0f;
+  if (vec) {
+    const f32x4* row4 = reinterpret_cast<const f32x4*>(row);
+    const f32x4* v4 = reinterpret_cast<const f32x4*>(vs);
 #pragma unroll 8
-  for (int c = lane; c < w.cols; c += 64) acc = fmaf(row[c], w.v[c], acc);                          // 16 loads in flight
-  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-  if (lane == 0) w.work[(int64_t)TP_SN_MAX_SLABS * w.cols + r] = acc;
-}
-
-// B2: u = normalize(s) (training) ; sigma = u . s
-__global__ __launch_bounds__(256) void sn_u_kernel(Batch b, int training) {
-  __shared__ float red[256];
-  const tp_sn_weight& w = b.w[blockIdx.x];
-  const float* s = w.work + (int64_t)TP_SN_MAX_SLABS * w.cols;
-  if (training) {
-    float ss = 0.0f;
-    for (int r = threadIdx.x; r < w.rows; r += 256) ss = fmaf(s[r], s[r], ss);
-    const float nrm = fmaxf(sqrtf(block_sum(ss, red)), 1e-12f);
-    for (int r = threadIdx.x; r < w.rows; r += 256) w.u[r] = s[r] / nrm;
-    __syncthreads();
-  }
-  float d = 0.0f;
-  for (int r = threadIdx.x; r < w.rows; r += 256) d = fmaf(w.u[r], s[r], d);
-  d = block_sum(d, red);
-  if (threadIdx.x == 0) *w.sigma = d;
-}
-
-// ---- A + A2 and B + B2 as ONE launch each (tp_sn_fwd with `tickets`): the workgroup of a weight that arrives LAST normalises.
-// Hand-over by the gfx950 contract of csrc/patch_conv.hip (reduce_tiles): handed-off words are stored and loaded agent-scope,
-// the storing lanes drained, one agent-scope counter add per workgroup behind a barrier; no device-scope fence (on gfx950 that
-// is a write-back + invalidate of the XCD's whole L2).  The reductions keep a fixed order: whichever workgroup is last runs the
-// same code over the same partials.
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
-#error "the fused spectral-norm kernels rely on the gfx950 agent-scope store / load hand-over (csrc/patch_conv.hip)"
-#endif
-__device__ __forceinline__ bool arrive_last(unsigned int* ticket, int n_blocks) {
-  __shared__ int last;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this thread's stores are complete
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(n_blocks - 1);
-    if (last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
-  }
-  __syncthreads();
-  return last != 0;
-}
-__device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-__global__ __launch_bounds__(256) void sn_wtu_v_kernel(Batch b) {
-  __shared__ float us[kSlabRows];
-  __shared__ float red[256];
-  int local;
-  const int wi = find_weight(b, blockIdx.x, local);
-  const tp_sn_weight& w = b.w[wi];
-  const int cblocks = (w.cols + 255) / 256;
-  const int slab = local / cblocks, cb = local - slab * cblocks;
-  const int r0 = slab * kSlabRows, nr = min(kSlabRows, w.rows - r0);
-  if (threadIdx.x < nr) us[threadIdx.x] = w.u[r0 + threadIdx.x];
-  __syncthreads();
-  const int c = cb * 256 + threadIdx.x;
-  if (c < w.cols) {
-    float acc = 0.0f;
-#pragma unroll 8
-    for (int r = 0; r < nr; ++r) acc = fmaf(w.weight[(int64_t)(r0 + r) * w.cols + c], us[r], acc);
-    st_agent(w.work + (int64_t)slab * w.cols + c, acc);
-  }
-  if (!arrive_last(b.tickets + wi, b.blk_a[wi + 1] - b.blk_a[wi])) return;
-  // A2 (one workgroup per weight): v = normalize(sum_slabs t_part).  The agent-scope loads travel past the L2 (~2 us each): 32 of
-  // them (4 columns x 8 slabs) are issued before the first is used; summed slab-ascending as in sn_v_kernel (absent slabs add 0).
-  const int slabs = (w.rows + kSlabRows - 1) / kSlabRows;
-  float ss = 0.0f;
-  for (int c0 = threadIdx.x; c0 < w.cols; c0 += 256 * 4) {
-    float part[4][TP_SN_MAX_SLABS];
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int sl = 0; sl < TP_SN_MAX_SLABS; ++sl)
-        part[j][sl] = (c0 + 256 * j < w.cols && sl < slabs) ? ld_agent(w.work + (int64_t)sl * w.cols + c0 + 256 * j) : 0.0f;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      if (c0 + 256 * j >= w.cols) continue;
-      float t = 0.0f;
-#pragma unroll
-      for (int sl = 0; sl < TP_SN_MAX_SLABS; ++sl) t += part[j][sl];
-      w.v[c0 + 256 * j] = t;
-      ss = fmaf(t, t, ss);
+    for (int c4 = lane; c4 < (w.cols >> 2); c4 += 64) {                        // 8 x 16-byte loads in flight
+      const f32x4 a = row4[c4], v = v4[c4];
+      acc = fmaf(a[3], v[3], fmaf(a[2], v[2], fmaf(a[1], v[1], fmaf(a[0], v[0], acc))));
     }
+  } else {
+#pragma unroll 8
+    for (int c = lane; c < w.cols; c += 64) acc = fmaf(row[c], vs[c], acc);
   }
-  const float nrm = fmaxf(sqrtf(block_sum(ss, red)), 1e-12f);
-  for (int cc = threadIdx.x; cc < w.cols; cc += 256) w.v[cc] = w.v[cc] / nrm;
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if (lane == 0) s[r] = acc;
 }
 
-__global__ __launch_bounds__(256) void sn_wv_u_kernel(Batch b, int training) {
+// C: u = normalize(s) (training; else the module's u), sigma = u . s, W_sn = W / sigma   (rows <= 512: two values of s per thread)
+constexpr int kScaleElems = 4096;              // elements of W per workgroup
+__global__ __launch_bounds__(256) void sn_scale_kernel(Batch b, int training) {
   __shared__ float red[256];
   int local;
-  const int wi = find_weight(b, blockIdx.x, local);
-  const tp_sn_weight& w = b.w[wi];
-  const int r = local * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  float* s = w.work + (int64_t)TP_SN_MAX_SLABS * w.cols;
-  if (r < w.rows) {
-    const float* row = w.weight + (int64_t)r * w.cols;
-    float acc = 0.0f;
-#pragma unroll 8
-    for (int c = lane; c < w.cols; c += 64) acc = fmaf(row[c], w.v[c], acc);
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-    if (lane == 0) st_agent(s + r, acc);
-  }
-  if (!arrive_last(b.tickets + kMaxW + wi, b.blk_a[wi + 1] - b.blk_a[wi])) return;
-  // B2 (one workgroup per weight): u = normalize(s) (training); sigma = u . s   (rows <= 512: two values per thread, loaded once)
+  const tp_sn_weight& w = b.w[find_weight(b, blockIdx.x, local)];
+  const float* s = w.work + (int64_t)TP_SN_MAX_SLABS * w.cols;
   const int r_a = threadIdx.x, r_b = threadIdx.x + 256;
-  const float s_a = r_a < w.rows ? ld_agent(s + r_a) : 0.0f, s_b = r_b < w.rows ? ld_agent(s + r_b) : 0.0f;
-  float u_a = r_a < w.rows ? w.u[r_a] : 0.0f, u_b = r_b < w.rows ? w.u[r_b] : 0.0f;
+  const float s_a = r_a < w.rows ? s[r_a] : 0.0f, s_b = r_b < w.rows ? s[r_b] : 0.0f;
+  float u_a, u_b;
   if (training) {
     const float ss = fmaf(s_b, s_b, fmaf(s_a, s_a, 0.0f));
     const float nrm = fmaxf(sqrtf(block_sum(ss, red)), 1e-12f);
     u_a = s_a / nrm; u_b = s_b / nrm;
-    if (r_a < w.rows) w.u[r_a] = u_a;
-    if (r_b < w.rows) w.u[r_b] = u_b;
+  } else {
+    u_a = r_a < w.rows ? w.u[r_a] : 0.0f; u_b = r_b < w.rows ? w.u[r_b] : 0.0f;
   }
-  float d = fmaf(u_b, s_b, fmaf(u_a, s_a, 0.0f));
-  d = block_sum(d, red);
-  if (threadIdx.x == 0) *w.sigma = d;
-}
-
-// C: W_sn = W / sigma
-__global__ __launch_bounds__(256) void sn_scale_kernel(Batch b) {
-  int local;
-  const tp_sn_weight& w = b.w[find_weight(b, blockIdx.x, local)];
+  const float sg = block_sum(fmaf(u_b, s_b, fmaf(u_a, s_a, 0.0f)), red);
+  if (local == 0) {                            // one workgroup per weight: the module's u, sigma, this forward's copy of u
+    if (training) {
+      if (r_a < w.rows) w.u[r_a] = u_a;
+      if (r_b < w.rows) w.u[r_b] = u_b;
+    }
+    if (w.u_out) {
+      if (r_a < w.rows) w.u_out[r_a] = u_a;
+      if (r_b < w.rows) w.u_out[r_b] = u_b;
+    }
+    if (threadIdx.x == 0) *w.sigma = sg;
+  }
   const int64_t n = (int64_t)w.rows * w.cols;
-  const float sg = *w.sigma;
-  for (int64_t i = (int64_t)local * 1024 + threadIdx.x; i < min(n, (int64_t)(local + 1) * 1024); i += 256)
+  for (int64_t i = (int64_t)local * kScaleElems + threadIdx.x; i < min(n, (int64_t)(local + 1) * kScaleElems); i += 256)
     w.weight_sn[i] = w.weight[i] / sg;
-  if (local == 0) {                     // this forward's u / v for its backward (one workgroup per weight)
-    if (w.u_out) for (int r = threadIdx.x; r < w.rows; r += 256) w.u_out[r] = w.u[r];
-    if (w.v_out) for (int c = threadIdx.x; c < w.cols; c += 256) w.v_out[c] = w.v[c];
-  }
 }
 
-// D: per-workgroup partial of <G, W_sn>
+// D: per-workgroup partial of <G, W_sn> (and of the second instance's <G2, W_sn2>)
 __global__ __launch_bounds__(256) void sn_dot_kernel(Batch b) {
   __shared__ float red[256];
   int local;
   const tp_sn_weight& w = b.w[find_weight(b, blockIdx.x, local)];
   const int64_t n = (int64_t)w.rows * w.cols;
-  float acc = 0.0f;
-  for (int64_t i = (int64_t)local * 4096 + threadIdx.x; i < min(n, (int64_t)(local + 1) * 4096); i += 256)
+  const int parts = (int)((n + 4095) / 4096);
+  float acc = 0.0f, acc2 = 0.0f;
+  for (int64_t i = (int64_t)local * 4096 + threadIdx.x; i < min(n, (int64_t)(local + 1) * 4096); i += 256) {
     acc = fmaf(w.grad_sn[i], w.weight_sn[i], acc);
+    if (w.grad_sn2) acc2 = fmaf(w.grad_sn2[i], w.weight_sn2[i], acc2);
+  }
   acc = block_sum(acc, red);
   if (threadIdx.x == 0) w.work[local] = acc;
+  if (w.grad_sn2) {
+    acc2 = block_sum(acc2, red);
+    if (threadIdx.x == 0) w.work[parts + local] = acc2;
+  }
 }
 
-// E: dW = (G - <G, W_sn> u v^T) / sigma
+// E: dW = (G - <G, W_sn> u v^T) / sigma  (+ the same of the second instance)
 __global__ __launch_bounds__(256) void sn_grad_kernel(Batch b) {
   __shared__ float red[256];
   int local;
   const tp_sn_weight& w = b.w[find_weight(b, blockIdx.x, local)];
   const int64_t n = (int64_t)w.rows * w.cols;
   const int parts = (int)((n + 4095) / 4096);
-  float d = 0.0f;
-  for (int i = threadIdx.x; i < parts; i += 256) d += w.work[i];
+  float d = 0.0f, d2 = 0.0f;
+  for (int i = threadIdx.x; i < parts; i += 256) { d += w.work[i]; if (w.grad_sn2) d2 += w.work[parts + i]; }
   d = block_sum(d, red);
-  const float sg = *w.sigma;
+  if (w.grad_sn2) d2 = block_sum(d2, red);
+  const float sg = *w.sigma, sg2 = w.grad_sn2 ? *w.sigma2 : 1.0f;
   for (int64_t i = (int64_t)local * 1024 + threadIdx.x; i < min(n, (int64_t)(local + 1) * 1024); i += 256) {
     const int r = (int)(i / w.cols), c = (int)(i - (int64_t)r * w.cols);
-    const float gv = (w.grad_sn[i] - d * w.u[r] * w.v[c]) / sg;
+    float gv = (w.grad_sn[i] - d * w.u[r] * w.v[c]) / sg;
+    if (w.grad_sn2) gv = gv + (w.grad_sn2[i] - d2 * w.u2[r] * w.v2[c]) / sg2;
     w.grad[i] = w.accumulate ? w.grad[i] + gv : gv;
   }
 }
@@ -271,39 +231,36 @@ int check(const tp_sn_weight* ws, int n, bool bwd, const char* what) {
     if (!w.u || !w.v || !w.sigma || !w.weight_sn || !w.work) { tp::set_error("%s: null pointer", what); return -1; }
     if (!bwd && !w.weight) { tp::set_error("%s: null weight", what); return -1; }
     if (bwd && (!w.grad_sn || !w.grad)) { tp::set_error("%s: null gradient pointer", what); return -1; }
+    if (bwd && w.grad_sn2 && (!w.weight_sn2 || !w.u2 || !w.v2 || !w.sigma2)) { tp::set_error("%s: incomplete second instance", what); return -1; }
   }
   return 0;
 }
 }  // namespace
 
 extern "C" int64_t tp_sn_work_floats(int rows, int cols) {
-  const int64_t fwd = (int64_t)TP_SN_MAX_SLABS * cols + rows, bwd = ((int64_t)rows * cols + 4095) / 4096;
+  const int64_t fwd = (int64_t)TP_SN_MAX_SLABS * cols + rows, bwd = 2 * (((int64_t)rows * cols + 4095) / 4096);
   return fwd > bwd ? fwd : bwd;
 }
 
-extern "C" int tp_sn_fwd(const tp_sn_weight* ws, int n, int training, uint32_t* tickets, tp_stream_t stream) {
+extern "C" int tp_sn_fwd(const tp_sn_weight* ws, int n, int training, tp_stream_t stream) {
   if (int rc = check(ws, n, false, "tp_sn_fwd")) return rc;
   hipStream_t st = (hipStream_t)stream;
   Batch b;
-  b.tickets = tickets;
+  int max_cols = 0;
+  for (int i = 0; i < n; ++i) max_cols = ws[i].cols > max_cols ? ws[i].cols : max_cols;
+  TP_REQUIRE((size_t)max_cols * sizeof(float) <= 64 * 1024, "at most 16384 columns");
   if (training) {
     int g = fill(b, ws, n, [](const tp_sn_weight& w) { return ((w.cols + 255) / 256) * ((w.rows + kSlabRows - 1) / kSlabRows); });
-    if (tickets) {
-      hipLaunchKernelGGL(sn_wtu_v_kernel, dim3(g), dim3(256), 0, st, b);
-    } else {
-      hipLaunchKernelGGL(sn_wtu_kernel, dim3(g), dim3(256), 0, st, b);
-      hipLaunchKernelGGL(sn_v_kernel, dim3(n), dim3(1024), 0, st, b);
-    }
+    hipLaunchKernelGGL(sn_wtu_kernel, dim3(g), dim3(256), 0, st, b);
   }
-  int g = fill(b, ws, n, [](const tp_sn_weight& w) { return (w.rows + 3) / 4; });
-  if (tickets) {
-    hipLaunchKernelGGL(sn_wv_u_kernel, dim3(g), dim3(256), 0, st, b, training);
-  } else {
-    hipLaunchKernelGGL(sn_wv_kernel, dim3(g), dim3(256), 0, st, b);
-    hipLaunchKernelGGL(sn_u_kernel, dim3(n), dim3(256), 0, st, b, training);
-  }
-  g = fill(b, ws, n, [](const tp_sn_weight& w) { return (int)(((int64_t)w.rows * w.cols + 1023) / 1024); });
-  hipLaunchKernelGGL(sn_scale_kernel, dim3(g), dim3(256), 0, st, b);
+  int g = fill(b, ws, n, [](const tp_sn_weight& w) { return (w.rows + kWvRows - 1) / kWvRows; });
+  static unsigned long long flags = 0;
+  if ((size_t)max_cols * sizeof(float) > 32 * 1024 && tp::first_use_on_device(flags))
+    TP_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(sn_wv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) == hipSuccess,
+               "cannot raise the LDS limit");
+  hipLaunchKernelGGL(sn_wv_kernel, dim3(g), dim3(256), (size_t)max_cols * sizeof(float), st, b, training);
+  g = fill(b, ws, n, [](const tp_sn_weight& w) { return (int)(((int64_t)w.rows * w.cols + kScaleElems - 1) / kScaleElems); });
+  hipLaunchKernelGGL(sn_scale_kernel, dim3(g), dim3(256), 0, st, b, training);
   return tp::check_launch("tp_sn_fwd");
 }
 
@@ -311,7 +268,6 @@ extern "C" int tp_sn_bwd(const tp_sn_weight* ws, int n, tp_stream_t stream) {
   if (int rc = check(ws, n, true, "tp_sn_bwd")) return rc;
   hipStream_t st = (hipStream_t)stream;
   Batch b;
-  b.tickets = nullptr;
   int g = fill(b, ws, n, [](const tp_sn_weight& w) { return (int)(((int64_t)w.rows * w.cols + 4095) / 4096); });
   hipLaunchKernelGGL(sn_dot_kernel, dim3(g), dim3(256), 0, st, b);
   g = fill(b, ws, n, [](const tp_sn_weight& w) { return (int)(((int64_t)w.rows * w.cols + 1023) / 1024); });

@@ -248,9 +248,10 @@ class DiscStepSchedule:
             gw_real = self._backward_plain(f_real, n_real.w, fake_forward_and_losses(f_real.out))
         res.d_real = f_real.out
         gw_fake = self._backward_plain(state["f_fake"], state["n_fake"].w, state["g_fake"])
-        grads = ops.spectral_norm_bwd(gw_real, n_real.w, n_real.u, n_real.v, n_real.sigma)
         n_fake = state["n_fake"]
-        grads = ops.spectral_norm_bwd(gw_fake, n_fake.w, n_fake.u, n_fake.v, n_fake.sigma, accumulate_into=grads)
+        # both normalised instances of the weights (real pass, fake pass) in one pair of launches: their terms are added per element
+        grads = ops.spectral_norm_bwd(gw_real, n_real.w, n_real.u, n_real.v, n_real.sigma,
+                                      second=(gw_fake, n_fake.w, n_fake.u, n_fake.v, n_fake.sigma))
         for conv, g in zip(self.convs(), grads):
             conv.weight_orig.grad = g
         return res

@@ -571,7 +571,6 @@ def eval_metrics(rgb_static: Tensor, image: Tensor, obj_mask: Tensor, H: int, W:
     return -10.0 * torch.log10(mse), out[:, 1].sum() / n, mse
 
 
-_sn_ticket_arrays = {}       # (device index, stream) -> zero-filled int32 tensor (the kernels leave it zero)
 _ticket_words = {}           # (device index, stream, entry point) -> one zero-filled int32 word (the kernel leaves it zero)
 
 
@@ -587,27 +586,11 @@ def _ticket(dev, name: str) -> int:
     return t.data_ptr()
 
 
-def _sn_tickets(dev) -> Optional[int]:
-    """Arrival counters of the fused spectral-norm kernels for the current stream (launches on different streams may overlap and
-    must not share them).  Inside a hipGraph capture on a stream that has none yet: None, i.e. the five-launch form."""
-    # measured (B=4 GAN step, same box, three alternating runs each): 3 launches 657-660 it/s, 5 launches 666-667 it/s -- the
-    # last-arriving workgroup's agent-scope loads (~2 us each, past the L2) cost more than the two launches they replace
-    if os.environ.get("TP_SN_FUSED") != "1":
-        return None
-    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
-    t = _sn_ticket_arrays.get(key)
-    if t is None:
-        if torch.cuda.is_current_stream_capturing():
-            return None
-        t = _sn_ticket_arrays[key] = torch.zeros(2 * _lib.SN_MAX_WEIGHTS, dtype=torch.int32, device=dev)
-    return t.data_ptr()
-
-
 @_on_tensor_device
 def spectral_norm_fwd(weights, us, vs, training: bool, keep_uv: bool = False, out=None):
     """weights[i] [out, ...] (contiguous), us[i] [out], vs[i] [K]: one power iteration per weight when ``training``
     (u, v updated IN PLACE, like torch.nn.utils.spectral_norm), then W_sn = W / sigma.  Returns (W_sn list, sigma
-    list of 1-element tensors).  All weights of a module in five launches (three with TP_SN_FUSED=1: slower, see _sn_tickets).  ``keep_uv``: also returns copies of u / v as
+    list of 1-element tensors).  All weights of a module in three launches (two in eval mode).  ``keep_uv``: also returns copies of u / v as
     they stand after this call (written by the last launch) as a third / fourth list.
     ``out`` = (W_sn list, sigma list, u-copy list, v-copy list, work list) of pre-allocated tensors (spectral_norm_buffers): nothing is
     allocated -- the captured training step writes the NEXT iteration's normalised weights into static buffers."""
@@ -637,7 +620,7 @@ def spectral_norm_fwd(weights, us, vs, training: bool, keep_uv: bool = False, ou
         if keep_uv:
             a.u_out, a.v_out = u_copies[i].data_ptr(), v_copies[i].data_ptr()
         outs.append(o); sigmas.append(sg); keep += [w, wk]
-    check(lib.tp_sn_fwd(arr, n, int(bool(training)), _sn_tickets(weights[0].device), _stream()), "tp_sn_fwd")
+    check(lib.tp_sn_fwd(arr, n, int(bool(training)), _stream()), "tp_sn_fwd")
     return (outs, sigmas, u_copies, v_copies) if keep_uv else (outs, sigmas)
 
 
@@ -651,10 +634,11 @@ def spectral_norm_buffers(weights, us, vs):
 
 
 @_on_tensor_device
-def spectral_norm_bwd(grads_sn, weights_sn, us, vs, sigmas, accumulate_into=None):
+def spectral_norm_bwd(grads_sn, weights_sn, us, vs, sigmas, accumulate_into=None, second=None):
     """dL/dW from dL/dW_sn with u, v treated as constants (torch's convention): (G - <G, W_sn> u v^T) / sigma.
-    ``accumulate_into``: a list of tensors the results are ADDED to (the second normalised instance of the same weights in one
-    optimiser step); they are what is returned."""
+    ``accumulate_into``: a list of tensors the results are ADDED to; they are what is returned.
+    ``second`` = (grads_sn2, weights_sn2, us2, vs2, sigmas2): a second normalised instance of the same weights in one optimiser
+    step (the discriminator step's fake pass) -- its term is added inside the same two launches."""
     lib = _lib.load()
     n = len(grads_sn)
     arr = (_lib.SnWeight * n)()
@@ -669,6 +653,13 @@ def spectral_norm_bwd(grads_sn, weights_sn, us, vs, sigmas, accumulate_into=None
         a.u, a.v, a.weight_sn, a.sigma, a.grad_sn, a.grad, a.work = (u.data_ptr(), v.data_ptr(), ws.data_ptr(), sg.data_ptr(),
                                                                        g.data_ptr(), o.data_ptr(), wk.data_ptr())
         a.rows, a.cols = rows, cols
+        if second is not None:
+            g2 = _f32(second[0][i], "grad")
+            if g2.shape != g.shape or second[1][i].shape != ws.shape:
+                raise ValueError("spectral_norm_bwd: the second instance must have the shapes of the first")
+            a.grad_sn2, a.weight_sn2, a.u2, a.v2, a.sigma2 = (g2.data_ptr(), second[1][i].data_ptr(), second[2][i].data_ptr(),
+                                                              second[3][i].data_ptr(), second[4][i].data_ptr())
+            keep.append(g2)
         outs.append(o); keep += [g, wk]
     check(lib.tp_sn_bwd(arr, n, _stream()), "tp_sn_bwd")
     return outs
@@ -767,20 +758,24 @@ def inorm_lrelu_bwd_bwd(xhat: Tensor, rstd: Tensor, gy: Tensor, ggx: Tensor, slo
 
 # ------------------------------------------------------------------------------------------ K10
 @_on_tensor_device
-def rmsprop_step(params, grads, square_avgs, lr, alpha: float = 0.99, eps: float = 1e-8, gate: Optional[Tensor] = None) -> None:
+def rmsprop_step(params, grads, square_avgs, lr, alpha: float = 0.99, eps: float = 1e-8, gate: Optional[Tensor] = None, steps=None) -> None:
     """One launch: sq = alpha sq + (1 - alpha) g^2;  p -= lr g / (sqrt(sq) + eps) for up to 16 tensors per call.
     ``lr``: python float, or a 0-dim CUDA tensor read on the device (captured training step).  ``gate``: int32 device words;
-    if any is non-zero nothing is changed."""
+    if any is non-zero nothing is changed (the step counters included)."""
     lib = _lib.load()
     lr_dev = lr.data_ptr() if isinstance(lr, torch.Tensor) else None
     lr_host = 0.0 if isinstance(lr, torch.Tensor) else float(lr)
     for i0 in range(0, len(params), _lib.RMSPROP_MAX_TENSORS):
-        chunk = list(zip(params, grads, square_avgs))[i0:i0 + _lib.RMSPROP_MAX_TENSORS]
+        chunk = list(zip(params, grads, square_avgs, steps if steps is not None else [None] * len(params)))[i0:i0 + _lib.RMSPROP_MAX_TENSORS]
         arr = (_lib.RmspropTensor * len(chunk))()
-        for a, (p, g, sq) in zip(arr, chunk):
+        for a, (p, g, sq, st) in zip(arr, chunk):
             if not (p.is_contiguous() and g.is_contiguous() and sq.is_contiguous() and p.dtype == g.dtype == sq.dtype == torch.float32):
                 raise _lib.TexposeLibraryError("rmsprop_step needs contiguous float32 tensors")
             a.param, a.grad, a.square_avg, a.numel = p.data_ptr(), g.data_ptr(), sq.data_ptr(), p.numel()
+            if st is not None:                                 # (``steps``: 0-dim float32 DEVICE tensors, += 1 by the same launch)
+                if not (st.is_cuda and st.dtype == torch.float32):
+                    raise _lib.TexposeLibraryError("rmsprop_step: step counters must be float32 device tensors")
+                a.step = st.data_ptr()
         check(lib.tp_rmsprop_step(arr, len(chunk), lr_dev, lr_host, float(alpha), float(eps), _ptr(gate), gate.numel() if gate is not None else 0,
                                   _stream()), "tp_rmsprop_step")
 

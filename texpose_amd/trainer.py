@@ -63,9 +63,12 @@ class FusedRMSprop(torch.optim.RMSprop):
                     st["step"] = torch.zeros((), dtype=torch.float32, device=p.device) if group["capturable"] else torch.tensor(0.0)
                     st["square_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
             if ps:
+                steps = [self.state[p]["step"] for p in ps]
+                on_device = all(st.is_cuda for st in steps)        # (capturable: the launch advances them; else a host-side add)
                 ops.rmsprop_step([p.data for p in ps], [p.grad.contiguous() for p in ps], [self.state[p]["square_avg"] for p in ps],
-                                 group["lr"], group["alpha"], group["eps"], gate=self.gate)
-                torch._foreach_add_([self.state[p]["step"] for p in ps], 1)
+                                 group["lr"], group["alpha"], group["eps"], gate=self.gate, steps=steps if on_device else None)
+                if not on_device:
+                    torch._foreach_add_(steps, 1)
         return None
 
 

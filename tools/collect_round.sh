@@ -18,11 +18,8 @@ python3 tools/launch_sequence.py gpurun_out/$T/gan4 > gpurun_out/$T/launch_seque
 for i in 1 2; do python3 tools/train_bench.py 4 1 200 1 f16x3 2>&1 | tail -1; python3 tools/train_bench.py 4 0 200 1 f16x3 2>&1 | tail -1; python3 tools/train_bench.py 32 0 60 1 f16x3 2>&1 | tail -1; done > gpurun_out/$T/train_lines.txt
 timeout 600 python bench.py --config c5 > gpurun_out/$T/c5.json 2> gpurun_out/$T/c5.err
 # the GAN loop with one round-3 change switched off at a time (same box, alternating with the product configuration)
-( for e in TP_X=1 TP_DISC_AUTOGRAD=1 TP_X=1 TP_NO_FEAT_BRANCH=1 TP_X=1 TP_NO_SN_PREFETCH=1 TP_X=1 TP_TORCH_RNG=1 TP_X=1 TP_SN_FUSED=1 TP_X=1; do
+( for e in TP_X=1 TP_DISC_AUTOGRAD=1 TP_X=1 TP_NO_FEAT_BRANCH=1 TP_X=1 TP_NO_SN_PREFETCH=1 TP_X=1 TP_TORCH_RNG=1 TP_X=1; do
     echo "$e $(env $e python3 tools/train_bench.py 4 1 200 1 f16x3 2>&1 | tail -1 | cut -c1-75)"; done ) > gpurun_out/$T/gan_ablations.txt
-TP_SN_FUSED=1 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/$T/gan4f -o t -- python3 tools/train_bench.py 4 1 12 1 f16x3 > gpurun_out/$T/gan4f.log 2>&1
-python3 tools/launch_histogram.py gpurun_out/$T/gan4f > gpurun_out/$T/launch_histogram_sn_fused.txt 2>&1
-rm -rf gpurun_out/$T/gan4f
 python3 tools/kstats.py gpurun_out/$T/train32 wgrad dgrad mlp_fwd finalize
 rm -rf gpurun_out/$T/train32 gpurun_out/$T/gan4
 cat gpurun_out/$T/train_lines.txt | cut -c1-100
