@@ -37,6 +37,11 @@ NCH = 115
 # timing experiments only (results are WRONG): TP_ASM_EXPERIMENT = nodma | nobarrier | noconv | recnostore (recording
 # blocks issue no vector stores) | recnolds (no staging-tile writes / reads either)
 EXPERIMENT = os.environ.get("TP_ASM_EXPERIMENT", "")
+# hi / lo split of a converted operand: "mix" (round 4) = v_cvt_pkrtz of the two values IS the truncation to 11 significand bits,
+# and lo = v - float(hi) comes from v_fma_mix_f32 reading hi as fp16 (exact; also right when hi is an fp16 subnormal, where the
+# masked fp32 value kept bits the fp16 conversion then dropped): 11 VALU instructions per two elements.  "and" = rounds 2-3:
+# hi = v & 0xFFFFE000, lo = v - hi, two conversions: 13 (A/B build: make split_and).
+SPLIT = os.environ.get("TP_ASM_SPLIT", "mix")
 
 VB = 160
 def F_hi(slot): return VB + 8 * slot
@@ -65,24 +70,33 @@ def mfma(dst, a, b, c=None):
 
 
 def conv(src_base, tile, g, bank):
-    """13 VALU instructions: elements 2g, 2g+1 of source tile `tile` -> packed word g of the hi / lo operands in `bank`"""
+    """11 (13 with SPLIT = "and") VALU instructions: elements 2g, 2g+1 of source tile `tile` -> packed word g of the hi / lo operands in `bank`"""
     xh = XB[bank] + (g >> 2) * 4 + (g & 3)
     xl = XB[bank] + 8 + (g >> 2) * 4 + (g & 3)
     t0, t1, h0, h1 = T, T + 1, T + 2, T + 3
     a = src_base + 16 * tile + 2 * g
-    return ["v_accvgpr_read_b32 v%d, a%d" % (t0, a),
+    head = ["v_accvgpr_read_b32 v%d, a%d" % (t0, a),
             "v_accvgpr_read_b32 v%d, a%d" % (t1, a + 1),
             "v_mul_f32 v%d, %%[kinv], v%d" % (t0, t0),
             "v_mul_f32 v%d, %%[kinv], v%d" % (t1, t1),
             "v_max_f32 v%d, 0, v%d" % (t0, t0),
-            "v_max_f32 v%d, 0, v%d" % (t1, t1),
-            "v_and_b32 v%d, %%[mask], v%d" % (h0, t0),
-            "v_and_b32 v%d, %%[mask], v%d" % (h1, t1),
-            "v_sub_f32 v%d, v%d, v%d" % (t0, t0, h0),
-            "v_sub_f32 v%d, v%d, v%d" % (t1, t1, h1),
-            "v_cvt_pkrtz_f16_f32 v%d, v%d, v%d" % (xh, h0, h1),
-            "v_cvt_pkrtz_f16_f32 v%d, v%d, v%d" % (xl, t0, t1),
-            "v_pk_max_f16 %%[amax], %%[amax], v%d" % xh]
+            "v_max_f32 v%d, 0, v%d" % (t1, t1)]
+    return head + split_ops(t0, t1, h0, h1, xh, xl) + ["v_pk_max_f16 %%[amax], %%[amax], v%d" % xh]
+
+
+def split_ops(t0, t1, h0, h1, xh, xl):
+    """(t0, t1) fp32 -> packed fp16 hi (xh) and lo (xl) words; t0 / t1 keep their values in the "mix" form"""
+    if SPLIT == "and":
+        return ["v_and_b32 v%d, %%[mask], v%d" % (h0, t0),
+                "v_and_b32 v%d, %%[mask], v%d" % (h1, t1),
+                "v_sub_f32 v%d, v%d, v%d" % (t0, t0, h0),
+                "v_sub_f32 v%d, v%d, v%d" % (t1, t1, h1),
+                "v_cvt_pkrtz_f16_f32 v%d, v%d, v%d" % (xh, h0, h1),
+                "v_cvt_pkrtz_f16_f32 v%d, v%d, v%d" % (xl, t0, t1)]
+    return ["v_cvt_pkrtz_f16_f32 v%d, v%d, v%d" % (xh, t0, t1),
+            "v_fma_mix_f32 v%d, -v%d, 1.0, v%d op_sel_hi:[1,0,0]" % (h0, xh, t0),
+            "v_fma_mix_f32 v%d, -v%d, 1.0, v%d op_sel:[1,0,0] op_sel_hi:[1,0,0]" % (h1, xh, t1),
+            "v_cvt_pkrtz_f16_f32 v%d, v%d, v%d" % (xl, h0, h1)]
 
 
 # ------------------------------------------------------------------------------------------------ recording variants
@@ -122,7 +136,7 @@ def conv_rec(src_base, tile, g, bank, mask=True):
                 "v_addc_co_u32_e32 v%d, vcc, v%d, v%d, vcc" % (MK, MK, MK),
                 "v_cmp_lt_f32_e32 vcc, 0, v%d" % t1,
                 "v_addc_co_u32_e32 v%d, vcc, v%d, v%d, vcc" % (MK, MK, MK)]
-    out += c[6:13]
+    out += c[6:]
     return out
 
 
@@ -449,8 +463,8 @@ def gen_head(src, rec=False):
         if not rec:
             if g == 7:
                 return [[], [], [], [], []]
-            # 104 VALU instructions over five gaps: the head is conversion-bound (one tile per six MFMAs)
-            return [cv[0:21], cv[21:42], cv[42:63], cv[63:84], cv[84:104]]
+            # 88 (104) VALU instructions over five gaps: the head is conversion-bound (one tile per six MFMAs)
+            return split_even(cv, 5)
         # tile g sits in its own accumulator registers again (read back at the end of the previous group / the prologue,
         # after its conversion): wait for those reads -- at
         # least the two ring refills after them are younger, so "at most two outstanding" covers them --, store the tile,
@@ -537,12 +551,7 @@ def conv_gate(src_base, tile, g, bank, xops=True):
            "ds_write_b32 %%[recw], v%d offset:%d" % (h1, rec_wr_off(r1)),
            "v_max3_f32 %%[dzm], |v%d|, |v%d|, %%[dzm]" % (h0, h1)]
     if xops:
-        out += ["v_and_b32 v%d, %%[mask], v%d" % (h0, t0),
-                "v_and_b32 v%d, %%[mask], v%d" % (h1, t1),
-                "v_sub_f32 v%d, v%d, v%d" % (t0, t0, h0),
-                "v_sub_f32 v%d, v%d, v%d" % (t1, t1, h1),
-                "v_cvt_pkrtz_f16_f32 v%d, v%d, v%d" % (xh, h0, h1),
-                "v_cvt_pkrtz_f16_f32 v%d, v%d, v%d" % (xl, t0, t1)]
+        out += split_ops(t0, t1, h0, h1, xh, xl)
     return out
 
 

@@ -16,7 +16,10 @@
 // 8s..8s+7 of a 32x32 tile, converted to fp16, ARE the B fragment of k-step s (rows 16s + 8(j>>2) + 4h + (j&3)),
 // and the packed weights absorb that row permutation (mlp_layout.h, "f16x3 stream").
 #include "mlp_mma.h"
-#include "wide_asm.inc.h"
+#ifndef TP_WIDE_ASM_INC
+#define TP_WIDE_ASM_INC "wide_asm.inc.h"
+#endif
+#include TP_WIDE_ASM_INC
 #include <cstdlib>
 #include <type_traits>
 
