@@ -22,10 +22,6 @@ import os
 import sys
 import time
 
-# The replayed training step is a multi-branch hipGraph; ROCm maps its branches onto hardware queues, and every dependency between
-# two queues costs far more than one inside a queue (measured on the B=4 GAN loop, same box: 8 queues 3.15 ms, 4 (the default) 1.23 ms,
-# 2 queues 1.17 ms per iteration; profiles/r4).  Read by the HIP runtime when it initialises, so it is set before torch is imported.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
 import numpy as np
 import torch
 

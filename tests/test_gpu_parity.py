@@ -927,13 +927,13 @@ def test_flagged_training_iteration_applies_no_update(ops, graphed):
         torch.cuda.synchronize()
         before = {k: v.detach().clone() for k, v in g2.state_dict().items()}
         tr2._bad[0] = 1                                  # what a raised range flag leaves in the gate word
-        tr2._graph.replay()
+        tr2.replay()
         torch.cuda.synchronize()
         for k, v in g2.state_dict().items():
             if k.startswith(("nerf.", "latent")) or "weight_orig" in k:
                 assert torch.equal(v, before[k]), k
         tr2._bad.zero_()
-        tr2._graph.replay()
+        tr2.replay()
         torch.cuda.synchronize()
         assert any(not torch.equal(v, before[k]) for k, v in g2.state_dict().items() if k.startswith(("nerf.mlp_", "latent")))
     ops.mlp_status(dev()).zero_()

@@ -256,41 +256,49 @@ class Graph(torch.nn.Module):
         var.nocs_sample, var.normal_sample = var.nocs_pred * ms, var.normal_pred * ms
         return var
 
-    def nerf_forward(self, opt, var, mode=None):
-        pose = self.get_pose(opt, var, mode=mode)
-        depth_range = (var.z_near[:, :, None], var.z_far[:, :, None])
-        if opt.nerf.rand_rays and mode == "train":
-            # var.jitter_rand (optional, [B,R,N,1]) pins the stratified draw for parity tests
-            ret = self.render(opt, pose, intr=var.intr, ray_idx=var.ray_idx, depth_range=depth_range,
-                              sample_idx=var.idx, mode=mode, rand=var.get("jitter_rand"))
-        elif mode == "val":
-            ret = self.render_by_slices(opt, pose, intr=var.intr, depth_range=depth_range, object_mask=var.obj_mask,
-                                        sample_idx=None, mode=mode)
-        else:
-            R_dist = rotation_distance(var.pose[..., :3, :3], var.pose_anchor[..., :3, :3]).unsqueeze(-1)
-            cand = torch.topk(R_dist, k=int(opt.render.N_candidate), dim=0, largest=False, sorted=True)[1]
-            light_idx = cand[torch.randperm(len(cand))[0]][0]
-            ret = self.render_by_slices(opt, pose, intr=var.intr, depth_range=depth_range, object_mask=var.obj_mask,
-                                        sample_idx=light_idx, mode=mode)
-        var.update(ret)
-        if mode == "train" and opt.gan is not None and hasattr(self, "discriminator"):
-            if opt.gan.geo_conditional:
-                var = self.sample_geometry(opt, var, mode)
-            B, h, w, _ = var.ray_idx.shape
-            if "gathered" in var and var.rgb.is_cuda and var.get("gathered_for") is var.ray_idx:
-                # K13: real / fake stacks in one launch (fake differentiable wrt rgb); the discriminator step of the same
-                # iteration re-uses them (same values: it detaches the very same render)
-                var.patch_real_nerf, patch_fake, var.patch_real_stack = autograd_ops.disc_patches(
-                    var.get("rgb_disc", var.rgb), var.gathered, (h, w), bool(opt.gan.geo_conditional))
-                var.patch_fake_nerf, var.disc_patches_for = patch_fake, var.ray_idx
+    def nerf_forward(self, opt, var, mode=None, stage=None):
+        """``stage`` (the captured training step that runs as several hipGraphs, trainer.GraphedGanTrainer): "render" = everything up
+        to the discriminator's patch stacks (render, gathers, K13 stacks), "consume" = the rest (feature chain, the discriminator's
+        pass for the generator) on a ``var`` that went through "render"; None = both, as the reference's nerf_forward."""
+        if stage != "consume":
+            pose = self.get_pose(opt, var, mode=mode)
+            depth_range = (var.z_near[:, :, None], var.z_far[:, :, None])
+            if opt.nerf.rand_rays and mode == "train":
+                # var.jitter_rand (optional, [B,R,N,1]) pins the stratified draw for parity tests
+                ret = self.render(opt, pose, intr=var.intr, ray_idx=var.ray_idx, depth_range=depth_range,
+                                  sample_idx=var.idx, mode=mode, rand=var.get("jitter_rand"))
+            elif mode == "val":
+                ret = self.render_by_slices(opt, pose, intr=var.intr, depth_range=depth_range, object_mask=var.obj_mask,
+                                            sample_idx=None, mode=mode)
             else:
-                patch_fake = var.rgb.view(B, h, w, 3).permute(0, 3, 1, 2)
+                R_dist = rotation_distance(var.pose[..., :3, :3], var.pose_anchor[..., :3, :3]).unsqueeze(-1)
+                cand = torch.topk(R_dist, k=int(opt.render.N_candidate), dim=0, largest=False, sorted=True)[1]
+                light_idx = cand[torch.randperm(len(cand))[0]][0]
+                ret = self.render_by_slices(opt, pose, intr=var.intr, depth_range=depth_range, object_mask=var.obj_mask,
+                                            sample_idx=light_idx, mode=mode)
+            var.update(ret)
+        if mode == "train" and opt.gan is not None and hasattr(self, "discriminator"):
+            B, h, w, _ = var.ray_idx.shape
+            if stage != "consume":
                 if opt.gan.geo_conditional:
-                    patch_fake = torch.cat([patch_fake, var.nocs_sample, var.normal_sample], dim=1)
+                    var = self.sample_geometry(opt, var, mode)
+                if "gathered" in var and var.rgb.is_cuda and var.get("gathered_for") is var.ray_idx:
+                    # K13: real / fake stacks in one launch (fake differentiable wrt rgb); the discriminator step of the same
+                    # iteration re-uses them (same values: it detaches the very same render)
+                    var.patch_real_nerf, patch_fake, var.patch_real_stack = autograd_ops.disc_patches(
+                        var.get("rgb_disc", var.rgb), var.gathered, (h, w), bool(opt.gan.geo_conditional))
+                    var.patch_fake_nerf, var.disc_patches_for = patch_fake, var.ray_idx
+                else:
+                    patch_fake = var.rgb.view(B, h, w, 3).permute(0, 3, 1, 2)
+                    if opt.gan.geo_conditional:
+                        patch_fake = torch.cat([patch_fake, var.nocs_sample, var.normal_sample], dim=1)
+                    var.patch_fake_nerf = patch_fake
+                if stage == "render":
+                    return var
             # (the feature chain is issued BEFORE the discriminator's pass: with the opposite order the replayed hipGraph put both chains
             # on one hardware queue, one after the other -- 1.406 vs 1.331 ms per B=4 iteration on one box, profiles/r4)
             self._feature_loss_early(opt, var, (h, w), mode)
-            var.d_fake_nerf = self.discriminator(opt, patch_fake, var.ray_scales)
+            var.d_fake_nerf = self.discriminator(opt, var.patch_fake_nerf, var.ray_scales)
         return var
 
     def _feature_loss_early(self, opt, var, hw, mode):

@@ -221,13 +221,18 @@ class GanTrainer:
         torch.autograd.backward(terms, ws)
         return loss
 
-    def nerf_forward_loss(self, var):
-        """First half of the nerf step: render, losses, weighted total -- everything the discriminator step needs."""
+    def nerf_forward_loss(self, var, stage=None):
+        """First half of the nerf step: render, losses, weighted total -- everything the discriminator step needs.
+        ``stage``: "render" (up to the discriminator's patch stacks; returns (var, None)) / "consume" (the rest), see
+        Graph.nerf_forward."""
         opt, g = self.opt, self.graph
-        if self.has_disc:
-            self._toggle(g.discriminator, False)
-        self.optim_nerf.zero_grad(set_to_none=True)
-        v = g.nerf_forward(opt, var, mode="train")
+        if stage != "consume":
+            if self.has_disc:
+                self._toggle(g.discriminator, False)
+            self.optim_nerf.zero_grad(set_to_none=True)
+        v = g.nerf_forward(opt, var, mode="train", stage=stage)
+        if stage == "render":
+            return v, None
         loss = g.compute_loss(opt, v, mode="train", train_step="nerf")
         return v, loss
 
@@ -424,6 +429,7 @@ class GraphedGanTrainer(GanTrainer):
         # gates are 1 only while all are 0 (separate words: the two branches of the captured step never write the same one)
         self._bad = torch.zeros(3, dtype=torch.int32, device=dev)
         self._side = None                        # second stream of the captured step (discriminator branch)
+        self._four, self._g4, self._ev4 = False, None, None    # the step as four graphs on two streams (`_use_four_graphs`)
         # what the optimiser launches read: the words as they stood when the step's own flags had been folded in
         self._gate_nerf, self._gate_disc = torch.zeros_like(self._bad), torch.zeros_like(self._bad)
         if isinstance(self.optim_nerf, FusedAdam):
@@ -491,7 +497,10 @@ class GraphedGanTrainer(GanTrainer):
             self.red_disc.reduce()
 
     def _body(self, var):
-        """One iteration (what is captured as ONE graph; `_body_a` / `_body_b` when the collectives stay outside)."""
+        """One iteration (what is captured as ONE graph; `_body_a` / `_body_b` when the collectives stay outside; `_four_eager` is
+        the same iteration in the four-graph form)."""
+        if self._four:
+            return self._four_eager(var)
         out = self._body_a(var)
         if self._deferred:
             self._reduce_all()
@@ -568,6 +577,127 @@ class GraphedGanTrainer(GanTrainer):
         if dloss is not None:
             loss.update({k: v for k, v in dloss.items() if k != "all"})
         return {k: v.detach() for k, v in loss.items() if torch.is_tensor(v)}
+
+    # ------------------------------------------------------------------ the step as FOUR graphs on two streams (one rank)
+    # A replayed multi-branch hipGraph resolves a dependency between two of its hardware queues late: the generator's backward sat
+    # behind ~60 % of the discriminator chain it does not depend on (profiles/r4: 220 us of a 1.22 ms iteration).  With the step cut
+    # into linear pieces the two chains are two STREAMS, and the only dependencies between them are three events:
+    #     main:  [wait D2 of the iteration before]  G1 = patch coordinates .. render .. gathers, patch stacks   -> ev_patches
+    #            [wait ev_sn]                       G2 = feature chain || D(fake), losses, gate, backward, Adam
+    #     disc:  D1 = the three spectral normalisations (after its own RMSprop step, stream order)             -> ev_sn
+    #            [wait ev_patches]                  D2 = discriminator step, RMSprop                             -> ev_d2
+    # (G2 keeps the feature chain as a branch of its own.)  Same kernels, same arithmetic as the one-graph form.
+    def _use_four_graphs(self, var):
+        if os.environ.get("TP_FOUR_GRAPHS", "1") != "1" or not self.has_disc or self._has_collective() or self._split_around_collectives():
+            return False
+        p, B = int(self.opt.patch_size), len(var.idx)
+        probe = torch.empty(0, device=var.idx.device).new_empty((B, 0, p, p))
+        disc = self.graph.discriminator
+        return (self._disc_schedule(probe) is not None and hasattr(disc, "prefetch_spectral_weights") and disc.training
+                and os.environ.get("TP_NO_SN_PREFETCH") != "1" and os.environ.get("TP_NO_BRANCH_OVERLAP") != "1")
+
+    def _seg_sn(self):
+        disc = self.graph.discriminator
+        disc.prefetch_spectral_weights(3)
+        # (the consumers run in OTHER graphs / on the other stream: their ordering behind this segment is the ev_sn event of the
+        # replay loop, not a wait recorded while one of them is being captured)
+        disc._sn_queue = [(o, sg, u, v, None) for o, sg, u, v, _ in disc._sn_queue]
+
+    def _seg_render(self, var):
+        opt = self.opt
+        counter = getattr(self, "_rng_counter", None)
+        self.graph.step_counter = self.graph.patch_sampler.device_counter = counter
+        try:
+            var = self.graph.get_ray_idx(opt, var)
+            if opt.nerf.sample_stratified and "jitter_rand" not in var and counter is None:
+                B, R = opt.batch_size, opt.patch_size ** 2
+                var.jitter_rand = torch.rand(B, R, opt.nerf.sample_intvs, 1, device=var.ray_idx.device)
+            var, _ = self.nerf_forward_loss(var, stage="render")
+        finally:
+            self.graph.step_counter = self.graph.patch_sampler.device_counter = None
+        return var
+
+    def _seg_generator(self, var):
+        dev = var.idx.device
+        if getattr(self.graph, "feat_stream", None) is None and os.environ.get("TP_NO_FEAT_BRANCH") != "1":
+            self.graph.feat_stream = torch.cuda.Stream(device=dev)
+        var, loss = self.nerf_forward_loss(var, stage="consume")
+        status = ops.mlp_status(dev) if self._uses_f16x3() else None
+        terms, ws = self._weighted_total(loss, flags=dict(bad=self._bad, word_finite=1, snapshot=self._gate_nerf, status=status,
+                                                          word_status=0, step_counter=getattr(self, "_rng_counter", None)))
+        torch.autograd.backward(terms, ws)
+        self._guard_nerf(var, loss)
+        self.nerf_apply()
+        return var, loss
+
+    def _seg_disc(self, var):
+        return self.disc_step(var, apply=True)
+
+    def _four_eager(self, var):
+        """The four segments on their two streams, eagerly (warm-up), with the same three dependencies as the replays."""
+        main = torch.cuda.current_stream(var.idx.device)
+        side = self._side
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            self._seg_sn()
+        var = self._seg_render(var)
+        side.wait_stream(main)
+        main.wait_stream(side)
+        var, loss = self._seg_generator(var)
+        with torch.cuda.stream(side):
+            var, dloss = self._seg_disc(var)
+        main.wait_stream(side)
+        loss.update({k: v for k, v in dloss.items() if k != "all"})
+        return {k: v.detach() for k, v in loss.items() if torch.is_tensor(v)}
+
+    def _capture_four(self, cap):
+        dev = self._bad.device
+        self._g4 = g4 = {k: torch.cuda.CUDAGraph() for k in ("D1", "G1", "G2", "D2")}
+        self._ev4 = {k: torch.cuda.Event() for k in ("sn", "patches", "g2", "d2")}
+        # Two memory pools, one per stream: graphs that share a pool must replay in capture order and never concurrently (a block freed
+        # while one is captured is handed to the next), which holds for D1 -> D2 and for G1 -> G2 but not across the streams.  Tensors
+        # that cross the streams (the spectral-norm sets, the render's patch stacks / scales) are kept referenced for the life of the
+        # graphs, so that no capture re-uses their memory.
+        with torch.cuda.graph(g4["D1"], stream=self._side):
+            self._seg_sn()
+        keep = [list(self.graph.discriminator._sn_queue)]
+        with torch.cuda.graph(g4["G1"], stream=cap):
+            var = self._seg_render(AttrDict(dict(self._static_in)))
+        keep.append(dict(var))
+        with torch.cuda.graph(g4["G2"], stream=cap, pool=g4["G1"].pool()):
+            var, loss = self._seg_generator(var)
+        keep.append(dict(var))
+        with torch.cuda.graph(g4["D2"], stream=self._side, pool=g4["D1"].pool()):
+            var, dloss = self._seg_disc(var)
+        keep.append(dict(var))
+        self._g4_keep = keep
+        loss.update({k: v for k, v in dloss.items() if k != "all"})
+        self._static_loss = {k: v.detach() for k, v in loss.items() if torch.is_tensor(v)}
+        self._four_first = True
+
+    def _replay_four(self):
+        g4, ev, side = self._g4, self._ev4, self._side
+        main = torch.cuda.current_stream(self._bad.device)
+        with torch.cuda.stream(side):
+            if self._four_first:                     # (parameters restored / loaded on the calling stream since the capture)
+                side.wait_stream(main)
+                self._four_first = False
+            else:
+                side.wait_event(ev["g2"])            # set 1 is read by the generator's backward through the frozen discriminator
+            g4["D1"].replay()
+            ev["sn"].record(side)
+        g4["G1"].replay()
+        ev["patches"].record(main)
+        main.wait_event(ev["sn"])
+        g4["G2"].replay()
+        ev["g2"].record(main)
+        with torch.cuda.stream(side):
+            side.wait_event(ev["patches"])
+            g4["D2"].replay()
+            ev["d2"].record(side)
+        # whatever the caller enqueues next on its stream -- reads of the step's losses, the next iteration's inputs and its G1, which
+        # overwrites the patch stacks / scales this discriminator step is reading -- comes after the discriminator step
+        main.wait_event(ev["d2"])
 
     def _prefetch_spectral_weights(self, var):
         """The spectral normalisations of this iteration's three discriminator passes (nerf step's D(fake), D(real), D(fake):
@@ -657,6 +787,9 @@ class GraphedGanTrainer(GanTrainer):
             if getattr(self, "_rng_counter", None) is None:
                 self._rng_counter = torch.zeros(1, dtype=torch.int64, device=dev)       # (attached to the graph only inside `_body_a`)
         self._static_in = AttrDict({k: v.clone() for k, v in var.items() if torch.is_tensor(v)})
+        self._four = self._use_four_graphs(var)
+        if self._four and self._side is None:
+            self._side = torch.cuda.Stream(device=dev)
         snap = self._snapshot()
         # warm up on the stream the capture will use: per-stream state (the tile counters of the convolution kernels,
         # ops._conv_scratch) must exist before the capture and is keyed by the stream
@@ -677,7 +810,9 @@ class GraphedGanTrainer(GanTrainer):
             self.optim_disc.zero_grad(set_to_none=True)
         self.graph.patch_sampler.update_device_bound()          # outside the capture
         self._graph_b = None
-        if self._split_around_collectives():
+        if self._four:
+            self._capture_four(side)
+        elif self._split_around_collectives():
             with torch.cuda.graph(self._graph, stream=side):
                 self._static_loss = self._body_a(AttrDict(dict(self._static_in)))
             self._graph_b = torch.cuda.CUDAGraph()
@@ -741,6 +876,23 @@ class GraphedGanTrainer(GanTrainer):
         self._bad_poll = None
         return self.capture(var, warmup=warmup)
 
+    def replay(self):
+        """Issue the captured step once on the current stream(s): one graph, four graphs on two streams (`_replay_four`), or -- several
+        ranks -- graph A, the gradient all-reduces, graph B."""
+        if self._four:
+            return self._replay_four()
+        self._graph.replay()
+        if self._graph_b is not None:                            # collectives between the two replays, stream-ordered
+            ev = getattr(self, "collective_events", None)        # (a list: HIP-event pairs around the step's reductions, bench.py)
+            if ev is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            self._reduce_all()
+            if ev is not None:
+                e1.record()
+                ev.append((e0, e1))
+            self._graph_b.replay()
+
     def train_iteration(self, var: AttrDict):
         if self._graph is None:
             self.capture(var)
@@ -767,17 +919,7 @@ class GraphedGanTrainer(GanTrainer):
             ev = torch.cuda.Event()
             ev.record()
             self._bad_poll = (poll, ev)
-        self._graph.replay()
-        if self._graph_b is not None:                            # collectives between the two replays, stream-ordered
-            ev = getattr(self, "collective_events", None)        # (a list: HIP-event pairs around the step's reductions, bench.py)
-            if ev is not None:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-            self._reduce_all()
-            if ev is not None:
-                e1.record()
-                ev.append((e0, e1))
-            self._graph_b.replay()
+        self.replay()
         self._after_step(fill_progress=False)
         flagged = self._read_bad()                              # outside the graph: event query of the pinned copy
         if flagged[0] and self._uses_f16x3():

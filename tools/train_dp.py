@@ -18,10 +18,6 @@ import sys
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-# The replayed training step is a multi-branch hipGraph; ROCm maps its branches onto hardware queues, and every dependency between
-# two queues costs far more than one inside a queue (measured on the B=4 GAN loop, same box: 8 queues 3.15 ms, 4 (the default) 1.23 ms,
-# 2 queues 1.17 ms per iteration; profiles/r4).  Read by the HIP runtime when it initialises, so it is set before torch is imported.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
 import torch                                                                    # noqa: E402
 
 
@@ -89,7 +85,9 @@ def measure(device, rank, world, global_batch=32, iters=50, warm=5, graphed=True
         coll = sum(a.elapsed_time(b) for a, b in trainer.collective_events) / len(trainer.collective_events)
     return dict(collective_ms=coll, metric="train iters/sec", value=1.0 / dt, ms_per_iter=dt * 1e3, n_gpus=world, global_batch=global_batch,
                 per_gpu_batch=global_batch // world, rays_per_iter=global_batch * 256, samples_per_iter=global_batch * 256 * 64,
-                launch=("hipGraph replay" if getattr(trainer, "_graph_b", None) is None else "two hipGraph replays with the gradient all-reduces between them") if graphed else "eager", recording_forward=graph.nerf.train_precision,
+                launch=("four hipGraph replays on two streams (render | generator step || spectral norm | discriminator step)" if getattr(trainer, "_four", False)
+                        else "hipGraph replay" if getattr(trainer, "_graph_b", None) is None
+                        else "two hipGraph replays with the gradient all-reduces between them") if graphed else "eager", recording_forward=graph.nerf.train_precision,
                 collective="one flat all-reduce per optimiser step (%.1f MB nerf, %.1f MB discriminator)"
                            % (trainer.red_nerf.nbytes / 1e6, (trainer.red_disc.nbytes if trainer.red_disc else 0) / 1e6),
                 loop="full GAN (render fwd+bwd, gathers, random-init VGG19[:15] feature loss, PatchGAN + R1, Adam + RMSprop)"
