@@ -733,6 +733,18 @@ def main():
     legs_failed = []
     leg = lambda name, fn: run_leg(legs_failed, name, fn)
 
+    # The train leg runs FIRST among the untimed legs: every stream a process creates takes the next hardware queue round-robin,
+    # and the trainer's graphs are fastest when its own streams are the first ones after the timed region's (DESIGN section 9,
+    # 'queues'); the roofline and masked-evaluation legs create timing streams of their own.
+    train = None
+    if not args.no_train:
+        train = leg("train", lambda: train_leg(device, rank, world))
+        if world == 1 and not args.no_cpu_baseline and "error" not in train:
+            train["cpu_baseline"] = leg("train.cpu_baseline", train_cpu_baseline)
+            if "error" not in train["cpu_baseline"]:
+                train["gpu_over_cpu"] = {"full_gan_loop_vs_cpu_render_only": train["full_gan_loop"]["value"] / train["cpu_baseline"]["value"],
+                                         "nerf_step_b4_vs_cpu": train["nerf_step_b4"]["value"] / train["cpu_baseline"]["value"]}
+
     hbm = None
     if rank == 0:
         hbm = leg("roofline_hbm", lambda: hbm_rooflines(device, dict(
@@ -743,15 +755,6 @@ def main():
     if rank == 0 and world == 1:
         eval_masked = leg("eval_masked", lambda: eval_masked_leg(device, graph, opt, sc))
         torch.cuda.empty_cache()
-    train = None
-    if not args.no_train:
-        train = leg("train", lambda: train_leg(device, rank, world))
-        if world == 1 and not args.no_cpu_baseline and "error" not in train:
-            train["cpu_baseline"] = leg("train.cpu_baseline", train_cpu_baseline)
-            if "error" not in train["cpu_baseline"]:
-                train["gpu_over_cpu"] = {"full_gan_loop_vs_cpu_render_only": train["full_gan_loop"]["value"] / train["cpu_baseline"]["value"],
-                                         "nerf_step_b4_vs_cpu": train["nerf_step_b4"]["value"] / train["cpu_baseline"]["value"]}
-
     trained = None
     if rank == 0 and world == 1 and not args.no_train and args.precision == "f16x3":
         # untimed leg: the f16x3 kernel on a TRAINED network (500 product-trainer iterations) and with the trunk feature

@@ -395,6 +395,12 @@ typedef struct tp_conv4s2_args {
 /* floats of workspace the operation `op` (TP_CONV_*) needs for these sizes; *n_counters = number of uint32 counters */
 int64_t tp_conv4s2_workspace(const tp_conv4s2_args* args, int op, int64_t* n_counters);
 int tp_conv4s2_fwd(const tp_conv4s2_args* args, tp_stream_t stream);
+/* The forward convolution with the InstanceNorm2d (affine = False) + LeakyReLU that follows it in the ladder in ONE launch, for 4x4 and
+ * 8x8 output maps (reference layers/discriminator.py:94-115): out = y = lrelu(xhat), xhat [N,Co,H/2,W/2], rstd [N*Co] as
+ * tp_inorm_lrelu_fwd returns them; the convolution's own output is not materialised.  Workspace / counters:
+ * tp_conv4s2_fwd_inorm_workspace (-1: map size not covered -> two launches). */
+int64_t tp_conv4s2_fwd_inorm_workspace(const tp_conv4s2_args* args, int64_t* n_counters);
+int tp_conv4s2_fwd_inorm(const tp_conv4s2_args* args, float eps, float slope, float* xhat, float* rstd, tp_stream_t stream);
 int tp_conv4s2_dgrad(const tp_conv4s2_args* args, tp_stream_t stream);
 int tp_conv4s2_wgrad(const tp_conv4s2_args* args, tp_stream_t stream);
 
@@ -588,6 +594,10 @@ typedef struct tp_disc_tail_args {
   const float* gy2;        /* bwd: [M2,N] extra cotangent rows of gW0 */
   const float* a2;         /* bwd: [M2,K] their inputs */
   float* gW1; float* gW2; float* gW3;
+  /* bwd, optional: the InstanceNorm2d + LeakyReLU backward of the ladder's LAST stage (K9 tp_inorm_lrelu_bwd) applied to c_a inside the
+   * launch: c_z [M,K] = rstd P(c_a s(xhat)) (+ in_addend); an instance = in_P consecutive columns (in_P | 64: the 4x4 map's 16),
+   * xhat [M,K], rstd [M K / in_P].  c_a may then be NULL (only c_z is written). */
+  const float* in_xhat; const float* in_rstd; const float* in_addend; float* c_z; int32_t in_P;
   void* workspace;         /* fwd, bwd_bwd */
   uint32_t* ticket;        /* fwd, bwd_bwd */
   int32_t M, M2, K, N, L, H;

@@ -2460,3 +2460,32 @@ def test_step_inputs_one_launch_for_the_per_iteration_host_state(ops):
     many = [(torch.zeros(33, device=d), torch.randn(33, device=d)) for _ in range(30)]           # more than one launch's table
     ops.step_inputs(many)
     assert all(torch.equal(a, b) for a, b in many)
+
+
+@pytest.mark.parametrize("N,C,HW,Co", [(4, 9, 16, 256), (4, 256, 8, 512), (1, 9, 16, 40), (3, 24, 8, 72), (8, 256, 8, 512), (5, 9, 16, 256)])
+def test_conv4s2_fwd_inorm_fused_launch(ops, N, C, HW, Co):
+    """tp_conv4s2_fwd_inorm (the ladder's stride-2 convolution with InstanceNorm + LeakyReLU in the epilogue of the workgroup that
+    holds an instance's split-K totals) against the two launches it replaces, K11 tp_conv4s2_fwd + K9 tp_inorm_lrelu_fwd (each pinned
+    to torch by its own test): y, xhat, rstd; ragged channel counts, odd image counts; two launches in a row give identical bits;
+    the autograd node for constant weights (the nerf step's pass) gives the unfused nodes' input gradient."""
+    from texpose_amd import autograd_ops
+    torch.manual_seed(N + C + Co)
+    x = torch.randn(N, C, HW, HW, device=dev())
+    w = torch.randn(Co, C, 4, 4, device=dev()) / (4 * C ** 0.5)
+    assert ops.conv4s2_fwd_inorm_supported(x)
+    y, xhat, rstd = ops.conv4s2_fwd_inorm(x, w, 1e-5, 0.2)
+    y_r, xhat_r, rstd_r = ops.inorm_lrelu_fwd(ops.conv4s2_fwd(x, w), 1e-5, 0.2)
+    torch.testing.assert_close(xhat, xhat_r, rtol=2e-5, atol=2e-5)
+    torch.testing.assert_close(y, y_r, rtol=2e-5, atol=2e-5)
+    torch.testing.assert_close(rstd, rstd_r, rtol=2e-5, atol=0)
+    again = ops.conv4s2_fwd_inorm(x, w, 1e-5, 0.2)
+    assert all(torch.equal(a, b) for a, b in zip(again, (y, xhat, rstd)))
+    stack = torch.zeros(2 * N, Co, HW // 2, HW // 2, device=dev())
+    y2, _, _ = ops.conv4s2_fwd_inorm(x, w, 1e-5, 0.2, y_out=stack[:N])
+    assert y2.data_ptr() == stack.data_ptr() and torch.equal(stack[:N], y) and float(stack[N:].abs().max()) == 0.0
+    # autograd node (constant weight) vs the unfused nodes
+    cot = torch.randn_like(y)
+    xa, xb = x.clone().requires_grad_(), x.clone().requires_grad_()
+    (autograd_ops.conv4s2_inorm(xa, w, 1e-5, 0.2) * cot).sum().backward()
+    (autograd_ops.inorm_lrelu(autograd_ops.conv4s2(xb, w), 1e-5, 0.2) * cot).sum().backward()
+    assert rel_l2(xa.grad, xb.grad) < 2e-5

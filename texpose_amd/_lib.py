@@ -28,7 +28,7 @@ SYMBOLS = (
     "tp_render_eval_workspace_bytes", "tp_render_eval",
     "tp_inorm_lrelu_fwd", "tp_inorm_lrelu_bwd", "tp_inorm_lrelu_bwd_bwd",
     "tp_rmsprop_step",
-    "tp_conv4s2_workspace", "tp_conv4s2_fwd", "tp_conv4s2_dgrad", "tp_conv4s2_wgrad",
+    "tp_conv4s2_workspace", "tp_conv4s2_fwd", "tp_conv4s2_dgrad", "tp_conv4s2_wgrad", "tp_conv4s2_fwd_inorm_workspace", "tp_conv4s2_fwd_inorm",
     "tp_conv3s1_workspace", "tp_conv3s1_fwd", "tp_conv3s1_dgrad",
     "tp_patch_coords", "tp_bce_logits_fwd", "tp_bce_logits_bwd", "tp_feat_inputs_fwd", "tp_feat_inputs_bwd", "tp_disc_inputs", "tp_step_flags", "tp_adam_step", "tp_step_inputs",
     "tp_fake_patch_bwd", "tp_feat_pair_loss_fwd", "tp_feat_pair_loss_bwd", "tp_sumsq_mean_fwd", "tp_sumsq_mean_bwd", "tp_sumsq_mean_fwd_bwd", "tp_gan_disc_losses", "tp_maxpool2_fwd", "tp_maxpool2_bwd", "tp_latent_rows_fwd",
@@ -132,7 +132,8 @@ DISC_TAIL_MAX_ROWS = 16
 
 class DiscTailArgs(C.Structure):
     _fields_ = [(k, vp) for k in ("a", "W0", "scale", "W1", "W2", "W3", "g_out", "t0", "t1", "t2", "e1", "e2", "out", "gz", "c_a", "gW0",
-                                  "gy2", "a2", "gW1", "gW2", "gW3", "workspace", "ticket")] + \
+                                  "gy2", "a2", "gW1", "gW2", "gW3", "in_xhat", "in_rstd", "in_addend", "c_z")] + [("in_P", C.c_int32)] + \
+               [(k, vp) for k in ("workspace", "ticket")] + \
                [(k, C.c_int32) for k in ("M", "M2", "K", "N", "L", "H")] + [("slope", C.c_float), ("accumulate_gw", C.c_int32)]
 
 
@@ -233,6 +234,8 @@ def load() -> C.CDLL:
     sig("tp_step_inputs", [C.POINTER(StepCopy), C.c_int, C.POINTER(vp), C.POINTER(C.c_float), C.c_int, vp, vp, C.c_int, vp])
     sig("tp_adam_step", [C.POINTER(AdamTensor), C.c_int, vp, C.c_double, C.c_double, C.c_double, C.c_double, vp, C.c_int, vp, vp])
     sig("tp_conv4s2_workspace", [C.POINTER(Conv4s2Args), C.c_int, C.POINTER(C.c_int64)], C.c_int64)
+    sig("tp_conv4s2_fwd_inorm_workspace", [C.POINTER(Conv4s2Args), C.POINTER(C.c_int64)], C.c_int64)
+    sig("tp_conv4s2_fwd_inorm", [C.POINTER(Conv4s2Args), C.c_float, C.c_float, vp, vp, vp])
     for name in ("tp_conv4s2_fwd", "tp_conv4s2_dgrad", "tp_conv4s2_wgrad"):
         sig(name, [C.POINTER(Conv4s2Args), vp])
     sig("tp_conv3s1_workspace", [C.POINTER(Conv3s1Args), C.c_int, C.POINTER(C.c_int64)], C.c_int64)

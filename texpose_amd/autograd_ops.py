@@ -350,6 +350,31 @@ def disc_head(z, scale, W1, W2, W3, L: int, slope: float = 0.2):
     return _DiscHead.apply(z.contiguous(), scale.contiguous(), W1.contiguous(), W2.contiguous(), W3.contiguous(), int(L), float(slope))
 
 
+# ---- K11 + K9 fused forward for FROZEN weights (the nerf step's pass through the discriminator): one launch instead of two
+class _Conv4s2Inorm(torch.autograd.Function):
+    """y = lrelu(instance_norm(conv4s2(x, w))) with a constant weight: forward tp_conv4s2_fwd_inorm, backward K9's first-order
+    kernel followed by K11's data gradient (two launches, as the unfused nodes).  First order only."""
+
+    @staticmethod
+    def forward(ctx, x, w, eps, slope):
+        y, xhat, rstd = ops.conv4s2_fwd_inorm(x, w, eps, slope)
+        ctx.save_for_backward(xhat, rstd, w)
+        ctx.slope = slope
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gy):
+        xhat, rstd, w = ctx.saved_tensors
+        gz = ops.inorm_lrelu_bwd(xhat, rstd, gy.contiguous(), ctx.slope)
+        gx = ops.conv4s2_dgrad(gz, w) if ctx.needs_input_grad[0] else None
+        return gx, None, None, None
+
+
+def conv4s2_inorm(x, w, eps: float, slope: float):
+    return _Conv4s2Inorm.apply(x.contiguous(), w.contiguous(), float(eps), float(slope))
+
+
 # ---- K17: full-map convolution + head as one launch each way (frozen discriminator of the nerf step: data gradient only)
 class _DiscTail(torch.autograd.Function):
     """out [B] of the PatchGAN's tail for FROZEN weights: forward tp_disc_tail_fwd, backward tp_disc_tail_bwd (c_a only).  First

@@ -41,10 +41,18 @@ struct TailP {
   float* out;            // F: out [M];  R1: d/d g [M] (optional)
   float* gz;             // B: [M,N] (optional)
   float* c_a;            // B: [M,K] data gradient (optional)
+  int c_a_store;         // B: c_a is written (0: only c_z is wanted; c_a != NULL still selects the data-gradient code)
   float* gW0;            // B: [N,K] (optional)
   const float* gy2;      // B: [M2,N] extra cotangent rows of the weight gradient (optional)
   const float* a2;       // B: [M2,K] their inputs
   float* gW1; float* gW2; float* gW3;  // B, R1: head weight gradients (optional in B)
+  // B, optional: the InstanceNorm + LeakyReLU backward of the ladder's last stage applied to c_a before it leaves the workgroup
+  // (K9 tp_inorm_lrelu_bwd: c_z = rstd P(c_a * s(xhat)) [+ addend]; an instance = in_P consecutive columns, in_P | 64)
+  const float* in_xhat;  // [M,K]
+  const float* in_rstd;  // [M * K / in_P]
+  const float* in_addend;// [M,K] or NULL
+  float* c_z;            // [M,K]
+  int in_P;
   float* ws;             // F, R1: partial sums [N][S][M]
   unsigned* ticket;      // F, R1: one zero word
   int M, M2, K, N, C, L, H, Cin, S;
@@ -332,11 +340,24 @@ __global__ __launch_bounds__(kT) void disc_tail_bwd_kernel(TailP p) {
 #pragma unroll
     for (int m = 0; m < MB; ++m) ps[(run * kMaxM + m) * 64 + kc] = acc[m];
     __syncthreads();
-    for (int e = t; e < M * 64; e += kT) {
-      const int m = e >> 6, c = e & 63, kk = blockIdx.x * 64 + c;
-      if (kk < p.K)
-        p.c_a[(size_t)m * p.K + kk] = ((ps[(0 * kMaxM + m) * 64 + c] + ps[(1 * kMaxM + m) * 64 + c]) + ps[(2 * kMaxM + m) * 64 + c]) +
-                                      ps[(3 * kMaxM + m) * 64 + c];
+    for (int e = t; e < ((M * 64 + kT - 1) / kT) * kT; e += kT) {               // (whole waves: the lane groups below shuffle)
+      const int m = min(e >> 6, M - 1), c = e & 63, kk = min(blockIdx.x * 64 + c, p.K - 1);
+      const bool live = (e >> 6) < M && blockIdx.x * 64 + c < p.K;
+      const float v = ((ps[(0 * kMaxM + m) * 64 + c] + ps[(1 * kMaxM + m) * 64 + c]) + ps[(2 * kMaxM + m) * 64 + c]) + ps[(3 * kMaxM + m) * 64 + c];
+      const size_t idx = (size_t)m * p.K + kk;
+      if (live && p.c_a_store) p.c_a[idx] = v;
+      if (p.c_z != nullptr) {
+        // K9's backward on the instance this lane group holds (in_P consecutive columns of row m): a = v s(xhat),
+        // c_z = rstd (a - mean a - xhat mean(a xhat)) [+ addend]; xor-shuffles inside the group (fixed order)
+        const float xh = p.in_xhat[idx];
+        const float a = v * (xh > 0.f ? 1.0f : p.slope);
+        float sa = a, sah = a * xh;
+        for (int o = 1; o < p.in_P; o <<= 1) { sa += __shfl_xor(sa, o, 64); sah += __shfl_xor(sah, o, 64); }
+        const float ma = sa / (float)p.in_P, mah = sah / (float)p.in_P;
+        float z = p.in_rstd[idx / p.in_P] * (a - ma - xh * mah);
+        if (p.in_addend != nullptr) z += p.in_addend[idx];
+        if (live) p.c_z[idx] = z;
+      }
     }
   }
   TSTAMP(3, blockIdx.x == 0);
@@ -394,6 +415,14 @@ int fill(TailP* q, const tp_disc_tail_args* a, const char* what) {
   q->t0 = a->t0; q->t1 = a->t1; q->t2 = a->t2; q->e1 = a->e1; q->e2 = a->e2; q->out = a->out; q->gz = a->gz; q->c_a = a->c_a;
   q->gW0 = a->gW0; q->gy2 = a->gy2; q->a2 = a->a2; q->gW1 = a->gW1; q->gW2 = a->gW2; q->gW3 = a->gW3;
   q->ws = (float*)a->workspace; q->ticket = a->ticket; q->accumulate = a->accumulate_gw;
+  q->in_xhat = a->in_xhat; q->in_rstd = a->in_rstd; q->in_addend = a->in_addend; q->c_z = a->c_z; q->in_P = a->in_P; q->c_a_store = a->c_a != nullptr;
+  if (q->c_z != nullptr) {
+    if (!q->in_xhat || !q->in_rstd || q->in_P <= 0 || 64 % q->in_P != 0 || q->K % q->in_P != 0 || (q->K & 63) != 0) {
+      tp::set_error("%s: the fused InstanceNorm backward needs xhat, rstd, in_P | 64 and K a multiple of 64", what);
+      return -1;
+    }
+    if (q->c_a == nullptr) q->c_a = q->c_z;          // (selects the data-gradient code; c_a_store = 0: nothing is written through it)
+  }
   if (!q->W0 || !q->W1 || !q->W2 || !q->W3 || !q->t0 || !q->t1 || !q->t2) { tp::set_error("%s: null pointer", what); return -1; }
   return 0;
 }

@@ -173,6 +173,112 @@ __global__ __launch_bounds__(256) void conv4s2_fwd_kernel(ConvP p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------- F + IN
+// The forward convolution with the InstanceNorm2d + LeakyReLU that follows it in the PatchGAN ladder (reference
+// layers/discriminator.py:94-115; K9 csrc/inorm_lrelu.hip) in its epilogue: a workgroup owns NT row tiles = 32 NT consecutive
+// positions of 32 output channels, i.e. WHOLE (image, channel) instances when the map has P = 16 (NT = 1: two images) or P = 64
+// (NT = 2: one image) positions.  The workgroup that ends up with the split-K totals normalises them: per instance 256 / n_inst
+// adjacent lanes hold P / parts rows each; mean and the sum of squared deviations by xor-shuffles inside the lane group (fixed order).
+// Outputs: y = lrelu(xhat), xhat, rstd -- what tp_inorm_lrelu_fwd returns -- and no z.  One launch instead of two per ladder stage.
+struct InP { float* xhat; float* rstd; float eps, slope; };
+
+template <int NT>
+__global__ __launch_bounds__(256) void conv4s2_fwd_in_kernel(ConvP p, InP q) {
+  __shared__ float lds[16 * 4 * 64 * (NT > 1 ? 2 : 1)];
+  const int t = threadIdx.x, w = t >> 6, lane = t & 63, col = lane & 31, h = lane >> 5;
+  const int s = blockIdx.x % p.S, tile = blockIdx.x / p.S, nt = tile % p.tiles_n, mt = tile / p.tiles_n;
+  const int P = 1 << p.lp, M = p.N << p.lp, HW = p.H * p.W;
+  int off[NT][8];
+  bool ok[NT][8];
+  const float* xa[NT];
+#pragma unroll
+  for (int r_ = 0; r_ < NT; ++r_) {
+    const int m = (mt * NT + r_) * 32 + col, mc = min(m, M - 1);
+    const int n = mc >> p.lp, pp = mc & (P - 1), oy = pp >> p.low, ox = pp & (p.OW - 1);
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int iy = 2 * oy - 1 + 2 * h + r, ix = 2 * ox - 1 + j;
+        ok[r_][r * 4 + j] = m < M && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        off[r_][r * 4 + j] = ok[r_][r * 4 + j] ? iy * p.W + ix : 0;
+      }
+    xa[r_] = p.x + (size_t)n * p.C * HW;
+  }
+  const int co = min(nt * 32 + col, p.Co - 1);
+  const float* wb = p.w + (size_t)co * p.C * 16 + 8 * h;
+  int cb, ce;
+  k_range(p.C, p.S, s, w, cb, ce);
+  f32x16 acc[NT] = {};
+  constexpr int kU = NT > 1 ? 4 : 8;
+  for (int c0 = cb; c0 < ce; c0 += kU) {
+    float a[NT][kU][8];
+    f32x4 b[kU][2];
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      const int ci = min(c0 + u, ce - 1);
+#pragma unroll
+      for (int r_ = 0; r_ < NT; ++r_) {
+        const float* xc = xa[r_] + (size_t)ci * HW;
+#pragma unroll
+        for (int qq = 0; qq < 8; ++qq) a[r_][u][qq] = xc[off[r_][qq]];
+      }
+      b[u][0] = *reinterpret_cast<const f32x4*>(wb + (size_t)ci * 16);
+      b[u][1] = *reinterpret_cast<const f32x4*>(wb + (size_t)ci * 16 + 4);
+    }
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      if (c0 + u < ce) {
+#pragma unroll
+        for (int r_ = 0; r_ < NT; ++r_)
+#pragma unroll
+          for (int qq = 0; qq < 8; ++qq) acc[r_] = mfma(ok[r_][qq] ? a[r_][u][qq] : 0.f, b[u][qq >> 2][qq & 3], acc[r_]);
+      }
+    }
+  }
+  float out[NT][4];
+  if (!reduce_tiles<NT>(acc, out, lds, p, tile, s)) return;
+  // ---- the totals of 32 NT rows x 32 columns through LDS: [row][33]
+  __syncthreads();
+  float* tl = lds;
+#pragma unroll
+  for (int r_ = 0; r_ < NT; ++r_)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) tl[(r_ * 32 + 8 * w + 4 * h + i) * 33 + col] = out[r_][i];
+  __syncthreads();
+  const int rows = 32 * NT, imgs = rows >> p.lp, n_inst = imgs * 32, parts = 256 / n_inst, rp = P / parts;     // 64 / 4 / 4  or  32 / 8 / 8
+  const int inst = t / parts, part = t - inst * parts, im = inst >> 5, c = inst & 31;
+  const int r0 = im * P + part * rp;
+  float v[8];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    v[i] = i < rp ? tl[(r0 + i) * 33 + c] : 0.f;
+    sum += v[i];
+  }
+  for (int o = 1; o < parts; o <<= 1) sum += __shfl_xor(sum, o, 64);
+  const float mean = sum / (float)P;
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+    if (i < rp) { const float d = v[i] - mean; sq += d * d; }
+  for (int o = 1; o < parts; o <<= 1) sq += __shfl_xor(sq, o, 64);
+  const float r = 1.0f / sqrtf(sq / (float)P + q.eps);
+  const int m0 = mt * rows + im * P, oc = nt * 32 + c;
+  if (m0 < M && oc < p.Co) {
+    const int n0 = m0 >> p.lp;
+    const size_t base = ((size_t)n0 * p.Co + oc) * P + part * rp;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (i < rp) {
+        const float hh = (v[i] - mean) * r;
+        q.xhat[base + i] = hh;
+        p.out[base + i] = hh > 0.f ? hh : hh * q.slope;
+      }
+    if (part == 0) q.rstd[(size_t)n0 * p.Co + oc] = r;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------- D
 __global__ __launch_bounds__(256) void conv4s2_dgrad_kernel(ConvP p) {
   __shared__ float lds[4 * 16 * 4 * 64];
@@ -450,6 +556,48 @@ static int conv_launch(const tp_conv4s2_args* a, int op, tp_stream_t stream) {
 }
 
 int tp_conv4s2_fwd(const tp_conv4s2_args* a, tp_stream_t stream) { return conv_launch(a, 0, stream); }
+
+// row tiles per workgroup of the fused convolution + InstanceNorm launch (0: this map size is not covered)
+static int fwd_in_nt(const tp_conv4s2_args* a) {
+  const int P = (a->H / 2) * (a->W / 2);
+  return P == 16 ? 1 : P == 64 ? 2 : 0;
+}
+static int conv_in_plan(const tp_conv4s2_args* a, Plan* q, ConvP* p) {
+  if (const int rc = conv_plan(a, 0, q, p)) return rc;
+  const int nt = fwd_in_nt(a);
+  TP_REQUIRE(nt > 0, "the fused convolution + InstanceNorm launch covers 4x4 and 8x8 output maps");
+  const int M = a->N * p->OH * p->OW;
+  TP_REQUIRE(M % (32 * nt) == 0 || nt == 1, "whole images per workgroup needed");
+  *q = plan(M, a->Co, a->C, nt, 256, 4);
+  q->tiles_m = (M + 32 * nt - 1) / (32 * nt);
+  const int tiles = q->tiles_m * q->tiles_n;
+  int S = tiles >= 256 ? 1 : (256 + tiles - 1) / tiles;
+  const int max_s = (a->C + 15) / 16;
+  if (S > max_s) S = max_s;
+  if (S < 1) S = 1;
+  q->S = S;
+  q->ws_floats = S > 1 ? (size_t)tiles * S * nt * 4 * 256 : 0;
+  p->S = S; p->tiles_n = q->tiles_n;
+  return 0;
+}
+int64_t tp_conv4s2_fwd_inorm_workspace(const tp_conv4s2_args* a, int64_t* n_counters) {
+  Plan q; ConvP p;
+  if (conv_in_plan(a, &q, &p) != 0) return -1;
+  if (n_counters) *n_counters = (int64_t)q.tiles_m * q.tiles_n;
+  return (int64_t)q.ws_floats;
+}
+int tp_conv4s2_fwd_inorm(const tp_conv4s2_args* a, float eps, float slope, float* xhat, float* rstd, tp_stream_t stream) {
+  Plan q; ConvP p;
+  if (const int rc = conv_in_plan(a, &q, &p)) return rc;
+  TP_REQUIRE(a->x && a->w && a->out && xhat && rstd && a->counters && (!q.ws_floats || a->workspace), "operand / counters / workspace missing");
+  TP_REQUIRE((a->N * p.OH * p.OW) % 16 == 0, "whole instances per tile needed");
+  p.x = a->x; p.w = a->w; p.gy = nullptr; p.out = a->out; p.ws = a->workspace; p.cnt = (unsigned*)a->counters;
+  InP in{xhat, rstd, eps, slope};
+  const dim3 grid((unsigned)(q.tiles_m * q.tiles_n * q.S)), block(256);
+  if (fwd_in_nt(a) == 1) hipLaunchKernelGGL(conv4s2_fwd_in_kernel<1>, grid, block, 0, (hipStream_t)stream, p, in);
+  else hipLaunchKernelGGL(conv4s2_fwd_in_kernel<2>, grid, block, 0, (hipStream_t)stream, p, in);
+  return tp::check_launch("tp_conv4s2_fwd_inorm");
+}
 int tp_conv4s2_dgrad(const tp_conv4s2_args* a, tp_stream_t stream) { return conv_launch(a, 1, stream); }
 int tp_conv4s2_wgrad(const tp_conv4s2_args* a, tp_stream_t stream) { return conv_launch(a, 2, stream); }
 

@@ -110,8 +110,12 @@ class DiscStepSchedule:
         K, B, sl = len(self.stages), x.shape[0], self.slope
         a, saved = x, []
         for l, (_conv, eps) in enumerate(self.stages):
-            z = ops.conv4s2_fwd(a, W[l])
-            y, xhat, rstd = ops.inorm_lrelu_fwd(z, eps, sl, y_out=None if stacks is None else stacks[l + 1][:B])
+            y_out = None if stacks is None else stacks[l + 1][:B]
+            if ops.conv4s2_fwd_inorm_supported(a):                # convolution + InstanceNorm + LeakyReLU in one launch
+                y, xhat, rstd = ops.conv4s2_fwd_inorm(a, W[l], eps, sl, y_out=y_out)
+            else:
+                z = ops.conv4s2_fwd(a, W[l])
+                y, xhat, rstd = ops.inorm_lrelu_fwd(z, eps, sl, y_out=y_out)
             saved.append(AttrDict(x=a, xhat=xhat, rstd=rstd))
             a = y
         a2d, W0 = a.reshape(B, -1), W[K].flatten(1)
@@ -133,16 +137,20 @@ class DiscStepSchedule:
         K, B, sl = len(self.stages), g_out.shape[0], self.slope
         t0, t1, t2 = f.head
         gw = [None] * (K + 1)
+        c_z_last = None
         if f.tail:
-            r = ops.disc_tail_bwd(g_out, t0, t1, t2, W[K].flatten(1), *self._head_w(W), self.disc.L_scale, sl, a=f.a_full.reshape(B, -1))
-            gw[K], gW1, gW2, gW3, c_a = r["gW0"], r["gW1"], r["gW2"], r["gW3"], r["c_a"].view_as(f.a_full)
+            # (the InstanceNorm + LeakyReLU backward of the last ladder stage rides in the same launch: no c_a round trip)
+            last = f.stages[K - 1]
+            r = ops.disc_tail_bwd(g_out, t0, t1, t2, W[K].flatten(1), *self._head_w(W), self.disc.L_scale, sl, a=f.a_full.reshape(B, -1),
+                                  want_c_a=False, inorm=dict(xhat=last.xhat, rstd=last.rstd))
+            gw[K], gW1, gW2, gW3, c_a, c_z_last = r["gW0"], r["gW1"], r["gW2"], r["gW3"], None, r["c_z"]
         else:
             c_z3, gW1, gW2, gW3, _, _ = ops.disc_head_bwd(g_out, t0, t1, t2, *self._head_w(W), f.C_z, self.disc.L_scale, sl)
             gw[K] = ops.skinny_linear_wgrad(c_z3, f.a_full.reshape(B, -1))
             c_a = ops.skinny_linear_dgrad(c_z3, W[K].flatten(1)).view_as(f.a_full)
         for l in range(K - 1, -1, -1):
             st = f.stages[l]
-            c_z = ops.inorm_lrelu_bwd(st.xhat, st.rstd, c_a, sl)
+            c_z = c_z_last if (l == K - 1 and c_z_last is not None) else ops.inorm_lrelu_bwd(st.xhat, st.rstd, c_a, sl)
             gw[l] = ops.conv4s2_wgrad(c_z, st.x)
             if l > 0:
                 c_a = ops.conv4s2_dgrad(c_z, W[l])
@@ -170,16 +178,19 @@ class DiscStepSchedule:
         ones = self._ones_like(f.out)
         # ---- R1, first pass: g = d D(real).sum() / d real  (reference :796-801)
         W0 = W[K].flatten(1)
+        gz_last = None
         if f.tail:
-            r = ops.disc_tail_bwd(ones, t0, t1, t2, W0, *Wh, L, sl, want_gW0=False, head_weight_grads=False, want_e=True, gz_out=gs[K][B:])
-            e1, e2, ga, ga_in = r["e1"], r["e2"], r["c_a"].view_as(f.a_full), [None] * K
+            last = f.stages[K - 1]
+            r = ops.disc_tail_bwd(ones, t0, t1, t2, W0, *Wh, L, sl, want_gW0=False, head_weight_grads=False, want_e=True, gz_out=gs[K][B:],
+                                  inorm=dict(xhat=last.xhat, rstd=last.rstd, out=gs[K - 1][B:]))
+            e1, e2, ga, ga_in, gz_last = r["e1"], r["e2"], r["c_a"].view_as(f.a_full), [None] * K, r["c_z"]
         else:
             gz3, _, _, _, e1, e2 = ops.disc_head_bwd(ones, t0, t1, t2, *Wh, f.C_z, L, sl, weight_grads=False, gz_out=gs[K][B:])
             ga, ga_in = ops.skinny_linear_dgrad(gz3, W0).view_as(f.a_full), [None] * K
         for l in range(K - 1, -1, -1):
             st = f.stages[l]
             ga_in[l] = ga
-            gz = ops.inorm_lrelu_bwd(st.xhat, st.rstd, ga, sl, out=gs[l][B:])
+            gz = gz_last if (l == K - 1 and gz_last is not None) else ops.inorm_lrelu_bwd(st.xhat, st.rstd, ga, sl, out=gs[l][B:])
             ga = ops.conv4s2_dgrad(gz, W[l])
         # ---- value and weighted cotangent of the penalty (reference :802-806 and the .mean() of :149)
         r1, c = ops.sumsq_mean_fwd_bwd(ga, w_reg, out_g=xs[0][B:])
@@ -195,9 +206,11 @@ class DiscStepSchedule:
             # ---- BCE path of the real pass, its cotangents joined with the R1 path's on the way: the R1 pair of the full-map weight
             # ((first-pass gz, second-pass c) = the second halves of the stacks) joins the weight-gradient sum inside the launch
             g_out = make_g_out(f.out)
+            last = f.stages[K - 1]
             r = ops.disc_tail_bwd(g_out, t0, t1, t2, W0, *Wh, L, sl, a=xs[K][:B].reshape(B, -1), accumulate_into=(gW1, gW2, gW3),
-                                  gy2=gs[K][B:], a2=xs[K][B:].reshape(B, -1))
-            gw[K], gW1, gW2, gW3, c_a = r["gW0"], r["gW1"], r["gW2"], r["gW3"], r["c_a"].view_as(f.a_full)
+                                  gy2=gs[K][B:], a2=xs[K][B:].reshape(B, -1), want_c_a=False,
+                                  inorm=dict(xhat=last.xhat, rstd=last.rstd, addend=c_zr[K - 1], out=gs[K - 1][:B]))
+            gw[K], gW1, gW2, gW3, c_a, c_z_last = r["gW0"], r["gW1"], r["gW2"], r["gW3"], None, r["c_z"]
         else:
             c_gz3 = ops.skinny_linear_fwd(c.reshape(B, -1), W0)
             _gg, gW1, gW2, gW3 = ops.disc_head_bwd_bwd(c_gz3, ones, t0, t1, t2, e1, e2, *Wh, L, sl)
@@ -207,9 +220,13 @@ class DiscStepSchedule:
                                                           gz_out=gs[K][:B])
             gw[K] = ops.skinny_linear_wgrad(gs[K], xs[K].reshape(2 * B, -1))
             c_a = ops.skinny_linear_dgrad(c_z3, W0).view_as(f.a_full)
+            c_z_last = None
         for l in range(K - 1, -1, -1):
             st = f.stages[l]
-            c_z = ops.inorm_lrelu_bwd(st.xhat, st.rstd, c_a, sl, addend=c_zr[l], out=gs[l][:B])
+            if l == K - 1 and f.tail:
+                c_z = c_z_last
+            else:
+                c_z = ops.inorm_lrelu_bwd(st.xhat, st.rstd, c_a, sl, addend=c_zr[l], out=gs[l][:B])
             gw[l] = ops.conv4s2_wgrad(gs[l], xs[l])
             if l > 0:
                 c_a = ops.conv4s2_dgrad(c_z, W[l])

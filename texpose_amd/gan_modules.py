@@ -153,6 +153,15 @@ class Discriminator(nn.Module):
         mods, i = list(seq), 0
         while i < len(mods):
             m = mods[i]
+            if (isinstance(m, SNConv2d) and x.is_cuda and i + 2 < len(mods) and isinstance(mods[i + 1], nn.InstanceNorm2d)
+                    and isinstance(mods[i + 2], nn.LeakyReLU) and not mods[i + 1].affine and not mods[i + 1].track_running_stats
+                    and tuple(m.weight_orig.shape[-2:]) == (4, 4) and m.stride == (2, 2) and m.padding == (1, 1)
+                    and not weights[0].requires_grad and Discriminator._fused_stage_ok(x)):
+                # constant weight (the nerf step's pass): convolution + InstanceNorm + LeakyReLU as one launch (K11 epilogue)
+                from . import autograd_ops
+                x = autograd_ops.conv4s2_inorm(x, weights.pop(0), mods[i + 1].eps, mods[i + 2].negative_slope)
+                i += 3
+                continue
             if isinstance(m, SNConv2d):
                 x = m(x, weights.pop(0))
             elif (x.is_cuda and isinstance(m, nn.InstanceNorm2d) and i + 1 < len(mods) and isinstance(mods[i + 1], nn.LeakyReLU)
@@ -170,6 +179,11 @@ class Discriminator(nn.Module):
                 x = m(x)
             i += 1
         return x
+
+    @staticmethod
+    def _fused_stage_ok(x):
+        from . import ops
+        return ops.conv4s2_fwd_inorm_supported(x)
 
     def _tail_fusable(self, x, weights):
         """GPU, scale-conditioned plain head, constant weights (no gradient wrt them is being recorded), a last ladder convolution

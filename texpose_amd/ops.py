@@ -864,6 +864,31 @@ def conv4s2_fwd(x: Tensor, w: Tensor, out: Optional[Tensor] = None) -> Tensor:
     return _conv4s2(_lib.CONV_FWD, "tp_conv4s2_fwd", x, w, None, y, N, C_in, H, W, w.shape[0])
 
 
+def conv4s2_fwd_inorm_supported(x: Tensor) -> bool:
+    """The fused convolution + InstanceNorm + LeakyReLU launch covers 4x4 and 8x8 output maps (whole instances per workgroup)."""
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and (x.shape[2] // 2) * (x.shape[3] // 2) in (16, 64)
+            and x.shape[2] == x.shape[3] and os.environ.get("TP_NO_CONV_INORM") != "1")
+
+
+@_on_tensor_device
+def conv4s2_fwd_inorm(x: Tensor, w: Tensor, eps: float, slope: float, y_out: Optional[Tensor] = None):
+    """-> (y, xhat, rstd) = inorm_lrelu_fwd(conv4s2_fwd(x, w), eps, slope) in ONE launch (the normalisation runs in the epilogue of
+    the workgroup that holds an instance's split-K totals); ``y_out`` as in inorm_lrelu_fwd."""
+    lib = _lib.load()
+    x, w = _f32(x, "x"), _f32(w, "w")
+    N, C_in, H, W = x.shape
+    Co = w.shape[0]
+    y = _out_like(y_out, x, (N, Co, H // 2, W // 2))
+    xhat, rstd = torch.empty(N, Co, H // 2, W // 2, device=x.device), torch.empty(N * Co, device=x.device)
+    a = _lib.Conv4s2Args()
+    a.N, a.C, a.H, a.W, a.Co = int(N), int(C_in), int(H), int(W), int(Co)
+    ws, cnt = _conv_scratch(lib, lambda args, _op, n: lib.tp_conv4s2_fwd_inorm_workspace(args, n), a, 0, x.device)
+    a.x, a.w = x.data_ptr(), w.data_ptr()
+    a.out, a.counters, a.workspace = y.data_ptr(), cnt.data_ptr(), _ptr(ws)
+    check(lib.tp_conv4s2_fwd_inorm(C.byref(a), float(eps), float(slope), xhat.data_ptr(), rstd.data_ptr(), _stream()), "tp_conv4s2_fwd_inorm")
+    return y, xhat, rstd
+
+
 @_on_tensor_device
 def conv4s2_dgrad(gy: Tensor, w: Tensor, out: Optional[Tensor] = None) -> Tensor:
     """gradient of conv4s2_fwd wrt x: gy [N,Co,H/2,W/2], w [Co,C,4,4] -> [N,C,H,W]."""
@@ -1345,18 +1370,32 @@ def disc_tail_fwd(a: Tensor, W0: Tensor, scale: Tensor, W1: Tensor, W2: Tensor, 
 def disc_tail_bwd(g_out: Tensor, t0: Tensor, t1: Tensor, t2: Tensor, W0: Tensor, W1: Tensor, W2: Tensor, W3: Tensor, L: int, slope: float,
                   a: Optional[Tensor] = None, want_c_a: bool = True, want_gW0: bool = True, head_weight_grads: bool = True,
                   accumulate_into=None, want_e: bool = False, gz_out: Optional[Tensor] = None, gy2: Optional[Tensor] = None,
-                  a2: Optional[Tensor] = None, c_a_out: Optional[Tensor] = None):
+                  a2: Optional[Tensor] = None, c_a_out: Optional[Tensor] = None, inorm=None):
     """The tail's backward in one launch -> dict(c_a [M,K], gW0 [N,K], gW1, gW2, gW3, gz [M,N], e1, e2) (absent entries None).
     ``a`` [M,K]: the ladder output (needed for gW0); ``gy2`` [M2,N] / ``a2`` [M2,K]: a second (cotangent, input) pair of the same
-    weight whose rows join gW0's sum; ``accumulate_into=(gW1, gW2, gW3)``: the head's weight gradients are ADDED to these."""
+    weight whose rows join gW0's sum; ``accumulate_into=(gW1, gW2, gW3)``: the head's weight gradients are ADDED to these.
+    ``inorm`` = dict(xhat [M,C,h,w], rstd [M*C], addend=None, out=None): the InstanceNorm + LeakyReLU backward of the ladder's last stage
+    (ops.inorm_lrelu_bwd) applied to c_a inside the launch -> res["c_z"] (shaped like xhat); c_a itself only with ``want_c_a``."""
     lib = _lib.load()
     g_out, W0, W1, W2, W3 = (_f32(t, n) for t, n in ((g_out, "g_out"), (W0, "W0"), (W1, "W1"), (W2, "W2"), (W3, "W3")))
     M, dev = t1.shape[0], t1.device
     q = _tail_args(W0, W1, W2, W3, M, L, slope)
-    res = dict(c_a=None, gW0=None, gW1=None, gW2=None, gW3=None, gz=None, e1=None, e2=None)
+    res = dict(c_a=None, gW0=None, gW1=None, gW2=None, gW3=None, gz=None, e1=None, e2=None, c_z=None)
     keep = []
     if want_c_a:
         res["c_a"] = _out_like(c_a_out, t1, (M, q.K))
+    if inorm is not None:
+        xhat, rstd = _f32(inorm["xhat"], "xhat"), _f32(inorm["rstd"], "rstd")
+        in_P = xhat.shape[-2] * xhat.shape[-1]
+        if xhat.numel() != M * q.K or rstd.numel() * in_P != M * q.K:
+            raise ValueError("disc_tail_bwd: xhat / rstd of the last ladder stage expected")
+        res["c_z"] = _out_like(inorm.get("out"), xhat)
+        q.in_xhat, q.in_rstd, q.c_z, q.in_P = xhat.data_ptr(), rstd.data_ptr(), res["c_z"].data_ptr(), int(in_P)
+        if inorm.get("addend") is not None:
+            ad = _f32(inorm["addend"], "addend")
+            keep.append(ad)
+            q.in_addend = ad.data_ptr()
+        keep += [xhat, rstd]
     if want_gW0:
         if a is None:
             raise ValueError("disc_tail_bwd: the weight gradient of the full-map convolution needs the ladder output")

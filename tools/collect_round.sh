@@ -3,7 +3,7 @@
 #   bench line; bench under rocprofv3 --kernel-trace --stats + PMC of the eval forward (profile_mlp.sh); B=32 training kernel
 #   stats; training PMC (pmc_train.sh); HBM-bound kernels: stats + PMC (pmc_hbm.sh); launch histogram + ordered launches of a
 #   replayed B=4 GAN iteration; training lines; C5 multi-object line.          Usage: tools/collect_round.sh [tag]
-T=${1:-r3}
+T=${1:-r4}
 mkdir -p gpurun_out/$T
 export TMPDIR=/tmp
 ( time timeout 1500 python bench.py > gpurun_out/$T/bench_full.json 2> gpurun_out/$T/bench_full.err ) 2> gpurun_out/$T/bench_wall.txt
@@ -17,9 +17,11 @@ python3 tools/launch_histogram.py gpurun_out/$T/gan4 > gpurun_out/$T/launch_hist
 python3 tools/launch_sequence.py gpurun_out/$T/gan4 > gpurun_out/$T/launch_sequence.txt 2>&1
 for i in 1 2; do python3 tools/train_bench.py 4 1 200 1 f16x3 2>&1 | tail -1; python3 tools/train_bench.py 4 0 200 1 f16x3 2>&1 | tail -1; python3 tools/train_bench.py 32 0 60 1 f16x3 2>&1 | tail -1; done > gpurun_out/$T/train_lines.txt
 timeout 600 python bench.py --config c5 > gpurun_out/$T/c5.json 2> gpurun_out/$T/c5.err
-# the GAN loop with one round-3 change switched off at a time (same box, alternating with the product configuration)
-( for e in TP_X=1 TP_DISC_AUTOGRAD=1 TP_X=1 TP_NO_FEAT_BRANCH=1 TP_X=1 TP_NO_SN_PREFETCH=1 TP_X=1 TP_TORCH_RNG=1 TP_X=1; do
+# the GAN loop with one change switched off at a time (same box, alternating with the product configuration)
+( for e in TP_X=1 TP_FOUR_GRAPHS=0 TP_X=1 TP_NO_DISC_TAIL=1 TP_X=1 TP_DISC_AUTOGRAD=1 TP_X=1 TP_NO_FEAT_BRANCH=1 TP_X=1 GPU_MAX_HW_QUEUES=2 TP_X=1; do
     echo "$e $(env $e python3 tools/train_bench.py 4 1 200 1 f16x3 2>&1 | tail -1 | cut -c1-75)"; done ) > gpurun_out/$T/gan_ablations.txt
+python3 tools/tail_bench.py 4 > gpurun_out/$T/tail_bench.txt 2>&1
+python3 tools/host_time.py > gpurun_out/$T/host_time.txt 2>&1
 python3 tools/kstats.py gpurun_out/$T/train32 wgrad dgrad mlp_fwd finalize
 rm -rf gpurun_out/$T/train32 gpurun_out/$T/gan4
 cat gpurun_out/$T/train_lines.txt | cut -c1-100
