@@ -489,6 +489,8 @@ typedef struct tp_step_copy { void* dst; const void* src; int64_t bytes; } tp_st
 int tp_step_inputs(const tp_step_copy* copies /* host array */, int n_copies, float* const* scalar_dst /* host array */,
                    const float* scalar_val /* host array */, int n_scalars, const int32_t* words_src, int32_t* words_dst, int n_words,
                    tp_stream_t stream);
+/* Diagnostic (no reference counterpart): the device's 100 MHz constant clock written to *slot by a one-thread launch in stream order. */
+int tp_stamp(uint64_t* slot, tp_stream_t stream);
 int tp_disc_inputs(const float* rgb, const float* gathered, int B, int P, int geo, float* real, float* fake, tp_stream_t stream);
 /* Cotangent of the fake stack wrt the rendered colours (the nerf step back-propagates D(fake) into the render):
  * g_rgb [B,P,3] = g_fake [B,nc,P] channels 0..2, transposed. */

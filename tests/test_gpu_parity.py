@@ -1171,6 +1171,109 @@ def test_graph_captured_training_matches_eager(ops):
     assert len(seen) == 3
 
 
+@pytest.mark.parametrize("mode", ["linear", "four", "one"])
+def test_graph_captured_full_gan_step_modes_match_eager(ops, mode, monkeypatch):
+    """The full GAN iteration WITH the feature loss, captured in each of its three forms -- six linear graphs on three streams (the
+    default: the feature chain and the discriminator's pass for the generator hand the composite backward cotangents instead of being
+    differentiated through in one backward call), four graphs on two streams (TP_LINEAR_GRAPHS=0), one graph (TP_FOUR_GRAPHS=0) --
+    against the eager GanTrainer on the same weights, batch and random numbers: same losses, same parameter updates."""
+    from texpose_amd.gan_modules import Discriminator, PerceptualLoss
+    from texpose_amd.graph import Graph
+    from texpose_amd.options import default_options, AttrDict
+    from texpose_amd.synthetic import training_batch
+    from texpose_amd.trainer import GanTrainer, GraphedGanTrainer
+    if mode == "four":
+        monkeypatch.setenv("TP_LINEAR_GRAPHS", "0")
+    if mode == "one":
+        monkeypatch.setenv("TP_FOUR_GRAPHS", "0")
+    B, H, W, n_train, N, steps = 2, 32, 32, 5, 8, 3
+    torch.manual_seed(3)
+    feat_net = PerceptualLoss()
+    feat_sd = {k: v.clone() for k, v in feat_net.state_dict().items()}
+
+    def build(cls):
+        opt = default_options(H=H, W=W, device="cuda:0")
+        opt.batch_size, opt.patch_size, opt.nerf.sample_intvs = B, 16, N
+        pl = PerceptualLoss()
+        pl.load_state_dict(feat_sd)
+        graph = Graph(opt, discriminator=Discriminator(opt), perceptual_loss=pl).to(dev())
+        graph.train()
+        graph.nerf.precision = "fp32"
+        return cls(opt, graph, n_train=n_train), graph
+
+    def reset(tr, graph, snap):
+        graph.load_state_dict(snap)
+        for o in (tr.optim_nerf, tr.optim_disc):
+            for st in o.state.values():
+                for v in st.values():
+                    if torch.is_tensor(v):
+                        v.zero_()
+        tr.it = 0
+        graph.patch_sampler.iterations = 0
+        graph.nerf.mark_heads_dirty()
+
+    eager, g_e = build(type("EagerCapturable", (GanTrainer,), dict(capturable=True)))
+    g_e.nerf.load_state_dict({**g_e.nerf.state_dict(), **{k: cu(v) for k, v in O.make_params(5).items()}})
+    dcpu = Discriminator(eager.opt)
+    O.seed_spectral_module(dcpu, 9)
+    g_e.discriminator.load_state_dict(dcpu.state_dict())
+    snap = {k: v.detach().clone() for k, v in g_e.state_dict().items()}
+    batch = training_batch(B, H, W, n_train=n_train, seed=1, device="cuda:0")
+    rnd = [(torch.rand(3, B, 1, 1, 1, device=dev()), torch.rand(B, 256, N, 1, device=dev())) for _ in range(steps)]
+    graphed, g_g = build(GraphedGanTrainer)
+    g_g.load_state_dict(snap)
+    ex = AttrDict(dict(batch))
+    ex.patch_u, ex.jitter_rand = rnd[0]
+    graphed.capture(ex, warmup=2)
+    assert (graphed._linear, graphed._four) == dict(linear=(True, True), four=(False, True), one=(False, False))[mode]
+    reset(graphed, g_g, snap)
+    for it, (u, jit) in enumerate(rnd):
+        v = AttrDict(dict(batch))
+        v.patch_u, v.jitter_rand = u, jit
+        _, l = eager.train_iteration(v)
+        a = {k: float(x.detach()) for k, x in l.items() if torch.is_tensor(x)}
+        v = AttrDict(dict(batch))
+        v.patch_u, v.jitter_rand = u, jit
+        _, l = graphed.train_iteration(v)
+        b_ = {k: float(x) for k, x in l.items()}
+        tol = (1e-3, 5e-3, 2e-2)[it]
+        for k in ("render", "uncert", "trans_reg", "feat", "gan_nerf", "gan_disc_real", "gan_disc_fake", "gan_reg_real"):
+            assert abs(a[k] - b_[k]) <= tol * abs(a[k]) + 1e-6, (mode, it, k, a[k], b_[k])
+    assert_updates_close(g_e.state_dict(), g_g.state_dict(), snap)
+
+
+def test_distinct_queue_streams_run_concurrently(ops):
+    """trainer.distinct_queue_streams: the streams it returns overlap with each other and with the calling stream -- a spin kernel on
+    one does not delay a fill on another (the property the six-graph step needs; which hardware queue a stream gets is the runtime's
+    round-robin) -- also after other streams were made and used first."""
+    from texpose_amd.trainer import distinct_queue_streams
+    pre = [torch.cuda.Stream() for _ in range(2)]
+    for st in pre:
+        with torch.cuda.stream(st):
+            torch.zeros(1, device=dev())
+    streams = distinct_queue_streams(torch.device(dev()), 3)
+    assert len(streams) == 3 and len({s.cuda_stream for s in streams}) == 3
+    cur = torch.cuda.current_stream()
+    probe = torch.zeros(1, device=dev())
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); torch.cuda._sleep(1_000_000); e1.record(); e1.synchronize()
+    cycles = int(1_000_000 * 2.0 / e0.elapsed_time(e1))                 # ~2 ms
+    every = [cur] + streams
+    for a in every:
+        for b in every:
+            if a is b:
+                continue
+            torch.cuda.synchronize()
+            da, db = torch.cuda.Event(), torch.cuda.Event()
+            with torch.cuda.stream(a):
+                torch.cuda._sleep(cycles); da.record(a)
+            with torch.cuda.stream(b):
+                probe.fill_(1.0); db.record(b)
+            db.synchronize()
+            assert not da.query(), "a fill waited for a spin kernel on another of the chosen streams"
+    torch.cuda.synchronize()
+
+
 # ------------------------------------------------------------------------------------------ eval metrics (f4)
 def test_eval_metrics_g14_and_oracle(ops):
     """tp_eval_metrics against the reference's MSE_loss / pytorch_ssim values (G14) and against the CPU oracle on

@@ -460,6 +460,16 @@ int tp_step_inputs(const tp_step_copy* copies, int n_copies, float* const* scala
   return tp::check_launch("tp_step_inputs");
 }
 
+// Diagnostic: the device's constant-rate clock (100 MHz) into *slot, as a launch of its own -- placed between the segments of a captured
+// step it gives the step's timeline without a tracer slowing the host down (tools/linear_timeline.py).
+__global__ void stamp_kernel(unsigned long long* slot) { *slot = wall_clock64(); }
+
+int tp_stamp(uint64_t* slot, tp_stream_t stream) {
+  TP_REQUIRE(slot != nullptr, "null slot");
+  hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (unsigned long long*)slot);
+  return tp::check_launch("tp_stamp");
+}
+
 int tp_adam_step(const tp_adam_tensor* tensors, int n, const float* lr_dev, double lr_host, double beta1, double beta2, double eps,
                  const int32_t* gate, int n_gate, uint32_t* ticket, tp_stream_t stream) {
   TP_REQUIRE(tensors != nullptr && n > 0 && n <= TP_ADAM_MAX_TENSORS, "bad tensor table");

@@ -297,7 +297,8 @@ class Graph(torch.nn.Module):
                     return var
             # (the feature chain is issued BEFORE the discriminator's pass: with the opposite order the replayed hipGraph put both chains
             # on one hardware queue, one after the other -- 1.406 vs 1.331 ms per B=4 iteration on one box, profiles/r4)
-            self._feature_loss_early(opt, var, (h, w), mode)
+            if var.get("feat_early_for") is not var.ray_idx:      # (else: a graph of its own already ran it, trainer._seg_feat)
+                self._feature_loss_early(opt, var, (h, w), mode)
             var.d_fake_nerf = self.discriminator(opt, var.patch_fake_nerf, var.ray_scales)
         return var
 
@@ -436,7 +437,8 @@ class Graph(torch.nn.Module):
                 fused_feat = ("gathered" in var and var.rgb.is_cuda and hasattr(self.perceptual_loss, "pairs_from_patches")
                               and opt.nerf.rand_rays and mode in ["train", "test-optim"])
                 if fused_feat and var.get("feat_early_for") is var.ray_idx:
-                    torch.cuda.current_stream(var.rgb.device).wait_stream(self.feat_stream)      # (enqueued by nerf_forward)
+                    if not var.get("feat_early_joined"):
+                        torch.cuda.current_stream(var.rgb.device).wait_stream(self.feat_stream)      # (enqueued by nerf_forward)
                     loss.feat, l1 = var.feat_early, None
                 elif fused_feat and hasattr(self.perceptual_loss, "loss_from_patches"):
                     # K13 + K12: inputs of the four batches in one launch, one pass through the network, l1 + 5 l2 in one launch

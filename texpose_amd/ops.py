@@ -1200,6 +1200,12 @@ def step_flags(total: Tensor, bad: Tensor, word_finite: int, snapshot: Tensor, s
                             snapshot.data_ptr(), _stream()), "tp_step_flags")
 
 
+def stamp(slots: torch.Tensor, i: int) -> None:
+    """Diagnostic: the device clock (100 MHz ticks) into ``slots[i]`` (int64 device tensor), one launch in stream order."""
+    assert slots.dtype == torch.int64 and slots.is_cuda and 0 <= i < slots.numel()
+    check(_lib.load().tp_stamp(slots.data_ptr() + 8 * i, _stream()), "tp_stamp")
+
+
 def step_inputs(copies, scalars=(), words=None, words_host=None) -> None:
     """The per-iteration host -> device state of a replayed step in ONE launch (K13 tp_step_inputs): ``copies`` = [(dst, src)]
     device tensors of equal byte size (the batch into the static inputs), ``scalars`` = [(0-dim float32 device tensor, value)],

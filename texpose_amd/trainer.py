@@ -402,6 +402,65 @@ class GanTrainer:
         return var, loss
 
 
+def distinct_queue_streams(dev, n, candidates=8):
+    """``n`` streams that run CONCURRENTLY with each other and with the current stream, found by measurement.
+
+    The HIP runtime multiplexes all streams of a process onto a few hardware queues (4 by default), round-robin in creation order, and a
+    hardware queue is in-order: two streams on one queue serialise, barrier packets included.  Which queue a new stream gets depends on
+    how many streams the process made before -- the captured training step ran 850 it/s with its three streams on three queues of their
+    own and 640-735 it/s when one of them shared the calling stream's queue (tools/train_bench.py with TP_PRE_STREAMS=1,2; profiles/r4).
+    There is no API to ask for a stream's queue, but sharing is observable: a spin kernel on A delays a one-element fill on B if and only
+    if they share a queue.  A few candidate streams are made and tested that way (each test ~1 ms, once per capture); streams that do
+    not pass are simply not used.  If fewer than ``n`` concurrent ones exist (GPU_MAX_HW_QUEUES < 4) the rest are taken in creation
+    order: the step is then correct as ever and slower."""
+    cur = torch.cuda.current_stream(dev)
+    pool = [torch.cuda.Stream(device=dev) for _ in range(candidates)]
+    probe = torch.zeros(1, device=dev)
+    # a spin long enough to tell: calibrate cycles -> ~1.5 ms
+    cycles = 1_000_000
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(dev)
+    e0.record(cur); torch.cuda._sleep(cycles); e1.record(cur); e1.synchronize()
+    cycles = int(cycles * 1.5 / max(e0.elapsed_time(e1), 1e-3))
+
+    def shares_queue(a, b):
+        """True when a one-element fill on ``b`` waits for a spin kernel issued on ``a`` just before."""
+        torch.cuda.synchronize(dev)
+        done_a, done_b = torch.cuda.Event(), torch.cuda.Event()
+        with torch.cuda.stream(a):
+            torch.cuda._sleep(cycles)
+            done_a.record(a)
+        with torch.cuda.stream(b):
+            probe.fill_(1.0)
+            done_b.record(b)
+        done_b.synchronize()
+        shared = done_a.query()
+        torch.cuda.synchronize(dev)
+        return shared
+
+    # every pair, twice: a stream gets its queue on first use and the first answers about it are not the final ones (measured: a pair
+    # reported as concurrent in the pass that first touched it serialised ever after); the second pass is the one that counts
+    every = [cur] + pool
+    for st in pool:
+        with torch.cuda.stream(st):
+            probe.fill_(0.0)
+    for _ in range(2):
+        shared = [[a is not b and shares_queue(a, b) for b in every] for a in every]
+    together = lambda i, j: shared[i][j] or shared[j][i]
+    picked = []
+    for i in range(1, len(every)):
+        if len(picked) < n and not together(0, i) and not any(together(j, i) for j in picked):
+            picked.append(i)
+    for i in range(1, len(every)):                   # (not enough concurrent ones: fill up in creation order)
+        if len(picked) < n and i not in picked:
+            picked.append(i)
+    chosen = [every[i] for i in picked]
+    if os.environ.get("TP_QUEUE_PROBE_VERBOSE") == "1":
+        print("distinct_queue_streams: candidates", [pool.index(c) for c in chosen], "pairwise sharing after the choice:",
+              [[int(shares_queue(a, b)) for b in [cur] + chosen] for a in [cur] + chosen], flush=True)
+    return chosen
+
+
 class GraphedGanTrainer(GanTrainer):
     """The same iteration captured ONCE into a hipGraph and replayed.
 
@@ -430,6 +489,7 @@ class GraphedGanTrainer(GanTrainer):
         self._bad = torch.zeros(3, dtype=torch.int32, device=dev)
         self._side = None                        # second stream of the captured step (discriminator branch)
         self._four, self._g4, self._ev4 = False, None, None    # the step as four graphs on two streams (`_use_four_graphs`)
+        self._linear = False                     # ... as six LINEAR graphs on three streams (`_use_linear_graphs`)
         # what the optimiser launches read: the words as they stood when the step's own flags had been folded in
         self._gate_nerf, self._gate_disc = torch.zeros_like(self._bad), torch.zeros_like(self._bad)
         if isinstance(self.optim_nerf, FusedAdam):
@@ -633,8 +693,55 @@ class GraphedGanTrainer(GanTrainer):
     def _seg_disc(self, var):
         return self.disc_step(var, apply=True)
 
+    # ------------------------------------------------------------------ ... and as SIX LINEAR graphs on three streams
+    # G2 above still forks inside the graph (the feature chain beside the discriminator's pass), and a replayed graph with a fork picks
+    # the hardware queue of its second branch by the runtime's round-robin over ALL streams the process ever made: the same trainer ran
+    # 870 it/s in a fresh process and 660 it/s behind other legs of bench.py that had created timing streams (profiles/r4).  Launching it
+    # also costs the host 110 us against 6-14 us for a linear graph.  So the fork is taken out of the graph as well: the feature chain
+    # runs forward AND backward as a graph of its own on a third stream and hands the generator step a cotangent,
+    #     main:  G1 = render .. patch stacks -> ev_patches;  [wait ev_sn] G2a = D(fake), loss terms, D's backward down to the patches;
+    #            [wait ev_feat] G2b = loss total + gate, composite / MLP backward from (terms, d gan / d rgb, d feat / d rgb), Adam
+    #     feat:  [wait ev_patches] F = feature inputs, network, pair loss, its backward down to the render's rgb   -> ev_feat
+    #     disc:  D1, D2 as above
+    # Every graph is a chain and every stream is the trainer's own, made one after the other (three consecutive hardware queues whatever
+    # the process created before).  Same kernels and the same cotangent values as the one-graph form: the composite's backward sums the
+    # cotangents of its rgb aliases either way (autograd_ops._Composite, fan_out).
+    def _use_linear_graphs(self, var):
+        opt, g = self.opt, self.graph
+        lw = opt.loss_weight
+        pl = getattr(g, "perceptual_loss", None)
+        return (os.environ.get("TP_LINEAR_GRAPHS", "1") == "1" and os.environ.get("TP_NO_FEAT_BRANCH") != "1" and lw.feat is not None
+                and lw.gan_nerf is not None and pl is not None and hasattr(pl, "loss_from_patches") and hasattr(pl, "pairs_from_patches")
+                and bool(opt.nerf.rand_rays))
+
+    def _seg_feat(self, var):
+        """The feature loss of the nerf step and its cotangent 10^w d feat / d rgb on the rgb alias the composite made for it."""
+        _, h, w, _ = var.ray_idx.shape
+        feat = self.graph.perceptual_loss.loss_from_patches(var.rgb_feat, var.gathered, (h, w), 5.0)
+        (var.g_rgb_feat,) = torch.autograd.grad(feat, var.rgb_feat, grad_outputs=self._weight(self.opt.loss_weight.feat, feat.device))
+        # (compute_loss takes the value from here; `joined`: the replay loop orders the streams, no wait is recorded in a capture)
+        var.feat_early, var.feat_early_for, var.feat_early_joined = feat.detach(), var.ray_idx, True
+
+    def _seg_gen_a(self, var):
+        var, loss = self.nerf_forward_loss(var, stage="consume")
+        (g_disc,) = torch.autograd.grad(loss.gan_nerf, var.rgb_disc, grad_outputs=self._weight(self.opt.loss_weight.gan_nerf, var.rgb.device))
+        return var, loss, g_disc
+
+    def _seg_gen_b(self, var, loss, g_disc):
+        dev, lw = var.idx.device, self.opt.loss_weight
+        status = ops.mlp_status(dev) if self._uses_f16x3() else None
+        keys = [k for k in loss if k != "all" and lw[k] is not None]
+        terms, ws = self._weighted_total(loss, flags=dict(bad=self._bad, word_finite=1, snapshot=self._gate_nerf, status=status,
+                                                          word_status=0, step_counter=getattr(self, "_rng_counter", None)))
+        roots = {"feat": (var.rgb_feat, var.g_rgb_feat), "gan_nerf": (var.rgb_disc, g_disc)}
+        pairs = [roots.get(k, (t, w)) for k, t, w in zip(keys, terms, ws)]
+        torch.autograd.backward([r for r, _ in pairs], [c for _, c in pairs])
+        self._guard_nerf(var, loss)
+        self.nerf_apply()
+        return var, loss
+
     def _four_eager(self, var):
-        """The four segments on their two streams, eagerly (warm-up), with the same three dependencies as the replays."""
+        """The segments on their streams, eagerly (warm-up), with the same dependencies as the replays."""
         main = torch.cuda.current_stream(var.idx.device)
         side = self._side
         side.wait_stream(main)
@@ -642,8 +749,20 @@ class GraphedGanTrainer(GanTrainer):
             self._seg_sn()
         var = self._seg_render(var)
         side.wait_stream(main)
-        main.wait_stream(side)
-        var, loss = self._seg_generator(var)
+        if self._linear and not ("rgb_feat" in var and "rgb_disc" in var and var.get("gathered_for") is var.ray_idx):
+            self._linear = False                     # (no fan-out aliases / fused gathers in this configuration: four graphs)
+        if self._linear:
+            feat = self.graph.feat_stream
+            feat.wait_stream(main)
+            with torch.cuda.stream(feat):
+                self._seg_feat(var)
+            main.wait_stream(side)
+            var, loss, g_disc = self._seg_gen_a(var)
+            main.wait_stream(feat)
+            var, loss = self._seg_gen_b(var, loss, g_disc)
+        else:
+            main.wait_stream(side)
+            var, loss = self._seg_generator(var)
         with torch.cuda.stream(side):
             var, dloss = self._seg_disc(var)
         main.wait_stream(side)
@@ -703,6 +822,84 @@ class GraphedGanTrainer(GanTrainer):
         # whatever the caller enqueues next on its stream -- reads of the step's losses, the next iteration's inputs and its G1, which
         # overwrites the patch stacks / scales this discriminator step is reading -- comes after the discriminator step
         main.wait_event(ev["d2"])
+
+    def _stamp(self, name):
+        """TP_STAMPS=1 (tools/linear_timeline.py): a one-thread launch writing the device clock, captured at the segment boundaries."""
+        if os.environ.get("TP_STAMPS") != "1":
+            return
+        if getattr(self, "_stamps", None) is None:
+            self._stamps, self._stamp_names = torch.zeros(32, dtype=torch.int64, device=self._bad.device), []
+        if name not in self._stamp_names:
+            self._stamp_names.append(name)
+        ops.stamp(self._stamps, self._stamp_names.index(name))
+
+    def _capture_linear(self, cap):
+        side, feat = self._side, self.graph.feat_stream
+        self._g4 = g = {k: torch.cuda.CUDAGraph() for k in ("D1", "G1", "F", "G2a", "G2b", "D2")}
+        self._ev4 = {k: torch.cuda.Event() for k in ("sn", "patches", "feat", "g2", "d2")}
+        # one memory pool per stream (see `_capture_four`); tensors that cross streams stay referenced for the life of the graphs
+        with torch.cuda.graph(g["D1"], stream=side):
+            self._stamp("D1.0"); self._seg_sn(); self._stamp("D1.1")
+        keep = [list(self.graph.discriminator._sn_queue)]
+        with torch.cuda.graph(g["G1"], stream=cap):
+            self._stamp("G1.0"); var = self._seg_render(AttrDict(dict(self._static_in))); self._stamp("G1.1")
+        keep.append(dict(var))
+        with torch.cuda.graph(g["F"], stream=feat):
+            self._stamp("F.0"); self._seg_feat(var); self._stamp("F.1")
+        keep.append(dict(var))
+        with torch.cuda.graph(g["G2a"], stream=cap, pool=g["G1"].pool()):
+            self._stamp("G2a.0"); var, loss, g_disc = self._seg_gen_a(var); self._stamp("G2a.1")
+        keep.append((dict(var), dict(loss), g_disc))
+        with torch.cuda.graph(g["G2b"], stream=cap, pool=g["G1"].pool()):
+            self._stamp("G2b.0"); var, loss = self._seg_gen_b(var, loss, g_disc); self._stamp("G2b.1")
+        keep.append(dict(var))
+        with torch.cuda.graph(g["D2"], stream=side, pool=g["D1"].pool()):
+            self._stamp("D2.0"); var, dloss = self._seg_disc(var); self._stamp("D2.1")
+        keep.append(dict(var))
+        self._g4_keep = keep
+        loss.update({k: v for k, v in dloss.items() if k != "all"})
+        self._static_loss = {k: v.detach() for k, v in loss.items() if torch.is_tensor(v)}
+        self._four_first = True
+
+    def _replay_linear(self):
+        g, ev = self._g4, self._ev4
+        main, side, feat = self._capture_stream, self._side, self.graph.feat_stream
+        cur = torch.cuda.current_stream(self._bad.device)
+        # the caller's stream hands over the step's inputs (and, the first time, parameters restored / loaded since the capture); it
+        # waited for the previous iteration's last launches below, so does everything here
+        main.wait_stream(cur)
+        with torch.cuda.stream(side):
+            if self._four_first:
+                side.wait_stream(cur)
+            else:
+                side.wait_event(ev["g2"])            # set 1 is read by the generator's passes through the frozen discriminator
+            g["D1"].replay()
+            ev["sn"].record(side)
+        with torch.cuda.stream(main):
+            g["G1"].replay()
+            ev["patches"].record(main)
+        # (The order in which the host submits F / G2a+G2b / D2 makes no difference -- six orders measured within 0.5 % on one box -- and the
+        # host is 4x ahead of the device: 260 us of launches per 1.17 ms iteration.)
+        with torch.cuda.stream(feat):
+            if self._four_first:
+                feat.wait_stream(cur)
+                self._four_first = False
+            feat.wait_event(ev["patches"])
+            g["F"].replay()
+            ev["feat"].record(feat)
+        with torch.cuda.stream(main):
+            main.wait_event(ev["sn"])
+            g["G2a"].replay()
+            main.wait_event(ev["feat"])
+            g["G2b"].replay()
+            ev["g2"].record(main)
+        with torch.cuda.stream(side):
+            side.wait_event(ev["patches"])
+            g["D2"].replay()
+            ev["d2"].record(side)
+        # what the caller enqueues next -- reads of the losses, the next iteration's inputs -- comes after both optimiser steps
+        cur.wait_event(ev["g2"])
+        cur.wait_event(ev["d2"])
 
     def _prefetch_spectral_weights(self, var):
         """The spectral normalisations of this iteration's three discriminator passes (nerf step's D(fake), D(real), D(fake):
@@ -793,8 +990,17 @@ class GraphedGanTrainer(GanTrainer):
                 self._rng_counter = torch.zeros(1, dtype=torch.int64, device=dev)       # (attached to the graph only inside `_body_a`)
         self._static_in = AttrDict({k: v.clone() for k, v in var.items() if torch.is_tensor(v)})
         self._four = self._use_four_graphs(var)
+        self._linear = self._four and self._use_linear_graphs(var)
+        # the step's streams are made here, one after the other (main / capture, discriminator, feature chain): consecutive hardware queues
+        if self._linear and (getattr(self, "_capture_stream", None) is None or self._side is None
+                             or getattr(self.graph, "feat_stream", None) is None) and os.environ.get("TP_NO_QUEUE_PROBE") != "1":
+            self._capture_stream, self._side, self.graph.feat_stream = distinct_queue_streams(dev, 3)
+        if getattr(self, "_capture_stream", None) is None:
+            self._capture_stream = torch.cuda.Stream(device=dev)
         if self._four and self._side is None:
             self._side = torch.cuda.Stream(device=dev)
+        if self._linear and getattr(self.graph, "feat_stream", None) is None:
+            self.graph.feat_stream = torch.cuda.Stream(device=dev)
         snap = self._snapshot()
         # warm up on the stream the capture will use: per-stream state (the tile counters of the convolution kernels,
         # ops._conv_scratch) must exist before the capture and is keyed by the stream
@@ -815,7 +1021,9 @@ class GraphedGanTrainer(GanTrainer):
             self.optim_disc.zero_grad(set_to_none=True)
         self.graph.patch_sampler.update_device_bound()          # outside the capture
         self._graph_b = None
-        if self._four:
+        if self._linear:
+            self._capture_linear(side)
+        elif self._four:
             self._capture_four(side)
         elif self._split_around_collectives():
             with torch.cuda.graph(self._graph, stream=side):
@@ -884,6 +1092,8 @@ class GraphedGanTrainer(GanTrainer):
     def replay(self):
         """Issue the captured step once on the current stream(s): one graph, four graphs on two streams (`_replay_four`), or -- several
         ranks -- graph A, the gradient all-reduces, graph B."""
+        if self._linear:
+            return self._replay_linear()
         if self._four:
             return self._replay_four()
         self._graph.replay()

@@ -16,10 +16,20 @@ var = training_batch(4, 128, 128, device="cuda:0")
 for _ in range(10):
     tr.train_iteration(AttrDict(dict(var)))
 torch.cuda.synchronize()
+# whole iteration host time without sync
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(50):
+    tr.train_iteration(AttrDict(dict(var)))
+t1 = time.perf_counter()
+torch.cuda.synchronize()
+t2 = time.perf_counter()
+print("50 iterations: host issue %.1f us/iter, with final sync %.1f us/iter" % ((t1 - t0) / 50 * 1e6, (t2 - t0) / 50 * 1e6))
+# (single segments replayed out of order: garbage state afterwards, this goes last)
 if tr._four:
-    for name in ("D1", "G1", "G2", "D2"):
-        g = tr._g4[name]
-        s = tr._side if name[0] == "D" else torch.cuda.current_stream()
+    print("mode:", "six linear graphs on three streams" if tr._linear else "four graphs on two streams")
+    for name, g in tr._g4.items():
+        s = tr._side if name[0] == "D" else tr.graph.feat_stream if name == "F" else torch.cuda.current_stream()
         ts = []
         for _ in range(20):
             torch.cuda.synchronize()
@@ -34,12 +44,3 @@ else:
         t0 = time.perf_counter(); tr._graph.replay(); t1 = time.perf_counter()
         ts.append((t1 - t0) * 1e6)
     print("one graph host us per replay: min %.1f median %.1f" % (min(ts), sorted(ts)[10]))
-# whole iteration host time without sync
-torch.cuda.synchronize()
-t0 = time.perf_counter()
-for _ in range(50):
-    tr.train_iteration(AttrDict(dict(var)))
-t1 = time.perf_counter()
-torch.cuda.synchronize()
-t2 = time.perf_counter()
-print("50 iterations: host issue %.1f us/iter, with final sync %.1f us/iter" % ((t1 - t0) / 50 * 1e6, (t2 - t0) / 50 * 1e6))

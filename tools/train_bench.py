@@ -21,6 +21,12 @@ def run(B=4, iters=20, warm=6, full=True, device="cuda:0", graphed=False, train_
     graph = Graph(opt, discriminator=Discriminator(opt) if full else None,
                   perceptual_loss=PerceptualLoss() if full else None).to(device)
     graph.nerf.train_precision = train_precision
+    # TP_PRE_STREAMS=k: k streams made (and used once) before the trainer makes its own -- shifts the round-robin assignment of hardware
+    # queues, the way earlier work in a larger process does (robustness check of the captured step's stream layout)
+    pre = [torch.cuda.Stream(device=device) for _ in range(int(os.environ.get("TP_PRE_STREAMS", "0")))]
+    for st in pre:
+        with torch.cuda.stream(st):
+            torch.zeros(1, device=device)
     tr = (GraphedGanTrainer if graphed else GanTrainer)(opt, graph, n_train=189)
     var = training_batch(B, 128, 128, device=device)
     for _ in range(warm):

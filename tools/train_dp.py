@@ -85,7 +85,8 @@ def measure(device, rank, world, global_batch=32, iters=50, warm=5, graphed=True
         coll = sum(a.elapsed_time(b) for a, b in trainer.collective_events) / len(trainer.collective_events)
     return dict(collective_ms=coll, metric="train iters/sec", value=1.0 / dt, ms_per_iter=dt * 1e3, n_gpus=world, global_batch=global_batch,
                 per_gpu_batch=global_batch // world, rays_per_iter=global_batch * 256, samples_per_iter=global_batch * 256 * 64,
-                launch=("four hipGraph replays on two streams (render | generator step || spectral norm | discriminator step)" if getattr(trainer, "_four", False)
+                launch=("six linear hipGraph replays on three streams (render | D(fake) + its backward | generator backward + Adam || feature chain || spectral norm | discriminator step)" if getattr(trainer, "_linear", False)
+                        else "four hipGraph replays on two streams (render | generator step || spectral norm | discriminator step)" if getattr(trainer, "_four", False)
                         else "hipGraph replay" if getattr(trainer, "_graph_b", None) is None
                         else "two hipGraph replays with the gradient all-reduces between them") if graphed else "eager", recording_forward=graph.nerf.train_precision,
                 collective="one flat all-reduce per optimiser step (%.1f MB nerf, %.1f MB discriminator)"
