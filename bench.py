@@ -682,7 +682,14 @@ def main():
         achieved = MLP_FLOP_PER_SAMPLE * samples / (ms * 1e-3) / 1e12
         peak = MFMA_PEAK_TFLOPS[precision]
         k = ISSUED_PER_ALGORITHMIC[precision]
-        return {"kernel": "mlp_fwd_exact_asm_kernel" if precision == "fp32" else "mlp_fwd_f16x3_kernel", "bound": "mfma",
+        rb = precision == "f16x3" and ops.ray_bias_applies("f16x3", N_SAMPLES, False, True)
+        if rb:
+            # ray-bias variant: the 75 ray-constant input columns of mlp_rgb.0 and the 16 of mlp_trans.0 (23,296 of the 910,592 MACs
+            # per sample) are contracted once per ray in fp32 by the pre-kernels -- inside the event window -- not on the matrix cores
+            k = k * (1.0 - 23_296 / 910_592)
+        return {"kernel": "mlp_fwd_exact_asm_kernel" if precision == "fp32" else
+                ("mlp_fwd_f16x3_kernel<false, true> (+ rb_image_bias / rb_ray_bias pre-kernels, in the event window)" if rb else "mlp_fwd_f16x3_kernel"),
+                "bound": "mfma",
                 "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": measured_traffic(precision, samples)[0],
                 "traffic_stale": measured_traffic(precision, samples)[1],
                 "traffic_unit": "bytes/launch, L2<->fabric (FETCH_SIZE x2 + WRITE_SIZE, profiles/traffic.json)",

@@ -109,7 +109,8 @@ typedef struct tp_mlp_weights {
 size_t tp_mlp_packed_bytes(void);
 /* Which parts to (re)pack: the trunk is frozen, the heads change every optimiser step. */
 enum { TP_PACK_TRUNK = 1, TP_PACK_HEADS = 2, TP_PACK_ALL = 3,
-       TP_PACK_F16X3 = 4 /* OR-ed in: build the split-fp16 (hi+lo) stream of the TP_MLP_F16X3 forward; same size */ };
+       TP_PACK_F16X3 = 4 /* OR-ed in: build the split-fp16 (hi+lo) stream of the TP_MLP_F16X3 forward; same size */,
+       TP_PACK_RAYBIAS = 8 /* OR-ed in with TP_PACK_F16X3: the stream variant of tp_mlp_fwd_args.ray_bias (same buffer size) */ };
 int tp_mlp_pack(const tp_mlp_weights* w /*host struct of device ptrs*/, int parts, void* packed, tp_stream_t stream);
 /* Training (TP_MLP_F16X3): everything that is rebuilt from the HEAD weights after an optimiser step, in one launch: the head chunks
  * and head biases of the f16x3 forward stream `packed` (what tp_mlp_pack(TP_PACK_HEADS | TP_PACK_F16X3) writes) and, when packed_t is
@@ -144,7 +145,14 @@ typedef struct tp_mlp_fwd_args {
                               pattern of the largest hidden activation handed to the matrix cores in this call (post-ReLU,
                               its fp16 hi part: 11 significant bits).  The range guard fires at 6e4; this word says how far
                               below it a network runs.  Zero it before the calls to be covered. */
+  float* ray_bias;         /* optional (NULL = off).  TP_MLP_F16X3 without `saved`, input form A, N % 128 == 0 (every 128-sample tile
+                              lies inside one ray), `packed` built with TP_PACK_F16X3 | TP_PACK_RAYBIAS: device scratch of
+                              tp_mlp_ray_bias_bytes(B, R).  The inputs of mlp_rgb.0 that are constant along a ray (view encoding 27,
+                              light code 48 of its 334 columns; reference layers/nerf_static_transient_light.py:104-118) and the
+                              transient code of mlp_trans.0 (:127-129) are then contracted once per ray / image in fp32 by a
+                              pre-kernel and enter the layer as a per-ray bias instead of 96 input columns of every sample. */
 } tp_mlp_fwd_args;
+size_t tp_mlp_ray_bias_bytes(int B, int R);
 /* TP_MLP_F16X3: every fp32 operand is split into hi + lo fp16 (22-bit significand) and hi*hi + hi*lo + lo*hi is
  * accumulated in fp32 on the f16 matrix cores (16x the fp32-MFMA rate / 3).  Measured error vs an fp64 oracle is
  * within 1.3x of plain fp32.  Requires |activation| < 6e4 (see `status`).  With `saved` it writes

@@ -763,6 +763,79 @@ def test_mlp_f16x3_matches_oracle(ops):
         torch.testing.assert_close(a.cpu(), r, rtol=1e-4, atol=1e-6)
 
 
+@pytest.mark.parametrize("B,R,N", [(1, 7, 128), (2, 33, 128), (3, 5, 256), (1, 300, 128)])
+def test_mlp_f16x3_ray_bias_variant(ops, B, R, N):
+    """tp_mlp_fwd with `ray_bias` (TP_PACK_RAYBIAS stream: the view encoding / light code of mlp_rgb.0 and the transient code of
+    mlp_trans.0 as a per-ray bias formed in fp32 by a pre-kernel, x re-read from the encoding stage) against the plain f16x3 kernel
+    on the same inputs (<= 1e-6 rel-L2: only the arithmetic of 96 of ~4,000 input columns changes, to exact fp32), against the CPU
+    oracle at the kernels' common bar, and -- its error against an fp64 evaluation -- no worse than the plain kernel's."""
+    rs = np.random.RandomState(B * 100 + R + N)
+    params = O.make_params(31 + N)
+    cparams = {k: cu(v) for k, v in params.items()}
+    p16 = ops.pack_weights(cparams, precision="f16x3")
+    prb = ops.pack_weights(cparams, precision="f16x3", ray_bias=True)
+    lt = torch.from_numpy(rs.normal(size=(B, 16)).astype(np.float32))
+    ll = torch.from_numpy(rs.normal(size=(B, 48)).astype(np.float32))
+    center = torch.from_numpy(rs.uniform(-1, 1, size=(B, R, 3)).astype(np.float32)) + torch.tensor([0., 0., -8.])
+    ray = torch.from_numpy(rs.normal(scale=0.3, size=(B, R, 3)).astype(np.float32))
+    ray[..., 2] = 1.0
+    depth = torch.sort(torch.from_numpy(rs.uniform(7, 9, size=(B, R, N, 1)).astype(np.float32)), dim=2).values
+    assert ops.ray_bias_applies("f16x3", N, False, True) and not ops.ray_bias_applies("f16x3", 64, False, True)
+    assert not ops.ray_bias_applies("fp32", N, False, True) and not ops.ray_bias_applies("f16x3", N, True, True)
+    ops.mlp_status(dev()).zero_()
+    plain = ops.mlp_forward(p16, cu(lt), cu(ll), center=cu(center), ray=cu(ray), depth=cu(depth), precision="f16x3")
+    rb = ops.mlp_forward(prb, cu(lt), cu(ll), center=cu(center), ray=cu(ray), depth=cu(depth), precision="f16x3", ray_bias=True)
+    again = ops.mlp_forward(prb, cu(lt), cu(ll), center=cu(center), ray=cu(ray), depth=cu(depth), precision="f16x3", ray_bias=True)
+    ops.check_mlp_status(dev())
+    with torch.no_grad():
+        ref = O.forward_samples(params, center, ray, depth, lt, ll)
+    for a, b_, c, r, name in zip(rb, plain, again, ref, ("rgb", "density", "uncert")):
+        assert torch.equal(a, c), name
+        assert rel_l2(a, b_) < 1e-6, (name, rel_l2(a, b_))
+        torch.testing.assert_close(a.cpu(), r, rtol=1e-4, atol=1e-6)
+    if R <= 33:
+        with torch.no_grad():
+            saved_posenc = O.posenc
+
+            def posenc64(x, L):
+                freq = (2 ** torch.arange(L, dtype=torch.float32)) * np.pi
+                spec = (x.float()[..., None] * freq).double()
+                return torch.stack([spec.sin(), spec.cos()], dim=-2).reshape(*x.shape[:-1], -1)
+            O.posenc = posenc64
+            try:
+                pts = (center[:, :, None] + ray[:, :, None] * depth).float()
+                unit = torch.nn.functional.normalize(ray, dim=-1)[:, :, None].expand(B, R, N, 3)
+                r64 = O.mlp_forward({k: v.double() for k, v in params.items()}, pts.double(), unit.float().double(), lt.double(), ll.double())
+            finally:
+                O.posenc = saved_posenc
+        for a, b_, r in zip(rb, plain, r64):
+            assert rel_l2(a, r) < 1.25 * rel_l2(b_, r) + 1e-7, (rel_l2(a, r), rel_l2(b_, r))
+
+
+def test_mlp_ray_bias_rejects_other_configurations(ops):
+    """A TP_PACK_RAYBIAS stream cannot run the plain kernels: a call outside the configuration it is laid out for is an error."""
+    from texpose_amd import _lib
+    params = {k: cu(v) for k, v in O.make_params(3).items()}
+    prb = ops.pack_weights(params, precision="f16x3", ray_bias=True)
+    lt, ll = torch.zeros(1, 16, device=dev()), torch.zeros(1, 48, device=dev())
+    center, ray = torch.zeros(1, 4, 3, device=dev()), torch.ones(1, 4, 3, device=dev())
+    depth = torch.ones(1, 4, 64, 1, device=dev())
+    with pytest.raises(AssertionError):
+        ops.mlp_forward(prb, lt, ll, center=center, ray=ray, depth=depth, precision="f16x3", ray_bias=True)
+    a = _lib.MlpFwdArgs()
+    out = [torch.empty(1, 4, 64, 6, device=dev()), torch.empty(1, 4, 64, 2, device=dev()), torch.empty(1, 4, 64, 1, device=dev())]
+    ws = torch.empty(int(_lib.load().tp_mlp_workspace_bytes(256)) // 4, device=dev())
+    scratch = torch.empty(int(_lib.load().tp_mlp_ray_bias_bytes(1, 4)) // 4, device=dev())
+    a.packed, a.center, a.ray, a.depth, a.lat_trans, a.lat_light = (t.data_ptr() for t in (prb, center, ray, depth, lt, ll))
+    a.B, a.R, a.N = 1, 4, 64
+    a.rgb, a.density, a.uncert, a.workspace, a.ray_bias = (t.data_ptr() for t in (*out, ws, scratch))
+    a.precision = ops.MLP_F16X3
+    a.status = ops.mlp_status(dev()).data_ptr()
+    import ctypes
+    assert _lib.load().tp_mlp_fwd(ctypes.byref(a), 0) != 0
+    assert b"N % 128" in _lib.load().tp_last_error()
+
+
 def test_both_mlp_kernels_are_fp32_grade_vs_fp64(ops, monkeypatch):
     """What "f32 carried as 2 x f16" means in numbers: against an fp64 evaluation of the same network (same fp32-rounded
     encoding arguments, as the reference computes them) the f16x3 kernel and the exact-fp32 kernel must both be as

@@ -19,7 +19,7 @@ SYMBOLS = (
     "tp_abi_version", "tp_last_error",
     "tp_raygen", "tp_aabb", "tp_sample_depth",
     "tp_mlp_packed_bytes", "tp_mlp_pack", "tp_mlp_pack_heads_f16x3", "tp_mlp_pack_host", "tp_mlp_workspace_bytes", "tp_mlp_fwd", "tp_posenc",
-    "tp_mlp_saved_bytes", "tp_mlp_packed_t_bytes", "tp_mlp_bwd_workspace_bytes", "tp_mlp_bwd",
+    "tp_mlp_saved_bytes", "tp_mlp_ray_bias_bytes", "tp_mlp_packed_t_bytes", "tp_mlp_bwd_workspace_bytes", "tp_mlp_bwd",
     "tp_composite_fwd", "tp_composite_bwd",
     "tp_patch_gather",
     "tp_eval_metrics_workspace_bytes", "tp_eval_metrics",
@@ -60,7 +60,7 @@ class MlpFwdArgs(C.Structure):
                 ("ray_unit", vp), ("lat_trans", vp), ("lat_light", vp),
                 ("B", C.c_int), ("R", C.c_int), ("N", C.c_int),
                 ("rgb", vp), ("density", vp), ("uncert", vp), ("saved", vp), ("workspace", vp),
-                ("precision", C.c_int), ("status", vp), ("act_max", vp)]
+                ("precision", C.c_int), ("status", vp), ("act_max", vp), ("ray_bias", vp)]
 
 
 class MlpBwdArgs(C.Structure):
@@ -208,6 +208,7 @@ def load() -> C.CDLL:
     sig("tp_mlp_packed_bytes", [], C.c_size_t)
     sig("tp_mlp_workspace_bytes", [C.c_int64], C.c_size_t)
     sig("tp_mlp_saved_bytes", [C.c_int64], C.c_size_t)
+    sig("tp_mlp_ray_bias_bytes", [C.c_int, C.c_int], C.c_size_t)
     sig("tp_mlp_packed_t_bytes", [], C.c_size_t)
     sig("tp_mlp_bwd_workspace_bytes", [C.c_int64], C.c_size_t)
     sig("tp_mlp_bwd", [C.POINTER(MlpBwdArgs), vp])

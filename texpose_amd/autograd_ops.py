@@ -59,9 +59,12 @@ class _Mlp(torch.autograd.Function):
     @staticmethod
     def forward(ctx, nerf, need_grad, lat_trans, lat_light, center, ray, depth, points, ray_unit, *head_params):
         precision = nerf.train_precision if need_grad else nerf.precision
-        packed = nerf.packed_weights(precision, for_training=bool(need_grad))       # (grad mode is off in here: the caller decided)
+        # evaluation renders with whole tiles inside one ray: view / light / transient inputs as a per-ray bias (ops.ray_bias_applies)
+        rb = ops.ray_bias_applies(precision, depth.numel() // (center.shape[0] * center.shape[1]) if center is not None else 0,
+                                  bool(need_grad), center is not None)
+        packed = nerf.packed_weights(precision, for_training=bool(need_grad), ray_bias=rb)   # (grad mode is off in here: the caller decided)
         res = ops.mlp_forward(packed, lat_trans, lat_light, center=center, ray=ray, depth=depth, points=points,
-                              ray_unit=ray_unit, save=need_grad, precision=precision)
+                              ray_unit=ray_unit, save=need_grad, precision=precision, ray_bias=rb)
         if need_grad:
             rgb, density, uncert, saved = res
             ctx.nerf = nerf

@@ -199,10 +199,11 @@ def ring_prologue(e):
         e("v_add_u32 v%d, %%[%s], %%[lane16]" % (VR + i, r))
         e("s_add_i32 %%[m%da], %%[ldswave], %%[%s]" % (i, r))
     e("s_add_i32 %[dch], %[chunk], 2")
-    e("s_cmp_ge_i32 %[dch], " + str(NCH))
-    e("s_cselect_b32 %[t0], " + str(NCH) + ", 0")
+    e("s_cmp_ge_i32 %[dch], %[nch]")
+    e("s_cselect_b32 %[t0], %[nch], 0")
     e("s_sub_i32 %[dch], %[dch], %[t0]")
-    # (NCH is read at generation time: main() switches it to the 34-chunk transposed stream for the data-gradient blocks)
+    # (%[nch] = number of chunks of the stream the block walks, an SGPR input: 115 forward, 112 forward with per-ray biases, 34
+    # transposed stream of the data gradient)
 
 
 def dma_base():
@@ -228,8 +229,8 @@ def dma_piece(e, k, dma_slot):
 def ring_epilogue(e, n_chunks):
     e("s_waitcnt lgkmcnt(0)")
     e("s_add_i32 %%[chunk], %%[chunk], %d" % n_chunks)
-    e("s_cmp_ge_i32 %[chunk], " + str(NCH))
-    e("s_cselect_b32 %[t0], " + str(NCH) + ", 0")
+    e("s_cmp_ge_i32 %[chunk], %[nch]")
+    e("s_cselect_b32 %[t0], %[nch], 0")
     e("s_sub_i32 %[chunk], %[chunk], %[t0]")
     e("s_add_i32 %%[buf], %%[buf], %d" % (n_chunks % 3))
     e("s_cmp_ge_i32 %[buf], 3")
@@ -293,7 +294,7 @@ def chunk_groups(e, npairs, ts, mf, fill, free_after, pieces_per_group, tail=Non
 
 
 def advance_dch():
-    return ["s_add_i32 %[dch], %[dch], 1", "s_cmp_eq_u32 %[dch], " + str(NCH), "s_cselect_b32 %[dch], 0, %[dch]"]
+    return ["s_add_i32 %[dch], %[dch], 1", "s_cmp_eq_u32 %[dch], %[nch]", "s_cselect_b32 %[dch], 0, %[dch]"]
 
 
 # ------------------------------------------------------------------------------------------------------ WIDE
@@ -689,13 +690,10 @@ def main():
     emit_macro(out, "TP_ASM_STASH_Q", "set Q -> v[32:159]", gen_stash(SET["Q"]))
     emit_macro(out, "TP_ASM_RESTORE_P", "v[32:159] -> set P", gen_restore(SET["P"]))
     # data gradient: the 34-chunk transposed stream
-    global NCH
-    NCH = 34
     emit_macro(out, "TP_ASM_DG_NARROW_P", "data gradient: set P = W3^T d (one k-step)", gen_dg_narrow(SET["P"]))
     emit_macro(out, "TP_ASM_DG_WIDE_PQ", "data gradient: set Q = W^T gated(set P), recording gated(set P)", gen_dg_wide(SET["P"], SET["Q"]))
     emit_macro(out, "TP_ASM_DG_WIDE_QP", "data gradient: set P = W^T gated(set Q), recording gated(set Q)", gen_dg_wide(SET["Q"], SET["P"]))
     emit_macro(out, "TP_ASM_DG_FINISH_P", "data gradient: record gated(set P)", gen_dg_finish(SET["P"]))
-    NCH = 115
     sys.stdout.write("\n".join(out) + "\n")
 
 

@@ -311,12 +311,12 @@ __device__ __forceinline__ float sigmoid(float x) { return 1.0f / (1.0f + expf(-
 // pinned to a[0:127], set Q to a[128:255], the fragment ring to v[160:191].  The C++ around them stages inputs, applies
 // the output non-linearities and stores.  (The dgrad kernel further down still uses the C++ layer body above.)
 // =====================================================================================================================
-struct AsmCtx { unsigned lane16, laneoff, ldswave, stream_lo, stream_hi, bias0, stage0; };
+struct AsmCtx { unsigned lane16, laneoff, ldswave, stream_lo, stream_hi, bias0, stage0; int nch; };
 // The context is RE-DERIVED from the hardware thread id at every block instead of being carried in registers: the compiler
 // owns ~40 VGPRs while the trunk feature is stashed, and seven context values kept live across the whole tile loop went to
 // scratch memory (whose lines, re-read every tile, then competed with the 3.6 MiB weight stream for the 4 MiB L2).  The
 // empty volatile asm makes each derivation opaque, so nothing of it is hoisted or shared between blocks.
-__device__ __forceinline__ AsmCtx asm_ctx_now(const float* packed) {
+__device__ __forceinline__ AsmCtx asm_ctx_now(const float* packed, int nch = kNumChunks) {
   extern __shared__ __attribute__((aligned(16))) float lds_base[];
   int tid = threadIdx.x;
   asm volatile("" : "+v"(tid));
@@ -333,6 +333,7 @@ __device__ __forceinline__ AsmCtx asm_ctx_now(const float* packed) {
   const unsigned bias_lds = lds0 + (unsigned)(kBufs * kChunkFloats) * 4u;
   c.bias0 = bias_lds + hh * 512u;                                          // + li * 1024: bias block of wide layer li
   c.stage0 = bias_lds + (unsigned)kBiasPad * 4u + (unsigned)tid * 16u;     // + ks * 8192: staged k-step ks (hi; lo at + 4096)
+  c.nch = nch;                                                             // chunks in the stream the blocks walk (a constant at every call site)
   return c;
 }
 #define TP_RING(f)                                                                                                     \
@@ -344,7 +345,7 @@ __device__ __forceinline__ AsmCtx asm_ctx_now(const float* packed) {
 #define TP_RING_INPUTS(c)                                                                                              \
   [lane16] "v"(c.lane16), [laneoff] "v"(c.laneoff), [ldswave] "s"(__builtin_amdgcn_readfirstlane(c.ldswave)),         \
       [stream_lo] "s"(__builtin_amdgcn_readfirstlane(c.stream_lo)),                                                    \
-      [stream_hi] "s"(__builtin_amdgcn_readfirstlane(c.stream_hi))
+      [stream_hi] "s"(__builtin_amdgcn_readfirstlane(c.stream_hi)), [nch] "s"(c.nch)
 #define TP_ASM_HACC "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247"
 #define TP_RING_LOCALS                                                                                                 \
   int chunk = __builtin_amdgcn_readfirstlane(p.chunk), buf = __builtin_amdgcn_readfirstlane(p.buf);                    \
@@ -531,6 +532,7 @@ struct Params {
   int64_t n_samples, n_tiles;
   float* rgb; float* density; float* uncert; float* saved; float* workspace; int* status;
   unsigned int* act_max;
+  const float* ray_bias;     // RB kernels: [B][2][256] per-image part, then [B*R][256] per-ray accumulator seeds of R0 (rb_*_kernel below)
 };
 
 // stage one "extra input" value as hi/lo halves: slot = 16 ks + 8 h + j of this lane
@@ -565,8 +567,14 @@ __device__ __forceinline__ float pick3(int c, float a0, float a1, float a2) {
   float* save = reinterpret_cast<float*>(st + kStageHalves) + tid;                                                     \
   (void)lane; (void)j; (void)hh; (void)wave; (void)save
 
-template <bool SAVE>
+// RB ("ray bias", evaluation only): the stream of chunk_desc_rb (mlp_layout.h).  Every tile lies inside one ray (N % 128 == 0); the
+// accumulators of R0 / T0 are seeded with the per-ray / per-image bias the pre-kernels below left in P.ray_bias, nothing is staged for
+// T0 and R0, and R0's only extra k-step re-reads x from k-step 3 of the encoding stage.
+template <bool SAVE, bool RB = false>
 __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_f16x3_kernel(Params P) {
+  static_assert(!(SAVE && RB), "the ray-bias stream has no recording variant");
+  constexpr int NCH = RB ? kNumChunksRB : kNumChunks;
+#define TP_CTX asm_ctx_now(P.packed, NCH)
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float* bias_lds = lds + kBufs * kChunkFloats;
@@ -576,7 +584,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_f16x3_kernel(Params P) {
   p.stream = P.packed; p.lds = lds; p.chunk = 0; p.buf = 0; p.wave = __builtin_amdgcn_readfirstlane(wave); p.lane = lane;
   // wide-layer biases are kept pre-scaled by 2^8 (exact): they seed the accumulators of the scaled products
   for (int i = tid; i < kBiasFloats; i += kThreads)
-    bias_lds[i] = P.packed[(size_t)kNumChunks * kChunkFloats + i] * (i < kHeadBiasOff ? (float)(1 << kF16WeightShift) : 1.0f);
+    bias_lds[i] = P.packed[(size_t)NCH * kChunkFloats + i] * (i < kHeadBiasOff ? (float)(1 << kF16WeightShift) : 1.0f);
   dma_chunk(p, 0, 0);
   dma_chunk(p, 1, 1);
   __syncthreads();
@@ -588,7 +596,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_f16x3_kernel(Params P) {
 #ifdef TP_TRACE
   const long long tr_start = tick();
 #endif
-  asm_init<true>(asm_ctx_now(P.packed), L0);        // set P starts as L0's bias; from then on every wide layer re-seeds its source set
+  asm_init<true>(TP_CTX, L0);        // set P starts as L0's bias; from then on every wide layer re-seeds its source set
 
   for (int64_t tile = blockIdx.x; tile < P.n_tiles; tile += gridDim.x) {
     TR_BEGIN(pro);
@@ -619,10 +627,19 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_f16x3_kernel(Params P) {
         vu0 = P.ray_unit[3 * s + 0]; vu1 = P.ray_unit[3 * s + 1]; vu2 = P.ray_unit[3 * s + 2];
       }
       save[0 * kThreads] = x0; save[1 * kThreads] = x1; save[2 * kThreads] = x2;
-      save[3 * kThreads] = vu0; save[4 * kThreads] = vu1; save[5 * kThreads] = vu2;
-      save[6 * kThreads] = __int_as_float(b);
+      if constexpr (!RB) {
+        save[3 * kThreads] = vu0; save[4 * kThreads] = vu1; save[5 * kThreads] = vu2;
+        save[6 * kThreads] = __int_as_float(b);
+      } else {
+        // this tile's accumulator seeds of R0 (per ray) and T0 (per image), already scaled by 2^8 and in bias-block order: one float
+        // per thread each.  The blocks that read them (T2 re-seeds set Q for R0, L7 re-seeds set P for T0) are many barriers away;
+        // the previous tile's reads of these two blocks lie before its last barriers.
+        const int64_t qt = (tile * 128) / P.N;                 // (wave-uniform: the tile's ray)
+        bias_lds[R0 * 256 + tid] = P.ray_bias[(size_t)P.B * 512 + (size_t)qt * 256 + tid];
+        bias_lds[T0 * 256 + tid] = P.ray_bias[(size_t)(qt / P.R) * 512 + tid];
+      }
     }
-    asm_init<false>(asm_ctx_now(P.packed), L1);       // set Q for L1 (set P was re-seeded for L0 by the previous tile's last layer)
+    asm_init<false>(TP_CTX, L1);       // set Q for L1 (set P was re-seeded for L0 by the previous tile's last layer)
     TR_END(4, pro);
     // The two accumulator sets: even layers read Q and accumulate into P, odd layers the reverse (the layer loop is
     // unrolled by two, so both roles are fixed registers).  A set holds raw accumulators, bias included (seeded with
@@ -642,14 +659,14 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_f16x3_kernel(Params P) {
       float a0, a1, a2, a3;
       if constexpr (SAVE && which != 0) {
         Head4 h4;
-        if constexpr (which == 2) h4 = asm_head_rec<false>(p, frag, amax, asm_ctx_now(P.packed), rec_ctx_now(P.saved, tile, SV_R2));
-        else h4 = asm_head_rec<true>(p, frag, amax, asm_ctx_now(P.packed), rec_ctx_now(P.saved, tile, SV_T2));
+        if constexpr (which == 2) h4 = asm_head_rec<false>(p, frag, amax, TP_CTX, rec_ctx_now(P.saved, tile, SV_R2));
+        else h4 = asm_head_rec<true>(p, frag, amax, TP_CTX, rec_ctx_now(P.saved, tile, SV_T2));
         a0 = h4.a0; a1 = h4.a1; a2 = h4.a2; a3 = h4.a3;
         TR_END(7, h);
       } else {
         f32x16 a;
-        if constexpr (which == 2) a = asm_head<false>(p, frag, amax, asm_ctx_now(P.packed));
-        else a = asm_head<true>(p, frag, amax, asm_ctx_now(P.packed));
+        if constexpr (which == 2) a = asm_head<false>(p, frag, amax, TP_CTX);
+        else a = asm_head<true>(p, frag, amax, TP_CTX);
         TR_END(7, h);
         a0 = a[0]; a1 = a[1]; a2 = a[2]; a3 = a[3];
       }
@@ -689,9 +706,9 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_f16x3_kernel(Params P) {
         const int next_li = li + 1 == kNumWide ? 0 : li + 1;
         // training: a wide layer whose SOURCE set is a recorded activation writes that record while it converts it
         // (T0 <- L7 = trunk feature, values only; T1 <- T0; T2 <- T1; R1 <- R0; R2 <- R1.  R0 re-reads the restored feature)
-        if constexpr (REC == 2) asm_wide_rec<true, false>(p, frag, amax, asm_ctx_now(P.packed), next_li, rec_ctx_now(P.saved, tile, SV_FEAT));
-        else if constexpr (REC == 1) asm_wide_rec<EVEN, true>(p, frag, amax, asm_ctx_now(P.packed), next_li, rec_ctx_now(P.saved, tile, li - 1 - L7));
-        else asm_wide<EVEN>(p, frag, amax, asm_ctx_now(P.packed), next_li);
+        if constexpr (REC == 2) asm_wide_rec<true, false>(p, frag, amax, TP_CTX, next_li, rec_ctx_now(P.saved, tile, SV_FEAT));
+        else if constexpr (REC == 1) asm_wide_rec<EVEN, true>(p, frag, amax, TP_CTX, next_li, rec_ctx_now(P.saved, tile, li - 1 - L7));
+        else asm_wide<EVEN>(p, frag, amax, TP_CTX, next_li);
         TR_END(3, w);
       }
 
@@ -737,8 +754,26 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_f16x3_kernel(Params P) {
         }
         TR_END(5, pe);
         TR_BEGIN(w);
-        asm_extra<2, true>(p, frag, asm_ctx_now(P.packed), 0);
-        asm_extra<2, true>(p, frag, asm_ctx_now(P.packed), 2);
+        asm_extra<2, true>(p, frag, TP_CTX, 0);
+        asm_extra<2, true>(p, frag, TP_CTX, 2);
+        TR_END(3, w);
+      } else if (RB && EVEN && li == T0) {
+        // (the transient code is in the layer's per-image bias)
+      } else if (RB && !EVEN && li == R0) {
+        // the transient head's non-linearities (see the staging section of the plain kernel below); x has been consumed by L0
+        TR_BEGIN(r0s);
+        TP_THREAD_IDS;
+        if (hh == 0) {
+          save[0 * kThreads] = sigmoid(fmaf(ta0, kInvScale, hbias[1]));
+          save[1 * kThreads] = sigmoid(fmaf(ta1, kInvScale, hbias[2]));
+          save[2 * kThreads] = sigmoid(fmaf(ta2, kInvScale, hbias[3]));
+          save[3 * kThreads] = softplus(fmaf(ta3, kInvScale, hbias[4]));
+        } else {
+          save[0 * kThreads] = softplus(fmaf(ta0, kInvScale, hbias[5]));
+        }
+        TR_END(6, r0s);
+        TR_BEGIN(w);
+        asm_extra<1, false>(p, frag, TP_CTX, 3);          // [PE slots 48..59 (zero weights) | x | 0] as staged for L0
         TR_END(3, w);
       } else if (EVEN && li == T0) {
         TR_BEGIN(t0s);
@@ -748,7 +783,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_f16x3_kernel(Params P) {
         for (int jj = 0; jj < 8; ++jj) stage(st, tid, 0, jj, P.lat_trans[bt * 16 + 8 * hh + jj]);
         TR_END(13, t0s);
         TR_BEGIN(w);
-        asm_extra<1, true>(p, frag, asm_ctx_now(P.packed), 0);
+        asm_extra<1, true>(p, frag, TP_CTX, 0);
         TR_END(3, w);
       } else if (!EVEN && li == R0) {
         // [ray_unit | PE(ray_unit) | x | light] in natural column order, 78 of 80 slots
@@ -830,9 +865,9 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_f16x3_kernel(Params P) {
         }
         TR_END(6, r0s);
         TR_BEGIN(w);
-        asm_extra<2, false>(p, frag, asm_ctx_now(P.packed), 0);
-        asm_extra<2, false>(p, frag, asm_ctx_now(P.packed), 2);
-        asm_extra<1, false>(p, frag, asm_ctx_now(P.packed), 4);
+        asm_extra<2, false>(p, frag, TP_CTX, 0);
+        asm_extra<2, false>(p, frag, TP_CTX, 2);
+        asm_extra<1, false>(p, frag, TP_CTX, 4);
         TR_END(3, w);
       }
 
@@ -911,6 +946,72 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_f16x3_kernel(Params P) {
            tot, p.tr[0], p.tr[1], p.tr[2], p.tr[3], p.tr[4], p.tr[5], p.tr[6], p.tr[7], p.tr[8], p.tr[9], p.tr[10], p.tr[11], p.tr[12], p.tr[13]);
   }
 #endif
+}
+#undef TP_CTX
+
+// ---- pre-kernels of the ray-bias variant (mlp_layout.h): accumulator seeds of T0 per image and of R0 per ray, fp32 FMA chains
+// over the transposed weight columns in the aux block of the stream, written in bias-block order (thread e <-> (h, t, r) of
+// bias_index, feature feat_of(t, r, h)) and scaled by 2^8 like the bias block in LDS.
+//   out[b][0][e] = 2^8 (b_T0[f] + sum_c W_T0[f][256 + c] trans[b][c])        (mlp_trans.0, reference layers/...light.py:127-131)
+//   out[b][1][e] =      b_R0[f] + sum_c W_R0[f][286 + c] light[b][c]          (unscaled: the per-image part of the ray kernel's sum)
+__global__ __launch_bounds__(256) void rb_image_bias_kernel(const float* __restrict__ packed, const float* __restrict__ lat_trans,
+                                                            const float* __restrict__ lat_light, float* __restrict__ out) {
+  const int b = blockIdx.x, e = threadIdx.x;
+  const int h = e >> 7, t = (e >> 4) & 7, r = e & 15, f = feat_of(t, r, h);
+  const float* bias = packed + (size_t)kNumChunksRB * kChunkFloats;
+  const float* aux = packed + kRbAuxOff;
+  float at = bias[bias_index(T0, h, t, r)];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) at = fmaf(aux[kRbAuxTrans + c * 256 + f], lat_trans[b * 16 + c], at);
+  float al = bias[bias_index(R0, h, t, r)];
+#pragma unroll 8
+  for (int c = 0; c < 48; ++c) al = fmaf(aux[kRbAuxLight + c * 256 + f], lat_light[b * 48 + c], al);
+  out[(size_t)b * 512 + e] = at * (float)(1 << kF16WeightShift);
+  out[(size_t)b * 512 + 256 + e] = al;
+}
+
+//   out[q][e] = 2^8 (img[b][1][e] + sum_c W_R0[f][256 + c] enc_q[c]),   enc_q = [ray_unit(3) | PE(ray_unit): 3 + 8 c + 4 sc + l]
+// with ray_unit and its encoding formed exactly as the plain kernel stages them (same normalisation, same fp64 reduction + angle
+// doubling), reference layers/...light.py:104-110.  One workgroup: kRbRays rays, thread e = one output feature.
+constexpr int kRbRays = 32;
+__global__ __launch_bounds__(256) void rb_ray_bias_kernel(const float* __restrict__ packed, const float* __restrict__ ray, int R,
+                                                          int64_t n_rays, const float* __restrict__ img, float* __restrict__ out) {
+  __shared__ float enc[kRbRays][28];
+  const int e = threadIdx.x;
+  const int64_t q0 = (int64_t)blockIdx.x * kRbRays;
+  if (e < kRbRays * 3) {
+    // thread (ray i, coordinate c): the unit direction's component and its four octaves
+    const int i = e / 3, c = e - 3 * i;
+    const int64_t q = q0 + i < n_rays ? q0 + i : n_rays - 1;
+    const float d0 = ray[3 * q + 0], d1 = ray[3 * q + 1], d2 = ray[3 * q + 2];
+    float nrm = tp::add_rn(0.f, tp::mul_rn(d0, d0));
+    nrm = tp::add_rn(nrm, tp::mul_rn(d1, d1));
+    nrm = tp::add_rn(nrm, tp::mul_rn(d2, d2));
+    const float den = fmaxf(sqrtf(nrm), 1e-12f);
+    const float vu = tp::div_rn(c == 0 ? d0 : (c == 1 ? d1 : d2), den);
+    enc[i][c] = vu;
+    tp::SinCos64 a = tp::sincos_f64(tp::mul_rn(vu, 3.14159274101257324f));
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+      enc[i][3 + 8 * c + l] = (float)a.s;
+      enc[i][3 + 8 * c + 4 + l] = (float)a.c;
+      if (l < 3) tp::sincos_double(a);
+    }
+  }
+  const int h = e >> 7, t = (e >> 4) & 7, r = e & 15, f = feat_of(t, r, h);
+  const float* aux = packed + kRbAuxOff + kRbAuxView;
+  float w[27];
+#pragma unroll
+  for (int c = 0; c < 27; ++c) w[c] = aux[c * 256 + f];
+  __syncthreads();
+  for (int i = 0; i < kRbRays; ++i) {
+    const int64_t q = q0 + i;
+    if (q >= n_rays) break;
+    float a = img[(size_t)(q / R) * 512 + 256 + e];
+#pragma unroll
+    for (int c = 0; c < 27; ++c) a = fmaf(w[c], enc[i][c], a);
+    out[(size_t)q * 256 + e] = a * (float)(1 << kF16WeightShift);
+  }
 }
 
 // =====================================================================================================================
@@ -1189,6 +1290,7 @@ __device__ __forceinline__ AsmCtx dg_ctx_now(const float* packed_t) {
   c.stream_hi = (unsigned)(sw >> 32);
   c.bias0 = 0;
   c.stage0 = lds0 + (unsigned)kDgStageOff * 4u + (unsigned)tid * 16u;
+  c.nch = kNumChunksT;
   return c;
 }
 #define TP_DG_INPUTS(m, isc, r)                                                                                        \
@@ -1344,6 +1446,8 @@ int tp_launch_mlp_dgrad_f16x3(const tp_mlp_bwd_args* a, float* dz, unsigned int*
   return tp::check_launch("tp_mlp_bwd(dgrad f16x3)");
 }
 
+extern "C" size_t tp_mlp_ray_bias_bytes(int B, int R) { return ((size_t)B * 512 + (size_t)B * R * 256) * sizeof(float); }
+
 // launched by tp_mlp_fwd (mlp_fwd.hip) when args->precision == TP_MLP_F16X3
 int tp_launch_mlp_fwd_f16x3(const tp_mlp_fwd_args* a, int grid, hipStream_t stream) {
   Params P;
@@ -1354,13 +1458,29 @@ int tp_launch_mlp_fwd_f16x3(const tp_mlp_fwd_args* a, int grid, hipStream_t stre
   P.n_samples = (int64_t)a->B * a->R * a->N;
   P.n_tiles = (P.n_samples + 127) / 128;
   P.rgb = a->rgb; P.density = a->density; P.uncert = a->uncert; P.saved = a->saved; P.workspace = (float*)a->workspace;
-  P.status = a->status; P.act_max = a->act_max;
+  P.status = a->status; P.act_max = a->act_max; P.ray_bias = a->ray_bias;
   static unsigned long long attr_devices = 0;
   if (tp::first_use_on_device(attr_devices)) {
     hipError_t e = hipFuncSetAttribute((const void*)mlp_fwd_f16x3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
     if (e == hipSuccess)
       e = hipFuncSetAttribute((const void*)mlp_fwd_f16x3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void*)mlp_fwd_f16x3_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
     if (e != hipSuccess) { tp::set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+  }
+  if (a->ray_bias != nullptr) {
+    // the ray-bias stream (TP_PACK_RAYBIAS): only the configuration it is laid out for -- a stream packed that way cannot run the
+    // plain kernels, so a call outside it is an error, not a fallback
+    TP_REQUIRE(a->saved == nullptr && a->center != nullptr && a->N % 128 == 0,
+               "tp_mlp_fwd: ray_bias needs input form A, no activation record and N % 128 == 0");
+    const int64_t n_rays = (int64_t)a->B * a->R;
+    float* img = a->ray_bias;
+    float* per_ray = a->ray_bias + (size_t)a->B * 512;
+    hipLaunchKernelGGL(rb_image_bias_kernel, dim3(a->B), dim3(256), 0, stream, P.packed, a->lat_trans, a->lat_light, img);
+    hipLaunchKernelGGL(rb_ray_bias_kernel, dim3((unsigned)((n_rays + kRbRays - 1) / kRbRays)), dim3(256), 0, stream, P.packed, a->ray,
+                       a->R, n_rays, (const float*)img, per_ray);
+    hipLaunchKernelGGL((mlp_fwd_f16x3_kernel<false, true>), dim3(grid), dim3(kThreads), kLdsBytes, stream, P);
+    return tp::check_launch("tp_mlp_fwd(f16x3, ray bias)");
   }
   if (P.saved != nullptr)
     hipLaunchKernelGGL(mlp_fwd_f16x3_kernel<true>, dim3(grid), dim3(kThreads), kLdsBytes, stream, P);

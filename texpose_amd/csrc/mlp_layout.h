@@ -43,7 +43,7 @@ enum { L0 = 0, L1, L2, L3, L4, L5, L6, L7, T0, T1, T2, R0, R1, R2 };
 // weight-matrix ids
 enum { W_FEAT0 = 0, W_RGB0 = 8, W_TRANS0 = 12 };
 
-enum ChunkKind { CK_GEN = 0, CK_ENC = 1, CK_X8 = 2, CK_X40 = 3, CK_HEAD = 4 };
+enum ChunkKind { CK_GEN = 0, CK_ENC = 1, CK_X8 = 2, CK_X40 = 3, CK_HEAD = 4, CK_RBX = 5 };
 
 struct ChunkDesc {
   int kind;     // ChunkKind
@@ -91,6 +91,30 @@ TP_HD ChunkDesc chunk_desc(int c) {
   if (c < 98) return {CK_X40, W_RGB0 + 0, c - 95, 0, 256, 334};
   if (c < 114) { int l = 1 + (c - 98) / 8; return {CK_GEN, W_RGB0 + l, (c - 98) % 8, 0, 0, 256}; }
   return {CK_HEAD, W_RGB0 + 3, 3, 0, 0, 256};
+}
+
+// ---- "ray-bias" variant of the f16x3 forward stream (evaluation renders whose 128-sample tiles lie inside one ray: N % 128 == 0).
+// The inputs of mlp_rgb.0 that are constant along a ray -- [ray_unit | PE(ray_unit)] (27 columns) and the light code (48) -- and the
+// transient code of mlp_trans.0 (16 columns, constant per image) do not go through the matrix cores as 80 + 16 "extra" input columns
+// of every sample: their products with the weights are added to the layer's bias ONCE per ray / image by a small pre-kernel
+// (mlp_fwd_f16x3.hip, rb_*_kernel) and the tile seeds its accumulators with that per-ray bias.  What is left of the extras of R0 is
+// x (3 columns), which the tile already staged for L0 / L4: k-step 3 of the encoding stage holds [PE slots 48..59 | x0 x1 x2 | 0], and
+// the one remaining extra chunk (CK_RBX) multiplies it with zeros for the 12 encoding slots and mlp_rgb.0 columns 283..285 for x.
+// Stream: the 115 chunks without the CK_X8 chunk (69) and with the three CK_X40 chunks (95..97) replaced by one CK_RBX chunk = 112
+// chunks, then the bias block, then (in the room of the three chunks saved) the transposed fp32 weight columns the pre-kernel reads:
+//   aux + 0      [27][256]  mlp_rgb.0 columns 256..282   (view)       aux = packed + kNumChunksRB * kChunkFloats + kBiasFloats
+//   aux + 6912   [48][256]  mlp_rgb.0 columns 286..333   (light)
+//   aux + 19200  [16][256]  mlp_trans.0 columns 256..271 (transient)
+constexpr int kNumChunksRB = 112;
+constexpr int kFirstHeadChunkRB = kFirstHeadChunk;
+constexpr int64_t kRbAuxOff = (int64_t)kNumChunksRB * kChunkFloats + kBiasFloats;
+constexpr int kRbAuxView = 0, kRbAuxLight = 27 * 256, kRbAuxTrans = (27 + 48) * 256, kRbAuxFloats = (27 + 48 + 16) * 256;
+static_assert(kRbAuxOff + kRbAuxFloats <= kPackedFloats, "the ray-bias stream and its aux block fit the standard packed buffer");
+TP_HD ChunkDesc chunk_desc_rb(int c) {
+  if (c < 69) return chunk_desc(c);
+  if (c < 94) return chunk_desc(c + 1);
+  if (c == 94) return {CK_RBX, W_RGB0 + 0, 0, 0, 256, 334};
+  return chunk_desc(c + 3);
 }
 
 // Source element of packed float `idx` (0..8191) of chunk c: returns (row, col) of the weight matrix
@@ -230,6 +254,7 @@ TP_HD void chunk16_src(const ChunkDesc& d, int idx, int& part, int& row, int& co
   if (d.kind == CK_GEN) k = acc_feat16(d.sub, s, h, j);
   else if (d.kind == CK_ENC) k = enc_slot_col((d.sub * 2 + s) * 16 + 8 * h + j);
   else if (d.kind == CK_X8) k = s == 0 ? x8_slot_col(8 * h + j) : -1;
+  else if (d.kind == CK_RBX) k = (s == 0 && h == 1 && j >= 4 && j <= 6) ? 27 + (j - 4) : -1;   // slots 60..62 of the encoding stage = x
   else k = x40_slot_col((d.sub * 2 + s) * 16 + 8 * h + j);
   if (k < 0) return;
   row = d.row_off + 32 * t + i;

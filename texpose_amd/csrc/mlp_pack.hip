@@ -25,12 +25,12 @@ __global__ void pack_kernel(W w, int chunk0, int chunk1, float* __restrict__ out
 }
 
 // f16x3 stream (mlp_layout.h): hi = fp16(W * 2^shift), lo = fp16(W * 2^shift - hi)
-__global__ void pack16_kernel(W w, int chunk0, int chunk1, _Float16* __restrict__ out) {
+__global__ void pack16_kernel(W w, int chunk0, int chunk1, _Float16* __restrict__ out, int rb) {
   const int64_t n = (int64_t)(chunk1 - chunk0) * kChunkHalves;
   const float scale = (float)(1 << kF16WeightShift);
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
     const int c = chunk0 + (int)(e / kChunkHalves), idx = (int)(e % kChunkHalves);
-    const ChunkDesc d = chunk_desc(c);
+    const ChunkDesc d = rb ? chunk_desc_rb(c) : chunk_desc(c);
     int part, row, col;
     chunk16_src(d, idx, part, row, col);
     float v = row < 0 ? 0.0f : w.w[d.mat][(int64_t)row * d.in_dim + col] * scale;
@@ -39,8 +39,19 @@ __global__ void pack16_kernel(W w, int chunk0, int chunk1, _Float16* __restrict_
   }
 }
 
-__global__ void pack_bias_kernel(W w, int wide0, int wide1, float* __restrict__ out) {
-  float* bias = out + (int64_t)kNumChunks * kChunkFloats;
+// ray-bias stream: the transposed fp32 columns of mlp_rgb.0 / mlp_trans.0 that the per-ray bias pre-kernel contracts (mlp_layout.h)
+__global__ void pack_rb_aux_kernel(W w, float* __restrict__ out) {
+  float* aux = out + kRbAuxOff;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= kRbAuxFloats) return;
+  const int c = e >> 8, f = e & 255;
+  if (c < 27) aux[e] = w.w[W_RGB0][(int64_t)f * 334 + 256 + c];
+  else if (c < 75) aux[e] = w.w[W_RGB0][(int64_t)f * 334 + 286 + (c - 27)];
+  else aux[e] = w.w[W_TRANS0][(int64_t)f * 272 + 256 + (c - 75)];
+}
+
+__global__ void pack_bias_kernel(W w, int wide0, int wide1, float* __restrict__ out, int nch) {
+  float* bias = out + (int64_t)nch * kChunkFloats;
   const int n = (wide1 - wide0) * 256;
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e < n) {
@@ -153,7 +164,9 @@ extern "C" int tp_mlp_pack_heads_f16x3(const tp_mlp_weights* p, void* packed, vo
 
 extern "C" int tp_mlp_pack(const tp_mlp_weights* p, int parts, void* packed, tp_stream_t stream) {
   TP_REQUIRE(p && packed, "null pointer");
-  TP_REQUIRE((parts & ~(TP_PACK_ALL | TP_PACK_F16X3)) == 0 && (parts & TP_PACK_ALL) != 0, "bad parts mask");
+  TP_REQUIRE((parts & ~(TP_PACK_ALL | TP_PACK_F16X3 | TP_PACK_RAYBIAS)) == 0 && (parts & TP_PACK_ALL) != 0, "bad parts mask");
+  const int rb = (parts & TP_PACK_RAYBIAS) ? 1 : 0;
+  TP_REQUIRE(!rb || (parts & TP_PACK_F16X3), "TP_PACK_RAYBIAS is a variant of the TP_PACK_F16X3 stream");
   W w;
   for (int i = 0; i < 8; ++i) { w.w[W_FEAT0 + i] = p->feat_w[i]; w.b[W_FEAT0 + i] = p->feat_b[i]; }
   for (int i = 0; i < 4; ++i) {
@@ -165,13 +178,16 @@ extern "C" int tp_mlp_pack(const tp_mlp_weights* p, int parts, void* packed, tp_
     const bool is_trunk = i < 8;
     if ((is_trunk && trunk) || (!is_trunk && heads)) TP_REQUIRE(w.w[i] && w.b[i], "null weight pointer");
   }
-  const int c0 = trunk ? 0 : kFirstHeadChunk, c1 = heads ? kNumChunks : kFirstHeadChunk;
+  const int nch = rb ? kNumChunksRB : kNumChunks;
+  const int c0 = trunk ? 0 : kFirstHeadChunk, c1 = heads ? nch : kFirstHeadChunk;
   const int w0 = trunk ? 0 : kFirstHeadWide, w1 = heads ? kNumWide : kFirstHeadWide;
   if (parts & TP_PACK_F16X3)
-    hipLaunchKernelGGL(pack16_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, w, c0, c1, (_Float16*)packed);
+    hipLaunchKernelGGL(pack16_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, w, c0, c1, (_Float16*)packed, rb);
   else
     hipLaunchKernelGGL(pack_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, w, c0, c1, (float*)packed);
   hipLaunchKernelGGL(pack_bias_kernel, dim3(((w1 - w0) * 256 + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, w0,
-                     w1, (float*)packed);
+                     w1, (float*)packed, nch);
+  if (rb && heads)
+    hipLaunchKernelGGL(pack_rb_aux_kernel, dim3((kRbAuxFloats + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, (float*)packed);
   return tp::check_launch("tp_mlp_pack");
 }

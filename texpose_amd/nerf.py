@@ -105,22 +105,25 @@ class NeRF(torch.nn.Module):
         """(name, parameter) of the trainable heads, in a fixed order shared by forward and backward."""
         return [(k, p) for k, p in self.named_parameters() if k.startswith(("mlp_rgb", "mlp_trans"))]
 
-    def packed_weights(self, precision: str = "fp32", for_training: bool = False) -> torch.Tensor:
+    def packed_weights(self, precision: str = "fp32", for_training: bool = False, ray_bias: bool = False) -> torch.Tensor:
         """MFMA-ordered weight stream for ``precision``, re-packed lazily: trunk once (frozen), heads when an
         optimiser step or a load_state_dict bumped a parameter version.  ``for_training`` (a recording f16x3 forward whose
-        backward will run): the same launch also writes the transposed head image of that backward."""
+        backward will run): the same launch also writes the transposed head image of that backward.  ``ray_bias``: the f16x3 stream
+        variant of ops.mlp_forward(..., ray_bias=True), kept beside the plain one."""
+        assert not (ray_bias and (for_training or precision != "f16x3"))
+        key = precision + ("+ray_bias" if ray_bias else "")
         st = self._state()
         vt = tuple((p.data_ptr(), p._version) for k, p in st.items() if k.startswith("mlp_feat"))
         vh = tuple((p.data_ptr(), p._version) for k, p in st.items() if not k.startswith("mlp_feat"))
         dev = next(self.parameters()).device
-        buf = self._packed.get(precision)
+        buf = self._packed.get(key)
         if buf is None or buf.device != dev:
-            buf = self._packed[precision] = torch.empty(ops.packed_bytes() // 4, device=dev)
-            self._versions[precision] = [None, None]
-        ver = self._versions[precision]
+            buf = self._packed[key] = torch.empty(ops.packed_bytes() // 4, device=dev)
+            self._versions[key] = [None, None]
+        ver = self._versions[key]
         with torch.no_grad():
             if ver[0] != vt:
-                ops.pack_weights(st, packed=buf, parts=ops.PACK_TRUNK, precision=precision)
+                ops.pack_weights(st, packed=buf, parts=ops.PACK_TRUNK, precision=precision, ray_bias=ray_bias)
                 ver[0] = vt
             if ver[1] != vh:
                 if precision == "f16x3" and for_training and os.environ.get("TP_NO_PACK_MERGE") != "1":
@@ -130,7 +133,7 @@ class NeRF(torch.nn.Module):
                     ops.pack_heads_train(st, buf, self._packed_t)
                     self._packed_t_ver = vh
                 else:
-                    ops.pack_weights(st, packed=buf, parts=ops.PACK_HEADS, precision=precision)
+                    ops.pack_weights(st, packed=buf, parts=ops.PACK_HEADS, precision=precision, ray_bias=ray_bias)
                 ver[1] = vh
         return buf
 

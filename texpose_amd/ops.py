@@ -24,7 +24,7 @@ Tensor = torch.Tensor
 PIX_COORDS, PIX_INDEX = 0, 1
 BOUNDS_MAP, BOUNDS_AABB, BOUNDS_NONE = 0, 1, 2
 JITTER_MID, JITTER_GIVEN, JITTER_PHILOX = 0, 1, 2
-PACK_TRUNK, PACK_HEADS, PACK_ALL, PACK_F16X3 = 1, 2, 3, 4
+PACK_TRUNK, PACK_HEADS, PACK_ALL, PACK_F16X3, PACK_RAYBIAS = 1, 2, 3, 4, 8
 MLP_FP32, MLP_F16X3 = 0, 1
 PRECISIONS = {"fp32": MLP_FP32, "f16x3": MLP_F16X3}
 
@@ -192,9 +192,10 @@ def packed_bytes() -> int:
 
 @_on_tensor_device
 def pack_weights(state: Dict[str, Tensor], packed: Optional[Tensor] = None, parts: int = PACK_ALL,
-                 prefix: str = "", precision: str = "fp32") -> Tensor:
+                 prefix: str = "", precision: str = "fp32", ray_bias: bool = False) -> Tensor:
     """state: reference state-dict style mapping (``mlp_feat.0.weight`` ...) of CUDA tensors.
-    precision 'f16x3' builds the split-fp16 stream for the fast forward (same size)."""
+    precision 'f16x3' builds the split-fp16 stream for the fast forward (same size); ``ray_bias``: its variant for
+    mlp_forward(..., ray_bias=True) (tp_mlp_fwd_args.ray_bias)."""
     lib = _lib.load()
     w = MlpWeights()
     keep = []
@@ -213,7 +214,7 @@ def pack_weights(state: Dict[str, Tensor], packed: Optional[Tensor] = None, part
     dev = keep[0].device
     if packed is None:
         packed = torch.empty(packed_bytes() // 4, device=dev)
-    flags = parts | (PACK_F16X3 if PRECISIONS[precision] == MLP_F16X3 else 0)
+    flags = parts | (PACK_F16X3 if PRECISIONS[precision] == MLP_F16X3 else 0) | (PACK_RAYBIAS if ray_bias else 0)
     check(lib.tp_mlp_pack(C.byref(w), flags, packed.data_ptr(), _stream()), "tp_mlp_pack")
     return packed
 
@@ -341,9 +342,9 @@ def poll_mlp_status(device, raise_on_flag: bool = True) -> bool:
 @_on_tensor_device
 def mlp_forward(packed: Tensor, lat_trans: Tensor, lat_light: Tensor, *, center: Optional[Tensor] = None,
                 ray: Optional[Tensor] = None, depth: Optional[Tensor] = None, points: Optional[Tensor] = None,
-                ray_unit: Optional[Tensor] = None, save: bool = False, precision: str = "fp32"):
+                ray_unit: Optional[Tensor] = None, save: bool = False, precision: str = "fp32", ray_bias: bool = False):
     """Returns rgb [B,R,N,3,2], density [B,R,N,2], uncert [B,R,N,1] (+ saved activations if save).
-    ``packed`` must have been built with the same ``precision``."""
+    ``packed`` must have been built with the same ``precision`` (and the same ``ray_bias``, see `ray_bias_applies`)."""
     lib = _lib.load()
     a = MlpFwdArgs()
     if center is not None:
@@ -376,8 +377,21 @@ def mlp_forward(packed: Tensor, lat_trans: Tensor, lat_light: Tensor, *, center:
     if a.precision == MLP_F16X3:
         a.status = mlp_status(dev).data_ptr()
         a.act_max = _act_max_ptr(dev)
+    rb = None
+    if ray_bias:
+        assert ray_bias_applies(precision, N, save, center is not None), "mlp_forward: ray_bias outside the configuration it covers"
+        rb = torch.empty(int(lib.tp_mlp_ray_bias_bytes(B, R)) // 4, device=dev)
+        a.ray_bias = rb.data_ptr()
     check(lib.tp_mlp_fwd(C.byref(a), _stream()), "tp_mlp_fwd")
     return (rgb, density, uncert, saved) if save else (rgb, density, uncert)
+
+
+def ray_bias_applies(precision: str, n_samples_per_ray: int, save: bool, center_form: bool) -> bool:
+    """The f16x3 forward can take the ray-constant inputs of mlp_rgb.0 / mlp_trans.0 as a per-ray bias (tp_mlp_fwd_args.ray_bias)
+    when no activation record is written, rays come as (center, ray, depth) and every 128-sample tile lies inside one ray.
+    TP_NO_RAY_BIAS=1 switches it off (same-box A/B)."""
+    return (precision == "f16x3" and not save and center_form and n_samples_per_ray % 128 == 0
+            and os.environ.get("TP_NO_RAY_BIAS") != "1")
 
 
 _bwd_scratch: Dict[Tuple[int, int], Dict[str, Tensor]] = {}
