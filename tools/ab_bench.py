@@ -7,8 +7,13 @@ import re
 import subprocess
 import sys
 
-libs = [a for a in sys.argv[1:] if not a.startswith("--")]
-rounds = int(sys.argv[sys.argv.index("--rounds") + 1]) if "--rounds" in sys.argv else 2
+rounds = 2
+argv = sys.argv[1:]
+if "--rounds" in argv:
+    i = argv.index("--rounds")
+    rounds = int(argv[i + 1])
+    del argv[i:i + 2]
+libs = [a for a in argv if not a.startswith("--")]
 here = os.path.dirname(os.path.abspath(__file__))
 res = {l: [] for l in libs}
 for r in range(rounds):

@@ -18,10 +18,15 @@ python3 tools/launch_sequence.py gpurun_out/$T/gan4 > gpurun_out/$T/launch_seque
 for i in 1 2; do python3 tools/train_bench.py 4 1 200 1 f16x3 2>&1 | tail -1; python3 tools/train_bench.py 4 0 200 1 f16x3 2>&1 | tail -1; python3 tools/train_bench.py 32 0 60 1 f16x3 2>&1 | tail -1; done > gpurun_out/$T/train_lines.txt
 timeout 600 python bench.py --config c5 > gpurun_out/$T/c5.json 2> gpurun_out/$T/c5.err
 # the GAN loop with one change switched off at a time (same box, alternating with the product configuration)
-( for e in TP_X=1 TP_FOUR_GRAPHS=0 TP_X=1 TP_NO_DISC_TAIL=1 TP_X=1 TP_DISC_AUTOGRAD=1 TP_X=1 TP_NO_FEAT_BRANCH=1 TP_X=1 GPU_MAX_HW_QUEUES=2 TP_X=1; do
+( for e in TP_X=1 TP_LINEAR_GRAPHS=0 TP_X=1 TP_FOUR_GRAPHS=0 TP_X=1 TP_NO_DISC_TAIL=1 TP_X=1 TP_NO_CONV_INORM=1 TP_X=1 TP_DISC_AUTOGRAD=1 TP_X=1 TP_PRE_STREAMS=1 TP_PRE_STREAMS=2 "TP_PRE_STREAMS=2 TP_NO_QUEUE_PROBE=1" "TP_PRE_STREAMS=2 TP_LINEAR_GRAPHS=0" GPU_MAX_HW_QUEUES=2 TP_X=1; do
     echo "$e $(env $e python3 tools/train_bench.py 4 1 200 1 f16x3 2>&1 | tail -1 | cut -c1-75)"; done ) > gpurun_out/$T/gan_ablations.txt
 python3 tools/tail_bench.py 4 > gpurun_out/$T/tail_bench.txt 2>&1
 python3 tools/host_time.py > gpurun_out/$T/host_time.txt 2>&1
+python3 tools/linear_timeline.py 50 > gpurun_out/$T/linear_timeline.txt 2>&1
+( for k in 0 1 2 3; do python3 tools/queue_probe.py $k 8; done ) > gpurun_out/$T/queue_probe.txt 2>&1
+# the evaluation render with / without the ray-bias variant of the f16x3 kernel, alternating on this box
+( for e in TP_X=1 TP_NO_RAY_BIAS=1 TP_X=1 TP_NO_RAY_BIAS=1; do
+    echo "$e $(env $e python3 bench.py --no-train --no-cpu-baseline --steps 6 --warmup 2 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d['roofline']['kernel_ms'], d['roofline']['frac'])")"; done ) > gpurun_out/$T/ray_bias_ab.txt 2>&1
 python3 tools/kstats.py gpurun_out/$T/train32 wgrad dgrad mlp_fwd finalize
 rm -rf gpurun_out/$T/train32 gpurun_out/$T/gan4
 cat gpurun_out/$T/train_lines.txt | cut -c1-100

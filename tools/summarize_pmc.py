@@ -19,11 +19,20 @@ for d in sorted(glob.glob(os.path.join(out, "*"))):
         rows = list(csv.DictReader(open(f)))
         if not rows:
             continue
-        disp = max(int(r["Dispatch_Id"]) for r in rows)
-        for r in rows:
+        main = [r for r in rows if "mlp_fwd" in r.get("Kernel_Name", "mlp_fwd")]
+        disp = max(int(r["Dispatch_Id"]) for r in main)
+        for r in main:
             if int(r["Dispatch_Id"]) == disp:
                 cnt[r["Counter_Name"]] = cnt.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
                 if "Start_Timestamp" in r and "End_Timestamp" in r:
                     cnt["kernel_ms"] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
+        # the ray-bias pre-kernels of the same image (rb_image_bias / rb_ray_bias: the last dispatch of each before the main kernel's)
+        for kname in sorted({r["Kernel_Name"] for r in rows if "rb_" in r.get("Kernel_Name", "")}):
+            last = max(int(r["Dispatch_Id"]) for r in rows if r["Kernel_Name"] == kname and int(r["Dispatch_Id"]) < disp)
+            short = "pre." + ("rb_image_bias" if "image" in kname else "rb_ray_bias")
+            for r in rows:
+                if int(r["Dispatch_Id"]) == last:
+                    key = short + "." + r["Counter_Name"]
+                    cnt[key] = cnt.get(key, 0.0) + float(r["Counter_Value"])
     res[name] = cnt
 print(json.dumps(res, indent=1))
