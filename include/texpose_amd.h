@@ -26,7 +26,7 @@ extern "C" {
 
 typedef void* tp_stream_t; /* hipStream_t */
 
-#define TP_ABI_VERSION 7
+#define TP_ABI_VERSION 8
 
 int tp_abi_version(void);
 const char* tp_last_error(void);

@@ -5,7 +5,7 @@ import collections, csv, glob, re, sys
 
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
-it = [i for i, r in enumerate(rows) if "mlp_fwd" in r["Kernel_Name"] and "<true>" in r["Kernel_Name"]]   # recording forward
+it = [i for i, r in enumerate(rows) if "mlp_fwd" in r["Kernel_Name"] and "<true" in r["Kernel_Name"]]   # recording forward
 seg = rows[it[-3]:it[-2]]
 busy = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in seg) / 1e6
 print(len(seg), "launches in one iteration; GPU busy %.3f ms; wall %.3f ms" %

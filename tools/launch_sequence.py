@@ -4,7 +4,7 @@ import csv, glob, re, sys
 
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
-it = [i for i, r in enumerate(rows) if "mlp_fwd" in r["Kernel_Name"] and "<true>" in r["Kernel_Name"]]
+it = [i for i, r in enumerate(rows) if "mlp_fwd" in r["Kernel_Name"] and "<true" in r["Kernel_Name"]]
 seg = rows[it[-3]:it[-2]]
 t0 = int(seg[0]["Start_Timestamp"])
 for r in seg:
