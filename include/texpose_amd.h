@@ -250,8 +250,10 @@ typedef struct tp_render_eval_args {
   float* out_ray;          /* [B*R,14] out, layout of tp_composite_args.out_ray */
   float* alpha_static;     /* [B*R,N] out or NULL */
   float* alpha_transient;  /* [B*R,N] out or NULL */
+  int packed_ray_bias;     /* non-zero: `packed` is the TP_PACK_F16X3 | TP_PACK_RAYBIAS stream (precision TP_MLP_F16X3, N % 128 == 0) and
+                              the MLP runs in its ray-bias form (tp_mlp_fwd_args.ray_bias; the scratch is part of `workspace`) */
 } tp_render_eval_args;
-size_t tp_render_eval_workspace_bytes(int B, int R, int N);
+size_t tp_render_eval_workspace_bytes(int B, int R, int N);   /* (includes the ray-bias scratch) */
 int tp_render_eval(const tp_render_eval_args* args, tp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------

@@ -662,6 +662,19 @@ def test_render_eval_one_call_equals_mirror(ops):
             assert torch.equal(out[..., lo:hi], ref[name]), (prec, name)
         assert torch.equal(a_s, ref["alpha_static"]) and torch.equal(a_t, ref["alpha_transient"])
     ops.check_mlp_status(dev())
+    # N % 128 == 0: the mirror takes the ray-bias form of the f16x3 kernel (ops.ray_bias_applies); the one-call entry point with
+    # `packed_ray_bias` launches the same kernels on the same stream variant
+    g, opt = _graph(params, H=H, W=W, N=128)
+    opt.nerf.sample_stratified = False
+    g.nerf.precision = "f16x3"
+    with torch.no_grad():
+        ref = g.render(opt, cu(sc["pose"]), intr=cu(sc["intr"]), ray_idx=cu(idx),
+                       depth_range=(cu(sc["z_near"])[:, :, None], cu(sc["z_far"])[:, :, None]), sample_idx=None, mode="val")
+        out = ops.render_eval(g.nerf.packed_weights("f16x3", ray_bias=True), cu(sc["intr"]), cu(sc["pose"]), cu(idx), cu(sc["z_near"]),
+                              cu(sc["z_far"]), lat_t, lat_l, H=H, W=W, n_samples=128, precision="f16x3", ray_bias=True)
+    for name, lo, hi in ops.COMPOSITE_RAY_FIELDS:
+        assert torch.equal(out[..., lo:hi], ref[name]), ("ray bias", name)
+    ops.check_mlp_status(dev())
 
 
 def test_render_by_slices_g9(ops):

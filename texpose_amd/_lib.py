@@ -169,7 +169,7 @@ class StepCopy(C.Structure):
 class RenderEvalArgs(C.Structure):
     _fields_ = [("raygen", RaygenArgs), ("packed", vp), ("lat_trans", vp), ("lat_light", vp), ("precision", C.c_int),
                 ("status", vp), ("min_uncert", C.c_float), ("workspace", vp), ("out_ray", vp), ("alpha_static", vp),
-                ("alpha_transient", vp)]
+                ("alpha_transient", vp), ("packed_ray_bias", C.c_int)]
 
 
 class TexposeLibraryError(RuntimeError):

@@ -6,7 +6,7 @@
 
 namespace {
 size_t align256(size_t x) { return (x + 255) / 256 * 256; }
-struct Layout { size_t center, ray, depth, rgb, density, uncert, mlp_ws, total; };
+struct Layout { size_t center, ray, depth, rgb, density, uncert, mlp_ws, ray_bias, total; };
 Layout layout(int64_t B, int64_t R, int64_t N) {
   Layout l;
   size_t o = 0;
@@ -17,6 +17,7 @@ Layout layout(int64_t B, int64_t R, int64_t N) {
   l.density = o; o += align256((size_t)B * R * N * 2 * 4);
   l.uncert = o; o += align256((size_t)B * R * N * 4);
   l.mlp_ws = o; o += align256(tp_mlp_workspace_bytes(B * R * N));
+  l.ray_bias = o; o += align256(tp_mlp_ray_bias_bytes((int)B, (int)R));
   l.total = o;
   return l;
 }
@@ -41,6 +42,10 @@ extern "C" int tp_render_eval(const tp_render_eval_args* a, tp_stream_t stream) 
   m.B = B; m.R = R; m.N = N;
   m.rgb = (float*)(ws + l.rgb); m.density = (float*)(ws + l.density); m.uncert = (float*)(ws + l.uncert);
   m.saved = nullptr; m.workspace = ws + l.mlp_ws; m.precision = a->precision; m.status = a->status;
+  if (a->packed_ray_bias) {
+    TP_REQUIRE(a->precision == TP_MLP_F16X3 && N % 128 == 0, "tp_render_eval: packed_ray_bias needs TP_MLP_F16X3 and N % 128 == 0");
+    m.ray_bias = (float*)(ws + l.ray_bias);
+  }
   if (int rc = tp_mlp_fwd(&m, stream)) return rc;
   tp_composite_args c = {};
   c.ray = rg.ray; c.rgb = m.rgb; c.density = m.density; c.depth = rg.depth; c.uncert = m.uncert;

@@ -797,8 +797,9 @@ def rmsprop_step(params, grads, square_avgs, lr, alpha: float = 0.99, eps: float
 @_on_tensor_device
 def render_eval(packed: Tensor, intr: Tensor, pose: Tensor, ray_idx: Tensor, z_near: Tensor, z_far: Tensor, lat_trans: Tensor,
                 lat_light: Tensor, *, H: int, W: int, n_samples: int, precision: str = "f16x3", min_uncert: float = 0.05,
-                rand: Optional[Tensor] = None, with_alphas: bool = False):
+                rand: Optional[Tensor] = None, with_alphas: bool = False, ray_bias: bool = False):
     """The C ABI's one-call evaluation render (tp_render_eval: ray-gen + MLP + composite, intermediates in one workspace).
+    ``ray_bias``: ``packed`` is the ray-bias stream (pack_weights(..., ray_bias=True); f16x3, n_samples % 128 == 0).
     Returns out_ray [B,R,14] (COMPOSITE_RAY_FIELDS) and, if asked, (alpha_static, alpha_transient) [B,R,N].  The Python
     mirror (Graph.render) launches the same three kernels itself; this entry point exists for non-Python hosts."""
     lib = _lib.load()
@@ -820,6 +821,7 @@ def render_eval(packed: Tensor, intr: Tensor, pose: Tensor, ray_idx: Tensor, z_n
         rg.jitter_mode = JITTER_MID
     a.packed, a.lat_trans, a.lat_light = packed.data_ptr(), lat_trans.data_ptr(), lat_light.data_ptr()
     a.precision, a.min_uncert = PRECISIONS[precision], float(min_uncert)
+    a.packed_ray_bias = 1 if ray_bias else 0
     a.status = mlp_status(dev).data_ptr() if precision == "f16x3" else None
     ws = torch.empty(int(lib.tp_render_eval_workspace_bytes(B, R, n_samples)) // 4 + 64, device=dev)
     out = torch.empty(B, R, 14, device=dev)
