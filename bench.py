@@ -685,8 +685,9 @@ def main():
         rb = precision == "f16x3" and ops.ray_bias_applies("f16x3", N_SAMPLES, False, True)
         if rb:
             # ray-bias variant: the 75 ray-constant input columns of mlp_rgb.0 and the 16 of mlp_trans.0 (23,296 of the 910,592 MACs
-            # per sample) are contracted once per ray in fp32 by the pre-kernels -- inside the event window -- not on the matrix cores
-            k = k * (1.0 - 23_296 / 910_592)
+            # per sample) are contracted once per ray in fp32 by the pre-kernels -- inside the event window --, and the three narrow
+            # output layers (9 rows x 256 = 2,304 MACs) run as fp32 dot products on the vector ALU: neither is on the matrix cores
+            k = k * (1.0 - (23_296 + 2_304) / 910_592)
         return {"kernel": "mlp_fwd_exact_asm_kernel" if precision == "fp32" else
                 ("mlp_fwd_f16x3_kernel<false, true> (+ rb_image_bias / rb_ray_bias pre-kernels, in the event window)" if rb else "mlp_fwd_f16x3_kernel"),
                 "bound": "mfma",

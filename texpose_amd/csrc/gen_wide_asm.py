@@ -489,6 +489,91 @@ def gen_head(src, rec=False):
     return L
 
 
+# ------------------------------------------------------------------------------------------------------ HEAD, fp32 VALU form
+def gen_head_valu(src, row_offs):
+    """Narrow output layer over relu(src set) as fp32 dot products on the vector ALU (ray-bias kernel only): out[row] =
+    sum_f relu(acc_f) W[row][f], no operand conversion, no dependent MFMA chain -- and no weight chunk: the 1 / 5 / 3 rows live in
+    LDS for the whole kernel (a table in the part of the input stage the ray-bias kernel does not use; mlp_fwd_f16x3.hip), so the
+    block stands OUTSIDE the ring protocol (no DMA piece, no publish, no chunk advance).  Inside the ring a 1.3-2.3 k-cycle block
+    waited at its publish point for the previous block's DMA pieces (an L2 -> LDS round trip is longer than it): 3.5 k cycles per
+    head, measured.
+    A lane holds 128 of its sample's 256 features (16 per tile; lane half h the other 128): per source tile 16 v_accvgpr_read +
+    16 v_max, then per row eight v_pk_fma_f32 against 16 weights (4 ds_read_b128 at %[hw] + row offset + 32 (4 t + k): the two
+    lane halves read the two 16-byte columns of a 32-byte unit, i.e. broadcast reads), two accumulator pairs per row.  Weight reads
+    run two row-steps ahead through three 16-register banks: v[208:223], v[232:247] and v[160:175] -- the fragment ring's registers,
+    which hold the first four pairs of the CURRENT chunk (fetched by the previous block's tail): they are read again from the
+    chunk's slot at the end (the slot stays valid until the ring has advanced twice), the next block's prologue waits for them.
+    Results: v[232 + row] = the row's sum over both lanes of a sample, scaled by 2^8 like the accumulators it was formed from."""
+    L = []
+    e = L.append
+    rows = len(row_offs)
+    e("s_waitcnt lgkmcnt(0)")
+    e("s_nop 7")                                     # (the source set may have been written by MFMAs just before the block)
+    e("s_nop 7")
+    VAL, WA = XB[0], VR + 2
+    pairs = [VB + 16 + 2 * i for i in range(8)] + [T, T + 2]
+    banks = [XB[1], HACC, VB]
+    e("v_mov_b32 v%d, %%[hw]" % WA)
+    for i in range(2 * rows):
+        e("v_mov_b32 v%d, 0" % pairs[i])
+        e("v_mov_b32 v%d, 0" % (pairs[i] + 1))
+    steps = [(t, row) for t in range(8) for row in range(rows)]
+
+    def wreads(si):
+        t, row = steps[si]
+        b = banks[si % 3]
+        return ["ds_read_b128 %s, v%d offset:%d" % (vr(b + 4 * k), WA, row_offs[row] + (4 * t + k) * 32) for k in range(4)]
+
+    for si in range(min(2, len(steps))):
+        for ins in wreads(si):
+            e(ins)
+    for t in range(8):
+        for r in range(16):
+            e("v_accvgpr_read_b32 v%d, a%d" % (VAL + r, src + 16 * t + r))
+        for r in range(16):
+            e("v_max_f32 v%d, 0, v%d" % (VAL + r, VAL + r))
+        for row in range(rows):
+            si = t * rows + row
+            later = min(len(steps) - 1, si + 1) - si
+            e("s_waitcnt lgkmcnt(%d)" % (4 * later))
+            b = banks[si % 3]
+            for k in range(8):
+                a = pairs[2 * row + (k & 1)]
+                e("v_pk_fma_f32 v[%d:%d], v[%d:%d], v[%d:%d], v[%d:%d]" % (a, a + 1, VAL + 2 * k, VAL + 2 * k + 1, b + 2 * k, b + 2 * k + 1, a, a + 1))
+            if si + 2 < len(steps):
+                for ins in wreads(si + 2):
+                    e(ins)
+    # sums over the two accumulator pairs, the register pair and the two lanes of a sample (v_permlane32_swap: X.hi <-> Y.lo)
+    for row in range(rows):
+        a0, a1 = pairs[2 * row], pairs[2 * row + 1]
+        e("v_pk_add_f32 v[%d:%d], v[%d:%d], v[%d:%d]" % (a0, a0 + 1, a0, a0 + 1, a1, a1 + 1))
+    for row in range(rows):
+        a0 = pairs[2 * row]
+        e("v_add_f32 v%d, v%d, v%d" % (a0, a0, a0 + 1))
+        e("v_mov_b32 v%d, v%d" % (a0 + 1, a0))
+    e("s_nop 1")
+    for row in range(rows):
+        a0 = pairs[2 * row]
+        e("v_permlane32_swap_b32 v%d, v%d" % (a0, a0 + 1))
+    e("s_nop 1")
+    for row in range(rows):
+        a0 = pairs[2 * row]
+        e("v_add_f32 v%d, v%d, v%d" % (HACC + row, a0, a0 + 1))
+    # the fragment ring again: pairs 0..3 of the current chunk, from its slot (byte offset buf << 15)
+    e("s_lshl_b32 %[t0], %[buf], 15")
+    e("v_add_u32 v%d, %%[t0], %%[lane16]" % (VR + 0))
+    for s_ in range(4):
+        refill(e, s_, s_, 16, 0, 1)
+    return L
+
+
+# byte offsets of the head rows in the LDS table, relative to the stage base (mlp_fwd_f16x3.hip: kHeadTab*): sigma | transient 0..4
+# | rgb 0, 1 fill k-step 4 of the input stage (8 KB at + 32 KB), rgb 2 sits in slot 6 of the save area (+ 40 KB + 6 KB)
+HEADTAB_SIGMA = [32768]
+HEADTAB_TRANS = [32768 + 1024 * (1 + r) for r in range(5)]
+HEADTAB_RGB = [32768 + 6144, 32768 + 7168, 40960 + 6144]
+
+
 # ------------------------------------------------------------------------------------------------------ INIT
 def gen_init(dst):
     """dst set = 128 floats at LDS address %[bias] (this lane half's bias block of the layer, already * 2^8): 32 LDS reads
@@ -687,6 +772,10 @@ def main():
         emit_macro(out, "TP_ASM_INIT_%s" % d, "seed set %s with the bias block" % d, gen_init(SET[d]))
         for t in range(8):
             emit_macro(out, "TP_ASM_READ_%s%d" % (d, t), "tile %d of set %s -> v[232:247]" % (t, d), gen_read_tile(SET[d], t))
+    emit_macro(out, "TP_ASM_HEADV_P1", "fp32 VALU head, 1 row, over relu(set P)", gen_head_valu(SET["P"], HEADTAB_SIGMA))
+    emit_macro(out, "TP_ASM_HEADV_P5", "fp32 VALU head, 5 rows, over relu(set P)", gen_head_valu(SET["P"], HEADTAB_TRANS))
+    emit_macro(out, "TP_ASM_HEADV_Q3", "fp32 VALU head, 3 rows, over relu(set Q)", gen_head_valu(SET["Q"], HEADTAB_RGB))
+    out.append("#define TP_HEADTAB_OFFSETS {%s}" % ", ".join(str(v) for v in HEADTAB_SIGMA + HEADTAB_TRANS + HEADTAB_RGB))
     emit_macro(out, "TP_ASM_STASH_Q", "set Q -> v[32:159]", gen_stash(SET["Q"]))
     emit_macro(out, "TP_ASM_RESTORE_P", "v[32:159] -> set P", gen_restore(SET["P"]))
     # data gradient: the 34-chunk transposed stream

@@ -515,6 +515,32 @@ __device__ __forceinline__ Head4 asm_head_rec(Pipe& p, Frag& f, Guard& amax, con
   return h;
 }
 
+// fp32 vector-ALU head of the ray-bias kernel (gen_head_valu): WHICH = 0 sigma (set P, 1 row), 1 transient (set P, 5 rows), 2 rgb
+// (set Q, 3 rows), weights from the LDS table (kernel start).  Outside the ring protocol: no chunk is consumed; the fragment ring's
+// registers are used as scratch and re-read from the current chunk's slot at the end.  Every lane gets every row's sum (still scaled
+// by 2^8)
+struct Head5 { float r0, r1, r2, r3, r4; };
+template <int WHICH>
+__device__ __forceinline__ Head5 asm_head_valu(const Pipe& p, Frag& f, const AsmCtx& c) {
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
+  const unsigned hw = c.stage0 - (unsigned)tid * 16u + (((unsigned)tid >> 5) & 1u) * 16u;   // stage base + 16 h
+  const int buf = __builtin_amdgcn_readfirstlane(p.buf);
+  int t0;
+  Head5 h;
+#define TP_HEADV(TXT)                                                                                                  \
+  asm volatile(TXT : TP_RING(f), [t0] "=&s"(t0), "=&{v232}"(h.r0), "=&{v233}"(h.r1), "=&{v234}"(h.r2), "=&{v235}"(h.r3), \
+                     "=&{v236}"(h.r4)                                                                                  \
+               : [hw] "v"(hw), [lane16] "v"(c.lane16), [buf] "s"(buf)                                                  \
+               : TP_ASM_CLOBBERS, "v231", "v237", "v238", "v239", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", \
+                 "memory", "scc")
+  if constexpr (WHICH == 0) TP_HEADV(TP_ASM_HEADV_P1);
+  else if constexpr (WHICH == 1) TP_HEADV(TP_ASM_HEADV_P5);
+  else TP_HEADV(TP_ASM_HEADV_Q3);
+#undef TP_HEADV
+  return h;
+}
+
 // seed set P (DST_P) or Q with the bias block of wide layer li (bias * 2^8 in LDS)
 template <bool DST_P>
 __device__ __forceinline__ void asm_init(const AsmCtx& c, int li) {
@@ -585,6 +611,14 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_f16x3_kernel(Params P) {
   // wide-layer biases are kept pre-scaled by 2^8 (exact): they seed the accumulators of the scaled products
   for (int i = tid; i < kBiasFloats; i += kThreads)
     bias_lds[i] = P.packed[(size_t)NCH * kChunkFloats + i] * (i < kHeadBiasOff ? (float)(1 << kF16WeightShift) : 1.0f);
+  if constexpr (RB) {
+    // the nine rows of the narrow output layers (fp32, lane-read order) into the parts of the input stage / save area this kernel
+    // does not use: k-step 4 of the stage and slot 6 of the save area (gen_wide_asm.py: HEADTAB_*)
+    constexpr int kHeadTabOff[kRbHeadRows] = TP_HEADTAB_OFFSETS;
+    const float* tab = P.packed + kRbAuxOff + kRbAuxHeads;
+    for (int i = tid; i < kRbHeadRows * 256; i += kThreads)
+      *reinterpret_cast<float*>(reinterpret_cast<char*>(st) + kHeadTabOff[i >> 8] + (i & 255) * 4) = tab[i];
+  }
   dma_chunk(p, 0, 0);
   dma_chunk(p, 1, 1);
   __syncthreads();
@@ -663,6 +697,13 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_f16x3_kernel(Params P) {
         else h4 = asm_head_rec<true>(p, frag, amax, TP_CTX, rec_ctx_now(P.saved, tile, SV_T2));
         a0 = h4.a0; a1 = h4.a1; a2 = h4.a2; a3 = h4.a3;
         TR_END(7, h);
+      } else if constexpr (RB) {
+        // ray-bias stream: the heads are fp32 dot products on the vector ALU; every lane gets every row (the matrix-core form
+        // leaves rows 0..3 in the lower lane half and row 4 in register 0 of the upper one: same hand-over below)
+        const Head5 h5 = asm_head_valu<which>(p, frag, TP_CTX);
+        TR_END(7, h);
+        TP_THREAD_IDS;
+        a0 = (which == 1 && hh) ? h5.r4 : h5.r0; a1 = h5.r1; a2 = h5.r2; a3 = h5.r3;
       } else {
         f32x16 a;
         if constexpr (which == 2) a = asm_head<false>(p, frag, amax, TP_CTX);

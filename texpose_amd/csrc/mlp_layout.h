@@ -100,21 +100,37 @@ TP_HD ChunkDesc chunk_desc(int c) {
 // (mlp_fwd_f16x3.hip, rb_*_kernel) and the tile seeds its accumulators with that per-ray bias.  What is left of the extras of R0 is
 // x (3 columns), which the tile already staged for L0 / L4: k-step 3 of the encoding stage holds [PE slots 48..59 | x0 x1 x2 | 0], and
 // the one remaining extra chunk (CK_RBX) multiplies it with zeros for the 12 encoding slots and mlp_rgb.0 columns 283..285 for x.
-// Stream: the 115 chunks without the CK_X8 chunk (69) and with the three CK_X40 chunks (95..97) replaced by one CK_RBX chunk = 112
-// chunks, then the bias block, then (in the room of the three chunks saved) the transposed fp32 weight columns the pre-kernel reads:
+// Stream: the 115 chunks without the CK_X8 chunk (69), with the three CK_X40 chunks (95..97) replaced by one CK_RBX chunk and without
+// the three CK_HEAD chunks (below) = 109 chunks, then the bias block, then (in the room of the chunks saved) the fp32 tables:
 //   aux + 0      [27][256]  mlp_rgb.0 columns 256..282   (view)       aux = packed + kNumChunksRB * kChunkFloats + kBiasFloats
 //   aux + 6912   [48][256]  mlp_rgb.0 columns 286..333   (light)
 //   aux + 19200  [16][256]  mlp_trans.0 columns 256..271 (transient)
-constexpr int kNumChunksRB = 112;
-constexpr int kFirstHeadChunkRB = kFirstHeadChunk;
+//   aux + 23296  [9][256]   the rows of the three narrow output layers in lane-read order (rb_head_src)
+constexpr int kNumChunksRB = 109;
+constexpr int kFirstHeadChunkRB = kFirstHeadChunk - 1;   // (the density head's chunk, 52, is not in this stream)
 constexpr int64_t kRbAuxOff = (int64_t)kNumChunksRB * kChunkFloats + kBiasFloats;
-constexpr int kRbAuxView = 0, kRbAuxLight = 27 * 256, kRbAuxTrans = (27 + 48) * 256, kRbAuxFloats = (27 + 48 + 16) * 256;
+constexpr int kRbAuxView = 0, kRbAuxLight = 27 * 256, kRbAuxTrans = (27 + 48) * 256, kRbAuxHeads = (27 + 48 + 16) * 256;
+constexpr int kRbHeadRows = 9;                            // density | transient 0..4 | rgb 0..2
+constexpr int kRbAuxFloats = kRbAuxHeads + kRbHeadRows * 256;
 static_assert(kRbAuxOff + kRbAuxFloats <= kPackedFloats, "the ray-bias stream and its aux block fit the standard packed buffer");
+// The three narrow output layers of this kernel run as fp32 dot products on the vector ALU from a table that stays in LDS
+// (gen_wide_asm.py: gen_head_valu), so the stream has no head chunks either: 115 - CK_X8 - 3 CK_X40 + CK_RBX - 3 CK_HEAD = 109.  The
+// aux block carries the nine rows UNSCALED in the order a lane reads them: float (k * 2 + h) * 4 + i of a row =
+// W[row][feat_of(k >> 2, 4 (k & 3) + i, h)]  (k: 16-byte read 0..31 = accumulator registers 4 (k & 3) .. + 3 of source tile k >> 2).
 TP_HD ChunkDesc chunk_desc_rb(int c) {
-  if (c < 69) return chunk_desc(c);
-  if (c < 94) return chunk_desc(c + 1);
-  if (c == 94) return {CK_RBX, W_RGB0 + 0, 0, 0, 256, 334};
-  return chunk_desc(c + 3);
+  if (c < 52) return chunk_desc(c);
+  if (c < 68) return chunk_desc(c + 1);
+  if (c < 84) return chunk_desc(c + 2);
+  if (c < 92) return chunk_desc(c + 3);
+  if (c == 92) return {CK_RBX, W_RGB0 + 0, 0, 0, 256, 334};
+  return chunk_desc(c + 5);
+}
+// (weight matrix, row, col) of float `e` (0 .. 9 * 256 - 1) of the head table
+TP_HD void rb_head_src(int e, int& mat, int& row, int& col) {
+  const int r = e >> 8, f = e & 255, i = f & 3, h = (f >> 2) & 1, k = f >> 3;
+  mat = r == 0 ? W_FEAT0 + 7 : (r < 6 ? W_TRANS0 + 3 : W_RGB0 + 3);
+  row = r == 0 ? 0 : (r < 6 ? r - 1 : r - 6);
+  col = feat_of(k >> 2, 4 * (k & 3) + i, h);
 }
 
 // Source element of packed float `idx` (0..8191) of chunk c: returns (row, col) of the weight matrix

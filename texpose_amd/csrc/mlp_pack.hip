@@ -40,10 +40,17 @@ __global__ void pack16_kernel(W w, int chunk0, int chunk1, _Float16* __restrict_
 }
 
 // ray-bias stream: the transposed fp32 columns of mlp_rgb.0 / mlp_trans.0 that the per-ray bias pre-kernel contracts (mlp_layout.h)
-__global__ void pack_rb_aux_kernel(W w, float* __restrict__ out) {
+__global__ void pack_rb_aux_kernel(W w, float* __restrict__ out, int trunk, int heads) {
   float* aux = out + kRbAuxOff;
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= kRbAuxFloats) return;
+  if (e >= kRbAuxHeads) {                            // rows of the narrow output layers (the density row belongs to the trunk)
+    int mat, row, col;
+    rb_head_src(e - kRbAuxHeads, mat, row, col);
+    if (mat == W_FEAT0 + 7 ? trunk : heads) aux[e] = w.w[mat][(int64_t)row * 256 + col];
+    return;
+  }
+  if (!heads) return;
   const int c = e >> 8, f = e & 255;
   if (c < 27) aux[e] = w.w[W_RGB0][(int64_t)f * 334 + 256 + c];
   else if (c < 75) aux[e] = w.w[W_RGB0][(int64_t)f * 334 + 286 + (c - 27)];
@@ -179,7 +186,8 @@ extern "C" int tp_mlp_pack(const tp_mlp_weights* p, int parts, void* packed, tp_
     if ((is_trunk && trunk) || (!is_trunk && heads)) TP_REQUIRE(w.w[i] && w.b[i], "null weight pointer");
   }
   const int nch = rb ? kNumChunksRB : kNumChunks;
-  const int c0 = trunk ? 0 : kFirstHeadChunk, c1 = heads ? nch : kFirstHeadChunk;
+  const int first_head = rb ? kFirstHeadChunkRB : kFirstHeadChunk;
+  const int c0 = trunk ? 0 : first_head, c1 = heads ? nch : first_head;
   const int w0 = trunk ? 0 : kFirstHeadWide, w1 = heads ? kNumWide : kFirstHeadWide;
   if (parts & TP_PACK_F16X3)
     hipLaunchKernelGGL(pack16_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, w, c0, c1, (_Float16*)packed, rb);
@@ -187,7 +195,8 @@ extern "C" int tp_mlp_pack(const tp_mlp_weights* p, int parts, void* packed, tp_
     hipLaunchKernelGGL(pack_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, w, c0, c1, (float*)packed);
   hipLaunchKernelGGL(pack_bias_kernel, dim3(((w1 - w0) * 256 + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, w0,
                      w1, (float*)packed, nch);
-  if (rb && heads)
-    hipLaunchKernelGGL(pack_rb_aux_kernel, dim3((kRbAuxFloats + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, (float*)packed);
+  if (rb)
+    hipLaunchKernelGGL(pack_rb_aux_kernel, dim3((kRbAuxFloats + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, (float*)packed,
+                       trunk ? 1 : 0, heads ? 1 : 0);
   return tp::check_launch("tp_mlp_pack");
 }
