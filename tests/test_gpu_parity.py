@@ -2207,6 +2207,39 @@ def test_exact_fp32_asm_kernel_bit_identical_to_compiled(ops, monkeypatch, B, R,
     assert float(outs[1][0].abs().sum()) > 0
 
 
+@pytest.mark.parametrize("B,R,N", [(1, 5, 32), (2, 37, 64), (1, 300, 21), (3, 16, 128)])
+def test_exact_fp32_asm_recording_bit_identical_to_compiled(ops, monkeypatch, B, R, N):
+    """The RECORDING form of the exact-fp32 forward on generated blocks (the bias + ReLU blocks of the seven recorded layers also write
+    the activation record and the ReLU sign words; the trunk feature stays in registers) against the compiled recording kernel it
+    replaces (TP_FP32_CXX=1: global slab for the feature, 132 scratch instructions): outputs AND the whole activation record are
+    bit-identical -- ragged sample counts (dead lanes store nothing: the zeroed padding stays zero), both input forms; and the
+    backward that consumes the record gives identical gradients."""
+    params = {k: cu(v) for k, v in O.make_params(14).items()}
+    packed = ops.pack_weights(params)
+    rs = np.random.RandomState(B * 1000 + R + N)
+    center = cu(torch.from_numpy(rs.normal(size=(B, R, 3)).astype(np.float32)))
+    ray = cu(torch.from_numpy(rs.normal(size=(B, R, 3)).astype(np.float32)))
+    depth = cu(torch.from_numpy(rs.uniform(0.5, 2.0, size=(B, R, N, 1)).astype(np.float32)))
+    lt = cu(torch.from_numpy(rs.normal(size=(B, 16)).astype(np.float32)))
+    ll = cu(torch.from_numpy(rs.normal(size=(B, 48)).astype(np.float32)))
+    pts = (center[:, :, None] + ray[:, :, None] * depth).contiguous()
+    unit = torch.nn.functional.normalize(ray, dim=-1)[:, :, None].expand(B, R, N, 3).contiguous()
+    from texpose_amd import _lib
+    n_saved = int(_lib.load().tp_mlp_saved_bytes(B * R * N)) // 4
+    outs = []
+    for cxx in ("1", "0"):
+        monkeypatch.setenv("TP_FP32_CXX", cxx)
+        # (records into zero-filled buffers: neither kernel writes every word of a group -- slot 7 holds 30 rows, dead lanes nothing)
+        sa, sb = torch.zeros(n_saved, device=dev()), torch.zeros(n_saved, device=dev())
+        a = ops.mlp_forward(packed, lt, ll, center=center, ray=ray, depth=depth, precision="fp32", save=True, saved_out=sa)
+        b = ops.mlp_forward(packed, lt, ll, points=pts, ray_unit=unit, precision="fp32", save=True, saved_out=sb)
+        torch.cuda.synchronize()
+        outs.append([t.clone() for t in a] + [t.clone() for t in b])
+    for i, (x, y) in enumerate(zip(*outs)):           # (bit patterns: the ReLU sign words of the record are not floats)
+        assert torch.equal(x.view(torch.int32), y.view(torch.int32)), (i, int((x.view(torch.int32) != y.view(torch.int32)).sum()))
+    assert int((outs[1][3].view(torch.int32) != 0).sum()) > 1000
+
+
 def test_prefetched_spectral_weights_equal_in_place_normalisation(ops):
     """Discriminator.prefetch_spectral_weights(n): the power iterations / normalisations of the next n training-mode passes run ahead
     of time (on another stream, as the captured step does), each pass then takes its set from the queue -- outputs and the u / v

@@ -70,8 +70,19 @@ def gen_extra(dst, n_steps, zero):
                     b_load=lambda s: "ds_read_b32 v%d, %%[b] offset:%d" % (BRING + s % 3, s * 1024))
 
 
-def gen_act(base):
+def gen_act(base, rec=False, mask=False):
+    """rec (training): the block also writes the layer's activation record -- the post-ReLU values it holds in v[216:231], tile
+    by tile -- in the layout of mlp_layout.h ("Training record": [256 features][32 samples] per wave, 16-byte sample quads
+    XOR-swizzled with (f >> 1) & 7).  Register r of a tile is feature (r & 3) + 8 (r >> 2) + 4 h of the tile's 32: the swizzle
+    term takes four values over a tile's 16 registers, so four per-lane byte offsets %[o0..o3] (index ((r & 3) >> 1) + 2 ((r >> 2) & 1))
+    plus an immediate ((r & 3) + 8 (r >> 2)) * 128 address every store; the tile base s[96:97] advances by 4 KB (fixed SGPRs, clobbers:
+    s[96:97] tile base, s[94:95] live mask, s[92:93] saved EXEC).  Only live lanes
+    store (EXEC = %[live] != 0 around the stores; the record's padding must stay as the caller zeroed it).
+    mask: also the ReLU sign words the data-gradient kernel reads -- bit b of word w <-> tile 2 w + b / 16, register b % 16:
+    pushed MSB-first with v_cmp / v_addc, reversed, stored at %[mkoff] + 256 w relative to the record block."""
     out = ["s_nop 7", "s_nop 7", "s_nop 7"]
+    if rec:
+        out += ["v_cmp_ne_u32_e64 s[94:95], 0, %[live]", "s_mov_b64 s[96:97], %[rbase]"]
     for t in range(8):
         out += ["ds_read_b128 v[%d:%d], %%[bl] offset:%d" % (200 + 4 * g, 203 + 4 * g, (t * 16 + g * 4) * 4) for g in range(4)]
         out += ["v_accvgpr_read_b32 v%d, a%d" % (216 + r, base + 16 * t + r) for r in range(16)]
@@ -79,6 +90,21 @@ def gen_act(base):
         out += ["v_add_f32 v%d, v%d, v%d" % (216 + r, 216 + r, 200 + r) for r in range(16)]
         out += ["v_max_f32 v%d, 0, v%d" % (216 + r, 216 + r) for r in range(16)]
         out += ["v_accvgpr_write_b32 a%d, v%d" % (base + 16 * t + r, 216 + r) for r in range(16)]
+        if rec:
+            if mask:
+                for r in range(16):
+                    out += ["v_cmp_lt_f32_e32 vcc, 0, v%d" % (216 + r), "v_addc_co_u32_e32 %[mk], vcc, %[mk], %[mk], vcc"]
+                if t & 1:
+                    out.append("v_bfrev_b32_e32 %[mk], %[mk]")
+            out.append("s_and_saveexec_b64 s[92:93], s[94:95]")
+            for r in range(16):
+                idx = ((r & 3) >> 1) + 2 * ((r >> 2) & 1)
+                out.append("global_store_dword %%[o%d], v%d, s[96:97] offset:%d" % (idx, 216 + r, ((r & 3) + 8 * (r >> 2)) * 128))
+            if mask and (t & 1):
+                out.append("global_store_dword %%[mkoff], %%[mk], %%[rbase] offset:%d" % ((t >> 1) * 256))
+            out.append("s_mov_b64 exec, s[92:93]")
+            if t < 7:
+                out += ["s_add_u32 s96, s96, 0x1000", "s_addc_u32 s97, s97, 0"]
     return out + ["s_nop 1"]
 
 
@@ -131,12 +157,16 @@ def main(path):
         emit_macro(out, "TP32_EXTRA16_%s" % dst, "16 extra-input k-steps into set %s" % dst, gen_extra(SET[dst], 16, False))
         emit_macro(out, "TP32_EXTRA8_%s" % dst, "8 extra-input k-steps into set %s" % dst, gen_extra(SET[dst], 8, False))
         emit_macro(out, "TP32_ACT_%s" % dst, "set %s <- max(set + bias, 0) in place" % dst, gen_act(SET[dst]))
+        emit_macro(out, "TP32_ACT_%s_REC" % dst, "set %s <- max(set + bias, 0) in place, recording the values" % dst, gen_act(SET[dst], rec=True))
+        emit_macro(out, "TP32_ACT_%s_RECM" % dst, "set %s <- max(set + bias, 0) in place, recording values + ReLU sign words" % dst,
+                   gen_act(SET[dst], rec=True, mask=True))
         emit_macro(out, "TP32_HEAD_%s" % dst, "1..5-row head over set %s -> v[232:247]" % dst, gen_head(SET[dst]))
     emit_macro(out, "TP32_STASH_Q", "set Q -> v[32:159]", gen_stash(SET["Q"]))
     emit_macro(out, "TP32_RESTORE_P", "v[32:159] -> set P", gen_restore(SET["P"]))
     out.append('#define TP32_RING_CLOBBERS "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v209", "v210", "v211", \\')
     out.append('  "v212", "v213", "v214", "v215", "v216", "v217", "v218", "v219", "v220", "v221", "v222", "v223", "v224", "v225", "v226"')
     out.append('#define TP32_ACT_CLOBBERS TP32_RING_CLOBBERS, "v227", "v228", "v229", "v230", "v231"')
+    out.append('#define TP32_REC_CLOBBERS "s92", "s93", "s94", "s95", "s96", "s97", "vcc"')
     out.append('#define TP32_ALL_AGPRS "a0", "a255"')
     open(path, "w").write("\n".join(out) + "\n")
 

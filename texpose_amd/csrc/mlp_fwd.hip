@@ -306,6 +306,26 @@ __device__ __forceinline__ void asm32_act(unsigned bl) {
   if constexpr (SET_P) asm volatile(TP32_ACT_P : : [bl] "v"(bl) : TP32_CLOB);
   else asm volatile(TP32_ACT_Q : : [bl] "v"(bl) : TP32_CLOB);
 }
+// training: bias + ReLU of a set AND its activation record (gen_fp32_asm.py: gen_act rec / mask).  `o` = the lane's four swizzled
+// byte offsets inside a 4 KB record tile, `rbase` the record block of this wave's group, `mkoff` the byte offset (from rbase) of the
+// lane's first ReLU sign word, `live` != 0 for lanes that own a sample of the call.
+struct Rec32 { unsigned o[4]; unsigned mkoff; int live; };
+template <bool SET_P, bool MASK>
+__device__ __forceinline__ void asm32_act_rec(unsigned bl, const Rec32& r, const float* rbase) {
+  unsigned mk = 0;
+  const uint64_t rb = (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)rbase) |
+                      ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((uintptr_t)rbase >> 32)) << 32);
+#define TP32_ACT_REC(TXT)                                                                                              \
+  asm volatile(TXT : [mk] "+v"(mk)                                                                                     \
+               : [bl] "v"(bl), [o0] "v"(r.o[0]), [o1] "v"(r.o[1]), [o2] "v"(r.o[2]), [o3] "v"(r.o[3]), [mkoff] "v"(r.mkoff),   \
+                 [live] "v"(r.live), [rbase] "s"(rb)                                                                   \
+               : TP32_CLOB, TP32_REC_CLOBBERS)
+  if constexpr (SET_P && MASK) TP32_ACT_REC(TP32_ACT_P_RECM);
+  else if constexpr (SET_P) TP32_ACT_REC(TP32_ACT_P_REC);
+  else if constexpr (MASK) TP32_ACT_REC(TP32_ACT_Q_RECM);
+  else TP32_ACT_REC(TP32_ACT_Q_REC);
+#undef TP32_ACT_REC
+}
 template <bool SET_P>
 __device__ __forceinline__ f32x16 asm32_head(unsigned a) {
   f32x16 v;
@@ -343,6 +363,11 @@ __device__ __forceinline__ void part_extra_asm(Pipe& p, const float* staged) {
   chunk_end(p, kNumChunks);
 }
 
+// SAVE (training): the ACT blocks of the seven recorded layers (trunk feature, T0..T2, R0..R2) also write the activation record and,
+// for the six head layers, the ReLU sign words -- the compiled recording kernel above parks the trunk feature in a global slab and
+// carries 132 scratch instructions; this one holds it in registers like the inference form.  Same arithmetic: records and outputs are
+// bit-identical to the compiled kernel's (TP_FP32_CXX=1 selects that one; test_exact_fp32_asm_recording_bit_identical_to_compiled).
+template <bool SAVE>
 __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_exact_asm_kernel(Params P) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -405,41 +430,83 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_exact_asm_kernel(Params P
 #pragma unroll
     for (int r = 15; r < 39; ++r) ex_lds[r * kThreads] = P.lat_light[b * 48 + (r - 15) + 24 * hh];
     ex_lds[39 * kThreads] = 0.0f;
-    const unsigned bias0 = lds_addr(bias_lds) + (unsigned)hh * 512u;            // + li * 1024: bias block of wide layer li
+    // LDS addresses that depend on the lane are RE-DERIVED from the hardware thread id wherever they are used (an empty volatile
+    // asm keeps the derivations apart), like the record operands below: carried through the tile next to the 128 registers of the
+    // trunk feature, the recording variant's extra live values made the compiler spill into AGPRs, which belong to the blocks
+    const auto fresh_tid = [] { int t_ = threadIdx.x; asm volatile("" : "+v"(t_)); return t_; };
+    const auto bias_of = [&](int li) { return lds_addr(bias_lds) + (((unsigned)fresh_tid() >> 5) & 1u) * 512u + (unsigned)li * 1024u; };
+    const auto enc_now = [&] { return bias_lds + kBiasPad + fresh_tid(); };
+    const auto ex_now = [&] { return bias_lds + kBiasPad + kEncFloats + fresh_tid(); };
+    if constexpr (SAVE) {
+      if (live) {   // mlp_rgb.0 input columns 256..285 for the weight gradient
+        float* sx = P.saved + (tile * 4 + wave) * (int64_t)kSavedGroupFloats + SV_EX * kBlockFloats;
+#pragma unroll
+        for (int r = 0; r < 15; ++r) sx[blk_off(x40_col(r, hh), j)] = ex_lds[r * kThreads];
+      }
+    }
+    // The record operands of slot `sl` are RE-DERIVED from the hardware thread id at every recording block (behind an empty volatile
+    // asm, so that nothing of it is hoisted): carried through the tile next to the 128 registers of the trunk feature they made the
+    // compiler spill into AGPRs -- which belong to the blocks (check_asm_ownership.py fails the build on that).
+    // Sign words of slot sl >= 1: kMaskOff + ((sl - 1) * 4 + w) * 64 + lane.
+    const auto rec_now = [&](int sl, const float*& base) {
+      int t_ = threadIdx.x;
+      asm volatile("" : "+v"(t_));
+      const unsigned ln = (unsigned)t_ & 63u, jj = ln & 31u, h_ = ln >> 5, q4 = jj >> 2;
+      const int wv = __builtin_amdgcn_readfirstlane(t_ >> 6);
+      Rec32 r;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const unsigned xv = ((unsigned)(c & 1) + 4u * (unsigned)(c >> 1) + 2u * h_) & 7u;   // (f >> 1) & 7 of the registers of class c
+        r.o[c] = ((((q4 ^ xv) << 2) | (jj & 3u)) + 128u * h_) * 4u;
+      }
+      r.live = (tile * kTileSamples + wv * 32 + (int64_t)jj) < P.n_samples ? 1 : 0;
+      r.mkoff = (unsigned)((kMaskOff + ((sl > 0 ? sl : 1) - 1) * 256 - sl * kBlockFloats) * 4) + ln * 4u;
+      base = P.saved + (tile * 4 + wv) * (int64_t)kSavedGroupFloats + (int64_t)sl * kBlockFloats;
+      return r;
+    };
 
     // ---- trunk: L0 (extras only) .. L7; set parity: even layers write P, odd layers write Q
-    part_extra_asm<true, 0>(p, enc_lds);
-    part_extra_asm<true, 1>(p, enc_lds + 16 * kThreads);
-    asm32_act<true>(bias0 + L0 * 1024u);
+    part_extra_asm<true, 0>(p, enc_now());
+    part_extra_asm<true, 1>(p, enc_now() + 16 * kThreads);
+    asm32_act<true>(bias_of(L0));
 #pragma nounroll
     for (int li = L1; li <= L6; li += 2) {                                      // (L1, L2), (L3, L4), (L5, L6)
       part_gen_asm<true>(p);
-      asm32_act<false>(bias0 + (unsigned)li * 1024u);
+      asm32_act<false>(bias_of(li));
       part_gen_asm<false>(p);
       if (li + 1 == L4) {                                                       // [x, PE(x)] again (layers/...light.py:90-91)
-        part_extra_asm<true, 1>(p, enc_lds);
-        part_extra_asm<true, 1>(p, enc_lds + 16 * kThreads);
+        part_extra_asm<true, 1>(p, enc_now());
+        part_extra_asm<true, 1>(p, enc_now() + 16 * kThreads);
       }
-      asm32_act<true>(bias0 + (unsigned)(li + 1) * 1024u);
+      asm32_act<true>(bias_of(li + 1));
     }
     const f32x16 hs = part_head_asm<true>(p);                                   // static density = softplus(row 0 of mlp_feat.7)
     const float sig_s = softplus(hs[0] + bias_lds[kHeadBiasOff + 0]);
     part_gen_asm<true>(p);                                                      // L7 -> Q
-    asm32_act<false>(bias0 + L7 * 1024u);
+    if constexpr (SAVE) { const float* rb_; const Rec32 rc_ = rec_now(SV_FEAT, rb_); asm32_act_rec<false, false>(bias_of(L7), rc_, rb_); }
+    else asm32_act<false>(bias_of(L7));
     f32x16 F[8];
     asm volatile(TP32_STASH_Q : TP32_SF_OUT(F) : : TP32_ALL_AGPRS);            // the trunk feature, held until the colour head
 
     // ---- transient head: T0 (Q + latent -> P), T1 (-> Q), T2 (-> P)
-    float* lat_lds = enc_lds;                                                   // (the [x, PE(x)] rows are dead after L4)
+    {
+      float* lat_lds = enc_now();                                               // (the [x, PE(x)] rows are dead after L4)
+      const int t_ = fresh_tid();
+      const int64_t sl_ = tile * kTileSamples + (t_ >> 6) * 32 + (t_ & 31);
+      const int b_ = (int)(((sl_ < P.n_samples ? sl_ : P.n_samples - 1) / P.N) / P.R);
 #pragma unroll
-    for (int r = 0; r < 8; ++r) lat_lds[r * kThreads] = P.lat_trans[b * 16 + r + 8 * hh];
+      for (int r = 0; r < 8; ++r) lat_lds[r * kThreads] = P.lat_trans[b_ * 16 + r + 8 * ((t_ >> 5) & 1)];
+    }
     part_gen_asm<false>(p);
-    part_extra_asm<true, 2>(p, lat_lds);
-    asm32_act<true>(bias0 + T0 * 1024u);
+    part_extra_asm<true, 2>(p, enc_now());
+    if constexpr (SAVE) { const float* rb_; const Rec32 rc_ = rec_now(SV_T0, rb_); asm32_act_rec<true, true>(bias_of(T0), rc_, rb_); }
+    else asm32_act<true>(bias_of(T0));
     part_gen_asm<true>(p);
-    asm32_act<false>(bias0 + T1 * 1024u);
+    if constexpr (SAVE) { const float* rb_; const Rec32 rc_ = rec_now(SV_T1, rb_); asm32_act_rec<false, true>(bias_of(T1), rc_, rb_); }
+    else asm32_act<false>(bias_of(T1));
     part_gen_asm<false>(p);
-    asm32_act<true>(bias0 + T2 * 1024u);
+    if constexpr (SAVE) { const float* rb_; const Rec32 rc_ = rec_now(SV_T2, rb_); asm32_act_rec<true, true>(bias_of(T2), rc_, rb_); }
+    else asm32_act<true>(bias_of(T2));
     const f32x16 ht = part_head_asm<true>(p);
     const float* hb = bias_lds + kHeadBiasOff + 1;
     const float rgb_t0 = sigmoid(ht[0] + hb[0]), rgb_t1 = sigmoid(ht[1] + hb[1]), rgb_t2 = sigmoid(ht[2] + hb[2]);
@@ -449,21 +516,27 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_exact_asm_kernel(Params P
     // ---- colour head: R0 (feature restored into P, + extras -> Q), R1 (-> P), R2 (-> Q)
     asm volatile(TP32_RESTORE_P : : TP32_SF_IN(F) : TP32_ALL_AGPRS);
     part_gen_asm<true>(p);
-    part_extra_asm<false, 1>(p, ex_lds);
-    part_extra_asm<false, 1>(p, ex_lds + 16 * kThreads);
-    part_extra_asm<false, 2>(p, ex_lds + 32 * kThreads);
-    asm32_act<false>(bias0 + R0 * 1024u);
+    part_extra_asm<false, 1>(p, ex_now());
+    part_extra_asm<false, 1>(p, ex_now() + 16 * kThreads);
+    part_extra_asm<false, 2>(p, ex_now() + 32 * kThreads);
+    if constexpr (SAVE) { const float* rb_; const Rec32 rc_ = rec_now(SV_R0, rb_); asm32_act_rec<false, true>(bias_of(R0), rc_, rb_); }
+    else asm32_act<false>(bias_of(R0));
     part_gen_asm<false>(p);
-    asm32_act<true>(bias0 + R1 * 1024u);
+    if constexpr (SAVE) { const float* rb_; const Rec32 rc_ = rec_now(SV_R1, rb_); asm32_act_rec<true, true>(bias_of(R1), rc_, rb_); }
+    else asm32_act<true>(bias_of(R1));
     part_gen_asm<true>(p);
-    asm32_act<false>(bias0 + R2 * 1024u);
+    if constexpr (SAVE) { const float* rb_; const Rec32 rc_ = rec_now(SV_R2, rb_); asm32_act_rec<false, true>(bias_of(R2), rc_, rb_); }
+    else asm32_act<false>(bias_of(R2));
     const f32x16 hr = part_head_asm<false>(p);
     const float* hc = bias_lds + kHeadBiasOff + 6;
     const float rgb_s0 = sigmoid(hr[0] + hc[0]), rgb_s1 = sigmoid(hr[1] + hc[1]), rgb_s2 = sigmoid(hr[2] + hc[2]);
 
-    if (live) {   // streaming stores: the 3.7 MB weight stream is what should stay in the 4 MB L2, not 36 B per sample of outputs
+    const int to_ = fresh_tid();
+    const int64_t so_ = tile * kTileSamples + (to_ >> 6) * 32 + (to_ & 31);
+    if (so_ < P.n_samples) {   // streaming stores: the 3.7 MB weight stream is what should stay in the 4 MB L2, not 36 B per sample of outputs
       using f32x2 = __attribute__((ext_vector_type(2))) float;
-      if (hh == 0) {
+      const int64_t s = so_;
+      if (((to_ >> 5) & 1) == 0) {
         f32x2* o = reinterpret_cast<f32x2*>(P.rgb + s * 6);
         __builtin_nontemporal_store(f32x2{rgb_s0, rgb_t0}, o);
         __builtin_nontemporal_store(f32x2{rgb_s1, rgb_t1}, o + 1);
@@ -534,20 +607,25 @@ extern "C" int tp_mlp_fwd(const tp_mlp_fwd_args* a, tp_stream_t stream) {
       e = hipFuncSetAttribute((const void*)mlp_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               kLdsFloats * (int)sizeof(float));
     if (e == hipSuccess)
-      e = hipFuncSetAttribute((const void*)mlp_fwd_exact_asm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+      e = hipFuncSetAttribute((const void*)mlp_fwd_exact_asm_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              kLdsFloats * (int)sizeof(float));
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void*)mlp_fwd_exact_asm_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               kLdsFloats * (int)sizeof(float));
     if (e != hipSuccess) { tp::set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
   }
   const int grid = persistent_grid(P.n_tiles);
-  // inference: the block kernel (trunk feature on the CU); TP_FP32_CXX=1 selects the compiled kernel (A/B, bit-identity test)
+  // the block kernels (trunk feature on the CU), inference and recording; TP_FP32_CXX=1 selects the compiled kernels (A/B, bit-identity tests)
   const char* env_cxx = getenv("TP_FP32_CXX");                      // (read per call: a test switches it inside one process)
   const bool exact_cxx = env_cxx != nullptr && env_cxx[0] == '1';
-  if (P.saved != nullptr)
+  if (P.saved != nullptr && exact_cxx)
     hipLaunchKernelGGL(mlp_fwd_kernel<true>, dim3(grid), dim3(kThreads), kLdsFloats * sizeof(float), (hipStream_t)stream, P);
+  else if (P.saved != nullptr)
+    hipLaunchKernelGGL(mlp_fwd_exact_asm_kernel<true>, dim3(grid), dim3(kThreads), kLdsFloats * sizeof(float), (hipStream_t)stream, P);
   else if (exact_cxx)
     hipLaunchKernelGGL(mlp_fwd_kernel<false>, dim3(grid), dim3(kThreads), kLdsFloats * sizeof(float), (hipStream_t)stream, P);
   else
-    hipLaunchKernelGGL(mlp_fwd_exact_asm_kernel, dim3(grid), dim3(kThreads), kLdsFloats * sizeof(float), (hipStream_t)stream, P);
+    hipLaunchKernelGGL(mlp_fwd_exact_asm_kernel<false>, dim3(grid), dim3(kThreads), kLdsFloats * sizeof(float), (hipStream_t)stream, P);
   return tp::check_launch("tp_mlp_fwd");
 }
 

@@ -342,9 +342,11 @@ def poll_mlp_status(device, raise_on_flag: bool = True) -> bool:
 @_on_tensor_device
 def mlp_forward(packed: Tensor, lat_trans: Tensor, lat_light: Tensor, *, center: Optional[Tensor] = None,
                 ray: Optional[Tensor] = None, depth: Optional[Tensor] = None, points: Optional[Tensor] = None,
-                ray_unit: Optional[Tensor] = None, save: bool = False, precision: str = "fp32", ray_bias: bool = False):
+                ray_unit: Optional[Tensor] = None, save: bool = False, precision: str = "fp32", ray_bias: bool = False,
+                saved_out: Optional[Tensor] = None):
     """Returns rgb [B,R,N,3,2], density [B,R,N,2], uncert [B,R,N,1] (+ saved activations if save).
-    ``packed`` must have been built with the same ``precision`` (and the same ``ray_bias``, see `ray_bias_applies`)."""
+    ``packed`` must have been built with the same ``precision`` (and the same ``ray_bias``, see `ray_bias_applies`).
+    ``saved_out``: caller-provided record buffer (tp_mlp_saved_bytes floats; its last tile's part zeroed when B*R*N % 128)."""
     lib = _lib.load()
     a = MlpFwdArgs()
     if center is not None:
@@ -364,7 +366,10 @@ def mlp_forward(packed: Tensor, lat_trans: Tensor, lat_light: Tensor, *, center:
     density = torch.empty(B, R, N, 2, device=dev)
     uncert = torch.empty(B, R, N, 1, device=dev)
     saved = None
-    if save:
+    if save and saved_out is not None:
+        assert saved_out.numel() == int(lib.tp_mlp_saved_bytes(S)) // 4 and saved_out.is_contiguous() and saved_out.dtype == torch.float32
+        saved = saved_out
+    elif save:
         saved = torch.empty(int(lib.tp_mlp_saved_bytes(S)) // 4, device=dev)
         if S % 128:        # the weight-gradient GEMM contracts whole 32-sample groups: padding must be zero
             saved[-(int(lib.tp_mlp_saved_bytes(128)) // 4):].zero_()
