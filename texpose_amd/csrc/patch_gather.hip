@@ -12,8 +12,14 @@
 
 namespace {
 
-__global__ void patch_gather_kernel(tp_patch_gather_args a) {
-  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// Workgroups are dispatched round-robin over the 8 XCDs (each with its own L2): with the natural order the 16 workgroups of one
+// 64 x 64 patch -- which sample overlapping rows of the same image region -- land on all eight, and every L2 fetches the region for
+// itself (PMC: 5x the algorithmic bytes).  `xcd_major` (set when the grid is a multiple of 8) gives XCD x the CONSECUTIVE logical
+// blocks [x n / 8, (x + 1) n / 8): an image's blocks share one L2.
+__global__ void patch_gather_kernel(tp_patch_gather_args a, int xcd_major) {
+  const unsigned nb = gridDim.x;
+  const unsigned lb = xcd_major ? (blockIdx.x & 7u) * (nb >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+  const int64_t q = (int64_t)lb * blockDim.x + threadIdx.x;
   const int64_t total = (int64_t)a.B * a.P;
   if (q >= total) return;
   const int b = (int)(q / a.P), p = (int)(q - (int64_t)b * a.P);
@@ -65,7 +71,7 @@ extern "C" int tp_patch_gather(const tp_patch_gather_args* a, tp_stream_t stream
                  a->out, "null pointer");
   TP_REQUIRE(a->B > 0 && a->P > 0 && a->H > 0 && a->W > 0, "bad sizes");
   const int64_t total = (int64_t)a->B * a->P;
-  hipLaunchKernelGGL(patch_gather_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                     *a);
+  const unsigned blocks = (unsigned)((total + 255) / 256);
+  hipLaunchKernelGGL(patch_gather_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *a, (blocks % 8 == 0 && blocks >= 16) ? 1 : 0);
   return tp::check_launch("tp_patch_gather");
 }
