@@ -622,9 +622,17 @@ __device__ __forceinline__ float part_sum(const FinParams& P, int gemm, int o, i
   const int wave = wide ? (o & 127) >> 5 : 0;
   const int ii = o & 31, h = (ii >> 2) & 1, r = (ii & 3) | ((ii >> 3) << 2);
   const float* p = P.partial + ((chunk0 * 4 + wave) * kWgTiles + ft) * 1024 + r * 64 + h * 32 + col;
+  // fixed order; up to 32 loads in flight (the slices of a GEMM: 38 wide / 14 narrow at 256 CUs -- 12 at a time left the launch
+  // latency-bound: 4 dependent round trips per element)
   float s = 0.0f;
-#pragma unroll 12
-  for (int sl = 0; sl < ns; ++sl) s += p[(int64_t)sl * 4 * kWgTiles * 1024];   // (fixed order; 12 loads in flight)
+  for (int sl0 = 0; sl0 < ns; sl0 += 32) {
+    float v[32];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) v[k] = sl0 + k < ns ? p[(int64_t)(sl0 + k) * 4 * kWgTiles * 1024] : 0.0f;
+#pragma unroll
+    for (int k = 0; k < 32; ++k)
+      if (sl0 + k < ns) s += v[k];
+  }
   return s;
 }
 

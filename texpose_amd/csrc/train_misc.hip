@@ -191,21 +191,20 @@ struct AdamTable {
 // The step counters are read by every block and must advance only after the last of them has: the block that finishes last (a
 // ticket in CALLER-OWNED device memory, one zero-filled word per stream that may run this entry point, reset by that block; agent-scope
 // accesses as in nerf_losses.hip) adds 1 to each distinct counter.
-__global__ __launch_bounds__(kBlock) void adam_kernel(AdamTable t, const float* lr_dev, double lr_host, double beta1, double beta2, float eps,
-                                                      float w1, float w2, int64_t total, const int* gate, int n_gate, unsigned int* ticket) {
+__global__ __launch_bounds__(kBlock) void adam_kernel(AdamTable t, const float* lr_dev, double lr_host, double log_beta1, double log_beta2, float b2,
+                                                      float eps, float w1, float w2, int64_t total, const int* gate, int n_gate, unsigned int* ticket) {
   __shared__ bool last;
   for (int k = 0; k < n_gate; ++k)
     if (gate[k] != 0) return;
   const double lr = lr_dev != nullptr ? (double)*lr_dev : lr_host;
-  const float b2 = (float)beta2;
   int k = 0, k_done = -1;
   float step_size = 0.f, bc2_sqrt = 1.f;
   for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < total; e += (int64_t)gridDim.x * kBlock) {
     while (e >= t.end[k]) ++k;
     const int64_t i = e - (k == 0 ? 0 : t.end[k - 1]);
-    if (k != k_done) {                                     // the bias corrections are per tensor: two double pow() once, not per element
-      const double step = (double)t.step[k][0] + 1.0;
-      const double bc1 = 1.0 - pow(beta1, step), bc2 = 1.0 - pow(beta2, step);
+    if (k != k_done) {                                     // the bias corrections are per tensor, once, not per element; beta^step as
+      const double step = (double)t.step[k][0] + 1.0;      // exp(step ln beta) in double (ln beta from the host): a generic double pow()
+      const double bc1 = 1.0 - exp(step * log_beta1), bc2 = 1.0 - exp(step * log_beta2);   // is ~6x the instructions of exp()
       step_size = (float)(lr / bc1); bc2_sqrt = (float)sqrt(bc2);
       k_done = k;
     }
@@ -487,8 +486,8 @@ int tp_adam_step(const tp_adam_tensor* tensors, int n, const float* lr_dev, doub
   t.n = n;
   int64_t blocks = (total + kBlock - 1) / kBlock;
   if (blocks > 512) blocks = 512;          // (one arrival per block on ONE counter word: 1,700 same-address atomics cost 16 us)
-  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, t, lr_dev, lr_host, beta1, beta2, (float)eps,
-                     (float)(1.0 - beta1), (float)(1.0 - beta2), total, gate, n_gate, ticket);
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, t, lr_dev, lr_host, log(beta1), log(beta2),
+                     (float)beta2, (float)eps, (float)(1.0 - beta1), (float)(1.0 - beta2), total, gate, n_gate, ticket);
   return tp::check_launch("tp_adam_step");
 }
 
