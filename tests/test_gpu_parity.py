@@ -2634,6 +2634,7 @@ def test_discriminator_forward_takes_the_fused_tail_for_frozen_weights(ops):
     """Discriminator.forward on the GPU with constant weights (the nerf step's pass: prefetched, detached spectral weights) runs the
     ladder's full-map convolution + head as K17's one launch each way; value and the gradient wrt the patch equal the unfused
     composition (TP_NO_DISC_TAIL=1)."""
+    from texpose_amd import autograd_ops
     from texpose_amd.gan_modules import Discriminator
     from texpose_amd.options import default_options
     opt = default_options(H=128, W=128, device="cuda:0")
@@ -2657,7 +2658,8 @@ def test_discriminator_forward_takes_the_fused_tail_for_frozen_weights(ops):
         try:
             disc.prefetch_spectral_weights(1)
             x = x0.clone().requires_grad_()
-            out = disc(opt, x, scale)
+            with autograd_ops.first_order_only():                      # (what Graph.nerf_forward declares around this pass)
+                out = disc(opt, x, scale)
             (out * torch.arange(1, 5, device=dev())).sum().backward()
             res.append((out.detach().clone(), x.grad.clone(), type(out.grad_fn).__name__))
         finally:
@@ -2665,6 +2667,22 @@ def test_discriminator_forward_takes_the_fused_tail_for_frozen_weights(ops):
     assert "DiscTail" in res[0][2] and "DiscTail" not in res[1][2]
     torch.testing.assert_close(res[0][0], res[1][0], rtol=2e-5, atol=2e-6)
     assert rel_l2(res[0][1], res[1][1]) < 1e-5
+    # frozen weights WITHOUT the declaration: the differentiable nodes run, and a gradient penalty wrt the input (create_graph=True)
+    # through the frozen discriminator differentiates a second time -- equal to the penalty's gradient with trainable weights
+    pens = []
+    for frozen in (True, False):
+        disc.load_state_dict(state)
+        for p in disc.parameters():
+            p.requires_grad_(not frozen)
+        x = x0.clone().requires_grad_()
+        if frozen:
+            disc.prefetch_spectral_weights(1)
+        out = disc(opt, x, scale)
+        assert "DiscTail" not in type(out.grad_fn).__name__ and "Conv4s2Inorm" not in type(out.grad_fn).__name__
+        (g1,) = torch.autograd.grad(out.sum(), x, create_graph=True)
+        (g2,) = torch.autograd.grad(g1.pow(2).sum(), x)
+        pens.append(g2)
+    assert float(pens[0].abs().sum()) > 0 and rel_l2(pens[0], pens[1]) < 1e-5
 
 
 def test_step_inputs_one_launch_for_the_per_iteration_host_state(ops):

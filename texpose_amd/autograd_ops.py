@@ -353,6 +353,27 @@ def disc_head(z, scale, W1, W2, W3, L: int, slope: float = 0.2):
     return _DiscHead.apply(z.contiguous(), scale.contiguous(), W1.contiguous(), W2.contiguous(), W3.contiguous(), int(L), float(slope))
 
 
+# The fused frozen-weight nodes below (_Conv4s2Inorm, _DiscTail) are first order in their input.  A frozen weight alone does not say
+# that first order suffices -- a gradient penalty wrt the input with create_graph=True under frozen weights needs the differentiable
+# K11 / K9 / K15 / K14 nodes -- so the caller that knows (the nerf step's pass through the discriminator, texpose_amd/graph.py)
+# says so explicitly:
+_FIRST_ORDER = [0]
+
+
+class first_order_only:
+    """``with first_order_only():`` -- passes through the discriminator issued inside need the data gradient once and nothing else."""
+
+    def __enter__(self):
+        _FIRST_ORDER[0] += 1
+
+    def __exit__(self, *exc):
+        _FIRST_ORDER[0] -= 1
+
+
+def first_order_declared():
+    return _FIRST_ORDER[0] > 0
+
+
 # ---- K11 + K9 fused forward for FROZEN weights (the nerf step's pass through the discriminator): one launch instead of two
 class _Conv4s2Inorm(torch.autograd.Function):
     """y = lrelu(instance_norm(conv4s2(x, w))) with a constant weight: forward tp_conv4s2_fwd_inorm, backward K9's first-order

@@ -156,7 +156,7 @@ class Discriminator(nn.Module):
             if (isinstance(m, SNConv2d) and x.is_cuda and i + 2 < len(mods) and isinstance(mods[i + 1], nn.InstanceNorm2d)
                     and isinstance(mods[i + 2], nn.LeakyReLU) and not mods[i + 1].affine and not mods[i + 1].track_running_stats
                     and tuple(m.weight_orig.shape[-2:]) == (4, 4) and m.stride == (2, 2) and m.padding == (1, 1)
-                    and not weights[0].requires_grad and Discriminator._fused_stage_ok(x)):
+                    and not weights[0].requires_grad and Discriminator._first_order() and Discriminator._fused_stage_ok(x)):
                 # constant weight (the nerf step's pass): convolution + InstanceNorm + LeakyReLU as one launch (K11 epilogue)
                 from . import autograd_ops
                 x = autograd_ops.conv4s2_inorm(x, weights.pop(0), mods[i + 1].eps, mods[i + 2].negative_slope)
@@ -181,6 +181,13 @@ class Discriminator(nn.Module):
         return x
 
     @staticmethod
+    def _first_order():
+        """The caller declared that this pass is differentiated once, wrt its input (autograd_ops.first_order_only): the fused
+        frozen-weight nodes are `once_differentiable`; without the declaration the differentiable K11 / K9 / K15 / K14 nodes run."""
+        from . import autograd_ops
+        return autograd_ops.first_order_declared() or not torch.is_grad_enabled()
+
+    @staticmethod
     def _fused_stage_ok(x):
         from . import ops
         return ops.conv4s2_fwd_inorm_supported(x)
@@ -190,6 +197,8 @@ class Discriminator(nn.Module):
         that covers its whole map, at most 16 patches."""
         from . import ops
         if not (x.is_cuda and self.scale_conditional and self._plain_head()) or any(w.requires_grad for w in weights):
+            return False
+        if not self._first_order():
             return False
         last = list(self.main)[-1]
         if not (isinstance(last, SNConv2d) and last.padding == (0, 0) and last.stride == (1, 1)):
@@ -236,7 +245,7 @@ class Discriminator(nn.Module):
             return None
         outs, sigmas, us, vs, issued_on = self._sn_queue.pop(0)
         cur = torch.cuda.current_stream(outs[0].device)
-        if cur != issued_on:
+        if issued_on is not None and cur != issued_on:         # (None: the replay loop's events order the streams)
             cur.wait_stream(issued_on)
         return outs, sigmas, us, vs
 

@@ -299,7 +299,9 @@ class Graph(torch.nn.Module):
             # on one hardware queue, one after the other -- 1.406 vs 1.331 ms per B=4 iteration on one box, profiles/r4)
             if var.get("feat_early_for") is not var.ray_idx:      # (else: a graph of its own already ran it, trainer._seg_feat)
                 self._feature_loss_early(opt, var, (h, w), mode)
-            var.d_fake_nerf = self.discriminator(opt, var.patch_fake_nerf, var.ray_scales)
+            # (the nerf step differentiates this pass once, wrt the patch: the fused frozen-weight kernels may serve it)
+            with autograd_ops.first_order_only():
+                var.d_fake_nerf = self.discriminator(opt, var.patch_fake_nerf, var.ray_scales)
         return var
 
     def _feature_loss_early(self, opt, var, hw, mode):

@@ -390,6 +390,12 @@ class GanTrainer:
                     setattr(self, name, value)
                     setattr(self, name + "_used", value)
 
+    def flush_flags(self):
+        """The eager trainer reads its guards before every optimiser step: nothing is pending (see GraphedGanTrainer.flush_flags)."""
+        return [0, 0, 0]
+
+    finish = flush_flags
+
     def train_iteration(self, var: AttrDict):
         var = self.graph.get_ray_idx(self.opt, var)
         var, loss = self.nerf_step(var)
@@ -402,7 +408,10 @@ class GanTrainer:
         return var, loss
 
 
-def distinct_queue_streams(dev, n, candidates=8):
+LAST_QUEUE_PROBE = {}        # outcome of the most recent probe (requested / concurrent / candidate indices / sharing matrix)
+
+
+def distinct_queue_streams(dev, n, candidates=8, votes=3):
     """``n`` streams that run CONCURRENTLY with each other and with the current stream, found by measurement.
 
     The HIP runtime multiplexes all streams of a process onto a few hardware queues (4 by default), round-robin in creation order, and a
@@ -444,19 +453,36 @@ def distinct_queue_streams(dev, n, candidates=8):
     for st in pool:
         with torch.cuda.stream(st):
             probe.fill_(0.0)
-    for _ in range(2):
-        shared = [[a is not b and shares_queue(a, b) for b in every] for a in every]
+    shared = [[a is not b and shares_queue(a, b) for b in every] for a in every]          # (first pass: discarded)
+    # A single probe can lie in ONE direction only: a host stall of more than the spin between the two enqueues lets the spin finish
+    # first and reads as "shared".  So a pair counts as sharing a queue only if the majority of `votes` probes say so.
+    counts = [[0] * len(every) for _ in every]
+    for _ in range(votes):
+        for i, a in enumerate(every):
+            for j, b in enumerate(every):
+                counts[i][j] += int(a is not b and shares_queue(a, b))
+    shared = [[2 * c > votes for c in row] for row in counts]
     together = lambda i, j: shared[i][j] or shared[j][i]
     picked = []
     for i in range(1, len(every)):
         if len(picked) < n and not together(0, i) and not any(together(j, i) for j in picked):
             picked.append(i)
+    concurrent = len(picked)
     for i in range(1, len(every)):                   # (not enough concurrent ones: fill up in creation order)
         if len(picked) < n and i not in picked:
             picked.append(i)
     chosen = [every[i] for i in picked]
+    idx = [0] + picked
+    report = dict(requested=n, concurrent=concurrent, candidates=[i - 1 for i in picked], votes=votes,
+                  sharing=[[int(together(a, b)) if a != b else 0 for b in idx] for a in idx])
+    LAST_QUEUE_PROBE.clear()
+    LAST_QUEUE_PROBE.update(report)
+    if concurrent < n:
+        warnings.warn("texpose_amd: only %d of the %d streams of the captured training step run concurrently with each other and "
+                      "with the calling stream (GPU_MAX_HW_QUEUES too small, or the process holds many streams): the step is "
+                      "correct and slower (measured 640-735 instead of 850 it/s at B=4)" % (concurrent, n))
     if os.environ.get("TP_QUEUE_PROBE_VERBOSE") == "1":
-        print("distinct_queue_streams: candidates", [pool.index(c) for c in chosen], "pairwise sharing after the choice:",
+        print("distinct_queue_streams:", report, "pairwise sharing after the choice:",
               [[int(shares_queue(a, b)) for b in [cur] + chosen] for a in [cur] + chosen], flush=True)
     return chosen
 
@@ -798,11 +824,13 @@ class GraphedGanTrainer(GanTrainer):
         g4, ev, side = self._g4, self._ev4, self._side
         main = torch.cuda.current_stream(self._bad.device)
         with torch.cuda.stream(side):
-            if self._four_first:                     # (parameters restored / loaded on the calling stream since the capture)
-                side.wait_stream(main)
-                self._four_first = False
-            else:
+            # the discriminator stream is ordered behind the CALLER's stream on every replay: D1 reads `weight_orig` and rewrites
+            # `weight_u` / `weight_v` in place, and whatever the caller enqueued between two iterations (a load_state_dict, a parameter
+            # broadcast, a checkpoint copy of u / v) must come first.  `main` is the calling stream here.
+            side.wait_stream(main)
+            if not self._four_first:
                 side.wait_event(ev["g2"])            # set 1 is read by the generator's backward through the frozen discriminator
+            self._four_first = False
             g4["D1"].replay()
             ev["sn"].record(side)
         # (Submission order G2 before D2.  Measured on one box, 200 iterations each: this order 1.184 ms, D2 first 1.197 ms; with the
@@ -869,9 +897,11 @@ class GraphedGanTrainer(GanTrainer):
         # waited for the previous iteration's last launches below, so does everything here
         main.wait_stream(cur)
         with torch.cuda.stream(side):
-            if self._four_first:
-                side.wait_stream(cur)
-            else:
+            # ... and so does the discriminator stream, on EVERY replay (D1 reads `weight_orig` and rewrites `weight_u` / `weight_v` in
+            # place: a load_state_dict, parameter broadcast or checkpoint copy the caller enqueued between two iterations comes first;
+            # the wait costs the tiny tp_step_inputs launch, which `main` waits for anyway)
+            side.wait_stream(cur)
+            if not self._four_first:
                 side.wait_event(ev["g2"])            # set 1 is read by the generator's passes through the frozen discriminator
             g["D1"].replay()
             ev["sn"].record(side)
@@ -881,10 +911,8 @@ class GraphedGanTrainer(GanTrainer):
         # (The order in which the host submits F / G2a+G2b / D2 makes no difference -- six orders measured within 0.5 % on one box -- and the
         # host is 4x ahead of the device: 260 us of launches per 1.17 ms iteration.)
         with torch.cuda.stream(feat):
-            if self._four_first:
-                feat.wait_stream(cur)
-                self._four_first = False
-            feat.wait_event(ev["patches"])
+            self._four_first = False
+            feat.wait_event(ev["patches"])           # (recorded on `main` behind its wait for the caller's stream)
             g["F"].replay()
             ev["feat"].record(feat)
         with torch.cuda.stream(main):
@@ -995,6 +1023,7 @@ class GraphedGanTrainer(GanTrainer):
         if self._linear and (getattr(self, "_capture_stream", None) is None or self._side is None
                              or getattr(self.graph, "feat_stream", None) is None) and os.environ.get("TP_NO_QUEUE_PROBE") != "1":
             self._capture_stream, self._side, self.graph.feat_stream = distinct_queue_streams(dev, 3)
+            self.queue_probe = dict(LAST_QUEUE_PROBE)                    # (bench lines report it: `train.queues`)
         if getattr(self, "_capture_stream", None) is None:
             self._capture_stream = torch.cuda.Stream(device=dev)
         if self._four and self._side is None:
@@ -1068,6 +1097,21 @@ class GraphedGanTrainer(GanTrainer):
             seen = prev[0].tolist()
             self._bad_poll = None
         return seen
+
+    def flush_flags(self):
+        """Blocking read of the gate words as the LAST replay left them; acts on them like `train_iteration` does.  The words of a
+        replay are copied out by the NEXT iteration's tp_step_inputs launch, so a caller that stops issuing iterations -- end of training,
+        before a checkpoint -- calls this to learn about a withheld final step (re-capture with fp32, or FloatingPointError)."""
+        if self._graph is None:
+            return [0, 0, 0]
+        flagged = self._read_bad(blocking=True)
+        if flagged[0] and self._uses_f16x3():
+            self._fall_back_to_fp32(AttrDict(dict(self._static_in)))
+        elif flagged[1] or flagged[2]:
+            raise FloatingPointError("non-finite loss in a captured training step (the update was withheld on the device)")
+        return flagged
+
+    finish = flush_flags
 
     def _bad_poll_slot(self):
         """Pinned host words for this iteration's copy of the gate words (written by the tp_step_inputs launch in front of the
