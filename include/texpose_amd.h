@@ -501,6 +501,10 @@ int tp_step_inputs(const tp_step_copy* copies /* host array */, int n_copies, fl
                    tp_stream_t stream);
 /* Diagnostic (no reference counterpart): the device's 100 MHz constant clock written to *slot by a one-thread launch in stream order. */
 int tp_stamp(uint64_t* slot, tp_stream_t stream);
+/* Diagnostic (no reference counterpart): one sleeping wave samples the shader clock against the 100 MHz constant clock over `windows`
+ * consecutive windows of window_us microseconds: out[2w] = shader cycles, out[2w+1] = 100-MHz ticks of window w (out: 2 * windows device
+ * words).  Launched on a side stream in front of a kernel, it reports the clock the chip holds under that kernel's load. */
+int tp_clock_probe(uint64_t* out, int windows, int64_t window_us, tp_stream_t stream);
 int tp_disc_inputs(const float* rgb, const float* gathered, int B, int P, int geo, float* real, float* fake, tp_stream_t stream);
 /* Cotangent of the fake stack wrt the rendered colours (the nerf step back-propagates D(fake) into the render):
  * g_rgb [B,P,3] = g_fake [B,nc,P] channels 0..2, transposed. */

@@ -392,3 +392,42 @@ def test_failed_capture_on_one_rank_sends_every_rank_to_the_eager_loop(tmp_path)
     for k in range(world):
         assert r[k]["calls"] == [True, False] and r[k]["res"] == dict(value=3.0, launch="eager")
     assert "capture failed" in r[1]["note"] and "another rank" in r[0]["note"]
+
+
+def _probe_order_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    from texpose_amd import trainer as ttrainer
+    tdist.init_distributed("gloo")
+    before = tdist.warm_collective_done()
+    seen_at_probe = []
+
+    def fake_probe(dev, n):
+        # what the real probe (distinct_queue_streams) would find: the job's first collective has already run
+        seen_at_probe.append((tdist.warm_collective_done(), tdist.ranks_seen()))
+        return ["stream%d" % i for i in range(n)]
+
+    streams = ttrainer.streams_after_collectives(torch.device("cpu"), 3, None, probe=fake_probe)
+    torch.save(dict(before=before, seen_at_probe=seen_at_probe, streams=streams, ranks_seen=tdist.ranks_seen()),
+               os.path.join(out_dir, f"po_rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_queue_probe_runs_behind_the_first_collective_and_ranks_seen_counts_the_job(tmp_path):
+    """Several ranks: the stream -> hardware-queue probe of the captured step (trainer.streams_after_collectives) runs only AFTER the
+    communicator's first collective (RCCL makes its own streams there), and that collective -- dist.ranks_seen, a SUM of ones --
+    reports the number of ranks the communicator joined (what every multi-GPU line of bench.py / tools carries)."""
+    world = 2
+    mp.spawn(_probe_order_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    for k in range(world):
+        r = torch.load(tmp_path / f"po_rank{k}.pt")
+        assert r["before"] is False                                # init_process_group alone is not the warm collective
+        assert r["seen_at_probe"] == [(True, world)] and r["ranks_seen"] == world
+        assert r["streams"] == ["stream0", "stream1", "stream2"]
+
+
+def test_ranks_seen_is_one_without_a_process_group():
+    assert not dist.is_initialized()
+    assert tdist.ranks_seen() == 1 and tdist.warm_collective_done()

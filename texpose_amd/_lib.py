@@ -30,7 +30,7 @@ SYMBOLS = (
     "tp_rmsprop_step",
     "tp_conv4s2_workspace", "tp_conv4s2_fwd", "tp_conv4s2_dgrad", "tp_conv4s2_wgrad", "tp_conv4s2_fwd_inorm_workspace", "tp_conv4s2_fwd_inorm",
     "tp_conv3s1_workspace", "tp_conv3s1_fwd", "tp_conv3s1_dgrad",
-    "tp_patch_coords", "tp_bce_logits_fwd", "tp_bce_logits_bwd", "tp_feat_inputs_fwd", "tp_feat_inputs_bwd", "tp_disc_inputs", "tp_step_flags", "tp_adam_step", "tp_step_inputs", "tp_stamp",
+    "tp_patch_coords", "tp_bce_logits_fwd", "tp_bce_logits_bwd", "tp_feat_inputs_fwd", "tp_feat_inputs_bwd", "tp_disc_inputs", "tp_step_flags", "tp_adam_step", "tp_step_inputs", "tp_stamp", "tp_clock_probe",
     "tp_fake_patch_bwd", "tp_feat_pair_loss_fwd", "tp_feat_pair_loss_bwd", "tp_sumsq_mean_fwd", "tp_sumsq_mean_bwd", "tp_sumsq_mean_fwd_bwd", "tp_gan_disc_losses", "tp_maxpool2_fwd", "tp_maxpool2_bwd", "tp_latent_rows_fwd",
     "tp_latent_rows_bwd", "tp_weighted_sum", "tp_weighted_sum_flags",
     "tp_disc_head_fwd", "tp_disc_head_bwd", "tp_disc_head_bwd_bwd",
@@ -233,6 +233,7 @@ def load() -> C.CDLL:
     sig("tp_rmsprop_step", [C.POINTER(RmspropTensor), C.c_int, vp, C.c_double, C.c_double, C.c_double, vp, C.c_int, vp])
     sig("tp_step_flags", [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp])
     sig("tp_stamp", [vp, vp])
+    sig("tp_clock_probe", [vp, C.c_int, C.c_int64, vp])
     sig("tp_step_inputs", [C.POINTER(StepCopy), C.c_int, C.POINTER(vp), C.POINTER(C.c_float), C.c_int, vp, vp, C.c_int, vp])
     sig("tp_adam_step", [C.POINTER(AdamTensor), C.c_int, vp, C.c_double, C.c_double, C.c_double, C.c_double, vp, C.c_int, vp, vp])
     sig("tp_conv4s2_workspace", [C.POINTER(Conv4s2Args), C.c_int, C.POINTER(C.c_int64)], C.c_int64)

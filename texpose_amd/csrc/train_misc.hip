@@ -463,6 +463,30 @@ int tp_step_inputs(const tp_step_copy* copies, int n_copies, float* const* scala
 // step it gives the step's timeline without a tracer slowing the host down (tools/linear_timeline.py).
 __global__ void stamp_kernel(unsigned long long* slot) { *slot = wall_clock64(); }
 
+// Diagnostic: the shader clock next to the constant 100 MHz clock over `windows` consecutive windows of `window_ticks` 100-MHz ticks,
+// from ONE sleeping wave (out[2w] = shader cycles, out[2w+1] = 100-MHz ticks of window w).  Launched on a side stream in front of a
+// render it tells what clock the chip HOLDS under that load (bench.py: roofline.clock_ghz; the f16x3 forward is power-limited well
+// below the 2.4 GHz the peaks are quoted at).  The wave holds one SIMD slot of one CU for the whole span.
+__global__ void clock_probe_kernel(unsigned long long* out, int windows, unsigned long long window_ticks) {
+  for (int w = 0; w < windows; ++w) {
+    const unsigned long long r0 = wall_clock64(), c0 = clock64();
+    unsigned long long r1 = r0;
+    while (r1 - r0 < window_ticks) {
+      __builtin_amdgcn_s_sleep(64);
+      r1 = wall_clock64();
+    }
+    out[2 * w] = clock64() - c0;
+    out[2 * w + 1] = r1 - r0;
+  }
+}
+
+int tp_clock_probe(uint64_t* out, int windows, int64_t window_us, tp_stream_t stream) {
+  TP_REQUIRE(out != nullptr && windows > 0 && windows <= 4096 && window_us > 0 && window_us <= 1000000, "bad arguments");
+  hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (unsigned long long*)out, windows,
+                     (unsigned long long)window_us * 100ull);
+  return tp::check_launch("tp_clock_probe");
+}
+
 int tp_stamp(uint64_t* slot, tp_stream_t stream) {
   TP_REQUIRE(slot != nullptr, "null slot");
   hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (unsigned long long*)slot);

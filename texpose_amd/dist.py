@@ -34,6 +34,33 @@ def init_distributed(backend: Optional[str] = None) -> tuple:
     return rank, world, local
 
 
+_RANKS_SEEN = {}
+
+
+def ranks_seen(group=None, device=None) -> int:
+    """SUM all-reduce of a one per rank: how many ranks the communicator (RCCL on GPUs) actually joins -- the figure every
+    multi-GPU line of bench.py / tools carries, so that the record itself says whether the collective library saw N ranks.
+    Also the WARM collective of a job: RCCL creates its channels, proxy threads and internal HIP streams on the first collective,
+    and whatever picks streams by measurement afterwards (trainer.distinct_queue_streams) must run behind it
+    (`warm_collective_done`).  1 without a process group.  The value is cached per group."""
+    key = id(group)
+    if key in _RANKS_SEEN:
+        return _RANKS_SEEN[key]
+    if not (dist.is_available() and dist.is_initialized()):
+        return 1
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    one = torch.ones(1, dtype=torch.float32, device=device)
+    dist.all_reduce(one, op=dist.ReduceOp.SUM, group=group)
+    _RANKS_SEEN[key] = int(round(float(one)))
+    return _RANKS_SEEN[key]
+
+
+def warm_collective_done(group=None) -> bool:
+    """True once `ranks_seen` has run its all-reduce on this group (or when there is no process group to warm up)."""
+    return id(group) in _RANKS_SEEN or not (dist.is_available() and dist.is_initialized())
+
+
 def shard_batch(n_items: int, rank: int, world: int) -> range:
     """Contiguous, balanced shard of n_items (images or rays) for this rank."""
     base, rem = divmod(n_items, world)
@@ -148,6 +175,7 @@ def setup_data_parallel(graph: torch.nn.Module, seed: int = 0, group=None) -> tu
     rank = dist.get_rank(group) if dist.is_available() and dist.is_initialized() else 0
     world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
     broadcast_module_state(graph, src=0, group=group)
+    ranks_seen(group)                                     # (the job's warm collective; cached for the lines that report it)
     torch.manual_seed(seed + rank)
     return rank, world
 

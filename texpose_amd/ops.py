@@ -1227,6 +1227,52 @@ def stamp(slots: torch.Tensor, i: int) -> None:
     check(_lib.load().tp_stamp(slots.data_ptr() + 8 * i, _stream()), "tp_stamp")
 
 
+_hip_runtime = []
+
+
+def capture_node_count(stream=None):
+    """Number of nodes (kernel launches, fills, copies) recorded so far in the hipGraph that ``stream`` (default: the current one) is
+    capturing into, or None when it is not capturing: hipStreamGetCaptureInfo_v2 + hipGraphGetNodes on the runtime torch already
+    loaded.  The trainers report it per captured graph (`launch_counts`: the launches of one training iteration)."""
+    import ctypes
+    stream = stream or torch.cuda.current_stream()
+    if not _hip_runtime:
+        try:
+            _hip_runtime.append(ctypes.CDLL("libamdhip64.so"))
+        except OSError:
+            _hip_runtime.append(None)
+    hip = _hip_runtime[0]
+    if hip is None:
+        return None
+    status, gid, graph = ctypes.c_int(0), ctypes.c_ulonglong(0), ctypes.c_void_p(0)
+    deps, n_deps, n = ctypes.c_void_p(0), ctypes.c_size_t(0), ctypes.c_size_t(0)
+    rc = hip.hipStreamGetCaptureInfo_v2(ctypes.c_void_p(stream.cuda_stream), ctypes.byref(status), ctypes.byref(gid), ctypes.byref(graph),
+                                        ctypes.byref(deps), ctypes.byref(n_deps))
+    if rc != 0 or status.value != 1 or not graph.value:
+        return None
+    if hip.hipGraphGetNodes(graph, None, ctypes.byref(n)) != 0:
+        return None
+    return int(n.value)
+
+
+def clock_probe(windows: int = 16, window_us: int = 5000) -> torch.Tensor:
+    """Diagnostic: launch the clock sampler on the CURRENT stream (use a side stream, then launch the load on another one); returns
+    the int64 device tensor [windows, 2] it fills with (shader cycles, 100-MHz ticks) per window -- read it after a synchronise;
+    `clock_ghz_from_probe` folds it."""
+    out = torch.zeros(windows, 2, dtype=torch.int64, device="cuda")
+    check(_lib.load().tp_clock_probe(out.data_ptr(), int(windows), int(window_us), _stream()), "tp_clock_probe")
+    return out
+
+
+def clock_ghz_from_probe(out: torch.Tensor) -> float:
+    """Median shader clock in GHz over the probe's windows (the first and the last one left out when there are more than four)."""
+    w = out.cpu().double()
+    ghz = (w[:, 0] / w[:, 1].clamp(min=1)) * 0.1
+    if len(ghz) > 4:
+        ghz = ghz[1:-1]
+    return float(ghz.median())
+
+
 def step_inputs(copies, scalars=(), words=None, words_host=None) -> None:
     """The per-iteration host -> device state of a replayed step in ONE launch (K13 tp_step_inputs): ``copies`` = [(dst, src)]
     device tensors of equal byte size (the batch into the static inputs), ``scalars`` = [(0-dim float32 device tensor, value)],

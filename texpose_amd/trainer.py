@@ -487,6 +487,15 @@ def distinct_queue_streams(dev, n, candidates=8, votes=3):
     return chosen
 
 
+def streams_after_collectives(dev, n, group=None, probe=None):
+    """`distinct_queue_streams` ordered BEHIND the job's first collective: in a multi-rank process RCCL makes streams (and hardware
+    queues) of its own on its first collective, and a stream -> queue assignment probed before that is not the one the step runs
+    with.  `dist.ranks_seen` is that collective (a no-op once it has run, or without a process group)."""
+    tdist.ranks_seen(group)
+    assert tdist.warm_collective_done(group)
+    return (probe or distinct_queue_streams)(dev, n)
+
+
 class GraphedGanTrainer(GanTrainer):
     """The same iteration captured ONCE into a hipGraph and replayed.
 
@@ -866,23 +875,24 @@ class GraphedGanTrainer(GanTrainer):
         self._g4 = g = {k: torch.cuda.CUDAGraph() for k in ("D1", "G1", "F", "G2a", "G2b", "D2")}
         self._ev4 = {k: torch.cuda.Event() for k in ("sn", "patches", "feat", "g2", "d2")}
         # one memory pool per stream (see `_capture_four`); tensors that cross streams stay referenced for the life of the graphs
+        counts = self.launch_counts = {}                 # nodes per captured graph (kernel launches; TP_STAMPS adds two to each)
         with torch.cuda.graph(g["D1"], stream=side):
-            self._stamp("D1.0"); self._seg_sn(); self._stamp("D1.1")
+            self._stamp("D1.0"); self._seg_sn(); self._stamp("D1.1"); counts["D1"] = ops.capture_node_count()
         keep = [list(self.graph.discriminator._sn_queue)]
         with torch.cuda.graph(g["G1"], stream=cap):
-            self._stamp("G1.0"); var = self._seg_render(AttrDict(dict(self._static_in))); self._stamp("G1.1")
+            self._stamp("G1.0"); var = self._seg_render(AttrDict(dict(self._static_in))); self._stamp("G1.1"); counts["G1"] = ops.capture_node_count()
         keep.append(dict(var))
         with torch.cuda.graph(g["F"], stream=feat):
-            self._stamp("F.0"); self._seg_feat(var); self._stamp("F.1")
+            self._stamp("F.0"); self._seg_feat(var); self._stamp("F.1"); counts["F"] = ops.capture_node_count()
         keep.append(dict(var))
         with torch.cuda.graph(g["G2a"], stream=cap, pool=g["G1"].pool()):
-            self._stamp("G2a.0"); var, loss, g_disc = self._seg_gen_a(var); self._stamp("G2a.1")
+            self._stamp("G2a.0"); var, loss, g_disc = self._seg_gen_a(var); self._stamp("G2a.1"); counts["G2a"] = ops.capture_node_count()
         keep.append((dict(var), dict(loss), g_disc))
         with torch.cuda.graph(g["G2b"], stream=cap, pool=g["G1"].pool()):
-            self._stamp("G2b.0"); var, loss = self._seg_gen_b(var, loss, g_disc); self._stamp("G2b.1")
+            self._stamp("G2b.0"); var, loss = self._seg_gen_b(var, loss, g_disc); self._stamp("G2b.1"); counts["G2b"] = ops.capture_node_count()
         keep.append(dict(var))
         with torch.cuda.graph(g["D2"], stream=side, pool=g["D1"].pool()):
-            self._stamp("D2.0"); var, dloss = self._seg_disc(var); self._stamp("D2.1")
+            self._stamp("D2.0"); var, dloss = self._seg_disc(var); self._stamp("D2.1"); counts["D2"] = ops.capture_node_count()
         keep.append(dict(var))
         self._g4_keep = keep
         loss.update({k: v for k, v in dloss.items() if k != "all"})
@@ -1022,7 +1032,7 @@ class GraphedGanTrainer(GanTrainer):
         # the step's streams are made here, one after the other (main / capture, discriminator, feature chain): consecutive hardware queues
         if self._linear and (getattr(self, "_capture_stream", None) is None or self._side is None
                              or getattr(self.graph, "feat_stream", None) is None) and os.environ.get("TP_NO_QUEUE_PROBE") != "1":
-            self._capture_stream, self._side, self.graph.feat_stream = distinct_queue_streams(dev, 3)
+            self._capture_stream, self._side, self.graph.feat_stream = streams_after_collectives(dev, 3, self.red_nerf.group)
             self.queue_probe = dict(LAST_QUEUE_PROBE)                    # (bench lines report it: `train.queues`)
         if getattr(self, "_capture_stream", None) is None:
             self._capture_stream = torch.cuda.Stream(device=dev)
@@ -1055,14 +1065,19 @@ class GraphedGanTrainer(GanTrainer):
         elif self._four:
             self._capture_four(side)
         elif self._split_around_collectives():
+            self.launch_counts = {}
             with torch.cuda.graph(self._graph, stream=side):
                 self._static_loss = self._body_a(AttrDict(dict(self._static_in)))
+                self.launch_counts["A"] = ops.capture_node_count()
             self._graph_b = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._graph_b, stream=side, pool=self._graph.pool()):
                 self._body_b()
+                self.launch_counts["B"] = ops.capture_node_count()
         else:
+            self.launch_counts = {}
             with torch.cuda.graph(self._graph, stream=side):
                 self._static_loss = self._body(AttrDict(dict(self._static_in)))
+                self.launch_counts["step"] = ops.capture_node_count()
         self._restore(snap)
         flagged = self._read_bad(blocking=True)
         if flagged[0] and self._uses_f16x3():

@@ -188,9 +188,10 @@ def measure(device, rank: int, world: int, n_objects: int = 8, images_per_object
     achieved = MLP_FLOP_PER_SAMPLE * tot_samples / (tot_ms * 1e-3) / 1e12 if tot_ms else 0.0
     peak = F16_PEAK_TFLOPS if precision == "f16x3" else 157.3
     total_rays = n_objects * rays_obj
+    from texpose_amd import dist as tdist
     line = dict(
         metric="rendered rays/sec, C5 (8 objects x 8 images, 240x320 / 480x640 alternating, 256 samples per ray)",
-        value=total_rays / dt, unit="rays/s", n_gpus=world, steps=steps, warmup=warm, ms_per_step=dt * 1e3,
+        value=total_rays / dt, unit="rays/s", n_gpus=world, ranks_seen=tdist.ranks_seen(device=device), steps=steps, warmup=warm, ms_per_step=dt * 1e3,
         higher_is_better=True, scaling="strong", vs_baseline=None,
         dtype="f32 carried as 2xf16 (f16x3 products, f32 accumulate)" if precision == "f16x3" else "f32", data="synthetic",
         config=dict(workload="C5: %d independent object models (one Graph each: own weights / latents / poses / box), %d "

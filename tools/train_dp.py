@@ -83,7 +83,14 @@ def measure(device, rank, world, global_batch=32, iters=50, warm=5, graphed=True
     coll = None
     if getattr(trainer, "collective_events", None):
         coll = sum(a.elapsed_time(b) for a, b in trainer.collective_events) / len(trainer.collective_events)
-    return dict(collective_ms=coll, metric="train iters/sec", value=1.0 / dt, ms_per_iter=dt * 1e3, n_gpus=world, global_batch=global_batch,
+    if hasattr(trainer, "flush_flags"):
+        trainer.flush_flags()                              # (the last replay's gate words: a withheld final step raises here)
+    counts = getattr(trainer, "launch_counts", None)
+    return dict(collective_ms=coll, ranks_seen=tdist.ranks_seen(),
+                # nodes of the captured graphs of ONE iteration + the tp_step_inputs launch in front of them (None: eager loop)
+                launches=(sum(v for v in counts.values() if v) + 1) if counts and all(v is not None for v in counts.values()) else None,
+                launch_counts=counts, queues=getattr(trainer, "queue_probe", None),
+                metric="train iters/sec", value=1.0 / dt, ms_per_iter=dt * 1e3, n_gpus=world, global_batch=global_batch,
                 per_gpu_batch=global_batch // world, rays_per_iter=global_batch * 256, samples_per_iter=global_batch * 256 * 64,
                 launch=("six linear hipGraph replays on three streams (render | D(fake) + its backward | generator backward + Adam || feature chain || spectral norm | discriminator step)" if getattr(trainer, "_linear", False)
                         else "four hipGraph replays on two streams (render | generator step || spectral norm | discriminator step)" if getattr(trainer, "_four", False)
