@@ -92,3 +92,23 @@ def run(device, tmp_path):
     n = ck.restore_pretrained_trunk(graph3, torch.load(path, map_location=device, weights_only=False))
     assert n == 16
     assert_state_matches(man["restored_trunk_only"]["graph"], O.state_summary(graph3.state_dict()), "trunk-only graph")
+    # ---- G15b: save_checkpoint(children=..., latest=False) and restore_pretrain_nerf (reference util.py:225-263)
+    var = json.load(open(os.path.join(GOLDEN, "g15b_checkpoint_variants.json")))
+    out = tmp_path / "run"
+    main = ck.save_checkpoint_dir(str(out), graph, epoch=None, it=77, latest=False, children=tuple(var["children"]),
+                                  optim_nerf=tr.optim_nerf, optim_disc=tr.optim_disc, sched_nerf=sched)
+    copy = out / var["copy_relpath"]
+    assert main == str(out / "model.ckpt") and copy.exists() and open(main, "rb").read() == open(copy, "rb").read()
+    ours = O.checkpoint_manifest(torch.load(main, map_location="cpu", weights_only=False))
+    ref = var["saved_children"]
+    assert ours["top_level"] == ref["top_level"] and (ours["epoch"], ours["iter"]) == (ref["epoch"], ref["iter"]) == (None, 77)
+    assert_state_matches(ref["graph"], ours["graph"], "children graph")
+    assert all(k.startswith(tuple(var["children"])) for k in ours["graph"]) and len(ours["graph"]) == 34
+    assert_optim_matches(ref["optim_nerf"], ours["optim_nerf"], "children optim_nerf")      # (optimisers are saved whole)
+    ck.save_checkpoint_dir(str(out), graph, epoch=3, it=1234, latest=True, optim_nerf=tr.optim_nerf, optim_disc=tr.optim_disc,
+                           sched_nerf=sched)
+    assert not (out / "model" / "1234.ckpt").exists()                                        # latest=True: no copy
+    opt4, graph4, tr4, _ = build(device, salt=44)
+    ep, it = ck.restore_pretrain_nerf(graph4, torch.load(str(out / "model.ckpt"), map_location=device, weights_only=False))
+    assert (ep, it) == (var["restored_nerf_only"]["epoch"], var["restored_nerf_only"]["iter"]) == (None, None)
+    assert_state_matches(var["restored_nerf_only"]["graph"], O.state_summary(graph4.state_dict()), "nerf-only graph")

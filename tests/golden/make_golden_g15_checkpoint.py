@@ -91,6 +91,31 @@ def main():
     json.dump(manifest, open(path, "w"), indent=1, sort_keys=True)
     print("wrote", path, os.path.getsize(path), "bytes;", len(manifest["graph"]), "graph tensors;", sorted(manifest["top_level"]))
 
+    # ---- G15b: the two remaining variants of util.py:225-263
+    # (1) save_checkpoint(children=...) with latest=False: only the graph entries whose key starts with one of `children`, and a copy
+    #     of model.ckpt under model/<it>.ckpt; (2) restore_pretrain_nerf: only the `nerf` child is taken from pretrain_model_real.ckpt.
+    variants = {}
+    out2 = tempfile.mkdtemp()
+    opt.output_path = out2
+    children = ("nerf", "latent_vars_light")
+    util.save_checkpoint(opt, a, ep=None, it=77, latest=False, children=children)
+    main_file, copy_file = os.path.join(out2, "model.ckpt"), os.path.join(out2, "model", "77.ckpt")
+    assert os.path.exists(copy_file) and open(main_file, "rb").read() == open(copy_file, "rb").read()
+    blob2 = torch.load(main_file, map_location="cpu", weights_only=False)
+    variants["children"] = list(children)
+    variants["saved_children"] = O.checkpoint_manifest(blob2)
+    variants["copy_relpath"] = "model/77.ckpt"
+    # a full checkpoint as the real-data pre-training stage leaves it
+    util.save_checkpoint(opt, a, ep=3, it=1234, latest=True)
+    os.replace(os.path.join(out2, "model.ckpt"), os.path.join(out2, "pretrain_model_real.ckpt"))
+    d = model(4)
+    d.graph.load_state_dict(O.seeded_state(d.graph.state_dict(), salt=44))
+    ep, it = util.restore_pretrain_nerf(opt, d, resume=True)
+    variants["restored_nerf_only"] = dict(epoch=ep, iter=it, graph=O.state_summary(d.graph.state_dict()))
+    path = os.path.join(HERE, "g15b_checkpoint_variants.json")
+    json.dump(variants, open(path, "w"), indent=1, sort_keys=True)
+    print("wrote", path, os.path.getsize(path), "bytes;", len(variants["saved_children"]["graph"]), "graph tensors in the children file")
+
 
 if __name__ == "__main__":
     main()

@@ -701,6 +701,50 @@ def test_render_by_slices_g9(ops):
             assert ev["density"].shape == g9["eval_density"].shape
 
 
+def test_eval_nerf_forward_picks_the_reference_light_latent_g18(ops):
+    """Graph.nerf_forward(mode='eval_noalign') on cuda:0 against golden G18 (the reference's evaluation branch,
+    model/nerf_adapt_st_gan.py:485-502): for every (N_candidate, seed) case the row of latent_vars_light that reaches
+    render_by_slices is the one the reference's seeded randperm draw picked; the render of one case matches the reference's
+    per-ray outputs (5e-3: from intrinsics, see G9) and is BIT-identical to a render_by_slices call with the golden row, while a
+    different row gives a different image (the pick matters)."""
+    from texpose_amd.options import AttrDict
+    g = load_golden("g18_eval_latent")
+    graph, opt = _graph(O.make_params(g["seed_w"]), n_train=g["n_train"], emb_seed=g["emb_seed"], H=g["H"], W=g["W"], N=g["N"])
+    opt.nerf.sample_stratified = False
+    opt.nerf.rand_rays = 48
+    seen = []
+    orig = graph.render_by_slices
+
+    def spy(opt_, pose, intr=None, depth_range=None, object_mask=None, sample_idx=None, mode=None):
+        seen.append(sample_idx)
+        return orig(opt_, pose, intr=intr, depth_range=depth_range, object_mask=object_mask, sample_idx=sample_idx, mode=mode)
+
+    graph.render_by_slices = spy
+    base = dict(idx=torch.tensor([0], device=dev()), pose=cu(g["pose"]), pose_init=cu(g["pose"]), intr=cu(g["intr"]),
+                z_near=cu(g["z_near"]), z_far=cu(g["z_far"]), obj_mask=cu(g["mask"])[None], pose_anchor=cu(g["pose_anchor"]))
+    rk, rseed = g["render_case"].tolist()
+    rendered = None
+    with torch.no_grad():
+        for k, seed, picked in g["cases"].tolist():
+            opt.render.N_candidate = k
+            torch.manual_seed(seed)
+            var = graph.nerf_forward(opt, AttrDict(dict(base)), mode="eval_noalign")
+            assert seen[-1].is_cuda and int(seen[-1]) == picked, (k, seed, int(seen[-1]), picked)
+            if (k, seed) == (rk, rseed):
+                rendered = (var, picked)
+        var, picked = rendered
+        for key in ("rgb", "rgb_static", "depth", "uncert", "opacity_static", "opacity"):
+            torch.testing.assert_close(var[key].cpu(), g["render_" + key], rtol=5e-3, atol=5e-4)
+        dr = (base["z_near"][:, :, None], base["z_far"][:, :, None])
+        same = orig(opt, base["pose"], intr=base["intr"], depth_range=dr, object_mask=base["obj_mask"],
+                    sample_idx=torch.tensor(picked, device=dev()), mode="eval_noalign")
+        other = orig(opt, base["pose"], intr=base["intr"], depth_range=dr, object_mask=base["obj_mask"],
+                     sample_idx=torch.tensor((picked + 1) % g["n_train"], device=dev()), mode="eval_noalign")
+    assert torch.equal(same.rgb, var.rgb) and torch.equal(same.rgb_static, var.rgb_static)
+    assert float((other.rgb_static - var.rgb_static).abs().max()) > 1e-3
+    ops.check_mlp_status(dev())
+
+
 def test_losses_and_patch_pipeline_g10(ops):
     from texpose_amd.graph import Graph, summarize_loss
     from texpose_amd.options import AttrDict, default_options
@@ -1148,6 +1192,138 @@ def test_train_iterations_match_reference_g13(ops):
         # bulk (relative L2) and bound the fraction of entries that moved differently
         assert float((d - ref).norm() / ref.norm()) < 0.12, (k, float((d - ref).norm() / ref.norm()))
         assert float(((d - ref).abs() > 0.25 * step).double().mean()) < 0.03, k
+
+
+def test_discriminator_matches_reference_g12_on_gpu(ops):
+    """Golden G12 (the REFERENCE's Discriminator: layers/discriminator.py:117-141, R1 penalty model/nerf_adapt_st_gan.py:794-807) on
+    cuda:0 through the HIP kernels -- spectral normalisation K7, stride-2 convolutions K11, InstanceNorm + LeakyReLU K9, full-map
+    convolution K15 / fused tail K17, head K14 -- and `Graph.compute_grad2`'s double backward through their differentiable nodes:
+    logits rtol 1e-4 / atol 1e-6, the per-sample squared-gradient penalty 1e-4, the BCE value 1e-5.  Eval mode as in the golden (no
+    power iteration), then the same weights with the fused frozen-weight forward (the nerf step's pass): same logits."""
+    from texpose_amd import autograd_ops
+    from texpose_amd.gan_modules import Discriminator
+    from texpose_amd.graph import Graph
+    from texpose_amd.options import default_options
+    g = load_golden("g12_discriminator")
+    opt = default_options(device="cuda:0")
+    d = Discriminator(opt)
+    O.seed_spectral_module(d, g["seed"])
+    d = d.to(dev()).eval()
+    x = cu(g["x"]).clone().requires_grad_()
+    out = d(opt, x, cu(g["scale"]))
+    assert "DiscTail" not in type(out.grad_fn).__name__                   # (differentiable nodes: a double backward follows)
+    torch.testing.assert_close(out.detach().cpu(), g["d_out"], rtol=1e-4, atol=1e-6)
+    reg = Graph.compute_grad2(opt, out, x)
+    torch.testing.assert_close(reg.detach().cpu(), g["grad2"], rtol=1e-4, atol=1e-8)
+    torch.testing.assert_close(Graph.compute_gan_loss(opt, out, 1).detach().cpu(), torch.as_tensor(g["bce_real"]), rtol=1e-5, atol=1e-6)
+    # the penalty's gradient wrt the weights exists and is finite (what disc_trainstep back-propagates)
+    grads = torch.autograd.grad(reg.mean(), [c.weight_orig for c in d.sn_convs()])
+    assert all(bool(torch.isfinite(t).all()) and float(t.abs().sum()) > 0 for t in grads)
+    for q in d.parameters():
+        q.requires_grad_(False)
+    with autograd_ops.first_order_only():
+        out2 = d(opt, cu(g["x"]).clone().requires_grad_(), cu(g["scale"]))
+    torch.testing.assert_close(out2.detach().cpu(), g["d_out"], rtol=1e-4, atol=1e-6)
+
+
+def _g13b_setup(G):
+    from texpose_amd.gan_modules import Discriminator
+    from texpose_amd.graph import Graph
+    from texpose_amd.options import default_options, AttrDict
+    from texpose_amd.synthetic import training_batch
+    from texpose_amd.trainer import GanTrainer
+    B, H, W, P, N, n_train = (int(G[k]) for k in ("B", "H", "W", "P", "N", "n_train"))
+    opt = default_options(H=H, W=W, device="cuda:0")
+    opt.batch_size, opt.patch_size, opt.nerf.sample_intvs = B, P, N
+    opt.loss_weight.feat = None
+    graph = Graph(opt, discriminator=Discriminator(opt)).to(dev())
+    disc_cpu = Discriminator(opt)
+    O.seed_spectral_module(disc_cpu, int(G["seed_d"]))
+    sd = disc_cpu.state_dict()
+    for k in list(sd):                                        # u / v as the reference's disc step found them (after the nerf step's pass)
+        if "in." + k in G:
+            sd[k] = G["in." + k]
+    graph.discriminator.load_state_dict(sd)
+    graph.attach_latents(n_train, opt)
+    graph.train()
+    tr = GanTrainer(opt, graph, n_train=n_train)
+    batch = training_batch(B, H, W, n_train=n_train, seed=int(G["seed_b"]), device="cuda:0")
+    var = AttrDict({k: v.clone() for k, v in batch.items()})
+    var.ray_idx, var.ray_scales, var.rgb = cu(G["ray_idx"]), cu(G["ray_scales"]), cu(G["rgb"])
+    var.uncert = torch.ones(B, P * P, 1, device=dev())       # (compute_loss views it before it branches on the step, as the reference does)
+    var = graph.gather_patches(opt, var)
+    return opt, graph, tr, var
+
+
+def _g13b_check(G, graph, var, dloss, gtol=2e-5):
+    stride = int(G["stride"])
+    torch.testing.assert_close(var.patch_real.detach().cpu(), G["patch_real"], rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(var.patch_fake.detach().cpu(), G["patch_fake"], rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(var.d_real_disc.detach().cpu(), G["d_real"], rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(var.d_fake_disc.detach().cpu(), G["d_fake"], rtol=1e-4, atol=1e-6)
+    for k in ("gan_disc_real", "gan_disc_fake", "gan_reg_real"):
+        # (the reference leaves every term scaled by its 10^w, in place: :145-153; the mirror scales only the R1 term it logs)
+        ours = float(dloss[k].detach()) * (float(G["w." + k]) if k != "gan_reg_real" else 1.0)
+        assert abs(ours - float(G["dloss." + k])) <= 1e-4 * abs(float(G["dloss." + k])) + 1e-7, (k, ours, float(G["dloss." + k]))
+    errs = {}
+    for name, q in graph.discriminator.named_parameters():
+        key = "grad." + name
+        if key + ".norm" not in G:
+            continue
+        t = q.grad.detach().reshape(-1).double().cpu()
+        ref = G[key].double() if key in G else G[key + ".sub"].double()
+        if key not in G:
+            assert abs(float(t.norm()) / float(G[key + ".norm"]) - 1) < gtol, (name, float(t.norm()), float(G[key + ".norm"]))
+            t = t[::stride]
+        errs[name] = float((t - ref).norm() / ref.norm())
+        assert errs[name] < gtol, (name, errs[name])
+    assert len(errs) == 6
+    return errs
+
+
+@pytest.mark.parametrize("form", ["schedule", "autograd", "schedule-graphed"])
+def test_disc_step_matches_reference_g13b(ops, form, monkeypatch):
+    """Golden G13b: the REFERENCE's disc_trainstep of iteration 0 (model/nerf_adapt_st_gan.py:129-171, 794-807) fed with the
+    reference's OWN render, patch coordinates, scales and power-iteration state (no render in the loop) -- D(real) + BCE, the R1
+    double backward, D(fake) + BCE in training mode (two power iterations): patches, logits, the three loss values, ALL SIX
+    weight_orig gradients to 2e-5 (rel-L2 of the strided subsample + the full norm; measured 1.0-1.5e-6) and weight_u / weight_v afterwards; through the
+    explicit launch schedule K16 (eager and replayed from a hipGraph) and through the autograd form over the same kernels."""
+    G = load_golden("g13b_disc_step")
+    if form == "autograd":
+        monkeypatch.setenv("TP_DISC_AUTOGRAD", "1")
+    opt, graph, tr, var = _g13b_setup(G)
+    if form != "schedule-graphed":
+        var, dloss = tr.disc_step(var, apply=False)
+        assert (tr.__dict__.get("_disc_sched") is not None) == (form == "schedule")
+    else:
+        for q in graph.discriminator.parameters():
+            q.grad = None
+        state = {k: v.clone() for k, v in graph.discriminator.state_dict().items()}
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            tr.disc_step(var, apply=False)                     # warm-up (advances u / v: restored below)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        with torch.no_grad():
+            for k, v in graph.discriminator.state_dict().items():
+                v.copy_(state[k])
+        cg = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(cg, stream=side):
+            var, dloss = tr.disc_step(var, apply=False)
+        with torch.no_grad():
+            for k, v in graph.discriminator.state_dict().items():
+                v.copy_(state[k])
+            for q in graph.discriminator.parameters():
+                if q.grad is not None:
+                    q.grad.zero_()
+        cg.replay()
+        torch.cuda.synchronize()
+    errs = _g13b_check(G, graph, var, dloss)
+    for k, v in graph.discriminator.state_dict().items():
+        if "out." + k in G:
+            assert rel_l2(v.cpu(), G["out." + k]) < 1e-5, k
+    print("G13b %s: weight_orig gradient rel-L2 vs the reference:" % form, {k: "%.1e" % v for k, v in errs.items()})
 
 
 def assert_updates_close(sd_a, sd_b, snap, rel=0.05, frac=0.01):
@@ -1635,6 +1811,19 @@ def test_full_size_render_properties(ops):
         assert float(keep["uncert"].min()) >= 0.05
     for k in ("rgb", "rgb_static", "depth", "uncert"):
         torch.testing.assert_close(outs["f16x3"][k], outs["fp32"][k], rtol=1e-4, atol=1e-6)
+    # The ORACLE on the full-size image directly: 8,192 rays strided over all 307,200 (every 37th pixel: all image regions, object and
+    # background bounds), 128 samples each = 1 M samples through the CPU restatement (~10 s), consuming the rays the HIP ray-gen
+    # produced for exactly those pixels (sample positions are ill-conditioned upstream of the encoding: DESIGN section 2); both
+    # arithmetics of the full-size render must match it at north_star's bar, rtol 1e-4 / atol 1e-6.
+    sub = torch.arange(0, H * W, 37, device=dev())[:8192]
+    center, ray, _, _, depth = ops.raygen(intr, pose, H=H, W=W, n_samples=bench.N_SAMPLES, ray_idx=sub[None], z_near=dr[0], z_far=dr[1])
+    with torch.no_grad():
+        r_o, d_o, u_o = O.forward_samples(params, center.cpu(), ray.cpu(), depth.cpu()[..., None], emb_t[:1], emb_l[:1])
+        ref = O.composite(ray.cpu(), r_o, d_o, depth.cpu()[..., None], u_o, 0.05)
+    names = {"rgb": 0, "rgb_static": 1, "depth": 3, "opacity": 4, "opacity_static": 5, "uncert": 8}
+    for prec in ("fp32", "f16x3"):
+        for k, i in names.items():
+            torch.testing.assert_close(outs[prec][k][:, sub].cpu(), ref[i], rtol=1e-4, atol=1e-6, msg=lambda m: "%s %s: %s" % (prec, k, m))
 
 
 # ------------------------------------------------------------------------------------------ K9 (f1)

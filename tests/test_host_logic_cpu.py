@@ -326,3 +326,26 @@ def test_disc_step_schedule_structure_and_eligibility():
     d._sn_queue.append(("stale",))
     with pytest.raises(RuntimeError):
         d.prefetch_spectral_weights(1)                                    # an unconsumed queue is an error
+
+
+def test_eval_light_latent_pick_g18():
+    """Graph.eval_light_index (reference model/nerf_adapt_st_gan.py:487-494, camera.py:345-350) against golden G18 -- the REFERENCE's
+    rotation distances (bit for bit), its top-k candidates and the row its seeded `torch.randperm` draw handed to the renderer, for
+    N_candidate 1 / 2 / 3 and several seeds (two anchors are nearly tied at 0.034 / 0.039 rad)."""
+    from conftest import load_golden
+    from texpose_amd.graph import Graph
+    from texpose_amd.options import AttrDict
+    g = load_golden("g18_eval_latent")
+    opt = default_options(device="cpu")
+    var = AttrDict(pose=g["pose"], pose_anchor=g["pose_anchor"])
+    assert torch.equal(rotation_distance(var.pose[..., :3, :3], var.pose_anchor[..., :3, :3]), g["R_dist"])
+    picks = set()
+    for k, seed, picked in g["cases"].tolist():
+        opt.render.N_candidate = k
+        cand = torch.topk(g["R_dist"][:, None], k=k, dim=0, largest=False, sorted=True)[1][:, 0]
+        assert torch.equal(cand, g["k%d_s%d_cand" % (k, seed)])
+        torch.manual_seed(seed)
+        idx = Graph.eval_light_index(opt, var)
+        assert idx.dim() == 0 and int(idx) == picked == int(g["k%d_s%d_picked" % (k, seed)])
+        picks.add(picked)
+    assert len(picks) >= 3

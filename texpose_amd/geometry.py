@@ -45,8 +45,9 @@ def compose_poses(*poses):
 def rotation_distance(R1, R2, eps=1e-7):
     """Geodesic angle between rotation matrices; evaluate_full uses it to pick the light latent of the
     nearest training view (reference camera.py:345-350, model/nerf_adapt_st_gan.py:489-494)."""
-    cos = ((R1 @ R2.transpose(-2, -1)).diagonal(dim1=-2, dim2=-1).sum(-1) - 1) / 2
-    return torch.acos(cos.clamp(-1 + eps, 1 - eps))
+    d = R1 @ R2.transpose(-2, -1)
+    trace = d[..., 0, 0] + d[..., 1, 1] + d[..., 2, 2]             # (left to right, as the reference adds them: golden G18 is bit-exact)
+    return torch.acos(((trace - 1) / 2).clamp(-1 + eps, 1 - eps))
 
 
 # ----------------------------------------------------------------------------- rays

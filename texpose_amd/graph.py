@@ -256,6 +256,15 @@ class Graph(torch.nn.Module):
         var.nocs_sample, var.normal_sample = var.nocs_pred * ms, var.normal_pred * ms
         return var
 
+    @staticmethod
+    def eval_light_index(opt, var):
+        """Row of ``latent_vars_light`` an evaluation render uses (reference model/nerf_adapt_st_gan.py:487-494): one of the
+        ``opt.render.N_candidate`` anchor (training) poses nearest in rotation to the test pose (camera.py:345-350), drawn with
+        ``torch.randperm`` from the global CPU generator exactly as the reference draws it.  0-dim index tensor on the poses' device."""
+        R_dist = rotation_distance(var.pose[..., :3, :3], var.pose_anchor[..., :3, :3]).unsqueeze(-1)
+        cand = torch.topk(R_dist, k=int(opt.render.N_candidate), dim=0, largest=False, sorted=True)[1]
+        return cand[torch.randperm(len(cand))[0]][0]
+
     def nerf_forward(self, opt, var, mode=None, stage=None):
         """``stage`` (the captured training step that runs as several hipGraphs, trainer.GraphedGanTrainer): "render" = everything up
         to the discriminator's patch stacks (render, gathers, K13 stacks), "consume" = the rest (feature chain, the discriminator's
@@ -271,9 +280,7 @@ class Graph(torch.nn.Module):
                 ret = self.render_by_slices(opt, pose, intr=var.intr, depth_range=depth_range, object_mask=var.obj_mask,
                                             sample_idx=None, mode=mode)
             else:
-                R_dist = rotation_distance(var.pose[..., :3, :3], var.pose_anchor[..., :3, :3]).unsqueeze(-1)
-                cand = torch.topk(R_dist, k=int(opt.render.N_candidate), dim=0, largest=False, sorted=True)[1]
-                light_idx = cand[torch.randperm(len(cand))[0]][0]
+                light_idx = self.eval_light_index(opt, var)
                 ret = self.render_by_slices(opt, pose, intr=var.intr, depth_range=depth_range, object_mask=var.obj_mask,
                                             sample_idx=light_idx, mode=mode)
             var.update(ret)
