@@ -26,7 +26,7 @@ extern "C" {
 
 typedef void* tp_stream_t; /* hipStream_t */
 
-#define TP_ABI_VERSION 8
+#define TP_ABI_VERSION 9
 
 int tp_abi_version(void);
 const char* tp_last_error(void);
@@ -465,6 +465,32 @@ typedef struct tp_feat_inputs_args {
 } tp_feat_inputs_args;
 int tp_feat_inputs_fwd(const tp_feat_inputs_args* args, float* out, tp_stream_t stream);
 int tp_feat_inputs_bwd(const tp_feat_inputs_args* args, const float* g_out, float* g_rgb, tp_stream_t stream);
+/* K18 -- the whole feature-loss chain of the generator step in ONE call (17 launches): the four image stacks (tp_feat_inputs_fwd), the
+ * frozen feature network F = torchvision VGG19 features[:15] (reference layers/perceptual_loss.py:8-45: 3x3 convolutions 3-64, 64-64,
+ * max pool, 64-128, 128-128, max pool, 128-256, 256-256, 256-256, ReLU after each but the last), the two-pair loss
+ * model/nerf_adapt_st_gan.py:758-766   loss = mse(F(fake1), F(real1)) + w2 mse(F(fake2), F(real2))   (targets detached)
+ * and its gradient wrt the rendered colours: g_rgb = scale * d loss / d rgb.  Pools, ReLU derivatives and un-pooling ride in the
+ * convolutions' epilogues; only the 2B fake images are differentiated.  16 x 16 patches (the reference's patch_size).
+ * loss[3] = {l1 + w2 l2, l1, l2}.  workspace / counters: sizes from tp_feat_chain_workspace; the counters must be zero before the first
+ * call and are left zero; both belong to ONE stream (calls that may overlap on different streams need their own). */
+#define TP_FEAT_CHAIN_LAYERS 7
+typedef struct tp_feat_chain_args {
+  const float* rgb;        /* [B,P,3] rendered colours, P = H * W */
+  const float* gathered;   /* [B,n_channels,P] tp_patch_gather output */
+  int32_t B, H, W, n_channels;
+  int32_t c_image, c_image_syn, c_mask, c_mask_syn;   /* first channel of each in `gathered` */
+  float mean[3], std[3];                               /* ImageNet normalisation constants */
+  const float* w[TP_FEAT_CHAIN_LAYERS];                /* [Co,C,3,3] of the seven convolutions, in order */
+  const float* bias[TP_FEAT_CHAIN_LAYERS];             /* [Co] */
+  float w2;                /* weight of the second pair (the reference: 5) */
+  float scale;             /* cotangent of the loss (the caller's loss weight 10^w; 1 for the plain gradient) */
+  float* loss;             /* [3] */
+  float* g_rgb;            /* [B,P,3] */
+  float* workspace; int64_t workspace_floats;
+  int32_t* counters; int64_t n_counters;
+} tp_feat_chain_args;
+int64_t tp_feat_chain_workspace(int32_t B, int32_t H, int32_t W, int64_t* n_counters);   /* floats; -1: shape not covered */
+int tp_feat_chain(const tp_feat_chain_args* args, tp_stream_t stream);
 /* The discriminator step's inputs (model/nerf_adapt_st_gan.py:478-497, no gradient): real [B,nc,P] = image m + rgb pad,
  * fake [B,nc,P] = rgb, nc = 3 or (geo) 9 with the masked nocs / normal channels 6..11 of `gathered` [B,14,P] appended. */
 /* Step gate of a captured training step (the reference asserts every weighted loss term finite on the host,

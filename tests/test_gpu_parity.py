@@ -2277,6 +2277,57 @@ def test_feature_loss_from_patches_matches_torch(ops):
     assert rel_l2(gr, grd) < 1e-5
 
 
+@pytest.mark.parametrize("B", [1, 3, 4])
+def test_feat_chain_one_call_matches_torch_fp64_and_the_general_pieces(ops, B, monkeypatch):
+    """K18 tp_feat_chain (csrc/feat_chain.hip: input stacks, VGG19 features[:15] with pools / ReLU derivatives / un-pooling in the
+    convolutions' epilogues, pair loss + cotangent in one launch, backward through the 2B fake images only) against the reference's
+    expression (model/nerf_adapt_st_gan.py:758-766 over layers/perceptual_loss.py:8-45) through the stock network in fp64: the loss, its
+    two terms and d loss / d rgb; against the round-4 composition of general pieces (TP_NO_FEAT_CHAIN=1); run-to-run bit-identical;
+    `scale` multiplies the gradient exactly."""
+    import copy
+    from texpose_amd.gan_modules import PerceptualLoss
+    torch.manual_seed(20 + B)
+    h = w = 16
+    net = PerceptualLoss().to(dev())
+    with torch.no_grad():
+        for m in net.model:                          # (biases away from zero: the default init's are tiny)
+            if isinstance(m, torch.nn.Conv2d):
+                m.bias.add_(0.05 * torch.randn_like(m.bias))
+    ref = copy.deepcopy(net).cpu().double()
+    rgb0 = torch.rand(B, h * w, 3, device=dev())
+    g = torch.rand(B, 14, h, w, device=dev())
+    g[:, 12] = (g[:, 12] > 0.4).float()
+    g[:, 13] = (g[:, 13] > 0.3).float()
+    assert net.chain_eligible(rgb0, g, (h, w))
+    r = rgb0.clone().requires_grad_()
+    loss = net.loss_from_patches(r, g, (h, w), 5.0)
+    assert "FeatChainLoss" in type(loss.grad_fn).__name__
+    gr, = torch.autograd.grad(loss, r)
+    ws, bs = net._chain_params()
+    loss3, g1 = ops.feat_chain(rgb0, g, ws, bs, net._mean_host, net._std_host, (h, w), 5.0, 1.0)
+    loss3b, g2 = ops.feat_chain(rgb0, g, ws, bs, net._mean_host, net._std_host, (h, w), 5.0, 0.125)
+    assert torch.equal(loss3, loss3b) and torch.equal(g1, gr) and torch.equal(g2, g1 * 0.125)
+    assert torch.equal(loss3[0], loss.detach())
+    # fp64 restatement of the reference through the stock modules
+    rd, gd = rgb0.double().cpu().requires_grad_(), g.double().cpu()
+    rgb = rd.view(B, h, w, 3).permute(0, 3, 1, 2)
+    image, image_syn, obj_mask, mask_syn = gd[:, 0:3], gd[:, 3:6], gd[:, 12:13], gd[:, 13:14]
+    pad = torch.logical_and(mask_syn == 1, obj_mask == 0).double()
+    feat = lambda t: ref.model((t - ref.mean) / ref.std)
+    l1d = F.mse_loss(feat(rgb), feat(image * obj_mask + image_syn * pad))
+    l2d = F.mse_loss(feat(rgb * obj_mask + image * (1 - obj_mask)), feat(image))
+    grd, = torch.autograd.grad(l1d + 5 * l2d, rd)
+    assert rel_l2(loss3[1], l1d) < 1e-5 and rel_l2(loss3[2], l2d) < 1e-5 and rel_l2(loss3[0], l1d + 5 * l2d) < 1e-5
+    assert rel_l2(gr, grd) < 1e-5, rel_l2(gr, grd)
+    # the general pieces (K13 inputs, K12 convolutions, pools, pair loss under autograd)
+    monkeypatch.setenv("TP_NO_FEAT_CHAIN", "1")
+    r2 = rgb0.clone().requires_grad_()
+    old = net.loss_from_patches(r2, g, (h, w), 5.0)
+    assert "FeatChainLoss" not in type(old.grad_fn).__name__
+    go, = torch.autograd.grad(old, r2)
+    assert rel_l2(loss, old) < 2e-6 and rel_l2(gr, go) < 5e-6
+
+
 # ------------------------------------------------------------------------------------------ round-3 K13 additions
 def test_composite_compact_outputs_and_cotangents(ops):
     """tp_composite_fwd's compact rgb / uncert copies equal columns 0..2 / 13 of out_ray bit for bit; tp_composite_bwd with the

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # TEXPOSE_AMD_LIB selects another build of the SAME library (e.g. the `make trace` diagnostic build); never a fallback
 LIB_PATH = os.environ.get("TEXPOSE_AMD_LIB") or os.path.join(_HERE, "libtexpose_amd.so")
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 # Every symbol include/texpose_amd.h declares (checked by tests/test_capi_cpu.py).
 SYMBOLS = (
@@ -36,6 +36,7 @@ SYMBOLS = (
     "tp_disc_head_fwd", "tp_disc_head_bwd", "tp_disc_head_bwd_bwd",
     "tp_skinny_linear_fwd", "tp_skinny_linear_wgrad", "tp_skinny_linear_dgrad",
     "tp_disc_tail_workspace_bytes", "tp_disc_tail_fwd", "tp_disc_tail_bwd", "tp_disc_tail_bwd_bwd",
+    "tp_feat_chain_workspace", "tp_feat_chain",
 )
 
 vp = C.c_void_p
@@ -143,6 +144,13 @@ class FeatInputsArgs(C.Structure):
                 ("mean", C.c_float * 3), ("std", C.c_float * 3)]
 
 
+class FeatChainArgs(C.Structure):
+    _fields_ = [("rgb", vp), ("gathered", vp), ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("n_channels", C.c_int32),
+                ("c_image", C.c_int32), ("c_image_syn", C.c_int32), ("c_mask", C.c_int32), ("c_mask_syn", C.c_int32),
+                ("mean", C.c_float * 3), ("std", C.c_float * 3), ("w", vp * 7), ("bias", vp * 7), ("w2", C.c_float), ("scale", C.c_float),
+                ("loss", vp), ("g_rgb", vp), ("workspace", vp), ("workspace_floats", C.c_int64), ("counters", vp), ("n_counters", C.c_int64)]
+
+
 class Conv3s1Args(C.Structure):
     _fields_ = [("inp", vp), ("w", vp), ("bias", vp), ("mask", vp), ("out", vp), ("workspace", vp), ("counters", vp),
                 ("N", C.c_int32), ("C", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Co", C.c_int32), ("relu", C.c_int32)]
@@ -247,6 +255,8 @@ def load() -> C.CDLL:
     sig("tp_patch_coords", [vp, C.c_int, C.c_int, vp, vp, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, C.c_uint64, vp, vp, vp, vp])
     sig("tp_bce_logits_fwd", [vp, C.c_int, C.c_float, vp, vp])
     sig("tp_bce_logits_bwd", [vp, C.c_int, C.c_float, vp, vp, vp])
+    sig("tp_feat_chain_workspace", [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int64)], C.c_int64)
+    sig("tp_feat_chain", [C.POINTER(FeatChainArgs), vp])
     sig("tp_feat_inputs_fwd", [C.POINTER(FeatInputsArgs), vp, vp])
     sig("tp_feat_inputs_bwd", [C.POINTER(FeatInputsArgs), vp, vp, vp])
     sig("tp_disc_inputs", [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp])

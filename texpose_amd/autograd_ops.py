@@ -305,6 +305,31 @@ def feat_inputs(rgb, gathered, mean, std, hw):
     return _FeatInputs.apply(rgb.contiguous(), gathered, tuple(mean), tuple(std), tuple(hw))
 
 
+# ---- K18: the whole feature-loss chain (inputs, frozen network, pair loss, data gradient) as one call
+class _FeatChainLoss(torch.autograd.Function):
+    """loss = P(fake1, real1) + w2 P(fake2, real2) of the generator step from rgb [B,P,3] and the gathered patches; the gradient wrt rgb is
+    computed together with the value (tp_feat_chain) and scaled by the incoming cotangent in backward.  First order only."""
+
+    @staticmethod
+    def forward(ctx, rgb, gathered, mean, std, hw, w2, weights_and_biases):
+        ws, bs = weights_and_biases
+        loss3, g_rgb = ops.feat_chain(rgb, gathered, ws, bs, mean, std, hw, w2, 1.0)
+        ctx.save_for_backward(g_rgb)
+        return loss3[0].clone(), loss3
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g, _g3):
+        (g_rgb,) = ctx.saved_tensors
+        return g_rgb * g, None, None, None, None, None, None
+
+
+def feat_chain_loss(rgb, gathered, mean, std, hw, w2, weights, biases):
+    """-> (loss, parts [3] = {loss, l1, l2} detached)."""
+    loss, parts = _FeatChainLoss.apply(rgb.contiguous(), gathered, tuple(mean), tuple(std), tuple(hw), float(w2), (list(weights), list(biases)))
+    return loss, parts.detach()
+
+
 # ---- K14: the scale-conditioned head of the PatchGAN, one launch per derivative order
 class _DiscHeadBackward(torch.autograd.Function):
     """(gz, gW1, gW2, gW3) of the head; differentiable once more for the R1 penalty, whose cotangent reaches gz only (the

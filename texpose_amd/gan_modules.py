@@ -355,10 +355,39 @@ class PerceptualLoss(nn.Module):
         """P(fake1, real1) + w2 P(fake2, real2) of the generator step (reference model/nerf_adapt_st_gan.py:762-766) as three
         launch groups: inputs (K13 tp_feat_inputs), one pass through the feature network (K12), the two mean squared
         differences and their weighted sum (K13 tp_feat_pair_loss)."""
-        from . import autograd_ops
+        from . import autograd_ops, ops
+        if self.chain_eligible(rgb, gathered, hw):
+            # K18: the chain written out as 17 launches, value and d / d rgb from ONE call (pools, ReLU derivatives and un-pooling in the
+            # convolutions' epilogues, backward through the 2B fake images only)
+            ws, bs = self._chain_params()
+            loss, _parts = autograd_ops.feat_chain_loss(rgb, gathered, self._mean_host, self._std_host, hw, w2, ws, bs)
+            return loss
         x = autograd_ops.feat_inputs(rgb, gathered, self._mean_host, self._std_host, hw)
         loss, _parts = autograd_ops.feat_pair_loss(self.features(x), w2)
         return loss
+
+    def _chain_params(self):
+        convs = [m for m in self.model if isinstance(m, nn.Conv2d)]
+        return [c.weight for c in convs], [c.bias for c in convs]
+
+    def chain_eligible(self, rgb, gathered, hw):
+        """tp_feat_chain covers the stock configuration: the seven frozen 3x3 convolutions of `CFG`, float32 CUDA tensors, 16 x 16
+        patches; anything else (an injected network, other patch sizes, trainable weights) takes the general pieces."""
+        from . import ops
+        convs = [m for m in self.model if isinstance(m, nn.Conv2d)]
+        return (ops.feat_chain_supported(rgb, gathered, hw) and len(convs) == 7 and len(list(self.model)) == 15
+                and all(c.kernel_size == (3, 3) and c.stride == (1, 1) and c.padding == (1, 1) and c.bias is not None
+                        and not c.weight.requires_grad and c.weight.is_cuda and c.weight.is_contiguous() for c in convs)
+                and [tuple(c.weight.shape[:2]) for c in convs] == [(64, 3), (64, 64), (128, 64), (128, 128), (256, 128), (256, 256), (256, 256)])
+
+    def loss_and_grad_from_patches(self, rgb, gathered, hw, w2: float = 5.0, scale: float = 1.0):
+        """(loss, scale * d loss / d rgb) without autograd (the captured training step's feature graph): K18 when eligible, else None."""
+        from . import ops
+        if not self.chain_eligible(rgb, gathered, hw):
+            return None
+        ws, bs = self._chain_params()
+        loss3, g_rgb = ops.feat_chain(rgb.detach(), gathered, ws, bs, self._mean_host, self._std_host, hw, w2, scale)
+        return loss3[0], g_rgb
 
     def pairs(self, *fake_real):
         """[MSE(feat(fake_i), feat(real_i))] for several (fake, real) pairs through ONE pass over the feature network

@@ -1050,6 +1050,57 @@ def feat_inputs_bwd(rgb: Tensor, gathered: Tensor, mean, std, g_out: Tensor) -> 
     return g_rgb
 
 
+_feat_chain_scratch: Dict[tuple, tuple] = {}
+
+
+def feat_chain_supported(rgb: Tensor, gathered: Tensor, hw) -> bool:
+    """K18 covers 16 x 16 patches of float32 CUDA tensors (tp_feat_chain)."""
+    return (rgb.is_cuda and rgb.dtype == torch.float32 and gathered.dtype == torch.float32 and tuple(hw) == (16, 16)
+            and rgb.dim() == 3 and rgb.shape[1] == 256 and os.environ.get("TP_NO_FEAT_CHAIN") != "1")
+
+
+@_on_tensor_device
+def feat_chain(rgb: Tensor, gathered: Tensor, weights, biases, mean, std, hw, w2: float = 5.0, scale: float = 1.0):
+    """K18 (tp_feat_chain): the feature loss of the generator step and its gradient wrt the rendered colours in ONE call --
+    (loss3 [3] = {l1 + w2 l2, l1, l2}, g_rgb [B,P,3] = scale * d loss3[0] / d rgb).  ``weights`` / ``biases``: the seven convolutions
+    of VGG19 features[:15].  Workspace and tile counters are per (device, stream, batch size) and persistent: calls on different
+    streams may overlap, and a captured call keeps its buffers."""
+    lib = _lib.load()
+    rgb, gathered = _f32(rgb.detach(), "rgb"), _f32(gathered, "gathered")
+    B, dev = rgb.shape[0], rgb.device
+    if len(weights) != 7 or len(biases) != 7:
+        raise ValueError("feat_chain: the seven convolutions of VGG19 features[:15] expected")
+    shapes = [(64, 3), (64, 64), (128, 64), (128, 128), (256, 128), (256, 256), (256, 256)]
+    for w, b, (co, ci) in zip(weights, biases, shapes):
+        if tuple(w.shape) != (co, ci, 3, 3) or tuple(b.shape) != (co,) or not w.is_contiguous() or w.dtype != torch.float32:
+            raise ValueError("feat_chain: weight %s / bias %s do not fit VGG19 features[:15]" % (tuple(w.shape), tuple(b.shape)))
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream, B)
+    scratch = _feat_chain_scratch.get(key)
+    if scratch is None:
+        n_cnt = C.c_int64(0)
+        n_ws = lib.tp_feat_chain_workspace(B, int(hw[0]), int(hw[1]), C.byref(n_cnt))
+        if n_ws < 0:
+            check(-1, "tp_feat_chain_workspace")
+        if torch.cuda.is_current_stream_capturing():
+            raise _lib.TexposeLibraryError("tp_feat_chain: its workspace must exist before a hipGraph capture (run one eager step first)")
+        scratch = _feat_chain_scratch[key] = (torch.empty(int(n_ws), device=dev), torch.zeros(int(n_cnt.value), dtype=torch.int32, device=dev))
+    ws, cnt = scratch
+    a = _lib.FeatChainArgs()
+    f = _feat_args(rgb, gathered, mean, std)
+    a.rgb, a.gathered, a.B, a.H, a.W, a.n_channels = f.rgb, f.gathered, B, int(hw[0]), int(hw[1]), f.n_channels
+    a.c_image, a.c_image_syn, a.c_mask, a.c_mask_syn = f.c_image, f.c_image_syn, f.c_mask, f.c_mask_syn
+    for c in range(3):
+        a.mean[c], a.std[c] = f.mean[c], f.std[c]
+    for l in range(7):
+        a.w[l], a.bias[l] = weights[l].data_ptr(), biases[l].data_ptr()
+    a.w2, a.scale = float(w2), float(scale)
+    loss3, g_rgb = torch.empty(3, device=dev), torch.empty_like(rgb)
+    a.loss, a.g_rgb = loss3.data_ptr(), g_rgb.data_ptr()
+    a.workspace, a.workspace_floats, a.counters, a.n_counters = ws.data_ptr(), ws.numel(), cnt.data_ptr(), cnt.numel()
+    check(lib.tp_feat_chain(C.byref(a), _stream()), "tp_feat_chain")
+    return loss3, g_rgb
+
+
 @_on_tensor_device
 def disc_inputs(rgb: Tensor, gathered: Tensor, hw, geo: bool, stacked: bool = False):
     """(real, fake) [B, 3 or 9, h, w] of the discriminator step from the render output and the gathered patches (K13).

@@ -752,8 +752,14 @@ class GraphedGanTrainer(GanTrainer):
     def _seg_feat(self, var):
         """The feature loss of the nerf step and its cotangent 10^w d feat / d rgb on the rgb alias the composite made for it."""
         _, h, w, _ = var.ray_idx.shape
-        feat = self.graph.perceptual_loss.loss_from_patches(var.rgb_feat, var.gathered, (h, w), 5.0)
-        (var.g_rgb_feat,) = torch.autograd.grad(feat, var.rgb_feat, grad_outputs=self._weight(self.opt.loss_weight.feat, feat.device))
+        pl = self.graph.perceptual_loss
+        fused = pl.loss_and_grad_from_patches(var.rgb_feat, var.gathered, (h, w), 5.0, 10 ** float(self.opt.loss_weight.feat)) \
+            if hasattr(pl, "loss_and_grad_from_patches") else None
+        if fused is not None:                      # K18: value and weighted cotangent from one call, no autograd graph
+            feat, var.g_rgb_feat = fused
+        else:
+            feat = pl.loss_from_patches(var.rgb_feat, var.gathered, (h, w), 5.0)
+            (var.g_rgb_feat,) = torch.autograd.grad(feat, var.rgb_feat, grad_outputs=self._weight(self.opt.loss_weight.feat, feat.device))
         # (compute_loss takes the value from here; `joined`: the replay loop orders the streams, no wait is recorded in a capture)
         var.feat_early, var.feat_early_for, var.feat_early_joined = feat.detach(), var.ray_idx, True
 
@@ -908,9 +914,14 @@ class GraphedGanTrainer(GanTrainer):
         main.wait_stream(cur)
         with torch.cuda.stream(side):
             # ... and so does the discriminator stream, on EVERY replay (D1 reads `weight_orig` and rewrites `weight_u` / `weight_v` in
-            # place: a load_state_dict, parameter broadcast or checkpoint copy the caller enqueued between two iterations comes first;
-            # the wait costs the tiny tp_step_inputs launch, which `main` waits for anyway)
-            side.wait_stream(cur)
+            # place: a load_state_dict, parameter broadcast or checkpoint copy the caller enqueued between two iterations comes first).
+            # `train_iteration` marks the caller's stream BEFORE its own tp_step_inputs launch (which writes nothing D1 reads): D1 then
+            # starts behind the caller's work without waiting for that launch; a bare `replay()` waits for the whole stream.
+            mark = self.__dict__.pop("_caller_mark", None)
+            if mark is not None:
+                side.wait_event(mark)
+            else:
+                side.wait_stream(cur)
             if not self._four_first:
                 side.wait_event(ev["g2"])            # set 1 is read by the generator's passes through the frozen discriminator
             g["D1"].replay()
@@ -933,6 +944,8 @@ class GraphedGanTrainer(GanTrainer):
             ev["g2"].record(main)
         with torch.cuda.stream(side):
             side.wait_event(ev["patches"])
+            if os.environ.get("TP_D2_AFTER_FEAT") == "1":       # (experiment: keep the discriminator step out of the feature chain's window)
+                side.wait_event(ev["feat"])
             g["D2"].replay()
             ev["d2"].record(side)
         # what the caller enqueues next -- reads of the losses, the next iteration's inputs -- comes after both optimiser steps
@@ -1173,6 +1186,10 @@ class GraphedGanTrainer(GanTrainer):
         # the batch into the static input tensors, the annealed patch-scale bound, the discriminator's progress value (of the
         # iteration before, as in the reference :182) and the gate words out to pinned memory: ONE launch (K13 tp_step_inputs;
         # torch: a multi-tensor copy per dtype, two fills, a copyBuffer)
+        if self._linear:
+            # everything the caller enqueued on its stream up to here is ordered in front of the discriminator stream's first graph
+            self._caller_mark = torch.cuda.Event()
+            self._caller_mark.record()
         pairs = [(dst, var[k]) for k, dst in self._static_in.items() if var[k] is not dst]
         fused = [(d, s) for d, s in pairs if torch.is_tensor(s) and s.device == d.device and s.dtype == d.dtype and s.shape == d.shape
                  and s.is_contiguous() and d.is_contiguous() and d.data_ptr() % 16 == 0 and s.data_ptr() % 16 == 0]
