@@ -480,7 +480,7 @@ typedef struct tp_feat_chain_args {
   int32_t B, H, W, n_channels;
   int32_t c_image, c_image_syn, c_mask, c_mask_syn;   /* first channel of each in `gathered` */
   float mean[3], std[3];                               /* ImageNet normalisation constants */
-  const float* w[TP_FEAT_CHAIN_LAYERS];                /* [Co,C,3,3] of the seven convolutions, in order */
+  const float* packed;                                 /* the seven [Co,C,3,3] weights as tp_feat_chain_pack wrote them */
   const float* bias[TP_FEAT_CHAIN_LAYERS];             /* [Co] */
   float w2;                /* weight of the second pair (the reference: 5) */
   float scale;             /* cotangent of the loss (the caller's loss weight 10^w; 1 for the plain gradient) */
@@ -490,6 +490,11 @@ typedef struct tp_feat_chain_args {
   int32_t* counters; int64_t n_counters;
 } tp_feat_chain_args;
 int64_t tp_feat_chain_workspace(int32_t B, int32_t H, int32_t W, int64_t* n_counters);   /* floats; -1: shape not covered */
+/* The frozen weights in the kernels' operand order, once per set of weights: packed [tp_feat_chain_packed_floats()] = for every layer
+ * [C][9][Co] (forward) followed by, for every layer, [Co][9, taps flipped][C] (data gradient) -- a half-wavefront's 32 produced channels
+ * are 128 consecutive bytes.  w: host array of the seven [Co,C,3,3] device tensors. */
+int64_t tp_feat_chain_packed_floats(void);
+int tp_feat_chain_pack(const float* const* w, float* packed, tp_stream_t stream);
 int tp_feat_chain(const tp_feat_chain_args* args, tp_stream_t stream);
 /* The discriminator step's inputs (model/nerf_adapt_st_gan.py:478-497, no gradient): real [B,nc,P] = image m + rgb pad,
  * fake [B,nc,P] = rgb, nc = 3 or (geo) 9 with the masked nocs / normal channels 6..11 of `gathered` [B,14,P] appended. */

@@ -2303,9 +2303,9 @@ def test_feat_chain_one_call_matches_torch_fp64_and_the_general_pieces(ops, B, m
     loss = net.loss_from_patches(r, g, (h, w), 5.0)
     assert "FeatChainLoss" in type(loss.grad_fn).__name__
     gr, = torch.autograd.grad(loss, r)
-    ws, bs = net._chain_params()
-    loss3, g1 = ops.feat_chain(rgb0, g, ws, bs, net._mean_host, net._std_host, (h, w), 5.0, 1.0)
-    loss3b, g2 = ops.feat_chain(rgb0, g, ws, bs, net._mean_host, net._std_host, (h, w), 5.0, 0.125)
+    packed, bs = net._chain_params()
+    loss3, g1 = ops.feat_chain(rgb0, g, packed, bs, net._mean_host, net._std_host, (h, w), 5.0, 1.0)
+    loss3b, g2 = ops.feat_chain(rgb0, g, packed, bs, net._mean_host, net._std_host, (h, w), 5.0, 0.125)
     assert torch.equal(loss3, loss3b) and torch.equal(g1, gr) and torch.equal(g2, g1 * 0.125)
     assert torch.equal(loss3[0], loss.detach())
     # fp64 restatement of the reference through the stock modules
@@ -2326,6 +2326,14 @@ def test_feat_chain_one_call_matches_torch_fp64_and_the_general_pieces(ops, B, m
     assert "FeatChainLoss" not in type(old.grad_fn).__name__
     go, = torch.autograd.grad(old, r2)
     assert rel_l2(loss, old) < 2e-6 and rel_l2(gr, go) < 5e-6
+    # the packed image follows the weights: an in-place change re-packs (same buffer), the loss moves with it
+    monkeypatch.delenv("TP_NO_FEAT_CHAIN")
+    with torch.no_grad():
+        net.model[0].weight.mul_(1.5)
+    packed2, _ = net._chain_params()
+    assert packed2.data_ptr() == packed.data_ptr()
+    moved = net.loss_from_patches(rgb0.clone().requires_grad_(), g, (h, w), 5.0)
+    assert abs(float(moved) - float(loss)) > 1e-3 * abs(float(loss))
 
 
 # ------------------------------------------------------------------------------------------ round-3 K13 additions

@@ -36,7 +36,7 @@ SYMBOLS = (
     "tp_disc_head_fwd", "tp_disc_head_bwd", "tp_disc_head_bwd_bwd",
     "tp_skinny_linear_fwd", "tp_skinny_linear_wgrad", "tp_skinny_linear_dgrad",
     "tp_disc_tail_workspace_bytes", "tp_disc_tail_fwd", "tp_disc_tail_bwd", "tp_disc_tail_bwd_bwd",
-    "tp_feat_chain_workspace", "tp_feat_chain",
+    "tp_feat_chain_workspace", "tp_feat_chain_packed_floats", "tp_feat_chain_pack", "tp_feat_chain",
 )
 
 vp = C.c_void_p
@@ -147,7 +147,7 @@ class FeatInputsArgs(C.Structure):
 class FeatChainArgs(C.Structure):
     _fields_ = [("rgb", vp), ("gathered", vp), ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("n_channels", C.c_int32),
                 ("c_image", C.c_int32), ("c_image_syn", C.c_int32), ("c_mask", C.c_int32), ("c_mask_syn", C.c_int32),
-                ("mean", C.c_float * 3), ("std", C.c_float * 3), ("w", vp * 7), ("bias", vp * 7), ("w2", C.c_float), ("scale", C.c_float),
+                ("mean", C.c_float * 3), ("std", C.c_float * 3), ("packed", vp), ("bias", vp * 7), ("w2", C.c_float), ("scale", C.c_float),
                 ("loss", vp), ("g_rgb", vp), ("workspace", vp), ("workspace_floats", C.c_int64), ("counters", vp), ("n_counters", C.c_int64)]
 
 
@@ -256,6 +256,8 @@ def load() -> C.CDLL:
     sig("tp_bce_logits_fwd", [vp, C.c_int, C.c_float, vp, vp])
     sig("tp_bce_logits_bwd", [vp, C.c_int, C.c_float, vp, vp, vp])
     sig("tp_feat_chain_workspace", [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int64)], C.c_int64)
+    sig("tp_feat_chain_packed_floats", [], C.c_int64)
+    sig("tp_feat_chain_pack", [C.POINTER(vp), vp, vp])
     sig("tp_feat_chain", [C.POINTER(FeatChainArgs), vp])
     sig("tp_feat_inputs_fwd", [C.POINTER(FeatInputsArgs), vp, vp])
     sig("tp_feat_inputs_bwd", [C.POINTER(FeatInputsArgs), vp, vp, vp])

@@ -311,9 +311,9 @@ class _FeatChainLoss(torch.autograd.Function):
     computed together with the value (tp_feat_chain) and scaled by the incoming cotangent in backward.  First order only."""
 
     @staticmethod
-    def forward(ctx, rgb, gathered, mean, std, hw, w2, weights_and_biases):
-        ws, bs = weights_and_biases
-        loss3, g_rgb = ops.feat_chain(rgb, gathered, ws, bs, mean, std, hw, w2, 1.0)
+    def forward(ctx, rgb, gathered, mean, std, hw, w2, packed_and_biases):
+        packed, bs = packed_and_biases
+        loss3, g_rgb = ops.feat_chain(rgb, gathered, packed, bs, mean, std, hw, w2, 1.0)
         ctx.save_for_backward(g_rgb)
         return loss3[0].clone(), loss3
 
@@ -324,9 +324,9 @@ class _FeatChainLoss(torch.autograd.Function):
         return g_rgb * g, None, None, None, None, None, None
 
 
-def feat_chain_loss(rgb, gathered, mean, std, hw, w2, weights, biases):
-    """-> (loss, parts [3] = {loss, l1, l2} detached)."""
-    loss, parts = _FeatChainLoss.apply(rgb.contiguous(), gathered, tuple(mean), tuple(std), tuple(hw), float(w2), (list(weights), list(biases)))
+def feat_chain_loss(rgb, gathered, mean, std, hw, w2, packed, biases):
+    """-> (loss, parts [3] = {loss, l1, l2} detached); ``packed`` = ops.feat_chain_pack of the seven weights."""
+    loss, parts = _FeatChainLoss.apply(rgb.contiguous(), gathered, tuple(mean), tuple(std), tuple(hw), float(w2), (packed, list(biases)))
     return loss, parts.detach()
 
 

@@ -87,15 +87,17 @@ __device__ __forceinline__ bool reduce_tiles(const f32x16 (&acc)[NT], float (&ou
   for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
     for (int i = 0; i < 4; ++i) out[nt][i] = 0.f;
-  for (int k0 = 0; k0 < p.S; k0 += 4) {              // four slices' loads in flight, added in slice order
-    float part[4][NT * 4];
+  // kFly slices' loads in flight, added in slice order
+  constexpr int kFly = 4;                           // (8 / 16 in flight measured: no difference, profiles/r5/02)
+  for (int k0 = 0; k0 < p.S; k0 += kFly) {
+    float part[kFly][NT * 4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < kFly; ++u)
 #pragma unroll
       for (int e = 0; e < NT * 4; ++e)
         part[u][e] = __hip_atomic_load(all + ((size_t)min(k0 + u, p.S - 1) * NT * 4 + e) * 256 + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < kFly; ++u)
       if (k0 + u < p.S)
 #pragma unroll
         for (int e = 0; e < NT * 4; ++e) out[e >> 2][e & 3] += part[u][e];

@@ -31,7 +31,7 @@ enum { EPI_PLAIN = 0, EPI_POOL = 1, EPI_MASK = 2, EPI_UNPOOL = 3 };
 
 struct FcP {
   const float* in;            // F: x [N,C,H,W];  T: gy [N,Co,H,W]
-  const float* w;             // [Co,C,3,3]
+  const float* w;             // packed: F [C][9][Co], T [Co][9 flipped][C]
   const float* bias;          // F: [Co]
   float* out;                 // F plain: [N,Co,H,W]; F pool: [N,Co,H/2,W/2]; T plain / mask: [N,C,H,W]; T unpool: [N,C,2H,2W]
   const float* act;           // T mask: the layer's input activation [.,C,H,W]; T unpool: the pooled activation [.,C,H,W]
@@ -64,9 +64,12 @@ __global__ __launch_bounds__(256) void fc_conv_kernel(FcP p) {
   }
   const float* ia = p.in + (size_t)n * CK * P;
   const int cn = min(nt * 32 + col, CN - 1);
-  // weight element of (produced channel cn, contracted channel ck, neighbourhood index k)
-  const size_t wbase = T ? (size_t)cn * 9 + 8 : (size_t)cn * p.C * 9;
-  const size_t wstep = T ? (size_t)p.C * 9 : 9;                 // per contracted channel
+  // weight element of (produced channel cn, contracted channel ck, neighbourhood index k): PACKED [ck][k][cn] (tp_feat_chain_pack; the
+  // backward image has its taps flipped), so that the 32 lanes of a half-wavefront read 128 consecutive bytes -- with the tensor's own
+  // [Co][C][3][3] layout every lane read its own row, 32 cache lines per load instruction, and the vector memory pipeline's line rate,
+  // not latency, set the kernel's time (10-13 us per layer, profiles/r5)
+  const float* wp = p.w + cn;
+  const size_t wstep = (size_t)9 * CN;                          // per contracted channel
   int qb, qe;
   k_range((CK + 1) >> 1, p.S, s, w, qb, qe);
   f32x16 acc[1] = {};
@@ -78,11 +81,11 @@ __global__ __launch_bounds__(256) void fc_conv_kernel(FcP p) {
       const int ck = 2 * min(q0 + u, qe - 1) + h, cc = min(ck, CK - 1);
       live[u] = (q0 + u < qe && ck < CK) ? 1.f : 0.f;
       const float* ic = ia + (size_t)cc * P;
-      const float* wc = p.w + wbase + wstep * cc;
+      const float* wc = wp + wstep * cc;
 #pragma unroll
       for (int k = 0; k < 9; ++k) {
         a[u][k] = ic[off[k]];
-        b[u][k] = T ? *(wc - k) : wc[k];
+        b[u][k] = wc[(size_t)k * CN];
       }
     }
 #pragma unroll
@@ -206,6 +209,22 @@ __global__ __launch_bounds__(kLossBlock) void fc_pair_loss_kernel(const float* _
   }
 }
 
+// one launch packs all seven weights both ways: fwd[l][(ci * 9 + k) * Co + co] = W[co][ci][k], bwd[l][(co * 9 + k) * C + ci] = W[co][ci][8 - k]
+struct PackP { const float* w[TP_FEAT_CHAIN_LAYERS]; long long end[TP_FEAT_CHAIN_LAYERS]; int C[TP_FEAT_CHAIN_LAYERS], Co[TP_FEAT_CHAIN_LAYERS]; float* fwd; float* bwd; };
+__global__ __launch_bounds__(256) void fc_pack_kernel(PackP q) {
+  const long long total = q.end[TP_FEAT_CHAIN_LAYERS - 1];
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    int l = 0;
+    while (e >= q.end[l]) ++l;
+    const long long base = l ? q.end[l - 1] : 0, i = e - base;          // i = (co * C + ci) * 9 + k in the tensor's own layout
+    const int C = q.C[l], Co = q.Co[l];
+    const int k = (int)(i % 9), ci = (int)((i / 9) % C), co = (int)(i / (9LL * C));
+    const float v = q.w[l][i];
+    q.fwd[base + ((long long)ci * 9 + k) * Co + co] = v;
+    q.bwd[base + ((long long)co * 9 + (8 - k)) * C + ci] = v;
+  }
+}
+
 constexpr int kLayers = TP_FEAT_CHAIN_LAYERS;
 const int kCin[kLayers] = {3, 64, 64, 128, 128, 256, 256};
 const int kCout[kLayers] = {64, 64, 128, 128, 256, 256, 256};
@@ -268,12 +287,41 @@ int64_t tp_feat_chain_workspace(int32_t B, int32_t H, int32_t W, int64_t* n_coun
   return L.total;
 }
 
+int64_t tp_feat_chain_packed_floats(void) {
+  int64_t total = 0;
+  for (int l = 0; l < kLayers; ++l) total += (int64_t)kCout[l] * kCin[l] * 9;
+  return 2 * total;
+}
+
+int tp_feat_chain_pack(const float* const* w, float* packed, tp_stream_t stream) {
+  TP_REQUIRE(w && packed, "null argument");
+  PackP q{};
+  long long o = 0;
+  for (int l = 0; l < kLayers; ++l) {
+    TP_REQUIRE(w[l] != nullptr, "null weight");
+    q.w[l] = w[l]; q.C[l] = kCin[l]; q.Co[l] = kCout[l];
+    o += (long long)kCout[l] * kCin[l] * 9;
+    q.end[l] = o;
+  }
+  q.fwd = packed; q.bwd = packed + o;
+  hipLaunchKernelGGL(fc_pack_kernel, dim3(512), dim3(256), 0, (hipStream_t)stream, q);
+  return tp::check_launch("tp_feat_chain_pack");
+}
+
 int tp_feat_chain(const tp_feat_chain_args* a, tp_stream_t stream) {
   TP_REQUIRE(a && a->rgb && a->gathered && a->loss && a->g_rgb && a->workspace && a->counters, "null argument");
   Layout L;
   TP_REQUIRE(layout(a->B, a->H, a->W, &L) == 0, "covers 16x16 patches");
   TP_REQUIRE(a->workspace_floats >= L.total && a->n_counters >= L.n_counters, "workspace / counters too small (tp_feat_chain_workspace)");
-  for (int l = 0; l < kLayers; ++l) TP_REQUIRE(a->w[l] && a->bias[l], "null weight / bias");
+  for (int l = 0; l < kLayers; ++l) TP_REQUIRE(a->bias[l], "null bias");
+  TP_REQUIRE(a->packed != nullptr, "packed weights missing (tp_feat_chain_pack)");
+  const float* wf[kLayers];
+  const float* wb[kLayers];
+  {
+    int64_t o = 0, total = 0;
+    for (int l = 0; l < kLayers; ++l) total += (int64_t)kCout[l] * kCin[l] * 9;
+    for (int l = 0; l < kLayers; ++l) { wf[l] = a->packed + o; wb[l] = a->packed + total + o; o += (int64_t)kCout[l] * kCin[l] * 9; }
+  }
   hipStream_t st = (hipStream_t)stream;
   float* W0 = a->workspace;
   const int B = a->B, n4 = 4 * B, nf = 2 * B;
@@ -290,7 +338,7 @@ int tp_feat_chain(const tp_feat_chain_args* a, tp_stream_t stream) {
   for (int l = 0; l < kLayers; ++l) {
     res[l] = h;
     FcP p{};
-    p.in = x; p.w = a->w[l]; p.bias = a->bias[l]; p.out = W0 + L.act[l]; p.ws = W0 + L.ws; p.cnt = (unsigned*)a->counters;
+    p.in = x; p.w = wf[l]; p.bias = a->bias[l]; p.out = W0 + L.act[l]; p.ws = W0 + L.ws; p.cnt = (unsigned*)a->counters;
     p.N = n4; p.C = kCin[l]; p.H = h; p.W = h; p.Co = kCout[l]; p.lw = ilog2(h); p.lp = 2 * p.lw; p.relu = l + 1 < kLayers;
     const Plan q = conv_plan(n4, h, h, kCout[l], kCin[l]);
     p.S = q.S; p.tiles_n = q.tiles_n;
@@ -316,7 +364,7 @@ int tp_feat_chain(const tp_feat_chain_args* a, tp_stream_t stream) {
   for (int l = kLayers - 1; l >= 0; --l) {
     const int hl = res[l];
     FcP p{};
-    p.in = W0 + L.g[l + 1]; p.w = a->w[l]; p.out = W0 + L.g[l]; p.ws = W0 + L.ws; p.cnt = (unsigned*)a->counters;
+    p.in = W0 + L.g[l + 1]; p.w = wb[l]; p.out = W0 + L.g[l]; p.ws = W0 + L.ws; p.cnt = (unsigned*)a->counters;
     p.N = nf; p.C = kCin[l]; p.H = hl; p.W = hl; p.Co = kCout[l]; p.lw = ilog2(hl); p.lp = 2 * p.lw;
     const Plan q = conv_plan(nf, hl, hl, kCin[l], kCout[l]);
     p.S = q.S; p.tiles_n = q.tiles_n;

@@ -359,16 +359,25 @@ class PerceptualLoss(nn.Module):
         if self.chain_eligible(rgb, gathered, hw):
             # K18: the chain written out as 17 launches, value and d / d rgb from ONE call (pools, ReLU derivatives and un-pooling in the
             # convolutions' epilogues, backward through the 2B fake images only)
-            ws, bs = self._chain_params()
-            loss, _parts = autograd_ops.feat_chain_loss(rgb, gathered, self._mean_host, self._std_host, hw, w2, ws, bs)
+            packed, bs = self._chain_params()
+            loss, _parts = autograd_ops.feat_chain_loss(rgb, gathered, self._mean_host, self._std_host, hw, w2, packed, bs)
             return loss
         x = autograd_ops.feat_inputs(rgb, gathered, self._mean_host, self._std_host, hw)
         loss, _parts = autograd_ops.feat_pair_loss(self.features(x), w2)
         return loss
 
     def _chain_params(self):
+        """(packed weights, biases) of K18.  The packed image is this module's: made on first use, re-made IN PLACE (a captured step
+        keeps its address) when a weight tensor was replaced or written (tensor identity + version counter)."""
+        from . import ops
         convs = [m for m in self.model if isinstance(m, nn.Conv2d)]
-        return [c.weight for c in convs], [c.bias for c in convs]
+        ws = [c.weight for c in convs]
+        stamp = tuple((id(w), w.data_ptr(), w._version) for w in ws)
+        cached = self.__dict__.get("_chain_packed")
+        if cached is None or cached[1] != stamp or cached[0].device != ws[0].device:
+            keep = cached[0] if cached is not None and cached[0].device == ws[0].device else None
+            self.__dict__["_chain_packed"] = cached = (ops.feat_chain_pack([w.detach() for w in ws], out=keep), stamp)
+        return cached[0], [c.bias for c in convs]
 
     def chain_eligible(self, rgb, gathered, hw):
         """tp_feat_chain covers the stock configuration: the seven frozen 3x3 convolutions of `CFG`, float32 CUDA tensors, 16 x 16
@@ -385,8 +394,8 @@ class PerceptualLoss(nn.Module):
         from . import ops
         if not self.chain_eligible(rgb, gathered, hw):
             return None
-        ws, bs = self._chain_params()
-        loss3, g_rgb = ops.feat_chain(rgb.detach(), gathered, ws, bs, self._mean_host, self._std_host, hw, w2, scale)
+        packed, bs = self._chain_params()
+        loss3, g_rgb = ops.feat_chain(rgb.detach(), gathered, packed, bs, self._mean_host, self._std_host, hw, w2, scale)
         return loss3[0], g_rgb
 
     def pairs(self, *fake_real):

@@ -1059,21 +1059,43 @@ def feat_chain_supported(rgb: Tensor, gathered: Tensor, hw) -> bool:
             and rgb.dim() == 3 and rgb.shape[1] == 256 and os.environ.get("TP_NO_FEAT_CHAIN") != "1")
 
 
+def feat_chain_pack(weights, out: Optional[Tensor] = None) -> Tensor:
+    """The seven frozen [Co,C,3,3] weights of VGG19 features[:15] in K18's operand order (tp_feat_chain_pack): one launch.  ``out``:
+    an earlier result to overwrite (a captured step keeps its address).  The OWNER of the weights caches the result
+    (gan_modules.PerceptualLoss): a cache keyed by addresses here would serve a new network the old one's weights."""
+    lib = _lib.load()
+    shapes = [(64, 3), (64, 64), (128, 64), (128, 128), (256, 128), (256, 256), (256, 256)]
+    if len(weights) != 7:
+        raise ValueError("feat_chain_pack: the seven convolutions of VGG19 features[:15] expected")
+    for w, (co, ci) in zip(weights, shapes):
+        if tuple(w.shape) != (co, ci, 3, 3) or not w.is_contiguous() or w.dtype != torch.float32 or not w.is_cuda:
+            raise ValueError("feat_chain_pack: weight %s does not fit VGG19 features[:15]" % (tuple(w.shape),))
+    dev = weights[0].device
+    n = int(lib.tp_feat_chain_packed_floats())
+    if out is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise _lib.TexposeLibraryError("tp_feat_chain_pack: pack before the hipGraph capture (run one eager step first)")
+        out = torch.empty(n, device=dev)
+    ptrs = (C.c_void_p * 7)(*[w.data_ptr() for w in weights])
+    with torch.cuda.device(dev):
+        check(lib.tp_feat_chain_pack(ptrs, out.data_ptr(), _stream()), "tp_feat_chain_pack")
+    return out
+
+
 @_on_tensor_device
-def feat_chain(rgb: Tensor, gathered: Tensor, weights, biases, mean, std, hw, w2: float = 5.0, scale: float = 1.0):
+def feat_chain(rgb: Tensor, gathered: Tensor, packed: Tensor, biases, mean, std, hw, w2: float = 5.0, scale: float = 1.0):
     """K18 (tp_feat_chain): the feature loss of the generator step and its gradient wrt the rendered colours in ONE call --
-    (loss3 [3] = {l1 + w2 l2, l1, l2}, g_rgb [B,P,3] = scale * d loss3[0] / d rgb).  ``weights`` / ``biases``: the seven convolutions
-    of VGG19 features[:15].  Workspace and tile counters are per (device, stream, batch size) and persistent: calls on different
-    streams may overlap, and a captured call keeps its buffers."""
+    (loss3 [3] = {l1 + w2 l2, l1, l2}, g_rgb [B,P,3] = scale * d loss3[0] / d rgb).  ``packed``: `feat_chain_pack` of the seven
+    convolution weights of VGG19 features[:15]; ``biases``: theirs.  Workspace and tile counters are per (device, stream, batch size)
+    and persistent: calls on different streams may overlap, and a captured call keeps its buffers."""
     lib = _lib.load()
     rgb, gathered = _f32(rgb.detach(), "rgb"), _f32(gathered, "gathered")
     B, dev = rgb.shape[0], rgb.device
-    if len(weights) != 7 or len(biases) != 7:
-        raise ValueError("feat_chain: the seven convolutions of VGG19 features[:15] expected")
-    shapes = [(64, 3), (64, 64), (128, 64), (128, 128), (256, 128), (256, 256), (256, 256)]
-    for w, b, (co, ci) in zip(weights, biases, shapes):
-        if tuple(w.shape) != (co, ci, 3, 3) or tuple(b.shape) != (co,) or not w.is_contiguous() or w.dtype != torch.float32:
-            raise ValueError("feat_chain: weight %s / bias %s do not fit VGG19 features[:15]" % (tuple(w.shape), tuple(b.shape)))
+    if len(biases) != 7 or packed.numel() != int(lib.tp_feat_chain_packed_floats()) or packed.dtype != torch.float32:
+        raise ValueError("feat_chain: packed weights (feat_chain_pack) and the seven biases of VGG19 features[:15] expected")
+    for b, co in zip(biases, (64, 64, 128, 128, 256, 256, 256)):
+        if tuple(b.shape) != (co,) or b.dtype != torch.float32:
+            raise ValueError("feat_chain: bias %s does not fit VGG19 features[:15]" % (tuple(b.shape),))
     key = (dev.index, torch.cuda.current_stream(dev).cuda_stream, B)
     scratch = _feat_chain_scratch.get(key)
     if scratch is None:
@@ -1091,8 +1113,9 @@ def feat_chain(rgb: Tensor, gathered: Tensor, weights, biases, mean, std, hw, w2
     a.c_image, a.c_image_syn, a.c_mask, a.c_mask_syn = f.c_image, f.c_image_syn, f.c_mask, f.c_mask_syn
     for c in range(3):
         a.mean[c], a.std[c] = f.mean[c], f.std[c]
+    a.packed = packed.data_ptr()
     for l in range(7):
-        a.w[l], a.bias[l] = weights[l].data_ptr(), biases[l].data_ptr()
+        a.bias[l] = biases[l].data_ptr()
     a.w2, a.scale = float(w2), float(scale)
     loss3, g_rgb = torch.empty(3, device=dev), torch.empty_like(rgb)
     a.loss, a.g_rgb = loss3.data_ptr(), g_rgb.data_ptr()

@@ -936,18 +936,28 @@ class GraphedGanTrainer(GanTrainer):
             feat.wait_event(ev["patches"])           # (recorded on `main` behind its wait for the caller's stream)
             g["F"].replay()
             ev["feat"].record(feat)
+        d2_first = os.environ.get("TP_G2B_AFTER_D2") == "1"      # (experiment: the render's backward starts behind the discriminator step)
+
+        def disc_step_graph():
+            with torch.cuda.stream(side):
+                side.wait_event(ev["patches"])
+                if os.environ.get("TP_D2_AFTER_FEAT") == "1":   # (experiment: keep the discriminator step out of the feature chain's window)
+                    side.wait_event(ev["feat"])
+                g["D2"].replay()
+                ev["d2"].record(side)
+
+        if d2_first:
+            disc_step_graph()
         with torch.cuda.stream(main):
             main.wait_event(ev["sn"])
             g["G2a"].replay()
             main.wait_event(ev["feat"])
+            if d2_first:
+                main.wait_event(ev["d2"])
             g["G2b"].replay()
             ev["g2"].record(main)
-        with torch.cuda.stream(side):
-            side.wait_event(ev["patches"])
-            if os.environ.get("TP_D2_AFTER_FEAT") == "1":       # (experiment: keep the discriminator step out of the feature chain's window)
-                side.wait_event(ev["feat"])
-            g["D2"].replay()
-            ev["d2"].record(side)
+        if not d2_first:
+            disc_step_graph()
         # what the caller enqueues next -- reads of the losses, the next iteration's inputs -- comes after both optimiser steps
         cur.wait_event(ev["g2"])
         cur.wait_event(ev["d2"])
