@@ -16,19 +16,10 @@ namespace {
 
 constexpr int kWaves = 4;  // waves (= rays in flight) per workgroup
 
-__device__ __forceinline__ float wave_incl_scan(float v, int lane) {
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const float t = __shfl_up(v, off, 64);
-    if (lane >= off) v += t;
-  }
-  return v;
-}
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
-}
+// Wave scans and sums on the vector ALU (tp_common.h: DPP).  Round 4 built them from __shfl (ds_bpermute_b32: 108 LDS instructions per
+// 64 samples in the forward, 186 in the backward) and the LDS pipe, not HBM, set both kernels' time.
+__device__ __forceinline__ float wave_incl_scan(float v, int) { return tp::wave_scan_dpp(v); }
+__device__ __forceinline__ float wave_sum(float v) { return tp::wave_total_dpp(v); }
 
 // Everything the forward derives for one sample.
 struct Sample {
@@ -58,17 +49,23 @@ __device__ __forceinline__ Sample load_sample(const tp_composite_args& p, int64_
     sig_s = dn.x; sig_t = dn.y;
     s.z = p.depth[e];
     s.u = p.uncert[e];
-    const float dz = (i == p.N - 1) ? 1e10f : (p.depth[e + 1] - s.z);
-    s.dist = dz * len;
+  }
+  {
+    // the next sample's depth: the neighbouring lane's (lane 63: the next chunk's first, its own load)
+    float zn = tp::wave_shl1(s.z);
+    if (lane == 63 && i + 1 < p.N) zn = p.depth[e + 1];
+    const float dz = (i == p.N - 1) ? 1e10f : (zn - s.z);
+    s.dist = ok ? dz * len : 0.f;
   }
   const float ts = sig_s * s.dist, tt = sig_t * s.dist, tj = ts + tt;
-  const float is = wave_incl_scan(ts, lane), it = wave_incl_scan(tt, lane), ij = wave_incl_scan(tj, lane);
-  float xs = __shfl_up(is, 1, 64), xt = __shfl_up(it, 1, 64), xj = __shfl_up(ij, 1, 64);
-  if (lane == 0) { xs = 0.f; xt = 0.f; xj = 0.f; }
+  float sc[3] = {ts, tt, tj};
+  tp::wave_scan_dpp(sc);                                  // the three scans step by step together
+  const float is = sc[0], it = sc[1], ij = sc[2];
+  const float xs = tp::wave_shr1(is), xt = tp::wave_shr1(it), xj = tp::wave_shr1(ij);
   s.Ts = expf(-(carry.s + xs)); s.Tt = expf(-(carry.t + xt)); s.T = expf(-(carry.j + xj));
   s.es = expf(-ts); s.et = expf(-tt); s.e = expf(-tj);
   s.as = 1.f - s.es; s.at = 1.f - s.et; s.a = 1.f - s.e;
-  carry.s += __shfl(is, 63, 64); carry.t += __shfl(it, 63, 64); carry.j += __shfl(ij, 63, 64);
+  carry.s += tp::lane_value(is, 63); carry.t += tp::lane_value(it, 63); carry.j += tp::lane_value(ij, 63);
   if (!ok) { s.T = s.Ts = s.Tt = 0.f; }   // padding lanes contribute nothing
   return s;
 }
@@ -111,8 +108,9 @@ __global__ __launch_bounds__(kWaves * 64) void composite_fwd_kernel(tp_composite
         if (p.prob) p.prob[e] = w;
       }
     }
+    tp::wave_scan_dpp(acc);                               // (lane 63 ends up with the 14 totals)
 #pragma unroll
-    for (int k = 0; k < 14; ++k) acc[k] = wave_sum(acc[k]);
+    for (int k = 0; k < 14; ++k) acc[k] = tp::lane_value(acc[k], 63);
     if (lane == 0) {
       acc[13] += p.min_uncert;
       float2* o = reinterpret_cast<float2*>(p.out_ray + q * 14);
@@ -124,14 +122,7 @@ __global__ __launch_bounds__(kWaves * 64) void composite_fwd_kernel(tp_composite
   }
 }
 
-__device__ __forceinline__ float wave_rev_incl_scan(float v, int lane) {
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const float t = __shfl_down(v, off, 64);
-    if (lane + off < 64) v += t;
-  }
-  return v;
-}
+__device__ __forceinline__ float wave_rev_incl_scan(float v, int lane) { return tp::wave_rev_scan_dpp(v, lane); }
 
 constexpr int kMaxChunks = 32;   // backward supports N <= 2048 samples per ray
 
@@ -180,12 +171,12 @@ __global__ __launch_bounds__(kWaves * 64) void composite_bwd_kernel(tp_composite
       const float P1 = s.T * (s.as * A + s.at * Bv + s.a * C);     // padding lanes: T = 0 -> 0
       const float P2 = s.Ts * s.as * D;
       const float P3 = s.Tt * s.at * E;
-      const float r1 = wave_rev_incl_scan(P1, lane), r2 = wave_rev_incl_scan(P2, lane),
-                  r3 = wave_rev_incl_scan(P3, lane);
-      float suf1 = __shfl_down(r1, 1, 64), suf2 = __shfl_down(r2, 1, 64), suf3 = __shfl_down(r3, 1, 64);
-      if (lane == 63) { suf1 = 0.f; suf2 = 0.f; suf3 = 0.f; }
+      float rv[3] = {P1, P2, P3};
+      tp::wave_rev_scan_dpp(rv, lane);
+      const float r1 = rv[0], r2 = rv[1], r3 = rv[2];
+      float suf1 = tp::wave_shl1(r1), suf2 = tp::wave_shl1(r2), suf3 = tp::wave_shl1(r3);
       suf1 += run1; suf2 += run2; suf3 += run3;
-      run1 += __shfl(r1, 0, 64); run2 += __shfl(r2, 0, 64); run3 += __shfl(r3, 0, 64);
+      run1 += tp::lane_value(r1, 0); run2 += tp::lane_value(r2, 0); run3 += tp::lane_value(r3, 0);
       if (!ok) continue;
       const float gas = b.g_alpha_static ? b.g_alpha_static[e] : 0.f;
       const float gat = b.g_alpha_transient ? b.g_alpha_transient[e] : 0.f;

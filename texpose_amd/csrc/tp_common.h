@@ -124,6 +124,73 @@ __device__ __forceinline__ void sincos_double(SinCos64& v) {
   v.s = s2;
 }
 
+// ---- cross-lane data movement on the vector ALU (DPP) instead of the LDS crossbar.  `__shfl*` compiles to ds_bpermute_b32: one LDS
+// instruction per step, and a wave scan is six of them -- the composite kernels issued 108 per 64 samples and were bound by the LDS
+// pipe, not by HBM (profiles/r5).  gfx9 DPP controls: row_shr:n 0x110+n, row_shl:n 0x100+n (within rows of 16 lanes), wave_shl:1 0x130,
+// wave_shr:1 0x138 (whole wavefront), row_bcast:15 0x142 / row_bcast:31 0x143 (lane 15 of a row -> the next row; lane 31 -> rows 2, 3).
+// Lanes without a source (row / wave ends, rows outside ROW_MASK) receive `old`.
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ float dpp(float old, float src) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src), CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ float lane_value(float v, int lane) {          // (a wave-uniform value: lands in a scalar register)
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+// inclusive prefix sum over the 64 lanes: Hillis-Steele inside each row of 16, then the row totals ripple up
+__device__ __forceinline__ float wave_scan_dpp(float v) {
+  v += dpp<0x111>(0.f, v);
+  v += dpp<0x112>(0.f, v);
+  v += dpp<0x114>(0.f, v);
+  v += dpp<0x118>(0.f, v);
+  v += dpp<0x142, 0xA>(0.f, v);
+  v += dpp<0x143, 0xC>(0.f, v);
+  return v;
+}
+// inclusive SUFFIX sum (lane l: sum of lanes l .. 63): the same inside the rows with left shifts; DPP has no downward broadcast, so the
+// totals of the rows above come through scalar registers
+__device__ __forceinline__ float wave_rev_scan_dpp(float v, int lane) {
+  v += dpp<0x101>(0.f, v);
+  v += dpp<0x102>(0.f, v);
+  v += dpp<0x104>(0.f, v);
+  v += dpp<0x108>(0.f, v);
+  const float t1 = lane_value(v, 16), t2 = lane_value(v, 32), t3 = lane_value(v, 48);
+  const int row = lane >> 4;
+  const float above = ((row < 3 ? t3 : 0.f) + (row < 2 ? t2 : 0.f)) + (row < 1 ? t1 : 0.f);
+  return v + above;
+}
+// the same scan / total for K independent values at once, step-major: consecutive DPP instructions then never depend on each other
+// (a DPP read of a register a vector instruction has just written costs two wait states: value-major code was one s_nop per step)
+template <int CTRL, int ROW_MASK, int K>
+__device__ __forceinline__ void dpp_add_step(float (&v)[K]) {
+#pragma unroll
+  for (int k = 0; k < K; ++k) v[k] += dpp<CTRL, ROW_MASK>(0.f, v[k]);
+}
+template <int K>
+__device__ __forceinline__ void wave_scan_dpp(float (&v)[K]) {
+  dpp_add_step<0x111, 0xf>(v);
+  dpp_add_step<0x112, 0xf>(v);
+  dpp_add_step<0x114, 0xf>(v);
+  dpp_add_step<0x118, 0xf>(v);
+  dpp_add_step<0x142, 0xA>(v);
+  dpp_add_step<0x143, 0xC>(v);
+}
+template <int K>
+__device__ __forceinline__ void wave_rev_scan_dpp(float (&v)[K], int lane) {
+  dpp_add_step<0x101, 0xf>(v);
+  dpp_add_step<0x102, 0xf>(v);
+  dpp_add_step<0x104, 0xf>(v);
+  dpp_add_step<0x108, 0xf>(v);
+  const int row = lane >> 4;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const float t1 = lane_value(v[k], 16), t2 = lane_value(v[k], 32), t3 = lane_value(v[k], 48);
+    v[k] += ((row < 3 ? t3 : 0.f) + (row < 2 ? t2 : 0.f)) + (row < 1 ? t1 : 0.f);
+  }
+}
+__device__ __forceinline__ float wave_shr1(float v) { return dpp<0x138>(0.f, v); }     // lane l <- lane l-1, lane 0 <- 0
+__device__ __forceinline__ float wave_shl1(float v) { return dpp<0x130>(0.f, v); }     // lane l <- lane l+1, lane 63 <- 0
+__device__ __forceinline__ float wave_total_dpp(float v) { return lane_value(wave_scan_dpp(v), 63); }
+
 // Philox4x32-10 (Salmon et al., SC'11); the stream layouts of its users are documented in oracle.philox_uniform (ray-gen jitter)
 // and at tp_patch_coords (patch draws).
 __device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) {
