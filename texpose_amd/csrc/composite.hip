@@ -31,33 +31,41 @@ struct Sample {
 
 struct Carry { float s, t, j; };
 
-// Loads sample i of ray q and runs the scan for the current chunk (all 64 lanes must call).
-__device__ __forceinline__ Sample load_sample(const tp_composite_args& p, int64_t q, int i, int lane, float len,
-                                              Carry& carry) {
-  Sample s;
+// The raw inputs of one sample: colours, densities, depth, uncertainty, and the distance to the next sample (already times |ray|).
+struct Raw { float cs[3], ct[3], sig_s, sig_t, z, u, dist; };
+
+// From global memory: sample i of ray q (all 64 lanes must call: the next depth comes from the neighbouring lane).
+__device__ __forceinline__ Raw fetch_global(const tp_composite_args& p, int64_t q, int i, int lane, float len) {
+  Raw r;
   const bool ok = i < p.N;
   const int64_t e = q * p.N + (ok ? i : 0);
-  float sig_s = 0.f, sig_t = 0.f;
-  s.z = 0.f; s.u = 0.f; s.dist = 0.f;
+  r.sig_s = 0.f; r.sig_t = 0.f; r.z = 0.f; r.u = 0.f;
 #pragma unroll
-  for (int c = 0; c < 3; ++c) { s.cs[c] = 0.f; s.ct[c] = 0.f; }
+  for (int c = 0; c < 3; ++c) { r.cs[c] = 0.f; r.ct[c] = 0.f; }
   if (ok) {
     const float2* rp = reinterpret_cast<const float2*>(p.rgb + e * 6);
     const float2 r0 = rp[0], r1 = rp[1], r2 = rp[2];
-    s.cs[0] = r0.x; s.ct[0] = r0.y; s.cs[1] = r1.x; s.ct[1] = r1.y; s.cs[2] = r2.x; s.ct[2] = r2.y;
+    r.cs[0] = r0.x; r.ct[0] = r0.y; r.cs[1] = r1.x; r.ct[1] = r1.y; r.cs[2] = r2.x; r.ct[2] = r2.y;
     const float2 dn = *reinterpret_cast<const float2*>(p.density + e * 2);
-    sig_s = dn.x; sig_t = dn.y;
-    s.z = p.depth[e];
-    s.u = p.uncert[e];
+    r.sig_s = dn.x; r.sig_t = dn.y;
+    r.z = p.depth[e];
+    r.u = p.uncert[e];
   }
-  {
-    // the next sample's depth: the neighbouring lane's (lane 63: the next chunk's first, its own load)
-    float zn = tp::wave_shl1(s.z);
-    if (lane == 63 && i + 1 < p.N) zn = p.depth[e + 1];
-    const float dz = (i == p.N - 1) ? 1e10f : (zn - s.z);
-    s.dist = ok ? dz * len : 0.f;
-  }
-  const float ts = sig_s * s.dist, tt = sig_t * s.dist, tj = ts + tt;
+  // the next sample's depth: the neighbouring lane's (lane 63: the next chunk's first, its own load)
+  float zn = tp::wave_shl1(r.z);
+  if (lane == 63 && i + 1 < p.N) zn = p.depth[e + 1];
+  const float dz = (i == p.N - 1) ? 1e10f : (zn - r.z);
+  r.dist = ok ? dz * len : 0.f;
+  return r;
+}
+
+// The scan of the current chunk on top of the carry (all 64 lanes must call; `ok`: this lane holds a sample).
+__device__ __forceinline__ Sample scan_sample(const Raw& r, bool ok, Carry& carry) {
+  Sample s;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) { s.cs[c] = r.cs[c]; s.ct[c] = r.ct[c]; }
+  s.z = r.z; s.u = r.u; s.dist = r.dist;
+  const float ts = r.sig_s * s.dist, tt = r.sig_t * s.dist, tj = ts + tt;
   float sc[3] = {ts, tt, tj};
   tp::wave_scan_dpp(sc);                                  // the three scans step by step together
   const float is = sc[0], it = sc[1], ij = sc[2];
@@ -68,6 +76,13 @@ __device__ __forceinline__ Sample load_sample(const tp_composite_args& p, int64_
   carry.s += tp::lane_value(is, 63); carry.t += tp::lane_value(it, 63); carry.j += tp::lane_value(ij, 63);
   if (!ok) { s.T = s.Ts = s.Tt = 0.f; }   // padding lanes contribute nothing
   return s;
+}
+
+// Loads sample i of ray q and runs the scan for the current chunk (all 64 lanes must call).
+__device__ __forceinline__ Sample load_sample(const tp_composite_args& p, int64_t q, int i, int lane, float len,
+                                              Carry& carry) {
+  const Raw r = fetch_global(p, q, i, lane, len);
+  return scan_sample(r, i < p.N, carry);
 }
 
 __device__ __forceinline__ float ray_len(const float* ray, int64_t q) {
@@ -209,6 +224,10 @@ extern "C" int tp_composite_fwd(const tp_composite_args* a, tp_stream_t stream) 
   TP_REQUIRE(a && a->ray && a->rgb && a->density && a->depth && a->uncert && a->out_ray, "null pointer");
   TP_REQUIRE(a->N > 0 && a->n >= 0, "bad sizes");
   if (a->n == 0) return 0;
+  // (Measured and dropped, profiles/r5/03: nontemporal loads of the inputs -- no change; a variant that brings 128 samples in by fully
+  // coalesced 16-byte loads, parks them in wavefront-private LDS and prefetches the next stage -- 4 % slower: with the scans on the
+  // vector ALU the kernel sits between its instruction count, ~500 per ray and wavefront, and the memory system; a pure 16-byte read
+  // stream reaches 5.4 TB/s on this chip, tools/ubench/read_bw.hip.)
   hipLaunchKernelGGL(composite_fwd_kernel, dim3(grid_for(a->n)), dim3(kWaves * 64), 0, (hipStream_t)stream, *a);
   return tp::check_launch("tp_composite_fwd");
 }
