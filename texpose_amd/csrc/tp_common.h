@@ -187,6 +187,52 @@ __device__ __forceinline__ void wave_rev_scan_dpp(float (&v)[K], int lane) {
     v[k] += ((row < 3 ? t3 : 0.f) + (row < 2 ? t2 : 0.f)) + (row < 1 ? t1 : 0.f);
   }
 }
+// ---- the wave totals of FOURTEEN values at once (the composite's per-ray sums) as a butterfly that halves the number of live
+// registers while it halves the lane span: gfx950's v_permlane32_swap / v_permlane16_swap exchange the upper half (the odd rows) of
+// one register with the lower half (the even rows) of another, so one add folds TWO values by 32 (16) lanes.  7 + 4 swap-adds, then
+// four registers x four in-row steps: 38 vector instructions instead of 14 x 6 steps with their masked broadcasts (~140).
+// out[k] = sum over the 64 lanes of v[k], the same in every lane (wave-uniform).
+// (Inline assembly, not __builtin_amdgcn_permlane{32,16}_swap: ROCm 7.2's hipcc folds `r[0] + r[1]` of the builtin's result pair into
+// `r[0] + r[0]` -- "v_permlane32_swap v1, v2; v_add_f32 v1, v1, v1" -- so sums came out doubled per step.  The s_nops cover the
+// instruction's read-after-VALU-write wait states, which the compiler's hazard recogniser cannot see inside the asm.)
+struct SwapPair { float a, b; };
+__device__ __forceinline__ SwapPair swap32(float a, float b) {     // a' = [a.lo | b.lo], b' = [a.hi | b.hi]
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+  return {a, b};
+}
+__device__ __forceinline__ SwapPair swap16(float a, float b) {     // rows: a' = [a0, b0, a2, b2], b' = [a1, b1, a3, b3]
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+  return {a, b};
+}
+__device__ __forceinline__ void wave_totals14(float (&v)[14]) {
+  float r[7];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) {                 // lanes < 32: v[k] folded by 32; lanes >= 32: v[k + 7] folded by 32
+    const SwapPair p = swap32(v[k], v[k + 7]);
+    r[k] = p.a + p.b;
+  }
+  float q[4];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {                 // rows: v[2k], v[2k+1], v[2k+7], v[2k+8], each folded to 16 lanes
+    const SwapPair p = swap16(r[2 * k], r[2 * k + 1]);
+    q[k] = p.a + p.b;
+  }
+  {
+    const SwapPair p = swap16(r[6], r[6]);      // rows: v[6], v[6], v[13], v[13]
+    q[3] = p.a + p.b;
+  }
+  dpp_add_step<0x111, 0xf>(q);                  // lane 15 of every row: the row's total
+  dpp_add_step<0x112, 0xf>(q);
+  dpp_add_step<0x114, 0xf>(q);
+  dpp_add_step<0x118, 0xf>(q);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    v[2 * k] = lane_value(q[k], 15); v[2 * k + 1] = lane_value(q[k], 31);
+    v[2 * k + 7] = lane_value(q[k], 47); v[2 * k + 8] = lane_value(q[k], 63);
+  }
+  v[6] = lane_value(q[3], 15);
+  v[13] = lane_value(q[3], 47);
+}
 __device__ __forceinline__ float wave_shr1(float v) { return dpp<0x138>(0.f, v); }     // lane l <- lane l-1, lane 0 <- 0
 __device__ __forceinline__ float wave_shl1(float v) { return dpp<0x130>(0.f, v); }     // lane l <- lane l+1, lane 63 <- 0
 __device__ __forceinline__ float wave_total_dpp(float v) { return lane_value(wave_scan_dpp(v), 63); }
