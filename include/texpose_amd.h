@@ -360,6 +360,19 @@ int tp_inorm_lrelu_bwd(const float* xhat, const float* rstd, const float* gy, in
 int tp_inorm_lrelu_bwd_bwd(const float* xhat, const float* rstd, const float* gy, const float* ggx, int64_t n_inst, int hw,
                            float slope, float* g_gy, float* g_x, tp_stream_t stream);
 
+/* ---- pairs: TWO independent problems of one kernel in ONE launch (workgroups [0, n_a) work on the first, the rest on the second).  The
+ * discriminator step (reference model/nerf_adapt_st_gan.py:129-171) passes the real and the fake patch stack through the same ladder and
+ * tail one after the other; both passes' launches are latency-sized at these shapes (10-15 us for a few hundred kFLOP..MFLOP), so a pair
+ * takes the time of one.  The two problems must not share an output, a split-K workspace, tile counters or a ticket. */
+typedef struct tp_inorm_bwd_args {
+  const float* xhat; const float* rstd; const float* gy;
+  int64_t n_inst; int32_t hw; float slope;
+  const float* addend;     /* or NULL */
+  float* gx;
+} tp_inorm_bwd_args;
+int tp_inorm_lrelu_bwd_pair(const tp_inorm_bwd_args* a, const tp_inorm_bwd_args* b, tp_stream_t stream);
+
+
 /* ------------------------------------------------------------------------------------------
  * K10  RMSprop step of the PatchGAN parameters in one launch (reference optim_disc.step(),
  * model/nerf_adapt_st_gan.py:168, torch.optim.RMSprop: alpha 0.99, eps 1e-8, no momentum / centring / weight decay).
@@ -413,6 +426,10 @@ int64_t tp_conv4s2_fwd_inorm_workspace(const tp_conv4s2_args* args, int64_t* n_c
 int tp_conv4s2_fwd_inorm(const tp_conv4s2_args* args, float eps, float slope, float* xhat, float* rstd, tp_stream_t stream);
 int tp_conv4s2_dgrad(const tp_conv4s2_args* args, tp_stream_t stream);
 int tp_conv4s2_wgrad(const tp_conv4s2_args* args, tp_stream_t stream);
+int tp_conv4s2_fwd_inorm_pair(const tp_conv4s2_args* a, float* xhat_a, float* rstd_a, const tp_conv4s2_args* b, float* xhat_b, float* rstd_b,
+                              float eps, float slope, tp_stream_t stream);            /* same map size in both problems */
+int tp_conv4s2_dgrad_pair(const tp_conv4s2_args* a, const tp_conv4s2_args* b, tp_stream_t stream);
+int tp_conv4s2_wgrad_pair(const tp_conv4s2_args* a, const tp_conv4s2_args* b, tp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * K12  3x3 / stride 1 / padding 1 convolution (+ bias, + ReLU) of the frozen perceptual-loss feature network
@@ -655,6 +672,8 @@ size_t tp_disc_tail_workspace_bytes(int N);
 int tp_disc_tail_fwd(const tp_disc_tail_args* args, tp_stream_t stream);
 int tp_disc_tail_bwd(const tp_disc_tail_args* args, tp_stream_t stream);
 int tp_disc_tail_bwd_bwd(const tp_disc_tail_args* args, tp_stream_t stream);
+int tp_disc_tail_fwd_pair(const tp_disc_tail_args* a, const tp_disc_tail_args* b, tp_stream_t stream);
+int tp_disc_tail_bwd_pair(const tp_disc_tail_args* a, const tp_disc_tail_args* b, tp_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -1326,6 +1326,45 @@ def test_disc_step_matches_reference_g13b(ops, form, monkeypatch):
     print("G13b %s: weight_orig gradient rel-L2 vs the reference:" % form, {k: "%.1e" % v for k, v in errs.items()})
 
 
+def test_disc_step_pairs_are_bit_identical_to_the_sequential_schedule(ops, monkeypatch):
+    """The discriminator step with its real and fake passes as PAIRS of launches (ops.paired / tp_*_pair: forward ladder + tail, tail
+    backward, weight / data gradients, InstanceNorm backward) against the sequential schedule (TP_NO_DISC_PAIRS=1) on golden G13b's
+    inputs: same kernels on the same operands -- logits, losses, all six weight_orig gradients and u / v bit for bit; the pair forms
+    refuse a partner-less or mismatched call."""
+    G = load_golden("g13b_disc_step")
+    res = []
+    for pairs in (True, False):
+        if pairs:
+            monkeypatch.delenv("TP_NO_DISC_PAIRS", raising=False)
+        else:
+            monkeypatch.setenv("TP_NO_DISC_PAIRS", "1")
+        opt, graph, tr, var = _g13b_setup(G)
+        var, dloss = tr.disc_step(var, apply=False)
+        assert tr._disc_sched.pairs_eligible(var.patch_real) == pairs
+        res.append(([q.grad.clone() for q in graph.discriminator.parameters() if q.grad is not None], var.d_real_disc.clone(),
+                    var.d_fake_disc.clone(), {k: v.detach().clone() for k, v in dloss.items()},
+                    {k: v.clone() for k, v in graph.discriminator.state_dict().items()}))
+    for a, b in zip(res[0][0], res[1][0]):
+        assert torch.equal(a, b)
+    assert len(res[0][0]) == 6 and torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
+    assert all(torch.equal(res[0][3][k], res[1][3][k]) for k in res[0][3])
+    assert all(torch.equal(res[0][4][k], res[1][4][k]) for k in res[0][4])
+    x = torch.randn(4, 9, 16, 16, device=dev())
+    w = torch.randn(256, 9, 4, 4, device=dev())
+    with pytest.raises(RuntimeError):
+        with ops.paired():
+            ops.conv4s2_fwd_inorm(x, w, 1e-5, 0.2)                          # no partner
+    with pytest.raises(RuntimeError):
+        with ops.paired():
+            ops.conv4s2_fwd_inorm(x, w, 1e-5, 0.2)
+            ops.conv4s2_wgrad(torch.randn(4, 256, 8, 8, device=dev()), x)   # another op
+    ya, _, _ = ops.conv4s2_fwd_inorm(x, w, 1e-5, 0.2)                       # (the context is clean again)
+    with ops.paired():
+        yb, _, _ = ops.conv4s2_fwd_inorm(x, w, 1e-5, 0.2)
+        yc, _, _ = ops.conv4s2_fwd_inorm(x * 2, w, 1e-5, 0.2)
+    assert torch.equal(ya, yb) and torch.equal(yc, ops.conv4s2_fwd_inorm(x * 2, w, 1e-5, 0.2)[0])
+
+
 def assert_updates_close(sd_a, sd_b, snap, rel=0.05, frac=0.01):
     """Parameter UPDATES of two training runs that should agree up to fp32 noise.  Adam / RMSprop normalise every entry,
     so a gradient entry at the noise floor can take a different +-lr step: compare the bulk of each update (relative L2)

@@ -26,16 +26,17 @@ SYMBOLS = (
     "tp_sn_work_floats", "tp_sn_fwd", "tp_sn_bwd",
     "tp_nerf_losses_fwd", "tp_nerf_losses_bwd",
     "tp_render_eval_workspace_bytes", "tp_render_eval",
-    "tp_inorm_lrelu_fwd", "tp_inorm_lrelu_bwd", "tp_inorm_lrelu_bwd_bwd",
+    "tp_inorm_lrelu_fwd", "tp_inorm_lrelu_bwd", "tp_inorm_lrelu_bwd_bwd", "tp_inorm_lrelu_bwd_pair",
     "tp_rmsprop_step",
     "tp_conv4s2_workspace", "tp_conv4s2_fwd", "tp_conv4s2_dgrad", "tp_conv4s2_wgrad", "tp_conv4s2_fwd_inorm_workspace", "tp_conv4s2_fwd_inorm",
+    "tp_conv4s2_fwd_inorm_pair", "tp_conv4s2_dgrad_pair", "tp_conv4s2_wgrad_pair",
     "tp_conv3s1_workspace", "tp_conv3s1_fwd", "tp_conv3s1_dgrad",
     "tp_patch_coords", "tp_bce_logits_fwd", "tp_bce_logits_bwd", "tp_feat_inputs_fwd", "tp_feat_inputs_bwd", "tp_disc_inputs", "tp_step_flags", "tp_adam_step", "tp_step_inputs", "tp_stamp", "tp_clock_probe",
     "tp_fake_patch_bwd", "tp_feat_pair_loss_fwd", "tp_feat_pair_loss_bwd", "tp_sumsq_mean_fwd", "tp_sumsq_mean_bwd", "tp_sumsq_mean_fwd_bwd", "tp_gan_disc_losses", "tp_maxpool2_fwd", "tp_maxpool2_bwd", "tp_latent_rows_fwd",
     "tp_latent_rows_bwd", "tp_weighted_sum", "tp_weighted_sum_flags",
     "tp_disc_head_fwd", "tp_disc_head_bwd", "tp_disc_head_bwd_bwd",
     "tp_skinny_linear_fwd", "tp_skinny_linear_wgrad", "tp_skinny_linear_dgrad",
-    "tp_disc_tail_workspace_bytes", "tp_disc_tail_fwd", "tp_disc_tail_bwd", "tp_disc_tail_bwd_bwd",
+    "tp_disc_tail_workspace_bytes", "tp_disc_tail_fwd", "tp_disc_tail_bwd", "tp_disc_tail_bwd_bwd", "tp_disc_tail_fwd_pair", "tp_disc_tail_bwd_pair",
     "tp_feat_chain_workspace", "tp_feat_chain_packed_floats", "tp_feat_chain_pack", "tp_feat_chain",
 )
 
@@ -144,6 +145,10 @@ class FeatInputsArgs(C.Structure):
                 ("mean", C.c_float * 3), ("std", C.c_float * 3)]
 
 
+class InormBwdArgs(C.Structure):
+    _fields_ = [("xhat", vp), ("rstd", vp), ("gy", vp), ("n_inst", C.c_int64), ("hw", C.c_int32), ("slope", C.c_float), ("addend", vp), ("gx", vp)]
+
+
 class FeatChainArgs(C.Structure):
     _fields_ = [("rgb", vp), ("gathered", vp), ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("n_channels", C.c_int32),
                 ("c_image", C.c_int32), ("c_image_syn", C.c_int32), ("c_mask", C.c_int32), ("c_mask_syn", C.c_int32),
@@ -249,6 +254,10 @@ def load() -> C.CDLL:
     sig("tp_conv4s2_fwd_inorm", [C.POINTER(Conv4s2Args), C.c_float, C.c_float, vp, vp, vp])
     for name in ("tp_conv4s2_fwd", "tp_conv4s2_dgrad", "tp_conv4s2_wgrad"):
         sig(name, [C.POINTER(Conv4s2Args), vp])
+    sig("tp_conv4s2_fwd_inorm_pair", [C.POINTER(Conv4s2Args), vp, vp, C.POINTER(Conv4s2Args), vp, vp, C.c_float, C.c_float, vp])
+    for name in ("tp_conv4s2_dgrad_pair", "tp_conv4s2_wgrad_pair"):
+        sig(name, [C.POINTER(Conv4s2Args), C.POINTER(Conv4s2Args), vp])
+    sig("tp_inorm_lrelu_bwd_pair", [C.POINTER(InormBwdArgs), C.POINTER(InormBwdArgs), vp])
     sig("tp_conv3s1_workspace", [C.POINTER(Conv3s1Args), C.c_int, C.POINTER(C.c_int64)], C.c_int64)
     for name in ("tp_conv3s1_fwd", "tp_conv3s1_dgrad"):
         sig(name, [C.POINTER(Conv3s1Args), vp])
@@ -280,6 +289,8 @@ def load() -> C.CDLL:
     for name in ("tp_skinny_linear_fwd", "tp_skinny_linear_wgrad", "tp_skinny_linear_dgrad"):
         sig(name, [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp])
     sig("tp_disc_tail_workspace_bytes", [C.c_int], C.c_size_t)
+    for name in ("tp_disc_tail_fwd_pair", "tp_disc_tail_bwd_pair"):
+        sig(name, [C.POINTER(DiscTailArgs), C.POINTER(DiscTailArgs), vp])
     for name in ("tp_disc_tail_fwd", "tp_disc_tail_bwd", "tp_disc_tail_bwd_bwd"):
         sig(name, [C.POINTER(DiscTailArgs), vp])
     _lib = lib

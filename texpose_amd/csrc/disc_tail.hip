@@ -157,21 +157,25 @@ __device__ __forceinline__ void outer_rows(float* out, const float* u, int ldu, 
 // ---------------------------------------------------------------------------------------------------------------- F / R1
 // MB: compile-time row bucket (4 / 8 / 16 >= M): the row loops are unrolled without predicates; rows M .. MB-1 of the LDS row arrays
 // are zero (filled at kernel start) or never consumed.
+// (pa, pb, na: two independent problems in one launch, workgroups [0, na) on the first -- see csrc/patch_conv.hip conv4s2_fwd_in_kernel)
 template <bool R1, int MB>
-__global__ __launch_bounds__(kT) void disc_tail_fwd_kernel(TailP p) {
+__global__ __launch_bounds__(kT) void disc_tail_fwd_kernel(TailP pa, TailP pb, int na) {
+  const bool second = na >= 0 && (int)blockIdx.x >= na;
+  const TailP& p = second ? pb : pa;
+  const int bid = (int)blockIdx.x - (second ? na : 0), vgrid = second ? (int)gridDim.x - na : (na >= 0 ? na : (int)gridDim.x);
   float* w1 = smem; float* w2 = w1 + p.H * p.Cin; float* w3 = w2 + p.H * (p.H + 1);
   float* a0 = w3 + p.H; float* a1 = a0 + kMaxM * p.Cin; float* a2 = a1 + kMaxM * p.H;
   float* ps = a2 + kMaxM * p.H;                    // [4][kMaxM][max(H, N)] partial sums; R1: then e1 | e2 [kMaxM][H] each, g [kMaxM]
   __shared__ int last;
   __shared__ float wsum[4][kMaxM];
-  const int t = threadIdx.x, n = blockIdx.x / p.S, s = blockIdx.x % p.S, M = p.M;
+  const int t = threadIdx.x, n = bid / p.S, s = bid % p.S, M = p.M;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
-  TSTAMP(0, blockIdx.x == 0);
+  TSTAMP(0, bid == 0);
   for (int e = t; e < kMaxM * (p.Cin + 2 * p.H); e += kT) a0[e] = 0.f;                     // a0 | a1 | a2: rows >= M stay zero
   if (R1)
     for (int e = t; e < 2 * kMaxM * p.H + kMaxM; e += kT) (ps + 4 * kMaxM * imax_dev(p.H, p.N))[e] = 0.f;      // e1 | e2 | g likewise
   stage_head_weights(p, w1, w2, w3);               // (every workgroup: whichever arrives last has them; issued first, consumed last)
-  TSTAMP(1, blockIdx.x == 0);
+  TSTAMP(1, bid == 0);
   // ---- this workgroup's slice of z[:, n]: k in [k0, k1), 16-byte loads, all rows' operands in flight together
   const int per = ((p.K / 4 + p.S - 1) / p.S) * 4, k0 = min(p.K, s * per), k1 = min(p.K, k0 + per);
   const float* wr = p.W0 + (size_t)n * p.K;
@@ -187,7 +191,7 @@ __global__ __launch_bounds__(kT) void disc_tail_fwd_kernel(TailP p) {
 #pragma unroll
     for (int r = 0; r < MB; ++r) acc[r] = fmaf(xv[r][3], wv[3], fmaf(xv[r][2], wv[2], fmaf(xv[r][1], wv[1], fmaf(xv[r][0], wv[0], acc[r]))));
   }
-  TSTAMP(2, blockIdx.x == 0);
+  TSTAMP(2, bid == 0);
   // wave butterfly (fixed order), then the four waves in wave order
 #pragma unroll
   for (int r = 0; r < MB; ++r) {
@@ -204,9 +208,9 @@ __global__ __launch_bounds__(kT) void disc_tail_fwd_kernel(TailP p) {
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (t == 0) last = __hip_atomic_fetch_add(p.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+  if (t == 0) last = __hip_atomic_fetch_add(p.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(vgrid - 1);
   __syncthreads();
-  TSTAMP(3, blockIdx.x == 0);
+  TSTAMP(3, bid == 0);
   if (!last) return;
   TSTAMP(4, true);
   if (t == 0) __hip_atomic_store(p.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // ready for the next launch
@@ -279,14 +283,17 @@ __global__ __launch_bounds__(kT) void disc_tail_fwd_kernel(TailP p) {
 
 // ---------------------------------------------------------------------------------------------------------------- B
 template <int MB>
-__global__ __launch_bounds__(kT) void disc_tail_bwd_kernel(TailP p) {
+__global__ __launch_bounds__(kT) void disc_tail_bwd_kernel(TailP pa, TailP pb, int na) {
+  const bool second = na >= 0 && (int)blockIdx.x >= na;
+  const TailP& p = second ? pb : pa;
+  const int bid = (int)blockIdx.x - (second ? na : 0), vgrid = second ? (int)gridDim.x - na : (na >= 0 ? na : (int)gridDim.x);
   float* w1 = smem; float* w2 = w1 + p.H * p.Cin; float* w3 = w2 + p.H * (p.H + 1);
   float* s2 = w3 + p.H; float* s1 = s2 + kMaxM * p.H; float* gzs = s1 + kMaxM * p.H;      // e2, e1 [kMaxM,H]; gz rows [2 kMaxM][N]
   float* t0s = gzs + 2 * kMaxM * p.N; float* t1s = t0s + kMaxM * p.Cin; float* t2s = t1s + kMaxM * p.H;
   float* gsm = t2s + kMaxM * p.H;                  // g [kMaxM]
   float* ps = gsm + kMaxM;                         // [4][kMaxM][max(H, N, 64)]: matvec partial sums, then the data gradient's
   const int t = threadIdx.x, M = p.M, M2 = p.M2;
-  TSTAMP(0, blockIdx.x == 0);
+  TSTAMP(0, bid == 0);
   // rows >= M (>= M2 of the extra rows) of every row array are zero: disjoint from what is written below, no barrier in between
   for (int e = t + M * p.H; e < kMaxM * p.H; e += kT) { s2[e] = 0.f; s1[e] = 0.f; t1s[e] = 0.f; t2s[e] = 0.f; }
   for (int e = t + M * p.N; e < kMaxM * p.N; e += kT) gzs[e] = 0.f;
@@ -299,7 +306,7 @@ __global__ __launch_bounds__(kT) void disc_tail_bwd_kernel(TailP p) {
   for (int e = t; e < M2 * p.N; e += kT) gzs[kMaxM * p.N + e] = p.gy2[e];       // (the extra rows start at row kMaxM)
   if (t < M) gsm[t] = p.g[t];
   __syncthreads();
-  TSTAMP(1, blockIdx.x == 0);
+  TSTAMP(1, bid == 0);
   // ---- the head's backward (recomputed by every workgroup: ~M (H + H H + H C) MACs)
   for (int e = t; e < M * p.H; e += kT) {
     const int m = e / p.H, o = e - m * p.H;
@@ -309,10 +316,10 @@ __global__ __launch_bounds__(kT) void disc_tail_bwd_kernel(TailP p) {
   matvec4<true, MB>(w2, p.H + 1, s2, p.H, p.H, p.H, M, ps, [&](int m, int j, float v) { s1[m * p.H + j] = v * dl(t1s[m * p.H + j], p.slope); });
   matvec4<true, MB>(w1, p.Cin, s1, p.H, p.H, p.N, M, ps,                                      // only the z part of e0 is anybody's gradient (N == C)
                     [&](int m, int j, float v) { gzs[m * p.N + j] = v * dl(t0s[m * p.Cin + j], p.slope); });
-  TSTAMP(2, blockIdx.x == 0);
+  TSTAMP(2, bid == 0);
   // ---- this workgroup's 64 columns of K: thread (kc, run) -- data gradient: run = quarter of the N rows of W0; weight gradient:
   // run = quarter of the N rows of gW0
-  const int kc = t & 63, k = blockIdx.x * 64 + kc, kk0 = min(k, p.K - 1);
+  const int kc = t & 63, k = bid * 64 + kc, kk0 = min(k, p.K - 1);
   const int run = __builtin_amdgcn_readfirstlane(t >> 6);
   const int per = (p.N + 3) / 4, n0 = run * per, n1 = min(p.N, n0 + per);
   float xa[MB], xb[MB];
@@ -341,8 +348,8 @@ __global__ __launch_bounds__(kT) void disc_tail_bwd_kernel(TailP p) {
     for (int m = 0; m < MB; ++m) ps[(run * kMaxM + m) * 64 + kc] = acc[m];
     __syncthreads();
     for (int e = t; e < ((M * 64 + kT - 1) / kT) * kT; e += kT) {               // (whole waves: the lane groups below shuffle)
-      const int m = min(e >> 6, M - 1), c = e & 63, kk = min(blockIdx.x * 64 + c, p.K - 1);
-      const bool live = (e >> 6) < M && blockIdx.x * 64 + c < p.K;
+      const int m = min(e >> 6, M - 1), c = e & 63, kk = min(bid * 64 + c, p.K - 1);
+      const bool live = (e >> 6) < M && bid * 64 + c < p.K;
       const float v = ((ps[(0 * kMaxM + m) * 64 + c] + ps[(1 * kMaxM + m) * 64 + c]) + ps[(2 * kMaxM + m) * 64 + c]) + ps[(3 * kMaxM + m) * 64 + c];
       const size_t idx = (size_t)m * p.K + kk;
       if (live && p.c_a_store) p.c_a[idx] = v;
@@ -360,7 +367,7 @@ __global__ __launch_bounds__(kT) void disc_tail_bwd_kernel(TailP p) {
       }
     }
   }
-  TSTAMP(3, blockIdx.x == 0);
+  TSTAMP(3, bid == 0);
   if (p.gW0 != nullptr && k < p.K) {
 #pragma unroll 2
     for (int n = n0; n < n1; ++n) {
@@ -375,9 +382,9 @@ __global__ __launch_bounds__(kT) void disc_tail_bwd_kernel(TailP p) {
       p.gW0[(size_t)n * p.K + k] = v;
     }
   }
-  TSTAMP(4, blockIdx.x == 0);
+  TSTAMP(4, bid == 0);
   // ---- what the caller keeps of the head's backward (workgroup 0), and the head's weight gradients, spread over the workgroups
-  if (blockIdx.x == 0) {
+  if (bid == 0) {
     for (int e = t; e < M * p.H; e += kT) {
       if (p.e1 != nullptr) p.e1[e] = s1[e];
       if (p.e2 != nullptr) p.e2[e] = s2[e];
@@ -387,12 +394,12 @@ __global__ __launch_bounds__(kT) void disc_tail_bwd_kernel(TailP p) {
   }
   if (p.gW1 == nullptr) return;
   const bool add = p.accumulate != 0;
-  const int G = gridDim.x, b = blockIdx.x;
+  const int G = vgrid, b = bid;
   const int n1e = p.H * p.Cin, n2e = p.H * p.H;
   outer_rows<MB>(p.gW1, s1, p.H, t0s, p.Cin, p.Cin, (int)((int64_t)n1e * b / G), (int)((int64_t)n1e * (b + 1) / G), add);
   outer_rows<MB>(p.gW2, s2, p.H, t1s, p.H, p.H, (int)((int64_t)n2e * b / G), (int)((int64_t)n2e * (b + 1) / G), add);
   outer_rows<MB>(p.gW3, gsm, 1, t2s, p.H, p.H, (int)((int64_t)p.H * b / G), (int)((int64_t)p.H * (b + 1) / G), add);
-  TSTAMP(5, blockIdx.x == 0);
+  TSTAMP(5, bid == 0);
 }
 
 int imax3(int a, int b, int c) { return a > b ? (a > c ? a : c) : (b > c ? b : c); }
@@ -427,15 +434,19 @@ int fill(TailP* q, const tp_disc_tail_args* a, const char* what) {
   return 0;
 }
 
+// one problem (qb == nullptr) or two in one launch
 template <class K>
-int launch(K kernel, const TailP& q, int grid, size_t lds, tp_stream_t stream, const char* what, unsigned long long& flags) {
+int launch(K kernel, const TailP& q, int grid, size_t lds, tp_stream_t stream, const char* what, unsigned long long& flags,
+           const TailP* qb = nullptr, int grid_b = 0, size_t lds_b = 0) {
+  if (lds_b > lds) lds = lds_b;
   if (lds > 150 * 1024) { tp::set_error("%s: head too wide for one workgroup's LDS", what); return -1; }
   if (lds > 48 * 1024 && tp::first_use_on_device(flags) &&
       hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) {
     tp::set_error("%s: cannot raise the LDS limit", what);
     return -1;
   }
-  hipLaunchKernelGGL(kernel, dim3(grid), dim3(kT), lds, (hipStream_t)stream, q);
+  if (qb != nullptr) hipLaunchKernelGGL(kernel, dim3(grid + grid_b), dim3(kT), lds, (hipStream_t)stream, q, *qb, grid);
+  else hipLaunchKernelGGL(kernel, dim3(grid), dim3(kT), lds, (hipStream_t)stream, q, q, -1);
   return tp::check_launch(what);
 }
 
@@ -466,6 +477,20 @@ int tp_disc_tail_fwd(const tp_disc_tail_args* a, tp_stream_t stream) {
   if (q.M <= 8) return launch(disc_tail_fwd_kernel<false, 8>, q, q.N * q.S, lds_fwd(q), stream, "tp_disc_tail_fwd", flags[1]);
   return launch(disc_tail_fwd_kernel<false, 16>, q, q.N * q.S, lds_fwd(q), stream, "tp_disc_tail_fwd", flags[2]);
 }
+int tp_disc_tail_fwd_pair(const tp_disc_tail_args* a, const tp_disc_tail_args* b, tp_stream_t stream) {
+  static unsigned long long flags[3] = {0, 0, 0};
+  TailP qa{}, qb{};
+  TP_REQUIRE(a && b, "null argument");
+  if (int rc = fill(&qa, a, "tp_disc_tail_fwd_pair")) return rc;
+  if (int rc = fill(&qb, b, "tp_disc_tail_fwd_pair")) return rc;
+  TP_REQUIRE(qa.a && qa.scale && qa.out && qa.ws && qa.ticket && qb.a && qb.scale && qb.out && qb.ws && qb.ticket, "operand missing");
+  TP_REQUIRE(qa.ws != qb.ws && qa.ticket != qb.ticket, "the two problems of a pair need their own workspace / ticket");
+  qa.S = splits_for(qa); qb.S = splits_for(qb);
+  const int rows = qa.M > qb.M ? qa.M : qb.M, ga = qa.N * qa.S, gb = qb.N * qb.S;
+  if (rows <= 4) return launch(disc_tail_fwd_kernel<false, 4>, qa, ga, lds_fwd(qa), stream, "tp_disc_tail_fwd_pair", flags[0], &qb, gb, lds_fwd(qb));
+  if (rows <= 8) return launch(disc_tail_fwd_kernel<false, 8>, qa, ga, lds_fwd(qa), stream, "tp_disc_tail_fwd_pair", flags[1], &qb, gb, lds_fwd(qb));
+  return launch(disc_tail_fwd_kernel<false, 16>, qa, ga, lds_fwd(qa), stream, "tp_disc_tail_fwd_pair", flags[2], &qb, gb, lds_fwd(qb));
+}
 int tp_disc_tail_bwd_bwd(const tp_disc_tail_args* a, tp_stream_t stream) {
   static unsigned long long flags[3] = {0, 0, 0};
   TailP q{};
@@ -476,14 +501,30 @@ int tp_disc_tail_bwd_bwd(const tp_disc_tail_args* a, tp_stream_t stream) {
   if (q.M <= 8) return launch(disc_tail_fwd_kernel<true, 8>, q, q.N * q.S, lds_fwd(q), stream, "tp_disc_tail_bwd_bwd", flags[1]);
   return launch(disc_tail_fwd_kernel<true, 16>, q, q.N * q.S, lds_fwd(q), stream, "tp_disc_tail_bwd_bwd", flags[2]);
 }
+static int bwd_fill(TailP* q, const tp_disc_tail_args* a, const char* what) {
+  if (int rc = fill(q, a, what)) return rc;
+  TP_REQUIRE(q->g != nullptr, "g_out missing");
+  TP_REQUIRE((q->gW1 && q->gW2 && q->gW3) || (!q->gW1 && !q->gW2 && !q->gW3), "gW1..3: all or none");
+  TP_REQUIRE(q->gW0 == nullptr || q->a != nullptr, "gW0 needs the ladder output a");
+  TP_REQUIRE(q->M2 == 0 || (q->gy2 && q->a2 && q->gW0), "the extra rows belong to the weight gradient gW0");
+  return 0;
+}
+int tp_disc_tail_bwd_pair(const tp_disc_tail_args* a, const tp_disc_tail_args* b, tp_stream_t stream) {
+  static unsigned long long flags[3] = {0, 0, 0};
+  TailP qa{}, qb{};
+  TP_REQUIRE(a && b, "null argument");
+  if (int rc = bwd_fill(&qa, a, "tp_disc_tail_bwd_pair")) return rc;
+  if (int rc = bwd_fill(&qb, b, "tp_disc_tail_bwd_pair")) return rc;
+  const int ra = qa.M > qa.M2 ? qa.M : qa.M2, rb = qb.M > qb.M2 ? qb.M : qb.M2, rows = ra > rb ? ra : rb;
+  const int ga = (qa.K + 63) / 64, gb = (qb.K + 63) / 64;
+  if (rows <= 4) return launch(disc_tail_bwd_kernel<4>, qa, ga, lds_bwd(qa), stream, "tp_disc_tail_bwd_pair", flags[0], &qb, gb, lds_bwd(qb));
+  if (rows <= 8) return launch(disc_tail_bwd_kernel<8>, qa, ga, lds_bwd(qa), stream, "tp_disc_tail_bwd_pair", flags[1], &qb, gb, lds_bwd(qb));
+  return launch(disc_tail_bwd_kernel<16>, qa, ga, lds_bwd(qa), stream, "tp_disc_tail_bwd_pair", flags[2], &qb, gb, lds_bwd(qb));
+}
 int tp_disc_tail_bwd(const tp_disc_tail_args* a, tp_stream_t stream) {
   static unsigned long long flags[3] = {0, 0, 0};
   TailP q{};
-  if (int rc = fill(&q, a, "tp_disc_tail_bwd")) return rc;
-  TP_REQUIRE(q.g != nullptr, "g_out missing");
-  TP_REQUIRE((q.gW1 && q.gW2 && q.gW3) || (!q.gW1 && !q.gW2 && !q.gW3), "gW1..3: all or none");
-  TP_REQUIRE(q.gW0 == nullptr || q.a != nullptr, "gW0 needs the ladder output a");
-  TP_REQUIRE(q.M2 == 0 || (q.gy2 && q.a2 && q.gW0), "the extra rows belong to the weight gradient gW0");
+  if (int rc = bwd_fill(&q, a, "tp_disc_tail_bwd")) return rc;
   const int rows = q.M > q.M2 ? q.M : q.M2, grid = (q.K + 63) / 64;
   if (rows <= 4) return launch(disc_tail_bwd_kernel<4>, q, grid, lds_bwd(q), stream, "tp_disc_tail_bwd", flags[0]);
   if (rows <= 8) return launch(disc_tail_bwd_kernel<8>, q, grid, lds_bwd(q), stream, "tp_disc_tail_bwd", flags[1]);

@@ -43,11 +43,19 @@ __global__ __launch_bounds__(256) void inorm_lrelu_fwd_kernel(const float* __res
   if (lane == 0) rstd[inst] = r;
 }
 
-__global__ __launch_bounds__(256) void inorm_lrelu_bwd_kernel(const float* __restrict__ xhat, const float* __restrict__ rstd,
-                                                               const float* __restrict__ gy, int64_t n_inst, int hw, float slope,
-                                                               const float* __restrict__ addend, float* __restrict__ gx) {
+struct InBwdP { const float* xhat; const float* rstd; const float* gy; int64_t n_inst; int hw; float slope; const float* addend; float* gx; };
+
+// (pa, pb, na: two independent problems in one launch, workgroups [0, na) on the first -- see csrc/patch_conv.hip conv4s2_fwd_in_kernel)
+__global__ __launch_bounds__(256) void inorm_lrelu_bwd_kernel(InBwdP pa, InBwdP pb, int na) {
+  const bool second = na >= 0 && (int)blockIdx.x >= na;
+  const InBwdP& p = second ? pb : pa;
+  const float* __restrict__ xhat = p.xhat; const float* __restrict__ rstd = p.rstd; const float* __restrict__ gy = p.gy;
+  const float* __restrict__ addend = p.addend; float* __restrict__ gx = p.gx;
+  const int64_t n_inst = p.n_inst;
+  const int hw = p.hw;
+  const float slope = p.slope;
   const int lane = threadIdx.x & 63;
-  const int64_t inst = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t inst = (int64_t)((int)blockIdx.x - (second ? na : 0)) * 4 + (threadIdx.x >> 6);
   if (inst >= n_inst) return;
   const float* h = xhat + inst * hw;
   const float* g = gy + inst * hw;
@@ -105,9 +113,19 @@ extern "C" int tp_inorm_lrelu_bwd(const float* xhat, const float* rstd, const fl
                                   const float* addend, float* gx, tp_stream_t stream) {
   TP_REQUIRE(xhat && rstd && gy && gx, "null pointer");
   TP_REQUIRE(n_inst > 0 && hw > 0, "bad sizes");
-  hipLaunchKernelGGL(inorm_lrelu_bwd_kernel, dim3((unsigned)((n_inst + 3) / 4)), dim3(256), 0, (hipStream_t)stream, xhat, rstd, gy,
-                     n_inst, hw, slope, addend, gx);
+  const InBwdP p{xhat, rstd, gy, n_inst, hw, slope, addend, gx};
+  hipLaunchKernelGGL(inorm_lrelu_bwd_kernel, dim3((unsigned)((n_inst + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p, p, -1);
   return tp::check_launch("tp_inorm_lrelu_bwd");
+}
+
+extern "C" int tp_inorm_lrelu_bwd_pair(const tp_inorm_bwd_args* a, const tp_inorm_bwd_args* b, tp_stream_t stream) {
+  TP_REQUIRE(a && b && a->xhat && a->rstd && a->gy && a->gx && b->xhat && b->rstd && b->gy && b->gx, "null pointer");
+  TP_REQUIRE(a->n_inst > 0 && a->hw > 0 && b->n_inst > 0 && b->hw > 0 && a->gx != b->gx, "bad sizes");
+  const InBwdP pa{a->xhat, a->rstd, a->gy, a->n_inst, a->hw, a->slope, a->addend, a->gx};
+  const InBwdP pb{b->xhat, b->rstd, b->gy, b->n_inst, b->hw, b->slope, b->addend, b->gx};
+  const unsigned ga = (unsigned)((a->n_inst + 3) / 4), gb = (unsigned)((b->n_inst + 3) / 4);
+  hipLaunchKernelGGL(inorm_lrelu_bwd_kernel, dim3(ga + gb), dim3(256), 0, (hipStream_t)stream, pa, pb, (int)ga);
+  return tp::check_launch("tp_inorm_lrelu_bwd_pair");
 }
 
 extern "C" int tp_inorm_lrelu_bwd_bwd(const float* xhat, const float* rstd, const float* gy, const float* ggx, int64_t n_inst,

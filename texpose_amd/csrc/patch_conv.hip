@@ -90,11 +90,18 @@ __global__ __launch_bounds__(256) void conv4s2_fwd_kernel(ConvP p) {
 // Outputs: y = lrelu(xhat), xhat, rstd -- what tp_inorm_lrelu_fwd returns -- and no z.  One launch instead of two per ladder stage.
 struct InP { float* xhat; float* rstd; float eps, slope; };
 
+// (pa, qa) and (pb, qb): TWO independent problems in one launch -- workgroups [0, na) work on the first, the rest on the second (na < 0: one
+// problem).  The discriminator step runs its real and its fake pass as such pairs (texpose_amd/disc_step.py): the kernels are latency-sized
+// at these shapes, so two side by side take the time of one.
 template <int NT>
-__global__ __launch_bounds__(256) void conv4s2_fwd_in_kernel(ConvP p, InP q) {
+__global__ __launch_bounds__(256) void conv4s2_fwd_in_kernel(ConvP pa, InP qa, ConvP pb, InP qb, int na) {
   __shared__ float lds[NT * 32 * 33 > kReduceLdsFloats ? NT * 32 * 33 : kReduceLdsFloats];    // (reduce_tiles, then the [rows][33] totals)
+  const bool second = na >= 0 && (int)blockIdx.x >= na;
+  const ConvP& p = second ? pb : pa;
+  const InP& q = second ? qb : qa;
+  const int bid = (int)blockIdx.x - (second ? na : 0);
   const int t = threadIdx.x, w = t >> 6, lane = t & 63, col = lane & 31, h = lane >> 5;
-  const int s = blockIdx.x % p.S, tile = blockIdx.x / p.S, nt = tile % p.tiles_n, mt = tile / p.tiles_n;
+  const int s = bid % p.S, tile = bid / p.S, nt = tile % p.tiles_n, mt = tile / p.tiles_n;
   const int P = 1 << p.lp, M = p.N << p.lp, HW = p.H * p.W;
   int off[NT][8];
   bool ok[NT][8];
@@ -188,10 +195,13 @@ __global__ __launch_bounds__(256) void conv4s2_fwd_in_kernel(ConvP p, InP q) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------- D
-__global__ __launch_bounds__(256) void conv4s2_dgrad_kernel(ConvP p) {
+__global__ __launch_bounds__(256) void conv4s2_dgrad_kernel(ConvP pa, ConvP pb, int na) {       // (two problems: see conv4s2_fwd_in_kernel)
   __shared__ float lds[kReduceLdsFloats];
+  const bool second = na >= 0 && (int)blockIdx.x >= na;
+  const ConvP& p = second ? pb : pa;
+  const int bid = (int)blockIdx.x - (second ? na : 0);
   const int t = threadIdx.x, w = t >> 6, lane = t & 63, col = lane & 31, h = lane >> 5;
-  const int s = blockIdx.x % p.S, tile = blockIdx.x / p.S, nt = tile % p.tiles_n, mt = tile / p.tiles_n;
+  const int s = bid % p.S, tile = bid / p.S, nt = tile % p.tiles_n, mt = tile / p.tiles_n;
   const int P = 1 << p.lp, M = p.N << p.lp;
   // A operand: gy in the 3x3 neighbourhood of (a, b), channel co = 2q + h
   const int m = mt * 32 + col, mc = min(m, M - 1);
@@ -264,10 +274,13 @@ __global__ __launch_bounds__(256) void conv4s2_dgrad_kernel(ConvP p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------- G
-__global__ __launch_bounds__(256) void conv4s2_wgrad_kernel(ConvP p) {
+__global__ __launch_bounds__(256) void conv4s2_wgrad_kernel(ConvP pa, ConvP pb, int na) {       // (two problems: see conv4s2_fwd_in_kernel)
   __shared__ float lds[kReduceLdsFloats];
+  const bool second = na >= 0 && (int)blockIdx.x >= na;
+  const ConvP& p = second ? pb : pa;
+  const int bid = (int)blockIdx.x - (second ? na : 0);
   const int t = threadIdx.x, w = t >> 6, lane = t & 63, col = lane & 31, h = lane >> 5;
-  const int s = blockIdx.x % p.S, tile = blockIdx.x / p.S, nt = tile % p.tiles_n, mt = tile / p.tiles_n;
+  const int s = bid % p.S, tile = bid / p.S, nt = tile % p.tiles_n, mt = tile / p.tiles_n;
   const int P = 1 << p.lp, M = p.N << p.lp, HW = p.H * p.W, KW = p.C * 16;
   // A operand: gy[n, co, p .. p+3]  (rows = co);  B operand: x gathered at (ci, ky, kx) = column j
   const int co = min(mt * 32 + col, p.Co - 1);
@@ -425,22 +438,38 @@ int64_t tp_conv4s2_workspace(const tp_conv4s2_args* a, int op, int64_t* n_counte
   return (int64_t)q.ws_floats;
 }
 
-static int conv_launch(const tp_conv4s2_args* a, int op, tp_stream_t stream) {
-  Plan q; ConvP p;
-  const int rc = conv_plan(a, op, &q, &p);
+static int conv_fill(const tp_conv4s2_args* a, int op, Plan* q, ConvP* p) {
+  const int rc = conv_plan(a, op, q, p);
   if (rc != 0) return rc;
-  TP_REQUIRE(a->out && a->counters && (!q.ws_floats || a->workspace), "out / counters / workspace missing");
+  TP_REQUIRE(a->out && a->counters && (!q->ws_floats || a->workspace), "out / counters / workspace missing");
   TP_REQUIRE((op == 1 || a->x) && (op == 2 || a->w) && (op == 0 || a->gy), "operand missing");
-  p.x = a->x; p.w = a->w; p.gy = a->gy; p.out = a->out; p.ws = a->workspace; p.cnt = (unsigned*)a->counters;
-  const dim3 grid((unsigned)(q.tiles_m * q.tiles_n * q.S)), block(256);
+  p->x = a->x; p->w = a->w; p->gy = a->gy; p->out = a->out; p->ws = a->workspace; p->cnt = (unsigned*)a->counters;
+  return 0;
+}
+// one problem (b == nullptr) or two in one launch (different counters / workspaces: they run side by side)
+static int conv_launch(const tp_conv4s2_args* a, const tp_conv4s2_args* b, int op, tp_stream_t stream) {
+  Plan qa, qb; ConvP pa, pb;
+  if (const int rc = conv_fill(a, op, &qa, &pa)) return rc;
+  const unsigned ga = (unsigned)(qa.tiles_m * qa.tiles_n * qa.S);
+  unsigned gb = 0;
+  int na = -1;
+  pb = pa;
+  if (b != nullptr) {
+    TP_REQUIRE(op != 0, "pairs: data gradient, weight gradient, forward + InstanceNorm");
+    if (const int rc = conv_fill(b, op, &qb, &pb)) return rc;
+    TP_REQUIRE(a->counters != b->counters && (a->workspace != b->workspace || !a->workspace) && a->out != b->out, "the two problems of a pair need their own counters / workspace / output");
+    gb = (unsigned)(qb.tiles_m * qb.tiles_n * qb.S);
+    na = (int)ga;
+  }
+  const dim3 grid(ga + gb), block(256);
   hipStream_t st = (hipStream_t)stream;
-  if (op == 0) hipLaunchKernelGGL(conv4s2_fwd_kernel, grid, block, 0, st, p);
-  else if (op == 1) hipLaunchKernelGGL(conv4s2_dgrad_kernel, grid, block, 0, st, p);
-  else hipLaunchKernelGGL(conv4s2_wgrad_kernel, grid, block, 0, st, p);
+  if (op == 0) hipLaunchKernelGGL(conv4s2_fwd_kernel, grid, block, 0, st, pa);
+  else if (op == 1) hipLaunchKernelGGL(conv4s2_dgrad_kernel, grid, block, 0, st, pa, pb, na);
+  else hipLaunchKernelGGL(conv4s2_wgrad_kernel, grid, block, 0, st, pa, pb, na);
   return tp::check_launch(op == 0 ? "tp_conv4s2_fwd" : op == 1 ? "tp_conv4s2_dgrad" : "tp_conv4s2_wgrad");
 }
 
-int tp_conv4s2_fwd(const tp_conv4s2_args* a, tp_stream_t stream) { return conv_launch(a, 0, stream); }
+int tp_conv4s2_fwd(const tp_conv4s2_args* a, tp_stream_t stream) { return conv_launch(a, nullptr, 0, stream); }
 
 // row tiles per workgroup of the fused convolution + InstanceNorm launch (0: this map size is not covered)
 static int fwd_in_nt(const tp_conv4s2_args* a) {
@@ -472,20 +501,52 @@ int64_t tp_conv4s2_fwd_inorm_workspace(const tp_conv4s2_args* a, int64_t* n_coun
   if (n_counters) *n_counters = (int64_t)q.tiles_m * q.tiles_n;
   return (int64_t)q.ws_floats;
 }
-int tp_conv4s2_fwd_inorm(const tp_conv4s2_args* a, float eps, float slope, float* xhat, float* rstd, tp_stream_t stream) {
-  Plan q; ConvP p;
-  if (const int rc = conv_in_plan(a, &q, &p)) return rc;
-  TP_REQUIRE(a->x && a->w && a->out && xhat && rstd && a->counters && (!q.ws_floats || a->workspace), "operand / counters / workspace missing");
-  TP_REQUIRE((a->N * p.OH * p.OW) % 16 == 0, "whole instances per tile needed");
-  p.x = a->x; p.w = a->w; p.gy = nullptr; p.out = a->out; p.ws = a->workspace; p.cnt = (unsigned*)a->counters;
-  InP in{xhat, rstd, eps, slope};
-  const dim3 grid((unsigned)(q.tiles_m * q.tiles_n * q.S)), block(256);
-  if (fwd_in_nt(a) == 1) hipLaunchKernelGGL(conv4s2_fwd_in_kernel<1>, grid, block, 0, (hipStream_t)stream, p, in);
-  else hipLaunchKernelGGL(conv4s2_fwd_in_kernel<2>, grid, block, 0, (hipStream_t)stream, p, in);
+static int conv_in_fill(const tp_conv4s2_args* a, float* xhat, float* rstd, Plan* q, ConvP* p) {
+  if (const int rc = conv_in_plan(a, q, p)) return rc;
+  TP_REQUIRE(a->x && a->w && a->out && xhat && rstd && a->counters && (!q->ws_floats || a->workspace), "operand / counters / workspace missing");
+  TP_REQUIRE((a->N * p->OH * p->OW) % 16 == 0, "whole instances per tile needed");
+  p->x = a->x; p->w = a->w; p->gy = nullptr; p->out = a->out; p->ws = a->workspace; p->cnt = (unsigned*)a->counters;
+  return 0;
+}
+static int conv_in_launch(const tp_conv4s2_args* a, float* xhat_a, float* rstd_a, const tp_conv4s2_args* b, float* xhat_b, float* rstd_b,
+                          float eps, float slope, tp_stream_t stream) {
+  Plan qa, qb; ConvP pa, pb;
+  if (const int rc = conv_in_fill(a, xhat_a, rstd_a, &qa, &pa)) return rc;
+  InP ia{xhat_a, rstd_a, eps, slope}, ib = ia;
+  unsigned ga = (unsigned)(qa.tiles_m * qa.tiles_n * qa.S), gb = 0;
+  int na = -1;
+  pb = pa;
+  if (b != nullptr) {
+    if (const int rc = conv_in_fill(b, xhat_b, rstd_b, &qb, &pb)) return rc;
+    TP_REQUIRE(fwd_in_nt(a) == fwd_in_nt(b), "the two problems of a pair need the same map size");
+    TP_REQUIRE(a->counters != b->counters && (a->workspace != b->workspace || !a->workspace) && a->out != b->out, "the two problems of a pair need their own counters / workspace / output");
+    ib = InP{xhat_b, rstd_b, eps, slope};
+    gb = (unsigned)(qb.tiles_m * qb.tiles_n * qb.S);
+    na = (int)ga;
+  }
+  const dim3 grid(ga + gb), block(256);
+  if (fwd_in_nt(a) == 1) hipLaunchKernelGGL(conv4s2_fwd_in_kernel<1>, grid, block, 0, (hipStream_t)stream, pa, ia, pb, ib, na);
+  else hipLaunchKernelGGL(conv4s2_fwd_in_kernel<2>, grid, block, 0, (hipStream_t)stream, pa, ia, pb, ib, na);
   return tp::check_launch("tp_conv4s2_fwd_inorm");
 }
-int tp_conv4s2_dgrad(const tp_conv4s2_args* a, tp_stream_t stream) { return conv_launch(a, 1, stream); }
-int tp_conv4s2_wgrad(const tp_conv4s2_args* a, tp_stream_t stream) { return conv_launch(a, 2, stream); }
+int tp_conv4s2_fwd_inorm(const tp_conv4s2_args* a, float eps, float slope, float* xhat, float* rstd, tp_stream_t stream) {
+  return conv_in_launch(a, xhat, rstd, nullptr, nullptr, nullptr, eps, slope, stream);
+}
+int tp_conv4s2_fwd_inorm_pair(const tp_conv4s2_args* a, float* xhat_a, float* rstd_a, const tp_conv4s2_args* b, float* xhat_b, float* rstd_b,
+                              float eps, float slope, tp_stream_t stream) {
+  TP_REQUIRE(a && b, "null argument");
+  return conv_in_launch(a, xhat_a, rstd_a, b, xhat_b, rstd_b, eps, slope, stream);
+}
+int tp_conv4s2_dgrad(const tp_conv4s2_args* a, tp_stream_t stream) { return conv_launch(a, nullptr, 1, stream); }
+int tp_conv4s2_wgrad(const tp_conv4s2_args* a, tp_stream_t stream) { return conv_launch(a, nullptr, 2, stream); }
+int tp_conv4s2_dgrad_pair(const tp_conv4s2_args* a, const tp_conv4s2_args* b, tp_stream_t stream) {
+  TP_REQUIRE(a && b, "null argument");
+  return conv_launch(a, b, 1, stream);
+}
+int tp_conv4s2_wgrad_pair(const tp_conv4s2_args* a, const tp_conv4s2_args* b, tp_stream_t stream) {
+  TP_REQUIRE(a && b, "null argument");
+  return conv_launch(a, b, 2, stream);
+}
 
 static int conv3_plan(const tp_conv3s1_args* a, int transposed, Plan* q, Conv3P* p) {
   TP_REQUIRE(a && a->N > 0 && a->C > 0 && a->Co > 0, "bad sizes");

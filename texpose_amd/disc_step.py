@@ -25,6 +25,7 @@ keeps its autograd form for those (golden generation, contract tests).
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional
 
 import torch
@@ -232,6 +233,119 @@ class DiscStepSchedule:
                 c_a = ops.conv4s2_dgrad(c_z, W[l])
         return f, r1, gw + [gW1, gW2, gW3]
 
+    # ------------------------------------------------------------------ the step with the real and the fake pass as PAIRS of launches
+    # D(real) and D(fake) go through the same kernels one after the other, and so do their backward passes; every one of those launches
+    # is latency-sized (10-15 us for MFLOPs), so the two problems of a pair run in ONE launch (ops.paired / tp_*_pair) in the time of
+    # one: 8 launches and ~75 us off the discriminator chain of the B=4 iteration, the chain that bounds it.  Same
+    # kernels on the same operands: values identical to the sequential schedule.
+    def pairs_eligible(self, x) -> bool:
+        if os.environ.get("TP_NO_DISC_PAIRS") == "1":
+            return False
+        B, _, h, w = x.shape
+        for _ in self.stages:
+            if (h // 2) * (w // 2) not in (16, 64) or h != w or os.environ.get("TP_NO_CONV_INORM") == "1":
+                return False
+            h, w = h // 2, w // 2
+        K_in = self.full.weight_orig.shape[1] * h * w
+        return K_in % 4 == 0 and B <= ops.DISC_TAIL_MAX_ROWS and os.environ.get("TP_NO_DISC_TAIL") != "1"
+
+    def _forward_pair(self, xr, Wr, xf, Wf, scale, stacks):
+        """`_forward` of the real patches (weights Wr, inputs of the later stages into `stacks`) and of the fake patches (Wf), in pairs."""
+        K, B, sl = len(self.stages), xr.shape[0], self.slope
+        ar, af, sr, sf = xr, xf, [], []
+        for l, (_conv, eps) in enumerate(self.stages):
+            with ops.paired():
+                yr, xhr, rsr = ops.conv4s2_fwd_inorm(ar, Wr[l], eps, sl, y_out=stacks[l + 1][:B])
+                yf, xhf, rsf = ops.conv4s2_fwd_inorm(af, Wf[l], eps, sl)
+            sr.append(AttrDict(x=ar, xhat=xhr, rstd=rsr))
+            sf.append(AttrDict(x=af, xhat=xhf, rstd=rsf))
+            ar, af = yr, yf
+        L = self.disc.L_scale
+        with ops.paired():
+            outr = ops.disc_tail_fwd(ar.reshape(B, -1), Wr[K].flatten(1), scale, *self._head_w(Wr), L, sl)
+            outf = ops.disc_tail_fwd(af.reshape(B, -1), Wf[K].flatten(1), scale, *self._head_w(Wf), L, sl)
+        fr = AttrDict(out=outr[0], stages=sr, a_full=ar, head=outr[1:], C_z=Wr[K].shape[0], tail=True)
+        ff = AttrDict(out=outf[0], stages=sf, a_full=af, head=outf[1:], C_z=Wf[K].shape[0], tail=True)
+        return fr, ff
+
+    def _r1_passes(self, f, W, xs, gs, w_reg):
+        """The R1 penalty on the real pass `f` (reference :794-807 and the .mean() of :149): first pass (d D(real).sum() / d real), value +
+        weighted cotangent, second pass back through the first.  Fills the second halves of the stacks xs / gs (the R1 pairs of the weight
+        gradients); returns (r1 = (value, weighted value), c_zr per stage, (gW1, gW2, gW3) of the head from the second pass)."""
+        K, B, sl, L = len(self.stages), f.out.shape[0], self.slope, self.disc.L_scale
+        t0, t1, t2 = f.head
+        Wh = self._head_w(W)
+        ones = self._ones_like(f.out)
+        W0 = W[K].flatten(1)
+        last = f.stages[K - 1]
+        r = ops.disc_tail_bwd(ones, t0, t1, t2, W0, *Wh, L, sl, want_gW0=False, head_weight_grads=False, want_e=True, gz_out=gs[K][B:],
+                              inorm=dict(xhat=last.xhat, rstd=last.rstd, out=gs[K - 1][B:]))
+        e1, e2, ga, ga_in, gz_last = r["e1"], r["e2"], r["c_a"].view_as(f.a_full), [None] * K, r["c_z"]
+        for l in range(K - 1, -1, -1):
+            st = f.stages[l]
+            ga_in[l] = ga
+            gz = gz_last if l == K - 1 else ops.inorm_lrelu_bwd(st.xhat, st.rstd, ga, sl, out=gs[l][B:])
+            ga = ops.conv4s2_dgrad(gz, W[l])
+        r1, c = ops.sumsq_mean_fwd_bwd(ga, w_reg, out_g=xs[0][B:])
+        c_zr = [None] * K
+        for l in range(K):
+            st = f.stages[l]
+            c_gz = ops.conv4s2_fwd(c, W[l])
+            c, c_zr[l] = ops.inorm_lrelu_bwd_bwd(st.xhat, st.rstd, ga_in[l], c_gz, sl, out_gy=xs[l + 1][B:])
+        gWh = ops.disc_tail_bwd_bwd(c.reshape(B, -1), ones, t0, t1, t2, e1, e2, W0, *Wh, L, sl)
+        return r1, c_zr, gWh
+
+    def _backward_pair(self, fr, Wr, g_real, xs, gs, c_zr, gWh, ff, Wf, g_fake):
+        """All weight gradients of both passes, in pairs: the real pass' BCE path joined with its R1 path on the way (stacks xs / gs, the
+        second-pass cotangents c_zr as addends, the head's second-pass gradients gWh accumulated into), the fake pass' plain backward."""
+        K, B, sl, L = len(self.stages), g_real.shape[0], self.slope, self.disc.L_scale
+        lr, lf = fr.stages[K - 1], ff.stages[K - 1]
+        with ops.paired():
+            rr = ops.disc_tail_bwd(g_real, *fr.head, Wr[K].flatten(1), *self._head_w(Wr), L, sl, a=xs[K][:B].reshape(B, -1), accumulate_into=gWh,
+                                   gy2=gs[K][B:], a2=xs[K][B:].reshape(B, -1), want_c_a=False,
+                                   inorm=dict(xhat=lr.xhat, rstd=lr.rstd, addend=c_zr[K - 1], out=gs[K - 1][:B]))
+            rf = ops.disc_tail_bwd(g_fake, *ff.head, Wf[K].flatten(1), *self._head_w(Wf), L, sl, a=ff.a_full.reshape(B, -1), want_c_a=False,
+                                   inorm=dict(xhat=lf.xhat, rstd=lf.rstd))
+        gwr, gwf = [None] * (K + 1), [None] * (K + 1)
+        gwr[K], gwf[K] = rr["gW0"], rf["gW0"]
+        czr, czf, car, caf = rr["c_z"], rf["c_z"], None, None
+        for l in range(K - 1, -1, -1):
+            sr, sf = fr.stages[l], ff.stages[l]
+            if l < K - 1:
+                with ops.paired():
+                    czr = ops.inorm_lrelu_bwd(sr.xhat, sr.rstd, car, sl, addend=c_zr[l], out=gs[l][:B])
+                    czf = ops.inorm_lrelu_bwd(sf.xhat, sf.rstd, caf, sl)
+            with ops.paired():
+                gwr[l] = ops.conv4s2_wgrad(gs[l], xs[l])
+                gwf[l] = ops.conv4s2_wgrad(czf, sf.x)
+            if l > 0:
+                with ops.paired():
+                    car = ops.conv4s2_dgrad(czr, Wr[l])
+                    caf = ops.conv4s2_dgrad(czf, Wf[l])
+        return gwr + [rr["gW1"], rr["gW2"], rr["gW3"]], gwf + [rf["gW1"], rf["gW2"], rf["gW3"]]
+
+    def _run_paired(self, real_stack, fake, scale, w_real, w_fake, w_reg, res):
+        B, dev = fake.shape[0], fake.device
+        n_real = self._normalised_weights()
+        n_fake = self._normalised_weights()          # (the reference's order of power iterations: D(real)'s, then D(fake)'s)
+        xs, gs, shp = [real_stack], [], real_stack[:B].shape
+        for conv, _eps in self.stages:
+            shp = (B, conv.weight_orig.shape[0], shp[2] // 2, shp[3] // 2)
+            xs.append(torch.empty((2 * B,) + shp[1:], device=dev))
+            gs.append(torch.empty((2 * B,) + shp[1:], device=dev))
+        gs.append(torch.empty(2 * B, self.full.weight_orig.shape[0], device=dev))
+        fr, ff = self._forward_pair(real_stack[:B], n_real.w, fake.contiguous(), n_fake.w, scale, xs)
+        out2, g_real, g_fake = ops.gan_disc_losses(fr.out, ff.out, w_real, w_fake)
+        res.gan_disc_real, res.gan_disc_fake, res.d_real, res.d_fake = out2[0], out2[1], fr.out, ff.out
+        r1, c_zr, gWh = self._r1_passes(fr, n_real.w, xs, gs, w_reg)
+        res.gan_reg_real, res.gan_reg_real_weighted = r1[0], r1[1]
+        gw_real, gw_fake = self._backward_pair(fr, n_real.w, g_real, xs, gs, c_zr, gWh, ff, n_fake.w, g_fake)
+        grads = ops.spectral_norm_bwd(gw_real, n_real.w, n_real.u, n_real.v, n_real.sigma,
+                                      second=(gw_fake, n_fake.w, n_fake.u, n_fake.v, n_fake.sigma))
+        for conv, g in zip(self.convs(), grads):
+            conv.weight_orig.grad = g
+        return res
+
     # ------------------------------------------------------------------ the step
     def run(self, real, fake, scale, w_real: float, w_fake: float, w_reg: Optional[float], real_stack=None):
         """Gradients of  w_real BCE(D(real), 1) + w_reg R1(real) + w_fake BCE(D(fake), 0)  wrt the discriminator's weights, written
@@ -242,6 +356,11 @@ class DiscStepSchedule:
         B = real.shape[0]
         scale = scale.reshape(-1).contiguous()
         res = AttrDict(gan_reg_real=None)
+        if w_reg is not None and self.pairs_eligible(real):
+            if real_stack is None or real_stack.shape[0] != 2 * B or real_stack.data_ptr() != real.data_ptr():
+                real_stack = torch.empty((2 * B,) + tuple(real.shape[1:]), device=real.device)
+                real_stack[:B].copy_(real)
+            return self._run_paired(real_stack, fake, scale, w_real, w_fake, w_reg, res)
         n_real = self._normalised_weights()
         state = {}
 

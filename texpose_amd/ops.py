@@ -593,6 +593,62 @@ def eval_metrics(rgb_static: Tensor, image: Tensor, obj_mask: Tensor, H: int, W:
 _ticket_words = {}           # (device index, stream, entry point) -> one zero-filled int32 word (the kernel leaves it zero)
 
 
+# ---- pairs: two calls of ONE pairable op issued as one launch (tp_*_pair: the real and the fake pass of the discriminator step)
+_pair_state = {"active": False, "pending": None}
+PAIRABLE = ("tp_conv4s2_fwd_inorm", "tp_conv4s2_dgrad", "tp_conv4s2_wgrad", "tp_disc_tail_fwd", "tp_disc_tail_bwd", "tp_inorm_lrelu_bwd")
+
+
+class paired:
+    """``with ops.paired():`` -- inside, calls of the pairable ops (PAIRABLE) must come in twos of the same op; the first of a pair only
+    prepares its arguments and outputs, the second launches both problems in ONE launch.  Outputs are returned by each call as usual
+    and are valid behind the pair's launch.  The second problem of a pair gets its own tile counters / workspace / ticket (slot 1)."""
+
+    def __enter__(self):
+        if _pair_state["active"]:
+            raise RuntimeError("ops.paired() does not nest")
+        _pair_state["active"], _pair_state["pending"] = True, None
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        pending, _pair_state["active"], _pair_state["pending"] = _pair_state["pending"], False, None
+        if exc_type is None and pending is not None:
+            raise RuntimeError("ops.paired(): %s was issued without a partner" % pending[0])
+        return False
+
+
+def _pair_slot() -> int:
+    """0 for the first problem of a pair (and outside ops.paired()), 1 for the second: which scratch set an op takes."""
+    return 1 if _pair_state["active"] and _pair_state["pending"] is not None else 0
+
+
+def _launch(name: str, args, extra=()):
+    """Launch ``lib.<name>(byref(args), *extra, stream)`` -- or, inside ops.paired(), hold it back / launch it with its partner through
+    ``lib.<name>_pair``.  ``extra``: per-problem trailing arguments (pointers), interleaved per problem in the pair entry points as the
+    header declares them; scalars shared by both problems are taken from the second call."""
+    lib = _lib.load()
+    if not _pair_state["active"]:
+        if name == "tp_inorm_lrelu_bwd":
+            check(lib.tp_inorm_lrelu_bwd(args.xhat, args.rstd, args.gy, args.n_inst, args.hw, args.slope, args.addend, args.gx, _stream()), name)
+        elif name == "tp_conv4s2_fwd_inorm":
+            check(lib.tp_conv4s2_fwd_inorm(C.byref(args), extra[2], extra[3], extra[0], extra[1], _stream()), name)
+        else:
+            check(getattr(lib, name)(C.byref(args), _stream()), name)
+        return
+    pending = _pair_state["pending"]
+    if pending is None:
+        _pair_state["pending"] = (name, args, extra, torch.cuda.current_stream().cuda_stream)
+        return
+    p_name, p_args, p_extra, p_stream = pending
+    _pair_state["pending"] = None
+    if p_name != name or p_stream != torch.cuda.current_stream().cuda_stream:
+        raise RuntimeError("ops.paired(): %s cannot be paired with %s (same op, same stream)" % (name, p_name))
+    if name == "tp_conv4s2_fwd_inorm":
+        check(lib.tp_conv4s2_fwd_inorm_pair(C.byref(p_args), p_extra[0], p_extra[1], C.byref(args), extra[0], extra[1], extra[2], extra[3],
+                                            _stream()), name + "_pair")
+    else:
+        check(getattr(lib, name + "_pair")(C.byref(p_args), C.byref(args), _stream()), name + "_pair")
+
+
 def _ticket(dev, name: str) -> int:
     """The arrival counter of a last-block hand-over (tp_nerf_losses_fwd, tp_adam_step) for the CURRENT stream: launches of one
     entry point that overlap on different streams of a device must not count each other's arrivals, so the word is owned by
@@ -758,8 +814,11 @@ def inorm_lrelu_bwd(xhat: Tensor, rstd: Tensor, gy: Tensor, slope: float, addend
         addend = _f32(addend, "addend")
         if addend.numel() != xhat.numel():
             raise ValueError("inorm_lrelu_bwd: addend must have the shape of x")
-    check(lib.tp_inorm_lrelu_bwd(xhat.data_ptr(), rstd.data_ptr(), gy.data_ptr(), rstd.numel(), xhat.numel() // rstd.numel(),
-                                 float(slope), _ptr(addend), gx.data_ptr(), _stream()), "tp_inorm_lrelu_bwd")
+    a = _lib.InormBwdArgs()
+    a.xhat, a.rstd, a.gy, a.n_inst, a.hw, a.slope = xhat.data_ptr(), rstd.data_ptr(), gy.data_ptr(), rstd.numel(), xhat.numel() // rstd.numel(), float(slope)
+    a.addend, a.gx = _ptr(addend), gx.data_ptr()
+    a._keep = (xhat, rstd, gy, addend, gx)
+    _launch("tp_inorm_lrelu_bwd", a)
     return gx
 
 
@@ -852,7 +911,7 @@ def _conv_scratch(lib, ws_fn, a, op: int, dev):
         check(-1, "tp_conv_workspace")
     # one counter array per (device, stream): launches on different streams may run concurrently (the two branches of the
     # captured training step) and must not see each other's tile arrivals
-    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream, _pair_slot())
     cnt = _conv_counters.get(key)
     if cnt is None or cnt.numel() < n_cnt.value:
         if torch.cuda.is_current_stream_capturing():
@@ -872,7 +931,11 @@ def _conv4s2(op: int, name: str, x, w, gy, out, N, C_in, H, W, Co):
     ws, cnt = _conv_scratch(lib, lib.tp_conv4s2_workspace, a, op, out.device)
     a.x, a.w, a.gy = _ptr(x), _ptr(w), _ptr(gy)
     a.out, a.counters, a.workspace = out.data_ptr(), cnt.data_ptr(), _ptr(ws)
-    check(getattr(lib, name)(C.byref(a), _stream()), name)
+    a._keep = (x, w, gy, out, ws, cnt)                # (a held-back first problem of a pair keeps its tensors alive)
+    if name in PAIRABLE:
+        _launch(name, a)
+    else:
+        check(getattr(lib, name)(C.byref(a), _stream()), name)
     return out
 
 
@@ -906,7 +969,8 @@ def conv4s2_fwd_inorm(x: Tensor, w: Tensor, eps: float, slope: float, y_out: Opt
     ws, cnt = _conv_scratch(lib, lambda args, _op, n: lib.tp_conv4s2_fwd_inorm_workspace(args, n), a, 0, x.device)
     a.x, a.w = x.data_ptr(), w.data_ptr()
     a.out, a.counters, a.workspace = y.data_ptr(), cnt.data_ptr(), _ptr(ws)
-    check(lib.tp_conv4s2_fwd_inorm(C.byref(a), float(eps), float(slope), xhat.data_ptr(), rstd.data_ptr(), _stream()), "tp_conv4s2_fwd_inorm")
+    a._keep = (x, w, y, xhat, rstd, ws, cnt)
+    _launch("tp_conv4s2_fwd_inorm", a, (xhat.data_ptr(), rstd.data_ptr(), float(eps), float(slope)))
     return y, xhat, rstd
 
 
@@ -1490,7 +1554,7 @@ def _tail_args(W0, W1, W2, W3, M, L, slope):
 
 
 def _tail_workspace(dev, N):
-    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream, N)
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream, N, _pair_slot())
     ws = _tail_ws.get(key)
     if ws is None:
         ws = _tail_ws[key] = torch.empty(int(_lib.load().tp_disc_tail_workspace_bytes(N)) // 4, device=dev)
@@ -1508,8 +1572,9 @@ def disc_tail_fwd(a: Tensor, W0: Tensor, scale: Tensor, W1: Tensor, W2: Tensor, 
                        torch.empty(M, q.H, device=dev))
     ws = _tail_workspace(dev, q.N)
     q.a, q.scale, q.out, q.t0, q.t1, q.t2 = a.data_ptr(), scale.data_ptr(), out.data_ptr(), t0.data_ptr(), t1.data_ptr(), t2.data_ptr()
-    q.workspace, q.ticket = ws.data_ptr(), _ticket(dev, "disc_tail")
-    check(lib.tp_disc_tail_fwd(C.byref(q), _stream()), "tp_disc_tail_fwd")
+    q.workspace, q.ticket = ws.data_ptr(), _ticket(dev, "disc_tail%d" % _pair_slot())
+    q._keep = (a, W0, scale, W1, W2, W3, out, t0, t1, t2, ws)
+    _launch("tp_disc_tail_fwd", q)
     return out, t0, t1, t2
 
 
@@ -1565,7 +1630,8 @@ def disc_tail_bwd(g_out: Tensor, t0: Tensor, t1: Tensor, t2: Tensor, W0: Tensor,
     q.g_out, q.t0, q.t1, q.t2 = g_out.data_ptr(), t0.data_ptr(), t1.data_ptr(), t2.data_ptr()
     q.c_a, q.gW0, q.gW1, q.gW2, q.gW3 = (_ptr(res[k]) for k in ("c_a", "gW0", "gW1", "gW2", "gW3"))
     q.gz, q.e1, q.e2 = _ptr(res["gz"]), _ptr(res["e1"]), _ptr(res["e2"])
-    check(lib.tp_disc_tail_bwd(C.byref(q), _stream()), "tp_disc_tail_bwd")
+    q._keep = (g_out, t0, t1, t2, W0, W1, W2, W3, a, keep, dict(res))
+    _launch("tp_disc_tail_bwd", q)
     return res
 
 
