@@ -297,6 +297,7 @@ int tp_eval_metrics(const tp_eval_metrics_args* args, tp_stream_t stream);
  * ------------------------------------------------------------------------------------------ */
 #define TP_SN_MAX_WEIGHTS 8
 #define TP_SN_MAX_SLABS 8        /* rows <= 512 */
+#define TP_SN_MAX_SETS 3         /* power iterations tp_sn_fwd_sets runs in a row */
 typedef struct tp_sn_weight {
   const float* weight;     /* [rows,cols] = weight_orig.view(out, -1); fwd only */
   float* u;                /* [rows]  updated in place when training */
@@ -319,6 +320,9 @@ typedef struct tp_sn_weight {
 int64_t tp_sn_work_floats(int rows, int cols);
 /* three launches (two in eval mode): every workgroup of the consuming kernel normalises v / u for itself */
 int tp_sn_fwd(const tp_sn_weight* weights, int n, int training, tp_stream_t stream);
+/* n_sets training-mode forwards in a row (entry k * n + i = weight i of set k: own weight_sn / sigma / u_out / v_out; weight, u, v, work
+ * shared): two launches per set and ONE normalisation launch for all sets; bit-identical to n_sets tp_sn_fwd calls. */
+int tp_sn_fwd_sets(const tp_sn_weight* weights, int n, int n_sets, tp_stream_t stream);
 int tp_sn_bwd(const tp_sn_weight* weights, int n, tp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------

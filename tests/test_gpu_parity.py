@@ -2562,6 +2562,23 @@ def test_prefetched_spectral_weights_equal_in_place_normalisation(ops):
     with pytest.raises(RuntimeError):
         d_b(opt, xs[0], sc)
     d_b._sn_queue.clear()
+    # tp_sn_fwd_sets (three power iterations, ONE normalisation launch) against three tp_sn_fwd calls: every set's W_sn, sigma, u / v
+    # copies and the module's u / v afterwards, bit for bit
+    import os
+    d_c, d_d = copy.deepcopy(d_a), copy.deepcopy(d_a)
+    d_c.prefetch_spectral_weights(3)
+    os.environ["TP_NO_SN_SETS"] = "1"
+    try:
+        d_d.prefetch_spectral_weights(3)
+    finally:
+        os.environ.pop("TP_NO_SN_SETS", None)
+    torch.cuda.synchronize()
+    for (oc, sc_, uc, vc, _), (od, sd_, ud, vd, _) in zip(d_c._sn_queue, d_d._sn_queue):
+        for a, b in zip(list(oc) + list(sc_) + list(uc) + list(vc), list(od) + list(sd_) + list(ud) + list(vd)):
+            assert torch.equal(a, b)
+    for (ka, va), (kb, vb) in zip(d_c.state_dict().items(), d_d.state_dict().items()):
+        assert torch.equal(va, vb), ka
+    d_c._sn_queue.clear(); d_d._sn_queue.clear()
 
 
 def test_one_launch_head_pack_is_bit_identical_to_the_three_launch_form(ops, monkeypatch):

@@ -23,7 +23,7 @@ SYMBOLS = (
     "tp_composite_fwd", "tp_composite_bwd",
     "tp_patch_gather",
     "tp_eval_metrics_workspace_bytes", "tp_eval_metrics",
-    "tp_sn_work_floats", "tp_sn_fwd", "tp_sn_bwd",
+    "tp_sn_work_floats", "tp_sn_fwd", "tp_sn_fwd_sets", "tp_sn_bwd",
     "tp_nerf_losses_fwd", "tp_nerf_losses_bwd",
     "tp_render_eval_workspace_bytes", "tp_render_eval",
     "tp_inorm_lrelu_fwd", "tp_inorm_lrelu_bwd", "tp_inorm_lrelu_bwd_bwd", "tp_inorm_lrelu_bwd_pair",
@@ -235,6 +235,7 @@ def load() -> C.CDLL:
     sig("tp_eval_metrics", [C.POINTER(EvalMetricsArgs), vp])
     sig("tp_sn_work_floats", [C.c_int, C.c_int], C.c_int64)
     sig("tp_sn_fwd", [C.POINTER(SnWeight), C.c_int, C.c_int, vp])
+    sig("tp_sn_fwd_sets", [C.POINTER(SnWeight), C.c_int, C.c_int, vp])
     sig("tp_sn_bwd", [C.POINTER(SnWeight), C.c_int, vp])
     sig("tp_nerf_losses_fwd", [C.POINTER(NerfLossesArgs), vp])
     sig("tp_nerf_losses_bwd", [C.POINTER(NerfLossesArgs), vp, vp, vp, vp, vp, vp, vp])

@@ -50,14 +50,25 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 }
 
 // A: t_part[slab][c] = sum_{r in slab} W[r][c] u[r]
-__global__ __launch_bounds__(256) void sn_wtu_kernel(Batch b) {
+// `set` > 0 (tp_sn_fwd_sets): u is not read from the module's buffer but formed from the PREVIOUS set's s = W v exactly as kernel C forms
+// it (same thread-to-row mapping, same reduction tree: the same bits) -- so the normalisation launches of all sets can wait until the end.
+__global__ __launch_bounds__(256) void sn_wtu_kernel(Batch b, int set) {
   __shared__ float us[kSlabRows];
+  __shared__ float red[256];
   int local;
   const tp_sn_weight& w = b.w[find_weight(b, blockIdx.x, local)];
   const int cblocks = (w.cols + 255) / 256;
   const int slab = local / cblocks, cb = local - slab * cblocks;
   const int r0 = slab * kSlabRows, nr = min(kSlabRows, w.rows - r0);
-  if (threadIdx.x < nr) us[threadIdx.x] = w.u[r0 + threadIdx.x];
+  if (set > 0) {
+    const float* sp = w.work + (int64_t)TP_SN_MAX_SLABS * w.cols + (int64_t)(set - 1) * w.rows;
+    const int r_a = threadIdx.x, r_b = threadIdx.x + 256;
+    const float s_a = r_a < w.rows ? sp[r_a] : 0.0f, s_b = r_b < w.rows ? sp[r_b] : 0.0f;
+    const float nrm = fmaxf(sqrtf(block_sum(fmaf(s_b, s_b, fmaf(s_a, s_a, 0.0f)), red)), 1e-12f);
+    if (threadIdx.x < nr) us[threadIdx.x] = sp[r0 + threadIdx.x] / nrm;
+  } else if (threadIdx.x < nr) {
+    us[threadIdx.x] = w.u[r0 + threadIdx.x];
+  }
   __syncthreads();
   const int c = cb * 256 + threadIdx.x;
   if (c >= w.cols) return;
@@ -73,7 +84,7 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 // B: v = normalize(sum_slabs t_part) (training; else the module's v) in LDS, then s[r] = sum_c W[r][c] v[c] for 4 rows (a wave per row).
 // 16-byte loads with 16-32 of them in flight per thread: a first version with 4-byte loads, eight in flight, paid one L2 latency per
 // batch, 16 + 16 batches per workgroup of the 512 x 4096 weight (29-36 us per launch; now 2 + 2 batches).
-__global__ __launch_bounds__(256) void sn_wv_kernel(Batch b, int training) {
+__global__ __launch_bounds__(256) void sn_wv_kernel(Batch b, int training, int set) {
   extern __shared__ __attribute__((aligned(16))) float vs[];      // [cols]
   __shared__ float red[256];
   int local;
@@ -122,7 +133,7 @@ __global__ __launch_bounds__(256) void sn_wv_kernel(Batch b, int training) {
     }
   }
   __syncthreads();
-  float* s = w.work + (int64_t)TP_SN_MAX_SLABS * w.cols;
+  float* s = w.work + (int64_t)TP_SN_MAX_SLABS * w.cols + (int64_t)set * w.rows;
   const int r = local * kWvRows + wave;
   if (r >= w.rows) return;
   const float* row = w.weight + (int64_t)r * w.cols;
@@ -175,6 +186,47 @@ __global__ __launch_bounds__(256) void sn_scale_kernel(Batch b, int training) {
   const int64_t n = (int64_t)w.rows * w.cols;
   for (int64_t i = (int64_t)local * kScaleElems + threadIdx.x; i < min(n, (int64_t)(local + 1) * kScaleElems); i += 256)
     w.weight_sn[i] = w.weight[i] / sg;
+}
+
+// C for SEVERAL sets in one launch (tp_sn_fwd_sets): u_k = normalize(s_k), sigma_k = u_k . s_k for every set k, the module's u from the
+// last one, W_sn_k = W / sigma_k for every set from ONE read of W.
+struct SetOuts { float* weight_sn[TP_SN_MAX_SETS][kMaxW]; float* sigma[TP_SN_MAX_SETS][kMaxW]; float* u_out[TP_SN_MAX_SETS][kMaxW]; };
+__global__ __launch_bounds__(256) void sn_scale_sets_kernel(Batch b, SetOuts o, int n_sets) {
+  __shared__ float red[256];
+  int local;
+  const int wi = find_weight(b, blockIdx.x, local);
+  const tp_sn_weight& w = b.w[wi];
+  const int r_a = threadIdx.x, r_b = threadIdx.x + 256;
+  float sg[TP_SN_MAX_SETS];
+#pragma unroll
+  for (int k = 0; k < TP_SN_MAX_SETS; ++k) {
+    sg[k] = 1.0f;
+    if (k < n_sets) {
+      const float* s = w.work + (int64_t)TP_SN_MAX_SLABS * w.cols + (int64_t)k * w.rows;
+      const float s_a = r_a < w.rows ? s[r_a] : 0.0f, s_b = r_b < w.rows ? s[r_b] : 0.0f;
+      const float nrm = fmaxf(sqrtf(block_sum(fmaf(s_b, s_b, fmaf(s_a, s_a, 0.0f)), red)), 1e-12f);
+      const float u_a = s_a / nrm, u_b = s_b / nrm;
+      sg[k] = block_sum(fmaf(u_b, s_b, fmaf(u_a, s_a, 0.0f)), red);
+      if (local == 0) {
+        if (k == n_sets - 1) {
+          if (r_a < w.rows) w.u[r_a] = u_a;
+          if (r_b < w.rows) w.u[r_b] = u_b;
+        }
+        if (o.u_out[k][wi]) {
+          if (r_a < w.rows) o.u_out[k][wi][r_a] = u_a;
+          if (r_b < w.rows) o.u_out[k][wi][r_b] = u_b;
+        }
+        if (threadIdx.x == 0) *o.sigma[k][wi] = sg[k];
+      }
+    }
+  }
+  const int64_t n = (int64_t)w.rows * w.cols;
+  for (int64_t i = (int64_t)local * kScaleElems + threadIdx.x; i < min(n, (int64_t)(local + 1) * kScaleElems); i += 256) {
+    const float wv = w.weight[i];
+#pragma unroll
+    for (int k = 0; k < TP_SN_MAX_SETS; ++k)
+      if (k < n_sets) o.weight_sn[k][wi][i] = wv / sg[k];
+  }
 }
 
 // D: per-workgroup partial of <G, W_sn> (and of the second instance's <G2, W_sn2>)
@@ -238,7 +290,7 @@ int check(const tp_sn_weight* ws, int n, bool bwd, const char* what) {
 }  // namespace
 
 extern "C" int64_t tp_sn_work_floats(int rows, int cols) {
-  const int64_t fwd = (int64_t)TP_SN_MAX_SLABS * cols + rows, bwd = 2 * (((int64_t)rows * cols + 4095) / 4096);
+  const int64_t fwd = (int64_t)TP_SN_MAX_SLABS * cols + (int64_t)TP_SN_MAX_SETS * rows, bwd = 2 * (((int64_t)rows * cols + 4095) / 4096);
   return fwd > bwd ? fwd : bwd;
 }
 
@@ -251,17 +303,55 @@ extern "C" int tp_sn_fwd(const tp_sn_weight* ws, int n, int training, tp_stream_
   TP_REQUIRE((size_t)max_cols * sizeof(float) <= 64 * 1024, "at most 16384 columns");
   if (training) {
     int g = fill(b, ws, n, [](const tp_sn_weight& w) { return ((w.cols + 255) / 256) * ((w.rows + kSlabRows - 1) / kSlabRows); });
-    hipLaunchKernelGGL(sn_wtu_kernel, dim3(g), dim3(256), 0, st, b);
+    hipLaunchKernelGGL(sn_wtu_kernel, dim3(g), dim3(256), 0, st, b, 0);
   }
   int g = fill(b, ws, n, [](const tp_sn_weight& w) { return (w.rows + kWvRows - 1) / kWvRows; });
   static unsigned long long flags = 0;
   if ((size_t)max_cols * sizeof(float) > 32 * 1024 && tp::first_use_on_device(flags))
     TP_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(sn_wv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) == hipSuccess,
                "cannot raise the LDS limit");
-  hipLaunchKernelGGL(sn_wv_kernel, dim3(g), dim3(256), (size_t)max_cols * sizeof(float), st, b, training);
+  hipLaunchKernelGGL(sn_wv_kernel, dim3(g), dim3(256), (size_t)max_cols * sizeof(float), st, b, training, 0);
   g = fill(b, ws, n, [](const tp_sn_weight& w) { return (int)(((int64_t)w.rows * w.cols + kScaleElems - 1) / kScaleElems); });
   hipLaunchKernelGGL(sn_scale_kernel, dim3(g), dim3(256), 0, st, b, training);
   return tp::check_launch("tp_sn_fwd");
+}
+
+// n_sets consecutive training-mode power iterations of the same n weights (what n_sets forwards in a row would run: the discriminator
+// step's three per iteration), entry k * n + i = weight i of set k (its weight_sn / sigma / u_out / v_out; weight, u, v, work shared):
+// 2 launches per set + ONE normalisation launch for all sets instead of 3 per set.  Bit-identical to n_sets tp_sn_fwd calls.
+extern "C" int tp_sn_fwd_sets(const tp_sn_weight* ws, int n, int n_sets, tp_stream_t stream) {
+  TP_REQUIRE(n_sets >= 1 && n_sets <= TP_SN_MAX_SETS, "1..TP_SN_MAX_SETS sets");
+  for (int k = 0; k < n_sets; ++k)
+    if (int rc = check(ws + (size_t)k * n, n, false, "tp_sn_fwd_sets")) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  int max_cols = 0;
+  for (int i = 0; i < n; ++i) {
+    max_cols = ws[i].cols > max_cols ? ws[i].cols : max_cols;
+    for (int k = 1; k < n_sets; ++k) {
+      const tp_sn_weight& a = ws[i], & c = ws[(size_t)k * n + i];
+      TP_REQUIRE(a.weight == c.weight && a.u == c.u && a.v == c.v && a.work == c.work && a.rows == c.rows && a.cols == c.cols,
+                 "the sets of a weight share weight / u / v / work");
+      TP_REQUIRE(a.weight_sn != c.weight_sn && a.sigma != c.sigma, "every set needs its own weight_sn / sigma");
+    }
+  }
+  TP_REQUIRE((size_t)max_cols * sizeof(float) <= 64 * 1024, "at most 16384 columns");
+  static unsigned long long flags = 0;
+  if ((size_t)max_cols * sizeof(float) > 32 * 1024 && tp::first_use_on_device(flags))
+    TP_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(sn_wv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) == hipSuccess,
+               "cannot raise the LDS limit");
+  Batch b;
+  SetOuts o{};
+  for (int k = 0; k < n_sets; ++k) {
+    const tp_sn_weight* wk = ws + (size_t)k * n;
+    int g = fill(b, wk, n, [](const tp_sn_weight& w) { return ((w.cols + 255) / 256) * ((w.rows + kSlabRows - 1) / kSlabRows); });
+    hipLaunchKernelGGL(sn_wtu_kernel, dim3(g), dim3(256), 0, st, b, k);
+    g = fill(b, wk, n, [](const tp_sn_weight& w) { return (w.rows + kWvRows - 1) / kWvRows; });
+    hipLaunchKernelGGL(sn_wv_kernel, dim3(g), dim3(256), (size_t)max_cols * sizeof(float), st, b, 1, k);
+    for (int i = 0; i < n; ++i) { o.weight_sn[k][i] = wk[i].weight_sn; o.sigma[k][i] = wk[i].sigma; o.u_out[k][i] = wk[i].u_out; }
+  }
+  const int g = fill(b, ws, n, [](const tp_sn_weight& w) { return (int)(((int64_t)w.rows * w.cols + kScaleElems - 1) / kScaleElems); });
+  hipLaunchKernelGGL(sn_scale_sets_kernel, dim3(g), dim3(256), 0, st, b, o, n_sets);
+  return tp::check_launch("tp_sn_fwd_sets");
 }
 
 extern "C" int tp_sn_bwd(const tp_sn_weight* ws, int n, tp_stream_t stream) {

@@ -233,9 +233,14 @@ class Discriminator(nn.Module):
         if self._sn_queue:
             raise RuntimeError("prefetch_spectral_weights: %d prefetched weight sets were never used" % len(self._sn_queue))
         convs = self.sn_convs()
+        W, U, V = [c.weight_orig.detach() for c in convs], [c.weight_u for c in convs], [c.weight_v for c in convs]
+        if 1 < n_calls <= ops.SN_MAX_SETS and os.environ.get("TP_NO_SN_SETS") != "1":
+            # all power iterations first (2 launches each), ONE normalisation launch for the n_calls sets: 2 n + 1 launches instead of 3 n
+            for outs, sigmas, us, vs in ops.spectral_norm_fwd_sets(W, U, V, n_calls):
+                self._sn_queue.append((outs, sigmas, us, vs, torch.cuda.current_stream(outs[0].device)))
+            return
         for _ in range(n_calls):
-            outs, sigmas, us, vs = ops.spectral_norm_fwd([c.weight_orig.detach() for c in convs], [c.weight_u for c in convs],
-                                                         [c.weight_v for c in convs], True, keep_uv=True)
+            outs, sigmas, us, vs = ops.spectral_norm_fwd(W, U, V, True, keep_uv=True)
             self._sn_queue.append((outs, sigmas, us, vs, torch.cuda.current_stream(outs[0].device)))
 
     def take_prefetched_weights(self):

@@ -699,6 +699,39 @@ def spectral_norm_fwd(weights, us, vs, training: bool, keep_uv: bool = False, ou
     return (outs, sigmas, u_copies, v_copies) if keep_uv else (outs, sigmas)
 
 
+SN_MAX_SETS = 3
+
+
+@_on_tensor_device
+def spectral_norm_fwd_sets(weights, us, vs, n_sets: int):
+    """``n_sets`` training-mode `spectral_norm_fwd(..., keep_uv=True)` calls in a row -- each advances u / v once -- as 2 n_sets + 1
+    launches instead of 3 n_sets (tp_sn_fwd_sets: one normalisation launch for all sets, W read once by it).  Returns a list of n_sets
+    tuples (W_sn list, sigma list, u copies, v copies); bit-identical to the separate calls."""
+    lib = _lib.load()
+    n = len(weights)
+    if not 1 <= n_sets <= SN_MAX_SETS:
+        raise ValueError("spectral_norm_fwd_sets: 1..%d sets" % SN_MAX_SETS)
+    arr = (_lib.SnWeight * (n * n_sets))()
+    ws = [_f32(w, "weight") for w in weights]
+    works = [torch.empty(lib.tp_sn_work_floats(w.shape[0], w.numel() // w.shape[0]), device=w.device) for w in ws]
+    sets = []
+    for k in range(n_sets):
+        flat = torch.empty(sum(u.numel() + v.numel() for u, v in zip(us, vs)), device=us[0].device)
+        parts = flat.split([t.numel() for t in list(us) + list(vs)])
+        u_copies, v_copies = list(parts[:n]), list(parts[n:])
+        outs, sigmas = [], []
+        for i, (w, u, v) in enumerate(zip(ws, us, vs)):
+            o, sg = torch.empty_like(w), torch.empty(1, device=w.device)
+            a = arr[k * n + i]
+            a.weight, a.u, a.v, a.weight_sn, a.sigma, a.work = w.data_ptr(), u.data_ptr(), v.data_ptr(), o.data_ptr(), sg.data_ptr(), works[i].data_ptr()
+            a.rows, a.cols = w.shape[0], w.numel() // w.shape[0]
+            a.u_out, a.v_out = u_copies[i].data_ptr(), v_copies[i].data_ptr()
+            outs.append(o); sigmas.append(sg)
+        sets.append((outs, sigmas, u_copies, v_copies))
+    check(lib.tp_sn_fwd_sets(arr, n, n_sets, _stream()), "tp_sn_fwd_sets")
+    return sets
+
+
 def spectral_norm_buffers(weights, us, vs):
     """Pre-allocated outputs of one `spectral_norm_fwd(..., out=)` call: (W_sn, sigma, u copies, v copies, work)."""
     lib = _lib.load()
