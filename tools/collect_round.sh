@@ -3,7 +3,7 @@
 #   bench line; bench under rocprofv3 --kernel-trace --stats + PMC of the eval forward (profile_mlp.sh); B=32 training kernel
 #   stats; training PMC (pmc_train.sh); HBM-bound kernels: stats + PMC (pmc_hbm.sh); launch histogram + ordered launches of a
 #   replayed B=4 GAN iteration; training lines; C5 multi-object line.          Usage: tools/collect_round.sh [tag]
-T=${1:-r4}
+T=${1:-r5}
 mkdir -p gpurun_out/$T
 export TMPDIR=/tmp
 ( time timeout 1500 python bench.py > gpurun_out/$T/bench_full.json 2> gpurun_out/$T/bench_full.err ) 2> gpurun_out/$T/bench_wall.txt
@@ -18,11 +18,18 @@ python3 tools/launch_sequence.py gpurun_out/$T/gan4 > gpurun_out/$T/launch_seque
 for i in 1 2; do python3 tools/train_bench.py 4 1 200 1 f16x3 2>&1 | tail -1; python3 tools/train_bench.py 4 0 200 1 f16x3 2>&1 | tail -1; python3 tools/train_bench.py 32 0 60 1 f16x3 2>&1 | tail -1; done > gpurun_out/$T/train_lines.txt
 timeout 600 python bench.py --config c5 > gpurun_out/$T/c5.json 2> gpurun_out/$T/c5.err
 # the GAN loop with one change switched off at a time (same box, alternating with the product configuration)
-( for e in TP_X=1 TP_LINEAR_GRAPHS=0 TP_X=1 TP_FOUR_GRAPHS=0 TP_X=1 TP_NO_DISC_TAIL=1 TP_X=1 TP_NO_CONV_INORM=1 TP_X=1 TP_DISC_AUTOGRAD=1 TP_X=1 TP_PRE_STREAMS=1 TP_PRE_STREAMS=2 "TP_PRE_STREAMS=2 TP_NO_QUEUE_PROBE=1" "TP_PRE_STREAMS=2 TP_LINEAR_GRAPHS=0" GPU_MAX_HW_QUEUES=2 TP_X=1; do
+( for e in TP_X=1 TP_NO_FEAT_CHAIN=1 TP_X=1 TP_NO_DISC_PAIRS=1 TP_X=1 TP_NO_SN_SETS=1 TP_X=1 "TP_NO_FEAT_CHAIN=1 TP_NO_DISC_PAIRS=1 TP_NO_SN_SETS=1" TP_X=1 TP_LINEAR_GRAPHS=0 TP_X=1 TP_FOUR_GRAPHS=0 TP_X=1 TP_PRE_STREAMS=2 "TP_PRE_STREAMS=2 TP_NO_QUEUE_PROBE=1" TP_X=1; do
     echo "$e $(env $e python3 tools/train_bench.py 4 1 200 1 f16x3 2>&1 | tail -1 | cut -c1-75)"; done ) > gpurun_out/$T/gan_ablations.txt
 python3 tools/tail_bench.py 4 > gpurun_out/$T/tail_bench.txt 2>&1
 python3 tools/host_time.py > gpurun_out/$T/host_time.txt 2>&1
 python3 tools/linear_timeline.py 50 > gpurun_out/$T/linear_timeline.txt 2>&1
+python3 tools/chain_probe.py 50 > gpurun_out/$T/chain_probe.txt 2>&1
+python3 tools/boundary_probe.py 64 > gpurun_out/$T/boundary_probe.txt 2>&1
+# fabric traffic of the exact-fp32 forward (profiles/traffic.json: fp32)
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --kernel-include-regex mlp_fwd --output-format csv -d gpurun_out/$T/fp32_$c -- python3 tools/render_once.py fp32 2 > gpurun_out/$T/fp32_$c.log 2>&1
+  cp $(find gpurun_out/$T/fp32_$c -name '*counter_collection.csv' | head -1) gpurun_out/$T/fp32_${c}_counter_collection.csv; rm -rf gpurun_out/$T/fp32_$c
+done
 ( for k in 0 1 2 3; do python3 tools/queue_probe.py $k 8; done ) > gpurun_out/$T/queue_probe.txt 2>&1
 # the evaluation render with / without the ray-bias variant of the f16x3 kernel, alternating on this box
 ( for e in TP_X=1 TP_NO_RAY_BIAS=1 TP_X=1 TP_NO_RAY_BIAS=1; do
