@@ -167,14 +167,19 @@ __global__ __launch_bounds__(kWaves * 64) void composite_bwd_kernel(tp_composite
   const int n_chunks = (p.N + 63) / 64;
   for (int64_t q = wave0; q < p.n; q += stride) {
     const float len = ray_len(p.ray, q);
+    // the ray's 14 cotangents are wave-uniform: lane k < 14 loads (and sums) the k-th, then they are read lane by lane into scalar
+    // registers -- one coalesced load per source instead of 14 same-address loads per lane
+    float gl = (b.g_out_ray && lane < 14) ? b.g_out_ray[q * 14 + lane] : 0.f;
+    if (lane < 3) {
+      if (b.g_rgb_ray) gl += b.g_rgb_ray[q * 3 + lane];
+      // cotangents of the two aliases of rgb_ray (each consumer of the colours back-propagates into its own: no add launches)
+      if (b.g_rgb_ray2) gl += b.g_rgb_ray2[q * 3 + lane];
+      if (b.g_rgb_ray3) gl += b.g_rgb_ray3[q * 3 + lane];
+    }
+    if (lane == 13 && b.g_uncert_ray) gl += b.g_uncert_ray[q];
     float g[14];
 #pragma unroll
-    for (int k = 0; k < 14; ++k) g[k] = b.g_out_ray ? b.g_out_ray[q * 14 + k] : 0.f;
-    if (b.g_rgb_ray) { g[0] += b.g_rgb_ray[q * 3]; g[1] += b.g_rgb_ray[q * 3 + 1]; g[2] += b.g_rgb_ray[q * 3 + 2]; }
-    // cotangents of the two aliases of rgb_ray (each consumer of the colours back-propagates into its own: no add launches)
-    if (b.g_rgb_ray2) { g[0] += b.g_rgb_ray2[q * 3]; g[1] += b.g_rgb_ray2[q * 3 + 1]; g[2] += b.g_rgb_ray2[q * 3 + 2]; }
-    if (b.g_rgb_ray3) { g[0] += b.g_rgb_ray3[q * 3]; g[1] += b.g_rgb_ray3[q * 3 + 1]; g[2] += b.g_rgb_ray3[q * 3 + 2]; }
-    if (b.g_uncert_ray) g[13] += b.g_uncert_ray[q];
+    for (int k = 0; k < 14; ++k) g[k] = tp::lane_value(gl, k);
     Carry carry = {0.f, 0.f, 0.f};
     for (int c = 0; c < n_chunks; ++c) {
       if (lane == 0) { s_carry[wv][0][c] = carry.s; s_carry[wv][1][c] = carry.t; s_carry[wv][2][c] = carry.j; }
