@@ -35,25 +35,30 @@ struct Carry { float s, t, j; };
 struct Raw { float cs[3], ct[3], sig_s, sig_t, z, u, dist; };
 
 // From global memory: sample i of ray q (all 64 lanes must call: the next depth comes from the neighbouring lane).
+// SQ (the forward): q is wave-uniform and held in scalar registers -- the kernel reads its wavefront index with readfirstlane --, so the
+// ray's base addresses are scalar arithmetic and every access is base + 32-bit lane offset instead of 64-bit vector address arithmetic
+// (316 -> 300 vector instructions per chunk).  The backward keeps the vector form: there the scalar form spills scalar registers.
+template <bool SQ>
 __device__ __forceinline__ Raw fetch_global(const tp_composite_args& p, int64_t q, int i, int lane, float len) {
   Raw r;
   const bool ok = i < p.N;
-  const int64_t e = q * p.N + (ok ? i : 0);
+  const int64_t e0 = SQ ? q * p.N : 0;
+  const int64_t e = SQ ? (int64_t)(ok ? (unsigned)i : 0u) : q * p.N + (ok ? i : 0);
   r.sig_s = 0.f; r.sig_t = 0.f; r.z = 0.f; r.u = 0.f;
 #pragma unroll
   for (int c = 0; c < 3; ++c) { r.cs[c] = 0.f; r.ct[c] = 0.f; }
   if (ok) {
-    const float2* rp = reinterpret_cast<const float2*>(p.rgb + e * 6);
+    const float2* rp = reinterpret_cast<const float2*>(p.rgb + e0 * 6) + e * 3;
     const float2 r0 = rp[0], r1 = rp[1], r2 = rp[2];
     r.cs[0] = r0.x; r.ct[0] = r0.y; r.cs[1] = r1.x; r.ct[1] = r1.y; r.cs[2] = r2.x; r.ct[2] = r2.y;
-    const float2 dn = *reinterpret_cast<const float2*>(p.density + e * 2);
+    const float2 dn = reinterpret_cast<const float2*>(p.density + e0 * 2)[e];
     r.sig_s = dn.x; r.sig_t = dn.y;
-    r.z = p.depth[e];
-    r.u = p.uncert[e];
+    r.z = (p.depth + e0)[e];
+    r.u = (p.uncert + e0)[e];
   }
   // the next sample's depth: the neighbouring lane's (lane 63: the next chunk's first, its own load)
   float zn = tp::wave_shl1(r.z);
-  if (lane == 63 && i + 1 < p.N) zn = p.depth[e + 1];
+  if (lane == 63 && i + 1 < p.N) zn = (p.depth + e0)[e + 1];
   const float dz = (i == p.N - 1) ? 1e10f : (zn - r.z);
   r.dist = ok ? dz * len : 0.f;
   return r;
@@ -92,9 +97,10 @@ __device__ __forceinline__ Sample scan_sample(const Raw& r, bool ok, Carry& carr
 }
 
 // Loads sample i of ray q and runs the scan for the current chunk (all 64 lanes must call).
+template <bool SQ = false>
 __device__ __forceinline__ Sample load_sample(const tp_composite_args& p, int64_t q, int i, int lane, float len,
                                               Carry& carry) {
-  const Raw r = fetch_global(p, q, i, lane, len);
+  const Raw r = fetch_global<SQ>(p, q, i, lane, len);
   return scan_sample(r, i < p.N, carry);
 }
 
@@ -105,7 +111,7 @@ __device__ __forceinline__ float ray_len(const float* ray, int64_t q) {
 
 __global__ __launch_bounds__(kWaves * 64) void composite_fwd_kernel(tp_composite_args p) {
   const int lane = threadIdx.x & 63;
-  const int64_t wave0 = (int64_t)blockIdx.x * kWaves + (threadIdx.x >> 6);
+  const int64_t wave0 = (int64_t)blockIdx.x * kWaves + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t stride = (int64_t)gridDim.x * kWaves;
   for (int64_t q = wave0; q < p.n; q += stride) {
     const float len = ray_len(p.ray, q);
@@ -115,7 +121,7 @@ __global__ __launch_bounds__(kWaves * 64) void composite_fwd_kernel(tp_composite
     for (int k = 0; k < 14; ++k) acc[k] = 0.f;
     for (int base = 0; base < p.N; base += 64) {
       const int i = base + lane;
-      const Sample s = load_sample(p, q, i, lane, len, carry);
+      const Sample s = load_sample<true>(p, q, i, lane, len, carry);
       const float ws = s.T * s.as, wt = s.T * s.at, w = s.T * s.a;
       const float os = s.Ts * s.as, ot = s.Tt * s.at;
 #pragma unroll
@@ -130,10 +136,10 @@ __global__ __launch_bounds__(kWaves * 64) void composite_fwd_kernel(tp_composite
       acc[12] += ot;
       acc[13] += s.u * wt;
       if (i < p.N) {
-        const int64_t e = q * p.N + i;
-        if (p.alpha_static) p.alpha_static[e] = s.as;
-        if (p.alpha_transient) p.alpha_transient[e] = s.at;
-        if (p.prob) p.prob[e] = w;
+        const int64_t e0 = q * p.N;
+        if (p.alpha_static) (p.alpha_static + e0)[(unsigned)i] = s.as;
+        if (p.alpha_transient) (p.alpha_transient + e0)[(unsigned)i] = s.at;
+        if (p.prob) (p.prob + e0)[(unsigned)i] = w;
       }
     }
     tp::wave_totals14(acc);
