@@ -22,6 +22,7 @@ for it in range(N_IT):
     if it % max(1, N_IT // 6) == 0 or it == N_IT - 1:
         hist.append({k: round(float(v), 5) for k, v in loss.items()})
         print(it, hist[-1], flush=True)
+tr.flush_flags()                                          # (the last replay's gate words: a withheld final step raises here)
 ops.check_mlp_status("cuda:0")
 sd = graph.state_dict()
 assert all(torch.isfinite(v).all() for v in sd.values() if v.dtype.is_floating_point)
