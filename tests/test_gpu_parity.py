@@ -1365,6 +1365,39 @@ def test_disc_step_pairs_are_bit_identical_to_the_sequential_schedule(ops, monke
     assert torch.equal(ya, yb) and torch.equal(yc, ops.conv4s2_fwd_inorm(x * 2, w, 1e-5, 0.2)[0])
 
 
+def test_pipelined_discriminator_tail_is_bit_identical(ops):
+    """GraphedGanTrainer.pipeline_disc_tail: the discriminator step replayed as two graphs, the second one (R1 passes, backward pairs,
+    RMSprop) allowed to run beside the NEXT iteration's render (that render waits for the first graph: the last reader of the patch
+    stacks).  Every dependency is an event, so eight iterations give bit-identical parameters, buffers, optimiser state and losses with
+    and without it; the calling stream sees the discriminator's results behind `finish()`."""
+    from texpose_amd.gan_modules import Discriminator, PerceptualLoss
+    from texpose_amd.graph import Graph
+    from texpose_amd.options import default_options, AttrDict
+    from texpose_amd.synthetic import training_batch
+    from texpose_amd.trainer import GraphedGanTrainer
+    out = []
+    for pipelined in (False, True):
+        torch.manual_seed(0)
+        opt = default_options(H=128, W=128, device="cuda:0")
+        opt.batch_size, opt.patch_size, opt.nerf.sample_intvs = 4, 16, 64
+        graph = Graph(opt, discriminator=Discriminator(opt), perceptual_loss=PerceptualLoss()).to(dev())
+        tr = GraphedGanTrainer(opt, graph, n_train=189)
+        tr.pipeline_disc_tail = pipelined
+        batches = [training_batch(4, 128, 128, seed=s_, device="cuda:0") for s_ in range(2)]
+        for it in range(8):
+            _, loss = tr.train_iteration(AttrDict(dict(batches[it % 2])))
+        assert tr._linear and "D2a" in tr._g4 and tr._pipelined() == pipelined
+        tr.finish()
+        torch.cuda.synchronize()
+        out.append(({k: v.clone() for k, v in graph.state_dict().items()}, {k: v.clone() for k, v in loss.items() if torch.is_tensor(v)},
+                    [t.clone() for st in tr.optim_disc.state.values() for t in st.values() if torch.is_tensor(t)]))
+    for k in out[0][0]:
+        assert torch.equal(out[0][0][k], out[1][0][k]), k
+    for k in out[0][1]:
+        assert torch.equal(out[0][1][k], out[1][1][k]), k
+    assert all(torch.equal(a, b) for a, b in zip(out[0][2], out[1][2])) and len(out[0][2]) > 0
+
+
 def assert_updates_close(sd_a, sd_b, snap, rel=0.05, frac=0.01):
     """Parameter UPDATES of two training runs that should agree up to fp32 noise.  Adam / RMSprop normalise every entry,
     so a gradient entry at the noise floor can take a different +-lr step: compare the bulk of each update (relative L2)

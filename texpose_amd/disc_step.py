@@ -324,27 +324,47 @@ class DiscStepSchedule:
                     caf = ops.conv4s2_dgrad(czf, Wf[l])
         return gwr + [rr["gW1"], rr["gW2"], rr["gW3"]], gwf + [rf["gW1"], rf["gW2"], rf["gW3"]]
 
-    def _run_paired(self, real_stack, fake, scale, w_real, w_fake, w_reg, res):
+    def run_paired_a(self, real_stack, fake, scale, w_real, w_fake, own_inputs: bool = False):
+        """First half of the paired step: both normalised weight sets, the forward pairs, both BCE terms and their cotangents -- and, with
+        ``own_inputs``, private copies of the two patch stacks (one launch) so that NOTHING behind this half reads a buffer of the render
+        (the captured trainer replays the two halves as two graphs and lets the next iteration's render start behind the first one).
+        Returns the context `run_paired_b` continues from."""
         B, dev = fake.shape[0], fake.device
+        scale = scale.reshape(-1).contiguous()
+        res = AttrDict(gan_reg_real=None)
         n_real = self._normalised_weights()
         n_fake = self._normalised_weights()          # (the reference's order of power iterations: D(real)'s, then D(fake)'s)
+        fake = fake.contiguous()
+        if own_inputs:
+            stack_own, fake_own = torch.empty_like(real_stack), torch.empty_like(fake)
+            ops.step_inputs([(stack_own[:B], real_stack[:B]), (fake_own, fake)])
+            real_stack, fake = stack_own, fake_own
         xs, gs, shp = [real_stack], [], real_stack[:B].shape
         for conv, _eps in self.stages:
             shp = (B, conv.weight_orig.shape[0], shp[2] // 2, shp[3] // 2)
             xs.append(torch.empty((2 * B,) + shp[1:], device=dev))
             gs.append(torch.empty((2 * B,) + shp[1:], device=dev))
         gs.append(torch.empty(2 * B, self.full.weight_orig.shape[0], device=dev))
-        fr, ff = self._forward_pair(real_stack[:B], n_real.w, fake.contiguous(), n_fake.w, scale, xs)
+        fr, ff = self._forward_pair(real_stack[:B], n_real.w, fake, n_fake.w, scale, xs)
         out2, g_real, g_fake = ops.gan_disc_losses(fr.out, ff.out, w_real, w_fake)
         res.gan_disc_real, res.gan_disc_fake, res.d_real, res.d_fake = out2[0], out2[1], fr.out, ff.out
-        r1, c_zr, gWh = self._r1_passes(fr, n_real.w, xs, gs, w_reg)
+        return AttrDict(res=res, n_real=n_real, n_fake=n_fake, xs=xs, gs=gs, fr=fr, ff=ff, g_real=g_real, g_fake=g_fake,
+                        real=real_stack[:B], fake=fake)
+
+    def run_paired_b(self, c, w_reg):
+        """Second half: the R1 passes, the backward pairs, the spectral-norm backward; gradients into ``.grad``.  Returns the result."""
+        res = c.res
+        r1, c_zr, gWh = self._r1_passes(c.fr, c.n_real.w, c.xs, c.gs, w_reg)
         res.gan_reg_real, res.gan_reg_real_weighted = r1[0], r1[1]
-        gw_real, gw_fake = self._backward_pair(fr, n_real.w, g_real, xs, gs, c_zr, gWh, ff, n_fake.w, g_fake)
-        grads = ops.spectral_norm_bwd(gw_real, n_real.w, n_real.u, n_real.v, n_real.sigma,
-                                      second=(gw_fake, n_fake.w, n_fake.u, n_fake.v, n_fake.sigma))
+        gw_real, gw_fake = self._backward_pair(c.fr, c.n_real.w, c.g_real, c.xs, c.gs, c_zr, gWh, c.ff, c.n_fake.w, c.g_fake)
+        grads = ops.spectral_norm_bwd(gw_real, c.n_real.w, c.n_real.u, c.n_real.v, c.n_real.sigma,
+                                      second=(gw_fake, c.n_fake.w, c.n_fake.u, c.n_fake.v, c.n_fake.sigma))
         for conv, g in zip(self.convs(), grads):
             conv.weight_orig.grad = g
         return res
+
+    def _run_paired(self, real_stack, fake, scale, w_real, w_fake, w_reg, res):
+        return self.run_paired_b(self.run_paired_a(real_stack, fake, scale, w_real, w_fake), w_reg)
 
     # ------------------------------------------------------------------ the step
     def run(self, real, fake, scale, w_real: float, w_fake: float, w_reg: Optional[float], real_stack=None):

@@ -302,12 +302,18 @@ class GanTrainer:
     def _disc_step_scheduled(self, sched, var, real, fake, stack, apply):
         """`disc_step` through the explicit schedule: same losses, same gradients (sums of two terms in another order), about a
         third fewer launches -- and no autograd graph."""
-        opt = self.opt
-        lw = opt.loss_weight
+        lw = self.opt.loss_weight
         w = lambda k: 10 ** float(lw[k])
         with torch.no_grad():
             res = sched.run(real, fake, var.ray_scales, w("gan_disc_real"), w("gan_disc_fake"),
                             None if lw.gan_reg_real is None else w("gan_reg_real"), real_stack=stack)
+        return self._disc_step_scheduled_post(var, res, real, fake, apply)
+
+    def _disc_step_scheduled_post(self, var, res, real, fake, apply):
+        """What follows the schedule's launches: the step's outputs, the loss total (+ gate), the optimiser step."""
+        lw = self.opt.loss_weight
+        w = lambda k: 10 ** float(lw[k])
+        with torch.no_grad():
             var.patch_real, var.patch_fake, var.d_real_disc, var.d_fake_disc = real, fake, res.d_real, res.d_fake
             loss = edict(gan_disc_real=res.gan_disc_real)
             if res.gan_reg_real is not None:
@@ -523,6 +529,13 @@ class GraphedGanTrainer(GanTrainer):
         # gates are 1 only while all are 0 (separate words: the two branches of the captured step never write the same one)
         self._bad = torch.zeros(3, dtype=torch.int32, device=dev)
         self._side = None                        # second stream of the captured step (discriminator branch)
+        # Opt-in: the discriminator step's second half (R1 passes, backward, RMSprop) of iteration i may run beside the render of
+        # iteration i + 1 -- every dependency is an event (the next render waits for the first half, the next spectral norm for the
+        # second), so the arithmetic is unchanged; but the CALLING stream no longer waits for it at the end of `train_iteration`:
+        # discriminator losses / weights / optimiser state may be read only behind `wait_all()` or `finish()` (tools/train_dp.py,
+        # bench.py and tools/train_bench.py set it; default off = everything ordered on the calling stream).
+        self.pipeline_disc_tail = os.environ.get("TP_PIPELINE_DISC") == "1"
+        self._d2_pending = False
         self._four, self._g4, self._ev4 = False, None, None    # the step as four graphs on two streams (`_use_four_graphs`)
         self._linear = False                     # ... as six LINEAR graphs on three streams (`_use_linear_graphs`)
         # what the optimiser launches read: the words as they stood when the step's own flags had been folded in
@@ -728,6 +741,36 @@ class GraphedGanTrainer(GanTrainer):
     def _seg_disc(self, var):
         return self.disc_step(var, apply=True)
 
+    def disc_step_zero_grads(self):
+        self._toggle(self.graph.discriminator, True)
+        self.optim_disc.zero_grad(set_to_none=True)
+
+    def _seg_disc_a(self, var, run=False):
+        """First half of the discriminator step as a segment of its own (see `_capture_linear`).  ``run=False``: only whether the split
+        applies (the paired schedule covers this step) -- True / None."""
+        opt, g, lw = self.opt, self.graph, self.opt.loss_weight
+        if not (var.rgb.is_cuda and lw.gan_reg_real is not None
+                and (var.get("disc_patches_for") is var.ray_idx or ("gathered" in var and var.get("gathered_for") is var.ray_idx))):
+            return None
+        real, fake, stack = g.disc_patch_stacks(opt, var)
+        sched = self._disc_schedule(real)
+        if sched is None or not sched.pairs_eligible(real):
+            return None
+        if not run:
+            return True
+        self._disc_flagged = False
+        self.disc_step_zero_grads()
+        w = lambda k: 10 ** float(lw[k])
+        with torch.no_grad():
+            ctx = sched.run_paired_a(stack, fake, var.ray_scales, w("gan_disc_real"), w("gan_disc_fake"), own_inputs=True)
+        ctx.sched = sched
+        return ctx
+
+    def _seg_disc_b(self, var, ctx):
+        with torch.no_grad():
+            res = ctx.sched.run_paired_b(ctx, 10 ** float(self.opt.loss_weight.gan_reg_real))
+        return self._disc_step_scheduled_post(var, res, ctx.real, ctx.fake, True)
+
     # ------------------------------------------------------------------ ... and as SIX LINEAR graphs on three streams
     # G2 above still forks inside the graph (the feature chain beside the discriminator's pass), and a replayed graph with a fork picks
     # the hardware queue of its second branch by the runtime's round-robin over ALL streams the process ever made: the same trainer ran
@@ -897,8 +940,23 @@ class GraphedGanTrainer(GanTrainer):
         with torch.cuda.graph(g["G2b"], stream=cap, pool=g["G1"].pool()):
             self._stamp("G2b.0"); var, loss = self._seg_gen_b(var, loss, g_disc); self._stamp("G2b.1"); counts["G2b"] = ops.capture_node_count()
         keep.append(dict(var))
-        with torch.cuda.graph(g["D2"], stream=side, pool=g["D1"].pool()):
-            self._stamp("D2.0"); var, dloss = self._seg_disc(var); self._stamp("D2.1"); counts["D2"] = ops.capture_node_count()
+        # The discriminator step in TWO graphs when its paired schedule applies: D2a = private copies of the patch stacks, forward pairs,
+        # BCE terms -- the last reads of anything the render wrote -- and D2b = the R1 passes, backward pairs, spectral-norm backward,
+        # RMSprop.  With `pipeline_disc_tail` the next iteration's render starts behind D2a instead of behind D2b (`_replay_linear`).
+        ctx = self._seg_disc_a(var) if os.environ.get("TP_NO_DISC_SPLIT") != "1" else None
+        if ctx is not None:
+            g["D2a"], g["D2b"] = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            self._ev4["d2a"] = torch.cuda.Event()
+            self.disc_step_zero_grads()
+            with torch.cuda.graph(g["D2a"], stream=side, pool=g["D1"].pool()):
+                self._stamp("D2.0"); ctx = self._seg_disc_a(var, run=True); counts["D2a"] = ops.capture_node_count()
+            keep.append(ctx)
+            with torch.cuda.graph(g["D2b"], stream=side, pool=g["D1"].pool()):
+                var, dloss = self._seg_disc_b(var, ctx); self._stamp("D2.1"); counts["D2b"] = ops.capture_node_count()
+            del g["D2"]
+        else:
+            with torch.cuda.graph(g["D2"], stream=side, pool=g["D1"].pool()):
+                self._stamp("D2.0"); var, dloss = self._seg_disc(var); self._stamp("D2.1"); counts["D2"] = ops.capture_node_count()
         keep.append(dict(var))
         self._g4_keep = keep
         loss.update({k: v for k, v in dloss.items() if k != "all"})
@@ -912,6 +970,10 @@ class GraphedGanTrainer(GanTrainer):
         # the caller's stream hands over the step's inputs (and, the first time, parameters restored / loaded since the capture); it
         # waited for the previous iteration's last launches below, so does everything here
         main.wait_stream(cur)
+        if getattr(self, "_d2_pending", False):
+            # pipelined: this render may start while the previous discriminator step's second half still runs; it overwrites the patch
+            # stacks / scales, whose last readers are in that step's FIRST half
+            main.wait_event(ev["d2a"])
         with torch.cuda.stream(side):
             # ... and so does the discriminator stream, on EVERY replay (D1 reads `weight_orig` and rewrites `weight_u` / `weight_v` in
             # place: a load_state_dict, parameter broadcast or checkpoint copy the caller enqueued between two iterations comes first).
@@ -943,7 +1005,12 @@ class GraphedGanTrainer(GanTrainer):
                 side.wait_event(ev["patches"])
                 if os.environ.get("TP_D2_AFTER_FEAT") == "1":   # (experiment: keep the discriminator step out of the feature chain's window)
                     side.wait_event(ev["feat"])
-                g["D2"].replay()
+                if "D2a" in g:
+                    g["D2a"].replay()
+                    ev["d2a"].record(side)
+                    g["D2b"].replay()
+                else:
+                    g["D2"].replay()
                 ev["d2"].record(side)
 
         if d2_first:
@@ -958,9 +1025,24 @@ class GraphedGanTrainer(GanTrainer):
             ev["g2"].record(main)
         if not d2_first:
             disc_step_graph()
-        # what the caller enqueues next -- reads of the losses, the next iteration's inputs -- comes after both optimiser steps
+        # what the caller enqueues next -- reads of the losses, the next iteration's inputs -- comes after both optimiser steps ...
         cur.wait_event(ev["g2"])
-        cur.wait_event(ev["d2"])
+        if self._pipelined():
+            # ... unless the caller asked for the discriminator step's second half to run beside the next iteration's render
+            # (`pipeline_disc_tail`): the calling stream then waits for the generator's step only; `finish()` waits for the rest.
+            self._d2_pending = True
+        else:
+            cur.wait_event(ev["d2"])
+
+    def _pipelined(self):
+        return bool(self.pipeline_disc_tail) and self._linear and self._g4 is not None and "D2a" in self._g4
+
+    def wait_all(self):
+        """Make the calling stream wait for everything the last `train_iteration` enqueued (with `pipeline_disc_tail`: the
+        discriminator step's second half and its RMSprop step)."""
+        if getattr(self, "_d2_pending", False):
+            torch.cuda.current_stream(self._bad.device).wait_event(self._ev4["d2"])
+            self._d2_pending = False
 
     def _prefetch_spectral_weights(self, var):
         """The spectral normalisations of this iteration's three discriminator passes (nerf step's D(fake), D(real), D(fake):
@@ -1077,6 +1159,7 @@ class GraphedGanTrainer(GanTrainer):
                 self._after_step()
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
+        self._d2_pending = False
         self._graph = torch.cuda.CUDAGraph()
         self.optim_nerf.zero_grad(set_to_none=True)
         if self.has_disc:
@@ -1142,6 +1225,7 @@ class GraphedGanTrainer(GanTrainer):
         before a checkpoint -- calls this to learn about a withheld final step (re-capture with fp32, or FloatingPointError)."""
         if self._graph is None:
             return [0, 0, 0]
+        self.wait_all()
         flagged = self._read_bad(blocking=True)
         if flagged[0] and self._uses_f16x3():
             self._fall_back_to_fp32(AttrDict(dict(self._static_in)))

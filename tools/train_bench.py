@@ -28,6 +28,8 @@ def run(B=4, iters=20, warm=6, full=True, device="cuda:0", graphed=False, train_
         with torch.cuda.stream(st):
             torch.zeros(1, device=device)
     tr = (GraphedGanTrainer if graphed else GanTrainer)(opt, graph, n_train=189)
+    if graphed and os.environ.get("TP_NO_PIPELINE_DISC") != "1":
+        tr.pipeline_disc_tail = True           # (losses / state are read behind the final synchronise only)
     var = training_batch(B, 128, 128, device=device)
     for _ in range(warm):
         tr.train_iteration(AttrDict(dict(var)))

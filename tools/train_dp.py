@@ -56,6 +56,10 @@ def measure(device, rank, world, global_batch=32, iters=50, warm=5, graphed=True
     opt, graph, cls = build(device, global_batch // world, full, train_precision, graphed)
     tdist.setup_data_parallel(graph, seed=seed)
     trainer = cls(opt, graph, n_train=189)
+    if hasattr(trainer, "pipeline_disc_tail") and os.environ.get("TP_NO_PIPELINE_DISC") != "1":
+        # the discriminator step's second half may run beside the next render (one rank, six-graph form); this loop reads losses and
+        # state only behind flush_flags() / a device synchronise
+        trainer.pipeline_disc_tail = True
     if hook is not None:
         hook(trainer)
     # a global batch, identical on all ranks (stands in for the sampler of a distributed data loader); each rank keeps its shard
