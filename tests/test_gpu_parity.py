@@ -1365,6 +1365,41 @@ def test_disc_step_pairs_are_bit_identical_to_the_sequential_schedule(ops, monke
     assert torch.equal(ya, yb) and torch.equal(yc, ops.conv4s2_fwd_inorm(x * 2, w, 1e-5, 0.2)[0])
 
 
+def test_generator_pass_schedule_matches_autograd(ops):
+    """disc_step.generator_pass -- the nerf step's D(fake) term (reference model/nerf_adapt_st_gan.py:108-127, :771-773) as an explicit
+    schedule of 9 launches -- against autograd through the Discriminator module (K7 / K11 / K9 / K17 Functions) on golden G13b's fake
+    patch and scales: the loss value and D(fake) bit for bit (same forward kernels), the gradient wrt the rendered colours to 1e-6 of its
+    norm (the last stage's InstanceNorm backward runs inside the tail's launch), and the power iteration advanced exactly once."""
+    from texpose_amd import autograd_ops
+    from texpose_amd.graph import Graph as G_
+    G = load_golden("g13b_disc_step")
+    out = []
+    for explicit in (True, False):
+        opt, graph, tr, var = _g13b_setup(G)
+        disc = graph.discriminator
+        for q in disc.parameters():
+            q.requires_grad_(False)
+        B, P = var.rgb.shape[0], var.rgb.shape[1]
+        rgb = var.rgb.detach().clone().requires_grad_(True)
+        _, fake, _ = autograd_ops.disc_patches(rgb, var.gathered, (16, 16), bool(opt.gan.geo_conditional))
+        w = 10 ** float(opt.loss_weight.gan_nerf)
+        if explicit:
+            sched = tr._disc_schedule(fake)
+            assert sched is not None and sched.generator_pass_eligible(opt, fake)
+            with torch.no_grad():
+                val, g_rgb, d = sched.generator_pass(fake.detach(), var.ray_scales, w)
+        else:
+            with autograd_ops.first_order_only():
+                d = disc(opt, fake, var.ray_scales)
+            val = G_.compute_gan_loss(opt, d_outs=d, target=1)
+            (g_rgb,) = torch.autograd.grad(val, rgb, grad_outputs=torch.tensor(w, device=dev(), dtype=torch.float32))
+        out.append((val.detach().clone(), g_rgb.clone(), d.detach().clone(), {k: v.clone() for k, v in disc.state_dict().items()}))
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][2].reshape(-1), out[1][2].reshape(-1))
+    assert out[0][1].shape == out[1][1].shape and float(out[1][1].norm()) > 0
+    assert float((out[0][1] - out[1][1]).norm() / out[1][1].norm()) < 1e-6
+    assert all(torch.equal(out[0][3][k], out[1][3][k]) for k in out[0][3])
+
+
 def test_pipelined_discriminator_tail_is_bit_identical(ops):
     """GraphedGanTrainer.pipeline_disc_tail: the discriminator step replayed as two graphs, the second one (R1 passes, backward pairs,
     RMSprop) allowed to run beside the NEXT iteration's render (that render waits for the first graph: the last reader of the patch
@@ -1376,26 +1411,28 @@ def test_pipelined_discriminator_tail_is_bit_identical(ops):
     from texpose_amd.synthetic import training_batch
     from texpose_amd.trainer import GraphedGanTrainer
     out = []
-    for pipelined in (False, True):
+    for pipelined in (False, True, "deferred"):
         torch.manual_seed(0)
         opt = default_options(H=128, W=128, device="cuda:0")
         opt.batch_size, opt.patch_size, opt.nerf.sample_intvs = 4, 16, 64
         graph = Graph(opt, discriminator=Discriminator(opt), perceptual_loss=PerceptualLoss()).to(dev())
         tr = GraphedGanTrainer(opt, graph, n_train=189)
-        tr.pipeline_disc_tail = pipelined
+        tr.pipeline_disc_tail = bool(pipelined)
+        tr.defer_results = pipelined == "deferred"
         batches = [training_batch(4, 128, 128, seed=s_, device="cuda:0") for s_ in range(2)]
         for it in range(8):
             _, loss = tr.train_iteration(AttrDict(dict(batches[it % 2])))
-        assert tr._linear and "D2a" in tr._g4 and tr._pipelined() == pipelined
+        assert tr._linear and "D2a" in tr._g4 and tr._pipelined() == bool(pipelined) and tr._defers_results() == (pipelined == "deferred")
         tr.finish()
         torch.cuda.synchronize()
         out.append(({k: v.clone() for k, v in graph.state_dict().items()}, {k: v.clone() for k, v in loss.items() if torch.is_tensor(v)},
                     [t.clone() for st in tr.optim_disc.state.values() for t in st.values() if torch.is_tensor(t)]))
-    for k in out[0][0]:
-        assert torch.equal(out[0][0][k], out[1][0][k]), k
-    for k in out[0][1]:
-        assert torch.equal(out[0][1][k], out[1][1][k]), k
-    assert all(torch.equal(a, b) for a, b in zip(out[0][2], out[1][2])) and len(out[0][2]) > 0
+    for other in out[1:]:
+        for k in out[0][0]:
+            assert torch.equal(out[0][0][k], other[0][k]), k
+        for k in out[0][1]:
+            assert torch.equal(out[0][1][k], other[1][k]), k
+        assert all(torch.equal(a, b) for a, b in zip(out[0][2], other[2])) and len(out[0][2]) > 0
 
 
 def assert_updates_close(sd_a, sd_b, snap, rel=0.05, frac=0.01):

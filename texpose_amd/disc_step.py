@@ -233,6 +233,43 @@ class DiscStepSchedule:
                 c_a = ops.conv4s2_dgrad(c_z, W[l])
         return f, r1, gw + [gW1, gW2, gW3]
 
+    # ------------------------------------------------------------------ the nerf step's pass through the frozen discriminator
+    def generator_pass(self, fake, scale, w_gan: float):
+        """D(fake) with target 1 and its gradient wrt the rendered colours (reference model/nerf_adapt_st_gan.py:108-127 `nerf_trainstep`,
+        :771-773 the `gan_nerf` term of compute_loss) as an explicit schedule: the weights are constants of this pass, so nothing but the
+        data gradient is formed -- forward (3 launches), loss value + weighted cotangent (1), the tail's backward with the last stage's
+        InstanceNorm backward inside (1), [data gradient, InstanceNorm backward]* (2 K - 1), the transposition to the render's layout (1).
+        -> (bce(D(fake), 1), d (w_gan bce) / d rgb [B, P, 3], D(fake) [B]).  `fake` [B, nc, h, w] is the stack `ops.disc_inputs` built."""
+        K, B, sl, L = len(self.stages), fake.shape[0], self.slope, self.disc.L_scale
+        W = self._normalised_weights().w
+        f = self._forward(fake, W, scale)
+        if not f.tail:
+            raise RuntimeError("generator_pass: the fused tail does not take this discriminator (check generator_pass_eligible)")
+        out2, g_out, _ = ops.gan_disc_losses(f.out, f.out, w_gan, 0.0)         # (term 0 = target 1; the second term is not used)
+        last = f.stages[K - 1]
+        r = ops.disc_tail_bwd(g_out, *f.head, W[K].flatten(1), *self._head_w(W), L, sl, want_gW0=False, head_weight_grads=False,
+                              want_c_a=False, inorm=dict(xhat=last.xhat, rstd=last.rstd))
+        c_z = r["c_z"]
+        for l in range(K - 1, -1, -1):
+            c_a = ops.conv4s2_dgrad(c_z, W[l])
+            if l > 0:
+                st = f.stages[l - 1]
+                c_z = ops.inorm_lrelu_bwd(st.xhat, st.rstd, c_a, sl)
+        g_rgb = ops.fake_patch_bwd(c_a, B, fake.shape[-2] * fake.shape[-1])
+        return out2[0], g_rgb, f.out
+
+    def generator_pass_eligible(self, opt, fake) -> bool:
+        if os.environ.get("TP_NO_GEN_SCHEDULE") == "1" or not self.eligible(opt, fake) or opt.loss_weight.get("gan_nerf") is None:
+            return False
+        return self.pairs_eligible(fake) or os.environ.get("TP_NO_DISC_PAIRS") == "1" and self._tail_ok(fake)
+
+    def _tail_ok(self, x) -> bool:
+        B, _, h, w = x.shape
+        for _ in self.stages:
+            h, w = h // 2, w // 2
+        K_in = self.full.weight_orig.shape[1] * h * w
+        return K_in % 4 == 0 and B <= ops.DISC_TAIL_MAX_ROWS and os.environ.get("TP_NO_DISC_TAIL") != "1"
+
     # ------------------------------------------------------------------ the step with the real and the fake pass as PAIRS of launches
     # D(real) and D(fake) go through the same kernels one after the other, and so do their backward passes; every one of those launches
     # is latency-sized (10-15 us for MFLOPs), so the two problems of a pair run in ONE launch (ops.paired / tp_*_pair) in the time of

@@ -221,7 +221,7 @@ class Discriminator(nn.Module):
         """The spectrally normalised convolutions in the order `forward` uses their weights: ladder, then head."""
         return [m for m in list(self.main) + (list(self.final) if self.scale_conditional else []) if isinstance(m, SNConv2d)]
 
-    def prefetch_spectral_weights(self, n_calls: int):
+    def prefetch_spectral_weights(self, n_calls: int, append: bool = False):
         """Run the power iterations / normalisations of the NEXT ``n_calls`` training-mode forwards now, in order (each advances
         weight_u / weight_v once, exactly as those forwards would), and queue the results.  They depend on the weights only, not on
         any input: the captured training step issues the three of an iteration (nerf step's D(fake), D(real), D(fake)) on a side
@@ -230,7 +230,7 @@ class Discriminator(nn.Module):
         from . import ops
         if not self.training:
             raise RuntimeError("prefetch_spectral_weights: training mode only")
-        if self._sn_queue:
+        if self._sn_queue and not append:          # (`append`: the caller issues an iteration's sets in two parts, trainer._seg_sn)
             raise RuntimeError("prefetch_spectral_weights: %d prefetched weight sets were never used" % len(self._sn_queue))
         convs = self.sn_convs()
         W, U, V = [c.weight_orig.detach() for c in convs], [c.weight_u for c in convs], [c.weight_v for c in convs]

@@ -307,8 +307,9 @@ class Graph(torch.nn.Module):
             if var.get("feat_early_for") is not var.ray_idx:      # (else: a graph of its own already ran it, trainer._seg_feat)
                 self._feature_loss_early(opt, var, (h, w), mode)
             # (the nerf step differentiates this pass once, wrt the patch: the fused frozen-weight kernels may serve it)
-            with autograd_ops.first_order_only():
-                var.d_fake_nerf = self.discriminator(opt, var.patch_fake_nerf, var.ray_scales)
+            if "gan_nerf_precomputed" not in var:       # (else: the trainer ran this pass as an explicit schedule, disc_step.generator_pass)
+                with autograd_ops.first_order_only():
+                    var.d_fake_nerf = self.discriminator(opt, var.patch_fake_nerf, var.ray_scales)
         return var
 
     def _feature_loss_early(self, opt, var, hw, mode):
@@ -470,7 +471,8 @@ class Graph(torch.nn.Module):
             if lw.lab is not None:
                 loss.lab, var.rgb_lab, var.img_syn_lab = self.lab_loss(rgb, image_syn, mask=mask_syn)
             if opt.gan is not None and lw.gan_nerf is not None and mode == "train":
-                loss.gan_nerf = self.compute_gan_loss(opt, d_outs=var.d_fake_nerf, target=1)
+                loss.gan_nerf = (var.gan_nerf_precomputed if "gan_nerf_precomputed" in var
+                                 else self.compute_gan_loss(opt, d_outs=var.d_fake_nerf, target=1))
         elif train_step == "disc":
             if lw.gan_disc_real is not None:
                 loss.gan_disc_real = self.compute_gan_loss(opt, d_outs=var.d_real_disc, target=1)

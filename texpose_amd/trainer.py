@@ -470,6 +470,8 @@ def distinct_queue_streams(dev, n, candidates=8, votes=3):
     shared = [[2 * c > votes for c in row] for row in counts]
     together = lambda i, j: shared[i][j] or shared[j][i]
     picked = []
+    # (Stream priorities are no lever here: with the discriminator stream, or it and the third one, at priority -1 the B=4 iteration ran
+    # 420-520 it/s instead of 910 on the same box -- docs/lab-notebook-r5.md.)
     for i in range(1, len(every)):
         if len(picked) < n and not together(0, i) and not any(together(j, i) for j in picked):
             picked.append(i)
@@ -535,6 +537,9 @@ class GraphedGanTrainer(GanTrainer):
         # discriminator losses / weights / optimiser state may be read only behind `wait_all()` or `finish()` (tools/train_dp.py,
         # bench.py and tools/train_bench.py set it; default off = everything ordered on the calling stream).
         self.pipeline_disc_tail = os.environ.get("TP_PIPELINE_DISC") == "1"
+        # opt-in: `train_iteration` returns with the calling stream ordered behind the consumption of its inputs, not behind its results
+        # (read losses / parameters behind `wait_all()`); the one-rank six-graph form only (`_replay_linear`)
+        self.defer_results = os.environ.get("TP_DEFER_RESULTS") == "1"
         self._d2_pending = False
         self._four, self._g4, self._ev4 = False, None, None    # the step as four graphs on two streams (`_use_four_graphs`)
         self._linear = False                     # ... as six LINEAR graphs on three streams (`_use_linear_graphs`)
@@ -704,9 +709,14 @@ class GraphedGanTrainer(GanTrainer):
         return (self._disc_schedule(probe) is not None and hasattr(disc, "prefetch_spectral_weights") and disc.training
                 and os.environ.get("TP_NO_SN_PREFETCH") != "1" and os.environ.get("TP_NO_BRANCH_OVERLAP") != "1")
 
-    def _seg_sn(self):
+    def _seg_sn(self, part=None):
+        """The three spectral normalisations of an iteration; `part` 0 / 1: the first one alone (the generator's pass through the frozen
+        discriminator waits for nothing else) / the other two."""
         disc = self.graph.discriminator
-        disc.prefetch_spectral_weights(3)
+        if part is None:
+            disc.prefetch_spectral_weights(3)
+        else:
+            disc.prefetch_spectral_weights(1 if part == 0 else 2, append=part == 1)
         # (the consumers run in OTHER graphs / on the other stream: their ordering behind this segment is the ev_sn event of the
         # replay loop, not a wait recorded while one of them is being captured)
         disc._sn_queue = [(o, sg, u, v, None) for o, sg, u, v, _ in disc._sn_queue]
@@ -807,6 +817,20 @@ class GraphedGanTrainer(GanTrainer):
         var.feat_early, var.feat_early_for, var.feat_early_joined = feat.detach(), var.ray_idx, True
 
     def _seg_gen_a(self, var):
+        lw = self.opt.loss_weight
+        sched = None
+        if (self.has_disc and self.opt.gan is not None and lw.gan_nerf is not None and var.get("disc_patches_for") is var.ray_idx
+                and "rgb_disc" in var):
+            sched = self._disc_schedule(var.patch_fake_nerf)
+            if sched is not None and not sched.generator_pass_eligible(self.opt, var.patch_fake_nerf):
+                sched = None
+        if sched is not None:
+            # the pass through the frozen discriminator as an explicit schedule: 9 launches instead of autograd's 11, no graph
+            with torch.no_grad():
+                val, g_disc, d_out = sched.generator_pass(var.patch_fake_nerf.detach(), var.ray_scales, 10 ** float(lw.gan_nerf))
+            var.gan_nerf_precomputed, var.d_fake_nerf = val, d_out
+            var, loss = self.nerf_forward_loss(var, stage="consume")
+            return var, loss, g_disc
         var, loss = self.nerf_forward_loss(var, stage="consume")
         (g_disc,) = torch.autograd.grad(loss.gan_nerf, var.rgb_disc, grad_outputs=self._weight(self.opt.loss_weight.gan_nerf, var.rgb.device))
         return var, loss, g_disc
@@ -909,6 +933,14 @@ class GraphedGanTrainer(GanTrainer):
         # overwrites the patch stacks / scales this discriminator step is reading -- comes after the discriminator step
         main.wait_event(ev["d2"])
 
+    def _extra(self, name):
+        """TP_EXTRA_LAUNCHES="G2a=10,F=10" (experiment): that many one-thread launches at the end of the named graph -- the slope of the
+        iteration time over the count says whether that graph's end is on the critical path (~3 us per launch) or not (0)."""
+        for item in os.environ.get("TP_EXTRA_LAUNCHES", "").split(","):
+            if item.strip() and item.split("=")[0].strip() == name:
+                for _ in range(int(item.split("=")[1])):
+                    ops.stamp(self._extra_slots, 0)
+
     def _stamp(self, name):
         """TP_STAMPS=1 (tools/linear_timeline.py): a one-thread launch writing the device clock, captured at the segment boundaries."""
         if os.environ.get("TP_STAMPS") != "1":
@@ -921,24 +953,39 @@ class GraphedGanTrainer(GanTrainer):
 
     def _capture_linear(self, cap):
         side, feat = self._side, self.graph.feat_stream
+        if os.environ.get("TP_STAMPS") == "1" and getattr(self, "_stamps", None) is None:
+            # (made OUTSIDE the captures: a zero-fill captured into the first graph would wipe the other streams' stamps on every replay)
+            self._stamps, self._stamp_names = torch.zeros(32, dtype=torch.int64, device=self._bad.device), []
+            torch.cuda.synchronize(self._bad.device)
         self._g4 = g = {k: torch.cuda.CUDAGraph() for k in ("D1", "G1", "F", "G2a", "G2b", "D2")}
-        self._ev4 = {k: torch.cuda.Event() for k in ("sn", "patches", "feat", "g2", "d2")}
+        self._ev4 = {k: torch.cuda.Event() for k in ("sn", "patches", "feat", "g2a", "g2", "d2")}
+        self._extra_slots = torch.zeros(1, dtype=torch.int64, device=self._bad.device)
         # one memory pool per stream (see `_capture_four`); tensors that cross streams stay referenced for the life of the graphs
         counts = self.launch_counts = {}                 # nodes per captured graph (kernel launches; TP_STAMPS adds two to each)
-        with torch.cuda.graph(g["D1"], stream=side):
-            self._stamp("D1.0"); self._seg_sn(); self._stamp("D1.1"); counts["D1"] = ops.capture_node_count()
+        # The generator's pass through the frozen discriminator (G2a) needs the FIRST normalised weight set only, and in steady state it
+        # is what the next render's backward waits for (D2b -> D1 -> G2a -> G2b): that set as a graph of its own (3 launches), the
+        # other two (2 x 2 + 1 launches) behind it, 8 launches instead of 7 (`TP_SN_SPLIT=1`; default: one graph).
+        if os.environ.get("TP_SN_SPLIT") != "1":       # (measured: 914-920 it/s split, 925-926 as one graph -- the launch count decides)
+            with torch.cuda.graph(g["D1"], stream=side):
+                self._stamp("D1.0"); self._seg_sn(); self._stamp("D1.1"); self._extra("D1"); counts["D1"] = ops.capture_node_count()
+        else:
+            g["D1b"] = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g["D1"], stream=side):
+                self._stamp("D1.0"); self._seg_sn(0); self._stamp("D1.1"); self._extra("D1"); counts["D1"] = ops.capture_node_count()
+            with torch.cuda.graph(g["D1b"], stream=side, pool=g["D1"].pool()):
+                self._seg_sn(1); counts["D1b"] = ops.capture_node_count()
         keep = [list(self.graph.discriminator._sn_queue)]
         with torch.cuda.graph(g["G1"], stream=cap):
-            self._stamp("G1.0"); var = self._seg_render(AttrDict(dict(self._static_in))); self._stamp("G1.1"); counts["G1"] = ops.capture_node_count()
+            self._stamp("G1.0"); var = self._seg_render(AttrDict(dict(self._static_in))); self._stamp("G1.1"); self._extra("G1"); counts["G1"] = ops.capture_node_count()
         keep.append(dict(var))
         with torch.cuda.graph(g["F"], stream=feat):
-            self._stamp("F.0"); self._seg_feat(var); self._stamp("F.1"); counts["F"] = ops.capture_node_count()
+            self._stamp("F.0"); self._seg_feat(var); self._stamp("F.1"); self._extra("F"); counts["F"] = ops.capture_node_count()
         keep.append(dict(var))
         with torch.cuda.graph(g["G2a"], stream=cap, pool=g["G1"].pool()):
-            self._stamp("G2a.0"); var, loss, g_disc = self._seg_gen_a(var); self._stamp("G2a.1"); counts["G2a"] = ops.capture_node_count()
+            self._stamp("G2a.0"); var, loss, g_disc = self._seg_gen_a(var); self._stamp("G2a.1"); self._extra("G2a"); counts["G2a"] = ops.capture_node_count()
         keep.append((dict(var), dict(loss), g_disc))
         with torch.cuda.graph(g["G2b"], stream=cap, pool=g["G1"].pool()):
-            self._stamp("G2b.0"); var, loss = self._seg_gen_b(var, loss, g_disc); self._stamp("G2b.1"); counts["G2b"] = ops.capture_node_count()
+            self._stamp("G2b.0"); var, loss = self._seg_gen_b(var, loss, g_disc); self._stamp("G2b.1"); self._extra("G2b"); counts["G2b"] = ops.capture_node_count()
         keep.append(dict(var))
         # The discriminator step in TWO graphs when its paired schedule applies: D2a = private copies of the patch stacks, forward pairs,
         # BCE terms -- the last reads of anything the render wrote -- and D2b = the R1 passes, backward pairs, spectral-norm backward,
@@ -949,10 +996,11 @@ class GraphedGanTrainer(GanTrainer):
             self._ev4["d2a"] = torch.cuda.Event()
             self.disc_step_zero_grads()
             with torch.cuda.graph(g["D2a"], stream=side, pool=g["D1"].pool()):
-                self._stamp("D2.0"); ctx = self._seg_disc_a(var, run=True); counts["D2a"] = ops.capture_node_count()
+                self._stamp("D2.0"); ctx = self._seg_disc_a(var, run=True); self._stamp("D2a.1"); self._extra("D2a"); counts["D2a"] = ops.capture_node_count()
             keep.append(ctx)
             with torch.cuda.graph(g["D2b"], stream=side, pool=g["D1"].pool()):
                 var, dloss = self._seg_disc_b(var, ctx); self._stamp("D2.1"); counts["D2b"] = ops.capture_node_count()
+                self._extra("D2b")
             del g["D2"]
         else:
             with torch.cuda.graph(g["D2"], stream=side, pool=g["D1"].pool()):
@@ -965,12 +1013,23 @@ class GraphedGanTrainer(GanTrainer):
 
     def _replay_linear(self):
         g, ev = self._g4, self._ev4
+        if os.environ.get("TP_ABLATE"):
+            # (timing diagnostic, tools/README: graphs left out of the replay -- what the iteration would cost without that chain; the
+            # numbers such an iteration computes are meaningless)
+            class _Skip:
+                def replay(self): pass
+            g = {k: (_Skip() if k in os.environ["TP_ABLATE"].split(",") else v) for k, v in g.items()}
         main, side, feat = self._capture_stream, self._side, self.graph.feat_stream
         cur = torch.cuda.current_stream(self._bad.device)
         # the caller's stream hands over the step's inputs (and, the first time, parameters restored / loaded since the capture); it
         # waited for the previous iteration's last launches below, so does everything here
-        main.wait_stream(cur)
-        if getattr(self, "_d2_pending", False):
+        if self.__dict__.pop("_inputs_on_main", False):
+            pass                                      # (`defer_results`: train_iteration already ordered `main` behind the caller's mark)
+        else:
+            main.wait_stream(cur)
+        if getattr(self, "_g2_pending", False) and not self._pipelined():
+            main.wait_event(ev["d2"])                 # (nothing else orders the render behind the previous discriminator step)
+        if getattr(self, "_d2_pending", False) and self._pipelined():
             # pipelined: this render may start while the previous discriminator step's second half still runs; it overwrites the patch
             # stacks / scales, whose last readers are in that step's FIRST half
             main.wait_event(ev["d2a"])
@@ -988,16 +1047,24 @@ class GraphedGanTrainer(GanTrainer):
                 side.wait_event(ev["g2"])            # set 1 is read by the generator's passes through the frozen discriminator
             g["D1"].replay()
             ev["sn"].record(side)
+            if "D1b" in g:
+                g["D1b"].replay()
         with torch.cuda.stream(main):
             g["G1"].replay()
             ev["patches"].record(main)
         # (The order in which the host submits F / G2a+G2b / D2 makes no difference -- six orders measured within 0.5 % on one box -- and the
         # host is 4x ahead of the device: 260 us of launches per 1.17 ms iteration.)
-        with torch.cuda.stream(feat):
-            self._four_first = False
-            feat.wait_event(ev["patches"])           # (recorded on `main` behind its wait for the caller's stream)
+        # Which of the two chains between the render and its backward shares the render's stream: each stream hop (event -> first launch
+        # of a graph on another hardware queue) costs ~20 us, and the feature chain (137 us alone) is the longer of the two, the
+        # generator's pass through the discriminator (101 us) also waits for D1 -- so the feature chain stays on `main` and that pass
+        # takes the third stream (`TP_FEAT_ON_OWN_STREAM=1`: the layout up to profiles/r5/21).
+        feat_on_main = os.environ.get("TP_FEAT_ON_OWN_STREAM") != "1"
+        self._four_first = False
+        with torch.cuda.stream(main if feat_on_main else feat):
+            if not feat_on_main:
+                feat.wait_event(ev["patches"])       # (recorded on `main` behind its wait for the caller's stream)
             g["F"].replay()
-            ev["feat"].record(feat)
+            ev["feat"].record()
         d2_first = os.environ.get("TP_G2B_AFTER_D2") == "1"      # (experiment: the render's backward starts behind the discriminator step)
 
         def disc_step_graph():
@@ -1015,10 +1082,19 @@ class GraphedGanTrainer(GanTrainer):
 
         if d2_first:
             disc_step_graph()
+        if feat_on_main:
+            with torch.cuda.stream(feat):
+                feat.wait_event(ev["patches"])
+                feat.wait_event(ev["sn"])
+                g["G2a"].replay()
+                ev["g2a"].record(feat)
         with torch.cuda.stream(main):
-            main.wait_event(ev["sn"])
-            g["G2a"].replay()
-            main.wait_event(ev["feat"])
+            if feat_on_main:
+                main.wait_event(ev["g2a"])
+            else:
+                main.wait_event(ev["sn"])
+                g["G2a"].replay()
+                main.wait_event(ev["feat"])
             if d2_first:
                 main.wait_event(ev["d2"])
             g["G2b"].replay()
@@ -1026,6 +1102,13 @@ class GraphedGanTrainer(GanTrainer):
         if not d2_first:
             disc_step_graph()
         # what the caller enqueues next -- reads of the losses, the next iteration's inputs -- comes after both optimiser steps ...
+        if self._defers_results():
+            # `defer_results`: the calling stream is ordered behind the consumption of this iteration's INPUTS only (train_iteration);
+            # `wait_all()` / `finish()` / `flush_flags()` order it behind the results.  The next iteration then starts on `main`
+            # straight behind this one's Adam launch, without the two stream hops main -> caller -> main.
+            self._g2_pending = True
+            self._d2_pending = True
+            return
         cur.wait_event(ev["g2"])
         if self._pipelined():
             # ... unless the caller asked for the discriminator step's second half to run beside the next iteration's render
@@ -1037,11 +1120,18 @@ class GraphedGanTrainer(GanTrainer):
     def _pipelined(self):
         return bool(self.pipeline_disc_tail) and self._linear and self._g4 is not None and "D2a" in self._g4
 
+    def _defers_results(self):
+        return bool(self.defer_results) and self._linear and self._g4 is not None
+
     def wait_all(self):
         """Make the calling stream wait for everything the last `train_iteration` enqueued (with `pipeline_disc_tail`: the
         discriminator step's second half and its RMSprop step)."""
+        cur = torch.cuda.current_stream(self._bad.device)
+        if getattr(self, "_g2_pending", False):
+            cur.wait_event(self._ev4["g2"])
+            self._g2_pending = False
         if getattr(self, "_d2_pending", False):
-            torch.cuda.current_stream(self._bad.device).wait_event(self._ev4["d2"])
+            cur.wait_event(self._ev4["d2"])
             self._d2_pending = False
 
     def _prefetch_spectral_weights(self, var):
@@ -1159,7 +1249,7 @@ class GraphedGanTrainer(GanTrainer):
                 self._after_step()
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
-        self._d2_pending = False
+        self._d2_pending = self._g2_pending = False
         self._graph = torch.cuda.CUDAGraph()
         self.optim_nerf.zero_grad(set_to_none=True)
         if self.has_disc:
@@ -1287,6 +1377,8 @@ class GraphedGanTrainer(GanTrainer):
         pairs = [(dst, var[k]) for k, dst in self._static_in.items() if var[k] is not dst]
         fused = [(d, s) for d, s in pairs if torch.is_tensor(s) and s.device == d.device and s.dtype == d.dtype and s.shape == d.shape
                  and s.is_contiguous() and d.is_contiguous() and d.data_ptr() % 16 == 0 and s.data_ptr() % 16 == 0]
+        if self._defers_results() and len(fused) != len(pairs):
+            self.wait_all()                                   # (a batch member the one-launch copy does not take: strict order this once)
         for d, s in pairs:
             if not any(d is d2 for d2, _ in fused):
                 d.copy_(s, non_blocking=True)
@@ -1299,10 +1391,23 @@ class GraphedGanTrainer(GanTrainer):
             # reference :182 leaves it / max_iter in `progress` after iteration `it`; nothing reads it during the iteration
             scalars.append((self.graph.discriminator.progress.data, self.it / self.max_iter))
         poll = self._bad_poll_slot()
-        ops.step_inputs(fused, scalars, words=self._bad if poll is not None else None, words_host=poll)
+        if self._defers_results():
+            # `defer_results`: the step's inputs go in on the generator stream itself, behind the caller's mark (its batch is ready) and,
+            # by stream order, behind the previous iteration's last reader of the static inputs -- no stream hop in front of the render
+            main = self._capture_stream
+            main.wait_event(self._caller_mark)
+            with torch.cuda.stream(main):
+                ops.step_inputs(fused, scalars, words=self._bad if poll is not None else None, words_host=poll)
+                ev = torch.cuda.Event()
+                ev.record()
+            torch.cuda.current_stream(self._bad.device).wait_event(ev)      # (the caller may overwrite its batch tensors behind this)
+            self._inputs_on_main = True
+        else:
+            ops.step_inputs(fused, scalars, words=self._bad if poll is not None else None, words_host=poll)
+            if poll is not None:
+                ev = torch.cuda.Event()
+                ev.record()
         if poll is not None:
-            ev = torch.cuda.Event()
-            ev.record()
             self._bad_poll = (poll, ev)
         self.replay()
         self._after_step(fill_progress=False)

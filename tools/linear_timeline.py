@@ -47,3 +47,10 @@ st = tr._stamps[:n].cpu().double()
 print("free-running, last of 50 iterations:")
 for name, v in zip(tr._stamp_names, ((st - st[tr._stamp_names.index("G1.0")]) / 100.0).tolist()):
     print("  %-6s %8.1f" % (name, v))
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(200):
+    tr.train_iteration(AttrDict(dict(var)))
+e1.record()
+torch.cuda.synchronize()
+print("period, free-running: %.1f us (pipeline_disc_tail %s, defer_results %s)" % (e0.elapsed_time(e1) / 200 * 1e3, tr._pipelined(), tr._defers_results()))

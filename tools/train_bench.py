@@ -30,6 +30,7 @@ def run(B=4, iters=20, warm=6, full=True, device="cuda:0", graphed=False, train_
     tr = (GraphedGanTrainer if graphed else GanTrainer)(opt, graph, n_train=189)
     if graphed and os.environ.get("TP_NO_PIPELINE_DISC") != "1":
         tr.pipeline_disc_tail = True           # (losses / state are read behind the final synchronise only)
+        tr.defer_results = os.environ.get("TP_NO_DEFER") != "1"
     var = training_batch(B, 128, 128, device=device)
     for _ in range(warm):
         tr.train_iteration(AttrDict(dict(var)))

@@ -60,6 +60,7 @@ def measure(device, rank, world, global_batch=32, iters=50, warm=5, graphed=True
         # the discriminator step's second half may run beside the next render (one rank, six-graph form); this loop reads losses and
         # state only behind flush_flags() / a device synchronise
         trainer.pipeline_disc_tail = True
+        trainer.defer_results = os.environ.get("TP_NO_DEFER") != "1"
     if hook is not None:
         hook(trainer)
     # a global batch, identical on all ranks (stands in for the sampler of a distributed data loader); each rank keeps its shard
