@@ -26,7 +26,7 @@ extern "C" {
 
 typedef void* tp_stream_t; /* hipStream_t */
 
-#define TP_ABI_VERSION 9
+#define TP_ABI_VERSION 10
 
 int tp_abi_version(void);
 const char* tp_last_error(void);
@@ -324,6 +324,21 @@ int tp_sn_fwd(const tp_sn_weight* weights, int n, int training, tp_stream_t stre
  * shared): two launches per set and ONE normalisation launch for all sets; bit-identical to n_sets tp_sn_fwd calls. */
 int tp_sn_fwd_sets(const tp_sn_weight* weights, int n, int n_sets, tp_stream_t stream);
 int tp_sn_bwd(const tp_sn_weight* weights, int n, tp_stream_t stream);
+/* tp_sn_bwd for a discriminator step that ENDS here (one rank, no gradient reduction behind it): the loss total + step gate ride in the
+ * first launch (what tp_weighted_sum_flags does: total = sum_k terms[k][0] * weights[k] in ascending k, bad[word_finite] |= 1 if it is not
+ * finite, snapshot[0..n_bad) = bad[...]), the RMSprop step of every weight (tp_rmsprop_step's arithmetic; withheld if a snapshot word is
+ * set) in the second, on the gradient element the thread has just formed -- 2 launches instead of 4.  The gradients are still written.
+ * ref: model/nerf_adapt_st_gan.py:129-171 (disc_trainstep: summarize_loss, backward, optim_disc.step()), model/base.py:145-157 */
+typedef struct tp_sn_step_tail {
+  const float* terms[4]; float weights[4]; int n_terms; int word_finite;
+  float* total;                                  /* [1] */
+  int32_t* bad; int32_t* snapshot; int n_bad; int pad_;
+  float* param[TP_SN_MAX_WEIGHTS];               /* weight_orig of weight i (the tensor tp_sn_weight.grad belongs to) */
+  float* square_avg[TP_SN_MAX_WEIGHTS];
+  float* step[TP_SN_MAX_WEIGHTS];                /* optional 0-dim float32 counters, += 1 per applied step */
+  const float* lr_dev; float lr_host, alpha, one_minus_alpha, eps;      /* (one_minus_alpha = (float)(1.0 - alpha) formed in double, like tp_rmsprop_step) */
+} tp_sn_step_tail;
+int tp_sn_bwd_step(const tp_sn_weight* weights, int n, const tp_sn_step_tail* tail, tp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * K8  render-consuming loss terms of the generator step (render, uncert, trans_reg) and their gradients

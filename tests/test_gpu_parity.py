@@ -1365,6 +1365,46 @@ def test_disc_step_pairs_are_bit_identical_to_the_sequential_schedule(ops, monke
     assert torch.equal(ya, yb) and torch.equal(yc, ops.conv4s2_fwd_inorm(x * 2, w, 1e-5, 0.2)[0])
 
 
+def test_disc_step_tail_in_the_sn_backward_is_bit_identical(ops, monkeypatch):
+    """tp_sn_bwd_step: the discriminator step's loss total + gate and its RMSprop update inside the spectral-norm backward's two launches
+    (trainer._disc_step_tail) against the same captured trainer with them as launches of their own (TP_NO_DISC_STEP_TAIL=1): after six
+    replayed iterations parameters, buffers, RMSprop state (square_avg AND step counters), losses and gate words are bit-identical, and
+    the replayed discriminator step is two launches shorter."""
+    from texpose_amd.gan_modules import Discriminator, PerceptualLoss
+    from texpose_amd.graph import Graph
+    from texpose_amd.options import default_options, AttrDict
+    from texpose_amd.synthetic import training_batch
+    from texpose_amd.trainer import GraphedGanTrainer
+    out = []
+    for fused in (True, False):
+        if fused:
+            monkeypatch.delenv("TP_NO_DISC_STEP_TAIL", raising=False)
+        else:
+            monkeypatch.setenv("TP_NO_DISC_STEP_TAIL", "1")
+        torch.manual_seed(0)
+        opt = default_options(H=128, W=128, device="cuda:0")
+        opt.batch_size, opt.patch_size, opt.nerf.sample_intvs = 4, 16, 64
+        graph = Graph(opt, discriminator=Discriminator(opt), perceptual_loss=PerceptualLoss()).to(dev())
+        tr = GraphedGanTrainer(opt, graph, n_train=189)
+        batches = [training_batch(4, 128, 128, seed=s_, device="cuda:0") for s_ in range(2)]
+        for it in range(6):
+            _, loss = tr.train_iteration(AttrDict(dict(batches[it % 2])))
+        tr.finish()
+        torch.cuda.synchronize()
+        assert tr._linear and "D2b" in tr._g4
+        out.append(({k: v.clone() for k, v in graph.state_dict().items()}, {k: v.clone() for k, v in loss.items() if torch.is_tensor(v)},
+                    [t.clone() for st in tr.optim_disc.state.values() for t in st.values() if torch.is_tensor(t)], tr._bad.clone(),
+                    tr.launch_counts["D2b"]))
+    for k in out[0][0]:
+        assert torch.equal(out[0][0][k], out[1][0][k]), k
+    for k in out[0][1]:
+        assert torch.equal(out[0][1][k], out[1][1][k]), k
+    assert len(out[0][2]) == len(out[1][2]) > 0 and all(torch.equal(a, b) for a, b in zip(out[0][2], out[1][2]))
+    assert torch.equal(out[0][3], out[1][3]) and out[0][4] == out[1][4] - 2
+    steps = [float(st["step"]) for st in tr.optim_disc.state.values()]
+    assert steps and all(v == steps[0] and v >= 6 for v in steps)
+
+
 def test_generator_pass_schedule_matches_autograd(ops):
     """disc_step.generator_pass -- the nerf step's D(fake) term (reference model/nerf_adapt_st_gan.py:108-127, :771-773) as an explicit
     schedule of 9 launches -- against autograd through the Discriminator module (K7 / K11 / K9 / K17 Functions) on golden G13b's fake

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # TEXPOSE_AMD_LIB selects another build of the SAME library (e.g. the `make trace` diagnostic build); never a fallback
 LIB_PATH = os.environ.get("TEXPOSE_AMD_LIB") or os.path.join(_HERE, "libtexpose_amd.so")
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 # Every symbol include/texpose_amd.h declares (checked by tests/test_capi_cpu.py).
 SYMBOLS = (
@@ -33,7 +33,7 @@ SYMBOLS = (
     "tp_conv3s1_workspace", "tp_conv3s1_fwd", "tp_conv3s1_dgrad",
     "tp_patch_coords", "tp_bce_logits_fwd", "tp_bce_logits_bwd", "tp_feat_inputs_fwd", "tp_feat_inputs_bwd", "tp_disc_inputs", "tp_step_flags", "tp_adam_step", "tp_step_inputs", "tp_stamp", "tp_clock_probe",
     "tp_fake_patch_bwd", "tp_feat_pair_loss_fwd", "tp_feat_pair_loss_bwd", "tp_sumsq_mean_fwd", "tp_sumsq_mean_bwd", "tp_sumsq_mean_fwd_bwd", "tp_gan_disc_losses", "tp_maxpool2_fwd", "tp_maxpool2_bwd", "tp_latent_rows_fwd",
-    "tp_latent_rows_bwd", "tp_weighted_sum", "tp_weighted_sum_flags",
+    "tp_latent_rows_bwd", "tp_weighted_sum", "tp_weighted_sum_flags", "tp_sn_bwd_step",
     "tp_disc_head_fwd", "tp_disc_head_bwd", "tp_disc_head_bwd_bwd",
     "tp_skinny_linear_fwd", "tp_skinny_linear_wgrad", "tp_skinny_linear_dgrad",
     "tp_disc_tail_workspace_bytes", "tp_disc_tail_fwd", "tp_disc_tail_bwd", "tp_disc_tail_bwd_bwd", "tp_disc_tail_fwd_pair", "tp_disc_tail_bwd_pair",
@@ -106,6 +106,13 @@ class SnWeight(C.Structure):
 
 
 SN_MAX_WEIGHTS = 8
+
+
+class SnStepTail(C.Structure):
+    _fields_ = [("terms", vp * 4), ("weights", C.c_float * 4), ("n_terms", C.c_int), ("word_finite", C.c_int), ("total", vp),
+                ("bad", vp), ("snapshot", vp), ("n_bad", C.c_int), ("pad_", C.c_int),
+                ("param", vp * SN_MAX_WEIGHTS), ("square_avg", vp * SN_MAX_WEIGHTS), ("step", vp * SN_MAX_WEIGHTS),
+                ("lr_dev", vp), ("lr_host", C.c_float), ("alpha", C.c_float), ("one_minus_alpha", C.c_float), ("eps", C.c_float)]
 
 
 class RmspropTensor(C.Structure):
@@ -237,6 +244,7 @@ def load() -> C.CDLL:
     sig("tp_sn_fwd", [C.POINTER(SnWeight), C.c_int, C.c_int, vp])
     sig("tp_sn_fwd_sets", [C.POINTER(SnWeight), C.c_int, C.c_int, vp])
     sig("tp_sn_bwd", [C.POINTER(SnWeight), C.c_int, vp])
+    sig("tp_sn_bwd_step", [C.POINTER(SnWeight), C.c_int, C.POINTER(SnStepTail), vp])
     sig("tp_nerf_losses_fwd", [C.POINTER(NerfLossesArgs), vp])
     sig("tp_nerf_losses_bwd", [C.POINTER(NerfLossesArgs), vp, vp, vp, vp, vp, vp, vp])
     sig("tp_render_eval_workspace_bytes", [C.c_int, C.c_int, C.c_int], C.c_size_t)

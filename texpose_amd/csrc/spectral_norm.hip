@@ -229,10 +229,28 @@ __global__ __launch_bounds__(256) void sn_scale_sets_kernel(Batch b, SetOuts o, 
   }
 }
 
+// what tp_sn_bwd_step adds to the two launches (all zero for tp_sn_bwd)
+struct StepTail {
+  const float* t[4]; float w[4]; int n;            // D: loss total = sum_k t[k][0] * w[k] ...
+  float* total; int* bad; int* snapshot; int n_bad, word_finite;    // ... its finiteness into the sticky word, the words' snapshot
+};
+struct RmsTail {
+  float* p[kMaxW]; float* sq[kMaxW]; float* step[kMaxW];            // E: RMSprop on the element just formed (on == 1)
+  const float* lr_dev; float lr_host, alpha, one_minus_alpha, eps;
+  const int* gate; int n_gate, on;
+};
+
 // D: per-workgroup partial of <G, W_sn> (and of the second instance's <G2, W_sn2>)
-__global__ __launch_bounds__(256) void sn_dot_kernel(Batch b) {
+__global__ __launch_bounds__(256) void sn_dot_kernel(Batch b, StepTail st) {
   __shared__ float red[256];
   int local;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && st.n > 0) {          // (tp_weighted_sum_flags's arithmetic and order of side effects)
+    float acc = 0.f;
+    for (int k = 0; k < st.n; ++k) acc += st.t[k][0] * st.w[k];
+    st.total[0] = acc;
+    if (!(acc - acc == 0.f)) st.bad[st.word_finite] |= 1;
+    for (int k = 0; k < st.n_bad; ++k) st.snapshot[k] = st.bad[k];
+  }
   const tp_sn_weight& w = b.w[find_weight(b, blockIdx.x, local)];
   const int64_t n = (int64_t)w.rows * w.cols;
   const int parts = (int)((n + 4095) / 4096);
@@ -250,10 +268,15 @@ __global__ __launch_bounds__(256) void sn_dot_kernel(Batch b) {
 }
 
 // E: dW = (G - <G, W_sn> u v^T) / sigma  (+ the same of the second instance)
-__global__ __launch_bounds__(256) void sn_grad_kernel(Batch b) {
+__global__ __launch_bounds__(256) void sn_grad_kernel(Batch b, RmsTail rt) {
   __shared__ float red[256];
   int local;
-  const tp_sn_weight& w = b.w[find_weight(b, blockIdx.x, local)];
+  const int wi = find_weight(b, blockIdx.x, local);
+  const tp_sn_weight& w = b.w[wi];
+  bool apply = rt.on != 0;
+  for (int k = 0; k < rt.n_gate; ++k) apply = apply && rt.gate[k] == 0;      // a flagged step: parameters and statistics stay as they are
+  const float lr = !apply ? 0.f : rt.lr_dev != nullptr ? *rt.lr_dev : rt.lr_host;
+  if (apply && local == 0 && threadIdx.x == 0 && rt.step[wi] != nullptr) rt.step[wi][0] += 1.0f;
   const int64_t n = (int64_t)w.rows * w.cols;
   const int parts = (int)((n + 4095) / 4096);
   float d = 0.0f, d2 = 0.0f;
@@ -265,7 +288,15 @@ __global__ __launch_bounds__(256) void sn_grad_kernel(Batch b) {
     const int r = (int)(i / w.cols), c = (int)(i - (int64_t)r * w.cols);
     float gv = (w.grad_sn[i] - d * w.u[r] * w.v[c]) / sg;
     if (w.grad_sn2) gv = gv + (w.grad_sn2[i] - d2 * w.u2[r] * w.v2[c]) / sg2;
-    w.grad[i] = w.accumulate ? w.grad[i] + gv : gv;
+    gv = w.accumulate ? w.grad[i] + gv : gv;
+    w.grad[i] = gv;
+    if (apply) {                                   // csrc/rmsprop.hip's arithmetic, torch's order
+      float sq = rt.sq[wi][i];
+      sq = __fadd_rn(__fmul_rn(sq, rt.alpha), __fmul_rn(__fmul_rn(rt.one_minus_alpha, gv), gv));
+      rt.sq[wi][i] = sq;
+      const float avg = __fadd_rn(sqrtf(sq), rt.eps);
+      rt.p[wi][i] = __fadd_rn(rt.p[wi][i], __fmul_rn(-lr, __fdiv_rn(gv, avg)));
+    }
   }
 }
 
@@ -354,13 +385,36 @@ extern "C" int tp_sn_fwd_sets(const tp_sn_weight* ws, int n, int n_sets, tp_stre
   return tp::check_launch("tp_sn_fwd_sets");
 }
 
-extern "C" int tp_sn_bwd(const tp_sn_weight* ws, int n, tp_stream_t stream) {
-  if (int rc = check(ws, n, true, "tp_sn_bwd")) return rc;
-  hipStream_t st = (hipStream_t)stream;
+namespace {
+int sn_bwd_launch(const tp_sn_weight* ws, int n, const StepTail& tl, const RmsTail& rt, hipStream_t st, const char* what) {
   Batch b;
   int g = fill(b, ws, n, [](const tp_sn_weight& w) { return (int)(((int64_t)w.rows * w.cols + 4095) / 4096); });
-  hipLaunchKernelGGL(sn_dot_kernel, dim3(g), dim3(256), 0, st, b);
+  hipLaunchKernelGGL(sn_dot_kernel, dim3(g), dim3(256), 0, st, b, tl);
   g = fill(b, ws, n, [](const tp_sn_weight& w) { return (int)(((int64_t)w.rows * w.cols + 1023) / 1024); });
-  hipLaunchKernelGGL(sn_grad_kernel, dim3(g), dim3(256), 0, st, b);
-  return tp::check_launch("tp_sn_bwd");
+  hipLaunchKernelGGL(sn_grad_kernel, dim3(g), dim3(256), 0, st, b, rt);
+  return tp::check_launch(what);
+}
+}  // namespace
+
+extern "C" int tp_sn_bwd(const tp_sn_weight* ws, int n, tp_stream_t stream) {
+  if (int rc = check(ws, n, true, "tp_sn_bwd")) return rc;
+  return sn_bwd_launch(ws, n, StepTail{}, RmsTail{}, (hipStream_t)stream, "tp_sn_bwd");
+}
+
+extern "C" int tp_sn_bwd_step(const tp_sn_weight* ws, int n, const tp_sn_step_tail* a, tp_stream_t stream) {
+  if (int rc = check(ws, n, true, "tp_sn_bwd_step")) return rc;
+  TP_REQUIRE(a != nullptr && a->n_terms >= 1 && a->n_terms <= 4 && a->total && a->bad && a->snapshot && a->n_bad > 0 && a->n_bad <= 64
+             && a->word_finite >= 0 && a->word_finite < a->n_bad, "tp_sn_bwd_step: bad loss-total / gate arguments");
+  StepTail tl{};
+  RmsTail rt{};
+  for (int k = 0; k < a->n_terms; ++k) { TP_REQUIRE(a->terms[k] != nullptr, "tp_sn_bwd_step: null term"); tl.t[k] = a->terms[k]; tl.w[k] = a->weights[k]; }
+  tl.n = a->n_terms; tl.total = a->total; tl.bad = a->bad; tl.snapshot = a->snapshot; tl.n_bad = a->n_bad; tl.word_finite = a->word_finite;
+  for (int i = 0; i < n; ++i) {
+    TP_REQUIRE(a->param[i] && a->square_avg[i] && !ws[i].accumulate, "tp_sn_bwd_step: parameter / square_avg of every weight, no accumulation");
+    for (int j = 0; j < i; ++j) TP_REQUIRE(a->param[j] != a->param[i] && (a->step[j] == nullptr || a->step[j] != a->step[i]), "tp_sn_bwd_step: repeated tensor");
+    rt.p[i] = a->param[i]; rt.sq[i] = a->square_avg[i]; rt.step[i] = a->step[i];
+  }
+  rt.lr_dev = a->lr_dev; rt.lr_host = a->lr_host; rt.alpha = a->alpha; rt.one_minus_alpha = a->one_minus_alpha; rt.eps = a->eps;
+  rt.gate = a->snapshot; rt.n_gate = a->n_bad; rt.on = 1;
+  return sn_bwd_launch(ws, n, tl, rt, (hipStream_t)stream, "tp_sn_bwd_step");
 }

@@ -388,14 +388,23 @@ class DiscStepSchedule:
         return AttrDict(res=res, n_real=n_real, n_fake=n_fake, xs=xs, gs=gs, fr=fr, ff=ff, g_real=g_real, g_fake=g_fake,
                         real=real_stack[:B], fake=fake)
 
-    def run_paired_b(self, c, w_reg):
-        """Second half: the R1 passes, the backward pairs, the spectral-norm backward; gradients into ``.grad``.  Returns the result."""
+    def run_paired_b(self, c, w_reg, step=None):
+        """Second half: the R1 passes, the backward pairs, the spectral-norm backward; gradients into ``.grad``.  Returns the result.
+        ``step`` = dict(w_real, w_fake, flags, square_avgs, steps, lr, alpha, eps): the step ENDS in the spectral-norm backward's two
+        launches -- loss total + gate in the first, RMSprop of the six weights in the second (ops.spectral_norm_bwd(step=)); the
+        result then carries ``total``."""
         res = c.res
         r1, c_zr, gWh = self._r1_passes(c.fr, c.n_real.w, c.xs, c.gs, w_reg)
         res.gan_reg_real, res.gan_reg_real_weighted = r1[0], r1[1]
         gw_real, gw_fake = self._backward_pair(c.fr, c.n_real.w, c.g_real, c.xs, c.gs, c_zr, gWh, c.ff, c.n_fake.w, c.g_fake)
+        if step is not None:
+            # (terms in the order of the autograd form's total: real, R1, fake)
+            step = dict(step, terms=[res.gan_disc_real, res.gan_reg_real, res.gan_disc_fake], weights=[step["w_real"], w_reg, step["w_fake"]],
+                        params=[conv.weight_orig.data for conv in self.convs()])
         grads = ops.spectral_norm_bwd(gw_real, c.n_real.w, c.n_real.u, c.n_real.v, c.n_real.sigma,
-                                      second=(gw_fake, c.n_fake.w, c.n_fake.u, c.n_fake.v, c.n_fake.sigma))
+                                      second=(gw_fake, c.n_fake.w, c.n_fake.u, c.n_fake.v, c.n_fake.sigma), step=step)
+        if step is not None:
+            res.total = step["total"]
         for conv, g in zip(self.convs(), grads):
             conv.weight_orig.grad = g
         return res

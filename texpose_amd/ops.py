@@ -742,11 +742,15 @@ def spectral_norm_buffers(weights, us, vs):
 
 
 @_on_tensor_device
-def spectral_norm_bwd(grads_sn, weights_sn, us, vs, sigmas, accumulate_into=None, second=None):
+def spectral_norm_bwd(grads_sn, weights_sn, us, vs, sigmas, accumulate_into=None, second=None, step=None):
     """dL/dW from dL/dW_sn with u, v treated as constants (torch's convention): (G - <G, W_sn> u v^T) / sigma.
     ``accumulate_into``: a list of tensors the results are ADDED to; they are what is returned.
     ``second`` = (grads_sn2, weights_sn2, us2, vs2, sigmas2): a second normalised instance of the same weights in one optimiser
-    step (the discriminator step's fake pass) -- its term is added inside the same two launches."""
+    step (the discriminator step's fake pass) -- its term is added inside the same two launches.
+    ``step`` = dict(terms, weights, flags=dict(bad, word_finite, snapshot), params, square_avgs, steps, lr, alpha, eps): the END of a
+    discriminator step in the same two launches (tp_sn_bwd_step) -- the loss total and the step gate (what `weighted_sum(flags=)`
+    does) in the first, the RMSprop update of ``params`` (what `rmsprop_step(gate=snapshot)` does) in the second; the total goes to
+    ``step["total"]`` (a 0-dim tensor made here)."""
     lib = _lib.load()
     n = len(grads_sn)
     arr = (_lib.SnWeight * n)()
@@ -769,7 +773,38 @@ def spectral_norm_bwd(grads_sn, weights_sn, us, vs, sigmas, accumulate_into=None
                                                               second[3][i].data_ptr(), second[4][i].data_ptr())
             keep.append(g2)
         outs.append(o); keep += [g, wk]
-    check(lib.tp_sn_bwd(arr, n, _stream()), "tp_sn_bwd")
+    if step is None:
+        check(lib.tp_sn_bwd(arr, n, _stream()), "tp_sn_bwd")
+        return outs
+    if accumulate_into is not None:
+        raise ValueError("spectral_norm_bwd(step=): the gradients are the step's own (no accumulate_into)")
+    t = _lib.SnStepTail()
+    terms = [_f32(x.detach(), "term") for x in step["terms"]]
+    if not 1 <= len(terms) <= 4 or len(step["weights"]) != len(terms) or len(step["params"]) != n:
+        raise ValueError("spectral_norm_bwd(step=): 1..4 terms with their weights, one parameter per weight")
+    for k, (x, w) in enumerate(zip(terms, step["weights"])):
+        t.terms[k], t.weights[k] = x.data_ptr(), float(w)
+    flags = step["flags"]
+    step["total"] = total = torch.empty((), device=terms[0].device)
+    t.n_terms, t.word_finite, t.total = len(terms), int(flags["word_finite"]), total.data_ptr()
+    t.bad, t.snapshot, t.n_bad = flags["bad"].data_ptr(), flags["snapshot"].data_ptr(), flags["bad"].numel()
+    if flags["snapshot"].numel() != flags["bad"].numel() or flags["bad"].dtype != torch.int32 or flags["snapshot"].dtype != torch.int32:
+        raise ValueError("spectral_norm_bwd(step=): int32 gate words and a snapshot of the same length")
+    steps = step.get("steps") or [None] * n
+    for i, (p, sq, st, o) in enumerate(zip(step["params"], step["square_avgs"], steps, outs)):
+        if not (p.is_contiguous() and sq.is_contiguous() and p.dtype == sq.dtype == torch.float32 and p.shape == o.shape == sq.shape):
+            raise _lib.TexposeLibraryError("spectral_norm_bwd(step=): contiguous float32 parameters shaped like their gradients")
+        t.param[i], t.square_avg[i] = p.data_ptr(), sq.data_ptr()
+        if st is not None:
+            if not (st.is_cuda and st.dtype == torch.float32):
+                raise _lib.TexposeLibraryError("spectral_norm_bwd(step=): step counters must be float32 device tensors")
+            t.step[i] = st.data_ptr()
+    lr = step["lr"]
+    t.lr_dev = lr.data_ptr() if isinstance(lr, torch.Tensor) else None
+    t.lr_host = 0.0 if isinstance(lr, torch.Tensor) else float(lr)
+    t.alpha, t.one_minus_alpha, t.eps = float(step["alpha"]), float(1.0 - float(step["alpha"])), float(step["eps"])
+    check(lib.tp_sn_bwd_step(arr, n, C.byref(t), _stream()), "tp_sn_bwd_step")
+    keep.append(terms)
     return outs
 
 

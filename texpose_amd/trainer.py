@@ -320,11 +320,16 @@ class GanTrainer:
                 loss.gan_reg_real = res.gan_reg_real
             loss.gan_disc_fake = res.gan_disc_fake
             keys = list(loss.keys())                               # (real, R1, fake: the order of the autograd form's total)
+            stepped = res.get("total") is not None                 # (total, gate and RMSprop rode in the schedule's last two launches)
             flags = self._disc_gate_flags()                        # (captured step: the gate update rides in the same launch)
-            total = ops.weighted_sum([loss[k] for k in keys], [w(k) for k in keys], flags=flags)
+            total = res.total if stepped else ops.weighted_sum([loss[k] for k in keys], [w(k) for k in keys], flags=flags)
             if res.gan_reg_real is not None:                       # logged WEIGHTED, as the reference does (:151-153)
                 loss.gan_reg_real = res.gan_reg_real_weighted
         self._disc_flagged = flags is not None
+        if stepped:
+            assert apply and flags is not None
+            self._disc_total = total
+            return var, loss
         if apply:
             self.disc_apply(None if flags is not None else total)
         else:
@@ -777,9 +782,37 @@ class GraphedGanTrainer(GanTrainer):
         return ctx
 
     def _seg_disc_b(self, var, ctx):
+        lw = self.opt.loss_weight
         with torch.no_grad():
-            res = ctx.sched.run_paired_b(ctx, 10 ** float(self.opt.loss_weight.gan_reg_real))
+            res = ctx.sched.run_paired_b(ctx, 10 ** float(lw.gan_reg_real), step=self._disc_step_tail(ctx.sched))
         return self._disc_step_scheduled_post(var, res, ctx.real, ctx.fake, True)
+
+    def _disc_step_tail(self, sched):
+        """The `step=` of disc_step.run_paired_b when the discriminator step may end inside the spectral-norm backward's two launches
+        (loss total + gate, RMSprop): one rank (no gradient reduction between gradient and step), the fused RMSprop with one plain group
+        over exactly the schedule's weights, the gate words on the device.  Else None: total, gate and step as launches of their own."""
+        flags, optim = self._disc_gate_flags(), self.optim_disc
+        if (flags is None or os.environ.get("TP_NO_DISC_STEP_TAIL") == "1" or not isinstance(optim, FusedRMSprop) or optim.gate is None
+                or self._has_collective() or (self.red_disc is not None and self.red_disc.world_size > 1) or len(optim.param_groups) != 1):
+            return None
+        group = optim.param_groups[0]
+        params = [c.weight_orig for c in sched.convs()]
+        others = [p for p in group["params"] if not any(p is q for q in params)]          # (`progress`: never a gradient)
+        if (group["momentum"] != 0 or group["centered"] or group["weight_decay"] != 0 or group["maximize"] or not group["capturable"]
+                or any(p.grad is not None for p in others) or not all(any(p is q for q in group["params"]) for p in params)
+                or optim.gate is not flags["snapshot"] or not all(p.is_contiguous() and p.dtype == torch.float32 for p in params)):
+            return None
+        for p in params:
+            st = optim.state[p]
+            if len(st) == 0:
+                st["step"] = torch.zeros((), dtype=torch.float32, device=p.device)
+                st["square_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            if not st["step"].is_cuda:
+                return None
+        lw = self.opt.loss_weight
+        return dict(w_real=10 ** float(lw.gan_disc_real), w_fake=10 ** float(lw.gan_disc_fake), flags=flags,
+                    square_avgs=[optim.state[p]["square_avg"] for p in params], steps=[optim.state[p]["step"] for p in params],
+                    lr=group["lr"], alpha=group["alpha"], eps=group["eps"])
 
     # ------------------------------------------------------------------ ... and as SIX LINEAR graphs on three streams
     # G2 above still forks inside the graph (the feature chain beside the discriminator's pass), and a replayed graph with a fork picks
