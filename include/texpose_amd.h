@@ -430,6 +430,12 @@ typedef struct tp_conv4s2_args {
   float* workspace;
   void* counters;
   int32_t N, C, H, W, Co;
+  /* dgrad, optional (in_gx != NULL; H = W = 8): the InstanceNorm + LeakyReLU backward of the ladder stage in FRONT of this convolution
+   * (tp_inorm_lrelu_bwd with gy = this data gradient: xhat [N,C,8,8], rstd [N*C], addend or NULL, gx = in_gx) inside the same launch,
+   * bit-identical to the two launches; skip_out != 0: the data gradient itself is not written (out may then be NULL... it is not read) */
+  int32_t skip_out;
+  const float* in_xhat; const float* in_rstd; const float* in_addend; float* in_gx;
+  float in_slope; int32_t pad_;
 } tp_conv4s2_args;
 #define TP_CONV_FWD 0
 #define TP_CONV_DGRAD 1

@@ -1365,6 +1365,35 @@ def test_disc_step_pairs_are_bit_identical_to_the_sequential_schedule(ops, monke
     assert torch.equal(ya, yb) and torch.equal(yc, ops.conv4s2_fwd_inorm(x * 2, w, 1e-5, 0.2)[0])
 
 
+@pytest.mark.parametrize("N", [1, 3, 4, 8])
+def test_conv4s2_dgrad_with_fused_inorm_backward_is_bit_identical(ops, N):
+    """tp_conv4s2_dgrad with in_gx set (the InstanceNorm + LeakyReLU backward of the stage in front of the convolution inside the data
+    gradient's launch) against the two launches, alone and as a pair, with and without the addend / the stored data gradient: every
+    output bit for bit (the epilogue runs K9's wavefront-per-instance code on the tile's totals)."""
+    torch.manual_seed(N)
+    C_in, Co, sl = 64, 128, 0.2
+    gy, gy2 = torch.randn(N, Co, 4, 4, device=dev()), torch.randn(N, Co, 4, 4, device=dev())
+    w, w2 = torch.randn(Co, C_in, 4, 4, device=dev()) * 0.05, torch.randn(Co, C_in, 4, 4, device=dev()) * 0.05
+    x = torch.randn(N, C_in, 8, 8, device=dev())
+    _, xhat, rstd = ops.inorm_lrelu_fwd(x, 1e-5, sl)
+    addend = torch.randn(N, C_in, 8, 8, device=dev())
+    assert ops.conv4s2_dgrad_inorm_supported(gy)
+    for ad in (None, addend):
+        ga = ops.conv4s2_dgrad(gy, w)
+        cz = ops.inorm_lrelu_bwd(xhat, rstd, ga, sl, addend=ad)
+        ga_f, cz_f = ops.conv4s2_dgrad(gy, w, inorm=dict(xhat=xhat, rstd=rstd, slope=sl, addend=ad))
+        assert torch.equal(ga, ga_f) and torch.equal(cz, cz_f)
+        none, cz_g = ops.conv4s2_dgrad(gy, w, inorm=dict(xhat=xhat, rstd=rstd, slope=sl, addend=ad, keep=False, out=torch.empty_like(cz)))
+        assert none is None and torch.equal(cz, cz_g)
+    cz2 = ops.inorm_lrelu_bwd(xhat, rstd, ops.conv4s2_dgrad(gy2, w2), sl)
+    with ops.paired():
+        _, pa = ops.conv4s2_dgrad(gy, w, inorm=dict(xhat=xhat, rstd=rstd, slope=sl, addend=addend, keep=False))
+        gb, pb = ops.conv4s2_dgrad(gy2, w2, inorm=dict(xhat=xhat, rstd=rstd, slope=sl))
+    assert torch.equal(pa, cz) and torch.equal(pb, cz2) and torch.equal(gb, ops.conv4s2_dgrad(gy2, w2))
+    with pytest.raises(Exception):
+        ops.conv4s2_dgrad(torch.randn(N, Co, 8, 8, device=dev()), w, inorm=dict(xhat=xhat, rstd=rstd, slope=sl))
+
+
 def test_disc_step_tail_in_the_sn_backward_is_bit_identical(ops, monkeypatch):
     """tp_sn_bwd_step: the discriminator step's loss total + gate and its RMSprop update inside the spectral-norm backward's two launches
     (trainer._disc_step_tail) against the same captured trainer with them as launches of their own (TP_NO_DISC_STEP_TAIL=1): after six

@@ -23,6 +23,9 @@ struct ConvP {
   int lp;              // log2(OH * OW)
   int S;               // workgroups per tile
   int tiles_n;         // column tiles
+  // D, optional (in_gx != NULL): the InstanceNorm + LeakyReLU backward of the stage in front of this convolution on the data gradient
+  // (8x8 maps), csrc/patch_conv.hip conv4s2_dgrad_kernel<true>
+  const float* in_xhat; const float* in_rstd; const float* in_addend; float* in_gx; float in_slope; int skip_out;
 };
 
 // Sum NT accumulator tiles over the 4 wavefronts of the workgroup and over the S workgroups of the tile.  True in the one

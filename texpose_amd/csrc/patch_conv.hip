@@ -195,8 +195,14 @@ __global__ __launch_bounds__(256) void conv4s2_fwd_in_kernel(ConvP pa, InP qa, C
 }
 
 // ---------------------------------------------------------------------------------------------------------------- D
+// IN: a problem with in_gx set also applies the InstanceNorm + LeakyReLU backward of the stage in front of the convolution (K9
+// inorm_lrelu_bwd_kernel) to its data gradient: with 4x4 output maps a tile of 32 positions x 32 channels IS 64 complete 8x8 instances, so
+// the workgroup that holds the tile's totals lays them out [instance][65] in LDS and runs K9's wavefront-per-instance code on them (lane =
+// element, the same butterfly sums: the same bits as the two launches) -- one launch less on the chain that bounds the B=4 iteration.
+constexpr int kDgInLds = 64 * 65;
+template <bool IN>
 __global__ __launch_bounds__(256) void conv4s2_dgrad_kernel(ConvP pa, ConvP pb, int na) {       // (two problems: see conv4s2_fwd_in_kernel)
-  __shared__ float lds[kReduceLdsFloats];
+  __shared__ float lds[IN && kDgInLds > kReduceLdsFloats ? kDgInLds : kReduceLdsFloats];
   const bool second = na >= 0 && (int)blockIdx.x >= na;
   const ConvP& p = second ? pb : pa;
   const int bid = (int)blockIdx.x - (second ? na : 0);
@@ -262,13 +268,59 @@ __global__ __launch_bounds__(256) void conv4s2_dgrad_kernel(ConvP pa, ConvP pb, 
   if (!reduce_tiles<4>(acc, out, lds, p, tile, s)) return;
   // thread: positions (a, b..b+3) of one image, channel ci -> pixels (2a+py, 2b .. 2b+7)
   const int m0 = mt * 32 + 8 * w + 4 * h, oc = nt * 32 + col;
-  if (m0 < M && oc < p.C) {
+  if (m0 < M && oc < p.C && !(IN && p.skip_out)) {
     const int n0 = m0 >> p.lp, p0 = m0 & (P - 1), a = p0 >> p.low, b = p0 & (p.OW - 1);
 #pragma unroll
     for (int py = 0; py < 2; ++py) {
       float* dst = p.out + (((size_t)n0 * p.C + oc) * p.H + 2 * a + py) * p.W + 2 * b;
       *reinterpret_cast<f32x4*>(dst) = f32x4{out[py * 2][0], out[py * 2 + 1][0], out[py * 2][1], out[py * 2 + 1][1]};
       *reinterpret_cast<f32x4*>(dst + 4) = f32x4{out[py * 2][2], out[py * 2 + 1][2], out[py * 2][3], out[py * 2 + 1][3]};
+    }
+  }
+  if (IN && p.in_gx != nullptr) {                    // (host: OH = OW = 4, so P = 16, a tile = images 2 mt, 2 mt + 1, b = 0)
+    // wave w takes instances 16 w .. 16 w + 15 of the tile (instance il = image (il >> 5) of the tile, channel il & 31), lane = element:
+    // ALL their operands are requested before anything else (a loop with the loads inside paid one memory latency per instance: the
+    // workgroup that finishes the tile took 25 us longer and the B=4 iteration ran 4 % SLOWER than with two launches)
+    float hh[16], ad[16], rs[16];
+    size_t at[16];
+    bool live[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int il = w * 16 + k, n = 2 * mt + (il >> 5), c = nt * 32 + (il & 31);
+      live[k] = n < p.N && c < p.C;                  // (wave-uniform)
+      at[k] = ((size_t)min(n, p.N - 1) * p.C + min(c, p.C - 1)) * 64 + lane;
+      hh[k] = p.in_xhat[at[k]];
+      rs[k] = p.in_rstd[at[k] >> 6];
+      ad[k] = p.in_addend ? p.in_addend[at[k]] : 0.f;
+    }
+    __syncthreads();                                 // (reduce_tiles' LDS reads are done)
+    const int im = w >> 1, a = 2 * (w & 1) + h;
+    float* tl = lds + (im * 32 + col) * 65;
+#pragma unroll
+    for (int py = 0; py < 2; ++py)
+#pragma unroll
+      for (int px = 0; px < 2; ++px)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) tl[(2 * a + py) * 8 + 2 * i + px] = out[py * 2 + px][i];
+    __syncthreads();
+    float av[16], sa[16], sah[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const float g = lds[(w * 16 + k) * 65 + lane];
+      av[k] = g * (hh[k] > 0.f ? 1.0f : p.in_slope);
+      sa[k] = 0.f; sah[k] = 0.f;
+      sa[k] += av[k];
+      sah[k] += av[k] * hh[k];
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1)
+#pragma unroll
+      for (int k = 0; k < 16; ++k) { sa[k] += __shfl_xor(sa[k], o, 64); sah[k] += __shfl_xor(sah[k], o, 64); }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const float ma = sa[k] / 64.f, mah = sah[k] / 64.f;
+      const float v = rs[k] * (av[k] - ma - hh[k] * mah);
+      if (live[k]) p.in_gx[at[k]] = p.in_addend ? v + ad[k] : v;
     }
   }
 }
@@ -444,6 +496,12 @@ static int conv_fill(const tp_conv4s2_args* a, int op, Plan* q, ConvP* p) {
   TP_REQUIRE(a->out && a->counters && (!q->ws_floats || a->workspace), "out / counters / workspace missing");
   TP_REQUIRE((op == 1 || a->x) && (op == 2 || a->w) && (op == 0 || a->gy), "operand missing");
   p->x = a->x; p->w = a->w; p->gy = a->gy; p->out = a->out; p->ws = a->workspace; p->cnt = (unsigned*)a->counters;
+  p->in_xhat = a->in_xhat; p->in_rstd = a->in_rstd; p->in_addend = a->in_addend; p->in_gx = a->in_gx; p->in_slope = a->in_slope; p->skip_out = a->skip_out;
+  if (a->in_gx != nullptr) {
+    TP_REQUIRE(op == 1 && a->in_xhat && a->in_rstd && a->H == 8 && a->W == 8, "the fused InstanceNorm backward: data gradient onto 8x8 maps, xhat and rstd given");
+  } else {
+    TP_REQUIRE(!a->skip_out, "skip_out without the fused InstanceNorm backward");
+  }
   return 0;
 }
 // one problem (b == nullptr) or two in one launch (different counters / workspaces: they run side by side)
@@ -464,7 +522,8 @@ static int conv_launch(const tp_conv4s2_args* a, const tp_conv4s2_args* b, int o
   const dim3 grid(ga + gb), block(256);
   hipStream_t st = (hipStream_t)stream;
   if (op == 0) hipLaunchKernelGGL(conv4s2_fwd_kernel, grid, block, 0, st, pa);
-  else if (op == 1) hipLaunchKernelGGL(conv4s2_dgrad_kernel, grid, block, 0, st, pa, pb, na);
+  else if (op == 1 && (pa.in_gx || pb.in_gx)) hipLaunchKernelGGL(conv4s2_dgrad_kernel<true>, grid, block, 0, st, pa, pb, na);
+  else if (op == 1) hipLaunchKernelGGL(conv4s2_dgrad_kernel<false>, grid, block, 0, st, pa, pb, na);
   else hipLaunchKernelGGL(conv4s2_wgrad_kernel, grid, block, 0, st, pa, pb, na);
   return tp::check_launch(op == 0 ? "tp_conv4s2_fwd" : op == 1 ? "tp_conv4s2_dgrad" : "tp_conv4s2_wgrad");
 }

@@ -251,6 +251,10 @@ class DiscStepSchedule:
                               want_c_a=False, inorm=dict(xhat=last.xhat, rstd=last.rstd))
         c_z = r["c_z"]
         for l in range(K - 1, -1, -1):
+            if l > 0 and ops.conv4s2_dgrad_inorm_supported(c_z):        # (the InstanceNorm backward of stage l - 1 in the same launch)
+                st = f.stages[l - 1]
+                _, c_z = ops.conv4s2_dgrad(c_z, W[l], inorm=dict(xhat=st.xhat, rstd=st.rstd, slope=sl, keep=False))
+                continue
             c_a = ops.conv4s2_dgrad(c_z, W[l])
             if l > 0:
                 st = f.stages[l - 1]
@@ -318,11 +322,17 @@ class DiscStepSchedule:
         r = ops.disc_tail_bwd(ones, t0, t1, t2, W0, *Wh, L, sl, want_gW0=False, head_weight_grads=False, want_e=True, gz_out=gs[K][B:],
                               inorm=dict(xhat=last.xhat, rstd=last.rstd, out=gs[K - 1][B:]))
         e1, e2, ga, ga_in, gz_last = r["e1"], r["e2"], r["c_a"].view_as(f.a_full), [None] * K, r["c_z"]
+        gz_next = None                       # (the InstanceNorm backward of stage l, formed by the data-gradient launch of stage l + 1)
         for l in range(K - 1, -1, -1):
             st = f.stages[l]
             ga_in[l] = ga
-            gz = gz_last if l == K - 1 else ops.inorm_lrelu_bwd(st.xhat, st.rstd, ga, sl, out=gs[l][B:])
-            ga = ops.conv4s2_dgrad(gz, W[l])
+            gz = gz_last if l == K - 1 else gz_next if gz_next is not None else ops.inorm_lrelu_bwd(st.xhat, st.rstd, ga, sl, out=gs[l][B:])
+            gz_next = None
+            if l > 0 and ops.conv4s2_dgrad_inorm_supported(gz):
+                prev = f.stages[l - 1]
+                ga, gz_next = ops.conv4s2_dgrad(gz, W[l], inorm=dict(xhat=prev.xhat, rstd=prev.rstd, slope=sl, out=gs[l - 1][B:]))
+            else:
+                ga = ops.conv4s2_dgrad(gz, W[l])
         r1, c = ops.sumsq_mean_fwd_bwd(ga, w_reg, out_g=xs[0][B:])
         c_zr = [None] * K
         for l in range(K):
@@ -346,16 +356,25 @@ class DiscStepSchedule:
         gwr, gwf = [None] * (K + 1), [None] * (K + 1)
         gwr[K], gwf[K] = rr["gW0"], rf["gW0"]
         czr, czf, car, caf = rr["c_z"], rf["c_z"], None, None
+        fused_next = False                   # (stage l's InstanceNorm backward came out of stage l + 1's data-gradient pair)
         for l in range(K - 1, -1, -1):
             sr, sf = fr.stages[l], ff.stages[l]
-            if l < K - 1:
+            if l < K - 1 and not fused_next:
                 with ops.paired():
                     czr = ops.inorm_lrelu_bwd(sr.xhat, sr.rstd, car, sl, addend=c_zr[l], out=gs[l][:B])
                     czf = ops.inorm_lrelu_bwd(sf.xhat, sf.rstd, caf, sl)
+            fused_next = False
             with ops.paired():
                 gwr[l] = ops.conv4s2_wgrad(gs[l], xs[l])
                 gwf[l] = ops.conv4s2_wgrad(czf, sf.x)
-            if l > 0:
+            if l > 0 and ops.conv4s2_dgrad_inorm_supported(czr):
+                pr, pf = fr.stages[l - 1], ff.stages[l - 1]
+                with ops.paired():
+                    _, czr = ops.conv4s2_dgrad(czr, Wr[l], inorm=dict(xhat=pr.xhat, rstd=pr.rstd, slope=sl, addend=c_zr[l - 1], out=gs[l - 1][:B],
+                                                                      keep=False))
+                    _, czf = ops.conv4s2_dgrad(czf, Wf[l], inorm=dict(xhat=pf.xhat, rstd=pf.rstd, slope=sl, keep=False))
+                fused_next = True
+            elif l > 0:
                 with ops.paired():
                     car = ops.conv4s2_dgrad(czr, Wr[l])
                     caf = ops.conv4s2_dgrad(czf, Wf[l])

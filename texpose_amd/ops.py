@@ -992,7 +992,7 @@ def _conv_scratch(lib, ws_fn, a, op: int, dev):
     return (torch.empty(int(ws_floats), device=dev) if ws_floats else None), cnt
 
 
-def _conv4s2(op: int, name: str, x, w, gy, out, N, C_in, H, W, Co):
+def _conv4s2(op: int, name: str, x, w, gy, out, N, C_in, H, W, Co, inorm=None):
     lib = _lib.load()
     a = _lib.Conv4s2Args()
     a.N, a.C, a.H, a.W, a.Co = int(N), int(C_in), int(H), int(W), int(Co)
@@ -1000,6 +1000,10 @@ def _conv4s2(op: int, name: str, x, w, gy, out, N, C_in, H, W, Co):
     a.x, a.w, a.gy = _ptr(x), _ptr(w), _ptr(gy)
     a.out, a.counters, a.workspace = out.data_ptr(), cnt.data_ptr(), _ptr(ws)
     a._keep = (x, w, gy, out, ws, cnt)                # (a held-back first problem of a pair keeps its tensors alive)
+    if inorm is not None:                             # (xhat, rstd, addend or None, gx, slope, skip_out)
+        a.in_xhat, a.in_rstd, a.in_addend, a.in_gx = inorm[0].data_ptr(), inorm[1].data_ptr(), _ptr(inorm[2]), inorm[3].data_ptr()
+        a.in_slope, a.skip_out = float(inorm[4]), int(bool(inorm[5]))
+        a._keep = a._keep + tuple(inorm[:4])
     if name in PAIRABLE:
         _launch(name, a)
     else:
@@ -1042,13 +1046,32 @@ def conv4s2_fwd_inorm(x: Tensor, w: Tensor, eps: float, slope: float, y_out: Opt
     return y, xhat, rstd
 
 
+def conv4s2_dgrad_inorm_supported(gy: Tensor) -> bool:
+    """The data gradient can carry the InstanceNorm + LeakyReLU backward of the stage in front of it: 8x8 input maps (whole instances
+    per workgroup)."""
+    return gy.is_cuda and gy.dim() == 4 and tuple(gy.shape[-2:]) == (4, 4) and os.environ.get("TP_NO_DGRAD_INORM") != "1"
+
+
 @_on_tensor_device
-def conv4s2_dgrad(gy: Tensor, w: Tensor, out: Optional[Tensor] = None) -> Tensor:
-    """gradient of conv4s2_fwd wrt x: gy [N,Co,H/2,W/2], w [Co,C,4,4] -> [N,C,H,W]."""
+def conv4s2_dgrad(gy: Tensor, w: Tensor, out: Optional[Tensor] = None, inorm=None):
+    """gradient of conv4s2_fwd wrt x: gy [N,Co,H/2,W/2], w [Co,C,4,4] -> [N,C,H,W].
+    ``inorm`` = dict(xhat [N,C,8,8], rstd [N*C], slope, addend=None, out=None, keep=True) (conv4s2_dgrad_inorm_supported): the
+    InstanceNorm + LeakyReLU backward of the stage in front of the convolution in the same launch -- returns (data gradient or None if
+    not ``keep``, inorm_lrelu_bwd(xhat, rstd, data gradient, slope, addend, out)), bit-identical to the two launches."""
     gy, w = _f32(gy, "gy"), _f32(w, "w")
     N, Co, OH, OW = gy.shape
     gx = _out_like(out, gy, (N, w.shape[1], 2 * OH, 2 * OW))
-    return _conv4s2(_lib.CONV_DGRAD, "tp_conv4s2_dgrad", None, w, gy, gx, N, w.shape[1], 2 * OH, 2 * OW, Co)
+    if inorm is None:
+        return _conv4s2(_lib.CONV_DGRAD, "tp_conv4s2_dgrad", None, w, gy, gx, N, w.shape[1], 2 * OH, 2 * OW, Co)
+    xhat, rstd = _f32(inorm["xhat"], "xhat"), _f32(inorm["rstd"], "rstd")
+    if tuple(xhat.shape) != (N, w.shape[1], 8, 8) or (OH, OW) != (4, 4) or rstd.numel() != N * w.shape[1]:
+        raise ValueError("conv4s2_dgrad(inorm=): xhat [N,C,8,8] / rstd [N*C] of the stage in front of the convolution expected")
+    addend = _f32(inorm["addend"], "addend") if inorm.get("addend") is not None else None
+    cz = _out_like(inorm.get("out"), xhat)
+    keep = bool(inorm.get("keep", True))
+    _conv4s2(_lib.CONV_DGRAD, "tp_conv4s2_dgrad", None, w, gy, gx, N, w.shape[1], 2 * OH, 2 * OW, Co,
+             inorm=(xhat, rstd, addend, cz, inorm["slope"], not keep))
+    return (gx if keep else None), cz
 
 
 @_on_tensor_device
