@@ -73,8 +73,8 @@ __global__ __launch_bounds__(256) void sn_wtu_kernel(Batch b, int set) {
   const int c = cb * 256 + threadIdx.x;
   if (c >= w.cols) return;
   float acc = 0.0f;
-#pragma unroll 8
-  for (int r = 0; r < nr; ++r) acc = fmaf(w.weight[(int64_t)(r0 + r) * w.cols + c], us[r], acc);   // 8 loads in flight
+#pragma unroll 32
+  for (int r = 0; r < nr; ++r) acc = fmaf(w.weight[(int64_t)(r0 + r) * w.cols + c], us[r], acc);   // 32 loads in flight (8: 4 more round trips)
   w.work[(int64_t)slab * w.cols + c] = acc;
 }
 
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void sn_wv_kernel(Batch b, int training, int s
     float ss = 0.0f;
     if (vec) {
       const int c4n = w.cols >> 2;
-#pragma unroll 2
+#pragma unroll 4
       for (int c4 = t; c4 < c4n; c4 += 256) {
         f32x4 part[TP_SN_MAX_SLABS];
 #pragma unroll
@@ -141,8 +141,8 @@ __global__ __launch_bounds__(256) void sn_wv_kernel(Batch b, int training, int s
   if (vec) {
     const f32x4* row4 = reinterpret_cast<const f32x4*>(row);
     const f32x4* v4 = reinterpret_cast<const f32x4*>(vs);
-#pragma unroll 8
-    for (int c4 = lane; c4 < (w.cols >> 2); c4 += 64) {                        // 8 x 16-byte loads in flight
+#pragma unroll 16
+    for (int c4 = lane; c4 < (w.cols >> 2); c4 += 64) {                        // 16 x 16-byte loads in flight
       const f32x4 a = row4[c4], v = v4[c4];
       acc = fmaf(a[3], v[3], fmaf(a[2], v[2], fmaf(a[1], v[1], fmaf(a[0], v[0], acc))));
     }
