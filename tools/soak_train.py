@@ -14,12 +14,15 @@ opt = default_options(H=128, W=128, device="cuda:0")
 opt.batch_size, opt.patch_size, opt.nerf.sample_intvs = 4, 16, 64
 graph = Graph(opt, discriminator=Discriminator(opt), perceptual_loss=PerceptualLoss()).to("cuda:0")
 tr = GraphedGanTrainer(opt, graph, n_train=189)
+if os.environ.get("TP_SOAK_STRICT") != "1":               # (the benchmark loops' configuration; results are read behind wait_all())
+    tr.pipeline_disc_tail = tr.defer_results = True
 var = training_batch(4, 128, 128, device="cuda:0")
 hist = []
 N_IT = int(sys.argv[1]) if len(sys.argv) > 1 else 600
 for it in range(N_IT):
     _, loss = tr.train_iteration(AttrDict(dict(var)))
     if it % max(1, N_IT // 6) == 0 or it == N_IT - 1:
+        tr.wait_all()
         hist.append({k: round(float(v), 5) for k, v in loss.items()})
         print(it, hist[-1], flush=True)
 tr.flush_flags()                                          # (the last replay's gate words: a withheld final step raises here)
@@ -30,4 +33,13 @@ assert all(all(abs(v) < 1e6 for v in h.values()) for h in hist)      # (random-n
 assert tr.skipped_steps == 0 and not graph.discriminator._sn_queue
 counter = int(tr._rng_counter) if getattr(tr, "_rng_counter", None) is not None else None
 assert counter is None or counter >= N_IT, counter            # (+ the warm-up iterations of the capture)
+import hashlib
+h = hashlib.sha256()
+for k in sorted(sd):
+    h.update(k.encode() + sd[k].detach().cpu().contiguous().numpy().tobytes())
+for st in list(tr.optim_disc.state.values()) + list(tr.optim_nerf.state.values()):
+    for k in sorted(st):
+        if torch.is_tensor(st[k]):
+            h.update(st[k].detach().cpu().contiguous().numpy().tobytes())
+print("state sha256 (parameters, buffers, optimiser state):", h.hexdigest()[:32], "deferred / pipelined:", tr._defers_results(), tr._pipelined())
 print("soak ok; step counter", counter, "patch sampler iterations", graph.patch_sampler.iterations, "progress", float(graph.discriminator.progress))
