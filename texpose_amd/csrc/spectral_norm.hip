@@ -36,15 +36,15 @@ __device__ __forceinline__ int find_weight(const Batch& b, int blk, int& local) 
   return i;
 }
 
+// sum over the 256 threads of the workgroup, the same value (same order of additions) in every thread: a butterfly inside each wavefront,
+// then the four wavefront sums in wavefront order -- 2 barriers (rounds 1-4: an LDS tree with 9; the six sums at the top of every
+// sn_scale_sets workgroup were a third of that launch)
 __device__ __forceinline__ float block_sum(float v, float* red) {
-  const int tid = threadIdx.x;
-  red[tid] = v;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
   __syncthreads();
-  for (int s = blockDim.x >> 1; s > 0; s >>= 1) {
-    if (tid < s) red[tid] += red[tid + s];
-    __syncthreads();
-  }
-  const float r = red[0];
+  const float r = ((red[0] + red[1]) + red[2]) + red[3];
   __syncthreads();
   return r;
 }
@@ -221,7 +221,28 @@ __global__ __launch_bounds__(256) void sn_scale_sets_kernel(Batch b, SetOuts o, 
     }
   }
   const int64_t n = (int64_t)w.rows * w.cols;
-  for (int64_t i = (int64_t)local * kScaleElems + threadIdx.x; i < min(n, (int64_t)(local + 1) * kScaleElems); i += 256) {
+  const int64_t i0 = (int64_t)local * kScaleElems, i1 = min(n, i0 + kScaleElems);
+  bool vec = (i1 - i0) == kScaleElems && ((uintptr_t)w.weight & 15) == 0;
+#pragma unroll
+  for (int k = 0; k < TP_SN_MAX_SETS; ++k)
+    if (k < n_sets) vec = vec && ((uintptr_t)o.weight_sn[k][wi] & 15) == 0;
+  if (vec) {                                       // 16-byte accesses, the block's four loads in flight together
+    f32x4 wv[kScaleElems / 1024];
+#pragma unroll
+    for (int j = 0; j < kScaleElems / 1024; ++j) wv[j] = reinterpret_cast<const f32x4*>(w.weight + i0)[j * 256 + threadIdx.x];
+#pragma unroll
+    for (int k = 0; k < TP_SN_MAX_SETS; ++k)
+      if (k < n_sets)
+#pragma unroll
+        for (int j = 0; j < kScaleElems / 1024; ++j) {
+          f32x4 q;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) q[e] = wv[j][e] / sg[k];
+          reinterpret_cast<f32x4*>(o.weight_sn[k][wi] + i0)[j * 256 + threadIdx.x] = q;
+        }
+    return;
+  }
+  for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
     const float wv = w.weight[i];
 #pragma unroll
     for (int k = 0; k < TP_SN_MAX_SETS; ++k)
