@@ -258,7 +258,7 @@ struct StepTail {
 struct RmsTail {
   float* p[kMaxW]; float* sq[kMaxW]; float* step[kMaxW];            // E: RMSprop on the element just formed (on == 1)
   const float* lr_dev; float lr_host, alpha, one_minus_alpha, eps;
-  const int* gate; int n_gate, on;
+  const int* gate; int n_gate, on, elems;
 };
 
 // D: per-workgroup partial of <G, W_sn> (and of the second instance's <G2, W_sn2>)
@@ -289,6 +289,7 @@ __global__ __launch_bounds__(256) void sn_dot_kernel(Batch b, StepTail st) {
 }
 
 // E: dW = (G - <G, W_sn> u v^T) / sigma  (+ the same of the second instance)
+constexpr int kGradElems = 1024;      // (TP_SN_GRAD_ELEMS: 2048 the same, 4096 / 8192 slower -- D2b alone 209 / 215 us, profiles/r5)
 __global__ __launch_bounds__(256) void sn_grad_kernel(Batch b, RmsTail rt) {
   __shared__ float red[256];
   int local;
@@ -305,7 +306,8 @@ __global__ __launch_bounds__(256) void sn_grad_kernel(Batch b, RmsTail rt) {
   d = block_sum(d, red);
   if (w.grad_sn2) d2 = block_sum(d2, red);
   const float sg = *w.sigma, sg2 = w.grad_sn2 ? *w.sigma2 : 1.0f;
-  for (int64_t i = (int64_t)local * 1024 + threadIdx.x; i < min(n, (int64_t)(local + 1) * 1024); i += 256) {
+#pragma unroll 4
+  for (int64_t i = (int64_t)local * rt.elems + threadIdx.x; i < min(n, (int64_t)(local + 1) * rt.elems); i += 256) {
     const int r = (int)(i / w.cols), c = (int)(i - (int64_t)r * w.cols);
     float gv = (w.grad_sn[i] - d * w.u[r] * w.v[c]) / sg;
     if (w.grad_sn2) gv = gv + (w.grad_sn2[i] - d2 * w.u2[r] * w.v2[c]) / sg2;
@@ -411,8 +413,13 @@ int sn_bwd_launch(const tp_sn_weight* ws, int n, const StepTail& tl, const RmsTa
   Batch b;
   int g = fill(b, ws, n, [](const tp_sn_weight& w) { return (int)(((int64_t)w.rows * w.cols + 4095) / 4096); });
   hipLaunchKernelGGL(sn_dot_kernel, dim3(g), dim3(256), 0, st, b, tl);
-  g = fill(b, ws, n, [](const tp_sn_weight& w) { return (int)(((int64_t)w.rows * w.cols + 1023) / 1024); });
-  hipLaunchKernelGGL(sn_grad_kernel, dim3(g), dim3(256), 0, st, b, rt);
+  static const int elems = [] { const char* e = getenv("TP_SN_GRAD_ELEMS"); const int v = e ? atoi(e) : 0; return v >= 256 ? v : kGradElems; }();
+  RmsTail r2 = rt;
+  r2.elems = elems;
+  b.n = n; b.blk_a[0] = 0;
+  for (int i = 0; i < n; ++i) { b.w[i] = ws[i]; b.blk_a[i + 1] = b.blk_a[i] + (int)(((int64_t)ws[i].rows * ws[i].cols + elems - 1) / elems); }
+  g = b.blk_a[n];
+  hipLaunchKernelGGL(sn_grad_kernel, dim3(g), dim3(256), 0, st, b, r2);
   return tp::check_launch(what);
 }
 }  // namespace
