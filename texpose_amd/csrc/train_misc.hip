@@ -15,6 +15,22 @@
 namespace {
 constexpr int kBlock = 256;
 
+// sum over the B threads of the workgroup (the same value in every thread): a butterfly inside each wavefront, then the wavefront sums in
+// wavefront order -- 2 barriers instead of the 9-11 of an LDS tree (these one-workgroup kernels sit on the chain that bounds the B=4
+// training iteration).  `red`: >= B / 64 floats.
+template <int B>
+__device__ __forceinline__ float block_total(float v, float* red) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float r = red[0];
+#pragma unroll
+  for (int i = 1; i < B / 64; ++i) r += red[i];
+  __syncthreads();
+  return r;
+}
+
 // ---- patch coordinates: s = u0 * (hi - lo) + lo;  x = lattice_j * s + (u1 * 2 - 1) * (1 - s);  y likewise with u2
 // u == NULL: the three uniforms of image b are drawn here, Philox4x32-10 with key = seed and counter (b, c_lo, 'patc', c_hi),
 // c = *counter (the step counter of a captured training step) -- words x, y, z -> scale, x shift, y shift.
@@ -56,13 +72,8 @@ __global__ __launch_bounds__(kBlock) void bce_logits_fwd_kernel(const float* __r
     const float ls = fminf(v, 0.f) - log1pf(expf(-fabsf(v)));      // log_sigmoid
     acc += (1.f - target) * v - ls;
   }
-  red[threadIdx.x] = acc;
-  __syncthreads();
-  for (int s = kBlock >> 1; s > 0; s >>= 1) {
-    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) out[0] = red[0] / (float)n;
+  const float tot = block_total<kBlock>(acc, red);
+  if (threadIdx.x == 0) out[0] = tot / (float)n;
 }
 __global__ __launch_bounds__(kBlock) void bce_logits_bwd_kernel(const float* __restrict__ x, int n, float target, const float* __restrict__ g,
                                                                  float* __restrict__ gx) {
@@ -280,13 +291,8 @@ __global__ __launch_bounds__(kRedBlock) void sumsq_mean_fwd_kernel(const float* 
   __shared__ float red[kRedBlock];
   float a = 0.f;
   for (int64_t i = threadIdx.x; i < n; i += kRedBlock) a += g[i] * g[i];
-  red[threadIdx.x] = a;
-  __syncthreads();
-  for (int s = kRedBlock >> 1; s > 0; s >>= 1) {
-    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) out[0] = red[0] / (float)B;
+  const float tot = block_total<kRedBlock>(a, red);
+  if (threadIdx.x == 0) out[0] = tot / (float)B;
 }
 __global__ __launch_bounds__(kBlock) void sumsq_mean_bwd_kernel(const float* __restrict__ g, int64_t n, int B, const float* __restrict__ cot,
                                                                  float* __restrict__ out) {
@@ -338,13 +344,8 @@ __global__ __launch_bounds__(kRedBlock) void sumsq_mean_fwd_bwd_kernel(const flo
   __shared__ float red[kRedBlock];
   float a = 0.f;
   for (int64_t i = threadIdx.x; i < n; i += kRedBlock) a += g[i] * g[i];
-  red[threadIdx.x] = a;
-  __syncthreads();
-  for (int s = kRedBlock >> 1; s > 0; s >>= 1) {
-    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) { out[0] = red[0] / (float)B; out[1] = w * out[0]; }      // (the reference logs the WEIGHTED penalty, :151-153)
+  const float tot = block_total<kRedBlock>(a, red);
+  if (threadIdx.x == 0) { out[0] = tot / (float)B; out[1] = w * out[0]; }      // (the reference logs the WEIGHTED penalty, :151-153)
 }
 
 // ---- both GAN-loss terms of the discriminator step (model/nerf_adapt_st_gan.py:139-160) and their weighted cotangents in one
@@ -366,14 +367,8 @@ __global__ __launch_bounds__(kBlock) void gan_disc_losses_kernel(const float* __
       const float sg = 1.f / (1.f + expf(-v));
       gx[i] = (sg - target) * w / (float)n;
     }
-    red[threadIdx.x] = acc;
-    __syncthreads();
-    for (int s = kBlock >> 1; s > 0; s >>= 1) {
-      if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
-      __syncthreads();
-    }
-    if (threadIdx.x == 0) out2[term] = red[0] / (float)n;
-    __syncthreads();
+    const float tot = block_total<kBlock>(acc, red);
+    if (threadIdx.x == 0) out2[term] = tot / (float)n;
   }
 }
 
