@@ -436,6 +436,8 @@ typedef struct tp_conv4s2_args {
   int32_t skip_out;
   const float* in_xhat; const float* in_rstd; const float* in_addend; float* in_gx;
   float in_slope; int32_t pad_;
+  /* tp_conv4s2_fwd_inorm[_pair], optional: the launch also copies x to x_copy (16-byte aligned, N C H W a multiple of 4) */
+  float* x_copy;
 } tp_conv4s2_args;
 #define TP_CONV_FWD 0
 #define TP_CONV_DGRAD 1

@@ -44,7 +44,7 @@ def test_struct_sizes_match_header():
     assert C.sizeof(_lib.SnStepTail) == 4 * 8 + 4 * 4 + 2 * 4 + 3 * 8 + 2 * 4 + 3 * 8 * 8 + 8 + 4 * 4
     assert C.sizeof(_lib.RmspropTensor) == 5 * 8
     assert C.sizeof(_lib.NerfLossesArgs) == 4 * 8 + 3 * 4 + 4 + 4 * 8
-    assert C.sizeof(_lib.Conv4s2Args) == 6 * 8 + 6 * 4 + 4 * 8 + 2 * 4        # (+ the fused InstanceNorm backward of the data gradient)
+    assert C.sizeof(_lib.Conv4s2Args) == 6 * 8 + 6 * 4 + 4 * 8 + 2 * 4 + 8    # (+ the fused InstanceNorm backward of the data gradient, x_copy)
     assert C.sizeof(_lib.Conv3s1Args) == 7 * 8 + 6 * 4
     assert C.sizeof(_lib.FeatInputsArgs) == 2 * 8 + 7 * 4 + 6 * 4 + 4
     assert C.sizeof(_lib.FeatChainArgs) == 2 * 8 + 8 * 4 + 6 * 4 + 8 * 8 + 2 * 4 + 6 * 8

@@ -171,7 +171,7 @@ class Conv3s1Args(C.Structure):
 class Conv4s2Args(C.Structure):
     _fields_ = [("x", vp), ("w", vp), ("gy", vp), ("out", vp), ("workspace", vp), ("counters", vp),
                 ("N", C.c_int32), ("C", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Co", C.c_int32), ("skip_out", C.c_int32),
-                ("in_xhat", vp), ("in_rstd", vp), ("in_addend", vp), ("in_gx", vp), ("in_slope", C.c_float), ("pad_", C.c_int32)]
+                ("in_xhat", vp), ("in_rstd", vp), ("in_addend", vp), ("in_gx", vp), ("in_slope", C.c_float), ("pad_", C.c_int32), ("x_copy", vp)]
 
 
 class NerfLossesArgs(C.Structure):

@@ -26,6 +26,9 @@ struct ConvP {
   // D, optional (in_gx != NULL): the InstanceNorm + LeakyReLU backward of the stage in front of this convolution on the data gradient
   // (8x8 maps), csrc/patch_conv.hip conv4s2_dgrad_kernel<true>
   const float* in_xhat; const float* in_rstd; const float* in_addend; float* in_gx; float in_slope; int skip_out;
+  // F + InstanceNorm, optional (x_copy != NULL): the launch also leaves a copy of its input x there (the workgroups share the work) --
+  // the discriminator step's private copy of the render's patch stacks without a launch of its own
+  float* x_copy;
 };
 
 // Sum NT accumulator tiles over the 4 wavefronts of the workgroup and over the S workgroups of the tile.  True in the one

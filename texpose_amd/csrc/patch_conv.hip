@@ -103,6 +103,10 @@ __global__ __launch_bounds__(256) void conv4s2_fwd_in_kernel(ConvP pa, InP qa, C
   const int t = threadIdx.x, w = t >> 6, lane = t & 63, col = lane & 31, h = lane >> 5;
   const int s = bid % p.S, tile = bid / p.S, nt = tile % p.tiles_n, mt = tile / p.tiles_n;
   const int P = 1 << p.lp, M = p.N << p.lp, HW = p.H * p.W;
+  if (p.x_copy != nullptr) {                         // (side job: this problem's input, 16 bytes per thread and step; host: a multiple of 4 floats)
+    const int n4 = (p.N * p.C * HW) >> 2, wgs = (second ? (int)gridDim.x - na : (na >= 0 ? na : (int)gridDim.x));
+    for (int i = bid * 256 + t; i < n4; i += wgs * 256) reinterpret_cast<f32x4*>(p.x_copy)[i] = reinterpret_cast<const f32x4*>(p.x)[i];
+  }
   int off[NT][8];
   bool ok[NT][8];
   const float* xa[NT];
@@ -496,6 +500,7 @@ static int conv_fill(const tp_conv4s2_args* a, int op, Plan* q, ConvP* p) {
   TP_REQUIRE(a->out && a->counters && (!q->ws_floats || a->workspace), "out / counters / workspace missing");
   TP_REQUIRE((op == 1 || a->x) && (op == 2 || a->w) && (op == 0 || a->gy), "operand missing");
   p->x = a->x; p->w = a->w; p->gy = a->gy; p->out = a->out; p->ws = a->workspace; p->cnt = (unsigned*)a->counters;
+  p->x_copy = nullptr;
   p->in_xhat = a->in_xhat; p->in_rstd = a->in_rstd; p->in_addend = a->in_addend; p->in_gx = a->in_gx; p->in_slope = a->in_slope; p->skip_out = a->skip_out;
   if (a->in_gx != nullptr) {
     TP_REQUIRE(op == 1 && a->in_xhat && a->in_rstd && a->H == 8 && a->W == 8, "the fused InstanceNorm backward: data gradient onto 8x8 maps, xhat and rstd given");
@@ -565,6 +570,9 @@ static int conv_in_fill(const tp_conv4s2_args* a, float* xhat, float* rstd, Plan
   TP_REQUIRE(a->x && a->w && a->out && xhat && rstd && a->counters && (!q->ws_floats || a->workspace), "operand / counters / workspace missing");
   TP_REQUIRE((a->N * p->OH * p->OW) % 16 == 0, "whole instances per tile needed");
   p->x = a->x; p->w = a->w; p->gy = nullptr; p->out = a->out; p->ws = a->workspace; p->cnt = (unsigned*)a->counters;
+  p->x_copy = a->x_copy;
+  TP_REQUIRE(a->x_copy == nullptr || ((((int64_t)a->N * a->C * a->H * a->W) & 3) == 0 && (((uintptr_t)a->x | (uintptr_t)a->x_copy) & 15) == 0 && a->x_copy != a->x),
+             "x_copy: 16-byte aligned, a multiple of 4 floats, not x itself");
   return 0;
 }
 static int conv_in_launch(const tp_conv4s2_args* a, float* xhat_a, float* rstd_a, const tp_conv4s2_args* b, float* xhat_b, float* rstd_b,

@@ -290,16 +290,19 @@ class DiscStepSchedule:
         K_in = self.full.weight_orig.shape[1] * h * w
         return K_in % 4 == 0 and B <= ops.DISC_TAIL_MAX_ROWS and os.environ.get("TP_NO_DISC_TAIL") != "1"
 
-    def _forward_pair(self, xr, Wr, xf, Wf, scale, stacks):
-        """`_forward` of the real patches (weights Wr, inputs of the later stages into `stacks`) and of the fake patches (Wf), in pairs."""
+    def _forward_pair(self, xr, Wr, xf, Wf, scale, stacks, copies=None):
+        """`_forward` of the real patches (weights Wr, inputs of the later stages into `stacks`) and of the fake patches (Wf), in pairs.
+        ``copies`` = (real copy, fake copy): the first pair of launches also copies its inputs there, and everything later (the weight
+        gradients of the first stage) reads the copies."""
         K, B, sl = len(self.stages), xr.shape[0], self.slope
         ar, af, sr, sf = xr, xf, [], []
         for l, (_conv, eps) in enumerate(self.stages):
+            cr, cf = copies if (copies is not None and l == 0) else (None, None)
             with ops.paired():
-                yr, xhr, rsr = ops.conv4s2_fwd_inorm(ar, Wr[l], eps, sl, y_out=stacks[l + 1][:B])
-                yf, xhf, rsf = ops.conv4s2_fwd_inorm(af, Wf[l], eps, sl)
-            sr.append(AttrDict(x=ar, xhat=xhr, rstd=rsr))
-            sf.append(AttrDict(x=af, xhat=xhf, rstd=rsf))
+                yr, xhr, rsr = ops.conv4s2_fwd_inorm(ar, Wr[l], eps, sl, y_out=stacks[l + 1][:B], copy_to=cr)
+                yf, xhf, rsf = ops.conv4s2_fwd_inorm(af, Wf[l], eps, sl, copy_to=cf)
+            sr.append(AttrDict(x=ar if cr is None else cr, xhat=xhr, rstd=rsr))
+            sf.append(AttrDict(x=af if cf is None else cf, xhat=xhf, rstd=rsf))
             ar, af = yr, yf
         L = self.disc.L_scale
         with ops.paired():
@@ -391,9 +394,14 @@ class DiscStepSchedule:
         n_real = self._normalised_weights()
         n_fake = self._normalised_weights()          # (the reference's order of power iterations: D(real)'s, then D(fake)'s)
         fake = fake.contiguous()
+        copies, src_real, src_fake = None, real_stack[:B], fake
         if own_inputs:
             stack_own, fake_own = torch.empty_like(real_stack), torch.empty_like(fake)
-            ops.step_inputs([(stack_own[:B], real_stack[:B]), (fake_own, fake)])
+            if os.environ.get("TP_NO_CONV_COPY") == "1" or real_stack[:B].numel() % 4 or not real_stack.is_contiguous():
+                ops.step_inputs([(stack_own[:B], real_stack[:B]), (fake_own, fake)])
+                src_real, src_fake = stack_own[:B], fake_own
+            else:
+                copies = (stack_own[:B], fake_own)         # (the first pair of convolution launches copies its inputs: no launch for it)
             real_stack, fake = stack_own, fake_own
         xs, gs, shp = [real_stack], [], real_stack[:B].shape
         for conv, _eps in self.stages:
@@ -401,7 +409,7 @@ class DiscStepSchedule:
             xs.append(torch.empty((2 * B,) + shp[1:], device=dev))
             gs.append(torch.empty((2 * B,) + shp[1:], device=dev))
         gs.append(torch.empty(2 * B, self.full.weight_orig.shape[0], device=dev))
-        fr, ff = self._forward_pair(real_stack[:B], n_real.w, fake, n_fake.w, scale, xs)
+        fr, ff = self._forward_pair(src_real, n_real.w, src_fake, n_fake.w, scale, xs, copies=copies)
         out2, g_real, g_fake = ops.gan_disc_losses(fr.out, ff.out, w_real, w_fake)
         res.gan_disc_real, res.gan_disc_fake, res.d_real, res.d_fake = out2[0], out2[1], fr.out, ff.out
         return AttrDict(res=res, n_real=n_real, n_fake=n_fake, xs=xs, gs=gs, fr=fr, ff=ff, g_real=g_real, g_fake=g_fake,

@@ -1027,9 +1027,10 @@ def conv4s2_fwd_inorm_supported(x: Tensor) -> bool:
 
 
 @_on_tensor_device
-def conv4s2_fwd_inorm(x: Tensor, w: Tensor, eps: float, slope: float, y_out: Optional[Tensor] = None):
+def conv4s2_fwd_inorm(x: Tensor, w: Tensor, eps: float, slope: float, y_out: Optional[Tensor] = None, copy_to: Optional[Tensor] = None):
     """-> (y, xhat, rstd) = inorm_lrelu_fwd(conv4s2_fwd(x, w), eps, slope) in ONE launch (the normalisation runs in the epilogue of
-    the workgroup that holds an instance's split-K totals); ``y_out`` as in inorm_lrelu_fwd."""
+    the workgroup that holds an instance's split-K totals); ``y_out`` as in inorm_lrelu_fwd.  ``copy_to`` (shaped like x, contiguous):
+    the launch also leaves a copy of x there."""
     lib = _lib.load()
     x, w = _f32(x, "x"), _f32(w, "w")
     N, C_in, H, W = x.shape
@@ -1041,7 +1042,11 @@ def conv4s2_fwd_inorm(x: Tensor, w: Tensor, eps: float, slope: float, y_out: Opt
     ws, cnt = _conv_scratch(lib, lambda args, _op, n: lib.tp_conv4s2_fwd_inorm_workspace(args, n), a, 0, x.device)
     a.x, a.w = x.data_ptr(), w.data_ptr()
     a.out, a.counters, a.workspace = y.data_ptr(), cnt.data_ptr(), _ptr(ws)
-    a._keep = (x, w, y, xhat, rstd, ws, cnt)
+    a._keep = (x, w, y, xhat, rstd, ws, cnt, copy_to)
+    if copy_to is not None:
+        if copy_to.shape != x.shape or copy_to.dtype != torch.float32 or not copy_to.is_contiguous() or copy_to.device != x.device:
+            raise ValueError("conv4s2_fwd_inorm: copy_to must be a contiguous float32 tensor shaped like x")
+        a.x_copy = copy_to.data_ptr()
     _launch("tp_conv4s2_fwd_inorm", a, (xhat.data_ptr(), rstd.data_ptr(), float(eps), float(slope)))
     return y, xhat, rstd
 
