@@ -270,6 +270,9 @@ typedef struct tp_patch_gather_args {
   const float* mask_syn;   /* [B,H,W]   */
   int B, P, H, W;
   float* out;              /* [B,14,P]: image3 image_syn3 nocs3*mask_syn normal3*mask_syn mask mask_syn */
+  /* optional (disc_rgb != NULL): the PatchGAN's input stacks of the same pixels in the same launch, what tp_disc_inputs forms from
+   * `out` and the rendered colours disc_rgb [B,P,3]: disc_real / disc_fake [B, disc_geo ? 9 : 3, P] (model/nerf_adapt_st_gan.py:478-497) */
+  const float* disc_rgb; float* disc_real; float* disc_fake; int disc_geo; int pad_;
 } tp_patch_gather_args;
 int tp_patch_gather(const tp_patch_gather_args* args, tp_stream_t stream);
 

@@ -1365,6 +1365,23 @@ def test_disc_step_pairs_are_bit_identical_to_the_sequential_schedule(ops, monke
     assert torch.equal(ya, yb) and torch.equal(yc, ops.conv4s2_fwd_inorm(x * 2, w, 1e-5, 0.2)[0])
 
 
+@pytest.mark.parametrize("geo", [False, True])
+def test_patch_gather_forms_the_discriminator_stacks_bit_identically(ops, geo):
+    """tp_patch_gather with disc_rgb set: the PatchGAN's real / fake stacks of the gathered pixels from the same launch, against
+    tp_disc_inputs on the gather's output -- and the gather's own output unchanged -- bit for bit."""
+    torch.manual_seed(11)
+    B, H, W, p = 3, 64, 48, 16
+    coords = torch.rand(B, p, p, 2, device=dev()) * 2.2 - 1.1                     # (some samples out of range)
+    imgs = [torch.rand(B, 3, H, W, device=dev()) for _ in range(4)]
+    m, ms = (torch.rand(B, H, W, device=dev()) > 0.4).float(), (torch.rand(B, H, W, device=dev()) > 0.3).float()
+    rgb = torch.rand(B, p * p, 3, device=dev())
+    g0 = ops.patch_gather(coords, *imgs, m, ms)
+    real0, fake0 = ops.disc_inputs(rgb, g0, (p, p), geo, stacked=True)
+    g1, real1, fake1 = ops.patch_gather(coords, *imgs, m, ms, disc_rgb=rgb, disc_geo=geo)
+    assert torch.equal(g0, g1) and torch.equal(real0[:B], real1[:B]) and torch.equal(fake0, fake1)
+    assert real1.shape == (2 * B, 9 if geo else 3, p, p)
+
+
 @pytest.mark.parametrize("N", [1, 3, 4, 8])
 def test_conv4s2_dgrad_with_fused_inorm_backward_is_bit_identical(ops, N):
     """tp_conv4s2_dgrad with in_gx set (the InstanceNorm + LeakyReLU backward of the stage in front of the convolution inside the data

@@ -91,7 +91,7 @@ class CompositeBwdArgs(C.Structure):
 class PatchGatherArgs(C.Structure):
     _fields_ = [("coords", vp), ("image", vp), ("image_syn", vp), ("nocs", vp), ("normal", vp),
                 ("obj_mask", vp), ("mask_syn", vp), ("B", C.c_int), ("P", C.c_int), ("H", C.c_int),
-                ("W", C.c_int), ("out", vp)]
+                ("W", C.c_int), ("out", vp), ("disc_rgb", vp), ("disc_real", vp), ("disc_fake", vp), ("disc_geo", C.c_int), ("pad_", C.c_int)]
 
 
 class EvalMetricsArgs(C.Structure):

@@ -508,8 +508,11 @@ class _DiscPatches(torch.autograd.Function):
     constant of the step (the second half belongs to the discriminator step's schedule, texpose_amd/disc_step.py)."""
 
     @staticmethod
-    def forward(ctx, rgb, gathered, hw, geo):
-        real, fake = ops.disc_inputs(rgb, gathered, hw, geo, stacked=True)
+    def forward(ctx, rgb, gathered, hw, geo, pre_real=None, pre_fake=None):
+        if pre_real is not None:                     # (formed by the gather's launch from this very rgb: ops.patch_gather(disc_rgb=))
+            real, fake = pre_real, pre_fake
+        else:
+            real, fake = ops.disc_inputs(rgb, gathered, hw, geo, stacked=True)
         ctx.dims = (rgb.shape[0], rgb.shape[1])
         ctx.mark_non_differentiable(real)
         ctx.set_materialize_grads(False)
@@ -519,13 +522,14 @@ class _DiscPatches(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, g_real, g_fake):
         if g_fake is None:
-            return None, None, None, None
-        return ops.fake_patch_bwd(g_fake.contiguous(), *ctx.dims), None, None, None
+            return None, None, None, None, None, None
+        return ops.fake_patch_bwd(g_fake.contiguous(), *ctx.dims), None, None, None, None, None
 
 
-def disc_patches(rgb, gathered, hw, geo: bool):
-    """-> (real [B,nc,h,w], fake [B,nc,h,w], real stack [2B,nc,h,w])."""
-    stack, fake = _DiscPatches.apply(rgb, gathered, tuple(hw), bool(geo))
+def disc_patches(rgb, gathered, hw, geo: bool, pre=None):
+    """-> (real [B,nc,h,w], fake [B,nc,h,w], real stack [2B,nc,h,w]).  ``pre`` = (real stack, fake, ...): already formed from this rgb."""
+    pr, pf = (pre[0], pre[1]) if pre is not None else (None, None)
+    stack, fake = _DiscPatches.apply(rgb, gathered, tuple(hw), bool(geo), pr, pf)
     return stack[:rgb.shape[0]], fake, stack
 
 

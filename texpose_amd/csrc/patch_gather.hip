@@ -47,6 +47,7 @@ __global__ void patch_gather_kernel(tp_patch_gather_args a, int xcd_major) {
 
   float* out = a.out + (int64_t)b * 14 * a.P + p;
   const float* srcs[4] = {a.image, a.image_syn, a.nocs, a.normal};
+  float val[12];
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
 #pragma unroll
@@ -58,10 +59,29 @@ __global__ void patch_gather_kernel(tp_patch_gather_args a, int xcd_major) {
       r = tp::fma_rn(ok11 ? pl[o00 + W + 1] : 0.0f, se, r);
       if (t >= 2) r = tp::mul_rn(r, ms);  // nocs_sample / normal_sample = gathered * mask_syn (:459-460)
       out[(int64_t)(t * 3 + c) * a.P] = r;
+      val[t * 3 + c] = r;
     }
   }
   out[(int64_t)12 * a.P] = m;
   out[(int64_t)13 * a.P] = ms;
+  if (a.disc_rgb != nullptr) {                       // (csrc/train_misc.hip disc_inputs_kernel on the values this thread has just formed)
+    const int nc = a.disc_geo ? 9 : 3;
+    const float pad = (ms == 1.f && m == 0.f) ? 1.f : 0.f;
+    float* real = a.disc_real + (int64_t)b * nc * a.P + p;
+    float* fake = a.disc_fake + (int64_t)b * nc * a.P + p;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float r = a.disc_rgb[q * 3 + c];
+      real[(int64_t)c * a.P] = tp::add_rn(tp::mul_rn(val[c], m), tp::mul_rn(r, pad));
+      fake[(int64_t)c * a.P] = r;
+    }
+    if (a.disc_geo)
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        real[(int64_t)(3 + c) * a.P] = val[6 + c];
+        fake[(int64_t)(3 + c) * a.P] = val[6 + c];
+      }
+  }
 }
 
 }  // namespace
@@ -70,6 +90,7 @@ extern "C" int tp_patch_gather(const tp_patch_gather_args* a, tp_stream_t stream
   TP_REQUIRE(a && a->coords && a->image && a->image_syn && a->nocs && a->normal && a->obj_mask && a->mask_syn &&
                  a->out, "null pointer");
   TP_REQUIRE(a->B > 0 && a->P > 0 && a->H > 0 && a->W > 0, "bad sizes");
+  TP_REQUIRE(a->disc_rgb == nullptr || (a->disc_real && a->disc_fake), "disc_rgb given: disc_real and disc_fake expected");
   const int64_t total = (int64_t)a->B * a->P;
   const unsigned blocks = (unsigned)((total + 255) / 256);
   hipLaunchKernelGGL(patch_gather_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *a, (blocks % 8 == 0 && blocks >= 16) ? 1 : 0);

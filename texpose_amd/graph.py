@@ -231,14 +231,21 @@ class Graph(torch.nn.Module):
         return out
 
     # ------------------------------------------------------------------ consumers of render()
-    def gather_patches(self, opt, var):
-        """One fused gather for everything compute_loss / sample_geometry / disc_forward sample at var.ray_idx."""
+    def gather_patches(self, opt, var, disc_rgb=None):
+        """One fused gather for everything compute_loss / sample_geometry / disc_forward sample at var.ray_idx.
+        ``disc_rgb`` (the rendered colours the PatchGAN's fake stack is built from): the same launch also forms the discriminator's
+        real / fake stacks (K13 tp_disc_inputs' values) -> var.disc_stacks = (real stack, fake, the rgb tensor they belong to)."""
         B = len(var.idx)
         if var.get("gathered_for") is var.ray_idx:          # same coordinates, same images: the gather is pure
             return var
-        g = ops.patch_gather(var.ray_idx, var.image, var.get("image_syn", var.image),
-                             var.get("nocs_pred", var.image), var.get("normal_pred", var.image),
-                             var.obj_mask.view(B, opt.H, opt.W), var.get("mask_syn", var.obj_mask).view(B, opt.H, opt.W))
+        args = (var.ray_idx, var.image, var.get("image_syn", var.image),
+                var.get("nocs_pred", var.image), var.get("normal_pred", var.image),
+                var.obj_mask.view(B, opt.H, opt.W), var.get("mask_syn", var.obj_mask).view(B, opt.H, opt.W))
+        if disc_rgb is not None and disc_rgb.is_cuda and os.environ.get("TP_NO_GATHER_DISC") != "1":
+            g, real, fake = ops.patch_gather(*args, disc_rgb=disc_rgb, disc_geo=bool(opt.gan.geo_conditional))
+            var.disc_stacks = (real, fake, disc_rgb)
+        else:
+            g = ops.patch_gather(*args)
         var.gathered, var.gathered_for = g, var.ray_idx
         var.image_sample, var.image_syn_sample = g[:, 0:3], g[:, 3:6]
         var.nocs_sample, var.normal_sample = g[:, 6:9], g[:, 9:12]
@@ -288,12 +295,18 @@ class Graph(torch.nn.Module):
             B, h, w, _ = var.ray_idx.shape
             if stage != "consume":
                 if opt.gan.geo_conditional:
+                    if var.rgb.is_cuda and var.get("gathered_for") is not var.ray_idx:
+                        # (the gather of this iteration's patches also forms the PatchGAN's stacks: one launch instead of two)
+                        var = self.gather_patches(opt, var, disc_rgb=var.get("rgb_disc", var.rgb))
                     var = self.sample_geometry(opt, var, mode)
                 if "gathered" in var and var.rgb.is_cuda and var.get("gathered_for") is var.ray_idx:
                     # K13: real / fake stacks in one launch (fake differentiable wrt rgb); the discriminator step of the same
                     # iteration re-uses them (same values: it detaches the very same render)
+                    pre = var.pop("disc_stacks", None)
+                    if pre is not None and pre[2] is not var.get("rgb_disc", var.rgb):
+                        pre = None
                     var.patch_real_nerf, patch_fake, var.patch_real_stack = autograd_ops.disc_patches(
-                        var.get("rgb_disc", var.rgb), var.gathered, (h, w), bool(opt.gan.geo_conditional))
+                        var.get("rgb_disc", var.rgb), var.gathered, (h, w), bool(opt.gan.geo_conditional), pre=pre)
                     var.patch_fake_nerf, var.disc_patches_for = patch_fake, var.ray_idx
                 else:
                     patch_fake = var.rgb.view(B, h, w, 3).permute(0, 3, 1, 2)

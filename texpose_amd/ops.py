@@ -551,8 +551,10 @@ def composite_bwd(ray, rgb, density, depth, uncert, g_out: Optional[Tensor], g_a
 # ------------------------------------------------------------------------------------------ K5
 @_on_tensor_device
 def patch_gather(coords: Tensor, image: Tensor, image_syn: Tensor, nocs: Tensor, normal: Tensor, obj_mask: Tensor,
-                 mask_syn: Tensor) -> Tensor:
-    """-> [B,14,p,p]: image3, image_syn3, nocs3*mask_syn, normal3*mask_syn, mask, mask_syn."""
+                 mask_syn: Tensor, disc_rgb: Optional[Tensor] = None, disc_geo: bool = False):
+    """-> [B,14,p,p]: image3, image_syn3, nocs3*mask_syn, normal3*mask_syn, mask, mask_syn.
+    ``disc_rgb`` [B,P,3] (the rendered colours): -> (that, real stack [2B,nc,p,p], fake [B,nc,p,p]) -- the PatchGAN's input stacks of
+    the same pixels from the same launch (`disc_inputs(disc_rgb, gathered, ..., stacked=True)`, bit for bit)."""
     lib = _lib.load()
     coords = _f32(coords, "coords")
     B, ph, pw, _ = coords.shape
@@ -563,8 +565,17 @@ def patch_gather(coords: Tensor, image: Tensor, image_syn: Tensor, nocs: Tensor,
     a.coords = coords.data_ptr()
     a.image, a.image_syn, a.nocs, a.normal, a.obj_mask, a.mask_syn = [t.data_ptr() for t in ts]
     a.B, a.P, a.H, a.W, a.out = B, ph * pw, H, W, out.data_ptr()
+    if disc_rgb is None:
+        check(lib.tp_patch_gather(C.byref(a), _stream()), "tp_patch_gather")
+        return out
+    rgb = _f32(disc_rgb.detach(), "disc_rgb")
+    if rgb.numel() != B * ph * pw * 3:
+        raise ValueError("patch_gather: disc_rgb [B,P,3] expected")
+    nc = 9 if disc_geo else 3
+    real, fake = torch.empty(2 * B, nc, ph, pw, device=coords.device), torch.empty(B, nc, ph, pw, device=coords.device)
+    a.disc_rgb, a.disc_real, a.disc_fake, a.disc_geo = rgb.data_ptr(), real.data_ptr(), fake.data_ptr(), int(bool(disc_geo))
     check(lib.tp_patch_gather(C.byref(a), _stream()), "tp_patch_gather")
-    return out
+    return out, real, fake
 
 
 @_on_tensor_device
