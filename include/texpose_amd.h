@@ -366,6 +366,12 @@ int tp_nerf_losses_fwd(const tp_nerf_losses_args* args, tp_stream_t stream);
 /* g_render / g_unc / g_trans: the upstream gradients of the three terms, one device scalar each (NULL = 0) */
 int tp_nerf_losses_bwd(const tp_nerf_losses_args* args, const float* g_render, const float* g_unc, const float* g_trans,
                        float* g_rgb, float* g_uncert, float* g_density, tp_stream_t stream);
+/* the same launch + the generator step's loss total and step gate (tp_weighted_sum_flags' arguments and arithmetic) as a side job of its
+ * first thread: one launch less on the render's backward chain (model/base.py:145-157 summarize_loss) */
+int tp_nerf_losses_bwd_total(const tp_nerf_losses_args* args, const float* g_render, const float* g_unc, const float* g_trans,
+                             float* g_rgb, float* g_uncert, float* g_density, const float* const* terms, const float* weights, int n,
+                             float* out, const int32_t* mlp_status, int32_t* bad, int n_bad, int word_status, int word_finite,
+                             int32_t* snapshot, uint64_t* step_counter, tp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * K9  InstanceNorm2d (affine = False) + LeakyReLU of the PatchGAN ladder, one launch per derivative order

@@ -24,7 +24,7 @@ SYMBOLS = (
     "tp_patch_gather",
     "tp_eval_metrics_workspace_bytes", "tp_eval_metrics",
     "tp_sn_work_floats", "tp_sn_fwd", "tp_sn_fwd_sets", "tp_sn_bwd",
-    "tp_nerf_losses_fwd", "tp_nerf_losses_bwd",
+    "tp_nerf_losses_fwd", "tp_nerf_losses_bwd", "tp_nerf_losses_bwd_total",
     "tp_render_eval_workspace_bytes", "tp_render_eval",
     "tp_inorm_lrelu_fwd", "tp_inorm_lrelu_bwd", "tp_inorm_lrelu_bwd_bwd", "tp_inorm_lrelu_bwd_pair",
     "tp_rmsprop_step",
@@ -248,6 +248,8 @@ def load() -> C.CDLL:
     sig("tp_sn_bwd_step", [C.POINTER(SnWeight), C.c_int, C.POINTER(SnStepTail), vp])
     sig("tp_nerf_losses_fwd", [C.POINTER(NerfLossesArgs), vp])
     sig("tp_nerf_losses_bwd", [C.POINTER(NerfLossesArgs), vp, vp, vp, vp, vp, vp, vp])
+    sig("tp_nerf_losses_bwd_total", [C.POINTER(NerfLossesArgs), vp, vp, vp, vp, vp, vp, C.POINTER(vp), C.POINTER(C.c_float), C.c_int, vp, vp, vp,
+                                     C.c_int, C.c_int, C.c_int, vp, vp, vp])
     sig("tp_render_eval_workspace_bytes", [C.c_int, C.c_int, C.c_int], C.c_size_t)
     sig("tp_render_eval", [C.POINTER(RenderEvalArgs), vp])
     sig("tp_inorm_lrelu_fwd", [vp, C.c_int64, C.c_int, C.c_float, C.c_float, vp, vp, vp, vp])

@@ -101,10 +101,28 @@ __global__ __launch_bounds__(kBlock) void nerf_losses_fwd_kernel(tp_nerf_losses_
 }
 
 
+// tp_nerf_losses_bwd_total: the generator step's loss total + step gate (csrc/train_misc.hip weighted_sum_flags_kernel, same arithmetic
+// and order of side effects) as a side job of this launch's first thread -- the total is not an input of any gradient, only of the gate
+// the optimiser launch reads, so it needs no launch of its own on the render's backward chain
+struct TotalJob {
+  const float* t[16]; float w[16]; int n;
+  float* out; const int* status; int* bad; int* snapshot; unsigned long long* step_counter;
+  int n_bad, word_status, word_finite;
+};
+
 // g_render / g_unc / g_trans: upstream gradients of (render, uncert, trans_reg), one device scalar each (NULL = 0)
 __global__ __launch_bounds__(kBlock) void nerf_losses_bwd_kernel(tp_nerf_losses_args a, const double* sums, const float* g_render,
                                                                  const float* g_unc, const float* g_trans,
-                                                                 float* g_rgb, float* g_uncert, float* g_density) {
+                                                                 float* g_rgb, float* g_uncert, float* g_density, TotalJob job) {
+  if (job.n > 0 && blockIdx.x == 0 && threadIdx.x == 0) {
+    if (job.step_counter != nullptr) job.step_counter[0] += 1;
+    float acc = 0.f;
+    for (int k = 0; k < job.n; ++k) acc += job.t[k][0] * job.w[k];
+    job.out[0] = acc;
+    if (job.status != nullptr && (job.status[0] & 1)) job.bad[job.word_status] |= 1;
+    if (!(acc - acc == 0.f)) job.bad[job.word_finite] |= 1;
+    for (int k = 0; k < job.n_bad; ++k) job.snapshot[k] = job.bad[k];
+  }
   const int64_t n_pix = (int64_t)a.B * a.P, n_den = n_pix * a.N;
   const float inv_den = (float)(1.0 / (sums[1] + 1e-5));
   const float gr = (g_render ? g_render[0] : 0.f) * inv_den, gu = (g_unc ? g_unc[0] : 0.f) / (float)n_pix,
@@ -153,6 +171,24 @@ extern "C" int tp_nerf_losses_bwd(const tp_nerf_losses_args* a, const float* g_r
   if (int rc = check(a, "tp_nerf_losses_bwd")) return rc;
   if (!g_rgb || !g_uncert || !g_density) { tp::set_error("tp_nerf_losses_bwd: null gradient pointer"); return -1; }
   hipLaunchKernelGGL(nerf_losses_bwd_kernel, dim3(grid_for(a)), dim3(kBlock), 0, (hipStream_t)stream, *a, (const double*)a->sums,
-                     g_render, g_unc, g_trans, g_rgb, g_uncert, g_density);
+                     g_render, g_unc, g_trans, g_rgb, g_uncert, g_density, TotalJob{});
   return tp::check_launch("tp_nerf_losses_bwd");
+}
+
+extern "C" int tp_nerf_losses_bwd_total(const tp_nerf_losses_args* a, const float* g_render, const float* g_unc, const float* g_trans,
+                                        float* g_rgb, float* g_uncert, float* g_density, const float* const* terms, const float* weights,
+                                        int n, float* out, const int32_t* mlp_status, int32_t* bad, int n_bad, int word_status,
+                                        int word_finite, int32_t* snapshot, uint64_t* step_counter, tp_stream_t stream) {
+  if (int rc = check(a, "tp_nerf_losses_bwd_total")) return rc;
+  if (!g_rgb || !g_uncert || !g_density) { tp::set_error("tp_nerf_losses_bwd_total: null gradient pointer"); return -1; }
+  TP_REQUIRE(terms && weights && out && n > 0 && n <= 16, "1..16 terms expected");
+  TP_REQUIRE(bad && snapshot && n_bad > 0 && word_finite >= 0 && word_finite < n_bad && (!mlp_status || (word_status >= 0 && word_status < n_bad)),
+             "bad gate arguments");
+  TotalJob job{};
+  for (int k = 0; k < n; ++k) { TP_REQUIRE(terms[k] != nullptr, "null term"); job.t[k] = terms[k]; job.w[k] = weights[k]; }
+  job.n = n; job.out = out; job.status = mlp_status; job.bad = bad; job.snapshot = snapshot; job.step_counter = (unsigned long long*)step_counter;
+  job.n_bad = n_bad; job.word_status = word_status; job.word_finite = word_finite;
+  hipLaunchKernelGGL(nerf_losses_bwd_kernel, dim3(grid_for(a)), dim3(kBlock), 0, (hipStream_t)stream, *a, (const double*)a->sums,
+                     g_render, g_unc, g_trans, g_rgb, g_uncert, g_density, job);
+  return tp::check_launch("tp_nerf_losses_bwd_total");
 }

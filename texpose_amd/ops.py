@@ -862,6 +862,18 @@ def nerf_losses_bwd(rgb: Tensor, uncert: Tensor, density: Tensor, gathered: Tens
         gs = [None if g is None else _f32(g, "g_loss") for g in g_losses]
     ptrs = [None if g is None else g.data_ptr() for g in gs]
     g_rgb, g_unc, g_den = torch.empty_like(keep[0]), torch.empty_like(keep[1]), torch.empty_like(keep[2])
+    job = _pending_total.pop("job", None)
+    if job is not None and job["stream"] == _stream():
+        # (the generator step's loss total + gate, handed over by weighted_sum(defer=True): a side job of this launch)
+        tp, wsf, n, out, flags = job["ptrs"], job["ws"], job["n"], job["out"], job["flags"]
+        bad = flags["bad"]
+        check(lib.tp_nerf_losses_bwd_total(C.byref(a), ptrs[0], ptrs[1], ptrs[2], g_rgb.data_ptr(), g_unc.data_ptr(), g_den.data_ptr(),
+                                           tp, wsf, n, out.data_ptr(), _ptr(flags.get("status")), bad.data_ptr(), bad.numel(),
+                                           int(flags.get("word_status", 0)), int(flags["word_finite"]), flags["snapshot"].data_ptr(),
+                                           _ptr(flags.get("step_counter")), _stream()), "tp_nerf_losses_bwd_total")
+        return g_rgb, g_unc, g_den
+    if job is not None:
+        _pending_total["job"] = job
     check(lib.tp_nerf_losses_bwd(C.byref(a), ptrs[0], ptrs[1], ptrs[2], g_rgb.data_ptr(), g_unc.data_ptr(), g_den.data_ptr(),
                                  _stream()), "tp_nerf_losses_bwd")
     return g_rgb, g_unc, g_den
@@ -1411,17 +1423,38 @@ def gan_disc_losses(d_real: Tensor, d_fake: Tensor, w_real: float, w_fake: float
     return out2, gr, gf
 
 
+_pending_total = {}          # "job": a loss total + gate waiting for the next nerf_losses_bwd launch on its stream (weighted_sum(defer=True))
+
+
+def flush_pending_total() -> None:
+    """Launch a total handed over with weighted_sum(defer=True) that no nerf_losses_bwd launch has taken (tp_weighted_sum_flags)."""
+    job = _pending_total.pop("job", None)
+    if job is None:
+        return
+    flags, bad = job["flags"], job["flags"]["bad"]
+    with torch.cuda.device(job["out"].device):
+        check(_lib.load().tp_weighted_sum_flags(job["ptrs"], job["ws"], job["n"], job["out"].data_ptr(), _ptr(flags.get("status")), bad.data_ptr(),
+                                                bad.numel(), int(flags.get("word_status", 0)), int(flags["word_finite"]),
+                                                flags["snapshot"].data_ptr(), _ptr(flags.get("step_counter")), _stream()), "tp_weighted_sum_flags")
+
+
 @_on_tensor_device
-def weighted_sum(terms, weights, flags=None) -> Tensor:
+def weighted_sum(terms, weights, flags=None, defer: bool = False) -> Tensor:
     """sum_k weights[k] * terms[k] for 0-dim float32 device tensors and host floats, one launch.  ``flags`` = dict(bad,
     word_finite, snapshot[, status, word_status, step_counter]): `step_flags` on the result in the same launch
-    (tp_weighted_sum_flags); ``step_counter`` (int64 [1]) is incremented by it."""
+    (tp_weighted_sum_flags); ``step_counter`` (int64 [1]) is incremented by it.
+    ``defer`` (with flags): nothing is launched -- the next `nerf_losses_bwd` launch on this stream carries the job
+    (tp_nerf_losses_bwd_total); the caller runs `flush_pending_total()` behind the backward pass in case there was none."""
     lib = _lib.load()
     n = len(terms)
     ts = [_f32(t.detach(), "term") for t in terms]
     ptrs = (C.c_void_p * n)(*[t.data_ptr() for t in ts])
     ws = (C.c_float * n)(*[float(w) for w in weights])
     out = torch.empty((), device=ts[0].device)
+    if defer and flags is not None:
+        flush_pending_total()
+        _pending_total["job"] = dict(ptrs=ptrs, ws=ws, n=n, out=out, flags=flags, stream=_stream(), keep=ts)
+        return out
     if flags is None:
         check(lib.tp_weighted_sum(ptrs, ws, n, out.data_ptr(), _stream()), "tp_weighted_sum")
     else:

@@ -190,7 +190,7 @@ class GanTrainer:
             cache[key] = torch.tensor(10 ** float(exponent), device=dev)
         return cache[key]
 
-    def _weighted_total(self, loss, flags=None):
+    def _weighted_total(self, loss, flags=None, defer=False):
         """``loss.all`` = detached sum 10^w_k loss_k (logging, the finite check); returns the terms and their weights.
         ``flags``: the step-gate update for this total (ops.step_flags arguments), folded into the same launch where possible."""
         opt = self.opt
@@ -205,7 +205,8 @@ class GanTrainer:
             cache[vec_key] = torch.stack(ws)
         with torch.no_grad():
             if dev.type == "cuda" and len(keys) <= 16 and all(loss[k].dtype == torch.float32 for k in keys):
-                loss.all = ops.weighted_sum([loss[k] for k in keys], [10 ** float(opt.loss_weight[k]) for k in keys], flags=flags)   # K13: one launch
+                loss.all = ops.weighted_sum([loss[k] for k in keys], [10 ** float(opt.loss_weight[k]) for k in keys], flags=flags,
+                                            defer=defer and flags is not None)   # K13: one launch (or a side job of the losses' backward)
             else:
                 loss.all = torch.dot(torch.stack([loss[k].detach() for k in keys]), cache[vec_key])
                 if flags is not None:
@@ -872,11 +873,14 @@ class GraphedGanTrainer(GanTrainer):
         dev, lw = var.idx.device, self.opt.loss_weight
         status = ops.mlp_status(dev) if self._uses_f16x3() else None
         keys = [k for k in loss if k != "all" and lw[k] is not None]
+        # (the total + gate ride in the first launch of the backward pass, K8's: nothing differentiates through them)
         terms, ws = self._weighted_total(loss, flags=dict(bad=self._bad, word_finite=1, snapshot=self._gate_nerf, status=status,
-                                                          word_status=0, step_counter=getattr(self, "_rng_counter", None)))
+                                                          word_status=0, step_counter=getattr(self, "_rng_counter", None)),
+                                         defer=os.environ.get("TP_NO_TOTAL_IN_BWD") != "1")
         roots = {"feat": (var.rgb_feat, var.g_rgb_feat), "gan_nerf": (var.rgb_disc, g_disc)}
         pairs = [roots.get(k, (t, w)) for k, t, w in zip(keys, terms, ws)]
         torch.autograd.backward([r for r, _ in pairs], [c for _, c in pairs])
+        ops.flush_pending_total()
         self._guard_nerf(var, loss)
         self.nerf_apply()
         return var, loss
