@@ -522,6 +522,13 @@ class GraphedGanTrainer(GanTrainer):
     Per-iteration host state goes through device memory: the batch is copied into static input tensors, the annealed
     patch-scale bound is a 0-dim device tensor, the jitter comes from torch's graph-safe Philox stream, the optimisers
     are ``capturable``.  Losses come back as static tensors (read them only when logging: that is the one sync).
+
+    By default `train_iteration` returns with the calling stream ordered behind everything the iteration enqueued.  Two opt-in
+    attributes relax that for throughput (one rank, the linear-graph form; bit-identical results either way): ``defer_results`` (the
+    calling stream is ordered behind the consumption of the iteration's INPUTS only) and ``pipeline_disc_tail`` (the discriminator
+    step's second half may still run beside the next render).  With either set, order the calling stream behind the results with
+    `wait_all()` -- or `finish()` / `flush_flags()`, which also read the gate words -- BEFORE reading losses, parameters or optimiser
+    state, saving a checkpoint or loading one.
     """
     capturable = True
 
