@@ -11,6 +11,7 @@
 //   tp_adam_step         optim_nerf.step() (model/nerf_adapt_st_gan.py:62-68,125: torch.optim.Adam) for every tensor at once, gated
 //   tp_disc_inputs       the real / fake patch stacks of the discriminator step (model/nerf_adapt_st_gan.py:478-497): 10 launches
 #include "tp_common.h"
+#include <stdlib.h>
 
 namespace {
 constexpr int kBlock = 256;
@@ -208,25 +209,44 @@ __global__ __launch_bounds__(kBlock) void adam_kernel(AdamTable t, const float* 
   for (int k = 0; k < n_gate; ++k)
     if (gate[k] != 0) return;
   const double lr = lr_dev != nullptr ? (double)*lr_dev : lr_host;
-  int k = 0, k_done = -1;
-  float step_size = 0.f, bc2_sqrt = 1.f;
-  for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < total; e += (int64_t)gridDim.x * kBlock) {
-    while (e >= t.end[k]) ++k;
-    const int64_t i = e - (k == 0 ? 0 : t.end[k - 1]);
-    if (k != k_done) {                                     // the bias corrections are per tensor, once, not per element; beta^step as
-      const double step = (double)t.step[k][0] + 1.0;      // exp(step ln beta) in double (ln beta from the host): a generic double pow()
-      const double bc1 = 1.0 - exp(step * log_beta1), bc2 = 1.0 - exp(step * log_beta2);   // is ~6x the instructions of exp()
-      step_size = (float)(lr / bc1); bc2_sqrt = (float)sqrt(bc2);
-      k_done = k;
+  // the bias corrections are per tensor: thread k of every workgroup forms tensor k's once (beta^step as exp(step ln beta) in double, ln
+  // beta from the host: a generic double pow() is ~6x the instructions of exp()), everybody reads them from LDS
+  __shared__ float s_step_size[TP_ADAM_MAX_TENSORS], s_bc2_sqrt[TP_ADAM_MAX_TENSORS];
+  if ((int)threadIdx.x < t.n) {
+    const double step = (double)t.step[threadIdx.x][0] + 1.0;
+    const double bc1 = 1.0 - exp(step * log_beta1), bc2 = 1.0 - exp(step * log_beta2);
+    s_step_size[threadIdx.x] = (float)(lr / bc1); s_bc2_sqrt[threadIdx.x] = (float)sqrt(bc2);
+  }
+  __syncthreads();
+  // four elements per thread and round, their sixteen loads in flight together (one element per round paid a memory latency per element:
+  // 18 us for 0.63 M parameters, at the end of the render's backward chain)
+  constexpr int kU = 4;
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t e0 = (int64_t)blockIdx.x * kBlock + threadIdx.x; e0 < total; e0 += kU * stride) {
+    int kk[kU]; int64_t ii[kU]; bool live[kU];
+    float g[kU], m[kU], v[kU], pv[kU];
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      const int64_t e = e0 + u * stride;
+      live[u] = e < total;
+      int k = 0;
+      while (live[u] && e >= t.end[k]) ++k;
+      kk[u] = k; ii[u] = live[u] ? e - (k == 0 ? 0 : t.end[k - 1]) : 0;
+      g[u] = t.g[k][ii[u]]; m[u] = t.m[k][ii[u]]; v[u] = t.v[k][ii[u]]; pv[u] = t.p[k][ii[u]];
     }
-    const float g = t.g[k][i];
-    float m = t.m[k][i], v = t.v[k][i];
-    m = tp::add_rn(m, tp::mul_rn(tp::sub_rn(g, m), w1));                      // exp_avg.lerp_(grad, 1 - beta1): w1 = (float)(1 - beta1)
-    v = tp::add_rn(tp::mul_rn(v, b2), tp::mul_rn(tp::mul_rn(w2, g), g));      // mul_(beta2).addcmul_(g, g, 1 - beta2): w2 = (float)(1 - beta2)
-    t.m[k][i] = m;
-    t.v[k][i] = v;
-    const float denom = tp::add_rn(tp::div_rn(sqrtf(v), bc2_sqrt), eps);
-    t.p[k][i] = tp::add_rn(t.p[k][i], tp::mul_rn(-step_size, tp::div_rn(m, denom)));    // addcdiv_(exp_avg, denom, value = -step_size)
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      if (!live[u]) continue;
+      const int k = kk[u]; const int64_t i = ii[u];
+      const float step_size = s_step_size[k], bc2_sqrt = s_bc2_sqrt[k];
+      float mm = m[u], vv = v[u];
+      mm = tp::add_rn(mm, tp::mul_rn(tp::sub_rn(g[u], mm), w1));                         // exp_avg.lerp_(grad, 1 - beta1): w1 = (float)(1 - beta1)
+      vv = tp::add_rn(tp::mul_rn(vv, b2), tp::mul_rn(tp::mul_rn(w2, g[u]), g[u]));      // mul_(beta2).addcmul_(g, g, 1 - beta2): w2 = (float)(1 - beta2)
+      t.m[k][i] = mm;
+      t.v[k][i] = vv;
+      const float denom = tp::add_rn(tp::div_rn(sqrtf(vv), bc2_sqrt), eps);
+      t.p[k][i] = tp::add_rn(pv[u], tp::mul_rn(-step_size, tp::div_rn(mm, denom)));   // addcdiv_(exp_avg, denom, value = -step_size)
+    }
   }
   __syncthreads();                                         // every thread of this block has read its counters
   if (threadIdx.x == 0) last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
@@ -504,7 +524,9 @@ int tp_adam_step(const tp_adam_tensor* tensors, int n, const float* lr_dev, doub
   for (int k = n; k < TP_ADAM_MAX_TENSORS; ++k) { t.p[k] = nullptr; t.g[k] = nullptr; t.m[k] = nullptr; t.v[k] = nullptr; t.step[k] = nullptr; t.end[k] = total; }
   t.n = n;
   int64_t blocks = (total + kBlock - 1) / kBlock;
-  if (blocks > 512) blocks = 512;          // (one arrival per block on ONE counter word: 1,700 same-address atomics cost 16 us)
+  if (blocks > 256) blocks = 256;          // (one arrival per block on ONE counter word: 1,700 same-address atomics cost 16 us; 512 / 256 / 128
+                                           //  workgroups: 915-925 / 931-932 / 926-929 it/s of the B=4 GAN iteration on one box)
+  { static const int forced = [] { const char* e = getenv("TP_ADAM_BLOCKS"); return e ? atoi(e) : 0; }(); if (forced > 0 && blocks > forced) blocks = forced; }
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, t, lr_dev, lr_host, log(beta1), log(beta2),
                      (float)beta2, (float)eps, (float)(1.0 - beta1), (float)(1.0 - beta2), total, gate, n_gate, ticket);
   return tp::check_launch("tp_adam_step");
