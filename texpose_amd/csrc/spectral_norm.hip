@@ -276,6 +276,7 @@ __global__ __launch_bounds__(256) void sn_dot_kernel(Batch b, StepTail st) {
   const int64_t n = (int64_t)w.rows * w.cols;
   const int parts = (int)((n + 4095) / 4096);
   float acc = 0.0f, acc2 = 0.0f;
+#pragma unroll 8
   for (int64_t i = (int64_t)local * 4096 + threadIdx.x; i < min(n, (int64_t)(local + 1) * 4096); i += 256) {
     acc = fmaf(w.grad_sn[i], w.weight_sn[i], acc);
     if (w.grad_sn2) acc2 = fmaf(w.grad_sn2[i], w.weight_sn2[i], acc2);
@@ -306,19 +307,41 @@ __global__ __launch_bounds__(256) void sn_grad_kernel(Batch b, RmsTail rt) {
   d = block_sum(d, red);
   if (w.grad_sn2) d2 = block_sum(d2, red);
   const float sg = *w.sigma, sg2 = w.grad_sn2 ? *w.sigma2 : 1.0f;
-#pragma unroll 4
-  for (int64_t i = (int64_t)local * rt.elems + threadIdx.x; i < min(n, (int64_t)(local + 1) * rt.elems); i += 256) {
-    const int r = (int)(i / w.cols), c = (int)(i - (int64_t)r * w.cols);
-    float gv = (w.grad_sn[i] - d * w.u[r] * w.v[c]) / sg;
-    if (w.grad_sn2) gv = gv + (w.grad_sn2[i] - d2 * w.u2[r] * w.v2[c]) / sg2;
-    gv = w.accumulate ? w.grad[i] + gv : gv;
-    w.grad[i] = gv;
-    if (apply) {                                   // csrc/rmsprop.hip's arithmetic, torch's order
-      float sq = rt.sq[wi][i];
-      sq = __fadd_rn(__fmul_rn(sq, rt.alpha), __fmul_rn(__fmul_rn(rt.one_minus_alpha, gv), gv));
-      rt.sq[wi][i] = sq;
-      const float avg = __fadd_rn(sqrtf(sq), rt.eps);
-      rt.p[wi][i] = __fadd_rn(rt.p[wi][i], __fmul_rn(-lr, __fdiv_rn(gv, avg)));
+  // four elements per thread and round: ALL their operands are requested before the first store (the pointers may alias as far as the
+  // compiler knows, so a plain loop waits out a memory latency per element -- the Adam kernel's lesson, csrc/train_misc.hip)
+  constexpr int kU = 4;
+  const int64_t i_end = min(n, (int64_t)(local + 1) * rt.elems);
+  for (int64_t i0 = (int64_t)local * rt.elems + threadIdx.x; i0 < i_end; i0 += kU * 256) {
+    float g1[kU], g2[kU], uv1[kU], uv2[kU], old[kU], sq0[kU], p0[kU];
+    bool live[kU];
+#pragma unroll
+    for (int q = 0; q < kU; ++q) {
+      const int64_t i = min(i0 + q * 256, i_end - 1);
+      live[q] = i0 + q * 256 < i_end;
+      const int r = (int)(i / w.cols), c = (int)(i - (int64_t)r * w.cols);
+      g1[q] = w.grad_sn[i];
+      uv1[q] = d * w.u[r] * w.v[c];                 // ((d u) v, the order of the plain form)
+      g2[q] = w.grad_sn2 ? w.grad_sn2[i] : 0.f;
+      uv2[q] = w.grad_sn2 ? d2 * w.u2[r] * w.v2[c] : 0.f;
+      old[q] = w.accumulate ? w.grad[i] : 0.f;
+      sq0[q] = apply ? rt.sq[wi][i] : 0.f;
+      p0[q] = apply ? rt.p[wi][i] : 0.f;
+    }
+#pragma unroll
+    for (int q = 0; q < kU; ++q) {
+      if (!live[q]) continue;
+      const int64_t i = i0 + q * 256;
+      float gv = (g1[q] - uv1[q]) / sg;
+      if (w.grad_sn2) gv = gv + (g2[q] - uv2[q]) / sg2;
+      gv = w.accumulate ? old[q] + gv : gv;
+      w.grad[i] = gv;
+      if (apply) {                                 // csrc/rmsprop.hip's arithmetic, torch's order
+        float sq = sq0[q];
+        sq = __fadd_rn(__fmul_rn(sq, rt.alpha), __fmul_rn(__fmul_rn(rt.one_minus_alpha, gv), gv));
+        rt.sq[wi][i] = sq;
+        const float avg = __fadd_rn(sqrtf(sq), rt.eps);
+        rt.p[wi][i] = __fadd_rn(p0[q], __fmul_rn(-lr, __fdiv_rn(gv, avg)));
+      }
     }
   }
 }
