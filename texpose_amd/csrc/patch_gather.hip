@@ -16,10 +16,16 @@ namespace {
 // 64 x 64 patch -- which sample overlapping rows of the same image region -- land on all eight, and every L2 fetches the region for
 // itself (PMC: 5x the algorithmic bytes).  `xcd_major` (set when the grid is a multiple of 8) gives XCD x the CONSECUTIVE logical
 // blocks [x n / 8, (x + 1) n / 8): an image's blocks share one L2.
+template <bool SPLIT>
 __global__ void patch_gather_kernel(tp_patch_gather_args a, int xcd_major) {
   const unsigned nb = gridDim.x;
   const unsigned lb = xcd_major ? (blockIdx.x & 7u) * (nb >> 3) + (blockIdx.x >> 3) : blockIdx.x;
-  const int64_t q = (int64_t)lb * blockDim.x + threadIdx.x;
+  // SPLIT (small launches: latency-sized): four threads per patch pixel, one per source image (image, synthetic image, nocs, normal: 3
+  // channels x 4 taps each) -- one thread per pixel issued ~56 loads in a row: 7.8 us for the 1,024 pixels of a B=4 step, behind the
+  // render on BOTH chains of the training iteration (4.5 us split).  Large launches are bandwidth-sized and keep one thread per pixel
+  // (B=32, 64 x 64 patches: 15.6 us, 20.9 split).
+  const int64_t q4 = (int64_t)lb * blockDim.x + threadIdx.x;
+  const int64_t q = SPLIT ? q4 >> 2 : q4;
   const int64_t total = (int64_t)a.B * a.P;
   if (q >= total) return;
   const int b = (int)(q / a.P), p = (int)(q - (int64_t)b * a.P);
@@ -46,41 +52,46 @@ __global__ void patch_gather_kernel(tp_patch_gather_args a, int xcd_major) {
   const float ms = nok ? (a.mask_syn[b * HW + on] > 0.0f ? 1.0f : 0.0f) : 0.0f;
 
   float* out = a.out + (int64_t)b * 14 * a.P + p;
-  const float* srcs[4] = {a.image, a.image_syn, a.nocs, a.normal};
-  float val[12];
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
+  for (int gi = 0; gi < (SPLIT ? 1 : 4); ++gi) {
+  const int grp = SPLIT ? (int)(q4 & 3) : gi;
+  const float* src = grp == 0 ? a.image : grp == 1 ? a.image_syn : grp == 2 ? a.nocs : a.normal;
+  float val[3];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      const float* pl = srcs[t] + ((int64_t)b * 3 + c) * HW;
-      float r = tp::mul_rn(ok00 ? pl[o00] : 0.0f, nw);
-      r = tp::fma_rn(ok10 ? pl[o00 + 1] : 0.0f, ne, r);
-      r = tp::fma_rn(ok01 ? pl[o00 + W] : 0.0f, sw, r);
-      r = tp::fma_rn(ok11 ? pl[o00 + W + 1] : 0.0f, se, r);
-      if (t >= 2) r = tp::mul_rn(r, ms);  // nocs_sample / normal_sample = gathered * mask_syn (:459-460)
-      out[(int64_t)(t * 3 + c) * a.P] = r;
-      val[t * 3 + c] = r;
-    }
+  for (int c = 0; c < 3; ++c) {
+    const float* pl = src + ((int64_t)b * 3 + c) * HW;
+    float r = tp::mul_rn(ok00 ? pl[o00] : 0.0f, nw);
+    r = tp::fma_rn(ok10 ? pl[o00 + 1] : 0.0f, ne, r);
+    r = tp::fma_rn(ok01 ? pl[o00 + W] : 0.0f, sw, r);
+    r = tp::fma_rn(ok11 ? pl[o00 + W + 1] : 0.0f, se, r);
+    if (grp >= 2) r = tp::mul_rn(r, ms);  // nocs_sample / normal_sample = gathered * mask_syn (:459-460)
+    out[(int64_t)(grp * 3 + c) * a.P] = r;
+    val[c] = r;
   }
-  out[(int64_t)12 * a.P] = m;
-  out[(int64_t)13 * a.P] = ms;
+  if (grp == 0) {
+    out[(int64_t)12 * a.P] = m;
+    out[(int64_t)13 * a.P] = ms;
+  }
   if (a.disc_rgb != nullptr) {                       // (csrc/train_misc.hip disc_inputs_kernel on the values this thread has just formed)
     const int nc = a.disc_geo ? 9 : 3;
-    const float pad = (ms == 1.f && m == 0.f) ? 1.f : 0.f;
     float* real = a.disc_real + (int64_t)b * nc * a.P + p;
     float* fake = a.disc_fake + (int64_t)b * nc * a.P + p;
+    if (grp == 0) {
+      const float pad = (ms == 1.f && m == 0.f) ? 1.f : 0.f;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      const float r = a.disc_rgb[q * 3 + c];
-      real[(int64_t)c * a.P] = tp::add_rn(tp::mul_rn(val[c], m), tp::mul_rn(r, pad));
-      fake[(int64_t)c * a.P] = r;
-    }
-    if (a.disc_geo)
-#pragma unroll
-      for (int c = 0; c < 6; ++c) {
-        real[(int64_t)(3 + c) * a.P] = val[6 + c];
-        fake[(int64_t)(3 + c) * a.P] = val[6 + c];
+      for (int c = 0; c < 3; ++c) {
+        const float r = a.disc_rgb[q * 3 + c];
+        real[(int64_t)c * a.P] = tp::add_rn(tp::mul_rn(val[c], m), tp::mul_rn(r, pad));
+        fake[(int64_t)c * a.P] = r;
       }
+    } else if (grp >= 2 && a.disc_geo) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        real[(int64_t)(3 * (grp - 1) + c) * a.P] = val[c];
+        fake[(int64_t)(3 * (grp - 1) + c) * a.P] = val[c];
+      }
+    }
+  }
   }
 }
 
@@ -91,8 +102,10 @@ extern "C" int tp_patch_gather(const tp_patch_gather_args* a, tp_stream_t stream
                  a->out, "null pointer");
   TP_REQUIRE(a->B > 0 && a->P > 0 && a->H > 0 && a->W > 0, "bad sizes");
   TP_REQUIRE(a->disc_rgb == nullptr || (a->disc_real && a->disc_fake), "disc_rgb given: disc_real and disc_fake expected");
-  const int64_t total = (int64_t)a->B * a->P;
+  const bool split = (int64_t)a->B * a->P <= 16384;
+  const int64_t total = (int64_t)a->B * a->P * (split ? 4 : 1);
   const unsigned blocks = (unsigned)((total + 255) / 256);
-  hipLaunchKernelGGL(patch_gather_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *a, (blocks % 8 == 0 && blocks >= 16) ? 1 : 0);
+  if (split) hipLaunchKernelGGL(patch_gather_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *a, (blocks % 8 == 0 && blocks >= 16) ? 1 : 0);
+  else hipLaunchKernelGGL(patch_gather_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *a, (blocks % 8 == 0 && blocks >= 16) ? 1 : 0);
   return tp::check_launch("tp_patch_gather");
 }
