@@ -497,7 +497,42 @@ def train_leg(device, rank, world):
                                    "replayed step (its other kernels, ~80 us, included: a lower bound); every product is three f16 "
                                    "MFMAs; pair_replay = tp_mlp_fwd + tp_mlp_bwd alone, 10 pairs replayed from a hipGraph, split by "
                                    "eager HIP-event brackets"}
+        try:
+            out["c4_form"] = c4_form_leg(device)
+        except Exception as exc:                     # (reported in the line; the one-rank figures above stand on their own)
+            import traceback
+            traceback.print_exc(file=sys.stderr)
+            out["c4_form"] = {"error": repr(exc)[:400]}
     return out
+
+
+def c4_form_leg(device, iters=40):
+    """The training step SEVERAL ranks run (config C4's per-GPU share: 4 images), timed on this ONE GPU: a 1-rank RCCL communicator
+    with the gradient all-reduces forced on, i.e. the linear graphs with [gradients, pack] | real RCCL call | [optimiser] for both
+    optimiser steps.  What the form costs against `full_gan_loop` (the one-rank form) before a byte crosses xGMI; `collective_ms` =
+    HIP events around the two RCCL calls of an iteration."""
+    import gc
+    import socket
+    import torch.distributed as dist
+    import train_dp
+    made = not dist.is_initialized()
+    if made:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=device)
+    try:
+        r = train_dp.measure(device, 0, 1, global_batch=4, iters=iters, warm=4, graphed=True, full=True, force_collectives=True)
+        keep = {k: r[k] for k in ("value", "ms_per_iter", "form", "launches", "launch_counts", "collective_ms", "collective_ms_by_step",
+                                  "ranks_seen", "launch", "collective", "finite", "skipped_steps")}
+        keep["note"] = ("ONE GPU, 1-rank RCCL communicator, collectives forced: the step several ranks run (per-GPU share of C4), "
+                        "nothing crosses xGMI")
+        return keep
+    finally:
+        gc.collect()
+        torch.cuda.synchronize()
+        if made:
+            dist.destroy_process_group()
 
 
 def eval_masked_leg(device, graph, opt, sc, images=3, mask_frac=0.10):
@@ -845,6 +880,13 @@ def main():
             rl["train_c3_launches"] = full.get("launches")
             if "nerf_step_b4" in train:
                 rl["train_c3_nerf_step_it_per_s"] = train["nerf_step_b4"]["value"]
+            c4 = train.get("c4_form")
+            if c4 and "error" not in c4:
+                # the several-rank form of the same iteration on this one GPU (1-rank RCCL communicator, collectives forced)
+                rl["train_c4_form_it_per_s"] = c4["value"]
+                rl["train_c4_form_launches"] = c4.get("launches")
+                rl["train_c4_form_collective_ms"] = c4.get("collective_ms")
+                rl["train_c4_form_over_c3"] = c4["value"] / full["value"]
         line = {}
         # the verbose legs FIRST, the contract keys and a compact summary LAST: the driver keeps the tail of stdout
         if hbm is not None:
@@ -901,6 +943,9 @@ def main():
                 "nerf_step_it_per_s": r3(rl.get("train_c3_nerf_step_it_per_s")),
                 "queues": (train["full_gan_loop"].get("queues") or {}).get("concurrent"),
                 "collective_ms": r3(train.get("collective_ms"))},
+            "c4_form": None if "train_c4_form_it_per_s" not in rl else {
+                "it_per_s": r3(rl["train_c4_form_it_per_s"]), "launches": rl["train_c4_form_launches"],
+                "collective_ms": r3(rl["train_c4_form_collective_ms"]), "over_train_c3": r3(rl["train_c4_form_over_c3"])},
             "cpu": None if cpu is None or "error" in cpu else {"rays_per_s": r3(cpu["value"]), "cores": cpu["cores"],
                                                                "gpu_over_cpu": r3(value / cpu["value"])},
             "legs_failed": list(legs_failed),

@@ -26,7 +26,7 @@ extern "C" {
 
 typedef void* tp_stream_t; /* hipStream_t */
 
-#define TP_ABI_VERSION 10
+#define TP_ABI_VERSION 11
 
 int tp_abi_version(void);
 const char* tp_last_error(void);
@@ -583,6 +583,18 @@ typedef struct tp_step_copy { void* dst; const void* src; int64_t bytes; } tp_st
 int tp_step_inputs(const tp_step_copy* copies /* host array */, int n_copies, float* const* scalar_dst /* host array */,
                    const float* scalar_val /* host array */, int n_scalars, const int32_t* words_src, int32_t* words_dst, int n_words,
                    tp_stream_t stream);
+/* Data parallel (no reference counterpart: options.py:112 asserts a single GPU; BASELINE.json config C4): the gradients of ONE
+ * optimiser step into the flat fp32 buffer that one RCCL all-reduce sums -- flat[concatenation of the n tensors] = scale * grads[k]
+ * (grads[k] NULL: zeros; scale = 1 / world, so the sum is the average) -- and the step-gate words into the buffer's tail as 0 / 1 floats:
+ * tail[j] = (words[j] != 0 || tail[j] != 0) for j < n_words (words may be NULL).  The tail is STICKY: after the all-reduce it is
+ * non-zero on every rank if any rank set it, in this or an earlier step, and read as int32 words it is the gate tp_adam_step /
+ * tp_rmsprop_step take.  One launch. */
+#define TP_GRAD_PACK_MAX_TENSORS 32
+int tp_grad_pack(const float* const* grads /* host array */, const int64_t* numel /* host array */, int n, float* flat, float scale,
+                 const int32_t* words, int n_words, float* tail, tp_stream_t stream);
+/* Diagnostic (no reference counterpart): number of nodes (kernel launches, fills, copies) recorded so far in the hipGraph that `stream`
+ * is capturing into, -1 when it is not capturing (the launch counts of a captured training iteration). */
+int64_t tp_capture_node_count(tp_stream_t stream);
 /* Diagnostic (no reference counterpart): the device's 100 MHz constant clock written to *slot by a one-thread launch in stream order. */
 int tp_stamp(uint64_t* slot, tp_stream_t stream);
 /* Diagnostic (no reference counterpart): one sleeping wave samples the shader clock against the 100 MHz constant clock over `windows`

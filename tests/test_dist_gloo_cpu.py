@@ -182,10 +182,10 @@ def _trainer_worker(rank, world, port, out_dir):
     tr = GanTrainer(opt, graph, n_train=6, max_iter=10)
     calls = []
     for name, red in (("nerf", tr.red_nerf), ("disc", tr.red_disc)):
-        def wrapped(orig=red.reduce, name=name, red=red):
+        def wrapped(orig=red.all_reduce, name=name, red=red):
             calls.append((name, [p.grad is not None for p in red.params].count(True)))
             return orig()
-        red.reduce = wrapped
+        red.all_reduce = wrapped
     full = training_batch(TB, TH, TH, n_train=6, seed=3, device="cpu")
     mine = tdist.shard_training_batch(full, rank, world)
     start = {k: v.detach().clone() for k, v in graph.state_dict().items()}
@@ -227,6 +227,132 @@ def test_data_parallel_trainer_glue(tmp_path):
         moved += int(not torch.equal(r0["end"][k], r0["start"][k]))
     assert moved >= n_heads + 6
     assert all(torch.equal(r0["end"][k], r0["start"][k]) for k in r0["end"] if k.startswith("nerf.mlp_feat"))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# DP(2 x B/2) == single(B): the several-rank step's data path -- gradients scaled by 1 / world into the flat buffer (pack), ONE SUM
+# all-reduce, the optimiser reading the buffer's views (adopt) -- against ONE process on the whole batch with the same patch
+# coordinates and stratified draws.  The hipGraph segments of trainer.GraphedGanTrainer need the GPU; what they capture around
+# the collective are these same three FlatGradAllReducer calls (tests/test_gpu_parity.py::test_linear_form_with_all_reduces_between_
+# graphs_is_bit_identical runs them captured, in a 1-rank RCCL group).
+# ---------------------------------------------------------------------------------------------------------------------
+def _dp_equiv_setup(world, rank):
+    from texpose_amd.options import AttrDict, default_options
+    from texpose_amd.synthetic import training_batch
+    from texpose_amd.trainer import GanTrainer
+    opt = default_options(H=TH, W=TH, device="cpu")
+    opt.batch_size, opt.patch_size, opt.nerf.sample_intvs = TB // world, 16, TN
+    opt.loss_weight.feat = None
+    torch.manual_seed(11)
+    graph = _oracle_backed_graph(opt)
+    graph.attach_latents(6, opt)
+    graph.train()
+    tr = GanTrainer(opt, graph, n_train=6, max_iter=10)
+    full = training_batch(TB, TH, TH, n_train=6, seed=3, device="cpu")
+    full.obj_mask = torch.ones_like(full.obj_mask)           # equal photometric normalisers on every shard (dist.setup_data_parallel)
+    gen = torch.Generator().manual_seed(5)
+    patch_u = torch.rand(3, TB, 1, 1, 1, generator=gen)
+    jitter = torch.rand(TB, 256, TN, 1, generator=gen)
+    sl = tdist.shard_batch(TB, rank, world)
+    mine = tdist.shard_training_batch(full, rank, world)
+    mine.patch_u, mine.jitter_rand = patch_u[:, sl.start:sl.stop].contiguous(), jitter[sl.start:sl.stop].contiguous()
+    grads = {}
+    for name, optim, params in (("nerf", tr.optim_nerf, tr.nerf_group), ("disc", tr.optim_disc, tr.disc_group)):
+        def step(orig=optim.step, name=name, params=params):
+            grads.setdefault(name, [None if p.grad is None else p.grad.detach().clone() for p in params])     # (first iteration's)
+            return orig()
+        optim.step = step
+    return tr, graph, AttrDict(dict(mine)), grads
+
+
+def _dp_equiv_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    tdist.init_distributed("gloo")
+    tr, graph, mine, grads = _dp_equiv_setup(world, rank)
+    start = {k: v.detach().clone() for k, v in graph.state_dict().items()}
+    for _ in range(2):
+        tr.train_iteration(type(mine)(dict(mine)))
+    flat_backed = all(p.grad is None or p.grad.data_ptr() == v.data_ptr() for red in (tr.red_nerf, tr.red_disc)
+                      for p, v in zip(red.params, red.views))
+    torch.save(dict(start=start, end={k: v.detach().clone() for k, v in graph.state_dict().items()}, grads=grads,
+                    flat_backed=flat_backed), os.path.join(out_dir, f"dp_equiv_rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_two_ranks_on_half_batches_equal_one_process_on_the_whole_batch(tmp_path):
+    world = 2
+    mp.spawn(_dp_equiv_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = (torch.load(tmp_path / f"dp_equiv_rank{r}.pt") for r in range(world))
+    torch.set_num_threads(4)
+    tr, graph, whole, grads = _dp_equiv_setup(1, 0)
+    start = {k: v.detach().clone() for k, v in graph.state_dict().items()}
+    for _ in range(2):
+        tr.train_iteration(type(whole)(dict(whole)))
+    end = {k: v.detach().clone() for k, v in graph.state_dict().items()}
+    assert r0["flat_backed"] and r1["flat_backed"]                       # the optimisers read the averaged gradients in the flat buffers
+    for k in start:
+        assert torch.equal(start[k], r0["start"][k]) and torch.equal(r0["end"][k], r1["end"][k]), k
+    # first-iteration gradients: average over the ranks of the half-batch gradients == the whole-batch gradient
+    n_checked = 0
+    for name in ("nerf", "disc"):
+        for g_dp, g_dp1, g_one in zip(r0["grads"][name], r1["grads"][name], grads[name]):
+            assert (g_dp is None) == (g_one is None)
+            if g_one is None:
+                continue
+            assert torch.equal(g_dp, g_dp1)
+            scale = float(g_one.abs().max())
+            if name == "nerf" and g_one.dim() == 2 and g_one.shape[0] == 6:
+                # (latent tables: each rank touches its own images' rows; the other rows are zero on it)
+                assert float((g_dp != 0).any(dim=1).sum()) == float((g_one != 0).any(dim=1).sum())
+            torch.testing.assert_close(g_dp, g_one, rtol=2e-4, atol=2e-6 * max(scale, 1e-30))
+            n_checked += 1
+    assert n_checked == 18 + 6
+    # ... and two optimiser steps later the parameters have moved alike (Adam / RMSprop normalise every entry: compare the bulk)
+    moved = 0
+    for k in end:
+        if not end[k].dtype.is_floating_point or torch.equal(end[k], start[k]) or k.endswith(("weight_u", "weight_v")):
+            continue
+        da, db = (end[k] - start[k]).double().flatten(), (r0["end"][k] - start[k]).double().flatten()
+        assert float((da - db).norm() / da.norm()) < 0.05, (k, float((da - db).norm() / da.norm()))
+        moved += 1
+    assert moved >= 18 + 6
+
+
+def _tail_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    tdist.init_distributed("gloo")
+    ps = [torch.nn.Parameter(torch.zeros(5, 3)), torch.nn.Parameter(torch.zeros(4))]
+    red = tdist.FlatGradAllReducer(ps)
+    seen = []
+    for it in range(4):
+        ps[0].grad = torch.full((5, 3), float(rank + 1 + it))
+        ps[1].grad = None
+        words = torch.zeros(3, dtype=torch.int32)
+        if it == 1 and rank == 1:
+            words[1] = 1                              # ONE rank raises a gate word in ONE iteration
+        red.pack(flags=words)
+        red.all_reduce()
+        red.adopt()
+        seen.append((red.gate_words.ne(0).tolist(), float(ps[0].grad[0, 0]), ps[1].grad is None, float(red.views[1].abs().sum())))
+        if it == 2:
+            red.clear_gate()                          # (what the trainer does once the host has acted on the words)
+    torch.save(seen, os.path.join(out_dir, f"tail_rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gate_words_in_the_tail_are_job_wide_and_sticky(tmp_path):
+    """The tail of the flat buffer: a word raised by one rank in one iteration is non-zero on EVERY rank from that all-reduce on (the
+    optimiser launches of both ranks are withheld together, and stay withheld) until it is cleared; the gradients are the average."""
+    world = 2
+    mp.spawn(_tail_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = (torch.load(tmp_path / f"tail_rank{r}.pt") for r in range(world))
+    assert r0 == r1
+    assert [s[0] for s in r0] == [[False] * 4, [False, True, False, False], [False, True, False, False], [False] * 4]
+    assert [s[1] for s in r0] == [1.5, 2.5, 3.5, 4.5] and all(s[2] and s[3] == 0.0 for s in r0)
 
 
 def _guard_worker(rank, world, port, out_dir):
@@ -289,26 +415,61 @@ def test_shard_training_batch_slices_only_per_sample_entries():
         tdist.shard_training_batch(AttrDict(idx=torch.arange(B), image=torch.zeros(B + 1, 3, 4, 4)), 0, 3)
 
 
-def test_graphed_trainer_selects_two_graphs_and_eager_collectives_for_several_ranks(monkeypatch):
-    """What `world > 1` selects in GraphedGanTrainer (host logic, no GPU): the two-graph form with the gradient all-reduces
-    issued eagerly between the replays; TP_COLLECTIVES_IN_GRAPH is off unless set; a single rank keeps one graph."""
-    from texpose_amd.options import default_options
+def test_graphed_trainer_form_selection_for_several_ranks(monkeypatch):
+    """What `world > 1` selects in GraphedGanTrainer (host logic, no GPU).  A configuration the linear graphs cover gets them WITH the
+    collectives (`_dp`: gradients + pack | all-reduce | optimiser graph, gates = the tails of the flat buffers); anything else gets the
+    generic two-graph form with the eager all-reduces between the replays; a single rank keeps the one-rank forms and the `_bad`
+    snapshots as gates.  TP_COLLECTIVES_IN_GRAPH only moves the RCCL calls into the graphs, TP_NO_LINEAR_DP opts out."""
+    from texpose_amd.options import default_options, AttrDict
+    from texpose_amd.gan_modules import Discriminator
     from texpose_amd.graph import Graph
-    from texpose_amd.trainer import GraphedGanTrainer
-    for var in ("TP_COLLECTIVES_IN_GRAPH", "TP_SPLIT_GRAPH", "TP_NO_BRANCH_OVERLAP"):
+    from texpose_amd.trainer import FusedAdam, FusedRMSprop, GraphedGanTrainer
+    for var in ("TP_COLLECTIVES_IN_GRAPH", "TP_SPLIT_GRAPH", "TP_NO_BRANCH_OVERLAP", "TP_NO_LINEAR_DP"):
         monkeypatch.delenv(var, raising=False)
+    # (a) no discriminator: never linear
     opt = default_options(H=32, W=32, device="cpu")
     opt.loss_weight.feat = opt.loss_weight.gan_nerf = None
     opt.gan = None
     g = Graph(opt)
     g.attach_latents(4, opt)
     tr = GraphedGanTrainer(opt, g, n_train=4)
-    assert os.environ.get("TP_COLLECTIVES_IN_GRAPH") is None
+    batch = AttrDict(idx=torch.arange(2))
     assert not tr._split_around_collectives() and not tr._has_collective()          # one rank: one graph, no collective
+    tr._select_form(batch)
+    assert not (tr._four or tr._linear or tr._dp)
     monkeypatch.setattr(tdist.FlatGradAllReducer, "world_size", property(lambda self: 2))
     assert tr._has_collective() and tr._split_around_collectives()                   # several ranks: A | reduce | B
+    tr._select_form(batch)
+    assert not (tr._four or tr._linear or tr._dp)
     monkeypatch.setenv("TP_COLLECTIVES_IN_GRAPH", "1")
     assert tr._has_collective() and not tr._split_around_collectives()               # opt-in only
+    monkeypatch.delenv("TP_COLLECTIVES_IN_GRAPH")
+    # (b) the full GAN iteration, as the GPU sees it (the predicates that need the HIP kernels are answered "yes" here)
+    opt = default_options(H=32, W=32, device="cpu")
+    g = Graph(opt, discriminator=Discriminator(opt))
+    g.attach_latents(4, opt)
+    tr = GraphedGanTrainer(opt, g, n_train=4)
+    monkeypatch.setattr(GraphedGanTrainer, "_use_four_graphs", lambda self, var: True)
+    monkeypatch.setattr(GraphedGanTrainer, "_use_linear_graphs", lambda self, var: True)
+    tr.optim_nerf = FusedAdam([dict(params=tr.nerf_group, lr=tr.lr_nerf_used)], capturable=True)
+    tr.optim_disc = FusedRMSprop([dict(params=tr.disc_group, lr=tr.lr_disc_used)], capturable=True)
+    tr._select_form(batch)
+    assert tr._linear and tr._dp
+    assert tr.optim_nerf.gate.data_ptr() == tr.red_nerf.gate_words.data_ptr() and tr.optim_nerf.gate.dtype == torch.int32
+    assert tr.optim_disc.gate.data_ptr() == tr.red_disc.gate_words.data_ptr() and len(tr.optim_disc.gate) == 3
+    assert tr._poll_words().data_ptr() == tr.red_nerf.gate_words.data_ptr()
+    monkeypatch.setenv("TP_NO_LINEAR_DP", "1")
+    tr._select_form(batch)
+    assert not (tr._four or tr._linear or tr._dp) and tr.optim_nerf.gate is tr._gate_nerf      # the generic two-graph form
+    monkeypatch.delenv("TP_NO_LINEAR_DP")
+    monkeypatch.setattr(tdist.FlatGradAllReducer, "world_size", property(lambda self: 1))
+    tr._select_form(batch)
+    assert tr._linear and not tr._dp and tr.optim_nerf.gate is tr._gate_nerf and tr.optim_disc.gate is tr._gate_disc
+    assert tr._poll_words() is tr._bad
+    # the job-wide gate state of the `_dp` form is read from the two tails
+    tr._dp = True
+    tr.red_disc.flag_tail[2] = 2.0                   # (two ranks raised word 2)
+    assert tr._read_bad(blocking=True) == [0, 0, 1]
 
 
 # ------------------------------------------------------------------------------------------ round 4: multi-GPU readiness without hardware

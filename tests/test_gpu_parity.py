@@ -1521,6 +1521,111 @@ def test_pipelined_discriminator_tail_is_bit_identical(ops):
         assert all(torch.equal(a, b) for a, b in zip(out[0][2], other[2])) and len(out[0][2]) > 0
 
 
+def test_linear_form_with_all_reduces_between_graphs_is_bit_identical(ops):
+    """The several-rank training step (trainer `_dp`): the linear graphs of the one-rank step with each optimiser launch as a graph of
+    its own behind ONE flat all-reduce -- [gradients, tp_grad_pack] | RCCL all-reduce | [Adam / RMSprop reading the flat buffer, gated by
+    its tail].  Run here in a 1-rank RCCL communicator with the collectives forced on: (a) stream-ordered calls between the replays (the
+    default with several ranks), (b) captured into the gradient graphs (TP_COLLECTIVES_IN_GRAPH).  With one rank the scale is 1 and the
+    sum is the identity, so eight iterations must leave parameters, buffers, optimiser state and losses BIT-IDENTICAL to the one-rank
+    linear form (whose discriminator step ends inside the spectral-norm backward's launches: same arithmetic, other launches).  Also: the
+    pipelined / deferred modes on the new form, the launch counts, the gate words read from the tails."""
+    import torch.distributed as dist
+    from texpose_amd.gan_modules import Discriminator, PerceptualLoss
+    from texpose_amd.graph import Graph
+    from texpose_amd.options import default_options, AttrDict
+    from texpose_amd.synthetic import training_batch
+    from texpose_amd.trainer import GraphedGanTrainer
+    made_group = not dist.is_initialized()
+    if made_group:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29519")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev())
+    out, tr, graph = [], None, None
+    try:
+        for mode in ("one_rank", "between", "between_pipelined", "in_graph"):
+            os.environ.pop("TP_COLLECTIVES_IN_GRAPH", None)
+            if mode == "in_graph":
+                os.environ["TP_COLLECTIVES_IN_GRAPH"] = "1"
+            torch.manual_seed(0)
+            opt = default_options(H=128, W=128, device="cuda:0")
+            opt.batch_size, opt.patch_size, opt.nerf.sample_intvs = 4, 16, 64
+            graph = Graph(opt, discriminator=Discriminator(opt), perceptual_loss=PerceptualLoss()).to(dev())
+            tr = GraphedGanTrainer(opt, graph, n_train=189)
+            forced = mode != "one_rank"
+            tr.red_nerf.single_rank_collective = tr.red_disc.single_rank_collective = forced
+            tr.pipeline_disc_tail = tr.defer_results = mode == "between_pipelined"
+            batches = [training_batch(4, 128, 128, seed=s_, device="cuda:0") for s_ in range(2)]
+            for it in range(8):
+                _, loss = tr.train_iteration(AttrDict(dict(batches[it % 2])))
+            assert tr._linear and tr._dp == forced and "D2a" in tr._g4
+            assert ("G2c" in tr._g4 and "D2c" in tr._g4) == (mode in ("between", "between_pipelined"))
+            assert tr.finish() == [0, 0, 0]
+            torch.cuda.synchronize()
+            if forced:
+                assert tr.optim_nerf.gate.data_ptr() == tr.red_nerf.gate_words.data_ptr()
+                assert int(tr.red_nerf.gate_words.abs().sum()) == 0 and int(tr.red_disc.gate_words.abs().sum()) == 0
+                # the averaged gradients live in the flat buffers: the optimisers read them there
+                assert all(p.grad is None or p.grad.data_ptr() == v.data_ptr() for p, v in zip(tr.red_disc.params, tr.red_disc.views))
+                assert sum(p.grad is not None for p in tr.red_disc.params) == 6 and graph.discriminator.progress.grad is None
+            counts = dict(tr.launch_counts)
+            assert all(v is not None and v > 0 for v in counts.values()), counts
+            out.append(({k: v.clone() for k, v in graph.state_dict().items()}, {k: v.clone() for k, v in loss.items() if torch.is_tensor(v)},
+                        {(oi, pi, name): t.clone() for oi, o in enumerate((tr.optim_nerf, tr.optim_disc))
+                         for pi, p in enumerate(q for gr in o.param_groups for q in gr["params"]) if p in o.state
+                         for name, t in o.state[p].items() if torch.is_tensor(t)},
+                        sum(counts.values())))
+        for other in out[1:]:
+            for k in out[0][0]:
+                assert torch.equal(out[0][0][k], other[0][k]), k
+            for k in out[0][1]:
+                assert torch.equal(out[0][1][k], other[1][k]), k
+            assert out[0][2].keys() == other[2].keys() and len(out[0][2]) > 40
+            for k in out[0][2]:
+                assert torch.equal(out[0][2][k], other[2][k]), k
+        # what the form costs in launches: the total / RMSprop pair the one-rank step folds into the spectral-norm backward, and two packs
+        assert out[0][3] < out[1][3] <= out[0][3] + 6, [o[3] for o in out]
+    finally:
+        os.environ.pop("TP_COLLECTIVES_IN_GRAPH", None)
+        tr = graph = None                       # (captured graphs that contain RCCL kernels go before the communicator does)
+        import gc
+        gc.collect()
+        torch.cuda.synchronize()
+        if made_group:
+            dist.destroy_process_group()
+
+
+def test_grad_pack_kernel(ops):
+    """K13 tp_grad_pack: flat = scale * concatenation of the gradients (None: zeros), sticky 0 / 1 tail from int32 words; through
+    FlatGradAllReducer.pack and against the CPU form of the same method."""
+    from texpose_amd import dist as tdist
+    rs = np.random.RandomState(0)
+    shapes = [(64, 99), (3,), (128, 64), (1, 128), (189, 16), (7,)] + [(5, 3)] * 40          # (46 tensors: two launches)
+    ps_c = [torch.nn.Parameter(torch.from_numpy(rs.normal(size=sh).astype(np.float32))) for sh in shapes]
+    ps_g = [torch.nn.Parameter(cu(p.detach())) for p in ps_c]
+    for i, (a, b) in enumerate(zip(ps_c, ps_g)):
+        if i % 5 != 1:
+            a.grad = torch.from_numpy(rs.normal(size=tuple(a.shape)).astype(np.float32))
+            b.grad = cu(a.grad)
+    rc, rg = tdist.FlatGradAllReducer(ps_c), tdist.FlatGradAllReducer(ps_g)
+    orig = tdist.FlatGradAllReducer.world_size
+    tdist.FlatGradAllReducer.world_size = property(lambda self: 8)              # (as if in a job of eight ranks: scale 1 / 8)
+    try:
+        for words in ([0, 0, 0], [0, 1, 0], [0, 0, 0], [1, 0, 0]):
+            rc.flat[:-4].fill_(7.0); rg.flat[:-4].fill_(7.0)
+            rc.pack(torch.tensor(words, dtype=torch.int32)); rg.pack(cu(torch.tensor(words, dtype=torch.int32)))
+            assert torch.equal(rg.flat.cpu(), rc.flat)
+        assert rg.gate_words.cpu().ne(0).tolist() == [True, True, False, False]          # sticky
+        assert torch.equal(rc.views[0], ps_c[0].grad / 8) and float(rc.views[1].abs().sum()) == 0
+        rg.clear_gate()
+        rg.pack(None)
+        assert rg.gate_words.cpu().tolist() == [0, 0, 0, 0]
+        rg.adopt()
+        assert all((p.grad is None) == (i % 5 == 1) and (p.grad is None or p.grad.data_ptr() == v.data_ptr())
+                   for i, (p, v) in enumerate(zip(rg.params, rg.views)))
+    finally:
+        tdist.FlatGradAllReducer.world_size = orig
+
+
 def assert_updates_close(sd_a, sd_b, snap, rel=0.05, frac=0.01):
     """Parameter UPDATES of two training runs that should agree up to fp32 noise.  Adam / RMSprop normalise every entry,
     so a gradient entry at the noise floor can take a different +-lr step: compare the bulk of each update (relative L2)

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # TEXPOSE_AMD_LIB selects another build of the SAME library (e.g. the `make trace` diagnostic build); never a fallback
 LIB_PATH = os.environ.get("TEXPOSE_AMD_LIB") or os.path.join(_HERE, "libtexpose_amd.so")
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 # Every symbol include/texpose_amd.h declares (checked by tests/test_capi_cpu.py).
 SYMBOLS = (
@@ -31,7 +31,7 @@ SYMBOLS = (
     "tp_conv4s2_workspace", "tp_conv4s2_fwd", "tp_conv4s2_dgrad", "tp_conv4s2_wgrad", "tp_conv4s2_fwd_inorm_workspace", "tp_conv4s2_fwd_inorm",
     "tp_conv4s2_fwd_inorm_pair", "tp_conv4s2_dgrad_pair", "tp_conv4s2_wgrad_pair",
     "tp_conv3s1_workspace", "tp_conv3s1_fwd", "tp_conv3s1_dgrad",
-    "tp_patch_coords", "tp_bce_logits_fwd", "tp_bce_logits_bwd", "tp_feat_inputs_fwd", "tp_feat_inputs_bwd", "tp_disc_inputs", "tp_step_flags", "tp_adam_step", "tp_step_inputs", "tp_stamp", "tp_clock_probe",
+    "tp_patch_coords", "tp_bce_logits_fwd", "tp_bce_logits_bwd", "tp_feat_inputs_fwd", "tp_feat_inputs_bwd", "tp_disc_inputs", "tp_step_flags", "tp_adam_step", "tp_step_inputs", "tp_grad_pack", "tp_capture_node_count", "tp_stamp", "tp_clock_probe",
     "tp_fake_patch_bwd", "tp_feat_pair_loss_fwd", "tp_feat_pair_loss_bwd", "tp_sumsq_mean_fwd", "tp_sumsq_mean_bwd", "tp_sumsq_mean_fwd_bwd", "tp_gan_disc_losses", "tp_maxpool2_fwd", "tp_maxpool2_bwd", "tp_latent_rows_fwd",
     "tp_latent_rows_bwd", "tp_weighted_sum", "tp_weighted_sum_flags", "tp_sn_bwd_step",
     "tp_disc_head_fwd", "tp_disc_head_bwd", "tp_disc_head_bwd_bwd",
@@ -127,6 +127,7 @@ class AdamTensor(C.Structure):
 
 
 ADAM_MAX_TENSORS = 32
+GRAD_PACK_MAX_TENSORS = 32
 CONV_FWD, CONV_DGRAD, CONV_WGRAD = 0, 1, 2
 
 
@@ -260,6 +261,8 @@ def load() -> C.CDLL:
     sig("tp_stamp", [vp, vp])
     sig("tp_clock_probe", [vp, C.c_int, C.c_int64, vp])
     sig("tp_step_inputs", [C.POINTER(StepCopy), C.c_int, C.POINTER(vp), C.POINTER(C.c_float), C.c_int, vp, vp, C.c_int, vp])
+    sig("tp_grad_pack", [C.POINTER(vp), C.POINTER(C.c_int64), C.c_int, vp, C.c_float, vp, C.c_int, vp, vp])
+    sig("tp_capture_node_count", [vp], C.c_int64)
     sig("tp_adam_step", [C.POINTER(AdamTensor), C.c_int, vp, C.c_double, C.c_double, C.c_double, C.c_double, vp, C.c_int, vp, vp])
     sig("tp_conv4s2_workspace", [C.POINTER(Conv4s2Args), C.c_int, C.POINTER(C.c_int64)], C.c_int64)
     sig("tp_conv4s2_fwd_inorm_workspace", [C.POINTER(Conv4s2Args), C.POINTER(C.c_int64)], C.c_int64)

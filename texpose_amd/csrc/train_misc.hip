@@ -261,6 +261,40 @@ __global__ __launch_bounds__(kBlock) void adam_kernel(AdamTable t, const float* 
   }
 }
 
+// ---- data parallel (no reference counterpart: options.py:112 asserts one GPU): the gradients of one optimiser step into the flat
+// all-reduce buffer, pre-scaled by 1 / world (the SUM all-reduce then leaves the average), and the step-gate words into the buffer's
+// tail as 0 / 1 floats -- STICKY: a tail word that is non-zero stays non-zero, so after the all-reduce the tail is the job-wide gate
+// of this and every later step until the host clears it.  One launch (torch: a multi-tensor copy, a scale, a compare + copy).
+struct GradPack {
+  const float* src[TP_GRAD_PACK_MAX_TENSORS];     // NULL: this rank has no gradient for the tensor (zeros)
+  int64_t end[TP_GRAD_PACK_MAX_TENSORS];
+  int n;
+};
+__global__ __launch_bounds__(kBlock) void grad_pack_kernel(GradPack t, float* __restrict__ flat, int64_t total, float scale,
+                                                           const int* __restrict__ words, int n_words, float* __restrict__ tail) {
+  if (blockIdx.x == 0 && (int)threadIdx.x < n_words) {
+    const bool set = (words != nullptr && words[threadIdx.x] != 0) || tail[threadIdx.x] != 0.f;
+    tail[threadIdx.x] = set ? 1.f : 0.f;
+  }
+  constexpr int kU = 4;
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t e0 = (int64_t)blockIdx.x * kBlock + threadIdx.x; e0 < total; e0 += kU * stride) {
+    float g[kU]; bool live[kU];
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      const int64_t e = e0 + u * stride;
+      live[u] = e < total;
+      int k = 0;
+      while (live[u] && e >= t.end[k]) ++k;
+      const float* s = live[u] ? t.src[k] : nullptr;
+      g[u] = s != nullptr ? s[e - (k == 0 ? 0 : t.end[k - 1])] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < kU; ++u)
+      if (live[u]) flat[e0 + u * stride] = tp::mul_rn(g[u], scale);
+  }
+}
+
 // ---- feature loss of the generator step (model/nerf_adapt_st_gan.py:762-766; layers/perceptual_loss.py:39-45):
 // feat [4n] = features of [fake1 | fake2 | real1 | real2]; l1 = mean((fake1 - real1)^2), l2 = mean((fake2 - real2)^2),
 // out = {l1 + w2 l2, l1, l2}.  One workgroup, fixed-order tree (torch: two mse_loss launches x 2 + mul + add).
@@ -474,6 +508,27 @@ int tp_step_inputs(const tp_step_copy* copies, int n_copies, float* const* scala
   return tp::check_launch("tp_step_inputs");
 }
 
+int tp_grad_pack(const float* const* grads, const int64_t* numel, int n, float* flat, float scale, const int32_t* words, int n_words,
+                 float* tail, tp_stream_t stream) {
+  TP_REQUIRE(grads != nullptr && numel != nullptr && flat != nullptr && n > 0 && n <= TP_GRAD_PACK_MAX_TENSORS, "bad tensor table");
+  TP_REQUIRE(n_words >= 0 && n_words <= 64 && (n_words == 0 || tail != nullptr), "bad gate-word arguments");
+  GradPack t;
+  int64_t total = 0;
+  for (int k = 0; k < n; ++k) {
+    TP_REQUIRE(numel[k] > 0, "empty tensor");
+    t.src[k] = grads[k];
+    total += numel[k];
+    t.end[k] = total;
+  }
+  for (int k = n; k < TP_GRAD_PACK_MAX_TENSORS; ++k) { t.src[k] = nullptr; t.end[k] = total; }
+  t.n = n;
+  int64_t blocks = (total + 4 * kBlock - 1) / (4 * kBlock);
+  if (blocks < 1) blocks = 1;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(grad_pack_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, t, flat, total, scale, words, n_words, tail);
+  return tp::check_launch("tp_grad_pack");
+}
+
 // Diagnostic: the device's constant-rate clock (100 MHz) into *slot, as a launch of its own -- placed between the segments of a captured
 // step it gives the step's timeline without a tracer slowing the host down (tools/linear_timeline.py).
 __global__ void stamp_kernel(unsigned long long* slot) { *slot = wall_clock64(); }
@@ -500,6 +555,20 @@ int tp_clock_probe(uint64_t* out, int windows, int64_t window_us, tp_stream_t st
   hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (unsigned long long*)out, windows,
                      (unsigned long long)window_us * 100ull);
   return tp::check_launch("tp_clock_probe");
+}
+
+// Diagnostic: nodes (kernel launches, fills, copies) recorded so far in the hipGraph `stream` is capturing into; -1 when it is not
+// capturing.  Asked of the HIP runtime THIS library is linked against (the one the capturing process already runs on).
+int64_t tp_capture_node_count(tp_stream_t stream) {
+  hipStreamCaptureStatus status = hipStreamCaptureStatusNone;
+  unsigned long long id = 0;
+  hipGraph_t graph = nullptr;
+  const hipGraphNode_t* deps = nullptr;
+  size_t n_deps = 0, n = 0;
+  if (hipStreamGetCaptureInfo_v2((hipStream_t)stream, &status, &id, &graph, &deps, &n_deps) != hipSuccess) { (void)hipGetLastError(); return -1; }
+  if (status != hipStreamCaptureStatusActive || graph == nullptr) return -1;
+  if (hipGraphGetNodes(graph, nullptr, &n) != hipSuccess) { (void)hipGetLastError(); return -1; }
+  return (int64_t)n;
 }
 
 int tp_stamp(uint64_t* slot, tp_stream_t stream) {

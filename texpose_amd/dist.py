@@ -34,7 +34,35 @@ def init_distributed(backend: Optional[str] = None) -> tuple:
     return rank, world, local
 
 
-_RANKS_SEEN = {}
+class _GroupCache:
+    """value per process group, keyed by the group OBJECT (an id() can be handed to a new group once the old one is destroyed);
+    the default group (None) has a slot of its own, dropped when the process group is destroyed and made again."""
+    def __init__(self):
+        import weakref
+        self._by_group, self._default = weakref.WeakKeyDictionary(), None
+
+    def _default_alive(self):
+        return self._default is not None and dist.is_initialized() and self._default[0] is dist.group.WORLD
+
+    def get(self, group):
+        if group is None:
+            return self._default[1] if self._default_alive() else None
+        try:
+            return self._by_group.get(group)
+        except TypeError:                      # (an object that cannot be weakly referenced: not cached)
+            return None
+
+    def put(self, group, value):
+        if group is None:
+            self._default = (dist.group.WORLD, value)
+            return
+        try:
+            self._by_group[group] = value
+        except TypeError:
+            pass
+
+
+_RANKS_SEEN = _GroupCache()
 
 
 def ranks_seen(group=None, device=None) -> int:
@@ -42,23 +70,24 @@ def ranks_seen(group=None, device=None) -> int:
     multi-GPU line of bench.py / tools carries, so that the record itself says whether the collective library saw N ranks.
     Also the WARM collective of a job: RCCL creates its channels, proxy threads and internal HIP streams on the first collective,
     and whatever picks streams by measurement afterwards (trainer.distinct_queue_streams) must run behind it
-    (`warm_collective_done`).  1 without a process group.  The value is cached per group."""
-    key = id(group)
-    if key in _RANKS_SEEN:
-        return _RANKS_SEEN[key]
+    (`warm_collective_done`).  1 without a process group.  The value is cached per group object."""
     if not (dist.is_available() and dist.is_initialized()):
         return 1
+    seen = _RANKS_SEEN.get(group)
+    if seen is not None:
+        return seen
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
     one = torch.ones(1, dtype=torch.float32, device=device)
     dist.all_reduce(one, op=dist.ReduceOp.SUM, group=group)
-    _RANKS_SEEN[key] = int(round(float(one)))
-    return _RANKS_SEEN[key]
+    seen = int(round(float(one)))
+    _RANKS_SEEN.put(group, seen)
+    return seen
 
 
 def warm_collective_done(group=None) -> bool:
     """True once `ranks_seen` has run its all-reduce on this group (or when there is no process group to warm up)."""
-    return id(group) in _RANKS_SEEN or not (dist.is_available() and dist.is_initialized())
+    return not (dist.is_available() and dist.is_initialized()) or _RANKS_SEEN.get(group) is not None
 
 
 def shard_batch(n_items: int, rank: int, world: int) -> range:
@@ -101,6 +130,72 @@ class FlatGradAllReducer:
     @property
     def world_size(self) -> int:
         return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
+
+    # ------------------------------------------------------------------ the step in three stream-ordered pieces
+    # pack | all_reduce | adopt: what a captured training step needs -- `pack` ends the graph that formed the gradients, the collective
+    # is an ordinary stream-ordered call (or a node of that graph), `adopt` opens the graph that holds the optimiser launch, which
+    # reads the averaged gradients straight from the flat buffer and the tail as its gate (trainer.GraphedGanTrainer, linear form).
+    @property
+    def gate_words(self) -> torch.Tensor:
+        """The tail as int32 words (a view): non-zero <=> some rank raised that gate word in this or an earlier step (0.0f is the
+        only float whose bits are zero here: the tail holds sums of 0 / 1).  What the fused optimiser launches take as ``gate``."""
+        return self.flag_tail.view(torch.int32)
+
+    @property
+    def active(self) -> bool:
+        """A collective is part of the step: several ranks, or a 1-rank group with the collective forced on."""
+        return dist.is_available() and dist.is_initialized() and (dist.get_world_size(self.group) > 1 or self.single_rank_collective)
+
+    def average(self) -> None:
+        """pack | all_reduce | adopt in one call (the eager trainer's step): afterwards every ``.grad`` is the job's average."""
+        if not self.active:
+            return
+        self.pack()
+        self.all_reduce()
+        self.adopt()
+
+    def clear_gate(self) -> None:
+        self.flag_tail.zero_()
+
+    def pack(self, flags: Optional[torch.Tensor] = None) -> None:
+        """``flat`` <- the gradients scaled by 1 / world (a parameter without one: zeros), tail <- sticky OR of ``flags`` (int32
+        words) as 0 / 1 floats.  GPU tensors: ONE launch (K13 tp_grad_pack); CPU tensors (gloo tests): the same values with torch ops."""
+        scale = 1.0 / self.world_size
+        # (a parameter takes part on all ranks or on none -- e.g. the discriminator's `progress` never has a gradient: `adopt` leaves
+        # such a parameter without one, so the optimiser makes no state for it, as in the reference)
+        self._packed = [p.grad is not None for p in self.params]
+        if self.flat.is_cuda:
+            from . import ops
+            ops.grad_pack([p.grad if p.grad is not None else (None, p.numel()) for p in self.params], self.flat, scale,
+                          words=flags, tail=self.flag_tail)
+            return
+        with torch.no_grad():
+            n = self.flag_tail.numel() if flags is None else flags.numel()
+            raised = self.flag_tail[:n] != 0
+            if flags is not None:
+                raised = raised | (flags != 0)
+            self.flag_tail[:n].copy_(raised)
+            for p, v in zip(self.params, self.views):
+                if p.grad is None:
+                    v.zero_()
+                else:
+                    torch.mul(p.grad, scale, out=v)
+
+    def all_reduce(self) -> None:
+        """SUM over the ranks of the packed buffer, on the current stream (nothing without a process group, or in a 1-rank group
+        unless the collective is forced)."""
+        if not (dist.is_available() and dist.is_initialized()):
+            return
+        if dist.get_world_size(self.group) == 1 and not self.single_rank_collective:
+            return
+        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+
+    def adopt(self) -> None:
+        """``.grad`` of every parameter that had a gradient at the last `pack` becomes its view of the flat buffer (the averaged
+        gradient; no copy back)."""
+        for p, v, had in zip(self.params, self.views, getattr(self, "_packed", [True] * len(self.params))):
+            if had:
+                p.grad = v
 
     def reduce(self, average: bool = True, flags: Optional[torch.Tensor] = None) -> None:
         """``flags`` (int32, at most FLAG_WORDS words; e.g. the sticky words of the captured step gate) travel in the tail of

@@ -1505,32 +1505,44 @@ def stamp(slots: torch.Tensor, i: int) -> None:
     check(_lib.load().tp_stamp(slots.data_ptr() + 8 * i, _stream()), "tp_stamp")
 
 
-_hip_runtime = []
-
-
 def capture_node_count(stream=None):
     """Number of nodes (kernel launches, fills, copies) recorded so far in the hipGraph that ``stream`` (default: the current one) is
-    capturing into, or None when it is not capturing: hipStreamGetCaptureInfo_v2 + hipGraphGetNodes on the runtime torch already
-    loaded.  The trainers report it per captured graph (`launch_counts`: the launches of one training iteration)."""
-    import ctypes
+    capturing into, or None when it is not capturing (tp_capture_node_count: hipStreamGetCaptureInfo_v2 + hipGraphGetNodes on the HIP
+    runtime the library is linked against -- the one this process already runs on).  The trainers report it per captured graph
+    (`launch_counts`: the launches of one training iteration)."""
     stream = stream or torch.cuda.current_stream()
-    if not _hip_runtime:
-        try:
-            _hip_runtime.append(ctypes.CDLL("libamdhip64.so"))
-        except OSError:
-            _hip_runtime.append(None)
-    hip = _hip_runtime[0]
-    if hip is None:
-        return None
-    status, gid, graph = ctypes.c_int(0), ctypes.c_ulonglong(0), ctypes.c_void_p(0)
-    deps, n_deps, n = ctypes.c_void_p(0), ctypes.c_size_t(0), ctypes.c_size_t(0)
-    rc = hip.hipStreamGetCaptureInfo_v2(ctypes.c_void_p(stream.cuda_stream), ctypes.byref(status), ctypes.byref(gid), ctypes.byref(graph),
-                                        ctypes.byref(deps), ctypes.byref(n_deps))
-    if rc != 0 or status.value != 1 or not graph.value:
-        return None
-    if hip.hipGraphGetNodes(graph, None, ctypes.byref(n)) != 0:
-        return None
-    return int(n.value)
+    n = int(_lib.load().tp_capture_node_count(stream.cuda_stream))
+    return None if n < 0 else n
+
+
+@_on_tensor_device
+def grad_pack(grads, flat: Tensor, scale: float, words: Optional[Tensor] = None, tail: Optional[Tensor] = None) -> None:
+    """The gradients of one optimiser step into the flat all-reduce buffer: flat[concatenation] = scale * grads[k] (``None`` entries:
+    ``numel`` zeros -- pass (None, numel)), and the gate words into the sticky tail (K13 tp_grad_pack, one launch per 32 tensors).
+    ``grads``: tensors, or (None, numel) pairs; ``words`` int32 device words, ``tail`` float32 view behind the gradients in ``flat``."""
+    lib = _lib.load()
+    rows, keep = [], []
+    for g in grads:
+        if isinstance(g, tuple):
+            rows.append((None, int(g[1])))
+            continue
+        g = _f32(g, "grad")
+        keep.append(g)
+        rows.append((g.data_ptr(), g.numel()))
+    if not flat.is_contiguous() or flat.dtype != torch.float32 or flat.numel() < sum(n for _, n in rows):
+        raise _lib.TexposeLibraryError("grad_pack: the flat buffer must be contiguous float32 and hold every gradient")
+    if words is not None and (words.dtype != torch.int32 or tail is None or tail.dtype != torch.float32 or tail.numel() < words.numel()):
+        raise _lib.TexposeLibraryError("grad_pack: int32 gate words need a float32 tail of at least their length")
+    off = 0
+    for i0 in range(0, len(rows), _lib.GRAD_PACK_MAX_TENSORS):
+        chunk = rows[i0:i0 + _lib.GRAD_PACK_MAX_TENSORS]
+        ptrs = (C.c_void_p * len(chunk))(*[p for p, _ in chunk])
+        numel = (C.c_int64 * len(chunk))(*[n for _, n in chunk])
+        last = i0 + _lib.GRAD_PACK_MAX_TENSORS >= len(rows)
+        n_words = 0 if (tail is None or not last) else (words.numel() if words is not None else tail.numel())
+        check(lib.tp_grad_pack(ptrs, numel, len(chunk), flat.data_ptr() + 4 * off, float(scale), _ptr(words) if last else None, n_words,
+                               _ptr(tail) if last else None, _stream()), "tp_grad_pack")
+        off += sum(n for _, n in chunk)
 
 
 def clock_probe(windows: int = 16, window_us: int = 5000) -> torch.Tensor:

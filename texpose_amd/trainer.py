@@ -238,7 +238,7 @@ class GanTrainer:
         return v, loss
 
     def nerf_apply(self):
-        self.red_nerf.reduce()
+        self.red_nerf.average()                  # (several ranks: pack | ONE flat all-reduce | .grad = views of the flat buffer)
         self.optim_nerf.step()
         # the packed weight image is re-built when a head parameter's version changes; fused optimiser kernels (and a
         # replayed hipGraph) update parameters WITHOUT bumping tensor versions, so say it explicitly
@@ -343,7 +343,7 @@ class GanTrainer:
 
     def disc_apply(self, total):
         self._guard_disc(total)
-        self.red_disc.reduce()
+        self.red_disc.average()
         self.optim_disc.step()
 
     def set_lr(self, nerf: float = None, disc: float = None):
@@ -418,6 +418,10 @@ class GanTrainer:
         self.it += 1
         self.graph.patch_sampler.iterations = self.it
         return var, loss
+
+
+class _FormUnavailable(Exception):
+    """Raised inside a warm-up iteration when the selected multi-graph form does not cover this configuration after all."""
 
 
 LAST_QUEUE_PROBE = {}        # outcome of the most recent probe (requested / concurrent / candidate indices / sharing matrix)
@@ -556,6 +560,7 @@ class GraphedGanTrainer(GanTrainer):
         self._d2_pending = False
         self._four, self._g4, self._ev4 = False, None, None    # the step as four graphs on two streams (`_use_four_graphs`)
         self._linear = False                     # ... as six LINEAR graphs on three streams (`_use_linear_graphs`)
+        self._dp = False                         # ... with a gradient all-reduce between each gradient graph and its optimiser graph
         # what the optimiser launches read: the words as they stood when the step's own flags had been folded in
         self._gate_nerf, self._gate_disc = torch.zeros_like(self._bad), torch.zeros_like(self._bad)
         if isinstance(self.optim_nerf, FusedAdam):
@@ -714,13 +719,34 @@ class GraphedGanTrainer(GanTrainer):
     #            [wait ev_patches]                  D2 = discriminator step, RMSprop                             -> ev_d2
     # (G2 keeps the feature chain as a branch of its own.)  Same kernels, same arithmetic as the one-graph form.
     def _use_four_graphs(self, var):
-        if os.environ.get("TP_FOUR_GRAPHS", "1") != "1" or not self.has_disc or self._has_collective() or self._split_around_collectives():
+        if os.environ.get("TP_FOUR_GRAPHS", "1") != "1" or not self.has_disc:
             return False
         p, B = int(self.opt.patch_size), len(var.idx)
         probe = torch.empty(0, device=var.idx.device).new_empty((B, 0, p, p))
         disc = self.graph.discriminator
         return (self._disc_schedule(probe) is not None and hasattr(disc, "prefetch_spectral_weights") and disc.training
                 and os.environ.get("TP_NO_SN_PREFETCH") != "1" and os.environ.get("TP_NO_BRANCH_OVERLAP") != "1")
+
+    def _select_form(self, var):
+        """Which captured form this configuration gets: the linear graphs (one rank: six; several ranks: the same with every
+        optimiser launch as a graph of its own behind its all-reduce, `_dp`), the four-graph form (one rank, no feature chain), or
+        ONE graph (`_body`; with several ranks: gradients | eager all-reduces | optimiser steps).  Also points the fused optimisers
+        at the gate words of that form."""
+        collective = self._has_collective() or self._split_around_collectives()
+        self._four = self._use_four_graphs(var)
+        self._linear = self._four and self._use_linear_graphs(var)
+        fused = isinstance(self.optim_nerf, FusedAdam) and self.has_disc and isinstance(self.optim_disc, FusedRMSprop)
+        self._dp = bool(collective and self._linear and fused and os.environ.get("TP_NO_LINEAR_DP") != "1")
+        if collective and not self._dp:
+            self._four = self._linear = False
+        self._point_gates()
+
+    def _point_gates(self):
+        """`_dp`: the optimiser launches read the (job-wide, sticky) tail of their all-reduce buffer; else the snapshots of `_bad`."""
+        if isinstance(self.optim_nerf, FusedAdam):
+            self.optim_nerf.gate = self.red_nerf.gate_words[:len(self._bad)] if self._dp else self._gate_nerf
+        if self.has_disc and isinstance(self.optim_disc, FusedRMSprop):
+            self.optim_disc.gate = self.red_disc.gate_words[:len(self._bad)] if self._dp else self._gate_disc
 
     def _seg_sn(self, part=None):
         """The three spectral normalisations of an iteration; `part` 0 / 1: the first one alone (the generator's pass through the frozen
@@ -762,7 +788,10 @@ class GraphedGanTrainer(GanTrainer):
         return var, loss
 
     def _seg_disc(self, var):
-        return self.disc_step(var, apply=True)
+        out = self.disc_step(var, apply=not self._dp)
+        if self._dp:
+            self._seg_disc_pack()
+        return out
 
     def disc_step_zero_grads(self):
         self._toggle(self.graph.discriminator, True)
@@ -793,7 +822,10 @@ class GraphedGanTrainer(GanTrainer):
         lw = self.opt.loss_weight
         with torch.no_grad():
             res = ctx.sched.run_paired_b(ctx, 10 ** float(lw.gan_reg_real), step=self._disc_step_tail(ctx.sched))
-        return self._disc_step_scheduled_post(var, res, ctx.real, ctx.fake, True)
+        out = self._disc_step_scheduled_post(var, res, ctx.real, ctx.fake, not self._dp)
+        if self._dp:
+            self._seg_disc_pack()
+        return out
 
     def _disc_step_tail(self, sched):
         """The `step=` of disc_step.run_paired_b when the discriminator step may end inside the spectral-norm backward's two launches
@@ -888,9 +920,53 @@ class GraphedGanTrainer(GanTrainer):
         pairs = [roots.get(k, (t, w)) for k, t, w in zip(keys, terms, ws)]
         torch.autograd.backward([r for r, _ in pairs], [c for _, c in pairs])
         ops.flush_pending_total()
+        if self._dp:
+            # several ranks: this graph ENDS with the gradients (scaled by 1 / world) and the gate words in the flat buffer; the
+            # all-reduce is a stream-ordered call behind the replay, the Adam launch a graph of its own (`_seg_gen_c`)
+            self.red_nerf.pack(flags=self._bad)
+            if self._collectives_in_graph():
+                self.red_nerf.all_reduce()
+                self._seg_gen_c()
+            return var, loss
         self._guard_nerf(var, loss)
         self.nerf_apply()
         return var, loss
+
+    def _seg_gen_c(self):
+        """Behind the nerf step's all-reduce: Adam on the averaged gradients where they lie in the flat buffer, gated by its tail."""
+        self.red_nerf.adopt()
+        self.optim_nerf.step()
+        self.graph.nerf.mark_heads_dirty()
+
+    def _seg_disc_pack(self):
+        """End of the discriminator step's gradient graph with several ranks (see `_seg_gen_b`)."""
+        self.red_disc.pack(flags=self._bad)
+        if self._collectives_in_graph():
+            self.red_disc.all_reduce()
+            self._seg_disc_c()
+
+    def _seg_disc_c(self):
+        self.red_disc.adopt()
+        self.optim_disc.step()
+
+    @staticmethod
+    def _collectives_in_graph():
+        """Opt-in (TP_COLLECTIVES_IN_GRAPH=1): the RCCL all-reduces are captured as nodes of the gradient graphs instead of issued
+        between two replays.  Exercised in a 1-rank group only (tests); stream-ordered calls are the default."""
+        return bool(os.environ.get("TP_COLLECTIVES_IN_GRAPH"))
+
+    def _collective(self, name, red):
+        """One flat all-reduce on the current stream, between two graph replays; HIP events around it when `collective_events` is a
+        list (bench.py / tools/train_dp.py: the xGMI figure)."""
+        ev = getattr(self, "collective_events", None)
+        if ev is None:
+            red.all_reduce()
+            return
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        red.all_reduce()
+        e1.record()
+        ev.append((name, e0, e1))
 
     def _four_eager(self, var):
         """The segments on their streams, eagerly (warm-up), with the same dependencies as the replays."""
@@ -902,6 +978,8 @@ class GraphedGanTrainer(GanTrainer):
         var = self._seg_render(var)
         side.wait_stream(main)
         if self._linear and not ("rgb_feat" in var and "rgb_disc" in var and var.get("gathered_for") is var.ray_idx):
+            if self._dp:
+                raise _FormUnavailable("no fan-out aliases / fused gathers in this configuration")
             self._linear = False                     # (no fan-out aliases / fused gathers in this configuration: four graphs)
         if self._linear:
             feat = self.graph.feat_stream
@@ -912,11 +990,17 @@ class GraphedGanTrainer(GanTrainer):
             var, loss, g_disc = self._seg_gen_a(var)
             main.wait_stream(feat)
             var, loss = self._seg_gen_b(var, loss, g_disc)
+            if self._dp and not self._collectives_in_graph():
+                self._collective("nerf", self.red_nerf)            # (same order on every rank: nerf, then discriminator)
+                self._seg_gen_c()
         else:
             main.wait_stream(side)
             var, loss = self._seg_generator(var)
         with torch.cuda.stream(side):
             var, dloss = self._seg_disc(var)
+            if self._dp and not self._collectives_in_graph():
+                self._collective("disc", self.red_disc)
+                self._seg_disc_c()
         main.wait_stream(side)
         loss.update({k: v for k, v in dloss.items() if k != "all"})
         return {k: v.detach() for k, v in loss.items() if torch.is_tensor(v)}
@@ -1031,6 +1115,12 @@ class GraphedGanTrainer(GanTrainer):
         with torch.cuda.graph(g["G2b"], stream=cap, pool=g["G1"].pool()):
             self._stamp("G2b.0"); var, loss = self._seg_gen_b(var, loss, g_disc); self._stamp("G2b.1"); self._extra("G2b"); counts["G2b"] = ops.capture_node_count()
         keep.append(dict(var))
+        split_dp = self._dp and not self._collectives_in_graph()
+        if split_dp:
+            # several ranks: [G2b: ... gradients, pack] | flat all-reduce (stream-ordered call) | [G2c: Adam from the flat buffer]
+            g["G2c"] = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g["G2c"], stream=cap, pool=g["G1"].pool()):
+                self._seg_gen_c(); self._extra("G2c"); counts["G2c"] = ops.capture_node_count()
         # The discriminator step in TWO graphs when its paired schedule applies: D2a = private copies of the patch stacks, forward pairs,
         # BCE terms -- the last reads of anything the render wrote -- and D2b = the R1 passes, backward pairs, spectral-norm backward,
         # RMSprop.  With `pipeline_disc_tail` the next iteration's render starts behind D2a instead of behind D2b (`_replay_linear`).
@@ -1050,6 +1140,10 @@ class GraphedGanTrainer(GanTrainer):
             with torch.cuda.graph(g["D2"], stream=side, pool=g["D1"].pool()):
                 self._stamp("D2.0"); var, dloss = self._seg_disc(var); self._stamp("D2.1"); counts["D2"] = ops.capture_node_count()
         keep.append(dict(var))
+        if split_dp:
+            g["D2c"] = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g["D2c"], stream=side, pool=g["D1"].pool()):
+                self._seg_disc_c(); self._extra("D2c"); counts["D2c"] = ops.capture_node_count()
         self._g4_keep = keep
         loss.update({k: v for k, v in dloss.items() if k != "all"})
         self._static_loss = {k: v.detach() for k, v in loss.items() if torch.is_tensor(v)}
@@ -1122,6 +1216,9 @@ class GraphedGanTrainer(GanTrainer):
                     g["D2b"].replay()
                 else:
                     g["D2"].replay()
+                if "D2c" in g:                       # several ranks: gradients | all-reduce | RMSprop
+                    self._collective("disc", self.red_disc)
+                    g["D2c"].replay()
                 ev["d2"].record(side)
 
         if d2_first:
@@ -1142,6 +1239,9 @@ class GraphedGanTrainer(GanTrainer):
             if d2_first:
                 main.wait_event(ev["d2"])
             g["G2b"].replay()
+            if "G2c" in g:                           # several ranks: gradients | all-reduce | Adam.  The host issues the nerf step's
+                self._collective("nerf", self.red_nerf)          # collective before the discriminator step's on EVERY rank.
+                g["G2c"].replay()
             ev["g2"].record(main)
         if not d2_first:
             disc_step_graph()
@@ -1266,8 +1366,7 @@ class GraphedGanTrainer(GanTrainer):
             if getattr(self, "_rng_counter", None) is None:
                 self._rng_counter = torch.zeros(1, dtype=torch.int64, device=dev)       # (attached to the graph only inside `_body_a`)
         self._static_in = AttrDict({k: v.clone() for k, v in var.items() if torch.is_tensor(v)})
-        self._four = self._use_four_graphs(var)
-        self._linear = self._four and self._use_linear_graphs(var)
+        self._select_form(var)
         # the step's streams are made here, one after the other (main / capture, discriminator, feature chain): consecutive hardware queues
         if self._linear and (getattr(self, "_capture_stream", None) is None or self._side is None
                              or getattr(self.graph, "feat_stream", None) is None) and os.environ.get("TP_NO_QUEUE_PROBE") != "1":
@@ -1287,10 +1386,20 @@ class GraphedGanTrainer(GanTrainer):
         side = self._capture_stream
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
-            for _ in range(warmup):
+            done = 0
+            while done < warmup:
                 self.graph.patch_sampler.update_device_bound()
-                self._body(AttrDict(dict(self._static_in)))
+                try:
+                    self._body(AttrDict(dict(self._static_in)))
+                except _FormUnavailable:
+                    # (every rank runs the same configuration and takes this branch in the same iteration, before any collective of it)
+                    self._restore(snap)
+                    self._four = self._linear = self._dp = False
+                    self._point_gates()
+                    done = 0
+                    continue
                 self._after_step()
+                done += 1
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         self._d2_pending = self._g2_pending = False
@@ -1343,15 +1452,24 @@ class GraphedGanTrainer(GanTrainer):
         it is one whole iteration old, so the wait only bounds how far the host runs ahead of the GPU."""
         if blocking:
             self._bad_poll = None
+            if self._dp:
+                # the job-wide words: both buffers' tails (a word a rank raises is packed into a tail in the same iteration)
+                n = len(self._bad)
+                return ((self.red_nerf.gate_words[:n] != 0) | (self.red_disc.gate_words[:n] != 0)).to(torch.int32).tolist()
             return self._bad.tolist()
         seen = [0, 0, 0]
         prev = self._bad_poll
         if prev is not None and self.red_nerf.world_size > 1:
             prev[1].synchronize()
         if prev is not None and prev[1].query():
-            seen = prev[0].tolist()
+            seen = [int(w != 0) for w in prev[0].tolist()[:3]]
             self._bad_poll = None
         return seen
+
+    def _poll_words(self):
+        """The device words `train_iteration` copies out to the host: the sticky words of this rank, or (`_dp`) the job-wide tail of
+        the nerf step's buffer, which carries them one pack later."""
+        return self.red_nerf.gate_words if self._dp else self._bad
 
     def flush_flags(self):
         """Blocking read of the gate words as the LAST replay left them; acts on them like `train_iteration` does.  The words of a
@@ -1374,8 +1492,9 @@ class GraphedGanTrainer(GanTrainer):
         replay, i.e. the words as the PREVIOUS replay left them), or None while an earlier copy has not been read yet."""
         if self._bad_poll is not None:
             return None
-        if getattr(self, "_bad_host", None) is None:
-            self._bad_host = torch.zeros(3, dtype=torch.int32).pin_memory()
+        n = self._poll_words().numel()
+        if getattr(self, "_bad_host", None) is None or self._bad_host.numel() != n:
+            self._bad_host = torch.zeros(n, dtype=torch.int32).pin_memory()
         return self._bad_host
 
     def _fall_back_to_fp32(self, var, warmup=3):
@@ -1385,6 +1504,9 @@ class GraphedGanTrainer(GanTrainer):
         self.skipped_steps += 1
         self.graph.nerf.train_precision = "fp32"
         self._bad.zero_()
+        self.red_nerf.clear_gate()
+        if self.red_disc is not None:
+            self.red_disc.clear_gate()
         ops.mlp_status(self._bad.device).zero_()
         self._bad_poll = None
         return self.capture(var, warmup=warmup)
@@ -1405,7 +1527,7 @@ class GraphedGanTrainer(GanTrainer):
             self._reduce_all()
             if ev is not None:
                 e1.record()
-                ev.append((e0, e1))
+                ev.append(("both", e0, e1))
             self._graph_b.replay()
 
     def train_iteration(self, var: AttrDict):
@@ -1414,10 +1536,6 @@ class GraphedGanTrainer(GanTrainer):
         # the batch into the static input tensors, the annealed patch-scale bound, the discriminator's progress value (of the
         # iteration before, as in the reference :182) and the gate words out to pinned memory: ONE launch (K13 tp_step_inputs;
         # torch: a multi-tensor copy per dtype, two fills, a copyBuffer)
-        if self._linear:
-            # everything the caller enqueued on its stream up to here is ordered in front of the discriminator stream's first graph
-            self._caller_mark = torch.cuda.Event()
-            self._caller_mark.record()
         pairs = [(dst, var[k]) for k, dst in self._static_in.items() if var[k] is not dst]
         fused = [(d, s) for d, s in pairs if torch.is_tensor(s) and s.device == d.device and s.dtype == d.dtype and s.shape == d.shape
                  and s.is_contiguous() and d.is_contiguous() and d.data_ptr() % 16 == 0 and s.data_ptr() % 16 == 0]
@@ -1425,7 +1543,13 @@ class GraphedGanTrainer(GanTrainer):
             self.wait_all()                                   # (a batch member the one-launch copy does not take: strict order this once)
         for d, s in pairs:
             if not any(d is d2 for d2, _ in fused):
-                d.copy_(s, non_blocking=True)
+                d.copy_(s, non_blocking=True)                 # (on the CALLER's stream, in front of the mark below)
+        if self._linear:
+            # everything the caller enqueued on its stream up to here -- the copies above included: with `defer_results` the render
+            # waits for this mark and nothing else of the caller's -- is ordered in front of the step's first graphs.  (It sits in front of
+            # the tp_step_inputs launch, which writes nothing the discriminator stream's first graph reads.)
+            self._caller_mark = torch.cuda.Event()
+            self._caller_mark.record()
         for name, optim in (("lr_nerf", self.optim_nerf), ("lr_disc", getattr(self, "optim_disc", None))):
             if optim is not None and any(g["lr"] is not getattr(self, name + "_used") for g in optim.param_groups):
                 self._adopt_group_lr(name, optim)             # an Optimizer.load_state_dict since the last replay
@@ -1441,13 +1565,13 @@ class GraphedGanTrainer(GanTrainer):
             main = self._capture_stream
             main.wait_event(self._caller_mark)
             with torch.cuda.stream(main):
-                ops.step_inputs(fused, scalars, words=self._bad if poll is not None else None, words_host=poll)
+                ops.step_inputs(fused, scalars, words=self._poll_words() if poll is not None else None, words_host=poll)
                 ev = torch.cuda.Event()
                 ev.record()
             torch.cuda.current_stream(self._bad.device).wait_event(ev)      # (the caller may overwrite its batch tensors behind this)
             self._inputs_on_main = True
         else:
-            ops.step_inputs(fused, scalars, words=self._bad if poll is not None else None, words_host=poll)
+            ops.step_inputs(fused, scalars, words=self._poll_words() if poll is not None else None, words_host=poll)
             if poll is not None:
                 ev = torch.cuda.Event()
                 ev.record()

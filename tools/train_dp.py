@@ -44,7 +44,7 @@ def build(device, per_rank_batch, full=True, train_precision="f16x3", graphed=Tr
 
 
 def measure(device, rank, world, global_batch=32, iters=50, warm=5, graphed=True, full=True, train_precision="f16x3",
-            seed=0, hook=None):
+            seed=0, hook=None, force_collectives=False):
     """Timed training loop of an already initialised job (world == 1: no process group needed).  ``hook(trainer)`` may
     instrument the trainer before the warm-up (bench.py times the training kernels with HIP events that way)."""
     from texpose_amd import dist as tdist
@@ -56,6 +56,12 @@ def measure(device, rank, world, global_batch=32, iters=50, warm=5, graphed=True
     opt, graph, cls = build(device, global_batch // world, full, train_precision, graphed)
     tdist.setup_data_parallel(graph, seed=seed)
     trainer = cls(opt, graph, n_train=189)
+    if force_collectives:
+        # ONE rank with the several-rank step: real RCCL calls in a 1-rank communicator (bench.py `train.c4_form`: what the form costs
+        # before a byte crosses xGMI)
+        trainer.red_nerf.single_rank_collective = True
+        if trainer.red_disc is not None:
+            trainer.red_disc.single_rank_collective = True
     if hasattr(trainer, "pipeline_disc_tail") and os.environ.get("TP_NO_PIPELINE_DISC") != "1":
         # the discriminator step's second half may run beside the next render (one rank, six-graph form); this loop reads losses and
         # state only behind flush_flags() / a device synchronise
@@ -75,8 +81,6 @@ def measure(device, rank, world, global_batch=32, iters=50, warm=5, graphed=True
     for i in range(warm):
         trainer.train_iteration(AttrDict(dict(batches[i % 2])))
     barrier()
-    if graphed and getattr(trainer, "_graph_b", None) is not None:
-        trainer.collective_events = []                     # HIP events around the step's gradient all-reduces (xGMI figure)
     t0 = time.perf_counter()
     for i in range(iters):
         _, loss = trainer.train_iteration(AttrDict(dict(batches[i % 2])))
@@ -85,19 +89,31 @@ def measure(device, rank, world, global_batch=32, iters=50, warm=5, graphed=True
     if world > 1:
         torch.distributed.all_reduce(dt, op=torch.distributed.ReduceOp.MAX)
     dt = float(dt) / iters
-    coll = None
-    if getattr(trainer, "collective_events", None):
-        coll = sum(a.elapsed_time(b) for a, b in trainer.collective_events) / len(trainer.collective_events)
+    # HIP events around the step's gradient all-reduces (the xGMI figure), in a short loop of its own BEHIND the timed one: the event
+    # records sit between graph replays and would cost the timed loop a few microseconds each
+    coll = coll_by = None
+    if graphed and (getattr(trainer, "_graph_b", None) is not None or getattr(trainer, "_dp", False)):
+        trainer.collective_events = []
+        for i in range(min(iters, 20)):
+            trainer.train_iteration(AttrDict(dict(batches[i % 2])))
+        barrier()
+        by = {}
+        for name, a, b in trainer.collective_events:
+            by.setdefault(name, []).append(a.elapsed_time(b))
+        trainer.collective_events = None
+        coll_by = {k: sum(v) / len(v) for k, v in by.items()}
+        coll = sum(coll_by.values())                       # (every name occurs once per iteration)
     if hasattr(trainer, "flush_flags"):
         trainer.flush_flags()                              # (the last replay's gate words: a withheld final step raises here)
     counts = getattr(trainer, "launch_counts", None)
-    return dict(collective_ms=coll, ranks_seen=tdist.ranks_seen(),
+    return dict(collective_ms=coll, collective_ms_by_step=coll_by, ranks_seen=tdist.ranks_seen(), form=_form(trainer, graphed),
                 # nodes of the captured graphs of ONE iteration + the tp_step_inputs launch in front of them (None: eager loop)
                 launches=(sum(v for v in counts.values() if v) + 1) if counts and all(v is not None for v in counts.values()) else None,
                 launch_counts=counts, queues=getattr(trainer, "queue_probe", None),
                 metric="train iters/sec", value=1.0 / dt, ms_per_iter=dt * 1e3, n_gpus=world, global_batch=global_batch,
                 per_gpu_batch=global_batch // world, rays_per_iter=global_batch * 256, samples_per_iter=global_batch * 256 * 64,
-                launch=("six linear hipGraph replays on three streams (render | D(fake) + its backward | generator backward + Adam || feature chain || spectral norm | discriminator step)" if getattr(trainer, "_linear", False)
+                launch=("linear hipGraph replays on three streams with one flat all-reduce between each gradient graph and its optimiser graph (render | D(fake) + its backward | generator backward, pack | all-reduce | Adam || feature chain || spectral norm | discriminator step, pack | all-reduce | RMSprop)" if getattr(trainer, "_dp", False)
+                        else "six linear hipGraph replays on three streams (render | D(fake) + its backward | generator backward + Adam || feature chain || spectral norm | discriminator step)" if getattr(trainer, "_linear", False)
                         else "four hipGraph replays on two streams (render | generator step || spectral norm | discriminator step)" if getattr(trainer, "_four", False)
                         else "hipGraph replay" if getattr(trainer, "_graph_b", None) is None
                         else "two hipGraph replays with the gradient all-reduces between them") if graphed else "eager", recording_forward=graph.nerf.train_precision,
@@ -107,6 +123,18 @@ def measure(device, rank, world, global_batch=32, iters=50, warm=5, graphed=True
                 if full else "nerf step only (render fwd+bwd, photometric/uncert/trans_reg losses, Adam)",
                 finite=all(bool(torch.isfinite(v)) for v in loss.values() if torch.is_tensor(v)),
                 skipped_steps=trainer.skipped_steps)
+
+
+def _form(trainer, graphed):
+    if not graphed:
+        return "eager"
+    if getattr(trainer, "_dp", False):
+        return "linear_dp"
+    if getattr(trainer, "_linear", False):
+        return "linear"
+    if getattr(trainer, "_four", False):
+        return "four_graphs"
+    return "one_graph" if getattr(trainer, "_graph_b", None) is None else "two_graphs_eager_collectives"
 
 
 def run(global_batch=32, iters=50, warm=5, graphed=True, full=True, train_precision="f16x3", seed=0):
