@@ -1326,6 +1326,142 @@ def test_disc_step_matches_reference_g13b(ops, form, monkeypatch):
     print("G13b %s: weight_orig gradient rel-L2 vs the reference:" % form, {k: "%.1e" % v for k, v in errs.items()})
 
 
+def _g13c_setup(G, precision):
+    from texpose_amd.gan_modules import Discriminator
+    from texpose_amd.graph import Graph
+    from texpose_amd.options import default_options, AttrDict
+    from texpose_amd.synthetic import training_batch
+    from texpose_amd.trainer import GraphedGanTrainer
+    B, H, W, P, N, n_train = (int(G[k]) for k in ("B", "H", "W", "P", "N", "n_train"))
+    opt = default_options(H=H, W=W, device="cuda:0")
+    opt.batch_size, opt.patch_size, opt.nerf.sample_intvs = B, P, N
+    opt.loss_weight.feat = None
+    graph = Graph(opt, discriminator=Discriminator(opt)).to(dev())
+    graph.nerf.load_state_dict({**graph.nerf.state_dict(), **{k: cu(v) for k, v in O.make_params(int(G["seed_w"])).items()}})
+    disc_cpu = Discriminator(opt)
+    O.seed_spectral_module(disc_cpu, int(G["seed_d"]))
+    sd = disc_cpu.state_dict()
+    sd.update({k: G["in." + k] for k in sd if "in." + k in G})
+    graph.discriminator.load_state_dict(sd)
+    graph.attach_latents(n_train, opt)
+    ers = np.random.RandomState(int(G["seed_e"]))
+    with torch.no_grad():
+        graph.latent_vars_trans.weight.copy_(torch.from_numpy(ers.normal(size=(n_train, 16)).astype(np.float32)))
+        graph.latent_vars_light.weight.copy_(torch.from_numpy(ers.normal(size=(n_train, 48)).astype(np.float32)))
+    graph.train()
+    graph.nerf.precision = graph.nerf.train_precision = precision
+    tr = GraphedGanTrainer(opt, graph, n_train=n_train)
+    batch = training_batch(B, H, W, n_train=n_train, seed=int(G["seed_b"]), device="cuda:0")
+    assert torch.equal(batch.idx.cpu(), G["sample_idx"].long())
+    assert torch.equal(graph.latent_vars_trans.weight[batch.idx].cpu(), G["in.lat_t"])        # the reference's latent rows
+    var = AttrDict({k: v.clone() for k, v in batch.items()})
+    var.ray_idx, var.ray_scales = cu(G["ray_idx"]), cu(G["ray_scales"])
+    return opt, graph, tr, var
+
+
+@pytest.mark.parametrize("precision", ["fp32", "f16x3"])
+@pytest.mark.parametrize("form", ["schedule", "schedule-graphed", "autograd"])
+def test_nerf_step_matches_reference_g13c(ops, form, precision, monkeypatch):
+    """Golden G13c: the REFERENCE's nerf_trainstep of iteration 0 (model/nerf_adapt_st_gan.py:108-127 render + :464-514 the pass
+    through the frozen discriminator + :747-776 the loss terms + model/base.py:145-157 the weighted total + backward) fed with the
+    reference's OWN rays, depth samples, latent rows, patch coordinates, scales and power-iteration state (tp_raygen's outputs are
+    replaced by the stored rays: ray generation differs from torch's CPU inverse in the last bit; everything behind
+    it is the product path -- recording MLP forward, composite, gather + PatchGAN stacks, K8 losses, the generator's pass through
+    the discriminator as the explicit 9-launch schedule `disc_step.generator_pass` or as autograd over the same kernels, loss
+    total + gate, composite / MLP backward).  Checked: render 1e-4 / 1e-6, D(fake) 1e-4, the four loss terms and their total 1e-5,
+    the gradients of the FULL loss on all 16 head tensors and both latent tables -- raw 1e-3 (ReLU gate flips) and FLIP-FREE 2e-5
+    (rays holding a gate within 64 ulp of zero carry no gradient on either side: the same mask at the render boundary,
+    tests/golden/make_golden_g13c.py) -- and weight_u / weight_v after the pass' power iteration; eager and replayed from a hipGraph,
+    both recording arithmetics."""
+    import texpose_amd.ops as ops_mod
+    G = load_golden("g13c_nerf_step")
+    B, P, N, n_train = int(G["B"]), int(G["P"]), int(G["N"]), int(G["n_train"])
+    R = P * P
+    if form == "autograd":
+        monkeypatch.setenv("TP_NO_GEN_SCHEDULE", "1")
+    center, ray, depth = cu(G["in.center"]).contiguous(), cu(G["in.ray"]).contiguous(), cu(G["in.depth"])[..., 0].contiguous()
+    monkeypatch.setattr(ops_mod, "raygen", lambda intr, pose, **kw: (center, ray, None, None, depth))
+    keep = cu(G["keep_ray"])
+    assert 0 < float(keep.sum()) < keep.numel()
+    names = [f"{m}.{li}.{kind}" for m in ("mlp_rgb", "mlp_trans") for li in range(4) for kind in ("weight", "bias")]
+    report = {}
+    # (measured on gfx950: flip-free 1.7e-7 fp32 record / 2.5e-6 f16x3 record; raw 2.5e-5 / 5.1e-6 -- this batch has few flips)
+    for tier, gtol in (("raw", 1e-3), ("ff", 2e-5)):
+        opt, graph, tr, var0 = _g13c_setup(G, precision)
+        graph.get_ray_idx = lambda opt_, v: v                     # (the stored coordinates: no draw, as in G13)
+        if tier == "ff":
+            plain = graph.render
+
+            def masked(opt_, pose, **kw):
+                ret = plain(opt_, pose, **kw)
+                for k, v in list(ret.items()):
+                    if torch.is_tensor(v) and v.requires_grad and tuple(v.shape[:2]) == (B, R):
+                        m = keep.view(B, R, *([1] * (v.dim() - 2)))
+                        ret[k] = m * v + (1 - m) * v.detach()
+                return ret
+            graph.render = masked
+
+        def step():
+            from texpose_amd.options import AttrDict
+            tr.optim_nerf.zero_grad(set_to_none=True)
+            var = tr._seg_render(AttrDict(dict(var0)))
+            var, loss, g_disc = tr._seg_gen_a(var)
+            var, loss = tr._seg_gen_b(var, loss, g_disc)
+            return var, loss
+
+        state = {k: v.clone() for k, v in graph.state_dict().items()}
+        if form != "schedule-graphed":
+            var, loss = step()
+        else:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                step()                                            # warm-up: an Adam step and a power iteration, undone below
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+
+            def restore():
+                with torch.no_grad():
+                    for k, v in graph.state_dict().items():
+                        v.copy_(state[k])
+                    for st in tr.optim_nerf.state.values():
+                        for t in st.values():
+                            if torch.is_tensor(t):
+                                t.zero_()
+                graph.nerf.mark_heads_dirty()
+            restore()
+            cg = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(cg, stream=side):
+                var, loss = step()
+            restore()
+            tr._bad.zero_()
+            cg.replay()
+            torch.cuda.synchronize()
+        assert ("gan_nerf_precomputed" in var) == (form != "autograd")             # the explicit schedule ran / did not run
+        assert tr._bad.tolist() == [0, 0, 0]
+        torch.testing.assert_close(var.rgb.detach().cpu(), G["out.rgb"], **RAY)
+        torch.testing.assert_close(var.uncert.detach().cpu(), G["out.uncert"], **RAY)
+        torch.testing.assert_close(var.depth.detach().cpu(), G["out.depth"], **RAY)
+        assert rel_l2(var.density, G["out.density"]) < 1e-4
+        torch.testing.assert_close(var.d_fake_nerf.detach().cpu().view(-1), G["out.d_fake_nerf"].view(-1), rtol=1e-4, atol=1e-6)
+        for k in ("render", "uncert", "trans_reg", "gan_nerf", "all"):
+            ours, ref = float(loss[k].detach()), float(G["gloss." + k])
+            report[f"{tier}.loss.{k}"] = abs(ours - ref) / abs(ref)
+            assert abs(ours - ref) <= 1e-5 * abs(ref) + 1e-7, (tier, k, ours, ref)
+        for k, v in graph.discriminator.state_dict().items():
+            if "out." + k in G and form != "schedule-graphed":    # (the graphed run restored u / v before the replay: one iteration too)
+                assert rel_l2(v.cpu(), G["out." + k]) < 1e-5, k
+        errs = {n: rel_l2(dict(graph.nerf.named_parameters())[n].grad, G[f"{tier}.g.{n}"]) for n in names}
+        errs["latent_vars_trans"] = rel_l2(graph.latent_vars_trans.weight.grad, G[tier + ".g.latent_vars_trans"])
+        errs["latent_vars_light"] = rel_l2(graph.latent_vars_light.weight.grad, G[tier + ".g.latent_vars_light"])
+        report[tier + ".grad.max"] = max(errs.values())
+        report[tier + ".grad.worst"] = max(errs, key=errs.get)
+        assert len(errs) == 18
+        for n, e in errs.items():
+            assert e < gtol, (tier, form, precision, n, e, errs)
+    print("G13c %s / %s record vs the REFERENCE:" % (form, precision), {k: (float("%.2e" % v) if isinstance(v, float) else v) for k, v in report.items()})
+
+
 def test_disc_step_pairs_are_bit_identical_to_the_sequential_schedule(ops, monkeypatch):
     """The discriminator step with its real and fake passes as PAIRS of launches (ops.paired / tp_*_pair: forward ladder + tail, tail
     backward, weight / data gradients, InstanceNorm backward) against the sequential schedule (TP_NO_DISC_PAIRS=1) on golden G13b's
@@ -1497,18 +1633,28 @@ def test_pipelined_discriminator_tail_is_bit_identical(ops):
     from texpose_amd.synthetic import training_batch
     from texpose_amd.trainer import GraphedGanTrainer
     out = []
-    for pipelined in (False, True, "deferred"):
+    for pipelined in (False, True, "deferred", "deferred_strided"):
         torch.manual_seed(0)
         opt = default_options(H=128, W=128, device="cuda:0")
         opt.batch_size, opt.patch_size, opt.nerf.sample_intvs = 4, 16, 64
         graph = Graph(opt, discriminator=Discriminator(opt), perceptual_loss=PerceptualLoss()).to(dev())
         tr = GraphedGanTrainer(opt, graph, n_train=189)
         tr.pipeline_disc_tail = bool(pipelined)
-        tr.defer_results = pipelined == "deferred"
+        tr.defer_results = str(pipelined).startswith("deferred")
         batches = [training_batch(4, 128, 128, seed=s_, device="cuda:0") for s_ in range(2)]
+        if pipelined == "deferred_strided":
+            # a batch member the one-launch input copy does not take (non-contiguous): it goes in by a copy on the CALLER's stream, and the
+            # render -- which under `defer_results` waits for the caller's mark only -- must still see it (the mark sits behind that copy)
+            for b in batches:
+                img = torch.empty(b.image.shape[:-2] + (b.image.shape[-1], b.image.shape[-2]), device=b.image.device).transpose(-1, -2)
+                img.copy_(b.image)
+                assert not img.is_contiguous() and torch.equal(img, b.image)
+                b.image = img
         for it in range(8):
+            if pipelined == "deferred_strided":
+                torch.cuda._sleep(2_000_000)          # (the caller's stream is busy when the copy is enqueued: a render that skipped the mark would be early)
             _, loss = tr.train_iteration(AttrDict(dict(batches[it % 2])))
-        assert tr._linear and "D2a" in tr._g4 and tr._pipelined() == bool(pipelined) and tr._defers_results() == (pipelined == "deferred")
+        assert tr._linear and "D2a" in tr._g4 and tr._pipelined() == bool(pipelined) and tr._defers_results() == str(pipelined).startswith("deferred")
         tr.finish()
         torch.cuda.synchronize()
         out.append(({k: v.clone() for k, v in graph.state_dict().items()}, {k: v.clone() for k, v in loss.items() if torch.is_tensor(v)},

@@ -386,3 +386,65 @@ def test_flip_free_gradients_g9c():
     errs = {k: _rel_l2(v.grad, gc["b_g." + k]) for k, v in p.items() if v.requires_grad}
     errs["lat_t"], errs["lat_l"] = _rel_l2(lt.grad, gc["b_g.lat_t"]), _rel_l2(ll.grad, gc["b_g.lat_l"])
     assert max(errs.values()) < 1e-5, errs
+
+
+def test_nerf_step_g13c_oracle():
+    """G13c: the REFERENCE's nerf_trainstep of iteration 0 (model/nerf_adapt_st_gan.py:108-127, 464-514, 747-776) with the reference's
+    OWN rays, depth samples, latent rows, patch coordinates, scales and power-iteration state as inputs, re-done with the CPU oracle
+    (MLP, composite, gathers, losses) and the discriminator mirror on CPU: render, D(fake), the four loss terms and their total at
+    1e-5, the gradients of all 16 head tensors and both latent tables -- raw (gate flips: 5e-3) and flip-free (1e-4: the rays holding a
+    gate within 64 ulp of zero carry no gradient, make_golden_g13c.py)."""
+    from texpose_amd.gan_modules import Discriminator
+    from texpose_amd.options import default_options
+    from texpose_amd.synthetic import training_batch
+    g = load_golden("g13c_nerf_step")
+    B, H, W, P, N, n_train = (int(g[k]) for k in ("B", "H", "W", "P", "N", "n_train"))
+    base = O.make_params(g["seed_w"])
+    var = training_batch(B, H, W, n_train=n_train, seed=g["seed_b"], device="cpu")
+    coords, scales, idx = g["ray_idx"], g["ray_scales"], g["sample_idx"].long()
+    opt = default_options(H=H, W=W, device="cpu")
+    opt.patch_size = P
+    smp = O.patch_gather(coords, var.image, var.image_syn, var.nocs_pred, var.normal_pred, var.obj_mask, var.mask_syn)
+    bce = torch.nn.functional.binary_cross_entropy_with_logits
+    keep = g["keep_ray"]
+    assert 0 < float(keep.sum()) < keep.numel()
+    for tier, tol in (("raw", 5e-3), ("ff", 1e-4)):
+        p = {k: v.clone().requires_grad_(not k.startswith("mlp_feat")) for k, v in base.items()}
+        lt, ll = g["in.lat_t"].clone().requires_grad_(), g["in.lat_l"].clone().requires_grad_()
+        rgb_s, den_s, unc_s = O.forward_samples(p, g["in.center"], g["in.ray"], g["in.depth"], lt, ll)
+        comp = O.composite(g["in.ray"], rgb_s, den_s, g["in.depth"], unc_s)
+        ret = dict(rgb=comp[0], uncert=comp[8], density=den_s)
+        close(ret["rgb"], g["out.rgb"], rtol=1e-5, atol=1e-6)
+        close(ret["uncert"], g["out.uncert"], rtol=1e-5, atol=1e-6)
+        assert _rel_l2(den_s, g["out.density"]) < 1e-5
+        if tier == "ff":
+            for k in ret:
+                m = keep.view(B, P * P, *([1] * (ret[k].dim() - 2)))
+                ret[k] = m * ret[k] + (1 - m) * ret[k].detach()
+        L = O.nerf_losses(ret["rgb"], ret["uncert"], ret["density"], smp)
+        disc = Discriminator(opt)
+        O.seed_spectral_module(disc, g["seed_d"])
+        sd = disc.state_dict()
+        sd.update({k: g["in." + k] for k in sd if "in." + k in g})
+        disc.load_state_dict(sd)
+        disc.train()
+        for q in disc.parameters():
+            q.requires_grad_(False)
+        _, fake = O.disc_patches(ret["rgb"], smp)
+        d_fake = disc(opt, fake, scales)
+        close(d_fake, g["out.d_fake_nerf"], rtol=1e-4, atol=1e-6)
+        for k, v in disc.state_dict().items():
+            if "out." + k in g:
+                assert _rel_l2(v, g["out." + k]) < 1e-5, k                    # one power iteration, as the reference's forward
+        L["gan_nerf"] = bce(d_fake, torch.ones_like(d_fake))
+        for k in ("render", "uncert", "trans_reg", "gan_nerf"):
+            close(L[k], torch.as_tensor(g["gloss." + k], dtype=torch.float32), rtol=1e-5, atol=1e-6)
+        tot = O.summarize(L, dict(render=0, uncert=0, trans_reg=-2, gan_nerf=-1))
+        close(tot, torch.as_tensor(g["gloss.all"], dtype=torch.float32), rtol=1e-5, atol=1e-6)
+        tot.backward()
+        errs = {k: _rel_l2(v.grad, g["%s.g.%s" % (tier, k)]) for k, v in p.items() if v.requires_grad}
+        # (the reference holds dense table gradients: row i = the sum of the latent-row gradients of the images with idx == i -- this
+        # batch draws the same row twice)
+        errs["lat_t"] = _rel_l2(torch.zeros(n_train, 16).index_add_(0, idx, lt.grad), g[tier + ".g.latent_vars_trans"])
+        errs["lat_l"] = _rel_l2(torch.zeros(n_train, 48).index_add_(0, idx, ll.grad), g[tier + ".g.latent_vars_light"])
+        assert len(errs) == 18 and max(errs.values()) < tol, (tier, errs)

@@ -916,7 +916,9 @@ class GraphedGanTrainer(GanTrainer):
         terms, ws = self._weighted_total(loss, flags=dict(bad=self._bad, word_finite=1, snapshot=self._gate_nerf, status=status,
                                                           word_status=0, step_counter=getattr(self, "_rng_counter", None)),
                                          defer=os.environ.get("TP_NO_TOTAL_IN_BWD") != "1")
-        roots = {"feat": (var.rgb_feat, var.g_rgb_feat), "gan_nerf": (var.rgb_disc, g_disc)}
+        roots = {"gan_nerf": (var.rgb_disc, g_disc)}
+        if "g_rgb_feat" in var:                        # (the feature chain ran as a graph of its own, `_seg_feat`)
+            roots["feat"] = (var.rgb_feat, var.g_rgb_feat)
         pairs = [roots.get(k, (t, w)) for k, t, w in zip(keys, terms, ws)]
         torch.autograd.backward([r for r, _ in pairs], [c for _, c in pairs])
         ops.flush_pending_total()
