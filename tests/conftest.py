@@ -44,3 +44,12 @@ def golden():
 
 def has_gpu():
     return torch.cuda.is_available()
+
+
+@pytest.fixture(autouse=True)
+def _knobs_follow_the_environment():
+    """texpose_amd.knobs parses the TP_* switches once; a test that flips one (monkeypatch.setenv + knobs.reload()) must not leak it:
+    this fixture is set up before `monkeypatch` and so torn down after it has restored the environment."""
+    yield
+    from texpose_amd import knobs
+    knobs.reload()

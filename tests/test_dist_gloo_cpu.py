@@ -16,6 +16,7 @@ sys.path.insert(0, REPO)
 
 from oracle import texpose_oracle as O          # noqa: E402
 from texpose_amd import dist as tdist           # noqa: E402
+from texpose_amd import knobs                  # noqa: E402
 
 B, P, N, H, W, N_TRAIN = 4, 3, 4, 12, 12, 6
 
@@ -436,20 +437,21 @@ def test_graphed_trainer_form_selection_for_several_ranks(monkeypatch):
     batch = AttrDict(idx=torch.arange(2))
     assert not tr._split_around_collectives() and not tr._has_collective()          # one rank: one graph, no collective
     tr._select_form(batch)
-    assert not (tr._four or tr._linear or tr._dp)
+    assert not (tr._linear or tr._dp)
     monkeypatch.setattr(tdist.FlatGradAllReducer, "world_size", property(lambda self: 2))
     assert tr._has_collective() and tr._split_around_collectives()                   # several ranks: A | reduce | B
     tr._select_form(batch)
-    assert not (tr._four or tr._linear or tr._dp)
+    assert not (tr._linear or tr._dp)
     monkeypatch.setenv("TP_COLLECTIVES_IN_GRAPH", "1")
+    knobs.reload()
     assert tr._has_collective() and not tr._split_around_collectives()               # opt-in only
     monkeypatch.delenv("TP_COLLECTIVES_IN_GRAPH")
+    knobs.reload()
     # (b) the full GAN iteration, as the GPU sees it (the predicates that need the HIP kernels are answered "yes" here)
     opt = default_options(H=32, W=32, device="cpu")
     g = Graph(opt, discriminator=Discriminator(opt))
     g.attach_latents(4, opt)
     tr = GraphedGanTrainer(opt, g, n_train=4)
-    monkeypatch.setattr(GraphedGanTrainer, "_use_four_graphs", lambda self, var: True)
     monkeypatch.setattr(GraphedGanTrainer, "_use_linear_graphs", lambda self, var: True)
     tr.optim_nerf = FusedAdam([dict(params=tr.nerf_group, lr=tr.lr_nerf_used)], capturable=True)
     tr.optim_disc = FusedRMSprop([dict(params=tr.disc_group, lr=tr.lr_disc_used)], capturable=True)
@@ -459,9 +461,11 @@ def test_graphed_trainer_form_selection_for_several_ranks(monkeypatch):
     assert tr.optim_disc.gate.data_ptr() == tr.red_disc.gate_words.data_ptr() and len(tr.optim_disc.gate) == 3
     assert tr._poll_words().data_ptr() == tr.red_nerf.gate_words.data_ptr()
     monkeypatch.setenv("TP_NO_LINEAR_DP", "1")
+    knobs.reload()
     tr._select_form(batch)
-    assert not (tr._four or tr._linear or tr._dp) and tr.optim_nerf.gate is tr._gate_nerf      # the generic two-graph form
+    assert not (tr._linear or tr._dp) and tr.optim_nerf.gate is tr._gate_nerf      # the generic two-graph form
     monkeypatch.delenv("TP_NO_LINEAR_DP")
+    knobs.reload()
     monkeypatch.setattr(tdist.FlatGradAllReducer, "world_size", property(lambda self: 1))
     tr._select_form(batch)
     assert tr._linear and not tr._dp and tr.optim_nerf.gate is tr._gate_nerf and tr.optim_disc.gate is tr._gate_disc

@@ -15,6 +15,7 @@ import torch.nn.functional as F
 
 from conftest import load_golden
 from oracle import texpose_oracle as O
+from texpose_amd import knobs
 
 pytestmark = pytest.mark.gpu
 
@@ -1291,6 +1292,7 @@ def test_disc_step_matches_reference_g13b(ops, form, monkeypatch):
     G = load_golden("g13b_disc_step")
     if form == "autograd":
         monkeypatch.setenv("TP_DISC_AUTOGRAD", "1")
+        knobs.reload()
     opt, graph, tr, var = _g13b_setup(G)
     if form != "schedule-graphed":
         var, dloss = tr.disc_step(var, apply=False)
@@ -1379,6 +1381,7 @@ def test_nerf_step_matches_reference_g13c(ops, form, precision, monkeypatch):
     R = P * P
     if form == "autograd":
         monkeypatch.setenv("TP_NO_GEN_SCHEDULE", "1")
+        knobs.reload()
     center, ray, depth = cu(G["in.center"]).contiguous(), cu(G["in.ray"]).contiguous(), cu(G["in.depth"])[..., 0].contiguous()
     monkeypatch.setattr(ops_mod, "raygen", lambda intr, pose, **kw: (center, ray, None, None, depth))
     keep = cu(G["keep_ray"])
@@ -1472,8 +1475,10 @@ def test_disc_step_pairs_are_bit_identical_to_the_sequential_schedule(ops, monke
     for pairs in (True, False):
         if pairs:
             monkeypatch.delenv("TP_NO_DISC_PAIRS", raising=False)
+            knobs.reload()
         else:
             monkeypatch.setenv("TP_NO_DISC_PAIRS", "1")
+            knobs.reload()
         opt, graph, tr, var = _g13b_setup(G)
         var, dloss = tr.disc_step(var, apply=False)
         assert tr._disc_sched.pairs_eligible(var.patch_real) == pairs
@@ -1561,8 +1566,10 @@ def test_disc_step_tail_in_the_sn_backward_is_bit_identical(ops, monkeypatch):
     for fused in (True, False):
         if fused:
             monkeypatch.delenv("TP_NO_DISC_STEP_TAIL", raising=False)
+            knobs.reload()
         else:
             monkeypatch.setenv("TP_NO_DISC_STEP_TAIL", "1")
+            knobs.reload()
         torch.manual_seed(0)
         opt = default_options(H=128, W=128, device="cuda:0")
         opt.batch_size, opt.patch_size, opt.nerf.sample_intvs = 4, 16, 64
@@ -1573,7 +1580,7 @@ def test_disc_step_tail_in_the_sn_backward_is_bit_identical(ops, monkeypatch):
             _, loss = tr.train_iteration(AttrDict(dict(batches[it % 2])))
         tr.finish()
         torch.cuda.synchronize()
-        assert tr._linear and "D2b" in tr._g4
+        assert tr._linear and "D2b" in tr._graphs
         out.append(({k: v.clone() for k, v in graph.state_dict().items()}, {k: v.clone() for k, v in loss.items() if torch.is_tensor(v)},
                     [t.clone() for st in tr.optim_disc.state.values() for t in st.values() if torch.is_tensor(t)], tr._bad.clone(),
                     tr.launch_counts["D2b"]))
@@ -1654,7 +1661,7 @@ def test_pipelined_discriminator_tail_is_bit_identical(ops):
             if pipelined == "deferred_strided":
                 torch.cuda._sleep(2_000_000)          # (the caller's stream is busy when the copy is enqueued: a render that skipped the mark would be early)
             _, loss = tr.train_iteration(AttrDict(dict(batches[it % 2])))
-        assert tr._linear and "D2a" in tr._g4 and tr._pipelined() == bool(pipelined) and tr._defers_results() == str(pipelined).startswith("deferred")
+        assert tr._linear and "D2a" in tr._graphs and tr._pipelined() == bool(pipelined) and tr._defers_results() == str(pipelined).startswith("deferred")
         tr.finish()
         torch.cuda.synchronize()
         out.append(({k: v.clone() for k, v in graph.state_dict().items()}, {k: v.clone() for k, v in loss.items() if torch.is_tensor(v)},
@@ -1690,8 +1697,10 @@ def test_linear_form_with_all_reduces_between_graphs_is_bit_identical(ops):
     try:
         for mode in ("one_rank", "between", "between_pipelined", "in_graph"):
             os.environ.pop("TP_COLLECTIVES_IN_GRAPH", None)
+            knobs.reload()
             if mode == "in_graph":
                 os.environ["TP_COLLECTIVES_IN_GRAPH"] = "1"
+                knobs.reload()
             torch.manual_seed(0)
             opt = default_options(H=128, W=128, device="cuda:0")
             opt.batch_size, opt.patch_size, opt.nerf.sample_intvs = 4, 16, 64
@@ -1703,8 +1712,8 @@ def test_linear_form_with_all_reduces_between_graphs_is_bit_identical(ops):
             batches = [training_batch(4, 128, 128, seed=s_, device="cuda:0") for s_ in range(2)]
             for it in range(8):
                 _, loss = tr.train_iteration(AttrDict(dict(batches[it % 2])))
-            assert tr._linear and tr._dp == forced and "D2a" in tr._g4
-            assert ("G2c" in tr._g4 and "D2c" in tr._g4) == (mode in ("between", "between_pipelined"))
+            assert tr._linear and tr._dp == forced and "D2a" in tr._graphs
+            assert ("G2c" in tr._graphs and "D2c" in tr._graphs) == (mode in ("between", "between_pipelined"))
             assert tr.finish() == [0, 0, 0]
             torch.cuda.synchronize()
             if forced:
@@ -1732,6 +1741,7 @@ def test_linear_form_with_all_reduces_between_graphs_is_bit_identical(ops):
         assert out[0][3] < out[1][3] <= out[0][3] + 6, [o[3] for o in out]
     finally:
         os.environ.pop("TP_COLLECTIVES_IN_GRAPH", None)
+        knobs.reload()
         tr = graph = None                       # (captured graphs that contain RCCL kernels go before the communicator does)
         import gc
         gc.collect()
@@ -1879,21 +1889,20 @@ def test_graph_captured_training_matches_eager(ops):
     assert len(seen) == 3
 
 
-@pytest.mark.parametrize("mode", ["linear", "four", "one"])
+@pytest.mark.parametrize("mode", ["linear", "one"])
 def test_graph_captured_full_gan_step_modes_match_eager(ops, mode, monkeypatch):
-    """The full GAN iteration WITH the feature loss, captured in each of its three forms -- six linear graphs on three streams (the
-    default: the feature chain and the discriminator's pass for the generator hand the composite backward cotangents instead of being
-    differentiated through in one backward call), four graphs on two streams (TP_LINEAR_GRAPHS=0), one graph (TP_FOUR_GRAPHS=0) --
+    """The full GAN iteration WITH the feature loss, captured in each of its two forms -- linear graphs on three streams (the default:
+    the feature chain and the discriminator's pass for the generator hand the composite backward cotangents instead of being
+    differentiated through in one backward call) and the generic ONE graph with its branches forked inside (TP_LINEAR_GRAPHS=0) --
     against the eager GanTrainer on the same weights, batch and random numbers: same losses, same parameter updates."""
     from texpose_amd.gan_modules import Discriminator, PerceptualLoss
     from texpose_amd.graph import Graph
     from texpose_amd.options import default_options, AttrDict
     from texpose_amd.synthetic import training_batch
     from texpose_amd.trainer import GanTrainer, GraphedGanTrainer
-    if mode == "four":
-        monkeypatch.setenv("TP_LINEAR_GRAPHS", "0")
     if mode == "one":
-        monkeypatch.setenv("TP_FOUR_GRAPHS", "0")
+        monkeypatch.setenv("TP_LINEAR_GRAPHS", "0")
+        knobs.reload()
     B, H, W, n_train, N, steps = 2, 32, 32, 5, 8, 3
     torch.manual_seed(3)
     feat_net = PerceptualLoss()
@@ -1933,7 +1942,7 @@ def test_graph_captured_full_gan_step_modes_match_eager(ops, mode, monkeypatch):
     ex = AttrDict(dict(batch))
     ex.patch_u, ex.jitter_rand = rnd[0]
     graphed.capture(ex, warmup=2)
-    assert (graphed._linear, graphed._four) == dict(linear=(True, True), four=(False, True), one=(False, False))[mode]
+    assert graphed._linear == (mode == "linear") and ("F" in (graphed._graphs or {})) == (mode == "linear")
     reset(graphed, g_g, snap)
     for it, (u, jit) in enumerate(rnd):
         v = AttrDict(dict(batch))
@@ -2077,9 +2086,10 @@ def test_spectral_weights_match_torch(ops):
 
 
 def test_graph_capture_with_rccl_all_reduce(ops):
-    """The data-parallel gradient all-reduce (RCCL) with the captured iteration: a 1-rank NCCL group on this GPU with the
+    """The data-parallel gradient all-reduce (RCCL) with the GENERIC captured form (TP_NO_LINEAR_DP=1; the linear graphs with the
+    collectives have test_linear_form_with_all_reduces_between_graphs_is_bit_identical): a 1-rank NCCL group on this GPU with the
     collective forced on, (a) inside the single captured graph, (b) eagerly between two replays (gradient graph, optimiser
-    graph: what a real multi-rank group uses).  Both must give the same parameters as the capture without the collective."""
+    graph).  Both must give the same parameters as the capture without the collective."""
     import torch.distributed as dist
     from texpose_amd.gan_modules import Discriminator
     from texpose_amd.graph import Graph
@@ -2095,11 +2105,14 @@ def test_graph_capture_with_rccl_all_reduce(ops):
         batch = training_batch(B, H, W, n_train=5, seed=2, device="cuda:0")
         rnd = (torch.rand(3, B, 1, 1, 1, device=dev()), torch.rand(B, 256, N, 1, device=dev()))
         results = []
+        os.environ["TP_NO_LINEAR_DP"] = "1"
         for forced, split in ((False, False), (True, False), (True, True)):
-            # split: the multi-GPU default -- the collectives run eagerly BETWEEN two graph replays (gradients, then optimisers)
+            # split: the collectives run eagerly BETWEEN two graph replays (gradients, then optimisers)
             os.environ.pop("TP_SPLIT_GRAPH", None)
+            knobs.reload()
             if split:
                 os.environ["TP_SPLIT_GRAPH"] = "1"
+                knobs.reload()
             opt = default_options(H=H, W=W, device="cuda:0")
             opt.batch_size, opt.patch_size, opt.nerf.sample_intvs = B, 16, N
             opt.loss_weight.feat = None
@@ -2132,11 +2145,13 @@ def test_graph_capture_with_rccl_all_reduce(ops):
                 _, loss = tr.train_iteration(v)
             assert all(np.isfinite(float(x)) for x in loss.values())
             results.append({k: v.detach().clone() for k, v in graph.state_dict().items()})
-            assert (tr._graph_b is not None) == split
+            assert (tr._graph_b is not None) == split and tr._linear == (not forced) and not tr._dp
         assert_updates_close(results[0], results[1], snap)
         assert_updates_close(results[0], results[2], snap)
     finally:
         os.environ.pop("TP_SPLIT_GRAPH", None)
+        os.environ.pop("TP_NO_LINEAR_DP", None)
+        knobs.reload()
         # the captured graphs that contain RCCL kernels go before the communicator does
         tr = graph = None
         import gc
@@ -2423,8 +2438,10 @@ def test_disc_step_schedule_matches_autograd_form(ops, patch, B, with_r1, monkey
     for graph, autograd_form in ((g_a, True), (g_b, False)):
         if autograd_form:
             monkeypatch.setenv("TP_DISC_AUTOGRAD", "1")
+            knobs.reload()
         else:
             monkeypatch.delenv("TP_DISC_AUTOGRAD", raising=False)
+            knobs.reload()
         tr = GanTrainer(opt, graph, n_train=5)
         torch.manual_seed(3)                                   # the same patch draws / jitter for both copies
         var = graph.get_ray_idx(opt, AttrDict(dict(batch)))
@@ -2673,6 +2690,7 @@ def test_skinny_linear_matches_torch_up_to_second_order(ops, M, K, N, monkeypatc
     """K15 (csrc/skinny_linear.hip: the PatchGAN's full-map convolution as x W^T for a handful of rows) against torch in fp64:
     the three kernels and their autograd composition incl. an R1-style second-order gradient."""
     monkeypatch.setenv("TP_SKINNY_DGRAD_KERNEL", "1")          # (the data-gradient kernel is opt-in: rocBLAS is 0.7 % faster per iteration)
+    knobs.reload()
     from texpose_amd import autograd_ops
     torch.manual_seed(M + K + N)
     x0 = torch.randn(M, K, device=dev())
@@ -2767,6 +2785,7 @@ def test_feat_chain_one_call_matches_torch_fp64_and_the_general_pieces(ops, B, m
     assert rel_l2(gr, grd) < 1e-5, rel_l2(gr, grd)
     # the general pieces (K13 inputs, K12 convolutions, pools, pair loss under autograd)
     monkeypatch.setenv("TP_NO_FEAT_CHAIN", "1")
+    knobs.reload()
     r2 = rgb0.clone().requires_grad_()
     old = net.loss_from_patches(r2, g, (h, w), 5.0)
     assert "FeatChainLoss" not in type(old.grad_fn).__name__
@@ -2774,6 +2793,7 @@ def test_feat_chain_one_call_matches_torch_fp64_and_the_general_pieces(ops, B, m
     assert rel_l2(loss, old) < 2e-6 and rel_l2(gr, go) < 5e-6
     # the packed image follows the weights: an in-place change re-packs (same buffer), the loss moves with it
     monkeypatch.delenv("TP_NO_FEAT_CHAIN")
+    knobs.reload()
     with torch.no_grad():
         net.model[0].weight.mul_(1.5)
     packed2, _ = net._chain_params()
@@ -2892,6 +2912,7 @@ def test_exact_fp32_asm_kernel_bit_identical_to_compiled(ops, monkeypatch, B, R,
     outs = []
     for cxx in ("1", "0"):
         monkeypatch.setenv("TP_FP32_CXX", cxx)
+        knobs.reload()
         a = ops.mlp_forward(packed, lt, ll, center=center, ray=ray, depth=depth, precision="fp32")
         b = ops.mlp_forward(packed, lt, ll, points=pts.contiguous(), ray_unit=unit, precision="fp32")
         torch.cuda.synchronize()
@@ -2923,6 +2944,7 @@ def test_exact_fp32_asm_recording_bit_identical_to_compiled(ops, monkeypatch, B,
     outs = []
     for cxx in ("1", "0"):
         monkeypatch.setenv("TP_FP32_CXX", cxx)
+        knobs.reload()
         # (records into zero-filled buffers: neither kernel writes every word of a group -- slot 7 holds 30 rows, dead lanes nothing)
         sa, sb = torch.zeros(n_saved, device=dev()), torch.zeros(n_saved, device=dev())
         a = ops.mlp_forward(packed, lt, ll, center=center, ray=ray, depth=depth, precision="fp32", save=True, saved_out=sa)
@@ -2975,10 +2997,12 @@ def test_prefetched_spectral_weights_equal_in_place_normalisation(ops):
     d_c, d_d = copy.deepcopy(d_a), copy.deepcopy(d_a)
     d_c.prefetch_spectral_weights(3)
     os.environ["TP_NO_SN_SETS"] = "1"
+    knobs.reload()
     try:
         d_d.prefetch_spectral_weights(3)
     finally:
         os.environ.pop("TP_NO_SN_SETS", None)
+        knobs.reload()
     torch.cuda.synchronize()
     for (oc, sc_, uc, vc, _), (od, sd_, ud, vd, _) in zip(d_c._sn_queue, d_d._sn_queue):
         for a, b in zip(list(oc) + list(sc_) + list(uc) + list(vc), list(od) + list(sd_) + list(ud) + list(vd)):
@@ -3004,8 +3028,10 @@ def test_one_launch_head_pack_is_bit_identical_to_the_three_launch_form(ops, mon
     for merged in (False, True):
         if merged:
             monkeypatch.delenv("TP_NO_PACK_MERGE", raising=False)
+            knobs.reload()
         else:
             monkeypatch.setenv("TP_NO_PACK_MERGE", "1")
+            knobs.reload()
         g, opt = _graph(params, N=N)
         g.nerf.train_precision = "f16x3"
         lt = cu(torch.from_numpy(np.random.RandomState(8).normal(size=(B, 16)).astype(np.float32))).requires_grad_()
@@ -3364,8 +3390,10 @@ def test_discriminator_forward_takes_the_fused_tail_for_frozen_weights(ops):
         disc.load_state_dict(state)
         if env is None:
             os.environ.pop("TP_NO_DISC_TAIL", None)
+            knobs.reload()
         else:
             os.environ["TP_NO_DISC_TAIL"] = env
+            knobs.reload()
         try:
             disc.prefetch_spectral_weights(1)
             x = x0.clone().requires_grad_()
@@ -3375,6 +3403,7 @@ def test_discriminator_forward_takes_the_fused_tail_for_frozen_weights(ops):
             res.append((out.detach().clone(), x.grad.clone(), type(out.grad_fn).__name__))
         finally:
             os.environ.pop("TP_NO_DISC_TAIL", None)
+            knobs.reload()
     assert "DiscTail" in res[0][2] and "DiscTail" not in res[1][2]
     torch.testing.assert_close(res[0][0], res[1][0], rtol=2e-5, atol=2e-6)
     assert rel_l2(res[0][1], res[1][1]) < 1e-5

@@ -25,13 +25,12 @@ keeps its autograd form for those (golden generation, contract tests).
 """
 from __future__ import annotations
 
-import os
 from typing import List, Optional
 
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import knobs, ops
 from .gan_modules import Discriminator, SNConv2d, _pow2_map
 from .options import AttrDict
 
@@ -263,16 +262,16 @@ class DiscStepSchedule:
         return out2[0], g_rgb, f.out
 
     def generator_pass_eligible(self, opt, fake) -> bool:
-        if os.environ.get("TP_NO_GEN_SCHEDULE") == "1" or not self.eligible(opt, fake) or opt.loss_weight.get("gan_nerf") is None:
+        if knobs.K.no_gen_schedule or not self.eligible(opt, fake) or opt.loss_weight.get("gan_nerf") is None:
             return False
-        return self.pairs_eligible(fake) or os.environ.get("TP_NO_DISC_PAIRS") == "1" and self._tail_ok(fake)
+        return self.pairs_eligible(fake) or knobs.K.no_disc_pairs and self._tail_ok(fake)
 
     def _tail_ok(self, x) -> bool:
         B, _, h, w = x.shape
         for _ in self.stages:
             h, w = h // 2, w // 2
         K_in = self.full.weight_orig.shape[1] * h * w
-        return K_in % 4 == 0 and B <= ops.DISC_TAIL_MAX_ROWS and os.environ.get("TP_NO_DISC_TAIL") != "1"
+        return K_in % 4 == 0 and B <= ops.DISC_TAIL_MAX_ROWS and not knobs.K.no_disc_tail
 
     # ------------------------------------------------------------------ the step with the real and the fake pass as PAIRS of launches
     # D(real) and D(fake) go through the same kernels one after the other, and so do their backward passes; every one of those launches
@@ -280,15 +279,15 @@ class DiscStepSchedule:
     # one: 8 launches and ~75 us off the discriminator chain of the B=4 iteration, the chain that bounds it.  Same
     # kernels on the same operands: values identical to the sequential schedule.
     def pairs_eligible(self, x) -> bool:
-        if os.environ.get("TP_NO_DISC_PAIRS") == "1":
+        if knobs.K.no_disc_pairs:
             return False
         B, _, h, w = x.shape
         for _ in self.stages:
-            if (h // 2) * (w // 2) not in (16, 64) or h != w or os.environ.get("TP_NO_CONV_INORM") == "1":
+            if (h // 2) * (w // 2) not in (16, 64) or h != w or knobs.K.no_conv_inorm:
                 return False
             h, w = h // 2, w // 2
         K_in = self.full.weight_orig.shape[1] * h * w
-        return K_in % 4 == 0 and B <= ops.DISC_TAIL_MAX_ROWS and os.environ.get("TP_NO_DISC_TAIL") != "1"
+        return K_in % 4 == 0 and B <= ops.DISC_TAIL_MAX_ROWS and not knobs.K.no_disc_tail
 
     def _forward_pair(self, xr, Wr, xf, Wf, scale, stacks, copies=None):
         """`_forward` of the real patches (weights Wr, inputs of the later stages into `stacks`) and of the fake patches (Wf), in pairs.
@@ -397,7 +396,7 @@ class DiscStepSchedule:
         copies, src_real, src_fake = None, real_stack[:B], fake
         if own_inputs:
             stack_own, fake_own = torch.empty_like(real_stack), torch.empty_like(fake)
-            if os.environ.get("TP_NO_CONV_COPY") == "1" or real_stack[:B].numel() % 4 or not real_stack.is_contiguous():
+            if knobs.K.no_conv_copy or real_stack[:B].numel() % 4 or not real_stack.is_contiguous():
                 ops.step_inputs([(stack_own[:B], real_stack[:B]), (fake_own, fake)])
                 src_real, src_fake = stack_own[:B], fake_own
             else:

@@ -14,11 +14,12 @@ PerceptualLoss needs torchvision's ImageNet VGG19 weights, which are not availab
 from __future__ import annotations
 
 import math
-import os
 
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+
+from . import knobs
 
 
 def _pow2_map(n: int) -> bool:
@@ -208,7 +209,7 @@ class Discriminator(nn.Module):
         if (x.shape[-2] >> n_down, x.shape[-1] >> n_down) != (kh, kw):
             return False
         k_in = last.weight_orig.shape[1] * kh * kw
-        return x.shape[0] <= ops.DISC_TAIL_MAX_ROWS and k_in % 4 == 0 and k_in >= 1024 and os.environ.get("TP_NO_DISC_TAIL") != "1"
+        return x.shape[0] <= ops.DISC_TAIL_MAX_ROWS and k_in % 4 == 0 and k_in >= 1024 and not knobs.K.no_disc_tail
 
     def _plain_head(self):
         """``final`` is LeakyReLU, 1x1, LeakyReLU, 1x1, LeakyReLU, 1x1 with one slope (what __init__ builds)."""
@@ -234,7 +235,7 @@ class Discriminator(nn.Module):
             raise RuntimeError("prefetch_spectral_weights: %d prefetched weight sets were never used" % len(self._sn_queue))
         convs = self.sn_convs()
         W, U, V = [c.weight_orig.detach() for c in convs], [c.weight_u for c in convs], [c.weight_v for c in convs]
-        if 1 < n_calls <= ops.SN_MAX_SETS and os.environ.get("TP_NO_SN_SETS") != "1":
+        if 1 < n_calls <= ops.SN_MAX_SETS and not knobs.K.no_sn_sets:
             # all power iterations first (2 launches each), ONE normalisation launch for the n_calls sets: 2 n + 1 launches instead of 3 n
             for outs, sigmas, us, vs in ops.spectral_norm_fwd_sets(W, U, V, n_calls):
                 self._sn_queue.append((outs, sigmas, us, vs, torch.cuda.current_stream(outs[0].device)))

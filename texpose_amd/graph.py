@@ -16,13 +16,12 @@ injected, not re-implemented.
 from __future__ import annotations
 
 import itertools
-import os
 import warnings
 
 import torch
 import torch.nn.functional as torch_F
 
-from . import autograd_ops, ops
+from . import autograd_ops, knobs, ops
 from .geometry import FlexPatchSampler, RaySampler, rotation_distance
 from .nerf import NeRF
 from .options import AttrDict as edict
@@ -241,7 +240,7 @@ class Graph(torch.nn.Module):
         args = (var.ray_idx, var.image, var.get("image_syn", var.image),
                 var.get("nocs_pred", var.image), var.get("normal_pred", var.image),
                 var.obj_mask.view(B, opt.H, opt.W), var.get("mask_syn", var.obj_mask).view(B, opt.H, opt.W))
-        if disc_rgb is not None and disc_rgb.is_cuda and os.environ.get("TP_NO_GATHER_DISC") != "1":
+        if disc_rgb is not None and disc_rgb.is_cuda and not knobs.K.no_gather_disc:
             g, real, fake = ops.patch_gather(*args, disc_rgb=disc_rgb, disc_geo=bool(opt.gan.geo_conditional))
             var.disc_stacks = (real, fake, disc_rgb)
         else:

@@ -8,12 +8,11 @@ architecture is compiled into the kernels; anything else raises instead of silen
 from __future__ import annotations
 
 import math
-import os
 from typing import Optional
 
 import torch
 
-from . import autograd_ops, ops
+from . import autograd_ops, knobs, ops
 
 
 def _layer_dims(layers):
@@ -126,7 +125,7 @@ class NeRF(torch.nn.Module):
                 ops.pack_weights(st, packed=buf, parts=ops.PACK_TRUNK, precision=precision, ray_bias=ray_bias)
                 ver[0] = vt
             if ver[1] != vh:
-                if precision == "f16x3" and for_training and os.environ.get("TP_NO_PACK_MERGE") != "1":
+                if precision == "f16x3" and for_training and not knobs.K.no_pack_merge:
                     # a training step: forward chunks, biases AND the transposed image of this step's data gradient in one launch
                     if self._packed_t is None or self._packed_t.device != dev:
                         self._packed_t = torch.empty(ops.packed_t_bytes() // 4, device=dev)

@@ -11,11 +11,10 @@ import ctypes as C
 import functools
 from typing import Dict, Optional, Tuple
 
-import os
 
 import torch
 
-from . import _lib
+from . import _lib, knobs
 from ._lib import (CompositeArgs, CompositeBwdArgs, MlpBwdArgs, MlpFwdArgs, MlpWeights, PatchGatherArgs, RaygenArgs,
                    check)
 
@@ -396,7 +395,7 @@ def ray_bias_applies(precision: str, n_samples_per_ray: int, save: bool, center_
     when no activation record is written, rays come as (center, ray, depth) and every 128-sample tile lies inside one ray.
     TP_NO_RAY_BIAS=1 switches it off (same-box A/B)."""
     return (precision == "f16x3" and not save and center_form and n_samples_per_ray % 128 == 0
-            and os.environ.get("TP_NO_RAY_BIAS") != "1")
+            and not knobs.K.no_ray_bias)
 
 
 _bwd_scratch: Dict[Tuple[int, int], Dict[str, Tensor]] = {}
@@ -1046,7 +1045,7 @@ def conv4s2_fwd(x: Tensor, w: Tensor, out: Optional[Tensor] = None) -> Tensor:
 def conv4s2_fwd_inorm_supported(x: Tensor) -> bool:
     """The fused convolution + InstanceNorm + LeakyReLU launch covers 4x4 and 8x8 output maps (whole instances per workgroup)."""
     return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and (x.shape[2] // 2) * (x.shape[3] // 2) in (16, 64)
-            and x.shape[2] == x.shape[3] and os.environ.get("TP_NO_CONV_INORM") != "1")
+            and x.shape[2] == x.shape[3] and not knobs.K.no_conv_inorm)
 
 
 @_on_tensor_device
@@ -1077,7 +1076,7 @@ def conv4s2_fwd_inorm(x: Tensor, w: Tensor, eps: float, slope: float, y_out: Opt
 def conv4s2_dgrad_inorm_supported(gy: Tensor) -> bool:
     """The data gradient can carry the InstanceNorm + LeakyReLU backward of the stage in front of it: 8x8 input maps (whole instances
     per workgroup)."""
-    return gy.is_cuda and gy.dim() == 4 and tuple(gy.shape[-2:]) == (4, 4) and os.environ.get("TP_NO_DGRAD_INORM") != "1"
+    return gy.is_cuda and gy.dim() == 4 and tuple(gy.shape[-2:]) == (4, 4) and not knobs.K.no_dgrad_inorm
 
 
 @_on_tensor_device
@@ -1239,7 +1238,7 @@ _feat_chain_scratch: Dict[tuple, tuple] = {}
 def feat_chain_supported(rgb: Tensor, gathered: Tensor, hw) -> bool:
     """K18 covers 16 x 16 patches of float32 CUDA tensors (tp_feat_chain)."""
     return (rgb.is_cuda and rgb.dtype == torch.float32 and gathered.dtype == torch.float32 and tuple(hw) == (16, 16)
-            and rgb.dim() == 3 and rgb.shape[1] == 256 and os.environ.get("TP_NO_FEAT_CHAIN") != "1")
+            and rgb.dim() == 3 and rgb.shape[1] == 256 and not knobs.K.no_feat_chain)
 
 
 def feat_chain_pack(weights, out: Optional[Tensor] = None) -> Tensor:
@@ -1691,7 +1690,7 @@ _tail_ws = {}                # (device index, stream) -> workspace tensor of the
 def disc_tail_eligible(a: Tensor, W0: Tensor, extra_rows: int = 0) -> bool:
     """The fused tail (K17) takes up to 16 rows (and 16 extra weight-gradient rows), K a multiple of 4, fp32 device tensors."""
     return (a.is_cuda and a.dtype == torch.float32 and a.dim() == 2 and a.shape[0] <= DISC_TAIL_MAX_ROWS and extra_rows <= DISC_TAIL_MAX_ROWS
-            and a.shape[1] % 4 == 0 and W0.shape[1] == a.shape[1] and os.environ.get("TP_NO_DISC_TAIL") != "1")
+            and a.shape[1] % 4 == 0 and W0.shape[1] == a.shape[1] and not knobs.K.no_disc_tail)
 
 
 def _tail_args(W0, W1, W2, W3, M, L, slope):
@@ -1829,7 +1828,7 @@ def skinny_linear_dgrad(gy: Tensor, w: Tensor, out: Optional[Tensor] = None) -> 
     """gy [M,N] @ w [N,K] -> [M,K].  A library GEMM by default (rocBLAS does this shape in ~5 us); TP_SKINNY_DGRAD_KERNEL=1 selects
     K15's own kernel for up to 16 rows (tp_skinny_linear_dgrad: the step then contains no library kernel, and runs 0.7 % slower --
     664-669 vs 671-677 it/s, three alternating runs on one box)."""
-    if gy.shape[0] > SKINNY_DGRAD_MAX_ROWS or os.environ.get("TP_SKINNY_DGRAD_KERNEL") != "1":
+    if gy.shape[0] > SKINNY_DGRAD_MAX_ROWS or not knobs.K.skinny_dgrad_kernel:
         return torch.mm(gy, w, out=out) if out is not None else torch.mm(gy, w)
     lib = _lib.load()
     gy, w = _f32(gy, "gy"), _f32(w, "w")

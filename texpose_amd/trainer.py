@@ -21,13 +21,12 @@ are averaged with ONE flat all-reduce after all backward calls of that step (too
 from __future__ import annotations
 
 import copy
-import os
 import warnings
 
 import torch
 
 from . import dist as tdist
-from . import ops
+from . import knobs, ops
 from .graph import Graph, summarize_loss
 from .options import AttrDict
 from .options import AttrDict as edict
@@ -131,7 +130,7 @@ class GanTrainer:
         self.lr_nerf_used = mk(opt.optim.lr)               # what the optimiser reads (captured: lr x the step gate)
         # captured trainer: every tensor of the Adam step in one launch (torch's foreach implementation with a tensor learning
         # rate is ~40 multi-tensor + 2 per-parameter launches, its fused one 4 launches / 60 us for these 25 small tensors)
-        fused_own = self.capturable and dev.type == "cuda" and not os.environ.get("TP_NO_FUSED_ADAM")
+        fused_own = self.capturable and dev.type == "cuda" and not knobs.K.no_fused_adam
         adam = FusedAdam if fused_own else torch.optim.Adam
         self.optim_nerf = adam([dict(params=nerf_params, lr=self.lr_nerf_used),
                                 dict(params=graph.latent_vars_light.parameters(), lr=self.lr_nerf_used),
@@ -142,7 +141,7 @@ class GanTrainer:
             self.disc_group = [p for p in graph.discriminator.parameters()]
             self.lr_disc = mk(opt.optim_disc.lr)
             self.lr_disc_used = mk(opt.optim_disc.lr)
-            rms = FusedRMSprop if self.capturable and dev.type == "cuda" and not os.environ.get("TP_NO_FUSED_RMSPROP") else torch.optim.RMSprop
+            rms = FusedRMSprop if self.capturable and dev.type == "cuda" and not knobs.K.no_fused_rmsprop else torch.optim.RMSprop
             self.optim_disc = rms([dict(params=self.disc_group, lr=self.lr_disc_used)], capturable=self.capturable)
         self.red_nerf = tdist.FlatGradAllReducer(self.nerf_group, group=group)
         self.red_disc = tdist.FlatGradAllReducer(self.disc_group, group=group) if self.has_disc else None
@@ -264,7 +263,7 @@ class GanTrainer:
     def _disc_schedule(self, x):
         """The explicit launch schedule of the discriminator step (K16, texpose_amd/disc_step.py) when it covers this
         discriminator and these tensors, else None (CPU tensors, other ladders / GAN losses: the autograd form below)."""
-        if os.environ.get("TP_DISC_AUTOGRAD") == "1":
+        if knobs.K.disc_autograd:
             return None
         sched = self.__dict__.get("_disc_sched")
         if sched is None or sched.disc is not self.graph.discriminator:
@@ -499,7 +498,7 @@ def distinct_queue_streams(dev, n, candidates=8, votes=3):
         warnings.warn("texpose_amd: only %d of the %d streams of the captured training step run concurrently with each other and "
                       "with the calling stream (GPU_MAX_HW_QUEUES too small, or the process holds many streams): the step is "
                       "correct and slower (measured 640-735 instead of 850 it/s at B=4)" % (concurrent, n))
-    if os.environ.get("TP_QUEUE_PROBE_VERBOSE") == "1":
+    if knobs.K.queue_probe_verbose:
         print("distinct_queue_streams:", report, "pairwise sharing after the choice:",
               [[int(shares_queue(a, b)) for b in [cur] + chosen] for a in [cur] + chosen], flush=True)
     return chosen
@@ -527,8 +526,12 @@ class GraphedGanTrainer(GanTrainer):
     patch-scale bound is a 0-dim device tensor, the jitter comes from torch's graph-safe Philox stream, the optimisers
     are ``capturable``.  Losses come back as static tensors (read them only when logging: that is the one sync).
 
+    Two captured forms (`_select_form`): the LINEAR graphs on three streams (the full GAN iteration; with several ranks each
+    optimiser launch is a graph of its own behind ONE flat all-reduce), and a generic form for every other configuration (one graph
+    with its branches forked inside; with several ranks gradients | eager all-reduces | optimisers).
+
     By default `train_iteration` returns with the calling stream ordered behind everything the iteration enqueued.  Two opt-in
-    attributes relax that for throughput (one rank, the linear-graph form; bit-identical results either way): ``defer_results`` (the
+    attributes relax that for throughput (the linear graphs; bit-identical results either way): ``defer_results`` (the
     calling stream is ordered behind the consumption of the iteration's INPUTS only) and ``pipeline_disc_tail`` (the discriminator
     step's second half may still run beside the next render).  With either set, order the calling stream behind the results with
     `wait_all()` -- or `finish()` / `flush_flags()`, which also read the gate words -- BEFORE reading losses, parameters or optimiser
@@ -553,13 +556,13 @@ class GraphedGanTrainer(GanTrainer):
         # second), so the arithmetic is unchanged; but the CALLING stream no longer waits for it at the end of `train_iteration`:
         # discriminator losses / weights / optimiser state may be read only behind `wait_all()` or `finish()` (tools/train_dp.py,
         # bench.py and tools/train_bench.py set it; default off = everything ordered on the calling stream).
-        self.pipeline_disc_tail = os.environ.get("TP_PIPELINE_DISC") == "1"
+        self.pipeline_disc_tail = knobs.K.pipeline_disc
         # opt-in: `train_iteration` returns with the calling stream ordered behind the consumption of its inputs, not behind its results
-        # (read losses / parameters behind `wait_all()`); the one-rank six-graph form only (`_replay_linear`)
-        self.defer_results = os.environ.get("TP_DEFER_RESULTS") == "1"
+        # (read losses / parameters behind `wait_all()`); the linear graphs only (`_replay_linear`)
+        self.defer_results = knobs.K.defer_results
         self._d2_pending = False
-        self._four, self._g4, self._ev4 = False, None, None    # the step as four graphs on two streams (`_use_four_graphs`)
-        self._linear = False                     # ... as six LINEAR graphs on three streams (`_use_linear_graphs`)
+        self._graphs, self._events = None, None  # the captured linear graphs by name, the events that order them across streams
+        self._linear = False                     # the step as LINEAR graphs on three streams (`_use_linear_graphs`)
         self._dp = False                         # ... with a gradient all-reduce between each gradient graph and its optimiser graph
         # what the optimiser launches read: the words as they stood when the step's own flags had been folded in
         self._gate_nerf, self._gate_disc = torch.zeros_like(self._bad), torch.zeros_like(self._bad)
@@ -615,9 +618,9 @@ class GraphedGanTrainer(GanTrainer):
         gradients, two eager collectives, replay B = the optimiser steps).  This is the DEFAULT whenever there is more than
         one rank; RCCL collectives inside a replayed hipGraph (TP_COLLECTIVES_IN_GRAPH=1 opts in) have only been exercised in
         a 1-rank group (tests), and between two replays they are ordinary stream-ordered calls."""
-        if os.environ.get("TP_COLLECTIVES_IN_GRAPH"):
+        if knobs.K.collectives_in_graph:
             return False
-        return self.red_nerf.world_size > 1 or bool(os.environ.get("TP_SPLIT_GRAPH"))
+        return self.red_nerf.world_size > 1 or knobs.K.split_graph
 
     def _reduce_all(self):
         """The step's collectives, in ONE fixed order on every rank, after both branches have joined.  The sticky gate words
@@ -628,10 +631,10 @@ class GraphedGanTrainer(GanTrainer):
             self.red_disc.reduce()
 
     def _body(self, var):
-        """One iteration (what is captured as ONE graph; `_body_a` / `_body_b` when the collectives stay outside; `_four_eager` is
-        the same iteration in the four-graph form)."""
-        if self._four:
-            return self._four_eager(var)
+        """One iteration (what is captured as ONE graph; `_body_a` / `_body_b` when the collectives stay outside; `_linear_eager` is
+        the same iteration with the segments and dependencies of the linear graphs)."""
+        if self._linear:
+            return self._linear_eager(var)
         out = self._body_a(var)
         if self._deferred:
             self._reduce_all()
@@ -649,10 +652,10 @@ class GraphedGanTrainer(GanTrainer):
         both optimiser steps follow after the join (`_reduce_all`, `_body_b`)."""
         opt = self.opt
         dev = var.idx.device
-        overlap = self.has_disc and not os.environ.get("TP_NO_BRANCH_OVERLAP")
+        overlap = self.has_disc and not knobs.K.no_branch_overlap
         if overlap and self._side is None:
             self._side = torch.cuda.Stream(device=dev)
-        if overlap and getattr(self.graph, "feat_stream", None) is None and os.environ.get("TP_NO_FEAT_BRANCH") != "1":
+        if overlap and getattr(self.graph, "feat_stream", None) is None and not knobs.K.no_feat_branch:
             # third chain of the replayed step: the feature network's forward and backward (graph.Graph._feature_loss_early)
             self.graph.feat_stream = torch.cuda.Stream(device=dev)
         self._prefetch_spectral_weights(var)                         # (first: it runs beside everything up to the render)
@@ -678,11 +681,6 @@ class GraphedGanTrainer(GanTrainer):
         dloss = None
         # optimiser steps (and reductions) after this function: whenever a collective is part of the step, or on request
         self._deferred = self._has_collective() or self._split_around_collectives()
-        # (diagnostic knobs, tools/gan_timeline.sh: TP_SKIP_DISC_STEP=1 leaves the discriminator step out of the iteration -- NOT a
-        # training step, only to time the generator chain alone; TP_BACKWARD_FIRST=1 issues the generator's backward before the
-        # discriminator branch, which changes the order of the nodes in the captured graph and nothing else)
-        skip_disc = os.environ.get("TP_SKIP_DISC_STEP") == "1"
-        backward_first = os.environ.get("TP_BACKWARD_FIRST") == "1"
 
         def generator_backward():
             torch.autograd.backward(terms, ws)
@@ -690,18 +688,13 @@ class GraphedGanTrainer(GanTrainer):
                 self._guard_nerf(var, loss)
                 self.nerf_apply()
 
-        if overlap and not skip_disc:
+        if overlap:
             main = torch.cuda.current_stream(var.rgb.device)
             self._side.wait_stream(main)                          # fork
-            if backward_first:
-                generator_backward()
             with torch.cuda.stream(self._side):
                 var, dloss = self.disc_step(var, apply=not self._deferred)
-        if not (overlap and not skip_disc and backward_first):
-            generator_backward()
-        if skip_disc:
-            pass
-        elif overlap:
+        generator_backward()
+        if overlap:
             main.wait_stream(self._side)                          # join
         elif self.has_disc:
             var, dloss = self.disc_step(var, apply=not self._deferred)
@@ -709,36 +702,34 @@ class GraphedGanTrainer(GanTrainer):
             loss.update({k: v for k, v in dloss.items() if k != "all"})
         return {k: v.detach() for k, v in loss.items() if torch.is_tensor(v)}
 
-    # ------------------------------------------------------------------ the step as FOUR graphs on two streams (one rank)
-    # A replayed multi-branch hipGraph resolves a dependency between two of its hardware queues late: the generator's backward sat
-    # behind ~60 % of the discriminator chain it does not depend on (profiles/r4: 220 us of a 1.22 ms iteration).  With the step cut
-    # into linear pieces the two chains are two STREAMS, and the only dependencies between them are three events:
-    #     main:  [wait D2 of the iteration before]  G1 = patch coordinates .. render .. gathers, patch stacks   -> ev_patches
-    #            [wait ev_sn]                       G2 = feature chain || D(fake), losses, gate, backward, Adam
-    #     disc:  D1 = the three spectral normalisations (after its own RMSprop step, stream order)             -> ev_sn
-    #            [wait ev_patches]                  D2 = discriminator step, RMSprop                             -> ev_d2
-    # (G2 keeps the feature chain as a branch of its own.)  Same kernels, same arithmetic as the one-graph form.
-    def _use_four_graphs(self, var):
-        if os.environ.get("TP_FOUR_GRAPHS", "1") != "1" or not self.has_disc:
+    # ------------------------------------------------------------------ which form
+    def _use_linear_graphs(self, var):
+        """The full GAN iteration of the reference's configuration: PatchGAN with the explicit schedule (K16) and prefetched spectral
+        norms, the generator's GAN term, patch rays.  The feature chain is optional (its graph F is left out without it)."""
+        opt, lw = self.opt, self.opt.loss_weight
+        if not (knobs.K.linear_graphs and self.has_disc and opt.gan is not None and lw.gan_nerf is not None and bool(opt.nerf.rand_rays)):
             return False
-        p, B = int(self.opt.patch_size), len(var.idx)
+        if knobs.K.no_sn_prefetch or knobs.K.no_branch_overlap or knobs.K.no_feat_branch:
+            return False
+        if lw.feat is not None:
+            pl = getattr(self.graph, "perceptual_loss", None)
+            if pl is None or not (hasattr(pl, "loss_from_patches") and hasattr(pl, "pairs_from_patches")):
+                return False
+        p, B = int(opt.patch_size), len(var.idx)
         probe = torch.empty(0, device=var.idx.device).new_empty((B, 0, p, p))
         disc = self.graph.discriminator
-        return (self._disc_schedule(probe) is not None and hasattr(disc, "prefetch_spectral_weights") and disc.training
-                and os.environ.get("TP_NO_SN_PREFETCH") != "1" and os.environ.get("TP_NO_BRANCH_OVERLAP") != "1")
+        return self._disc_schedule(probe) is not None and hasattr(disc, "prefetch_spectral_weights") and disc.training
 
     def _select_form(self, var):
-        """Which captured form this configuration gets: the linear graphs (one rank: six; several ranks: the same with every
-        optimiser launch as a graph of its own behind its all-reduce, `_dp`), the four-graph form (one rank, no feature chain), or
-        ONE graph (`_body`; with several ranks: gradients | eager all-reduces | optimiser steps).  Also points the fused optimisers
-        at the gate words of that form."""
+        """Which captured form this configuration gets: the linear graphs (several ranks: the same with every optimiser launch as a
+        graph of its own behind its all-reduce, `_dp`), or ONE graph (`_body`; with several ranks: gradients | eager all-reduces |
+        optimiser steps).  Also points the fused optimisers at the gate words of that form."""
         collective = self._has_collective() or self._split_around_collectives()
-        self._four = self._use_four_graphs(var)
-        self._linear = self._four and self._use_linear_graphs(var)
+        self._linear = self._use_linear_graphs(var)
         fused = isinstance(self.optim_nerf, FusedAdam) and self.has_disc and isinstance(self.optim_disc, FusedRMSprop)
-        self._dp = bool(collective and self._linear and fused and os.environ.get("TP_NO_LINEAR_DP") != "1")
+        self._dp = bool(collective and self._linear and fused and not knobs.K.no_linear_dp)
         if collective and not self._dp:
-            self._four = self._linear = False
+            self._linear = False
         self._point_gates()
 
     def _point_gates(self):
@@ -773,19 +764,6 @@ class GraphedGanTrainer(GanTrainer):
         finally:
             self.graph.step_counter = self.graph.patch_sampler.device_counter = None
         return var
-
-    def _seg_generator(self, var):
-        dev = var.idx.device
-        if getattr(self.graph, "feat_stream", None) is None and os.environ.get("TP_NO_FEAT_BRANCH") != "1":
-            self.graph.feat_stream = torch.cuda.Stream(device=dev)
-        var, loss = self.nerf_forward_loss(var, stage="consume")
-        status = ops.mlp_status(dev) if self._uses_f16x3() else None
-        terms, ws = self._weighted_total(loss, flags=dict(bad=self._bad, word_finite=1, snapshot=self._gate_nerf, status=status,
-                                                          word_status=0, step_counter=getattr(self, "_rng_counter", None)))
-        torch.autograd.backward(terms, ws)
-        self._guard_nerf(var, loss)
-        self.nerf_apply()
-        return var, loss
 
     def _seg_disc(self, var):
         out = self.disc_step(var, apply=not self._dp)
@@ -832,7 +810,7 @@ class GraphedGanTrainer(GanTrainer):
         (loss total + gate, RMSprop): one rank (no gradient reduction between gradient and step), the fused RMSprop with one plain group
         over exactly the schedule's weights, the gate words on the device.  Else None: total, gate and step as launches of their own."""
         flags, optim = self._disc_gate_flags(), self.optim_disc
-        if (flags is None or os.environ.get("TP_NO_DISC_STEP_TAIL") == "1" or not isinstance(optim, FusedRMSprop) or optim.gate is None
+        if (flags is None or knobs.K.no_disc_step_tail or not isinstance(optim, FusedRMSprop) or optim.gate is None
                 or self._has_collective() or (self.red_disc is not None and self.red_disc.world_size > 1) or len(optim.param_groups) != 1):
             return None
         group = optim.param_groups[0]
@@ -854,27 +832,22 @@ class GraphedGanTrainer(GanTrainer):
                     square_avgs=[optim.state[p]["square_avg"] for p in params], steps=[optim.state[p]["step"] for p in params],
                     lr=group["lr"], alpha=group["alpha"], eps=group["eps"])
 
-    # ------------------------------------------------------------------ ... and as SIX LINEAR graphs on three streams
-    # G2 above still forks inside the graph (the feature chain beside the discriminator's pass), and a replayed graph with a fork picks
-    # the hardware queue of its second branch by the runtime's round-robin over ALL streams the process ever made: the same trainer ran
-    # 870 it/s in a fresh process and 660 it/s behind other legs of bench.py that had created timing streams (profiles/r4).  Launching it
-    # also costs the host 110 us against 6-14 us for a linear graph.  So the fork is taken out of the graph as well: the feature chain
-    # runs forward AND backward as a graph of its own on a third stream and hands the generator step a cotangent,
-    #     main:  G1 = render .. patch stacks -> ev_patches;  [wait ev_sn] G2a = D(fake), loss terms, D's backward down to the patches;
-    #            [wait ev_feat] G2b = loss total + gate, composite / MLP backward from (terms, d gan / d rgb, d feat / d rgb), Adam
-    #     feat:  [wait ev_patches] F = feature inputs, network, pair loss, its backward down to the render's rgb   -> ev_feat
-    #     disc:  D1, D2 as above
-    # Every graph is a chain and every stream is the trainer's own, made one after the other (three consecutive hardware queues whatever
-    # the process created before).  Same kernels and the same cotangent values as the one-graph form: the composite's backward sums the
-    # cotangents of its rgb aliases either way (autograd_ops._Composite, fan_out).
-    def _use_linear_graphs(self, var):
-        opt, g = self.opt, self.graph
-        lw = opt.loss_weight
-        pl = getattr(g, "perceptual_loss", None)
-        return (os.environ.get("TP_LINEAR_GRAPHS", "1") == "1" and os.environ.get("TP_NO_FEAT_BRANCH") != "1" and lw.feat is not None
-                and lw.gan_nerf is not None and pl is not None and hasattr(pl, "loss_from_patches") and hasattr(pl, "pairs_from_patches")
-                and bool(opt.nerf.rand_rays))
-
+    # ------------------------------------------------------------------ the step as LINEAR graphs on three streams
+    # A replayed multi-branch hipGraph resolves a dependency between two of its hardware queues late (profiles/r4: the generator's
+    # backward sat behind ~60 % of a discriminator chain it does not depend on), picks the hardware queue of a forked branch by the
+    # runtime's round-robin over ALL streams the process ever made (870 it/s in a fresh process, 660 behind other work), and costs the
+    # host 110 us to launch against 6-14 us for a linear graph.  So the iteration is cut into chains, every one a graph without a fork,
+    # on three streams of the trainer's own; the only dependencies between streams are events:
+    #     main:  G1 = patch coordinates .. render .. gathers, patch stacks -> ev patches;  F = feature inputs, network, pair loss and its
+    #            backward down to the render's rgb (K18);  [wait ev g2a] G2b = loss total + gate, composite / MLP backward from (terms,
+    #            d gan / d rgb, d feat / d rgb), Adam  -> ev g2
+    #     third: [wait ev patches, ev sn] G2a = D(fake) for the generator, its loss term and gradient wrt the rendered colours -> ev g2a
+    #     disc:  D1 = the three spectral normalisations (after its own RMSprop step, stream order) -> ev sn;  [wait ev patches] D2a =
+    #            forward pairs, BCE -> ev d2a;  D2b = R1, backward pairs, spectral-norm backward + RMSprop -> ev d2
+    # Several ranks (`_dp`): G2b and D2b end with the gradients packed into their flat buffer, the all-reduce is a stream-ordered call
+    # behind the replay, and the optimiser launch is a graph of its own (G2c, D2c) behind it.
+    # Same kernels and the same cotangent values as the one-graph form: the composite's backward sums the cotangents of its rgb
+    # aliases either way (autograd_ops._Composite, fan_out).
     def _seg_feat(self, var):
         """The feature loss of the nerf step and its cotangent 10^w d feat / d rgb on the rgb alias the composite made for it."""
         _, h, w, _ = var.ray_idx.shape
@@ -915,7 +888,7 @@ class GraphedGanTrainer(GanTrainer):
         # (the total + gate ride in the first launch of the backward pass, K8's: nothing differentiates through them)
         terms, ws = self._weighted_total(loss, flags=dict(bad=self._bad, word_finite=1, snapshot=self._gate_nerf, status=status,
                                                           word_status=0, step_counter=getattr(self, "_rng_counter", None)),
-                                         defer=os.environ.get("TP_NO_TOTAL_IN_BWD") != "1")
+                                         defer=not knobs.K.no_total_in_bwd)
         roots = {"gan_nerf": (var.rgb_disc, g_disc)}
         if "g_rgb_feat" in var:                        # (the feature chain ran as a graph of its own, `_seg_feat`)
             roots["feat"] = (var.rgb_feat, var.g_rgb_feat)
@@ -955,7 +928,7 @@ class GraphedGanTrainer(GanTrainer):
     def _collectives_in_graph():
         """Opt-in (TP_COLLECTIVES_IN_GRAPH=1): the RCCL all-reduces are captured as nodes of the gradient graphs instead of issued
         between two replays.  Exercised in a 1-rank group only (tests); stream-ordered calls are the default."""
-        return bool(os.environ.get("TP_COLLECTIVES_IN_GRAPH"))
+        return knobs.K.collectives_in_graph
 
     def _collective(self, name, red):
         """One flat all-reduce on the current stream, between two graph replays; HIP events around it when `collective_events` is a
@@ -970,7 +943,7 @@ class GraphedGanTrainer(GanTrainer):
         e1.record()
         ev.append((name, e0, e1))
 
-    def _four_eager(self, var):
+    def _linear_eager(self, var):
         """The segments on their streams, eagerly (warm-up), with the same dependencies as the replays."""
         main = torch.cuda.current_stream(var.idx.device)
         side = self._side
@@ -979,25 +952,21 @@ class GraphedGanTrainer(GanTrainer):
             self._seg_sn()
         var = self._seg_render(var)
         side.wait_stream(main)
-        if self._linear and not ("rgb_feat" in var and "rgb_disc" in var and var.get("gathered_for") is var.ray_idx):
-            if self._dp:
-                raise _FormUnavailable("no fan-out aliases / fused gathers in this configuration")
-            self._linear = False                     # (no fan-out aliases / fused gathers in this configuration: four graphs)
-        if self._linear:
-            feat = self.graph.feat_stream
-            feat.wait_stream(main)
-            with torch.cuda.stream(feat):
+        if not ("rgb_disc" in var and var.get("gathered_for") is var.ray_idx and (self.opt.loss_weight.feat is None or "rgb_feat" in var)):
+            raise _FormUnavailable("no fan-out aliases / fused gathers in this configuration")
+        if self.opt.loss_weight.feat is not None:
+            third = self._third
+            third.wait_stream(main)
+            with torch.cuda.stream(third):            # (the stream F is CAPTURED on, see `_capture_linear`)
                 self._seg_feat(var)
-            main.wait_stream(side)
-            var, loss, g_disc = self._seg_gen_a(var)
-            main.wait_stream(feat)
-            var, loss = self._seg_gen_b(var, loss, g_disc)
-            if self._dp and not self._collectives_in_graph():
-                self._collective("nerf", self.red_nerf)            # (same order on every rank: nerf, then discriminator)
-                self._seg_gen_c()
-        else:
-            main.wait_stream(side)
-            var, loss = self._seg_generator(var)
+        main.wait_stream(side)
+        var, loss, g_disc = self._seg_gen_a(var)           # (on `main`, the stream G2a is CAPTURED on: per-stream kernel state is keyed by it)
+        if self.opt.loss_weight.feat is not None:
+            main.wait_stream(self._third)
+        var, loss = self._seg_gen_b(var, loss, g_disc)
+        if self._dp and not self._collectives_in_graph():
+            self._collective("nerf", self.red_nerf)                # (same order on every rank: nerf, then discriminator)
+            self._seg_gen_c()
         with torch.cuda.stream(side):
             var, dloss = self._seg_disc(var)
             if self._dp and not self._collectives_in_graph():
@@ -1007,73 +976,17 @@ class GraphedGanTrainer(GanTrainer):
         loss.update({k: v for k, v in dloss.items() if k != "all"})
         return {k: v.detach() for k, v in loss.items() if torch.is_tensor(v)}
 
-    def _capture_four(self, cap):
-        dev = self._bad.device
-        self._g4 = g4 = {k: torch.cuda.CUDAGraph() for k in ("D1", "G1", "G2", "D2")}
-        self._ev4 = {k: torch.cuda.Event() for k in ("sn", "patches", "g2", "d2")}
-        # Two memory pools, one per stream: graphs that share a pool must replay in capture order and never concurrently (a block freed
-        # while one is captured is handed to the next), which holds for D1 -> D2 and for G1 -> G2 but not across the streams.  Tensors
-        # that cross the streams (the spectral-norm sets, the render's patch stacks / scales) are kept referenced for the life of the
-        # graphs, so that no capture re-uses their memory.
-        with torch.cuda.graph(g4["D1"], stream=self._side):
-            self._seg_sn()
-        keep = [list(self.graph.discriminator._sn_queue)]
-        with torch.cuda.graph(g4["G1"], stream=cap):
-            var = self._seg_render(AttrDict(dict(self._static_in)))
-        keep.append(dict(var))
-        with torch.cuda.graph(g4["G2"], stream=cap, pool=g4["G1"].pool()):
-            var, loss = self._seg_generator(var)
-        keep.append(dict(var))
-        with torch.cuda.graph(g4["D2"], stream=self._side, pool=g4["D1"].pool()):
-            var, dloss = self._seg_disc(var)
-        keep.append(dict(var))
-        self._g4_keep = keep
-        loss.update({k: v for k, v in dloss.items() if k != "all"})
-        self._static_loss = {k: v.detach() for k, v in loss.items() if torch.is_tensor(v)}
-        self._four_first = True
-
-    def _replay_four(self):
-        g4, ev, side = self._g4, self._ev4, self._side
-        main = torch.cuda.current_stream(self._bad.device)
-        with torch.cuda.stream(side):
-            # the discriminator stream is ordered behind the CALLER's stream on every replay: D1 reads `weight_orig` and rewrites
-            # `weight_u` / `weight_v` in place, and whatever the caller enqueued between two iterations (a load_state_dict, a parameter
-            # broadcast, a checkpoint copy of u / v) must come first.  `main` is the calling stream here.
-            side.wait_stream(main)
-            if not self._four_first:
-                side.wait_event(ev["g2"])            # set 1 is read by the generator's backward through the frozen discriminator
-            self._four_first = False
-            g4["D1"].replay()
-            ev["sn"].record(side)
-        # (Submission order G2 before D2.  Measured on one box, 200 iterations each: this order 1.184 ms, D2 first 1.197 ms; with the
-        # feature chain inside G2 as a serial part of the main stream 1.22 ms either way; more than 4 hardware queues
-        # (GPU_MAX_HW_QUEUES=5..8) 2.57 ms; profiles/r4.  Which hardware queue the replayed G2 gives its feature branch is the
-        # runtime's round-robin choice: with one or five more streams created before the capture it shares the discriminator stream's
-        # queue and the iteration takes 1.39-1.46 ms.)
-        g4["G1"].replay()
-        ev["patches"].record(main)
-        main.wait_event(ev["sn"])
-        g4["G2"].replay()
-        ev["g2"].record(main)
-        with torch.cuda.stream(side):
-            side.wait_event(ev["patches"])
-            g4["D2"].replay()
-            ev["d2"].record(side)
-        # whatever the caller enqueues next on its stream -- reads of the step's losses, the next iteration's inputs and its G1, which
-        # overwrites the patch stacks / scales this discriminator step is reading -- comes after the discriminator step
-        main.wait_event(ev["d2"])
-
     def _extra(self, name):
         """TP_EXTRA_LAUNCHES="G2a=10,F=10" (experiment): that many one-thread launches at the end of the named graph -- the slope of the
         iteration time over the count says whether that graph's end is on the critical path (~3 us per launch) or not (0)."""
-        for item in os.environ.get("TP_EXTRA_LAUNCHES", "").split(","):
+        for item in knobs.K.extra_launches.split(","):
             if item.strip() and item.split("=")[0].strip() == name:
                 for _ in range(int(item.split("=")[1])):
                     ops.stamp(self._extra_slots, 0)
 
     def _stamp(self, name):
         """TP_STAMPS=1 (tools/linear_timeline.py): a one-thread launch writing the device clock, captured at the segment boundaries."""
-        if os.environ.get("TP_STAMPS") != "1":
+        if not knobs.K.stamps:
             return
         if getattr(self, "_stamps", None) is None:
             self._stamps, self._stamp_names = torch.zeros(32, dtype=torch.int64, device=self._bad.device), []
@@ -1082,35 +995,34 @@ class GraphedGanTrainer(GanTrainer):
         ops.stamp(self._stamps, self._stamp_names.index(name))
 
     def _capture_linear(self, cap):
-        side, feat = self._side, self.graph.feat_stream
-        if os.environ.get("TP_STAMPS") == "1" and getattr(self, "_stamps", None) is None:
+        side = self._side
+        has_feat = self.opt.loss_weight.feat is not None
+        if knobs.K.stamps and getattr(self, "_stamps", None) is None:
             # (made OUTSIDE the captures: a zero-fill captured into the first graph would wipe the other streams' stamps on every replay)
             self._stamps, self._stamp_names = torch.zeros(32, dtype=torch.int64, device=self._bad.device), []
             torch.cuda.synchronize(self._bad.device)
-        self._g4 = g = {k: torch.cuda.CUDAGraph() for k in ("D1", "G1", "F", "G2a", "G2b", "D2")}
-        self._ev4 = {k: torch.cuda.Event() for k in ("sn", "patches", "feat", "g2a", "g2", "d2")}
+        self._graphs = g = {k: torch.cuda.CUDAGraph() for k in ["D1", "G1"] + (["F"] if has_feat else []) + ["G2a", "G2b"]}
+        self._events = {k: torch.cuda.Event() for k in ("sn", "patches", "g2a", "g2", "d2")}
         self._extra_slots = torch.zeros(1, dtype=torch.int64, device=self._bad.device)
-        # one memory pool per stream (see `_capture_four`); tensors that cross streams stay referenced for the life of the graphs
+        # Memory pools: graphs that share a pool must replay in capture order and never concurrently (a block freed while one is
+        # captured is handed to the next), which holds for D1 -> D2a -> D2b and for G1 -> G2a -> G2b but not across the streams (F: its own).
+        # Tensors that cross the streams (the spectral-norm sets, the render's patch stacks / scales) are kept referenced for the life of
+        # the graphs, so that no capture re-uses their memory.
         counts = self.launch_counts = {}                 # nodes per captured graph (kernel launches; TP_STAMPS adds two to each)
-        # The generator's pass through the frozen discriminator (G2a) needs the FIRST normalised weight set only, and in steady state it
-        # is what the next render's backward waits for (D2b -> D1 -> G2a -> G2b): that set as a graph of its own (3 launches), the
-        # other two (2 x 2 + 1 launches) behind it, 8 launches instead of 7 (`TP_SN_SPLIT=1`; default: one graph).
-        if os.environ.get("TP_SN_SPLIT") != "1":       # (measured: 914-920 it/s split, 925-926 as one graph -- the launch count decides)
-            with torch.cuda.graph(g["D1"], stream=side):
-                self._stamp("D1.0"); self._seg_sn(); self._stamp("D1.1"); self._extra("D1"); counts["D1"] = ops.capture_node_count()
-        else:
-            g["D1b"] = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g["D1"], stream=side):
-                self._stamp("D1.0"); self._seg_sn(0); self._stamp("D1.1"); self._extra("D1"); counts["D1"] = ops.capture_node_count()
-            with torch.cuda.graph(g["D1b"], stream=side, pool=g["D1"].pool()):
-                self._seg_sn(1); counts["D1b"] = ops.capture_node_count()
+        # (D1 as two graphs -- the first normalised set, which is all G2a waits for, and the other two behind it -- measured 914-920 it/s
+        # against 925-926 as one graph: the launch count decides, profiles/r5.)
+        with torch.cuda.graph(g["D1"], stream=side):
+            self._stamp("D1.0"); self._seg_sn(); self._stamp("D1.1"); self._extra("D1"); counts["D1"] = ops.capture_node_count()
         keep = [list(self.graph.discriminator._sn_queue)]
         with torch.cuda.graph(g["G1"], stream=cap):
             self._stamp("G1.0"); var = self._seg_render(AttrDict(dict(self._static_in))); self._stamp("G1.1"); self._extra("G1"); counts["G1"] = ops.capture_node_count()
         keep.append(dict(var))
-        with torch.cuda.graph(g["F"], stream=feat):
-            self._stamp("F.0"); self._seg_feat(var); self._stamp("F.1"); self._extra("F"); counts["F"] = ops.capture_node_count()
-        keep.append(dict(var))
+        if has_feat:
+            # (captured on the THIRD stream although it replays on `main`: per-stream kernel state -- tile counters, workspaces -- is keyed
+            # by the capturing stream, and F runs beside G2a, which is captured on `cap`; a pool of its own for the same reason)
+            with torch.cuda.graph(g["F"], stream=self._third):
+                self._stamp("F.0"); self._seg_feat(var); self._stamp("F.1"); self._extra("F"); counts["F"] = ops.capture_node_count()
+            keep.append(dict(var))
         with torch.cuda.graph(g["G2a"], stream=cap, pool=g["G1"].pool()):
             self._stamp("G2a.0"); var, loss, g_disc = self._seg_gen_a(var); self._stamp("G2a.1"); self._extra("G2a"); counts["G2a"] = ops.capture_node_count()
         keep.append((dict(var), dict(loss), g_disc))
@@ -1126,10 +1038,10 @@ class GraphedGanTrainer(GanTrainer):
         # The discriminator step in TWO graphs when its paired schedule applies: D2a = private copies of the patch stacks, forward pairs,
         # BCE terms -- the last reads of anything the render wrote -- and D2b = the R1 passes, backward pairs, spectral-norm backward,
         # RMSprop.  With `pipeline_disc_tail` the next iteration's render starts behind D2a instead of behind D2b (`_replay_linear`).
-        ctx = self._seg_disc_a(var) if os.environ.get("TP_NO_DISC_SPLIT") != "1" else None
+        ctx = self._seg_disc_a(var) if not knobs.K.no_disc_split else None
         if ctx is not None:
             g["D2a"], g["D2b"] = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            self._ev4["d2a"] = torch.cuda.Event()
+            self._events["d2a"] = torch.cuda.Event()
             self.disc_step_zero_grads()
             with torch.cuda.graph(g["D2a"], stream=side, pool=g["D1"].pool()):
                 self._stamp("D2.0"); ctx = self._seg_disc_a(var, run=True); self._stamp("D2a.1"); self._extra("D2a"); counts["D2a"] = ops.capture_node_count()
@@ -1137,8 +1049,8 @@ class GraphedGanTrainer(GanTrainer):
             with torch.cuda.graph(g["D2b"], stream=side, pool=g["D1"].pool()):
                 var, dloss = self._seg_disc_b(var, ctx); self._stamp("D2.1"); counts["D2b"] = ops.capture_node_count()
                 self._extra("D2b")
-            del g["D2"]
         else:
+            g["D2"] = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g["D2"], stream=side, pool=g["D1"].pool()):
                 self._stamp("D2.0"); var, dloss = self._seg_disc(var); self._stamp("D2.1"); counts["D2"] = ops.capture_node_count()
         keep.append(dict(var))
@@ -1146,20 +1058,14 @@ class GraphedGanTrainer(GanTrainer):
             g["D2c"] = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g["D2c"], stream=side, pool=g["D1"].pool()):
                 self._seg_disc_c(); self._extra("D2c"); counts["D2c"] = ops.capture_node_count()
-        self._g4_keep = keep
+        self._graphs_keep = keep
         loss.update({k: v for k, v in dloss.items() if k != "all"})
         self._static_loss = {k: v.detach() for k, v in loss.items() if torch.is_tensor(v)}
-        self._four_first = True
+        self._first_replay = True
 
     def _replay_linear(self):
-        g, ev = self._g4, self._ev4
-        if os.environ.get("TP_ABLATE"):
-            # (timing diagnostic, tools/README: graphs left out of the replay -- what the iteration would cost without that chain; the
-            # numbers such an iteration computes are meaningless)
-            class _Skip:
-                def replay(self): pass
-            g = {k: (_Skip() if k in os.environ["TP_ABLATE"].split(",") else v) for k, v in g.items()}
-        main, side, feat = self._capture_stream, self._side, self.graph.feat_stream
+        g, ev = self._graphs, self._events
+        main, side, third = self._capture_stream, self._side, self._third
         cur = torch.cuda.current_stream(self._bad.device)
         # the caller's stream hands over the step's inputs (and, the first time, parameters restored / loaded since the capture); it
         # waited for the previous iteration's last launches below, so does everything here
@@ -1183,70 +1089,46 @@ class GraphedGanTrainer(GanTrainer):
                 side.wait_event(mark)
             else:
                 side.wait_stream(cur)
-            if not self._four_first:
+            if not self._first_replay:
                 side.wait_event(ev["g2"])            # set 1 is read by the generator's passes through the frozen discriminator
             g["D1"].replay()
             ev["sn"].record(side)
-            if "D1b" in g:
-                g["D1b"].replay()
-        with torch.cuda.stream(main):
-            g["G1"].replay()
-            ev["patches"].record(main)
-        # (The order in which the host submits F / G2a+G2b / D2 makes no difference -- six orders measured within 0.5 % on one box -- and the
-        # host is 4x ahead of the device: 260 us of launches per 1.17 ms iteration.)
+        self._first_replay = False
+        # (The order in which the host submits F / G2a + G2b / D2 makes no difference -- six orders measured within 0.5 % on one box -- and
+        # the host is 4x ahead of the device: 260 us of launches per 1.17 ms iteration.)
         # Which of the two chains between the render and its backward shares the render's stream: each stream hop (event -> first launch
         # of a graph on another hardware queue) costs ~20 us, and the feature chain (137 us alone) is the longer of the two, the
         # generator's pass through the discriminator (101 us) also waits for D1 -- so the feature chain stays on `main` and that pass
-        # takes the third stream (`TP_FEAT_ON_OWN_STREAM=1`: the layout up to profiles/r5/21).
-        feat_on_main = os.environ.get("TP_FEAT_ON_OWN_STREAM") != "1"
-        self._four_first = False
-        with torch.cuda.stream(main if feat_on_main else feat):
-            if not feat_on_main:
-                feat.wait_event(ev["patches"])       # (recorded on `main` behind its wait for the caller's stream)
-            g["F"].replay()
-            ev["feat"].record()
-        d2_first = os.environ.get("TP_G2B_AFTER_D2") == "1"      # (experiment: the render's backward starts behind the discriminator step)
-
-        def disc_step_graph():
-            with torch.cuda.stream(side):
-                side.wait_event(ev["patches"])
-                if os.environ.get("TP_D2_AFTER_FEAT") == "1":   # (experiment: keep the discriminator step out of the feature chain's window)
-                    side.wait_event(ev["feat"])
-                if "D2a" in g:
-                    g["D2a"].replay()
-                    ev["d2a"].record(side)
-                    g["D2b"].replay()
-                else:
-                    g["D2"].replay()
-                if "D2c" in g:                       # several ranks: gradients | all-reduce | RMSprop
-                    self._collective("disc", self.red_disc)
-                    g["D2c"].replay()
-                ev["d2"].record(side)
-
-        if d2_first:
-            disc_step_graph()
-        if feat_on_main:
-            with torch.cuda.stream(feat):
-                feat.wait_event(ev["patches"])
-                feat.wait_event(ev["sn"])
-                g["G2a"].replay()
-                ev["g2a"].record(feat)
+        # takes the third stream (the other layout: profiles/r5/21).
         with torch.cuda.stream(main):
-            if feat_on_main:
-                main.wait_event(ev["g2a"])
-            else:
-                main.wait_event(ev["sn"])
-                g["G2a"].replay()
-                main.wait_event(ev["feat"])
-            if d2_first:
-                main.wait_event(ev["d2"])
+            g["G1"].replay()
+            ev["patches"].record(main)
+            if "F" in g:
+                g["F"].replay()
+        with torch.cuda.stream(third):
+            third.wait_event(ev["patches"])           # (recorded on `main` behind its wait for the caller's stream)
+            third.wait_event(ev["sn"])
+            g["G2a"].replay()
+            ev["g2a"].record(third)
+        with torch.cuda.stream(main):
+            main.wait_event(ev["g2a"])
             g["G2b"].replay()
             if "G2c" in g:                           # several ranks: gradients | all-reduce | Adam.  The host issues the nerf step's
                 self._collective("nerf", self.red_nerf)          # collective before the discriminator step's on EVERY rank.
                 g["G2c"].replay()
             ev["g2"].record(main)
-        if not d2_first:
-            disc_step_graph()
+        with torch.cuda.stream(side):
+            side.wait_event(ev["patches"])
+            if "D2a" in g:
+                g["D2a"].replay()
+                ev["d2a"].record(side)
+                g["D2b"].replay()
+            else:
+                g["D2"].replay()
+            if "D2c" in g:                           # several ranks: gradients | all-reduce | RMSprop
+                self._collective("disc", self.red_disc)
+                g["D2c"].replay()
+            ev["d2"].record(side)
         # what the caller enqueues next -- reads of the losses, the next iteration's inputs -- comes after both optimiser steps ...
         if self._defers_results():
             # `defer_results`: the calling stream is ordered behind the consumption of this iteration's INPUTS only (train_iteration);
@@ -1263,21 +1145,27 @@ class GraphedGanTrainer(GanTrainer):
         else:
             cur.wait_event(ev["d2"])
 
+    @property
+    def _third(self):
+        """Third stream of the linear graphs (the generator's pass through the frozen discriminator); the generic form forks the feature
+        chain onto it (graph.Graph._feature_loss_early)."""
+        return self.graph.feat_stream
+
     def _pipelined(self):
-        return bool(self.pipeline_disc_tail) and self._linear and self._g4 is not None and "D2a" in self._g4
+        return bool(self.pipeline_disc_tail) and self._linear and self._graphs is not None and "D2a" in self._graphs
 
     def _defers_results(self):
-        return bool(self.defer_results) and self._linear and self._g4 is not None
+        return bool(self.defer_results) and self._linear and self._graphs is not None
 
     def wait_all(self):
         """Make the calling stream wait for everything the last `train_iteration` enqueued (with `pipeline_disc_tail`: the
         discriminator step's second half and its RMSprop step)."""
         cur = torch.cuda.current_stream(self._bad.device)
         if getattr(self, "_g2_pending", False):
-            cur.wait_event(self._ev4["g2"])
+            cur.wait_event(self._events["g2"])
             self._g2_pending = False
         if getattr(self, "_d2_pending", False):
-            cur.wait_event(self._ev4["d2"])
+            cur.wait_event(self._events["d2"])
             self._d2_pending = False
 
     def _prefetch_spectral_weights(self, var):
@@ -1286,14 +1174,14 @@ class GraphedGanTrainer(GanTrainer):
         stream, next to the render's MLP kernel, instead of 5 launches in front of each pass (K7; gan_modules.Discriminator.
         prefetch_spectral_weights).  Only when every consumer of the iteration takes prefetched weights: the frozen
         discriminator of the nerf step always does, the discriminator step when it runs as the explicit schedule (K16)."""
-        if not self.has_disc or self._side is None or os.environ.get("TP_NO_SN_PREFETCH") == "1":
+        if not self.has_disc or self._side is None or knobs.K.no_sn_prefetch:
             return
         opt, disc = self.opt, self.graph.discriminator
         if not (hasattr(disc, "prefetch_spectral_weights") and disc.training and opt.gan is not None):
             return
         p, B = int(opt.patch_size), len(var.idx)
         probe = torch.empty(0, device=var.idx.device).new_empty((B, 0, p, p))          # (shape / device carrier: no data)
-        n = 1 + (2 if self._disc_schedule(probe) is not None and os.environ.get("TP_SKIP_DISC_STEP") != "1" else 0)
+        n = 1 + (2 if self._disc_schedule(probe) is not None else 0)
         main = torch.cuda.current_stream(probe.device)
         self._side.wait_stream(main)                 # (after the previous iteration's RMSprop step, whichever stream ran it)
         with torch.cuda.stream(self._side):
@@ -1361,7 +1249,7 @@ class GraphedGanTrainer(GanTrainer):
             if optim is not None:
                 self._adopt_group_lr(name, optim)             # (a load_state_dict before the capture replaced the tensors)
         self.graph.patch_sampler.device_lo = torch.zeros((), device=dev)
-        if os.environ.get("TP_TORCH_RNG") != "1":
+        if not knobs.K.torch_rng:
             # the step's random draws (patch scale / shifts, stratified jitter) come from Philox streams keyed by the seed and a
             # step counter on the device, read inside tp_patch_coords / tp_raygen and advanced by the loss-total launch: no
             # torch.rand launches in the step and no generator-state fills before every replay
@@ -1371,12 +1259,12 @@ class GraphedGanTrainer(GanTrainer):
         self._select_form(var)
         # the step's streams are made here, one after the other (main / capture, discriminator, feature chain): consecutive hardware queues
         if self._linear and (getattr(self, "_capture_stream", None) is None or self._side is None
-                             or getattr(self.graph, "feat_stream", None) is None) and os.environ.get("TP_NO_QUEUE_PROBE") != "1":
+                             or getattr(self.graph, "feat_stream", None) is None) and not knobs.K.no_queue_probe:
             self._capture_stream, self._side, self.graph.feat_stream = streams_after_collectives(dev, 3, self.red_nerf.group)
             self.queue_probe = dict(LAST_QUEUE_PROBE)                    # (bench lines report it: `train.queues`)
         if getattr(self, "_capture_stream", None) is None:
             self._capture_stream = torch.cuda.Stream(device=dev)
-        if self._four and self._side is None:
+        if self._linear and self._side is None:
             self._side = torch.cuda.Stream(device=dev)
         if self._linear and getattr(self.graph, "feat_stream", None) is None:
             self.graph.feat_stream = torch.cuda.Stream(device=dev)
@@ -1396,7 +1284,7 @@ class GraphedGanTrainer(GanTrainer):
                 except _FormUnavailable:
                     # (every rank runs the same configuration and takes this branch in the same iteration, before any collective of it)
                     self._restore(snap)
-                    self._four = self._linear = self._dp = False
+                    self._linear = self._dp = False
                     self._point_gates()
                     done = 0
                     continue
@@ -1413,8 +1301,6 @@ class GraphedGanTrainer(GanTrainer):
         self._graph_b = None
         if self._linear:
             self._capture_linear(side)
-        elif self._four:
-            self._capture_four(side)
         elif self._split_around_collectives():
             self.launch_counts = {}
             with torch.cuda.graph(self._graph, stream=side):
@@ -1514,12 +1400,10 @@ class GraphedGanTrainer(GanTrainer):
         return self.capture(var, warmup=warmup)
 
     def replay(self):
-        """Issue the captured step once on the current stream(s): one graph, four graphs on two streams (`_replay_four`), or -- several
-        ranks -- graph A, the gradient all-reduces, graph B."""
+        """Issue the captured step once: the linear graphs on their three streams (`_replay_linear`), or the generic form on the current
+        stream -- one graph, or (several ranks) graph A, the gradient all-reduces, graph B."""
         if self._linear:
             return self._replay_linear()
-        if self._four:
-            return self._replay_four()
         self._graph.replay()
         if self._graph_b is not None:                            # collectives between the two replays, stream-ordered
             ev = getattr(self, "collective_events", None)        # (a list: HIP-event pairs around the step's reductions, bench.py)

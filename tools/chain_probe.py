@@ -38,8 +38,8 @@ streams = {"D1": tr._side, "G1": tr._capture_stream, "F": tr.graph.feat_stream, 
            "D2": tr._side, "D2a": tr._side, "D2b": tr._side, "D1b": tr._side}
 print("graph   us per replay, alone on the GPU (%d back-to-back replays between two HIP events)" % reps)
 total = 0.0
-for name in [n for n in ("G1", "F", "G2a", "G2b", "D1", "D1b", "D2", "D2a", "D2b") if n in tr._g4]:
-    g, st = tr._g4[name], streams[name]
+for name in [n for n in ("G1", "F", "G2a", "G2b", "D1", "D1b", "D2", "D2a", "D2b") if n in tr._graphs]:
+    g, st = tr._graphs[name], streams[name]
     with torch.cuda.stream(st):
         for _ in range(3):
             g.replay()

@@ -26,9 +26,9 @@ torch.cuda.synchronize()
 t2 = time.perf_counter()
 print("50 iterations: host issue %.1f us/iter, with final sync %.1f us/iter" % ((t1 - t0) / 50 * 1e6, (t2 - t0) / 50 * 1e6))
 # (single segments replayed out of order: garbage state afterwards, this goes last)
-if tr._four:
+if tr._linear:
     print("mode:", "six linear graphs on three streams" if tr._linear else "four graphs on two streams")
-    for name, g in tr._g4.items():
+    for name, g in tr._graphs.items():
         s = tr._side if name[0] == "D" else tr.graph.feat_stream if name == "F" else torch.cuda.current_stream()
         ts = []
         for _ in range(20):

@@ -12,6 +12,8 @@ from texpose_amd.trainer import GraphedGanTrainer
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 order = os.environ.get("TP_TIMELINE_ORDER", "product")
 os.environ["TP_STAMPS"] = "1"
+from texpose_amd import knobs
+knobs.reload()
 torch.manual_seed(0)
 opt = default_options(H=128, W=128, device="cuda:0")
 opt.batch_size, opt.patch_size, opt.nerf.sample_intvs = 4, 16, 64

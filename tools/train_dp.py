@@ -114,7 +114,6 @@ def measure(device, rank, world, global_batch=32, iters=50, warm=5, graphed=True
                 per_gpu_batch=global_batch // world, rays_per_iter=global_batch * 256, samples_per_iter=global_batch * 256 * 64,
                 launch=("linear hipGraph replays on three streams with one flat all-reduce between each gradient graph and its optimiser graph (render | D(fake) + its backward | generator backward, pack | all-reduce | Adam || feature chain || spectral norm | discriminator step, pack | all-reduce | RMSprop)" if getattr(trainer, "_dp", False)
                         else "six linear hipGraph replays on three streams (render | D(fake) + its backward | generator backward + Adam || feature chain || spectral norm | discriminator step)" if getattr(trainer, "_linear", False)
-                        else "four hipGraph replays on two streams (render | generator step || spectral norm | discriminator step)" if getattr(trainer, "_four", False)
                         else "hipGraph replay" if getattr(trainer, "_graph_b", None) is None
                         else "two hipGraph replays with the gradient all-reduces between them") if graphed else "eager", recording_forward=graph.nerf.train_precision,
                 collective="one flat all-reduce per optimiser step (%.1f MB nerf, %.1f MB discriminator)"
@@ -132,8 +131,6 @@ def _form(trainer, graphed):
         return "linear_dp"
     if getattr(trainer, "_linear", False):
         return "linear"
-    if getattr(trainer, "_four", False):
-        return "four_graphs"
     return "one_graph" if getattr(trainer, "_graph_b", None) is None else "two_graphs_eager_collectives"
 
 
