@@ -191,6 +191,11 @@ typedef struct tp_mlp_bwd_args {
   int dz_max_is_clear;     /* TP_MLP_F16X3: the scale word inside `workspace` is known to be zero -- true after any completed call
                               with the same workspace and B*R*N (the call's last kernel clears it) -- so the call does not
                               memset it.  0 = clear it first (always safe). */
+  int wgrad_cus;           /* TP_MLP_F16X3: compute units the weight-gradient launch fills (one workgroup each; its split-K slice
+                              counts follow).  0 = all.  A caller that runs other streams beside this call (the captured GAN
+                              iteration: the discriminator step) passes 7/8 of the device so that their launches are not starved
+                              for the length of the weight gradient; values are identical for every choice up to the order of
+                              the fixed-order split-K sums. */
 } tp_mlp_bwd_args;
 int tp_mlp_bwd(const tp_mlp_bwd_args* args, tp_stream_t stream);
 
@@ -636,8 +641,10 @@ int tp_weighted_sum(const float* const* terms, const float* weights, int n, floa
 int tp_weighted_sum_flags(const float* const* terms, const float* weights, int n, float* out, const int32_t* mlp_status, int32_t* bad,
                           int n_bad, int word_status, int word_finite, int32_t* snapshot, uint64_t* step_counter /* optional: += 1 */,
                           tp_stream_t stream);
+/* idx_copy (optional, [B]): the launch also copies idx there -- the backward of a captured step reads that private copy, so that the
+ * caller's idx buffer may be refilled for the next iteration while this one's backward is still to run */
 int tp_latent_rows_fwd(const float* w_trans, const float* w_light, const int64_t* idx, int B, int C_trans, int C_light, float* out_trans,
-                       float* out_light, tp_stream_t stream);
+                       float* out_light, int64_t* idx_copy, tp_stream_t stream);
 int tp_latent_rows_bwd(const float* g_trans, const float* g_light, const int64_t* idx, int B, int n_rows, int C_trans, int C_light,
                        float* gw_trans, float* gw_light, tp_stream_t stream);
 

@@ -71,7 +71,7 @@ class MlpBwdArgs(C.Structure):
                 ("lat_trans", vp), ("lat_light", vp), ("B", C.c_int), ("R", C.c_int), ("N", C.c_int),
                 ("g_rgb_w", vp * 4), ("g_rgb_b", vp * 4), ("g_trans_w", vp * 4), ("g_trans_b", vp * 4),
                 ("g_lat_trans", vp), ("g_lat_light", vp), ("workspace", vp), ("wgrad_precision", C.c_int),
-                ("dz_max_is_clear", C.c_int)]
+                ("dz_max_is_clear", C.c_int), ("wgrad_cus", C.c_int)]
 
 
 class CompositeArgs(C.Structure):
@@ -297,7 +297,7 @@ def load() -> C.CDLL:
     sig("tp_gan_disc_losses", [vp, vp, C.c_int, C.c_float, C.c_float, vp, vp, vp, vp])
     sig("tp_weighted_sum", [C.POINTER(vp), C.POINTER(C.c_float), C.c_int, vp, vp])
     sig("tp_weighted_sum_flags", [C.POINTER(vp), C.POINTER(C.c_float), C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp])
-    sig("tp_latent_rows_fwd", [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp])
+    sig("tp_latent_rows_fwd", [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp])
     sig("tp_latent_rows_bwd", [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp])
     for name in ("tp_disc_head_fwd", "tp_disc_head_bwd", "tp_disc_head_bwd_bwd"):
         sig(name, [C.POINTER(DiscHeadArgs), vp])

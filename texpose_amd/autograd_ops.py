@@ -589,9 +589,12 @@ class _LatentRows(torch.autograd.Function):
         # the kernels read int64 rows: save what the forward actually passed down (an int32 or strided idx is accepted, like
         # index_select's, and converted ONCE here -- the backward must see the same buffer)
         idx = idx.to(torch.int64).contiguous()
-        ctx.save_for_backward(idx)
+        # ... a PRIVATE copy, written by the forward's own launch: the captured training step refills the caller's idx buffer for the
+        # next iteration while this one's backward is still to run (trainer.GraphedGanTrainer, `defer_results`)
+        own = torch.empty_like(idx)
+        ctx.save_for_backward(own)
         ctx.n_rows = w_trans.shape[0]
-        return ops.latent_rows_fwd(w_trans, w_light, idx)
+        return ops.latent_rows_fwd(w_trans, w_light, idx, idx_copy=own)
 
     @staticmethod
     @torch.autograd.function.once_differentiable

@@ -752,6 +752,7 @@ extern "C" int tp_mlp_bwd(const tp_mlp_bwd_args* a, tp_stream_t stream_) {
                    a->g_trans_b[i], "null weight / gradient pointer");
   TP_REQUIRE(a->g_lat_trans && a->g_lat_light, "null latent gradient pointer");
   TP_REQUIRE(a->wgrad_precision == TP_MLP_FP32 || a->wgrad_precision == TP_MLP_F16X3, "unknown wgrad_precision");
+  TP_REQUIRE(a->wgrad_cus >= 0, "negative wgrad_cus");
   hipStream_t stream = (hipStream_t)stream_;
   const int64_t S = (int64_t)a->B * a->R * a->N;
   const int64_t n_tiles = (S + 127) / 128, ng = n_tiles * 4;
@@ -796,13 +797,15 @@ extern "C" int tp_mlp_bwd(const tp_mlp_bwd_args* a, tp_stream_t stream_) {
   }
 
   int n_w, n_n;                                  // split-K slices of the wide / narrow GEMMs (partial layout, finalize)
+  int cus_w = cus;                               // CUs the weight-gradient launch fills (one workgroup each)
   if (f16) {
     // one workgroup per CU: 6 wide GEMMs x n_w slices + 2 narrow x n_n; 38 + 14 slices level the two kinds on 256 CUs
     // (measured: 39 + 11 makes the narrow stream the tail, 36 + 20 the wide GEMMs)
-    n_w = cus * 19 / 128;
+    if (a->wgrad_cus > 0 && a->wgrad_cus < cus) cus_w = a->wgrad_cus < 16 ? 16 : a->wgrad_cus;
+    n_w = cus_w * 19 / 128;
     if (n_w > 64) n_w = 64;
     if (n_w < 1) n_w = 1;
-    n_n = (cus - 6 * n_w) / 2;
+    n_n = (cus_w - 6 * n_w) / 2;
     if (n_n > 64) n_n = 64;
     if (n_n < 1) n_n = 1;
     if (ng < n_w) n_w = (int)ng;

@@ -453,11 +453,13 @@ __global__ void weighted_sum_flags_kernel(TermTable tb, float* __restrict__ out,
 // and their gradient: dense [n_rows, C] tables with g[r] = sum over the images b with idx[b] == r, in ascending b (no
 // atomics, no zero-fill launch; torch: index_select x 2 forward, zeros + index_add_ x 2 backward)
 __global__ __launch_bounds__(kBlock) void latent_rows_fwd_kernel(const float* __restrict__ wt, const float* __restrict__ wl, const int64_t* __restrict__ idx,
-                                                                  int B, int Ct, int Cl, float* __restrict__ ot, float* __restrict__ ol) {
+                                                                  int B, int Ct, int Cl, float* __restrict__ ot, float* __restrict__ ol,
+                                                                  int64_t* __restrict__ idx_copy) {
   const int e = blockIdx.x * kBlock + threadIdx.x, C = Ct + Cl;
   if (e >= B * C) return;
   const int b = e / C, c = e - b * C;
   const int64_t r = idx[b];
+  if (c == 0 && idx_copy != nullptr) idx_copy[b] = r;
   if (c < Ct) ot[b * Ct + c] = wt[r * Ct + c];
   else ol[b * Cl + (c - Ct)] = wl[r * Cl + (c - Ct)];
 }
@@ -708,11 +710,11 @@ int tp_sumsq_mean_bwd(const float* g, int64_t n, int B, const float* cot, float*
   return tp::check_launch("tp_sumsq_mean_bwd");
 }
 int tp_latent_rows_fwd(const float* w_trans, const float* w_light, const int64_t* idx, int B, int C_trans, int C_light, float* out_trans,
-                       float* out_light, tp_stream_t stream) {
+                       float* out_light, int64_t* idx_copy, tp_stream_t stream) {
   TP_REQUIRE(w_trans && w_light && idx && out_trans && out_light && B > 0 && C_trans > 0 && C_light > 0, "bad arguments");
   const int n = B * (C_trans + C_light);
   hipLaunchKernelGGL(latent_rows_fwd_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, (hipStream_t)stream, w_trans, w_light, idx, B,
-                     C_trans, C_light, out_trans, out_light);
+                     C_trans, C_light, out_trans, out_light, idx_copy);
   return tp::check_launch("tp_latent_rows_fwd");
 }
 int tp_latent_rows_bwd(const float* g_trans, const float* g_light, const int64_t* idx, int B, int n_rows, int C_trans, int C_light,

@@ -30,6 +30,7 @@ _SPEC: Tuple[Tuple[str, str, object, str], ...] = (
     ("no_branch_overlap", "TP_NO_BRANCH_OVERLAP", False, "generic form: the discriminator step on the capturing stream instead of a second one"),
     ("no_feat_branch", "TP_NO_FEAT_BRANCH", False, "generic form: the feature chain on the capturing stream instead of a third one (also switches the linear graphs off)"),
     ("no_sn_prefetch", "TP_NO_SN_PREFETCH", False, "spectral normalisations in front of each discriminator pass instead of three sets up front (also switches the linear graphs off)"),
+    ("no_sn_split", "TP_NO_SN_SPLIT", False, "linear graphs: the three spectral normalisations as one graph instead of [first set] | [the other two]"),
     ("no_disc_split", "TP_NO_DISC_SPLIT", False, "linear graphs: the discriminator step as one graph instead of two (no `pipeline_disc_tail`)"),
     ("no_queue_probe", "TP_NO_QUEUE_PROBE", False, "the step's three streams in creation order instead of by the measured stream -> hardware-queue probe"),
     ("pipeline_disc", "TP_PIPELINE_DISC", False, "default of GraphedGanTrainer.pipeline_disc_tail"),
@@ -53,6 +54,7 @@ _SPEC: Tuple[Tuple[str, str, object, str], ...] = (
     ("no_feat_chain", "TP_NO_FEAT_CHAIN", False, "feature loss through per-layer launches + autograd instead of the one-call K18 chain"),
     # ---- MLP kernels
     ("no_ray_bias", "TP_NO_RAY_BIAS", False, "evaluation renders with N % 128 == 0 take the plain f16x3 kernel instead of the ray-bias form"),
+    ("wgrad_all_cus", "TP_WGRAD_ALL_CUS", False, "linear graphs: the render's weight gradient fills every CU instead of 7/8 (the discriminator step then sits it out)"),
     ("no_pack_merge", "TP_NO_PACK_MERGE", False, "f16x3 training: head stream and transposed head image packed by two launches instead of one"),
     # ---- diagnostics
     ("stamps", "TP_STAMPS", False, "one-thread launches writing the device clock at the boundaries of the captured graphs (tools/linear_timeline.py)"),

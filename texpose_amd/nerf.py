@@ -59,6 +59,9 @@ class NeRF(torch.nn.Module):
         # training step (the backward kernels are fp32 MFMA either way and consume the same activation record)
         self.precision = opt.arch.get("mlp_precision", "f16x3")
         self.train_precision = opt.arch.get("mlp_train_precision", "f16x3")
+        # compute units the weight-gradient launch of the backward fills (tp_mlp_bwd_args.wgrad_cus; 0 = all): a training step that runs
+        # other streams beside the backward sets it (trainer.GraphedGanTrainer, linear graphs)
+        self.wgrad_cus = 0
         if self.precision not in ops.PRECISIONS or self.train_precision not in ops.PRECISIONS:
             raise ValueError("arch.mlp_precision / mlp_train_precision must be one of %s" % list(ops.PRECISIONS))
         self._packed = {}

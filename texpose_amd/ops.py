@@ -466,6 +466,9 @@ def mlp_backward(nerf, lat_trans: Tensor, lat_light: Tensor, saved: Tensor, rgb:
     a.B, a.R, a.N = B, R, N
     a.g_lat_trans, a.g_lat_light, a.workspace = g_lt.data_ptr(), g_ll.data_ptr(), sc["ws"].data_ptr()
     a.wgrad_precision = PRECISIONS[wgrad_precision]
+    # (a caller that runs other streams beside the backward -- the captured GAN iteration -- leaves them a share of the device for the
+    # length of the weight gradient: NeRF.wgrad_cus, 0 = all)
+    a.wgrad_cus = int(getattr(nerf, "wgrad_cus", 0) or 0)
     check(lib.tp_mlp_bwd(C.byref(a), _stream()), "tp_mlp_bwd")
     if not capturing:
         sc["clear_for"] = clear_key
@@ -1465,14 +1468,17 @@ def weighted_sum(terms, weights, flags=None, defer: bool = False) -> Tensor:
 
 
 @_on_tensor_device
-def latent_rows_fwd(w_trans: Tensor, w_light: Tensor, idx: Tensor):
+def latent_rows_fwd(w_trans: Tensor, w_light: Tensor, idx: Tensor, idx_copy: Optional[Tensor] = None):
+    """``idx_copy`` (int64 [B], optional): the launch also writes idx there (a private copy for the backward)."""
     lib = _lib.load()
     w_trans, w_light = _f32(w_trans, "w_trans"), _f32(w_light, "w_light")
     idx = idx.to(torch.int64).contiguous()
     B = idx.numel()
     ot, ol = torch.empty(B, w_trans.shape[1], device=idx.device), torch.empty(B, w_light.shape[1], device=idx.device)
+    if idx_copy is not None and not (idx_copy.dtype == torch.int64 and idx_copy.is_contiguous() and idx_copy.numel() == B and idx_copy.device == idx.device):
+        raise _lib.TexposeLibraryError("latent_rows_fwd: idx_copy must be a contiguous int64 device tensor of idx's length")
     check(lib.tp_latent_rows_fwd(w_trans.data_ptr(), w_light.data_ptr(), idx.data_ptr(), B, w_trans.shape[1], w_light.shape[1], ot.data_ptr(),
-                                 ol.data_ptr(), _stream()), "tp_latent_rows_fwd")
+                                 ol.data_ptr(), _ptr(idx_copy), _stream()), "tp_latent_rows_fwd")
     return ot, ol
 
 

@@ -720,6 +720,11 @@ class GraphedGanTrainer(GanTrainer):
         disc = self.graph.discriminator
         return self._disc_schedule(probe) is not None and hasattr(disc, "prefetch_spectral_weights") and disc.training
 
+    def _set_wgrad_share(self):
+        nerf, dev = self.graph.nerf, self._bad.device
+        cus = torch.cuda.get_device_properties(dev).multi_processor_count if dev.type == "cuda" else 0
+        nerf.wgrad_cus = int(cus * self.WGRAD_CU_SHARE) if (self._linear and cus and not knobs.K.wgrad_all_cus) else 0
+
     def _select_form(self, var):
         """Which captured form this configuration gets: the linear graphs (several ranks: the same with every optimiser launch as a
         graph of its own behind its all-reduce, `_dp`), or ONE graph (`_body`; with several ranks: gradients | eager all-reduces |
@@ -731,6 +736,7 @@ class GraphedGanTrainer(GanTrainer):
         if collective and not self._dp:
             self._linear = False
         self._point_gates()
+        self._set_wgrad_share()
 
     def _point_gates(self):
         """`_dp`: the optimiser launches read the (job-wide, sticky) tail of their all-reduce buffer; else the snapshots of `_bad`."""
@@ -842,8 +848,8 @@ class GraphedGanTrainer(GanTrainer):
     #            backward down to the render's rgb (K18);  [wait ev g2a] G2b = loss total + gate, composite / MLP backward from (terms,
     #            d gan / d rgb, d feat / d rgb), Adam  -> ev g2
     #     third: [wait ev patches, ev sn] G2a = D(fake) for the generator, its loss term and gradient wrt the rendered colours -> ev g2a
-    #     disc:  D1 = the three spectral normalisations (after its own RMSprop step, stream order) -> ev sn;  [wait ev patches] D2a =
-    #            forward pairs, BCE -> ev d2a;  D2b = R1, backward pairs, spectral-norm backward + RMSprop -> ev d2
+    #     disc:  D1 = the first spectral normalisation (after its own RMSprop step, stream order) -> ev sn;  D1b = the other two;
+    #            [wait ev patches] D2a = forward pairs, BCE -> ev d2a;  D2b = R1, backward pairs, spectral-norm backward + RMSprop -> ev d2
     # Several ranks (`_dp`): G2b and D2b end with the gradients packed into their flat buffer, the all-reduce is a stream-ordered call
     # behind the replay, and the optimiser launch is a graph of its own (G2c, D2c) behind it.
     # Same kernels and the same cotangent values as the one-graph form: the composite's backward sums the cotangents of its rgb
@@ -994,6 +1000,11 @@ class GraphedGanTrainer(GanTrainer):
             self._stamp_names.append(name)
         ops.stamp(self._stamps, self._stamp_names.index(name))
 
+    # share of the device the weight gradient of the render's backward fills in the linear graphs: the discriminator step's second half
+    # runs beside it, and with every CU taken (one 158-KB workgroup each) its launches sat out the whole kernel -- 7/8 measured best
+    # (256 / 248 / 240 / 232 / 224 / 208 CUs: 956 / 958 / 950 / 956 / 977 / 969 it/s on one box, profiles/r6)
+    WGRAD_CU_SHARE = 7 / 8
+
     def _capture_linear(self, cap):
         side = self._side
         has_feat = self.opt.loss_weight.feat is not None
@@ -1009,10 +1020,20 @@ class GraphedGanTrainer(GanTrainer):
         # Tensors that cross the streams (the spectral-norm sets, the render's patch stacks / scales) are kept referenced for the life of
         # the graphs, so that no capture re-uses their memory.
         counts = self.launch_counts = {}                 # nodes per captured graph (kernel launches; TP_STAMPS adds two to each)
-        # (D1 as two graphs -- the first normalised set, which is all G2a waits for, and the other two behind it -- measured 914-920 it/s
-        # against 925-926 as one graph: the launch count decides, profiles/r5.)
-        with torch.cuda.graph(g["D1"], stream=side):
-            self._stamp("D1.0"); self._seg_sn(); self._stamp("D1.1"); self._extra("D1"); counts["D1"] = ops.capture_node_count()
+        # The generator's pass through the frozen discriminator (G2a) needs the FIRST normalised weight set only, and D1 does not start
+        # before the render's MLP kernel ends (it sits that kernel out: every CU is taken), so G2a is what the render's backward waits
+        # for: that set as a graph of its own (3 launches), the other two behind it (D1b: 2 x 2 + 1), 8 launches instead of 7.
+        # Measured +0.8 % (939-940 -> 945-948 it/s on one box, profiles/r6) now that the iteration boundary is short; in round 5, with
+        # a 70-us boundary in which D1 ran unhindered, the extra launch cost more than the split gave (914-920 against 925-926).
+        if not knobs.K.no_sn_split:
+            g["D1b"] = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g["D1"], stream=side):
+                self._stamp("D1.0"); self._seg_sn(0); self._stamp("D1.1"); self._extra("D1"); counts["D1"] = ops.capture_node_count()
+            with torch.cuda.graph(g["D1b"], stream=side, pool=g["D1"].pool()):
+                self._seg_sn(1); self._extra("D1b"); counts["D1b"] = ops.capture_node_count()
+        else:
+            with torch.cuda.graph(g["D1"], stream=side):
+                self._stamp("D1.0"); self._seg_sn(); self._stamp("D1.1"); self._extra("D1"); counts["D1"] = ops.capture_node_count()
         keep = [list(self.graph.discriminator._sn_queue)]
         with torch.cuda.graph(g["G1"], stream=cap):
             self._stamp("G1.0"); var = self._seg_render(AttrDict(dict(self._static_in))); self._stamp("G1.1"); self._extra("G1"); counts["G1"] = ops.capture_node_count()
@@ -1069,8 +1090,9 @@ class GraphedGanTrainer(GanTrainer):
         cur = torch.cuda.current_stream(self._bad.device)
         # the caller's stream hands over the step's inputs (and, the first time, parameters restored / loaded since the capture); it
         # waited for the previous iteration's last launches below, so does everything here
-        if self.__dict__.pop("_inputs_on_main", False):
-            pass                                      # (`defer_results`: train_iteration already ordered `main` behind the caller's mark)
+        inputs = self.__dict__.pop("_inputs_event", None)
+        if inputs is not None:
+            main.wait_event(inputs)                   # (`defer_results`: the inputs went in on the third stream, behind the caller's mark)
         else:
             main.wait_stream(cur)
         if getattr(self, "_g2_pending", False) and not self._pipelined():
@@ -1093,6 +1115,8 @@ class GraphedGanTrainer(GanTrainer):
                 side.wait_event(ev["g2"])            # set 1 is read by the generator's passes through the frozen discriminator
             g["D1"].replay()
             ev["sn"].record(side)
+            if "D1b" in g:
+                g["D1b"].replay()
         self._first_replay = False
         # (The order in which the host submits F / G2a + G2b / D2 makes no difference -- six orders measured within 0.5 % on one box -- and
         # the host is 4x ahead of the device: 260 us of launches per 1.17 ms iteration.)
@@ -1286,6 +1310,7 @@ class GraphedGanTrainer(GanTrainer):
                     self._restore(snap)
                     self._linear = self._dp = False
                     self._point_gates()
+                    self._set_wgrad_share()
                     done = 0
                     continue
                 self._after_step()
@@ -1446,16 +1471,21 @@ class GraphedGanTrainer(GanTrainer):
             scalars.append((self.graph.discriminator.progress.data, self.it / self.max_iter))
         poll = self._bad_poll_slot()
         if self._defers_results():
-            # `defer_results`: the step's inputs go in on the generator stream itself, behind the caller's mark (its batch is ready) and,
-            # by stream order, behind the previous iteration's last reader of the static inputs -- no stream hop in front of the render
-            main = self._capture_stream
-            main.wait_event(self._caller_mark)
-            with torch.cuda.stream(main):
+            # `defer_results`: the step's inputs go in on the THIRD stream, behind the caller's mark (its batch is ready) and behind the
+            # previous iteration's render -- the last reader of the static inputs (the latent rows' backward reads a private copy of
+            # `idx`, autograd_ops._LatentRows) -- i.e. while that iteration's backward still runs.  The generator stream then goes from
+            # its Adam graph straight into the next render graph: an eager launch between two graphs of one stream cost 39 + 13 us of
+            # idle stream there (graph end -> kernel -> graph start; profiles/r6), an event wait costs nothing.
+            third = self._third
+            third.wait_event(self._caller_mark)
+            if not self._first_replay:
+                third.wait_event(self._events["patches"])
+            with torch.cuda.stream(third):
                 ops.step_inputs(fused, scalars, words=self._poll_words() if poll is not None else None, words_host=poll)
                 ev = torch.cuda.Event()
                 ev.record()
             torch.cuda.current_stream(self._bad.device).wait_event(ev)      # (the caller may overwrite its batch tensors behind this)
-            self._inputs_on_main = True
+            self._inputs_event = ev
         else:
             ops.step_inputs(fused, scalars, words=self._poll_words() if poll is not None else None, words_host=poll)
             if poll is not None:
