@@ -151,6 +151,9 @@ typedef struct tp_mlp_fwd_args {
                               light code 48 of its 334 columns; reference layers/nerf_static_transient_light.py:104-118) and the
                               transient code of mlp_trans.0 (:127-129) are then contracted once per ray / image in fp32 by a
                               pre-kernel and enter the layer as a per-ray bias instead of 96 input columns of every sample. */
+  const float* density_noise; /* optional (NULL = off), [B*R*N]: added to the STATIC density's pre-activation before its softplus
+                              (reference nerf.density_noise_reg, layers/nerf_static_transient_light.py:96-97, train mode: the caller
+                              passes randn * density_noise_reg).  Not with `ray_bias`. */
 } tp_mlp_fwd_args;
 size_t tp_mlp_ray_bias_bytes(int B, int R);
 /* TP_MLP_F16X3: every fp32 operand is split into hi + lo fp16 (22-bit significand) and hi*hi + hi*lo + lo*hi is

@@ -291,12 +291,24 @@ def philox_uniform(n_elems: int, seed: int, offset: int = 0) -> np.ndarray:
 # a10  positional encoding                   layers/nerf_static_transient_light.py:217-234
 # ----------------------------------------------------------------------------
 
-def posenc(x: Tensor, L: int) -> Tensor:
+def c2f_weight(L: int, progress: float, c2f_range, start=None) -> Tensor:
+    """Coarse-to-fine weight of frequency band l < L (layers/nerf_static_transient_light.py:225-231): with
+    alpha = (progress - range[0]) / (range[1] - range[0]) * L and k = l - (start or 0): (1 - cos(pi clamp(alpha - k, 0, 1))) / 2."""
+    lo, hi = float(c2f_range[0]), float(c2f_range[1])
+    alpha = (torch.tensor(float(progress), dtype=torch.float32) - lo) / (hi - lo) * L
+    k = torch.arange(L, dtype=torch.float32) - (0 if start is None else start)
+    return (1 - (alpha - k).clamp(min=0, max=1).mul(np.pi).cos()) / 2
+
+
+def posenc(x: Tensor, L: int, weight: Optional[Tensor] = None) -> Tensor:
     """[...,C] -> [...,2*C*L], index = c*2L + s*L + l  (s: 0 sin, 1 cos).
-    c2f weighting is inactive because c2f.range is None (options yaml:4-6)."""
+    ``weight`` [L]: the c2f weights (`c2f_weight`), applied per band l to the sin and the cos entry (:232-233); None when
+    c2f.range is None, as in the shipped yaml (options/nerf_lm_adapt_gan.yaml:4-6)."""
     freq = (2 ** torch.arange(L, dtype=torch.float32)) * np.pi
     spec = x[..., None] * freq
     enc = torch.stack([spec.sin(), spec.cos()], dim=-2)
+    if weight is not None:
+        enc = enc * weight
     return enc.reshape(*x.shape[:-1], -1)
 
 
@@ -342,7 +354,8 @@ def make_params(seed: int, width: int = 256, n_lat_trans: int = 16, n_lat_light:
 
 def mlp_forward(p: Dict[str, Tensor], points: Tensor, ray_unit: Tensor,
                 lat_trans: Tensor, lat_light: Tensor, L_3D: int = 10, L_view: int = 4,
-                skip: Sequence[int] = (4,), taps: Optional[Dict[str, Tensor]] = None) -> Tuple[Tensor, Tensor, Tensor]:
+                skip: Sequence[int] = (4,), taps: Optional[Dict[str, Tensor]] = None, c2f=None,
+                density_noise: Optional[Tensor] = None) -> Tuple[Tensor, Tensor, Tensor]:
     """points, ray_unit [B,R,N,3]; lat_trans [B,Lt]; lat_light [B,Ll]
     -> rgb [B,R,N,3,2], density [B,R,N,2], uncert [B,R,N,1].
     ``taps`` (tests only): filled with the detached PRE-activations of the hidden head layers, ``mlp_rgb.{0,1,2}`` /
@@ -350,12 +363,19 @@ def mlp_forward(p: Dict[str, Tensor], points: Tensor, ray_unit: Tensor,
 
     layers/nerf_static_transient_light.py:76-145.  The trunk runs without
     autograd in the reference (:87-100); here the caller decides by detaching.
+    ``c2f`` = dict(progress, range, start): coarse-to-fine weights on BOTH encodings (:81,104 pass c2f=True).
+    ``density_noise`` [B,R,N]: added to the static density's pre-activation (train mode with nerf.density_noise_reg, :96-97:
+    the caller passes randn * reg).
     """
+    w3 = wv = None
+    if c2f is not None and c2f.get("range") is not None:
+        w3 = c2f_weight(L_3D, c2f["progress"], c2f["range"], c2f.get("start"))
+        wv = c2f_weight(L_view, c2f["progress"], c2f["range"], c2f.get("start"))
     B, R, N, _ = points.shape
     n_feat = len([k for k in p if k.startswith("mlp_feat.") and k.endswith(".weight")])
     n_rgb = len([k for k in p if k.startswith("mlp_rgb.") and k.endswith(".weight")])
     n_tr = len([k for k in p if k.startswith("mlp_trans.") and k.endswith(".weight")])
-    enc = torch.cat([points, posenc(points, L_3D)], dim=-1)
+    enc = torch.cat([points, posenc(points, L_3D, w3)], dim=-1)
     h = enc
     with torch.no_grad():
         for li in range(n_feat):
@@ -363,11 +383,12 @@ def mlp_forward(p: Dict[str, Tensor], points: Tensor, ray_unit: Tensor,
                 h = torch.cat([h, enc], dim=-1)
             h = torch.nn.functional.linear(h, p[f"mlp_feat.{li}.weight"], p[f"mlp_feat.{li}.bias"])
             if li == n_feat - 1:
-                sigma_s = torch.nn.functional.softplus(h[..., 0])
+                raw = h[..., 0] if density_noise is None else h[..., 0] + density_noise
+                sigma_s = torch.nn.functional.softplus(raw)
                 h = h[..., 1:]
             h = torch.relu(h)
     feat = h
-    venc = torch.cat([ray_unit, posenc(ray_unit, L_view)], dim=-1)
+    venc = torch.cat([ray_unit, posenc(ray_unit, L_view, wv)], dim=-1)
     light = lat_light[:, None, None, :].expand(B, R, N, lat_light.shape[-1])
     g = torch.cat([feat, venc, points, light], dim=-1)
     for li in range(n_rgb):

@@ -67,7 +67,7 @@ def test_flex_patch_sampler_on_device_matches_oracle_and_golden():
 
 
 # ------------------------------------------------------------------------------------------ C3 at its literal size
-def _c3(graphed, train_precision="f16x3", seed=0):
+def _c3(graphed, train_precision="f16x3", seed=0, options=None):
     from texpose_amd.gan_modules import Discriminator, PerceptualLoss
     from texpose_amd.graph import Graph
     from texpose_amd.options import default_options
@@ -75,6 +75,8 @@ def _c3(graphed, train_precision="f16x3", seed=0):
     torch.manual_seed(seed)
     opt = default_options(H=128, W=128, device="cuda:0")
     opt.batch_size, opt.patch_size, opt.nerf.sample_intvs = 4, 16, 64
+    if options is not None:
+        options(opt)
     graph = Graph(opt, discriminator=Discriminator(opt), perceptual_loss=PerceptualLoss()).to(dev())
     graph.nerf.load_state_dict({**graph.nerf.state_dict(), **{k: cu(v) for k, v in O.make_params(41).items()}})
     graph.nerf.train_precision = train_precision
@@ -139,6 +141,47 @@ def test_c3_literal_size_train_iteration_eager_and_graphed():
             torch.testing.assert_close(ret[k].detach().cpu(), o, **RAY)
         assert rel_l2(ret.density, den_o) < 1e-4 and rel_l2(ret.alpha_static, ref[9]) < 1e-4
     ops.check_mlp_status(dev())
+
+
+def test_c3_train_iteration_with_the_yaml_options_the_reference_leaves_empty():
+    """The C3 iteration with the option values golden G19 pins stage by stage switched ON together -- c2f.range / start with
+    `progress` inside the window, nerf.density_noise_reg, gan.L_nocs / L_normal / geo_c2f -- eager and hipGraph-replayed: finite losses,
+    the frozen trunk untouched, heads / latents / the 33-channel first discriminator layer updated, a new density-noise draw on every
+    replay (the discriminator step declines its explicit schedule here, so the captured step takes the generic one-graph form)."""
+    from texpose_amd import ops
+    from texpose_amd.options import AttrDict
+    from texpose_amd.synthetic import training_batch
+
+    def options(opt):
+        opt.c2f.range, opt.c2f.start = [0.1, 0.5], 1
+        opt.nerf.density_noise_reg = 0.2
+        opt.gan.L_nocs = opt.gan.L_normal = 2
+        opt.gan.geo_c2f = [0.0, 0.5]
+
+    batch = training_batch(4, 128, 128, n_train=189, seed=3, device="cuda:0")
+    for graphed in (False, True):
+        opt, graph, tr = _c3(graphed, options=options)
+        graph.nerf.set_progress(0.3)
+        assert graph.discriminator.main[0].weight_orig.shape[1] == 33
+        trunk0 = [p.detach().clone() for p in graph.nerf.mlp_feat.parameters()]
+        head0 = graph.nerf.mlp_rgb[0].weight.detach().clone()
+        disc0 = graph.discriminator.main[0].weight_orig.detach().clone()
+        seen = set()
+        for _ in range(3):
+            var, loss = tr.train_iteration(AttrDict(dict(batch)))
+            seen.add(round(float(loss["trans_reg"]), 7))
+        if graphed:
+            tr.finish()
+            assert not tr._linear and tr._graph is not None
+        vals = {k: float(v) for k, v in loss.items() if torch.is_tensor(v)}
+        assert all(np.isfinite(v) for v in vals.values()) and len(vals) >= 8, vals
+        assert len(seen) == 3
+        ops.check_mlp_status(dev())
+        for p, q in zip(graph.nerf.mlp_feat.parameters(), trunk0):
+            assert torch.equal(p, q)
+        assert not torch.equal(graph.nerf.mlp_rgb[0].weight, head0)
+        assert not torch.equal(graph.discriminator.main[0].weight_orig, disc0)
+        assert abs(float(graph.nerf.progress) - 0.3) < 1e-7           # (the adapt stage never moves NeRF.progress: reference :182 moves the discriminator's)
 
 
 # ------------------------------------------------------------------------------------------ C5, 480x640 x 256 samples

@@ -16,6 +16,7 @@ import torch.nn.functional as F
 from conftest import load_golden
 from oracle import texpose_oracle as O
 from texpose_amd import knobs
+from g19_checks import g19_sub as _g19_sub, g19c_disc as _g19c_disc, g19c_check as _g19c_check
 
 pytestmark = pytest.mark.gpu
 
@@ -3469,3 +3470,104 @@ def test_conv4s2_fwd_inorm_fused_launch(ops, N, C, HW, Co):
     (autograd_ops.conv4s2_inorm(xa, w, 1e-5, 0.2) * cot).sum().backward()
     (autograd_ops.inorm_lrelu(autograd_ops.conv4s2(xb, w), 1e-5, 0.2) * cot).sum().backward()
     assert rel_l2(xa.grad, xb.grad) < 2e-5
+
+
+# ------------------------------------------------------------------------------------------ round 6: option values of a10 / a11 / f1
+@pytest.mark.parametrize("precision", ["fp32", "f16x3"])
+def test_c2f_encoding_weights_match_reference_g19a(ops, precision):
+    """`c2f.range` / `c2f.start` (reference layers/nerf_static_transient_light.py:217-234; empty in the shipped yaml): the
+    coarse-to-fine weights of both positional encodings at three values of `NeRF.progress` -- before, inside and behind the window.
+    The kernels encode unweighted; the weights are folded into the encoding columns of the packed mlp_feat.0 / mlp_feat.4 / mlp_rgb.0
+    (NeRF._state_for_pack) and into the view-encoding columns of mlp_rgb.0's gradient.  Outputs at 1e-4 / 1e-6, flip-free head
+    gradients at 1e-4 (output layers 1e-5) against the REFERENCE (golden G19a), both MLP arithmetics; a re-pack follows `progress`."""
+    from texpose_amd.graph import Graph
+    from texpose_amd.options import default_options
+    G = load_golden("g19_options")
+    opt = default_options(H=16, W=16, device="cuda:0")
+    opt.c2f.range, opt.c2f.start = [float(v) for v in G["a.range"]], int(G["a.start"])
+    g = Graph(opt).to(dev())
+    nerf = g.nerf
+    nerf.load_state_dict({**nerf.state_dict(), **{k: cu(v) for k, v in O.make_params(int(G["a.seed_w"])).items()}})
+    nerf.precision = nerf.train_precision = precision
+    pts, unit = cu(G["a.points"]), cu(G["a.ray_unit"])
+    for tag in ("p005", "p027", "p100", "p027"):                       # (back to p027: the packed stream follows `progress`)
+        nerf.set_progress(float(G[f"a.{tag}.progress"]))
+        torch.testing.assert_close(nerf.positional_encoding(opt, cu(G["a.enc_x"]), L=10, c2f=True).cpu(), G[f"a.{tag}.enc10"], rtol=1e-5, atol=2e-6)
+        torch.testing.assert_close(nerf.positional_encoding(opt, cu(G["a.enc_x"]), L=4, c2f=True).cpu(), G[f"a.{tag}.enc4"], rtol=1e-5, atol=2e-6)
+        with torch.no_grad():
+            rgb, den, unc = nerf.forward(opt, pts, ray_unit=unit, latent_variable_trans=cu(G["a.lat_trans"]),
+                                         latent_variable_light=cu(G["a.lat_light"]), mode="val")
+        for o, k in zip((rgb, den, unc), ("rgb", "density", "uncert")):
+            torch.testing.assert_close(o.cpu(), G[f"a.{tag}.{k}"], **RAY)
+    assert rel_l2(rgb, G["a.p005.rgb"]) > 1e-3                          # (the weights matter on these inputs)
+    # gradients inside the window
+    tag = "p027"
+    lt, ll = cu(G["a.lat_trans"]).requires_grad_(), cu(G["a.lat_light"]).requires_grad_()
+    g.zero_grad(set_to_none=True)
+    outs = nerf.forward(opt, pts, ray_unit=unit, latent_variable_trans=lt, latent_variable_light=ll, mode="val")
+    sum((o * cu(G[f"a.{tag}.cot_{k}"])).sum() for o, k in zip(outs, ("rgb", "density", "uncert"))).backward()
+    errs = {}
+    for name in ("mlp_rgb", "mlp_trans"):
+        for li in range(4):
+            for kind in ("weight", "bias"):
+                errs[f"{name}.{li}.{kind}"] = _g19_sub(G, f"a.{tag}.g.{name}.{li}.{kind}", getattr(getattr(nerf, name)[li], kind).grad)
+    errs["viewenc"] = rel_l2(nerf.mlp_rgb[0].weight.grad[:, 256:283], G[f"a.{tag}.g.mlp_rgb.0.weight.viewenc"])
+    errs["lat_t"], errs["lat_l"] = rel_l2(lt.grad, G[f"a.{tag}.g.lat_t"]), rel_l2(ll.grad, G[f"a.{tag}.g.lat_l"])
+    print("G19a %s record, flip-free gradients vs the REFERENCE:" % precision, {k: float("%.2e" % v) for k, v in errs.items()})
+    for k, v in errs.items():
+        assert v < (1e-5 if ".3." in k else 1e-4), (precision, k, v)
+    ops.check_mlp_status(dev())
+
+
+@pytest.mark.parametrize("precision", ["fp32", "f16x3"])
+def test_density_noise_reg_matches_reference_g19b(ops, precision):
+    """`nerf.density_noise_reg` (reference :96-97; empty in the shipped yaml): randn * reg on the static density's pre-activation in
+    train mode only -- tp_mlp_fwd_args.density_noise.  On the reference's own draw (golden G19b): density at 1e-4 / 1e-6, nothing else
+    moves; val mode ignores it; without an injected draw a train-mode forward draws its own."""
+    from texpose_amd.graph import Graph
+    from texpose_amd.options import default_options
+    G = load_golden("g19_options")
+    opt = default_options(H=16, W=16, device="cuda:0")
+    opt.nerf.density_noise_reg = float(G["b.reg"])
+    g = Graph(opt).to(dev())
+    nerf = g.nerf
+    nerf.load_state_dict({**nerf.state_dict(), **{k: cu(v) for k, v in O.make_params(int(G["a.seed_w"])).items()}})
+    nerf.precision = nerf.train_precision = precision
+    args = dict(ray_unit=cu(G["a.ray_unit"]), latent_variable_trans=cu(G["a.lat_trans"]), latent_variable_light=cu(G["a.lat_light"]))
+    with torch.no_grad():
+        nerf.density_noise_override = cu(G["b.noise"])
+        rgb, den, unc = nerf.forward(opt, cu(G["a.points"]), mode="train", **args)
+        assert nerf.density_noise_override is None
+        torch.testing.assert_close(den.cpu(), G["b.density_train"], **RAY)
+        torch.testing.assert_close(rgb.cpu(), G["b.rgb"], **RAY)
+        torch.testing.assert_close(unc.cpu(), G["b.uncert"], **RAY)
+        _, den_v, _ = nerf.forward(opt, cu(G["a.points"]), mode="val", **args)
+        torch.testing.assert_close(den_v.cpu(), G["b.density_val"], **RAY)
+        _, d1, _ = nerf.forward(opt, cu(G["a.points"]), mode="train", **args)            # own draws: new noise every call
+        _, d2, _ = nerf.forward(opt, cu(G["a.points"]), mode="train", **args)
+        assert not torch.equal(d1[..., 0], d2[..., 0]) and torch.equal(d1[..., 1], d2[..., 1])
+    # with gradients (the recording forward takes the same argument); the density is the frozen trunk's: no gradient path through it
+    nerf.density_noise_override = cu(G["b.noise"])
+    lt = cu(G["a.lat_trans"]).requires_grad_()
+    rgb, den, unc = nerf.forward(opt, cu(G["a.points"]), ray_unit=cu(G["a.ray_unit"]), latent_variable_trans=lt,
+                                 latent_variable_light=cu(G["a.lat_light"]), mode="train")
+    torch.testing.assert_close(den.detach().cpu(), G["b.density_train"], **RAY)
+    (rgb.sum() + unc.sum()).backward()
+    assert lt.grad is not None
+    ops.check_mlp_status(dev())
+
+
+def test_discriminator_geometry_encodings_match_reference_g19c(ops):
+    """`gan.L_nocs` / `gan.L_normal` / `gan.geo_c2f` (reference layers/discriminator.py:117-141,145-168; empty in the shipped yaml):
+    positional encodings of the nocs / normal channels in front of the ladder, coarse-to-fine weighted from `Discriminator.progress`.
+    Golden G19c from the reference: logits, the R1 pass' input gradient and value, all six weight_orig gradients of
+    BCE + 10 R1 (a double backward THROUGH the encodings) and u / v after the pass, at two progress values; the ladder and head run
+    on the HIP kernels (first convolution: 33 input channels), the encodings as torch element-wise ops; the explicit schedule K16
+    declines this configuration."""
+    from texpose_amd.disc_step import DiscStepSchedule
+    G = load_golden("g19_options")
+    opt, disc = _g19c_disc(G, dev())
+    assert disc.main[0].weight_orig.shape[1] == 33
+    assert DiscStepSchedule(disc).reason is not None
+    errs = _g19c_check(G, opt, disc, dev(), wtol=1e-4)
+    print("G19c weight_orig gradients vs the REFERENCE:", {k: float("%.1e" % v) for k, v in errs.items()})

@@ -349,3 +349,18 @@ def test_eval_light_latent_pick_g18():
         assert idx.dim() == 0 and int(idx) == picked == int(g["k%d_s%d_picked" % (k, seed)])
         picks.add(picked)
     assert len(picks) >= 3
+
+
+def test_discriminator_geometry_encodings_cpu_mirror_g19c():
+    """The mirror's geometry encodings (gan.L_nocs / L_normal / geo_c2f) on CPU tensors against the reference's own outputs (golden
+    G19c): same check as the GPU test, stock torch ops for the ladder."""
+    import g19_checks as T
+    G = load_golden("g19_options")
+    opt, disc = T.g19c_disc(G, torch.device("cpu"))
+    T.g19c_check(G, opt, disc, torch.device("cpu"), wtol=1e-4)
+    from texpose_amd.gan_modules import Discriminator
+    from texpose_amd.options import default_options
+    bad = default_options(H=32, W=32, device="cpu")
+    bad.gan.L_nocs, bad.gan.L_normal = 2, 3
+    with pytest.raises(ValueError):
+        Discriminator(bad)

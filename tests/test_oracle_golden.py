@@ -448,3 +448,49 @@ def test_nerf_step_g13c_oracle():
         errs["lat_t"] = _rel_l2(torch.zeros(n_train, 16).index_add_(0, idx, lt.grad), g[tier + ".g.latent_vars_trans"])
         errs["lat_l"] = _rel_l2(torch.zeros(n_train, 48).index_add_(0, idx, ll.grad), g[tier + ".g.latent_vars_light"])
         assert len(errs) == 18 and max(errs.values()) < tol, (tier, errs)
+
+
+def test_option_values_g19_oracle():
+    """G19 (a), (b): the coarse-to-fine encoding weights (layers/nerf_static_transient_light.py:217-234) at three progress values --
+    encodings bit-close, MLP outputs, flip-free head gradients -- and the density noise of train mode (:96-97) on the reference's own
+    noise draw, with the CPU oracle."""
+    g = load_golden("g19_options")
+    rng, start = g["a.range"].tolist(), int(g["a.start"])
+    base = O.make_params(int(g["a.seed_w"]))
+    for tag in ("p005", "p027", "p100"):
+        c2f = dict(progress=float(g[f"a.{tag}.progress"]), range=rng, start=start)
+        for L in (10, 4):
+            w = O.c2f_weight(L, c2f["progress"], rng, start)
+            close(O.posenc(g["a.enc_x"], L, w), g[f"a.{tag}.enc{L}"], rtol=1e-6, atol=1e-6)
+        if tag == "p005":
+            # before the window only the bands below `start` carry weight (k = l - start < alpha)
+            assert float(O.c2f_weight(10, c2f["progress"], rng, start)[start:].abs().sum()) == 0
+        if tag == "p100":
+            assert torch.equal(O.c2f_weight(4, c2f["progress"], rng, start), torch.ones(4))        # behind it: every band on
+        p = {k: v.clone().requires_grad_(not k.startswith("mlp_feat")) for k, v in base.items()}
+        lt, ll = g["a.lat_trans"].clone().requires_grad_(), g["a.lat_light"].clone().requires_grad_()
+        outs = O.mlp_forward(p, g["a.points"], g["a.ray_unit"], lt, ll, c2f=c2f)
+        for o, k in zip(outs, ("rgb", "density", "uncert")):
+            close(o, g[f"a.{tag}.{k}"], rtol=2e-5, atol=2e-6)
+        if tag != "p027":
+            continue
+        sum((o * g[f"a.{tag}.cot_{k}"]).sum() for o, k in zip(outs, ("rgb", "density", "uncert"))).backward()
+        stride = int(g["stride"])
+        for k, v in p.items():
+            if not v.requires_grad:
+                continue
+            key = f"a.{tag}.g.{k}"
+            t = v.grad.reshape(-1).double()
+            ref = g[key].double() if key in g else g[key + ".sub"].double()
+            t = t if key in g else t[::stride]
+            assert float((t - ref).norm() / ref.norm()) < 1e-5, k
+            assert abs(float(v.grad.double().norm()) - float(g[key + ".norm"])) <= 1e-5 * float(g[key + ".norm"]), k
+        assert _rel_l2(p["mlp_rgb.0.weight"].grad[:, 256:283], g[f"a.{tag}.g.mlp_rgb.0.weight.viewenc"]) < 1e-5
+        assert _rel_l2(lt.grad, g[f"a.{tag}.g.lat_t"]) < 1e-5 and _rel_l2(ll.grad, g[f"a.{tag}.g.lat_l"]) < 1e-5
+    # (b)
+    outs = O.mlp_forward(base, g["a.points"], g["a.ray_unit"], g["a.lat_trans"], g["a.lat_light"],
+                         density_noise=g["b.noise"] * float(g["b.reg"]))
+    close(outs[1], g["b.density_train"], rtol=2e-5, atol=2e-6)
+    close(outs[0], g["b.rgb"], rtol=2e-5, atol=2e-6)
+    plain = O.mlp_forward(base, g["a.points"], g["a.ray_unit"], g["a.lat_trans"], g["a.lat_light"])
+    close(plain[1], g["b.density_val"], rtol=2e-5, atol=2e-6)

@@ -62,7 +62,7 @@ class MlpFwdArgs(C.Structure):
                 ("ray_unit", vp), ("lat_trans", vp), ("lat_light", vp),
                 ("B", C.c_int), ("R", C.c_int), ("N", C.c_int),
                 ("rgb", vp), ("density", vp), ("uncert", vp), ("saved", vp), ("workspace", vp),
-                ("precision", C.c_int), ("status", vp), ("act_max", vp), ("ray_bias", vp)]
+                ("precision", C.c_int), ("status", vp), ("act_max", vp), ("ray_bias", vp), ("density_noise", vp)]
 
 
 class MlpBwdArgs(C.Structure):

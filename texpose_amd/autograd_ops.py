@@ -57,17 +57,18 @@ def composite(ray, rgb, density, depth, uncert, min_uncert, per_sample=True, wan
 
 class _Mlp(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, nerf, need_grad, lat_trans, lat_light, center, ray, depth, points, ray_unit, *head_params):
+    def forward(ctx, nerf, need_grad, density_noise, lat_trans, lat_light, center, ray, depth, points, ray_unit, *head_params):
         precision = nerf.train_precision if need_grad else nerf.precision
         # evaluation renders with whole tiles inside one ray: view / light / transient inputs as a per-ray bias (ops.ray_bias_applies)
         rb = ops.ray_bias_applies(precision, depth.numel() // (center.shape[0] * center.shape[1]) if center is not None else 0,
                                   bool(need_grad), center is not None)
         packed = nerf.packed_weights(precision, for_training=bool(need_grad), ray_bias=rb)   # (grad mode is off in here: the caller decided)
         res = ops.mlp_forward(packed, lat_trans, lat_light, center=center, ray=ray, depth=depth, points=points,
-                              ray_unit=ray_unit, save=need_grad, precision=precision, ray_bias=rb)
+                              ray_unit=ray_unit, save=need_grad, precision=precision, ray_bias=rb, density_noise=density_noise)
         if need_grad:
             rgb, density, uncert, saved = res
             ctx.nerf = nerf
+            ctx.grad_scale = nerf.c2f_grad_scale()       # (coarse-to-fine weights folded into the packed columns: see NeRF._state_for_pack)
             # the split-fp16 weight-gradient GEMM needs activations inside the fp16 range: guaranteed (flagged) by
             # the f16x3 recording forward only
             ctx.wgrad_precision = precision
@@ -81,13 +82,17 @@ class _Mlp(torch.autograd.Function):
         lat_trans, lat_light, saved, rgb, density, uncert = ctx.saved_tensors
         grads = ops.mlp_backward(ctx.nerf, lat_trans, lat_light, saved, rgb, density, uncert, g_rgb, g_density,
                                  g_uncert, wgrad_precision=ctx.wgrad_precision)
-        return (None, None, grads["lat_trans"], grads["lat_light"], None, None, None, None, None) + tuple(grads["params"])
+        if ctx.grad_scale is not None:
+            # d / dW[:, c] of W (w (.) enc) = w_c times the gradient the kernels formed from the UNWEIGHTED recorded encoding
+            idx, cols, scale = ctx.grad_scale
+            grads["params"][idx][:, cols[0]:cols[1]].mul_(scale)
+        return (None, None, None, grads["lat_trans"], grads["lat_light"], None, None, None, None, None) + tuple(grads["params"])
 
 
 MAX_IMAGES_PER_BACKWARD = 32     # tp_mlp_bwd: the one-hot "image id" tile of the weight-gradient GEMM has 32 columns
 
 
-def mlp(nerf, lat_trans, lat_light, center=None, ray=None, depth=None, points=None, ray_unit=None):
+def mlp(nerf, lat_trans, lat_light, center=None, ray=None, depth=None, points=None, ray_unit=None, density_noise=None):
     head_params = [p for _, p in nerf.head_parameters()]
     # decided here: inside Function.forward grad mode is always off and needs_input_grad ignores no_grad()
     need_grad = torch.is_grad_enabled() and (lat_trans.requires_grad or lat_light.requires_grad
@@ -100,10 +105,10 @@ def mlp(nerf, lat_trans, lat_light, center=None, ray=None, depth=None, points=No
         for b0 in range(0, B, MAX_IMAGES_PER_BACKWARD):
             sl = slice(b0, min(B, b0 + MAX_IMAGES_PER_BACKWARD))
             part = lambda t: None if t is None else t[sl]
-            outs.append(_Mlp.apply(nerf, True, lat_trans[sl], lat_light[sl], part(center), part(ray), part(depth),
+            outs.append(_Mlp.apply(nerf, True, part(density_noise), lat_trans[sl], lat_light[sl], part(center), part(ray), part(depth),
                                    part(points), part(ray_unit), *head_params))
         return tuple(torch.cat(o, dim=0) for o in zip(*outs))
-    return _Mlp.apply(nerf, need_grad, lat_trans, lat_light, center, ray, depth, points, ray_unit, *head_params)
+    return _Mlp.apply(nerf, need_grad, density_noise, lat_trans, lat_light, center, ray, depth, points, ray_unit, *head_params)
 
 
 class _NerfLosses(torch.autograd.Function):

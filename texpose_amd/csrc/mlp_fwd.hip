@@ -73,7 +73,16 @@ struct Params {
   int B, R, N;
   int64_t n_samples, n_tiles;
   float* rgb; float* density; float* uncert; float* saved; float* workspace;
+  const float* density_noise;      // optional: added to the static density's pre-activation (nerf.density_noise_reg, train mode)
 };
+
+// this lane's sample of `tile` (lanes j and j + 32 of a wave hold sample wave * 32 + j), clamped into the call
+__device__ __forceinline__ float density_noise_of(const Params& P, int64_t tile, int wave, int j) {
+  if (P.density_noise == nullptr) return 0.0f;
+  int64_t s = tile * 128 + wave * 32 + j;
+  if (s >= P.n_samples) s = P.n_samples - 1;
+  return P.density_noise[s];
+}
 
 template <bool SAVE>
 __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_kernel(Params P) {
@@ -139,7 +148,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_kernel(Params P) {
     for (int li = 0; li < kNumWide; ++li) {
       if (li == L7) {   // static density = softplus(row 0 of mlp_feat.7) (layers/...light.py:94-98)
         const f32x16 a = part_head(p, h);
-        sig_s = softplus(a[0] + bias_lds[kHeadBiasOff + 0]);
+        sig_s = softplus(a[0] + bias_lds[kHeadBiasOff + 0] + density_noise_of(P, tile, wave, j));
       }
       if (li == R0) {   // bring the trunk feature back for the rgb head
 #pragma unroll
@@ -481,7 +490,9 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_exact_asm_kernel(Params P
       asm32_act<true>(bias_of(li + 1));
     }
     const f32x16 hs = part_head_asm<true>(p);                                   // static density = softplus(row 0 of mlp_feat.7)
-    const float sig_s = softplus(hs[0] + bias_lds[kHeadBiasOff + 0]);
+    float dn_ = 0.0f;
+    if (P.density_noise != nullptr) { const int t_ = fresh_tid(); dn_ = density_noise_of(P, tile, t_ >> 6, t_ & 31); }
+    const float sig_s = softplus(hs[0] + bias_lds[kHeadBiasOff + 0] + dn_);
     part_gen_asm<true>(p);                                                      // L7 -> Q
     if constexpr (SAVE) { const float* rb_; const Rec32 rc_ = rec_now(SV_FEAT, rb_); asm32_act_rec<false, false>(bias_of(L7), rc_, rb_); }
     else asm32_act<false>(bias_of(L7));
@@ -599,6 +610,7 @@ extern "C" int tp_mlp_fwd(const tp_mlp_fwd_args* a, tp_stream_t stream) {
   P.n_samples = (int64_t)a->B * a->R * a->N;
   P.n_tiles = (P.n_samples + kTileSamples - 1) / kTileSamples;
   P.rgb = a->rgb; P.density = a->density; P.uncert = a->uncert; P.saved = a->saved; P.workspace = (float*)a->workspace;
+  P.density_noise = a->density_noise;
   static unsigned long long attr_devices = 0;
   if (tp::first_use_on_device(attr_devices)) {
     hipError_t e = hipFuncSetAttribute((const void*)mlp_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -557,6 +557,7 @@ struct Params {
   int B, R, N;
   int64_t n_samples, n_tiles;
   float* rgb; float* density; float* uncert; float* saved; float* workspace; int* status;
+  const float* density_noise;      // optional: added to the static density's pre-activation (nerf.density_noise_reg, train mode)
   unsigned int* act_max;
   const float* ray_bias;     // RB kernels: [B][2][256] per-image part, then [B*R][256] per-ray accumulator seeds of R0 (rb_*_kernel below)
 };
@@ -713,7 +714,14 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_fwd_f16x3_kernel(Params P) {
       }
       after();
       if (which == 0) {
-        sig_s = softplus(fmaf(a0, kInvScale, hbias[0]));
+        float dn = 0.0f;
+        if (P.density_noise != nullptr) {          // (uniform branch; the sample index is re-derived here, not carried through the tile)
+          TP_THREAD_IDS;
+          int64_t sn = tile * 128 + wave * 32 + j;
+          if (sn >= P.n_samples) sn = P.n_samples - 1;
+          dn = P.density_noise[sn];
+        }
+        sig_s = softplus(fmaf(a0, kInvScale, hbias[0]) + dn);
       } else if (which == 1) {
         // raw accumulators only: the non-linearities run at the end of the R0 staging section (no asm block in between),
         // whose results go to the lane-private LDS area -- held in registers until the output section they crossed R0..R2
@@ -1500,6 +1508,8 @@ int tp_launch_mlp_fwd_f16x3(const tp_mlp_fwd_args* a, int grid, hipStream_t stre
   P.n_tiles = (P.n_samples + 127) / 128;
   P.rgb = a->rgb; P.density = a->density; P.uncert = a->uncert; P.saved = a->saved; P.workspace = (float*)a->workspace;
   P.status = a->status; P.act_max = a->act_max; P.ray_bias = a->ray_bias;
+  P.density_noise = a->density_noise;
+  TP_REQUIRE(a->ray_bias == nullptr || a->density_noise == nullptr, "tp_mlp_fwd: density_noise (train mode) does not go with ray_bias (evaluation)");
   static unsigned long long attr_devices = 0;
   if (tp::first_use_on_device(attr_devices)) {
     hipError_t e = hipFuncSetAttribute((const void*)mlp_fwd_f16x3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);

@@ -49,6 +49,8 @@ class DiscStepSchedule:
         d = self.disc
         if not isinstance(d, Discriminator) or not d.scale_conditional or not d._plain_head():
             return "needs the scale-conditioned three-layer head"
+        if d.L_nocs or d.L_normal:
+            return "geometry encodings in front of the ladder (the R1 penalty differentiates through them): autograd form"
         mods, i, slopes = list(d.main), 0, {d.final[0].negative_slope}
         while i + 2 < len(mods):
             c, n, a = mods[i], mods[i + 1], mods[i + 2]

@@ -109,16 +109,26 @@ def spectral_weights(convs, training: bool):
 
 
 class Discriminator(nn.Module):
-    """patch [B, 3(+6 geo), p, p] (+ patch scale) -> logit [B]."""
+    """patch [B, 3(+6 geo), p, p] (+ patch scale) -> logit [B] (reference layers/discriminator.py:7-141).
+    ``gan.L_nocs`` / ``gan.L_normal`` (empty in the shipped yaml): positional encodings of the nocs / normal channels appended to the
+    input (:128-136), ``gan.geo_c2f``: coarse-to-fine weights on them from ``progress`` (:157-165).  Formed with torch element-wise
+    ops in front of the ladder (differentiable twice: the R1 penalty goes through them); the discriminator step then runs through
+    autograd over the HIP kernels instead of the explicit schedule K16 (disc_step.DiscStepSchedule covers the shipped configuration)."""
 
     def __init__(self, opt, ndf: int = 64):
         super().__init__()
         g = opt.gan
         self.scale_conditional, self.geo_conditional = bool(g.scale_conditional), bool(g.geo_conditional)
         self.L_scale = g.L_scale
-        if g.L_nocs or g.L_normal or g.geo_c2f is not None:
-            raise NotImplementedError("geometry positional encodings are off in the reference config")
-        nc = 3 + (6 if self.geo_conditional else 0)
+        self.L_nocs, self.L_normal = g.L_nocs, g.L_normal
+        self.c2f_range = None if g.geo_c2f is None else (float(g.geo_c2f[0]), float(g.geo_c2f[1]))
+        if (self.L_nocs or self.L_normal or self.c2f_range is not None) and not (self.geo_conditional and (self.L_nocs or self.L_normal)):
+            raise ValueError("gan.L_nocs / L_normal / geo_c2f need gan.geo_conditional and at least one encoding (reference :18-20)")
+        if self.L_normal and self.L_normal != self.L_nocs:
+            # the reference encodes the normals with L = L_nocs (layers/discriminator.py:134) while it sizes the first convolution
+            # with L_normal (:24): any other combination fails there with a channel mismatch
+            raise ValueError("gan.L_normal must equal gan.L_nocs (the reference encodes the normals with L_nocs)")
+        nc = 3 + (6 if self.geo_conditional else 0) + 6 * ((self.L_nocs or 0) + (self.L_normal or 0))
         p = opt.patch_size
         if p not in (16, 32, 64, 128):
             raise ValueError("patch_size must be 16, 32, 64 or 128")
@@ -255,7 +265,29 @@ class Discriminator(nn.Module):
             cur.wait_stream(issued_on)
         return outs, sigmas, us, vs
 
+    def geo_encoding(self, x, L):
+        """[B,3,h,w] -> [B,6L,h,w], channel c 2L + s L + l = sin / cos (2^l pi x_c) (reference positional_encoding :145-168 with
+        reshape=True), times the coarse-to-fine weight of band l when gan.geo_c2f is set."""
+        B, C, h, w = x.shape
+        freq = (2 ** torch.arange(L, dtype=torch.float32, device=x.device)) * math.pi
+        spec = x[:, :, None] * freq.view(1, 1, L, 1, 1)                       # [B,C,L,h,w]
+        enc = torch.stack([spec.sin(), spec.cos()], dim=2)                     # [B,C,2,L,h,w]
+        if self.c2f_range is not None:
+            lo, hi = self.c2f_range
+            alpha = (self.progress.detach() - lo) / (hi - lo) * L
+            k = torch.arange(L, dtype=torch.float32, device=x.device)
+            enc = enc * ((1 - (alpha - k).clamp(min=0, max=1).mul(math.pi).cos()) / 2).view(1, 1, 1, L, 1, 1)
+        return enc.reshape(B, 2 * C * L, h, w)
+
     def forward(self, opt, x, scale=None):
+        if self.L_nocs or self.L_normal:
+            _image, nocs, normal = x.split(3, dim=1)
+            parts = [x]
+            if self.L_nocs is not None:
+                parts.append(self.geo_encoding(nocs, self.L_nocs))
+            if self.L_normal is not None:
+                parts.append(self.geo_encoding(normal, self.L_nocs))          # (L_nocs: as the reference, :134)
+            x = torch.cat(parts, dim=1)
         convs = self.sn_convs()
         pre = None
         if self._sn_queue:

@@ -62,6 +62,12 @@ class NeRF(torch.nn.Module):
         # compute units the weight-gradient launch of the backward fills (tp_mlp_bwd_args.wgrad_cus; 0 = all): a training step that runs
         # other streams beside the backward sets it (trainer.GraphedGanTrainer, linear graphs)
         self.wgrad_cus = 0
+        # coarse-to-fine weights of the two positional encodings (reference :217-234; None: off, as in the shipped yaml).  The kernels
+        # encode unweighted; the weight of band l is folded into the COLUMNS of the three weight matrices that read the encodings when
+        # the stream is packed (`_state_for_pack`): W (w (.) enc) = (W (.) w^T) enc
+        c = opt.c2f
+        self._c2f = None if (c is None or c.range is None) else (float(c.range[0]), float(c.range[1]), 0 if c.start is None else int(c.start))
+        self.density_noise_override = None       # tests: the [B,R,N] standard-normal draw of the next train-mode forward
         if self.precision not in ops.PRECISIONS or self.train_precision not in ops.PRECISIONS:
             raise ValueError("arch.mlp_precision / mlp_train_precision must be one of %s" % list(ops.PRECISIONS))
         self._packed = {}
@@ -80,10 +86,6 @@ class NeRF(torch.nn.Module):
         if not ok:
             raise NotImplementedError("the gfx950 MLP kernels are built for the reference default architecture "
                                       "(options/nerf_lm_adapt_gan.yaml:9-17,37-40); got " + repr(dict(a)))
-        if opt.c2f is not None and opt.c2f.range is not None:
-            raise NotImplementedError("coarse-to-fine posenc weighting (c2f.range) is off in the reference config")
-        if opt.nerf.density_noise_reg:
-            raise NotImplementedError("nerf.density_noise_reg is None in the reference config")
 
     @staticmethod
     def tensorflow_init_weights(linear, out=None):
@@ -103,6 +105,69 @@ class NeRF(torch.nn.Module):
     def _state(self):
         return {k: v for k, v in self.named_parameters() if k.startswith("mlp_")}
 
+    def c2f_weight(self, L: int):
+        """Weight of frequency band l < L at the current ``progress`` (reference :225-231), a device tensor [L]; None: c2f off."""
+        if self._c2f is None:
+            return None
+        lo, hi, start = self._c2f
+        dev = self.progress.device
+        alpha = (self.progress.detach() - lo) / (hi - lo) * L
+        k = torch.arange(L, dtype=torch.float32, device=dev) - start
+        return (1 - (alpha - k).clamp(min=0, max=1).mul(math.pi).cos()) / 2
+
+    # columns of the encodings in the three matrices that read them ([x | PE(x)] = 3 + 60; mlp_rgb.0: feat 256 | view 3 | PE(view) 24 | x 3 | light 48)
+    _VIEW_ENC_COLS = (WIDTH + 3, WIDTH + 3 + 6 * L_VIEW)
+
+    def _state_for_pack(self):
+        """`_state()` with the c2f weights folded into the encoding columns of mlp_feat.0 / mlp_feat.4 / mlp_rgb.0 (copies; the
+        parameters keep the reference's meaning)."""
+        st = self._state()
+        if self._c2f is None:
+            return st
+        w3, wv = self.c2f_weight(self.L_3D), self.c2f_weight(self.L_VIEW)
+        one = lambda n: torch.ones(n, device=w3.device)
+        s3 = torch.cat([one(3), w3.repeat(6)])                       # (index c 2L + s L + l: the band is the fastest index)
+        st = dict(st)
+        with torch.no_grad():
+            st["mlp_feat.0.weight"] = st["mlp_feat.0.weight"].detach() * s3
+            st["mlp_feat.4.weight"] = st["mlp_feat.4.weight"].detach() * torch.cat([one(self.WIDTH), s3])
+            st["mlp_rgb.0.weight"] = st["mlp_rgb.0.weight"].detach() * torch.cat([one(self.WIDTH + 3), wv.repeat(6), one(3 + self.N_LIGHT)])
+        return st
+
+    def c2f_grad_scale(self):
+        """(index of mlp_rgb.0.weight among the head parameters, its view-encoding columns, their weights) for the backward: the kernels
+        form dL/dW from the unweighted recorded encoding.  None: c2f off."""
+        if self._c2f is None:
+            return None
+        names = [k for k, _ in self.head_parameters()]
+        return names.index("mlp_rgb.0.weight"), self._VIEW_ENC_COLS, self.c2f_weight(self.L_VIEW).repeat(6)
+
+    def set_progress(self, value: float):
+        """``progress.data.fill_(value)`` (what the reference's pretrain stages do, model/nerf_pretrain.py:77) AND a re-pack of the
+        weight streams at the next forward: with c2f on, the packed encoding columns depend on it, and a write through ``.data``
+        does not bump the tensor version the lazy re-pack watches (a load_state_dict does).  Code that writes ``progress.data``
+        itself calls `mark_heads_dirty()` afterwards."""
+        with torch.no_grad():
+            self.progress.fill_(float(value))
+        self.mark_heads_dirty()
+
+    def _version_keys(self):
+        st = self._state()
+        extra = ((self.progress.data_ptr(), self.progress._version),) if self._c2f is not None else ()
+        vt = tuple((p.data_ptr(), p._version) for k, p in st.items() if k.startswith("mlp_feat")) + extra
+        vh = tuple((p.data_ptr(), p._version) for k, p in st.items() if not k.startswith("mlp_feat")) + extra
+        return vt, vh
+
+    def density_noise(self, opt, mode, shape, device):
+        """randn * nerf.density_noise_reg for a train-mode forward (reference :96-97), else None."""
+        reg = opt.nerf.density_noise_reg
+        if not reg or mode != "train":
+            return None
+        draw, self.density_noise_override = self.density_noise_override, None
+        if draw is None:
+            draw = torch.randn(shape, device=device)
+        return draw.reshape(shape) * float(reg)
+
     def head_parameters(self):
         """(name, parameter) of the trainable heads, in a fixed order shared by forward and backward."""
         return [(k, p) for k, p in self.named_parameters() if k.startswith(("mlp_rgb", "mlp_trans"))]
@@ -114,9 +179,7 @@ class NeRF(torch.nn.Module):
         variant of ops.mlp_forward(..., ray_bias=True), kept beside the plain one."""
         assert not (ray_bias and (for_training or precision != "f16x3"))
         key = precision + ("+ray_bias" if ray_bias else "")
-        st = self._state()
-        vt = tuple((p.data_ptr(), p._version) for k, p in st.items() if k.startswith("mlp_feat"))
-        vh = tuple((p.data_ptr(), p._version) for k, p in st.items() if not k.startswith("mlp_feat"))
+        vt, vh = self._version_keys()
         dev = next(self.parameters()).device
         buf = self._packed.get(key)
         if buf is None or buf.device != dev:
@@ -124,6 +187,7 @@ class NeRF(torch.nn.Module):
             self._versions[key] = [None, None]
         ver = self._versions[key]
         with torch.no_grad():
+            st = self._state_for_pack() if (ver[0] != vt or ver[1] != vh) else None
             if ver[0] != vt:
                 ops.pack_weights(st, packed=buf, parts=ops.PACK_TRUNK, precision=precision, ray_bias=ray_bias)
                 ver[0] = vt
@@ -144,7 +208,7 @@ class NeRF(torch.nn.Module):
         step's forward), else None."""
         if self._packed_t is None or self._packed_t_ver is None:
             return None
-        vh = tuple((p.data_ptr(), p._version) for k, p in self._state().items() if not k.startswith("mlp_feat"))
+        vh = self._version_keys()[1]
         return self._packed_t if vh == self._packed_t_ver else None
 
     def mark_heads_dirty(self):
@@ -154,6 +218,8 @@ class NeRF(torch.nn.Module):
         texpose_amd.trainer call this after every optimiser step."""
         for ver in self._versions.values():
             ver[1] = None
+            if self._c2f is not None:
+                ver[0] = None               # (coarse-to-fine weights folded into the trunk's encoding columns: they follow `progress`)
         self._packed_t_ver = None
 
     # ------------------------------------------------------------------ reference API
@@ -163,14 +229,16 @@ class NeRF(torch.nn.Module):
         (reference layers/...light.py:76-145)."""
         assert ray_unit is not None, "view_dep=True needs ray_unit"
         lt, ll = self._per_image(latent_variable_trans, latent_variable_light, points_3D.shape[0])
-        return autograd_ops.mlp(self, lt, ll, points=points_3D, ray_unit=ray_unit)
+        return autograd_ops.mlp(self, lt, ll, points=points_3D, ray_unit=ray_unit,
+                                density_noise=self.density_noise(opt, mode, tuple(points_3D.shape[:3]), points_3D.device))
 
     def forward_samples(self, opt, center, ray, depth_samples, latent_variable_trans=None,
                         latent_variable_light=None, mode=None):
         """center, ray [B,R,3], depth_samples [B,R,N,1]: points and unit view directions are formed inside the
         kernel (reference layers/...light.py:147-166)."""
         lt, ll = self._per_image(latent_variable_trans, latent_variable_light, center.shape[0])
-        return autograd_ops.mlp(self, lt, ll, center=center, ray=ray, depth=depth_samples)
+        return autograd_ops.mlp(self, lt, ll, center=center, ray=ray, depth=depth_samples,
+                                density_noise=self.density_noise(opt, mode, tuple(depth_samples.shape[:3]), center.device))
 
     @staticmethod
     def _per_image(lat_trans, lat_light, B):
@@ -201,5 +269,8 @@ class NeRF(torch.nn.Module):
                 f["opacity_transient"], None if prob is None else prob[..., None], unc_ray, a_s, a_t)
 
     def positional_encoding(self, opt, x, L, c2f=False):
-        """[..., C] -> [..., 2 C L], index c*2L + s*L + l (reference layers/...light.py:217-234)."""
-        return ops.posenc(x, L)
+        """[..., C] -> [..., 2 C L], index c*2L + s*L + l (reference layers/...light.py:217-234); ``c2f``: with the coarse-to-fine weights
+        when opt.c2f.range is set."""
+        enc = ops.posenc(x, L)
+        w = self.c2f_weight(L) if c2f else None
+        return enc if w is None else (enc.view(-1, L) * w).view(enc.shape)

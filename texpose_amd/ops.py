@@ -342,8 +342,9 @@ def poll_mlp_status(device, raise_on_flag: bool = True) -> bool:
 def mlp_forward(packed: Tensor, lat_trans: Tensor, lat_light: Tensor, *, center: Optional[Tensor] = None,
                 ray: Optional[Tensor] = None, depth: Optional[Tensor] = None, points: Optional[Tensor] = None,
                 ray_unit: Optional[Tensor] = None, save: bool = False, precision: str = "fp32", ray_bias: bool = False,
-                saved_out: Optional[Tensor] = None):
+                saved_out: Optional[Tensor] = None, density_noise: Optional[Tensor] = None):
     """Returns rgb [B,R,N,3,2], density [B,R,N,2], uncert [B,R,N,1] (+ saved activations if save).
+    ``density_noise`` [B,R,N]: added to the static density's pre-activation (reference nerf.density_noise_reg, train mode).
     ``packed`` must have been built with the same ``precision`` (and the same ``ray_bias``, see `ray_bias_applies`).
     ``saved_out``: caller-provided record buffer (tp_mlp_saved_bytes floats; its last tile's part zeroed when B*R*N % 128)."""
     lib = _lib.load()
@@ -386,6 +387,11 @@ def mlp_forward(packed: Tensor, lat_trans: Tensor, lat_light: Tensor, *, center:
         assert ray_bias_applies(precision, N, save, center is not None), "mlp_forward: ray_bias outside the configuration it covers"
         rb = torch.empty(int(lib.tp_mlp_ray_bias_bytes(B, R)) // 4, device=dev)
         a.ray_bias = rb.data_ptr()
+    if density_noise is not None:
+        density_noise = _f32(density_noise, "density_noise")
+        if density_noise.numel() != B * R * N or density_noise.device != dev:
+            raise _lib.TexposeLibraryError("mlp_forward: density_noise must hold one value per sample, on the render's device")
+        a.density_noise = density_noise.data_ptr()
     check(lib.tp_mlp_fwd(C.byref(a), _stream()), "tp_mlp_fwd")
     return (rgb, density, uncert, saved) if save else (rgb, density, uncert)
 
