@@ -36,7 +36,7 @@ def test_struct_sizes_match_header():
     assert C.sizeof(_lib.RaygenArgs) == 7 * 8 + 6 * 4 + 2 * 4 + 8 + 2 * 8 + 8 + 8 * 4 + 5 * 8
     assert C.sizeof(_lib.CompositeArgs) == 5 * 8 + 8 + 4 + 4 + 6 * 8
     assert C.sizeof(_lib.CompositeBwdArgs) == C.sizeof(_lib.CompositeArgs) + 12 * 8
-    assert C.sizeof(_lib.MlpFwdArgs) == 8 * 8 + 3 * 4 + 4 + 5 * 8 + 4 + 4 + 8 + 8 + 8       # (+ ray_bias)
+    assert C.sizeof(_lib.MlpFwdArgs) == 8 * 8 + 3 * 4 + 4 + 5 * 8 + 4 + 4 + 8 + 8 + 8 + 8   # (+ ray_bias, density_noise)
     assert C.sizeof(_lib.MlpWeights) == 32 * 8
     assert C.sizeof(_lib.PatchGatherArgs) == 7 * 8 + 4 * 4 + 8 + 3 * 8 + 2 * 4          # (+ the PatchGAN stacks of the same launch)
     assert C.sizeof(_lib.EvalMetricsArgs) == 3 * 8 + 5 * 4 + 4 + 2 * 8
