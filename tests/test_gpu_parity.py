@@ -2690,8 +2690,7 @@ def test_disc_head_matches_torch_up_to_second_order(ops, B, C_z, H, L):
 def test_skinny_linear_matches_torch_up_to_second_order(ops, M, K, N, monkeypatch):
     """K15 (csrc/skinny_linear.hip: the PatchGAN's full-map convolution as x W^T for a handful of rows) against torch in fp64:
     the three kernels and their autograd composition incl. an R1-style second-order gradient."""
-    monkeypatch.setenv("TP_SKINNY_DGRAD_KERNEL", "1")          # (the data-gradient kernel is opt-in: rocBLAS is 0.7 % faster per iteration)
-    knobs.reload()
+    assert not knobs.K.skinny_dgrad_mm                          # (K15's own data-gradient kernel is the default; TP_SKINNY_DGRAD_MM=1: rocBLAS)
     from texpose_amd import autograd_ops
     torch.manual_seed(M + K + N)
     x0 = torch.randn(M, K, device=dev())
@@ -3571,3 +3570,19 @@ def test_discriminator_geometry_encodings_match_reference_g19c(ops):
     assert DiscStepSchedule(disc).reason is not None
     errs = _g19c_check(G, opt, disc, dev(), wtol=1e-4)
     print("G19c weight_orig gradients vs the REFERENCE:", {k: float("%.1e" % v) for k, v in errs.items()})
+
+
+def test_feat_chain_is_taken_only_for_the_vgg_layer_sequence(ops):
+    """K18 is hard-wired to VGG19.features[:15]: `chain_eligible` checks the module SEQUENCE (Conv, ReLU, ..., MaxPool2d(2), ...), not
+    just the convolution shapes -- an injected network with other activations or pooling takes the general per-layer path."""
+    from texpose_amd.gan_modules import PerceptualLoss
+    rgb, gathered = torch.rand(2, 256, 3, device=dev()), torch.rand(2, 14, 256, device=dev())
+    pl = PerceptualLoss().to(dev())
+    assert pl.chain_eligible(rgb, gathered, (16, 16))
+    for idx, repl in ((1, torch.nn.LeakyReLU(0.1)), (4, torch.nn.AvgPool2d(2, 2)), (9, torch.nn.MaxPool2d(3, 2, 1)), (13, torch.nn.Identity())):
+        other = PerceptualLoss().to(dev())
+        other.model[idx] = repl
+        assert not other.chain_eligible(rgb, gathered, (16, 16)), idx
+    trainable = PerceptualLoss().to(dev())
+    trainable.model[0].bias.requires_grad_(True)
+    assert not trainable.chain_eligible(rgb, gathered, (16, 16))

@@ -410,6 +410,8 @@ class PerceptualLoss(nn.Module):
         from . import ops
         convs = [m for m in self.model if isinstance(m, nn.Conv2d)]
         ws = [c.weight for c in convs]
+        # (a captured step replays the launches recorded with THIS image: weights written afterwards -- a load_state_dict of the
+        # perceptual network -- are picked up by the next EAGER call or capture only; load them before the trainer captures)
         stamp = tuple((id(w), w.data_ptr(), w._version) for w in ws)
         cached = self.__dict__.get("_chain_packed")
         if cached is None or cached[1] != stamp or cached[0].device != ws[0].device:
@@ -421,10 +423,20 @@ class PerceptualLoss(nn.Module):
         """tp_feat_chain covers the stock configuration: the seven frozen 3x3 convolutions of `CFG`, float32 CUDA tensors, 16 x 16
         patches; anything else (an injected network, other patch sizes, trainable weights) takes the general pieces."""
         from . import ops
-        convs = [m for m in self.model if isinstance(m, nn.Conv2d)]
-        return (ops.feat_chain_supported(rgb, gathered, hw) and len(convs) == 7 and len(list(self.model)) == 15
+        mods = list(self.model)
+        convs = [m for m in mods if isinstance(m, nn.Conv2d)]
+        # the hard-wired chain is VGG19.features[:15]: Conv, ReLU, Conv, ReLU, MaxPool(2), Conv, ReLU, Conv, ReLU, MaxPool(2), Conv, ReLU,
+        # Conv, ReLU, Conv -- an injected network with the same convolution shapes but other activations / pooling is NOT it
+        kinds = [nn.Conv2d, nn.ReLU] * 2 + [nn.MaxPool2d] + [nn.Conv2d, nn.ReLU] * 2 + [nn.MaxPool2d] + [nn.Conv2d, nn.ReLU] * 2 + [nn.Conv2d]
+        if len(mods) != 15 or any(type(m) is not k for m, k in zip(mods, kinds)):
+            return False
+        if any(not (m.kernel_size in (2, (2, 2)) and m.stride in (2, (2, 2)) and m.padding in (0, (0, 0)) and m.dilation in (1, (1, 1))
+                    and not m.ceil_mode) for m in mods if isinstance(m, nn.MaxPool2d)):
+            return False
+        return (ops.feat_chain_supported(rgb, gathered, hw) and len(convs) == 7
                 and all(c.kernel_size == (3, 3) and c.stride == (1, 1) and c.padding == (1, 1) and c.bias is not None
-                        and not c.weight.requires_grad and c.weight.is_cuda and c.weight.is_contiguous() for c in convs)
+                        and not c.weight.requires_grad and not c.bias.requires_grad and c.dilation == (1, 1) and c.groups == 1
+                        and c.weight.is_cuda and c.weight.is_contiguous() for c in convs)
                 and [tuple(c.weight.shape[:2]) for c in convs] == [(64, 3), (64, 64), (128, 64), (128, 128), (256, 128), (256, 256), (256, 256)])
 
     def loss_and_grad_from_patches(self, rgb, gathered, hw, w2: float = 5.0, scale: float = 1.0):

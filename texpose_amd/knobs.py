@@ -48,7 +48,7 @@ _SPEC: Tuple[Tuple[str, str, object, str], ...] = (
     ("no_dgrad_inorm", "TP_NO_DGRAD_INORM", False, "InstanceNorm backward as a launch in front of the 8x8 data gradient instead of inside it"),
     ("no_conv_copy", "TP_NO_CONV_COPY", False, "the discriminator step's private patch copies by a tp_step_inputs launch instead of by the first convolution pair"),
     ("no_sn_sets", "TP_NO_SN_SETS", False, "three tp_sn_fwd calls instead of one tp_sn_fwd_sets"),
-    ("skinny_dgrad_kernel", "TP_SKINNY_DGRAD_KERNEL", False, "K15's own data-gradient kernel instead of torch.mm for the skinny linear layer reached through autograd"),
+    ("skinny_dgrad_mm", "TP_SKINNY_DGRAD_MM", False, "torch.mm (rocBLAS) instead of K15's own data-gradient kernel for the skinny linear layer reached through autograd"),
     ("no_total_in_bwd", "TP_NO_TOTAL_IN_BWD", False, "the generator's loss total + gate as a launch of its own instead of a side job of tp_nerf_losses_bwd_total"),
     ("no_gather_disc", "TP_NO_GATHER_DISC", False, "the PatchGAN's stacks by tp_disc_inputs instead of by the patch gather's launch"),
     ("no_feat_chain", "TP_NO_FEAT_CHAIN", False, "feature loss through per-layer launches + autograd instead of the one-call K18 chain"),

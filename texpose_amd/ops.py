@@ -1837,10 +1837,11 @@ SKINNY_DGRAD_MAX_ROWS = 16
 
 @_on_tensor_device
 def skinny_linear_dgrad(gy: Tensor, w: Tensor, out: Optional[Tensor] = None) -> Tensor:
-    """gy [M,N] @ w [N,K] -> [M,K].  A library GEMM by default (rocBLAS does this shape in ~5 us); TP_SKINNY_DGRAD_KERNEL=1 selects
-    K15's own kernel for up to 16 rows (tp_skinny_linear_dgrad: the step then contains no library kernel, and runs 0.7 % slower --
-    664-669 vs 671-677 it/s, three alternating runs on one box)."""
-    if gy.shape[0] > SKINNY_DGRAD_MAX_ROWS or not knobs.K.skinny_dgrad_kernel:
+    """gy [M,N] @ w [N,K] -> [M,K]: K15's own kernel (tp_skinny_linear_dgrad) for up to 16 rows -- every batch size of BASELINE's
+    configurations -- so that the discriminator pass contains no library kernel in its autograd form either (the captured default
+    iteration never reaches this function: its explicit schedule uses the fused tail K17).  TP_SKINNY_DGRAD_MM=1 selects rocBLAS
+    (0.7 % faster per autograd-form iteration: 671-677 vs 664-669 it/s, round 5); more than 16 rows always take it."""
+    if gy.shape[0] > SKINNY_DGRAD_MAX_ROWS or knobs.K.skinny_dgrad_mm:
         return torch.mm(gy, w, out=out) if out is not None else torch.mm(gy, w)
     lib = _lib.load()
     gy, w = _f32(gy, "gy"), _f32(w, "w")

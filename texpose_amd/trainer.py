@@ -530,6 +530,11 @@ class GraphedGanTrainer(GanTrainer):
     optimiser launch is a graph of its own behind ONE flat all-reduce), and a generic form for every other configuration (one graph
     with its branches forked inside; with several ranks gradients | eager all-reduces | optimisers).
 
+    The step gate across the two optimisers is best-effort in time: a discriminator step's non-finite flag withholds the NEXT nerf step
+    at the latest (with `pipeline_disc_tail` the next render may already be running when the flag is written; in strict mode the same
+    step's Adam launch may have snapshotted the words before the discriminator branch wrote its own) -- each optimiser's own flags
+    always gate its own step, and once a word is set every later step of both is withheld until the host has acted.
+
     By default `train_iteration` returns with the calling stream ordered behind everything the iteration enqueued.  Two opt-in
     attributes relax that for throughput (the linear graphs; bit-identical results either way): ``defer_results`` (the
     calling stream is ordered behind the consumption of the iteration's INPUTS only) and ``pipeline_disc_tail`` (the discriminator
