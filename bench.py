@@ -580,6 +580,27 @@ def eval_masked_leg(device, graph, opt, sc, images=3, mask_frac=0.10):
     return res
 
 
+_REAL_STDOUT = None
+
+
+def protect_stdout():
+    """The contract is ONE JSON line on stdout.  Libraries write to file descriptor 1 behind Python's back -- RCCL prints a version
+    block (from C stdio, flushed at exit) when a communicator is created -- so everything but `emit()` is sent to stderr: fd 1 is
+    pointed at fd 2 for the life of the process and the line goes to a private duplicate of the original stdout."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
+
+
+def emit(line):
+    """Print the result line (a dict) on the process's original stdout."""
+    out = _REAL_STDOUT if _REAL_STDOUT is not None else sys.stdout
+    out.write(json.dumps(line) + "\n")
+    out.flush()
+
+
 def spawn_ranks(n_gpus, argv):
     """`python bench.py --gpus N` without a torchrun environment: start N fresh rank processes as CHILDREN
     (python -m torch.distributed.run, rendezvous on 127.0.0.1 with a free port), pass their output through and return the
@@ -623,6 +644,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
         raise SystemExit("--gpus %d but the launcher started %d rank(s)" % (args.gpus, world))
+    protect_stdout()
     if args.spawn_check and args.config == "c5":
         # the C5 entry point's sharding and aggregation with a stub renderer, on CPU under gloo (no GPU touched)
         import torch.distributed as dist
@@ -632,10 +654,10 @@ def main():
         if world > 1:
             dist.destroy_process_group()
         if rank == 0:
-            print(json.dumps({"spawn_check": world, "config": "c5", "n_gpus": line["n_gpus"],
-                              "per_object_ms": [round(o["ms"], 1) for o in line["per_object"]],
-                              "samples_all_ranks": line["roofline"]["samples_all_ranks"],
-                              "parallelism": line["config"]["parallelism"]}))
+            emit({"spawn_check": world, "config": "c5", "n_gpus": line["n_gpus"],
+                  "per_object_ms": [round(o["ms"], 1) for o in line["per_object"]],
+                  "samples_all_ranks": line["roofline"]["samples_all_ranks"],
+                  "parallelism": line["config"]["parallelism"]})
         return
     if args.spawn_check:
         import torch.distributed as dist
@@ -646,13 +668,13 @@ def main():
             dist.all_reduce(t)
             dist.destroy_process_group()
         if rank == 0:
-            print(json.dumps({"spawn_check": world, "rank_sum": float(t)}))
+            emit({"spawn_check": world, "rank_sum": float(t)})
         return
     if args.config == "c5":
         sys.path.insert(0, os.path.join(REPO, "tools"))
         import eval_multi_object
         eval_multi_object.run(["--steps", str(max(1, min(args.steps, 2))), "--warmup", str(min(args.warmup, 1)),
-                               "--precision", args.precision])
+                               "--precision", args.precision], emit=emit)
         return
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
@@ -950,8 +972,7 @@ def main():
                                                                "gpu_over_cpu": r3(value / cpu["value"])},
             "legs_failed": list(legs_failed),
         }
-        print(json.dumps(line))
-        sys.stdout.flush()
+        emit(line)
     if world > 1:
         torch.distributed.destroy_process_group()
     if legs_failed:

@@ -364,3 +364,39 @@ def test_discriminator_geometry_encodings_cpu_mirror_g19c():
     bad.gan.L_nocs, bad.gan.L_normal = 2, 3
     with pytest.raises(ValueError):
         Discriminator(bad)
+
+
+def test_knobs_are_parsed_once_warn_on_unknown_names_and_are_all_documented(monkeypatch):
+    """texpose_amd.knobs: one frozen object; reload() follows the environment; a TP_* name nobody knows warns; INTEGRATION.md lists
+    every switch; no other module of the package reads os.environ for a TP_* switch."""
+    import glob
+    import re
+    import warnings
+    from texpose_amd import knobs
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    doc = open(os.path.join(repo, "INTEGRATION.md")).read()
+    for _field, env, _default, _doc in knobs._SPEC:
+        assert "`%s`" % env in doc, env
+    for env in knobs.LIBRARY_SWITCHES:
+        assert "`%s`" % env in doc, env
+    with pytest.raises(Exception):
+        knobs.K.no_disc_pairs = True                              # frozen
+    monkeypatch.setenv("TP_NO_DISC_PAIRS", "1")
+    assert not knobs.K.no_disc_pairs                              # parsed once ...
+    assert knobs.reload().no_disc_pairs and knobs.K.no_disc_pairs  # ... until asked again
+    monkeypatch.setenv("TP_NO_DISK_PAIRS", "1")                   # a typo
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        knobs.reload()
+    assert any("TP_NO_DISK_PAIRS" in str(x.message) for x in w)
+    with knobs.override(linear_graphs=False):
+        assert not knobs.K.linear_graphs
+    assert knobs.K.linear_graphs
+    for path in glob.glob(os.path.join(repo, "texpose_amd", "*.py")):
+        if path.endswith(("knobs.py", "_lib.py", "dist.py")):      # (_lib: TEXPOSE_AMD_LIB; dist: the launcher's RANK / WORLD_SIZE)
+            continue
+        assert not re.search(r"os\.environ|getenv", open(path).read()), path
+    # every switch the library itself reads is a known name
+    for path in glob.glob(os.path.join(repo, "texpose_amd", "csrc", "*.h*")):
+        for name in re.findall(r'getenv\("(TP_[A-Z0-9_]+)"\)', open(path).read()):
+            assert name in knobs.LIBRARY_SWITCHES, (path, name)

@@ -6,20 +6,19 @@ export TMPDIR=/tmp
 O=gpurun_out/$T
 ( time timeout 1500 python bench.py > $O/bench_full.json 2> $O/bench_full.err ) 2> $O/bench_wall.txt
 # the same command under rocprofv3 --kernel-trace --stats (kernel averages must agree with the line's HIP-event figures)
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/stats.err
-f=$(find $O/stats -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/kernel_stats.csv
-rm -rf $O/stats
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof/stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/stats.err
+f=$(find $O/prof/stats -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/kernel_stats.csv
 # fabric traffic of the two MLP forward kernels (one counter per pass; KiB, FETCH_SIZE x2 on gfx950) + issue-side counters of the f16x3 one
 pass() { local name=$1 prec=$2; shift 2
-  rocprofv3 --pmc "$@" --kernel-include-regex "mlp_fwd|rb_" --output-format csv -d $O/pmc/$name -- python3 tools/render_once.py $prec 2 > $O/pmc_$name.log 2>&1; }
+  rocprofv3 --pmc "$@" --kernel-include-regex "mlp_fwd|rb_" --output-format csv -d $O/prof/$name -- python3 tools/render_once.py $prec 2 > $O/pmc_$name.log 2>&1; }
 pass f16x3_sq_a f16x3 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA
 pass f16x3_sq_b f16x3 GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU
 pass f16x3_fetch f16x3 FETCH_SIZE
 pass f16x3_write f16x3 WRITE_SIZE
 pass fp32_fetch fp32 FETCH_SIZE
 pass fp32_write fp32 WRITE_SIZE
-python3 tools/summarize_pmc.py $O/pmc > $O/mlp_pmc_summary.json 2> $O/mlp_pmc_summary.err
-python3 - $O/pmc > $O/mlp_traffic.json <<'PY'
+python3 tools/summarize_pmc.py $O/prof > $O/mlp_pmc_summary.json 2> $O/mlp_pmc_summary.err
+python3 - $O/prof > $O/mlp_traffic.json <<'PY'
 import collections, csv, glob, json, sys
 out = {}
 for prec in ("f16x3", "fp32"):
@@ -38,7 +37,7 @@ for prec in ("f16x3", "fp32"):
     out[prec] = dict(fetch_bytes_per_launch=sum(tot["FETCH_SIZE"].values()), write_bytes_per_launch=sum(tot["WRITE_SIZE"].values()), kernels=tot)
 print(json.dumps(out, indent=1))
 PY
-rm -rf $O/pmc
+rm -rf $O/prof
 bash tools/pmc_train.sh $T > /dev/null 2>&1; cp gpurun_out/pmc_train_$T.json $O/train_b32_pmc.json
 # the training iteration: lines, launch counts, timeline, knobs switched off one at a time, the several-rank form, soak
 for i in 1 2 3; do python3 tools/train_bench.py 4 1 400 1 f16x3 2>/dev/null | tail -1 | cut -c1-70; done > $O/train_lines.txt

@@ -262,7 +262,8 @@ def spawn_check(rank: int, world: int, n_objects: int = 8, images_per_object: in
     return line
 
 
-def run(argv=None):
+def run(argv=None, emit=None):
+    """``emit``: how rank 0 hands over its result line (bench.py passes its stdout guard; default: print)."""
     ap = argparse.ArgumentParser()
     ap.add_argument("--objects", type=int, default=8)
     ap.add_argument("--images-per-object", type=int, default=8)
@@ -277,7 +278,7 @@ def run(argv=None):
     device = torch.device("cuda", local)
     line = measure(device, rank, world, a.objects, a.images_per_object, a.samples, a.precision, a.warmup, a.steps)
     if rank == 0:
-        print(json.dumps(line))
+        (emit or (lambda l: print(json.dumps(l))))(line)
     if world > 1:
         torch.distributed.destroy_process_group()
     return line
