@@ -94,9 +94,14 @@ __device__ __forceinline__ float bilin_map(const Bilin& b, const float* __restri
 using tp::philox4x32_10;
 using tp::u01;
 
-__device__ __forceinline__ float strat(float r, int i, float fN, float span, float near) {
-  // ((rand + i) / N) * (far - near) + near, each op rounded as in the reference expression
-  return tp::add_rn(tp::mul_rn(tp::div_rn(tp::add_rn(r, (float)i), fN), span), near);
+// ((rand + i) / N) * (far - near) + near, each op rounded as in the reference expression.  POW2: N is a power of two (64, 128, 256:
+// every BASELINE configuration), so the correctly-rounded quotient IS the product with 2^-k -- exact, and a third of the instructions
+// of an IEEE division (the kernel was as much bound by them as by its stores: 61 us for 167 MB at 480x640x128).
+template <bool POW2>
+__device__ __forceinline__ float strat(float r, int i, float fN, float invN, float span, float near) {
+  const float t = tp::add_rn(r, (float)i);
+  const float q = POW2 ? tp::mul_rn(t, invN) : tp::div_rn(t, fN);
+  return tp::add_rn(tp::mul_rn(q, span), near);
 }
 
 struct Args {
@@ -130,7 +135,7 @@ __device__ __forceinline__ void slab(const float* amin, const float* amax, const
 // TILE rays per workgroup of kTile threads: 256 for image-sized launches (one ray per thread, then 256 N depths written by the
 // workgroup), 32 for patch-sized ones (a training step has 1,024 rays: 4 workgroups would each walk 16 K depths -- and, with the
 // in-kernel Philox draw, 16 x 10 rounds per thread -- on the step's critical path; 32 workgroups take an eighth of that).
-template <int TILE>
+template <int TILE, bool POW2>
 __global__ __launch_bounds__(kTile) void raygen_kernel(Args a) {
   __shared__ float s_near[TILE];
   __shared__ float s_span[TILE];
@@ -215,7 +220,7 @@ __global__ __launch_bounds__(kTile) void raygen_kernel(Args a) {
   const int64_t rays_here = (total - tile0) < TILE ? (total - tile0) : TILE;
   const int64_t n_el = rays_here * a.N;
   const int64_t e0 = tile0 * a.N;  // first global element of this tile
-  const float fN = (float)a.N;
+  const float fN = (float)a.N, invN = 1.0f / fN;
   const uint2 key = make_uint2((uint32_t)a.seed, (uint32_t)(a.seed >> 32));
   const uint64_t off = a.offset + (a.offset_dev ? *a.offset_dev : 0);       // (a captured step: the step counter on the device)
   if ((a.N & 3) == 0) {
@@ -231,10 +236,10 @@ __global__ __launch_bounds__(kTile) void raygen_kernel(Args a) {
       }
       const float nr = s_near[r], sp = s_span[r];
       float4 z;
-      z.x = strat(rr.x, i + 0, fN, sp, nr);
-      z.y = strat(rr.y, i + 1, fN, sp, nr);
-      z.z = strat(rr.z, i + 2, fN, sp, nr);
-      z.w = strat(rr.w, i + 3, fN, sp, nr);
+      z.x = strat<POW2>(rr.x, i + 0, fN, invN, sp, nr);
+      z.y = strat<POW2>(rr.y, i + 1, fN, invN, sp, nr);
+      z.z = strat<POW2>(rr.z, i + 2, fN, invN, sp, nr);
+      z.w = strat<POW2>(rr.w, i + 3, fN, invN, sp, nr);
       *reinterpret_cast<float4*>(a.depth + e0 + e) = z;
     }
   } else {
@@ -249,7 +254,7 @@ __global__ __launch_bounds__(kTile) void raygen_kernel(Args a) {
         const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
         rr = u01(ws[ge & 3]);
       }
-      a.depth[e0 + e] = strat(rr, i, fN, s_span[r], s_near[r]);
+      a.depth[e0 + e] = strat<POW2>(rr, i, fN, invN, s_span[r], s_near[r]);
     }
   }
 }
@@ -284,7 +289,7 @@ __global__ void sample_depth_kernel(const float* __restrict__ near, const float*
       rr = u01(ws[e & 3]);
     }
     const float nr = near[r];
-    depth[e] = strat(rr, i, fN, tp::sub_rn(far[r], nr), nr);
+    depth[e] = strat<false>(rr, i, fN, 0.0f, tp::sub_rn(far[r], nr), nr);
   }
 }
 
@@ -309,8 +314,15 @@ extern "C" int tp_raygen(const tp_raygen_args* p, tp_stream_t stream) {
   const int tile = total <= 16384 ? 32 : kTile;
   const int64_t blocks = (total + tile - 1) / tile;
   TP_REQUIRE(blocks < (1ll << 31), "too many rays for one launch");
-  if (tile == 32) hipLaunchKernelGGL(raygen_kernel<32>, dim3((unsigned)blocks), dim3(kTile), 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL(raygen_kernel<kTile>, dim3((unsigned)blocks), dim3(kTile), 0, (hipStream_t)stream, a);
+  const bool pow2 = p->N > 0 && (p->N & (p->N - 1)) == 0;          // (x / 2^k == x * 2^-k exactly: no IEEE division in the depth loop)
+  const dim3 grid((unsigned)blocks), block(kTile);
+  if (tile == 32) {
+    if (pow2) hipLaunchKernelGGL((raygen_kernel<32, true>), grid, block, 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((raygen_kernel<32, false>), grid, block, 0, (hipStream_t)stream, a);
+  } else {
+    if (pow2) hipLaunchKernelGGL((raygen_kernel<kTile, true>), grid, block, 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((raygen_kernel<kTile, false>), grid, block, 0, (hipStream_t)stream, a);
+  }
   return tp::check_launch("tp_raygen");
 }
 
