@@ -375,7 +375,8 @@ def mlp_forward(p: Dict[str, Tensor], points: Tensor, ray_unit: Tensor,
     n_feat = len([k for k in p if k.startswith("mlp_feat.") and k.endswith(".weight")])
     n_rgb = len([k for k in p if k.startswith("mlp_rgb.") and k.endswith(".weight")])
     n_tr = len([k for k in p if k.startswith("mlp_trans.") and k.endswith(".weight")])
-    enc = torch.cat([points, posenc(points, L_3D, w3)], dim=-1)
+    # (two-argument calls when c2f is off: tests substitute an fp64 `posenc(x, L)`)
+    enc = torch.cat([points, posenc(points, L_3D) if w3 is None else posenc(points, L_3D, w3)], dim=-1)
     h = enc
     with torch.no_grad():
         for li in range(n_feat):
@@ -388,7 +389,7 @@ def mlp_forward(p: Dict[str, Tensor], points: Tensor, ray_unit: Tensor,
                 h = h[..., 1:]
             h = torch.relu(h)
     feat = h
-    venc = torch.cat([ray_unit, posenc(ray_unit, L_view, wv)], dim=-1)
+    venc = torch.cat([ray_unit, posenc(ray_unit, L_view) if wv is None else posenc(ray_unit, L_view, wv)], dim=-1)
     light = lat_light[:, None, None, :].expand(B, R, N, lat_light.shape[-1])
     g = torch.cat([feat, venc, points, light], dim=-1)
     for li in range(n_rgb):

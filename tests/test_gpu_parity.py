@@ -1679,72 +1679,33 @@ def test_linear_form_with_all_reduces_between_graphs_is_bit_identical(ops):
     """The several-rank training step (trainer `_dp`): the linear graphs of the one-rank step with each optimiser launch as a graph of
     its own behind ONE flat all-reduce -- [gradients, tp_grad_pack] | RCCL all-reduce | [Adam / RMSprop reading the flat buffer, gated by
     its tail].  Run here in a 1-rank RCCL communicator with the collectives forced on: (a) stream-ordered calls between the replays (the
-    default with several ranks), (b) captured into the gradient graphs (TP_COLLECTIVES_IN_GRAPH).  With one rank the scale is 1 and the
-    sum is the identity, so eight iterations must leave parameters, buffers, optimiser state and losses BIT-IDENTICAL to the one-rank
-    linear form (whose discriminator step ends inside the spectral-norm backward's launches: same arithmetic, other launches).  Also: the
-    pipelined / deferred modes on the new form, the launch counts, the gate words read from the tails."""
+    default with several ranks), (b) the same with pipeline_disc_tail + defer_results, (c) captured into the gradient graphs
+    (TP_COLLECTIVES_IN_GRAPH; in a child process, tests/rccl_graph_cases.py says why).  With one rank the scale is 1 and the sum is the
+    identity, so eight iterations must leave parameters, buffers, optimiser state and losses BIT-IDENTICAL to the one-rank linear form
+    (whose discriminator step ends inside the spectral-norm backward's launches: same arithmetic, other launches).  Also checked inside
+    the cases: the launch counts, the gate words read from the tails, the optimisers reading the flat buffers."""
+    import gc
     import torch.distributed as dist
-    from texpose_amd.gan_modules import Discriminator, PerceptualLoss
-    from texpose_amd.graph import Graph
-    from texpose_amd.options import default_options, AttrDict
-    from texpose_amd.synthetic import training_batch
-    from texpose_amd.trainer import GraphedGanTrainer
-    made_group = not dist.is_initialized()
-    if made_group:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29519")
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev())
-    out, tr, graph = [], None, None
+    import rccl_graph_cases as cases
+    made_group = cases.ensure_group()
+    keep = None
     try:
-        for mode in ("one_rank", "between", "between_pipelined", "in_graph"):
-            os.environ.pop("TP_COLLECTIVES_IN_GRAPH", None)
-            knobs.reload()
-            if mode == "in_graph":
-                os.environ["TP_COLLECTIVES_IN_GRAPH"] = "1"
-                knobs.reload()
-            torch.manual_seed(0)
-            opt = default_options(H=128, W=128, device="cuda:0")
-            opt.batch_size, opt.patch_size, opt.nerf.sample_intvs = 4, 16, 64
-            graph = Graph(opt, discriminator=Discriminator(opt), perceptual_loss=PerceptualLoss()).to(dev())
-            tr = GraphedGanTrainer(opt, graph, n_train=189)
-            forced = mode != "one_rank"
-            tr.red_nerf.single_rank_collective = tr.red_disc.single_rank_collective = forced
-            tr.pipeline_disc_tail = tr.defer_results = mode == "between_pipelined"
-            batches = [training_batch(4, 128, 128, seed=s_, device="cuda:0") for s_ in range(2)]
-            for it in range(8):
-                _, loss = tr.train_iteration(AttrDict(dict(batches[it % 2])))
-            assert tr._linear and tr._dp == forced and "D2a" in tr._graphs
-            assert ("G2c" in tr._graphs and "D2c" in tr._graphs) == (mode in ("between", "between_pipelined"))
-            assert tr.finish() == [0, 0, 0]
-            torch.cuda.synchronize()
-            if forced:
-                assert tr.optim_nerf.gate.data_ptr() == tr.red_nerf.gate_words.data_ptr()
-                assert int(tr.red_nerf.gate_words.abs().sum()) == 0 and int(tr.red_disc.gate_words.abs().sum()) == 0
-                # the averaged gradients live in the flat buffers: the optimisers read them there
-                assert all(p.grad is None or p.grad.data_ptr() == v.data_ptr() for p, v in zip(tr.red_disc.params, tr.red_disc.views))
-                assert sum(p.grad is not None for p in tr.red_disc.params) == 6 and graph.discriminator.progress.grad is None
-            counts = dict(tr.launch_counts)
-            assert all(v is not None and v > 0 for v in counts.values()), counts
-            out.append(({k: v.clone() for k, v in graph.state_dict().items()}, {k: v.clone() for k, v in loss.items() if torch.is_tensor(v)},
-                        {(oi, pi, name): t.clone() for oi, o in enumerate((tr.optim_nerf, tr.optim_disc))
-                         for pi, p in enumerate(q for gr in o.param_groups for q in gr["params"]) if p in o.state
-                         for name, t in o.state[p].items() if torch.is_tensor(t)},
-                        sum(counts.values())))
+        out = []
+        for mode in ("one_rank", "between", "between_pipelined"):
+            res, keep = cases.run_linear(mode)
+            out.append(res)
+            keep = None
+        out.append(cases.in_child("linear", "in_graph"))
         for other in out[1:]:
-            for k in out[0][0]:
-                assert torch.equal(out[0][0][k], other[0][k]), k
-            for k in out[0][1]:
-                assert torch.equal(out[0][1][k], other[1][k]), k
-            assert out[0][2].keys() == other[2].keys() and len(out[0][2]) > 40
-            for k in out[0][2]:
-                assert torch.equal(out[0][2][k], other[2][k]), k
+            for part in ("state", "loss", "optim"):
+                assert out[0][part].keys() == other[part].keys()
+                for k in out[0][part]:
+                    assert torch.equal(out[0][part][k], other[part][k]), (part, k)
+            assert len(out[0]["optim"]) > 40
         # what the form costs in launches: the total / RMSprop pair the one-rank step folds into the spectral-norm backward, and two packs
-        assert out[0][3] < out[1][3] <= out[0][3] + 6, [o[3] for o in out]
+        assert out[0]["launches"] < out[1]["launches"] <= out[0]["launches"] + 6, [o["launches"] for o in out]
     finally:
-        os.environ.pop("TP_COLLECTIVES_IN_GRAPH", None)
-        knobs.reload()
-        tr = graph = None                       # (captured graphs that contain RCCL kernels go before the communicator does)
-        import gc
+        keep = None
         gc.collect()
         torch.cuda.synchronize()
         if made_group:
@@ -2089,76 +2050,27 @@ def test_spectral_weights_match_torch(ops):
 def test_graph_capture_with_rccl_all_reduce(ops):
     """The data-parallel gradient all-reduce (RCCL) with the GENERIC captured form (TP_NO_LINEAR_DP=1; the linear graphs with the
     collectives have test_linear_form_with_all_reduces_between_graphs_is_bit_identical): a 1-rank NCCL group on this GPU with the
-    collective forced on, (a) inside the single captured graph, (b) eagerly between two replays (gradient graph, optimiser
-    graph).  Both must give the same parameters as the capture without the collective."""
+    collective forced on, (a) inside the single captured graph (in a child process, tests/rccl_graph_cases.py says why), (b) eagerly
+    between two replays (gradient graph, optimiser graph).  Both must give the same parameters as the capture without the collective."""
+    import gc
     import torch.distributed as dist
-    from texpose_amd.gan_modules import Discriminator
-    from texpose_amd.graph import Graph
-    from texpose_amd.options import default_options, AttrDict
-    from texpose_amd.synthetic import training_batch
-    from texpose_amd.trainer import GraphedGanTrainer
-    if not dist.is_initialized():
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29517")
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev())
+    import rccl_graph_cases as cases
+    made_group = cases.ensure_group()
+    keep = None
     try:
-        B, H, W, N = 2, 32, 32, 8
-        batch = training_batch(B, H, W, n_train=5, seed=2, device="cuda:0")
-        rnd = (torch.rand(3, B, 1, 1, 1, device=dev()), torch.rand(B, 256, N, 1, device=dev()))
-        results = []
-        os.environ["TP_NO_LINEAR_DP"] = "1"
-        for forced, split in ((False, False), (True, False), (True, True)):
-            # split: the collectives run eagerly BETWEEN two graph replays (gradients, then optimisers)
-            os.environ.pop("TP_SPLIT_GRAPH", None)
-            knobs.reload()
-            if split:
-                os.environ["TP_SPLIT_GRAPH"] = "1"
-                knobs.reload()
-            opt = default_options(H=H, W=W, device="cuda:0")
-            opt.batch_size, opt.patch_size, opt.nerf.sample_intvs = B, 16, N
-            opt.loss_weight.feat = None
-            graph = Graph(opt, discriminator=Discriminator(opt)).to(dev())
-            graph.nerf.load_state_dict({**graph.nerf.state_dict(), **{k: cu(v) for k, v in O.make_params(6).items()}})
-            dcpu = Discriminator(opt)
-            O.seed_spectral_module(dcpu, 10)
-            graph.discriminator.load_state_dict(dcpu.state_dict())
-            graph.train()
-            graph.nerf.precision = "fp32"
-            tr = GraphedGanTrainer(opt, graph, n_train=5)
-            with torch.no_grad():
-                graph.latent_vars_trans.weight.fill_(0.1)
-                graph.latent_vars_light.weight.fill_(-0.2)
-            tr.red_nerf.single_rank_collective = tr.red_disc.single_rank_collective = forced
-            snap = {k: v.detach().clone() for k, v in graph.state_dict().items()}
-            ex = AttrDict(dict(batch))
-            ex.patch_u, ex.jitter_rand = rnd
-            tr.capture(ex, warmup=2)
-            graph.load_state_dict(snap)
-            for o in (tr.optim_nerf, tr.optim_disc):
-                for st in o.state.values():
-                    for v in st.values():
-                        if torch.is_tensor(v):
-                            v.zero_()
-            graph.nerf.mark_heads_dirty()
-            for _ in range(2):
-                v = AttrDict(dict(batch))
-                v.patch_u, v.jitter_rand = rnd
-                _, loss = tr.train_iteration(v)
-            assert all(np.isfinite(float(x)) for x in loss.values())
-            results.append({k: v.detach().clone() for k, v in graph.state_dict().items()})
-            assert (tr._graph_b is not None) == split and tr._linear == (not forced) and not tr._dp
-        assert_updates_close(results[0], results[1], snap)
-        assert_updates_close(results[0], results[2], snap)
+        plain, keep = cases.run_generic(False, False)
+        keep = None
+        between, keep = cases.run_generic(True, True)
+        keep = None
+        captured = cases.in_child("generic", 1, 0)
+        assert_updates_close(plain["state"], captured["state"], plain["snap"])
+        assert_updates_close(plain["state"], between["state"], plain["snap"])
     finally:
-        os.environ.pop("TP_SPLIT_GRAPH", None)
-        os.environ.pop("TP_NO_LINEAR_DP", None)
-        knobs.reload()
-        # the captured graphs that contain RCCL kernels go before the communicator does
-        tr = graph = None
-        import gc
+        keep = None
         gc.collect()
         torch.cuda.synchronize()
-        dist.destroy_process_group()
+        if made_group:
+            dist.destroy_process_group()
 
 
 def test_bench_scene_bounds_match_oracle(ops):
