@@ -39,6 +39,9 @@ print(json.dumps(out, indent=1))
 PY
 rm -rf $O/prof
 bash tools/pmc_train.sh $T > /dev/null 2>&1; cp gpurun_out/pmc_train_$T.json $O/train_b32_pmc.json
+# the HBM-bound kernels alone: HIP-event GB/s + fabric bytes per launch (composite forward / backward, ray-gen, patch gather)
+bash tools/pmc_hbm.sh $T > /dev/null 2>&1; cp gpurun_out/hbm_$T/pmc.json $O/hbm_kernels_pmc.json 2>/dev/null; cp gpurun_out/hbm_$T/line.json $O/hbm_kernels_events.json 2>/dev/null; rm -f gpurun_out/hbm_$T/*_counter_collection.csv
+python3 -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.txt 2>&1
 # the training iteration: lines, launch counts, timeline, knobs switched off one at a time, the several-rank form, soak
 for i in 1 2 3; do python3 tools/train_bench.py 4 1 400 1 f16x3 2>/dev/null | tail -1 | cut -c1-70; done > $O/train_lines.txt
 python3 tools/launch_counts.py > $O/launch_counts.txt 2>&1
