@@ -50,12 +50,28 @@ class SNConv2d(nn.Module):
             if x2.shape[0] <= 256 and x2.shape[1] >= 1024:              # K15: one pass over the weight, one launch per node
                 from . import autograd_ops
                 return autograd_ops.skinny_linear(x2, w2)[:, :, None, None]
+            _library_kernel_note("a full-map convolution of %d x %d (K15 takes at most 256 rows of at least 1024 columns)" % tuple(x2.shape))
             return F.linear(x2, w2)[:, :, None, None]
         if (x.is_cuda and tuple(weight.shape[-2:]) == (4, 4) and self.stride == (2, 2) and self.padding == (1, 1)
                 and _pow2_map(x.shape[-2]) and _pow2_map(x.shape[-1])):
             from . import autograd_ops                                 # K11: one launch per derivative node
             return autograd_ops.conv4s2(x, weight)
+        if x.is_cuda:
+            _library_kernel_note("a %s convolution, stride %s, on a %d x %d map (K11 takes 4x4 stride-2 convolutions on power-of-two maps)"
+                                 % (tuple(weight.shape[-2:]), self.stride, x.shape[-2], x.shape[-1]))
         return F.conv2d(x, weight, None, self.stride, self.padding)
+
+
+_library_notes = set()
+
+
+def _library_kernel_note(what):
+    """Said once per shape: a PatchGAN geometry outside the HIP kernels' coverage runs this layer through the stock library kernel
+    (MIOpen / rocBLAS) -- same values; none of BASELINE's configurations gets here."""
+    if what not in _library_notes:
+        _library_notes.add(what)
+        import warnings
+        warnings.warn("texpose_amd: %s runs through the stock library kernel, not a HIP kernel of this package" % what)
 
 
 class _SpectralWeightsHip(torch.autograd.Function):
