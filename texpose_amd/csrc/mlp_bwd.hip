@@ -601,57 +601,59 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_wgrad_f16x3_kernel(Wg2Params 
 }
 
 // ------------------------------------------------------------------------------------------------
-enum { SEG_W = 0, SEG_DZSUM = 2 };
-struct Seg {
-  float* out;
-  int kind, gemm;      // gemm 0..5 wide (T2,T1,T0,R2,R1,R0), 6 = T3, 7 = R3
-  int rows, cols;      // SEG_W: output tensor shape and its leading dimension in `ld`; SEG_DZSUM: [B][256]
-  int ld;
-  int64_t start;       // prefix offset in the flattened element space
-};
-struct FinParams {
-  Seg seg[20];
-  int n_seg; int64_t total;
-  const float* partial; int n_w, n_n; int B;   // slices of the wide / narrow GEMMs
+// Phase 1 of the fixed-order reduction: the split-K slices of every partial tile are summed in ascending slice order (one fixed order:
+// run-to-run deterministic) and the sums go to their places -- weight matrices get their recorded-feature columns (and mlp_rgb.0 its
+// [view enc, x] columns); the one-hot tiles become per-image sums of dz, dzsum[gemm][b][o], from which phase 2 forms everything that
+// multiplies a per-image constant.
+// One workgroup per 4-KiB partial tile (item, row tile, feature tile); thread t owns floats 4 t .. 4 t + 3 of the tile, i.e. ONE 16-byte
+// load per slice and thread, a whole tile read contiguously per slice.  (Round 5's form -- one thread per OUTPUT element, four bytes per
+// slice and thread, a wavefront touching two 128-byte pieces 4 KiB apart -- read the 57 MB of partials at 2 TB/s: 28 us at the end of
+// the B=4 iteration's critical path.)
+struct FinTiles {
+  float* w_out[8]; int w_ld[8]; int w_rows[8];   // per gemm id: 0..2 = mlp_trans.{2,1,0}, 3..5 = mlp_rgb.{2,1,0}, 6 = mlp_trans.3, 7 = mlp_rgb.3
+  float* dzsum;                                   // [8][32][256]
+  const float* partial; int n_w, n_n; int B;
 };
 
-__device__ __forceinline__ float part_sum(const FinParams& P, int gemm, int o, int ft, int col) {
-  const bool wide = gemm < 6;
-  const int64_t chunk0 = wide ? (int64_t)(2 * gemm + (o >> 7)) * P.n_w : (int64_t)12 * P.n_w + (int64_t)(gemm - 6) * P.n_n;
+__global__ __launch_bounds__(256) void mlp_wgrad_finalize(FinTiles P) {
+  // blockIdx.x = (item * 4 + rt) * kWgTiles + ft;  items 0..11 = (gemm 0..5, row half), 12 / 13 = the narrow GEMMs 6 / 7 (rt 0 only)
+  const int ft = (int)blockIdx.x % kWgTiles, rt = ((int)blockIdx.x / kWgTiles) & 3, item = (int)blockIdx.x / (4 * kWgTiles);
+  const bool wide = item < 12;
+  const int gemm = wide ? item >> 1 : item - 6;
+  if ((!wide && rt != 0) || (ft == 9 && gemm != 5)) return;            // tiles nobody wrote
   const int ns = wide ? P.n_w : P.n_n;
-  const int wave = wide ? (o & 127) >> 5 : 0;
-  const int ii = o & 31, h = (ii >> 2) & 1, r = (ii & 3) | ((ii >> 3) << 2);
-  const float* p = P.partial + ((chunk0 * 4 + wave) * kWgTiles + ft) * 1024 + r * 64 + h * 32 + col;
-  // fixed order; up to 32 loads in flight (the slices of a GEMM: 38 wide / 14 narrow at 256 CUs -- 12 at a time left the launch
-  // latency-bound: 4 dependent round trips per element)
-  float s = 0.0f;
+  const int64_t chunk0 = wide ? (int64_t)item * P.n_w : (int64_t)12 * P.n_w + (int64_t)(gemm - 6) * P.n_n;
+  const float4* p = reinterpret_cast<const float4*>(P.partial + ((chunk0 * 4 + rt) * kWgTiles + ft) * 1024) + threadIdx.x;
+  const int64_t stride4 = (int64_t)kWgTiles * 1024;                    // float4 units between the slices of a tile (4 kWgTiles 1024 floats)
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int sl0 = 0; sl0 < ns; sl0 += 32) {
-    float v[32];
+    float4 v[32];
 #pragma unroll
-    for (int k = 0; k < 32; ++k) v[k] = sl0 + k < ns ? p[(int64_t)(sl0 + k) * 4 * kWgTiles * 1024] : 0.0f;
+    for (int k = 0; k < 32; ++k) v[k] = sl0 + k < ns ? p[(int64_t)(sl0 + k) * stride4] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int k = 0; k < 32; ++k)
-      if (sl0 + k < ns) s += v[k];
+      if (sl0 + k < ns) { s.x += v[k].x; s.y += v[k].y; s.z += v[k].z; s.w += v[k].w; }
   }
-  return s;
-}
-
-// Phase 1 of the fixed-order reduction: one thread per output element sums the split-K slices.  Weight matrices get
-// their recorded-feature columns (and mlp_rgb.0 its [view enc, x] columns); the one-hot tiles become per-image sums of
-// dz, dzsum[gemm][b][o], from which phase 2 forms everything that multiplies a per-image constant.
-__global__ void mlp_wgrad_finalize(FinParams P) {
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < P.total; e += (int64_t)gridDim.x * blockDim.x) {
-    int si = 0;
-    while (si + 1 < P.n_seg && e >= P.seg[si + 1].start) ++si;
-    const Seg& sg = P.seg[si];
-    const int64_t le = e - sg.start;
-    if (sg.kind == SEG_W) {
-      const int o = (int)(le / sg.cols), c = (int)(le % sg.cols);
-      sg.out[(int64_t)o * sg.ld + c] = c < 256 ? part_sum(P, sg.gemm, o, c >> 5, c & 31) : part_sum(P, 5, o, 9, c - 256);
-    } else {
-      const int b = (int)(le / sg.cols), o = (int)(le % sg.cols);
-      sg.out[b * 256 + o] = part_sum(P, sg.gemm, o, 8, b);
-    }
+  // where the four sums go: tile float q = r * 64 + h * 32 + col holds output row ii = (r & 3) | (h << 2) | ((r >> 2) << 3) of the row tile
+  const int q = (int)threadIdx.x * 4, r = q >> 6, h = (q >> 5) & 1, col = q & 31;
+  const int ii = (r & 3) | (h << 2) | ((r >> 2) << 3);
+  const int o = wide ? (item & 1) * 128 + rt * 32 + ii : ii;
+  if (o >= P.w_rows[gemm]) return;
+  const float v4[4] = {s.x, s.y, s.z, s.w};
+  if (ft < 8) {
+    float* dst = P.w_out[gemm] + (int64_t)o * P.w_ld[gemm] + ft * 32 + col;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dst[k] = v4[k];
+  } else if (ft == 8) {
+    float* dst = P.dzsum + (int64_t)gemm * 32 * 256 + o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (col + k < P.B) dst[(col + k) * 256] = v4[k];
+  } else {                                                             // mlp_rgb.0's [view enc, x] columns 256 .. 285
+    float* dst = P.w_out[5] + (int64_t)o * P.w_ld[5] + 256 + col;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (col + k < 30) dst[k] = v4[k];
   }
 }
 
@@ -828,24 +830,15 @@ extern "C" int tp_mlp_bwd(const tp_mlp_bwd_args* a, tp_stream_t stream_) {
     hipLaunchKernelGGL(mlp_wgrad_kernel, dim3(wg_grid), dim3(kThreads), 2 * kWgBufFloats * sizeof(float), stream, Wg);
   }
 
-  FinParams F;
-  int n = 0; int64_t off = 0;
-  auto add = [&](float* out, int kind, int gemm, int rows, int cols, int ld) {
-    F.seg[n] = Seg{out, kind, gemm, rows, cols, ld, off};
-    off += (int64_t)rows * cols; ++n;
-  };
+  FinTiles F;
   // gemm ids: 0..2 = mlp_trans.{2,1,0}, 3..5 = mlp_rgb.{2,1,0}, 6 = mlp_trans.3, 7 = mlp_rgb.3
-  add(a->g_trans_w[3], SEG_W, 6, 5, 256, 256);
-  add(a->g_trans_w[2], SEG_W, 0, 256, 256, 256);
-  add(a->g_trans_w[1], SEG_W, 1, 256, 256, 256);
-  add(a->g_trans_w[0], SEG_W, 2, 256, 256, 272);      // (latent columns: phase 2)
-  add(a->g_rgb_w[3], SEG_W, 7, 3, 256, 256);
-  add(a->g_rgb_w[2], SEG_W, 3, 256, 256, 256);
-  add(a->g_rgb_w[1], SEG_W, 4, 256, 256, 256);
-  add(a->g_rgb_w[0], SEG_W, 5, 256, 286, 334);        // recorded features + [view enc, x]
-  for (int g = 0; g < 8; ++g) add(dzsum + g * 32 * 256, SEG_DZSUM, g, a->B, g < 6 ? 256 : (g == 6 ? 5 : 3), 256);
-  F.n_seg = n; F.total = off; F.partial = partial; F.n_w = n_w; F.n_n = n_n; F.B = a->B;
-  hipLaunchKernelGGL(mlp_wgrad_finalize, dim3((unsigned)((off + 255) / 256)), dim3(256), 0, stream, F);
+  float* const w_out[8] = {a->g_trans_w[2], a->g_trans_w[1], a->g_trans_w[0], a->g_rgb_w[2], a->g_rgb_w[1], a->g_rgb_w[0],
+                           a->g_trans_w[3], a->g_rgb_w[3]};
+  const int w_ld[8] = {256, 256, 272, 256, 256, 334, 256, 256};       // (mlp_trans.0 / mlp_rgb.0: the latent columns are phase 2's)
+  const int w_rows[8] = {256, 256, 256, 256, 256, 256, 5, 3};
+  for (int g = 0; g < 8; ++g) { F.w_out[g] = w_out[g]; F.w_ld[g] = w_ld[g]; F.w_rows[g] = w_rows[g]; }
+  F.dzsum = dzsum; F.partial = partial; F.n_w = n_w; F.n_n = n_n; F.B = a->B;
+  hipLaunchKernelGGL(mlp_wgrad_finalize, dim3((unsigned)(kWgItems * 4 * kWgTiles)), dim3(256), 0, stream, F);
 
   Fin2Params G;
   G.dzsum = dzsum;
