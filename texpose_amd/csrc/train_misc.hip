@@ -212,6 +212,17 @@ __global__ __launch_bounds__(kBlock) void adam_kernel(AdamTable t, const float* 
   // the bias corrections are per tensor: thread k of every workgroup forms tensor k's once (beta^step as exp(step ln beta) in double, ln
   // beta from the host: a generic double pow() is ~6x the instructions of exp()), everybody reads them from LDS
   __shared__ float s_step_size[TP_ADAM_MAX_TENSORS], s_bc2_sqrt[TP_ADAM_MAX_TENSORS];
+  // the tensor table goes to LDS once per workgroup: indexed per LANE out of the kernel-argument segment it was a dependent global
+  // load per step of the search below and per pointer (up to 18 + 4 round trips in front of every element's own loads)
+  __shared__ int64_t s_end[TP_ADAM_MAX_TENSORS];
+  __shared__ float* s_p[TP_ADAM_MAX_TENSORS];
+  __shared__ const float* s_g[TP_ADAM_MAX_TENSORS];
+  __shared__ float* s_m[TP_ADAM_MAX_TENSORS];
+  __shared__ float* s_v[TP_ADAM_MAX_TENSORS];
+  if ((int)threadIdx.x < TP_ADAM_MAX_TENSORS) {
+    const int k = threadIdx.x;
+    s_end[k] = t.end[k]; s_p[k] = t.p[k]; s_g[k] = t.g[k]; s_m[k] = t.m[k]; s_v[k] = t.v[k];      // (entries >= n: end = total, null pointers)
+  }
   if ((int)threadIdx.x < t.n) {
     const double step = (double)t.step[threadIdx.x][0] + 1.0;
     const double bc1 = 1.0 - exp(step * log_beta1), bc2 = 1.0 - exp(step * log_beta2);
@@ -230,9 +241,16 @@ __global__ __launch_bounds__(kBlock) void adam_kernel(AdamTable t, const float* 
       const int64_t e = e0 + u * stride;
       live[u] = e < total;
       int k = 0;
-      while (live[u] && e >= t.end[k]) ++k;
-      kk[u] = k; ii[u] = live[u] ? e - (k == 0 ? 0 : t.end[k - 1]) : 0;
-      g[u] = t.g[k][ii[u]]; m[u] = t.m[k][ii[u]]; v[u] = t.v[k][ii[u]]; pv[u] = t.p[k][ii[u]];
+      if (live[u]) {                                      // first tensor whose running end lies beyond e: five LDS reads
+        int hi = TP_ADAM_MAX_TENSORS - 1;
+        while (k < hi) {
+          const int mid = (k + hi) >> 1;
+          if (e >= s_end[mid]) k = mid + 1; else hi = mid;
+        }
+      }
+      kk[u] = k; ii[u] = live[u] ? e - (k == 0 ? 0 : s_end[k - 1]) : 0;
+      if (live[u]) { g[u] = s_g[k][ii[u]]; m[u] = s_m[k][ii[u]]; v[u] = s_v[k][ii[u]]; pv[u] = s_p[k][ii[u]]; }
+      else { g[u] = m[u] = v[u] = pv[u] = 0.0f; }
     }
 #pragma unroll
     for (int u = 0; u < kU; ++u) {
@@ -242,10 +260,10 @@ __global__ __launch_bounds__(kBlock) void adam_kernel(AdamTable t, const float* 
       float mm = m[u], vv = v[u];
       mm = tp::add_rn(mm, tp::mul_rn(tp::sub_rn(g[u], mm), w1));                         // exp_avg.lerp_(grad, 1 - beta1): w1 = (float)(1 - beta1)
       vv = tp::add_rn(tp::mul_rn(vv, b2), tp::mul_rn(tp::mul_rn(w2, g[u]), g[u]));      // mul_(beta2).addcmul_(g, g, 1 - beta2): w2 = (float)(1 - beta2)
-      t.m[k][i] = mm;
-      t.v[k][i] = vv;
+      s_m[k][i] = mm;
+      s_v[k][i] = vv;
       const float denom = tp::add_rn(tp::div_rn(sqrtf(vv), bc2_sqrt), eps);
-      t.p[k][i] = tp::add_rn(pv[u], tp::mul_rn(-step_size, tp::div_rn(mm, denom)));   // addcdiv_(exp_avg, denom, value = -step_size)
+      s_p[k][i] = tp::add_rn(pv[u], tp::mul_rn(-step_size, tp::div_rn(mm, denom)));   // addcdiv_(exp_avg, denom, value = -step_size)
     }
   }
   __syncthreads();                                         // every thread of this block has read its counters
