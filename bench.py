@@ -447,7 +447,7 @@ def train_leg(device, rank, world):
                        "random-init VGG19[:15] feature network (weights unavailable offline)"}
     # The captured two-branch step.  On several GPUs the trainer keeps the RCCL all-reduces OUT of the graphs: replay A (render,
     # losses, all backward passes), two eager stream-ordered collectives, replay B (optimiser steps) -- collectives inside a
-    # replayed hipGraph have only ever run in a 1-rank group here (TP_COLLECTIVES_IN_GRAPH=1 opts in).
+    # replayed hipGraph are not supported (ProcessGroupNCCL's watchdog aborts on the captured work event).
     graphed = os.environ.get("TP_BENCH_TRAIN_EAGER", "0") != "1"
     full, note = captured_or_eager(lambda g: train_dp.measure(device, rank, world, global_batch=4 * world, iters=40, warm=4,
                                                               graphed=g, full=True), device, world, graphed,

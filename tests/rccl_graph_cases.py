@@ -1,14 +1,7 @@
-"""Training-iteration cases with RCCL collectives (1-rank communicator, collectives forced), shared by two GPU tests.
-
-The variants that CAPTURE the all-reduces into a hipGraph (TP_COLLECTIVES_IN_GRAPH=1, an opt-in) run in a child process that
-leaves through os._exit() once its results are on disk: destroying a hipGraphExec that holds RCCL kernel nodes next to a live
-communicator crashed once in ~7 full suite runs on this stack (inside gc.collect(), no Python frame: the runtime / RCCL, not this
-repo), and a fatal signal there would take the whole pytest process with it.  Everything the tests compare is computed and saved
-before that point; the stream-ordered (default) form runs in the test process.
-
-    python tests/rccl_graph_cases.py linear in_graph out.pt
-    python tests/rccl_graph_cases.py generic 1 0 out.pt
-"""
+"""Training-iteration cases with RCCL collectives (1-rank communicator, collectives forced), shared by two GPU tests.  The collectives
+are stream-ordered calls BETWEEN graph replays in every case: capturing them into a hipGraph (an opt-in up to round 6) was removed --
+ProcessGroupNCCL's watchdog thread polls the work event the captured call recorded and aborts the process ("operation not permitted
+on an event last recorded in a capturing stream"), about one run in five on this stack."""
 import os
 import sys
 
@@ -35,17 +28,14 @@ def ensure_group():
 
 def run_linear(mode):
     """Eight iterations of the full GAN step (B=4, C3 size) in one of: "one_rank" (no collective), "between" (the several-rank form:
-    all-reduces as stream-ordered calls between the replays), "between_pipelined" (+ pipeline_disc_tail / defer_results), "in_graph"
-    (the RCCL calls captured).  -> dict(state, loss, optim, launches)."""
+    all-reduces as stream-ordered calls between the replays), "between_pipelined" (+ pipeline_disc_tail / defer_results).
+    -> (dict(state, loss, optim, launches), objects to keep alive)."""
     from texpose_amd import knobs
     from texpose_amd.gan_modules import Discriminator, PerceptualLoss
     from texpose_amd.graph import Graph
     from texpose_amd.options import default_options, AttrDict
     from texpose_amd.synthetic import training_batch
     from texpose_amd.trainer import GraphedGanTrainer
-    os.environ.pop("TP_COLLECTIVES_IN_GRAPH", None)
-    if mode == "in_graph":
-        os.environ["TP_COLLECTIVES_IN_GRAPH"] = "1"
     knobs.reload()
     try:
         torch.manual_seed(0)
@@ -60,7 +50,7 @@ def run_linear(mode):
         for it in range(8):
             _, loss = tr.train_iteration(AttrDict(dict(batches[it % 2])))
         assert tr._linear and tr._dp == forced and "D2a" in tr._graphs
-        assert ("G2c" in tr._graphs and "D2c" in tr._graphs) == (mode in ("between", "between_pipelined"))
+        assert ("G2c" in tr._graphs and "D2c" in tr._graphs) == forced
         assert tr.finish() == [0, 0, 0]
         torch.cuda.synchronize()
         if forced:
@@ -79,13 +69,12 @@ def run_linear(mode):
                    launches=sum(counts.values()))
         return res, (tr, graph)
     finally:
-        os.environ.pop("TP_COLLECTIVES_IN_GRAPH", None)
         knobs.reload()
 
 
 def run_generic(forced, split):
-    """Two iterations of the GENERIC captured form (TP_NO_LINEAR_DP=1, no feature loss, 32x32 crops): no collective / the all-reduces
-    captured into the single graph (forced, not split) / eagerly between two replays (forced, split).  -> dict(state, snap)."""
+    """Two iterations of the GENERIC captured form (TP_NO_LINEAR_DP=1, no feature loss, 32x32 crops): no collective (one graph; with
+    ``split`` two), or the all-reduces forced -- then always eagerly between two replays.  -> (dict(state, snap), objects)."""
     from oracle import texpose_oracle as O
     from texpose_amd import knobs
     from texpose_amd.gan_modules import Discriminator
@@ -135,7 +124,7 @@ def run_generic(forced, split):
             v.patch_u, v.jitter_rand = rnd
             _, loss = tr.train_iteration(v)
         assert all(np.isfinite(float(x)) for x in loss.values())
-        assert (tr._graph_b is not None) == split and tr._linear == (not forced) and not tr._dp
+        assert (tr._graph_b is not None) == (split or forced) and tr._linear == (not (forced or split)) and not tr._dp
         torch.cuda.synchronize()
         return dict(state={k: v.detach().cpu().clone() for k, v in graph.state_dict().items()},
                     snap={k: v.cpu() for k, v in snap.items()}), (tr, graph)
@@ -143,30 +132,3 @@ def run_generic(forced, split):
         os.environ.pop("TP_SPLIT_GRAPH", None)
         os.environ.pop("TP_NO_LINEAR_DP", None)
         knobs.reload()
-
-
-def in_child(*args, timeout=900):
-    """Run this module's __main__ with ``args`` in a child process and load what it saved."""
-    import subprocess
-    import tempfile
-    with tempfile.TemporaryDirectory() as tmp:
-        out = os.path.join(tmp, "out.pt")
-        env = dict(os.environ)
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        r = subprocess.run([sys.executable, os.path.abspath(__file__)] + [str(a) for a in args] + [out], env=env, capture_output=True,
-                           text=True, timeout=timeout)
-        if not os.path.exists(out):
-            raise AssertionError("child %r failed (rc %s):\n%s\n%s" % (args, r.returncode, r.stdout[-2000:], r.stderr[-4000:]))
-        return torch.load(out)
-
-
-if __name__ == "__main__":
-    ensure_group()
-    if sys.argv[1] == "linear":
-        res, keep = run_linear(sys.argv[2])
-    else:
-        res, keep = run_generic(bool(int(sys.argv[2])), bool(int(sys.argv[3])))
-    torch.save(res, sys.argv[-1] + ".tmp")
-    os.replace(sys.argv[-1] + ".tmp", sys.argv[-1])
-    sys.stdout.flush()
-    os._exit(0)               # (no teardown of graphs that hold RCCL kernel nodes: see the module docstring)

@@ -420,12 +420,12 @@ def test_graphed_trainer_form_selection_for_several_ranks(monkeypatch):
     """What `world > 1` selects in GraphedGanTrainer (host logic, no GPU).  A configuration the linear graphs cover gets them WITH the
     collectives (`_dp`: gradients + pack | all-reduce | optimiser graph, gates = the tails of the flat buffers); anything else gets the
     generic two-graph form with the eager all-reduces between the replays; a single rank keeps the one-rank forms and the `_bad`
-    snapshots as gates.  TP_COLLECTIVES_IN_GRAPH only moves the RCCL calls into the graphs, TP_NO_LINEAR_DP opts out."""
+    snapshots as gates.  TP_NO_LINEAR_DP opts out of the linear graphs for several ranks."""
     from texpose_amd.options import default_options, AttrDict
     from texpose_amd.gan_modules import Discriminator
     from texpose_amd.graph import Graph
     from texpose_amd.trainer import FusedAdam, FusedRMSprop, GraphedGanTrainer
-    for var in ("TP_COLLECTIVES_IN_GRAPH", "TP_SPLIT_GRAPH", "TP_NO_BRANCH_OVERLAP", "TP_NO_LINEAR_DP"):
+    for var in ("TP_SPLIT_GRAPH", "TP_NO_BRANCH_OVERLAP", "TP_NO_LINEAR_DP"):
         monkeypatch.delenv(var, raising=False)
     # (a) no discriminator: never linear
     opt = default_options(H=32, W=32, device="cpu")
@@ -442,11 +442,6 @@ def test_graphed_trainer_form_selection_for_several_ranks(monkeypatch):
     assert tr._has_collective() and tr._split_around_collectives()                   # several ranks: A | reduce | B
     tr._select_form(batch)
     assert not (tr._linear or tr._dp)
-    monkeypatch.setenv("TP_COLLECTIVES_IN_GRAPH", "1")
-    knobs.reload()
-    assert tr._has_collective() and not tr._split_around_collectives()               # opt-in only
-    monkeypatch.delenv("TP_COLLECTIVES_IN_GRAPH")
-    knobs.reload()
     # (b) the full GAN iteration, as the GPU sees it (the predicates that need the HIP kernels are answered "yes" here)
     opt = default_options(H=32, W=32, device="cpu")
     g = Graph(opt, discriminator=Discriminator(opt))

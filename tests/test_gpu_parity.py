@@ -1679,8 +1679,7 @@ def test_linear_form_with_all_reduces_between_graphs_is_bit_identical(ops):
     """The several-rank training step (trainer `_dp`): the linear graphs of the one-rank step with each optimiser launch as a graph of
     its own behind ONE flat all-reduce -- [gradients, tp_grad_pack] | RCCL all-reduce | [Adam / RMSprop reading the flat buffer, gated by
     its tail].  Run here in a 1-rank RCCL communicator with the collectives forced on: (a) stream-ordered calls between the replays (the
-    default with several ranks), (b) the same with pipeline_disc_tail + defer_results, (c) captured into the gradient graphs
-    (TP_COLLECTIVES_IN_GRAPH; in a child process, tests/rccl_graph_cases.py says why).  With one rank the scale is 1 and the sum is the
+    default with several ranks), (b) the same with pipeline_disc_tail + defer_results.  With one rank the scale is 1 and the sum is the
     identity, so eight iterations must leave parameters, buffers, optimiser state and losses BIT-IDENTICAL to the one-rank linear form
     (whose discriminator step ends inside the spectral-norm backward's launches: same arithmetic, other launches).  Also checked inside
     the cases: the launch counts, the gate words read from the tails, the optimisers reading the flat buffers."""
@@ -1695,7 +1694,6 @@ def test_linear_form_with_all_reduces_between_graphs_is_bit_identical(ops):
             res, keep = cases.run_linear(mode)
             out.append(res)
             keep = None
-        out.append(cases.in_child("linear", "in_graph"))
         for other in out[1:]:
             for part in ("state", "loss", "optim"):
                 assert out[0][part].keys() == other[part].keys()
@@ -2050,8 +2048,8 @@ def test_spectral_weights_match_torch(ops):
 def test_graph_capture_with_rccl_all_reduce(ops):
     """The data-parallel gradient all-reduce (RCCL) with the GENERIC captured form (TP_NO_LINEAR_DP=1; the linear graphs with the
     collectives have test_linear_form_with_all_reduces_between_graphs_is_bit_identical): a 1-rank NCCL group on this GPU with the
-    collective forced on, (a) inside the single captured graph (in a child process, tests/rccl_graph_cases.py says why), (b) eagerly
-    between two replays (gradient graph, optimiser graph).  Both must give the same parameters as the capture without the collective."""
+    collective forced on: the all-reduces run eagerly between two replays (gradient graph, optimiser graph) and must give the same
+    parameters as the capture without the collective, as one graph and as two (TP_SPLIT_GRAPH)."""
     import gc
     import torch.distributed as dist
     import rccl_graph_cases as cases
@@ -2060,10 +2058,11 @@ def test_graph_capture_with_rccl_all_reduce(ops):
     try:
         plain, keep = cases.run_generic(False, False)
         keep = None
-        between, keep = cases.run_generic(True, True)
+        split, keep = cases.run_generic(False, True)
         keep = None
-        captured = cases.in_child("generic", 1, 0)
-        assert_updates_close(plain["state"], captured["state"], plain["snap"])
+        between, keep = cases.run_generic(True, False)
+        keep = None
+        assert_updates_close(plain["state"], split["state"], plain["snap"])
         assert_updates_close(plain["state"], between["state"], plain["snap"])
     finally:
         keep = None

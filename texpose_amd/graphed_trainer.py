@@ -125,13 +125,12 @@ class GraphedGanTrainer(GanTrainer):
         return any(r.world_size > 1 or r.single_rank_collective for r in reds)
 
     def _split_around_collectives(self):
-        """Real multi-rank group: the gradient all-reduces stay OUTSIDE the captured graphs (replay A = everything up to the
-        gradients, two eager collectives, replay B = the optimiser steps).  This is the DEFAULT whenever there is more than
-        one rank; RCCL collectives inside a replayed hipGraph (TP_COLLECTIVES_IN_GRAPH=1 opts in) have only been exercised in
-        a 1-rank group (tests), and between two replays they are ordinary stream-ordered calls."""
-        if knobs.K.collectives_in_graph:
-            return False
-        return self.red_nerf.world_size > 1 or knobs.K.split_graph
+        """Generic form: the gradient all-reduces stay OUTSIDE the captured graphs (replay A = everything up to the gradients, two
+        eager collectives, replay B = the optimiser steps) -- whenever a collective is part of the step.  Between two replays they
+        are ordinary stream-ordered calls.  (Capturing the RCCL calls INTO a graph was an opt-in up to round 6 and is gone:
+        ProcessGroupNCCL's watchdog thread polls the work event that the captured call recorded and aborts the process with "operation
+        not permitted on an event last recorded in a capturing stream" -- about one run in five on this stack.)"""
+        return self._has_collective() or knobs.K.split_graph
 
     def _reduce_all(self):
         """The step's collectives, in ONE fixed order on every rank, after both branches have joined.  The sticky gate words
@@ -416,9 +415,6 @@ class GraphedGanTrainer(GanTrainer):
             # several ranks: this graph ENDS with the gradients (scaled by 1 / world) and the gate words in the flat buffer; the
             # all-reduce is a stream-ordered call behind the replay, the Adam launch a graph of its own (`_seg_gen_c`)
             self.red_nerf.pack(flags=self._bad)
-            if self._collectives_in_graph():
-                self.red_nerf.all_reduce()
-                self._seg_gen_c()
             return var, loss
         self._guard_nerf(var, loss)
         self.nerf_apply()
@@ -433,19 +429,10 @@ class GraphedGanTrainer(GanTrainer):
     def _seg_disc_pack(self):
         """End of the discriminator step's gradient graph with several ranks (see `_seg_gen_b`)."""
         self.red_disc.pack(flags=self._bad)
-        if self._collectives_in_graph():
-            self.red_disc.all_reduce()
-            self._seg_disc_c()
 
     def _seg_disc_c(self):
         self.red_disc.adopt()
         self.optim_disc.step()
-
-    @staticmethod
-    def _collectives_in_graph():
-        """Opt-in (TP_COLLECTIVES_IN_GRAPH=1): the RCCL all-reduces are captured as nodes of the gradient graphs instead of issued
-        between two replays.  Exercised in a 1-rank group only (tests); stream-ordered calls are the default."""
-        return knobs.K.collectives_in_graph
 
     def _collective(self, name, red):
         """One flat all-reduce on the current stream, between two graph replays; HIP events around it when `collective_events` is a
@@ -481,12 +468,12 @@ class GraphedGanTrainer(GanTrainer):
         if self.opt.loss_weight.feat is not None:
             main.wait_stream(self._third)
         var, loss = self._seg_gen_b(var, loss, g_disc)
-        if self._dp and not self._collectives_in_graph():
+        if self._dp:
             self._collective("nerf", self.red_nerf)                # (same order on every rank: nerf, then discriminator)
             self._seg_gen_c()
         with torch.cuda.stream(side):
             var, dloss = self._seg_disc(var)
-            if self._dp and not self._collectives_in_graph():
+            if self._dp:
                 self._collective("disc", self.red_disc)
                 self._seg_disc_c()
         main.wait_stream(side)
@@ -561,7 +548,7 @@ class GraphedGanTrainer(GanTrainer):
         with torch.cuda.graph(g["G2b"], stream=cap, pool=g["G1"].pool()):
             self._stamp("G2b.0"); var, loss = self._seg_gen_b(var, loss, g_disc); self._stamp("G2b.1"); self._extra("G2b"); counts["G2b"] = ops.capture_node_count()
         keep.append(dict(var))
-        split_dp = self._dp and not self._collectives_in_graph()
+        split_dp = self._dp
         if split_dp:
             # several ranks: [G2b: ... gradients, pack] | flat all-reduce (stream-ordered call) | [G2c: Adam from the flat buffer]
             g["G2c"] = torch.cuda.CUDAGraph()

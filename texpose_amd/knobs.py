@@ -25,7 +25,6 @@ _SPEC: Tuple[Tuple[str, str, object, str], ...] = (
     # ---- form of the captured training step (trainer.GraphedGanTrainer)
     ("linear_graphs", "TP_LINEAR_GRAPHS", True, "0: the iteration as ONE captured graph (two with several ranks) instead of the linear graphs on three streams"),
     ("no_linear_dp", "TP_NO_LINEAR_DP", False, "several ranks take the generic form [one graph: gradients] | eager all-reduces | [one graph: optimisers]"),
-    ("collectives_in_graph", "TP_COLLECTIVES_IN_GRAPH", False, "the RCCL all-reduces are captured as graph nodes instead of issued between two replays (1-rank groups only so far)"),
     ("split_graph", "TP_SPLIT_GRAPH", False, "generic form: gradients and optimiser steps as two graphs even without a collective (tests)"),
     ("no_branch_overlap", "TP_NO_BRANCH_OVERLAP", False, "generic form: the discriminator step on the capturing stream instead of a second one"),
     ("no_feat_branch", "TP_NO_FEAT_BRANCH", False, "generic form: the feature chain on the capturing stream instead of a third one (also switches the linear graphs off)"),
