@@ -400,3 +400,17 @@ def test_knobs_are_parsed_once_warn_on_unknown_names_and_are_all_documented(monk
     for path in glob.glob(os.path.join(repo, "texpose_amd", "csrc", "*.h*")):
         for name in re.findall(r'getenv\("(TP_[A-Z0-9_]+)"\)', open(path).read()):
             assert name in knobs.LIBRARY_SWITCHES, (path, name)
+
+
+def test_bench_stdout_carries_only_the_result_line():
+    """bench.py's contract is ONE JSON line on stdout; libraries write to file descriptor 1 behind Python's back (RCCL prints a version
+    block from C stdio when a communicator is created): `protect_stdout` sends everything but `emit` to stderr."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import bench, os, ctypes; bench.protect_stdout(); os.write(1, b'library banner\\n'); "
+            "ctypes.CDLL(None).puts(b'C stdio banner, flushed at exit'); print('python chatter'); bench.emit({'ok': 1})")
+    r = subprocess.run([sys.executable, "-c", code], cwd=repo, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout.strip().splitlines() == ['{"ok": 1}'], r.stdout
+    assert "library banner" in r.stderr and "C stdio banner" in r.stderr and "python chatter" in r.stderr
