@@ -67,6 +67,20 @@ def run_linear(mode):
                           for pi, p in enumerate(q for gr in o.param_groups for q in gr["params"]) if p in o.state
                           for name, t in o.state[p].items() if torch.is_tensor(t)},
                    launches=sum(counts.values()))
+        # the host side of the gate in this form: a word raised on the device (here: by hand) reaches the host through the copy the
+        # form queues -- one rank: the step-input launch; several ranks: the nerf buffer's tail one pack later, copied out on the
+        # discriminator stream when the results are deferred -- and the call that sees it raises
+        tr._bad[1] = 1
+        raised = None
+        for extra in range(4):
+            try:
+                tr.train_iteration(AttrDict(dict(batches[extra % 2])))
+            except FloatingPointError:
+                raised = extra
+                break
+        assert raised is not None and (raised >= 1 or not forced), raised           # (several ranks: the word travels through a pack first)
+        assert "_poll_on_side" not in tr.__dict__
+        res["raised_after"] = raised
         return res, (tr, graph)
     finally:
         knobs.reload()

@@ -611,6 +611,14 @@ class GraphedGanTrainer(GanTrainer):
                 side.wait_stream(cur)
             if not self._first_replay:
                 side.wait_event(ev["g2"])            # set 1 is read by the generator's passes through the frozen discriminator
+            poll = self.__dict__.pop("_poll_on_side", None)
+            if poll is not None:
+                # (several ranks + `defer_results`: the gate words out to the host HERE -- behind both all-reduces of the previous
+                # iteration, in front of this iteration's packs, on every rank alike; D1 sits the render's forward out anyway)
+                ops.step_inputs([], [], words=self._poll_words(), words_host=poll)
+                polled = torch.cuda.Event()
+                polled.record(side)
+                self._bad_poll = (poll, polled)
             g["D1"].replay()
             ev["sn"].record(side)
             if "D1b" in g:
@@ -974,16 +982,23 @@ class GraphedGanTrainer(GanTrainer):
             # `idx`, autograd_ops._LatentRows) -- i.e. while that iteration's backward still runs.  The generator stream then goes from
             # its Adam graph straight into the next render graph: an eager launch between two graphs of one stream cost 39 + 13 us of
             # idle stream there (graph end -> kernel -> graph start; profiles/r6), an event wait costs nothing.
+            # Several ranks (`_dp`): the gate words the host polls must be read at the SAME point of the step on every rank -- behind
+            # the previous iteration's all-reduces, in front of this one's pack -- or two ranks could act on a word one iteration apart
+            # and meet in different collectives.  This launch has no such place (it floats against the previous backward), so the words
+            # are copied out by a launch of their own on the discriminator stream (`_replay_linear`: behind ev g2 and D2c, in front of D1).
+            words_here = poll is not None and not self._dp
             third = self._third
             third.wait_event(self._caller_mark)
             if not self._first_replay:
                 third.wait_event(self._events["patches"])
             with torch.cuda.stream(third):
-                ops.step_inputs(fused, scalars, words=self._poll_words() if poll is not None else None, words_host=poll)
+                ops.step_inputs(fused, scalars, words=self._poll_words() if words_here else None, words_host=poll if words_here else None)
                 ev = torch.cuda.Event()
                 ev.record()
             torch.cuda.current_stream(self._bad.device).wait_event(ev)      # (the caller may overwrite its batch tensors behind this)
             self._inputs_event = ev
+            if poll is not None and not words_here:
+                self._poll_on_side, poll = poll, None
         else:
             ops.step_inputs(fused, scalars, words=self._poll_words() if poll is not None else None, words_host=poll)
             if poll is not None:
