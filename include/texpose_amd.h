@@ -26,7 +26,7 @@ extern "C" {
 
 typedef void* tp_stream_t; /* hipStream_t */
 
-#define TP_ABI_VERSION 11
+#define TP_ABI_VERSION 12
 
 int tp_abi_version(void);
 const char* tp_last_error(void);
@@ -52,6 +52,10 @@ enum tp_jitter_mode {
   TP_JITTER_GIVEN = 1,  /* rand [B,R,N] supplied by the caller (parity runs) */
   TP_JITTER_PHILOX = 2  /* in-kernel Philox4x32-10 keyed by (seed, offset) */
 };
+enum tp_depth_param {   /* options nerf.depth.param (model/nerf_adapt_st_gan.py:699) */
+  TP_DEPTH_METRIC = 0,
+  TP_DEPTH_INVERSE = 1  /* 1 / (sample + 1e-8) */
+};
 
 typedef struct tp_raygen_args {
   const float* intr;      /* [B,3,3] */
@@ -73,8 +77,12 @@ typedef struct tp_raygen_args {
                                * step: the same launch draws different numbers at every replay) */
   int B, R, H, W, N;      /* N = samples per ray (0: no depth output) */
   int pixel_mode, bounds_mode, jitter_mode;
+  int ndc;                /* non-zero: centre / ray re-expressed in normalised device coordinates, near plane z = 1 (camera.py:325-342
+                           * convert_NDC; model/nerf_adapt_st_gan.py:581-583 `camera.ndc`).  Applied AFTER the bounds, which the reference
+                           * takes from the metric rays. */
+  int depth_param;        /* TP_DEPTH_METRIC, or TP_DEPTH_INVERSE: depth = 1 / (sample + 1e-8) (model/nerf_adapt_st_gan.py:699) */
   float* center;          /* [B,R,3] out */
-  float* ray;             /* [B,R,3] out (camera-z component == 1) */
+  float* ray;             /* [B,R,3] out (camera-z component == 1 unless ndc) */
   float* near;            /* [B,R] out, may be NULL */
   float* far;             /* [B,R] out, may be NULL */
   float* depth;           /* [B,R,N] out, may be NULL */
@@ -88,7 +96,7 @@ int tp_aabb(const float* aabb_min3 /*host*/, const float* aabb_max3 /*host*/, co
 
 /* Standalone Graph.sample_depth (model/nerf_adapt_st_gan.py:683-700): near,far [n] -> depth [n,N]. */
 int tp_sample_depth(const float* near, const float* far, const float* rand /*[n,N] or NULL*/, int jitter_mode,
-                    uint64_t seed, uint64_t offset, int64_t n, int N, float* depth, tp_stream_t stream);
+                    uint64_t seed, uint64_t offset, int64_t n, int N, int depth_param /* TP_DEPTH_* */, float* depth, tp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * K2/K3  positional encoding + static/transient/light MLP

@@ -233,13 +233,28 @@ def box_bounds(aabb_min: Tensor, aabb_max: Tensor, o: Tensor, d: Tensor,
 # a7  stratified depth samples               model/nerf_adapt_st_gan.py:683-700
 # ----------------------------------------------------------------------------
 
-def stratified_depths(near: Tensor, far: Tensor, n: int, rand: Optional[Tensor] = None) -> Tensor:
-    """near, far [B,R] -> [B,R,n,1];  rand [B,R,n,1] in [0,1) or None (=0.5)."""
+def stratified_depths(near: Tensor, far: Tensor, n: int, rand: Optional[Tensor] = None, param: str = "metric") -> Tensor:
+    """near, far [B,R] -> [B,R,n,1];  rand [B,R,n,1] in [0,1) or None (=0.5).  ``param`` = options nerf.depth.param
+    (model/nerf_adapt_st_gan.py:699): 'inverse' returns 1 / (sample + 1e-8)."""
     near = near[:, :, None, None]
     far = far[:, :, None, None]
     r = rand if rand is not None else 0.5
     r = r + torch.arange(n)[None, None, :, None].float()
-    return r / n * (far - near) + near
+    z = r / n * (far - near) + near
+    return {"metric": z, "inverse": 1 / (z + 1e-8)}[param]
+
+
+def rays_to_ndc(center: Tensor, ray: Tensor, intr: Tensor, near: float = 1.0) -> Tuple[Tensor, Tensor]:
+    """camera.convert_NDC (camera.py:325-342): rays [B,R,3] moved onto the plane z = near and re-expressed in normalised device
+    coordinates of a camera looking down +z; intr [B,3,3]."""
+    center = center + (near - center[..., 2:]) / ray[..., 2:] * ray
+    cx, cy, cz = center.unbind(-1)
+    rx, ry, rz = ray.unbind(-1)
+    sx = (intr[:, 0, 0] / intr[:, 0, 2])[:, None]
+    sy = (intr[:, 1, 1] / intr[:, 1, 2])[:, None]
+    c = torch.stack([sx * (cx / cz), sy * (cy / cz), 1 - 2 * near / cz], dim=-1)
+    d = torch.stack([sx * (rx / rz - cx / cz), sy * (ry / rz - cy / cz), 2 * near / cz], dim=-1)
+    return c, d
 
 
 # ----------------------------------------------------------------------------
@@ -471,9 +486,10 @@ RENDER_KEYS = ("rgb", "rgb_static", "rgb_transient", "opacity", "opacity_static"
 def render(p, emb_trans: Tensor, emb_light: Tensor, pose: Tensor, intr: Tensor, ray_idx: Tensor,
            depth_range: Tuple[Tensor, Tensor], sample_idx, mode: str, H: int, W: int, n_samples: int,
            rand: Optional[Tensor] = None, transient: str = "zero", min_uncert: float = 0.05,
-           **kw) -> Dict[str, Tensor]:
+           ndc: bool = False, depth_param: str = "metric", **kw) -> Dict[str, Tensor]:
     """depth_range = (z_near [B,HW,1], z_far [B,HW,1]).  ``rand`` replaces the
-    internal torch.rand draw of sample_depth ([B,R,N,1]); None = unstratified."""
+    internal torch.rand draw of sample_depth ([B,R,N,1]); None = unstratified.  ``ndc`` / ``depth_param``: options camera.ndc
+    (reference :581-583, after the bounds) and nerf.depth.param (:699)."""
     if mode == "train":
         B, h, w, _ = ray_idx.shape
         center, ray = rays_train(intr, ray_idx, pose, H, W)
@@ -486,7 +502,9 @@ def render(p, emb_trans: Tensor, emb_light: Tensor, pose: Tensor, intr: Tensor, 
         center, ray = gather_rows(center, ray_idx), gather_rows(ray, ray_idx)
         zn = gather_rows(depth_range[0], ray_idx).squeeze(-1)
         zf = gather_rows(depth_range[1], ray_idx).squeeze(-1)
-    z = stratified_depths(zn, zf, n_samples, rand)
+    if ndc:
+        center, ray = rays_to_ndc(center, ray, intr)
+    z = stratified_depths(zn, zf, n_samples, rand, depth_param)
     if mode == "train":
         lt, ll = emb_trans[sample_idx], emb_light[sample_idx]
     elif mode == "val":

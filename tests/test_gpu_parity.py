@@ -3497,3 +3497,80 @@ def test_feat_chain_is_taken_only_for_the_vgg_layer_sequence(ops):
     trainable = PerceptualLoss().to(dev())
     trainable.model[0].bias.requires_grad_(True)
     assert not trainable.chain_eligible(rgb, gathered, (16, 16))
+
+
+@pytest.mark.gpu
+def test_ndc_and_inverse_depth_g20(ops):
+    """Options `camera.ndc` (model/nerf_adapt_st_gan.py:581-583 -> camera.py:325-342) and `nerf.depth.param = inverse` (:699), off in the
+    reference's shipped yaml, are flags of the ray-generation launch (tp_raygen_args.ndc / .depth_param).  Golden G20 holds the
+    reference's values.  (a) the transformed rays: BIT-identical to the oracle's restatement applied to the kernel's own metric rays
+    (every operation rounded as the reference expression rounds it), and the reference's at the ray-gen tolerance; (b) inverse depths
+    bit-identical to the reference's, standalone and inside the fused launch; (c) Graph.render with each option and with both: against
+    the reference end to end at the amplified G9 bound, against the oracle on the kernel's own rays at 1e-4, both MLP arithmetics."""
+    g = load_golden("g20_ndc_inverse")
+    H, W = int(g["a.H"]), int(g["a.W"])
+    intr, pose = cu(g["a.intr"]), cu(g["a.pose"])
+    every = torch.arange(H * W, device=dev())[None].expand(intr.shape[0], -1).contiguous()
+    for src in (dict(ray_idx=every), dict(coords=cu(g["a.coords"]))):
+        c0, r0, _, _, _ = ops.raygen(intr, pose, H=H, W=W, **src)
+        c1, r1, _, _, _ = ops.raygen(intr, pose, H=H, W=W, ndc=True, **src)
+        co, ro = O.rays_to_ndc(c0.cpu(), r0.cpu(), g["a.intr"])
+        assert torch.equal(c1.cpu(), co) and torch.equal(r1.cpu(), ro)
+        tag = "" if "ray_idx" in src else "_t"
+        torch.testing.assert_close(c1.cpu(), g[f"a.center{tag}_ndc"], rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(r1.cpu(), g[f"a.ray{tag}_ndc"], rtol=1e-5, atol=1e-5)
+    # (b)
+    N = int(g["b.N"])
+    near, far = cu(g["b.near"]), cu(g["b.far"])
+    assert torch.equal(ops.sample_depth(near, far, N, depth_param="inverse").cpu(), g["b.z_mid"][..., 0])
+    assert torch.equal(ops.sample_depth(near, far, N, rand=cu(g["b.rand"]), depth_param="inverse").cpu(), g["b.z_strat"][..., 0])
+    with pytest.raises(KeyError):
+        ops.sample_depth(near, far, N, depth_param="log")
+    # (c)
+    H, W, N = int(g["c.H"]), int(g["c.W"]), int(g["c.N"])
+    params = O.make_params(int(g["c.seed"]))
+    cases = {
+        "ndc": dict(ndc=True, param="metric", mode="train", intr=g["c.intr"], pose=g["c.pose"], idx=g["c.coords"], rand=g["c.ndc.rand"],
+                    sample_idx=g["c.sample_idx"]),
+        "inv": dict(ndc=False, param="inverse", mode="val", intr=g["c.inv.intr"], pose=g["c.inv.pose"], idx=torch.arange(H * W)[None], rand=None,
+                    sample_idx=None),
+        "both": dict(ndc=True, param="inverse", mode="train", intr=g["c.intr"], pose=g["c.pose"], idx=g["c.coords"], rand=g["c.both.rand"],
+                     sample_idx=g["c.sample_idx"]),
+    }
+    for prec in ("fp32", "f16x3"):
+        for tag, cs in cases.items():
+            graph, opt = _graph(params, n_train=int(g["c.n_train"]), emb_seed=int(g["c.emb_seed"]), H=H, W=W, N=N)
+            graph.nerf.precision = graph.nerf.train_precision = prec
+            opt.camera.ndc, opt.nerf.depth.param = cs["ndc"], cs["param"]
+            opt.nerf.sample_stratified = cs["rand"] is not None
+            zn, zf = cu(g[f"c.{tag}.z_near"]), cu(g[f"c.{tag}.z_far"])
+            train = cs["mode"] == "train"
+            with torch.set_grad_enabled(tag == "ndc"):
+                ret = graph.render(opt, cu(cs["pose"]), intr=cu(cs["intr"]), ray_idx=cu(cs["idx"]), depth_range=(zn[:, :, None], zf[:, :, None]),
+                                   sample_idx=None if cs["sample_idx"] is None else cu(cs["sample_idx"]), mode=cs["mode"],
+                                   rand=None if cs["rand"] is None else cu(cs["rand"]))
+            for k in ("rgb", "rgb_static", "rgb_transient", "uncert", "depth", "opacity"):
+                torch.testing.assert_close(ret[k].detach().cpu(), g[f"c.{tag}.out_{k}"], rtol=5e-3, atol=5e-4)
+            assert rel_l2(ret["density"].detach(), g[f"c.{tag}.out_density"]) < 5e-3
+            assert rel_l2(ret["alpha_static"].detach(), g[f"c.{tag}.out_alpha_static"]) < 5e-3
+            # the oracle on the kernel's own rays and depths
+            src = dict(coords=cu(cs["idx"])) if train else dict(ray_idx=cu(cs["idx"]))
+            c, r, _, _, depth = ops.raygen(cu(cs["intr"]), cu(cs["pose"]), H=H, W=W, n_samples=N, z_near=zn, z_far=zf, ndc=cs["ndc"],
+                                           depth_param=cs["param"], **({} if cs["rand"] is None else dict(rand=cu(cs["rand"]))), **src)
+            et, el = graph.latent_vars_trans.weight.detach().cpu(), graph.latent_vars_light.weight.detach().cpu()
+            rows = cs["sample_idx"] if train else torch.tensor([0])
+            with torch.no_grad():
+                rgb_o, den_o, unc_o = O.forward_samples(params, c.cpu(), r.cpu(), depth.cpu()[..., None], et[rows], el[rows])
+                ref = O.composite(r.cpu(), rgb_o, den_o, depth.cpu()[..., None], unc_o, 0.05)
+            for k, v in dict(rgb=ref[0], rgb_static=ref[1], rgb_transient=ref[2], depth=ref[3], uncert=ref[8]).items():
+                torch.testing.assert_close(ret[k].detach().cpu(), v, **RAY)
+            assert rel_l2(ret["density"].detach(), den_o) < 1e-4
+            if tag != "ndc":
+                continue
+            cot = {k[len("c.ndc.cot_"):]: v for k, v in g.items() if k.startswith("c.ndc.cot_")}
+            sum((ret[k] * cu(cot[k])).sum() for k in cot).backward()
+            from g19_checks import g19_sub
+            errs = {name: g19_sub(g, "c.ndc.g." + name, p.grad) for name, p in graph.nerf.named_parameters() if p.grad is not None}
+            errs["light"] = rel_l2(graph.latent_vars_light.weight.grad, g["c.ndc.g.latent_vars_light"])
+            errs["trans"] = rel_l2(graph.latent_vars_trans.weight.grad, g["c.ndc.g.latent_vars_trans"])
+            assert len(errs) == 18 and max(errs.values()) < 5e-3, errs

@@ -494,3 +494,55 @@ def test_option_values_g19_oracle():
     close(outs[0], g["b.rgb"], rtol=2e-5, atol=2e-6)
     plain = O.mlp_forward(base, g["a.points"], g["a.ray_unit"], g["a.lat_trans"], g["a.lat_light"])
     close(plain[1], g["b.density_val"], rtol=2e-5, atol=2e-6)
+
+
+def test_ndc_and_inverse_depth_g20_oracle():
+    """G20 (tests/golden/make_golden_g20_ndc_inverse.py): the options `camera.ndc` (camera.py:325-342) and `nerf.depth.param =
+    inverse` (model/nerf_adapt_st_gan.py:699) of the reference, off in its shipped yaml: the oracle's restatements against the
+    reference's values -- the ray transform on eval and train rays, the depth samples, and Graph.render with each and with both."""
+    g = load_golden("g20_ndc_inverse")
+    # (a) the transform is a handful of elementwise operations: same operations, same values
+    c, d = O.rays_to_ndc(g["a.center"], g["a.ray"], g["a.intr"])
+    assert torch.equal(c, g["a.center_ndc"]) and torch.equal(d, g["a.ray_ndc"])
+    B = g["a.coords"].shape[0]
+    c, d = O.rays_to_ndc(g["a.center_t"].view(B, -1, 3), g["a.ray_t"].view(B, -1, 3), g["a.intr"])
+    assert torch.equal(c, g["a.center_t_ndc"]) and torch.equal(d, g["a.ray_t_ndc"])
+    assert float((g["a.center_ndc"][..., 2] + 1).abs().max()) < 1e-5            # every centre on the near plane: z_ndc = -1
+    # (b)
+    N = int(g["b.N"])
+    assert torch.equal(O.stratified_depths(g["b.near"], g["b.far"], N, None, "inverse"), g["b.z_mid"])
+    assert torch.equal(O.stratified_depths(g["b.near"], g["b.far"], N, g["b.rand"], "inverse"), g["b.z_strat"])
+    assert float(g["b.z_mid"].min()) > 4 and bool((g["b.z_mid"][:, :, 1:] < g["b.z_mid"][:, :, :-1]).all())      # metric, far to near
+    # (c)
+    H, W, N = int(g["c.H"]), int(g["c.W"]), int(g["c.N"])
+    p = {k: v.clone().requires_grad_(not k.startswith("mlp_feat")) for k, v in O.make_params(int(g["c.seed"])).items()}
+    et, el = _embeddings(int(g["c.n_train"]), int(g["c.emb_seed"]))
+    et.requires_grad_()
+    el.requires_grad_()
+    ret = O.render(p, et, el, g["c.pose"], g["c.intr"], g["c.coords"], (g["c.ndc.z_near"][:, :, None], g["c.ndc.z_far"][:, :, None]),
+                   g["c.sample_idx"], "train", H, W, N, rand=g["c.ndc.rand"], ndc=True)
+    for k in O.RENDER_KEYS:
+        close(ret[k], g["c.ndc.out_" + k], rtol=2e-5, atol=2e-6)
+    cot = {k[len("c.ndc.cot_"):]: v for k, v in g.items() if k.startswith("c.ndc.cot_")}
+    sum((ret[k] * cot[k]).sum() for k in cot).backward()
+    stride = int(g["stride"])
+    for k, v in p.items():
+        if not v.requires_grad:
+            continue
+        key = "c.ndc.g." + k
+        t = v.grad.reshape(-1).double()
+        ref = g[key].double() if key in g else g[key + ".sub"].double()
+        t = t if key in g else t[::stride]
+        assert float((t - ref).norm() / ref.norm()) < 1e-3, k
+        assert abs(float(v.grad.double().norm()) - float(g[key + ".norm"])) <= 1e-3 * float(g[key + ".norm"]), k
+    close(et.grad, g["c.ndc.g.latent_vars_trans"], rtol=1e-3, atol=1e-4)
+    close(el.grad, g["c.ndc.g.latent_vars_light"], rtol=1e-3, atol=1e-4)
+    with torch.no_grad():
+        every = torch.arange(H * W)[None]
+        val = O.render(p, et, el, g["c.inv.pose"], g["c.inv.intr"], every, (g["c.inv.z_near"][:, :, None], g["c.inv.z_far"][:, :, None]),
+                       None, "val", H, W, N, depth_param="inverse")
+        both = O.render(p, et, el, g["c.pose"], g["c.intr"], g["c.coords"], (g["c.both.z_near"][:, :, None], g["c.both.z_far"][:, :, None]),
+                        g["c.sample_idx"], "train", H, W, N, rand=g["c.both.rand"], ndc=True, depth_param="inverse")
+    for k in O.RENDER_KEYS:
+        close(val[k], g["c.inv.out_" + k], rtol=2e-5, atol=2e-6)
+        close(both[k], g["c.both.out_" + k], rtol=2e-5, atol=2e-6)

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # TEXPOSE_AMD_LIB selects another build of the SAME library (e.g. the `make trace` diagnostic build); never a fallback
 LIB_PATH = os.environ.get("TEXPOSE_AMD_LIB") or os.path.join(_HERE, "libtexpose_amd.so")
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 # Every symbol include/texpose_amd.h declares (checked by tests/test_capi_cpu.py).
 SYMBOLS = (
@@ -48,7 +48,7 @@ class RaygenArgs(C.Structure):
                 ("z_far", vp), ("rand", vp), ("aabb_min", C.c_float * 3), ("aabb_max", C.c_float * 3),
                 ("bg_near", C.c_float), ("bg_far", C.c_float), ("valid_rect", vp), ("seed", C.c_uint64), ("offset", C.c_uint64), ("offset_dev", vp),
                 ("B", C.c_int), ("R", C.c_int), ("H", C.c_int), ("W", C.c_int), ("N", C.c_int),
-                ("pixel_mode", C.c_int), ("bounds_mode", C.c_int), ("jitter_mode", C.c_int),
+                ("pixel_mode", C.c_int), ("bounds_mode", C.c_int), ("jitter_mode", C.c_int), ("ndc", C.c_int), ("depth_param", C.c_int),
                 ("center", vp), ("ray", vp), ("near", vp), ("far", vp), ("depth", vp)]
 
 
@@ -224,7 +224,7 @@ def load() -> C.CDLL:
 
     sig("tp_raygen", [C.POINTER(RaygenArgs), vp])
     sig("tp_aabb", [C.POINTER(C.c_float), C.POINTER(C.c_float), vp, vp, C.c_int64, vp, vp, vp, vp])
-    sig("tp_sample_depth", [vp, vp, vp, C.c_int, C.c_uint64, C.c_uint64, C.c_int64, C.c_int, vp, vp])
+    sig("tp_sample_depth", [vp, vp, vp, C.c_int, C.c_uint64, C.c_uint64, C.c_int64, C.c_int, C.c_int, vp, vp])
     sig("tp_composite_fwd", [C.POINTER(CompositeArgs), vp])
     sig("tp_composite_bwd", [C.POINTER(CompositeBwdArgs), vp])
     sig("tp_mlp_packed_bytes", [], C.c_size_t)

@@ -103,6 +103,23 @@ __device__ __forceinline__ float strat(float r, int i, float fN, float invN, flo
   const float q = POW2 ? tp::mul_rn(t, invN) : tp::div_rn(t, fN);
   return tp::add_rn(tp::mul_rn(q, span), near);
 }
+// nerf.depth.param = inverse (reference :699): 1 / (sample + 1e-8)
+__device__ __forceinline__ float depth_of(float z, bool inverse) { return inverse ? tp::div_rn(1.0f, tp::add_rn(z, 1e-8f)) : z; }
+
+// camera.convert_NDC (camera.py:325-342), near plane z = 1, every operation rounded as the reference expression rounds it:
+//   o' = o + (1 - o_z) / d_z * d;   centre = (sx o'_x / o'_z, sy o'_y / o'_z, 1 - 2 / o'_z),  sx = K00 / K02, sy = K11 / K12
+//   ray = (sx (d_x / d_z - o'_x / o'_z), sy (d_y / d_z - o'_y / o'_z), 2 / o'_z)
+__device__ __forceinline__ void to_ndc(const float* __restrict__ K, float* o, float* d) {
+  const float t = tp::div_rn(tp::sub_rn(1.0f, o[2]), d[2]);
+  float c[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) c[j] = tp::add_rn(o[j], tp::mul_rn(t, d[j]));
+  const float sx = tp::div_rn(K[0], K[2]), sy = tp::div_rn(K[4], K[5]);
+  const float cxz = tp::div_rn(c[0], c[2]), cyz = tp::div_rn(c[1], c[2]), two_z = tp::div_rn(2.0f, c[2]);
+  const float rx = tp::sub_rn(tp::div_rn(d[0], d[2]), cxz), ry = tp::sub_rn(tp::div_rn(d[1], d[2]), cyz);
+  o[0] = tp::mul_rn(sx, cxz); o[1] = tp::mul_rn(sy, cyz); o[2] = tp::sub_rn(1.0f, two_z);
+  d[0] = tp::mul_rn(sx, rx);  d[1] = tp::mul_rn(sy, ry);  d[2] = two_z;
+}
 
 struct Args {
   const float* intr; const float* pose; const float* coords; const int64_t* ray_idx;
@@ -111,7 +128,7 @@ struct Args {
   const float* valid_rect;
   uint64_t seed, offset;
   const uint64_t* offset_dev;
-  int B, R, H, W, N, pixel_mode, bounds_mode, jitter_mode;
+  int B, R, H, W, N, pixel_mode, bounds_mode, jitter_mode, ndc, inverse;
   float* center; float* ray; float* near; float* far; float* depth;
 };
 
@@ -178,10 +195,12 @@ __global__ __launch_bounds__(kTile) void raygen_kernel(Args a) {
       o[j] = cam.tinv[j];
       d[j] = tp::sub_rn(world, cam.tinv[j]);
     }
+    if (!a.ndc) {
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      a.center[3 * q + j] = o[j];
-      a.ray[3 * q + j] = d[j];
+      for (int j = 0; j < 3; ++j) {
+        a.center[3 * q + j] = o[j];
+        a.ray[3 * q + j] = d[j];
+      }
     }
     if (a.bounds_mode == TP_BOUNDS_MAP) {
       const float* zn = a.z_near + (int64_t)b * a.H * a.W;
@@ -209,6 +228,14 @@ __global__ __launch_bounds__(kTile) void raygen_kernel(Args a) {
     if (a.bounds_mode != TP_BOUNDS_NONE) {
       if (a.near) a.near[q] = near;
       if (a.far) a.far[q] = far;
+    }
+    if (a.ndc) {                           // (behind the bounds: the reference's ranges come from the metric rays)
+      to_ndc(a.intr + 9 * b, o, d);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        a.center[3 * q + j] = o[j];
+        a.ray[3 * q + j] = d[j];
+      }
     }
   }
   if (a.depth == nullptr || a.N <= 0 || a.bounds_mode == TP_BOUNDS_NONE) return;
@@ -240,6 +267,7 @@ __global__ __launch_bounds__(kTile) void raygen_kernel(Args a) {
       z.y = strat<POW2>(rr.y, i + 1, fN, invN, sp, nr);
       z.z = strat<POW2>(rr.z, i + 2, fN, invN, sp, nr);
       z.w = strat<POW2>(rr.w, i + 3, fN, invN, sp, nr);
+      if (a.inverse) { z.x = depth_of(z.x, true); z.y = depth_of(z.y, true); z.z = depth_of(z.z, true); z.w = depth_of(z.w, true); }
       *reinterpret_cast<float4*>(a.depth + e0 + e) = z;
     }
   } else {
@@ -254,7 +282,7 @@ __global__ __launch_bounds__(kTile) void raygen_kernel(Args a) {
         const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
         rr = u01(ws[ge & 3]);
       }
-      a.depth[e0 + e] = strat<POW2>(rr, i, fN, invN, s_span[r], s_near[r]);
+      a.depth[e0 + e] = depth_of(strat<POW2>(rr, i, fN, invN, s_span[r], s_near[r]), a.inverse != 0);
     }
   }
 }
@@ -272,7 +300,7 @@ __global__ void aabb_kernel(float3 lo, float3 hi, const float* __restrict__ o, c
 
 __global__ void sample_depth_kernel(const float* __restrict__ near, const float* __restrict__ far,
                                     const float* __restrict__ rnd, int jitter, uint64_t seed, uint64_t offset,
-                                    int64_t n, int N, float* __restrict__ depth) {
+                                    int64_t n, int N, int inverse, float* __restrict__ depth) {
   const int64_t total = n * N;
   const uint2 key = make_uint2((uint32_t)seed, (uint32_t)(seed >> 32));
   const float fN = (float)N;
@@ -289,7 +317,7 @@ __global__ void sample_depth_kernel(const float* __restrict__ near, const float*
       rr = u01(ws[e & 3]);
     }
     const float nr = near[r];
-    depth[e] = strat<false>(rr, i, fN, 0.0f, tp::sub_rn(far[r], nr), nr);
+    depth[e] = depth_of(strat<false>(rr, i, fN, 0.0f, tp::sub_rn(far[r], nr), nr), inverse != 0);
   }
 }
 
@@ -309,6 +337,8 @@ extern "C" int tp_raygen(const tp_raygen_args* p, tp_stream_t stream) {
   a.bg_near = p->bg_near; a.bg_far = p->bg_far; a.valid_rect = p->valid_rect; a.seed = p->seed; a.offset = p->offset; a.offset_dev = p->offset_dev;
   a.B = p->B; a.R = p->R; a.H = p->H; a.W = p->W; a.N = p->N;
   a.pixel_mode = p->pixel_mode; a.bounds_mode = p->bounds_mode; a.jitter_mode = p->jitter_mode;
+  TP_REQUIRE(p->depth_param == TP_DEPTH_METRIC || p->depth_param == TP_DEPTH_INVERSE, "unknown depth_param");
+  a.ndc = p->ndc != 0; a.inverse = p->depth_param == TP_DEPTH_INVERSE;
   a.center = p->center; a.ray = p->ray; a.near = p->near; a.far = p->far; a.depth = p->depth;
   const int64_t total = (int64_t)p->B * p->R;
   const int tile = total <= 16384 ? 32 : kTile;
@@ -337,13 +367,14 @@ extern "C" int tp_aabb(const float* lo, const float* hi, const float* o, const f
 }
 
 extern "C" int tp_sample_depth(const float* near, const float* far, const float* rnd, int jitter, uint64_t seed,
-                               uint64_t offset, int64_t n, int N, float* depth, tp_stream_t stream) {
+                               uint64_t offset, int64_t n, int N, int depth_param, float* depth, tp_stream_t stream) {
   TP_REQUIRE(near && far && depth && N > 0, "bad arguments");
+  TP_REQUIRE(depth_param == TP_DEPTH_METRIC || depth_param == TP_DEPTH_INVERSE, "unknown depth_param");
   TP_REQUIRE(jitter != TP_JITTER_GIVEN || rnd != nullptr, "missing rand tensor");
   if (n == 0) return 0;
   int64_t blocks = (n * N + 255) / 256;
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(sample_depth_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, near, far, rnd,
-                     jitter, seed, offset, n, N, depth);
+                     jitter, seed, offset, n, N, depth_param == TP_DEPTH_INVERSE, depth);
   return tp::check_launch("tp_sample_depth");
 }

@@ -91,10 +91,15 @@ class Graph(torch.nn.Module):
     @staticmethod
     def sample_depth(opt, batch_size, depth_range, num_rays=None, rand=None):
         """(near, far) [B,R] -> stratified depths [B,R,N,1] (reference :683-700)."""
-        if opt.nerf.depth.param != "metric":
-            raise NotImplementedError("nerf.depth.param=%r (the reference config uses 'metric')" % opt.nerf.depth.param)
         near, far = depth_range
-        return ops.sample_depth(near, far, opt.nerf.sample_intvs, **Graph._jitter(opt, rand))[..., None]
+        return ops.sample_depth(near, far, opt.nerf.sample_intvs, depth_param=Graph._depth_param(opt), **Graph._jitter(opt, rand))[..., None]
+
+    @staticmethod
+    def _depth_param(opt):
+        param = opt.nerf.depth.param
+        if param not in ops.DEPTH_PARAMS:
+            raise KeyError(param)                                    # (the reference indexes a dict of the two, :699)
+        return param
 
     @staticmethod
     def ray_batch_sample(ray_identity, ray_idx):
@@ -105,16 +110,13 @@ class Graph(torch.nn.Module):
 
     # ------------------------------------------------------------------ rendering (the hot path)
     def render(self, opt, pose, intr=None, ray_idx=None, depth_range=None, sample_idx=None, mode=None, rand=None):
-        if opt.camera.ndc:
-            raise NotImplementedError("camera.ndc (false in the reference config)")
-        if opt.nerf.depth.param != "metric":
-            raise NotImplementedError("nerf.depth.param != 'metric'")
         N = opt.nerf.sample_intvs
         z_near, z_far = depth_range
         batch_size = len(pose)
         src = dict(coords=ray_idx) if mode == "train" else dict(ray_idx=ray_idx)
+        # camera.ndc (reference :581-583) and nerf.depth.param (:699) are flags of the same launch
         center, ray, _, _, depth = ops.raygen(intr, pose, H=opt.H, W=opt.W, n_samples=N, z_near=z_near, z_far=z_far,
-                                              **src, **self._jitter(opt, rand, getattr(self, "step_counter", None) if mode == "train" else None))
+                                              ndc=bool(opt.camera.ndc), depth_param=self._depth_param(opt), **src, **self._jitter(opt, rand, getattr(self, "step_counter", None) if mode == "train" else None))
         depth_samples = depth[..., None]                                     # [B,R,N,1]
         if (mode == "train" and torch.is_tensor(sample_idx) and sample_idx.dim() == 1 and sample_idx.is_cuda
                 and self.latent_vars_trans.weight.shape[0] == self.latent_vars_light.weight.shape[0]):

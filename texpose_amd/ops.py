@@ -23,6 +23,7 @@ Tensor = torch.Tensor
 PIX_COORDS, PIX_INDEX = 0, 1
 BOUNDS_MAP, BOUNDS_AABB, BOUNDS_NONE = 0, 1, 2
 JITTER_MID, JITTER_GIVEN, JITTER_PHILOX = 0, 1, 2
+DEPTH_PARAMS = {"metric": 0, "inverse": 1}          # options nerf.depth.param -> TP_DEPTH_*
 PACK_TRUNK, PACK_HEADS, PACK_ALL, PACK_F16X3, PACK_RAYBIAS = 1, 2, 3, 4, 8
 MLP_FP32, MLP_F16X3 = 0, 1
 PRECISIONS = {"fp32": MLP_FP32, "f16x3": MLP_F16X3}
@@ -97,10 +98,12 @@ def raygen(intr: Tensor, pose: Tensor, *, H: int, W: int, n_samples: int = 0, co
            aabb: Optional[Tuple[Tuple[float, float, float], Tuple[float, float, float]]] = None,
            bg_range: Tuple[float, float] = (0.0, 30.0), rand: Optional[Tensor] = None,
            jitter: int = JITTER_MID, seed: int = 0, offset: int = 0, valid_rect: Optional[Tensor] = None,
-           offset_dev: Optional[Tensor] = None):
+           offset_dev: Optional[Tensor] = None, ndc: bool = False, depth_param: str = "metric"):
     """Fused ray-gen + bounds + stratified depths.  Returns (center, ray, near, far, depth);
     near/far/depth are None when no bounds source is given, depth is [B,R,N].  ``offset_dev`` (int64 [1] on the device): added
-    to the Philox ``offset`` inside the kernel (the step counter of a captured training step)."""
+    to the Philox ``offset`` inside the kernel (the step counter of a captured training step).  ``ndc``: centre / ray in normalised
+    device coordinates (camera.py:325-342; the bounds still come from the metric rays, as in the reference); ``depth_param``
+    'inverse': depth = 1 / (sample + 1e-8) (model/nerf_adapt_st_gan.py:699)."""
     lib = _lib.load()
     intr, pose = _f32(intr, "intr"), _f32(pose, "pose")
     B = pose.shape[0]
@@ -145,6 +148,7 @@ def raygen(intr: Tensor, pose: Tensor, *, H: int, W: int, n_samples: int = 0, co
         jitter = JITTER_GIVEN
         a.rand = rand.data_ptr()
     a.jitter_mode, a.seed, a.offset = jitter, seed, offset
+    a.ndc, a.depth_param = int(bool(ndc)), DEPTH_PARAMS[depth_param]
     if offset_dev is not None:
         if offset_dev.dtype != torch.int64 or offset_dev.numel() != 1 or offset_dev.device != dev:
             raise ValueError("raygen: offset_dev must be one int64 word on the device of the inputs")
@@ -173,14 +177,14 @@ def aabb_intersect(aabb_min, aabb_max, o: Tensor, d: Tensor):
 
 @_on_tensor_device
 def sample_depth(near: Tensor, far: Tensor, n_samples: int, rand: Optional[Tensor] = None, jitter: int = JITTER_MID,
-                 seed: int = 0, offset: int = 0) -> Tensor:
+                 seed: int = 0, offset: int = 0, depth_param: str = "metric") -> Tensor:
     lib = _lib.load()
     near, far = _f32(near, "near"), _f32(far, "far")
     if rand is not None:
         rand, jitter = _f32(rand, "rand"), JITTER_GIVEN
     depth = torch.empty(*near.shape, n_samples, device=near.device)
     check(lib.tp_sample_depth(near.data_ptr(), far.data_ptr(), _ptr(rand), jitter, seed, offset, near.numel(),
-                              n_samples, depth.data_ptr(), _stream()), "tp_sample_depth")
+                              n_samples, DEPTH_PARAMS[depth_param], depth.data_ptr(), _stream()), "tp_sample_depth")
     return depth
 
 
@@ -960,7 +964,8 @@ def rmsprop_step(params, grads, square_avgs, lr, alpha: float = 0.99, eps: float
 @_on_tensor_device
 def render_eval(packed: Tensor, intr: Tensor, pose: Tensor, ray_idx: Tensor, z_near: Tensor, z_far: Tensor, lat_trans: Tensor,
                 lat_light: Tensor, *, H: int, W: int, n_samples: int, precision: str = "f16x3", min_uncert: float = 0.05,
-                rand: Optional[Tensor] = None, with_alphas: bool = False, ray_bias: bool = False):
+                rand: Optional[Tensor] = None, with_alphas: bool = False, ray_bias: bool = False, ndc: bool = False,
+                depth_param: str = "metric"):
     """The C ABI's one-call evaluation render (tp_render_eval: ray-gen + MLP + composite, intermediates in one workspace).
     ``ray_bias``: ``packed`` is the ray-bias stream (pack_weights(..., ray_bias=True); f16x3, n_samples % 128 == 0).
     Returns out_ray [B,R,14] (COMPOSITE_RAY_FIELDS) and, if asked, (alpha_static, alpha_transient) [B,R,N].  The Python
@@ -977,6 +982,7 @@ def render_eval(packed: Tensor, intr: Tensor, pose: Tensor, ray_idx: Tensor, z_n
     rg.intr, rg.pose, rg.ray_idx, rg.z_near, rg.z_far = intr.data_ptr(), pose.data_ptr(), ray_idx.data_ptr(), z_near.data_ptr(), z_far.data_ptr()
     rg.B, rg.R, rg.H, rg.W, rg.N = B, R, H, W, n_samples
     rg.pixel_mode, rg.bounds_mode = PIX_INDEX, BOUNDS_MAP
+    rg.ndc, rg.depth_param = int(bool(ndc)), DEPTH_PARAMS[depth_param]
     if rand is not None:
         rand = _f32(rand, "rand")
         rg.rand, rg.jitter_mode = rand.data_ptr(), JITTER_GIVEN
