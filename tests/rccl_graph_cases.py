@@ -72,9 +72,12 @@ def run_linear(mode):
         # discriminator stream when the results are deferred -- and the call that sees it raises
         tr._bad[1] = 1
         raised = None
-        for extra in range(4):
+        for extra in range(5):
             try:
-                tr.train_iteration(AttrDict(dict(batches[extra % 2])))
+                if extra < 4:
+                    tr.train_iteration(AttrDict(dict(batches[extra % 2])))
+                else:
+                    tr.finish()             # (the host may be iterations ahead of the copies it polls: the blocking read at the end)
             except FloatingPointError:
                 raised = extra
                 break
