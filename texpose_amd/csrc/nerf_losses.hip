@@ -104,6 +104,7 @@ __global__ __launch_bounds__(kBlock) void nerf_losses_fwd_kernel(tp_nerf_losses_
 // tp_nerf_losses_bwd_total: the generator step's loss total + step gate (csrc/train_misc.hip weighted_sum_flags_kernel, same arithmetic
 // and order of side effects) as a side job of this launch's first thread -- the total is not an input of any gradient, only of the gate
 // the optimiser launch reads, so it needs no launch of its own on the render's backward chain
+constexpr int kMaxBadWords = 8;
 struct TotalJob {
   const float* t[16]; float w[16]; int n;
   float* out; const int* status; int* bad; int* snapshot; unsigned long long* step_counter;
@@ -115,13 +116,29 @@ __global__ __launch_bounds__(kBlock) void nerf_losses_bwd_kernel(tp_nerf_losses_
                                                                  const float* g_unc, const float* g_trans,
                                                                  float* g_rgb, float* g_uncert, float* g_density, TotalJob job) {
   if (job.n > 0 && blockIdx.x == 0 && threadIdx.x == 0) {
-    if (job.step_counter != nullptr) job.step_counter[0] += 1;
+    // every load of the job issued before the first use (the terms, the status word, the gate words, the counter: up to 26 independent
+    // loads in flight instead of a chain of ~20 round trips -- this thread's job IS the launch's duration at the B=4 training size)
+    float tv[16];
+    int bw[kMaxBadWords];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) tv[k] = k < job.n ? job.t[k][0] : 0.f;
+#pragma unroll
+    for (int k = 0; k < kMaxBadWords; ++k) bw[k] = k < job.n_bad ? job.bad[k] : 0;
+    const int st = job.status != nullptr ? job.status[0] : 0;
+    const unsigned long long cnt = job.step_counter != nullptr ? job.step_counter[0] : 0ull;
     float acc = 0.f;
-    for (int k = 0; k < job.n; ++k) acc += job.t[k][0] * job.w[k];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) if (k < job.n) acc += tv[k] * job.w[k];
     job.out[0] = acc;
-    if (job.status != nullptr && (job.status[0] & 1)) job.bad[job.word_status] |= 1;
-    if (!(acc - acc == 0.f)) job.bad[job.word_finite] |= 1;
-    for (int k = 0; k < job.n_bad; ++k) job.snapshot[k] = job.bad[k];
+    if (job.step_counter != nullptr) job.step_counter[0] = cnt + 1;
+    const bool ranged = (st & 1) != 0, nonfinite = !(acc - acc == 0.f);
+#pragma unroll
+    for (int k = 0; k < kMaxBadWords; ++k) {
+      if (k >= job.n_bad) break;
+      const int v = bw[k] | ((ranged && k == job.word_status) || (nonfinite && k == job.word_finite) ? 1 : 0);
+      if (v != bw[k]) job.bad[k] = v;
+      job.snapshot[k] = v;
+    }
   }
   const int64_t n_pix = (int64_t)a.B * a.P, n_den = n_pix * a.N;
   const float inv_den = (float)(1.0 / (sums[1] + 1e-5));
@@ -182,6 +199,7 @@ extern "C" int tp_nerf_losses_bwd_total(const tp_nerf_losses_args* a, const floa
   if (int rc = check(a, "tp_nerf_losses_bwd_total")) return rc;
   if (!g_rgb || !g_uncert || !g_density) { tp::set_error("tp_nerf_losses_bwd_total: null gradient pointer"); return -1; }
   TP_REQUIRE(terms && weights && out && n > 0 && n <= 16, "1..16 terms expected");
+  TP_REQUIRE(n_bad <= kMaxBadWords, "at most 8 gate words");
   TP_REQUIRE(bad && snapshot && n_bad > 0 && word_finite >= 0 && word_finite < n_bad && (!mlp_status || (word_status >= 0 && word_status < n_bad)),
              "bad gate arguments");
   TotalJob job{};

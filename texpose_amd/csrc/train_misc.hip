@@ -206,8 +206,13 @@ struct AdamTable {
 __global__ __launch_bounds__(kBlock) void adam_kernel(AdamTable t, const float* lr_dev, double lr_host, double log_beta1, double log_beta2, float b2,
                                                       float eps, float w1, float w2, int64_t total, const int* gate, int n_gate, unsigned int* ticket) {
   __shared__ bool last;
-  for (int k = 0; k < n_gate; ++k)
-    if (gate[k] != 0) return;
+  {
+    // the gate words in ONE round trip (lane k of every wavefront loads word k; a scalar loop with an early exit was a dependent
+    // load per word in front of everything else)
+    const int lane = threadIdx.x & 63;
+    const int word = lane < n_gate ? gate[lane] : 0;
+    if (__builtin_amdgcn_ballot_w64(word != 0) != 0ull) return;
+  }
   const double lr = lr_dev != nullptr ? (double)*lr_dev : lr_host;
   // the bias corrections are per tensor: thread k of every workgroup forms tensor k's once (beta^step as exp(step ln beta) in double, ln
   // beta from the host: a generic double pow() is ~6x the instructions of exp()), everybody reads them from LDS
@@ -602,6 +607,7 @@ int tp_adam_step(const tp_adam_tensor* tensors, int n, const float* lr_dev, doub
   TP_REQUIRE(tensors != nullptr && n > 0 && n <= TP_ADAM_MAX_TENSORS, "bad tensor table");
   TP_REQUIRE(ticket != nullptr, "ticket (a zero-filled device word owned by the calling stream) is required");
   TP_REQUIRE(n_gate == 0 || gate != nullptr, "gate words missing");
+  TP_REQUIRE(n_gate >= 0 && n_gate <= 64, "at most 64 gate words");
   AdamTable t;
   int64_t total = 0;
   for (int k = 0; k < n; ++k) {
