@@ -26,7 +26,7 @@ extern "C" {
 
 typedef void* tp_stream_t; /* hipStream_t */
 
-#define TP_ABI_VERSION 12
+#define TP_ABI_VERSION 13
 
 int tp_abi_version(void);
 const char* tp_last_error(void);
@@ -89,6 +89,31 @@ typedef struct tp_raygen_args {
 } tp_raygen_args;
 
 int tp_raygen(const tp_raygen_args* args /* host struct */, tp_stream_t stream);
+
+/* The ray generation of a TRAINING step with the two small launches in front of it folded in (a captured iteration is a chain of
+ * dependent launches: each one fewer is ~5 us of it).  `sampler` (or NULL): the launch draws the patch coordinates itself -- the
+ * arguments of tp_patch_coords (K13; tools/patch_sampler.py:64-114), ray q = element q of the B x p x p grid, R == p * p,
+ * args->pixel_mode TP_PIX_COORDS, args->coords ignored -- and writes them to sampler->coords / ->scales for the later consumers.
+ * `rows` (or NULL): extra workgroups gather the per-image latent rows (the arguments of tp_latent_rows_fwd).  Same values as the
+ * separate launches, bit for bit. */
+typedef struct tp_patch_sampler_job {
+  const float* u;          /* [3,B] uniforms, or NULL: drawn in the kernel from (seed, *counter) */
+  int p;
+  const float* lattice;    /* [p] linspace(-1, 1, p) */
+  const float* lo_dev;     /* device word, or NULL: lo_host */
+  float lo_host, span_host, hi;
+  int random_scale, random_shift;
+  uint64_t seed;
+  const uint64_t* counter;
+  float* coords;           /* [B,p,p,2] out */
+  float* scales;           /* [B] out */
+} tp_patch_sampler_job;
+typedef struct tp_latent_rows_job {
+  const float* w_trans; const float* w_light; const int64_t* idx;
+  int B, C_trans, C_light;
+  float* out_trans; float* out_light; int64_t* idx_copy /* or NULL */;
+} tp_latent_rows_job;
+int tp_raygen_train(const tp_raygen_args* args, const tp_patch_sampler_job* sampler, const tp_latent_rows_job* rows, tp_stream_t stream);
 
 /* Standalone slab test (camera.py:415-433): o,d [n,3] -> t_near,t_far [n], valid [n] (uint8). */
 int tp_aabb(const float* aabb_min3 /*host*/, const float* aabb_max3 /*host*/, const float* o, const float* d,

@@ -35,6 +35,8 @@ def test_struct_sizes_match_header():
     # the ctypes mirrors must have the C layout (8-byte pointers, natural alignment)
     assert C.sizeof(_lib.RaygenArgs) == 7 * 8 + 6 * 4 + 2 * 4 + 8 + 2 * 8 + 8 + 10 * 4 + 5 * 8          # (+ ndc, depth_param)
     assert C.sizeof(_lib.CompositeArgs) == 5 * 8 + 8 + 4 + 4 + 6 * 8
+    assert C.sizeof(_lib.PatchSamplerJob) == 8 + 8 + 8 + 8 + 3 * 4 + 2 * 4 + 4 + 8 + 8 + 8 + 8          # (p and the tail of the float / int run are padded to 8)
+    assert C.sizeof(_lib.LatentRowsJob) == 3 * 8 + 3 * 4 + 4 + 3 * 8
     assert C.sizeof(_lib.CompositeBwdArgs) == C.sizeof(_lib.CompositeArgs) + 12 * 8
     assert C.sizeof(_lib.MlpFwdArgs) == 8 * 8 + 3 * 4 + 4 + 5 * 8 + 4 + 4 + 8 + 8 + 8 + 8   # (+ ray_bias, density_noise)
     assert C.sizeof(_lib.MlpWeights) == 32 * 8

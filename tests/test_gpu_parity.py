@@ -1384,7 +1384,14 @@ def test_nerf_step_matches_reference_g13c(ops, form, precision, monkeypatch):
         monkeypatch.setenv("TP_NO_GEN_SCHEDULE", "1")
         knobs.reload()
     center, ray, depth = cu(G["in.center"]).contiguous(), cu(G["in.ray"]).contiguous(), cu(G["in.depth"])[..., 0].contiguous()
-    monkeypatch.setattr(ops_mod, "raygen", lambda intr, pose, **kw: (center, ray, None, None, depth))
+    real_raygen = ops_mod.raygen
+
+    def stored_rays(intr, pose, **kw):
+        if kw.get("rows") is not None:                # the latent rows ride in the training step's ray-generation launch: run that part
+            real_raygen(intr, pose, H=kw["H"], W=kw["W"], coords=kw["coords"], rows=kw["rows"])
+        assert kw.get("sampler") is None              # (the stored coordinates: `get_ray_idx` is replaced below)
+        return center, ray, None, None, depth
+    monkeypatch.setattr(ops_mod, "raygen", stored_rays)
     keep = cu(G["keep_ray"])
     assert 0 < float(keep.sum()) < keep.numel()
     names = [f"{m}.{li}.{kind}" for m in ("mlp_rgb", "mlp_trans") for li in range(4) for kind in ("weight", "bias")]
@@ -3574,3 +3581,95 @@ def test_ndc_and_inverse_depth_g20(ops):
             errs["light"] = rel_l2(graph.latent_vars_light.weight.grad, g["c.ndc.g.latent_vars_light"])
             errs["trans"] = rel_l2(graph.latent_vars_trans.weight.grad, g["c.ndc.g.latent_vars_trans"])
             assert len(errs) == 18 and max(errs.values()) < 5e-3, errs
+
+
+@pytest.mark.gpu
+def test_raygen_train_carries_sampler_and_latent_rows(ops):
+    """tp_raygen_train: the ray-generation launch of a training step draws the patch coordinates itself (the arithmetic of
+    tp_patch_coords, tools/patch_sampler.py:64-114) and gathers the per-image latent rows in extra workgroups (tp_latent_rows_fwd,
+    model/nerf_adapt_st_gan.py:589-593): every output bit-identical to the three separate launches -- given uniforms and in-kernel
+    Philox draw, device-side and host-side scale bound, with NDC / inverse depths on."""
+    rs = np.random.RandomState(5)
+    B, p, H, W, N, n_rows = 3, 8, 64, 64, 16, 11
+    g1 = load_golden("g1_rays_train")
+    intr, pose = cu(g1["intr"])[:B].contiguous(), cu(g1["pose"])[:B].contiguous()
+    zn = cu(torch.from_numpy(rs.uniform(5, 7, size=(B, H * W)).astype(np.float32)))
+    zf = zn + 1.0
+    wt, wl = cu(torch.from_numpy(rs.normal(size=(n_rows, 16)).astype(np.float32))), cu(torch.from_numpy(rs.normal(size=(n_rows, 48)).astype(np.float32)))
+    idx = cu(torch.tensor([7, 0, 7]))
+    counter = torch.tensor([41], dtype=torch.int64, device=dev())
+    lo_dev = torch.tensor(0.31, device=dev())
+    for case in (dict(u=cu(torch.rand(3, B, 1, 1, 1, generator=torch.Generator().manual_seed(3))), lo=0.25),
+                 dict(u=None, lo=lo_dev, counter=counter, nbatch=B, seed=1234),
+                 dict(u=None, lo=0.4, counter=counter, nbatch=B, seed=99, random_shift=False, ndc=True, depth_param="inverse")):
+        extra = {k: case[k] for k in ("ndc", "depth_param") if k in case}
+        kw = {k: v for k, v in case.items() if k not in ("u", "lo", "ndc", "depth_param")}
+        coords, scales = ops.patch_coords(case["u"], p, case["lo"], 1.0, **kw)
+        ref = ops.raygen(intr, pose, H=H, W=W, n_samples=N, coords=coords, z_near=zn, z_far=zf, jitter=ops.JITTER_PHILOX, seed=5, offset=2, **extra)
+        own = torch.empty_like(idx)
+        rt, rl = ops.latent_rows_fwd(wt, wl, idx, idx_copy=own)
+        coords2, scales2 = ops.patch_coords(case["u"], p, case["lo"], 1.0, defer=True, **kw)
+        job = coords2.__dict__.pop("_tp_sampler_job")
+        own2 = torch.zeros_like(idx)
+        rt2, rl2, rows = ops.latent_rows_fwd(wt, wl, idx, idx_copy=own2, defer=True)
+        for t in (coords2, scales2, rt2, rl2):
+            t.fill_(float("nan"))
+        got = ops.raygen(intr, pose, H=H, W=W, n_samples=N, coords=coords2, z_near=zn, z_far=zf, jitter=ops.JITTER_PHILOX, seed=5, offset=2,
+                         sampler=job, rows=rows, **extra)
+        assert torch.equal(coords, coords2) and torch.equal(scales, scales2)
+        assert all(torch.equal(a, b) for a, b in zip(ref, got))
+        assert torch.equal(rt, rt2) and torch.equal(rl, rl2) and torch.equal(own, own2) and torch.equal(own2, idx)
+    # each job alone; a sampler job needs its own coords tensor as the pixel source
+    coords2, scales2 = ops.patch_coords(None, p, 0.25, 1.0, defer=True, nbatch=B, seed=1, counter=counter)
+    job = coords2.__dict__.pop("_tp_sampler_job")
+    with pytest.raises(ValueError):
+        ops.raygen(intr, pose, H=H, W=W, coords=torch.zeros_like(coords2), sampler=job)
+    only = ops.raygen(intr, pose, H=H, W=W, coords=coords2, sampler=job)
+    c3, s3 = ops.patch_coords(None, p, 0.25, 1.0, nbatch=B, seed=1, counter=counter)
+    assert torch.equal(coords2, c3) and torch.equal(scales2, s3) and torch.equal(only[0], ops.raygen(intr, pose, H=H, W=W, coords=c3)[0])
+    rt2, rl2, rows = ops.latent_rows_fwd(wt, wl, idx, defer=True)
+    ops.raygen(intr, pose, H=H, W=W, coords=c3, rows=rows)
+    assert torch.equal(rt2, wt[idx]) and torch.equal(rl2, wl[idx])
+
+
+@pytest.mark.gpu
+def test_fused_prologue_of_captured_step_is_bit_identical(ops, monkeypatch):
+    """The captured training step draws its patch coordinates and gathers its latent rows inside the ray-generation launch
+    (Graph.fuse_prologue, tp_raygen_train); TP_NO_FUSED_PROLOGUE=1 keeps the three launches.  Six iterations leave parameters, buffers,
+    losses and the latent tables' optimiser state bit-identical; the render graph is two launches shorter."""
+    from texpose_amd import knobs
+    from texpose_amd.gan_modules import Discriminator, PerceptualLoss
+    from texpose_amd.graph import Graph
+    from texpose_amd.options import default_options, AttrDict
+    from texpose_amd.synthetic import training_batch
+    from texpose_amd.trainer import GraphedGanTrainer
+    out = []
+    try:
+        for fused in (True, False):
+            if fused:
+                monkeypatch.delenv("TP_NO_FUSED_PROLOGUE", raising=False)
+            else:
+                monkeypatch.setenv("TP_NO_FUSED_PROLOGUE", "1")
+            knobs.reload()
+            torch.manual_seed(0)
+            opt = default_options(H=128, W=128, device="cuda:0")
+            opt.batch_size, opt.patch_size, opt.nerf.sample_intvs = 4, 16, 64
+            graph = Graph(opt, discriminator=Discriminator(opt), perceptual_loss=PerceptualLoss()).to(dev())
+            tr = GraphedGanTrainer(opt, graph, n_train=189)
+            batches = [training_batch(4, 128, 128, seed=s_, device="cuda:0") for s_ in range(2)]
+            for it in range(6):
+                _, loss = tr.train_iteration(AttrDict(dict(batches[it % 2])))
+            tr.finish()
+            torch.cuda.synchronize()
+            assert tr._linear and not getattr(graph, "fuse_prologue", False)
+            out.append(({k: v.clone() for k, v in graph.state_dict().items()}, {k: v.clone() for k, v in loss.items() if torch.is_tensor(v)},
+                        [t.clone() for st in tr.optim_nerf.state.values() for t in st.values() if torch.is_tensor(t)], tr.launch_counts["G1"]))
+    finally:
+        monkeypatch.delenv("TP_NO_FUSED_PROLOGUE", raising=False)
+        knobs.reload()
+    for k in out[0][0]:
+        assert torch.equal(out[0][0][k], out[1][0][k]), k
+    for k in out[0][1]:
+        assert torch.equal(out[0][1][k], out[1][1][k]), k
+    assert len(out[0][2]) == len(out[1][2]) > 0 and all(torch.equal(a, b) for a, b in zip(out[0][2], out[1][2]))
+    assert out[0][3] == out[1][3] - 2, (out[0][3], out[1][3])

@@ -12,12 +12,12 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # TEXPOSE_AMD_LIB selects another build of the SAME library (e.g. the `make trace` diagnostic build); never a fallback
 LIB_PATH = os.environ.get("TEXPOSE_AMD_LIB") or os.path.join(_HERE, "libtexpose_amd.so")
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 # Every symbol include/texpose_amd.h declares (checked by tests/test_capi_cpu.py).
 SYMBOLS = (
     "tp_abi_version", "tp_last_error",
-    "tp_raygen", "tp_aabb", "tp_sample_depth",
+    "tp_raygen", "tp_raygen_train", "tp_aabb", "tp_sample_depth",
     "tp_mlp_packed_bytes", "tp_mlp_pack", "tp_mlp_pack_heads_f16x3", "tp_mlp_pack_host", "tp_mlp_workspace_bytes", "tp_mlp_fwd", "tp_posenc",
     "tp_mlp_saved_bytes", "tp_mlp_ray_bias_bytes", "tp_mlp_packed_t_bytes", "tp_mlp_bwd_workspace_bytes", "tp_mlp_bwd",
     "tp_composite_fwd", "tp_composite_bwd",
@@ -50,6 +50,16 @@ class RaygenArgs(C.Structure):
                 ("B", C.c_int), ("R", C.c_int), ("H", C.c_int), ("W", C.c_int), ("N", C.c_int),
                 ("pixel_mode", C.c_int), ("bounds_mode", C.c_int), ("jitter_mode", C.c_int), ("ndc", C.c_int), ("depth_param", C.c_int),
                 ("center", vp), ("ray", vp), ("near", vp), ("far", vp), ("depth", vp)]
+
+
+class PatchSamplerJob(C.Structure):
+    _fields_ = [("u", vp), ("p", C.c_int), ("lattice", vp), ("lo_dev", vp), ("lo_host", C.c_float), ("span_host", C.c_float), ("hi", C.c_float),
+                ("random_scale", C.c_int), ("random_shift", C.c_int), ("seed", C.c_uint64), ("counter", vp), ("coords", vp), ("scales", vp)]
+
+
+class LatentRowsJob(C.Structure):
+    _fields_ = [("w_trans", vp), ("w_light", vp), ("idx", vp), ("B", C.c_int), ("C_trans", C.c_int), ("C_light", C.c_int),
+                ("out_trans", vp), ("out_light", vp), ("idx_copy", vp)]
 
 
 class MlpWeights(C.Structure):
@@ -223,6 +233,7 @@ def load() -> C.CDLL:
         fn.restype = restype
 
     sig("tp_raygen", [C.POINTER(RaygenArgs), vp])
+    sig("tp_raygen_train", [C.POINTER(RaygenArgs), C.POINTER(PatchSamplerJob), C.POINTER(LatentRowsJob), vp])
     sig("tp_aabb", [C.POINTER(C.c_float), C.POINTER(C.c_float), vp, vp, C.c_int64, vp, vp, vp, vp])
     sig("tp_sample_depth", [vp, vp, vp, C.c_int, C.c_uint64, C.c_uint64, C.c_int64, C.c_int, C.c_int, vp, vp])
     sig("tp_composite_fwd", [C.POINTER(CompositeArgs), vp])

@@ -590,7 +590,7 @@ class _LatentRows(torch.autograd.Function):
     """Rows idx of the transient / light latent tables in one launch; dense table gradients in one launch (no zero fill)."""
 
     @staticmethod
-    def forward(ctx, w_trans, w_light, idx):
+    def forward(ctx, w_trans, w_light, idx, job_out=None):
         # the kernels read int64 rows: save what the forward actually passed down (an int32 or strided idx is accepted, like
         # index_select's, and converted ONCE here -- the backward must see the same buffer)
         idx = idx.to(torch.int64).contiguous()
@@ -599,6 +599,11 @@ class _LatentRows(torch.autograd.Function):
         own = torch.empty_like(idx)
         ctx.save_for_backward(own)
         ctx.n_rows = w_trans.shape[0]
+        if job_out is not None:
+            # nothing launched here: the ray-generation launch of the training step carries the gather (ops.raygen(..., rows=job))
+            ot, ol, job = ops.latent_rows_fwd(w_trans, w_light, idx, idx_copy=own, defer=True)
+            job_out.append(job)
+            return ot, ol
         return ops.latent_rows_fwd(w_trans, w_light, idx, idx_copy=own)
 
     @staticmethod
@@ -606,8 +611,13 @@ class _LatentRows(torch.autograd.Function):
     def backward(ctx, g_trans, g_light):
         (idx,) = ctx.saved_tensors
         gwt, gwl = ops.latent_rows_bwd(g_trans.contiguous(), g_light.contiguous(), idx, ctx.n_rows)
-        return gwt, gwl, None
+        return gwt, gwl, None, None
 
 
-def latent_rows(w_trans, w_light, idx):
-    return _LatentRows.apply(w_trans, w_light, idx)
+def latent_rows(w_trans, w_light, idx, defer=False):
+    """``defer``: -> (rows_trans, rows_light, job); the tensors are filled by the ray-generation launch that is given the job."""
+    if not defer:
+        return _LatentRows.apply(w_trans, w_light, idx)
+    job = []
+    ot, ol = _LatentRows.apply(w_trans, w_light, idx, job)
+    return ot, ol, job[0]

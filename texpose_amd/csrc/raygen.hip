@@ -15,6 +15,7 @@
 // workgroup write the 256*N depth samples of the tile as contiguous 16-byte stores, with the
 // per-ray (near, far-near) pair staged in LDS.
 #include "tp_common.h"
+#include "step_prologue.h"
 
 namespace {
 
@@ -130,6 +131,10 @@ struct Args {
   const uint64_t* offset_dev;
   int B, R, H, W, N, pixel_mode, bounds_mode, jitter_mode, ndc, inverse;
   float* center; float* ray; float* near; float* far; float* depth;
+  // tp_raygen_train: the launch draws its own patch coordinates (sampler_on) and carries the latent rows as extra workgroups behind the
+  // ray_blocks of the ray generation (rows.B > 0)
+  tp_prologue::Sampler sampler; tp_prologue::Rows rows;
+  int sampler_on, ray_blocks;
 };
 
 __device__ __forceinline__ void slab(const float* amin, const float* amax, const float* o, const float* d,
@@ -156,6 +161,10 @@ template <int TILE, bool POW2>
 __global__ __launch_bounds__(kTile) void raygen_kernel(Args a) {
   __shared__ float s_near[TILE];
   __shared__ float s_span[TILE];
+  if ((int)blockIdx.x >= a.ray_blocks) {                      // (uniform per workgroup: the latent rows of a training launch)
+    tp_prologue::latent_row_element(a.rows, ((int)blockIdx.x - a.ray_blocks) * kTile + (int)threadIdx.x);
+    return;
+  }
   const int64_t total = (int64_t)a.B * a.R;
   const int64_t tile0 = (int64_t)blockIdx.x * TILE;
   const int64_t q = tile0 + threadIdx.x;
@@ -168,7 +177,9 @@ __global__ __launch_bounds__(kTile) void raygen_kernel(Args a) {
     Bilin bl;
     int64_t pix = 0;
     if (a.pixel_mode == TP_PIX_COORDS) {
-      const float x = a.coords[2 * q], y = a.coords[2 * q + 1];
+      float x, y;
+      if (a.sampler_on) tp_prologue::patch_coord(a.sampler, (int)q, x, y);          // (ray q IS element q of the B x p x p grid)
+      else { x = a.coords[2 * q]; y = a.coords[2 * q + 1]; }
       bl = bilin_setup(x, y, a.H, a.W);
       u = bilin_apply(bl, (float)bl.x0, (float)(bl.x0 + 1), (float)bl.x0, (float)(bl.x0 + 1));
       v = bilin_apply(bl, (float)bl.y0, (float)bl.y0, (float)(bl.y0 + 1), (float)(bl.y0 + 1));
@@ -323,11 +334,17 @@ __global__ void sample_depth_kernel(const float* __restrict__ near, const float*
 
 }  // namespace
 
-extern "C" int tp_raygen(const tp_raygen_args* p, tp_stream_t stream) {
+extern "C" int tp_raygen(const tp_raygen_args* p, tp_stream_t stream) { return tp_raygen_train(p, nullptr, nullptr, stream); }
+
+extern "C" int tp_raygen_train(const tp_raygen_args* p, const tp_patch_sampler_job* sj, const tp_latent_rows_job* rj, tp_stream_t stream) {
   TP_REQUIRE(p != nullptr, "null args");
   TP_REQUIRE(p->B > 0 && p->R > 0 && p->H > 0 && p->W > 0, "bad sizes");
   TP_REQUIRE(p->intr && p->pose && p->center && p->ray, "null camera / output pointer");
-  TP_REQUIRE(p->pixel_mode == TP_PIX_COORDS ? p->coords != nullptr : p->ray_idx != nullptr, "missing pixel source");
+  TP_REQUIRE(sj == nullptr || (p->pixel_mode == TP_PIX_COORDS && sj->lattice && sj->coords && sj->scales && sj->p > 0 && sj->p * sj->p == p->R),
+             "sampler job: TP_PIX_COORDS, R == p * p, lattice / coords / scales expected");
+  TP_REQUIRE(rj == nullptr || (rj->w_trans && rj->w_light && rj->idx && rj->out_trans && rj->out_light && rj->B > 0 && rj->C_trans > 0 && rj->C_light > 0),
+             "latent-rows job: bad arguments");
+  TP_REQUIRE(p->pixel_mode == TP_PIX_COORDS ? (p->coords != nullptr || sj != nullptr) : p->ray_idx != nullptr, "missing pixel source");
   TP_REQUIRE(p->bounds_mode != TP_BOUNDS_MAP || (p->z_near && p->z_far), "missing z_near/z_far maps");
   TP_REQUIRE(p->jitter_mode != TP_JITTER_GIVEN || p->depth == nullptr || p->rand != nullptr, "missing rand tensor");
   Args a;
@@ -342,7 +359,22 @@ extern "C" int tp_raygen(const tp_raygen_args* p, tp_stream_t stream) {
   a.center = p->center; a.ray = p->ray; a.near = p->near; a.far = p->far; a.depth = p->depth;
   const int64_t total = (int64_t)p->B * p->R;
   const int tile = total <= 16384 ? 32 : kTile;
-  const int64_t blocks = (total + tile - 1) / tile;
+  const int64_t ray_blocks = (total + tile - 1) / tile;
+  a.sampler = tp_prologue::Sampler{}; a.rows = tp_prologue::Rows{}; a.sampler_on = 0; a.ray_blocks = (int)ray_blocks;
+  int64_t blocks = ray_blocks;
+  if (sj != nullptr) {
+    tp_prologue::Sampler& q = a.sampler;
+    q.u = sj->u; q.lattice = sj->lattice; q.lo_dev = sj->lo_dev; q.counter = sj->counter; q.coords = sj->coords; q.scales = sj->scales;
+    q.seed = sj->seed; q.lo_host = sj->lo_host; q.span_host = sj->span_host; q.hi = sj->hi; q.B = p->B; q.p = sj->p;
+    q.random_scale = sj->random_scale; q.random_shift = sj->random_shift;
+    a.sampler_on = 1;
+  }
+  if (rj != nullptr) {
+    tp_prologue::Rows& q = a.rows;
+    q.wt = rj->w_trans; q.wl = rj->w_light; q.idx = rj->idx; q.ot = rj->out_trans; q.ol = rj->out_light; q.idx_copy = rj->idx_copy;
+    q.B = rj->B; q.Ct = rj->C_trans; q.Cl = rj->C_light;
+    blocks += ((int64_t)rj->B * (rj->C_trans + rj->C_light) + kTile - 1) / kTile;
+  }
   TP_REQUIRE(blocks < (1ll << 31), "too many rays for one launch");
   const bool pow2 = p->N > 0 && (p->N & (p->N - 1)) == 0;          // (x / 2^k == x * 2^-k exactly: no IEEE division in the depth loop)
   const dim3 grid((unsigned)blocks), block(kTile);

@@ -11,6 +11,7 @@
 //   tp_adam_step         optim_nerf.step() (model/nerf_adapt_st_gan.py:62-68,125: torch.optim.Adam) for every tensor at once, gated
 //   tp_disc_inputs       the real / fake patch stacks of the discriminator step (model/nerf_adapt_st_gan.py:478-497): 10 launches
 #include "tp_common.h"
+#include "step_prologue.h"
 #include <stdlib.h>
 
 namespace {
@@ -35,33 +36,12 @@ __device__ __forceinline__ float block_total(float v, float* red) {
 // ---- patch coordinates: s = u0 * (hi - lo) + lo;  x = lattice_j * s + (u1 * 2 - 1) * (1 - s);  y likewise with u2
 // u == NULL: the three uniforms of image b are drawn here, Philox4x32-10 with key = seed and counter (b, c_lo, 'patc', c_hi),
 // c = *counter (the step counter of a captured training step) -- words x, y, z -> scale, x shift, y shift.
-__global__ __launch_bounds__(kBlock) void patch_coords_kernel(const float* __restrict__ u, int B, int p, const float* __restrict__ lattice,
-                                                              const float* lo_dev, float lo_host, float span_host, float hi,
-                                                              int random_scale, int random_shift, uint64_t seed, const uint64_t* counter,
-                                                              float* __restrict__ coords, float* __restrict__ scales) {
+// (the arithmetic: step_prologue.h, shared with the ray-generation launch of a captured training step)
+__global__ __launch_bounds__(kBlock) void patch_coords_kernel(tp_prologue::Sampler q) {
   const int e = blockIdx.x * kBlock + threadIdx.x;
-  if (e >= B * p * p) return;
-  const int b = e / (p * p), r = e - b * p * p, i = r / p, j = r - i * p;
-  const float lo = lo_dev ? *lo_dev : lo_host;
-  const float span = lo_dev ? tp::sub_rn(hi, lo) : span_host;      // (a device-side bound is subtracted in fp32, like torch)
-  float u0, u1, u2;
-  if (u != nullptr) { u0 = u[b]; u1 = u[B + b]; u2 = u[2 * B + b]; }
-  else {
-    const uint64_t c = counter ? *counter : 0;
-    const uint4 w = tp::philox4x32_10(make_uint4((uint32_t)b, (uint32_t)c, 0x70617463u, (uint32_t)(c >> 32)),
-                                      make_uint2((uint32_t)seed, (uint32_t)(seed >> 32)));
-    u0 = tp::u01(w.x); u1 = tp::u01(w.y); u2 = tp::u01(w.z);
-  }
-  const float s = random_scale ? tp::add_rn(tp::mul_rn(u0, span), lo) : tp::add_rn(0.f, lo);
-  float x = tp::mul_rn(lattice[j], s), y = tp::mul_rn(lattice[i], s);
-  if (random_shift) {
-    const float room = tp::sub_rn(1.f, s);
-    x = tp::add_rn(x, tp::mul_rn(tp::sub_rn(tp::mul_rn(u1, 2.0f), 1.0f), room));
-    y = tp::add_rn(y, tp::mul_rn(tp::sub_rn(tp::mul_rn(u2, 2.0f), 1.0f), room));
-  }
-  coords[2 * (size_t)e] = x;
-  coords[2 * (size_t)e + 1] = y;
-  if (r == 0) scales[b] = s;
+  if (e >= q.B * q.p * q.p) return;
+  float x, y;
+  tp_prologue::patch_coord(q, e, x, y);
 }
 
 // ---- mean_i [ (1 - t) x_i - log_sigmoid(x_i) ]  (torch's formula), one workgroup, fixed-order tree
@@ -475,16 +455,8 @@ __global__ void weighted_sum_flags_kernel(TermTable tb, float* __restrict__ out,
 // ---- per-image latent rows (model/nerf_adapt_st_gan.py:589-593: Embedding.weight[var.idx]) of BOTH tables in one launch,
 // and their gradient: dense [n_rows, C] tables with g[r] = sum over the images b with idx[b] == r, in ascending b (no
 // atomics, no zero-fill launch; torch: index_select x 2 forward, zeros + index_add_ x 2 backward)
-__global__ __launch_bounds__(kBlock) void latent_rows_fwd_kernel(const float* __restrict__ wt, const float* __restrict__ wl, const int64_t* __restrict__ idx,
-                                                                  int B, int Ct, int Cl, float* __restrict__ ot, float* __restrict__ ol,
-                                                                  int64_t* __restrict__ idx_copy) {
-  const int e = blockIdx.x * kBlock + threadIdx.x, C = Ct + Cl;
-  if (e >= B * C) return;
-  const int b = e / C, c = e - b * C;
-  const int64_t r = idx[b];
-  if (c == 0 && idx_copy != nullptr) idx_copy[b] = r;
-  if (c < Ct) ot[b * Ct + c] = wt[r * Ct + c];
-  else ol[b * Cl + (c - Ct)] = wl[r * Cl + (c - Ct)];
+__global__ __launch_bounds__(kBlock) void latent_rows_fwd_kernel(tp_prologue::Rows q) {
+  tp_prologue::latent_row_element(q, blockIdx.x * kBlock + threadIdx.x);
 }
 __global__ __launch_bounds__(kBlock) void latent_rows_bwd_kernel(const float* __restrict__ gt, const float* __restrict__ gl, const int64_t* __restrict__ idx,
                                                                   int B, int n_rows, int Ct, int Cl, float* __restrict__ gwt, float* __restrict__ gwl) {
@@ -639,8 +611,10 @@ int tp_patch_coords(const float* u, int B, int p, const float* lattice, const fl
                     tp_stream_t stream) {
   TP_REQUIRE(lattice && coords && scales && B > 0 && p > 0, "bad arguments");
   const int n = B * p * p;
-  hipLaunchKernelGGL(patch_coords_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, (hipStream_t)stream, u, B, p, lattice, lo_dev,
-                     lo_host, span_host, hi, random_scale, random_shift, seed, counter, coords, scales);
+  tp_prologue::Sampler q;
+  q.u = u; q.lattice = lattice; q.lo_dev = lo_dev; q.counter = counter; q.coords = coords; q.scales = scales; q.seed = seed;
+  q.lo_host = lo_host; q.span_host = span_host; q.hi = hi; q.B = B; q.p = p; q.random_scale = random_scale; q.random_shift = random_shift;
+  hipLaunchKernelGGL(patch_coords_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, (hipStream_t)stream, q);
   return tp::check_launch("tp_patch_coords");
 }
 
@@ -737,8 +711,9 @@ int tp_latent_rows_fwd(const float* w_trans, const float* w_light, const int64_t
                        float* out_light, int64_t* idx_copy, tp_stream_t stream) {
   TP_REQUIRE(w_trans && w_light && idx && out_trans && out_light && B > 0 && C_trans > 0 && C_light > 0, "bad arguments");
   const int n = B * (C_trans + C_light);
-  hipLaunchKernelGGL(latent_rows_fwd_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, (hipStream_t)stream, w_trans, w_light, idx, B,
-                     C_trans, C_light, out_trans, out_light, idx_copy);
+  tp_prologue::Rows q;
+  q.wt = w_trans; q.wl = w_light; q.idx = idx; q.ot = out_trans; q.ol = out_light; q.idx_copy = idx_copy; q.B = B; q.Ct = C_trans; q.Cl = C_light;
+  hipLaunchKernelGGL(latent_rows_fwd_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, (hipStream_t)stream, q);
   return tp::check_launch("tp_latent_rows_fwd");
 }
 int tp_latent_rows_bwd(const float* g_trans, const float* g_light, const int64_t* idx, int B, int n_rows, int C_trans, int C_light,

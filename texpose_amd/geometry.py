@@ -200,15 +200,16 @@ class FlexPatchSampler:
     def update_device_bound(self):
         self.device_lo.fill_(self._host_range()[0])
 
-    def __call__(self, nbatch, patch_size, device="cuda", u=None):
-        """``u`` ([3,B,1,1,1] uniforms: scale, x-shift, y-shift) replaces the internal draw in parity tests."""
+    def __call__(self, nbatch, patch_size, device="cuda", u=None, defer=False):
+        """``u`` ([3,B,1,1,1] uniforms: scale, x-shift, y-shift) replaces the internal draw in parity tests.  ``defer`` (captured training
+        step, in-kernel draw only): nothing is launched; the ray-generation launch fills the returned tensors (ops.patch_coords)."""
         lo, hi = self.scales_curr = self.scale_range()
         if u is None and self.device_counter is not None:
             # captured training step: no torch.rand launch (and no generator-state fills before every replay); the kernel draws
             # from Philox(seed, step counter) -- the counter lives on the device and is advanced once per step
             from . import ops
             return ops.patch_coords(None, patch_size, lo, hi, self.random_scale, self.random_shift, nbatch=nbatch,
-                                    seed=torch.initial_seed(), counter=self.device_counter)
+                                    seed=torch.initial_seed(), counter=self.device_counter, defer=defer)
         if u is None:
             u = torch.rand(3, nbatch, 1, 1, 1, device=device)
         if u.is_cuda:                                        # one launch (K13 tp_patch_coords), same fp32 operation order

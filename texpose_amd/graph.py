@@ -65,8 +65,10 @@ class Graph(torch.nn.Module):
     # ------------------------------------------------------------------ ray / sample selection
     def get_ray_idx(self, opt, var):
         # var.patch_u (optional, [3,B,1,1,1] uniforms) pins the scale / shift draw for parity tests
+        # (`fuse_prologue`, set by the captured training step around its render: the coordinates are drawn by the ray-generation launch)
+        defer = dict(defer=True) if getattr(self, "fuse_prologue", False) and var.get("patch_u") is None else {}
         var.ray_idx, var.ray_scales = self.patch_sampler(nbatch=opt.batch_size, patch_size=opt.patch_size,
-                                                         device=opt.device, u=var.get("patch_u"))
+                                                         device=opt.device, u=var.get("patch_u"), **defer)
         return var
 
     @staticmethod
@@ -114,12 +116,28 @@ class Graph(torch.nn.Module):
         z_near, z_far = depth_range
         batch_size = len(pose)
         src = dict(coords=ray_idx) if mode == "train" else dict(ray_idx=ray_idx)
+        rows_k13 = (mode == "train" and torch.is_tensor(sample_idx) and sample_idx.dim() == 1 and sample_idx.is_cuda
+                    and self.latent_vars_trans.weight.shape[0] == self.latent_vars_light.weight.shape[0])
+        fused = {}
+        if mode == "train" and getattr(self, "fuse_prologue", False):
+            # captured training step: the patch coordinates (a deferred sampler call, `get_ray_idx`) and the latent rows ride in the
+            # ray-generation launch (tp_raygen_train) -- one launch instead of three in front of the MLP forward
+            job = ray_idx.__dict__.pop("_tp_sampler_job", None)
+            if job is not None:
+                fused["sampler"] = job
+            if rows_k13:
+                lat_t, lat_l, fused["rows"] = autograd_ops.latent_rows(self.latent_vars_trans.weight, self.latent_vars_light.weight, sample_idx,
+                                                                       defer=True)
+        elif torch.is_tensor(ray_idx) and "_tp_sampler_job" in ray_idx.__dict__:
+            raise RuntimeError("render: ray_idx comes from a deferred sampler call but this render does not fill it (fuse_prologue is off)")
         # camera.ndc (reference :581-583) and nerf.depth.param (:699) are flags of the same launch
         center, ray, _, _, depth = ops.raygen(intr, pose, H=opt.H, W=opt.W, n_samples=N, z_near=z_near, z_far=z_far,
-                                              ndc=bool(opt.camera.ndc), depth_param=self._depth_param(opt), **src, **self._jitter(opt, rand, getattr(self, "step_counter", None) if mode == "train" else None))
+                                              ndc=bool(opt.camera.ndc), depth_param=self._depth_param(opt), **src, **fused,
+                                              **self._jitter(opt, rand, getattr(self, "step_counter", None) if mode == "train" else None))
         depth_samples = depth[..., None]                                     # [B,R,N,1]
-        if (mode == "train" and torch.is_tensor(sample_idx) and sample_idx.dim() == 1 and sample_idx.is_cuda
-                and self.latent_vars_trans.weight.shape[0] == self.latent_vars_light.weight.shape[0]):
+        if "rows" in fused:
+            pass                                                             # (lat_t / lat_l: filled by the launch above)
+        elif rows_k13:
             # K13: the rows of both tables in one launch, their dense gradients in one launch (index_select: two launches
             # forward, zeros + index_add_ per table backward; indexing's backward is a seven-launch index_put_)
             lat_t, lat_l = autograd_ops.latent_rows(self.latent_vars_trans.weight, self.latent_vars_light.weight, sample_idx)

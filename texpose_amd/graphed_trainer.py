@@ -271,6 +271,8 @@ class GraphedGanTrainer(GanTrainer):
         opt = self.opt
         counter = getattr(self, "_rng_counter", None)
         self.graph.step_counter = self.graph.patch_sampler.device_counter = counter
+        # the patch coordinates and the latent rows ride in the ray-generation launch (Graph.render, tp_raygen_train)
+        self.graph.fuse_prologue = not knobs.K.no_fused_prologue
         try:
             var = self.graph.get_ray_idx(opt, var)
             if opt.nerf.sample_stratified and "jitter_rand" not in var and counter is None:
@@ -279,6 +281,7 @@ class GraphedGanTrainer(GanTrainer):
             var, _ = self.nerf_forward_loss(var, stage="render")
         finally:
             self.graph.step_counter = self.graph.patch_sampler.device_counter = None
+            self.graph.fuse_prologue = False
         return var
 
     def _seg_disc(self, var):

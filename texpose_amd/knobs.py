@@ -30,6 +30,7 @@ _SPEC: Tuple[Tuple[str, str, object, str], ...] = (
     ("no_feat_branch", "TP_NO_FEAT_BRANCH", False, "generic form: the feature chain on the capturing stream instead of a third one (also switches the linear graphs off)"),
     ("no_sn_prefetch", "TP_NO_SN_PREFETCH", False, "spectral normalisations in front of each discriminator pass instead of three sets up front (also switches the linear graphs off)"),
     ("no_sn_split", "TP_NO_SN_SPLIT", False, "linear graphs: the three spectral normalisations as one graph instead of [first set] | [the other two]"),
+    ("no_fused_prologue", "TP_NO_FUSED_PROLOGUE", False, "linear graphs: patch coordinates and latent rows as launches of their own instead of parts of the ray-generation launch"),
     ("no_disc_split", "TP_NO_DISC_SPLIT", False, "linear graphs: the discriminator step as one graph instead of two (no `pipeline_disc_tail`)"),
     ("no_queue_probe", "TP_NO_QUEUE_PROBE", False, "the step's three streams in creation order instead of by the measured stream -> hardware-queue probe"),
     ("pipeline_disc", "TP_PIPELINE_DISC", False, "default of GraphedGanTrainer.pipeline_disc_tail"),

@@ -98,12 +98,16 @@ def raygen(intr: Tensor, pose: Tensor, *, H: int, W: int, n_samples: int = 0, co
            aabb: Optional[Tuple[Tuple[float, float, float], Tuple[float, float, float]]] = None,
            bg_range: Tuple[float, float] = (0.0, 30.0), rand: Optional[Tensor] = None,
            jitter: int = JITTER_MID, seed: int = 0, offset: int = 0, valid_rect: Optional[Tensor] = None,
-           offset_dev: Optional[Tensor] = None, ndc: bool = False, depth_param: str = "metric"):
+           offset_dev: Optional[Tensor] = None, ndc: bool = False, depth_param: str = "metric",
+           sampler: Optional[dict] = None, rows: Optional[dict] = None):
     """Fused ray-gen + bounds + stratified depths.  Returns (center, ray, near, far, depth);
     near/far/depth are None when no bounds source is given, depth is [B,R,N].  ``offset_dev`` (int64 [1] on the device): added
     to the Philox ``offset`` inside the kernel (the step counter of a captured training step).  ``ndc``: centre / ray in normalised
     device coordinates (camera.py:325-342; the bounds still come from the metric rays, as in the reference); ``depth_param``
-    'inverse': depth = 1 / (sample + 1e-8) (model/nerf_adapt_st_gan.py:699)."""
+    'inverse': depth = 1 / (sample + 1e-8) (model/nerf_adapt_st_gan.py:699).
+    Training step (tp_raygen_train): ``sampler`` (a `patch_coords(..., defer=True)` job; give its `coords` tensor as ``coords``): the launch
+    draws the patch coordinates itself and fills the job's coords / scales; ``rows`` (a `latent_rows_fwd(..., defer=True)` job): extra
+    workgroups of the launch gather the latent rows.  Same values as the separate launches."""
     lib = _lib.load()
     intr, pose = _f32(intr, "intr"), _f32(pose, "pose")
     B = pose.shape[0]
@@ -156,7 +160,28 @@ def raygen(intr: Tensor, pose: Tensor, *, H: int, W: int, n_samples: int = 0, co
     a.intr, a.pose = intr.data_ptr(), pose.data_ptr()
     a.B, a.R, a.H, a.W, a.N = B, R, H, W, n_samples
     a.center, a.ray = center.data_ptr(), ray.data_ptr()
-    check(lib.tp_raygen(C.byref(a), _stream()), "tp_raygen")
+    if sampler is None and rows is None:
+        check(lib.tp_raygen(C.byref(a), _stream()), "tp_raygen")
+        return center, ray, near, far, depth
+    sj = rj = None
+    if sampler is not None:
+        if coords is None or coords.data_ptr() != sampler["coords"].data_ptr() or sampler["B"] != B:
+            raise ValueError("raygen: a sampler job fills ITS coords tensor -- pass that tensor as coords")
+        sj = _lib.PatchSamplerJob()
+        lo = sampler["lo"]
+        sj.u, sj.p, sj.lattice = _ptr(sampler["u"]), sampler["p"], sampler["lattice"].data_ptr()
+        sj.lo_dev = lo.data_ptr() if torch.is_tensor(lo) else None
+        sj.lo_host = 0.0 if torch.is_tensor(lo) else float(lo)
+        sj.span_host, sj.hi = float(sampler["hi"]) - sj.lo_host, float(sampler["hi"])
+        sj.random_scale, sj.random_shift = int(bool(sampler["random_scale"])), int(bool(sampler["random_shift"]))
+        sj.seed, sj.counter = int(sampler["seed"]) & (2 ** 64 - 1), _ptr(sampler["counter"])
+        sj.coords, sj.scales = sampler["coords"].data_ptr(), sampler["scales"].data_ptr()
+    if rows is not None:
+        rj = _lib.LatentRowsJob()
+        rj.w_trans, rj.w_light, rj.idx = rows["w_trans"].data_ptr(), rows["w_light"].data_ptr(), rows["idx"].data_ptr()
+        rj.B, rj.C_trans, rj.C_light = rows["idx"].numel(), rows["w_trans"].shape[1], rows["w_light"].shape[1]
+        rj.out_trans, rj.out_light, rj.idx_copy = rows["out_trans"].data_ptr(), rows["out_light"].data_ptr(), _ptr(rows["idx_copy"])
+    check(lib.tp_raygen_train(C.byref(a), None if sj is None else C.byref(sj), None if rj is None else C.byref(rj), _stream()), "tp_raygen_train")
     return center, ray, near, far, depth
 
 
@@ -1170,10 +1195,12 @@ _lattices = {}
 
 @_on_tensor_device
 def patch_coords(u: Optional[Tensor], patch_size: int, lo, hi: float, random_scale: bool = True, random_shift: bool = True, *,
-                 nbatch: Optional[int] = None, seed: int = 0, counter: Optional[Tensor] = None, device=None):
+                 nbatch: Optional[int] = None, seed: int = 0, counter: Optional[Tensor] = None, device=None, defer: bool = False):
     """FlexPatchSampler in one launch: u [3,B,...] uniforms -> (coords [B,p,p,2], scales [B,1,1,1]); ``lo`` is a float or a
     0-dim device tensor (the annealed bound of a captured step).  ``u`` None: ``nbatch`` images, the uniforms drawn inside the
-    kernel from (``seed``, the device word ``counter``: int64 [1], the step counter of a captured training step)."""
+    kernel from (``seed``, the device word ``counter``: int64 [1], the step counter of a captured training step).
+    ``defer``: nothing is launched; the returned tensors are filled by the ray-generation launch that is given the job stored as
+    ``coords._tp_sampler_job`` (`raygen(..., coords=coords, sampler=job)`)."""
     lib = _lib.load()
     if u is not None:
         u = _f32(u, "u")
@@ -1188,6 +1215,10 @@ def patch_coords(u: Optional[Tensor], patch_size: int, lo, hi: float, random_sca
         _lattices[key] = torch.linspace(-1, 1, p, device=dev)
     coords = torch.empty(B, p, p, 2, device=dev)
     scales = torch.empty(B, 1, 1, 1, device=dev)
+    if defer:
+        coords._tp_sampler_job = dict(u=u, B=B, p=p, lattice=_lattices[key], lo=lo, hi=hi, random_scale=random_scale, random_shift=random_shift,
+                                      seed=seed, counter=counter, coords=coords, scales=scales)
+        return coords, scales
     lo_dev = lo.data_ptr() if torch.is_tensor(lo) else None
     lo_host = 0.0 if torch.is_tensor(lo) else float(lo)
     check(lib.tp_patch_coords(_ptr(u), B, p, _lattices[key].data_ptr(), lo_dev, lo_host, float(hi) - lo_host, float(hi),
@@ -1480,8 +1511,9 @@ def weighted_sum(terms, weights, flags=None, defer: bool = False) -> Tensor:
 
 
 @_on_tensor_device
-def latent_rows_fwd(w_trans: Tensor, w_light: Tensor, idx: Tensor, idx_copy: Optional[Tensor] = None):
-    """``idx_copy`` (int64 [B], optional): the launch also writes idx there (a private copy for the backward)."""
+def latent_rows_fwd(w_trans: Tensor, w_light: Tensor, idx: Tensor, idx_copy: Optional[Tensor] = None, defer: bool = False):
+    """``idx_copy`` (int64 [B], optional): the launch also writes idx there (a private copy for the backward).  ``defer``: nothing is
+    launched; returns (out_trans, out_light, job) -- the ray-generation launch given the job fills them (`raygen(..., rows=job)`)."""
     lib = _lib.load()
     w_trans, w_light = _f32(w_trans, "w_trans"), _f32(w_light, "w_light")
     idx = idx.to(torch.int64).contiguous()
@@ -1489,6 +1521,8 @@ def latent_rows_fwd(w_trans: Tensor, w_light: Tensor, idx: Tensor, idx_copy: Opt
     ot, ol = torch.empty(B, w_trans.shape[1], device=idx.device), torch.empty(B, w_light.shape[1], device=idx.device)
     if idx_copy is not None and not (idx_copy.dtype == torch.int64 and idx_copy.is_contiguous() and idx_copy.numel() == B and idx_copy.device == idx.device):
         raise _lib.TexposeLibraryError("latent_rows_fwd: idx_copy must be a contiguous int64 device tensor of idx's length")
+    if defer:
+        return ot, ol, dict(w_trans=w_trans, w_light=w_light, idx=idx, out_trans=ot, out_light=ol, idx_copy=idx_copy)
     check(lib.tp_latent_rows_fwd(w_trans.data_ptr(), w_light.data_ptr(), idx.data_ptr(), B, w_trans.shape[1], w_light.shape[1], ot.data_ptr(),
                                  ol.data_ptr(), _ptr(idx_copy), _stream()), "tp_latent_rows_fwd")
     return ot, ol
